@@ -1,0 +1,88 @@
+"""Seeded corpus generators used by tests and bench.  Test/bench fixture code."""
+import random
+
+import numpy as np
+
+
+def readme_corpus(n_lines=10000, n_chars=100, alphabet="abcd ", seed=19):
+    """C1: exactly tests/unit_tests/utils_for_testing.py:23-36 of the reference."""
+    random.seed(seed)
+    out = []
+    for _ in range(n_lines):
+        out.append("".join([random.choice(alphabet) for _ in range(n_chars)]))
+    return ("\n".join(out) + "\n").encode()
+
+
+def abcd_corpus(nbytes, seed=19, line=100, alphabet=b"abcd "):
+    """C2 / C4 family: uniform over the alphabet, `line` chars per row + newline (numpy default_rng)."""
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(alphabet, dtype=np.uint8)
+    nlines = max(1, nbytes // (line + 1))
+    out = np.empty((nlines, line + 1), dtype=np.uint8)
+    out[:, :line] = alpha[rng.integers(0, len(alpha), size=(nlines, line))]
+    out[:, line] = 10
+    return out.tobytes()
+
+
+def zipf_corpus(nbytes, seed=7, vocab=20000, line_words=16, exponent=1.05):
+    """C3 family: Zipfian word ids over a synthetic lowercase lexicon."""
+    rng = np.random.default_rng(seed)
+    letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", dtype=np.uint8)
+    p = np.array([12.7, 9.1, 8.2, 7.5, 7.0, 6.7, 6.3, 6.1, 6.0, 4.3, 4.0, 2.8, 2.8, 2.4, 2.4, 2.2, 2.0, 2.0, 1.9,
+                  1.5, 1.0, 0.8, 0.15, 0.15, 0.1, 0.07])
+    p /= p.sum()
+    lens = np.clip(rng.poisson(5.5, size=vocab) + 1, 1, 20)
+    lex = [bytes(letters[rng.choice(26, size=l, p=p)]) for l in lens]
+    ranks = np.arange(1, vocab + 1)
+    w = 1 / ranks ** exponent
+    w /= w.sum()
+    avg = float((w * (lens + 1)).sum())
+    nwords = max(1, int(nbytes / avg))
+    ids = rng.choice(vocab, size=nwords, p=w)
+    toks = [lex[i] for i in ids]
+    lines = [b" ".join(toks[i:i + line_words]) for i in range(0, nwords, line_words)]
+    return b"\n".join(lines) + b"\n"
+
+
+def stress_text(rng: random.Random, n_limit=1000, train=True):
+    """Random text in the spirit of the reference stress generator (tests/unit_tests/stress_test.cpp:272-311):
+    short alphabet, single chars mixed with repeated segments so that long runs of equal symbols occur."""
+    sigma = "abc " if train else "abcd "
+    n = min(rng.randint(1, 1000), n_limit)
+    s = [sigma[0]]
+    while len(s) < n:
+        if rng.randint(0, 1):
+            s.append(rng.choice(sigma))
+        else:
+            rep = rng.randint(2, 6)
+            seg = [rng.choice(sigma) for _ in range(rng.randint(1, 4))]
+            s.extend(seg * rep)
+    s = s[:n]
+    while s and s[-1] == " ":
+        s.pop()
+    while len(s) < n:
+        s.append(sigma[0])
+    return "".join(s)
+
+
+UNICODE_ALPHABETS = {
+    "ascii": "abcdefghij  ",
+    "cyr": "абвгдежзик  ",
+    "cjk": "日本語山川木気水火  ",
+    "mix": "aбc日😀é ß\t\n  ",
+}
+
+
+def unicode_text(rng: random.Random, n, kind="mix", p_run=0.2, p_invalid=0.0):
+    """Random UTF-8 bytes over a small multi-script alphabet, with symbol runs and optional invalid bytes."""
+    sigma = UNICODE_ALPHABETS[kind]
+    out = bytearray()
+    i = 0
+    while i < n:
+        ch = rng.choice(sigma)
+        k = rng.randint(2, 7) if rng.random() < p_run else 1
+        out += (ch * k).encode()
+        if p_invalid and rng.random() < p_invalid:
+            out += bytes([rng.choice([0x80, 0xBF, 0xC0, 0xE2, 0xF0, 0xFF, 0xED])])
+        i += k
+    return bytes(out)
