@@ -1,0 +1,482 @@
+// gpu_ctx.cpp -- HBM buffer management and kernel sequencing for the MI355X BPE trainer (see gpu_ctx.h).
+#include "gpu_ctx.h"
+
+#include <string.h>
+
+#include <algorithm>
+
+namespace yttm {
+
+static unsigned long long pow2_at_least(unsigned long long v) {
+  unsigned long long c = 1;
+  while (c < v) c <<= 1;
+  return c;
+}
+
+template <class T>
+static T *dmalloc(size_t n) {
+  void *p = nullptr;
+  HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+  return (T *)p;
+}
+#define DFREE(p)            \
+  do {                      \
+    if (p) (void)hipFree((void *)(p)); \
+    p = nullptr;            \
+  } while (0)
+
+constexpr unsigned int CAND_CAP = 1u << 20;
+constexpr unsigned int RULES_CAP = 1u << 14;  // hash slots for the per-round rule table (batch <= RULES_CAP/2)
+constexpr size_t PIN_BYTES = (size_t)CAND_CAP * sizeof(CandRec) + (size_t)RULES_CAP * sizeof(RuleSlot) + (1u << 20);
+
+GpuCtx::GpuCtx(int device) : device_(device) {
+  HIP_CHECK(hipSetDevice(device_));
+  HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  d_counters_ = dmalloc<unsigned long long>(64);
+  d_stats_ = dmalloc<unsigned long long>(8);
+  HIP_CHECK(hipMemset(d_stats_, 0, 8 * sizeof(unsigned long long)));
+  d_cand_ = dmalloc<CandRec>(CAND_CAP);
+  cand_cap_ = CAND_CAP;
+  d_cand_n_ = dmalloc<unsigned int>(4);
+  d_cand_hist_ = dmalloc<unsigned long long>(CAND_BINS);
+  d_rules_ = dmalloc<RuleSlot>(RULES_CAP);
+  rules_cap_ = RULES_CAP;
+  HIP_CHECK(hipHostMalloc(&h_pin_, PIN_BYTES, hipHostMallocDefault));
+  h_pin_bytes_ = PIN_BYTES;
+}
+
+GpuCtx::~GpuCtx() {
+  (void)hipSetDevice(device_);
+  (void)hipStreamSynchronize(st_);
+  for (auto &e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_tok_); DFREE(d_tile_start_);
+  DFREE(d_tile_len_); DFREE(d_tile_word0_); DFREE(d_wcnt_); DFREE(d_uw_off_); DFREE(d_rules_); DFREE(d_tokflag_);
+  DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_cand_); DFREE(d_cand_n_); DFREE(d_cand_hist_); DFREE(d_recv_);
+  if (db_.recs) (void)hipFree(db_.recs);
+  if (db_.n) (void)hipFree(db_.n);
+  free_table(pt_);
+  if (h_pin_) (void)hipHostFree(h_pin_);
+  if (st_) (void)hipStreamDestroy(st_);
+}
+
+void GpuCtx::sync() { HIP_CHECK(hipStreamSynchronize(st_)); }
+
+void GpuCtx::t_begin(int which) {
+  (void)which;
+  if (!profile) return;
+  HIP_CHECK(hipEventCreate(&cur_a_));
+  HIP_CHECK(hipEventRecord(cur_a_, st_));
+}
+void GpuCtx::t_end(int which, unsigned long long bytes) {
+  kt.launches[which]++;
+  kt.bytes[which] += bytes;
+  if (!profile) return;
+  hipEvent_t b;
+  HIP_CHECK(hipEventCreate(&b));
+  HIP_CHECK(hipEventRecord(b, st_));
+  evs_.push_back(Ev{cur_a_, b, which});
+  cur_a_ = nullptr;
+}
+void GpuCtx::resolve_timers() {
+  sync();
+  for (auto &e : evs_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) kt.ms[e.which] += ms;
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  evs_.clear();
+}
+
+// ------------------------------------------------------------------------------------------------- corpus
+void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
+  HIP_CHECK(hipSetDevice(device_));
+  DFREE(d_text_owned_);
+  d_text_owned_ = dmalloc<uint8_t>(n + 64);
+  if (n) HIP_CHECK(hipMemcpyAsync(d_text_owned_, host, n, hipMemcpyHostToDevice, st_));
+  sync();
+  d_text_ = d_text_owned_;
+  n_text_ = n;
+  corpus_bytes = n;
+}
+void GpuCtx::attach_corpus(const void *dev, unsigned long long n) {
+  HIP_CHECK(hipSetDevice(device_));
+  DFREE(d_text_owned_);
+  if (((uintptr_t)dev & 15u) != 0) throw GpuError{"attach_corpus: device pointer must be 16-byte aligned"};
+  d_text_ = (const uint8_t *)dev;
+  n_text_ = n;
+  corpus_bytes = n;
+}
+
+// ------------------------------------------------------------------------------------------------- K1
+void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long long> &cnts, unsigned long long &n_codepoints) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
+  HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
+  HIP_CHECK(hipMemsetAsync(d_counters_, 0, 64 * 8, st_));
+  t_begin(KT_CHAR_HIST);
+  if (n_text_) launch_char_hist(d_text_, n_text_, d_hist_, d_counters_, st_);
+  t_end(KT_CHAR_HIST, n_text_);
+  unsigned long long h_cnt[2] = {0, 0};
+  HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 16, hipMemcpyDeviceToHost, st_));
+  sync();
+  n_segments = h_cnt[1];  // local segments (before any cross-rank reduction)
+  if (comm_ && comm_->world > 1) {
+    comm_->allreduce_sum_u64(d_hist_, N_CODEPOINTS, st_);
+    comm_->allreduce_sum_u64(d_counters_, 1, st_);
+    HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 8, hipMemcpyDeviceToHost, st_));
+    sync();
+  }
+  n_codepoints = h_cnt[0];
+  // compact the non-zero bins
+  uint32_t *d_cps = dmalloc<uint32_t>(N_CODEPOINTS);
+  unsigned long long *d_cnts = dmalloc<unsigned long long>(N_CODEPOINTS);
+  unsigned int *d_n = (unsigned int *)(d_counters_ + 8);
+  HIP_CHECK(hipMemsetAsync(d_n, 0, 4, st_));
+  launch_hist_compact(d_hist_, d_cps, d_cnts, d_n, N_CODEPOINTS, st_);
+  unsigned int k = 0;
+  HIP_CHECK(hipMemcpyAsync(&k, d_n, 4, hipMemcpyDeviceToHost, st_));
+  sync();
+  cps.resize(k);
+  cnts.resize(k);
+  if (k) {
+    HIP_CHECK(hipMemcpyAsync(cps.data(), d_cps, (size_t)k * 4, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipMemcpyAsync(cnts.data(), d_cnts, (size_t)k * 8, hipMemcpyDeviceToHost, st_));
+    sync();
+  }
+  DFREE(d_cps);
+  DFREE(d_cnts);
+}
+
+// ------------------------------------------------------------------------------------------------- K2
+void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n_alpha, uint32_t space_id, uint32_t n_ids_cap) {
+  HIP_CHECK(hipSetDevice(device_));
+  // code point -> class map
+  {
+    std::vector<uint32_t> cpmap(N_CODEPOINTS, CP_DROP);
+    for (uint32_t i = 0; i < n_alpha; i++)
+      if (cp[i] < N_CODEPOINTS) cpmap[cp[i]] = id[i];
+    const uint32_t spaces[] = {9, 10, 11, 12, 13, 32, 9601};
+    for (uint32_t s : spaces) cpmap[s] = CP_SPACE;
+    if (!d_cpmap_) d_cpmap_ = dmalloc<uint32_t>(N_CODEPOINTS);
+    HIP_CHECK(hipMemcpyAsync(d_cpmap_, cpmap.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, st_));
+    sync();
+  }
+  DFREE(d_tok_); DFREE(d_tile_start_); DFREE(d_tile_len_); DFREE(d_tile_word0_); DFREE(d_wcnt_);
+  n_alpha_ = n_alpha;
+  n_unique = 0; n_tokens0 = 0; n_tiles = 0;
+  ts_ = TileSet{};
+  tokflag_cap_ = n_ids_cap + 64;
+  DFREE(d_tokflag_);
+  d_tokflag_ = dmalloc<uint8_t>(tokflag_cap_);
+  HIP_CHECK(hipMemsetAsync(d_tokflag_, 0, tokflag_cap_, st_));
+  DFREE(d_flag_upd_);
+  d_flag_upd_ = dmalloc<uint32_t>(4 * (size_t)RULES_CAP);
+  prev_flag_toks_.clear();
+
+  const unsigned long long n_segs = n_segments;
+  if (n_segs == 0 || n_text_ == 0) return;
+  // segment starts
+  unsigned long long *d_seg = dmalloc<unsigned long long>(n_segs);
+  HIP_CHECK(hipMemsetAsync(d_counters_ + 16, 0, 8, st_));
+  t_begin(KT_SEGS);
+  launch_seg_write(d_text_, n_text_, d_seg, d_counters_ + 16, st_);
+  t_end(KT_SEGS, n_text_ + 8 * n_segs);
+  // hash dedup
+  const unsigned long long ht_cap = pow2_at_least(n_segs + n_segs / 2 + 1024);
+  unsigned long long *ht_key = dmalloc<unsigned long long>(ht_cap);
+  unsigned long long *ht_cnt = dmalloc<unsigned long long>(ht_cap);
+  uint32_t *ht_len = dmalloc<uint32_t>(ht_cap);
+  launch_fill_u64(ht_key, PT_EMPTY, ht_cap, st_);
+  HIP_CHECK(hipMemsetAsync(ht_cnt, 0, ht_cap * 8, st_));
+  unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
+  HIP_CHECK(hipMemsetAsync(d_status, 0, 16, st_));
+  t_begin(KT_DEDUP);
+  launch_insert_words(d_text_, n_text_, d_cpmap_, d_seg, n_segs, ht_key, ht_cnt, ht_len, ht_cap - 1, d_status, st_);
+  t_end(KT_DEDUP, n_text_ + 8 * n_segs);
+  unsigned int h_status[4] = {0, 0, 0, 0};
+  HIP_CHECK(hipMemcpyAsync(h_status, d_status, 16, hipMemcpyDeviceToHost, st_));
+  sync();
+  DFREE(d_seg);
+  if (h_status[1] & 1u) {
+    DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len);
+    throw GpuError{"a word longer than " + std::to_string(TILE_TOK - 1) + " characters is not supported by the tile kernels yet"};
+  }
+  const unsigned int U = h_status[0];
+  n_unique = U;
+  if (U == 0) { DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len); return; }
+  unsigned long long *uw_pos = dmalloc<unsigned long long>(U);
+  uint32_t *uw_len = dmalloc<uint32_t>(U);
+  d_wcnt_ = dmalloc<uint32_t>(U);
+  unsigned int *d_cursor = (unsigned int *)(d_counters_ + 32);
+  HIP_CHECK(hipMemsetAsync(d_cursor, 0, 4, st_));
+  t_begin(KT_BUILD);
+  launch_compact_words(ht_key, ht_cnt, ht_len, ht_cap, uw_pos, d_wcnt_, uw_len, d_cursor, d_status, st_);
+  HIP_CHECK(hipMemcpyAsync(h_status, d_status, 16, hipMemcpyDeviceToHost, st_));
+  sync();
+  DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len);
+  if (h_status[1] & 2u) { DFREE(uw_pos); DFREE(uw_len); throw GpuError{"a word occurs >= 2^32 times (uint32 word weights)"}; }
+  // token offsets
+  unsigned long long *uw_off = dmalloc<unsigned long long>(U);
+  unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(U));
+  launch_exclusive_scan(uw_len, U, uw_off, scan_tmp, d_counters_ + 40, st_);
+  unsigned long long total = 0, last_off = 0;
+  HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 40, 8, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&last_off, uw_off + (U - 1), 8, hipMemcpyDeviceToHost, st_));
+  sync();
+  DFREE(scan_tmp);
+  n_tokens0 = total;
+  d_tok_ = dmalloc<uint32_t>(total + 64);
+  launch_fill_tokens(d_text_, n_text_, d_cpmap_, space_id, uw_pos, uw_off, U, d_tok_, st_);
+  n_tiles = (unsigned int)(last_off / TILE_TOK) + 1;
+  d_tile_start_ = dmalloc<unsigned long long>(n_tiles);
+  d_tile_word0_ = dmalloc<uint32_t>(n_tiles);
+  d_tile_len_ = dmalloc<uint32_t>(n_tiles);
+  launch_tiles(uw_off, U, d_tile_start_, d_tile_word0_, st_);
+  launch_tile_len(d_tile_start_, n_tiles, total, d_tile_len_, st_);
+  t_end(KT_BUILD, n_text_ / 8 + 4 * total + 16ull * U);
+  sync();
+  DFREE(uw_pos); DFREE(uw_len); DFREE(uw_off);
+  ts_.tok = d_tok_;
+  ts_.tile_start = d_tile_start_;
+  ts_.tile_len = d_tile_len_;
+  ts_.tile_word0 = d_tile_word0_;
+  ts_.wcnt = d_wcnt_;
+  ts_.n_tiles = n_tiles;
+}
+
+void GpuCtx::download_word_table(std::vector<uint32_t> &tok, std::vector<unsigned long long> &off, std::vector<uint32_t> &cnt) {
+  tok.clear(); off.clear(); cnt.clear();
+  off.push_back(0);
+  if (!n_tiles) return;
+  std::vector<uint32_t> all(n_tokens0), tl(n_tiles), wc(n_unique);
+  std::vector<unsigned long long> tstart(n_tiles);
+  HIP_CHECK(hipMemcpyAsync(all.data(), d_tok_, n_tokens0 * 4, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(tl.data(), d_tile_len_, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(tstart.data(), d_tile_start_, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(wc.data(), d_wcnt_, (size_t)n_unique * 4, hipMemcpyDeviceToHost, st_));
+  sync();
+  for (unsigned int t = 0; t < n_tiles; t++) {
+    for (uint32_t p = 0; p < tl[t]; p++) {
+      uint32_t v = all[tstart[t] + p];
+      if ((v & TOK_WS) && !tok.empty()) off.push_back(tok.size());
+      tok.push_back(v & TOK_MASK);
+    }
+  }
+  off.push_back(tok.size());
+  cnt = wc;
+}
+
+// ------------------------------------------------------------------------------------------------- pair table
+void GpuCtx::alloc_table(PairTable &pt, unsigned long long cap) {
+  pt.keys = dmalloc<unsigned long long>(cap);
+  pt.cnts = dmalloc<unsigned long long>(cap);
+  pt.n_keys = dmalloc<unsigned int>(4);
+  pt.mask = cap - 1;
+  launch_fill_u64(pt.keys, PT_EMPTY, cap, st_);
+  HIP_CHECK(hipMemsetAsync(pt.cnts, 0, cap * 8, st_));
+  HIP_CHECK(hipMemsetAsync(pt.n_keys, 0, 16, st_));
+}
+void GpuCtx::free_table(PairTable &pt) {
+  DFREE(pt.keys);
+  DFREE(pt.cnts);
+  DFREE(pt.n_keys);
+  pt.mask = 0;
+}
+
+void GpuCtx::ensure_table_capacity(unsigned long long need_keys) {
+  if (pt_cap_ && need_keys * 2 <= pt_cap_) return;
+  unsigned long long new_cap = pow2_at_least(std::max<unsigned long long>(1ull << 16, need_keys * 4));
+  if (!pt_cap_) {
+    alloc_table(pt_, new_cap);
+    pt_cap_ = new_cap;
+    return;
+  }
+  PairTable nt{};
+  alloc_table(nt, new_cap);
+  launch_pt_rehash(pt_, nt, st_);
+  unsigned int nk = 0;
+  HIP_CHECK(hipMemcpyAsync(&nk, nt.n_keys, 4, hipMemcpyDeviceToHost, st_));
+  sync();
+  free_table(pt_);
+  pt_ = nt;
+  pt_cap_ = new_cap;
+  n_keys_host = nk;
+}
+
+void GpuCtx::exchange_deltas() {
+  if (!comm_ || comm_->world <= 1) return;
+  unsigned long long n_local = 0;
+  HIP_CHECK(hipMemcpyAsync(&n_local, db_.n, 8, hipMemcpyDeviceToHost, st_));
+  sync();
+  if (n_local > db_.cap) throw GpuError{"delta exchange buffer overflow"};
+  size_t n_remote = comm_->allgather_recs(db_.recs, (size_t)n_local, d_recv_, (size_t)recv_cap_, st_);
+  if (n_remote > recv_cap_) throw GpuError{"delta receive buffer overflow"};
+  ensure_table_capacity(n_keys_host + n_remote);
+  launch_pt_apply(pt_, d_recv_, n_remote, st_);
+  HIP_CHECK(hipMemsetAsync(db_.n, 0, 8, st_));
+  unsigned int nk = 0;
+  HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
+  sync();
+  n_keys_host = nk;
+}
+
+void GpuCtx::pair_count() {
+  HIP_CHECK(hipSetDevice(device_));
+  free_table(pt_);
+  pt_cap_ = 0;
+  n_keys_host = 0;
+  // distinct initial pairs <= number of adjacencies <= tokens
+  unsigned long long bound = std::min<unsigned long long>(n_tokens0 + 16, ((unsigned long long)n_alpha_ + 1) * (n_alpha_ + 1));
+  bound = std::min<unsigned long long>(bound, 1ull << 26);
+  if (comm_ && comm_->world > 1) {
+    bound = std::min<unsigned long long>(bound * comm_->world, 1ull << 27);
+    if (!db_.recs) {
+      // worst case: every live token emits a handful of records in one pass
+      db_.cap = std::max<unsigned long long>(1ull << 20, 5 * n_tokens0 + 1024);
+      db_.recs = dmalloc<DeltaRec>(db_.cap);
+      db_.n = dmalloc<unsigned long long>(2);
+      HIP_CHECK(hipMemsetAsync(db_.n, 0, 16, st_));
+      recv_cap_ = db_.cap * (unsigned long long)comm_->world;
+      d_recv_ = dmalloc<DeltaRec>(recv_cap_);
+    }
+  }
+  ensure_table_capacity(bound);
+  t_begin(KT_PAIR_COUNT);
+  launch_pair_count(ts_, pt_, db_, st_);
+  t_end(KT_PAIR_COUNT, 4 * n_tokens0 + 8 * n_unique);
+  unsigned int nk = 0;
+  HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
+  sync();
+  n_keys_host = nk;
+  exchange_deltas();
+}
+
+void GpuCtx::download_pairs(std::vector<unsigned long long> &keys, std::vector<unsigned long long> &cnts) {
+  std::vector<CandRec> out;
+  uint32_t n = candidates(0, 0xffffffffu, out, nullptr);
+  if (n > out.size()) throw GpuError{"download_pairs: more than 2^20 live pairs"};
+  keys.resize(n);
+  cnts.resize(n);
+  for (uint32_t i = 0; i < n; i++) { keys[i] = out[i].key; cnts[i] = out[i].cnt; }
+}
+
+uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist) {
+  HIP_CHECK(hipSetDevice(device_));
+  out.clear();
+  if (!pt_cap_) {
+    if (hist) memset(hist, 0, CAND_BINS * 8);
+    return 0;
+  }
+  HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, st_));
+  if (hist) HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, st_));
+  t_begin(KT_CAND);
+  launch_cand_scan(pt_, tau_cnt, tau_mx, d_cand_, cand_cap_, d_cand_n_, hist ? d_cand_hist_ : nullptr, st_);
+  t_end(KT_CAND, 16 * pt_cap_);
+  // one D2H for header + histogram, a second one for the candidates
+  unsigned int *h_n = (unsigned int *)h_pin_;
+  unsigned long long *h_hist = (unsigned long long *)((char *)h_pin_ + 64);
+  HIP_CHECK(hipMemcpyAsync(h_n, d_cand_n_, 4, hipMemcpyDeviceToHost, st_));
+  if (hist) HIP_CHECK(hipMemcpyAsync(h_hist, d_cand_hist_, CAND_BINS * 8, hipMemcpyDeviceToHost, st_));
+  sync();
+  const unsigned int n = *h_n;
+  if (hist) memcpy(hist, h_hist, CAND_BINS * 8);
+  const unsigned int take = std::min(n, cand_cap_);
+  if (take) {
+    CandRec *h_c = (CandRec *)((char *)h_pin_ + (1u << 16));
+    HIP_CHECK(hipMemcpyAsync(h_c, d_cand_, (size_t)take * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
+    sync();
+    out.assign(h_c, h_c + take);
+  }
+  return n;
+}
+
+void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned long long *outv) {
+  if (!n) return;
+  unsigned long long *d_k = dmalloc<unsigned long long>(n), *d_o = dmalloc<unsigned long long>(n);
+  HIP_CHECK(hipMemcpyAsync(d_k, keys, (size_t)n * 8, hipMemcpyHostToDevice, st_));
+  launch_pt_query(pt_, d_k, n, d_o, st_);
+  HIP_CHECK(hipMemcpyAsync(outv, d_o, (size_t)n * 8, hipMemcpyDeviceToHost, st_));
+  sync();
+  DFREE(d_k);
+  DFREE(d_o);
+}
+
+// ------------------------------------------------------------------------------------------------- K4
+void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (!k || !n_tiles) return;
+  if (k > RULES_CAP / 2) throw GpuError{"merge_apply: batch too large"};
+  // new pairs this round: every site adds <= 2 neighbours (+ the z,z run pair); distinct new keys per rule are also
+  // bounded by the number of live token types on either side
+  uint32_t vmax = 0;
+  for (uint32_t j = 0; j < k; j++) vmax = std::max(vmax, xyz[3 * j + 2]);
+  unsigned long long bound_new = 0;
+  for (uint32_t j = 0; j < k; j++) {
+    unsigned long long by_tokens = 2ull * (vmax + 1) + 1;
+    unsigned long long by_count = rule_counts ? 3 * rule_counts[j] : by_tokens;
+    bound_new += std::min(by_tokens, by_count);
+  }
+  ensure_table_capacity(n_keys_host + bound_new);
+
+  // rule hash (x != y rules) + at most one x == y rule passed by value
+  unsigned int cap = 64;
+  while (cap < 2 * k) cap <<= 1;
+  char *pin = (char *)h_pin_ + (1u << 16) + (size_t)CAND_CAP * sizeof(CandRec);
+  RuleSlot *h_rules = (RuleSlot *)pin;
+  uint32_t *h_upd = (uint32_t *)(pin + (size_t)RULES_CAP * sizeof(RuleSlot));
+  for (unsigned int i = 0; i < cap; i++) { h_rules[i].key = PT_EMPTY; h_rules[i].z = 0; h_rules[i].pad = 0; }
+  uint32_t self_x = 0xffffffffu, self_z = 0;
+  std::vector<std::pair<uint32_t, uint8_t>> flags;
+  flags.reserve(2 * k + prev_flag_toks_.size());
+  for (uint32_t t : prev_flag_toks_) flags.push_back({t, 0});
+  std::vector<uint32_t> now;
+  for (uint32_t j = 0; j < k; j++) {
+    const uint32_t x = xyz[3 * j], y = xyz[3 * j + 1], z = xyz[3 * j + 2];
+    if (x >= tokflag_cap_ || y >= tokflag_cap_ || z >= tokflag_cap_) throw GpuError{"merge_apply: token id out of range"};
+    if (x == y) {
+      if (self_x != 0xffffffffu) throw GpuError{"merge_apply: more than one x==y rule in a batch"};
+      self_x = x;
+      self_z = z;
+      continue;
+    }
+    const unsigned long long key = pair_key(x, y);
+    unsigned int h = (unsigned int)mix64(key) & (cap - 1);
+    while (h_rules[h].key != PT_EMPTY) h = (h + 1) & (cap - 1);
+    h_rules[h].key = key;
+    h_rules[h].z = z;
+    flags.push_back({x, 1});
+    flags.push_back({y, 2});
+    now.push_back(x);
+    now.push_back(y);
+  }
+  // final flag value per token (clears of the previous batch first, then ORs of this batch)
+  std::sort(flags.begin(), flags.end(), [](const std::pair<uint32_t, uint8_t> &a, const std::pair<uint32_t, uint8_t> &b) { return a.first < b.first; });
+  unsigned int n_upd = 0;
+  for (size_t i = 0; i < flags.size();) {
+    size_t j = i;
+    uint8_t v = 0;
+    while (j < flags.size() && flags[j].first == flags[i].first) v |= flags[j++].second;
+    h_upd[2 * n_upd] = flags[i].first;
+    h_upd[2 * n_upd + 1] = v;
+    n_upd++;
+    i = j;
+  }
+  prev_flag_toks_.swap(now);
+  HIP_CHECK(hipMemcpyAsync(d_rules_, h_rules, (size_t)cap * sizeof(RuleSlot), hipMemcpyHostToDevice, st_));
+  if (n_upd) {
+    HIP_CHECK(hipMemcpyAsync(d_flag_upd_, h_upd, (size_t)n_upd * 8, hipMemcpyHostToDevice, st_));
+    launch_set_tokflag(d_tokflag_, d_flag_upd_, n_upd, st_);
+  }
+  t_begin(KT_MERGE);
+  launch_merge_apply(ts_, pt_, db_, d_rules_, cap - 1, d_tokflag_, self_x, self_z, d_stats_, st_);
+  t_end(KT_MERGE, 0);
+  merge_rounds++;
+  unsigned int nk = 0;
+  HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
+  sync();  // also makes the pinned staging reusable
+  n_keys_host = nk;
+  exchange_deltas();
+}
+
+}  // namespace yttm

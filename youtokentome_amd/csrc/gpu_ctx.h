@@ -1,0 +1,136 @@
+// gpu_ctx.h -- device context of the BPE trainer: owns every HBM buffer, one HIP stream, and (multi-GPU) the RCCL
+// communicator.  The C-ABI in include/yttm_gpu.h is a thin wrapper over this class.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "yttm_kernels.h"
+
+namespace yttm {
+
+struct GpuError {
+  std::string msg;
+};
+
+// Exchange interface for the multi-GPU path (one process per GPU).  Implementations: RCCL over xGMI
+// (comm_rccl.cpp) and a host-callback variant used by the gloo CPU tests.
+struct Comm {
+  int rank = 0, world = 1;
+  virtual ~Comm() {}
+  // in-place sum of n uint64 values living in device memory
+  virtual void allreduce_sum_u64(unsigned long long *dev, size_t n, hipStream_t st) = 0;
+  // every rank contributes n_local records; recv (device, capacity cap records) receives the records of all OTHER ranks
+  // back to back; returns their total number
+  virtual size_t allgather_recs(const DeltaRec *send, size_t n_local, DeltaRec *recv, size_t cap, hipStream_t st) = 0;
+};
+
+struct KernelTimes {  // accumulated GPU time per kernel family, measured with HIP events on the ctx stream
+  double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // algorithmic bytes
+};
+enum { KT_CHAR_HIST = 0, KT_SEGS = 1, KT_DEDUP = 2, KT_BUILD = 3, KT_PAIR_COUNT = 4, KT_MERGE = 5, KT_CAND = 6, KT_ENCODE = 7 };
+
+class GpuCtx {
+ public:
+  explicit GpuCtx(int device);
+  ~GpuCtx();
+
+  // ---- corpus
+  void upload_corpus(const uint8_t *host, unsigned long long n);
+  void attach_corpus(const void *dev, unsigned long long n);
+
+  // ---- K1
+  void char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long long> &cnts, unsigned long long &n_codepoints);
+  // ---- K2: builds the unique-word token tiles from the char->id map (chars not listed are deleted)
+  void build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n_alpha, uint32_t space_id, uint32_t n_ids_cap);
+  void download_word_table(std::vector<uint32_t> &tok, std::vector<unsigned long long> &off, std::vector<uint32_t> &cnt);
+  // ---- K3
+  void pair_count();
+  void download_pairs(std::vector<unsigned long long> &keys, std::vector<unsigned long long> &cnts);
+  // ---- K4: apply a batch of mutually non-intersecting rules (x,y,z)*k
+  void merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts);
+  void pair_query(const unsigned long long *keys, uint32_t n, unsigned long long *out);
+  // candidate filter; returns number of candidates that passed (may exceed out.size() capacity => retry with higher tau)
+  uint32_t candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist /*CAND_BINS or null*/);
+
+  void sync();
+  void set_comm(Comm *c) { comm_ = c; }
+  Comm *comm() const { return comm_; }
+  int device() const { return device_; }
+  hipStream_t stream() const { return st_; }
+
+  unsigned long long n_unique = 0, n_tokens0 = 0, n_segments = 0, corpus_bytes = 0;
+  unsigned int n_tiles = 0;
+  unsigned long long n_keys_host = 0;
+  bool profile = false;
+  KernelTimes kt;
+  unsigned long long merge_sites = 0, merge_rounds = 0;
+  void resolve_timers();
+
+ private:
+  void ensure_table_capacity(unsigned long long need_keys);
+  void alloc_table(PairTable &pt, unsigned long long cap);
+  void free_table(PairTable &pt);
+  void exchange_deltas();
+  void t_begin(int which);
+  void t_end(int which, unsigned long long bytes);
+
+  int device_;
+  hipStream_t st_ = nullptr;
+  Comm *comm_ = nullptr;
+
+  // corpus
+  const uint8_t *d_text_ = nullptr;
+  uint8_t *d_text_owned_ = nullptr;
+  unsigned long long n_text_ = 0;
+  // K1
+  unsigned long long *d_hist_ = nullptr;      // [N_CODEPOINTS]
+  unsigned long long *d_counters_ = nullptr;  // small scratch of u64 counters
+  // K2
+  uint32_t *d_cpmap_ = nullptr;  // [N_CODEPOINTS]
+  uint32_t n_alpha_ = 0;
+  // token tiles
+  TileSet ts_{};
+  uint32_t *d_tok_ = nullptr;
+  unsigned long long *d_tile_start_ = nullptr;
+  uint32_t *d_tile_len_ = nullptr, *d_tile_word0_ = nullptr, *d_wcnt_ = nullptr;
+  unsigned long long *d_uw_off_ = nullptr;  // kept for download_word_table (initial layout)
+  // pair table
+  PairTable pt_{};
+  unsigned long long pt_cap_ = 0;
+  // per-round staging
+  RuleSlot *d_rules_ = nullptr;
+  unsigned int rules_cap_ = 0;
+  uint8_t *d_tokflag_ = nullptr;
+  uint32_t tokflag_cap_ = 0;
+  uint32_t *d_flag_upd_ = nullptr;
+  unsigned long long *d_stats_ = nullptr;
+  void *h_pin_ = nullptr;  // pinned staging (rules + flag updates + candidate header)
+  size_t h_pin_bytes_ = 0;
+  std::vector<uint32_t> prev_flag_toks_;
+  // candidates
+  CandRec *d_cand_ = nullptr;
+  unsigned int cand_cap_ = 0;
+  unsigned int *d_cand_n_ = nullptr;
+  unsigned long long *d_cand_hist_ = nullptr;
+  // multi-GPU delta exchange
+  DeltaBuf db_{};
+  DeltaRec *d_recv_ = nullptr;
+  unsigned long long recv_cap_ = 0;
+
+  struct Ev { hipEvent_t a, b; int which; };
+  std::vector<Ev> evs_;
+  hipEvent_t cur_a_ = nullptr;
+};
+
+#define HIP_CHECK(expr)                                                                                         \
+  do {                                                                                                          \
+    hipError_t _e = (expr);                                                                                     \
+    if (_e != hipSuccess) throw yttm::GpuError{std::string(#expr) + ": " + hipGetErrorString(_e)};             \
+  } while (0)
+
+}  // namespace yttm

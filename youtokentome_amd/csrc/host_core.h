@@ -1,0 +1,122 @@
+// host_core.h -- host-side (C++17) half of the drop-in: model state + file format, alphabet, the trainer's ordered
+// pick, and the encoder object.  Mirrors the C++ surface declared in the reference's bpe.h / utils.h (same names,
+// argument meaning and error strings) on top of the HIP kernels; nothing here computes the hot path on the CPU.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace yttm {
+
+constexpr uint32_t SPACE_TOKEN = 9601;  // utils.h:9
+
+struct Status {  // utils.h:56-64
+  int code = 0;
+  std::string message;
+  Status() = default;
+  Status(int c, std::string m) : code(c), message(std::move(m)) {}
+  bool ok() const { return code == 0; }
+};
+
+struct SpecialTokens {  // utils.h:22-43 (note the constructor order pad, unk, bos, eos)
+  int pad_id = -1, unk_id = -1, bos_id = -1, eos_id = -1;
+  bool taken_id(int id) const { return id == unk_id || id == pad_id || id == bos_id || id == eos_id; }
+  uint64_t n_special_tokens() const { return (unk_id != -1) + (pad_id != -1) + (bos_id != -1) + (eos_id != -1); }
+};
+
+struct BpeConfig {  // utils.h:45-54
+  double character_coverage = 1;
+  int n_threads = 0;
+  SpecialTokens special_tokens;
+};
+
+struct BPE_Rule {  // utils.h:11-20
+  uint32_t x = 0, y = 0, z = 0;
+};
+
+struct BPEState {  // utils.h:66-74; chars are kept in MODEL-FILE order (the reference's hash-slot order)
+  std::vector<std::pair<uint32_t, uint32_t>> char2id;  // (code point, id)
+  std::vector<BPE_Rule> rules;
+  SpecialTokens special_tokens;
+  Status dump(const std::string &file_name) const;  // utils.cpp:50-66
+  Status load(const std::string &file_name);        // utils.cpp:68-91
+};
+
+// Slot order of a ska::flat_hash_map<uint32_t,...> after inserting `keys` in order into an empty map and
+// copy-constructing it once (bpe.cpp:1289 copies char2id into BPEState; utils.cpp:57-59 iterates the copy).
+std::vector<uint32_t> flat_hash_map_order(const std::vector<uint32_t> &keys);
+
+// bpe.cpp:316-355 compute_alphabet_helper.  Returns chars in INSERTION order (▁ first, then by descending
+// (count, code point)) with compact ids n_special, n_special+1, ...
+void compute_alphabet(const std::vector<uint32_t> &cps, const std::vector<unsigned long long> &cnts, unsigned long long data_len,
+                      const BpeConfig &cfg, std::vector<std::pair<uint32_t, uint32_t>> &char2id_insertion, uint64_t &n_removed);
+
+Status check_config(BpeConfig &cfg, int vocab_size);  // bpe.cpp:1295-1350
+
+struct TrainReport {
+  double seconds_total = 0, seconds_frontend = 0, seconds_merge = 0, seconds_io = 0;
+  unsigned long long corpus_bytes = 0, n_unique = 0, n_tokens = 0, rounds = 0, rules = 0, cand_rescans = 0;
+  // per kernel family: ms, launches, algorithmic bytes (gpu_ctx.h KT_*)
+  double kt_ms[8] = {0};
+  unsigned long long kt_launches[8] = {0}, kt_bytes[8] = {0};
+};
+
+class GpuCtx;
+struct Comm;
+
+// bpe.h:19 train_bpe -- file based.  `device` = HIP device ordinal.
+Status train_bpe(const std::string &input_path, const std::string &model_path, int vocab_size, BpeConfig cfg, int device = 0,
+                 TrainReport *report = nullptr, Comm *comm = nullptr);
+// same, corpus already in host memory / already resident in HBM (bench: timed region starts with the bytes in HBM)
+Status train_bpe_from_memory(const uint8_t *text, unsigned long long n, const std::string &model_path, int vocab_size, BpeConfig cfg,
+                             int device = 0, TrainReport *report = nullptr, Comm *comm = nullptr);
+Status train_bpe_from_device(const void *d_text, unsigned long long n, const std::string &model_path, int vocab_size, BpeConfig cfg,
+                             int device = 0, TrainReport *report = nullptr, Comm *comm = nullptr, bool profile = false);
+// learn_bpe_from_string (bpe.cpp:859-1293) on an attached corpus
+Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const BpeConfig &cfg, BPEState *state, TrainReport *report);
+
+struct EncoderDevice;  // HBM-resident model tables for K5
+
+class BaseEncoder {  // bpe.h:22-82
+ public:
+  BPEState bpe_state;
+  std::unordered_map<uint32_t, uint32_t> char2id, id2char;
+  std::unordered_map<uint32_t, std::vector<uint32_t>> recipe;
+  std::unordered_map<std::string, uint32_t> reversed_recipe;
+  int n_threads = 1;
+
+  BaseEncoder(const std::string &model_path, int n_threads, Status *ret_status, int device = 0);
+  ~BaseEncoder();
+
+  // packed batch API (bytes + offsets[S+1]); ids/out_off are filled on the host
+  Status encode_as_ids(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos, bool reverse,
+                       double dropout_prob, std::vector<int32_t> *ids, std::vector<unsigned long long> *out_off) const;
+  Status encode_as_subwords(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,
+                            bool reverse, double dropout_prob, std::vector<std::string> *pieces,
+                            std::vector<unsigned long long> *piece_off) const;
+  // device-resident variant used by bench.py: input already in HBM, output left in HBM (ids_dev/off_dev owned by the encoder)
+  Status encode_device(const void *d_bytes, const void *d_offsets, unsigned long long n_sent, unsigned long long total_bytes,
+                       unsigned long long max_sentence_bytes, bool bos, bool eos, bool reverse, double dropout_prob,
+                       unsigned long long *n_ids_out, double *kernel_ms) const;
+  Status fetch_device_result(int32_t *ids, unsigned long long *out_off, unsigned long long n_sent) const;
+
+  Status id_to_subword(int id, std::string *subword, bool replace_space = false) const;  // bpe.cpp:1774-1807
+  int subword_to_id(const std::string &token) const;                                      // bpe.cpp:1809-1826
+  Status decode(const std::vector<int> &ids, std::string *sentence, const std::unordered_set<int> *ignore_ids) const;  // bpe.cpp:1843
+  int vocab_size() const;                                                                 // bpe.cpp:1692
+  std::vector<std::string> vocabulary() const;                                            // bpe.cpp:1884
+
+ private:
+  void fill_from_state();  // bpe.cpp:1667-1690
+  EncoderDevice *dev_ = nullptr;
+  int device_ = 0;
+};
+
+std::string encode_utf8(const std::vector<uint32_t> &text);  // utf8.cpp:102-109
+std::vector<uint32_t> decode_utf8(const char *begin, const char *end, bool *invalid = nullptr);  // utf8.cpp:111-128
+bool is_space(uint32_t ch);  // utils.cpp:99-101
+
+}  // namespace yttm

@@ -1,0 +1,348 @@
+// host_encoder.cpp -- BaseEncoder (bpe.h:22-82): model load, HBM-resident rule tables, batch encode through K5,
+// and the tiny host-side helpers of the drop-in surface (id<->subword, decode, vocabulary).
+#include <string.h>
+
+#include <algorithm>
+
+#include "gpu_ctx.h"
+#include "host_core.h"
+
+namespace yttm {
+
+static const std::string UNK_TOKEN = "<UNK>", PAD_TOKEN = "<PAD>", BOS_TOKEN = "<BOS>", EOS_TOKEN = "<EOS>";  // bpe.h:12-15
+
+template <class T>
+static T *dalloc(size_t n) {
+  void *p = nullptr;
+  HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+  return (T *)p;
+}
+
+struct EncoderDevice {
+  hipStream_t st = nullptr;
+  uint32_t *d_cpmap = nullptr;
+  RuleSlot *d_rules = nullptr;
+  uint32_t *d_rule_z = nullptr;
+  EncModel m{};
+  // reusable batch buffers (grown on demand)
+  uint8_t *d_bytes = nullptr; size_t cap_bytes = 0;
+  unsigned long long *d_off = nullptr; size_t cap_off = 0;
+  int32_t *d_scratch = nullptr; size_t cap_scratch = 0;
+  uint32_t *d_counts = nullptr; size_t cap_counts = 0;
+  unsigned long long *d_out_off = nullptr; size_t cap_out_off = 0;
+  unsigned long long *d_scan_tmp = nullptr; size_t cap_scan_tmp = 0;
+  unsigned long long *d_total = nullptr;
+  int32_t *d_ids = nullptr; size_t cap_ids = 0;
+  uint32_t *d_work = nullptr; size_t cap_work = 0;
+  unsigned long long last_n_ids = 0, last_n_sent = 0;
+
+  template <class T>
+  void grow(T *&p, size_t &cap, size_t need) {
+    if (need <= cap) return;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    size_t c = need + need / 4 + 64;
+    p = dalloc<T>(c);
+    cap = c;
+  }
+  ~EncoderDevice() {
+    for (void *p : {(void *)d_cpmap, (void *)d_rules, (void *)d_rule_z, (void *)d_bytes, (void *)d_off, (void *)d_scratch, (void *)d_counts,
+                    (void *)d_out_off, (void *)d_scan_tmp, (void *)d_total, (void *)d_ids, (void *)d_work})
+      if (p) (void)hipFree(p);
+    if (st) (void)hipStreamDestroy(st);
+  }
+};
+
+BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *ret_status, int device) : n_threads(_n_threads), device_(device) {
+  Status status = bpe_state.load(model_path);  // bpe.cpp:1643-1656
+  if (!status.ok()) { *ret_status = status; return; }
+  fill_from_state();
+  try {
+    HIP_CHECK(hipSetDevice(device_));
+    dev_ = new EncoderDevice();
+    HIP_CHECK(hipStreamCreateWithFlags(&dev_->st, hipStreamNonBlocking));
+    // code point -> final id / CP_SPACE / CP_UNK.  is_space wins over char2id (words are split first, bpe.cpp:1509-1510).
+    std::vector<uint32_t> cpmap(N_CODEPOINTS, CP_UNK);
+    for (auto &c : bpe_state.char2id)
+      if (c.first < N_CODEPOINTS) cpmap[c.first] = c.second;
+    for (uint32_t s : {9u, 10u, 11u, 12u, 13u, 32u, 9601u}) cpmap[s] = CP_SPACE;
+    dev_->d_cpmap = dalloc<uint32_t>(N_CODEPOINTS);
+    HIP_CHECK(hipMemcpy(dev_->d_cpmap, cpmap.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice));
+    // rule hash: (x,y) -> rule index; later rules overwrite earlier duplicates like rule2id (bpe.cpp:1672-1674)
+    const size_t nr = bpe_state.rules.size();
+    unsigned int cap = 64;
+    while (cap < 2 * nr + 2) cap <<= 1;
+    std::vector<RuleSlot> slots(cap);
+    for (auto &s : slots) { s.key = PT_EMPTY; s.z = 0; s.pad = 0; }
+    std::vector<uint32_t> rz(nr ? nr : 1, 0);
+    for (size_t i = 0; i < nr; i++) {
+      const BPE_Rule &r = bpe_state.rules[i];
+      rz[i] = r.z;
+      const unsigned long long key = pair_key(r.x, r.y);
+      unsigned int h = (unsigned int)mix64(key) & (cap - 1);
+      while (slots[h].key != PT_EMPTY && slots[h].key != key) h = (h + 1) & (cap - 1);
+      slots[h].key = key;
+      slots[h].z = r.z;
+      slots[h].pad = (uint32_t)i;
+    }
+    dev_->d_rules = dalloc<RuleSlot>(cap);
+    HIP_CHECK(hipMemcpy(dev_->d_rules, slots.data(), (size_t)cap * sizeof(RuleSlot), hipMemcpyHostToDevice));
+    dev_->d_rule_z = dalloc<uint32_t>(rz.size());
+    HIP_CHECK(hipMemcpy(dev_->d_rule_z, rz.data(), rz.size() * 4, hipMemcpyHostToDevice));
+    dev_->d_total = dalloc<unsigned long long>(2);
+    EncModel &m = dev_->m;
+    m.cpmap = dev_->d_cpmap;
+    m.rules = dev_->d_rules;
+    m.rule_z = dev_->d_rule_z;
+    m.rule_mask = cap - 1;
+    auto it = char2id.find(SPACE_TOKEN);
+    m.space_id = it == char2id.end() ? 0u : it->second;
+    m.unk_id = bpe_state.special_tokens.unk_id;
+    m.bos_id = bpe_state.special_tokens.bos_id;
+    m.eos_id = bpe_state.special_tokens.eos_id;
+  } catch (const GpuError &e) {
+    *ret_status = Status(2, "GPU error: " + e.msg);
+    return;
+  }
+  if (n_threads == -1) n_threads = 1;  // accepted for API compatibility; encode runs on the GPU
+  *ret_status = Status();
+}
+
+BaseEncoder::~BaseEncoder() {
+  if (dev_) {
+    (void)hipSetDevice(device_);
+    delete dev_;
+  }
+}
+
+void BaseEncoder::fill_from_state() {  // bpe.cpp:1667-1690
+  for (auto &x : bpe_state.char2id) { char2id[x.first] = x.second; id2char[x.second] = x.first; }
+  for (auto &x : id2char) recipe[x.first] = {x.first};
+  for (auto &r : bpe_state.rules) {
+    std::vector<uint32_t> v = recipe[r.x];
+    const std::vector<uint32_t> &w = recipe[r.y];
+    v.insert(v.end(), w.begin(), w.end());
+    recipe[r.z] = std::move(v);
+  }
+  for (auto &kv : recipe) {
+    std::vector<uint32_t> cps;
+    for (uint32_t id : kv.second) cps.push_back(id2char.at(id));
+    reversed_recipe[encode_utf8(cps)] = kv.first;
+  }
+  reversed_recipe[BOS_TOKEN] = (uint32_t)bpe_state.special_tokens.bos_id;
+  reversed_recipe[EOS_TOKEN] = (uint32_t)bpe_state.special_tokens.eos_id;
+}
+
+int BaseEncoder::vocab_size() const {
+  return (int)(bpe_state.rules.size() + bpe_state.char2id.size() + bpe_state.special_tokens.n_special_tokens());
+}
+
+Status BaseEncoder::encode_device(const void *d_bytes, const void *d_offsets, unsigned long long n_sent, unsigned long long total_bytes,
+                                  unsigned long long max_sentence_bytes, bool bos, bool eos, bool reverse, double dropout_prob,
+                                  unsigned long long *n_ids_out, double *kernel_ms) const {
+  // bpe.cpp:1702-1707
+  if (bos && bpe_state.special_tokens.bos_id == -1) return Status(1, "Can't add <BOS> token. Model was trained without it.");
+  if (eos && bpe_state.special_tokens.eos_id == -1) return Status(1, "Can't add <EOS> token. Model was trained without it.");
+  if (dropout_prob != 0) return Status(2, "BPE-dropout is not implemented on the GPU path yet");
+  if (!dev_) return Status(2, "encoder has no device state");
+  try {
+    HIP_CHECK(hipSetDevice(device_));
+    EncoderDevice &d = *dev_;
+    d.last_n_sent = n_sent;
+    d.last_n_ids = 0;
+    if (n_ids_out) *n_ids_out = 0;
+    if (n_sent == 0) return Status();
+    d.grow(d.d_scratch, d.cap_scratch, (size_t)(2 * total_bytes + 2 * n_sent));
+    d.grow(d.d_counts, d.cap_counts, (size_t)n_sent);
+    d.grow(d.d_out_off, d.cap_out_off, (size_t)n_sent + 1);
+    d.grow(d.d_scan_tmp, d.cap_scan_tmp, (size_t)scan_scratch_blocks(n_sent));
+    unsigned int max_blocks = 256 * 3;  // 3 workgroups of 4 waves per CU (48 KB LDS each)
+    unsigned long long stride = 0;
+    if (2 * max_sentence_bytes + 2 > 1024) {
+      stride = 2 * max_sentence_bytes + 2;
+      unsigned long long per_wave = 3 * stride * 4;
+      unsigned long long waves = std::max<unsigned long long>(1, (2ull << 30) / per_wave);
+      max_blocks = (unsigned int)std::max<unsigned long long>(1, std::min<unsigned long long>(max_blocks, waves / NWAVES));
+      d.grow(d.d_work, d.cap_work, (size_t)(3 * stride * (unsigned long long)max_blocks * NWAVES));
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (kernel_ms) {
+      HIP_CHECK(hipEventCreate(&e0));
+      HIP_CHECK(hipEventCreate(&e1));
+      HIP_CHECK(hipEventRecord(e0, d.st));
+    }
+    launch_encode(d.m, (const uint8_t *)d_bytes, (const unsigned long long *)d_offsets, n_sent, bos, eos, reverse, d.d_scratch, d.d_counts,
+                  d.d_work, stride, max_blocks, d.st);
+    if (kernel_ms) HIP_CHECK(hipEventRecord(e1, d.st));
+    launch_exclusive_scan(d.d_counts, n_sent, d.d_out_off, d.d_scan_tmp, d.d_total, d.st);
+    unsigned long long total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, d.d_total, 8, hipMemcpyDeviceToHost, d.st));
+    HIP_CHECK(hipStreamSynchronize(d.st));
+    HIP_CHECK(hipMemcpyAsync(d.d_out_off + n_sent, &total, 8, hipMemcpyHostToDevice, d.st));
+    d.grow(d.d_ids, d.cap_ids, (size_t)total);
+    launch_encode_gather(d.d_scratch, (const unsigned long long *)d_offsets, d.d_out_off, n_sent, d.d_ids, d.st);
+    HIP_CHECK(hipStreamSynchronize(d.st));
+    if (kernel_ms) {
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      *kernel_ms = ms;
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+    d.last_n_ids = total;
+    if (n_ids_out) *n_ids_out = total;
+  } catch (const GpuError &e) {
+    return Status(2, "GPU error: " + e.msg);
+  }
+  return Status();
+}
+
+Status BaseEncoder::fetch_device_result(int32_t *ids, unsigned long long *out_off, unsigned long long n_sent) const {
+  if (!dev_ || n_sent != dev_->last_n_sent) return Status(2, "fetch_device_result: no matching result");
+  try {
+    HIP_CHECK(hipSetDevice(device_));
+    if (n_sent == 0) { if (out_off) out_off[0] = 0; return Status(); }
+    if (ids && dev_->last_n_ids) HIP_CHECK(hipMemcpyAsync(ids, dev_->d_ids, (size_t)dev_->last_n_ids * 4, hipMemcpyDeviceToHost, dev_->st));
+    if (out_off) HIP_CHECK(hipMemcpyAsync(out_off, dev_->d_out_off, (size_t)(n_sent + 1) * 8, hipMemcpyDeviceToHost, dev_->st));
+    HIP_CHECK(hipStreamSynchronize(dev_->st));
+  } catch (const GpuError &e) {
+    return Status(2, "GPU error: " + e.msg);
+  }
+  return Status();
+}
+
+Status BaseEncoder::encode_as_ids(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,
+                                  bool reverse, double dropout_prob, std::vector<int32_t> *ids, std::vector<unsigned long long> *out_off) const {
+  if (bos && bpe_state.special_tokens.bos_id == -1) return Status(1, "Can't add <BOS> token. Model was trained without it.");
+  if (eos && bpe_state.special_tokens.eos_id == -1) return Status(1, "Can't add <EOS> token. Model was trained without it.");
+  ids->clear();
+  out_off->assign((size_t)n_sent + 1, 0);
+  if (n_sent == 0) return Status();
+  if (!dev_) return Status(2, "encoder has no device state");
+  unsigned long long total_bytes = offsets[n_sent] - offsets[0], max_len = 0;
+  for (unsigned long long i = 0; i < n_sent; i++) max_len = std::max(max_len, offsets[i + 1] - offsets[i]);
+  try {
+    HIP_CHECK(hipSetDevice(device_));
+    EncoderDevice &d = *dev_;
+    d.grow(d.d_bytes, d.cap_bytes, (size_t)total_bytes + 16);
+    d.grow(d.d_off, d.cap_off, (size_t)n_sent + 1);
+    // offsets are rebased to the first byte of the batch
+    std::vector<unsigned long long> rel((size_t)n_sent + 1);
+    for (unsigned long long i = 0; i <= n_sent; i++) rel[i] = offsets[i] - offsets[0];
+    if (total_bytes) HIP_CHECK(hipMemcpyAsync(d.d_bytes, bytes + offsets[0], (size_t)total_bytes, hipMemcpyHostToDevice, d.st));
+    HIP_CHECK(hipMemcpyAsync(d.d_off, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, d.st));
+    HIP_CHECK(hipStreamSynchronize(d.st));
+  } catch (const GpuError &e) {
+    return Status(2, "GPU error: " + e.msg);
+  }
+  unsigned long long n_ids = 0;
+  Status s = encode_device(dev_->d_bytes, dev_->d_off, n_sent, total_bytes, max_len, bos, eos, reverse, dropout_prob, &n_ids, nullptr);
+  if (!s.ok()) return s;
+  ids->resize((size_t)n_ids);
+  return fetch_device_result(ids->data(), out_off->data(), n_sent);
+}
+
+Status BaseEncoder::encode_as_subwords(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,
+                                       bool reverse, double dropout_prob, std::vector<std::string> *pieces,
+                                       std::vector<unsigned long long> *piece_off) const {
+  // ids come from the GPU (forward order, no bos/eos); pieces are a host lookup (bpe.cpp:1597-1613).  The k-th unk id
+  // of a sentence is the k-th run of unknown chars, whose text is recovered from the sentence itself.
+  if (bos && bpe_state.special_tokens.bos_id == -1) return Status(1, "Can't add <BOS> token. Model was trained without it.");
+  if (eos && bpe_state.special_tokens.eos_id == -1) return Status(1, "Can't add <EOS> token. Model was trained without it.");
+  std::vector<int32_t> ids;
+  std::vector<unsigned long long> off;
+  Status s = encode_as_ids(bytes, offsets, n_sent, false, false, false, dropout_prob, &ids, &off);
+  if (!s.ok()) return s;
+  pieces->clear();
+  piece_off->assign(1, 0);
+  const int unk = bpe_state.special_tokens.unk_id;
+  for (unsigned long long i = 0; i < n_sent; i++) {
+    std::vector<std::string> sent;
+    if (bos) sent.push_back(BOS_TOKEN);
+    // unknown runs of this sentence, in order
+    std::vector<std::string> unk_runs;
+    {
+      std::vector<uint32_t> text = decode_utf8((const char *)bytes + offsets[i], (const char *)bytes + offsets[i + 1]);
+      std::vector<uint32_t> run;
+      for (uint32_t c : text) {
+        const bool known = !is_space(c) && char2id.count(c);
+        if (!is_space(c) && !known) { run.push_back(c); continue; }
+        if (!run.empty()) { unk_runs.push_back(encode_utf8(run)); run.clear(); }
+      }
+      if (!run.empty()) unk_runs.push_back(encode_utf8(run));
+    }
+    size_t next_unk = 0;
+    for (unsigned long long k = off[i]; k < off[i + 1]; k++) {
+      const int id = ids[k];
+      if (id == unk) {
+        sent.push_back(next_unk < unk_runs.size() ? unk_runs[next_unk++] : std::string());
+      } else {
+        std::string piece;
+        id_to_subword(id, &piece, false);
+        sent.push_back(piece);
+      }
+    }
+    if (eos) sent.push_back(EOS_TOKEN);
+    if (reverse) std::reverse(sent.begin(), sent.end());
+    for (auto &p : sent) pieces->push_back(std::move(p));
+    piece_off->push_back(pieces->size());
+  }
+  return Status();
+}
+
+Status BaseEncoder::id_to_subword(int id, std::string *subword, bool replace_space) const {  // bpe.cpp:1774-1807
+  if (id < 0 || vocab_size() <= id)
+    return Status(1, "id must be in the range [0, vocab_size - 1]. Current value: vocab_size = " + std::to_string(vocab_size()) +
+                         "; id=" + std::to_string(id) + ";");
+  const SpecialTokens &sp = bpe_state.special_tokens;
+  if (sp.unk_id == id) { *subword = UNK_TOKEN; return Status(); }
+  if (sp.pad_id == id) { *subword = PAD_TOKEN; return Status(); }
+  if (sp.bos_id == id) { *subword = BOS_TOKEN; return Status(); }
+  if (sp.eos_id == id) { *subword = EOS_TOKEN; return Status(); }
+  auto it = recipe.find((uint32_t)id);
+  if (it == recipe.end()) { subword->clear(); return Status(); }
+  std::vector<uint32_t> cps;
+  for (uint32_t t : it->second) cps.push_back(id2char.at(t));
+  if (replace_space && !cps.empty() && cps[0] == SPACE_TOKEN) {
+    *subword = " " + encode_utf8(std::vector<uint32_t>(cps.begin() + 1, cps.end()));
+    return Status();
+  }
+  *subword = encode_utf8(cps);
+  return Status();
+}
+
+int BaseEncoder::subword_to_id(const std::string &token) const {  // bpe.cpp:1809-1826
+  const SpecialTokens &sp = bpe_state.special_tokens;
+  if (UNK_TOKEN == token) return sp.unk_id;
+  if (PAD_TOKEN == token) return sp.pad_id;
+  if (BOS_TOKEN == token) return sp.bos_id;
+  if (EOS_TOKEN == token) return sp.eos_id;
+  auto it = reversed_recipe.find(token);
+  if (it != reversed_recipe.end()) return (int)it->second;
+  return sp.unk_id;
+}
+
+Status BaseEncoder::decode(const std::vector<int> &ids, std::string *sentence, const std::unordered_set<int> *ignore_ids) const {
+  // bpe.cpp:1843-1861
+  bool first_iter = true;
+  for (int id : ids) {
+    std::string subword;
+    if (!ignore_ids || ignore_ids->count(id) == 0) {
+      Status status = id_to_subword(id, &subword, true);
+      if (!status.ok()) return status;
+      *sentence += subword;
+      if (first_iter && !sentence->empty() && sentence->at(0) == ' ') *sentence = sentence->substr(1);
+      first_iter = false;
+    }
+  }
+  return Status();
+}
+
+std::vector<std::string> BaseEncoder::vocabulary() const {  // bpe.cpp:1884-1894
+  int n = vocab_size();
+  std::vector<std::string> vocab((size_t)n);
+  for (int i = 0; i < n; i++) id_to_subword(i, &vocab[(size_t)i]);
+  return vocab;
+}
+
+}  // namespace yttm

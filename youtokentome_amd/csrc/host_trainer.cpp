@@ -1,0 +1,319 @@
+// host_trainer.cpp -- the host half of BPE training: alphabet, the exact ordered pick of the next merges, rename, dump.
+//
+// Mirrors train_bpe / learn_bpe_from_string (bpe.cpp:1368-1388, :859-1293).  The reference keeps a lazy priority
+// queue on the host and two rules in flight (:1121-1282); here the host keeps NO pair state at all: every round the
+// device filters the pair table for candidates above a count threshold, the host orders them exactly as
+// MergeCandidate::operator< does (bpe.cpp:110-126) and takes the longest prefix of mutually non-intersecting rules
+// (rule_intersection, bpe.cpp:145-147; an x==y rule closes the batch, cf. :1160) -- provably the same sequence as the
+// one-at-a-time greedy of the -DDETERMINISTIC_QUEUE build / learn_bpe_slow -- and one K4 pass applies
+// the whole batch.
+#include <stdio.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+
+#include "gpu_ctx.h"
+#include "host_core.h"
+
+namespace yttm {
+
+using clk = std::chrono::steady_clock;
+static double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+namespace {
+struct Cand {
+  unsigned long long cnt;
+  uint32_t x, y;
+};
+// true if a must be picked before b: larger count; then smaller max(x,y); then smaller min(x,y); then larger x
+inline bool before(const Cand &a, const Cand &b) {
+  if (a.cnt != b.cnt) return a.cnt > b.cnt;
+  const uint32_t amx = std::max(a.x, a.y), bmx = std::max(b.x, b.y);
+  if (amx != bmx) return amx < bmx;
+  const uint32_t amn = std::min(a.x, a.y), bmn = std::min(b.x, b.y);
+  if (amn != bmn) return amn < bmn;
+  return a.x > b.x;
+}
+struct HeapCmp {  // std heap keeps the "largest" on top: largest = picked first
+  bool operator()(const Cand &a, const Cand &b) const { return before(b, a); }
+};
+
+// threshold such that about `target` pairs have count >= tau (from the device histogram of live counts)
+unsigned long long choose_tau(const unsigned long long *hist, unsigned long long target, unsigned long long *total_out) {
+  unsigned long long total = 0;
+  for (int b = 1; b < CAND_BINS; b++) total += hist[b];
+  if (total_out) *total_out = total;
+  unsigned long long acc = 0;
+  for (int b = CAND_BINS - 1; b >= 1; b--) {
+    acc += hist[b];
+    if (acc >= target) return std::max<unsigned long long>(1, cand_bin_lower(b));
+  }
+  return 1;
+}
+}  // namespace
+
+Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const BpeConfig &cfg, BPEState *state_out,
+                 TrainReport *rep) {
+  const auto t_all = clk::now();
+  Comm *comm = g.comm();
+  const bool root = !comm || comm->rank == 0;
+  // ---- K1 + alphabet (bpe.cpp:941-944, :1013-1021)
+  std::vector<uint32_t> cps;
+  std::vector<unsigned long long> cnts;
+  unsigned long long data_len = 0;
+  g.char_hist(cps, cnts, data_len);
+  // deterministic order for the host sort (the device compaction order is arbitrary)
+  {
+    std::vector<size_t> idx(cps.size());
+    for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return cps[a] < cps[b]; });
+    std::vector<uint32_t> c2(cps.size());
+    std::vector<unsigned long long> n2(cps.size());
+    for (size_t i = 0; i < idx.size(); i++) { c2[i] = cps[idx[i]]; n2[i] = cnts[idx[i]]; }
+    cps.swap(c2);
+    cnts.swap(n2);
+  }
+  std::vector<std::pair<uint32_t, uint32_t>> alpha;  // insertion order, compact ids
+  uint64_t n_removed = 0;
+  compute_alphabet(cps, cnts, data_len, cfg, alpha, n_removed);
+  const uint32_t n_special = (uint32_t)cfg.special_tokens.n_special_tokens();
+  uint64_t used_ids = alpha.size() + n_special;
+  if (used_ids > (uint64_t)vocab_size) {  // bpe.cpp:1051-1062
+    return Status(1, "Incorrect arguments. Vocabulary size too small. Set vocab_size>=" + std::to_string(used_ids) +
+                         ".  Current value for vocab_size=" + std::to_string(vocab_size));
+  }
+  // ---- K2 + K3
+  {
+    std::vector<uint32_t> a_cp(alpha.size()), a_id(alpha.size());
+    for (size_t i = 0; i < alpha.size(); i++) { a_cp[i] = alpha[i].first; a_id[i] = alpha[i].second; }
+    g.build_word_table(a_cp.data(), a_id.data(), (uint32_t)alpha.size(), /*space_id=*/n_special, (uint32_t)vocab_size);
+  }
+  g.pair_count();
+  if (rep) rep->seconds_frontend = since(t_all);
+  const auto t_merge = clk::now();
+
+  // ---- merge loop
+  std::vector<BPE_Rule> rules;
+  rules.reserve((size_t)vocab_size);
+  const unsigned long long TARGET = 2048;
+  const uint32_t MX_ALL = 0xffffffffu;
+  unsigned long long tau = 1;
+  uint32_t tau_mx = MX_ALL;
+  std::vector<CandRec> recs;
+  std::vector<Cand> heap;
+  std::vector<uint32_t> batch_xyz;
+  std::vector<unsigned long long> batch_cnt;
+  unsigned long long hist[CAND_BINS];
+  unsigned long long rounds = 0, rescans = 0;
+  std::vector<uint8_t> in_batch((size_t)vocab_size + 1, 0);  // bit0: token is the x of a batch rule, bit1: the y
+  while (used_ids < (uint64_t)vocab_size) {
+    // Candidate set = every pair with count > tau, or count == tau and max(x,y) <= tau_mx: a complete prefix of the
+    // global order, so the batch built from it is exact.  The threshold only trades list length against early batch ends.
+    uint32_t n = g.candidates(tau, tau_mx, recs, hist);
+    unsigned long long total_pairs = 0;
+    const unsigned long long tau_hint = choose_tau(hist, TARGET, &total_pairs);
+    if (total_pairs == 0) {
+      if (root) fprintf(stderr, "WARNING merged only: %llu pairs of tokens\n", (unsigned long long)used_ids);  // bpe.cpp:1139
+      break;
+    }
+    if (n == 0 || (n < TARGET / 8 && tau_hint < tau)) {  // threshold too high: use the histogram's
+      tau = std::min(tau, tau_hint);
+      tau_mx = MX_ALL;
+      rescans++;
+      if (n == 0) continue;
+      n = g.candidates(tau, tau_mx, recs, hist);
+    }
+    if (n > recs.size()) {
+      // More candidates than the buffer holds (rare: huge ties).  Raise the count threshold by the histogram, then
+      // bisect the exact count, then bisect the max(x,y) bound inside the overflowing count.
+      rescans++;
+      if (tau_hint > tau) { tau = tau_hint; tau_mx = MX_ALL; continue; }
+      int top = CAND_BINS - 1;
+      while (top > 1 && hist[top] == 0) top--;
+      unsigned long long lo = tau, hi = cand_bin_lower(top + 1 < CAND_BINS ? top + 1 : top) * 2 + 1;
+      while (hi - lo > 1) {
+        const unsigned long long mid = lo + (hi - lo) / 2;
+        rescans++;
+        if (g.candidates(mid, MX_ALL, recs, nullptr) > recs.size()) lo = mid; else hi = mid;
+      }
+      uint32_t mlo = 0, mhi = (uint32_t)used_ids;
+      while (mhi - mlo > 1) {
+        const uint32_t mid = mlo + (mhi - mlo) / 2;
+        rescans++;
+        if (g.candidates(lo, mid, recs, nullptr) > recs.size()) mhi = mid; else mlo = mid;
+      }
+      tau = lo;
+      tau_mx = mlo;
+      n = g.candidates(tau, tau_mx, recs, nullptr);
+      if (n == 0 || n > recs.size()) return Status(2, "candidate filter could not be fitted (more than 2^20 exact ties)");
+    }
+    heap.resize(n);
+    for (uint32_t i = 0; i < n; i++) heap[i] = Cand{recs[i].cnt, (uint32_t)(recs[i].key >> 32), (uint32_t)recs[i].key};
+    std::make_heap(heap.begin(), heap.end(), HeapCmp());
+    batch_xyz.clear();
+    batch_cnt.clear();
+    const size_t max_batch = 4096;
+    while (!heap.empty() && used_ids + batch_cnt.size() < (uint64_t)vocab_size && batch_cnt.size() < max_batch) {
+      std::pop_heap(heap.begin(), heap.end(), HeapCmp());
+      const Cand c = heap.back();
+      heap.pop_back();
+      // rule_intersection (bpe.cpp:145-147) against every earlier rule of the batch: x == some y_j or y == some x_j
+      const bool intersects = (in_batch[c.x] & 2) || (in_batch[c.y] & 1);
+      if (intersects) break;  // its exact count after the earlier rules is unknown: close the batch here
+      in_batch[c.x] |= 1;
+      in_batch[c.y] |= 2;
+      const uint32_t z = (uint32_t)(used_ids + batch_cnt.size());
+      batch_xyz.push_back(c.x);
+      batch_xyz.push_back(c.y);
+      batch_xyz.push_back(z);
+      batch_cnt.push_back(c.cnt);
+      if (root && z % 1000 == 0) fprintf(stderr, "id: %u=%u+%u  freq: %llu\n", z, c.x, c.y, c.cnt);  // cf. bpe.cpp:1198-1219
+      if (c.x == c.y) break;  // a self-pair rule must be the last of its batch
+    }
+    const uint32_t k = (uint32_t)batch_cnt.size();
+    for (uint32_t j = 0; j < k; j++) in_batch[batch_xyz[3 * j]] = in_batch[batch_xyz[3 * j + 1]] = 0;
+    g.merge_apply(batch_xyz.data(), k, batch_cnt.data());
+    for (uint32_t j = 0; j < k; j++) rules.push_back(BPE_Rule{batch_xyz[3 * j], batch_xyz[3 * j + 1], batch_xyz[3 * j + 2]});
+    used_ids += k;
+    rounds++;
+    // next threshold: keep about TARGET candidates above it (any threshold is valid, see above)
+    tau = tau_hint;
+    tau_mx = MX_ALL;
+  }
+  if (rep) {
+    rep->seconds_merge = since(t_merge);
+    rep->rounds = rounds;
+    rep->cand_rescans = rescans;
+    rep->rules = rules.size();
+    rep->n_unique = g.n_unique;
+    rep->n_tokens = g.n_tokens0;
+    rep->corpus_bytes = g.corpus_bytes;
+  }
+
+  // ---- rename_tokens (bpe.cpp:814-837) + dump (utils.cpp:50-66)
+  const auto t_io = clk::now();
+  std::vector<uint32_t> ren((size_t)vocab_size + 1, 0);
+  {
+    uint32_t cur = n_special;
+    for (int i = 0; i < vocab_size; i++)
+      if (!cfg.special_tokens.taken_id(i)) ren[cur++] = (uint32_t)i;
+  }
+  BPEState st;
+  st.special_tokens = cfg.special_tokens;
+  {
+    std::vector<uint32_t> keys(alpha.size());
+    for (size_t i = 0; i < alpha.size(); i++) keys[i] = alpha[i].first;
+    std::vector<uint32_t> order = flat_hash_map_order(keys);
+    std::vector<std::pair<uint32_t, uint32_t>> sorted(alpha);
+    std::sort(sorted.begin(), sorted.end());
+    for (uint32_t cp : order) {
+      auto it = std::lower_bound(sorted.begin(), sorted.end(), std::make_pair(cp, 0u));
+      st.char2id.emplace_back(cp, ren[it->second]);
+    }
+  }
+  for (auto &r : rules) st.rules.push_back(BPE_Rule{ren[r.x], ren[r.y], ren[r.z]});
+  Status s;
+  if (root && !model_path.empty()) {
+    s = st.dump(model_path);
+    if (s.ok()) fprintf(stderr, "model saved to: %s\n", model_path.c_str());
+  }
+  if (state_out) *state_out = st;
+  if (rep) {
+    rep->seconds_io = since(t_io);
+    rep->seconds_total = since(t_all);
+    g.resolve_timers();
+    for (int i = 0; i < 8; i++) { rep->kt_ms[i] = g.kt.ms[i]; rep->kt_launches[i] = g.kt.launches[i]; rep->kt_bytes[i] = g.kt.bytes[i]; }
+  }
+  return s;
+}
+
+static void print_config(const std::string &input_path, const std::string &model_path, int vocab_size, const BpeConfig &c) {
+  // bpe.cpp:1352-1366
+  fprintf(stderr, "Training parameters\n  input: %s\n  model: %s\n  vocab_size: %d\n  n_threads: %d\n  character_coverage: %g\n", input_path.c_str(),
+          model_path.c_str(), vocab_size, c.n_threads, c.character_coverage);
+  fprintf(stderr, "  pad: %d\n  unk: %d\n  bos: %d\n  eos: %d\n\n", c.special_tokens.pad_id, c.special_tokens.unk_id, c.special_tokens.bos_id,
+          c.special_tokens.eos_id);
+}
+
+template <class F>
+static Status guarded(F &&f) {
+  try {
+    return f();
+  } catch (const GpuError &e) {
+    return Status(2, "GPU error: " + e.msg);
+  } catch (const std::exception &e) {
+    return Status(2, std::string("error: ") + e.what());
+  }
+}
+
+Status train_bpe_from_device(const void *d_text, unsigned long long n, const std::string &model_path, int vocab_size, BpeConfig cfg,
+                             int device, TrainReport *report, Comm *comm, bool profile) {
+  Status st = check_config(cfg, vocab_size);
+  if (!st.ok()) return st;
+  return guarded([&]() {
+    GpuCtx g(device);
+    g.profile = profile;
+    g.set_comm(comm);
+    g.attach_corpus(d_text, n);
+    return learn_bpe(g, vocab_size, model_path, cfg, nullptr, report);
+  });
+}
+
+Status train_bpe_from_memory(const uint8_t *text, unsigned long long n, const std::string &model_path, int vocab_size, BpeConfig cfg,
+                             int device, TrainReport *report, Comm *comm) {
+  Status st = check_config(cfg, vocab_size);
+  if (!st.ok()) return st;
+  return guarded([&]() {
+    GpuCtx g(device);
+    g.set_comm(comm);
+    g.upload_corpus(text, n);
+    return learn_bpe(g, vocab_size, model_path, cfg, nullptr, report);
+  });
+}
+
+Status train_bpe(const std::string &input_path, const std::string &model_path, int vocab_size, BpeConfig cfg, int device,
+                 TrainReport *report, Comm *comm) {
+  Status st = check_config(cfg, vocab_size);
+  if (!st.ok()) return st;
+  print_config(input_path, model_path, vocab_size, cfg);
+  fprintf(stderr, "reading file...\n");
+  int fd = open(input_path.c_str(), O_RDONLY);
+  if (fd < 0) return Status(1, "Failed to open file: " + input_path);  // bpe.cpp:72
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); return Status(1, "Failed to open file: " + input_path); }
+  unsigned long long size = (unsigned long long)sb.st_size;
+  const uint8_t *map = nullptr;
+  if (size) {
+    map = (const uint8_t *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (map == MAP_FAILED) { close(fd); return Status(1, "Failed to open file: " + input_path); }
+  }
+  // multi-GPU: each rank takes the byte range [size*r/W, size*(r+1)/W), advanced to the next ASCII space like the
+  // reference's per-thread split (bpe.cpp:864-873)
+  unsigned long long lo = 0, hi = size;
+  if (comm && comm->world > 1) {
+    auto split = [&](int i) {
+      unsigned long long c = size * (unsigned long long)i / (unsigned long long)comm->world;
+      while (c < size && !(map[c] == 32 || (map[c] >= 9 && map[c] <= 13))) c++;
+      return c;
+    };
+    lo = split(comm->rank);
+    hi = split(comm->rank + 1);
+  }
+  fprintf(stderr, "learning bpe...\n");
+  Status r = guarded([&]() {
+    GpuCtx g(device);
+    g.set_comm(comm);
+    g.upload_corpus(map ? map + lo : nullptr, hi - lo);
+    return learn_bpe(g, vocab_size, model_path, cfg, nullptr, report);
+  });
+  if (map) munmap((void *)map, size);
+  close(fd);
+  return r;
+}
+
+}  // namespace yttm

@@ -1,0 +1,271 @@
+// k_encode.hip -- K5: batch BPE encode, one sentence per wavefront (gfx950, wave64).
+//
+// Replaces BaseEncoder::encode_sentence (bpe.cpp:1455-1632) + encode_parallel (bpe.cpp:1697-1738) for dropout_prob == 0.
+// The reference pops (rule id, position) events from a per-word priority queue; that is equivalent to
+// rounds of "per word: find the smallest rule id among adjacent pairs, apply all its occurrences left to right".  A
+// wavefront runs those rounds for ALL words of its sentence at once: lanes = token positions, word-segmented minimum
+// through LDS atomics, x==x runs resolved by parity from the run start, in-place compaction with wave ballots.
+// Working arrays live in LDS (3 x 4 B per token); sentences too long for LDS use an HBM scratch with the same code.
+#include "yttm_device.h"
+#include "yttm_kernels.h"
+
+namespace yttm {
+
+constexpr int ENC_WCAP = 1024;               // tokens per wave held in LDS
+constexpr uint32_t ENC_UNKP = 0x7ffffff0u;   // placeholder token for a run of unknown chars (bpe.cpp:1517-1527)
+constexpr uint32_t ENC_INF = 0xffffffffu;
+
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct LdsArr {
+  uint32_t *p;
+  __device__ uint32_t get(int i) const { return p[i]; }
+  __device__ void set(int i, uint32_t v) const { p[i] = v; }
+  __device__ void amin(int i, uint32_t v) const { atomicMin(&p[i], v); }
+};
+struct GlbArr {  // HBM scratch for long sentences: bypass the non-coherent L1 (agent-scope atomics)
+  uint32_t *p;
+  __device__ uint32_t get(int i) const { return __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ void set(int i, uint32_t v) const { __hip_atomic_store(&p[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ void amin(int i, uint32_t v) const { atomicMin(&p[i], v); }
+};
+
+__device__ inline uint32_t enc_rule_lookup(const EncModel &m, uint32_t a, uint32_t b) {
+  const unsigned long long key = pair_key(a, b);
+  unsigned int h = (unsigned int)mix64(key) & m.rule_mask;
+  for (;;) {
+    const unsigned long long k = m.rules[h].key;
+    if (k == key) return h;
+    if (k == PT_EMPTY) return ENC_INF;
+    h = (h + 1) & m.rule_mask;
+  }
+}
+
+// One wavefront encodes one sentence.  wt = tokens (bit31 = first token of a word), wr = rule slot of the pair that
+// starts at p (or ENC_INF), wm = per-word minimum rule priority stored at the word's first position.
+template <class A>
+__device__ void encode_wave(const EncModel &m, const uint8_t *__restrict__ s, unsigned long long nbytes, A wt, A wr, A wm, int bos, int eos,
+                            int reverse, int32_t *__restrict__ out, uint32_t *__restrict__ count_out) {
+  const int lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+  // ---- A. UTF-8 decode + char -> token, word starts, unknown-run collapse ---------------------------------------------
+  int n = 0;
+  bool carry_space = true, carry_unk = false;  // class of the last valid char before this step (start of text acts like a space)
+  for (unsigned long long b0 = 0; b0 < nbytes; b0 += 64) {
+    const unsigned long long i = b0 + (unsigned long long)lane;
+    bool valid = false, space = false, unk = false;
+    uint32_t id = 0;
+    if (i < nbytes && u8_is_start(s, i, nbytes)) {
+      uint32_t len;
+      const uint32_t cp = u8_decode_at(s, i, nbytes, &len);
+      if (cp != INVALID_CP) {  // invalid bytes are dropped (utf8.cpp:111-128)
+        valid = true;
+        id = m.cpmap[cp];
+        space = id == CP_SPACE;
+        unk = id == CP_UNK;
+      }
+    }
+    const unsigned long long V = __ballot(valid), S = __ballot(space), U = __ballot(unk);
+    bool prev_space = carry_space, prev_unk = carry_unk;
+    const unsigned long long pv = V & lt;
+    if (pv) {
+      const int j = 63 - __clzll((long long)pv);
+      prev_space = (S >> j) & 1ull;
+      prev_unk = (U >> j) & 1ull;
+    }
+    int emit = 0;
+    bool wstart = false;
+    if (valid && !space) {
+      wstart = prev_space;
+      if (unk && prev_unk && !wstart) emit = 0;  // continues an unknown run
+      else emit = wstart ? 2 : 1;
+    }
+    const unsigned long long e1 = __ballot(emit >= 1), e2 = __ballot(emit == 2);
+    const int pos = n + __popcll(e1 & lt) + __popcll(e2 & lt);
+    const uint32_t tv = unk ? ENC_UNKP : id;
+    if (emit == 2) {
+      wt.set(pos, m.space_id | TOK_WS);  // every word starts with "▁" (bpe.cpp:1514)
+      wt.set(pos + 1, tv);
+    } else if (emit == 1) {
+      wt.set(pos, tv);
+    }
+    n += __popcll(e1) + __popcll(e2);
+    if (V) {
+      const int j = 63 - __clzll((long long)V);
+      carry_space = (S >> j) & 1ull;
+      carry_unk = (U >> j) & 1ull;
+    }
+  }
+  wave_sync();
+  // ---- B. merge rounds -----------------------------------------------------------------------------------------------
+  for (;;) {
+    const int nchunks = (n + 63) >> 6;
+    // phase 1: rule of every adjacency, word-segmented minimum
+    int carry_ws = 0;
+    for (int c = 0; c < nchunks; c++) {
+      const int p = c * 64 + lane;
+      if (p < n && (wt.get(p) & TOK_WS)) wm.set(p, ENC_INF);
+    }
+    wave_sync();
+    for (int c = 0; c < nchunks; c++) {
+      const int p = c * 64 + lane;
+      uint32_t t0 = 0, r = ENC_INF;
+      bool ws = false;
+      if (p < n) {
+        t0 = wt.get(p);
+        ws = t0 & TOK_WS;
+        if (p + 1 < n) {
+          const uint32_t t1 = wt.get(p + 1);
+          if (!(t1 & TOK_WS)) {
+            const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
+            const uint32_t slot = enc_rule_lookup(m, a, b);
+            if (slot != ENC_INF) {
+              r = m.rules[slot].pad;  // rule index = priority (smaller first)
+              if (a == b) {
+                // x==x: greedy left to right = even offsets from the start of the run of x's
+                int q = p;
+                while (q > 0 && !(wt.get(q) & TOK_WS) && (wt.get(q - 1) & TOK_MASK) == a) q--;
+                if ((p - q) & 1) r = ENC_INF;
+              }
+            }
+          }
+        }
+      }
+      const unsigned long long W = __ballot(ws);
+      int wsp = carry_ws;
+      const unsigned long long wle = W & ((2ull << lane) - 1ull);
+      if (wle) wsp = c * 64 + 63 - __clzll((long long)wle);
+      if (p < n) {
+        wr.set(p, r);
+        if (r != ENC_INF) wm.amin(wsp, r);
+      }
+      if (W) carry_ws = c * 64 + 63 - __clzll((long long)W);
+    }
+    wave_sync();
+    // phase 2: apply the per-word minimum rule, compact in place (ascending chunks; writes never pass unread data)
+    int base = 0;
+    bool prev_site = false;  // site flag of the last position of the previous chunk
+    bool any = false;
+    carry_ws = 0;
+    for (int c = 0; c < nchunks; c++) {
+      const int p = c * 64 + lane;
+      uint32_t t0 = 0;
+      bool ws = false, site = false;
+      uint32_t nt = 0;
+      if (p < n) {
+        t0 = wt.get(p);
+        ws = t0 & TOK_WS;
+      }
+      const unsigned long long W = __ballot(ws);
+      int wsp = carry_ws;
+      const unsigned long long wle = W & ((2ull << lane) - 1ull);
+      if (wle) wsp = c * 64 + 63 - __clzll((long long)wle);
+      if (W) carry_ws = c * 64 + 63 - __clzll((long long)W);
+      if (p < n) {
+        const uint32_t r = wr.get(p);
+        site = r != ENC_INF && r == wm.get(wsp);
+        nt = site ? (m.rule_z[r] | (t0 & TOK_WS)) : t0;
+      }
+      const unsigned long long SM = __ballot(site);
+      const bool dead = lane == 0 ? prev_site : ((SM >> (lane - 1)) & 1ull);
+      const bool alive = p < n && !dead;
+      const unsigned long long AM = __ballot(alive);
+      wave_sync();  // all lanes have read their inputs before anyone overwrites lower positions
+      if (alive) wt.set(base + __popcll(AM & lt), nt);
+      base += __popcll(AM);
+      prev_site = (SM >> 63) & 1ull;
+      any = any || SM != 0;
+      wave_sync();
+    }
+    n = base;
+    if (!any) break;
+  }
+  // ---- C. output (bpe.cpp:1591-1630): unknown runs -> unk_id; the id-0 quirk drops an unmerged leading "▁" whose id is 0
+  const int nb = bos ? 1 : 0;
+  int total = nb;
+  for (int c = 0; c < ((n + 63) >> 6); c++) {
+    const int p = c * 64 + lane;
+    bool emit = false;
+    uint32_t t0 = 0;
+    if (p < n) {
+      t0 = wt.get(p);
+      emit = !(t0 == TOK_WS);  // == (id 0 | TOK_WS): only the space token can be a word start with id 0
+    }
+    const unsigned long long E = __ballot(emit);
+    if (emit) {
+      const uint32_t id = t0 & TOK_MASK;
+      wm.set(total - nb + __popcll(E & lt), id == ENC_UNKP ? (uint32_t)m.unk_id : id);
+    }
+    total += __popcll(E);
+  }
+  wave_sync();
+  const int n_ids = total + (eos ? 1 : 0);
+  for (int k = lane; k < n_ids; k += 64) {
+    int32_t v;
+    if (bos && k == 0) v = m.bos_id;
+    else if (eos && k == n_ids - 1) v = m.eos_id;
+    else v = (int32_t)wm.get(k - nb);
+    out[reverse ? (n_ids - 1 - k) : k] = v;
+  }
+  if (lane == 0) *count_out = (uint32_t)n_ids;
+}
+
+__global__ __launch_bounds__(BLOCK) void k5_encode(EncModel m, const uint8_t *__restrict__ text,
+                                                   const unsigned long long *__restrict__ offsets, unsigned long long n_sent, int bos,
+                                                   int eos, int reverse, int32_t *__restrict__ scratch_ids,
+                                                   uint32_t *__restrict__ counts, uint32_t *__restrict__ work,
+                                                   unsigned long long work_stride) {
+  __shared__ uint32_t lds[NWAVES][3][ENC_WCAP];
+  const int wave = (int)(threadIdx.x >> 6);
+  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + wave;
+  const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
+  for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
+    const unsigned long long b0 = offsets[sidx], b1 = offsets[sidx + 1];
+    const unsigned long long nbytes = b1 - b0;
+    int32_t *out = scratch_ids + 2 * b0 + 2 * sidx;  // capacity 2*nbytes + 2 ids per sentence
+    if (2 * nbytes + 2 <= (unsigned long long)ENC_WCAP) {
+      LdsArr a{lds[wave][0]}, b{lds[wave][1]}, c{lds[wave][2]};
+      encode_wave(m, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx]);
+    } else {
+      uint32_t *w = work + gw * 3 * work_stride;
+      GlbArr a{w}, b{w + work_stride}, c{w + 2 * work_stride};
+      encode_wave(m, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx]);
+    }
+    wave_sync();
+  }
+}
+
+// copy ids from the over-allocated scratch to the packed output (one wave per sentence)
+__global__ __launch_bounds__(BLOCK) void k5_gather(const int32_t *__restrict__ scratch_ids, const unsigned long long *__restrict__ offsets,
+                                                   const unsigned long long *__restrict__ out_off, unsigned long long n_sent,
+                                                   int32_t *__restrict__ ids_out) {
+  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
+  const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
+  for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
+    const int32_t *src = scratch_ids + 2 * offsets[sidx] + 2 * sidx;
+    const unsigned long long o0 = out_off[sidx], o1 = out_off[sidx + 1];
+    for (unsigned long long k = lane_id(); k < o1 - o0; k += 64) ids_out[o0 + k] = src[k];
+  }
+}
+
+void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long long *offsets, unsigned long long n_sent, int bos,
+                   int eos, int reverse, int32_t *scratch_ids, uint32_t *counts, uint32_t *work, unsigned long long work_stride,
+                   unsigned int max_blocks, hipStream_t st) {
+  if (!n_sent) return;
+  unsigned long long b = (n_sent + NWAVES - 1) / NWAVES;
+  if (b > max_blocks) b = max_blocks;
+  hipLaunchKernelGGL(k5_encode, dim3((unsigned int)b), dim3(BLOCK), 0, st, m, text, offsets, n_sent, bos, eos, reverse, scratch_ids,
+                     counts, work, work_stride);
+}
+void launch_encode_gather(const int32_t *scratch_ids, const unsigned long long *offsets, const unsigned long long *out_off,
+                          unsigned long long n_sent, int32_t *ids_out, hipStream_t st) {
+  if (!n_sent) return;
+  unsigned long long b = (n_sent + NWAVES - 1) / NWAVES;
+  if (b > 256 * 16) b = 256 * 16;
+  hipLaunchKernelGGL(k5_gather, dim3((unsigned int)b), dim3(BLOCK), 0, st, scratch_ids, offsets, out_off, n_sent, ids_out);
+}
+
+}  // namespace yttm

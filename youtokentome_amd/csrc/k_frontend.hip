@@ -1,0 +1,489 @@
+// k_frontend.hip -- K1 (char histogram + UTF-8 scan) and K2 (word split + hash dedup + tile build) for gfx950.
+//
+// Replaces the O(N) front end of the reference trainer:
+//   K1  compute_char_count            bpe.cpp:839-857   (+ UTF8Iterator utf8.h:21-64, chars_to_utf8 utf8.cpp:37-74)
+//   K2  remove_rare_chars             bpe.cpp:357-380
+//       compute_word_count            bpe.cpp:388-418   (+ merge of per-thread maps :1029-1044)
+//       build_linked_list (layout)    bpe.cpp:436-478   -> flat token tiles instead of linked lists
+// All of it is HBM-bound byte/integer work: coalesced 16 B/lane loads staged through LDS, LDS-private histograms,
+// one global atomic per wave/block for cursors.  No MFMA.
+#include "yttm_device.h"
+#include "yttm_kernels.h"
+
+namespace yttm {
+
+constexpr int FE_BYTES_PER_THREAD = 16;
+constexpr int FE_CHUNK = BLOCK * FE_BYTES_PER_THREAD;  // 4096 bytes per block iteration
+constexpr int LH_BINS = 2048;                          // LDS-private histogram covers code points < 0x800
+
+// byte k of the 24-byte register window W[6] (k is a compile-time constant after unrolling)
+#define WB(k) ((W[(k) >> 2] >> (8 * ((k)&3))) & 0xffu)
+
+// MODE 0: histogram + number of decode steps + number of segment starts.
+// MODE 1: append the byte offsets of segment starts (a segment = maximal run of non-space chars) to seg_pos.
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_scan_bytes(const uint8_t *__restrict__ text, unsigned long long n,
+                                                      unsigned long long *__restrict__ hist,
+                                                      unsigned long long *__restrict__ counters /* [0]=steps [1]=segs */,
+                                                      unsigned long long *__restrict__ seg_pos,
+                                                      unsigned long long *__restrict__ seg_cursor) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage[FE_CHUNK + 16];  // [0..3] halo before, [4..4+FE_CHUNK) main, then halo after
+  __shared__ unsigned int lh[MODE == 0 ? LH_BINS : 1];
+  __shared__ uint32_t scan_lds[NWAVES];
+  __shared__ unsigned long long blk_base;
+  const int tid = (int)threadIdx.x;
+  if (MODE == 0) {
+    for (int b = tid; b < LH_BINS; b += BLOCK) lh[b] = 0;
+  }
+  unsigned long long my_steps = 0, my_segs = 0;
+  const unsigned long long n_chunks = (n + FE_CHUNK - 1) / FE_CHUNK;
+  for (unsigned long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const unsigned long long c0 = chunk * FE_CHUNK;
+    __syncthreads();  // previous iteration done with `stage`
+    {
+      // coalesced 16 B/lane load of the chunk (text base is 256 B aligned: hipMalloc), zero fill past the end
+      unsigned long long g = c0 + (unsigned long long)tid * 16;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (g + 16 <= n) {
+        v = *reinterpret_cast<const uint4 *>(text + g);
+      } else if (g < n) {
+        uint32_t t[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 16 && g + j < n; j++) t[j >> 2] |= (uint32_t)text[g + j] << (8 * (j & 3));
+        v = make_uint4(t[0], t[1], t[2], t[3]);
+      }
+      *reinterpret_cast<uint4 *>(&stage[4 + tid * 16]) = v;
+      if (tid == 0) {
+        uint32_t h = 0;
+        if (c0 >= 4) h = *reinterpret_cast<const uint32_t *>(text + c0 - 4);
+        *reinterpret_cast<uint32_t *>(&stage[0]) = h;
+      }
+      if (tid == 1) {
+        uint32_t h = 0;
+        unsigned long long e = c0 + FE_CHUNK;
+        for (int j = 0; j < 4; j++)
+          if (e + j < n) h |= (uint32_t)text[e + j] << (8 * j);
+        *reinterpret_cast<uint32_t *>(&stage[4 + FE_CHUNK]) = h;
+      }
+    }
+    __syncthreads();
+    const unsigned long long i0 = c0 + (unsigned long long)tid * 16;
+    uint32_t W[6];
+    {
+      W[0] = *reinterpret_cast<const uint32_t *>(&stage[tid * 16]);
+      uint4 m = *reinterpret_cast<const uint4 *>(&stage[4 + tid * 16]);
+      W[1] = m.x; W[2] = m.y; W[3] = m.z; W[4] = m.w;
+      W[5] = *reinterpret_cast<const uint32_t *>(&stage[4 + tid * 16 + 16]);
+    }
+    uint32_t seg_mask = 0;  // bit j: byte i0+j starts a segment
+    uint32_t n_starts = 0;
+    if (i0 < n) {
+      const bool all_ascii = ((W[0] | W[1] | W[2] | W[3] | W[4] | W[5]) & 0x80808080u) == 0;
+#pragma unroll
+      for (int k = 4; k < 20; k++) {
+        const unsigned long long gi = i0 + (unsigned long long)(k - 4);
+        if (gi < n) {
+          const uint32_t b = WB(k);
+          bool start = true;
+          uint32_t cp = b;
+          if (!all_ascii) {
+            if (u8_cont(b)) {
+#pragma unroll
+              for (int d = 1; d <= 3; d++) {
+                if ((unsigned long long)d > gi) break;
+                const uint32_t c = WB(k - d);
+                if (u8_cont(c)) continue;
+                uint32_t len;
+                uint32_t q = u8_decode(c, WB(k - d + 1), WB(k - d + 2), WB(k - d + 3), n - (gi - d), &len);
+                start = !(q != INVALID_CP && len > (uint32_t)d);
+                break;
+              }
+              cp = INVALID_CP;  // a continuation byte that starts a char is an invalid char
+            } else if (b >= 0x80u) {
+              uint32_t len;
+              cp = u8_decode(b, WB(k + 1), WB(k + 2), WB(k + 3), n - gi, &len);
+            }
+          }
+          if (start) {
+            n_starts++;
+            const bool space = cp != INVALID_CP && cp_is_space(cp);
+            if (MODE == 0) {
+              if (cp != INVALID_CP && !space) {
+                if (cp < (uint32_t)LH_BINS) atomicAdd(&lh[cp], 1u);
+                else atomicAdd(&hist[cp], 1ull);
+              }
+            }
+            if (!space) {
+              // previous char is a space (or start of text)?  ASCII space byte, or the 3 bytes E2 96 81 ("▁").
+              bool prev_space = gi == 0;
+              if (!prev_space) {
+                const uint32_t p1 = WB(k - 1);
+                prev_space = (p1 == 32u || (p1 >= 9u && p1 <= 13u)) ||
+                             (gi >= 3 && p1 == 0x81u && WB(k - 2) == 0x96u && WB(k - 3) == 0xe2u);
+              }
+              if (prev_space) seg_mask |= 1u << (k - 4);
+            }
+          }
+        }
+      }
+    }
+    my_steps += n_starts;
+    const uint32_t nseg = (uint32_t)__popc(seg_mask);
+    my_segs += nseg;
+    if (MODE == 1) {
+      uint32_t total;
+      uint32_t off = block_excl_scan(nseg, scan_lds, &total);
+      if (tid == 0) blk_base = total ? atomicAdd(seg_cursor, (unsigned long long)total) : 0ull;
+      __syncthreads();
+      unsigned long long o = blk_base + off;
+      uint32_t m = seg_mask;
+      while (m) {
+        int j = __ffs((int)m) - 1;
+        m &= m - 1;
+        seg_pos[o++] = i0 + (unsigned long long)j;
+      }
+    }
+  }
+  if (MODE == 0) {
+    unsigned long long s = wave_sum_u64(my_steps);
+    unsigned long long g = wave_sum_u64(my_segs);
+    if (lane_id() == 0) {
+      if (s) atomicAdd(&counters[0], s);
+      if (g) atomicAdd(&counters[1], g);
+    }
+    __syncthreads();
+    for (int b = tid; b < LH_BINS; b += BLOCK) {
+      unsigned int v = lh[b];
+      if (v) atomicAdd(&hist[b], (unsigned long long)v);
+    }
+  }
+}
+
+// Compact the non-zero bins of the dense code-point histogram into (cp,count) lists.
+__global__ __launch_bounds__(BLOCK) void k_hist_compact(const unsigned long long *__restrict__ hist, uint32_t *__restrict__ cps,
+                                                        unsigned long long *__restrict__ cnts, unsigned int *__restrict__ n_out,
+                                                        unsigned int cap) {
+  unsigned int cp = blockIdx.x * BLOCK + threadIdx.x;
+  if (cp >= N_CODEPOINTS) return;
+  unsigned long long c = hist[cp];
+  if (c) {
+    unsigned int o = atomicAdd(n_out, 1u);
+    if (o < cap) { cps[o] = cp; cnts[o] = c; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- K2: word dedup
+// One thread per segment.  The word is the segment's kept chars (cpmap != DROP, valid UTF-8); words are identified by
+// their token-id sequence.  Hash table slot = (tag:24 | representative byte offset:40) claimed with one 64-bit CAS, so
+// a matching tag is always verified against the representative's bytes: the dedup is exact, never probabilistic.
+
+__device__ inline unsigned long long word_hash_step(unsigned long long h, uint32_t id) {
+  return (h ^ (unsigned long long)id) * 0x100000001b3ull + 0x9e3779b97f4a7c15ull;
+}
+
+// walks a segment starting at byte `pos`; returns number of kept chars and the hash
+__device__ inline uint32_t seg_scan(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap,
+                                    unsigned long long pos, unsigned long long *hash_out) {
+  unsigned long long h = 0xcbf29ce484222325ull;
+  uint32_t L = 0;
+  unsigned long long i = pos;
+  while (i < n) {
+    uint32_t len;
+    uint32_t cp = u8_decode_at(text, i, n, &len);
+    if (cp != INVALID_CP) {
+      uint32_t id = cpmap[cp];
+      if (id == CP_SPACE) break;
+      if (id != CP_DROP) { h = word_hash_step(h, id); L++; }
+    }
+    i += len;
+  }
+  *hash_out = mix64(h ^ ((unsigned long long)L << 48));
+  return L;
+}
+
+// exact comparison of the kept-token sequences of the segments at a and b
+__device__ inline bool seg_equal(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap,
+                                 unsigned long long a, unsigned long long b) {
+  if (a == b) return true;
+  for (;;) {
+    uint32_t ia = CP_SPACE, ib = CP_SPACE;
+    while (a < n) {
+      uint32_t len;
+      uint32_t cp = u8_decode_at(text, a, n, &len);
+      a += len;
+      if (cp == INVALID_CP) continue;
+      uint32_t id = cpmap[cp];
+      if (id == CP_DROP) continue;
+      ia = id;
+      break;
+    }
+    while (b < n) {
+      uint32_t len;
+      uint32_t cp = u8_decode_at(text, b, n, &len);
+      b += len;
+      if (cp == INVALID_CP) continue;
+      uint32_t id = cpmap[cp];
+      if (id == CP_DROP) continue;
+      ib = id;
+      break;
+    }
+    if (ia != ib) return false;
+    if (ia == CP_SPACE) return true;  // both ended (space or end of text)
+  }
+}
+
+constexpr unsigned long long WH_POS_MASK = (1ull << 40) - 1;
+
+__global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restrict__ text, unsigned long long n,
+                                                          const uint32_t *__restrict__ cpmap,
+                                                          const unsigned long long *__restrict__ seg_pos, unsigned long long n_segs,
+                                                          unsigned long long *__restrict__ ht_key, unsigned long long *__restrict__ ht_cnt,
+                                                          uint32_t *__restrict__ ht_len, unsigned long long ht_mask,
+                                                          unsigned int *__restrict__ status /* [0]=n_unique [1]=too_long flag */) {
+  unsigned long long s = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
+  for (; s < n_segs; s += stride) {
+    const unsigned long long pos = seg_pos[s];
+    unsigned long long h;
+    const uint32_t L = seg_scan(text, n, cpmap, pos, &h);
+    if (L == 0) continue;  // segment made only of dropped chars: no word (bpe.cpp:357-380 deletes them first)
+    if (L + 1 > (uint32_t)TILE_TOK) { atomicOr(&status[1], 1u); continue; }
+    const unsigned long long mine = ((h >> 40) << 40) | pos;
+    const unsigned long long tag = h >> 40;
+    unsigned long long i = h & ht_mask;
+    for (;;) {
+      unsigned long long cur = ld_agent(&ht_key[i]);
+      if (cur == PT_EMPTY) {
+        cur = atomicCAS(&ht_key[i], PT_EMPTY, mine);
+        if (cur == PT_EMPTY) {
+          ht_len[i] = L + 1;  // + the leading "▁" token; read only by later kernels
+          atomicAdd(&ht_cnt[i], 1ull);
+          atomicAdd(&status[0], 1u);
+          break;
+        }
+      }
+      if ((cur >> 40) == tag && seg_equal(text, n, cpmap, cur & WH_POS_MASK, pos)) {
+        atomicAdd(&ht_cnt[i], 1ull);
+        break;
+      }
+      i = (i + 1) & ht_mask;
+    }
+  }
+}
+
+// Compact occupied hash slots into the unique-word arrays (block-aggregated append; order is not significant).
+__global__ __launch_bounds__(BLOCK) void k2c_compact_words(const unsigned long long *__restrict__ ht_key,
+                                                           const unsigned long long *__restrict__ ht_cnt,
+                                                           const uint32_t *__restrict__ ht_len, unsigned long long n_slots,
+                                                           unsigned long long *__restrict__ uw_pos, uint32_t *__restrict__ uw_cnt,
+                                                           uint32_t *__restrict__ uw_len, unsigned int *__restrict__ cursor,
+                                                           unsigned int *__restrict__ status) {
+  __shared__ uint32_t scan_lds[NWAVES];
+  __shared__ unsigned int blk_base;
+  const unsigned long long n_iter = (n_slots + BLOCK - 1) / BLOCK;
+  for (unsigned long long it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    unsigned long long i = it * BLOCK + threadIdx.x;
+    unsigned long long k = i < n_slots ? ht_key[i] : PT_EMPTY;
+    uint32_t has = k != PT_EMPTY;
+    uint32_t total;
+    uint32_t off = block_excl_scan(has, scan_lds, &total);
+    if (threadIdx.x == 0) blk_base = total ? atomicAdd(cursor, total) : 0u;
+    __syncthreads();
+    if (has) {
+      unsigned int o = blk_base + off;
+      unsigned long long c = ht_cnt[i];
+      if (c > 0xffffffffull) atomicOr(&status[1], 2u);  // a word seen >= 2^32 times: weights are uint32
+      uw_pos[o] = k & WH_POS_MASK;
+      uw_cnt[o] = (uint32_t)c;
+      uw_len[o] = ht_len[i];
+    }
+    __syncthreads();
+  }
+}
+
+// ---- generic exclusive scan of uint32 -> uint64 (3 kernels: block sums, scan of sums, add) ------------------------
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = BLOCK * SCAN_ITEMS;
+
+__global__ __launch_bounds__(BLOCK) void k_scan_block_sums(const uint32_t *__restrict__ in, unsigned long long n,
+                                                           unsigned long long *__restrict__ block_sums) {
+  __shared__ unsigned long long ws[NWAVES];
+  unsigned long long base = (unsigned long long)blockIdx.x * SCAN_TILE;
+  unsigned long long s = 0;
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    unsigned long long i = base + (unsigned long long)j * BLOCK + threadIdx.x;
+    if (i < n) s += in[i];
+  }
+  s = wave_sum_u64(s);
+  if (lane_id() == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int k = 0; k < NWAVES; k++) t += ws[k];
+    block_sums[blockIdx.x] = t;
+  }
+}
+
+// single-block serial-by-chunks exclusive scan of the block sums (n_blocks <= a few hundred thousand)
+__global__ __launch_bounds__(BLOCK) void k_scan_sums(unsigned long long *__restrict__ block_sums, unsigned long long n_blocks,
+                                                     unsigned long long *__restrict__ total_out) {
+  __shared__ unsigned long long ws[NWAVES];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (unsigned long long b0 = 0; b0 < n_blocks; b0 += BLOCK) {
+    unsigned long long i = b0 + threadIdx.x;
+    unsigned long long v = i < n_blocks ? block_sums[i] : 0;
+    // inclusive scan in the wave
+    unsigned long long inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      unsigned long long t = __shfl_up(inc, o);
+      if (lane_id() >= o) inc += t;
+    }
+    if (lane_id() == 63) ws[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    unsigned long long base = carry;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); k++) base += ws[k];
+    if (i < n_blocks) block_sums[i] = base + inc - v;
+    __syncthreads();
+    if (threadIdx.x == BLOCK - 1) carry = base + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t *__restrict__ in, unsigned long long n,
+                                                      const unsigned long long *__restrict__ block_sums,
+                                                      unsigned long long *__restrict__ out) {
+  __shared__ uint32_t scan_lds[NWAVES];
+  unsigned long long base = (unsigned long long)blockIdx.x * SCAN_TILE + (unsigned long long)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint32_t s = 0;
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    unsigned long long i = base + j;
+    v[j] = i < n ? in[i] : 0;
+    s += v[j];
+  }
+  // per-thread sums are < 2^32 because word lengths are <= TILE_TOK
+  uint32_t total;
+  uint32_t off = block_excl_scan(s, scan_lds, &total);
+  unsigned long long run = block_sums[blockIdx.x] + off;
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    unsigned long long i = base + j;
+    if (i < n) out[i] = run;
+    run += v[j];
+  }
+}
+
+// Write the token stream: word u = [space_id|TOK_WS, id(c1), id(c2), ...]  (bpe.cpp:406-411)
+__global__ __launch_bounds__(BLOCK) void k2e_fill_tokens(const uint8_t *__restrict__ text, unsigned long long n,
+                                                         const uint32_t *__restrict__ cpmap, uint32_t space_id,
+                                                         const unsigned long long *__restrict__ uw_pos,
+                                                         const unsigned long long *__restrict__ uw_off, unsigned int n_words,
+                                                         uint32_t *__restrict__ tok) {
+  unsigned int u = blockIdx.x * BLOCK + threadIdx.x;
+  if (u >= n_words) return;
+  unsigned long long i = uw_pos[u];
+  unsigned long long o = uw_off[u];
+  tok[o++] = space_id | TOK_WS;
+  while (i < n) {
+    uint32_t len;
+    uint32_t cp = u8_decode_at(text, i, n, &len);
+    if (cp != INVALID_CP) {
+      uint32_t id = cpmap[cp];
+      if (id == CP_SPACE) break;
+      if (id != CP_DROP) tok[o++] = id;
+    }
+    i += len;
+  }
+}
+
+// Tiles: word u belongs to tile uw_off[u] / TILE_TOK; the first word of each tile records the tile start.
+__global__ __launch_bounds__(BLOCK) void k2f_tiles(const unsigned long long *__restrict__ uw_off, unsigned int n_words,
+                                                   unsigned long long *__restrict__ tile_start, uint32_t *__restrict__ tile_word0) {
+  unsigned int u = blockIdx.x * BLOCK + threadIdx.x;
+  if (u >= n_words) return;
+  unsigned long long t = uw_off[u] / TILE_TOK;
+  if (u == 0 || uw_off[u - 1] / TILE_TOK != t) {
+    tile_start[t] = uw_off[u];
+    tile_word0[t] = u;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k2g_tile_len(const unsigned long long *__restrict__ tile_start, unsigned int n_tiles,
+                                                      unsigned long long total_tokens, uint32_t *__restrict__ tile_len) {
+  unsigned int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= n_tiles) return;
+  unsigned long long e = (t + 1 < n_tiles) ? tile_start[t + 1] : total_tokens;
+  tile_len[t] = (uint32_t)(e - tile_start[t]);
+}
+
+// ------------------------------------------------------------------------------------------------- launchers
+static inline unsigned int grid_for(unsigned long long items, unsigned int per_block, unsigned int max_blocks) {
+  unsigned long long b = (items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (unsigned int)b;
+}
+
+void launch_char_hist(const uint8_t *text, unsigned long long n, unsigned long long *hist, unsigned long long *counters,
+                      hipStream_t st) {
+  unsigned int g = grid_for(n, FE_CHUNK, 256 * 8);
+  hipLaunchKernelGGL(k_scan_bytes<0>, dim3(g), dim3(BLOCK), 0, st, text, n, hist, counters, (unsigned long long *)nullptr,
+                     (unsigned long long *)nullptr);
+}
+void launch_seg_write(const uint8_t *text, unsigned long long n, unsigned long long *seg_pos, unsigned long long *seg_cursor,
+                      hipStream_t st) {
+  unsigned int g = grid_for(n, FE_CHUNK, 256 * 8);
+  hipLaunchKernelGGL(k_scan_bytes<1>, dim3(g), dim3(BLOCK), 0, st, text, n, (unsigned long long *)nullptr,
+                     (unsigned long long *)nullptr, seg_pos, seg_cursor);
+}
+void launch_hist_compact(const unsigned long long *hist, uint32_t *cps, unsigned long long *cnts, unsigned int *n_out,
+                         unsigned int cap, hipStream_t st) {
+  hipLaunchKernelGGL(k_hist_compact, dim3((N_CODEPOINTS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, hist, cps, cnts, n_out, cap);
+}
+void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *seg_pos,
+                         unsigned long long n_segs, unsigned long long *ht_key, unsigned long long *ht_cnt, uint32_t *ht_len,
+                         unsigned long long ht_mask, unsigned int *status, hipStream_t st) {
+  unsigned int g = grid_for(n_segs, BLOCK, 256 * 32);
+  hipLaunchKernelGGL(k2b_insert_words, dim3(g), dim3(BLOCK), 0, st, text, n, cpmap, seg_pos, n_segs, ht_key, ht_cnt, ht_len,
+                     ht_mask, status);
+}
+void launch_compact_words(const unsigned long long *ht_key, const unsigned long long *ht_cnt, const uint32_t *ht_len,
+                          unsigned long long n_slots, unsigned long long *uw_pos, uint32_t *uw_cnt, uint32_t *uw_len,
+                          unsigned int *cursor, unsigned int *status, hipStream_t st) {
+  unsigned int g = grid_for(n_slots, BLOCK, 256 * 16);
+  hipLaunchKernelGGL(k2c_compact_words, dim3(g), dim3(BLOCK), 0, st, ht_key, ht_cnt, ht_len, n_slots, uw_pos, uw_cnt, uw_len,
+                     cursor, status);
+}
+void launch_exclusive_scan(const uint32_t *in, unsigned long long n, unsigned long long *out, unsigned long long *block_sums,
+                           unsigned long long *total_out, hipStream_t st) {
+  unsigned long long nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nb == 0) nb = 1;
+  hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned int)nb), dim3(BLOCK), 0, st, in, n, block_sums);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, st, block_sums, nb, total_out);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned int)nb), dim3(BLOCK), 0, st, in, n, block_sums, out);
+}
+unsigned long long scan_scratch_blocks(unsigned long long n) {
+  unsigned long long nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  return nb ? nb : 1;
+}
+void launch_fill_tokens(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, uint32_t space_id,
+                        const unsigned long long *uw_pos, const unsigned long long *uw_off, unsigned int n_words, uint32_t *tok,
+                        hipStream_t st) {
+  if (!n_words) return;
+  hipLaunchKernelGGL(k2e_fill_tokens, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, text, n, cpmap, space_id, uw_pos,
+                     uw_off, n_words, tok);
+}
+void launch_tiles(const unsigned long long *uw_off, unsigned int n_words, unsigned long long *tile_start, uint32_t *tile_word0,
+                  hipStream_t st) {
+  if (!n_words) return;
+  hipLaunchKernelGGL(k2f_tiles, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, uw_off, n_words, tile_start, tile_word0);
+}
+void launch_tile_len(const unsigned long long *tile_start, unsigned int n_tiles, unsigned long long total_tokens,
+                     uint32_t *tile_len, hipStream_t st) {
+  if (!n_tiles) return;
+  hipLaunchKernelGGL(k2g_tile_len, dim3((n_tiles + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, tile_start, n_tiles, total_tokens,
+                     tile_len);
+}
+
+}  // namespace yttm

@@ -1,0 +1,208 @@
+// yttm_device.h -- shared device-side definitions for the MI355X (gfx950) BPE kernels.
+//
+// Data layout in HBM:
+//   * token stream `tok[T]`   : uint32 per token; bit31 (TOK_WS) marks the first token of a word (the one that carries
+//                               the leading "▁", bpe.cpp:407/1514), bits 0..30 = compact token id.  Words are stored back to
+//                               back; a pair (tok[p],tok[p+1]) is an adjacency iff tok[p+1] has no TOK_WS.
+//   * tiles                   : the stream is cut at word boundaries into tiles of ~TILE_TOK tokens; one workgroup owns a
+//                               tile, stages it in LDS, and compacts it in place as merges remove tokens.
+//   * word weights `wcnt[U]`  : uint32 frequency per unique word (bpe.cpp:382-385 WordCount::cnt).
+//   * pair table              : open-addressing hash map (x<<32|y) -> uint64 count in HBM (replaces pair2cnt, bpe.cpp:891).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace yttm {
+
+constexpr uint32_t TOK_WS = 0x80000000u;
+constexpr uint32_t TOK_MASK = 0x7fffffffu;
+
+// code point -> class map values (cpmap[0x110000])
+constexpr uint32_t CP_DROP = 0xffffffffu;   // removed by coverage / not in the alphabet (train) -- deleted from the text
+constexpr uint32_t CP_SPACE = 0xfffffffeu;  // utils.cpp:99-101 is_space
+constexpr uint32_t CP_UNK = 0xfffffffdu;    // encode: char not in the model (bpe.cpp:1517)
+constexpr uint32_t N_CODEPOINTS = 0x110000u;
+constexpr uint32_t INVALID_CP = 0x0fffffffu;  // utf8.h:9
+
+constexpr int TILE_TOK = 2048;  // nominal tokens per tile; also the longest word the tile kernels accept
+constexpr int TILE_MAX = 4096;  // a tile holds whole words, so it can overshoot TILE_TOK by < one word
+constexpr int TILE_CHUNKS = TILE_MAX / 64;
+constexpr int BLOCK = 256;      // 4 wavefronts of 64 lanes
+constexpr int NWAVES = BLOCK / 64;
+
+constexpr unsigned long long PT_EMPTY = ~0ull;
+
+struct PairTable {
+  unsigned long long *keys;  // PT_EMPTY = free slot
+  unsigned long long *cnts;
+  unsigned long long mask;   // capacity - 1 (capacity is a power of two)
+  unsigned int *n_keys;      // number of occupied slots
+};
+
+struct TileSet {
+  uint32_t *tok;
+  const unsigned long long *tile_start;  // [n_tiles]
+  uint32_t *tile_len;                    // [n_tiles] live tokens (compacted prefix of the tile)
+  const uint32_t *tile_word0;            // [n_tiles] index of the first word of the tile
+  const uint32_t *wcnt;                  // [U]
+  uint32_t n_tiles;
+};
+
+// one slot of the per-round rule table uploaded by the host (key = x<<32|y)
+struct RuleSlot {
+  unsigned long long key;
+  uint32_t z;
+  uint32_t pad;
+};
+
+// exchange record (multi-GPU): signed count delta for one pair
+struct DeltaRec {
+  unsigned long long key;
+  long long delta;
+};
+
+struct DeltaBuf {
+  DeltaRec *recs;          // nullptr = single-GPU mode (no records kept)
+  unsigned long long cap;
+  unsigned long long *n;   // append cursor; may run past cap (overflow is reported by the host)
+};
+
+__host__ __device__ inline unsigned long long mix64(unsigned long long x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+
+__host__ __device__ inline unsigned long long pair_key(uint32_t x, uint32_t y) {
+  return ((unsigned long long)x << 32) | (unsigned long long)y;
+}
+
+// ---- racy reads go through agent-scope atomic loads (per-CU L1 is not coherent; MI355X_MICROARCH.md) -------------
+__device__ inline unsigned long long ld_agent(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// pair table: insert-or-add.  Keys are never removed, so a non-empty slot observed once stays valid.
+__device__ inline void pt_add(const PairTable &pt, unsigned long long key, long long delta) {
+  unsigned long long i = mix64(key) & pt.mask;
+  for (;;) {
+    unsigned long long k = ld_agent(&pt.keys[i]);
+    if (k == PT_EMPTY) {
+      k = atomicCAS(&pt.keys[i], PT_EMPTY, key);
+      if (k == PT_EMPTY) {
+        atomicAdd(pt.n_keys, 1u);
+        k = key;
+      }
+    }
+    if (k == key) {
+      atomicAdd(&pt.cnts[i], (unsigned long long)delta);
+      return;
+    }
+    i = (i + 1) & pt.mask;
+  }
+}
+
+__device__ inline unsigned long long pt_get(const PairTable &pt, unsigned long long key) {
+  unsigned long long i = mix64(key) & pt.mask;
+  for (;;) {
+    unsigned long long k = pt.keys[i];
+    if (k == PT_EMPTY) return 0;
+    if (k == key) return pt.cnts[i];
+    i = (i + 1) & pt.mask;
+  }
+}
+
+// ---- UTF-8 (utf8.cpp:14-74), device version ----------------------------------------------------------------------
+__host__ __device__ inline bool u8_cont(uint32_t b) { return (b & 0xc0u) == 0x80u; }
+__host__ __device__ inline bool cp_ok(uint32_t x) { return (x < 0xd800u) || (0xdfffu < x && x < 0x110000u); }
+
+// Decodes the char whose first byte is b0 at position i; `avail` = bytes available from i (>=1); b1..b3 are the
+// following bytes (only read when available).  Returns code point or INVALID_CP; *len = bytes consumed (1 if invalid).
+__host__ __device__ inline uint32_t u8_decode(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, unsigned long long avail,
+                                              uint32_t *len) {
+  *len = 1;
+  if ((b0 & 0x80u) == 0) return b0;
+  if ((b0 & 0xe0u) == 0xc0u) {
+    if (avail >= 2 && u8_cont(b1)) {
+      uint32_t cp = ((b0 & 0x1fu) << 6) + (b1 & 0x3fu);
+      if (cp >= 0x80u && cp_ok(cp)) { *len = 2; return cp; }
+    }
+  } else if ((b0 & 0xf0u) == 0xe0u) {
+    if (avail >= 3 && u8_cont(b1) && u8_cont(b2)) {
+      uint32_t cp = ((b0 & 0x0fu) << 12) + ((b1 & 0x3fu) << 6) + (b2 & 0x3fu);
+      if (cp >= 0x800u && cp_ok(cp)) { *len = 3; return cp; }
+    }
+  } else if ((b0 & 0xf8u) == 0xf0u) {
+    if (avail >= 4 && u8_cont(b1) && u8_cont(b2) && u8_cont(b3)) {
+      uint32_t cp = ((b0 & 0x07u) << 18) + ((b1 & 0x3fu) << 12) + ((b2 & 0x3fu) << 6) + (b3 & 0x3fu);
+      if (cp >= 0x10000u && cp_ok(cp)) { *len = 4; return cp; }
+    }
+  }
+  return INVALID_CP;
+}
+
+__host__ __device__ inline bool cp_is_space(uint32_t ch) {  // utils.cpp:99-101; isspace() in the C locale
+  return (ch < 256u && (ch == 32u || (ch >= 9u && ch <= 13u))) || ch == 9601u;
+}
+
+// Sequential decode at byte offset i of text[0..n): used by the one-thread-per-segment front-end kernels.
+__device__ inline uint32_t u8_decode_at(const uint8_t *text, unsigned long long i, unsigned long long n, uint32_t *len) {
+  uint32_t b0 = text[i];
+  if (b0 < 0x80u) { *len = 1; return b0; }
+  unsigned long long avail = n - i;
+  uint32_t b1 = avail > 1 ? text[i + 1] : 0, b2 = avail > 2 ? text[i + 2] : 0, b3 = avail > 3 ? text[i + 3] : 0;
+  return u8_decode(b0, b1, b2, b3, avail, len);
+}
+
+// Is byte i the first byte of a char in the reference's left-to-right decode (utf8.cpp:111-128)?  Every
+// non-continuation byte is; a continuation byte is unless a VALID multi-byte char starting <= 3 bytes earlier covers it.
+__device__ inline bool u8_is_start(const uint8_t *text, unsigned long long i, unsigned long long n) {
+  uint32_t b = text[i];
+  if (!u8_cont(b)) return true;
+  for (uint32_t d = 1; d <= 3 && d <= i; d++) {
+    uint32_t c = text[i - d];
+    if (u8_cont(c)) continue;
+    // nearest non-continuation byte at distance d
+    uint32_t len;
+    uint32_t cp = u8_decode_at(text, i - d, n, &len);
+    return !(cp != INVALID_CP && len > d);
+  }
+  return true;
+}
+
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ inline unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// ---- wave / block scans (wave = 64 lanes; all lanes of the block must call) ---------------------------------------
+__device__ inline uint32_t wave_incl_scan(uint32_t v) {
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(v, o);
+    if (lane_id() >= o) v += t;
+  }
+  return v;
+}
+__device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;  // valid in lane 0
+}
+// exclusive scan over the BLOCK threads; lds = NWAVES words of scratch; *total = block sum
+__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *lds, uint32_t *total) {
+  uint32_t inc = wave_incl_scan(v);
+  int w = (int)(threadIdx.x >> 6);
+  if (lane_id() == 63) lds[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (int k = 0; k < NWAVES; k++) {
+    uint32_t s = lds[k];
+    if (k < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+}  // namespace yttm

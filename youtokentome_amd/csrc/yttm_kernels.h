@@ -1,0 +1,73 @@
+// yttm_kernels.h -- host-callable launchers of the gfx950 kernels (k_frontend.hip, k_merge.hip, k_encode.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "yttm_device.h"
+
+namespace yttm {
+
+constexpr int CAND_BINS = 704;  // counts 0..255 exact, then 8 bins per power of two
+
+struct CandRec {
+  unsigned long long key;  // x<<32|y
+  unsigned long long cnt;
+};
+
+// lower bound of a candidate-histogram bin (inverse of cand_bin in k_merge.hip)
+inline unsigned long long cand_bin_lower(int bin) {
+  if (bin < 256) return (unsigned long long)bin;
+  int e = 8 + (bin - 256) / 8, m3 = (bin - 256) % 8;
+  return (unsigned long long)(8 + m3) << (e - 3);
+}
+
+// ---- front end (k_frontend.hip)
+void launch_char_hist(const uint8_t *text, unsigned long long n, unsigned long long *hist, unsigned long long *counters, hipStream_t st);
+void launch_seg_write(const uint8_t *text, unsigned long long n, unsigned long long *seg_pos, unsigned long long *seg_cursor, hipStream_t st);
+void launch_hist_compact(const unsigned long long *hist, uint32_t *cps, unsigned long long *cnts, unsigned int *n_out, unsigned int cap,
+                         hipStream_t st);
+void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *seg_pos,
+                         unsigned long long n_segs, unsigned long long *ht_key, unsigned long long *ht_cnt, uint32_t *ht_len,
+                         unsigned long long ht_mask, unsigned int *status, hipStream_t st);
+void launch_compact_words(const unsigned long long *ht_key, const unsigned long long *ht_cnt, const uint32_t *ht_len,
+                          unsigned long long n_slots, unsigned long long *uw_pos, uint32_t *uw_cnt, uint32_t *uw_len,
+                          unsigned int *cursor, unsigned int *status, hipStream_t st);
+void launch_exclusive_scan(const uint32_t *in, unsigned long long n, unsigned long long *out, unsigned long long *block_sums,
+                           unsigned long long *total_out, hipStream_t st);
+unsigned long long scan_scratch_blocks(unsigned long long n);
+void launch_fill_tokens(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, uint32_t space_id,
+                        const unsigned long long *uw_pos, const unsigned long long *uw_off, unsigned int n_words, uint32_t *tok,
+                        hipStream_t st);
+void launch_tiles(const unsigned long long *uw_off, unsigned int n_words, unsigned long long *tile_start, uint32_t *tile_word0,
+                  hipStream_t st);
+void launch_tile_len(const unsigned long long *tile_start, unsigned int n_tiles, unsigned long long total_tokens, uint32_t *tile_len,
+                     hipStream_t st);
+
+// ---- merge loop (k_merge.hip)
+void launch_pair_count(const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st);
+void launch_merge_apply(const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
+                        const uint8_t *tokflag, uint32_t self_x, uint32_t self_z, unsigned long long *stats, hipStream_t st);
+void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
+                      unsigned int *n_out, unsigned long long *hist, hipStream_t st);
+void launch_pt_rehash(const PairTable &src, const PairTable &dst, hipStream_t st);
+void launch_pt_query(const PairTable &pt, const unsigned long long *keys, unsigned int n, unsigned long long *out, hipStream_t st);
+void launch_pt_apply(const PairTable &pt, const DeltaRec *recs, unsigned long long n, hipStream_t st);
+void launch_set_tokflag(uint8_t *tokflag, const uint32_t *upd, unsigned int n, hipStream_t st);
+void launch_fill_u64(unsigned long long *p, unsigned long long v, unsigned long long n, hipStream_t st);
+
+// ---- batch encode (k_encode.hip)
+struct EncModel {
+  const uint32_t *cpmap;      // [N_CODEPOINTS]: final token id, CP_SPACE, CP_UNK
+  const RuleSlot *rules;      // hash (x<<32|y) -> RuleSlot{z, pad = rule index = priority}
+  const uint32_t *rule_z;     // [n_rules] z of rule i
+  unsigned int rule_mask;
+  uint32_t space_id;
+  int unk_id, bos_id, eos_id;
+};
+void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long long *offsets, unsigned long long n_sent, int bos,
+                   int eos, int reverse, int32_t *scratch_ids, uint32_t *counts, uint32_t *work, unsigned long long work_stride,
+                   unsigned int max_blocks, hipStream_t st);
+void launch_encode_gather(const int32_t *scratch_ids, const unsigned long long *offsets, const unsigned long long *out_off,
+                          unsigned long long n_sent, int32_t *ids_out, hipStream_t st);
+
+}  // namespace yttm
