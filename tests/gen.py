@@ -14,12 +14,16 @@ def readme_corpus(n_lines=10000, n_chars=100, alphabet="abcd ", seed=19):
 
 
 def abcd_corpus(nbytes, seed=19, line=100, alphabet=b"abcd "):
-    """C2 / C4 family: uniform over the alphabet, `line` chars per row + newline (numpy default_rng)."""
+    """C2 / C4 family: uniform over the alphabet, `line` chars per row + newline (numpy default_rng, uint8 draws,
+    generated in row chunks so that 1 GB needs ~1 GB of host memory)."""
     rng = np.random.default_rng(seed)
     alpha = np.frombuffer(alphabet, dtype=np.uint8)
     nlines = max(1, nbytes // (line + 1))
     out = np.empty((nlines, line + 1), dtype=np.uint8)
-    out[:, :line] = alpha[rng.integers(0, len(alpha), size=(nlines, line))]
+    step = 1 << 20
+    for r0 in range(0, nlines, step):
+        r1 = min(nlines, r0 + step)
+        out[r0:r1, :line] = alpha[rng.integers(0, len(alpha), size=(r1 - r0, line), dtype=np.uint8)]
     out[:, line] = 10
     return out.tobytes()
 

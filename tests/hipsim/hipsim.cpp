@@ -1,7 +1,6 @@
 // tests/hipsim/hipsim.cpp -- fiber scheduler of the HIP emulator (TEST INFRASTRUCTURE ONLY; see the header).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#include <ucontext.h>
 
 #include <vector>
 
@@ -11,8 +10,34 @@ dim3 g_blockDim(1, 1, 1), g_gridDim(1, 1, 1);
 
 enum State { RUNNABLE, WAIT_BLOCK, WAIT_WAVE, DONE };
 enum WaveOp { OP_BALLOT, OP_SHFL, OP_BARRIER };
+// Minimal x86-64 System V context switch (callee-saved registers + stack pointer); ~100x cheaper than swapcontext,
+// which matters because every emulated GPU thread is a fiber.
+extern "C" void hipsim_swap(void **save_sp, void *new_sp);
+asm(R"(
+.text
+.globl hipsim_swap
+.type hipsim_swap,@function
+hipsim_swap:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipsim_swap,.-hipsim_swap
+)");
+
 struct Fiber {
-  ucontext_t ctx;
+  void *sp = nullptr;
   char *stack = nullptr;
   State state = DONE;
   unsigned tid = 0;
@@ -22,17 +47,17 @@ struct Fiber {
   int src = 0;
 };
 static std::vector<Fiber> g_fibers;
-static ucontext_t g_sched;
+static void *g_sched_sp = nullptr;
 static Fiber *g_cur = nullptr;
 static const std::function<void()> *g_body = nullptr;
-static const size_t STACK = 256 * 1024;
+static const size_t STACK = 128 * 1024;
 
+static void yield_to_sched() { hipsim_swap(&g_cur->sp, g_sched_sp); }
 static void fiber_main() {
   (*g_body)();
   g_cur->state = DONE;
-  swapcontext(&g_cur->ctx, &g_sched);
+  for (;;) yield_to_sched();
 }
-static void yield_to_sched() { swapcontext(&g_cur->ctx, &g_sched); }
 
 void sync_block() {
   if (!g_cur) return;
@@ -57,11 +82,14 @@ static void run_block(unsigned nthreads) {
   for (unsigned t = 0; t < nthreads; t++) {
     Fiber &f = g_fibers[t];
     if (!f.stack) f.stack = (char *)malloc(STACK);
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = f.stack;
-    f.ctx.uc_stack.ss_size = STACK;
-    f.ctx.uc_link = &g_sched;
-    makecontext(&f.ctx, fiber_main, 0);
+    {
+      uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+      void **sp = (void **)top;
+      *--sp = nullptr;               // alignment slot: fiber_main starts with rsp = 8 (mod 16), as after a call
+      *--sp = (void *)fiber_main;    // return address popped by hipsim_swap's ret
+      for (int r = 0; r < 6; r++) *--sp = nullptr;  // rbp rbx r12 r13 r14 r15
+      f.sp = (void *)sp;
+    }
     f.state = RUNNABLE;
     f.tid = t;
   }
@@ -73,7 +101,7 @@ static void run_block(unsigned nthreads) {
       if (f.state != RUNNABLE) continue;
       g_cur = &f;
       g_threadIdx.x = f.tid;
-      swapcontext(&g_sched, &f.ctx);
+      hipsim_swap(&g_sched_sp, f.sp);
       progressed = true;
       if (f.state == DONE) done++;
     }

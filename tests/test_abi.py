@@ -1,0 +1,43 @@
+"""The C-ABI shared library loads and exports every symbol that include/*.h declares (no compute calls: no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "youtokentome_amd", "libyttm_mi355x.so")
+
+
+def declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(yttm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(LIB):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "youtokentome_amd", "csrc"), "-j8"], check=True, capture_output=True)
+    lib = ctypes.CDLL(LIB)
+    names = declared("yttm_mi355x.h") + declared("yttm_gpu.h")
+    assert len(names) > 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_binding_lists_the_same_symbols():
+    from youtokentome_amd import _lib
+    names = set(declared("yttm_mi355x.h") + declared("yttm_gpu.h"))
+    assert names <= set(_lib.EXPORTS) | {"yttm_comm_rccl_unique_id", "yttm_comm_rccl_create", "yttm_comm_destroy",
+                                         "yttm_train_bpe_from_device_comm", "yttm_comm_callback_create"}
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a GPU the product must fail loudly, never fall back to a CPU path."""
+    if os.path.exists("/dev/kfd"):
+        return
+    code = ("import os,sys; os.environ.pop('YTTM_AMD_LIB',None); sys.path.insert(0,%r); import youtokentome_amd as y;\n"
+            "open('/tmp/_abi_t.txt','w').write('aa bb ab')\n"
+            "try:\n    y.BPE.train('/tmp/_abi_t.txt','/tmp/_abi_t.model',20)\n    print('TRAINED')\nexcept ValueError as e:\n    print('ERR', e)\n" % ROOT)
+    r = subprocess.run(["python", "-c", code], capture_output=True, text=True)
+    assert "TRAINED" not in r.stdout
+    assert "ERR" in r.stdout and "GPU" in r.stdout

@@ -1,0 +1,170 @@
+"""Parity tests proper: the HIP path on a real MI355X, through the C ABI, against the oracle (bit exact), the committed
+golden fixtures, the unmodified reference binaries (oracle/_ref, when present) and size-independent properties."""
+import filecmp
+import os
+import random
+
+import numpy as np
+import pytest
+
+import gen
+import oracle_lib as O
+import refbin
+import stage_checks as S
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_is_gfx950():
+    from youtokentome_amd import _lib
+    rc, info = _lib.device_info(0)
+    assert rc == 0, info
+    assert "gfx950" in info, info
+
+
+def test_k1_char_hist():
+    for t in S.texts_small(0, n=8, size=20000) + [gen.readme_corpus(3000, 100), gen.zipf_corpus(300000, vocab=5000)]:
+        S.check_char_hist(t)
+
+
+def test_k2_k3_word_table_and_pair_count():
+    for i, t in enumerate(S.texts_small(1, n=8, size=20000)):
+        S.check_word_table_and_pairs(t, coverage=1.0 if i % 2 == 0 else 0.9)
+    S.check_word_table_and_pairs(gen.readme_corpus(3000, 100, seed=3))
+    S.check_word_table_and_pairs(gen.zipf_corpus(400000, vocab=8000))
+
+
+def test_k4_merge_apply_rounds():
+    for i, t in enumerate(S.texts_small(2, n=6, size=8000)):
+        if t.strip():
+            S.check_merge_rounds(t, rounds=8, seed=i)
+    S.check_merge_rounds(gen.readme_corpus(1500, 100, seed=9), rounds=25, seed=3)
+    t = ("aaaa aaaaa aaaaaaa abababab aabbaabb abcabcabc bbbbbb ab aaab baaa " + "a" * 700 + " " + "ab" * 500 + " ") * 3
+    S.check_merge_rounds(t.encode(), rounds=14, seed=1)
+
+
+@pytest.mark.parametrize("name", S.golden_train_names())
+def test_golden_train(name, tmp_path):
+    S.check_golden_train(name, tmp_path)
+
+
+@pytest.mark.parametrize("name", S.golden_encode_names())
+def test_golden_encode(name):
+    S.check_golden_encode(name)
+
+
+def test_train_encode_vs_oracle_random(tmp_path):
+    rng = random.Random(5)
+    layouts = [(0, 1, 2, 3), (-1, 0, -1, -1), (5, 7, -1, 2), (3, 2, 1, 0), (0, 40, 29, 35)]
+    for it in range(30):
+        kind = rng.choice(list(gen.UNICODE_ALPHABETS))
+        inv = it % 3 == 0
+        text = gen.unicode_text(rng, rng.randint(200, 20000), kind, p_invalid=0.02 if inv else 0.0)
+        cov = rng.choice([0.9, 0.7, 0.99]) if inv else rng.choice([1.0, 1.0, 0.95])
+        model = S.check_train_vs_oracle(text, rng.randint(45, 300), tmp_path, cov, layouts[it % 5], tag=f"r{it}")
+        if model:
+            sents = [gen.unicode_text(rng, rng.randint(0, 200), kind, p_invalid=0.01).decode(errors="ignore").replace("\n", " ")
+                     for _ in range(100)] + ["", "  "]
+            S.check_encode_vs_oracle(model, sents)
+
+
+def test_stress_texts_vs_oracle(tmp_path):
+    rng = random.Random(77)
+    for it in range(60):
+        text = gen.stress_text(rng, 1000, True).encode()
+        vocab = len(set(text.decode()) | {" "}) + 4 + rng.randint(0, 40)
+        cov = 1.0 if rng.randint(0, 1) == 0 else 1 - rng.random() * 0.4
+        model = S.check_train_vs_oracle(text, vocab, tmp_path, cov, tag=f"s{it}")
+        if model:
+            S.check_encode_vs_oracle(model, [gen.stress_text(rng, 1000, False) for _ in range(4)], flags=((0, 0, 0),))
+
+
+def test_config_errors(tmp_path):
+    for kw in [dict(coverage=0.0), dict(coverage=1.5), dict(ids=(0, 300, 2, 3)), dict(ids=(0, 1, 1, 3)), dict(ids=(-2, 1, 2, 3)),
+               dict(vocab=5)]:
+        S.check_train_vs_oracle(b"aaa bbb abab", kw.get("vocab", 50), tmp_path, kw.get("coverage", 1.0), kw.get("ids", (0, 1, 2, 3)), tag="e")
+
+
+def test_c1_readme_corpus_full(tmp_path):
+    """BASELINE.json configs[0]: 10k lines x 100 chars over 'abcd ', vocab 5000 (tests/unit_tests/utils_for_testing.py:23-36)."""
+    text = gen.readme_corpus()
+    model = S.check_train_vs_oracle(text, 5000, tmp_path, tag="c1")
+    sents = [ln.decode() for ln in gen.readme_corpus(3000, 100, "abcde ", seed=4).split(b"\n") if ln]
+    S.check_encode_vs_oracle(model, sents)
+
+
+def test_zipf_corpus_vs_oracle(tmp_path):
+    text = gen.zipf_corpus(3_000_000, vocab=30000)
+    model = S.check_train_vs_oracle(text, 6000, tmp_path, tag="z")
+    sents = [ln.decode() for ln in gen.zipf_corpus(200000, seed=11, vocab=30000).split(b"\n") if ln]
+    S.check_encode_vs_oracle(model, sents, flags=((0, 0, 0), (1, 1, 1)))
+
+
+def test_long_words_and_long_sentences(tmp_path):
+    rng = random.Random(3)
+    words = ["".join(rng.choice("abc") for _ in range(n)) for n in (2046, 1500, 1024, 700, 65, 64, 63, 1)]
+    text = (" ".join(words) + "\n") * 3 + gen.readme_corpus(50, 80).decode()
+    model = S.check_train_vs_oracle(text.encode(), 200, tmp_path, tag="lw")
+    # sentences longer than the LDS budget of the encode kernel take its HBM-scratch path
+    sents = [" ".join(words), "ab" * 3000, ("abc " * 2000).strip(), "a"]
+    S.check_encode_vs_oracle(model, sents)
+
+
+def test_word_too_long_is_a_loud_error(tmp_path):
+    import youtokentome_amd as yttm
+    p = str(tmp_path / "long.txt")
+    open(p, "w").write("a" * 5000 + " b c\n")
+    with pytest.raises(ValueError) as e:
+        yttm.BPE.train(p, str(tmp_path / "long.model"), 50)
+    assert "longer than" in str(e.value)
+
+
+@pytest.mark.skipif(not refbin.available("det"), reason="oracle/_ref not present")
+def test_medium_corpus_vs_reference_binary(tmp_path):
+    """30 MB 'abcd ' corpus, vocab 8000: too big for the oracle's comfort, checked against the unmodified reference
+    (-DDETERMINISTIC_QUEUE) running on the host cores."""
+    import youtokentome_amd as yttm
+    text = gen.abcd_corpus(30_000_000, seed=21)
+    corpus = str(tmp_path / "m.txt")
+    open(corpus, "wb").write(text)
+    m_gpu, m_ref = str(tmp_path / "gpu.model"), str(tmp_path / "ref.model")
+    yttm.BPE.train(corpus, m_gpu, 8000)
+    refbin.train(corpus, m_ref, 8000, n_threads=8, kind="det")
+    assert filecmp.cmp(m_gpu, m_ref, shallow=False)
+    # encode 200k sentences: ids identical to the reference encoder
+    lines = str(tmp_path / "enc.txt")
+    sent_bytes = gen.abcd_corpus(200_000 * 129, seed=5, line=128)
+    open(lines, "wb").write(sent_bytes)
+    want = refbin.encode_bench(m_ref, lines, n_threads=8)
+    bpe = yttm.BPE(m_gpu)
+    offs = np.arange(200_001, dtype=np.uint64) * 129
+    ids, off = bpe.bpe_cython.encode_packed(sent_bytes, offs)
+    assert len(ids) == want["ids"]
+    import bench
+    assert bench._fnv(ids, off) == want["fnv1a64"]
+
+
+def test_encode_properties_at_scale(tmp_path):
+    """Size-independent properties on 1M sentences: batch == sum of chunks, decode(encode(x)) == normalised x,
+    reverse == reversed, bos/eos only add the two ids."""
+    import youtokentome_amd as yttm
+    text = gen.readme_corpus(5000, 100)
+    corpus = str(tmp_path / "p.txt")
+    open(corpus, "wb").write(text)
+    bpe = yttm.BPE.train(corpus, str(tmp_path / "p.model"), 3000)
+    n = 1_000_000
+    blob = gen.abcd_corpus(n * 65, seed=8, line=64)
+    offs = np.arange(n + 1, dtype=np.uint64) * 65
+    core = bpe.bpe_cython
+    ids, off = core.encode_packed(blob, offs)
+    ids2, off2 = core.encode_packed(blob, offs, bos=True, eos=True, reverse=True)
+    assert len(ids2) == len(ids) + 2 * n
+    k = 200_000
+    part_ids, part_off = core.encode_packed(blob[: k * 65], offs[: k + 1])
+    assert np.array_equal(part_ids, ids[: int(off[k])]) and np.array_equal(part_off, off[: k + 1])
+    for i in (0, 1, 999_999, 123_456):
+        a, b = int(off[i]), int(off[i + 1])
+        a2, b2 = int(off2[i]), int(off2[i + 1])
+        assert ids2[a2:b2].tolist() == [3] + ids[a:b].tolist()[::-1] + [2]
+        sent = blob[i * 65:(i + 1) * 65].decode()
+        assert bpe.decode([ids[a:b].tolist()])[0] == " ".join(sent.split())

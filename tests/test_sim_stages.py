@@ -1,0 +1,67 @@
+"""Kernel-logic tests on GPU-less machines: the UNMODIFIED product sources (youtokentome_amd/csrc) built against the
+HIP emulator (tests/hipsim), driven through the same C ABI and checked against the oracle / golden fixtures.
+(The parity tests proper are tests/test_gpu_parity.py, -m gpu, on a real MI355X.)"""
+import random
+
+import pytest
+
+import gen
+import stage_checks as S
+
+pytestmark = pytest.mark.usefixtures("sim_lib")
+
+
+def test_char_hist():
+    for t in S.texts_small(0, n=4, size=1500) + [gen.readme_corpus(100, 100)]:
+        S.check_char_hist(t)
+
+
+def test_word_table_and_pair_count():
+    for i, t in enumerate(S.texts_small(1, n=4, size=2000)):
+        S.check_word_table_and_pairs(t, coverage=1.0 if i % 2 == 0 else 0.9)
+
+
+def test_word_table_multi_tile():
+    S.check_word_table_and_pairs(gen.readme_corpus(150, 100, seed=3))  # ~10k dedup tokens: several tiles
+
+
+def test_merge_apply_rounds():
+    for i, t in enumerate(S.texts_small(2, n=3, size=1500)):
+        if t.strip():
+            S.check_merge_rounds(t, rounds=5, seed=i)
+
+
+def test_merge_apply_runs():
+    t = ("aaaa aaaaa aaaaaaa abababab aabbaabb abcabcabc bbbbbb ab aaab baaa aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa " * 3).encode()
+    S.check_merge_rounds(t, rounds=12, seed=1)
+
+
+@pytest.mark.parametrize("name", S.golden_train_names())
+def test_golden_train(name, tmp_path):
+    S.check_golden_train(name, tmp_path)
+
+
+@pytest.mark.parametrize("name", S.golden_encode_names())
+def test_golden_encode(name):
+    S.check_golden_encode(name)
+
+
+def test_train_encode_vs_oracle_random(tmp_path):
+    rng = random.Random(5)
+    layouts = [(0, 1, 2, 3), (-1, 0, -1, -1), (5, 7, -1, 2), (3, 2, 1, 0)]
+    for it in range(6):
+        kind = rng.choice(list(gen.UNICODE_ALPHABETS))
+        text = gen.unicode_text(rng, rng.randint(200, 2500), kind, p_invalid=0.02 if it % 3 == 0 else 0.0)
+        cov = rng.choice([1.0, 0.9, 0.7]) if it % 3 == 0 else rng.choice([1.0, 1.0, 0.95])
+        ids = layouts[it % 4]
+        if cov == 1.0 and it % 3 == 0:
+            cov = 0.9  # invalid bytes + coverage 1 would crash the reference; both drop them here anyway
+        model = S.check_train_vs_oracle(text, rng.randint(40, 90), tmp_path, cov, ids, tag=f"r{it}")
+        if model:
+            sents = [gen.unicode_text(rng, rng.randint(0, 60), kind).decode().replace("\n", " ") for _ in range(20)] + ["", "  "]
+            S.check_encode_vs_oracle(model, sents)
+
+
+def test_config_errors(tmp_path):
+    for kw in [dict(coverage=0.0), dict(ids=(0, 300, 2, 3)), dict(ids=(0, 1, 1, 3)), dict(vocab=5)]:
+        S.check_train_vs_oracle(b"aaa bbb abab", kw.get("vocab", 50), tmp_path, kw.get("coverage", 1.0), kw.get("ids", (0, 1, 2, 3)), tag="e")

@@ -79,6 +79,14 @@ void GpuCtx::t_end(int which, unsigned long long bytes) {
 }
 void GpuCtx::resolve_timers() {
   sync();
+  {
+    // K4 traffic: every pass streams the live tokens once (4 B each) and rewrites the tiles that had a merge site
+    unsigned long long st[8] = {0};
+    if (hipMemcpy(st, d_stats_, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
+      merge_sites = st[0];
+      kt.bytes[KT_MERGE] = 4 * st[2] + 4 * st[3];
+    }
+  }
   for (auto &e : evs_) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) kt.ms[e.which] += ms;

@@ -172,7 +172,7 @@ struct MergeLds {
 __global__ __launch_bounds__(BLOCK) void k4_merge_apply(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
                                                         unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                         uint32_t self_x, uint32_t self_z,
-                                                        unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched */) {
+                                                        unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
   __shared__ MergeLds M;
   TileLds &L = M.t;
   agg_init(L);
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(BLOCK) void k4_merge_apply(TileSet ts, PairTable pt
       }
     }
     __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)n);
     if (!M.any_site) {
       __syncthreads();  // keep any_site stable until everyone has read it
       continue;
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k4_merge_apply(TileSet ts, PairTable pt
     if (threadIdx.x == 0) {
       ts.tile_len[t] = M.new_len;
       atomicAdd(&stats[1], 1ull);
+      atomicAdd(&stats[3], (unsigned long long)n);
     }
     my_sites = wave_sum_u64(my_sites);
     if (lane == 0 && my_sites) atomicAdd(&stats[0], my_sites);
