@@ -65,3 +65,13 @@ def test_train_encode_vs_oracle_random(tmp_path):
 def test_config_errors(tmp_path):
     for kw in [dict(coverage=0.0), dict(ids=(0, 300, 2, 3)), dict(ids=(0, 1, 1, 3)), dict(vocab=5)]:
         S.check_train_vs_oracle(b"aaa bbb abab", kw.get("vocab", 50), tmp_path, kw.get("coverage", 1.0), kw.get("ids", (0, 1, 2, 3)), tag="e")
+
+
+def test_long_words_class_b(tmp_path):
+    """words of 513..2047 chars live in the second tile class (slot 4096, one wave per workgroup)"""
+    rng = random.Random(3)
+    words = ["".join(rng.choice("abc") for _ in range(n)) for n in (2046, 1500, 700, 513, 512, 511, 65, 64, 63, 1)]
+    text = (" ".join(words) + "\n") * 2 + "ab abc aabb\n"
+    S.check_merge_rounds(text.encode(), rounds=6, seed=2)
+    model = S.check_train_vs_oracle(text.encode(), 60, tmp_path, tag="lw")
+    S.check_encode_vs_oracle(model, [" ".join(words[2:]), "ab" * 700, "a"], flags=((0, 0, 0), (1, 1, 1)))

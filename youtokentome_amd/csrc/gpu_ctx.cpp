@@ -49,8 +49,8 @@ GpuCtx::~GpuCtx() {
   (void)hipSetDevice(device_);
   (void)hipStreamSynchronize(st_);
   for (auto &e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_tok_); DFREE(d_tile_start_);
-  DFREE(d_tile_len_); DFREE(d_tile_word0_); DFREE(d_wcnt_); DFREE(d_uw_off_); DFREE(d_rules_); DFREE(d_tokflag_);
+  DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_);
+  free_class(cls_[0]); free_class(cls_[1]);
   DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_cand_); DFREE(d_cand_n_); DFREE(d_cand_hist_); DFREE(d_recv_);
   if (db_.recs) (void)hipFree(db_.recs);
   if (db_.n) (void)hipFree(db_.n);
@@ -170,10 +170,11 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
     HIP_CHECK(hipMemcpyAsync(d_cpmap_, cpmap.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, st_));
     sync();
   }
-  DFREE(d_tok_); DFREE(d_tile_start_); DFREE(d_tile_len_); DFREE(d_tile_word0_); DFREE(d_wcnt_);
+  free_class(cls_[0]); free_class(cls_[1]);
+  cls_[0].nom = TILE_NOM_A; cls_[0].slot = TILE_SLOT_A;
+  cls_[1].nom = TILE_NOM_B; cls_[1].slot = TILE_SLOT_B;
   n_alpha_ = n_alpha;
   n_unique = 0; n_tokens0 = 0; n_tiles = 0;
-  ts_ = TileSet{};
   tokflag_cap_ = n_ids_cap + 64;
   DFREE(d_tokflag_);
   d_tokflag_ = dmalloc<uint8_t>(tokflag_cap_);
@@ -208,23 +209,44 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   DFREE(d_seg);
   if (h_status[1] & 1u) {
     DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len);
-    throw GpuError{"a word longer than " + std::to_string(TILE_TOK - 1) + " characters is not supported by the tile kernels yet"};
+    throw GpuError{"a word longer than " + std::to_string(MAX_WORD_TOKENS - 1) + " characters is not supported by the tile kernels yet"};
   }
-  const unsigned int U = h_status[0];
+  const unsigned int U = h_status[0], UB = h_status[2], UA = U - UB;
   n_unique = U;
   if (U == 0) { DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len); return; }
-  unsigned long long *uw_pos = dmalloc<unsigned long long>(U);
-  uint32_t *uw_len = dmalloc<uint32_t>(U);
-  d_wcnt_ = dmalloc<uint32_t>(U);
+  unsigned long long *posA = dmalloc<unsigned long long>(UA), *posB = dmalloc<unsigned long long>(UB);
+  uint32_t *lenA = dmalloc<uint32_t>(UA), *lenB = dmalloc<uint32_t>(UB);
+  cls_[0].d_wcnt = dmalloc<uint32_t>(UA);
+  cls_[1].d_wcnt = dmalloc<uint32_t>(UB);
   unsigned int *d_cursor = (unsigned int *)(d_counters_ + 32);
-  HIP_CHECK(hipMemsetAsync(d_cursor, 0, 4, st_));
+  HIP_CHECK(hipMemsetAsync(d_cursor, 0, 8, st_));
   t_begin(KT_BUILD);
-  launch_compact_words(ht_key, ht_cnt, ht_len, ht_cap, uw_pos, d_wcnt_, uw_len, d_cursor, d_status, st_);
+  launch_compact_words(ht_key, ht_cnt, ht_len, ht_cap, posA, cls_[0].d_wcnt, lenA, posB, cls_[1].d_wcnt, lenB, d_cursor, d_status, st_);
   HIP_CHECK(hipMemcpyAsync(h_status, d_status, 16, hipMemcpyDeviceToHost, st_));
   sync();
   DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len);
-  if (h_status[1] & 2u) { DFREE(uw_pos); DFREE(uw_len); throw GpuError{"a word occurs >= 2^32 times (uint32 word weights)"}; }
-  // token offsets
+  if (h_status[1] & 2u) { DFREE(posA); DFREE(posB); DFREE(lenA); DFREE(lenB); throw GpuError{"a word occurs >= 2^32 times (uint32 word weights)"}; }
+  build_class(0, posA, lenA, UA, space_id);
+  build_class(1, posB, lenB, UB, space_id);
+  t_end(KT_BUILD, n_text_ / 8 + 4 * (cls_[0].n_tokens0 + cls_[1].n_tokens0) + 16ull * U);
+  sync();
+  DFREE(posA); DFREE(posB); DFREE(lenA); DFREE(lenB);
+  n_tokens0 = cls_[0].n_tokens0 + cls_[1].n_tokens0;
+  n_tiles = cls_[0].n_tiles + cls_[1].n_tiles;
+}
+
+void GpuCtx::free_class(WordClass &c) {
+  DFREE(c.d_tok); DFREE(c.d_tile_len); DFREE(c.d_tile_word0); DFREE(c.d_wcnt);
+  c.ts = TileSet{};
+  c.n_unique = c.n_tokens0 = 0;
+  c.n_tiles = 0;
+}
+
+// offsets -> tiles -> token slots for one class of unique words
+void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, unsigned int U, uint32_t space_id) {
+  WordClass &c = cls_[ci];
+  c.n_unique = U;
+  if (U == 0) return;
   unsigned long long *uw_off = dmalloc<unsigned long long>(U);
   unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(U));
   launch_exclusive_scan(uw_len, U, uw_off, scan_tmp, d_counters_ + 40, st_);
@@ -233,46 +255,47 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   HIP_CHECK(hipMemcpyAsync(&last_off, uw_off + (U - 1), 8, hipMemcpyDeviceToHost, st_));
   sync();
   DFREE(scan_tmp);
-  n_tokens0 = total;
-  d_tok_ = dmalloc<uint32_t>(total + 64);
-  launch_fill_tokens(d_text_, n_text_, d_cpmap_, space_id, uw_pos, uw_off, U, d_tok_, st_);
-  n_tiles = (unsigned int)(last_off / TILE_TOK) + 1;
-  d_tile_start_ = dmalloc<unsigned long long>(n_tiles);
-  d_tile_word0_ = dmalloc<uint32_t>(n_tiles);
-  d_tile_len_ = dmalloc<uint32_t>(n_tiles);
-  launch_tiles(uw_off, U, d_tile_start_, d_tile_word0_, st_);
-  launch_tile_len(d_tile_start_, n_tiles, total, d_tile_len_, st_);
-  t_end(KT_BUILD, n_text_ / 8 + 4 * total + 16ull * U);
+  c.n_tokens0 = total;
+  c.n_tiles = (unsigned int)(last_off / c.nom) + 1;
+  unsigned long long *tile_start = dmalloc<unsigned long long>(c.n_tiles);
+  c.d_tile_word0 = dmalloc<uint32_t>(c.n_tiles);
+  c.d_tile_len = dmalloc<uint32_t>(c.n_tiles);
+  c.d_tok = dmalloc<uint32_t>((size_t)c.n_tiles * c.slot + 64);
+  launch_tiles(uw_off, U, c.nom, tile_start, c.d_tile_word0, st_);
+  launch_tile_len(tile_start, c.n_tiles, total, c.d_tile_len, st_);
+  launch_fill_tokens(d_text_, n_text_, d_cpmap_, space_id, uw_pos, uw_off, U, c.nom, c.slot, tile_start, c.d_tok, st_);
   sync();
-  DFREE(uw_pos); DFREE(uw_len); DFREE(uw_off);
-  ts_.tok = d_tok_;
-  ts_.tile_start = d_tile_start_;
-  ts_.tile_len = d_tile_len_;
-  ts_.tile_word0 = d_tile_word0_;
-  ts_.wcnt = d_wcnt_;
-  ts_.n_tiles = n_tiles;
+  DFREE(uw_off);
+  DFREE(tile_start);
+  c.ts.tok = c.d_tok;
+  c.ts.tile_len = c.d_tile_len;
+  c.ts.tile_word0 = c.d_tile_word0;
+  c.ts.wcnt = c.d_wcnt;
+  c.ts.n_tiles = c.n_tiles;
 }
 
 void GpuCtx::download_word_table(std::vector<uint32_t> &tok, std::vector<unsigned long long> &off, std::vector<uint32_t> &cnt) {
   tok.clear(); off.clear(); cnt.clear();
   off.push_back(0);
-  if (!n_tiles) return;
-  std::vector<uint32_t> all(n_tokens0), tl(n_tiles), wc(n_unique);
-  std::vector<unsigned long long> tstart(n_tiles);
-  HIP_CHECK(hipMemcpyAsync(all.data(), d_tok_, n_tokens0 * 4, hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipMemcpyAsync(tl.data(), d_tile_len_, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipMemcpyAsync(tstart.data(), d_tile_start_, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipMemcpyAsync(wc.data(), d_wcnt_, (size_t)n_unique * 4, hipMemcpyDeviceToHost, st_));
-  sync();
-  for (unsigned int t = 0; t < n_tiles; t++) {
-    for (uint32_t p = 0; p < tl[t]; p++) {
-      uint32_t v = all[tstart[t] + p];
-      if ((v & TOK_WS) && !tok.empty()) off.push_back(tok.size());
-      tok.push_back(v & TOK_MASK);
+  for (int ci = 0; ci < 2; ci++) {
+    WordClass &c = cls_[ci];
+    if (!c.n_tiles) continue;
+    std::vector<uint32_t> all((size_t)c.n_tiles * c.slot), tl(c.n_tiles), wc(c.n_unique);
+    HIP_CHECK(hipMemcpyAsync(all.data(), c.d_tok, all.size() * 4, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipMemcpyAsync(tl.data(), c.d_tile_len, (size_t)c.n_tiles * 4, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipMemcpyAsync(wc.data(), c.d_wcnt, (size_t)c.n_unique * 4, hipMemcpyDeviceToHost, st_));
+    sync();
+    for (unsigned int t = 0; t < c.n_tiles; t++) {
+      for (uint32_t p = 0; p < tl[t]; p++) {
+        uint32_t v = all[(size_t)t * c.slot + p];
+        if ((v & TOK_WS) && !tok.empty()) off.push_back(tok.size());
+        tok.push_back(v & TOK_MASK);
+      }
     }
+    cnt.insert(cnt.end(), wc.begin(), wc.end());
   }
   off.push_back(tok.size());
-  cnt = wc;
+  if (tok.empty()) { off.assign(1, 0); }
 }
 
 // ------------------------------------------------------------------------------------------------- pair table
@@ -351,7 +374,7 @@ void GpuCtx::pair_count() {
   }
   ensure_table_capacity(bound);
   t_begin(KT_PAIR_COUNT);
-  launch_pair_count(ts_, pt_, db_, st_);
+  for (int ci = 0; ci < 2; ci++) launch_pair_count(ci, cls_[ci].ts, pt_, db_, st_);
   t_end(KT_PAIR_COUNT, 4 * n_tokens0 + 8 * n_unique);
   unsigned int nk = 0;
   HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
@@ -477,7 +500,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     launch_set_tokflag(d_tokflag_, d_flag_upd_, n_upd, st_);
   }
   t_begin(KT_MERGE);
-  launch_merge_apply(ts_, pt_, db_, d_rules_, cap - 1, d_tokflag_, self_x, self_z, d_stats_, st_);
+  for (int ci = 0; ci < 2; ci++) launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, self_x, self_z, d_stats_, st_);
   t_end(KT_MERGE, 0);
   merge_rounds++;
   unsigned int nk = 0;

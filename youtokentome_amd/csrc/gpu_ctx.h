@@ -93,12 +93,16 @@ class GpuCtx {
   // K2
   uint32_t *d_cpmap_ = nullptr;  // [N_CODEPOINTS]
   uint32_t n_alpha_ = 0;
-  // token tiles
-  TileSet ts_{};
-  uint32_t *d_tok_ = nullptr;
-  unsigned long long *d_tile_start_ = nullptr;
-  uint32_t *d_tile_len_ = nullptr, *d_tile_word0_ = nullptr, *d_wcnt_ = nullptr;
-  unsigned long long *d_uw_off_ = nullptr;  // kept for download_word_table (initial layout)
+  // token tiles: class 0 = short words (slot 1024), class 1 = long words (slot 4096)
+  struct WordClass {
+    TileSet ts{};
+    uint32_t *d_tok = nullptr, *d_tile_len = nullptr, *d_tile_word0 = nullptr, *d_wcnt = nullptr;
+    unsigned long long n_unique = 0, n_tokens0 = 0;
+    unsigned int n_tiles = 0, nom = 0, slot = 0;
+  };
+  WordClass cls_[2];
+  void free_class(WordClass &c);
+  void build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, unsigned int U, uint32_t space_id);
   // pair table
   PairTable pt_{};
   unsigned long long pt_cap_ = 0;

@@ -15,11 +15,6 @@ constexpr int ENC_WCAP = 1024;               // tokens per wave held in LDS
 constexpr uint32_t ENC_UNKP = 0x7ffffff0u;   // placeholder token for a run of unknown chars (bpe.cpp:1517-1527)
 constexpr uint32_t ENC_INF = 0xffffffffu;
 
-__device__ inline void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
 struct LdsArr {
   uint32_t *p;
   __device__ uint32_t get(int i) const { return p[i]; }

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
                                                           const unsigned long long *__restrict__ seg_pos, unsigned long long n_segs,
                                                           unsigned long long *__restrict__ ht_key, unsigned long long *__restrict__ ht_cnt,
                                                           uint32_t *__restrict__ ht_len, unsigned long long ht_mask,
-                                                          unsigned int *__restrict__ status /* [0]=n_unique [1]=too_long flag */) {
+                                                          unsigned int *__restrict__ status /* [0]=n_unique [1]=flags [2]=n_unique of class B */) {
   unsigned long long s = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
   for (; s < n_segs; s += stride) {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
     unsigned long long h;
     const uint32_t L = seg_scan(text, n, cpmap, pos, &h);
     if (L == 0) continue;  // segment made only of dropped chars: no word (bpe.cpp:357-380 deletes them first)
-    if (L + 1 > (uint32_t)TILE_TOK) { atomicOr(&status[1], 1u); continue; }
+    if (L + 1 > (uint32_t)MAX_WORD_TOKENS) { atomicOr(&status[1], 1u); continue; }
     const unsigned long long mine = ((h >> 40) << 40) | pos;
     const unsigned long long tag = h >> 40;
     unsigned long long i = h & ht_mask;
@@ -258,6 +258,7 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
           ht_len[i] = L + 1;  // + the leading "▁" token; read only by later kernels
           atomicAdd(&ht_cnt[i], 1ull);
           atomicAdd(&status[0], 1u);
+          if (L + 1 > (uint32_t)TILE_NOM_A) atomicAdd(&status[2], 1u);
           break;
         }
       }
@@ -270,12 +271,15 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
   }
 }
 
-// Compact occupied hash slots into the unique-word arrays (block-aggregated append; order is not significant).
+// Compact occupied hash slots into the unique-word arrays of the two tile classes (short words: block-aggregated
+// append; long words are rare: one atomic each).  Order is not significant.
 __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const unsigned long long *__restrict__ ht_key,
                                                            const unsigned long long *__restrict__ ht_cnt,
                                                            const uint32_t *__restrict__ ht_len, unsigned long long n_slots,
-                                                           unsigned long long *__restrict__ uw_pos, uint32_t *__restrict__ uw_cnt,
-                                                           uint32_t *__restrict__ uw_len, unsigned int *__restrict__ cursor,
+                                                           unsigned long long *__restrict__ posA, uint32_t *__restrict__ cntA,
+                                                           uint32_t *__restrict__ lenA, unsigned long long *__restrict__ posB,
+                                                           uint32_t *__restrict__ cntB, uint32_t *__restrict__ lenB,
+                                                           unsigned int *__restrict__ cursor /* [0]=A [1]=B */,
                                                            unsigned int *__restrict__ status) {
   __shared__ uint32_t scan_lds[NWAVES];
   __shared__ unsigned int blk_base;
@@ -283,18 +287,24 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const unsigned long l
   for (unsigned long long it = blockIdx.x; it < n_iter; it += gridDim.x) {
     unsigned long long i = it * BLOCK + threadIdx.x;
     unsigned long long k = i < n_slots ? ht_key[i] : PT_EMPTY;
-    uint32_t has = k != PT_EMPTY;
+    const bool has = k != PT_EMPTY;
+    const uint32_t len = has ? ht_len[i] : 0;
+    const bool isB = has && len > (uint32_t)TILE_NOM_A;
+    const uint32_t hasA = has && !isB;
     uint32_t total;
-    uint32_t off = block_excl_scan(has, scan_lds, &total);
-    if (threadIdx.x == 0) blk_base = total ? atomicAdd(cursor, total) : 0u;
+    uint32_t off = block_excl_scan(hasA, scan_lds, &total);
+    if (threadIdx.x == 0) blk_base = total ? atomicAdd(&cursor[0], total) : 0u;
     __syncthreads();
     if (has) {
-      unsigned int o = blk_base + off;
       unsigned long long c = ht_cnt[i];
       if (c > 0xffffffffull) atomicOr(&status[1], 2u);  // a word seen >= 2^32 times: weights are uint32
-      uw_pos[o] = k & WH_POS_MASK;
-      uw_cnt[o] = (uint32_t)c;
-      uw_len[o] = ht_len[i];
+      if (isB) {
+        unsigned int o = atomicAdd(&cursor[1], 1u);
+        posB[o] = k & WH_POS_MASK; cntB[o] = (uint32_t)c; lenB[o] = len;
+      } else {
+        unsigned int o = blk_base + off;
+        posA[o] = k & WH_POS_MASK; cntA[o] = (uint32_t)c; lenA[o] = len;
+      }
     }
     __syncthreads();
   }
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t *__restrict
     v[j] = i < n ? in[i] : 0;
     s += v[j];
   }
-  // per-thread sums are < 2^32 because word lengths are <= TILE_TOK
+  // per-thread sums are < 2^32 because word lengths are <= MAX_WORD_TOKENS
   uint32_t total;
   uint32_t off = block_excl_scan(s, scan_lds, &total);
   unsigned long long run = block_sums[blockIdx.x] + off;
@@ -374,36 +384,14 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t *__restrict
   }
 }
 
-// Write the token stream: word u = [space_id|TOK_WS, id(c1), id(c2), ...]  (bpe.cpp:406-411)
-__global__ __launch_bounds__(BLOCK) void k2e_fill_tokens(const uint8_t *__restrict__ text, unsigned long long n,
-                                                         const uint32_t *__restrict__ cpmap, uint32_t space_id,
-                                                         const unsigned long long *__restrict__ uw_pos,
-                                                         const unsigned long long *__restrict__ uw_off, unsigned int n_words,
-                                                         uint32_t *__restrict__ tok) {
-  unsigned int u = blockIdx.x * BLOCK + threadIdx.x;
-  if (u >= n_words) return;
-  unsigned long long i = uw_pos[u];
-  unsigned long long o = uw_off[u];
-  tok[o++] = space_id | TOK_WS;
-  while (i < n) {
-    uint32_t len;
-    uint32_t cp = u8_decode_at(text, i, n, &len);
-    if (cp != INVALID_CP) {
-      uint32_t id = cpmap[cp];
-      if (id == CP_SPACE) break;
-      if (id != CP_DROP) tok[o++] = id;
-    }
-    i += len;
-  }
-}
-
-// Tiles: word u belongs to tile uw_off[u] / TILE_TOK; the first word of each tile records the tile start.
-__global__ __launch_bounds__(BLOCK) void k2f_tiles(const unsigned long long *__restrict__ uw_off, unsigned int n_words,
+// Write the token tiles: word u = [space_id|TOK_WS, id(c1), id(c2), ...]  (bpe.cpp:406-411) at its place in the slot
+// of its tile.  Word u belongs to tile uw_off[u] / nom; the first word of each tile records the tile start.
+__global__ __launch_bounds__(BLOCK) void k2f_tiles(const unsigned long long *__restrict__ uw_off, unsigned int n_words, unsigned int nom,
                                                    unsigned long long *__restrict__ tile_start, uint32_t *__restrict__ tile_word0) {
   unsigned int u = blockIdx.x * BLOCK + threadIdx.x;
   if (u >= n_words) return;
-  unsigned long long t = uw_off[u] / TILE_TOK;
-  if (u == 0 || uw_off[u - 1] / TILE_TOK != t) {
+  unsigned long long t = uw_off[u] / nom;
+  if (u == 0 || uw_off[u - 1] / nom != t) {
     tile_start[t] = uw_off[u];
     tile_word0[t] = u;
   }
@@ -415,6 +403,30 @@ __global__ __launch_bounds__(BLOCK) void k2g_tile_len(const unsigned long long *
   if (t >= n_tiles) return;
   unsigned long long e = (t + 1 < n_tiles) ? tile_start[t + 1] : total_tokens;
   tile_len[t] = (uint32_t)(e - tile_start[t]);
+}
+
+__global__ __launch_bounds__(BLOCK) void k2e_fill_tokens(const uint8_t *__restrict__ text, unsigned long long n,
+                                                         const uint32_t *__restrict__ cpmap, uint32_t space_id,
+                                                         const unsigned long long *__restrict__ uw_pos,
+                                                         const unsigned long long *__restrict__ uw_off, unsigned int n_words,
+                                                         unsigned int nom, unsigned int slot,
+                                                         const unsigned long long *__restrict__ tile_start, uint32_t *__restrict__ tok) {
+  unsigned int u = blockIdx.x * BLOCK + threadIdx.x;
+  if (u >= n_words) return;
+  unsigned long long i = uw_pos[u];
+  const unsigned long long t = uw_off[u] / nom;
+  unsigned long long o = t * slot + (uw_off[u] - tile_start[t]);
+  tok[o++] = space_id | TOK_WS;
+  while (i < n) {
+    uint32_t len;
+    uint32_t cp = u8_decode_at(text, i, n, &len);
+    if (cp != INVALID_CP) {
+      uint32_t id = cpmap[cp];
+      if (id == CP_SPACE) break;
+      if (id != CP_DROP) tok[o++] = id;
+    }
+    i += len;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------- launchers
@@ -449,10 +461,10 @@ void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32
                      ht_mask, status);
 }
 void launch_compact_words(const unsigned long long *ht_key, const unsigned long long *ht_cnt, const uint32_t *ht_len,
-                          unsigned long long n_slots, unsigned long long *uw_pos, uint32_t *uw_cnt, uint32_t *uw_len,
-                          unsigned int *cursor, unsigned int *status, hipStream_t st) {
+                          unsigned long long n_slots, unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB,
+                          uint32_t *cntB, uint32_t *lenB, unsigned int *cursor, unsigned int *status, hipStream_t st) {
   unsigned int g = grid_for(n_slots, BLOCK, 256 * 16);
-  hipLaunchKernelGGL(k2c_compact_words, dim3(g), dim3(BLOCK), 0, st, ht_key, ht_cnt, ht_len, n_slots, uw_pos, uw_cnt, uw_len,
+  hipLaunchKernelGGL(k2c_compact_words, dim3(g), dim3(BLOCK), 0, st, ht_key, ht_cnt, ht_len, n_slots, posA, cntA, lenA, posB, cntB, lenB,
                      cursor, status);
 }
 void launch_exclusive_scan(const uint32_t *in, unsigned long long n, unsigned long long *out, unsigned long long *block_sums,
@@ -468,16 +480,16 @@ unsigned long long scan_scratch_blocks(unsigned long long n) {
   return nb ? nb : 1;
 }
 void launch_fill_tokens(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, uint32_t space_id,
-                        const unsigned long long *uw_pos, const unsigned long long *uw_off, unsigned int n_words, uint32_t *tok,
-                        hipStream_t st) {
+                        const unsigned long long *uw_pos, const unsigned long long *uw_off, unsigned int n_words, unsigned int nom,
+                        unsigned int slot, const unsigned long long *tile_start, uint32_t *tok, hipStream_t st) {
   if (!n_words) return;
   hipLaunchKernelGGL(k2e_fill_tokens, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, text, n, cpmap, space_id, uw_pos,
-                     uw_off, n_words, tok);
+                     uw_off, n_words, nom, slot, tile_start, tok);
 }
-void launch_tiles(const unsigned long long *uw_off, unsigned int n_words, unsigned long long *tile_start, uint32_t *tile_word0,
-                  hipStream_t st) {
+void launch_tiles(const unsigned long long *uw_off, unsigned int n_words, unsigned int nom, unsigned long long *tile_start,
+                  uint32_t *tile_word0, hipStream_t st) {
   if (!n_words) return;
-  hipLaunchKernelGGL(k2f_tiles, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, uw_off, n_words, tile_start, tile_word0);
+  hipLaunchKernelGGL(k2f_tiles, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, uw_off, n_words, nom, tile_start, tile_word0);
 }
 void launch_tile_len(const unsigned long long *tile_start, unsigned int n_tiles, unsigned long long total_tokens,
                      uint32_t *tile_len, hipStream_t st) {

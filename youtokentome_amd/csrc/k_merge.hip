@@ -9,25 +9,33 @@
 //                                           ordered pick stays on the host: host_trainer.cpp)
 // Design: no linked lists and no per-pair position lists.  Each round the host picks a batch of mutually
 // non-intersecting rules; one streaming pass over the token tiles applies all of them at once: a
-// workgroup stages its tile in LDS, finds merge sites with one cached hash lookup per adjacency, resolves x==y runs by
-// parity from the run start, emits exact count deltas only around the sites (aggregated in an LDS hash, then 64-bit
-// atomics into the HBM pair table), compacts the tile with wave ballots and writes it back in place.
+// WAVEFRONT owns a tile (no workgroup barriers in the loop), prefetches the next tile into registers while it works on
+// the current one in LDS, finds merge sites with one cached flag test per token (+ a hash lookup on a hit), resolves
+// x==y runs by parity from the run start, emits exact count deltas only around the sites (summed in an LDS hash shared
+// by the workgroup, then 64-bit atomics into the HBM pair table), compacts the tile with wave ballots and writes it
+// back in place.
 // HBM-bound integer work: no MFMA.
 #include "yttm_device.h"
 #include "yttm_kernels.h"
 
 namespace yttm {
 
-constexpr int AGG_SLOTS = 1024;  // LDS delta aggregator (per workgroup)
+constexpr int AGG_SLOTS = 256;  // LDS delta aggregator shared by the waves of a workgroup
 
-struct TileLds {
-  uint32_t tk[TILE_MAX + 4];
-  unsigned long long wsmask[TILE_CHUNKS];
-  uint32_t wsbase[TILE_CHUNKS];
-  uint32_t tmp[TILE_CHUNKS];
-  unsigned long long akey[AGG_SLOTS];
-  unsigned long long aval[AGG_SLOTS];
-  unsigned int agg_fill;
+// per-wavefront tile state in LDS
+template <int SLOT>
+struct WaveLds {
+  uint32_t tk[SLOT + 4];                   // staged tokens (+ sentinels)
+  uint32_t nz[SLOT];                       // new token (z | inherited TOK_WS) at merge-site positions
+  unsigned long long wsmask[SLOT / 64];    // bit p: token p starts a word
+  unsigned long long sitemask[SLOT / 64];  // bit p: a merge (tk[p],tk[p+1]) -> nz[p] starts at p
+  unsigned long long amask[SLOT / 64];     // bit p: position p survives
+  uint32_t wsbase[SLOT / 64];              // number of word starts before the chunk
+  uint32_t abase[SLOT / 64];               // number of survivors before the chunk
+};
+struct AggLds {
+  unsigned long long key[AGG_SLOTS];
+  unsigned long long val[AGG_SLOTS];
 };
 
 __device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta) {
@@ -41,21 +49,19 @@ __device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsi
   }
 }
 
-// LDS-staged partial counts: most deltas of a tile hit few distinct pairs early in training (small alphabet), so they
-// are summed in LDS first and only the per-workgroup totals go to HBM atomics (cdna guide, Guideline 12).
-__device__ inline void agg_emit(TileLds &L, const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta) {
+// LDS-staged partial counts: early in training (small alphabet) the deltas of many tiles hit few distinct pairs, so they
+// are summed in LDS first and only per-workgroup totals go to HBM atomics (cdna guide, Guideline 12).  Keys stay for the
+// whole kernel; when the table is full a delta goes straight to HBM.
+__device__ inline void agg_emit(AggLds &A, const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta) {
   unsigned int h = (unsigned int)(mix64(key) >> 24) & (AGG_SLOTS - 1);
-  for (int probe = 0; probe < 8; probe++) {
-    unsigned long long k = ((volatile unsigned long long *)L.akey)[h];
+  for (int probe = 0; probe < 4; probe++) {
+    unsigned long long k = ((volatile unsigned long long *)A.key)[h];
     if (k == PT_EMPTY) {
-      k = atomicCAS(&L.akey[h], PT_EMPTY, key);
-      if (k == PT_EMPTY) {
-        atomicAdd(&L.agg_fill, 1u);
-        k = key;
-      }
+      k = atomicCAS(&A.key[h], PT_EMPTY, key);
+      if (k == PT_EMPTY) k = key;
     }
     if (k == key) {
-      atomicAdd(&L.aval[h], (unsigned long long)delta);
+      atomicAdd(&A.val[h], (unsigned long long)delta);
       return;
     }
     h = (h + 1) & (AGG_SLOTS - 1);
@@ -63,265 +69,260 @@ __device__ inline void agg_emit(TileLds &L, const PairTable &pt, const DeltaBuf 
   global_emit(pt, db, key, delta);
 }
 
-__device__ inline void agg_init(TileLds &L) {
-  for (int s = (int)threadIdx.x; s < AGG_SLOTS; s += BLOCK) {
-    L.akey[s] = PT_EMPTY;
-    L.aval[s] = 0;
+template <int NT>
+__device__ inline void agg_init(AggLds &A) {
+  for (int s = (int)threadIdx.x; s < AGG_SLOTS; s += NT) {
+    A.key[s] = PT_EMPTY;
+    A.val[s] = 0;
   }
-  if (threadIdx.x == 0) L.agg_fill = 0;
 }
-
-__device__ inline void agg_flush(TileLds &L, const PairTable &pt, const DeltaBuf &db) {
+template <int NT>
+__device__ inline void agg_flush(AggLds &A, const PairTable &pt, const DeltaBuf &db) {
   __syncthreads();
-  for (int s = (int)threadIdx.x; s < AGG_SLOTS; s += BLOCK) {
-    unsigned long long k = L.akey[s];
+  for (int s = (int)threadIdx.x; s < AGG_SLOTS; s += NT) {
+    unsigned long long k = A.key[s];
     if (k != PT_EMPTY) {
-      long long v = (long long)L.aval[s];
+      long long v = (long long)A.val[s];
       if (v != 0) global_emit(pt, db, k, v);
-      L.akey[s] = PT_EMPTY;
-      L.aval[s] = 0;
     }
   }
-  if (threadIdx.x == 0) L.agg_fill = 0;
-  __syncthreads();
 }
 
-// Stage tile `t` into LDS and build the word-start masks / per-chunk word index bases.  Returns live length n.
-__device__ inline int tile_load(TileLds &L, const TileSet &ts, uint32_t t) {
-  const int n = (int)ts.tile_len[t];
-  const unsigned long long base = ts.tile_start[t];
-  for (int p = (int)threadIdx.x; p < n; p += BLOCK) L.tk[p] = ts.tok[base + p];
-  if (threadIdx.x == 0) {
-    L.tk[n] = TOK_WS;  // sentinel: "next token starts a word" => no adjacency past the end
-    L.tk[n + 1] = TOK_WS;
-    L.tk[n + 2] = TOK_WS;
+// 16 B/lane coalesced loads of a tile into registers (issued one tile ahead of use: the HBM latency of the next tile
+// hides behind the processing of the current one)
+template <int SLOT>
+__device__ inline void tile_fetch(uint4 (&r)[SLOT / 256], const TileSet &ts, uint32_t t, int n) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(ts.tok + (size_t)t * SLOT);
+#pragma unroll
+  for (int j = 0; j < SLOT / 256; j++) {
+    const int i = lane_id() + 64 * j;
+    r[j] = (4 * i < n) ? src[i] : make_uint4(0, 0, 0, 0);
   }
-  __syncthreads();
+}
+
+// registers -> LDS, sentinels, word-start masks and per-chunk word-index bases (wave-local)
+template <int SLOT>
+__device__ inline void tile_stage(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256], int n) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int j = 0; j < SLOT / 256; j++) reinterpret_cast<uint4 *>(W.tk)[lane + 64 * j] = r[j];
+  wave_sync();
+  if (lane == 0) {
+    W.tk[n] = TOK_WS;  // sentinel: "next token starts a word" => no adjacency past the end
+    W.tk[n + 1] = TOK_WS;
+    W.tk[n + 2] = TOK_WS;
+  }
+  wave_sync();
   const int nchunks = (n + 63) >> 6;
-  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-  for (int c = wave; c < nchunks; c += NWAVES) {
-    int p = c * 64 + lane;
-    bool ws = p < n && (L.tk[p] & TOK_WS);
-    unsigned long long m = __ballot(ws);
+  uint32_t base = 0;
+  for (int c = 0; c < nchunks; c++) {
+    const int p = c * 64 + lane;
+    const bool ws = p < n && (W.tk[p] & TOK_WS);
+    const unsigned long long m = __ballot(ws);
     if (lane == 0) {
-      L.wsmask[c] = m;
-      L.tmp[c] = (uint32_t)__popcll(m);
+      W.wsmask[c] = m;
+      W.wsbase[c] = base;
     }
+    base += (uint32_t)__popcll(m);
   }
-  __syncthreads();
-  if (wave == 0) {
-    uint32_t v = lane < nchunks ? L.tmp[lane] : 0;
-    uint32_t inc = wave_incl_scan(v);
-    if (lane < nchunks) L.wsbase[lane] = inc - v;
-  }
-  __syncthreads();
-  return n;
+  wave_sync();
 }
 
 // frequency of the word that contains tile position p
-__device__ inline long long tile_weight(const TileLds &L, const TileSet &ts, uint32_t t, int p) {
-  int c = p >> 6;
-  unsigned long long le = (2ull << (p & 63)) - 1ull;  // bits 0..(p&63)
-  uint32_t k = L.wsbase[c] + (uint32_t)__popcll(L.wsmask[c] & le);
+template <int SLOT>
+__device__ inline long long tile_weight(const WaveLds<SLOT> &W, const TileSet &ts, uint32_t t, int p) {
+  const int c = p >> 6;
+  const unsigned long long le = (2ull << (p & 63)) - 1ull;  // bits 0..(p&63)
+  const uint32_t k = W.wsbase[c] + (uint32_t)__popcll(W.wsmask[c] & le);
   return (long long)ts.wcnt[ts.tile_word0[t] + k - 1];
 }
 
-// ------------------------------------------------------------------------------------------------- K3: pair count
-// Weighted bigram histogram of the whole token table: every adjacency counts the word frequency;
-// inside a run of L equal tokens the self pair counts floor(L/2) (emitted once by the run's first token).
-__global__ __launch_bounds__(BLOCK) void k3_pair_count(TileSet ts, PairTable pt, DeltaBuf db) {
-  __shared__ TileLds L;
-  agg_init(L);
-  __syncthreads();
-  for (uint32_t t = blockIdx.x; t < ts.n_tiles; t += gridDim.x) {
-    const int n = tile_load(L, ts, t);
-    for (int p = (int)threadIdx.x; p < n; p += BLOCK) {
-      const uint32_t t0 = L.tk[p], t1 = L.tk[p + 1];
-      if (t1 & TOK_WS) continue;
-      const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
-      if (a != b) {
-        agg_emit(L, pt, db, pair_key(a, b), tile_weight(L, ts, t, p));
-      } else {
-        const bool run_start = (t0 & TOK_WS) || p == 0 || (L.tk[p - 1] & TOK_MASK) != a;
-        if (run_start) {
-          int q = p + 1;
-          while (!(L.tk[q + 1] & TOK_WS) && (L.tk[q + 1] & TOK_MASK) == a) q++;
-          const long long len = q - p + 1;
-          agg_emit(L, pt, db, pair_key(a, a), (len / 2) * tile_weight(L, ts, t, p));
-        }
-      }
-    }
-    __syncthreads();
-    if (L.agg_fill > AGG_SLOTS / 2) agg_flush(L, pt, db);
-    __syncthreads();
-  }
-  agg_flush(L, pt, db);
-}
-
-// ------------------------------------------------------------------------------------------------- K4: merge apply
-struct MergeLds {
-  TileLds t;
-  uint32_t nz[TILE_MAX];                     // new token (z | inherited TOK_WS) at merge-site positions
-  unsigned long long sitemask[TILE_CHUNKS];  // bit p: a merge (tk[p],tk[p+1]) -> nz[p] starts at p
-  unsigned long long amask[TILE_CHUNKS];     // bit p: position p survives
-  uint32_t abase[TILE_CHUNKS];
-  int any_site;
-  uint32_t new_len;
-};
-
-__global__ __launch_bounds__(BLOCK) void k4_merge_apply(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
-                                                        unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
-                                                        uint32_t self_x, uint32_t self_z,
-                                                        unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
-  __shared__ MergeLds M;
-  TileLds &L = M.t;
-  agg_init(L);
+// ------------------------------------------------------------------------------------------------- K3 / K4
+// One wavefront per tile.  MERGE=false: K3, weighted bigram histogram of the whole table (every
+// adjacency counts the word frequency; a run of L equal tokens counts floor(L/2) for its self pair).
+// MERGE=true: K4, apply the batch rules and emit the exact count deltas around the merge sites.
+template <int SLOT, int WPB, bool MERGE>
+__global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
+                                                    unsigned int rule_mask, const uint8_t *__restrict__ tokflag, uint32_t self_x,
+                                                    uint32_t self_z,
+                                                    unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
+  __shared__ WaveLds<SLOT> WL[WPB];
+  __shared__ AggLds A;
+  agg_init<WPB * 64>(A);
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-  for (uint32_t t = blockIdx.x; t < ts.n_tiles; t += gridDim.x) {
-    if (threadIdx.x == 0) M.any_site = 0;
-    const int n = tile_load(L, ts, t);  // contains barriers
+  WaveLds<SLOT> &W = WL[wave];
+  const uint32_t stride = gridDim.x * WPB;
+  uint32_t t = blockIdx.x * WPB + wave;
+  int n = t < ts.n_tiles ? (int)ts.tile_len[t] : 0;
+  uint4 r[SLOT / 256];
+  if (t < ts.n_tiles) tile_fetch<SLOT>(r, ts, t, n);
+  unsigned long long my_sites = 0, st_touched = 0, st_scanned = 0, st_touched_tok = 0;
+  while (t < ts.n_tiles) {
+    tile_stage<SLOT>(W, r, n);
+    // prefetch the next tile of this wave
+    const uint32_t t_next = t + stride;
+    const int n_next = t_next < ts.n_tiles ? (int)ts.tile_len[t_next] : 0;
+    if (t_next < ts.n_tiles) tile_fetch<SLOT>(r, ts, t_next, n_next);
     const int nchunks = (n + 63) >> 6;
+    st_scanned += (unsigned long long)n;
 
-    // ---- phase 1: merge sites -------------------------------------------------------------------------------------
-    for (int c = wave; c < nchunks; c += NWAVES) {
-      const int p = c * 64 + lane;
-      bool s = false;
-      if (p < n) {
-        const uint32_t t0 = L.tk[p], t1 = L.tk[p + 1];
-        if (!(t1 & TOK_WS)) {
-          const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
-          uint32_t z = 0;
-          if (a == self_x && b == self_x) {
-            // x==y rule: left-to-right greedy inside the run = positions at even offset from the run start
-            int r = p;
-            while (r > 0 && !(L.tk[r] & TOK_WS) && (L.tk[r - 1] & TOK_MASK) == a) r--;
-            if (((p - r) & 1) == 0) { s = true; z = self_z; }
-          } else if ((tokflag[a] & 1u) && (tokflag[b] & 2u)) {
-            const unsigned long long key = pair_key(a, b);
-            unsigned int h = (unsigned int)mix64(key) & rule_mask;
-            for (;;) {
-              const unsigned long long k = rules[h].key;
-              if (k == key) { s = true; z = rules[h].z; break; }
-              if (k == PT_EMPTY) break;
-              h = (h + 1) & rule_mask;
-            }
+    if (!MERGE) {
+      for (int c = 0; c < nchunks; c++) {
+        const int p = c * 64 + lane;
+        if (p >= n) continue;
+        const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
+        if (t1 & TOK_WS) continue;
+        const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
+        if (a != b) {
+          agg_emit(A, pt, db, pair_key(a, b), tile_weight<SLOT>(W, ts, t, p));
+        } else {
+          const bool run_start = (t0 & TOK_WS) || p == 0 || (W.tk[p - 1] & TOK_MASK) != a;
+          if (run_start) {
+            int q = p + 1;
+            while (!(W.tk[q + 1] & TOK_WS) && (W.tk[q + 1] & TOK_MASK) == a) q++;
+            const long long len = q - p + 1;
+            agg_emit(A, pt, db, pair_key(a, a), (len / 2) * tile_weight<SLOT>(W, ts, t, p));
           }
-          if (s) M.nz[p] = z | (t0 & TOK_WS);
         }
       }
-      const unsigned long long m = __ballot(s);
-      if (lane == 0) {
-        M.sitemask[c] = m;
-        if (m) M.any_site = 1;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)n);
-    if (!M.any_site) {
-      __syncthreads();  // keep any_site stable until everyone has read it
-      continue;
-    }
-
-#define SITE(q) ((q) >= 0 && (((M.sitemask[(q) >> 6] >> ((q)&63)) & 1ull) != 0))
-    // ---- phase 2: count deltas around the sites + survivor masks -----------------------------------------------------
-    unsigned long long my_sites = 0;
-    for (int c = wave; c < nchunks; c += NWAVES) {
-      const int p = c * 64 + lane;
-      bool alive = false;
-      if (p < n) {
-        const uint32_t t0 = L.tk[p], t1 = L.tk[p + 1];
-        const uint32_t a = t0 & TOK_MASK;
-        const bool sp = SITE(p);
-        const bool dp = SITE(p - 1);
-        const bool adj1 = !(t1 & TOK_WS);
-        alive = !dp;
-        if (sp || dp || (adj1 && SITE(p + 1))) {
-          const long long f = tile_weight(L, ts, t, p);
-          if (sp) {
-            my_sites++;
-            const uint32_t b = t1 & TOK_MASK;
-            const uint32_t z = M.nz[p] & TOK_MASK;
-            agg_emit(L, pt, db, pair_key(a, b), -f);  // the merged pair itself
-            // run of new z tokens (x y x y ... or the halves of an x-run): counted floor(Lz/2) by its first site
-            const bool prev_same = p >= 2 && !(t0 & TOK_WS) && SITE(p - 2) && (M.nz[p - 2] & TOK_MASK) == z;
-            if (!prev_same) {
-              int q = p, lz = 1;
-              while (!(L.tk[q + 2] & TOK_WS) && q + 2 < n && SITE(q + 2) && (M.nz[q + 2] & TOK_MASK) == z) { q += 2; lz++; }
-              if (lz >= 2) agg_emit(L, pt, db, pair_key(z, z), (long long)(lz / 2) * f);
-            }
-            // new adjacency (z, right neighbour)
-            const int q = p + 2;
-            if (q < n && !(L.tk[q] & TOK_WS)) {
-              const uint32_t B = SITE(q) ? (M.nz[q] & TOK_MASK) : (L.tk[q] & TOK_MASK);
-              if (B != z) agg_emit(L, pt, db, pair_key(z, B), f);
-            }
-            // x != y rule whose x is the last token of a run of a's: the run shrinks by one
-            if (a != self_x && p > 0 && !(t0 & TOK_WS) && (L.tk[p - 1] & TOK_MASK) == a) {
-              int r = p;
-              while (r > 0 && !(L.tk[r] & TOK_WS) && (L.tk[r - 1] & TOK_MASK) == a) r--;
-              const int len = p - r + 1;
-              if ((len & 1) == 0) agg_emit(L, pt, db, pair_key(a, a), -f);
-            }
-          } else if (!dp) {
-            // unmerged token whose right neighbour starts a site: (a,x) -> (a,z)
-            const uint32_t x_ = t1 & TOK_MASK;
-            const uint32_t z = M.nz[p + 1] & TOK_MASK;
-            if (a != x_) agg_emit(L, pt, db, pair_key(a, x_), -f);
-            agg_emit(L, pt, db, pair_key(a, z), f);
-          }
-          if (dp && adj1) {
-            // p was the y of the site at p-1: its old right adjacency disappears
-            const uint32_t b_ = t1 & TOK_MASK;
-            if (a != b_) {
-              agg_emit(L, pt, db, pair_key(a, b_), -f);
-            } else if (a != self_x) {
-              // x != y rule whose y is the first token of a run of a's: the run shrinks by one
+    } else {
+      // ---- phase 1: merge sites ---------------------------------------------------------------------------------------
+      bool any = false;
+      for (int c = 0; c < nchunks; c++) {
+        const int p = c * 64 + lane;
+        bool s = false;
+        if (p < n) {
+          const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
+          if (!(t1 & TOK_WS)) {
+            const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
+            uint32_t z = 0;
+            if (a == self_x && b == self_x) {
+              // x==y rule: left-to-right greedy inside the run = positions at even offset from the run start
               int q = p;
-              while (!(L.tk[q + 1] & TOK_WS) && (L.tk[q + 1] & TOK_MASK) == a) q++;
-              const int len = q - p + 1;
-              if ((len & 1) == 0) agg_emit(L, pt, db, pair_key(a, a), -f);
+              while (q > 0 && !(W.tk[q] & TOK_WS) && (W.tk[q - 1] & TOK_MASK) == a) q--;
+              if (((p - q) & 1) == 0) { s = true; z = self_z; }
+            } else if ((tokflag[a] & 1u) && (tokflag[b] & 2u)) {
+              const unsigned long long key = pair_key(a, b);
+              unsigned int h = (unsigned int)mix64(key) & rule_mask;
+              for (;;) {
+                const unsigned long long k = rules[h].key;
+                if (k == key) { s = true; z = rules[h].z; break; }
+                if (k == PT_EMPTY) break;
+                h = (h + 1) & rule_mask;
+              }
+            }
+            if (s) W.nz[p] = z | (t0 & TOK_WS);
+          }
+        }
+        const unsigned long long m = __ballot(s);
+        if (lane == 0) W.sitemask[c] = m;
+        any = any || m != 0;
+      }
+      wave_sync();
+      if (any) {
+#define SITE(q) ((q) >= 0 && (((W.sitemask[(q) >> 6] >> ((q)&63)) & 1ull) != 0))
+        // ---- phase 2: count deltas around the sites + survivor masks ---------------------------------------------------
+        uint32_t abase = 0;
+        for (int c = 0; c < nchunks; c++) {
+          const int p = c * 64 + lane;
+          bool alive = false;
+          if (p < n) {
+            const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
+            const uint32_t a = t0 & TOK_MASK;
+            const bool sp = SITE(p);
+            const bool dp = SITE(p - 1);
+            const bool adj1 = !(t1 & TOK_WS);
+            alive = !dp;
+            if (sp || dp || (adj1 && SITE(p + 1))) {
+              const long long f = tile_weight<SLOT>(W, ts, t, p);
+              if (sp) {
+                my_sites++;
+                const uint32_t b = t1 & TOK_MASK;
+                const uint32_t z = W.nz[p] & TOK_MASK;
+                agg_emit(A, pt, db, pair_key(a, b), -f);  // the merged pair itself
+                // run of new z tokens (x y x y ... or the halves of an x-run): counted floor(Lz/2) by its first site
+                const bool prev_same = p >= 2 && !(t0 & TOK_WS) && SITE(p - 2) && (W.nz[p - 2] & TOK_MASK) == z;
+                if (!prev_same) {
+                  int q = p, lz = 1;
+                  while (!(W.tk[q + 2] & TOK_WS) && q + 2 < n && SITE(q + 2) && (W.nz[q + 2] & TOK_MASK) == z) { q += 2; lz++; }
+                  if (lz >= 2) agg_emit(A, pt, db, pair_key(z, z), (long long)(lz / 2) * f);
+                }
+                // new adjacency (z, right neighbour)
+                const int q = p + 2;
+                if (q < n && !(W.tk[q] & TOK_WS)) {
+                  const uint32_t B = SITE(q) ? (W.nz[q] & TOK_MASK) : (W.tk[q] & TOK_MASK);
+                  if (B != z) agg_emit(A, pt, db, pair_key(z, B), f);
+                }
+                // x != y rule whose x is the last token of a run of a's: the run shrinks by one
+                if (a != self_x && p > 0 && !(t0 & TOK_WS) && (W.tk[p - 1] & TOK_MASK) == a) {
+                  int rr = p;
+                  while (rr > 0 && !(W.tk[rr] & TOK_WS) && (W.tk[rr - 1] & TOK_MASK) == a) rr--;
+                  const int len = p - rr + 1;
+                  if ((len & 1) == 0) agg_emit(A, pt, db, pair_key(a, a), -f);
+                }
+              } else if (!dp) {
+                // unmerged token whose right neighbour starts a site: (a,x) -> (a,z)
+                const uint32_t x_ = t1 & TOK_MASK;
+                const uint32_t z = W.nz[p + 1] & TOK_MASK;
+                if (a != x_) agg_emit(A, pt, db, pair_key(a, x_), -f);
+                agg_emit(A, pt, db, pair_key(a, z), f);
+              }
+              if (dp && adj1) {
+                // p was the y of the site at p-1: its old right adjacency disappears
+                const uint32_t b_ = t1 & TOK_MASK;
+                if (a != b_) {
+                  agg_emit(A, pt, db, pair_key(a, b_), -f);
+                } else if (a != self_x) {
+                  // x != y rule whose y is the first token of a run of a's: the run shrinks by one
+                  int q = p;
+                  while (!(W.tk[q + 1] & TOK_WS) && (W.tk[q + 1] & TOK_MASK) == a) q++;
+                  const int len = q - p + 1;
+                  if ((len & 1) == 0) agg_emit(A, pt, db, pair_key(a, a), -f);
+                }
+              }
+            }
+          }
+          const unsigned long long am = __ballot(alive);
+          if (lane == 0) {
+            W.amask[c] = am;
+            W.abase[c] = abase;
+          }
+          abase += (uint32_t)__popcll(am);
+        }
+        wave_sync();
+        // ---- phase 3: compact in place (all reads come from LDS, so overwriting the slot in HBM is safe) ----------------
+        uint32_t *dst = ts.tok + (size_t)t * SLOT;
+        for (int c = 0; c < nchunks; c++) {
+          const int p = c * 64 + lane;
+          if (p < n) {
+            const unsigned long long am = W.amask[c];
+            if ((am >> lane) & 1ull) {
+              const uint32_t np = W.abase[c] + (uint32_t)__popcll(am & lanemask_lt());
+              dst[np] = SITE(p) ? W.nz[p] : W.tk[p];
             }
           }
         }
-      }
-      const unsigned long long am = __ballot(alive);
-      if (lane == 0) {
-        M.amask[c] = am;
-        L.tmp[c] = (uint32_t)__popcll(am);
-      }
-    }
-    __syncthreads();
-    if (wave == 0) {
-      uint32_t v = lane < nchunks ? L.tmp[lane] : 0;
-      uint32_t inc = wave_incl_scan(v);
-      if (lane < nchunks) M.abase[lane] = inc - v;
-      if (lane == 63) M.new_len = inc;
-    }
-    __syncthreads();
-    // ---- phase 3: compact in place (all reads come from LDS, so overwriting the tile in HBM is safe) ------------------
-    const unsigned long long base = ts.tile_start[t];
-    for (int p = (int)threadIdx.x; p < n; p += BLOCK) {
-      const int c = p >> 6;
-      const unsigned long long am = M.amask[c];
-      if ((am >> (p & 63)) & 1ull) {
-        const uint32_t np = M.abase[c] + (uint32_t)__popcll(am & ((1ull << (p & 63)) - 1ull));
-        ts.tok[base + np] = SITE(p) ? M.nz[p] : L.tk[p];
-      }
-    }
-    if (threadIdx.x == 0) {
-      ts.tile_len[t] = M.new_len;
-      atomicAdd(&stats[1], 1ull);
-      atomicAdd(&stats[3], (unsigned long long)n);
-    }
-    my_sites = wave_sum_u64(my_sites);
-    if (lane == 0 && my_sites) atomicAdd(&stats[0], my_sites);
+        if (lane == 0) ts.tile_len[t] = abase;
+        st_touched++;
+        st_touched_tok += (unsigned long long)n;
 #undef SITE
-    __syncthreads();
-    if (L.agg_fill > AGG_SLOTS / 2) agg_flush(L, pt, db);
-    __syncthreads();
+      }
+    }
+    wave_sync();  // everyone is done with this tile's LDS state before it is restaged
+    t = t_next;
+    n = n_next;
   }
-  agg_flush(L, pt, db);
+  agg_flush<WPB * 64>(A, pt, db);
+  if (MERGE) {
+    my_sites = wave_sum_u64(my_sites);
+    if (lane == 0) {
+      if (my_sites) atomicAdd(&stats[0], my_sites);
+      if (st_touched) atomicAdd(&stats[1], st_touched);
+      if (st_scanned) atomicAdd(&stats[2], st_scanned);
+      if (st_touched_tok) atomicAdd(&stats[3], st_touched_tok);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------- pair table kernels
@@ -416,21 +417,31 @@ __global__ __launch_bounds__(BLOCK) void k_fill_u64(unsigned long long *__restri
 }
 
 // ------------------------------------------------------------------------------------------------- launchers
-static inline unsigned int tile_grid(unsigned int n_tiles, unsigned int per_cu) {
-  unsigned int g = 256u * per_cu;
-  if (g > n_tiles) g = n_tiles;
+static inline unsigned int tile_grid(unsigned int n_tiles, unsigned int wpb, unsigned int blocks_per_cu) {
+  unsigned int need = (n_tiles + wpb - 1) / wpb;
+  unsigned int g = 256u * blocks_per_cu;
+  if (g > need) g = need;
   return g ? g : 1u;
 }
 
-void launch_pair_count(const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st) {
+void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st) {
   if (!ts.n_tiles) return;
-  hipLaunchKernelGGL(k3_pair_count, dim3(tile_grid(ts.n_tiles, 8)), dim3(BLOCK), 0, st, ts, pt, db);
+  if (cls == 0)
+    hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
+                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, 0xffffffffu, 0u, (unsigned long long *)nullptr);
+  else
+    hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
+                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, 0xffffffffu, 0u, (unsigned long long *)nullptr);
 }
-void launch_merge_apply(const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
+void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, uint32_t self_x, uint32_t self_z, unsigned long long *stats, hipStream_t st) {
   if (!ts.n_tiles) return;
-  hipLaunchKernelGGL(k4_merge_apply, dim3(tile_grid(ts.n_tiles, 6)), dim3(BLOCK), 0, st, ts, pt, db, rules, rule_mask, tokflag, self_x,
-                     self_z, stats);
+  if (cls == 0)
+    hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
+                       tokflag, self_x, self_z, stats);
+  else
+    hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
+                       tokflag, self_x, self_z, stats);
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
                       unsigned int *n_out, unsigned long long *hist, hipStream_t st) {

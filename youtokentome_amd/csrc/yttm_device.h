@@ -24,9 +24,14 @@ constexpr uint32_t CP_UNK = 0xfffffffdu;    // encode: char not in the model (bp
 constexpr uint32_t N_CODEPOINTS = 0x110000u;
 constexpr uint32_t INVALID_CP = 0x0fffffffu;  // utf8.h:9
 
-constexpr int TILE_TOK = 2048;  // nominal tokens per tile; also the longest word the tile kernels accept
-constexpr int TILE_MAX = 4096;  // a tile holds whole words, so it can overshoot TILE_TOK by < one word
-constexpr int TILE_CHUNKS = TILE_MAX / 64;
+// Token tiles.  A tile holds whole words and lives in a fixed slot of SLOT tokens (tile t = tok[t*SLOT ..)), of which
+// the first tile_len[t] are live; merges compact a tile in place.  One WAVEFRONT owns a tile (no workgroup barriers in
+// the hot loops).  Two classes so that LDS stays small for the common case:
+//   class A: words of <= 512 tokens, nominal 512 tokens per tile, slot 1024 (4 waves per workgroup)
+//   class B: words of 513..2048 tokens, nominal 2048 per tile, slot 4096 (1 wave per workgroup; rare)
+constexpr int TILE_NOM_A = 512, TILE_SLOT_A = 1024;
+constexpr int TILE_NOM_B = 2048, TILE_SLOT_B = 4096;
+constexpr int MAX_WORD_TOKENS = TILE_NOM_B;  // longest word the tile kernels accept (incl. the leading space token)
 constexpr int BLOCK = 256;      // 4 wavefronts of 64 lanes
 constexpr int NWAVES = BLOCK / 64;
 
@@ -40,11 +45,10 @@ struct PairTable {
 };
 
 struct TileSet {
-  uint32_t *tok;
-  const unsigned long long *tile_start;  // [n_tiles]
-  uint32_t *tile_len;                    // [n_tiles] live tokens (compacted prefix of the tile)
-  const uint32_t *tile_word0;            // [n_tiles] index of the first word of the tile
-  const uint32_t *wcnt;                  // [U]
+  uint32_t *tok;               // [n_tiles * SLOT]
+  uint32_t *tile_len;          // [n_tiles] live tokens (compacted prefix of the slot)
+  const uint32_t *tile_word0;  // [n_tiles] index of the first word of the tile
+  const uint32_t *wcnt;        // [U] word frequencies, in tile order
   uint32_t n_tiles;
 };
 
@@ -174,6 +178,12 @@ __device__ inline bool u8_is_start(const uint8_t *text, unsigned long long i, un
 }
 
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63u); }
+// LDS hand-off between the lanes of ONE wavefront: DS ops of a wave execute in order, so only the compiler must be
+// kept from reordering (fence) and the lanes kept converged (wave_barrier).
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 __device__ inline unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 // ---- wave / block scans (wave = 64 lanes; all lanes of the block must call) ---------------------------------------

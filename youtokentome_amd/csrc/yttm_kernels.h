@@ -30,22 +30,23 @@ void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32
                          unsigned long long n_segs, unsigned long long *ht_key, unsigned long long *ht_cnt, uint32_t *ht_len,
                          unsigned long long ht_mask, unsigned int *status, hipStream_t st);
 void launch_compact_words(const unsigned long long *ht_key, const unsigned long long *ht_cnt, const uint32_t *ht_len,
-                          unsigned long long n_slots, unsigned long long *uw_pos, uint32_t *uw_cnt, uint32_t *uw_len,
-                          unsigned int *cursor, unsigned int *status, hipStream_t st);
+                          unsigned long long n_slots, unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB,
+                          uint32_t *cntB, uint32_t *lenB, unsigned int *cursor, unsigned int *status, hipStream_t st);
 void launch_exclusive_scan(const uint32_t *in, unsigned long long n, unsigned long long *out, unsigned long long *block_sums,
                            unsigned long long *total_out, hipStream_t st);
 unsigned long long scan_scratch_blocks(unsigned long long n);
 void launch_fill_tokens(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, uint32_t space_id,
-                        const unsigned long long *uw_pos, const unsigned long long *uw_off, unsigned int n_words, uint32_t *tok,
-                        hipStream_t st);
-void launch_tiles(const unsigned long long *uw_off, unsigned int n_words, unsigned long long *tile_start, uint32_t *tile_word0,
-                  hipStream_t st);
+                        const unsigned long long *uw_pos, const unsigned long long *uw_off, unsigned int n_words, unsigned int nom,
+                        unsigned int slot, const unsigned long long *tile_start, uint32_t *tok, hipStream_t st);
+void launch_tiles(const unsigned long long *uw_off, unsigned int n_words, unsigned int nom, unsigned long long *tile_start,
+                  uint32_t *tile_word0, hipStream_t st);
 void launch_tile_len(const unsigned long long *tile_start, unsigned int n_tiles, unsigned long long total_tokens, uint32_t *tile_len,
                      hipStream_t st);
 
 // ---- merge loop (k_merge.hip)
-void launch_pair_count(const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st);
-void launch_merge_apply(const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
+// cls: 0 = class A tiles (slot 1024), 1 = class B tiles (slot 4096)
+void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st);
+void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, uint32_t self_x, uint32_t self_z, unsigned long long *stats, hipStream_t st);
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
                       unsigned int *n_out, unsigned long long *hist, hipStream_t st);
