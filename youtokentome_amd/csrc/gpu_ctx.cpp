@@ -261,6 +261,8 @@ void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, u
   c.d_tile_word0 = dmalloc<uint32_t>(c.n_tiles);
   c.d_tile_len = dmalloc<uint32_t>(c.n_tiles);
   c.d_tok = dmalloc<uint32_t>((size_t)c.n_tiles * c.slot + 64);
+  // slots are read 16 B wide past the live prefix and the staged ids index the flag table: never leave them undefined
+  HIP_CHECK(hipMemsetAsync(c.d_tok, 0, ((size_t)c.n_tiles * c.slot + 64) * 4, st_));
   launch_tiles(uw_off, U, c.nom, tile_start, c.d_tile_word0, st_);
   launch_tile_len(tile_start, c.n_tiles, total, c.d_tile_len, st_);
   launch_fill_tokens(d_text_, n_text_, d_cpmap_, space_id, uw_pos, uw_off, U, c.nom, c.slot, tile_start, c.d_tok, st_);
@@ -440,8 +442,12 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   if (k > RULES_CAP / 2) throw GpuError{"merge_apply: batch too large"};
   // new pairs this round: every site adds <= 2 neighbours (+ the z,z run pair); distinct new keys per rule are also
   // bounded by the number of live token types on either side
-  uint32_t vmax = 0;
-  for (uint32_t j = 0; j < k; j++) vmax = std::max(vmax, xyz[3 * j + 2]);
+  uint32_t vmax = 0, z_base = xyz[2];
+  for (uint32_t j = 0; j < k; j++) {
+    vmax = std::max(vmax, xyz[3 * j + 2]);
+    if (xyz[3 * j + 2] != z_base + j) throw GpuError{"merge_apply: the new ids of a batch must be consecutive"};
+  }
+  if (vmax >= (1u << 29)) throw GpuError{"merge_apply: token ids must be below 2^29"};
   unsigned long long bound_new = 0;
   for (uint32_t j = 0; j < k; j++) {
     unsigned long long by_tokens = 2ull * (vmax + 1) + 1;
@@ -500,7 +506,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     launch_set_tokflag(d_tokflag_, d_flag_upd_, n_upd, st_);
   }
   t_begin(KT_MERGE);
-  for (int ci = 0; ci < 2; ci++) launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, self_x, self_z, d_stats_, st_);
+  for (int ci = 0; ci < 2; ci++) launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, self_x, self_z, z_base, d_stats_, st_);
   t_end(KT_MERGE, 0);
   merge_rounds++;
   unsigned int nk = 0;

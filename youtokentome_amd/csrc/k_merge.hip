@@ -20,18 +20,27 @@
 
 namespace yttm {
 
-constexpr int AGG_SLOTS = 256;  // LDS delta aggregator shared by the waves of a workgroup
+constexpr int AGG_SLOTS = 128;   // LDS delta aggregator shared by the waves of a workgroup (hot pairs)
+constexpr int QCAP = 128;        // per-wave queue of deltas that missed the aggregator (drained 64 lanes wide)
+constexpr int CAND_CAP_W = 256;  // per-wave list of merge-site candidates awaiting their rule lookup
+
+// Staged (LDS) token word: bit31 = first token of a word, bit30 = id is the y of some batch rule, bit29 = id is the x
+// of some batch rule, bits 0..28 = id.  HBM tokens carry only bit31 + id.
+constexpr uint32_t L_ISX = 1u << 29, L_ISY = 1u << 30, L_ID = (1u << 29) - 1;
 
 // per-wavefront tile state in LDS
 template <int SLOT>
 struct WaveLds {
   uint32_t tk[SLOT + 4];                   // staged tokens (+ sentinels)
-  uint32_t nz[SLOT];                       // new token (z | inherited TOK_WS) at merge-site positions
+  uint16_t ridx[SLOT];                     // merge site at p: index of its rule in the batch (z = z_base + ridx)
   unsigned long long wsmask[SLOT / 64];    // bit p: token p starts a word
-  unsigned long long sitemask[SLOT / 64];  // bit p: a merge (tk[p],tk[p+1]) -> nz[p] starts at p
+  unsigned long long sitemask[SLOT / 64];  // bit p: a merge (tk[p],tk[p+1]) starts at p
   unsigned long long amask[SLOT / 64];     // bit p: position p survives
   uint32_t wsbase[SLOT / 64];              // number of word starts before the chunk
   uint32_t abase[SLOT / 64];               // number of survivors before the chunk
+  uint16_t cand[CAND_CAP_W];
+  unsigned int ncand, qn;
+  DeltaRec q[QCAP];
 };
 struct AggLds {
   unsigned long long key[AGG_SLOTS];
@@ -49,12 +58,15 @@ __device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsi
   }
 }
 
-// LDS-staged partial counts: early in training (small alphabet) the deltas of many tiles hit few distinct pairs, so they
-// are summed in LDS first and only per-workgroup totals go to HBM atomics (cdna guide, Guideline 12).  Keys stay for the
-// whole kernel; when the table is full a delta goes straight to HBM.
-__device__ inline void agg_emit(AggLds &A, const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta) {
+// Count deltas go through two LDS stages before they become HBM atomics (cdna guide, Guideline 12):
+//  1. a small hash shared by the workgroup sums the deltas of hot pairs (early training: few distinct pairs, huge
+//     counts -- without it every tile would hammer the same few HBM addresses);
+//  2. what misses the hash is queued per wave and drained 64 lanes wide between tiles, so the ~2 us latency of a
+//     table update is paid once per 64 updates instead of once per update on the few lanes that own a merge site.
+template <int SLOT>
+__device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta) {
   unsigned int h = (unsigned int)(mix64(key) >> 24) & (AGG_SLOTS - 1);
-  for (int probe = 0; probe < 4; probe++) {
+  for (int probe = 0; probe < 2; probe++) {
     unsigned long long k = ((volatile unsigned long long *)A.key)[h];
     if (k == PT_EMPTY) {
       k = atomicCAS(&A.key[h], PT_EMPTY, key);
@@ -66,7 +78,24 @@ __device__ inline void agg_emit(AggLds &A, const PairTable &pt, const DeltaBuf &
     }
     h = (h + 1) & (AGG_SLOTS - 1);
   }
-  global_emit(pt, db, key, delta);
+  const unsigned int i = atomicAdd(&W.qn, 1u);
+  if (i < (unsigned int)QCAP) {
+    W.q[i].key = key;
+    W.q[i].delta = delta;
+  } else {
+    global_emit(pt, db, key, delta);
+  }
+}
+
+template <int SLOT>
+__device__ inline void drain_queue(WaveLds<SLOT> &W, const PairTable &pt, const DeltaBuf &db) {
+  // call wave-converged, after a wave_sync
+  unsigned int n = W.qn;
+  if (n > (unsigned int)QCAP) n = QCAP;
+  for (unsigned int i = (unsigned int)lane_id(); i < n; i += 64) global_emit(pt, db, W.q[i].key, W.q[i].delta);
+  wave_sync();
+  if (lane_id() == 0) W.qn = 0;
+  wave_sync();
 }
 
 template <int NT>
@@ -100,72 +129,130 @@ __device__ inline void tile_fetch(uint4 (&r)[SLOT / 256], const TileSet &ts, uin
   }
 }
 
-// registers -> LDS, sentinels, word-start masks and per-chunk word-index bases (wave-local)
-template <int SLOT>
-__device__ inline void tile_stage(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256], int n) {
+__device__ inline uint32_t flagged(uint32_t tok, const uint8_t *__restrict__ tokflag) {
+  return tok | ((uint32_t)(tokflag[tok & TOK_MASK] & 3u) << 29);
+}
+
+// registers -> LDS (+ the per-token batch flags, gathered for all 16 tokens of a lane at once so that their latency
+// overlaps), sentinels, word-start masks and per-chunk word-index bases (wave-local)
+template <int SLOT, bool MERGE>
+__device__ inline void tile_stage(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256], int n, const uint8_t *__restrict__ tokflag) {
   const int lane = lane_id();
 #pragma unroll
-  for (int j = 0; j < SLOT / 256; j++) reinterpret_cast<uint4 *>(W.tk)[lane + 64 * j] = r[j];
+  for (int j = 0; j < SLOT / 256; j++) {
+    uint4 v = r[j];
+    if (MERGE) {
+      const int i = lane + 64 * j;
+      if (4 * i < n) {
+        v.x = flagged(v.x, tokflag); v.y = flagged(v.y, tokflag); v.z = flagged(v.z, tokflag); v.w = flagged(v.w, tokflag);
+      }
+    }
+    reinterpret_cast<uint4 *>(W.tk)[lane + 64 * j] = v;
+  }
   wave_sync();
   if (lane == 0) {
     W.tk[n] = TOK_WS;  // sentinel: "next token starts a word" => no adjacency past the end
     W.tk[n + 1] = TOK_WS;
     W.tk[n + 2] = TOK_WS;
-  }
-  wave_sync();
-  const int nchunks = (n + 63) >> 6;
-  uint32_t base = 0;
-  for (int c = 0; c < nchunks; c++) {
-    const int p = c * 64 + lane;
-    const bool ws = p < n && (W.tk[p] & TOK_WS);
-    const unsigned long long m = __ballot(ws);
-    if (lane == 0) {
-      W.wsmask[c] = m;
-      W.wsbase[c] = base;
-    }
-    base += (uint32_t)__popcll(m);
+    W.ncand = 0;
   }
   wave_sync();
 }
 
 // frequency of the word that contains tile position p
 template <int SLOT>
-__device__ inline long long tile_weight(const WaveLds<SLOT> &W, const TileSet &ts, uint32_t t, int p) {
+__device__ inline long long tile_weight(const WaveLds<SLOT> &W, const uint32_t *__restrict__ wcnt, uint32_t word0, int p) {
   const int c = p >> 6;
   const unsigned long long le = (2ull << (p & 63)) - 1ull;  // bits 0..(p&63)
   const uint32_t k = W.wsbase[c] + (uint32_t)__popcll(W.wsmask[c] & le);
-  return (long long)ts.wcnt[ts.tile_word0[t] + k - 1];
+  return (long long)wcnt[word0 + k - 1];
 }
 
 // ------------------------------------------------------------------------------------------------- K3 / K4
 // One wavefront per tile.  MERGE=false: K3, weighted bigram histogram of the whole table (every
 // adjacency counts the word frequency; a run of L equal tokens counts floor(L/2) for its self pair).
-// MERGE=true: K4, apply the batch rules and emit the exact count deltas around the merge sites.
+// MERGE=true: K4, apply the batch rules (z ids are consecutive: rule j of the batch creates z_base + j) and emit the
+// exact count deltas around the merge sites.
 template <int SLOT, int WPB, bool MERGE>
 __global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag, uint32_t self_x,
-                                                    uint32_t self_z,
+                                                    uint32_t self_z, uint32_t z_base,
                                                     unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
   __shared__ WaveLds<SLOT> WL[WPB];
   __shared__ AggLds A;
   agg_init<WPB * 64>(A);
-  __syncthreads();
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   WaveLds<SLOT> &W = WL[wave];
+  if (lane == 0) W.qn = 0;
+  __syncthreads();
   const uint32_t stride = gridDim.x * WPB;
   uint32_t t = blockIdx.x * WPB + wave;
   int n = t < ts.n_tiles ? (int)ts.tile_len[t] : 0;
+  uint32_t word0 = t < ts.n_tiles ? ts.tile_word0[t] : 0;
   uint4 r[SLOT / 256];
   if (t < ts.n_tiles) tile_fetch<SLOT>(r, ts, t, n);
   unsigned long long my_sites = 0, st_touched = 0, st_scanned = 0, st_touched_tok = 0;
   while (t < ts.n_tiles) {
-    tile_stage<SLOT>(W, r, n);
+    tile_stage<SLOT, MERGE>(W, r, n, tokflag);
     // prefetch the next tile of this wave
     const uint32_t t_next = t + stride;
     const int n_next = t_next < ts.n_tiles ? (int)ts.tile_len[t_next] : 0;
+    const uint32_t word0_next = t_next < ts.n_tiles ? ts.tile_word0[t_next] : 0;
     if (t_next < ts.n_tiles) tile_fetch<SLOT>(r, ts, t_next, n_next);
     const int nchunks = (n + 63) >> 6;
     st_scanned += (unsigned long long)n;
+
+    // ---- phase 1a: word-start masks; (MERGE) merge-site candidates = x-flagged token followed by a y-flagged token ----
+    uint32_t wbase = 0;
+    bool any = false;
+    for (int c = 0; c < nchunks; c++) {
+      const int p = c * 64 + lane;
+      bool ws = false, self_site = false;
+      if (p < n) {
+        const uint32_t t0 = W.tk[p];
+        ws = t0 & TOK_WS;
+        if (MERGE) {
+          const uint32_t t1 = W.tk[p + 1];
+          if (!(t1 & TOK_WS)) {
+            const uint32_t a = t0 & L_ID, b = t1 & L_ID;
+            if (a == self_x && b == self_x) {
+              // x==y rule: left-to-right greedy inside the run = positions at even offset from the run start
+              int q = p;
+              while (q > 0 && !(W.tk[q] & TOK_WS) && (W.tk[q - 1] & L_ID) == a) q--;
+              if (((p - q) & 1) == 0) {
+                self_site = true;
+                W.ridx[p] = (uint16_t)(self_z - z_base);
+              }
+            } else if ((t0 & L_ISX) && (t1 & L_ISY)) {
+              const unsigned int i = atomicAdd(&W.ncand, 1u);
+              if (i < (unsigned int)CAND_CAP_W) {
+                W.cand[i] = (uint16_t)p;
+              } else {
+                // candidate list full: look the rule up right here
+                const unsigned long long key = pair_key(a, b);
+                unsigned int h = (unsigned int)mix64(key) & rule_mask;
+                for (;;) {
+                  const unsigned long long k = rules[h].key;
+                  if (k == key) { self_site = true; W.ridx[p] = (uint16_t)(rules[h].z - z_base); break; }
+                  if (k == PT_EMPTY) break;
+                  h = (h + 1) & rule_mask;
+                }
+              }
+            }
+          }
+        }
+      }
+      const unsigned long long m = __ballot(ws);
+      const unsigned long long sm = MERGE ? __ballot(self_site) : 0ull;
+      if (lane == 0) {
+        W.wsmask[c] = m;
+        W.wsbase[c] = wbase;
+        if (MERGE) W.sitemask[c] = sm;
+      }
+      wbase += (uint32_t)__popcll(m);
+      any = any || sm != 0;
+    }
+    wave_sync();
 
     if (!MERGE) {
       for (int c = 0; c < nchunks; c++) {
@@ -175,53 +262,44 @@ __global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, De
         if (t1 & TOK_WS) continue;
         const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
         if (a != b) {
-          agg_emit(A, pt, db, pair_key(a, b), tile_weight<SLOT>(W, ts, t, p));
+          emit<SLOT>(A, W, pt, db, pair_key(a, b), tile_weight<SLOT>(W, ts.wcnt, word0, p));
         } else {
           const bool run_start = (t0 & TOK_WS) || p == 0 || (W.tk[p - 1] & TOK_MASK) != a;
           if (run_start) {
             int q = p + 1;
             while (!(W.tk[q + 1] & TOK_WS) && (W.tk[q + 1] & TOK_MASK) == a) q++;
             const long long len = q - p + 1;
-            agg_emit(A, pt, db, pair_key(a, a), (len / 2) * tile_weight<SLOT>(W, ts, t, p));
+            emit<SLOT>(A, W, pt, db, pair_key(a, a), (len / 2) * tile_weight<SLOT>(W, ts.wcnt, word0, p));
           }
         }
       }
     } else {
-      // ---- phase 1: merge sites ---------------------------------------------------------------------------------------
-      bool any = false;
-      for (int c = 0; c < nchunks; c++) {
-        const int p = c * 64 + lane;
-        bool s = false;
-        if (p < n) {
-          const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
-          if (!(t1 & TOK_WS)) {
-            const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
-            uint32_t z = 0;
-            if (a == self_x && b == self_x) {
-              // x==y rule: left-to-right greedy inside the run = positions at even offset from the run start
-              int q = p;
-              while (q > 0 && !(W.tk[q] & TOK_WS) && (W.tk[q - 1] & TOK_MASK) == a) q--;
-              if (((p - q) & 1) == 0) { s = true; z = self_z; }
-            } else if ((tokflag[a] & 1u) && (tokflag[b] & 2u)) {
-              const unsigned long long key = pair_key(a, b);
-              unsigned int h = (unsigned int)mix64(key) & rule_mask;
-              for (;;) {
-                const unsigned long long k = rules[h].key;
-                if (k == key) { s = true; z = rules[h].z; break; }
-                if (k == PT_EMPTY) break;
-                h = (h + 1) & rule_mask;
-              }
+      // ---- phase 1b: rule lookups for all candidates of the tile at once (their latencies overlap) --------------------
+      unsigned int nc = W.ncand;
+      if (nc > (unsigned int)CAND_CAP_W) nc = CAND_CAP_W;
+      if (nc) {
+        for (unsigned int i = (unsigned int)lane; i < nc; i += 64) {
+          const int p = (int)W.cand[i];
+          const unsigned long long key = pair_key(W.tk[p] & L_ID, W.tk[p + 1] & L_ID);
+          unsigned int h = (unsigned int)mix64(key) & rule_mask;
+          for (;;) {
+            const unsigned long long k = rules[h].key;
+            if (k == key) {
+              W.ridx[p] = (uint16_t)(rules[h].z - z_base);
+              atomicOr(&W.sitemask[p >> 6], 1ull << (p & 63));
+              break;
             }
-            if (s) W.nz[p] = z | (t0 & TOK_WS);
+            if (k == PT_EMPTY) break;
+            h = (h + 1) & rule_mask;
           }
         }
-        const unsigned long long m = __ballot(s);
-        if (lane == 0) W.sitemask[c] = m;
-        any = any || m != 0;
+        wave_sync();
+        for (int c = lane; c < nchunks; c += 64) any = any || W.sitemask[c] != 0;
+        any = __ballot(any) != 0;
       }
-      wave_sync();
       if (any) {
 #define SITE(q) ((q) >= 0 && (((W.sitemask[(q) >> 6] >> ((q)&63)) & 1ull) != 0))
+#define NEWTOK(q) (z_base + (uint32_t)W.ridx[(q)])
         // ---- phase 2: count deltas around the sites + survivor masks ---------------------------------------------------
         uint32_t abase = 0;
         for (int c = 0; c < nchunks; c++) {
@@ -229,56 +307,56 @@ __global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, De
           bool alive = false;
           if (p < n) {
             const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
-            const uint32_t a = t0 & TOK_MASK;
+            const uint32_t a = t0 & L_ID;
             const bool sp = SITE(p);
             const bool dp = SITE(p - 1);
             const bool adj1 = !(t1 & TOK_WS);
             alive = !dp;
             if (sp || dp || (adj1 && SITE(p + 1))) {
-              const long long f = tile_weight<SLOT>(W, ts, t, p);
+              const long long f = tile_weight<SLOT>(W, ts.wcnt, word0, p);
               if (sp) {
                 my_sites++;
-                const uint32_t b = t1 & TOK_MASK;
-                const uint32_t z = W.nz[p] & TOK_MASK;
-                agg_emit(A, pt, db, pair_key(a, b), -f);  // the merged pair itself
+                const uint32_t b = t1 & L_ID;
+                const uint32_t z = NEWTOK(p);
+                emit<SLOT>(A, W, pt, db, pair_key(a, b), -f);  // the merged pair itself
                 // run of new z tokens (x y x y ... or the halves of an x-run): counted floor(Lz/2) by its first site
-                const bool prev_same = p >= 2 && !(t0 & TOK_WS) && SITE(p - 2) && (W.nz[p - 2] & TOK_MASK) == z;
+                const bool prev_same = p >= 2 && !(t0 & TOK_WS) && SITE(p - 2) && NEWTOK(p - 2) == z;
                 if (!prev_same) {
                   int q = p, lz = 1;
-                  while (!(W.tk[q + 2] & TOK_WS) && q + 2 < n && SITE(q + 2) && (W.nz[q + 2] & TOK_MASK) == z) { q += 2; lz++; }
-                  if (lz >= 2) agg_emit(A, pt, db, pair_key(z, z), (long long)(lz / 2) * f);
+                  while (!(W.tk[q + 2] & TOK_WS) && q + 2 < n && SITE(q + 2) && NEWTOK(q + 2) == z) { q += 2; lz++; }
+                  if (lz >= 2) emit<SLOT>(A, W, pt, db, pair_key(z, z), (long long)(lz / 2) * f);
                 }
                 // new adjacency (z, right neighbour)
                 const int q = p + 2;
                 if (q < n && !(W.tk[q] & TOK_WS)) {
-                  const uint32_t B = SITE(q) ? (W.nz[q] & TOK_MASK) : (W.tk[q] & TOK_MASK);
-                  if (B != z) agg_emit(A, pt, db, pair_key(z, B), f);
+                  const uint32_t B = SITE(q) ? NEWTOK(q) : (W.tk[q] & L_ID);
+                  if (B != z) emit<SLOT>(A, W, pt, db, pair_key(z, B), f);
                 }
                 // x != y rule whose x is the last token of a run of a's: the run shrinks by one
-                if (a != self_x && p > 0 && !(t0 & TOK_WS) && (W.tk[p - 1] & TOK_MASK) == a) {
+                if (a != self_x && p > 0 && !(t0 & TOK_WS) && (W.tk[p - 1] & L_ID) == a) {
                   int rr = p;
-                  while (rr > 0 && !(W.tk[rr] & TOK_WS) && (W.tk[rr - 1] & TOK_MASK) == a) rr--;
+                  while (rr > 0 && !(W.tk[rr] & TOK_WS) && (W.tk[rr - 1] & L_ID) == a) rr--;
                   const int len = p - rr + 1;
-                  if ((len & 1) == 0) agg_emit(A, pt, db, pair_key(a, a), -f);
+                  if ((len & 1) == 0) emit<SLOT>(A, W, pt, db, pair_key(a, a), -f);
                 }
               } else if (!dp) {
                 // unmerged token whose right neighbour starts a site: (a,x) -> (a,z)
-                const uint32_t x_ = t1 & TOK_MASK;
-                const uint32_t z = W.nz[p + 1] & TOK_MASK;
-                if (a != x_) agg_emit(A, pt, db, pair_key(a, x_), -f);
-                agg_emit(A, pt, db, pair_key(a, z), f);
+                const uint32_t x_ = t1 & L_ID;
+                const uint32_t z = NEWTOK(p + 1);
+                if (a != x_) emit<SLOT>(A, W, pt, db, pair_key(a, x_), -f);
+                emit<SLOT>(A, W, pt, db, pair_key(a, z), f);
               }
               if (dp && adj1) {
                 // p was the y of the site at p-1: its old right adjacency disappears
-                const uint32_t b_ = t1 & TOK_MASK;
+                const uint32_t b_ = t1 & L_ID;
                 if (a != b_) {
-                  agg_emit(A, pt, db, pair_key(a, b_), -f);
+                  emit<SLOT>(A, W, pt, db, pair_key(a, b_), -f);
                 } else if (a != self_x) {
                   // x != y rule whose y is the first token of a run of a's: the run shrinks by one
                   int q = p;
-                  while (!(W.tk[q + 1] & TOK_WS) && (W.tk[q + 1] & TOK_MASK) == a) q++;
+                  while (!(W.tk[q + 1] & TOK_WS) && (W.tk[q + 1] & L_ID) == a) q++;
                   const int len = q - p + 1;
-                  if ((len & 1) == 0) agg_emit(A, pt, db, pair_key(a, a), -f);
+                  if ((len & 1) == 0) emit<SLOT>(A, W, pt, db, pair_key(a, a), -f);
                 }
               }
             }
@@ -299,7 +377,8 @@ __global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, De
             const unsigned long long am = W.amask[c];
             if ((am >> lane) & 1ull) {
               const uint32_t np = W.abase[c] + (uint32_t)__popcll(am & lanemask_lt());
-              dst[np] = SITE(p) ? W.nz[p] : W.tk[p];
+              const uint32_t t0 = W.tk[p];
+              dst[np] = SITE(p) ? (NEWTOK(p) | (t0 & TOK_WS)) : (t0 & ~(L_ISX | L_ISY));
             }
           }
         }
@@ -307,12 +386,17 @@ __global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, De
         st_touched++;
         st_touched_tok += (unsigned long long)n;
 #undef SITE
+#undef NEWTOK
       }
     }
     wave_sync();  // everyone is done with this tile's LDS state before it is restaged
+    if (W.qn >= (unsigned int)(QCAP / 2)) drain_queue<SLOT>(W, pt, db);
     t = t_next;
     n = n_next;
+    word0 = word0_next;
   }
+  wave_sync();
+  drain_queue<SLOT>(W, pt, db);
   agg_flush<WPB * 64>(A, pt, db);
   if (MERGE) {
     my_sites = wave_sum_u64(my_sites);
@@ -428,20 +512,20 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
   if (!ts.n_tiles) return;
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
-                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, 0xffffffffu, 0u, (unsigned long long *)nullptr);
+                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, 0xffffffffu, 0u, 0u, (unsigned long long *)nullptr);
   else
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
-                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, 0xffffffffu, 0u, (unsigned long long *)nullptr);
+                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, 0xffffffffu, 0u, 0u, (unsigned long long *)nullptr);
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
-                        const uint8_t *tokflag, uint32_t self_x, uint32_t self_z, unsigned long long *stats, hipStream_t st) {
+                        const uint8_t *tokflag, uint32_t self_x, uint32_t self_z, uint32_t z_base, unsigned long long *stats, hipStream_t st) {
   if (!ts.n_tiles) return;
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                       tokflag, self_x, self_z, stats);
+                       tokflag, self_x, self_z, z_base, stats);
   else
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                       tokflag, self_x, self_z, stats);
+                       tokflag, self_x, self_z, z_base, stats);
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
                       unsigned int *n_out, unsigned long long *hist, hipStream_t st) {
