@@ -123,6 +123,8 @@ static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
 template <class T>
 static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 template <class T>
+static inline T atomicAnd(T *p, T v) { T o = *p; *p = o & v; return o; }
+template <class T>
 static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T>
 static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }

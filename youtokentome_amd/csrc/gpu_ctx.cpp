@@ -49,7 +49,7 @@ GpuCtx::~GpuCtx() {
   (void)hipSetDevice(device_);
   (void)hipStreamSynchronize(st_);
   for (auto &e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_);
+  DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_); DFREE(d_flagbits_);
   free_class(cls_[0]); free_class(cls_[1]);
   DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_cand_); DFREE(d_cand_n_); DFREE(d_cand_hist_); DFREE(d_recv_);
   if (db_.recs) (void)hipFree(db_.recs);
@@ -179,6 +179,8 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   DFREE(d_tokflag_);
   d_tokflag_ = dmalloc<uint8_t>(tokflag_cap_);
   HIP_CHECK(hipMemsetAsync(d_tokflag_, 0, tokflag_cap_, st_));
+  if (!d_flagbits_) d_flagbits_ = dmalloc<uint32_t>(32768 / 16);
+  HIP_CHECK(hipMemsetAsync(d_flagbits_, 0, 32768 / 16 * 4, st_));
   DFREE(d_flag_upd_);
   d_flag_upd_ = dmalloc<uint32_t>(4 * (size_t)RULES_CAP);
   prev_flag_toks_.clear();
@@ -503,10 +505,10 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   HIP_CHECK(hipMemcpyAsync(d_rules_, h_rules, (size_t)cap * sizeof(RuleSlot), hipMemcpyHostToDevice, st_));
   if (n_upd) {
     HIP_CHECK(hipMemcpyAsync(d_flag_upd_, h_upd, (size_t)n_upd * 8, hipMemcpyHostToDevice, st_));
-    launch_set_tokflag(d_tokflag_, d_flag_upd_, n_upd, st_);
+    launch_set_tokflag(d_tokflag_, d_flagbits_, d_flag_upd_, n_upd, st_);
   }
   t_begin(KT_MERGE);
-  for (int ci = 0; ci < 2; ci++) launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, self_x, self_z, z_base, d_stats_, st_);
+  for (int ci = 0; ci < 2; ci++) launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, d_stats_, st_);
   t_end(KT_MERGE, 0);
   merge_rounds++;
   unsigned int nk = 0;

@@ -110,6 +110,7 @@ class GpuCtx {
   RuleSlot *d_rules_ = nullptr;
   unsigned int rules_cap_ = 0;
   uint8_t *d_tokflag_ = nullptr;
+  uint32_t *d_flagbits_ = nullptr;
   uint32_t tokflag_cap_ = 0;
   uint32_t *d_flag_upd_ = nullptr;
   unsigned long long *d_stats_ = nullptr;

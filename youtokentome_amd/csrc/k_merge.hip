@@ -21,8 +21,8 @@
 namespace yttm {
 
 constexpr int AGG_SLOTS = 128;   // LDS delta aggregator shared by the waves of a workgroup (hot pairs)
-constexpr int QCAP = 128;        // per-wave queue of deltas that missed the aggregator (drained 64 lanes wide)
 constexpr int CAND_CAP_W = 256;  // per-wave list of merge-site candidates awaiting their rule lookup
+constexpr uint32_t FLAG_LDS_IDS = 32768;  // batch flags of ids below this live in an LDS bitmap (2 bits per id, 8 KB)
 
 // Staged (LDS) token word: bit31 = first token of a word, bit30 = id is the y of some batch rule, bit29 = id is the x
 // of some batch rule, bits 0..28 = id.  HBM tokens carry only bit31 + id.
@@ -39,12 +39,12 @@ struct WaveLds {
   uint32_t wsbase[SLOT / 64];              // number of word starts before the chunk
   uint32_t abase[SLOT / 64];               // number of survivors before the chunk
   uint16_t cand[CAND_CAP_W];
-  unsigned int ncand, qn;
-  DeltaRec q[QCAP];
+  unsigned int ncand, pad_;
 };
 struct AggLds {
   unsigned long long key[AGG_SLOTS];
   unsigned long long val[AGG_SLOTS];
+  uint32_t flagbits[FLAG_LDS_IDS / 16];  // 2 bits per token id: bit0 = x of a batch rule, bit1 = y of a batch rule
 };
 
 __device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta) {
@@ -58,13 +58,12 @@ __device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsi
   }
 }
 
-// Count deltas go through two LDS stages before they become HBM atomics (cdna guide, Guideline 12):
-//  1. a small hash shared by the workgroup sums the deltas of hot pairs (early training: few distinct pairs, huge
-//     counts -- without it every tile would hammer the same few HBM addresses);
-//  2. what misses the hash is queued per wave and drained 64 lanes wide between tiles, so the ~2 us latency of a
-//     table update is paid once per 64 updates instead of once per update on the few lanes that own a merge site.
+// Count deltas of hot pairs are summed in a small LDS hash shared by the workgroup before they become HBM atomics
+// (cdna guide, Guideline 12): early in training there are few distinct pairs with huge counts, and without the hash
+// every tile would hammer the same few HBM addresses.  What misses the hash goes straight to the HBM pair table.
 template <int SLOT>
 __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta) {
+  (void)W;
   unsigned int h = (unsigned int)(mix64(key) >> 24) & (AGG_SLOTS - 1);
   for (int probe = 0; probe < 2; probe++) {
     unsigned long long k = ((volatile unsigned long long *)A.key)[h];
@@ -78,32 +77,17 @@ __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, co
     }
     h = (h + 1) & (AGG_SLOTS - 1);
   }
-  const unsigned int i = atomicAdd(&W.qn, 1u);
-  if (i < (unsigned int)QCAP) {
-    W.q[i].key = key;
-    W.q[i].delta = delta;
-  } else {
-    global_emit(pt, db, key, delta);
-  }
-}
-
-template <int SLOT>
-__device__ inline void drain_queue(WaveLds<SLOT> &W, const PairTable &pt, const DeltaBuf &db) {
-  // call wave-converged, after a wave_sync
-  unsigned int n = W.qn;
-  if (n > (unsigned int)QCAP) n = QCAP;
-  for (unsigned int i = (unsigned int)lane_id(); i < n; i += 64) global_emit(pt, db, W.q[i].key, W.q[i].delta);
-  wave_sync();
-  if (lane_id() == 0) W.qn = 0;
-  wave_sync();
+  global_emit(pt, db, key, delta);
 }
 
 template <int NT>
-__device__ inline void agg_init(AggLds &A) {
+__device__ inline void agg_init(AggLds &A, const uint32_t *__restrict__ flagbits_g) {
   for (int s = (int)threadIdx.x; s < AGG_SLOTS; s += NT) {
     A.key[s] = PT_EMPTY;
     A.val[s] = 0;
   }
+  if (flagbits_g)
+    for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += NT) A.flagbits[s] = flagbits_g[s];
 }
 template <int NT>
 __device__ inline void agg_flush(AggLds &A, const PairTable &pt, const DeltaBuf &db) {
@@ -129,14 +113,19 @@ __device__ inline void tile_fetch(uint4 (&r)[SLOT / 256], const TileSet &ts, uin
   }
 }
 
-__device__ inline uint32_t flagged(uint32_t tok, const uint8_t *__restrict__ tokflag) {
-  return tok | ((uint32_t)(tokflag[tok & TOK_MASK] & 3u) << 29);
+__device__ inline uint32_t flagged(uint32_t tok, const AggLds &A, const uint8_t *__restrict__ tokflag) {
+  const uint32_t id = tok & TOK_MASK;
+  uint32_t f;
+  if (id < FLAG_LDS_IDS) f = (A.flagbits[id >> 4] >> ((id & 15u) * 2)) & 3u;
+  else f = tokflag[id] & 3u;
+  return tok | (f << 29);
 }
 
 // registers -> LDS (+ the per-token batch flags, gathered for all 16 tokens of a lane at once so that their latency
-// overlaps), sentinels, word-start masks and per-chunk word-index bases (wave-local)
+// overlaps), sentinels (wave-local).  The batch flags come from the LDS bitmap, so a tile without merge candidates
+// touches no HBM besides its own prefetched tokens.
 template <int SLOT, bool MERGE>
-__device__ inline void tile_stage(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256], int n, const uint8_t *__restrict__ tokflag) {
+__device__ inline void tile_stage(WaveLds<SLOT> &W, const AggLds &A, const uint4 (&r)[SLOT / 256], int n, const uint8_t *__restrict__ tokflag) {
   const int lane = lane_id();
 #pragma unroll
   for (int j = 0; j < SLOT / 256; j++) {
@@ -144,7 +133,7 @@ __device__ inline void tile_stage(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256]
     if (MERGE) {
       const int i = lane + 64 * j;
       if (4 * i < n) {
-        v.x = flagged(v.x, tokflag); v.y = flagged(v.y, tokflag); v.z = flagged(v.z, tokflag); v.w = flagged(v.w, tokflag);
+        v.x = flagged(v.x, A, tokflag); v.y = flagged(v.y, A, tokflag); v.z = flagged(v.z, A, tokflag); v.w = flagged(v.w, A, tokflag);
       }
     }
     reinterpret_cast<uint4 *>(W.tk)[lane + 64 * j] = v;
@@ -173,32 +162,17 @@ __device__ inline long long tile_weight(const WaveLds<SLOT> &W, const uint32_t *
 // adjacency counts the word frequency; a run of L equal tokens counts floor(L/2) for its self pair).
 // MERGE=true: K4, apply the batch rules (z ids are consecutive: rule j of the batch creates z_base + j) and emit the
 // exact count deltas around the merge sites.
-template <int SLOT, int WPB, bool MERGE>
-__global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
-                                                    unsigned int rule_mask, const uint8_t *__restrict__ tokflag, uint32_t self_x,
-                                                    uint32_t self_z, uint32_t z_base,
-                                                    unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
-  __shared__ WaveLds<SLOT> WL[WPB];
-  __shared__ AggLds A;
-  agg_init<WPB * 64>(A);
-  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-  WaveLds<SLOT> &W = WL[wave];
-  if (lane == 0) W.qn = 0;
-  __syncthreads();
-  const uint32_t stride = gridDim.x * WPB;
-  uint32_t t = blockIdx.x * WPB + wave;
-  int n = t < ts.n_tiles ? (int)ts.tile_len[t] : 0;
-  uint32_t word0 = t < ts.n_tiles ? ts.tile_word0[t] : 0;
-  uint4 r[SLOT / 256];
-  if (t < ts.n_tiles) tile_fetch<SLOT>(r, ts, t, n);
-  unsigned long long my_sites = 0, st_touched = 0, st_scanned = 0, st_touched_tok = 0;
-  while (t < ts.n_tiles) {
-    tile_stage<SLOT, MERGE>(W, r, n, tokflag);
-    // prefetch the next tile of this wave
-    const uint32_t t_next = t + stride;
-    const int n_next = t_next < ts.n_tiles ? (int)ts.tile_len[t_next] : 0;
-    const uint32_t word0_next = t_next < ts.n_tiles ? ts.tile_word0[t_next] : 0;
-    if (t_next < ts.n_tiles) tile_fetch<SLOT>(r, ts, t_next, n_next);
+struct TileStats {
+  unsigned long long sites = 0, touched = 0, scanned = 0, touched_tok = 0;
+};
+
+// everything that happens to one staged tile (K3 count or K4 merge)
+template <int SLOT, bool MERGE>
+__device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &ts, const PairTable &pt, const DeltaBuf &db,
+                                    const RuleSlot *__restrict__ rules, unsigned int rule_mask, uint32_t self_x, uint32_t self_z,
+                                    uint32_t z_base, uint32_t t, int n, uint32_t word0, TileStats &S) {
+  const int lane = lane_id();
+  unsigned long long &my_sites = S.sites, &st_touched = S.touched, &st_scanned = S.scanned, &st_touched_tok = S.touched_tok;
     const int nchunks = (n + 63) >> 6;
     st_scanned += (unsigned long long)n;
 
@@ -389,22 +363,60 @@ __global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, De
 #undef NEWTOK
       }
     }
-    wave_sync();  // everyone is done with this tile's LDS state before it is restaged
-    if (W.qn >= (unsigned int)(QCAP / 2)) drain_queue<SLOT>(W, pt, db);
-    t = t_next;
-    n = n_next;
-    word0 = word0_next;
+}
+
+template <int SLOT, int WPB, bool MERGE>
+__global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
+                                                    unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
+                                                    const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
+                                                    unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
+  __shared__ WaveLds<SLOT> WL[WPB];
+  __shared__ AggLds A;
+  agg_init<WPB * 64>(A, MERGE ? flagbits : nullptr);
+  __syncthreads();
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  WaveLds<SLOT> &W = WL[wave];
+  const uint32_t stride = gridDim.x * WPB;
+  const uint32_t NT = ts.n_tiles;
+  // Software pipeline over the tiles of this wave: tokens are fetched TWO tiles ahead into two alternating register
+  // buffers and tile headers three ahead, so that the only HBM latency a tile without merge candidates waits for is a
+  // load issued two tiles earlier.  (vmcnt retires in order: the header load is issued before the token fetch.)
+  uint32_t t = blockIdx.x * WPB + wave;           // tile i
+  int n0 = 0, n1 = 0, n2 = 0;                     // live lengths of tiles i, i+1, i+2
+  uint32_t w0 = 0, w1 = 0, w2 = 0;                // first word index of tiles i, i+1, i+2
+  if (t < NT) { n0 = (int)ts.tile_len[t]; w0 = ts.tile_word0[t]; }
+  if (t + stride < NT) { n1 = (int)ts.tile_len[t + stride]; w1 = ts.tile_word0[t + stride]; }
+  if (t + 2 * stride < NT) { n2 = (int)ts.tile_len[t + 2 * stride]; w2 = ts.tile_word0[t + 2 * stride]; }
+  uint4 ra[SLOT / 256], rb[SLOT / 256];
+  if (t < NT) tile_fetch<SLOT>(ra, ts, t, n0);
+  if (t + stride < NT) tile_fetch<SLOT>(rb, ts, t + stride, n1);
+  TileStats S;
+#define PIPE_STEP(R)                                                                                                \
+  {                                                                                                                 \
+    tile_stage<SLOT, MERGE>(W, A, R, n0, tokflag);                                                                  \
+    int n3 = 0;                                                                                                     \
+    uint32_t w3 = 0;                                                                                                \
+    if (t + 3 * stride < NT) { n3 = (int)ts.tile_len[t + 3 * stride]; w3 = ts.tile_word0[t + 3 * stride]; }         \
+    if (t + 2 * stride < NT) tile_fetch<SLOT>(R, ts, t + 2 * stride, n2);                                            \
+    process_tile<SLOT, MERGE>(W, A, ts, pt, db, rules, rule_mask, self_x, self_z, z_base, t, n0, w0, S);              \
+    wave_sync(); /* everyone is done with this tile's LDS state before it is restaged */                            \
+    t += stride;                                                                                                    \
+    n0 = n1; w0 = w1; n1 = n2; w1 = w2; n2 = n3; w2 = w3;                                                           \
   }
-  wave_sync();
-  drain_queue<SLOT>(W, pt, db);
+  while (t < NT) {
+    PIPE_STEP(ra);
+    if (t >= NT) break;
+    PIPE_STEP(rb);
+  }
+#undef PIPE_STEP
   agg_flush<WPB * 64>(A, pt, db);
   if (MERGE) {
-    my_sites = wave_sum_u64(my_sites);
+    S.sites = wave_sum_u64(S.sites);
     if (lane == 0) {
-      if (my_sites) atomicAdd(&stats[0], my_sites);
-      if (st_touched) atomicAdd(&stats[1], st_touched);
-      if (st_scanned) atomicAdd(&stats[2], st_scanned);
-      if (st_touched_tok) atomicAdd(&stats[3], st_touched_tok);
+      if (S.sites) atomicAdd(&stats[0], S.sites);
+      if (S.touched) atomicAdd(&stats[1], S.touched);
+      if (S.scanned) atomicAdd(&stats[2], S.scanned);
+      if (S.touched_tok) atomicAdd(&stats[3], S.touched_tok);
     }
   }
 }
@@ -489,9 +501,18 @@ __global__ __launch_bounds__(BLOCK) void k_pt_apply(PairTable pt, const DeltaRec
   for (; i < n; i += stride) pt_add(pt, recs[i].key, recs[i].delta);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_set_tokflag(uint8_t *__restrict__ tokflag, const uint32_t *__restrict__ upd, unsigned int n) {
+// per-round batch flags: byte table for every id + packed 2-bit copy of the first FLAG_LDS_IDS ids (staged into LDS by K4)
+__global__ __launch_bounds__(BLOCK) void k_set_tokflag(uint8_t *__restrict__ tokflag, uint32_t *__restrict__ flagbits,
+                                                       const uint32_t *__restrict__ upd, unsigned int n) {
   unsigned int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i < n) tokflag[upd[2 * i]] = (uint8_t)upd[2 * i + 1];
+  if (i >= n) return;
+  const uint32_t id = upd[2 * i], v = upd[2 * i + 1] & 3u;
+  tokflag[id] = (uint8_t)v;
+  if (id < 32768u) {
+    const uint32_t sh = (id & 15u) * 2;
+    atomicAnd(&flagbits[id >> 4], ~(3u << sh));
+    atomicOr(&flagbits[id >> 4], v << sh);
+  }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_fill_u64(unsigned long long *__restrict__ p, unsigned long long v, unsigned long long n) {
@@ -512,20 +533,23 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
   if (!ts.n_tiles) return;
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
-                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, 0xffffffffu, 0u, 0u, (unsigned long long *)nullptr);
+                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
+                       (unsigned long long *)nullptr);
   else
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
-                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, 0xffffffffu, 0u, 0u, (unsigned long long *)nullptr);
+                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
+                       (unsigned long long *)nullptr);
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
-                        const uint8_t *tokflag, uint32_t self_x, uint32_t self_z, uint32_t z_base, unsigned long long *stats, hipStream_t st) {
+                        const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
+                        unsigned long long *stats, hipStream_t st) {
   if (!ts.n_tiles) return;
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                       tokflag, self_x, self_z, z_base, stats);
+                       tokflag, flagbits, self_x, self_z, z_base, stats);
   else
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                       tokflag, self_x, self_z, z_base, stats);
+                       tokflag, flagbits, self_x, self_z, z_base, stats);
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
                       unsigned int *n_out, unsigned long long *hist, hipStream_t st) {
@@ -550,9 +574,9 @@ void launch_pt_apply(const PairTable &pt, const DeltaRec *recs, unsigned long lo
   if (b > 256 * 16) b = 256 * 16;
   hipLaunchKernelGGL(k_pt_apply, dim3((unsigned int)b), dim3(BLOCK), 0, st, pt, recs, n);
 }
-void launch_set_tokflag(uint8_t *tokflag, const uint32_t *upd, unsigned int n, hipStream_t st) {
+void launch_set_tokflag(uint8_t *tokflag, uint32_t *flagbits, const uint32_t *upd, unsigned int n, hipStream_t st) {
   if (!n) return;
-  hipLaunchKernelGGL(k_set_tokflag, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, tokflag, upd, n);
+  hipLaunchKernelGGL(k_set_tokflag, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, tokflag, flagbits, upd, n);
 }
 void launch_fill_u64(unsigned long long *p, unsigned long long v, unsigned long long n, hipStream_t st) {
   if (!n) return;

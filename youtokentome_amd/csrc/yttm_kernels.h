@@ -47,14 +47,14 @@ void launch_tile_len(const unsigned long long *tile_start, unsigned int n_tiles,
 // cls: 0 = class A tiles (slot 1024), 1 = class B tiles (slot 4096)
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st);
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
-                        const uint8_t *tokflag, uint32_t self_x, uint32_t self_z, uint32_t z_base, unsigned long long *stats,
-                        hipStream_t st);
+                        const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
+                        unsigned long long *stats, hipStream_t st);
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
                       unsigned int *n_out, unsigned long long *hist, hipStream_t st);
 void launch_pt_rehash(const PairTable &src, const PairTable &dst, hipStream_t st);
 void launch_pt_query(const PairTable &pt, const unsigned long long *keys, unsigned int n, unsigned long long *out, hipStream_t st);
 void launch_pt_apply(const PairTable &pt, const DeltaRec *recs, unsigned long long n, hipStream_t st);
-void launch_set_tokflag(uint8_t *tokflag, const uint32_t *upd, unsigned int n, hipStream_t st);
+void launch_set_tokflag(uint8_t *tokflag, uint32_t *flagbits, const uint32_t *upd, unsigned int n, hipStream_t st);
 void launch_fill_u64(unsigned long long *p, unsigned long long v, unsigned long long n, hipStream_t st);
 
 // ---- batch encode (k_encode.hip)
