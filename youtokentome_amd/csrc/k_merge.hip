@@ -121,73 +121,29 @@ __device__ inline uint32_t flagged(uint32_t tok, const AggLds &A, const uint8_t 
   return tok | (f << 29);
 }
 
-// Batch flags for the 16 tokens a lane holds, and the merge-site candidate test, entirely in registers: a tile without
-// any (x-flagged, y-flagged) adjacency -- the common case late in training -- is never staged into LDS at all.
-// Lane l holds tokens 256 j + 4 l + {0,1,2,3} in r[j]; the right neighbour of a lane's last token comes by shuffle.
-template <int SLOT>
-__device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const AggLds &A, const uint8_t *__restrict__ tokflag, uint32_t self_x) {
+// registers -> LDS (+ the per-token batch flags, gathered for all 16 tokens of a lane at once so that their latency
+// overlaps), sentinels (wave-local).  The batch flags come from the LDS bitmap, so a tile without merge candidates
+// touches no HBM besides its own prefetched tokens.
+template <int SLOT, bool MERGE>
+__device__ inline void tile_stage(WaveLds<SLOT> &W, const AggLds &A, const uint4 (&r)[SLOT / 256], int n, const uint8_t *__restrict__ tokflag) {
   const int lane = lane_id();
 #pragma unroll
   for (int j = 0; j < SLOT / 256; j++) {
-    if (256 * j < n) {
-      r[j].x = flagged(r[j].x, A, tokflag); r[j].y = flagged(r[j].y, A, tokflag);
-      r[j].z = flagged(r[j].z, A, tokflag); r[j].w = flagged(r[j].w, A, tokflag);
+    uint4 v = r[j];
+    if (MERGE) {
+      const int i = lane + 64 * j;
+      if (4 * i < n) {
+        v.x = flagged(v.x, A, tokflag); v.y = flagged(v.y, A, tokflag); v.z = flagged(v.z, A, tokflag); v.w = flagged(v.w, A, tokflag);
+      }
     }
+    reinterpret_cast<uint4 *>(W.tk)[lane + 64 * j] = v;
   }
-  bool cand = false;
-#define PAIR_TEST(T0, T1, P)                                                                        \
-  if ((P) + 1 < n && !((T1)&TOK_WS))                                                                 \
-    cand = cand || (((T0)&L_ISX) && ((T1)&L_ISY)) || ((((T0)&L_ID) == self_x) && (((T1)&L_ID) == self_x));
-#pragma unroll
-  for (int j = 0; j < SLOT / 256; j++) {
-    if (256 * j < n) {
-      uint32_t nx = __shfl_down(r[j].x, 1);
-      uint32_t nx0 = TOK_WS;
-      if (j + 1 < SLOT / 256) nx0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
-      if (lane == 63) nx = nx0;
-      const int p = 256 * j + 4 * lane;
-      PAIR_TEST(r[j].x, r[j].y, p)
-      PAIR_TEST(r[j].y, r[j].z, p + 1)
-      PAIR_TEST(r[j].z, r[j].w, p + 2)
-      PAIR_TEST(r[j].w, nx, p + 3)
-    }
-  }
-#undef PAIR_TEST
-  return __ballot(cand) != 0;
-}
-
-// registers -> LDS, sentinels (wave-local)
-template <int SLOT>
-__device__ inline void tile_stage(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256], int n) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int j = 0; j < SLOT / 256; j++)
-    if (256 * j < n) reinterpret_cast<uint4 *>(W.tk)[lane + 64 * j] = r[j];
   wave_sync();
   if (lane == 0) {
     W.tk[n] = TOK_WS;  // sentinel: "next token starts a word" => no adjacency past the end
     W.tk[n + 1] = TOK_WS;
     W.tk[n + 2] = TOK_WS;
     W.ncand = 0;
-  }
-  wave_sync();
-}
-
-// word-start masks and per-chunk word-index bases of the staged tile (needed for the word weights)
-template <int SLOT>
-__device__ inline void tile_word_masks(WaveLds<SLOT> &W, int n) {
-  const int lane = lane_id();
-  const int nchunks = (n + 63) >> 6;
-  uint32_t wbase = 0;
-  for (int c = 0; c < nchunks; c++) {
-    const int p = c * 64 + lane;
-    const bool ws = p < n && (W.tk[p] & TOK_WS);
-    const unsigned long long m = __ballot(ws);
-    if (lane == 0) {
-      W.wsmask[c] = m;
-      W.wsbase[c] = wbase;
-    }
-    wbase += (uint32_t)__popcll(m);
   }
   wave_sync();
 }
@@ -220,15 +176,16 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
     const int nchunks = (n + 63) >> 6;
     st_scanned += (unsigned long long)n;
 
-    if (!MERGE) tile_word_masks<SLOT>(W, n);
-    // ---- phase 1a (MERGE): merge-site candidates = x-flagged token followed by a y-flagged token ----------------------
+    // ---- phase 1a: word-start masks; (MERGE) merge-site candidates = x-flagged token followed by a y-flagged token ----
+    uint32_t wbase = 0;
     bool any = false;
-    for (int c = 0; MERGE && c < nchunks; c++) {
+    for (int c = 0; c < nchunks; c++) {
       const int p = c * 64 + lane;
-      bool self_site = false;
+      bool ws = false, self_site = false;
       if (p < n) {
         const uint32_t t0 = W.tk[p];
-        {
+        ws = t0 & TOK_WS;
+        if (MERGE) {
           const uint32_t t1 = W.tk[p + 1];
           if (!(t1 & TOK_WS)) {
             const uint32_t a = t0 & L_ID, b = t1 & L_ID;
@@ -259,8 +216,14 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
           }
         }
       }
-      const unsigned long long sm = __ballot(self_site);
-      if (lane == 0) W.sitemask[c] = sm;
+      const unsigned long long m = __ballot(ws);
+      const unsigned long long sm = MERGE ? __ballot(self_site) : 0ull;
+      if (lane == 0) {
+        W.wsmask[c] = m;
+        W.wsbase[c] = wbase;
+        if (MERGE) W.sitemask[c] = sm;
+      }
+      wbase += (uint32_t)__popcll(m);
       any = any || sm != 0;
     }
     wave_sync();
@@ -309,7 +272,6 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         any = __ballot(any) != 0;
       }
       if (any) {
-        tile_word_masks<SLOT>(W, n);
 #define SITE(q) ((q) >= 0 && (((W.sitemask[(q) >> 6] >> ((q)&63)) & 1ull) != 0))
 #define NEWTOK(q) (z_base + (uint32_t)W.ridx[(q)])
         // ---- phase 2: count deltas around the sites + survivor masks ---------------------------------------------------
@@ -431,18 +393,13 @@ __global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, De
   TileStats S;
 #define PIPE_STEP(R)                                                                                                \
   {                                                                                                                 \
-    const bool dirty = MERGE ? reg_candidates<SLOT>(R, n0, A, tokflag, self_x) : true;                               \
-    if (dirty) tile_stage<SLOT>(W, R, n0);                                                                          \
+    tile_stage<SLOT, MERGE>(W, A, R, n0, tokflag);                                                                  \
     int n3 = 0;                                                                                                     \
     uint32_t w3 = 0;                                                                                                \
     if (t + 3 * stride < NT) { n3 = (int)ts.tile_len[t + 3 * stride]; w3 = ts.tile_word0[t + 3 * stride]; }         \
     if (t + 2 * stride < NT) tile_fetch<SLOT>(R, ts, t + 2 * stride, n2);                                            \
-    if (dirty) {                                                                                                    \
-      process_tile<SLOT, MERGE>(W, A, ts, pt, db, rules, rule_mask, self_x, self_z, z_base, t, n0, w0, S);            \
-      wave_sync(); /* everyone is done with this tile's LDS state before it is restaged */                          \
-    } else {                                                                                                        \
-      S.scanned += (unsigned long long)n0;                                                                          \
-    }                                                                                                               \
+    process_tile<SLOT, MERGE>(W, A, ts, pt, db, rules, rule_mask, self_x, self_z, z_base, t, n0, w0, S);              \
+    wave_sync(); /* everyone is done with this tile's LDS state before it is restaged */                            \
     t += stride;                                                                                                    \
     n0 = n1; w0 = w1; n1 = n2; w1 = w2; n2 = n3; w2 = w3;                                                           \
   }
