@@ -91,7 +91,8 @@ def main():
         comm_handle = _init_rccl(L, dist, torch, dev, rank, world, local_rank)
 
     tmpdir = tempfile.mkdtemp(prefix="yttm_bench_")
-    model_path = os.path.join(tmpdir, f"bench_rank{rank}.model")
+    # one model file per job: rank 0 writes it (single node), every rank's encoder loads it afterwards
+    model_path = os.path.join(tempfile.gettempdir(), "yttm_bench_%s.model" % os.environ.get("MASTER_PORT", str(os.getpid())))
     err = C.create_string_buffer(_lib.ERRLEN)
     rep = C.create_string_buffer(8192)
 
@@ -175,6 +176,7 @@ def main():
     if "encode" in out:
         out["encode"].pop("_host_sample", None)
         out["encode"].pop("_sample_ids", None)
+        out["encode"].pop("_model_path", None)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -225,6 +227,7 @@ def _bench_encode(L, _lib, torch, np, gen, dev, local_rank, model_path, args, ra
                         "unit": "GB/s", "frac": round(alg_bytes / 1e9 / (kavg / 1e3) / HBM_PEAK_GBS, 4), "traffic": None}}
     # FNV-1a-64 of (len, ids...) per sentence over a bounded sample, for the parity line next to the CPU baseline
     res["_host_sample"] = host[: 1_000_000 * (line + 1)]
+    res["_model_path"] = model_path
     m = min(n_sent, 1_000_000)
     ids = np.zeros(n_ids.value, dtype=np.int32)
     off = np.zeros(n_sent + 1, dtype=np.uint64)
@@ -273,8 +276,7 @@ def _cpu_baseline(host, args, tmpdir, enc):
         lines = os.path.join(tmpdir, "enc_sample.txt")
         with open(lines, "wb") as f:
             f.write(enc["_host_sample"])
-        gpu_model = os.path.join(tmpdir, "bench_rank0.model")
-        r = subprocess.run([ref, "encode_bench", gpu_model, lines, "8", "0.0", "1000000"], capture_output=True, text=True)
+        r = subprocess.run([ref, "encode_bench", enc["_model_path"], lines, "8", "0.0", "1000000"], capture_output=True, text=True)
         try:
             j = json.loads(r.stdout.strip().splitlines()[-1])
             ids, off = enc["_sample_ids"]
@@ -286,6 +288,7 @@ def _cpu_baseline(host, args, tmpdir, enc):
     if enc is not None:
         enc.pop("_host_sample", None)
         enc.pop("_sample_ids", None)
+        enc.pop("_model_path", None)
     return res
 
 

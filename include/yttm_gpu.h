@@ -19,6 +19,10 @@ int yttm_gpu_ctx_create(int device, yttm_ctx **out);
 void yttm_gpu_ctx_destroy(yttm_ctx *ctx);
 const char *yttm_gpu_last_error(void);
 
+/* multi-GPU: attach a communicator (yttm_comm* from include/yttm_mi355x.h, passed as void*) before the stages run;
+ * the context then holds ITS shard and the pair table holds GLOBAL counts */
+int yttm_gpu_ctx_set_comm(yttm_ctx *ctx, void *comm);
+
 /* corpus bytes: copy from host, or adopt a buffer already resident in HBM (16-byte aligned device pointer) */
 int yttm_gpu_upload_corpus(yttm_ctx *ctx, const uint8_t *utf8, uint64_t n);
 int yttm_gpu_attach_corpus(yttm_ctx *ctx, const void *device_ptr, uint64_t n);

@@ -76,6 +76,29 @@ int yttm_vocab_size(yttm_encoder *enc);
 /* vector<string> vocabulary() const                                   bpe.h:64, bpe.cpp:1884; yttm.pyx:163-165 */
 int yttm_vocabulary(yttm_encoder *enc, char **blob, uint64_t **offsets, uint64_t *n);
 
+/* ---- multi-GPU (one process per GPU) ---------------------------------------------------------------
+ * The corpus shards across ranks; the only exchanged quantities are the char histogram (once) and sparse pair-count
+ * deltas (after the initial count and after every merge round) -- the RCCL form of the reference's main thread summing
+ * per-thread maps (bpe.cpp:1099-1108, :1245-1251).  Every rank passes ITS shard to the *_comm entry points; rank 0
+ * writes the model file. */
+typedef struct yttm_comm yttm_comm;
+/* RCCL over xGMI: rank 0 makes the id, the application broadcasts its 128 bytes, every rank creates its communicator */
+int yttm_comm_rccl_unique_id(uint8_t out[128]);
+int yttm_comm_rccl_create(const uint8_t id[128], int rank, int world, int device, yttm_comm **out);
+/* host-callback transport (torch.distributed/gloo, MPI, ...): in-place sum of n uint64; gather of the other ranks' bytes */
+typedef int (*yttm_allreduce_u64_fn)(void *user, unsigned long long *buf, size_t n);
+typedef int (*yttm_allgather_bytes_fn)(void *user, const void *send, size_t send_bytes, void *recv, size_t recv_cap,
+                                       unsigned long long *recv_bytes);
+int yttm_comm_callback_create(int rank, int world, yttm_allreduce_u64_fn allreduce, yttm_allgather_bytes_fn allgather,
+                              void *user, yttm_comm **out);
+void yttm_comm_destroy(yttm_comm *comm);
+int yttm_train_bpe_from_device_comm(const void *d_text, uint64_t n, const char *model_path, int vocab_size, double coverage,
+                                    int pad_id, int unk_id, int bos_id, int eos_id, int device, int profile,
+                                    yttm_comm *comm, char *report_json, int report_len, char *err, int errlen);
+int yttm_train_bpe_from_memory_comm(const uint8_t *text, uint64_t n, const char *model_path, int vocab_size, double coverage,
+                                    int pad_id, int unk_id, int bos_id, int eos_id, int device, yttm_comm *comm,
+                                    char *report_json, int report_len, char *err, int errlen);
+
 void yttm_free(void *p);
 /* "gfx950 MI355X ..." or an error text when no usable GPU is visible */
 int yttm_device_info(int device, char *buf, int buflen);

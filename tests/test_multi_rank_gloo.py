@@ -1,0 +1,49 @@
+"""N>1 path on CPU: two ranks (torch.distributed/gloo on 127.0.0.1), each with its own corpus shard, exchange char
+histograms and pair-count deltas through the library's communicator interface; the model must be byte-identical to the
+oracle trained on the whole corpus.  (Kernels run under the HIP emulator; the RCCL transport itself needs GPUs.)"""
+import filecmp
+import os
+import random
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import gen
+import oracle_lib as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_world(corpus, model, vocab, coverage, world, lib):
+    port = str(free_port())
+    env = dict(os.environ, YTTM_AMD_LIB=lib)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_train_worker.py"), str(r), str(world), port, corpus, model, str(vocab),
+                               repr(coverage)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, (o, e[-3000:])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_ranks_equal_single_oracle(tmp_path, sim_lib, world):
+    rng = random.Random(world)
+    cases = [(gen.readme_corpus(120, 80, seed=2), 300, 1.0),
+             (gen.unicode_text(rng, 4000, "mix", p_invalid=0.01), 90, 0.9),
+             (("aaaa aaaaa abababab aabbaabb bbbbbb ab aaab baaa " * 12).encode(), 40, 1.0)]
+    for i, (text, vocab, cov) in enumerate(cases):
+        corpus = str(tmp_path / f"c{i}.txt")
+        open(corpus, "wb").write(text)
+        m_mp, m_ora = str(tmp_path / f"mp{i}.model"), str(tmp_path / f"ora{i}.model")
+        run_world(corpus, m_mp, vocab, cov, world, sim_lib)
+        O.train(text, m_ora, vocab, cov)
+        assert filecmp.cmp(m_mp, m_ora, shallow=False), f"case {i}"

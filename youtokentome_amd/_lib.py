@@ -21,9 +21,10 @@ EXPORTS = [
     "yttm_train_bpe", "yttm_train_bpe_from_memory", "yttm_train_bpe_from_device", "yttm_encoder_create",
     "yttm_encoder_destroy", "yttm_encode_as_ids", "yttm_encode_as_subwords", "yttm_encode_device", "yttm_encode_fetch",
     "yttm_id_to_subword", "yttm_subword_to_id", "yttm_decode", "yttm_vocab_size", "yttm_vocabulary", "yttm_free",
-    "yttm_device_info",
+    "yttm_device_info", "yttm_comm_rccl_unique_id", "yttm_comm_rccl_create", "yttm_comm_callback_create",
+    "yttm_comm_destroy", "yttm_train_bpe_from_device_comm", "yttm_train_bpe_from_memory_comm",
     # include/yttm_gpu.h
-    "yttm_gpu_ctx_create", "yttm_gpu_ctx_destroy", "yttm_gpu_last_error", "yttm_gpu_upload_corpus",
+    "yttm_gpu_ctx_create", "yttm_gpu_ctx_destroy", "yttm_gpu_ctx_set_comm", "yttm_gpu_last_error", "yttm_gpu_upload_corpus",
     "yttm_gpu_attach_corpus", "yttm_gpu_char_hist", "yttm_gpu_build_word_table", "yttm_gpu_download_word_table",
     "yttm_gpu_pair_count", "yttm_gpu_download_pairs", "yttm_gpu_merge_apply", "yttm_gpu_pair_query",
     "yttm_gpu_candidates",
@@ -62,8 +63,20 @@ def load():
     L.yttm_free.argtypes = [cvp]
     L.yttm_free.restype = None
     L.yttm_device_info.argtypes = [ci, cs, ci]
+    ALLREDUCE_FN = C.CFUNCTYPE(ci, cvp, C.POINTER(C.c_ulonglong), C.c_size_t)
+    ALLGATHER_FN = C.CFUNCTYPE(ci, cvp, cvp, C.c_size_t, cvp, C.c_size_t, C.POINTER(C.c_ulonglong))
+    L.ALLREDUCE_FN, L.ALLGATHER_FN = ALLREDUCE_FN, ALLGATHER_FN
+    L.yttm_comm_callback_create.argtypes = [ci, ci, ALLREDUCE_FN, ALLGATHER_FN, cvp, C.POINTER(cvp)]
+    L.yttm_comm_destroy.argtypes = [cvp]
+    L.yttm_comm_destroy.restype = None
+    L.yttm_train_bpe_from_device_comm.argtypes = [cvp, C.c_uint64, cs, ci, cd, ci, ci, ci, ci, ci, ci, cvp, cs, ci, cs, ci]
+    L.yttm_train_bpe_from_memory_comm.argtypes = [cs, C.c_uint64, cs, ci, cd, ci, ci, ci, ci, ci, cvp, cs, ci, cs, ci]
+    if hasattr(L, "yttm_comm_rccl_create"):  # absent from the emulator build (no RCCL there)
+        L.yttm_comm_rccl_unique_id.argtypes = [u8p]
+        L.yttm_comm_rccl_create.argtypes = [u8p, ci, ci, ci, C.POINTER(cvp)]
     L.yttm_gpu_ctx_create.argtypes = [ci, C.POINTER(cvp)]
     L.yttm_gpu_ctx_destroy.argtypes = [cvp]
+    L.yttm_gpu_ctx_set_comm.argtypes = [cvp, cvp]
     L.yttm_gpu_ctx_destroy.restype = None
     L.yttm_gpu_last_error.restype = cs
     L.yttm_gpu_upload_corpus.argtypes = [cvp, cs, C.c_uint64]

@@ -31,7 +31,7 @@ static BpeConfig make_cfg(double coverage, int n_threads, int pad, int unk, int 
   c.special_tokens.eos_id = eos;
   return c;
 }
-static void report_to_json(const TrainReport &r, char *buf, int len) {
+void yttm_report_to_json(const TrainReport &r, char *buf, int len) {
   if (!buf || len <= 0) return;
   static const char *names[8] = {"char_hist", "segments", "dedup", "build", "pair_count", "merge_apply", "cand_scan", "encode"};
   std::string s = "{";
@@ -71,7 +71,7 @@ int yttm_train_bpe_from_memory(const uint8_t *text, uint64_t n, const char *mode
                                int unk_id, int bos_id, int eos_id, int device, char *report_json, int report_len, char *err, int errlen) {
   TrainReport rep;
   Status s = train_bpe_from_memory(text, n, model_path ? model_path : "", vocab_size, make_cfg(coverage, 1, pad_id, unk_id, bos_id, eos_id), device, &rep);
-  if (s.ok()) report_to_json(rep, report_json, report_len);
+  if (s.ok()) yttm_report_to_json(rep, report_json, report_len);
   return finish(s, err, errlen);
 }
 
@@ -80,7 +80,7 @@ int yttm_train_bpe_from_device(const void *d_text, uint64_t n, const char *model
   TrainReport rep;
   Status s = train_bpe_from_device(d_text, n, model_path ? model_path : "", vocab_size, make_cfg(coverage, 1, pad_id, unk_id, bos_id, eos_id), device,
                                    &rep, nullptr, profile != 0);
-  if (s.ok()) report_to_json(rep, report_json, report_len);
+  if (s.ok()) yttm_report_to_json(rep, report_json, report_len);
   return finish(s, err, errlen);
 }
 
@@ -233,6 +233,7 @@ void yttm_gpu_ctx_destroy(yttm_ctx *c) {
   delete c->g;
   delete c;
 }
+int yttm_gpu_ctx_set_comm(yttm_ctx *c, void *comm) { GUARD(c->g->set_comm((Comm *)comm)) }
 int yttm_gpu_upload_corpus(yttm_ctx *c, const uint8_t *utf8, uint64_t n) { GUARD(c->g->upload_corpus(utf8, n)) }
 int yttm_gpu_attach_corpus(yttm_ctx *c, const void *p, uint64_t n) { GUARD(c->g->attach_corpus(p, n)) }
 

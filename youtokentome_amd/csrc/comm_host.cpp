@@ -1,0 +1,102 @@
+// comm_host.cpp -- host-callback exchange (any transport the application has: torch.distributed/gloo, MPI, ...), and
+// the communicator-taking training entry points.  The callback variant stages through host memory; it exists so that
+// the N>1 control flow can run (and is tested) where no RCCL/xGMI is available.
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/yttm_mi355x.h"
+#include "gpu_ctx.h"
+#include "host_core.h"
+
+namespace yttm {
+
+struct CallbackComm : Comm {
+  yttm_allreduce_u64_fn allreduce = nullptr;
+  yttm_allgather_bytes_fn allgather = nullptr;
+  void *user = nullptr;
+  std::vector<unsigned long long> h_buf;
+  std::vector<unsigned char> h_send, h_recv;
+  void allreduce_sum_u64(unsigned long long *dev, size_t n, hipStream_t st) override {
+    h_buf.resize(n);
+    HIP_CHECK(hipMemcpyAsync(h_buf.data(), dev, n * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (allreduce(user, h_buf.data(), n) != 0) throw GpuError{"allreduce callback failed"};
+    HIP_CHECK(hipMemcpyAsync(dev, h_buf.data(), n * 8, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+  size_t allgather_recs(const DeltaRec *send, size_t n_local, DeltaRec *recv, size_t cap, hipStream_t st) override {
+    h_send.resize(n_local * sizeof(DeltaRec) + 1);
+    if (n_local) HIP_CHECK(hipMemcpyAsync(h_send.data(), send, n_local * sizeof(DeltaRec), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    h_recv.resize(cap * sizeof(DeltaRec) + 1);
+    unsigned long long got = 0;
+    // the callback returns the concatenated bytes of all OTHER ranks
+    if (allgather(user, h_send.data(), n_local * sizeof(DeltaRec), h_recv.data(), cap * sizeof(DeltaRec), &got) != 0)
+      throw GpuError{"allgather callback failed"};
+    size_t n = (size_t)(got / sizeof(DeltaRec));
+    if (n > cap) return n;
+    if (n) HIP_CHECK(hipMemcpyAsync(recv, h_recv.data(), n * sizeof(DeltaRec), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    return n;
+  }
+};
+
+}  // namespace yttm
+
+using namespace yttm;
+
+static void put_err(char *err, int errlen, const std::string &m) {
+  if (err && errlen > 0) snprintf(err, (size_t)errlen, "%s", m.c_str());
+}
+static BpeConfig make_cfg(double coverage, int pad, int unk, int bos, int eos) {
+  BpeConfig c;
+  c.character_coverage = coverage;
+  c.n_threads = 1;
+  c.special_tokens.pad_id = pad;
+  c.special_tokens.unk_id = unk;
+  c.special_tokens.bos_id = bos;
+  c.special_tokens.eos_id = eos;
+  return c;
+}
+void yttm_report_to_json(const TrainReport &r, char *buf, int len);  // capi.cpp
+
+extern "C" {
+
+int yttm_comm_callback_create(int rank, int world, yttm_allreduce_u64_fn allreduce, yttm_allgather_bytes_fn allgather, void *user,
+                              yttm_comm **out) {
+  CallbackComm *c = new CallbackComm();
+  c->rank = rank;
+  c->world = world;
+  c->allreduce = allreduce;
+  c->allgather = allgather;
+  c->user = user;
+  *out = (yttm_comm *)static_cast<Comm *>(c);
+  return 0;
+}
+
+void yttm_comm_destroy(yttm_comm *c) { delete (Comm *)c; }
+
+int yttm_train_bpe_from_device_comm(const void *d_text, uint64_t n, const char *model_path, int vocab_size, double coverage, int pad_id,
+                                    int unk_id, int bos_id, int eos_id, int device, int profile, yttm_comm *comm, char *report_json,
+                                    int report_len, char *err, int errlen) {
+  TrainReport rep;
+  Status s = train_bpe_from_device(d_text, n, model_path ? model_path : "", vocab_size, make_cfg(coverage, pad_id, unk_id, bos_id, eos_id), device,
+                                   &rep, (Comm *)comm, profile != 0);
+  if (s.ok()) yttm_report_to_json(rep, report_json, report_len);
+  else put_err(err, errlen, s.message);
+  return s.code;
+}
+
+int yttm_train_bpe_from_memory_comm(const uint8_t *text, uint64_t n, const char *model_path, int vocab_size, double coverage, int pad_id,
+                                    int unk_id, int bos_id, int eos_id, int device, yttm_comm *comm, char *report_json, int report_len,
+                                    char *err, int errlen) {
+  TrainReport rep;
+  Status s = train_bpe_from_memory(text, n, model_path ? model_path : "", vocab_size, make_cfg(coverage, pad_id, unk_id, bos_id, eos_id), device,
+                                   &rep, (Comm *)comm);
+  if (s.ok()) yttm_report_to_json(rep, report_json, report_len);
+  else put_err(err, errlen, s.message);
+  return s.code;
+}
+
+}  // extern "C"

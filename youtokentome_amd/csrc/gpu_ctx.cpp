@@ -440,7 +440,8 @@ void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned lon
 // ------------------------------------------------------------------------------------------------- K4
 void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts) {
   HIP_CHECK(hipSetDevice(device_));
-  if (!k || !n_tiles) return;
+  if (!k) return;
+  if (!n_tiles && !(comm_ && comm_->world > 1)) return;  // a rank without words still takes part in the exchange
   if (k > RULES_CAP / 2) throw GpuError{"merge_apply: batch too large"};
   // new pairs this round: every site adds <= 2 neighbours (+ the z,z run pair); distinct new keys per rule are also
   // bounded by the number of live token types on either side

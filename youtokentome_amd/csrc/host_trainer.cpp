@@ -297,6 +297,7 @@ Status train_bpe(const std::string &input_path, const std::string &model_path, i
   unsigned long long lo = 0, hi = size;
   if (comm && comm->world > 1) {
     auto split = [&](int i) {
+      if (i == 0) return 0ull;  // split_pos[0] = 0 (bpe.cpp:865)
       unsigned long long c = size * (unsigned long long)i / (unsigned long long)comm->world;
       while (c < size && !(map[c] == 32 || (map[c] >= 9 && map[c] <= 13))) c++;
       return c;
