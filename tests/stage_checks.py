@@ -186,3 +186,52 @@ def check_encode_vs_oracle(model_path, sentences, flags=((0, 0, 0), (1, 1, 0), (
                 assert str(ex) == str(ex2)
             continue
         assert bpe.encode(sentences, yttm.OutputType.ID, bos=b, eos=e, reverse=r) == want
+
+
+def check_dropout_extremes(model_path, sentences):
+    """p -> 0 must reproduce the deterministic encoder; p = 1 must leave every word at character level
+    (DropoutQueue skips every event, bpe.cpp:1430-1437)."""
+    import youtokentome_amd as yttm
+    bpe = yttm.BPE(model_path)
+    m = O.Model(model_path)
+    raw = [s.encode() for s in sentences]
+    base = bpe.encode(sentences, yttm.OutputType.ID)
+    assert bpe.encode(sentences, yttm.OutputType.ID, dropout_prob=1e-18) == base
+    O.rng_reset()
+    assert bpe.encode(sentences, yttm.OutputType.ID, dropout_prob=1.0) == m.encode(raw, dropout_prob=1.0)
+    got = bpe.encode(sentences, yttm.OutputType.ID, bos=True, eos=True, reverse=True, dropout_prob=0.3)
+    for g, s in zip(got, sentences):
+        # whatever was dropped, decoding gives the text back
+        assert bpe.decode([g[::-1]], ignore_ids=[2, 3])[0] == " ".join(s.split())
+
+
+def dropout_stats(ids_lists, vocab):
+    lens = np.array([len(x) for x in ids_lists], dtype=np.float64)
+    hist = np.bincount(np.concatenate([np.asarray(x, dtype=np.int64) for x in ids_lists if len(x)]), minlength=vocab).astype(np.float64)
+    return lens, hist
+
+
+def check_dropout_distribution(model_path, sentences, p, vocab):
+    """BASELINE.json configs[4]: per-lane RNG cannot replay the reference's global mt19937, so compare distributions with
+    the bit-exact oracle emulation of the reference at n_threads=1: mean ids/sentence, sentence-length histogram
+    (two-sample KS) and unigram id histogram (chi-square per degree of freedom)."""
+    import youtokentome_amd as yttm
+    bpe = yttm.BPE(model_path)
+    m = O.Model(model_path)
+    O.rng_reset()
+    want = m.encode([s.encode() for s in sentences], dropout_prob=p)
+    got = bpe.encode(sentences, yttm.OutputType.ID, dropout_prob=p)
+    lw, hw = dropout_stats(want, vocab)
+    lg, hg = dropout_stats(got, vocab)
+    assert abs(lg.mean() - lw.mean()) / lw.mean() < 0.01, (lg.mean(), lw.mean())
+    # KS on sentence lengths
+    grid = np.arange(0, max(lw.max(), lg.max()) + 2)
+    cw = np.searchsorted(np.sort(lw), grid, side="right") / len(lw)
+    cg = np.searchsorted(np.sort(lg), grid, side="right") / len(lg)
+    ks = np.abs(cw - cg).max()
+    assert ks < 1.95 * np.sqrt(2.0 / len(lw)), ks  # alpha ~ 0.001
+    # chi-square on unigram counts (bins with enough mass)
+    mask = (hw + hg) >= 20
+    chi = (((hg[mask] - hw[mask]) ** 2) / (hg[mask] + hw[mask])).sum() / max(1, mask.sum() - 1)
+    assert chi < 1.5, chi
+    return lg.mean(), lw.mean(), ks, chi

@@ -168,3 +168,25 @@ def test_encode_properties_at_scale(tmp_path):
         assert ids2[a2:b2].tolist() == [3] + ids[a:b].tolist()[::-1] + [2]
         sent = blob[i * 65:(i + 1) * 65].decode()
         assert bpe.decode([ids[a:b].tolist()])[0] == " ".join(sent.split())
+
+
+def test_dropout_extremes_and_roundtrip():
+    model = os.path.join(S.G, "train_readme_small.model")
+    rng = random.Random(4)
+    sents = ["".join(rng.choice("abcd  ") for _ in range(rng.randint(0, 200))) for _ in range(2000)] + ["", " ", "abcd" * 400]
+    S.check_dropout_extremes(model, sents)
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_dropout_distribution_vs_reference_semantics(p, tmp_path):
+    """BASELINE.json configs[4] (scaled to 200k sentences): distribution match against the oracle's bit-exact emulation of
+    the reference at n_threads=1."""
+    import youtokentome_amd as yttm
+    text = gen.readme_corpus(4000, 100)
+    corpus = str(tmp_path / "d.txt")
+    open(corpus, "wb").write(text)
+    model = str(tmp_path / "d.model")
+    yttm.BPE.train(corpus, model, 2000)
+    sents = [ln.decode() for ln in gen.abcd_corpus(200_000 * 129, seed=77, line=128).split(b"\n") if ln]
+    mean_g, mean_w, ks, chi = S.check_dropout_distribution(model, sents, p, 2000)
+    print(f"dropout p={p}: ids/sentence gpu {mean_g:.3f} oracle {mean_w:.3f} KS {ks:.5f} chi2/dof {chi:.3f}")

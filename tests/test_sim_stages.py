@@ -75,3 +75,19 @@ def test_long_words_class_b(tmp_path):
     S.check_merge_rounds(text.encode(), rounds=6, seed=2)
     model = S.check_train_vs_oracle(text.encode(), 60, tmp_path, tag="lw")
     S.check_encode_vs_oracle(model, [" ".join(words[2:]), "ab" * 700, "a"], flags=((0, 0, 0), (1, 1, 1)))
+
+
+def test_dropout_extremes_and_roundtrip():
+    import os
+    model = os.path.join(S.G, "train_readme_small.model")
+    rng = random.Random(4)
+    sents = ["".join(rng.choice("abcd  ") for _ in range(rng.randint(0, 70))) for _ in range(40)] + ["", " ", "abcd" * 40]
+    S.check_dropout_extremes(model, sents)
+
+
+def test_dropout_distribution_small():
+    import os
+    model = os.path.join(S.G, "train_readme_small.model")
+    rng = random.Random(6)
+    sents = ["".join(rng.choice("abcd  ") for _ in range(60)) for _ in range(1500)]
+    S.check_dropout_distribution(model, sents, 0.1, 600)

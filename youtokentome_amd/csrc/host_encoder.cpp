@@ -23,6 +23,9 @@ struct EncoderDevice {
   uint32_t *d_cpmap = nullptr;
   RuleSlot *d_rules = nullptr;
   uint32_t *d_rule_z = nullptr;
+  unsigned long long *d_rule_xy = nullptr;
+  uint32_t *d_drop = nullptr; size_t cap_drop = 0;
+  unsigned long long dropout_calls = 0;
   EncModel m{};
   // reusable batch buffers (grown on demand)
   uint8_t *d_bytes = nullptr; size_t cap_bytes = 0;
@@ -46,7 +49,7 @@ struct EncoderDevice {
     cap = c;
   }
   ~EncoderDevice() {
-    for (void *p : {(void *)d_cpmap, (void *)d_rules, (void *)d_rule_z, (void *)d_bytes, (void *)d_off, (void *)d_scratch, (void *)d_counts,
+    for (void *p : {(void *)d_cpmap, (void *)d_rules, (void *)d_rule_z, (void *)d_rule_xy, (void *)d_drop, (void *)d_bytes, (void *)d_off, (void *)d_scratch, (void *)d_counts,
                     (void *)d_out_off, (void *)d_scan_tmp, (void *)d_total, (void *)d_ids, (void *)d_work})
       if (p) (void)hipFree(p);
     if (st) (void)hipStreamDestroy(st);
@@ -75,9 +78,11 @@ BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *
     std::vector<RuleSlot> slots(cap);
     for (auto &s : slots) { s.key = PT_EMPTY; s.z = 0; s.pad = 0; }
     std::vector<uint32_t> rz(nr ? nr : 1, 0);
+    std::vector<unsigned long long> rxy(nr ? nr : 1, 0);
     for (size_t i = 0; i < nr; i++) {
       const BPE_Rule &r = bpe_state.rules[i];
       rz[i] = r.z;
+      rxy[i] = pair_key(r.x, r.y);
       const unsigned long long key = pair_key(r.x, r.y);
       unsigned int h = (unsigned int)mix64(key) & (cap - 1);
       while (slots[h].key != PT_EMPTY && slots[h].key != key) h = (h + 1) & (cap - 1);
@@ -89,11 +94,14 @@ BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *
     HIP_CHECK(hipMemcpy(dev_->d_rules, slots.data(), (size_t)cap * sizeof(RuleSlot), hipMemcpyHostToDevice));
     dev_->d_rule_z = dalloc<uint32_t>(rz.size());
     HIP_CHECK(hipMemcpy(dev_->d_rule_z, rz.data(), rz.size() * 4, hipMemcpyHostToDevice));
+    dev_->d_rule_xy = dalloc<unsigned long long>(rxy.size());
+    HIP_CHECK(hipMemcpy(dev_->d_rule_xy, rxy.data(), rxy.size() * 8, hipMemcpyHostToDevice));
     dev_->d_total = dalloc<unsigned long long>(2);
     EncModel &m = dev_->m;
     m.cpmap = dev_->d_cpmap;
     m.rules = dev_->d_rules;
     m.rule_z = dev_->d_rule_z;
+    m.rule_xy = dev_->d_rule_xy;
     m.rule_mask = cap - 1;
     auto it = char2id.find(SPACE_TOKEN);
     m.space_id = it == char2id.end() ? 0u : it->second;
@@ -143,7 +151,6 @@ Status BaseEncoder::encode_device(const void *d_bytes, const void *d_offsets, un
   // bpe.cpp:1702-1707
   if (bos && bpe_state.special_tokens.bos_id == -1) return Status(1, "Can't add <BOS> token. Model was trained without it.");
   if (eos && bpe_state.special_tokens.eos_id == -1) return Status(1, "Can't add <EOS> token. Model was trained without it.");
-  if (dropout_prob != 0) return Status(2, "BPE-dropout is not implemented on the GPU path yet");
   if (!dev_) return Status(2, "encoder has no device state");
   try {
     HIP_CHECK(hipSetDevice(device_));
@@ -157,14 +164,29 @@ Status BaseEncoder::encode_device(const void *d_bytes, const void *d_offsets, un
     d.grow(d.d_out_off, d.cap_out_off, (size_t)n_sent + 1);
     d.grow(d.d_scan_tmp, d.cap_scan_tmp, (size_t)scan_scratch_blocks(n_sent));
     unsigned int max_blocks = 256 * 3;  // 3 workgroups of 4 waves per CU (48 KB LDS each)
-    unsigned long long stride = 0;
-    if (2 * max_sentence_bytes + 2 > 1024) {
-      stride = 2 * max_sentence_bytes + 2;
-      unsigned long long per_wave = 3 * stride * 4;
-      unsigned long long waves = std::max<unsigned long long>(1, (2ull << 30) / per_wave);
-      max_blocks = (unsigned int)std::max<unsigned long long>(1, std::min<unsigned long long>(max_blocks, waves / NWAVES));
-      d.grow(d.d_work, d.cap_work, (size_t)(3 * stride * (unsigned long long)max_blocks * NWAVES));
+    const unsigned long long tok_cap = std::max<unsigned long long>(1024, 2 * max_sentence_bytes + 2);  // tokens per sentence
+    unsigned long long stride = 0, drop_stride = 0;
+    {
+      // per-wave HBM scratch: 3 working arrays for sentences that do not fit LDS, + (dropout) word starts and event queues
+      unsigned long long per_wave = 0;
+      if (tok_cap > 1024) per_wave += 3 * tok_cap * 4;
+      if (dropout_prob > 0) per_wave += 7 * tok_cap * 4;
+      if (per_wave) {
+        unsigned long long waves = std::max<unsigned long long>(1, (4ull << 30) / per_wave);
+        max_blocks = (unsigned int)std::max<unsigned long long>(1, std::min<unsigned long long>(max_blocks, waves / NWAVES));
+      }
     }
+    unsigned long long nb = (n_sent + NWAVES - 1) / NWAVES;
+    const unsigned int n_blocks = (unsigned int)std::min<unsigned long long>(nb, max_blocks);
+    if (tok_cap > 1024) {
+      stride = tok_cap;
+      d.grow(d.d_work, d.cap_work, (size_t)(3 * stride * (unsigned long long)n_blocks * NWAVES));
+    }
+    if (dropout_prob > 0) {
+      drop_stride = tok_cap;
+      d.grow(d.d_drop, d.cap_drop, (size_t)(7 * drop_stride * (unsigned long long)n_blocks * NWAVES));
+    }
+    const unsigned long long seed = mix64(0x5bd1e995ull + (++d.dropout_calls));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (kernel_ms) {
       HIP_CHECK(hipEventCreate(&e0));
@@ -172,7 +194,7 @@ Status BaseEncoder::encode_device(const void *d_bytes, const void *d_offsets, un
       HIP_CHECK(hipEventRecord(e0, d.st));
     }
     launch_encode(d.m, (const uint8_t *)d_bytes, (const unsigned long long *)d_offsets, n_sent, bos, eos, reverse, d.d_scratch, d.d_counts,
-                  d.d_work, stride, max_blocks, d.st);
+                  d.d_work, stride, n_blocks, dropout_prob, seed, d.d_drop, drop_stride, d.st);
     if (kernel_ms) HIP_CHECK(hipEventRecord(e1, d.st));
     launch_exclusive_scan(d.d_counts, n_sent, d.d_out_off, d.d_scan_tmp, d.d_total, d.st);
     unsigned long long total = 0;

@@ -41,9 +41,114 @@ __device__ inline uint32_t enc_rule_lookup(const EncModel &m, uint32_t a, uint32
 
 // One wavefront encodes one sentence.  wt = tokens (bit31 = first token of a word), wr = rule slot of the pair that
 // starts at p (or ENC_INF), wm = per-word minimum rule priority stored at the word's first position.
+// ---- BPE-dropout (bpe.cpp:1417-1453 DropoutQueue + :1560-1589) --------------------------------------------------------
+// Exact per-word process of the reference: events (rule index, position) in priority order; every pop walks the queue,
+// each event is skipped with probability p, the first one not skipped is taken (stale events included: they consume the
+// pop), all-skipped ends the word.  One word per lane (the process is inherently sequential within a word); the RNG is a
+// counter-based hash of (seed, sentence, word, draw) -- a per-lane stream cannot reproduce the reference's single global
+// mt19937 order, so parity is a distribution match (BASELINE.json configs[4]).
+struct DropoutArgs {
+  unsigned long long thr;   // skip iff hash < thr  (thr = p * 2^64); always_skip for p == 1
+  unsigned long long seed;
+  int enabled, always_skip;
+  uint32_t *wsl;            // [cap] word start positions
+  unsigned long long *ev;   // [3*cap] sorted event queues, word w owns [3*ws, 3*we)
+};
+
+__device__ inline bool drop_skip(const DropoutArgs &d, unsigned long long sidx, uint32_t word, uint32_t draw) {
+  if (d.always_skip) return true;
+  const unsigned long long r = mix64(d.seed + sidx * 0x9e3779b97f4a7c15ull + ((unsigned long long)word << 34) + draw);
+  return r < d.thr;
+}
+
+template <class A>
+__device__ inline void ev_insert(unsigned long long *ev, int &ne, unsigned long long key) {
+  int j = ne++;
+  while (j > 0 && ev[j - 1] > key) { ev[j] = ev[j - 1]; j--; }
+  ev[j] = key;
+}
+
+template <class A>
+__device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev*/, int n, const DropoutArgs &d, unsigned long long sidx) {
+  const int lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+  constexpr uint32_t DEAD = 0xffffffffu, NIL = 0xffffffffu;
+  // word starts
+  int nw = 0;
+  for (int c = 0; c < ((n + 63) >> 6); c++) {
+    const int p = c * 64 + lane;
+    const bool ws = p < n && (wt.get(p) & TOK_WS);
+    const unsigned long long W = __ballot(ws);
+    if (ws) d.wsl[nw + __popcll(W & lt)] = (uint32_t)p;
+    nw += __popcll(W);
+  }
+  wave_sync();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+  for (int w = lane; w < nw; w += 64) {
+    const int ws = (int)__hip_atomic_load(&d.wsl[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int we = w + 1 < nw ? (int)__hip_atomic_load(&d.wsl[w + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n;
+    unsigned long long *ev = d.ev + 3 * (size_t)ws;
+    int ne = 0;
+    for (int i = ws; i < we; i++) {
+      wr.set(i, i + 1 < we ? (uint32_t)(i + 1) : NIL);
+      wm.set(i, i > ws ? (uint32_t)(i - 1) : NIL);
+    }
+    for (int i = ws; i + 1 < we; i++) {  // bpe.cpp:1556-1558
+      const uint32_t slot = enc_rule_lookup(m, wt.get(i) & TOK_MASK, wt.get(i + 1) & TOK_MASK);
+      if (slot != ENC_INF) ev_insert<A>(ev, ne, ((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)i);
+    }
+    uint32_t draw = 0;
+    for (;;) {
+      int acc = -1;
+      for (int j = 0; j < ne; j++) {
+        if (!drop_skip(d, sidx, (uint32_t)w, draw++)) { acc = j; break; }
+      }
+      if (acc < 0) break;  // every event skipped: the word is finished (bpe.cpp:1431-1437)
+      const unsigned long long e = ev[acc];
+      for (int j = acc; j + 1 < ne; j++) ev[j] = ev[j + 1];
+      ne--;
+      const uint32_t rule = (uint32_t)(e >> 32);
+      const int p1 = (int)(uint32_t)e;
+      const uint32_t p2 = wr.get(p1);
+      const unsigned long long xy = m.rule_xy[rule];
+      const uint32_t t1 = wt.get(p1);
+      if (t1 == DEAD || (t1 & TOK_MASK) != (uint32_t)(xy >> 32) || p2 == NIL || (wt.get((int)p2) & TOK_MASK) != (uint32_t)xy) continue;  // :1569-1572
+      const uint32_t p0 = wm.get(p1), p3 = wr.get((int)p2);
+      wt.set((int)p2, DEAD);
+      wr.set((int)p2, NIL);
+      wt.set(p1, m.rule_z[rule] | (t1 & TOK_WS));
+      wr.set(p1, p3);
+      if (p3 != NIL) wm.set((int)p3, (uint32_t)p1);
+      if (p0 != NIL) {
+        const uint32_t slot = enc_rule_lookup(m, wt.get((int)p0) & TOK_MASK, wt.get(p1) & TOK_MASK);
+        if (slot != ENC_INF) ev_insert<A>(ev, ne, ((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)p0);
+      }
+      if (p3 != NIL) {
+        const uint32_t slot = enc_rule_lookup(m, wt.get(p1) & TOK_MASK, wt.get((int)p3) & TOK_MASK);
+        if (slot != ENC_INF) ev_insert<A>(ev, ne, ((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)p1);
+      }
+    }
+  }
+  wave_sync();
+  // drop dead nodes (order is preserved, so this is the linked-list traversal of bpe.cpp:1597)
+  int base = 0;
+  for (int c = 0; c < ((n + 63) >> 6); c++) {
+    const int p = c * 64 + lane;
+    const uint32_t t0 = p < n ? wt.get(p) : DEAD;
+    const bool alive = t0 != DEAD;
+    const unsigned long long AM = __ballot(alive);
+    wave_sync();
+    if (alive) wt.set(base + __popcll(AM & lt), t0);
+    base += __popcll(AM);
+    wave_sync();
+  }
+  return base;
+}
+
 template <class A>
 __device__ void encode_wave(const EncModel &m, const uint8_t *__restrict__ s, unsigned long long nbytes, A wt, A wr, A wm, int bos, int eos,
-                            int reverse, int32_t *__restrict__ out, uint32_t *__restrict__ count_out) {
+                            int reverse, int32_t *__restrict__ out, uint32_t *__restrict__ count_out, const DropoutArgs &drop,
+                            unsigned long long sidx) {
   const int lane = lane_id();
   const unsigned long long lt = lanemask_lt();
   // ---- A. UTF-8 decode + char -> token, word starts, unknown-run collapse ---------------------------------------------
@@ -96,7 +201,8 @@ __device__ void encode_wave(const EncModel &m, const uint8_t *__restrict__ s, un
   }
   wave_sync();
   // ---- B. merge rounds -----------------------------------------------------------------------------------------------
-  for (;;) {
+  if (drop.enabled) n = dropout_merge<A>(m, wt, wr, wm, n, drop, sidx);
+  else for (;;) {
     const int nchunks = (n + 63) >> 6;
     // phase 1: rule of every adjacency, word-segmented minimum
     int carry_ws = 0;
@@ -212,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) void k5_encode(EncModel m, const uint8_t *__
                                                    const unsigned long long *__restrict__ offsets, unsigned long long n_sent, int bos,
                                                    int eos, int reverse, int32_t *__restrict__ scratch_ids,
                                                    uint32_t *__restrict__ counts, uint32_t *__restrict__ work,
-                                                   unsigned long long work_stride) {
+                                                   unsigned long long work_stride, DropoutArgs drop, unsigned long long drop_stride) {
   __shared__ uint32_t lds[NWAVES][3][ENC_WCAP];
   const int wave = (int)(threadIdx.x >> 6);
   const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + wave;
@@ -221,13 +327,18 @@ __global__ __launch_bounds__(BLOCK) void k5_encode(EncModel m, const uint8_t *__
     const unsigned long long b0 = offsets[sidx], b1 = offsets[sidx + 1];
     const unsigned long long nbytes = b1 - b0;
     int32_t *out = scratch_ids + 2 * b0 + 2 * sidx;  // capacity 2*nbytes + 2 ids per sentence
+    DropoutArgs d = drop;
+    if (d.enabled) {  // per-wave slice of the dropout scratch: word starts, then the event queues
+      d.wsl = drop.wsl + gw * 7 * drop_stride;
+      d.ev = reinterpret_cast<unsigned long long *>(drop.wsl + gw * 7 * drop_stride + drop_stride);
+    }
     if (2 * nbytes + 2 <= (unsigned long long)ENC_WCAP) {
       LdsArr a{lds[wave][0]}, b{lds[wave][1]}, c{lds[wave][2]};
-      encode_wave(m, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx]);
+      encode_wave(m, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx], d, sidx);
     } else {
       uint32_t *w = work + gw * 3 * work_stride;
       GlbArr a{w}, b{w + work_stride}, c{w + 2 * work_stride};
-      encode_wave(m, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx]);
+      encode_wave(m, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx], d, sidx);
     }
     wave_sync();
   }
@@ -248,12 +359,18 @@ __global__ __launch_bounds__(BLOCK) void k5_gather(const int32_t *__restrict__ s
 
 void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long long *offsets, unsigned long long n_sent, int bos,
                    int eos, int reverse, int32_t *scratch_ids, uint32_t *counts, uint32_t *work, unsigned long long work_stride,
-                   unsigned int max_blocks, hipStream_t st) {
+                   unsigned int n_blocks, double dropout_prob, unsigned long long seed, uint32_t *drop_scratch,
+                   unsigned long long drop_stride, hipStream_t st) {
   if (!n_sent) return;
-  unsigned long long b = (n_sent + NWAVES - 1) / NWAVES;
-  if (b > max_blocks) b = max_blocks;
-  hipLaunchKernelGGL(k5_encode, dim3((unsigned int)b), dim3(BLOCK), 0, st, m, text, offsets, n_sent, bos, eos, reverse, scratch_ids,
-                     counts, work, work_stride);
+  DropoutArgs d{};
+  d.enabled = dropout_prob > 0;
+  d.always_skip = dropout_prob >= 1.0;
+  d.thr = d.always_skip ? ~0ull : (unsigned long long)(dropout_prob * 18446744073709551616.0);
+  d.seed = seed;
+  d.wsl = drop_scratch;
+  d.ev = nullptr;
+  hipLaunchKernelGGL(k5_encode, dim3(n_blocks), dim3(BLOCK), 0, st, m, text, offsets, n_sent, bos, eos, reverse, scratch_ids, counts, work,
+                     work_stride, d, drop_stride);
 }
 void launch_encode_gather(const int32_t *scratch_ids, const unsigned long long *offsets, const unsigned long long *out_off,
                           unsigned long long n_sent, int32_t *ids_out, hipStream_t st) {

@@ -62,13 +62,15 @@ struct EncModel {
   const uint32_t *cpmap;      // [N_CODEPOINTS]: final token id, CP_SPACE, CP_UNK
   const RuleSlot *rules;      // hash (x<<32|y) -> RuleSlot{z, pad = rule index = priority}
   const uint32_t *rule_z;     // [n_rules] z of rule i
+  const unsigned long long *rule_xy;  // [n_rules] x<<32|y of rule i
   unsigned int rule_mask;
   uint32_t space_id;
   int unk_id, bos_id, eos_id;
 };
 void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long long *offsets, unsigned long long n_sent, int bos,
                    int eos, int reverse, int32_t *scratch_ids, uint32_t *counts, uint32_t *work, unsigned long long work_stride,
-                   unsigned int max_blocks, hipStream_t st);
+                   unsigned int n_blocks, double dropout_prob, unsigned long long seed, uint32_t *drop_scratch,
+                   unsigned long long drop_stride, hipStream_t st);
 void launch_encode_gather(const int32_t *scratch_ids, const unsigned long long *offsets, const unsigned long long *out_off,
                           unsigned long long n_sent, int32_t *ids_out, hipStream_t st);
 
