@@ -302,6 +302,36 @@ void GpuCtx::download_word_table(std::vector<uint32_t> &tok, std::vector<unsigne
   if (tok.empty()) { off.assign(1, 0); }
 }
 
+// Re-deal the live words of a tile class into fresh, full tiles when the average fill has dropped below half.
+void GpuCtx::maybe_repack(int ci) {
+  WordClass &c = cls_[ci];
+  if (c.n_tiles < 2) return;
+  unsigned long long *off = dmalloc<unsigned long long>(c.n_tiles);
+  unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(c.n_tiles));
+  launch_exclusive_scan(c.d_tile_len, c.n_tiles, off, scan_tmp, d_counters_ + 48, st_);
+  unsigned long long total = 0;
+  HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 48, 8, hipMemcpyDeviceToHost, st_));
+  sync();
+  DFREE(scan_tmp);
+  if (total == 0 || total * 2 > (unsigned long long)c.n_tiles * c.nom) { DFREE(off); return; }
+  const unsigned int n_new = (unsigned int)((total - 1) / c.nom) + 1;
+  uint32_t *new_tok = dmalloc<uint32_t>((size_t)n_new * c.slot + 64);
+  uint32_t *new_len = dmalloc<uint32_t>(n_new), *new_word0 = dmalloc<uint32_t>(n_new);
+  unsigned long long *gstart = dmalloc<unsigned long long>(n_new);
+  HIP_CHECK(hipMemsetAsync(new_tok, 0, ((size_t)n_new * c.slot + 64) * 4, st_));
+  HIP_CHECK(hipMemsetAsync(gstart, 0xff, (size_t)n_new * 8, st_));
+  HIP_CHECK(hipMemsetAsync(new_word0, 0xff, (size_t)n_new * 4, st_));
+  launch_repack(ci, c.ts, off, c.nom, total, gstart, n_new, new_tok, new_len, new_word0, st_);
+  sync();
+  DFREE(off); DFREE(gstart);
+  DFREE(c.d_tok); DFREE(c.d_tile_len); DFREE(c.d_tile_word0);
+  c.d_tok = new_tok; c.d_tile_len = new_len; c.d_tile_word0 = new_word0;
+  c.n_tiles = n_new;
+  c.ts.tok = new_tok; c.ts.tile_len = new_len; c.ts.tile_word0 = new_word0; c.ts.n_tiles = n_new;
+  n_tiles = cls_[0].n_tiles + cls_[1].n_tiles;
+  repacks++;
+}
+
 // ------------------------------------------------------------------------------------------------- pair table
 void GpuCtx::alloc_table(PairTable &pt, unsigned long long cap) {
   pt.keys = dmalloc<unsigned long long>(cap);
@@ -321,7 +351,8 @@ void GpuCtx::free_table(PairTable &pt) {
 
 void GpuCtx::ensure_table_capacity(unsigned long long need_keys) {
   if (pt_cap_ && need_keys * 2 <= pt_cap_) return;
-  unsigned long long new_cap = pow2_at_least(std::max<unsigned long long>(1ull << 16, need_keys * 4));
+  // load stays between 1/4 and 1/2: the candidate filter streams the whole table every round
+  unsigned long long new_cap = pow2_at_least(std::max<unsigned long long>(1ull << 16, need_keys * 2 + need_keys / 2));
   if (!pt_cap_) {
     alloc_table(pt_, new_cap);
     pt_cap_ = new_cap;
@@ -512,6 +543,10 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   for (int ci = 0; ci < 2; ci++) launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, d_stats_, st_);
   t_end(KT_MERGE, 0);
   merge_rounds++;
+  if (++rounds_since_check_ >= 8) {
+    rounds_since_check_ = 0;
+    for (int ci = 0; ci < 2; ci++) maybe_repack(ci);
+  }
   unsigned int nk = 0;
   HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
   sync();  // also makes the pinned staging reusable

@@ -68,7 +68,7 @@ class GpuCtx {
   unsigned long long n_keys_host = 0;
   bool profile = false;
   KernelTimes kt;
-  unsigned long long merge_sites = 0, merge_rounds = 0;
+  unsigned long long merge_sites = 0, merge_rounds = 0, repacks = 0;
   void resolve_timers();
 
  private:
@@ -103,6 +103,8 @@ class GpuCtx {
   WordClass cls_[2];
   void free_class(WordClass &c);
   void build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, unsigned int U, uint32_t space_id);
+  void maybe_repack(int ci);
+  unsigned long long rounds_since_check_ = 0;
   // pair table
   PairTable pt_{};
   unsigned long long pt_cap_ = 0;

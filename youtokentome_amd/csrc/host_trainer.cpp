@@ -227,6 +227,8 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     rep->seconds_io = since(t_io);
     rep->seconds_total = since(t_all);
     g.resolve_timers();
+    rep->repacks = g.repacks;
+    rep->merge_sites = g.merge_sites;
     for (int i = 0; i < 8; i++) { rep->kt_ms[i] = g.kt.ms[i]; rep->kt_launches[i] = g.kt.launches[i]; rep->kt_bytes[i] = g.kt.bytes[i]; }
   }
   return s;

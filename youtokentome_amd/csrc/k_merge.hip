@@ -20,8 +20,8 @@
 
 namespace yttm {
 
-constexpr int AGG_SLOTS = 128;   // LDS delta aggregator shared by the waves of a workgroup (hot pairs)
-constexpr int CAND_CAP_W = 256;  // per-wave list of merge-site candidates awaiting their rule lookup
+constexpr int AGG_SLOTS = 256;   // LDS delta aggregator shared by the waves of a workgroup (hot pairs)
+constexpr int CAND_CAP_W = 192;  // per-wave list of merge-site candidates awaiting their rule lookup
 constexpr uint32_t FLAG_LDS_IDS = 32768;  // batch flags of ids below this live in an LDS bitmap (2 bits per id, 8 KB)
 
 // Staged (LDS) token word: bit31 = first token of a word, bit30 = id is the y of some batch rule, bit29 = id is the x
@@ -65,7 +65,7 @@ template <int SLOT>
 __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta) {
   (void)W;
   unsigned int h = (unsigned int)(mix64(key) >> 24) & (AGG_SLOTS - 1);
-  for (int probe = 0; probe < 2; probe++) {
+  for (int probe = 0; probe < 8; probe++) {
     unsigned long long k = ((volatile unsigned long long *)A.key)[h];
     if (k == PT_EMPTY) {
       k = atomicCAS(&A.key[h], PT_EMPTY, key);
@@ -444,9 +444,9 @@ __global__ __launch_bounds__(BLOCK) void k_cand_scan(PairTable pt, unsigned long
     bool pass = false;
     unsigned long long k = PT_EMPTY, c = 0;
     if (i < n_slots) {
-      k = pt.keys[i];
-      c = pt.cnts[i];
-      if (k != PT_EMPTY && c > 0) {
+      c = pt.cnts[i];  // empty and dead slots have count 0: their keys are never read
+      if (c > 0) {
+        k = pt.keys[i];
         if (hist) atomicAdd(&lh[cand_bin(c)], 1u);
         const uint32_t x = (uint32_t)(k >> 32), y = (uint32_t)k;
         const uint32_t mx = x > y ? x : y;
@@ -521,7 +521,86 @@ __global__ __launch_bounds__(BLOCK) void k_fill_u64(unsigned long long *__restri
   for (; i < n; i += stride) p[i] = v;
 }
 
+// ------------------------------------------------------------------------------------------------- tile repack
+// Merges shrink tiles in place; once the average fill is low the fixed per-tile cost dominates a pass, so the live
+// words are re-dealt into fresh tiles (same word order, so wcnt stays valid).  off[t] = live tokens before tile t.
+template <int SLOT>
+__global__ __launch_bounds__(BLOCK) void k_repack_mark(TileSet ts, const unsigned long long *__restrict__ off, unsigned int nom,
+                                                       unsigned long long *__restrict__ gstart, uint32_t *__restrict__ gword0) {
+  const int lane = lane_id();
+  const uint32_t stride = gridDim.x * NWAVES;
+  for (uint32_t t = blockIdx.x * NWAVES + (threadIdx.x >> 6); t < ts.n_tiles; t += stride) {
+    const int n = (int)ts.tile_len[t];
+    const uint32_t *src = ts.tok + (size_t)t * SLOT;
+    uint32_t wbase = 0;
+    for (int c = 0; c < ((n + 63) >> 6); c++) {
+      const int p = c * 64 + lane;
+      const bool ws = p < n && (src[p] & TOK_WS);
+      const unsigned long long m = __ballot(ws);
+      if (ws) {
+        const unsigned long long woff = off[t] + (unsigned long long)p;
+        const unsigned long long g = woff / nom;
+        atomicMin(&gstart[g], woff);
+        atomicMin(&gword0[g], ts.tile_word0[t] + wbase + (uint32_t)__popcll(m & lanemask_lt()));
+      }
+      wbase += (uint32_t)__popcll(m);
+    }
+  }
+}
+
+template <int SLOT>
+__global__ __launch_bounds__(BLOCK) void k_repack_copy(TileSet ts, const unsigned long long *__restrict__ off, unsigned int nom,
+                                                       const unsigned long long *__restrict__ gstart, uint32_t *__restrict__ new_tok) {
+  const int lane = lane_id();
+  const uint32_t stride = gridDim.x * NWAVES;
+  for (uint32_t t = blockIdx.x * NWAVES + (threadIdx.x >> 6); t < ts.n_tiles; t += stride) {
+    const int n = (int)ts.tile_len[t];
+    const uint32_t *src = ts.tok + (size_t)t * SLOT;
+    int carry_ws = 0;  // position of the last word start seen in earlier chunks (a tile starts with a word start)
+    for (int c = 0; c < ((n + 63) >> 6); c++) {
+      const int p = c * 64 + lane;
+      const uint32_t tk = p < n ? src[p] : 0;
+      const bool ws = p < n && (tk & TOK_WS);
+      const unsigned long long m = __ballot(ws);
+      int wsp = carry_ws;
+      const unsigned long long le = m & ((2ull << lane) - 1ull);
+      if (le) wsp = c * 64 + 63 - __clzll((long long)le);
+      if (m) carry_ws = c * 64 + 63 - __clzll((long long)m);
+      if (p < n) {
+        const unsigned long long g = (off[t] + (unsigned long long)wsp) / nom;
+        new_tok[g * SLOT + (off[t] + (unsigned long long)p - gstart[g])] = tk;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_repack_len(const unsigned long long *__restrict__ gstart, unsigned int n_new,
+                                                      unsigned long long total, uint32_t *__restrict__ new_len) {
+  unsigned int g = blockIdx.x * BLOCK + threadIdx.x;
+  if (g >= n_new) return;
+  const unsigned long long s0 = gstart[g];
+  if (s0 == ~0ull) { new_len[g] = 0; return; }
+  unsigned long long e = total;
+  if (g + 1 < n_new && gstart[g + 1] != ~0ull) e = gstart[g + 1];
+  new_len[g] = (uint32_t)(e - s0);
+}
+
 // ------------------------------------------------------------------------------------------------- launchers
+void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, unsigned int nom, unsigned long long total,
+                   unsigned long long *gstart, unsigned int n_new, uint32_t *new_tok, uint32_t *new_len, uint32_t *new_word0, hipStream_t st) {
+  unsigned int g = (ts.n_tiles + NWAVES - 1) / NWAVES;
+  if (g > 256 * 8) g = 256 * 8;
+  if (!g) g = 1;
+  if (cls == 0) {
+    hipLaunchKernelGGL((k_repack_mark<TILE_SLOT_A>), dim3(g), dim3(BLOCK), 0, st, ts, off, nom, gstart, new_word0);
+    hipLaunchKernelGGL((k_repack_copy<TILE_SLOT_A>), dim3(g), dim3(BLOCK), 0, st, ts, off, nom, gstart, new_tok);
+  } else {
+    hipLaunchKernelGGL((k_repack_mark<TILE_SLOT_B>), dim3(g), dim3(BLOCK), 0, st, ts, off, nom, gstart, new_word0);
+    hipLaunchKernelGGL((k_repack_copy<TILE_SLOT_B>), dim3(g), dim3(BLOCK), 0, st, ts, off, nom, gstart, new_tok);
+  }
+  hipLaunchKernelGGL(k_repack_len, dim3((n_new + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, gstart, n_new, total, new_len);
+}
+
 static inline unsigned int tile_grid(unsigned int n_tiles, unsigned int wpb, unsigned int blocks_per_cu) {
   unsigned int need = (n_tiles + wpb - 1) / wpb;
   unsigned int g = 256u * blocks_per_cu;
