@@ -1,6 +1,8 @@
 // gpu_ctx.cpp -- HBM buffer management and kernel sequencing for the MI355X BPE trainer (see gpu_ctx.h).
 #include "gpu_ctx.h"
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -87,13 +89,16 @@ void GpuCtx::resolve_timers() {
       kt.bytes[KT_MERGE] = 4 * st[2] + 4 * st[3];
     }
   }
+  FILE *trace = getenv("YTTM_TRACE") ? fopen(getenv("YTTM_TRACE"), "w") : nullptr;  // per-launch times for tuning
   for (auto &e : evs_) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) kt.ms[e.which] += ms;
+    if (trace) fprintf(trace, "%d %.4f\n", e.which, ms);
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
   evs_.clear();
+  if (trace) fclose(trace);
 }
 
 // ------------------------------------------------------------------------------------------------- corpus
