@@ -548,6 +548,9 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   for (int ci = 0; ci < 2; ci++) launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, d_stats_, st_);
   t_end(KT_MERGE, 0);
   merge_rounds++;
+  pending_zero_ = true;
+  zero_cap_ = cap;
+  zero_self_key_ = self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY;
   if (++rounds_since_check_ >= 8) {
     rounds_since_check_ = 0;
     for (int ci = 0; ci < 2; ci++) maybe_repack(ci);
@@ -557,6 +560,9 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   sync();  // also makes the pinned staging reusable
   n_keys_host = nk;
   exchange_deltas();
+  // every occurrence of the batch's pairs has been merged (on every rank): their counts are exactly zero
+  launch_pt_zero(pt_, d_rules_, zero_cap_, zero_self_key_, st_);
+  pending_zero_ = false;
 }
 
 }  // namespace yttm

@@ -105,6 +105,9 @@ class GpuCtx {
   void build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, unsigned int U, uint32_t space_id);
   void maybe_repack(int ci);
   unsigned long long rounds_since_check_ = 0;
+  bool pending_zero_ = false;
+  unsigned int zero_cap_ = 0;
+  unsigned long long zero_self_key_ = 0;
   // pair table
   PairTable pt_{};
   unsigned long long pt_cap_ = 0;

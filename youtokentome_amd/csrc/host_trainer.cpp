@@ -8,6 +8,7 @@
 // one-at-a-time greedy of the -DDETERMINISTIC_QUEUE build / learn_bpe_slow -- and one K4 pass applies
 // the whole batch.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -110,11 +111,15 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   std::vector<unsigned long long> batch_cnt;
   unsigned long long hist[CAND_BINS];
   unsigned long long rounds = 0, rescans = 0;
+  double w_cand = 0, w_pick = 0, w_apply = 0;
   std::vector<uint8_t> in_batch((size_t)vocab_size + 1, 0);  // bit0: token is the x of a batch rule, bit1: the y
   while (used_ids < (uint64_t)vocab_size) {
     // Candidate set = every pair with count > tau, or count == tau and max(x,y) <= tau_mx: a complete prefix of the
     // global order, so the batch built from it is exact.  The threshold only trades list length against early batch ends.
+    auto tw0 = clk::now();
     uint32_t n = g.candidates(tau, tau_mx, recs, hist);
+    w_cand += since(tw0);
+    auto tw1 = clk::now();
     unsigned long long total_pairs = 0;
     const unsigned long long tau_hint = choose_tau(hist, TARGET, &total_pairs);
     if (total_pairs == 0) {
@@ -177,7 +182,10 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     }
     const uint32_t k = (uint32_t)batch_cnt.size();
     for (uint32_t j = 0; j < k; j++) in_batch[batch_xyz[3 * j]] = in_batch[batch_xyz[3 * j + 1]] = 0;
+    w_pick += since(tw1);
+    auto tw2 = clk::now();
     g.merge_apply(batch_xyz.data(), k, batch_cnt.data());
+    w_apply += since(tw2);
     for (uint32_t j = 0; j < k; j++) rules.push_back(BPE_Rule{batch_xyz[3 * j], batch_xyz[3 * j + 1], batch_xyz[3 * j + 2]});
     used_ids += k;
     rounds++;
@@ -187,6 +195,8 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   }
   if (rep) {
     rep->seconds_merge = since(t_merge);
+    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu\n",
+                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks);
     rep->rounds = rounds;
     rep->cand_rescans = rescans;
     rep->rules = rules.size();

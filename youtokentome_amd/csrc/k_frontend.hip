@@ -232,13 +232,52 @@ __device__ inline bool seg_equal(const uint8_t *__restrict__ text, unsigned long
 }
 
 constexpr unsigned long long WH_POS_MASK = (1ull << 40) - 1;
+constexpr int WL_SLOTS = 512;  // per-workgroup LDS combiner for frequent words
 
+// insert-or-add `count` occurrences of the word whose representative segment starts at `pos` into the HBM table
+__device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap,
+                                          unsigned long long h, unsigned long long pos, uint32_t len_tokens, unsigned long long count,
+                                          unsigned long long *__restrict__ ht_key, unsigned long long *__restrict__ ht_cnt,
+                                          uint32_t *__restrict__ ht_len, unsigned long long ht_mask, unsigned int *__restrict__ status) {
+  const unsigned long long tag = h >> 40;
+  const unsigned long long mine = (tag << 40) | pos;
+  unsigned long long i = h & ht_mask;
+  for (;;) {
+    unsigned long long cur = ld_agent(&ht_key[i]);
+    if (cur == PT_EMPTY) {
+      cur = atomicCAS(&ht_key[i], PT_EMPTY, mine);
+      if (cur == PT_EMPTY) {
+        ht_len[i] = len_tokens;  // read only by later kernels
+        atomicAdd(&ht_cnt[i], count);
+        atomicAdd(&status[0], 1u);
+        if (len_tokens > (uint32_t)TILE_NOM_A) atomicAdd(&status[2], 1u);
+        return;
+      }
+    }
+    if ((cur >> 40) == tag && seg_equal(text, n, cpmap, cur & WH_POS_MASK, pos)) {
+      atomicAdd(&ht_cnt[i], count);
+      return;
+    }
+    i = (i + 1) & ht_mask;
+  }
+}
+
+// One thread per segment.  Frequent (short) words would otherwise hammer a handful of HBM addresses with atomics, so
+// each workgroup first combines its segments in an LDS table (same exact scheme: a (tag | representative offset) word
+// claimed by one CAS, tag matches verified against the representative's bytes) and flushes one (word, count) per
+// distinct word at the end; what does not fit goes straight to the HBM table.
 __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restrict__ text, unsigned long long n,
                                                           const uint32_t *__restrict__ cpmap,
                                                           const unsigned long long *__restrict__ seg_pos, unsigned long long n_segs,
                                                           unsigned long long *__restrict__ ht_key, unsigned long long *__restrict__ ht_cnt,
                                                           uint32_t *__restrict__ ht_len, unsigned long long ht_mask,
                                                           unsigned int *__restrict__ status /* [0]=n_unique [1]=flags [2]=n_unique of class B */) {
+  __shared__ unsigned long long l_key[WL_SLOTS];   // (tag:24 | pos:40) or PT_EMPTY
+  __shared__ unsigned long long l_hash[WL_SLOTS];  // full hash of the word (for the flush)
+  __shared__ unsigned int l_cnt[WL_SLOTS];
+  __shared__ unsigned int l_len[WL_SLOTS];
+  for (int i = (int)threadIdx.x; i < WL_SLOTS; i += BLOCK) { l_key[i] = PT_EMPTY; l_cnt[i] = 0; }
+  __syncthreads();
   unsigned long long s = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
   for (; s < n_segs; s += stride) {
@@ -247,27 +286,37 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
     const uint32_t L = seg_scan(text, n, cpmap, pos, &h);
     if (L == 0) continue;  // segment made only of dropped chars: no word (bpe.cpp:357-380 deletes them first)
     if (L + 1 > (uint32_t)MAX_WORD_TOKENS) { atomicOr(&status[1], 1u); continue; }
-    const unsigned long long mine = ((h >> 40) << 40) | pos;
     const unsigned long long tag = h >> 40;
-    unsigned long long i = h & ht_mask;
-    for (;;) {
-      unsigned long long cur = ld_agent(&ht_key[i]);
-      if (cur == PT_EMPTY) {
-        cur = atomicCAS(&ht_key[i], PT_EMPTY, mine);
+    bool done = false;
+    if (L <= 8) {  // only short words are frequent enough to be worth an LDS slot
+      unsigned int j = (unsigned int)(h >> 8) & (WL_SLOTS - 1);
+      for (int probe = 0; probe < 4 && !done; probe++) {
+        unsigned long long cur = ((volatile unsigned long long *)l_key)[j];
         if (cur == PT_EMPTY) {
-          ht_len[i] = L + 1;  // + the leading "▁" token; read only by later kernels
-          atomicAdd(&ht_cnt[i], 1ull);
-          atomicAdd(&status[0], 1u);
-          if (L + 1 > (uint32_t)TILE_NOM_A) atomicAdd(&status[2], 1u);
+          cur = atomicCAS(&l_key[j], PT_EMPTY, (tag << 40) | pos);
+          if (cur == PT_EMPTY) {
+            l_hash[j] = h;
+            l_len[j] = L + 1;
+            atomicAdd(&l_cnt[j], 1u);
+            done = true;
+            break;
+          }
+        }
+        if ((cur >> 40) == tag && seg_equal(text, n, cpmap, cur & WH_POS_MASK, pos)) {
+          atomicAdd(&l_cnt[j], 1u);
+          done = true;
           break;
         }
+        j = (j + 1) & (WL_SLOTS - 1);
       }
-      if ((cur >> 40) == tag && seg_equal(text, n, cpmap, cur & WH_POS_MASK, pos)) {
-        atomicAdd(&ht_cnt[i], 1ull);
-        break;
-      }
-      i = (i + 1) & ht_mask;
     }
+    if (!done) word_insert_global(text, n, cpmap, h, pos, L + 1, 1ull, ht_key, ht_cnt, ht_len, ht_mask, status);
+  }
+  __syncthreads();
+  for (int i = (int)threadIdx.x; i < WL_SLOTS; i += BLOCK) {
+    const unsigned long long k = l_key[i];
+    if (k != PT_EMPTY)
+      word_insert_global(text, n, cpmap, l_hash[i], k & WH_POS_MASK, l_len[i], (unsigned long long)l_cnt[i], ht_key, ht_cnt, ht_len, ht_mask, status);
   }
 }
 

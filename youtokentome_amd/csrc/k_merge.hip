@@ -64,7 +64,8 @@ __device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsi
 template <int SLOT>
 __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta) {
   (void)W;
-  unsigned int h = (unsigned int)(mix64(key) >> 24) & (AGG_SLOTS - 1);
+  // 8 replicas per key (by lane): LDS atomics on one address serialise, and early in training 64 lanes share ~5 keys
+  unsigned int h = ((unsigned int)(mix64(key) >> 24) + (unsigned int)(lane_id() & 7) * 29u) & (AGG_SLOTS - 1);
   for (int probe = 0; probe < 8; probe++) {
     unsigned long long k = ((volatile unsigned long long *)A.key)[h];
     if (k == PT_EMPTY) {
@@ -292,7 +293,8 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
                 my_sites++;
                 const uint32_t b = t1 & L_ID;
                 const uint32_t z = NEWTOK(p);
-                emit<SLOT>(A, W, pt, db, pair_key(a, b), -f);  // the merged pair itself
+                // (the merged pair (x,y) itself is not retracted here: every occurrence of it is merged, so its count is
+                //  simply set to zero by k_pt_zero after the pass -- it would be the most contended delta of all)
                 // run of new z tokens (x y x y ... or the halves of an x-run): counted floor(Lz/2) by its first site
                 const bool prev_same = p >= 2 && !(t0 & TOK_WS) && SITE(p - 2) && NEWTOK(p - 2) == z;
                 if (!prev_same) {
@@ -494,6 +496,23 @@ __global__ __launch_bounds__(BLOCK) void k_pt_query(PairTable pt, const unsigned
   if (i < n) out[i] = pt_get(pt, keys[i]);
 }
 
+// the rules of a finished batch: all their occurrences were merged, their counts are exactly zero now
+__global__ __launch_bounds__(BLOCK) void k_pt_zero(PairTable pt, const RuleSlot *__restrict__ rules, unsigned int n_slots,
+                                                   unsigned long long self_key) {
+  unsigned int i = blockIdx.x * BLOCK + threadIdx.x;
+  unsigned long long key = PT_EMPTY;
+  if (i < n_slots) key = rules[i].key;
+  else if (i == n_slots) key = self_key;
+  if (key == PT_EMPTY) return;
+  unsigned long long j = mix64(key) & pt.mask;
+  for (;;) {
+    const unsigned long long k = pt.keys[j];
+    if (k == PT_EMPTY) return;
+    if (k == key) { pt.cnts[j] = 0; return; }
+    j = (j + 1) & pt.mask;
+  }
+}
+
 // multi-GPU: fold the count deltas received from the other ranks into the local replica of the global pair table
 __global__ __launch_bounds__(BLOCK) void k_pt_apply(PairTable pt, const DeltaRec *__restrict__ recs, unsigned long long n) {
   unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -642,6 +661,9 @@ void launch_pt_rehash(const PairTable &src, const PairTable &dst, hipStream_t st
   unsigned long long b = (n_slots + BLOCK - 1) / BLOCK;
   if (b > 256 * 16) b = 256 * 16;
   hipLaunchKernelGGL(k_pt_rehash, dim3((unsigned int)b), dim3(BLOCK), 0, st, src, dst);
+}
+void launch_pt_zero(const PairTable &pt, const RuleSlot *rules, unsigned int n_slots, unsigned long long self_key, hipStream_t st) {
+  hipLaunchKernelGGL(k_pt_zero, dim3((n_slots + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, pt, rules, n_slots, self_key);
 }
 void launch_pt_query(const PairTable &pt, const unsigned long long *keys, unsigned int n, unsigned long long *out, hipStream_t st) {
   if (!n) return;

@@ -54,6 +54,7 @@ void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, un
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
                       unsigned int *n_out, unsigned long long *hist, hipStream_t st);
 void launch_pt_rehash(const PairTable &src, const PairTable &dst, hipStream_t st);
+void launch_pt_zero(const PairTable &pt, const RuleSlot *rules, unsigned int n_slots, unsigned long long self_key, hipStream_t st);
 void launch_pt_query(const PairTable &pt, const unsigned long long *keys, unsigned int n, unsigned long long *out, hipStream_t st);
 void launch_pt_apply(const PairTable &pt, const DeltaRec *recs, unsigned long long n, hipStream_t st);
 void launch_set_tokflag(uint8_t *tokflag, uint32_t *flagbits, const uint32_t *upd, unsigned int n, hipStream_t st);
