@@ -64,8 +64,7 @@ __device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsi
 template <int SLOT>
 __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta) {
   (void)W;
-  unsigned int h = (((unsigned int)(key >> 32) * 0x9e3779b1u) ^ ((unsigned int)key * 0x85ebca77u)) >> 24;  // 8 bits = AGG_SLOTS
-  static_assert(AGG_SLOTS == 256, "hash width");
+  unsigned int h = (unsigned int)(mix64(key) >> 24) & (AGG_SLOTS - 1);
   for (int probe = 0; probe < 8; probe++) {
     unsigned long long k = ((volatile unsigned long long *)A.key)[h];
     if (k == PT_EMPTY) {
@@ -280,12 +279,6 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         for (int c = 0; c < nchunks; c++) {
           const int p = c * 64 + lane;
           bool alive = false;
-          unsigned long long pk0 = 0, pk1 = 0, pk2 = 0;
-          long long pd0 = 0, pd1 = 0, pd2 = 0;
-          int np = 0;
-          // deltas are first parked in registers (<= 3 per lane) and applied after the branches have reconverged: the
-          // LDS-hash update then runs once per slot for all lanes together instead of once per branch
-#define PEND(K, D) { const unsigned long long _k = (K); const long long _d = (D); if (np == 0) { pk0 = _k; pd0 = _d; } else if (np == 1) { pk1 = _k; pd1 = _d; } else { pk2 = _k; pd2 = _d; } np++; }
           if (p < n) {
             const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
             const uint32_t a = t0 & L_ID;
@@ -299,60 +292,49 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
                 my_sites++;
                 const uint32_t b = t1 & L_ID;
                 const uint32_t z = NEWTOK(p);
-                // (the merged pair (x,y) itself is not retracted here: every occurrence of it is merged, so its count is
-                //  simply set to zero by k_pt_zero after the pass -- it would be the most contended delta of all)
+                emit<SLOT>(A, W, pt, db, pair_key(a, b), -f);  // the merged pair itself
                 // run of new z tokens (x y x y ... or the halves of an x-run): counted floor(Lz/2) by its first site
                 const bool prev_same = p >= 2 && !(t0 & TOK_WS) && SITE(p - 2) && NEWTOK(p - 2) == z;
                 if (!prev_same) {
                   int q = p, lz = 1;
                   while (!(W.tk[q + 2] & TOK_WS) && q + 2 < n && SITE(q + 2) && NEWTOK(q + 2) == z) { q += 2; lz++; }
-                  if (lz >= 2) PEND(pair_key(z, z), (long long)(lz / 2) * f);
+                  if (lz >= 2) emit<SLOT>(A, W, pt, db, pair_key(z, z), (long long)(lz / 2) * f);
                 }
                 // new adjacency (z, right neighbour)
                 const int q = p + 2;
                 if (q < n && !(W.tk[q] & TOK_WS)) {
                   const uint32_t B = SITE(q) ? NEWTOK(q) : (W.tk[q] & L_ID);
-                  if (B != z) PEND(pair_key(z, B), f);
+                  if (B != z) emit<SLOT>(A, W, pt, db, pair_key(z, B), f);
                 }
                 // x != y rule whose x is the last token of a run of a's: the run shrinks by one
                 if (a != self_x && p > 0 && !(t0 & TOK_WS) && (W.tk[p - 1] & L_ID) == a) {
                   int rr = p;
                   while (rr > 0 && !(W.tk[rr] & TOK_WS) && (W.tk[rr - 1] & L_ID) == a) rr--;
                   const int len = p - rr + 1;
-                  if ((len & 1) == 0) PEND(pair_key(a, a), -f);
+                  if ((len & 1) == 0) emit<SLOT>(A, W, pt, db, pair_key(a, a), -f);
                 }
               } else if (!dp) {
                 // unmerged token whose right neighbour starts a site: (a,x) -> (a,z)
                 const uint32_t x_ = t1 & L_ID;
                 const uint32_t z = NEWTOK(p + 1);
-                if (a != x_) PEND(pair_key(a, x_), -f);
-                PEND(pair_key(a, z), f);
+                if (a != x_) emit<SLOT>(A, W, pt, db, pair_key(a, x_), -f);
+                emit<SLOT>(A, W, pt, db, pair_key(a, z), f);
               }
               if (dp && adj1) {
                 // p was the y of the site at p-1: its old right adjacency disappears
                 const uint32_t b_ = t1 & L_ID;
                 if (a != b_) {
-                  PEND(pair_key(a, b_), -f);
+                  emit<SLOT>(A, W, pt, db, pair_key(a, b_), -f);
                 } else if (a != self_x) {
                   // x != y rule whose y is the first token of a run of a's: the run shrinks by one
                   int q = p;
                   while (!(W.tk[q + 1] & TOK_WS) && (W.tk[q + 1] & L_ID) == a) q++;
                   const int len = q - p + 1;
-                  if ((len & 1) == 0) PEND(pair_key(a, a), -f);
+                  if ((len & 1) == 0) emit<SLOT>(A, W, pt, db, pair_key(a, a), -f);
                 }
               }
             }
           }
-          if (__ballot(np > 0)) {
-            if (np > 0) emit<SLOT>(A, W, pt, db, pk0, pd0);
-            if (__ballot(np > 1)) {
-              if (np > 1) emit<SLOT>(A, W, pt, db, pk1, pd1);
-              if (__ballot(np > 2)) {
-                if (np > 2) emit<SLOT>(A, W, pt, db, pk2, pd2);
-              }
-            }
-          }
-#undef PEND
           const unsigned long long am = __ballot(alive);
           if (lane == 0) {
             W.amask[c] = am;
