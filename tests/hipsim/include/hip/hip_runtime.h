@@ -20,6 +20,7 @@
 #define __launch_bounds__(...)
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
 
 struct dim3 {
   unsigned x, y, z;

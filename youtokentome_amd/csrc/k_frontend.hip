@@ -291,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
     if (L <= 8) {  // only short words are frequent enough to be worth an LDS slot
       unsigned int j = (unsigned int)(h >> 8) & (WL_SLOTS - 1);
       for (int probe = 0; probe < 4 && !done; probe++) {
-        unsigned long long cur = ((volatile unsigned long long *)l_key)[j];
+        unsigned long long cur = __hip_atomic_load(&l_key[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_read, not a flat load
         if (cur == PT_EMPTY) {
           cur = atomicCAS(&l_key[j], PT_EMPTY, (tag << 40) | pos);
           if (cur == PT_EMPTY) {

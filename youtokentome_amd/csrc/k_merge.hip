@@ -66,7 +66,7 @@ __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, co
   (void)W;
   unsigned int h = (unsigned int)(mix64(key) >> 24) & (AGG_SLOTS - 1);
   for (int probe = 0; probe < 8; probe++) {
-    unsigned long long k = ((volatile unsigned long long *)A.key)[h];
+    unsigned long long k = __hip_atomic_load(&A.key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_read, not a flat load
     if (k == PT_EMPTY) {
       k = atomicCAS(&A.key[h], PT_EMPTY, key);
       if (k == PT_EMPTY) k = key;
