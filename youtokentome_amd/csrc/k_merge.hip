@@ -378,37 +378,43 @@ __global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, De
   WaveLds<SLOT> &W = WL[wave];
   const uint32_t stride = gridDim.x * WPB;
   const uint32_t NT = ts.n_tiles;
-  // Software pipeline over the tiles of this wave: tokens are fetched TWO tiles ahead into two alternating register
-  // buffers and tile headers three ahead, so that the only HBM latency a tile without merge candidates waits for is a
-  // load issued two tiles earlier.  (vmcnt retires in order: the header load is issued before the token fetch.)
-  uint32_t t = blockIdx.x * WPB + wave;           // tile i
-  int n0 = 0, n1 = 0, n2 = 0;                     // live lengths of tiles i, i+1, i+2
-  uint32_t w0 = 0, w1 = 0, w2 = 0;                // first word index of tiles i, i+1, i+2
-  if (t < NT) { n0 = (int)ts.tile_len[t]; w0 = ts.tile_word0[t]; }
-  if (t + stride < NT) { n1 = (int)ts.tile_len[t + stride]; w1 = ts.tile_word0[t + stride]; }
-  if (t + 2 * stride < NT) { n2 = (int)ts.tile_len[t + 2 * stride]; w2 = ts.tile_word0[t + 2 * stride]; }
-  uint4 ra[SLOT / 256], rb[SLOT / 256];
-  if (t < NT) tile_fetch<SLOT>(ra, ts, t, n0);
-  if (t + stride < NT) tile_fetch<SLOT>(rb, ts, t + stride, n1);
+  // Tile loop of this wave.  Headers (live length, first word) of the next 64 tiles are loaded with ONE vector load
+  // each (lane j holds tile i+j) and handed out by shuffles, so a tile costs no header round trip.  Tokens of tile i+1
+  // are fetched right after tile i has been staged into LDS and arrive while tile i is processed.  (All waits the
+  // compiler emits are vmcnt(0), so a deeper prefetch buys nothing; measured.)
+  uint32_t t = blockIdx.x * WPB + wave;  // tile i
+  int hn = 0;                            // lane j: live length of tile t_batch + j*stride
+  uint32_t hw = 0;                       // lane j: first word of that tile
+  uint32_t t_batch = t;
+  auto load_headers = [&](uint32_t tb) {
+    const unsigned long long tj = (unsigned long long)tb + (unsigned long long)lane * stride;
+    hn = 0; hw = 0;
+    if (tj < NT) { hn = (int)ts.tile_len[tj]; hw = ts.tile_word0[tj]; }
+  };
+  uint4 r[SLOT / 256];
   TileStats S;
-#define PIPE_STEP(R)                                                                                                \
-  {                                                                                                                 \
-    tile_stage<SLOT, MERGE>(W, A, R, n0, tokflag);                                                                  \
-    int n3 = 0;                                                                                                     \
-    uint32_t w3 = 0;                                                                                                \
-    if (t + 3 * stride < NT) { n3 = (int)ts.tile_len[t + 3 * stride]; w3 = ts.tile_word0[t + 3 * stride]; }         \
-    if (t + 2 * stride < NT) tile_fetch<SLOT>(R, ts, t + 2 * stride, n2);                                            \
-    process_tile<SLOT, MERGE>(W, A, ts, pt, db, rules, rule_mask, self_x, self_z, z_base, t, n0, w0, S);              \
-    wave_sync(); /* everyone is done with this tile's LDS state before it is restaged */                            \
-    t += stride;                                                                                                    \
-    n0 = n1; w0 = w1; n1 = n2; w1 = w2; n2 = n3; w2 = w3;                                                           \
+  int j = 0;
+  if (t < NT) {
+    load_headers(t_batch);
+    tile_fetch<SLOT>(r, ts, t, __shfl(hn, 0));
   }
   while (t < NT) {
-    PIPE_STEP(ra);
-    if (t >= NT) break;
-    PIPE_STEP(rb);
+    const int n0 = __shfl(hn, j);
+    const uint32_t w0 = __shfl(hw, j);
+    tile_stage<SLOT, MERGE>(W, A, r, n0, tokflag);
+    // next tile of this wave: header from the batch (reload the batch every 64 tiles), tokens prefetched now
+    const uint32_t t_next = t + stride;
+    j++;
+    if (j == 64 && t_next < NT) {
+      j = 0;
+      t_batch = t_next;
+      load_headers(t_batch);
+    }
+    if (t_next < NT) tile_fetch<SLOT>(r, ts, t_next, __shfl(hn, j));
+    process_tile<SLOT, MERGE>(W, A, ts, pt, db, rules, rule_mask, self_x, self_z, z_base, t, n0, w0, S);
+    wave_sync();  // everyone is done with this tile's LDS state before it is restaged
+    t = t_next;
   }
-#undef PIPE_STEP
   agg_flush<WPB * 64>(A, pt, db);
   if (MERGE) {
     S.sites = wave_sum_u64(S.sites);
