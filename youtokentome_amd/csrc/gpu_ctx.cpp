@@ -548,6 +548,13 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   for (int ci = 0; ci < 2; ci++) launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, d_stats_, st_);
   t_end(KT_MERGE, 0);
   merge_rounds++;
+  if (getenv("YTTM_TRACE_ROUNDS")) {  // tuning aid: cumulative device stats after every round (adds a sync)
+    unsigned long long stt[8];
+    HIP_CHECK(hipMemcpyAsync(stt, d_stats_, sizeof stt, hipMemcpyDeviceToHost, st_));
+    sync();
+    FILE *f = fopen(getenv("YTTM_TRACE_ROUNDS"), merge_rounds == 1 ? "w" : "a");
+    if (f) { fprintf(f, "%llu %u %llu %llu %llu %llu %u\n", merge_rounds, k, stt[0], stt[1], stt[2], stt[3], cls_[0].n_tiles); fclose(f); }
+  }
   pending_zero_ = true;
   zero_cap_ = cap;
   zero_self_key_ = self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY;

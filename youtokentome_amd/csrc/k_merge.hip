@@ -113,31 +113,69 @@ __device__ inline void tile_fetch(uint4 (&r)[SLOT / 256], const TileSet &ts, uin
   }
 }
 
-__device__ inline uint32_t flagged(uint32_t tok, const AggLds &A, const uint8_t *__restrict__ tokflag) {
-  const uint32_t id = tok & TOK_MASK;
-  uint32_t f;
-  if (id < FLAG_LDS_IDS) f = (A.flagbits[id >> 4] >> ((id & 15u) * 2)) & 3u;
-  else f = tokflag[id] & 3u;
-  return tok | (f << 29);
+__device__ inline uint32_t flagged_small(uint32_t tok, const AggLds &A) {
+  const uint32_t id = tok & (FLAG_LDS_IDS - 1);  // ids >= FLAG_LDS_IDS are patched afterwards (rare, wave-uniform test)
+  return tok | (((A.flagbits[id >> 4] >> ((id & 15u) * 2)) & 3u) << 29);
+}
+__device__ inline uint32_t flagged_big(uint32_t tok, const uint8_t *__restrict__ tokflag) {
+  const uint32_t id = tok & TOK_MASK & L_ID;
+  if (id < FLAG_LDS_IDS) return tok;
+  return (tok & ~(L_ISX | L_ISY)) | ((uint32_t)(tokflag[id] & 3u) << 29);
 }
 
-// registers -> LDS (+ the per-token batch flags, gathered for all 16 tokens of a lane at once so that their latency
-// overlaps), sentinels (wave-local).  The batch flags come from the LDS bitmap, so a tile without merge candidates
-// touches no HBM besides its own prefetched tokens.
-template <int SLOT, bool MERGE>
-__device__ inline void tile_stage(WaveLds<SLOT> &W, const AggLds &A, const uint4 (&r)[SLOT / 256], int n, const uint8_t *__restrict__ tokflag) {
+// Batch flags for the 16 tokens a lane holds and the merge-site candidate test, entirely in registers: a tile without
+// any (x-flagged, y-flagged) adjacency -- the common case late in training -- is never staged into LDS at all.
+// Lane l holds tokens 256 j + 4 l + {0,1,2,3} in r[j]; the right neighbour of a lane's last token comes by shuffle.
+template <int SLOT>
+__device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const AggLds &A, const uint8_t *__restrict__ tokflag, uint32_t self_x) {
   const int lane = lane_id();
+  bool big = false;
 #pragma unroll
   for (int j = 0; j < SLOT / 256; j++) {
-    uint4 v = r[j];
-    if (MERGE) {
-      const int i = lane + 64 * j;
-      if (4 * i < n) {
-        v.x = flagged(v.x, A, tokflag); v.y = flagged(v.y, A, tokflag); v.z = flagged(v.z, A, tokflag); v.w = flagged(v.w, A, tokflag);
+    if (256 * j < n) {
+      big = big || ((r[j].x | r[j].y | r[j].z | r[j].w) & TOK_MASK) >= FLAG_LDS_IDS;
+      r[j].x = flagged_small(r[j].x, A); r[j].y = flagged_small(r[j].y, A);
+      r[j].z = flagged_small(r[j].z, A); r[j].w = flagged_small(r[j].w, A);
+    }
+  }
+  if (__ballot(big)) {  // some id does not fit the LDS bitmap: take its flags from the HBM byte table
+#pragma unroll
+    for (int j = 0; j < SLOT / 256; j++) {
+      if (256 * j < n) {
+        r[j].x = flagged_big(r[j].x, tokflag); r[j].y = flagged_big(r[j].y, tokflag);
+        r[j].z = flagged_big(r[j].z, tokflag); r[j].w = flagged_big(r[j].w, tokflag);
       }
     }
-    reinterpret_cast<uint4 *>(W.tk)[lane + 64 * j] = v;
   }
+  bool cand = false;
+#define PAIR_TEST(T0, T1, P)                                                                        \
+  if ((P) + 1 < n && !((T1)&TOK_WS))                                                                 \
+    cand = cand || (((T0)&L_ISX) && ((T1)&L_ISY)) || ((((T0)&L_ID) == self_x) && (((T1)&L_ID) == self_x));
+#pragma unroll
+  for (int j = 0; j < SLOT / 256; j++) {
+    if (256 * j < n) {
+      uint32_t nx = __shfl_down(r[j].x, 1);
+      uint32_t nx0 = TOK_WS;
+      if (j + 1 < SLOT / 256) nx0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
+      if (lane == 63) nx = nx0;
+      const int p = 256 * j + 4 * lane;
+      PAIR_TEST(r[j].x, r[j].y, p)
+      PAIR_TEST(r[j].y, r[j].z, p + 1)
+      PAIR_TEST(r[j].z, r[j].w, p + 2)
+      PAIR_TEST(r[j].w, nx, p + 3)
+    }
+  }
+#undef PAIR_TEST
+  return __ballot(cand) != 0;
+}
+
+// registers -> LDS, sentinels (wave-local)
+template <int SLOT>
+__device__ inline void tile_stage(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256], int n) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int j = 0; j < SLOT / 256; j++)
+    if (256 * j < n) reinterpret_cast<uint4 *>(W.tk)[lane + 64 * j] = r[j];
   wave_sync();
   if (lane == 0) {
     W.tk[n] = TOK_WS;  // sentinel: "next token starts a word" => no adjacency past the end
@@ -366,7 +404,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
 }
 
 template <int SLOT, int WPB, bool MERGE>
-__global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
+__global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                                                     unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
@@ -401,7 +439,9 @@ __global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, De
   while (t < NT) {
     const int n0 = __shfl(hn, j);
     const uint32_t w0 = __shfl(hw, j);
-    tile_stage<SLOT, MERGE>(W, A, r, n0, tokflag);
+    // K4: a tile with no (x-flagged, y-flagged) adjacency is dismissed in registers and never touches LDS
+    const bool dirty = MERGE ? reg_candidates<SLOT>(r, n0, A, tokflag, self_x) : true;
+    if (dirty) tile_stage<SLOT>(W, r, n0);
     // next tile of this wave: header from the batch (reload the batch every 64 tiles), tokens prefetched now
     const uint32_t t_next = t + stride;
     j++;
@@ -411,8 +451,12 @@ __global__ __launch_bounds__(WPB * 64) void k_tiles(TileSet ts, PairTable pt, De
       load_headers(t_batch);
     }
     if (t_next < NT) tile_fetch<SLOT>(r, ts, t_next, __shfl(hn, j));
-    process_tile<SLOT, MERGE>(W, A, ts, pt, db, rules, rule_mask, self_x, self_z, z_base, t, n0, w0, S);
-    wave_sync();  // everyone is done with this tile's LDS state before it is restaged
+    if (dirty) {
+      process_tile<SLOT, MERGE>(W, A, ts, pt, db, rules, rule_mask, self_x, self_z, z_base, t, n0, w0, S);
+      wave_sync();  // everyone is done with this tile's LDS state before it is restaged
+    } else {
+      S.scanned += (unsigned long long)n0;
+    }
     t = t_next;
   }
   agg_flush<WPB * 64>(A, pt, db);
