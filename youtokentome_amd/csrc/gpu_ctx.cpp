@@ -243,7 +243,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
 }
 
 void GpuCtx::free_class(WordClass &c) {
-  DFREE(c.d_tok); DFREE(c.d_tile_len); DFREE(c.d_tile_word0); DFREE(c.d_wcnt);
+  DFREE(c.d_tok); DFREE(c.d_tile_len); DFREE(c.d_tile_word0); DFREE(c.d_wcnt); DFREE(c.d_worklist); DFREE(c.d_work_n);
   c.ts = TileSet{};
   c.n_unique = c.n_tokens0 = 0;
   c.n_tiles = 0;
@@ -267,6 +267,8 @@ void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, u
   unsigned long long *tile_start = dmalloc<unsigned long long>(c.n_tiles);
   c.d_tile_word0 = dmalloc<uint32_t>(c.n_tiles);
   c.d_tile_len = dmalloc<uint32_t>(c.n_tiles);
+  c.d_worklist = dmalloc<uint32_t>(c.n_tiles + 64);
+  c.d_work_n = dmalloc<unsigned int>(4);
   c.d_tok = dmalloc<uint32_t>((size_t)c.n_tiles * c.slot + 64);
   // slots are read 16 B wide past the live prefix and the staged ids index the flag table: never leave them undefined
   HIP_CHECK(hipMemsetAsync(c.d_tok, 0, ((size_t)c.n_tiles * c.slot + 64) * 4, st_));
@@ -545,7 +547,12 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     launch_set_tokflag(d_tokflag_, d_flagbits_, d_flag_upd_, n_upd, st_);
   }
   t_begin(KT_MERGE);
-  for (int ci = 0; ci < 2; ci++) launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, d_stats_, st_);
+  for (int ci = 0; ci < 2; ci++) {
+    if (!cls_[ci].n_tiles) continue;
+    HIP_CHECK(hipMemsetAsync(cls_[ci].d_work_n, 0, 4, st_));
+    launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
+                       cls_[ci].d_work_n, d_stats_, st_);
+  }
   t_end(KT_MERGE, 0);
   merge_rounds++;
   if (getenv("YTTM_TRACE_ROUNDS")) {  // tuning aid: cumulative device stats after every round (adds a sync)

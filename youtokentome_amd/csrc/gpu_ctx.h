@@ -96,7 +96,8 @@ class GpuCtx {
   // token tiles: class 0 = short words (slot 1024), class 1 = long words (slot 4096)
   struct WordClass {
     TileSet ts{};
-    uint32_t *d_tok = nullptr, *d_tile_len = nullptr, *d_tile_word0 = nullptr, *d_wcnt = nullptr;
+    uint32_t *d_tok = nullptr, *d_tile_len = nullptr, *d_tile_word0 = nullptr, *d_wcnt = nullptr, *d_worklist = nullptr;
+    unsigned int *d_work_n = nullptr;
     unsigned long long n_unique = 0, n_tokens0 = 0;
     unsigned int n_tiles = 0, nom = 0, slot = 0;
   };

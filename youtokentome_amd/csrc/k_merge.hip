@@ -113,9 +113,9 @@ __device__ inline void tile_fetch(uint4 (&r)[SLOT / 256], const TileSet &ts, uin
   }
 }
 
-__device__ inline uint32_t flagged_small(uint32_t tok, const AggLds &A) {
+__device__ inline uint32_t flagged_small(uint32_t tok, const uint32_t *flagbits_lds) {
   const uint32_t id = tok & (FLAG_LDS_IDS - 1);  // ids >= FLAG_LDS_IDS are patched afterwards (rare, wave-uniform test)
-  return tok | (((A.flagbits[id >> 4] >> ((id & 15u) * 2)) & 3u) << 29);
+  return tok | (((flagbits_lds[id >> 4] >> ((id & 15u) * 2)) & 3u) << 29);
 }
 __device__ inline uint32_t flagged_big(uint32_t tok, const uint8_t *__restrict__ tokflag) {
   const uint32_t id = tok & TOK_MASK & L_ID;
@@ -127,15 +127,15 @@ __device__ inline uint32_t flagged_big(uint32_t tok, const uint8_t *__restrict__
 // any (x-flagged, y-flagged) adjacency -- the common case late in training -- is never staged into LDS at all.
 // Lane l holds tokens 256 j + 4 l + {0,1,2,3} in r[j]; the right neighbour of a lane's last token comes by shuffle.
 template <int SLOT>
-__device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const AggLds &A, const uint8_t *__restrict__ tokflag, uint32_t self_x) {
+__device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds, const uint8_t *__restrict__ tokflag, uint32_t self_x) {
   const int lane = lane_id();
   bool big = false;
 #pragma unroll
   for (int j = 0; j < SLOT / 256; j++) {
     if (256 * j < n) {
       big = big || ((r[j].x | r[j].y | r[j].z | r[j].w) & TOK_MASK) >= FLAG_LDS_IDS;
-      r[j].x = flagged_small(r[j].x, A); r[j].y = flagged_small(r[j].y, A);
-      r[j].z = flagged_small(r[j].z, A); r[j].w = flagged_small(r[j].w, A);
+      r[j].x = flagged_small(r[j].x, flagbits_lds); r[j].y = flagged_small(r[j].y, flagbits_lds);
+      r[j].z = flagged_small(r[j].z, flagbits_lds); r[j].w = flagged_small(r[j].w, flagbits_lds);
     }
   }
   if (__ballot(big)) {  // some id does not fit the LDS bitmap: take its flags from the HBM byte table
@@ -407,6 +407,7 @@ template <int SLOT, int WPB, bool MERGE>
 __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
+                                                    const uint32_t *__restrict__ worklist, const unsigned int *__restrict__ work_n,
                                                     unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
   __shared__ WaveLds<SLOT> WL[WPB];
   __shared__ AggLds A;
@@ -415,32 +416,38 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   WaveLds<SLOT> &W = WL[wave];
   const uint32_t stride = gridDim.x * WPB;
-  const uint32_t NT = ts.n_tiles;
+  // K4 runs over the worklist of dirty tiles written by k_filter; K3 over all tiles
+  const uint32_t NT = worklist ? *work_n : ts.n_tiles;
   // Tile loop of this wave.  Headers (live length, first word) of the next 64 tiles are loaded with ONE vector load
   // each (lane j holds tile i+j) and handed out by shuffles, so a tile costs no header round trip.  Tokens of tile i+1
   // are fetched right after tile i has been staged into LDS and arrive while tile i is processed.  (All waits the
   // compiler emits are vmcnt(0), so a deeper prefetch buys nothing; measured.)
-  uint32_t t = blockIdx.x * WPB + wave;  // tile i
-  int hn = 0;                            // lane j: live length of tile t_batch + j*stride
-  uint32_t hw = 0;                       // lane j: first word of that tile
+  uint32_t t = blockIdx.x * WPB + wave;  // work item i (tile index, or index into the worklist)
+  int hn = 0;                            // lane j: live length of work item t_batch + j*stride
+  uint32_t hw = 0, ht = 0;               // lane j: first word / tile id of that work item
   uint32_t t_batch = t;
   auto load_headers = [&](uint32_t tb) {
     const unsigned long long tj = (unsigned long long)tb + (unsigned long long)lane * stride;
-    hn = 0; hw = 0;
-    if (tj < NT) { hn = (int)ts.tile_len[tj]; hw = ts.tile_word0[tj]; }
+    hn = 0; hw = 0; ht = 0;
+    if (tj < NT) {
+      ht = worklist ? worklist[tj] : (uint32_t)tj;
+      hn = (int)ts.tile_len[ht];
+      hw = ts.tile_word0[ht];
+    }
   };
   uint4 r[SLOT / 256];
   TileStats S;
   int j = 0;
   if (t < NT) {
     load_headers(t_batch);
-    tile_fetch<SLOT>(r, ts, t, __shfl(hn, 0));
+    tile_fetch<SLOT>(r, ts, __shfl(ht, 0), __shfl(hn, 0));
   }
   while (t < NT) {
     const int n0 = __shfl(hn, j);
     const uint32_t w0 = __shfl(hw, j);
+    const uint32_t tile = __shfl(ht, j);
     // K4: a tile with no (x-flagged, y-flagged) adjacency is dismissed in registers and never touches LDS
-    const bool dirty = MERGE ? reg_candidates<SLOT>(r, n0, A, tokflag, self_x) : true;
+    const bool dirty = MERGE ? reg_candidates<SLOT>(r, n0, A.flagbits, tokflag, self_x) : true;
     if (dirty) tile_stage<SLOT>(W, r, n0);
     // next tile of this wave: header from the batch (reload the batch every 64 tiles), tokens prefetched now
     const uint32_t t_next = t + stride;
@@ -450,9 +457,9 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
       t_batch = t_next;
       load_headers(t_batch);
     }
-    if (t_next < NT) tile_fetch<SLOT>(r, ts, t_next, __shfl(hn, j));
+    if (t_next < NT) tile_fetch<SLOT>(r, ts, __shfl(ht, j), __shfl(hn, j));
     if (dirty) {
-      process_tile<SLOT, MERGE>(W, A, ts, pt, db, rules, rule_mask, self_x, self_z, z_base, t, n0, w0, S);
+      process_tile<SLOT, MERGE>(W, A, ts, pt, db, rules, rule_mask, self_x, self_z, z_base, tile, n0, w0, S);
       wave_sync();  // everyone is done with this tile's LDS state before it is restaged
     } else {
       S.scanned += (unsigned long long)n0;
@@ -465,10 +472,52 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
     if (lane == 0) {
       if (S.sites) atomicAdd(&stats[0], S.sites);
       if (S.touched) atomicAdd(&stats[1], S.touched);
-      if (S.scanned) atomicAdd(&stats[2], S.scanned);
+      if (S.scanned && !worklist) atomicAdd(&stats[2], S.scanned);
       if (S.touched_tok) atomicAdd(&stats[3], S.touched_tok);
     }
   }
+}
+
+// K4 filter: streams every tile once with maximal occupancy (no per-wave LDS, two tiles in flight per wave) and writes
+// the ids of the tiles that contain a merge-site candidate -- an x-flagged token followed by a y-flagged one, or the
+// x x of a self rule -- to the worklist that k_tiles<..., true> then processes.  Late in training a batch touches a
+// few percent of the tiles; this pass is the part that has to run at HBM speed.
+template <int SLOT>
+__global__ __launch_bounds__(BLOCK) void k_filter(TileSet ts, const uint8_t *__restrict__ tokflag, const uint32_t *__restrict__ flagbits,
+                                                  uint32_t self_x, uint32_t *__restrict__ worklist, unsigned int *__restrict__ work_n,
+                                                  unsigned long long *__restrict__ stats) {
+  __shared__ uint32_t fb[FLAG_LDS_IDS / 16];
+  for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += BLOCK) fb[s] = flagbits[s];
+  __syncthreads();
+  const int lane = lane_id();
+  const uint32_t stride = gridDim.x * NWAVES;
+  const uint32_t NT = ts.n_tiles;
+  uint32_t my_dirty = 0;  // lane k keeps the k-th dirty tile found by this wave since the last flush
+  int nd = 0;
+  unsigned long long scanned = 0;
+  auto flush = [&]() {
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(work_n, (unsigned int)nd);
+    base = __shfl(base, 0);
+    if (lane < nd) worklist[base + lane] = my_dirty;
+    nd = 0;
+  };
+  for (uint32_t t = blockIdx.x * NWAVES + (threadIdx.x >> 6); t < NT; t += 2 * stride) {
+    const uint32_t t2 = t + stride;
+    const int n1 = (int)ts.tile_len[t];
+    const int n2 = t2 < NT ? (int)ts.tile_len[t2] : 0;
+    uint4 r1[SLOT / 256], r2[SLOT / 256];
+    tile_fetch<SLOT>(r1, ts, t, n1);
+    if (t2 < NT) tile_fetch<SLOT>(r2, ts, t2, n2);
+    const bool d1 = reg_candidates<SLOT>(r1, n1, fb, tokflag, self_x);
+    const bool d2 = t2 < NT && reg_candidates<SLOT>(r2, n2, fb, tokflag, self_x);
+    scanned += (unsigned long long)(n1 + n2);
+    if (d1) { if (lane == nd) my_dirty = t; nd++; }
+    if (d2) { if (lane == nd) my_dirty = t2; nd++; }
+    if (nd >= 62) flush();
+  }
+  if (nd) flush();
+  if (lane == 0 && scanned) atomicAdd(&stats[2], scanned);
 }
 
 // ------------------------------------------------------------------------------------------------- pair table kernels
@@ -680,22 +729,28 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (unsigned long long *)nullptr);
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr);
   else
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (unsigned long long *)nullptr);
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr);
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
-                        unsigned long long *stats, hipStream_t st) {
+                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, hipStream_t st) {
   if (!ts.n_tiles) return;
-  if (cls == 0)
+  // pass 1: which tiles have a merge-site candidate; pass 2: apply the batch to those
+  unsigned int fg = (ts.n_tiles + 2 * NWAVES - 1) / (2 * NWAVES);
+  if (fg > 256 * 8) fg = 256 * 8;
+  if (cls == 0) {
+    hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, self_x, worklist, work_n, stats);
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                       tokflag, flagbits, self_x, self_z, z_base, stats);
-  else
+                       tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats);
+  } else {
+    hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, self_x, worklist, work_n, stats);
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                       tokflag, flagbits, self_x, self_z, z_base, stats);
+                       tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats);
+  }
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
                       unsigned int *n_out, unsigned long long *hist, hipStream_t st) {
