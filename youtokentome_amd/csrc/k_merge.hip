@@ -45,10 +45,12 @@ struct AggLds {
   unsigned long long key[AGG_SLOTS];
   unsigned long long val[AGG_SLOTS];
   uint32_t flagbits[FLAG_LDS_IDS / 16];  // 2 bits per token id: bit0 = x of a batch rule, bit1 = y of a batch rule
+  unsigned int new_keys;                 // slots claimed by this workgroup (added to pt.n_keys once, at the end)
+  unsigned long long st[4];              // workgroup-local stats (one global atomic each at the end)
 };
 
-__device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta) {
-  pt_add(pt, key, delta);
+__device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta, unsigned int *new_keys) {
+  pt_add(pt, key, delta, new_keys);
   if (db.recs) {
     unsigned long long i = atomicAdd(db.n, 1ull);
     if (i < db.cap) {
@@ -77,7 +79,7 @@ __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, co
     }
     h = (h + 1) & (AGG_SLOTS - 1);
   }
-  global_emit(pt, db, key, delta);
+  global_emit(pt, db, key, delta, &A.new_keys);
 }
 
 template <int NT>
@@ -88,6 +90,7 @@ __device__ inline void agg_init(AggLds &A, const uint32_t *__restrict__ flagbits
   }
   if (flagbits_g)
     for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += NT) A.flagbits[s] = flagbits_g[s];
+  if (threadIdx.x == 0) { A.new_keys = 0; A.st[0] = A.st[1] = A.st[2] = A.st[3] = 0; }
 }
 template <int NT>
 __device__ inline void agg_flush(AggLds &A, const PairTable &pt, const DeltaBuf &db) {
@@ -96,7 +99,7 @@ __device__ inline void agg_flush(AggLds &A, const PairTable &pt, const DeltaBuf 
     unsigned long long k = A.key[s];
     if (k != PT_EMPTY) {
       long long v = (long long)A.val[s];
-      if (v != 0) global_emit(pt, db, k, v);
+      if (v != 0) global_emit(pt, db, k, v, &A.new_keys);
     }
   }
 }
@@ -466,15 +469,22 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
     }
     t = t_next;
   }
-  agg_flush<WPB * 64>(A, pt, db);
   if (MERGE) {
     S.sites = wave_sum_u64(S.sites);
     if (lane == 0) {
-      if (S.sites) atomicAdd(&stats[0], S.sites);
-      if (S.touched) atomicAdd(&stats[1], S.touched);
-      if (S.scanned && !worklist) atomicAdd(&stats[2], S.scanned);
-      if (S.touched_tok) atomicAdd(&stats[3], S.touched_tok);
+      if (S.sites) atomicAdd(&A.st[0], S.sites);
+      if (S.touched) atomicAdd(&A.st[1], S.touched);
+      if (S.scanned && !worklist) atomicAdd(&A.st[2], S.scanned);
+      if (S.touched_tok) atomicAdd(&A.st[3], S.touched_tok);
     }
+  }
+  agg_flush<WPB * 64>(A, pt, db);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (A.new_keys) atomicAdd(pt.n_keys, A.new_keys);
+    if (MERGE)
+      for (int i = 0; i < 4; i++)
+        if (A.st[i]) atomicAdd(&stats[i], A.st[i]);
   }
 }
 
@@ -489,35 +499,53 @@ __global__ __launch_bounds__(BLOCK) void k_filter(TileSet ts, const uint8_t *__r
   __shared__ uint32_t fb[FLAG_LDS_IDS / 16];
   for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += BLOCK) fb[s] = flagbits[s];
   __syncthreads();
+  __shared__ uint32_t dl[1024];  // dirty tiles found by this workgroup since the last flush
+  __shared__ unsigned int dn, dbase;
+  __shared__ unsigned long long scanned_blk;
+  if (threadIdx.x == 0) { dn = 0; scanned_blk = 0; }
+  __syncthreads();
   const int lane = lane_id();
   const uint32_t stride = gridDim.x * NWAVES;
   const uint32_t NT = ts.n_tiles;
-  uint32_t my_dirty = 0;  // lane k keeps the k-th dirty tile found by this wave since the last flush
-  int nd = 0;
   unsigned long long scanned = 0;
-  auto flush = [&]() {
-    unsigned int base = 0;
-    if (lane == 0) base = atomicAdd(work_n, (unsigned int)nd);
-    base = __shfl(base, 0);
-    if (lane < nd) worklist[base + lane] = my_dirty;
-    nd = 0;
-  };
-  for (uint32_t t = blockIdx.x * NWAVES + (threadIdx.x >> 6); t < NT; t += 2 * stride) {
+  // all waves of the workgroup run the same number of iterations, so the block-level flush below is convergent
+  const uint32_t first = blockIdx.x * NWAVES;
+  for (uint32_t tb = first; tb < NT; tb += 2 * stride) {
+    const uint32_t t = tb + (threadIdx.x >> 6);
     const uint32_t t2 = t + stride;
-    const int n1 = (int)ts.tile_len[t];
-    const int n2 = t2 < NT ? (int)ts.tile_len[t2] : 0;
-    uint4 r1[SLOT / 256], r2[SLOT / 256];
-    tile_fetch<SLOT>(r1, ts, t, n1);
-    if (t2 < NT) tile_fetch<SLOT>(r2, ts, t2, n2);
-    const bool d1 = reg_candidates<SLOT>(r1, n1, fb, tokflag, self_x);
-    const bool d2 = t2 < NT && reg_candidates<SLOT>(r2, n2, fb, tokflag, self_x);
-    scanned += (unsigned long long)(n1 + n2);
-    if (d1) { if (lane == nd) my_dirty = t; nd++; }
-    if (d2) { if (lane == nd) my_dirty = t2; nd++; }
-    if (nd >= 62) flush();
+    bool d1 = false, d2 = false;
+    if (t < NT) {
+      const int n1 = (int)ts.tile_len[t];
+      const int n2 = t2 < NT ? (int)ts.tile_len[t2] : 0;
+      uint4 r1[SLOT / 256], r2[SLOT / 256];
+      tile_fetch<SLOT>(r1, ts, t, n1);
+      if (t2 < NT) tile_fetch<SLOT>(r2, ts, t2, n2);
+      d1 = reg_candidates<SLOT>(r1, n1, fb, tokflag, self_x);
+      d2 = t2 < NT && reg_candidates<SLOT>(r2, n2, fb, tokflag, self_x);
+      scanned += (unsigned long long)(n1 + n2);
+      if (lane == 0) {
+        if (d1) dl[atomicAdd(&dn, 1u)] = t;
+        if (d2) dl[atomicAdd(&dn, 1u)] = t2;
+      }
+    }
+    __syncthreads();
+    if (dn > 1024 - 2 * NWAVES) {  // one global atomic per flush per workgroup
+      if (threadIdx.x == 0) dbase = atomicAdd(work_n, dn);
+      __syncthreads();
+      for (unsigned int i = threadIdx.x; i < dn; i += BLOCK) worklist[dbase + i] = dl[i];
+      __syncthreads();
+      if (threadIdx.x == 0) dn = 0;
+      __syncthreads();
+    }
   }
-  if (nd) flush();
-  if (lane == 0 && scanned) atomicAdd(&stats[2], scanned);
+  if (lane == 0 && scanned) atomicAdd(&scanned_blk, scanned);
+  __syncthreads();
+  if (dn) {
+    if (threadIdx.x == 0) dbase = atomicAdd(work_n, dn);
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < dn; i += BLOCK) worklist[dbase + i] = dl[i];
+  }
+  if (threadIdx.x == 0 && scanned_blk) atomicAdd(&stats[2], scanned_blk);
 }
 
 // ------------------------------------------------------------------------------------------------- pair table kernels

@@ -90,14 +90,17 @@ __device__ inline unsigned long long ld_agent(const unsigned long long *p) {
 }
 
 // pair table: insert-or-add.  Keys are never removed, so a non-empty slot observed once stays valid.
-__device__ inline void pt_add(const PairTable &pt, unsigned long long key, long long delta) {
+// `new_keys` (optional): a workgroup-local counter of freshly claimed slots; the caller adds it to pt.n_keys once per
+// workgroup -- thousands of waves bumping ONE global counter serialise at the L2 atomic unit and put a floor of
+// ~0.1 ms under every launch.
+__device__ inline void pt_add(const PairTable &pt, unsigned long long key, long long delta, unsigned int *new_keys = nullptr) {
   unsigned long long i = mix64(key) & pt.mask;
   for (;;) {
     unsigned long long k = ld_agent(&pt.keys[i]);
     if (k == PT_EMPTY) {
       k = atomicCAS(&pt.keys[i], PT_EMPTY, key);
       if (k == PT_EMPTY) {
-        atomicAdd(pt.n_keys, 1u);
+        atomicAdd(new_keys ? new_keys : pt.n_keys, 1u);
         k = key;
       }
     }
