@@ -219,6 +219,9 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
     throw GpuError{"a word longer than " + std::to_string(MAX_WORD_TOKENS - 1) + " characters is not supported by the tile kernels yet"};
   }
   const unsigned int U = h_status[0], UB = h_status[2], UA = U - UB;
+  // A tile holds whole words in a fixed slot and only ever shrinks, so the slack a slot needs is one word: pack the
+  // slots as full as the longest word allows (HBM pages are then read densely and there are fewer tiles to visit).
+  if (h_status[3] > 0 && h_status[3] < (unsigned int)TILE_NOM_A) cls_[0].nom = (unsigned int)TILE_SLOT_A - h_status[3];
   n_unique = U;
   if (U == 0) { DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len); return; }
   unsigned long long *posA = dmalloc<unsigned long long>(UA), *posB = dmalloc<unsigned long long>(UB);

@@ -251,6 +251,7 @@ __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsi
         atomicAdd(&ht_cnt[i], count);
         atomicAdd(&status[0], 1u);
         if (len_tokens > (uint32_t)TILE_NOM_A) atomicAdd(&status[2], 1u);
+        else atomicMax(&status[3], len_tokens);  // longest class-A word: decides how full a tile slot may be packed
         return;
       }
     }
