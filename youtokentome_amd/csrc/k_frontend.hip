@@ -251,7 +251,6 @@ __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsi
         atomicAdd(&ht_cnt[i], count);
         atomicAdd(&status[0], 1u);
         if (len_tokens > (uint32_t)TILE_NOM_A) atomicAdd(&status[2], 1u);
-        else atomicMax(&status[3], len_tokens);  // longest class-A word: decides how full a tile slot may be packed
         return;
       }
     }
@@ -277,7 +276,9 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
   __shared__ unsigned long long l_hash[WL_SLOTS];  // full hash of the word (for the flush)
   __shared__ unsigned int l_cnt[WL_SLOTS];
   __shared__ unsigned int l_len[WL_SLOTS];
+  __shared__ unsigned int l_maxlen;  // longest class-A word seen by this workgroup (one global atomicMax at the end)
   for (int i = (int)threadIdx.x; i < WL_SLOTS; i += BLOCK) { l_key[i] = PT_EMPTY; l_cnt[i] = 0; }
+  if (threadIdx.x == 0) l_maxlen = 0;
   __syncthreads();
   unsigned long long s = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
     if (L == 0) continue;  // segment made only of dropped chars: no word (bpe.cpp:357-380 deletes them first)
     if (L + 1 > (uint32_t)MAX_WORD_TOKENS) { atomicOr(&status[1], 1u); continue; }
     const unsigned long long tag = h >> 40;
+    if (L + 1 <= (uint32_t)TILE_NOM_A && L + 1 > l_maxlen) atomicMax(&l_maxlen, L + 1);
     bool done = false;
     if (L <= 8) {  // only short words are frequent enough to be worth an LDS slot
       unsigned int j = (unsigned int)(h >> 8) & (WL_SLOTS - 1);
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
     if (k != PT_EMPTY)
       word_insert_global(text, n, cpmap, l_hash[i], k & WH_POS_MASK, l_len[i], (unsigned long long)l_cnt[i], ht_key, ht_cnt, ht_len, ht_mask, status);
   }
+  if (threadIdx.x == 0 && l_maxlen) atomicMax(&status[3], l_maxlen);
 }
 
 // Compact occupied hash slots into the unique-word arrays of the two tile classes (short words: block-aggregated
