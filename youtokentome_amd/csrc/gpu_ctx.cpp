@@ -37,10 +37,13 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   d_counters_ = dmalloc<unsigned long long>(64);
   d_stats_ = dmalloc<unsigned long long>(8);
   HIP_CHECK(hipMemset(d_stats_, 0, 8 * sizeof(unsigned long long)));
-  d_cand_ = dmalloc<CandRec>(CAND_CAP);
+  // one block for everything the host reads back per round, so that it is ONE device-to-host copy:
+  // [0] n_cand, [4] n_keys | [64..) count histogram | [8192..) candidates
+  d_round_ = dmalloc<unsigned char>(8192 + (size_t)CAND_CAP * sizeof(CandRec));
+  d_cand_n_ = (unsigned int *)d_round_;
+  d_cand_hist_ = (unsigned long long *)(d_round_ + 64);
+  d_cand_ = (CandRec *)(d_round_ + 8192);
   cand_cap_ = CAND_CAP;
-  d_cand_n_ = dmalloc<unsigned int>(4);
-  d_cand_hist_ = dmalloc<unsigned long long>(CAND_BINS);
   d_rules_ = dmalloc<RuleSlot>(RULES_CAP);
   rules_cap_ = RULES_CAP;
   HIP_CHECK(hipHostMalloc(&h_pin_, PIN_BYTES, hipHostMallocDefault));
@@ -53,7 +56,7 @@ GpuCtx::~GpuCtx() {
   for (auto &e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_); DFREE(d_flagbits_);
   free_class(cls_[0]); free_class(cls_[1]);
-  DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_cand_); DFREE(d_cand_n_); DFREE(d_cand_hist_); DFREE(d_recv_);
+  DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_);
   if (db_.recs) (void)hipFree(db_.recs);
   if (db_.n) (void)hipFree(db_.n);
   free_table(pt_);
@@ -449,21 +452,22 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
   t_begin(KT_CAND);
   launch_cand_scan(pt_, tau_cnt, tau_mx, d_cand_, cand_cap_, d_cand_n_, hist ? d_cand_hist_ : nullptr, st_);
   t_end(KT_CAND, 16 * pt_cap_);
-  // one D2H for header + histogram, a second one for the candidates
-  unsigned int *h_n = (unsigned int *)h_pin_;
-  unsigned long long *h_hist = (unsigned long long *)((char *)h_pin_ + 64);
-  HIP_CHECK(hipMemcpyAsync(h_n, d_cand_n_, 4, hipMemcpyDeviceToHost, st_));
-  if (hist) HIP_CHECK(hipMemcpyAsync(h_hist, d_cand_hist_, CAND_BINS * 8, hipMemcpyDeviceToHost, st_));
+  // ONE device-to-host copy per round: header + histogram + the first CAND_FAST candidates; a second copy only when
+  // more candidates passed (the host rarely looks past a few thousand)
+  constexpr unsigned int CAND_FAST = 4096;
+  unsigned char *h = (unsigned char *)h_pin_;
+  HIP_CHECK(hipMemcpyAsync(h, d_round_, 8192 + (size_t)CAND_FAST * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
   sync();
-  const unsigned int n = *h_n;
-  if (hist) memcpy(hist, h_hist, CAND_BINS * 8);
+  const unsigned int n = *(unsigned int *)h;
+  n_keys_host = *(unsigned int *)(h + 4);
+  if (hist) memcpy(hist, h + 64, CAND_BINS * 8);
   const unsigned int take = std::min(n, cand_cap_);
-  if (take) {
-    CandRec *h_c = (CandRec *)((char *)h_pin_ + (1u << 16));
-    HIP_CHECK(hipMemcpyAsync(h_c, d_cand_, (size_t)take * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
+  CandRec *h_c = (CandRec *)(h + 8192);
+  if (take > CAND_FAST) {
+    HIP_CHECK(hipMemcpyAsync(h_c + CAND_FAST, d_cand_ + CAND_FAST, (size_t)(take - CAND_FAST) * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
     sync();
-    out.assign(h_c, h_c + take);
   }
+  out.assign(h_c, h_c + take);
   return n;
 }
 
@@ -503,7 +507,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // rule hash (x != y rules) + at most one x == y rule passed by value
   unsigned int cap = 64;
   while (cap < 2 * k) cap <<= 1;
-  char *pin = (char *)h_pin_ + (1u << 16) + (size_t)CAND_CAP * sizeof(CandRec);
+  char *pin = (char *)h_pin_ + (1u << 16) + (size_t)CAND_CAP * sizeof(CandRec);  // after the read-back area of candidates()
   RuleSlot *h_rules = (RuleSlot *)pin;
   uint32_t *h_upd = (uint32_t *)(pin + (size_t)RULES_CAP * sizeof(RuleSlot));
   for (unsigned int i = 0; i < cap; i++) { h_rules[i].key = PT_EMPTY; h_rules[i].z = 0; h_rules[i].pad = 0; }
@@ -572,11 +576,15 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     rounds_since_check_ = 0;
     for (int ci = 0; ci < 2; ci++) maybe_repack(ci);
   }
-  unsigned int nk = 0;
-  HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
-  sync();  // also makes the pinned staging reusable
-  n_keys_host = nk;
-  exchange_deltas();
+  if (comm_ && comm_->world > 1) {
+    unsigned int nk = 0;
+    HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
+    sync();
+    n_keys_host = nk;
+    exchange_deltas();
+  }
+  // single GPU: no sync here -- the candidate filter that always follows reads n_keys back together with its results
+  // (its sync also makes the pinned rule staging reusable for the next round)
   // every occurrence of the batch's pairs has been merged (on every rank): their counts are exactly zero
   launch_pt_zero(pt_, d_rules_, zero_cap_, zero_self_key_, st_);
   pending_zero_ = false;

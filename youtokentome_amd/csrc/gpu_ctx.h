@@ -124,6 +124,7 @@ class GpuCtx {
   size_t h_pin_bytes_ = 0;
   std::vector<uint32_t> prev_flag_toks_;
   // candidates
+  unsigned char *d_round_ = nullptr;
   CandRec *d_cand_ = nullptr;
   unsigned int cand_cap_ = 0;
   unsigned int *d_cand_n_ = nullptr;

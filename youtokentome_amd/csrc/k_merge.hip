@@ -563,6 +563,7 @@ __global__ __launch_bounds__(BLOCK) void k_cand_scan(PairTable pt, unsigned long
                                                      unsigned long long *__restrict__ hist) {
   __shared__ unsigned int lh[CAND_BINS];
   for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) lh[b] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) n_out[1] = *pt.n_keys;  // rides along in the host's per-round read-back
   __syncthreads();
   const unsigned long long n_slots = pt.mask + 1;
   const unsigned long long n_iter = (n_slots + BLOCK - 1) / BLOCK;
