@@ -142,16 +142,31 @@ def main():
                           "avg_ms": round(k["ms"] / k["launches"], 4),
                           "algorithmic_GB": round(k["bytes"] / 1e9, 4),
                           "GBps": round(k["bytes"] / 1e9 / (k["ms"] / 1e3), 1)}
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, separate
+    # --pmc runs of this same command; tools/pmc_summary.py) -- only quoted for the exact workload they were taken on
+    traffic = {}
+    pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_hbm_1gb_final.json")
+    if os.path.exists(pmc_file) and args.size_mb == 1000 and args.corpus == "abcd" and args.vocab == 32000 and n_gpus == 1:
+        pm = json.load(open(pmc_file))
+        fam = {"char_hist": ["k_scan_bytes<0>"], "segments": ["k_scan_bytes<1>"], "dedup": ["k2b_insert_words"],
+               "pair_count": ["k_tiles<1024, 4, false>"], "merge_apply": ["k_filter<1024>", "k_tiles<1024, 4, true>"],
+               "cand_scan": ["k_cand_scan"]}
+        for name, ks in fam.items():
+            if all(k in pm for k in ks):
+                traffic[name] = sum(pm[k]["traffic_bytes_per_launch"] for k in ks)
     dom = max(kern, key=lambda n: kern[n]["ms_total"]) if kern else None
     roofline = None
     if dom:
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic.get(dom),
+                    "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r1_pmc_hbm_1gb_final.json)",
+                    "algorithmic_bytes_per_launch": round(kern[dom]["algorithmic_GB"] * 1e9 / kern[dom]["launches"]),
                     "avg_launch_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"]}
     roofline_pc = None
     if "pair_count" in kern:
         roofline_pc = {"kernel": "pair_count (K3)", "bound": "hbm", "achieved": kern["pair_count"]["GBps"], "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": round(kern["pair_count"]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None}
+                       "unit": "GB/s", "frac": round(kern["pair_count"]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic.get("pair_count"),
+                       "algorithmic_bytes_per_launch": round(kern["pair_count"]["algorithmic_GB"] * 1e9)}
 
     out = {
         "metric": "bpe_train_throughput", "value": round(value, 2), "unit": "MB/s", "n_gpus": n_gpus, "steps": args.steps,
