@@ -85,11 +85,12 @@ void GpuCtx::t_end(int which, unsigned long long bytes) {
 void GpuCtx::resolve_timers() {
   sync();
   {
-    // K4 traffic: every pass streams the live tokens once (4 B each) and rewrites the tiles that had a merge site
+    // K4 traffic: the filter streams the live tokens once (4 B each); the apply kernel re-reads and rewrites the tiles
+    // that had a merge site
     unsigned long long st[8] = {0};
     if (hipMemcpy(st, d_stats_, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
       merge_sites = st[0];
-      kt.bytes[KT_MERGE] = 4 * st[2] + 4 * st[3];
+      kt.bytes[KT_MERGE] = 4 * st[2] + 8 * st[3];
     }
   }
   FILE *trace = getenv("YTTM_TRACE") ? fopen(getenv("YTTM_TRACE"), "w") : nullptr;  // per-launch times for tuning
