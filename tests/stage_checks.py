@@ -188,6 +188,39 @@ def check_encode_vs_oracle(model_path, sentences, flags=((0, 0, 0), (1, 1, 0), (
         assert bpe.encode(sentences, yttm.OutputType.ID, bos=b, eos=e, reverse=r) == want
 
 
+def check_encode_mixed_shapes(n_sent=150, seed=11, model="readme_small"):
+    """Shapes that steer the encode kernels: many short sentences per wavefront group, sentences that only partly fit a
+    wavefront's LDS region, sentences beyond it (cooperative kernel on HBM scratch), words of every length class
+    (<=4, <=8, <=16, longer), runs of one letter, unknown characters, empty lines."""
+    import random
+    rng = random.Random(seed)
+    model_path = os.path.join(G, f"train_{model}.model")
+    sents = []
+    for i in range(n_sent):
+        kind = i % 10
+        if kind < 4:
+            nbytes = rng.randint(0, 40)
+        elif kind < 7:
+            nbytes = rng.randint(100, 260)
+        elif kind < 9:
+            nbytes = rng.randint(261, 519)
+        else:
+            nbytes = rng.randint(520, 1500)
+        out = []
+        size = 0
+        while size < nbytes:
+            r = rng.random()
+            wl = rng.randint(1, 4) if r < 0.5 else rng.randint(5, 8) if r < 0.8 else rng.randint(9, 16) if r < 0.95 else rng.randint(17, 60)
+            if rng.random() < 0.1:
+                w = rng.choice("abcd") * wl
+            else:
+                w = "".join(rng.choice("abcd") if rng.random() > 0.03 else rng.choice("xyz\u044f") for _ in range(wl))
+            out.append(w)
+            size += wl + 1
+        sents.append((" " * rng.randint(0, 2)).join([""] + out) if rng.random() < 0.2 else " ".join(out))
+    check_encode_vs_oracle(model_path, sents, flags=((0, 0, 0), (1, 1, 1)))
+
+
 def check_dropout_extremes(model_path, sentences):
     """p -> 0 must reproduce the deterministic encoder; p = 1 must leave every word at character level
     (DropoutQueue skips every event, bpe.cpp:1430-1437)."""

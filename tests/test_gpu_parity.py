@@ -79,6 +79,10 @@ def test_stress_texts_vs_oracle(tmp_path):
             S.check_encode_vs_oracle(model, [gen.stress_text(rng, 1000, False) for _ in range(4)], flags=((0, 0, 0),))
 
 
+def test_encode_mixed_shapes():
+    S.check_encode_mixed_shapes(n_sent=3000)
+
+
 def test_config_errors(tmp_path):
     for kw in [dict(coverage=0.0), dict(coverage=1.5), dict(ids=(0, 300, 2, 3)), dict(ids=(0, 1, 1, 3)), dict(ids=(-2, 1, 2, 3)),
                dict(vocab=5)]:

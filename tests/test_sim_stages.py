@@ -62,6 +62,10 @@ def test_train_encode_vs_oracle_random(tmp_path):
             S.check_encode_vs_oracle(model, sents)
 
 
+def test_encode_mixed_shapes():
+    S.check_encode_mixed_shapes(n_sent=150)
+
+
 def test_config_errors(tmp_path):
     for kw in [dict(coverage=0.0), dict(ids=(0, 300, 2, 3)), dict(ids=(0, 1, 1, 3)), dict(vocab=5)]:
         S.check_train_vs_oracle(b"aaa bbb abab", kw.get("vocab", 50), tmp_path, kw.get("coverage", 1.0), kw.get("ids", (0, 1, 2, 3)), tag="e")

@@ -1,5 +1,7 @@
 // host_encoder.cpp -- BaseEncoder (bpe.h:22-82): model load, HBM-resident rule tables, batch encode through K5,
 // and the tiny host-side helpers of the drop-in surface (id<->subword, decode, vocabulary).
+#include <cstdlib>
+#include <cstdio>
 #include <string.h>
 
 #include <algorithm>
@@ -24,6 +26,7 @@ struct EncoderDevice {
   RuleSlot *d_rules = nullptr;
   uint32_t *d_rule_z = nullptr;
   unsigned long long *d_rule_xy = nullptr;
+  uint32_t *d_bloom = nullptr;
   uint32_t *d_drop = nullptr; size_t cap_drop = 0;
   unsigned long long dropout_calls = 0;
   EncModel m{};
@@ -49,7 +52,7 @@ struct EncoderDevice {
     cap = c;
   }
   ~EncoderDevice() {
-    for (void *p : {(void *)d_cpmap, (void *)d_rules, (void *)d_rule_z, (void *)d_rule_xy, (void *)d_drop, (void *)d_bytes, (void *)d_off, (void *)d_scratch, (void *)d_counts,
+    for (void *p : {(void *)d_cpmap, (void *)d_rules, (void *)d_rule_z, (void *)d_rule_xy, (void *)d_bloom, (void *)d_drop, (void *)d_bytes, (void *)d_off, (void *)d_scratch, (void *)d_counts,
                     (void *)d_out_off, (void *)d_scan_tmp, (void *)d_total, (void *)d_ids, (void *)d_work})
       if (p) (void)hipFree(p);
     if (st) (void)hipStreamDestroy(st);
@@ -74,7 +77,7 @@ BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *
     // rule hash: (x,y) -> rule index; later rules overwrite earlier duplicates like rule2id (bpe.cpp:1672-1674)
     const size_t nr = bpe_state.rules.size();
     unsigned int cap = 64;
-    while (cap < 2 * nr + 2) cap <<= 1;
+    while (cap < 4 * nr + 2) cap <<= 1;  // load factor <= 1/4: nine lookups in ten end at the first slot
     std::vector<RuleSlot> slots(cap);
     for (auto &s : slots) { s.key = PT_EMPTY; s.z = 0; s.pad = 0; }
     std::vector<uint32_t> rz(nr ? nr : 1, 0);
@@ -84,7 +87,7 @@ BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *
       rz[i] = r.z;
       rxy[i] = pair_key(r.x, r.y);
       const unsigned long long key = pair_key(r.x, r.y);
-      unsigned int h = (unsigned int)mix64(key) & (cap - 1);
+      unsigned int h = enc_hash(r.x, r.y) & (cap - 1);
       while (slots[h].key != PT_EMPTY && slots[h].key != key) h = (h + 1) & (cap - 1);
       slots[h].key = key;
       slots[h].z = r.z;
@@ -96,13 +99,32 @@ BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *
     HIP_CHECK(hipMemcpy(dev_->d_rule_z, rz.data(), rz.size() * 4, hipMemcpyHostToDevice));
     dev_->d_rule_xy = dalloc<unsigned long long>(rxy.size());
     HIP_CHECK(hipMemcpy(dev_->d_rule_xy, rxy.data(), rxy.size() * 8, hipMemcpyHostToDevice));
+    std::vector<uint32_t> bloom(ENC_BLOOM_WORDS, 0);
+    for (size_t i = 0; i < nr; i++) {
+      const uint32_t h = enc_hash(bpe_state.rules[i].x, bpe_state.rules[i].y);
+      bloom[enc_bloom_word(h)] |= enc_bloom_bits(h);
+    }
+    dev_->d_bloom = dalloc<uint32_t>(ENC_BLOOM_WORDS);
+    HIP_CHECK(hipMemcpy(dev_->d_bloom, bloom.data(), (size_t)ENC_BLOOM_WORDS * 4, hipMemcpyHostToDevice));
     dev_->d_total = dalloc<unsigned long long>(2);
     EncModel &m = dev_->m;
+    m.bloom = dev_->d_bloom;
     m.cpmap = dev_->d_cpmap;
     m.rules = dev_->d_rules;
     m.rule_z = dev_->d_rule_z;
     m.rule_xy = dev_->d_rule_xy;
     m.rule_mask = cap - 1;
+    {  // merged tokens are numbered in rule order with the special ids skipped (bpe.cpp:814-837): z(r) without a load
+      m.z_affine = nr > 0;
+      m.z_base = nr ? rz[0] : 0;
+      for (uint32_t &b : m.z_bp) b = 0xffffffffu;
+      int nbp = 0;
+      for (size_t i = 1; i < nr && m.z_affine; i++) {
+        const long long step = (long long)rz[i] - (long long)rz[i - 1] - 1;
+        if (step < 0 || nbp + step > 4) m.z_affine = 0;
+        else for (long long k = 0; k < step; k++) m.z_bp[nbp++] = (uint32_t)i;
+      }
+    }
     auto it = char2id.find(SPACE_TOKEN);
     m.space_id = it == char2id.end() ? 0u : it->second;
     m.unk_id = bpe_state.special_tokens.unk_id;
@@ -163,28 +185,28 @@ Status BaseEncoder::encode_device(const void *d_bytes, const void *d_offsets, un
     d.grow(d.d_counts, d.cap_counts, (size_t)n_sent);
     d.grow(d.d_out_off, d.cap_out_off, (size_t)n_sent + 1);
     d.grow(d.d_scan_tmp, d.cap_scan_tmp, (size_t)scan_scratch_blocks(n_sent));
-    unsigned int max_blocks = 256 * 3;  // 3 workgroups of 4 waves per CU (48 KB LDS each)
-    const unsigned long long tok_cap = std::max<unsigned long long>(1024, 2 * max_sentence_bytes + 2);  // tokens per sentence
+    unsigned int max_blocks = 256 * 2;  // 2 workgroups of 8 waves per CU (80 KB LDS each)
+    const unsigned long long tok_cap = std::max<unsigned long long>(ENC_LDS_TOKENS, 2 * max_sentence_bytes + 2);  // tokens per sentence
     unsigned long long stride = 0, drop_stride = 0;
     {
       // per-wave HBM scratch: 3 working arrays for sentences that do not fit LDS, + (dropout) word starts and event queues
       unsigned long long per_wave = 0;
-      if (tok_cap > 1024) per_wave += 3 * tok_cap * 4;
+      if (tok_cap > (unsigned long long)ENC_LDS_TOKENS) per_wave += 3 * tok_cap * 4;
       if (dropout_prob > 0) per_wave += 7 * tok_cap * 4;
       if (per_wave) {
         unsigned long long waves = std::max<unsigned long long>(1, (4ull << 30) / per_wave);
-        max_blocks = (unsigned int)std::max<unsigned long long>(1, std::min<unsigned long long>(max_blocks, waves / NWAVES));
+        max_blocks = (unsigned int)std::max<unsigned long long>(1, std::min<unsigned long long>(max_blocks, waves / ENC_WAVES_PER_BLOCK));
       }
     }
-    unsigned long long nb = (n_sent + NWAVES - 1) / NWAVES;
+    unsigned long long nb = (n_sent + ENC_WAVES_PER_BLOCK - 1) / ENC_WAVES_PER_BLOCK;
     const unsigned int n_blocks = (unsigned int)std::min<unsigned long long>(nb, max_blocks);
-    if (tok_cap > 1024) {
+    if (tok_cap > (unsigned long long)ENC_LDS_TOKENS) {
       stride = tok_cap;
-      d.grow(d.d_work, d.cap_work, (size_t)(3 * stride * (unsigned long long)n_blocks * NWAVES));
+      d.grow(d.d_work, d.cap_work, (size_t)(3 * stride * (unsigned long long)n_blocks * ENC_WAVES_PER_BLOCK));
     }
     if (dropout_prob > 0) {
       drop_stride = tok_cap;
-      d.grow(d.d_drop, d.cap_drop, (size_t)(7 * drop_stride * (unsigned long long)n_blocks * NWAVES));
+      d.grow(d.d_drop, d.cap_drop, (size_t)(7 * drop_stride * (unsigned long long)n_blocks * ENC_WAVES_PER_BLOCK));
     }
     const unsigned long long seed = mix64(0x5bd1e995ull + (++d.dropout_calls));
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -11,7 +11,11 @@
 
 namespace yttm {
 
-constexpr int ENC_WCAP = 1024;               // tokens per wave held in LDS
+constexpr int ENC_WCAP = ENC_LDS_TOKENS;     // tokens per wave held in LDS (3 arrays x 2 KB)
+constexpr int ENC_WAVES = ENC_WAVES_PER_BLOCK;
+constexpr int ENC_THREADS = ENC_WAVES * 64;
+constexpr uint32_t ENC_DIRTY = 0xfffffffeu;  // pair (p,p+1) must be looked up again
+constexpr uint32_t ENC_SITE = 0x80000000u;   // pair (p,p+1) is merged in this round
 constexpr uint32_t ENC_UNKP = 0x7ffffff0u;   // placeholder token for a run of unknown chars (bpe.cpp:1517-1527)
 constexpr uint32_t ENC_INF = 0xffffffffu;
 
@@ -28,9 +32,18 @@ struct GlbArr {  // HBM scratch for long sentences: bypass the non-coherent L1 (
   __device__ void amin(int i, uint32_t v) const { atomicMin(&p[i], v); }
 };
 
+__device__ inline RuleSlot enc_load_slot(const EncModel &m, uint32_t h) {  // one global_load_dwordx4
+  const uint4 v = *reinterpret_cast<const uint4 *>(&m.rules[h]);
+  RuleSlot r;
+  r.key = ((unsigned long long)v.y << 32) | v.x;
+  r.z = v.z;
+  r.pad = v.w;
+  return r;
+}
+// slot of the rule (a,b) in the hash, or ENC_INF
 __device__ inline uint32_t enc_rule_lookup(const EncModel &m, uint32_t a, uint32_t b) {
   const unsigned long long key = pair_key(a, b);
-  unsigned int h = (unsigned int)mix64(key) & m.rule_mask;
+  uint32_t h = enc_hash(a, b) & m.rule_mask;
   for (;;) {
     const unsigned long long k = m.rules[h].key;
     if (k == key) return h;
@@ -38,9 +51,22 @@ __device__ inline uint32_t enc_rule_lookup(const EncModel &m, uint32_t a, uint32
     h = (h + 1) & m.rule_mask;
   }
 }
+// priority (= rule index, smaller merges first) of the pair (a,b), or ENC_INF.  The Bloom filter in LDS answers most
+// "no such rule" cases without leaving the CU; a positive costs one 16-byte load from the rule hash (L2-resident).
+__device__ inline uint32_t enc_pair_prio(const EncModel &m, const uint32_t *bloom, uint32_t a, uint32_t b) {
+  const uint32_t h = enc_hash(a, b);
+  const uint32_t bits = enc_bloom_bits(h);
+  if ((bloom[enc_bloom_word(h)] & bits) != bits) return ENC_INF;
+  const unsigned long long key = pair_key(a, b);
+  uint32_t sl = h & m.rule_mask;
+  for (;;) {
+    const RuleSlot r = enc_load_slot(m, sl);
+    if (r.key == key) return r.pad;
+    if (r.key == PT_EMPTY) return ENC_INF;
+    sl = (sl + 1) & m.rule_mask;
+  }
+}
 
-// One wavefront encodes one sentence.  wt = tokens (bit31 = first token of a word), wr = rule slot of the pair that
-// starts at p (or ENC_INF), wm = per-word minimum rule priority stored at the word's first position.
 // ---- BPE-dropout (bpe.cpp:1417-1453 DropoutQueue + :1560-1589) --------------------------------------------------------
 // Exact per-word process of the reference: events (rule index, position) in priority order; every pop walks the queue,
 // each event is skipped with probability p, the first one not skipped is taken (stale events included: they consume the
@@ -145,14 +171,13 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
   return base;
 }
 
+// UTF-8 decode + char -> token, word starts, unknown-run collapse (bpe.cpp:1497-1530).  Appends the sentence's tokens to
+// wt[n0...) and returns the new end.  A sentence of B bytes yields at most B+1 tokens.
 template <class A>
-__device__ void encode_wave(const EncModel &m, const uint8_t *__restrict__ s, unsigned long long nbytes, A wt, A wr, A wm, int bos, int eos,
-                            int reverse, int32_t *__restrict__ out, uint32_t *__restrict__ count_out, const DropoutArgs &drop,
-                            unsigned long long sidx) {
+__device__ int enc_tokenize(const EncModel &m, const uint8_t *__restrict__ s, unsigned long long nbytes, A wt, int n0) {
   const int lane = lane_id();
   const unsigned long long lt = lanemask_lt();
-  // ---- A. UTF-8 decode + char -> token, word starts, unknown-run collapse ---------------------------------------------
-  int n = 0;
+  int n = n0;
   bool carry_space = true, carry_unk = false;  // class of the last valid char before this step (start of text acts like a space)
   for (unsigned long long b0 = 0; b0 < nbytes; b0 += 64) {
     const unsigned long long i = b0 + (unsigned long long)lane;
@@ -177,9 +202,8 @@ __device__ void encode_wave(const EncModel &m, const uint8_t *__restrict__ s, un
       prev_unk = (U >> j) & 1ull;
     }
     int emit = 0;
-    bool wstart = false;
     if (valid && !space) {
-      wstart = prev_space;
+      const bool wstart = prev_space;
       if (unk && prev_unk && !wstart) emit = 0;  // continues an unknown run
       else emit = wstart ? 2 : 1;
     }
@@ -199,90 +223,140 @@ __device__ void encode_wave(const EncModel &m, const uint8_t *__restrict__ s, un
       carry_unk = (U >> j) & 1ull;
     }
   }
+  return n;
+}
+
+// id of the token that rule r creates.  Trained models number merged tokens consecutively in rule order, skipping the
+// (<= 4) special ids (bpe.cpp:814-837), so z is r + z_base + #{breakpoints <= r}; a hand-made model without that
+// structure reads the table instead.
+__device__ inline uint32_t enc_rule_z(const EncModel &m, uint32_t r) {
+  if (!m.z_affine) return m.rule_z[r];
+  return m.z_base + r + (r >= m.z_bp[0]) + (r >= m.z_bp[1]) + (r >= m.z_bp[2]) + (r >= m.z_bp[3]);
+}
+
+// Cooperative path: one wavefront encodes one sentence, lanes = token positions.  wt = tokens (bit31 = first token of a
+// word), wr = priority of the pair that starts at p, wm = per-word minimum priority stored at the word's first position.
+// Sentences too long for the LDS arrays run the same code on HBM scratch (GlbArr).
+template <class A>
+__device__ void encode_wave(const EncModel &m, const uint32_t *bloom, const uint8_t *__restrict__ s, unsigned long long nbytes, A wt, A wr,
+                            A wm, int bos, int eos, int reverse, int32_t *__restrict__ out, uint32_t *__restrict__ count_out,
+                            const DropoutArgs &drop, unsigned long long sidx) {
+  const int lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+  int n = enc_tokenize<A>(m, s, nbytes, wt, 0);
   wave_sync();
   // ---- B. merge rounds -----------------------------------------------------------------------------------------------
   if (drop.enabled) n = dropout_merge<A>(m, wt, wr, wm, n, drop, sidx);
-  else for (;;) {
-    const int nchunks = (n + 63) >> 6;
-    // phase 1: rule of every adjacency, word-segmented minimum
-    int carry_ws = 0;
-    for (int c = 0; c < nchunks; c++) {
+  else {
+    // wr[p] = priority (rule index) of the pair (p,p+1), ENC_INF if it has no rule, ENC_DIRTY if unknown.  Only pairs next
+    // to a merge change, so after the first round a handful of pairs per word are looked up again; a pair is first
+    // tested against the LDS-resident Bloom filter of all rules, and only a positive goes to the rule hash in L2/HBM.
+    for (int c = 0; c < ((n + 63) >> 6); c++) {
       const int p = c * 64 + lane;
-      if (p < n && (wt.get(p) & TOK_WS)) wm.set(p, ENC_INF);
+      if (p < n) {
+        wr.set(p, ENC_DIRTY);
+        if (wt.get(p) & TOK_WS) wm.set(p, ENC_INF);
+      }
     }
     wave_sync();
-    for (int c = 0; c < nchunks; c++) {
-      const int p = c * 64 + lane;
-      uint32_t t0 = 0, r = ENC_INF;
-      bool ws = false;
-      if (p < n) {
-        t0 = wt.get(p);
-        ws = t0 & TOK_WS;
-        if (p + 1 < n) {
-          const uint32_t t1 = wt.get(p + 1);
-          if (!(t1 & TOK_WS)) {
-            const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
-            const uint32_t slot = enc_rule_lookup(m, a, b);
-            if (slot != ENC_INF) {
-              r = m.rules[slot].pad;  // rule index = priority (smaller first)
-              if (a == b) {
-                // x==x: greedy left to right = even offsets from the start of the run of x's
-                int q = p;
-                while (q > 0 && !(wt.get(q) & TOK_WS) && (wt.get(q - 1) & TOK_MASK) == a) q--;
-                if ((p - q) & 1) r = ENC_INF;
-              }
+    for (;;) {
+      const int nchunks = (n + 63) >> 6;
+      // phase 1+2: (re)compute dirty pairs and fold every priority into its word's minimum (kept at the word's first
+      // position; reset to ENC_INF when that position was written)
+      int carry_ws = 0;
+      for (int c = 0; c < nchunks; c++) {
+        const int p = c * 64 + lane;
+        const uint32_t t0 = p < n ? wt.get(p) : 0u;
+        const bool ws = p < n && (t0 & TOK_WS);
+        const unsigned long long W = __ballot(ws);
+        int wsp = carry_ws;
+        const unsigned long long wle = W & ((2ull << lane) - 1ull);
+        if (wle) wsp = c * 64 + 63 - __clzll((long long)wle);
+        if (W) carry_ws = c * 64 + 63 - __clzll((long long)W);
+        if (p < n) {
+          uint32_t r = wr.get(p);
+          if (r == ENC_DIRTY) {
+            r = ENC_INF;
+            if (p + 1 < n) {
+              const uint32_t t1 = wt.get(p + 1);
+              const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
+              if (!(t1 & TOK_WS) && a != ENC_UNKP && b != ENC_UNKP) r = enc_pair_prio(m, bloom, a, b);
             }
+            wr.set(p, r);
           }
+          if (r != ENC_INF) wm.amin(wsp, r);
         }
       }
-      const unsigned long long W = __ballot(ws);
-      int wsp = carry_ws;
-      const unsigned long long wle = W & ((2ull << lane) - 1ull);
-      if (wle) wsp = c * 64 + 63 - __clzll((long long)wle);
-      if (p < n) {
-        wr.set(p, r);
-        if (r != ENC_INF) wm.amin(wsp, r);
-      }
-      if (W) carry_ws = c * 64 + 63 - __clzll((long long)W);
-    }
-    wave_sync();
-    // phase 2: apply the per-word minimum rule, compact in place (ascending chunks; writes never pass unread data)
-    int base = 0;
-    bool prev_site = false;  // site flag of the last position of the previous chunk
-    bool any = false;
-    carry_ws = 0;
-    for (int c = 0; c < nchunks; c++) {
-      const int p = c * 64 + lane;
-      uint32_t t0 = 0;
-      bool ws = false, site = false;
-      uint32_t nt = 0;
-      if (p < n) {
-        t0 = wt.get(p);
-        ws = t0 & TOK_WS;
-      }
-      const unsigned long long W = __ballot(ws);
-      int wsp = carry_ws;
-      const unsigned long long wle = W & ((2ull << lane) - 1ull);
-      if (wle) wsp = c * 64 + 63 - __clzll((long long)wle);
-      if (W) carry_ws = c * 64 + 63 - __clzll((long long)W);
-      if (p < n) {
-        const uint32_t r = wr.get(p);
-        site = r != ENC_INF && r == wm.get(wsp);
-        nt = site ? (m.rule_z[r] | (t0 & TOK_WS)) : t0;
-      }
-      const unsigned long long SM = __ballot(site);
-      const bool dead = lane == 0 ? prev_site : ((SM >> (lane - 1)) & 1ull);
-      const bool alive = p < n && !dead;
-      const unsigned long long AM = __ballot(alive);
-      wave_sync();  // all lanes have read their inputs before anyone overwrites lower positions
-      if (alive) wt.set(base + __popcll(AM & lt), nt);
-      base += __popcll(AM);
-      prev_site = (SM >> 63) & 1ull;
-      any = any || SM != 0;
       wave_sync();
+      // phase 3: merge sites = pairs carrying their word's minimum; x==x pairs only at even offsets from the run start
+      // (= the left-to-right greedy of the reference).  Marked in place (ENC_SITE) before anything moves.
+      bool any = false;
+      carry_ws = 0;
+      for (int c = 0; c < nchunks; c++) {
+        const int p = c * 64 + lane;
+        const uint32_t t0 = p < n ? wt.get(p) : 0;
+        const bool ws = p < n && (t0 & TOK_WS);
+        const unsigned long long W = __ballot(ws);
+        int wsp = carry_ws;
+        const unsigned long long wle = W & ((2ull << lane) - 1ull);
+        if (wle) wsp = c * 64 + 63 - __clzll((long long)wle);
+        if (W) carry_ws = c * 64 + 63 - __clzll((long long)W);
+        bool site = false;
+        if (p < n) {
+          const uint32_t r = wr.get(p);
+          if (r != ENC_INF && r == wm.get(wsp)) {
+            site = true;
+            const uint32_t a = t0 & TOK_MASK;
+            if ((wt.get(p + 1) & TOK_MASK) == a) {
+              int q = p;
+              while (q > 0 && !(wt.get(q) & TOK_WS) && (wt.get(q - 1) & TOK_MASK) == a) q--;
+              site = ((p - q) & 1) == 0;
+            }
+            if (site) wr.set(p, r | ENC_SITE);
+          }
+        }
+        any = any || __ballot(site) != 0;
+      }
+      wave_sync();
+      if (!any) break;
+      // phase 4: apply + compact in place (ascending chunks; writes never pass unread data).  A surviving pair keeps its
+      // priority unless one of its two tokens changed.
+      int base = 0;
+      bool prev_site = false;  // site flag of the last position of the previous chunk
+      for (int c = 0; c < nchunks; c++) {
+        const int p = c * 64 + lane;
+        uint32_t t0 = 0, r = ENC_INF, r_next = ENC_INF;
+        if (p < n) {
+          t0 = wt.get(p);
+          r = wr.get(p);
+          if (p + 1 < n) r_next = wr.get(p + 1);
+        }
+        const bool site = p < n && r != ENC_INF && r != ENC_DIRTY && (r & ENC_SITE);
+        const bool next_site = r_next != ENC_INF && r_next != ENC_DIRTY && (r_next & ENC_SITE);
+        const unsigned long long SM = __ballot(site);
+        const bool dead = lane == 0 ? prev_site : ((SM >> (lane - 1)) & 1ull);
+        const bool alive = p < n && !dead;
+        const unsigned long long AM = __ballot(alive);
+        uint32_t nt = t0, nr = r;
+        if (site) {
+          nt = enc_rule_z(m, r & ~ENC_SITE) | (t0 & TOK_WS);
+          nr = ENC_DIRTY;
+        } else if (next_site) {
+          nr = ENC_DIRTY;
+        }
+        wave_sync();  // all lanes have read their inputs before anyone overwrites lower positions
+        if (alive) {
+          const int np = base + __popcll(AM & lt);
+          wt.set(np, nt);
+          wr.set(np, nr);
+          if (nt & TOK_WS) wm.set(np, ENC_INF);
+        }
+        base += __popcll(AM);
+        prev_site = (SM >> 63) & 1ull;
+        wave_sync();
+      }
+      n = base;
     }
-    n = base;
-    if (!any) break;
   }
   // ---- C. output (bpe.cpp:1591-1630): unknown runs -> unk_id; the id-0 quirk drops an unmerged leading "▁" whose id is 0
   const int nb = bos ? 1 : 0;
@@ -314,15 +388,18 @@ __device__ void encode_wave(const EncModel &m, const uint8_t *__restrict__ s, un
   if (lane == 0) *count_out = (uint32_t)n_ids;
 }
 
-__global__ __launch_bounds__(BLOCK) void k5_encode(EncModel m, const uint8_t *__restrict__ text,
+__global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8_t *__restrict__ text,
                                                    const unsigned long long *__restrict__ offsets, unsigned long long n_sent, int bos,
                                                    int eos, int reverse, int32_t *__restrict__ scratch_ids,
                                                    uint32_t *__restrict__ counts, uint32_t *__restrict__ work,
                                                    unsigned long long work_stride, DropoutArgs drop, unsigned long long drop_stride) {
-  __shared__ uint32_t lds[NWAVES][3][ENC_WCAP];
+  __shared__ uint32_t lds[ENC_WAVES][3][ENC_WCAP];
+  __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
+  for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += ENC_THREADS) bloom[i] = m.bloom[i];
+  __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
-  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + wave;
-  const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
+  const unsigned long long gw = (unsigned long long)blockIdx.x * ENC_WAVES + wave;
+  const unsigned long long n_waves = (unsigned long long)gridDim.x * ENC_WAVES;
   for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
     const unsigned long long b0 = offsets[sidx], b1 = offsets[sidx + 1];
     const unsigned long long nbytes = b1 - b0;
@@ -334,11 +411,11 @@ __global__ __launch_bounds__(BLOCK) void k5_encode(EncModel m, const uint8_t *__
     }
     if (2 * nbytes + 2 <= (unsigned long long)ENC_WCAP) {
       LdsArr a{lds[wave][0]}, b{lds[wave][1]}, c{lds[wave][2]};
-      encode_wave(m, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx], d, sidx);
+      encode_wave(m, bloom, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx], d, sidx);
     } else {
       uint32_t *w = work + gw * 3 * work_stride;
       GlbArr a{w}, b{w + work_stride}, c{w + 2 * work_stride};
-      encode_wave(m, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx], d, sidx);
+      encode_wave(m, bloom, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx], d, sidx);
     }
     wave_sync();
   }
@@ -369,7 +446,7 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   d.seed = seed;
   d.wsl = drop_scratch;
   d.ev = nullptr;
-  hipLaunchKernelGGL(k5_encode, dim3(n_blocks), dim3(BLOCK), 0, st, m, text, offsets, n_sent, bos, eos, reverse, scratch_ids, counts, work,
+  hipLaunchKernelGGL(k5_encode, dim3(n_blocks), dim3(ENC_THREADS), 0, st, m, text, offsets, n_sent, bos, eos, reverse, scratch_ids, counts, work,
                      work_stride, d, drop_stride);
 }
 void launch_encode_gather(const int32_t *scratch_ids, const unsigned long long *offsets, const unsigned long long *out_off,

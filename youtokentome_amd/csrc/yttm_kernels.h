@@ -61,12 +61,35 @@ void launch_set_tokflag(uint8_t *tokflag, uint32_t *flagbits, const uint32_t *up
 void launch_fill_u64(unsigned long long *p, unsigned long long v, unsigned long long n, hipStream_t st);
 
 // ---- batch encode (k_encode.hip)
+constexpr int ENC_BLOOM_WORDS = 8192;    // 32 KB of LDS: 8 bits per rule at 32k rules
+constexpr int ENC_WAVES_PER_BLOCK = 8;   // 512 threads; 48 KB of working arrays + the filter = 80 KB, two workgroups per CU
+constexpr int ENC_LDS_TOKENS = 512;      // cooperative kernel: longer sentences (2*bytes+2 tokens) work in HBM scratch
+// One 32-bit hash of a token pair serves the rule hash (low bits = slot) and the Bloom filter (top 13 bits = word,
+// 3 x 5 bits of a second multiply = bit positions).  64-bit multiplies cost ~8 VALU instructions each on CDNA; this is 9 in all.
+__host__ __device__ inline uint32_t enc_hash(uint32_t a, uint32_t b) {
+  uint32_t h = a * 0x9E3779B1u;
+  h ^= b + 0x7F4A7C15u + (h << 6) + (h >> 2);
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+// Blocked Bloom filter of all rule keys (one 32-bit word, 3 bits per key), resident in LDS: most adjacent pairs have no
+// rule, and this answers "certainly none" without leaving the CU.  The host fills it with the same functions.
+__host__ __device__ inline uint32_t enc_bloom_bits(uint32_t h) {
+  const uint32_t g = h * 0x27D4EB2Fu;
+  return (1u << (g >> 27)) | (1u << ((g >> 22) & 31)) | (1u << ((g >> 17) & 31));
+}
+__host__ __device__ inline uint32_t enc_bloom_word(uint32_t h) { return h >> 19; }  // 13 bits = ENC_BLOOM_WORDS
 struct EncModel {
   const uint32_t *cpmap;      // [N_CODEPOINTS]: final token id, CP_SPACE, CP_UNK
   const RuleSlot *rules;      // hash (x<<32|y) -> RuleSlot{z, pad = rule index = priority}
   const uint32_t *rule_z;     // [n_rules] z of rule i
   const unsigned long long *rule_xy;  // [n_rules] x<<32|y of rule i
+  const uint32_t *bloom;      // [ENC_BLOOM_WORDS] blocked Bloom filter of the rule keys (staged into LDS)
   unsigned int rule_mask;
+  uint32_t z_affine, z_base, z_bp[4];  // rule_z[r] == z_base + r + #{k : z_bp[k] <= r} when z_affine 
   uint32_t space_id;
   int unk_id, bos_id, eos_id;
 };
