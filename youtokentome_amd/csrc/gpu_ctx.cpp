@@ -35,8 +35,8 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   HIP_CHECK(hipSetDevice(device_));
   HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
   d_counters_ = dmalloc<unsigned long long>(64);
-  d_stats_ = dmalloc<unsigned long long>(8);
-  HIP_CHECK(hipMemset(d_stats_, 0, 8 * sizeof(unsigned long long)));
+  d_stats_ = dmalloc<unsigned long long>(24);  // [0..3] K4 counters, [8..23] per-phase cycles of a YTTM_K4_PROF build
+  HIP_CHECK(hipMemset(d_stats_, 0, 24 * sizeof(unsigned long long)));
   // one block for everything the host reads back per round, so that it is ONE device-to-host copy:
   // [0] n_cand, [4] n_keys | [64..) count histogram | [8192..) candidates
   d_round_ = dmalloc<unsigned char>(8192 + (size_t)CAND_CAP * sizeof(CandRec));
@@ -230,8 +230,8 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   if (U == 0) { DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len); return; }
   unsigned long long *posA = dmalloc<unsigned long long>(UA), *posB = dmalloc<unsigned long long>(UB);
   uint32_t *lenA = dmalloc<uint32_t>(UA), *lenB = dmalloc<uint32_t>(UB);
-  cls_[0].d_wcnt = dmalloc<uint32_t>(UA);
-  cls_[1].d_wcnt = dmalloc<uint32_t>(UB);
+  cls_[0].d_wcnt = dmalloc<uint32_t>(UA + 64);  // +64: k_tiles loads 64 frequencies from a tile's first word unconditionally
+  cls_[1].d_wcnt = dmalloc<uint32_t>(UB + 64);
   unsigned int *d_cursor = (unsigned int *)(d_counters_ + 32);
   HIP_CHECK(hipMemsetAsync(d_cursor, 0, 8, st_));
   t_begin(KT_BUILD);
@@ -275,7 +275,7 @@ void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, u
   c.d_tile_word0 = dmalloc<uint32_t>(c.n_tiles);
   c.d_tile_len = dmalloc<uint32_t>(c.n_tiles);
   c.d_worklist = dmalloc<uint32_t>(c.n_tiles + 64);
-  c.d_work_n = dmalloc<unsigned int>(4);
+  c.d_work_n = dmalloc<unsigned int>(4);  // [0] worklist length, [1] dynamic hand-out counter
   c.d_tok = dmalloc<uint32_t>((size_t)c.n_tiles * c.slot + 64);
   // slots are read 16 B wide past the live prefix and the staged ids index the flag table: never leave them undefined
   HIP_CHECK(hipMemsetAsync(c.d_tok, 0, ((size_t)c.n_tiles * c.slot + 64) * 4, st_));
@@ -557,18 +557,24 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   t_begin(KT_MERGE);
   for (int ci = 0; ci < 2; ci++) {
     if (!cls_[ci].n_tiles) continue;
-    HIP_CHECK(hipMemsetAsync(cls_[ci].d_work_n, 0, 4, st_));
+    HIP_CHECK(hipMemsetAsync(cls_[ci].d_work_n, 0, 8, st_));  // [0] worklist length (k_filter), [1] hand-out counter (k_tiles)
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
                        cls_[ci].d_work_n, d_stats_, st_);
   }
   t_end(KT_MERGE, 0);
   merge_rounds++;
   if (getenv("YTTM_TRACE_ROUNDS")) {  // tuning aid: cumulative device stats after every round (adds a sync)
-    unsigned long long stt[8];
+    unsigned long long stt[24];
     HIP_CHECK(hipMemcpyAsync(stt, d_stats_, sizeof stt, hipMemcpyDeviceToHost, st_));
     sync();
     FILE *f = fopen(getenv("YTTM_TRACE_ROUNDS"), merge_rounds == 1 ? "w" : "a");
-    if (f) { fprintf(f, "%llu %u %llu %llu %llu %llu %u\n", merge_rounds, k, stt[0], stt[1], stt[2], stt[3], cls_[0].n_tiles); fclose(f); }
+    if (f) {
+      fprintf(f, "%llu %u %llu %llu %llu %llu %u", merge_rounds, k, stt[0], stt[1], stt[2], stt[3], cls_[0].n_tiles);
+      for (int i = 8; i < 24; i++) fprintf(f, " %llu", stt[i]);
+      fprintf(f, "\n");
+      fclose(f);
+    }
+    HIP_CHECK(hipMemsetAsync(d_stats_ + 8 + 11, 0, 3 * 8, st_));  // per-round slots of the YTTM_K4_PROF build
   }
   pending_zero_ = true;
   zero_cap_ = cap;

@@ -21,6 +21,7 @@
 namespace yttm {
 
 constexpr int AGG_SLOTS = 256;   // LDS delta aggregator shared by the waves of a workgroup (hot pairs)
+constexpr uint32_t DYN_TILES_PER_WAVE = 0;  // worklists shorter than this per wavefront are handed out dynamically
 constexpr int CAND_CAP_W = 192;  // per-wave list of merge-site candidates awaiting their rule lookup
 constexpr uint32_t FLAG_LDS_IDS = 32768;  // batch flags of ids below this live in an LDS bitmap (2 bits per id, 8 KB)
 
@@ -47,6 +48,9 @@ struct AggLds {
   uint32_t flagbits[FLAG_LDS_IDS / 16];  // 2 bits per token id: bit0 = x of a batch rule, bit1 = y of a batch rule
   unsigned int new_keys;                 // slots claimed by this workgroup (added to pt.n_keys once, at the end)
   unsigned long long st[4];              // workgroup-local stats (one global atomic each at the end)
+#ifdef YTTM_K4_PROF
+  unsigned long long miss_n, miss_cyc;
+#endif
 };
 
 __device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta, unsigned int *new_keys) {
@@ -79,7 +83,14 @@ __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, co
     }
     h = (h + 1) & (AGG_SLOTS - 1);
   }
+#ifdef YTTM_K4_PROF
+  const unsigned long long t0_ = (unsigned long long)clock64();
+#endif
   global_emit(pt, db, key, delta, &A.new_keys);
+#ifdef YTTM_K4_PROF
+  atomicAdd(&A.miss_n, 1ull);
+  atomicAdd(&A.miss_cyc, (unsigned long long)clock64() - t0_);
+#endif
 }
 
 template <int NT>
@@ -90,7 +101,13 @@ __device__ inline void agg_init(AggLds &A, const uint32_t *__restrict__ flagbits
   }
   if (flagbits_g)
     for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += NT) A.flagbits[s] = flagbits_g[s];
-  if (threadIdx.x == 0) { A.new_keys = 0; A.st[0] = A.st[1] = A.st[2] = A.st[3] = 0; }
+  if (threadIdx.x == 0) {
+    A.new_keys = 0;
+    A.st[0] = A.st[1] = A.st[2] = A.st[3] = 0;
+#ifdef YTTM_K4_PROF
+    A.miss_n = A.miss_cyc = 0;
+#endif
+  }
 }
 template <int NT>
 __device__ inline void agg_flush(AggLds &A, const PairTable &pt, const DeltaBuf &db) {
@@ -129,8 +146,29 @@ __device__ inline uint32_t flagged_big(uint32_t tok, const uint8_t *__restrict__
 // Batch flags for the 16 tokens a lane holds and the merge-site candidate test, entirely in registers: a tile without
 // any (x-flagged, y-flagged) adjacency -- the common case late in training -- is never staged into LDS at all.
 // Lane l holds tokens 256 j + 4 l + {0,1,2,3} in r[j]; the right neighbour of a lane's last token comes by shuffle.
+// Exact membership test of a pair in the batch (k_filter): the x/y flags are per token, so with k rules in the batch up
+// to k*k flagged adjacencies exist of which k are rules; late in training two thirds of the flag-dirty tiles hold no
+// merge site at all.  Keys of the batch's rule hash sit in LDS when they fit (FILTER_LDS_KEYS slots), else in L2.
+constexpr unsigned int FILTER_LDS_KEYS = 1024;
+struct RuleProbe {
+  const unsigned long long *lds_keys;  // [mask+1] or nullptr
+  const RuleSlot *g;                   // the same hash in HBM; nullptr = no exact test
+  unsigned int mask;
+  __device__ bool has(uint32_t a, uint32_t b) const {
+    const unsigned long long key = pair_key(a, b);
+    unsigned int h = (unsigned int)mix64(key) & mask;
+    for (;;) {
+      const unsigned long long k = lds_keys ? __hip_atomic_load(&lds_keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : g[h].key;
+      if (k == key) return true;
+      if (k == PT_EMPTY) return false;
+      h = (h + 1) & mask;
+    }
+  }
+};
+
 template <int SLOT>
-__device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds, const uint8_t *__restrict__ tokflag, uint32_t self_x) {
+__device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds, const uint8_t *__restrict__ tokflag, uint32_t self_x,
+                                      const RuleProbe probe = RuleProbe{nullptr, nullptr, 0}) {
   const int lane = lane_id();
   bool big = false;
 #pragma unroll
@@ -169,7 +207,31 @@ __device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint3
     }
   }
 #undef PAIR_TEST
-  return __ballot(cand) != 0;
+  if (__ballot(cand) == 0) return false;
+  if (!probe.g) return true;
+  // some adjacency is flagged: is any of them a rule of the batch (or the x x of the self rule)?
+  bool hit = false;
+#define PAIR_EXACT(T0, T1, P)                                                                                     \
+  if (!hit && (P) + 1 < n && !((T1)&TOK_WS)) {                                                                     \
+    if ((((T0)&L_ID) == self_x) && (((T1)&L_ID) == self_x)) hit = true;                                            \
+    else if (((T0)&L_ISX) && ((T1)&L_ISY)) hit = probe.has((T0)&L_ID, (T1)&L_ID);                                  \
+  }
+#pragma unroll
+  for (int j = 0; j < SLOT / 256; j++) {
+    if (256 * j < n) {
+      uint32_t nx = __shfl_down(r[j].x, 1);
+      uint32_t nx0 = TOK_WS;
+      if (j + 1 < SLOT / 256) nx0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
+      if (lane == 63) nx = nx0;
+      const int p = 256 * j + 4 * lane;
+      PAIR_EXACT(r[j].x, r[j].y, p)
+      PAIR_EXACT(r[j].y, r[j].z, p + 1)
+      PAIR_EXACT(r[j].z, r[j].w, p + 2)
+      PAIR_EXACT(r[j].w, nx, p + 3)
+    }
+  }
+#undef PAIR_EXACT
+  return __ballot(hit) != 0;
 }
 
 // registers -> LDS, sentinels (wave-local)
@@ -190,12 +252,22 @@ __device__ inline void tile_stage(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256]
 }
 
 // frequency of the word that contains tile position p
+// Index (within the tile) of the word that contains tile position p.
 template <int SLOT>
-__device__ inline long long tile_weight(const WaveLds<SLOT> &W, const uint32_t *__restrict__ wcnt, uint32_t word0, int p) {
+__device__ inline uint32_t tile_word_index(const WaveLds<SLOT> &W, int p) {
   const int c = p >> 6;
   const unsigned long long le = (2ull << (p & 63)) - 1ull;  // bits 0..(p&63)
-  const uint32_t k = W.wsbase[c] + (uint32_t)__popcll(W.wsmask[c] & le);
-  return (long long)wcnt[word0 + k - 1];
+  return W.wsbase[c] + (uint32_t)__popcll(W.wsmask[c] & le) - 1u;
+}
+// Frequency of word k of the tile.  The weights of the tile's first 64 words were loaded with the tile (lane j holds
+// word j in wreg) and are read by a cross-lane shuffle -- the gather from HBM that this replaces sat, TLB miss and all,
+// on the critical path of every tile.  MUST be called by all lanes of the wave (ds_bpermute reads only active lanes).
+template <int SLOT>
+__device__ inline long long tile_weight_all(const WaveLds<SLOT> &W, const uint32_t *__restrict__ wcnt, uint32_t word0, uint32_t wreg, int p, bool valid) {
+  const uint32_t k = valid ? tile_word_index<SLOT>(W, p) : 0u;
+  uint32_t f = __shfl(wreg, (int)(k & 63u));
+  if (valid && k >= 64u) f = wcnt[word0 + k];
+  return (long long)f;
 }
 
 // ------------------------------------------------------------------------------------------------- K3 / K4
@@ -203,7 +275,17 @@ __device__ inline long long tile_weight(const WaveLds<SLOT> &W, const uint32_t *
 // adjacency counts the word frequency; a run of L equal tokens counts floor(L/2) for its self pair).
 // MERGE=true: K4, apply the batch rules (z ids are consecutive: rule j of the batch creates z_base + j) and emit the
 // exact count deltas around the merge sites.
+#ifdef YTTM_K4_PROF
+#define K4_MARK(k) do { const unsigned long long t_ = (unsigned long long)clock64(); S.pt[k] += t_ - S.t_last; S.t_last = t_; } while (0)
+#define K4_COUNT(k) (S.pt[k]++)
+#else
+#define K4_MARK(k) ((void)0)
+#define K4_COUNT(k) ((void)0)
+#endif
 struct TileStats {
+#ifdef YTTM_K4_PROF
+  unsigned long long pt[16] = {0}, t_last = 0;
+#endif
   unsigned long long sites = 0, touched = 0, scanned = 0, touched_tok = 0;
 };
 
@@ -211,7 +293,7 @@ struct TileStats {
 template <int SLOT, bool MERGE>
 __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &ts, const PairTable &pt, const DeltaBuf &db,
                                     const RuleSlot *__restrict__ rules, unsigned int rule_mask, uint32_t self_x, uint32_t self_z,
-                                    uint32_t z_base, uint32_t t, int n, uint32_t word0, TileStats &S) {
+                                    uint32_t z_base, uint32_t t, int n, uint32_t word0, uint32_t wreg, TileStats &S) {
   const int lane = lane_id();
   unsigned long long &my_sites = S.sites, &st_touched = S.touched, &st_scanned = S.scanned, &st_touched_tok = S.touched_tok;
     const int nchunks = (n + 63) >> 6;
@@ -268,23 +350,25 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
       any = any || sm != 0;
     }
     wave_sync();
+    if (MERGE) K4_MARK(3);
 
     if (!MERGE) {
       for (int c = 0; c < nchunks; c++) {
         const int p = c * 64 + lane;
+        const long long f = tile_weight_all<SLOT>(W, ts.wcnt, word0, wreg, p, p < n);
         if (p >= n) continue;
         const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
         if (t1 & TOK_WS) continue;
         const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
         if (a != b) {
-          emit<SLOT>(A, W, pt, db, pair_key(a, b), tile_weight<SLOT>(W, ts.wcnt, word0, p));
+          emit<SLOT>(A, W, pt, db, pair_key(a, b), f);
         } else {
           const bool run_start = (t0 & TOK_WS) || p == 0 || (W.tk[p - 1] & TOK_MASK) != a;
           if (run_start) {
             int q = p + 1;
             while (!(W.tk[q + 1] & TOK_WS) && (W.tk[q + 1] & TOK_MASK) == a) q++;
             const long long len = q - p + 1;
-            emit<SLOT>(A, W, pt, db, pair_key(a, a), (len / 2) * tile_weight<SLOT>(W, ts.wcnt, word0, p));
+            emit<SLOT>(A, W, pt, db, pair_key(a, a), (len / 2) * f);
           }
         }
       }
@@ -312,81 +396,128 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         for (int c = lane; c < nchunks; c += 64) any = any || W.sitemask[c] != 0;
         any = __ballot(any) != 0;
       }
+      K4_MARK(4);
       if (any) {
+        K4_COUNT(9);
 #define SITE(q) ((q) >= 0 && (((W.sitemask[(q) >> 6] >> ((q)&63)) & 1ull) != 0))
 #define NEWTOK(q) (z_base + (uint32_t)W.ridx[(q)])
         // ---- phase 2: count deltas around the sites + survivor masks ---------------------------------------------------
         uint32_t abase = 0;
+        // a chunk is active if a site starts in it or right next to it; the others (most of a tile late in training) keep
+        // all their tokens and emit nothing
+        auto chunk_active = [&](int c) {
+          return W.sitemask[c] != 0ull || (c > 0 && (W.sitemask[c - 1] >> 63)) || (c + 1 < nchunks && (W.sitemask[c + 1] & 1ull));
+        };
+        int first_site_chunk = nchunks;
         for (int c = 0; c < nchunks; c++) {
           const int p = c * 64 + lane;
+          const bool act = chunk_active(c);
+          if (!act) {
+            const unsigned long long am = __ballot(p < n);
+            if (lane == 0) {
+              W.amask[c] = am;
+              W.abase[c] = abase;
+            }
+            abase += (uint32_t)__popcll(am);
+            continue;
+          }
+          if (first_site_chunk == nchunks && W.sitemask[c] != 0ull) first_site_chunk = c;
+#ifdef YTTM_K4_PROF
+          S.pt[14]++;
+          const unsigned long long tc0_ = (unsigned long long)clock64();
+#endif
+          const long long f = tile_weight_all<SLOT>(W, ts.wcnt, word0, wreg, p, p < n);
+#ifdef YTTM_K4_PROF
+          {
+            const bool near_ = p < n && (SITE(p) || SITE(p - 1) || SITE(p + 1));
+            if (__ballot(near_ && f == 0x7fffffffffffffffll)) S.pt[13]++;  // forces f to be materialised here
+            S.pt[10] += (unsigned long long)clock64() - tc0_;
+          }
+#endif
+          // Site bits of this chunk and its neighbours live in registers (every SITE() below used to be a dependent LDS
+          // read), and the up to four count deltas of a lane are collected first and emitted by all lanes together: four
+          // convergent trips through the LDS aggregator instead of nine divergent ones.
+          const unsigned long long sm0 = c > 0 ? W.sitemask[c - 1] : 0ull, sm1 = W.sitemask[c],
+                                   sm2 = c + 1 < nchunks ? W.sitemask[c + 1] : 0ull;
+          const bool sp = (sm1 >> lane) & 1ull;
+          const bool dp = lane >= 1 ? ((sm1 >> ((lane - 1) & 63)) & 1ull) : (sm0 >> 63);
+          const bool s_p1 = lane <= 62 ? ((sm1 >> ((lane + 1) & 63)) & 1ull) : (sm2 & 1ull);
+          const bool s_m2 = lane >= 2 ? ((sm1 >> ((lane - 2) & 63)) & 1ull) : ((sm0 >> ((62 + lane) & 63)) & 1ull);
+          const bool s_p2 = lane <= 61 ? ((sm1 >> ((lane + 2) & 63)) & 1ull) : ((sm2 >> ((lane - 62) & 63)) & 1ull);
           bool alive = false;
+          bool v0 = false, v1 = false, v2 = false, v3 = false;
+          unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+          long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
           if (p < n) {
             const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
             const uint32_t a = t0 & L_ID;
-            const bool sp = SITE(p);
-            const bool dp = SITE(p - 1);
             const bool adj1 = !(t1 & TOK_WS);
             alive = !dp;
-            if (sp || dp || (adj1 && SITE(p + 1))) {
-              const long long f = tile_weight<SLOT>(W, ts.wcnt, word0, p);
-              if (sp) {
-                my_sites++;
-                const uint32_t b = t1 & L_ID;
-                const uint32_t z = NEWTOK(p);
-                emit<SLOT>(A, W, pt, db, pair_key(a, b), -f);  // the merged pair itself
-                // run of new z tokens (x y x y ... or the halves of an x-run): counted floor(Lz/2) by its first site
-                const bool prev_same = p >= 2 && !(t0 & TOK_WS) && SITE(p - 2) && NEWTOK(p - 2) == z;
-                if (!prev_same) {
-                  int q = p, lz = 1;
-                  while (!(W.tk[q + 2] & TOK_WS) && q + 2 < n && SITE(q + 2) && NEWTOK(q + 2) == z) { q += 2; lz++; }
-                  if (lz >= 2) emit<SLOT>(A, W, pt, db, pair_key(z, z), (long long)(lz / 2) * f);
-                }
-                // new adjacency (z, right neighbour)
-                const int q = p + 2;
-                if (q < n && !(W.tk[q] & TOK_WS)) {
-                  const uint32_t B = SITE(q) ? NEWTOK(q) : (W.tk[q] & L_ID);
-                  if (B != z) emit<SLOT>(A, W, pt, db, pair_key(z, B), f);
-                }
-                // x != y rule whose x is the last token of a run of a's: the run shrinks by one
-                if (a != self_x && p > 0 && !(t0 & TOK_WS) && (W.tk[p - 1] & L_ID) == a) {
-                  int rr = p;
-                  while (rr > 0 && !(W.tk[rr] & TOK_WS) && (W.tk[rr - 1] & L_ID) == a) rr--;
-                  const int len = p - rr + 1;
-                  if ((len & 1) == 0) emit<SLOT>(A, W, pt, db, pair_key(a, a), -f);
-                }
-              } else if (!dp) {
-                // unmerged token whose right neighbour starts a site: (a,x) -> (a,z)
-                const uint32_t x_ = t1 & L_ID;
-                const uint32_t z = NEWTOK(p + 1);
-                if (a != x_) emit<SLOT>(A, W, pt, db, pair_key(a, x_), -f);
-                emit<SLOT>(A, W, pt, db, pair_key(a, z), f);
+            if (sp) {
+              my_sites++;
+              const uint32_t b = t1 & L_ID;
+              const uint32_t z = NEWTOK(p);
+              v0 = true; k0 = pair_key(a, b); d0 = -f;  // the merged pair itself
+              // run of new z tokens (x y x y ... or the halves of an x-run): counted floor(Lz/2) by its first site
+              const bool prev_same = p >= 2 && !(t0 & TOK_WS) && s_m2 && NEWTOK(p - 2) == z;
+              const uint32_t t2 = W.tk[p + 2];
+              if (!prev_same && !(t2 & TOK_WS) && p + 2 < n && s_p2 && NEWTOK(p + 2) == z) {
+                int q = p + 2, lz = 2;
+                while (!(W.tk[q + 2] & TOK_WS) && q + 2 < n && SITE(q + 2) && NEWTOK(q + 2) == z) { q += 2; lz++; }
+                v1 = true; k1 = pair_key(z, z); d1 = (long long)(lz / 2) * f;
               }
-              if (dp && adj1) {
-                // p was the y of the site at p-1: its old right adjacency disappears
-                const uint32_t b_ = t1 & L_ID;
-                if (a != b_) {
-                  emit<SLOT>(A, W, pt, db, pair_key(a, b_), -f);
-                } else if (a != self_x) {
-                  // x != y rule whose y is the first token of a run of a's: the run shrinks by one
-                  int q = p;
-                  while (!(W.tk[q + 1] & TOK_WS) && (W.tk[q + 1] & L_ID) == a) q++;
-                  const int len = q - p + 1;
-                  if ((len & 1) == 0) emit<SLOT>(A, W, pt, db, pair_key(a, a), -f);
-                }
+              // new adjacency (z, right neighbour)
+              if (p + 2 < n && !(t2 & TOK_WS)) {
+                const uint32_t B = s_p2 ? NEWTOK(p + 2) : (t2 & L_ID);
+                if (B != z) { v2 = true; k2 = pair_key(z, B); d2 = f; }
+              }
+              // x != y rule whose x is the last token of a run of a's: the run shrinks by one
+              if (a != self_x && p > 0 && !(t0 & TOK_WS) && (W.tk[p - 1] & L_ID) == a) {
+                int rr = p;
+                while (rr > 0 && !(W.tk[rr] & TOK_WS) && (W.tk[rr - 1] & L_ID) == a) rr--;
+                const int len = p - rr + 1;
+                if ((len & 1) == 0) { v3 = true; k3 = pair_key(a, a); d3 = -f; }
+              }
+            } else if (!dp && adj1 && s_p1) {
+              // unmerged token whose right neighbour starts a site: (a,x) -> (a,z)
+              const uint32_t x_ = t1 & L_ID;
+              const uint32_t z = NEWTOK(p + 1);
+              if (a != x_) { v0 = true; k0 = pair_key(a, x_); d0 = -f; }
+              v1 = true; k1 = pair_key(a, z); d1 = f;
+            }
+            if (dp && adj1) {
+              // p was the y of the site at p-1: its old right adjacency disappears
+              const uint32_t b_ = t1 & L_ID;
+              if (a != b_) {
+                v2 = true; k2 = pair_key(a, b_); d2 = -f;
+              } else if (a != self_x) {
+                // x != y rule whose y is the first token of a run of a's: the run shrinks by one
+                int q = p;
+                while (!(W.tk[q + 1] & TOK_WS) && (W.tk[q + 1] & L_ID) == a) q++;
+                const int len = q - p + 1;
+                if ((len & 1) == 0) { v2 = true; k2 = pair_key(a, a); d2 = -f; }
               }
             }
           }
+          if (__ballot(v0)) { if (v0) emit<SLOT>(A, W, pt, db, k0, d0); }
+          if (__ballot(v1)) { if (v1) emit<SLOT>(A, W, pt, db, k1, d1); }
+          if (__ballot(v2)) { if (v2) emit<SLOT>(A, W, pt, db, k2, d2); }
+          if (__ballot(v3)) { if (v3) emit<SLOT>(A, W, pt, db, k3, d3); }
           const unsigned long long am = __ballot(alive);
           if (lane == 0) {
             W.amask[c] = am;
             W.abase[c] = abase;
           }
           abase += (uint32_t)__popcll(am);
+#ifdef YTTM_K4_PROF
+          S.pt[15] += (unsigned long long)clock64() - tc0_;
+#endif
         }
         wave_sync();
+        K4_MARK(5);
         // ---- phase 3: compact in place (all reads come from LDS, so overwriting the slot in HBM is safe) ----------------
         uint32_t *dst = ts.tok + (size_t)t * SLOT;
-        for (int c = 0; c < nchunks; c++) {
+        for (int c = first_site_chunk; c < nchunks; c++) {  // tokens before the first site neither move nor change
           const int p = c * 64 + lane;
           if (p < n) {
             const unsigned long long am = W.amask[c];
@@ -400,6 +531,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         if (lane == 0) ts.tile_len[t] = abase;
         st_touched++;
         st_touched_tok += (unsigned long long)n;
+        K4_MARK(6);
 #undef SITE
 #undef NEWTOK
       }
@@ -411,7 +543,7 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                                                     const uint32_t *__restrict__ worklist, const unsigned int *__restrict__ work_n,
-                                                    unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
+                                                    unsigned int *__restrict__ work_ctr, unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
   __shared__ WaveLds<SLOT> WL[WPB];
   __shared__ AggLds A;
   agg_init<WPB * 64>(A, MERGE ? flagbits : nullptr);
@@ -439,35 +571,123 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
     }
   };
   uint4 r[SLOT / 256];
+  uint32_t wq = 0;  // frequencies of the first 64 words of the tile held in r (lane j: word j; the array is padded by 64)
   TileStats S;
-  int j = 0;
-  if (t < NT) {
-    load_headers(t_batch);
-    tile_fetch<SLOT>(r, ts, __shfl(ht, 0), __shfl(hn, 0));
-  }
-  while (t < NT) {
-    const int n0 = __shfl(hn, j);
-    const uint32_t w0 = __shfl(hw, j);
-    const uint32_t tile = __shfl(ht, j);
+#ifdef YTTM_K4_PROF
+  S.t_last = (unsigned long long)clock64();
+  const unsigned long long t_loop0 = S.t_last;
+#endif
+  // tile i is in registers: flag/stage it; then (prefetch of tile i+1 by the caller); then process it from LDS
+  auto stage_part = [&](int n0) {
     // K4: a tile with no (x-flagged, y-flagged) adjacency is dismissed in registers and never touches LDS
     const bool dirty = MERGE ? reg_candidates<SLOT>(r, n0, A.flagbits, tokflag, self_x) : true;
+    if (MERGE) K4_MARK(0);
     if (dirty) tile_stage<SLOT>(W, r, n0);
-    // next tile of this wave: header from the batch (reload the batch every 64 tiles), tokens prefetched now
-    const uint32_t t_next = t + stride;
-    j++;
-    if (j == 64 && t_next < NT) {
-      j = 0;
-      t_batch = t_next;
-      load_headers(t_batch);
-    }
-    if (t_next < NT) tile_fetch<SLOT>(r, ts, __shfl(ht, j), __shfl(hn, j));
+    if (MERGE) K4_MARK(1);
+    return dirty;
+  };
+  auto process_part = [&](bool dirty, uint32_t tile, int n0, uint32_t w0, uint32_t wcur) {
+    if (MERGE) K4_MARK(2);
     if (dirty) {
-      process_tile<SLOT, MERGE>(W, A, ts, pt, db, rules, rule_mask, self_x, self_z, z_base, tile, n0, w0, S);
+      K4_COUNT(8);
+#ifdef YTTM_K4_PROF
+      const unsigned long long p4_ = S.pt[4], p5_ = S.pt[5], p3_ = S.pt[3], p6_ = S.pt[6];
+#endif
+      process_tile<SLOT, MERGE>(W, A, ts, pt, db, rules, rule_mask, self_x, self_z, z_base, tile, n0, w0, wcur, S);
+#ifdef YTTM_K4_PROF
+      (void)p3_; (void)p4_; (void)p5_; (void)p6_;
+#endif
       wave_sync();  // everyone is done with this tile's LDS state before it is restaged
     } else {
       S.scanned += (unsigned long long)n0;
     }
-    t = t_next;
+  };
+  if (MERGE && work_ctr && NT <= DYN_TILES_PER_WAVE * stride) {
+    // Short worklist (the usual case after the first ~100 rounds): a static split leaves the launch waiting for the
+    // unluckiest wavefront (measured: slowest wave 4-7x the mean).  Each wave takes its first two items statically and
+    // then pulls items from a global counter.  The chain counter -> worklist entry -> tile header -> tokens is kept
+    // four items deep, each hop issued one tile ahead of its use, so no hop is waited for.
+    const uint32_t wid = blockIdx.x * WPB + wave;
+    int seq = 0;
+    uint32_t grabbed = 0;  // lane 0: result of the pending counter read (broadcast when used)
+    auto issue_index = [&]() {
+      if (seq < 2) grabbed = wid + (uint32_t)seq * stride;
+      else if (lane == 0) grabbed = 2u * stride + atomicAdd(work_ctr, 1u);
+      seq++;
+    };
+    auto take_index = [&]() { return seq <= 2 ? grabbed : (uint32_t)__shfl((int)grabbed, 0); };  // static values are uniform
+    uint32_t i2, tile2 = 0, tile1 = 0, tile0 = 0, w1 = 0, w0 = 0;
+    int n1 = 0, n0 = 0;
+    bool v2, v1, v0;
+    // prologue: fill the pipe
+    issue_index();
+    i2 = take_index();
+    issue_index();
+    v2 = i2 < NT;
+    if (v2) tile2 = worklist[i2];
+    tile1 = tile2; v1 = v2;
+    i2 = take_index();
+    issue_index();
+    v2 = i2 < NT;
+    if (v2) tile2 = worklist[i2];
+    if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = ts.tile_word0[tile1]; }
+    tile0 = tile1; n0 = n1; w0 = w1; v0 = v1;
+    tile1 = tile2; v1 = v2;
+    i2 = take_index();
+    issue_index();
+    v2 = i2 < NT;
+    if (v2) tile2 = worklist[i2];
+    if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = ts.tile_word0[tile1]; }
+    if (v0) {
+      tile_fetch<SLOT>(r, ts, tile0, n0);
+      wq = ts.wcnt[w0 + lane];
+    }
+    while (v0) {
+      const bool dirty = stage_part(n0);
+      const uint32_t wcur = wq, tile_c = tile0, w_c = w0;
+      const int n_c = n0;
+      // shift the pipe: tokens of the next tile, header of the one after, worklist entry of the third, a new index
+      tile0 = tile1; n0 = n1; w0 = w1; v0 = v1;
+      if (v0) {
+        tile_fetch<SLOT>(r, ts, tile0, n0);
+        wq = ts.wcnt[w0 + lane];
+      }
+      tile1 = tile2; v1 = v2;
+      if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = ts.tile_word0[tile1]; }
+      i2 = take_index();
+      issue_index();
+      v2 = v1 && i2 < NT;  // indices of a wave only grow: nothing valid follows an invalid one
+      if (v2) tile2 = worklist[i2];
+      process_part(dirty, tile_c, n_c, w_c, wcur);
+    }
+  } else {
+    int j = 0;
+    if (t < NT) {
+      load_headers(t_batch);
+      tile_fetch<SLOT>(r, ts, __shfl(ht, 0), __shfl(hn, 0));
+      wq = ts.wcnt[__shfl(hw, 0) + lane];
+    }
+    while (t < NT) {
+      const int n0 = __shfl(hn, j);
+      const uint32_t w0 = __shfl(hw, j);
+      const uint32_t tile = __shfl(ht, j);
+      const bool dirty = stage_part(n0);
+      // next tile of this wave: header from the batch (reload the batch every 64 tiles), tokens prefetched now
+      const uint32_t t_next = t + stride;
+      j++;
+      if (j == 64 && t_next < NT) {
+        j = 0;
+        t_batch = t_next;
+        load_headers(t_batch);
+      }
+      const uint32_t wcur = wq;
+      if (t_next < NT) {
+        tile_fetch<SLOT>(r, ts, __shfl(ht, j), __shfl(hn, j));
+        wq = ts.wcnt[__shfl(hw, j) + lane];
+      }
+      process_part(dirty, tile, n0, w0, wcur);
+      t = t_next;
+    }
   }
   if (MERGE) {
     S.sites = wave_sum_u64(S.sites);
@@ -480,6 +700,19 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
   }
   agg_flush<WPB * 64>(A, pt, db);
   __syncthreads();
+#ifdef YTTM_K4_PROF
+  if (MERGE && lane == 0 && SLOT == TILE_SLOT_A) {  // slowest wavefront of the launch vs the sum over wavefronts (tile loop only)
+    atomicMax(&stats[8 + 11], S.t_last - t_loop0);
+    atomicAdd(&stats[8 + 12], S.t_last - t_loop0);
+    atomicAdd(&stats[8 + 13], 1ull);
+  }
+  if (MERGE) {
+    K4_MARK(7);
+    if (lane == 0)
+      for (int i = 0; i < 16; i++)
+        if (S.pt[i]) atomicAdd(&stats[8 + i], S.pt[i]);
+  }
+#endif
   if (threadIdx.x == 0) {
     if (A.new_keys) atomicAdd(pt.n_keys, A.new_keys);
     if (MERGE)
@@ -494,10 +727,16 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
 // few percent of the tiles; this pass is the part that has to run at HBM speed.
 template <int SLOT>
 __global__ __launch_bounds__(BLOCK) void k_filter(TileSet ts, const uint8_t *__restrict__ tokflag, const uint32_t *__restrict__ flagbits,
-                                                  uint32_t self_x, uint32_t *__restrict__ worklist, unsigned int *__restrict__ work_n,
+                                                  const RuleSlot *__restrict__ rules, unsigned int rule_mask, uint32_t self_x,
+                                                  uint32_t *__restrict__ worklist, unsigned int *__restrict__ work_n,
                                                   unsigned long long *__restrict__ stats) {
   __shared__ uint32_t fb[FLAG_LDS_IDS / 16];
+  __shared__ unsigned long long rkeys[FILTER_LDS_KEYS];
   for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += BLOCK) fb[s] = flagbits[s];
+  const bool keys_in_lds = rule_mask < FILTER_LDS_KEYS;
+  if (keys_in_lds)
+    for (unsigned int s = threadIdx.x; s <= rule_mask; s += BLOCK) rkeys[s] = rules[s].key;
+  const RuleProbe probe{keys_in_lds ? rkeys : nullptr, rules, rule_mask};
   __syncthreads();
   __shared__ uint32_t dl[1024];  // dirty tiles found by this workgroup since the last flush
   __shared__ unsigned int dn, dbase;
@@ -520,8 +759,8 @@ __global__ __launch_bounds__(BLOCK) void k_filter(TileSet ts, const uint8_t *__r
       uint4 r1[SLOT / 256], r2[SLOT / 256];
       tile_fetch<SLOT>(r1, ts, t, n1);
       if (t2 < NT) tile_fetch<SLOT>(r2, ts, t2, n2);
-      d1 = reg_candidates<SLOT>(r1, n1, fb, tokflag, self_x);
-      d2 = t2 < NT && reg_candidates<SLOT>(r2, n2, fb, tokflag, self_x);
+      d1 = reg_candidates<SLOT>(r1, n1, fb, tokflag, self_x, probe);
+      d2 = t2 < NT && reg_candidates<SLOT>(r2, n2, fb, tokflag, self_x, probe);
       scanned += (unsigned long long)(n1 + n2);
       if (lane == 0) {
         if (d1) dl[atomicAdd(&dn, 1u)] = t;
@@ -758,11 +997,11 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr);
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned int *)nullptr, (unsigned long long *)nullptr);
   else
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr);
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned int *)nullptr, (unsigned long long *)nullptr);
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
@@ -772,13 +1011,15 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
   unsigned int fg = (ts.n_tiles + 2 * NWAVES - 1) / (2 * NWAVES);
   if (fg > 256 * 8) fg = 256 * 8;
   if (cls == 0) {
-    hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, self_x, worklist, work_n, stats);
+    hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, rules, rule_mask, self_x, worklist, work_n,
+                       stats);
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                       tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats);
+                       tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
   } else {
-    hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, self_x, worklist, work_n, stats);
+    hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, rules, rule_mask, self_x, worklist, work_n,
+                       stats);
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                       tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats);
+                       tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
   }
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
