@@ -66,6 +66,20 @@ def test_encode_mixed_shapes():
     S.check_encode_mixed_shapes(n_sent=150)
 
 
+def test_hot_list_rebuilds(tmp_path, monkeypatch):
+    """The candidate filter reads a hot list of pairs instead of the whole pair table; shrink the list so that tiny corpora
+    go through its rebuild, overflow and whole-table fallback paths, and demand the same models."""
+    for target, mn, cap in ((8, 3, 64), (4, 2, 16), (64, 8, 4096)):
+        monkeypatch.setenv("YTTM_HOT_TARGET", str(target))
+        monkeypatch.setenv("YTTM_HOT_MIN", str(mn))
+        monkeypatch.setenv("YTTM_HOT_CAP", str(cap))
+        for name in ("readme_small", "runs", "mix_cov"):
+            S.check_golden_train(name, tmp_path)
+        rng = random.Random(target)
+        text = gen.unicode_text(rng, 3000, "ascii")
+        S.check_train_vs_oracle(text, 150, tmp_path, tag=f"hot{target}")
+
+
 def test_config_errors(tmp_path):
     for kw in [dict(coverage=0.0), dict(ids=(0, 300, 2, 3)), dict(ids=(0, 1, 1, 3)), dict(vocab=5)]:
         S.check_train_vs_oracle(b"aaa bbb abab", kw.get("vocab", 50), tmp_path, kw.get("coverage", 1.0), kw.get("ids", (0, 1, 2, 3)), tag="e")

@@ -39,8 +39,8 @@ void yttm_report_to_json(const TrainReport &r, char *buf, int len) {
   snprintf(tmp, sizeof tmp, "\"seconds_total\": %.6f, \"seconds_frontend\": %.6f, \"seconds_merge\": %.6f, \"seconds_io\": %.6f, ", r.seconds_total,
            r.seconds_frontend, r.seconds_merge, r.seconds_io);
   s += tmp;
-  snprintf(tmp, sizeof tmp, "\"corpus_bytes\": %llu, \"n_unique\": %llu, \"n_tokens\": %llu, \"rounds\": %llu, \"rules\": %llu, \"cand_rescans\": %llu, \"repacks\": %llu, \"merge_sites\": %llu, ",
-           r.corpus_bytes, r.n_unique, r.n_tokens, r.rounds, r.rules, r.cand_rescans, r.repacks, r.merge_sites);
+  snprintf(tmp, sizeof tmp, "\"corpus_bytes\": %llu, \"n_unique\": %llu, \"n_tokens\": %llu, \"rounds\": %llu, \"rules\": %llu, \"cand_rescans\": %llu, \"hot_rebuilds\": %llu, \"repacks\": %llu, \"merge_sites\": %llu, ",
+           r.corpus_bytes, r.n_unique, r.n_tokens, r.rounds, r.rules, r.cand_rescans, r.hot_rebuilds, r.repacks, r.merge_sites);
   s += tmp;
   s += "\"kernels\": {";
   for (int i = 0; i < 8; i++) {

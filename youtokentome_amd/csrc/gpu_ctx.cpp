@@ -28,6 +28,13 @@ static T *dmalloc(size_t n) {
   } while (0)
 
 constexpr unsigned int CAND_CAP = 1u << 20;
+constexpr unsigned int HOT_CAP = 1u << 18;  // hot-list slots (entries appended between rebuilds included)
+// a rebuild picks the threshold that lists about HOT_TARGET pairs; fewer live entries than HOT_MIN: lower the threshold.
+// YTTM_HOT_TARGET / YTTM_HOT_MIN / YTTM_HOT_CAP override them (the test-suite shrinks them to exercise rebuilds on tiny corpora).
+static unsigned int env_uint(const char *name, unsigned int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? (unsigned int)strtoul(v, nullptr, 10) : dflt;
+}
 constexpr unsigned int RULES_CAP = 1u << 14;  // hash slots for the per-round rule table (batch <= RULES_CAP/2)
 constexpr size_t PIN_BYTES = (size_t)CAND_CAP * sizeof(CandRec) + (size_t)RULES_CAP * sizeof(RuleSlot) + (1u << 20);
 
@@ -40,6 +47,11 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   // one block for everything the host reads back per round, so that it is ONE device-to-host copy:
   // [0] n_cand, [4] n_keys | [64..) count histogram | [8192..) candidates
   d_round_ = dmalloc<unsigned char>(8192 + (size_t)CAND_CAP * sizeof(CandRec));
+  hot_cap_ = std::min(env_uint("YTTM_HOT_CAP", HOT_CAP), HOT_CAP);
+  hot_target_ = env_uint("YTTM_HOT_TARGET", 1u << 15);
+  hot_min_ = env_uint("YTTM_HOT_MIN", 512);
+  d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);
+  d_hot_n_ = dmalloc<unsigned int>(4);
   d_cand_n_ = (unsigned int *)d_round_;
   d_cand_hist_ = (unsigned long long *)(d_round_ + 64);
   d_cand_ = (CandRec *)(d_round_ + 8192);
@@ -56,7 +68,7 @@ GpuCtx::~GpuCtx() {
   for (auto &e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_); DFREE(d_flagbits_);
   free_class(cls_[0]); free_class(cls_[1]);
-  DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_);
+  DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_);
   if (db_.recs) (void)hipFree(db_.recs);
   if (db_.n) (void)hipFree(db_.n);
   free_table(pt_);
@@ -352,6 +364,11 @@ void GpuCtx::alloc_table(PairTable &pt, unsigned long long cap) {
   pt.cnts = dmalloc<unsigned long long>(cap);
   pt.n_keys = dmalloc<unsigned int>(4);
   pt.mask = cap - 1;
+  pt.hot_tau = ~0ull;  // no hot list until rebuild_hot()
+  pt.hot_slots = d_hot_slots_;
+  pt.hot_n = d_hot_n_;
+  pt.hot_cap = hot_cap_;
+  hot_state_ = HOT_INVALID;
   launch_fill_u64(pt.keys, PT_EMPTY, cap, st_);
   HIP_CHECK(hipMemsetAsync(pt.cnts, 0, cap * 8, st_));
   HIP_CHECK(hipMemsetAsync(pt.n_keys, 0, 16, st_));
@@ -434,14 +451,14 @@ void GpuCtx::pair_count() {
 
 void GpuCtx::download_pairs(std::vector<unsigned long long> &keys, std::vector<unsigned long long> &cnts) {
   std::vector<CandRec> out;
-  uint32_t n = candidates(0, 0xffffffffu, out, nullptr);
+  uint32_t n = scan_full(0, 0xffffffffu, out, nullptr);
   if (n > out.size()) throw GpuError{"download_pairs: more than 2^20 live pairs"};
   keys.resize(n);
   cnts.resize(n);
   for (uint32_t i = 0; i < n; i++) { keys[i] = out[i].key; cnts[i] = out[i].cnt; }
 }
 
-uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist) {
+uint32_t GpuCtx::scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist) {
   HIP_CHECK(hipSetDevice(device_));
   out.clear();
   if (!pt_cap_) {
@@ -470,6 +487,91 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
   }
   out.assign(h_c, h_c + take);
   return n;
+}
+
+// Choose hot_tau from the histogram of the whole table (about HOT_TARGET pairs at or above it, never more than half the
+// list) and list those slots.  Huge ties that do not fit switch the filter back to whole-table scans for a while.
+void GpuCtx::rebuild_hot() {
+  std::vector<CandRec> none;
+  unsigned long long hist[CAND_BINS];
+  pt_.hot_tau = ~0ull;
+  scan_full(~0ull >> 1, 0, none, hist);
+  unsigned long long acc = 0;
+  int chosen = -1;
+  for (int b = CAND_BINS - 1; b >= 1; b--) {
+    if (acc + hist[b] > hot_cap_ / 2) break;
+    acc += hist[b];
+    chosen = b;
+    if (acc >= hot_target_) break;
+  }
+  hot_rebuilds++;
+  if (chosen < 0 || (acc < hot_min_ && chosen > 1)) {  // ties too large for the list right below the few top pairs
+    hot_state_ = HOT_FULLSCAN;
+    fullscan_rounds_ = 0;
+    return;
+  }
+  pt_.hot_tau = std::max<unsigned long long>(1, cand_bin_lower(chosen));
+  HIP_CHECK(hipMemsetAsync(d_hot_n_, 0, 4, st_));
+  t_begin(KT_CAND);
+  launch_hot_rebuild(pt_, st_);
+  t_end(KT_CAND, 8 * pt_cap_);
+  hot_state_ = HOT_ACTIVE;
+}
+
+uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist) {
+  HIP_CHECK(hipSetDevice(device_));
+  out.clear();
+  if (!pt_cap_) {
+    if (hist) memset(hist, 0, CAND_BINS * 8);
+    return 0;
+  }
+  for (int attempt = 0;; attempt++) {
+    if (hot_state_ == HOT_FULLSCAN && ++fullscan_rounds_ >= 64) hot_state_ = HOT_INVALID;  // ties may have dissolved
+    if (hot_state_ == HOT_INVALID) rebuild_hot();
+    if (hot_state_ == HOT_FULLSCAN) return scan_full(tau_cnt, tau_mx, out, hist);
+    unsigned long long t = tau_cnt;
+    uint32_t tm = tau_mx;
+    if (t < pt_.hot_tau) {  // the list is complete only from hot_tau up
+      t = pt_.hot_tau;
+      tm = 0xffffffffu;
+    }
+    HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, st_));
+    HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, st_));
+    t_begin(KT_CAND);
+    launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, st_);
+    t_end(KT_CAND, 20ull * listed_last_);
+    constexpr unsigned int CAND_FAST = 4096;
+    unsigned char *h = (unsigned char *)h_pin_;
+    HIP_CHECK(hipMemcpyAsync(h, d_round_, 8192 + (size_t)CAND_FAST * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
+    sync();
+    const unsigned int *hdr = (const unsigned int *)h;
+    const unsigned int n = hdr[0], listed = hdr[2], live = hdr[3];
+    n_keys_host = hdr[1];
+    listed_last_ = std::min(listed, hot_cap_);
+    unsigned long long overflow = listed > hot_cap_ ? 1 : 0;
+    if (comm_ && comm_->world > 1) {
+      // how many slots were listed depends on the order in which a rank applied its deltas: agree on the overflow verdict
+      // (everything else the decision uses -- live, hot_tau, n_keys -- is the same on every rank)
+      unsigned long long *d_flag = (unsigned long long *)(d_hot_n_ + 2);
+      HIP_CHECK(hipMemcpyAsync(d_flag, &overflow, 8, hipMemcpyHostToDevice, st_));
+      comm_->allreduce_sum_u64(d_flag, 1, st_);
+      HIP_CHECK(hipMemcpyAsync(&overflow, d_flag, 8, hipMemcpyDeviceToHost, st_));
+      sync();
+    }
+    if (attempt < 2 && (overflow || (live < hot_min_ && pt_.hot_tau > 1))) {
+      hot_state_ = HOT_INVALID;  // overflowed, or running dry: relist with a new threshold
+      continue;
+    }
+    if (hist) memcpy(hist, h + 64, CAND_BINS * 8);
+    const unsigned int take = std::min(n, cand_cap_);
+    CandRec *h_c = (CandRec *)(h + 8192);
+    if (take > CAND_FAST) {
+      HIP_CHECK(hipMemcpyAsync(h_c + CAND_FAST, d_cand_ + CAND_FAST, (size_t)(take - CAND_FAST) * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
+      sync();
+    }
+    out.assign(h_c, h_c + take);
+    return n;
+  }
 }
 
 void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned long long *outv) {

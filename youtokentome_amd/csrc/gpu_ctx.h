@@ -55,7 +55,13 @@ class GpuCtx {
   void merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts);
   void pair_query(const unsigned long long *keys, uint32_t n, unsigned long long *out);
   // candidate filter; returns number of candidates that passed (may exceed out.size() capacity => retry with higher tau)
+  // Pairs with count > tau_cnt, or == tau_cnt and max(x,y) <= tau_mx (a complete prefix of the pick order), + histogram
+  // of the counts the filter looked at.  Served from the hot list (counts >= hot_tau(); a lower tau_cnt is raised to it).
   uint32_t candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist /*CAND_BINS or null*/);
+  // the same over the whole table (one streaming pass)
+  uint32_t scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist);
+  unsigned long long hot_tau() const { return hot_state_ == HOT_ACTIVE ? pt_.hot_tau : 1; }
+  unsigned long long hot_rebuilds = 0;
 
   void sync();
   void set_comm(Comm *c) { comm_ = c; }
@@ -73,6 +79,13 @@ class GpuCtx {
 
  private:
   void ensure_table_capacity(unsigned long long need_keys);
+  void rebuild_hot();
+  enum HotState { HOT_INVALID, HOT_ACTIVE, HOT_FULLSCAN };
+  HotState hot_state_ = HOT_INVALID;
+  uint32_t *d_hot_slots_ = nullptr;
+  unsigned int *d_hot_n_ = nullptr;
+  unsigned int fullscan_rounds_ = 0;
+  unsigned int hot_cap_ = 0, hot_target_ = 0, hot_min_ = 0, listed_last_ = 0;
   void alloc_table(PairTable &pt, unsigned long long cap);
   void free_table(PairTable &pt);
   void exchange_deltas();

@@ -58,7 +58,7 @@ Status check_config(BpeConfig &cfg, int vocab_size);  // bpe.cpp:1295-1350
 
 struct TrainReport {
   double seconds_total = 0, seconds_frontend = 0, seconds_merge = 0, seconds_io = 0;
-  unsigned long long corpus_bytes = 0, n_unique = 0, n_tokens = 0, rounds = 0, rules = 0, cand_rescans = 0, repacks = 0, merge_sites = 0;
+  unsigned long long corpus_bytes = 0, n_unique = 0, n_tokens = 0, rounds = 0, rules = 0, cand_rescans = 0, repacks = 0, merge_sites = 0, hot_rebuilds = 0;
   // per kernel family: ms, launches, algorithmic bytes (gpu_ctx.h KT_*)
   double kt_ms[8] = {0};
   unsigned long long kt_launches[8] = {0}, kt_bytes[8] = {0};

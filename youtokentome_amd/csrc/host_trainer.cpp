@@ -199,6 +199,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
                                        w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks);
     rep->rounds = rounds;
     rep->cand_rescans = rescans;
+    rep->hot_rebuilds = g.hot_rebuilds;
     rep->rules = rules.size();
     rep->n_unique = g.n_unique;
     rep->n_tokens = g.n_tokens0;

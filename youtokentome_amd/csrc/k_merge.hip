@@ -811,7 +811,7 @@ __global__ __launch_bounds__(BLOCK) void k_cand_scan(PairTable pt, unsigned long
     bool pass = false;
     unsigned long long k = PT_EMPTY, c = 0;
     if (i < n_slots) {
-      c = pt.cnts[i];  // empty and dead slots have count 0: their keys are never read
+      c = pt.cnts[i] & PT_CNT;  // empty and dead slots have count 0: their keys are never read
       if (c > 0) {
         k = pt.keys[i];
         if (hist) atomicAdd(&lh[cand_bin(c)], 1u);
@@ -843,6 +843,88 @@ __global__ __launch_bounds__(BLOCK) void k_cand_scan(PairTable pt, unsigned long
   }
 }
 
+// Candidate filter over the hot list: same outputs as k_cand_scan, but only the listed slots are inspected and the
+// histogram covers the counts >= hot_tau.  n_out: [0] candidates, [1] n_keys, [2] list length, [3] listed slots that
+// are still >= hot_tau.
+__global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *__restrict__ out,
+                                                    unsigned int cap, unsigned int *__restrict__ n_out, unsigned long long *__restrict__ hist) {
+  __shared__ unsigned int lh[CAND_BINS];
+  __shared__ unsigned int live_blk;
+  for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) lh[b] = 0;
+  if (threadIdx.x == 0) live_blk = 0;
+  const unsigned int hn_raw = *pt.hot_n;
+  const unsigned int hn = hn_raw < pt.hot_cap ? hn_raw : pt.hot_cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    n_out[1] = *pt.n_keys;
+    n_out[2] = hn_raw;
+  }
+  __syncthreads();
+  unsigned int live = 0;
+  for (unsigned int i0 = blockIdx.x * BLOCK; i0 < hn; i0 += gridDim.x * BLOCK) {
+    const unsigned int i = i0 + threadIdx.x;
+    bool pass = false;
+    unsigned long long k = PT_EMPTY, c = 0;
+    if (i < hn) {
+      const uint32_t sl = pt.hot_slots[i];
+      c = pt.cnts[sl] & PT_CNT;
+      if (c >= pt.hot_tau) {
+        live++;
+        k = pt.keys[sl];
+        atomicAdd(&lh[cand_bin(c)], 1u);
+        const uint32_t x = (uint32_t)(k >> 32), y = (uint32_t)k;
+        const uint32_t mx = x > y ? x : y;
+        pass = c > tau_cnt || (c == tau_cnt && mx <= tau_mx);
+      }
+    }
+    const unsigned long long m = __ballot(pass);
+    if (m) {
+      unsigned int base = 0;
+      if (lane_id() == 0) base = atomicAdd(n_out, (unsigned int)__popcll(m));
+      base = __shfl(base, 0);
+      if (pass) {
+        const unsigned int o = base + (unsigned int)__popcll(m & lanemask_lt());
+        if (o < cap) {
+          out[o].key = k;
+          out[o].cnt = c;
+        }
+      }
+    }
+  }
+  if (live) atomicAdd(&live_blk, live);
+  __syncthreads();
+  for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) {
+    const unsigned int v = lh[b];
+    if (v) atomicAdd(&hist[b], (unsigned long long)v);
+  }
+  if (threadIdx.x == 0 && live_blk) atomicAdd(&n_out[3], live_blk);
+}
+
+// (Re)build the hot list: every slot with count >= pt.hot_tau, in one streaming pass; PT_HOT is set exactly on those.
+__global__ __launch_bounds__(BLOCK) void k_hot_rebuild(PairTable pt) {
+  const unsigned long long n_slots = pt.mask + 1;
+  const unsigned long long n_iter = (n_slots + BLOCK - 1) / BLOCK;
+  for (unsigned long long it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    const unsigned long long i = it * BLOCK + threadIdx.x;
+    bool hot = false;
+    if (i < n_slots) {
+      const unsigned long long raw = pt.cnts[i], c = raw & PT_CNT;
+      hot = c >= pt.hot_tau && c > 0;
+      const unsigned long long want = hot ? (c | PT_HOT) : c;
+      if (want != raw) pt.cnts[i] = want;
+    }
+    const unsigned long long m = __ballot(hot);
+    if (m) {
+      unsigned int base = 0;
+      if (lane_id() == 0) base = atomicAdd(pt.hot_n, (unsigned int)__popcll(m));
+      base = __shfl(base, 0);
+      if (hot) {
+        const unsigned int o = base + (unsigned int)__popcll(m & lanemask_lt());
+        if (o < pt.hot_cap) pt.hot_slots[o] = (uint32_t)i;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_pt_rehash(PairTable src, PairTable dst) {
   const unsigned long long n_slots = src.mask + 1;
   unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -850,7 +932,7 @@ __global__ __launch_bounds__(BLOCK) void k_pt_rehash(PairTable src, PairTable ds
   for (; i < n_slots; i += stride) {
     unsigned long long k = src.keys[i];
     if (k == PT_EMPTY) continue;
-    unsigned long long c = src.cnts[i];
+    unsigned long long c = src.cnts[i] & PT_CNT;
     if (c) pt_add(dst, k, (long long)c);  // dead pairs (count 0) can never come back: drop them
   }
 }
@@ -873,7 +955,7 @@ __global__ __launch_bounds__(BLOCK) void k_pt_zero(PairTable pt, const RuleSlot 
   for (;;) {
     const unsigned long long k = pt.keys[j];
     if (k == PT_EMPTY) return;
-    if (k == key) { pt.cnts[j] = 0; return; }
+    if (k == key) { pt.cnts[j] &= PT_HOT; return; }  // a listed slot stays listed (once)
     j = (j + 1) & pt.mask;
   }
 }
@@ -1028,6 +1110,16 @@ void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t 
   unsigned long long b = (n_slots + BLOCK - 1) / BLOCK;
   if (b > 256 * 16) b = 256 * 16;
   hipLaunchKernelGGL(k_cand_scan, dim3((unsigned int)b), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist);
+}
+void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
+                     unsigned long long *hist, hipStream_t st) {
+  hipLaunchKernelGGL(k_hot_scan, dim3(256), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist);
+}
+void launch_hot_rebuild(const PairTable &pt, hipStream_t st) {
+  unsigned long long n_slots = pt.mask + 1;
+  unsigned long long b = (n_slots + BLOCK - 1) / BLOCK;
+  if (b > 256 * 16) b = 256 * 16;
+  hipLaunchKernelGGL(k_hot_rebuild, dim3((unsigned int)b), dim3(BLOCK), 0, st, pt);
 }
 void launch_pt_rehash(const PairTable &src, const PairTable &dst, hipStream_t st) {
   unsigned long long n_slots = src.mask + 1;

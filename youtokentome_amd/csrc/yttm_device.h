@@ -37,11 +37,20 @@ constexpr int NWAVES = BLOCK / 64;
 
 constexpr unsigned long long PT_EMPTY = ~0ull;
 
+// Bit 63 of a count marks a slot that is on the hot list (candidate filter): the list holds every slot whose count
+// reached hot_tau since the list was built, so a round inspects tens of thousands of slots instead of the whole table.
+constexpr unsigned long long PT_HOT = 1ull << 63;
+constexpr unsigned long long PT_CNT = PT_HOT - 1;
+
 struct PairTable {
   unsigned long long *keys;  // PT_EMPTY = free slot
-  unsigned long long *cnts;
+  unsigned long long *cnts;  // count (bits 0..62) | PT_HOT
   unsigned long long mask;   // capacity - 1 (capacity is a power of two)
   unsigned int *n_keys;      // number of occupied slots
+  unsigned long long hot_tau;  // a count reaching this puts its slot on the hot list (~0ull: list off)
+  uint32_t *hot_slots;         // [hot_cap]
+  unsigned int *hot_n;         // appended entries (may exceed hot_cap: then the list is rebuilt)
+  unsigned int hot_cap;
 };
 
 struct TileSet {
@@ -105,7 +114,20 @@ __device__ inline void pt_add(const PairTable &pt, unsigned long long key, long 
       }
     }
     if (k == key) {
-      atomicAdd(&pt.cnts[i], (unsigned long long)delta);
+      if (delta > 0 && pt.hot_tau != ~0ull) {
+        // only an increase can cross the threshold; the adder that observes the crossing (exactly one: the adds on a
+        // slot are serialised) sets PT_HOT, and whoever sets it first appends the slot
+        const unsigned long long old = atomicAdd(&pt.cnts[i], (unsigned long long)delta);
+        if (!(old & PT_HOT) && (old & PT_CNT) + (unsigned long long)delta >= pt.hot_tau) {
+          const unsigned long long o2 = atomicOr(&pt.cnts[i], PT_HOT);
+          if (!(o2 & PT_HOT)) {
+            const unsigned int j = atomicAdd(pt.hot_n, 1u);
+            if (j < pt.hot_cap) pt.hot_slots[j] = (uint32_t)i;
+          }
+        }
+      } else {
+        atomicAdd(&pt.cnts[i], (unsigned long long)delta);
+      }
       return;
     }
     i = (i + 1) & pt.mask;
@@ -117,7 +139,7 @@ __device__ inline unsigned long long pt_get(const PairTable &pt, unsigned long l
   for (;;) {
     unsigned long long k = pt.keys[i];
     if (k == PT_EMPTY) return 0;
-    if (k == key) return pt.cnts[i];
+    if (k == key) return pt.cnts[i] & PT_CNT;
     i = (i + 1) & pt.mask;
   }
 }

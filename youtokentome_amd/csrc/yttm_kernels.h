@@ -53,6 +53,9 @@ void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, un
                    unsigned long long *gstart, unsigned int n_new, uint32_t *new_tok, uint32_t *new_len, uint32_t *new_word0, hipStream_t st);
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
                       unsigned int *n_out, unsigned long long *hist, hipStream_t st);
+void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
+                     unsigned long long *hist, hipStream_t st);
+void launch_hot_rebuild(const PairTable &pt, hipStream_t st);
 void launch_pt_rehash(const PairTable &src, const PairTable &dst, hipStream_t st);
 void launch_pt_zero(const PairTable &pt, const RuleSlot *rules, unsigned int n_slots, unsigned long long self_key, hipStream_t st);
 void launch_pt_query(const PairTable &pt, const unsigned long long *keys, unsigned int n, unsigned long long *out, hipStream_t st);
