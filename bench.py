@@ -113,7 +113,7 @@ def main():
     def quiet(on):  # the trainer prints progress to stderr like the reference
         os.dup2(devnull if on else saved_err, 2)
 
-    quiet(True)
+    quiet(not os.environ.get("YTTM_TRACE"))
     try:
         for _ in range(args.warmup):
             train_step(False)

@@ -32,7 +32,7 @@ static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 typedef int hipError_t;
 typedef struct hipsimStream *hipStream_t;
 typedef struct hipsimEvent *hipEvent_t;
-enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorUnknown = 999 };
 enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
 struct hipDeviceProp_t {
@@ -79,6 +79,7 @@ static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)calloc(1, 8); return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
@@ -92,6 +93,8 @@ static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, h
 
 // ---- device builtins -------------------------------------------------------------------------------------------------
 static inline void __syncthreads() { hipsim::sync_block(); }
+static inline void __threadfence() {}
+static inline void __threadfence_system() {}
 static inline unsigned long long __ballot(int pred) { return hipsim::wave_ballot(pred != 0); }
 template <class T>
 static inline T __shfl(T v, int src) {

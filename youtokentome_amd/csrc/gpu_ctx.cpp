@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 
 namespace yttm {
 
@@ -51,7 +52,9 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   hot_target_ = env_uint("YTTM_HOT_TARGET", 1u << 15);
   hot_min_ = env_uint("YTTM_HOT_MIN", 512);
   d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);
-  d_hot_n_ = dmalloc<unsigned int>(4);
+  d_hot_n_ = dmalloc<unsigned int>(4);  // [0] list length, [1] k_hot_scan's finished-workgroup ticket, [2..3] overflow verdict (u64)
+  HIP_CHECK(hipMemset(d_hot_n_, 0, 16));
+  HIP_CHECK(hipMemset(d_round_, 0, 8192));  // k_hot_scan leaves its counters zeroed for the next call
   d_cand_n_ = (unsigned int *)d_round_;
   d_cand_hist_ = (unsigned long long *)(d_round_ + 64);
   d_cand_ = (CandRec *)(d_round_ + 8192);
@@ -60,6 +63,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   rules_cap_ = RULES_CAP;
   HIP_CHECK(hipHostMalloc(&h_pin_, PIN_BYTES, hipHostMallocDefault));
   h_pin_bytes_ = PIN_BYTES;
+  memset(h_pin_, 0, 8192);  // mailbox header (k_hot_scan publishes its round id at byte 32)
 }
 
 GpuCtx::~GpuCtx() {
@@ -486,6 +490,8 @@ uint32_t GpuCtx::scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vec
     sync();
   }
   out.assign(h_c, h_c + take);
+  HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, st_));  // the hot-list filter expects its counters cleared
+  HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, st_));
   return n;
 }
 
@@ -535,15 +541,28 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
       t = pt_.hot_tau;
       tm = 0xffffffffu;
     }
-    HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, st_));
-    HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, st_));
-    t_begin(KT_CAND);
-    launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, st_);
-    t_end(KT_CAND, 20ull * listed_last_);
     constexpr unsigned int CAND_FAST = 4096;
     unsigned char *h = (unsigned char *)h_pin_;
-    HIP_CHECK(hipMemcpyAsync(h, d_round_, 8192 + (size_t)CAND_FAST * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
-    sync();
+    const uint32_t round_id = ++mail_round_;
+    t_begin(KT_CAND);
+    launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, st_);
+    t_end(KT_CAND, 20ull * listed_last_);
+    {
+      // the kernel's last workgroup writes header + histogram + first candidates into the pinned mailbox and then the
+      // round id: poll for it (a copy + stream synchronisation costs tens of microseconds per round)
+      volatile uint32_t *flag = (volatile uint32_t *)(h + 32);
+      for (unsigned long long spins = 0; *flag != round_id; spins++) {
+        if ((spins & 0x3fff) == 0x3fff) {
+          const hipError_t q = hipStreamQuery(st_);
+          if (q == hipSuccess) {
+            if (*flag != round_id) throw GpuError{"candidate mailbox was not published"};
+          } else if (q != hipErrorNotReady) {
+            throw GpuError{std::string("candidate filter: ") + hipGetErrorString(q)};
+          }
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
     const unsigned int *hdr = (const unsigned int *)h;
     const unsigned int n = hdr[0], listed = hdr[2], live = hdr[3];
     n_keys_host = hdr[1];
@@ -651,15 +670,11 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     i = j;
   }
   prev_flag_toks_.swap(now);
-  HIP_CHECK(hipMemcpyAsync(d_rules_, h_rules, (size_t)cap * sizeof(RuleSlot), hipMemcpyHostToDevice, st_));
-  if (n_upd) {
-    HIP_CHECK(hipMemcpyAsync(d_flag_upd_, h_upd, (size_t)n_upd * 8, hipMemcpyHostToDevice, st_));
-    launch_set_tokflag(d_tokflag_, d_flagbits_, d_flag_upd_, n_upd, st_);
-  }
+  launch_round_begin(h_rules, cap, d_rules_, h_upd, n_upd, d_tokflag_, d_flagbits_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr,
+                     cls_[1].n_tiles ? cls_[1].d_work_n : nullptr, st_);
   t_begin(KT_MERGE);
   for (int ci = 0; ci < 2; ci++) {
     if (!cls_[ci].n_tiles) continue;
-    HIP_CHECK(hipMemsetAsync(cls_[ci].d_work_n, 0, 8, st_));  // [0] worklist length (k_filter), [1] hand-out counter (k_tiles)
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
                        cls_[ci].d_work_n, d_stats_, st_);
   }

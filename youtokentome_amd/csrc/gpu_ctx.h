@@ -85,6 +85,7 @@ class GpuCtx {
   uint32_t *d_hot_slots_ = nullptr;
   unsigned int *d_hot_n_ = nullptr;
   unsigned int fullscan_rounds_ = 0;
+  uint32_t mail_round_ = 0;
   unsigned int hot_cap_ = 0, hot_target_ = 0, hot_min_ = 0, listed_last_ = 0;
   void alloc_table(PairTable &pt, unsigned long long cap);
   void free_table(PairTable &pt);

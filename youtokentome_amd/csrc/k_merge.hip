@@ -455,9 +455,8 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
             alive = !dp;
             if (sp) {
               my_sites++;
-              const uint32_t b = t1 & L_ID;
               const uint32_t z = NEWTOK(p);
-              v0 = true; k0 = pair_key(a, b); d0 = -f;  // the merged pair itself
+              // (the merged pair itself is not retracted site by site: every occurrence goes, its count is zeroed afterwards)
               // run of new z tokens (x y x y ... or the halves of an x-run): counted floor(Lz/2) by its first site
               const bool prev_same = p >= 2 && !(t0 & TOK_WS) && s_m2 && NEWTOK(p - 2) == z;
               const uint32_t t2 = W.tk[p + 2];
@@ -846,8 +845,13 @@ __global__ __launch_bounds__(BLOCK) void k_cand_scan(PairTable pt, unsigned long
 // Candidate filter over the hot list: same outputs as k_cand_scan, but only the listed slots are inspected and the
 // histogram covers the counts >= hot_tau.  n_out: [0] candidates, [1] n_keys, [2] list length, [3] listed slots that
 // are still >= hot_tau.
+// The last workgroup to finish copies header, histogram and the first `fast` candidates into the host's pinned mailbox,
+// publishes `round_id` there (system-scope release) and clears the device-side counters for the next call: the host
+// polls the mailbox instead of paying a copy + stream synchronisation every round.
 __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *__restrict__ out,
-                                                    unsigned int cap, unsigned int *__restrict__ n_out, unsigned long long *__restrict__ hist) {
+                                                    unsigned int cap, unsigned int *__restrict__ n_out, unsigned long long *__restrict__ hist,
+                                                    unsigned int *__restrict__ done_ctr, unsigned char *__restrict__ mailbox, unsigned int fast,
+                                                    uint32_t round_id) {
   __shared__ unsigned int lh[CAND_BINS];
   __shared__ unsigned int live_blk;
   for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) lh[b] = 0;
@@ -897,6 +901,40 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
     if (v) atomicAdd(&hist[b], (unsigned long long)v);
   }
   if (threadIdx.x == 0 && live_blk) atomicAdd(&n_out[3], live_blk);
+  // ---- last workgroup: publish
+  __shared__ unsigned int is_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(done_ctr, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  const unsigned int n = __hip_atomic_load(&n_out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned int *mb_hdr = reinterpret_cast<unsigned int *>(mailbox);
+  unsigned long long *mb_hist = reinterpret_cast<unsigned long long *>(mailbox + 64);
+  uint4 *mb_out = reinterpret_cast<uint4 *>(mailbox + 8192);
+  if (threadIdx.x < 4) mb_hdr[threadIdx.x] = __hip_atomic_load(&n_out[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) {
+    mb_hist[b] = __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hist[b] = 0;
+  }
+  unsigned int take = n < cap ? n : cap;
+  if (take > fast) take = fast;
+  const unsigned long long *src = reinterpret_cast<const unsigned long long *>(out);
+  for (unsigned int i = threadIdx.x; i < take; i += BLOCK) {
+    uint4 v;
+    const unsigned long long a = __hip_atomic_load(&src[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(&src[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.x = (uint32_t)a; v.y = (uint32_t)(a >> 32); v.z = (uint32_t)b; v.w = (uint32_t)(b >> 32);
+    mb_out[i] = v;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    n_out[0] = n_out[1] = n_out[2] = n_out[3] = 0;
+    *done_ctr = 0;
+    __hip_atomic_store(&mb_hdr[8], round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // (Re)build the hot list: every slot with count >= pt.hot_tau, in one streaming pass; PT_HOT is set exactly on those.
@@ -978,6 +1016,31 @@ __global__ __launch_bounds__(BLOCK) void k_set_tokflag(uint8_t *__restrict__ tok
     const uint32_t sh = (id & 15u) * 2;
     atomicAnd(&flagbits[id >> 4], ~(3u << sh));
     atomicOr(&flagbits[id >> 4], v << sh);
+  }
+}
+
+// Start of a merge round, one launch instead of two copies, a kernel and two memsets: the batch's rule hash and the token
+// flag updates are read straight from the host's pinned staging area (a few KB over PCIe), the worklist counters are
+// reset.
+__global__ __launch_bounds__(BLOCK) void k_round_begin(const RuleSlot *__restrict__ src_rules, unsigned int n_slots, RuleSlot *__restrict__ dst_rules,
+                                                       const uint32_t *__restrict__ upd, unsigned int n_upd, uint8_t *__restrict__ tokflag,
+                                                       uint32_t *__restrict__ flagbits, unsigned int *__restrict__ work_n_a,
+                                                       unsigned int *__restrict__ work_n_b) {
+  const unsigned int tid = blockIdx.x * BLOCK + threadIdx.x, nt = gridDim.x * BLOCK;
+  for (unsigned int i = tid; i < n_slots; i += nt)
+    reinterpret_cast<uint4 *>(dst_rules)[i] = reinterpret_cast<const uint4 *>(src_rules)[i];
+  for (unsigned int i = tid; i < n_upd; i += nt) {
+    const uint32_t id = upd[2 * i], v = upd[2 * i + 1] & 3u;
+    tokflag[id] = (uint8_t)v;
+    if (id < FLAG_LDS_IDS) {
+      const uint32_t sh = (id & 15u) * 2;
+      atomicAnd(&flagbits[id >> 4], ~(3u << sh));
+      atomicOr(&flagbits[id >> 4], v << sh);
+    }
+  }
+  if (tid == 0) {
+    if (work_n_a) work_n_a[0] = work_n_a[1] = 0;
+    if (work_n_b) work_n_b[0] = work_n_b[1] = 0;
   }
 }
 
@@ -1112,8 +1175,9 @@ void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t 
   hipLaunchKernelGGL(k_cand_scan, dim3((unsigned int)b), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist);
 }
 void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
-                     unsigned long long *hist, hipStream_t st) {
-  hipLaunchKernelGGL(k_hot_scan, dim3(256), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist);
+                     unsigned long long *hist, unsigned int *done_ctr, unsigned char *mailbox, unsigned int fast, uint32_t round_id,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(k_hot_scan, dim3(256), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id);
 }
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st) {
   unsigned long long n_slots = pt.mask + 1;
@@ -1143,6 +1207,14 @@ void launch_pt_apply(const PairTable &pt, const DeltaRec *recs, unsigned long lo
 void launch_set_tokflag(uint8_t *tokflag, uint32_t *flagbits, const uint32_t *upd, unsigned int n, hipStream_t st) {
   if (!n) return;
   hipLaunchKernelGGL(k_set_tokflag, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, tokflag, flagbits, upd, n);
+}
+void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, const uint32_t *upd, unsigned int n_upd,
+                        uint8_t *tokflag, uint32_t *flagbits, unsigned int *work_n_a, unsigned int *work_n_b, hipStream_t st) {
+  unsigned int work = n_slots > n_upd ? n_slots : n_upd;
+  unsigned int b = (work + BLOCK - 1) / BLOCK;
+  if (b < 1) b = 1;
+  if (b > 64) b = 64;
+  hipLaunchKernelGGL(k_round_begin, dim3(b), dim3(BLOCK), 0, st, src_rules, n_slots, dst_rules, upd, n_upd, tokflag, flagbits, work_n_a, work_n_b);
 }
 void launch_fill_u64(unsigned long long *p, unsigned long long v, unsigned long long n, hipStream_t st) {
   if (!n) return;
