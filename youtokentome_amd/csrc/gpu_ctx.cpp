@@ -386,8 +386,8 @@ void GpuCtx::free_table(PairTable &pt) {
 
 void GpuCtx::ensure_table_capacity(unsigned long long need_keys) {
   if (pt_cap_ && need_keys * 2 <= pt_cap_) return;
-  // load stays between 1/4 and 1/2: the candidate filter streams the whole table every round
-  unsigned long long new_cap = pow2_at_least(std::max<unsigned long long>(1ull << 16, need_keys * 2 + need_keys / 2));
+  // load stays below 1/2; growth is by 4x (a rehash also costs a rebuild of the hot list)
+  unsigned long long new_cap = pow2_at_least(std::max<unsigned long long>(1ull << 16, need_keys * 4));
   if (!pt_cap_) {
     alloc_table(pt_, new_cap);
     pt_cap_ = new_cap;
@@ -396,6 +396,7 @@ void GpuCtx::ensure_table_capacity(unsigned long long need_keys) {
   PairTable nt{};
   alloc_table(nt, new_cap);
   launch_pt_rehash(pt_, nt, st_);
+  rehashes++;
   unsigned int nk = 0;
   HIP_CHECK(hipMemcpyAsync(&nk, nt.n_keys, 4, hipMemcpyDeviceToHost, st_));
   sync();
@@ -441,6 +442,13 @@ void GpuCtx::pair_count() {
       recv_cap_ = db_.cap * (unsigned long long)comm_->world;
       d_recv_ = dmalloc<DeltaRec>(recv_cap_);
     }
+  }
+  // The candidate filter no longer streams the table, so its size costs nothing per round, while every growth step is a
+  // rehash plus a hot-list rebuild: start at the size a corpus of this many tokens typically ends with.
+  {
+    unsigned long long guess = n_tokens0 / 16;  // keys; the table holds them at load <= 1/2
+    if (comm_ && comm_->world > 1) guess *= (unsigned long long)comm_->world;
+    bound = std::max(bound, std::min<unsigned long long>(guess, 1ull << 25));
   }
   ensure_table_capacity(bound);
   t_begin(KT_PAIR_COUNT);
@@ -545,7 +553,7 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     unsigned char *h = (unsigned char *)h_pin_;
     const uint32_t round_id = ++mail_round_;
     t_begin(KT_CAND);
-    launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, st_);
+    launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_, st_);
     t_end(KT_CAND, 20ull * listed_last_);
     {
       // the kernel's last workgroup writes header + histogram + first candidates into the pinned mailbox and then the
@@ -562,6 +570,13 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
         }
       }
       std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    {
+      const unsigned long long cum = *(const unsigned long long *)(h + 40);
+      if (cum != scanned_cum_) {  // a merge round ran since the last call: that is how many tokens its filters streamed
+        live_tokens_last_ = cum - scanned_cum_;
+        scanned_cum_ = cum;
+      }
     }
     const unsigned int *hdr = (const unsigned int *)h;
     const unsigned int n = hdr[0], listed = hdr[2], live = hdr[3];
@@ -696,7 +711,15 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   pending_zero_ = true;
   zero_cap_ = cap;
   zero_self_key_ = self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY;
-  if (++rounds_since_check_ >= 8) {
+  // repack when the tiles are less than half full.  With the hot-list filter the fill is known for free (the previous
+  // round's filters report the tokens they streamed); otherwise look every 8 rounds.
+  if (hot_state_ == HOT_ACTIVE && live_tokens_last_) {
+    const unsigned long long nominal = (unsigned long long)cls_[0].n_tiles * cls_[0].nom + (unsigned long long)cls_[1].n_tiles * cls_[1].nom;
+    if (live_tokens_last_ * 2 <= nominal && ++rounds_since_check_ >= 2) {
+      rounds_since_check_ = 0;
+      for (int ci = 0; ci < 2; ci++) maybe_repack(ci);
+    }
+  } else if (++rounds_since_check_ >= 8) {
     rounds_since_check_ = 0;
     for (int ci = 0; ci < 2; ci++) maybe_repack(ci);
   }

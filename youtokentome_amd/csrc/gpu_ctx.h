@@ -61,7 +61,8 @@ class GpuCtx {
   // the same over the whole table (one streaming pass)
   uint32_t scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist);
   unsigned long long hot_tau() const { return hot_state_ == HOT_ACTIVE ? pt_.hot_tau : 1; }
-  unsigned long long hot_rebuilds = 0;
+  unsigned long long hot_rebuilds = 0, rehashes = 0;
+  unsigned long long table_capacity() const { return pt_cap_; }
 
   void sync();
   void set_comm(Comm *c) { comm_ = c; }
@@ -86,6 +87,7 @@ class GpuCtx {
   unsigned int *d_hot_n_ = nullptr;
   unsigned int fullscan_rounds_ = 0;
   uint32_t mail_round_ = 0;
+  unsigned long long scanned_cum_ = 0, live_tokens_last_ = 0;
   unsigned int hot_cap_ = 0, hot_target_ = 0, hot_min_ = 0, listed_last_ = 0;
   void alloc_table(PairTable &pt, unsigned long long cap);
   void free_table(PairTable &pt);

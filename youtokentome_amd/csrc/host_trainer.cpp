@@ -101,7 +101,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   // ---- merge loop
   std::vector<BPE_Rule> rules;
   rules.reserve((size_t)vocab_size);
-  const unsigned long long TARGET = 2048;
+  const unsigned long long TARGET = getenv("YTTM_CAND_TARGET") ? strtoull(getenv("YTTM_CAND_TARGET"), nullptr, 10) : 256;  // candidates kept above the threshold (tuning hook)
   const uint32_t MX_ALL = 0xffffffffu;
   unsigned long long tau = 1;
   uint32_t tau_mx = MX_ALL;
@@ -195,8 +195,8 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   }
   if (rep) {
     rep->seconds_merge = since(t_merge);
-    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu\n",
-                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks);
+    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu, hot rebuilds %llu, pair table %llu keys in %llu slots (%llu rehashes)\n",
+                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.hot_rebuilds, g.n_keys_host, g.table_capacity(), g.rehashes);
     rep->rounds = rounds;
     rep->cand_rescans = rescans;
     rep->hot_rebuilds = g.hot_rebuilds;

@@ -851,7 +851,7 @@ __global__ __launch_bounds__(BLOCK) void k_cand_scan(PairTable pt, unsigned long
 __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *__restrict__ out,
                                                     unsigned int cap, unsigned int *__restrict__ n_out, unsigned long long *__restrict__ hist,
                                                     unsigned int *__restrict__ done_ctr, unsigned char *__restrict__ mailbox, unsigned int fast,
-                                                    uint32_t round_id) {
+                                                    uint32_t round_id, const unsigned long long *__restrict__ stats) {
   __shared__ unsigned int lh[CAND_BINS];
   __shared__ unsigned int live_blk;
   for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) lh[b] = 0;
@@ -914,6 +914,8 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
   unsigned long long *mb_hist = reinterpret_cast<unsigned long long *>(mailbox + 64);
   uint4 *mb_out = reinterpret_cast<uint4 *>(mailbox + 8192);
   if (threadIdx.x < 4) mb_hdr[threadIdx.x] = __hip_atomic_load(&n_out[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 4)  // tokens streamed by the K4 filters so far: the host derives the tiles' fill from it (repack trigger)
+    *reinterpret_cast<unsigned long long *>(mailbox + 40) = __hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) {
     mb_hist[b] = __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     hist[b] = 0;
@@ -1176,8 +1178,9 @@ void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t 
 }
 void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
                      unsigned long long *hist, unsigned int *done_ctr, unsigned char *mailbox, unsigned int fast, uint32_t round_id,
-                     hipStream_t st) {
-  hipLaunchKernelGGL(k_hot_scan, dim3(256), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id);
+                     const unsigned long long *stats, hipStream_t st) {
+  hipLaunchKernelGGL(k_hot_scan, dim3(256), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id,
+                     stats);
 }
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st) {
   unsigned long long n_slots = pt.mask + 1;
