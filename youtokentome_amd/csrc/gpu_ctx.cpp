@@ -364,8 +364,7 @@ void GpuCtx::maybe_repack(int ci) {
 
 // ------------------------------------------------------------------------------------------------- pair table
 void GpuCtx::alloc_table(PairTable &pt, unsigned long long cap) {
-  pt.keys = dmalloc<unsigned long long>(cap);
-  pt.cnts = dmalloc<unsigned long long>(cap);
+  pt.slots = dmalloc<unsigned long long>(2 * cap);
   pt.n_keys = dmalloc<unsigned int>(4);
   pt.mask = cap - 1;
   pt.hot_tau = ~0ull;  // no hot list until rebuild_hot()
@@ -373,13 +372,11 @@ void GpuCtx::alloc_table(PairTable &pt, unsigned long long cap) {
   pt.hot_n = d_hot_n_;
   pt.hot_cap = hot_cap_;
   hot_state_ = HOT_INVALID;
-  launch_fill_u64(pt.keys, PT_EMPTY, cap, st_);
-  HIP_CHECK(hipMemsetAsync(pt.cnts, 0, cap * 8, st_));
+  launch_pt_clear(pt, st_);
   HIP_CHECK(hipMemsetAsync(pt.n_keys, 0, 16, st_));
 }
 void GpuCtx::free_table(PairTable &pt) {
-  DFREE(pt.keys);
-  DFREE(pt.cnts);
+  DFREE(pt.slots);
   DFREE(pt.n_keys);
   pt.mask = 0;
 }

@@ -810,9 +810,9 @@ __global__ __launch_bounds__(BLOCK) void k_cand_scan(PairTable pt, unsigned long
     bool pass = false;
     unsigned long long k = PT_EMPTY, c = 0;
     if (i < n_slots) {
-      c = pt.cnts[i] & PT_CNT;  // empty and dead slots have count 0: their keys are never read
+      c = (*pt.cnt_p(i)) & PT_CNT;  // empty and dead slots have count 0: their keys are never read
       if (c > 0) {
-        k = pt.keys[i];
+        k = (*pt.key_p(i));
         if (hist) atomicAdd(&lh[cand_bin(c)], 1u);
         const uint32_t x = (uint32_t)(k >> 32), y = (uint32_t)k;
         const uint32_t mx = x > y ? x : y;
@@ -870,10 +870,11 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
     unsigned long long k = PT_EMPTY, c = 0;
     if (i < hn) {
       const uint32_t sl = pt.hot_slots[i];
-      c = pt.cnts[sl] & PT_CNT;
+      const uint4 rec = *reinterpret_cast<const uint4 *>(pt.key_p(sl));  // key and count in one 16-byte load
+      c = (((unsigned long long)rec.w << 32) | rec.z) & PT_CNT;
       if (c >= pt.hot_tau) {
         live++;
-        k = pt.keys[sl];
+        k = ((unsigned long long)rec.y << 32) | rec.x;
         atomicAdd(&lh[cand_bin(c)], 1u);
         const uint32_t x = (uint32_t)(k >> 32), y = (uint32_t)k;
         const uint32_t mx = x > y ? x : y;
@@ -947,10 +948,10 @@ __global__ __launch_bounds__(BLOCK) void k_hot_rebuild(PairTable pt) {
     const unsigned long long i = it * BLOCK + threadIdx.x;
     bool hot = false;
     if (i < n_slots) {
-      const unsigned long long raw = pt.cnts[i], c = raw & PT_CNT;
+      const unsigned long long raw = (*pt.cnt_p(i)), c = raw & PT_CNT;
       hot = c >= pt.hot_tau && c > 0;
       const unsigned long long want = hot ? (c | PT_HOT) : c;
-      if (want != raw) pt.cnts[i] = want;
+      if (want != raw) (*pt.cnt_p(i)) = want;
     }
     const unsigned long long m = __ballot(hot);
     if (m) {
@@ -970,9 +971,9 @@ __global__ __launch_bounds__(BLOCK) void k_pt_rehash(PairTable src, PairTable ds
   unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
   for (; i < n_slots; i += stride) {
-    unsigned long long k = src.keys[i];
+    unsigned long long k = (*src.key_p(i));
     if (k == PT_EMPTY) continue;
-    unsigned long long c = src.cnts[i] & PT_CNT;
+    unsigned long long c = (*src.cnt_p(i)) & PT_CNT;
     if (c) pt_add(dst, k, (long long)c);  // dead pairs (count 0) can never come back: drop them
   }
 }
@@ -993,9 +994,9 @@ __global__ __launch_bounds__(BLOCK) void k_pt_zero(PairTable pt, const RuleSlot 
   if (key == PT_EMPTY) return;
   unsigned long long j = mix64(key) & pt.mask;
   for (;;) {
-    const unsigned long long k = pt.keys[j];
+    const unsigned long long k = (*pt.key_p(j));
     if (k == PT_EMPTY) return;
-    if (k == key) { pt.cnts[j] &= PT_HOT; return; }  // a listed slot stays listed (once)
+    if (k == key) { (*pt.cnt_p(j)) &= PT_HOT; return; }  // a listed slot stays listed (once)
     j = (j + 1) & pt.mask;
   }
 }
@@ -1218,6 +1219,17 @@ void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlo
   if (b < 1) b = 1;
   if (b > 64) b = 64;
   hipLaunchKernelGGL(k_round_begin, dim3(b), dim3(BLOCK), 0, st, src_rules, n_slots, dst_rules, upd, n_upd, tokflag, flagbits, work_n_a, work_n_b);
+}
+__global__ __launch_bounds__(BLOCK) void k_pt_clear(uint4 *__restrict__ slots, unsigned long long n) {
+  unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
+  const uint4 e{0xffffffffu, 0xffffffffu, 0u, 0u};  // { PT_EMPTY, 0 }
+  for (; i < n; i += stride) slots[i] = e;
+}
+void launch_pt_clear(const PairTable &pt, hipStream_t st) {
+  unsigned long long n = pt.mask + 1, b = (n + BLOCK - 1) / BLOCK;
+  if (b > 256 * 16) b = 256 * 16;
+  hipLaunchKernelGGL(k_pt_clear, dim3((unsigned int)b), dim3(BLOCK), 0, st, reinterpret_cast<uint4 *>(pt.slots), n);
 }
 void launch_fill_u64(unsigned long long *p, unsigned long long v, unsigned long long n, hipStream_t st) {
   if (!n) return;

@@ -27,9 +27,10 @@ constexpr uint32_t INVALID_CP = 0x0fffffffu;  // utf8.h:9
 // Token tiles.  A tile holds whole words and lives in a fixed slot of SLOT tokens (tile t = tok[t*SLOT ..)), of which
 // the first tile_len[t] are live; merges compact a tile in place.  One WAVEFRONT owns a tile (no workgroup barriers in
 // the hot loops).  Two classes so that LDS stays small for the common case:
-//   class A: words of <= 512 tokens, nominal 512 tokens per tile, slot 1024 (4 waves per workgroup)
-//   class B: words of 513..2048 tokens, nominal 2048 per tile, slot 4096 (1 wave per workgroup; rare)
-constexpr int TILE_NOM_A = 512, TILE_SLOT_A = 1024;
+//   class A: words of <= 256 tokens, nominal 256 tokens per tile (more when the longest word is shorter), slot 512
+//            (4 waves per workgroup).  Measured at 1 GB: slot 1024 -> 392 ms, 512 -> 383 ms, 256 -> 401 ms per step.
+//   class B: words of 257..2048 tokens, nominal 2048 per tile, slot 4096 (1 wave per workgroup; rare)
+constexpr int TILE_NOM_A = 256, TILE_SLOT_A = 512;
 constexpr int TILE_NOM_B = 2048, TILE_SLOT_B = 4096;
 constexpr int MAX_WORD_TOKENS = TILE_NOM_B;  // longest word the tile kernels accept (incl. the leading space token)
 constexpr int BLOCK = 256;      // 4 wavefronts of 64 lanes
@@ -43,9 +44,11 @@ constexpr unsigned long long PT_HOT = 1ull << 63;
 constexpr unsigned long long PT_CNT = PT_HOT - 1;
 
 struct PairTable {
-  unsigned long long *keys;  // PT_EMPTY = free slot
-  unsigned long long *cnts;  // count (bits 0..62) | PT_HOT
-  unsigned long long mask;   // capacity - 1 (capacity is a power of two)
+  unsigned long long *slots;  // [2 * capacity]: slot i = { key (PT_EMPTY = free), count (bits 0..62) | PT_HOT } -- one 16-byte
+                              // record, so the probe of a key and the update of its count touch the same HBM sector
+  unsigned long long mask;    // capacity - 1 (capacity is a power of two)
+  __host__ __device__ unsigned long long *key_p(unsigned long long i) const { return slots + 2 * i; }
+  __host__ __device__ unsigned long long *cnt_p(unsigned long long i) const { return slots + 2 * i + 1; }
   unsigned int *n_keys;      // number of occupied slots
   unsigned long long hot_tau;  // a count reaching this puts its slot on the hot list (~0ull: list off)
   uint32_t *hot_slots;         // [hot_cap]
@@ -105,9 +108,9 @@ __device__ inline unsigned long long ld_agent(const unsigned long long *p) {
 __device__ inline void pt_add(const PairTable &pt, unsigned long long key, long long delta, unsigned int *new_keys = nullptr) {
   unsigned long long i = mix64(key) & pt.mask;
   for (;;) {
-    unsigned long long k = ld_agent(&pt.keys[i]);
+    unsigned long long k = ld_agent(pt.key_p(i));
     if (k == PT_EMPTY) {
-      k = atomicCAS(&pt.keys[i], PT_EMPTY, key);
+      k = atomicCAS(pt.key_p(i), PT_EMPTY, key);
       if (k == PT_EMPTY) {
         atomicAdd(new_keys ? new_keys : pt.n_keys, 1u);
         k = key;
@@ -117,16 +120,16 @@ __device__ inline void pt_add(const PairTable &pt, unsigned long long key, long 
       if (delta > 0 && pt.hot_tau != ~0ull) {
         // only an increase can cross the threshold; the adder that observes the crossing (exactly one: the adds on a
         // slot are serialised) sets PT_HOT, and whoever sets it first appends the slot
-        const unsigned long long old = atomicAdd(&pt.cnts[i], (unsigned long long)delta);
+        const unsigned long long old = atomicAdd(pt.cnt_p(i), (unsigned long long)delta);
         if (!(old & PT_HOT) && (old & PT_CNT) + (unsigned long long)delta >= pt.hot_tau) {
-          const unsigned long long o2 = atomicOr(&pt.cnts[i], PT_HOT);
+          const unsigned long long o2 = atomicOr(pt.cnt_p(i), PT_HOT);
           if (!(o2 & PT_HOT)) {
             const unsigned int j = atomicAdd(pt.hot_n, 1u);
             if (j < pt.hot_cap) pt.hot_slots[j] = (uint32_t)i;
           }
         }
       } else {
-        atomicAdd(&pt.cnts[i], (unsigned long long)delta);
+        atomicAdd(pt.cnt_p(i), (unsigned long long)delta);
       }
       return;
     }
@@ -137,9 +140,9 @@ __device__ inline void pt_add(const PairTable &pt, unsigned long long key, long 
 __device__ inline unsigned long long pt_get(const PairTable &pt, unsigned long long key) {
   unsigned long long i = mix64(key) & pt.mask;
   for (;;) {
-    unsigned long long k = pt.keys[i];
+    unsigned long long k = *pt.key_p(i);
     if (k == PT_EMPTY) return 0;
-    if (k == key) return pt.cnts[i] & PT_CNT;
+    if (k == key) return *pt.cnt_p(i) & PT_CNT;
     i = (i + 1) & pt.mask;
   }
 }

@@ -59,6 +59,7 @@ void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t t
 void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, const uint32_t *upd, unsigned int n_upd,
                         uint8_t *tokflag, uint32_t *flagbits, unsigned int *work_n_a, unsigned int *work_n_b, hipStream_t st);
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st);
+void launch_pt_clear(const PairTable &pt, hipStream_t st);
 void launch_pt_rehash(const PairTable &src, const PairTable &dst, hipStream_t st);
 void launch_pt_zero(const PairTable &pt, const RuleSlot *rules, unsigned int n_slots, unsigned long long self_key, hipStream_t st);
 void launch_pt_query(const PairTable &pt, const unsigned long long *keys, unsigned int n, unsigned long long *out, hipStream_t st);
