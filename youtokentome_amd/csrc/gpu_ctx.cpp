@@ -43,8 +43,8 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   HIP_CHECK(hipSetDevice(device_));
   HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
   d_counters_ = dmalloc<unsigned long long>(64);
-  d_stats_ = dmalloc<unsigned long long>(24);  // [0..3] K4 counters, [8..23] per-phase cycles of a YTTM_K4_PROF build
-  HIP_CHECK(hipMemset(d_stats_, 0, 24 * sizeof(unsigned long long)));
+  d_stats_ = dmalloc<unsigned long long>(STATS_WORDS);  // [0..3] K4 counters, [8..23] per-phase cycles of a YTTM_K4_PROF build, [32..) per-workgroup rows
+  HIP_CHECK(hipMemset(d_stats_, 0, STATS_WORDS * sizeof(unsigned long long)));
   // one block for everything the host reads back per round, so that it is ONE device-to-host copy:
   // [0] n_cand, [4] n_keys | [64..) count histogram | [8192..) candidates
   d_round_ = dmalloc<unsigned char>(8192 + (size_t)CAND_CAP * sizeof(CandRec));
@@ -104,6 +104,8 @@ void GpuCtx::resolve_timers() {
     // K4 traffic: the filter streams the live tokens once (4 B each); the apply kernel re-reads and rewrites the tiles
     // that had a merge site
     unsigned long long st[8] = {0};
+    if (pt_cap_) launch_fold_stats(d_stats_, pt_.n_keys, st_);
+    sync();
     if (hipMemcpy(st, d_stats_, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
       merge_sites = st[0];
       kt.bytes[KT_MERGE] = 4 * st[2] + 8 * st[3];
@@ -246,8 +248,8 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   if (U == 0) { DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len); return; }
   unsigned long long *posA = dmalloc<unsigned long long>(UA), *posB = dmalloc<unsigned long long>(UB);
   uint32_t *lenA = dmalloc<uint32_t>(UA), *lenB = dmalloc<uint32_t>(UB);
-  cls_[0].d_wcnt = dmalloc<uint32_t>(UA + 64);  // +64: k_tiles loads 64 frequencies from a tile's first word unconditionally
-  cls_[1].d_wcnt = dmalloc<uint32_t>(UB + 64);
+  cls_[0].d_wcnt = dmalloc<uint32_t>(UA + 256);  // padding: k_tiles loads SLOT/2 frequencies from a tile's first word unconditionally
+  cls_[1].d_wcnt = dmalloc<uint32_t>(UB + 256);
   unsigned int *d_cursor = (unsigned int *)(d_counters_ + 32);
   HIP_CHECK(hipMemsetAsync(d_cursor, 0, 8, st_));
   t_begin(KT_BUILD);
@@ -405,6 +407,7 @@ void GpuCtx::ensure_table_capacity(unsigned long long need_keys) {
 
 void GpuCtx::exchange_deltas() {
   if (!comm_ || comm_->world <= 1) return;
+  launch_fold_stats(d_stats_, pt_.n_keys, st_);  // the apply kernels leave their slot counts in per-workgroup rows
   unsigned long long n_local = 0;
   HIP_CHECK(hipMemcpyAsync(&n_local, db_.n, 8, hipMemcpyDeviceToHost, st_));
   sync();
@@ -474,6 +477,7 @@ uint32_t GpuCtx::scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vec
     if (hist) memset(hist, 0, CAND_BINS * 8);
     return 0;
   }
+  launch_fold_stats(d_stats_, pt_.n_keys, st_);
   HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, st_));
   if (hist) HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, st_));
   t_begin(KT_CAND);
@@ -694,6 +698,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   merge_rounds++;
   if (getenv("YTTM_TRACE_ROUNDS")) {  // tuning aid: cumulative device stats after every round (adds a sync)
     unsigned long long stt[24];
+    launch_fold_stats(d_stats_, pt_.n_keys, st_);
     HIP_CHECK(hipMemcpyAsync(stt, d_stats_, sizeof stt, hipMemcpyDeviceToHost, st_));
     sync();
     FILE *f = fopen(getenv("YTTM_TRACE_ROUNDS"), merge_rounds == 1 ? "w" : "a");
@@ -703,7 +708,6 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       fprintf(f, "\n");
       fclose(f);
     }
-    HIP_CHECK(hipMemsetAsync(d_stats_ + 8 + 11, 0, 3 * 8, st_));  // per-round slots of the YTTM_K4_PROF build
   }
   pending_zero_ = true;
   zero_cap_ = cap;
@@ -721,6 +725,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     for (int ci = 0; ci < 2; ci++) maybe_repack(ci);
   }
   if (comm_ && comm_->world > 1) {
+    launch_fold_stats(d_stats_, pt_.n_keys, st_);
     unsigned int nk = 0;
     HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
     sync();

@@ -22,7 +22,6 @@ namespace yttm {
 
 constexpr int AGG_SLOTS = 256;   // LDS delta aggregator shared by the waves of a workgroup (hot pairs)
 constexpr uint32_t DYN_TILES_PER_WAVE = 0;  // worklists shorter than this per wavefront are handed out dynamically
-constexpr int CAND_CAP_W = 192;  // per-wave list of merge-site candidates awaiting their rule lookup
 constexpr uint32_t FLAG_LDS_IDS = 32768;  // batch flags of ids below this live in an LDS bitmap (2 bits per id, 8 KB)
 
 // Staged (LDS) token word: bit31 = first token of a word, bit30 = id is the y of some batch rule, bit29 = id is the x
@@ -39,8 +38,6 @@ struct WaveLds {
   unsigned long long amask[SLOT / 64];     // bit p: position p survives
   uint32_t wsbase[SLOT / 64];              // number of word starts before the chunk
   uint32_t abase[SLOT / 64];               // number of survivors before the chunk
-  uint16_t cand[CAND_CAP_W];
-  unsigned int ncand, pad_;
 };
 struct AggLds {
   unsigned long long key[AGG_SLOTS];
@@ -91,6 +88,49 @@ __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, co
   atomicAdd(&A.miss_n, 1ull);
   atomicAdd(&A.miss_cyc, (unsigned long long)clock64() - t0_);
 #endif
+}
+
+// Per-workgroup statistics.  A launch of >= 1024 workgroups that each bump the same global counters serialises at
+// ~11 ns per atomic (measured: +10 us per launch at 1024 workgroups, +47 us at 4096), a floor under every short kernel of
+// a late round.  So workgroup b adds to its own row stats[BLK_BASE + 8 b + j] with plain stores (launches on the stream
+// are serial), and one workgroup folds the rows into the totals when somebody needs them (fold_blk_stats).
+constexpr int BLK_BASE = 32, BLK_ROWS = 1536;  // >= the largest grid of k_filter / k_tiles<.., true>  // j: 0..3 = the K4 counters, 4 = pair-table slots claimed
+__device__ inline void blk_add(unsigned long long *stats, int j, unsigned long long v) {
+  if (v) stats[BLK_BASE + 8 * (blockIdx.x % BLK_ROWS) + j] += v;
+}
+// called by ONE workgroup of 256 threads, all threads; ends with the totals in stats[0..3] and *n_keys
+__device__ inline void fold_blk_stats(unsigned long long *stats, unsigned int *n_keys) {
+  __shared__ unsigned long long fold_acc[5];
+  if (threadIdx.x < 5) fold_acc[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned long long a[5] = {0, 0, 0, 0, 0};
+  for (int b = (int)threadIdx.x; b < BLK_ROWS; b += (int)blockDim.x) {
+    unsigned long long *row = stats + BLK_BASE + 8 * b;  // written by earlier kernels: plain 16-byte loads
+    const uint4 v01 = *reinterpret_cast<const uint4 *>(row), v23 = *reinterpret_cast<const uint4 *>(row + 2);
+    const unsigned long long v4 = row[4];
+    const unsigned long long v[5] = {((unsigned long long)v01.y << 32) | v01.x, ((unsigned long long)v01.w << 32) | v01.z,
+                                     ((unsigned long long)v23.y << 32) | v23.x, ((unsigned long long)v23.w << 32) | v23.z, v4};
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      a[j] += v[j];
+      any = any || v[j] != 0;
+    }
+    if (any) {
+      const uint4 z{0u, 0u, 0u, 0u};
+      *reinterpret_cast<uint4 *>(row) = z;
+      *reinterpret_cast<uint4 *>(row + 2) = z;
+      row[4] = 0;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 5; j++)
+    if (a[j]) atomicAdd(&fold_acc[j], a[j]);
+  __syncthreads();
+  if (threadIdx.x < 4 && fold_acc[threadIdx.x]) stats[threadIdx.x] += fold_acc[threadIdx.x];
+  if (threadIdx.x == 4 && fold_acc[4]) *n_keys += (unsigned int)fold_acc[4];
+  __threadfence();
+  __syncthreads();
 }
 
 template <int NT>
@@ -161,6 +201,33 @@ struct RuleProbe {
       const unsigned long long k = lds_keys ? __hip_atomic_load(&lds_keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : g[h].key;
       if (k == key) return true;
       if (k == PT_EMPTY) return false;
+      h = (h + 1) & mask;
+    }
+  }
+};
+
+// The batch's rule hash as the apply kernel sees it: in LDS when it fits (the usual case: <= APPLY_LDS_RULES/2 rules), so
+// that processing a tile issues NO global load -- any such load would also wait (vmcnt is in-order) for the prefetch of
+// the wave's next tile, a random HBM access that costs several microseconds late in training.
+constexpr unsigned int APPLY_LDS_RULES = 512;
+template <bool IN_LDS>
+struct RuleTab {
+  const unsigned long long *lds_keys;  // [mask+1] (IN_LDS)
+  const uint16_t *lds_ridx;            // z - z_base
+  const RuleSlot *g;                   // the hash in HBM (!IN_LDS: batches of more than APPLY_LDS_RULES/2 rules)
+  unsigned int mask;
+  uint32_t z_base;
+  // index of the rule in the batch, or 0xffffffff.  Two instantiations, not a run-time choice: with both paths in one
+  // function the compiler waits for vmcnt(0) where they join, prefetch included.
+  __device__ uint32_t find(uint32_t a, uint32_t b) const {
+    const unsigned long long key = pair_key(a, b);
+    unsigned int h = (unsigned int)mix64(key) & mask;
+    for (;;) {
+      unsigned long long k;
+      if (IN_LDS) k = __hip_atomic_load(&lds_keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else k = g[h].key;
+      if (k == key) return IN_LDS ? (uint32_t)lds_ridx[h] : g[h].z - z_base;
+      if (k == PT_EMPTY) return 0xffffffffu;
       h = (h + 1) & mask;
     }
   }
@@ -246,7 +313,6 @@ __device__ inline void tile_stage(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256]
     W.tk[n] = TOK_WS;  // sentinel: "next token starts a word" => no adjacency past the end
     W.tk[n + 1] = TOK_WS;
     W.tk[n + 2] = TOK_WS;
-    W.ncand = 0;
   }
   wave_sync();
 }
@@ -259,14 +325,31 @@ __device__ inline uint32_t tile_word_index(const WaveLds<SLOT> &W, int p) {
   const unsigned long long le = (2ull << (p & 63)) - 1ull;  // bits 0..(p&63)
   return W.wsbase[c] + (uint32_t)__popcll(W.wsmask[c] & le) - 1u;
 }
-// Frequency of word k of the tile.  The weights of the tile's first 64 words were loaded with the tile (lane j holds
-// word j in wreg) and are read by a cross-lane shuffle -- the gather from HBM that this replaces sat, TLB miss and all,
-// on the critical path of every tile.  MUST be called by all lanes of the wave (ds_bpermute reads only active lanes).
+// Frequencies of ALL words of a tile travel with it in registers: lane j holds words j, j+64, ... (a class-A tile has at
+// most SLOT/2 words, a class-B tile -- words of more than TILE_NOM_A tokens -- at most 16).  They are loaded together with
+// the tokens, one tile ahead, and read by cross-lane shuffles: the gather from HBM that this replaces cost ~6 us per
+// active chunk late in training (random 4-byte reads into a 64 MB array: a TLB miss almost every time).
 template <int SLOT>
-__device__ inline long long tile_weight_all(const WaveLds<SLOT> &W, const uint32_t *__restrict__ wcnt, uint32_t word0, uint32_t wreg, int p, bool valid) {
+struct WReg {
+  static constexpr int N = SLOT == TILE_SLOT_A ? SLOT / 128 : 1;
+  uint32_t v[N];
+};
+template <int SLOT>
+__device__ inline void wreg_load(WReg<SLOT> &w, const uint32_t *__restrict__ wcnt, uint32_t word0) {  // wcnt is padded by 64*N
+  const int lane = lane_id();
+#pragma unroll
+  for (int i = 0; i < WReg<SLOT>::N; i++) w.v[i] = wcnt[word0 + (uint32_t)(lane + 64 * i)];
+}
+// Frequency of the word that contains tile position p.  MUST be called by all lanes of the wave (ds_bpermute).
+template <int SLOT>
+__device__ inline long long tile_weight_all(const WaveLds<SLOT> &W, const WReg<SLOT> &wreg, int p, bool valid) {
   const uint32_t k = valid ? tile_word_index<SLOT>(W, p) : 0u;
-  uint32_t f = __shfl(wreg, (int)(k & 63u));
-  if (valid && k >= 64u) f = wcnt[word0 + k];
+  uint32_t f = 0;
+#pragma unroll
+  for (int i = 0; i < WReg<SLOT>::N; i++) {
+    const uint32_t fi = __shfl(wreg.v[i], (int)(k & 63u));
+    if ((k >> 6) == (uint32_t)i) f = fi;
+  }
   return (long long)f;
 }
 
@@ -290,10 +373,10 @@ struct TileStats {
 };
 
 // everything that happens to one staged tile (K3 count or K4 merge)
-template <int SLOT, bool MERGE>
+template <int SLOT, bool MERGE, bool LDSR>
 __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &ts, const PairTable &pt, const DeltaBuf &db,
-                                    const RuleSlot *__restrict__ rules, unsigned int rule_mask, uint32_t self_x, uint32_t self_z,
-                                    uint32_t z_base, uint32_t t, int n, uint32_t word0, uint32_t wreg, TileStats &S) {
+                                    const RuleTab<LDSR> &rtab, uint32_t self_x, uint32_t self_z,
+                                    uint32_t z_base, uint32_t t, int n, uint32_t word0, const WReg<SLOT> &wreg, TileStats &S) {
   const int lane = lane_id();
   unsigned long long &my_sites = S.sites, &st_touched = S.touched, &st_scanned = S.scanned, &st_touched_tok = S.touched_tok;
     const int nchunks = (n + 63) >> 6;
@@ -321,19 +404,10 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
                 W.ridx[p] = (uint16_t)(self_z - z_base);
               }
             } else if ((t0 & L_ISX) && (t1 & L_ISY)) {
-              const unsigned int i = atomicAdd(&W.ncand, 1u);
-              if (i < (unsigned int)CAND_CAP_W) {
-                W.cand[i] = (uint16_t)p;
-              } else {
-                // candidate list full: look the rule up right here
-                const unsigned long long key = pair_key(a, b);
-                unsigned int h = (unsigned int)mix64(key) & rule_mask;
-                for (;;) {
-                  const unsigned long long k = rules[h].key;
-                  if (k == key) { self_site = true; W.ridx[p] = (uint16_t)(rules[h].z - z_base); break; }
-                  if (k == PT_EMPTY) break;
-                  h = (h + 1) & rule_mask;
-                }
+              const uint32_t ri = rtab.find(a, b);
+              if (ri != 0xffffffffu) {
+                self_site = true;
+                W.ridx[p] = (uint16_t)ri;
               }
             }
           }
@@ -355,7 +429,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
     if (!MERGE) {
       for (int c = 0; c < nchunks; c++) {
         const int p = c * 64 + lane;
-        const long long f = tile_weight_all<SLOT>(W, ts.wcnt, word0, wreg, p, p < n);
+        const long long f = tile_weight_all<SLOT>(W, wreg, p, p < n);
         if (p >= n) continue;
         const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
         if (t1 & TOK_WS) continue;
@@ -373,29 +447,6 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         }
       }
     } else {
-      // ---- phase 1b: rule lookups for all candidates of the tile at once (their latencies overlap) --------------------
-      unsigned int nc = W.ncand;
-      if (nc > (unsigned int)CAND_CAP_W) nc = CAND_CAP_W;
-      if (nc) {
-        for (unsigned int i = (unsigned int)lane; i < nc; i += 64) {
-          const int p = (int)W.cand[i];
-          const unsigned long long key = pair_key(W.tk[p] & L_ID, W.tk[p + 1] & L_ID);
-          unsigned int h = (unsigned int)mix64(key) & rule_mask;
-          for (;;) {
-            const unsigned long long k = rules[h].key;
-            if (k == key) {
-              W.ridx[p] = (uint16_t)(rules[h].z - z_base);
-              atomicOr(&W.sitemask[p >> 6], 1ull << (p & 63));
-              break;
-            }
-            if (k == PT_EMPTY) break;
-            h = (h + 1) & rule_mask;
-          }
-        }
-        wave_sync();
-        for (int c = lane; c < nchunks; c += 64) any = any || W.sitemask[c] != 0;
-        any = __ballot(any) != 0;
-      }
       K4_MARK(4);
       if (any) {
         K4_COUNT(9);
@@ -423,17 +474,13 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
           }
           if (first_site_chunk == nchunks && W.sitemask[c] != 0ull) first_site_chunk = c;
 #ifdef YTTM_K4_PROF
-          S.pt[14]++;
-          const unsigned long long tc0_ = (unsigned long long)clock64();
 #endif
-          const long long f = tile_weight_all<SLOT>(W, ts.wcnt, word0, wreg, p, p < n);
 #ifdef YTTM_K4_PROF
-          {
-            const bool near_ = p < n && (SITE(p) || SITE(p - 1) || SITE(p + 1));
-            if (__ballot(near_ && f == 0x7fffffffffffffffll)) S.pt[13]++;  // forces f to be materialised here
-            S.pt[10] += (unsigned long long)clock64() - tc0_;
-          }
+#define K4_SUB(k) ((void)0)
+#else
+#define K4_SUB(k) ((void)0)
 #endif
+          const long long f = tile_weight_all<SLOT>(W, wreg, p, p < n);
           // Site bits of this chunk and its neighbours live in registers (every SITE() below used to be a dependent LDS
           // read), and the up to four count deltas of a lane are collected first and emitted by all lanes together: four
           // convergent trips through the LDS aggregator instead of nine divergent ones.
@@ -444,6 +491,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
           const bool s_p1 = lane <= 62 ? ((sm1 >> ((lane + 1) & 63)) & 1ull) : (sm2 & 1ull);
           const bool s_m2 = lane >= 2 ? ((sm1 >> ((lane - 2) & 63)) & 1ull) : ((sm0 >> ((62 + lane) & 63)) & 1ull);
           const bool s_p2 = lane <= 61 ? ((sm1 >> ((lane + 2) & 63)) & 1ull) : ((sm2 >> ((lane - 62) & 63)) & 1ull);
+          K4_SUB(10);
           bool alive = false;
           bool v0 = false, v1 = false, v2 = false, v3 = false;
           unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
@@ -498,10 +546,15 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
               }
             }
           }
+          K4_SUB(11);
           if (__ballot(v0)) { if (v0) emit<SLOT>(A, W, pt, db, k0, d0); }
+          K4_SUB(12);
           if (__ballot(v1)) { if (v1) emit<SLOT>(A, W, pt, db, k1, d1); }
+          K4_SUB(13);
           if (__ballot(v2)) { if (v2) emit<SLOT>(A, W, pt, db, k2, d2); }
+          K4_SUB(14);
           if (__ballot(v3)) { if (v3) emit<SLOT>(A, W, pt, db, k3, d3); }
+          K4_SUB(15);
           const unsigned long long am = __ballot(alive);
           if (lane == 0) {
             W.amask[c] = am;
@@ -509,7 +562,6 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
           }
           abase += (uint32_t)__popcll(am);
 #ifdef YTTM_K4_PROF
-          S.pt[15] += (unsigned long long)clock64() - tc0_;
 #endif
         }
         wave_sync();
@@ -537,15 +589,26 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
     }
 }
 
-template <int SLOT, int WPB, bool MERGE>
+template <int SLOT, int WPB, bool MERGE, bool LDSR>
 __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                                                     const uint32_t *__restrict__ worklist, const unsigned int *__restrict__ work_n,
                                                     unsigned int *__restrict__ work_ctr, unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
   __shared__ WaveLds<SLOT> WL[WPB];
+#ifdef YTTM_K4_PROF
+  const unsigned long long t_entry_ = (unsigned long long)clock64();
+#endif
   __shared__ AggLds A;
+  __shared__ unsigned long long rkeys[LDSR ? APPLY_LDS_RULES : 1];
+  __shared__ uint16_t rridx[LDSR ? APPLY_LDS_RULES : 1];
   agg_init<WPB * 64>(A, MERGE ? flagbits : nullptr);
+  if (LDSR)
+    for (unsigned int i = threadIdx.x; i <= rule_mask; i += WPB * 64) {
+      rkeys[i] = rules[i].key;
+      rridx[i] = (uint16_t)(rules[i].z - z_base);
+    }
+  const RuleTab<LDSR> rtab{rkeys, rridx, rules, rule_mask, z_base};
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   WaveLds<SLOT> &W = WL[wave];
@@ -570,11 +633,10 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
     }
   };
   uint4 r[SLOT / 256];
-  uint32_t wq = 0;  // frequencies of the first 64 words of the tile held in r (lane j: word j; the array is padded by 64)
+  WReg<SLOT> wq{};  // word frequencies of the tile held in r
   TileStats S;
 #ifdef YTTM_K4_PROF
   S.t_last = (unsigned long long)clock64();
-  const unsigned long long t_loop0 = S.t_last;
 #endif
   // tile i is in registers: flag/stage it; then (prefetch of tile i+1 by the caller); then process it from LDS
   auto stage_part = [&](int n0) {
@@ -585,14 +647,14 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
     if (MERGE) K4_MARK(1);
     return dirty;
   };
-  auto process_part = [&](bool dirty, uint32_t tile, int n0, uint32_t w0, uint32_t wcur) {
+  auto process_part = [&](bool dirty, uint32_t tile, int n0, uint32_t w0, const WReg<SLOT> &wcur) {
     if (MERGE) K4_MARK(2);
     if (dirty) {
       K4_COUNT(8);
 #ifdef YTTM_K4_PROF
       const unsigned long long p4_ = S.pt[4], p5_ = S.pt[5], p3_ = S.pt[3], p6_ = S.pt[6];
 #endif
-      process_tile<SLOT, MERGE>(W, A, ts, pt, db, rules, rule_mask, self_x, self_z, z_base, tile, n0, w0, wcur, S);
+      process_tile<SLOT, MERGE, LDSR>(W, A, ts, pt, db, rtab, self_x, self_z, z_base, tile, n0, w0, wcur, S);
 #ifdef YTTM_K4_PROF
       (void)p3_; (void)p4_; (void)p5_; (void)p6_;
 #endif
@@ -639,17 +701,18 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
     if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = ts.tile_word0[tile1]; }
     if (v0) {
       tile_fetch<SLOT>(r, ts, tile0, n0);
-      wq = ts.wcnt[w0 + lane];
+      wreg_load<SLOT>(wq, ts.wcnt, w0);
     }
     while (v0) {
       const bool dirty = stage_part(n0);
-      const uint32_t wcur = wq, tile_c = tile0, w_c = w0;
+      const WReg<SLOT> wcur = wq;
+      const uint32_t tile_c = tile0, w_c = w0;
       const int n_c = n0;
       // shift the pipe: tokens of the next tile, header of the one after, worklist entry of the third, a new index
       tile0 = tile1; n0 = n1; w0 = w1; v0 = v1;
       if (v0) {
         tile_fetch<SLOT>(r, ts, tile0, n0);
-        wq = ts.wcnt[w0 + lane];
+        wreg_load<SLOT>(wq, ts.wcnt, w0);
       }
       tile1 = tile2; v1 = v2;
       if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = ts.tile_word0[tile1]; }
@@ -664,7 +727,7 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
     if (t < NT) {
       load_headers(t_batch);
       tile_fetch<SLOT>(r, ts, __shfl(ht, 0), __shfl(hn, 0));
-      wq = ts.wcnt[__shfl(hw, 0) + lane];
+      wreg_load<SLOT>(wq, ts.wcnt, __shfl(hw, 0));
     }
     while (t < NT) {
       const int n0 = __shfl(hn, j);
@@ -679,10 +742,10 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
         t_batch = t_next;
         load_headers(t_batch);
       }
-      const uint32_t wcur = wq;
+      const WReg<SLOT> wcur = wq;
       if (t_next < NT) {
         tile_fetch<SLOT>(r, ts, __shfl(ht, j), __shfl(hn, j));
-        wq = ts.wcnt[__shfl(hw, j) + lane];
+        wreg_load<SLOT>(wq, ts.wcnt, __shfl(hw, j));
       }
       process_part(dirty, tile, n0, w0, wcur);
       t = t_next;
@@ -697,26 +760,48 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
       if (S.touched_tok) atomicAdd(&A.st[3], S.touched_tok);
     }
   }
+#ifdef YTTM_K4_PROF
+  if (MERGE) K4_MARK(7);   // end of own tile loop
+  __syncthreads();
+  if (MERGE) K4_MARK(11);  // waiting for the other waves of the workgroup
+#endif
+#ifdef YTTM_K4_PROF
+  {
+    unsigned long long nflush_ = 0;
+    for (int s_ = (int)threadIdx.x; s_ < AGG_SLOTS; s_ += WPB * 64) {
+      const unsigned long long k_ = A.key[s_];
+      if (k_ != PT_EMPTY && (long long)A.val[s_] != 0) {
+        nflush_++;
+        // time the three steps of pt_add for this slot separately
+        const unsigned long long ta_ = (unsigned long long)clock64();
+        unsigned long long i_ = mix64(k_) & pt.mask, kk_;
+        int probes_ = 0;
+        for (;;) { kk_ = ld_agent(pt.key_p(i_)); probes_++; if (kk_ == k_ || kk_ == PT_EMPTY) break; i_ = (i_ + 1) & pt.mask; }
+        const unsigned long long tb_ = (unsigned long long)clock64();
+        if (MERGE && lane == 0) { S.pt[13] += tb_ - ta_; S.pt[14] += (unsigned long long)probes_; S.pt[15]++; }
+      }
+    }
+    (void)nflush_;
+  }
+  if (MERGE) K4_MARK(10);
+#endif
   agg_flush<WPB * 64>(A, pt, db);
   __syncthreads();
 #ifdef YTTM_K4_PROF
-  if (MERGE && lane == 0 && SLOT == TILE_SLOT_A) {  // slowest wavefront of the launch vs the sum over wavefronts (tile loop only)
-    atomicMax(&stats[8 + 11], S.t_last - t_loop0);
-    atomicAdd(&stats[8 + 12], S.t_last - t_loop0);
-    atomicAdd(&stats[8 + 13], 1ull);
-  }
   if (MERGE) {
-    K4_MARK(7);
+    K4_MARK(12);  // flush
     if (lane == 0)
       for (int i = 0; i < 16; i++)
         if (S.pt[i]) atomicAdd(&stats[8 + i], S.pt[i]);
   }
 #endif
   if (threadIdx.x == 0) {
-    if (A.new_keys) atomicAdd(pt.n_keys, A.new_keys);
-    if (MERGE)
-      for (int i = 0; i < 4; i++)
-        if (A.st[i]) atomicAdd(&stats[i], A.st[i]);
+    if (MERGE) {
+      blk_add(stats, 4, A.new_keys);
+      for (int i = 0; i < 4; i++) blk_add(stats, i, A.st[i]);
+    } else if (A.new_keys) {
+      atomicAdd(pt.n_keys, A.new_keys);  // K3: one launch
+    }
   }
 }
 
@@ -783,7 +868,7 @@ __global__ __launch_bounds__(BLOCK) void k_filter(TileSet ts, const uint8_t *__r
     __syncthreads();
     for (unsigned int i = threadIdx.x; i < dn; i += BLOCK) worklist[dbase + i] = dl[i];
   }
-  if (threadIdx.x == 0 && scanned_blk) atomicAdd(&stats[2], scanned_blk);
+  if (threadIdx.x == 0) blk_add(stats, 2, scanned_blk);
 }
 
 // ------------------------------------------------------------------------------------------------- pair table kernels
@@ -851,16 +936,30 @@ __global__ __launch_bounds__(BLOCK) void k_cand_scan(PairTable pt, unsigned long
 __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *__restrict__ out,
                                                     unsigned int cap, unsigned int *__restrict__ n_out, unsigned long long *__restrict__ hist,
                                                     unsigned int *__restrict__ done_ctr, unsigned char *__restrict__ mailbox, unsigned int fast,
-                                                    uint32_t round_id, const unsigned long long *__restrict__ stats) {
+                                                    uint32_t round_id, unsigned long long *__restrict__ stats) {
   __shared__ unsigned int lh[CAND_BINS];
   __shared__ unsigned int live_blk;
   for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) lh[b] = 0;
   if (threadIdx.x == 0) live_blk = 0;
   const unsigned int hn_raw = *pt.hot_n;
   const unsigned int hn = hn_raw < pt.hot_cap ? hn_raw : pt.hot_cap;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    n_out[1] = *pt.n_keys;
-    n_out[2] = hn_raw;
+  if (blockIdx.x == 0 && threadIdx.x == 0) n_out[2] = hn_raw;
+  {  // every workgroup folds its share of the per-workgroup statistics rows (see fold_blk_stats) into the totals
+    const int per = (BLK_ROWS + (int)gridDim.x - 1) / (int)gridDim.x;
+    if ((int)threadIdx.x < per) {
+      const int b = (int)blockIdx.x * per + (int)threadIdx.x;
+      if (b < BLK_ROWS) {
+        unsigned long long *row = stats + BLK_BASE + 8 * b;
+        for (int j = 0; j < 5; j++) {
+          const unsigned long long v = row[j];
+          if (v) {
+            row[j] = 0;
+            if (j < 4) atomicAdd(&stats[j], v);
+            else atomicAdd(pt.n_keys, (unsigned int)v);
+          }
+        }
+      }
+    }
   }
   __syncthreads();
   unsigned int live = 0;
@@ -910,6 +1009,8 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
   __syncthreads();
   if (!is_last) return;
   __threadfence();
+  if (threadIdx.x == 0) n_out[1] = __hip_atomic_load(pt.n_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
   const unsigned int n = __hip_atomic_load(&n_out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned int *mb_hdr = reinterpret_cast<unsigned int *>(mailbox);
   unsigned long long *mb_hist = reinterpret_cast<unsigned long long *>(mailbox + 64);
@@ -965,6 +1066,8 @@ __global__ __launch_bounds__(BLOCK) void k_hot_rebuild(PairTable pt) {
     }
   }
 }
+
+__global__ __launch_bounds__(BLOCK) void k_fold_stats(unsigned long long *stats, unsigned int *n_keys) { fold_blk_stats(stats, n_keys); }
 
 __global__ __launch_bounds__(BLOCK) void k_pt_rehash(PairTable src, PairTable dst) {
   const unsigned long long n_slots = src.mask + 1;
@@ -1143,11 +1246,11 @@ static inline unsigned int tile_grid(unsigned int n_tiles, unsigned int wpb, uns
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st) {
   if (!ts.n_tiles) return;
   if (cls == 0)
-    hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
+    hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
                        (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned int *)nullptr, (unsigned long long *)nullptr);
   else
-    hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
+    hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
                        (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned int *)nullptr, (unsigned long long *)nullptr);
 }
@@ -1157,17 +1260,25 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
   if (!ts.n_tiles) return;
   // pass 1: which tiles have a merge-site candidate; pass 2: apply the batch to those
   unsigned int fg = (ts.n_tiles + 2 * NWAVES - 1) / (2 * NWAVES);
-  if (fg > 256 * 8) fg = 256 * 8;
+  if (fg > 256 * 5) fg = 256 * 5;  // 5 workgroups per CU are resident; each ends with one atomic on the worklist counter
   if (cls == 0) {
     hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, rules, rule_mask, self_x, worklist, work_n,
                        stats);
-    hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                       tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
+    if (rule_mask < APPLY_LDS_RULES)
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, true>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
+    else
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
   } else {
     hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, rules, rule_mask, self_x, worklist, work_n,
                        stats);
-    hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                       tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
+    if (rule_mask < APPLY_LDS_RULES)
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
+    else
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
   }
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
@@ -1179,7 +1290,7 @@ void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t 
 }
 void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
                      unsigned long long *hist, unsigned int *done_ctr, unsigned char *mailbox, unsigned int fast, uint32_t round_id,
-                     const unsigned long long *stats, hipStream_t st) {
+                     unsigned long long *stats, hipStream_t st) {
   hipLaunchKernelGGL(k_hot_scan, dim3(256), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id,
                      stats);
 }
@@ -1188,6 +1299,9 @@ void launch_hot_rebuild(const PairTable &pt, hipStream_t st) {
   unsigned long long b = (n_slots + BLOCK - 1) / BLOCK;
   if (b > 256 * 16) b = 256 * 16;
   hipLaunchKernelGGL(k_hot_rebuild, dim3((unsigned int)b), dim3(BLOCK), 0, st, pt);
+}
+void launch_fold_stats(unsigned long long *stats, unsigned int *n_keys, hipStream_t st) {
+  hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(BLOCK), 0, st, stats, n_keys);
 }
 void launch_pt_rehash(const PairTable &src, const PairTable &dst, hipStream_t st) {
   unsigned long long n_slots = src.mask + 1;
