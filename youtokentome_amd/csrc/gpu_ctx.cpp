@@ -577,6 +577,9 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
       if (cum != scanned_cum_) {  // a merge round ran since the last call: that is how many tokens its filters streamed
         live_tokens_last_ = cum - scanned_cum_;
         scanned_cum_ = cum;
+        const unsigned long long touched = *(const unsigned long long *)(h + 48);
+        touched_last_ = touched - touched_cum_;
+        touched_cum_ = touched;
       }
     }
     const unsigned int *hdr = (const unsigned int *)h;
@@ -692,7 +695,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   for (int ci = 0; ci < 2; ci++) {
     if (!cls_[ci].n_tiles) continue;
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
-                       cls_[ci].d_work_n, d_stats_, st_);
+                       cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, st_);
   }
   t_end(KT_MERGE, 0);
   merge_rounds++;

@@ -817,7 +817,7 @@ __global__ __launch_bounds__(BLOCK) void k_filter(TileSet ts, const uint8_t *__r
   __shared__ uint32_t fb[FLAG_LDS_IDS / 16];
   __shared__ unsigned long long rkeys[FILTER_LDS_KEYS];
   for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += BLOCK) fb[s] = flagbits[s];
-  const bool keys_in_lds = rule_mask < FILTER_LDS_KEYS;
+  const bool keys_in_lds = rules && rule_mask < FILTER_LDS_KEYS;  // rules == nullptr: flag test only (dense rounds)
   if (keys_in_lds)
     for (unsigned int s = threadIdx.x; s <= rule_mask; s += BLOCK) rkeys[s] = rules[s].key;
   const RuleProbe probe{keys_in_lds ? rkeys : nullptr, rules, rule_mask};
@@ -831,28 +831,44 @@ __global__ __launch_bounds__(BLOCK) void k_filter(TileSet ts, const uint8_t *__r
   const uint32_t stride = gridDim.x * NWAVES;
   const uint32_t NT = ts.n_tiles;
   unsigned long long scanned = 0;
-  // all waves of the workgroup run the same number of iterations, so the block-level flush below is convergent
-  const uint32_t first = blockIdx.x * NWAVES;
-  for (uint32_t tb = first; tb < NT; tb += 2 * stride) {
-    const uint32_t t = tb + (threadIdx.x >> 6);
-    const uint32_t t2 = t + stride;
-    bool d1 = false, d2 = false;
-    if (t < NT) {
-      const int n1 = (int)ts.tile_len[t];
-      const int n2 = t2 < NT ? (int)ts.tile_len[t2] : 0;
-      uint4 r1[SLOT / 256], r2[SLOT / 256];
-      tile_fetch<SLOT>(r1, ts, t, n1);
-      if (t2 < NT) tile_fetch<SLOT>(r2, ts, t2, n2);
-      d1 = reg_candidates<SLOT>(r1, n1, fb, tokflag, self_x, probe);
-      d2 = t2 < NT && reg_candidates<SLOT>(r2, n2, fb, tokflag, self_x, probe);
-      scanned += (unsigned long long)(n1 + n2);
-      if (lane == 0) {
-        if (d1) dl[atomicAdd(&dn, 1u)] = t;
-        if (d2) dl[atomicAdd(&dn, 1u)] = t2;
+  // KT tiles per wavefront and iteration are in flight together, and their lengths were loaded one iteration earlier:
+  // an iteration exposes ONE memory round trip for 4-8 KB per wave (the first version had two tiles and a dependent
+  // length load in front of every fetch, and streamed at 2 TB/s).  All waves of the workgroup run the same number of
+  // iterations, so the block-level flush below is convergent.
+  constexpr int KT = SLOT <= 512 ? 2 : 1;
+  const uint32_t first = blockIdx.x * NWAVES + (threadIdx.x >> 6);
+  int nn[KT];
+#pragma unroll
+  for (int k = 0; k < KT; k++) {
+    const uint32_t t = first + (uint32_t)k * stride;
+    nn[k] = t < NT ? (int)ts.tile_len[t] : 0;
+  }
+  for (uint32_t tb = blockIdx.x * NWAVES; tb < NT; tb += KT * stride) {
+    const uint32_t t0 = tb + (threadIdx.x >> 6);
+    uint4 r[KT][SLOT / 256];
+    int n[KT];
+#pragma unroll
+    for (int k = 0; k < KT; k++) {
+      n[k] = nn[k];
+      const uint32_t t = t0 + (uint32_t)k * stride;
+      if (t < NT) tile_fetch<SLOT>(r[k], ts, t, n[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < KT; k++) {  // lengths for the next iteration
+      const unsigned long long t = (unsigned long long)t0 + (unsigned long long)(KT + k) * stride;
+      nn[k] = t < NT ? (int)ts.tile_len[t] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < KT; k++) {
+      const uint32_t t = t0 + (uint32_t)k * stride;
+      if (t < NT) {
+        const bool d = reg_candidates<SLOT>(r[k], n[k], fb, tokflag, self_x, probe);
+        scanned += (unsigned long long)n[k];
+        if (d && lane == 0) dl[atomicAdd(&dn, 1u)] = t;
       }
     }
     __syncthreads();
-    if (dn > 1024 - 2 * NWAVES) {  // one global atomic per flush per workgroup
+    if (dn > 1024 - KT * NWAVES) {  // one global atomic per flush per workgroup
       if (threadIdx.x == 0) dbase = atomicAdd(work_n, dn);
       __syncthreads();
       for (unsigned int i = threadIdx.x; i < dn; i += BLOCK) worklist[dbase + i] = dl[i];
@@ -1018,6 +1034,8 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
   if (threadIdx.x < 4) mb_hdr[threadIdx.x] = __hip_atomic_load(&n_out[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 4)  // tokens streamed by the K4 filters so far: the host derives the tiles' fill from it (repack trigger)
     *reinterpret_cast<unsigned long long *>(mailbox + 40) = __hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 5)  // tiles that held a merge site so far: a dense round skips the filter's exact rule test
+    *reinterpret_cast<unsigned long long *>(mailbox + 48) = __hip_atomic_load(&stats[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) {
     mb_hist[b] = __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     hist[b] = 0;
@@ -1256,13 +1274,15 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
-                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, hipStream_t st) {
+                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, hipStream_t st) {
   if (!ts.n_tiles) return;
+  const RuleSlot *frules = exact_filter ? rules : nullptr;
   // pass 1: which tiles have a merge-site candidate; pass 2: apply the batch to those
-  unsigned int fg = (ts.n_tiles + 2 * NWAVES - 1) / (2 * NWAVES);
-  if (fg > 256 * 5) fg = 256 * 5;  // 5 workgroups per CU are resident; each ends with one atomic on the worklist counter
+  const unsigned int kt = cls == 0 ? 2 : 1;  // tiles per wavefront and iteration (k_filter: KT)
+  unsigned int fg = (ts.n_tiles + kt * NWAVES - 1) / (kt * NWAVES);
+  if (fg > 256 * 5) fg = 256 * 5;  // 5 workgroups per CU are resident; each ends with one atomic on the worklist counter (measured: 1280 beats 2048)
   if (cls == 0) {
-    hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, rules, rule_mask, self_x, worklist, work_n,
+    hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, true>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
@@ -1271,7 +1291,7 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
                          tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
   } else {
-    hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, rules, rule_mask, self_x, worklist, work_n,
+    hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
