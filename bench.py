@@ -145,21 +145,24 @@ def main():
     # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, separate
     # --pmc runs of this same command; tools/pmc_summary.py) -- only quoted for the exact workload they were taken on
     traffic = {}
-    pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_hbm_1gb_final.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r1_1gb_final_pmc_hbm.json")  # written by tools/profile_round.sh
     if os.path.exists(pmc_file) and args.size_mb == 1000 and args.corpus == "abcd" and args.vocab == 32000 and n_gpus == 1:
         pm = json.load(open(pmc_file))
-        fam = {"char_hist": ["k_scan_bytes<0>"], "segments": ["k_scan_bytes<1>"], "dedup": ["k2b_insert_words"],
-               "pair_count": ["k_tiles<1024, 4, false>"], "merge_apply": ["k_filter<1024>", "k_tiles<1024, 4, true>"],
-               "cand_scan": ["k_cand_scan"]}
-        for name, ks in fam.items():
-            if all(k in pm for k in ks):
-                traffic[name] = sum(pm[k]["traffic_bytes_per_launch"] for k in ks)
+        # kernel families as the trainer times them; a family's traffic per launch = bytes of all its kernels / its launches
+        fam = {"char_hist": ("k_scan_bytes<0>",), "segments": ("k_scan_bytes<1>",), "dedup": ("k2b_insert_words",),
+               "pair_count": ("k_tiles<512, 4, false", "k_tiles<4096, 1, false"),
+               "merge_apply": ("k_filter<", "k_tiles<512, 4, true", "k_tiles<4096, 1, true"), "cand_scan": ("k_hot_scan", "k_cand_scan")}
+        for name, prefixes in fam.items():
+            ks = [k for k in pm if k.startswith(prefixes)]
+            if ks and name in kern:
+                total = sum(pm[k]["traffic_bytes_per_launch"] * pm[k]["launches"] for k in ks)
+                traffic[name] = round(total / max(1, max(pm[k]["launches"] for k in ks)))
     dom = max(kern, key=lambda n: kern[n]["ms_total"]) if kern else None
     roofline = None
     if dom:
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic.get(dom),
-                    "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r1_pmc_hbm_1gb_final.json)",
+                    "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r1_1gb_final_pmc_hbm.json)",
                     "algorithmic_bytes_per_launch": round(kern[dom]["algorithmic_GB"] * 1e9 / kern[dom]["launches"]),
                     "avg_launch_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"]}
     roofline_pc = None
