@@ -221,6 +221,23 @@ def check_encode_mixed_shapes(n_sent=150, seed=11, model="readme_small"):
     check_encode_vs_oracle(model_path, sents, flags=((0, 0, 0), (1, 1, 1)))
 
 
+def check_very_long_words(tmp_path, lengths=(2047, 2048, 2049, 3000, 5000)):
+    """Words beyond the LDS tile kernels (> 2047 chars) take the workgroup-per-tile path in HBM (k_giant.hip): random text,
+    runs of one letter, periodic text (xyxy... merges into runs of a new token), repeated long words (weight > 1)."""
+    import random
+    rng = random.Random(17)
+    words = []
+    for n in lengths:
+        words.append("".join(rng.choice("abc") for _ in range(n)))
+    words.append("a" * (lengths[-1] // 2 + 1))
+    words.append("ab" * (lengths[0] + 7))
+    words.append(("abc" * (lengths[1] // 3 + 5))[: lengths[1] + 11])
+    text = (" ".join(words) + "\n") * 2 + " ".join(words[:2]) + "\n" + gen.readme_corpus(40, 60).decode()
+    model = check_train_vs_oracle(text.encode(), 120, tmp_path, tag="giant")
+    assert model
+    check_encode_vs_oracle(model, [" ".join(words[:3]), words[-1], "a b"], flags=((0, 0, 0), (1, 1, 1)))
+
+
 def check_dropout_extremes(model_path, sentences):
     """p -> 0 must reproduce the deterministic encoder; p = 1 must leave every word at character level
     (DropoutQueue skips every event, bpe.cpp:1430-1437)."""

@@ -114,13 +114,8 @@ def test_long_words_and_long_sentences(tmp_path):
     S.check_encode_vs_oracle(model, sents)
 
 
-def test_word_too_long_is_a_loud_error(tmp_path):
-    import youtokentome_amd as yttm
-    p = str(tmp_path / "long.txt")
-    open(p, "w").write("a" * 5000 + " b c\n")
-    with pytest.raises(ValueError) as e:
-        yttm.BPE.train(p, str(tmp_path / "long.model"), 50)
-    assert "longer than" in str(e.value)
+def test_very_long_words(tmp_path):
+    S.check_very_long_words(tmp_path, lengths=(2047, 2048, 2049, 5000, 20000, 70000))
 
 
 @pytest.mark.skipif(not refbin.available("det"), reason="oracle/_ref not present")

@@ -80,6 +80,10 @@ def test_hot_list_rebuilds(tmp_path, monkeypatch):
         S.check_train_vs_oracle(text, 150, tmp_path, tag=f"hot{target}")
 
 
+def test_very_long_words(tmp_path):
+    S.check_very_long_words(tmp_path)
+
+
 def test_config_errors(tmp_path):
     for kw in [dict(coverage=0.0), dict(ids=(0, 300, 2, 3)), dict(ids=(0, 1, 1, 3)), dict(vocab=5)]:
         S.check_train_vs_oracle(b"aaa bbb abab", kw.get("vocab", 50), tmp_path, kw.get("coverage", 1.0), kw.get("ids", (0, 1, 2, 3)), tag="e")

@@ -71,7 +71,7 @@ GpuCtx::~GpuCtx() {
   (void)hipStreamSynchronize(st_);
   for (auto &e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_); DFREE(d_flagbits_);
-  free_class(cls_[0]); free_class(cls_[1]);
+  free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_);
   if (db_.recs) (void)hipFree(db_.recs);
   if (db_.n) (void)hipFree(db_.n);
@@ -197,7 +197,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
     HIP_CHECK(hipMemcpyAsync(d_cpmap_, cpmap.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, st_));
     sync();
   }
-  free_class(cls_[0]); free_class(cls_[1]);
+  free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   cls_[0].nom = TILE_NOM_A; cls_[0].slot = TILE_SLOT_A;
   cls_[1].nom = TILE_NOM_B; cls_[1].slot = TILE_SLOT_B;
   n_alpha_ = n_alpha;
@@ -228,47 +228,55 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   launch_fill_u64(ht_key, PT_EMPTY, ht_cap, st_);
   HIP_CHECK(hipMemsetAsync(ht_cnt, 0, ht_cap * 8, st_));
   unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
-  HIP_CHECK(hipMemsetAsync(d_status, 0, 16, st_));
+  HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
   t_begin(KT_DEDUP);
   launch_insert_words(d_text_, n_text_, d_cpmap_, d_seg, n_segs, ht_key, ht_cnt, ht_len, ht_cap - 1, d_status, st_);
   t_end(KT_DEDUP, n_text_ + 8 * n_segs);
-  unsigned int h_status[4] = {0, 0, 0, 0};
-  HIP_CHECK(hipMemcpyAsync(h_status, d_status, 16, hipMemcpyDeviceToHost, st_));
+  unsigned int h_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
   sync();
   DFREE(d_seg);
-  if (h_status[1] & 1u) {
+  if (h_status[5] >= (1u << 28)) {
     DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len);
-    throw GpuError{"a word longer than " + std::to_string(MAX_WORD_TOKENS - 1) + " characters is not supported by the tile kernels yet"};
+    throw GpuError{"a word of 2^28 or more characters is not supported"};
   }
-  const unsigned int U = h_status[0], UB = h_status[2], UA = U - UB;
+  const unsigned int U = h_status[0], UC = h_status[4], UB = h_status[2] - UC, UA = U - UB - UC;
+  if (UC) {  // very long words: same layout, slot sized by the longest of them, one workgroup per tile (k_giant.hip)
+    cls_[2].nom = h_status[5];
+    cls_[2].slot = (2 * h_status[5] + 3u) & ~3u;
+  }
   // A tile holds whole words in a fixed slot and only ever shrinks, so the slack a slot needs is one word: pack the
   // slots as full as the longest word allows (HBM pages are then read densely and there are fewer tiles to visit).
   if (h_status[3] > 0 && h_status[3] < (unsigned int)TILE_NOM_A) cls_[0].nom = (unsigned int)TILE_SLOT_A - h_status[3];
   n_unique = U;
   if (U == 0) { DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len); return; }
-  unsigned long long *posA = dmalloc<unsigned long long>(UA), *posB = dmalloc<unsigned long long>(UB);
-  uint32_t *lenA = dmalloc<uint32_t>(UA), *lenB = dmalloc<uint32_t>(UB);
+  unsigned long long *posA = dmalloc<unsigned long long>(UA), *posB = dmalloc<unsigned long long>(UB), *posC = dmalloc<unsigned long long>(UC);
+  uint32_t *lenA = dmalloc<uint32_t>(UA), *lenB = dmalloc<uint32_t>(UB), *lenC = dmalloc<uint32_t>(UC);
+  cls_[2].d_wcnt = dmalloc<uint32_t>(UC + 256);
   cls_[0].d_wcnt = dmalloc<uint32_t>(UA + 256);  // padding: k_tiles loads SLOT/2 frequencies from a tile's first word unconditionally
   cls_[1].d_wcnt = dmalloc<uint32_t>(UB + 256);
   unsigned int *d_cursor = (unsigned int *)(d_counters_ + 32);
-  HIP_CHECK(hipMemsetAsync(d_cursor, 0, 8, st_));
+  HIP_CHECK(hipMemsetAsync(d_cursor, 0, 16, st_));
   t_begin(KT_BUILD);
-  launch_compact_words(ht_key, ht_cnt, ht_len, ht_cap, posA, cls_[0].d_wcnt, lenA, posB, cls_[1].d_wcnt, lenB, d_cursor, d_status, st_);
+  launch_compact_words(ht_key, ht_cnt, ht_len, ht_cap, posA, cls_[0].d_wcnt, lenA, posB, cls_[1].d_wcnt, lenB, posC, cls_[2].d_wcnt, lenC, d_cursor,
+                       d_status, st_);
   HIP_CHECK(hipMemcpyAsync(h_status, d_status, 16, hipMemcpyDeviceToHost, st_));
   sync();
   DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len);
-  if (h_status[1] & 2u) { DFREE(posA); DFREE(posB); DFREE(lenA); DFREE(lenB); throw GpuError{"a word occurs >= 2^32 times (uint32 word weights)"}; }
+  if (h_status[1] & 2u) { DFREE(posA); DFREE(posB); DFREE(lenA); DFREE(lenB); DFREE(posC); DFREE(lenC); throw GpuError{"a word occurs >= 2^32 times (uint32 word weights)"}; }
   build_class(0, posA, lenA, UA, space_id);
   build_class(1, posB, lenB, UB, space_id);
-  t_end(KT_BUILD, n_text_ / 8 + 4 * (cls_[0].n_tokens0 + cls_[1].n_tokens0) + 16ull * U);
+  build_class(2, posC, lenC, UC, space_id);
+  if (cls_[2].n_tiles) cls_[2].d_scratch = dmalloc<uint32_t>((size_t)cls_[2].n_tiles * 4 * cls_[2].slot);
+  t_end(KT_BUILD, n_text_ / 8 + 4 * (cls_[0].n_tokens0 + cls_[1].n_tokens0 + cls_[2].n_tokens0) + 16ull * U);
   sync();
-  DFREE(posA); DFREE(posB); DFREE(lenA); DFREE(lenB);
-  n_tokens0 = cls_[0].n_tokens0 + cls_[1].n_tokens0;
-  n_tiles = cls_[0].n_tiles + cls_[1].n_tiles;
+  DFREE(posA); DFREE(posB); DFREE(lenA); DFREE(lenB); DFREE(posC); DFREE(lenC);
+  n_tokens0 = cls_[0].n_tokens0 + cls_[1].n_tokens0 + cls_[2].n_tokens0;
+  n_tiles = cls_[0].n_tiles + cls_[1].n_tiles + cls_[2].n_tiles;
 }
 
 void GpuCtx::free_class(WordClass &c) {
-  DFREE(c.d_tok); DFREE(c.d_tile_len); DFREE(c.d_tile_word0); DFREE(c.d_wcnt); DFREE(c.d_worklist); DFREE(c.d_work_n);
+  DFREE(c.d_tok); DFREE(c.d_tile_len); DFREE(c.d_tile_word0); DFREE(c.d_wcnt); DFREE(c.d_worklist); DFREE(c.d_work_n); DFREE(c.d_scratch);
   c.ts = TileSet{};
   c.n_unique = c.n_tokens0 = 0;
   c.n_tiles = 0;
@@ -313,7 +321,7 @@ void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, u
 void GpuCtx::download_word_table(std::vector<uint32_t> &tok, std::vector<unsigned long long> &off, std::vector<uint32_t> &cnt) {
   tok.clear(); off.clear(); cnt.clear();
   off.push_back(0);
-  for (int ci = 0; ci < 2; ci++) {
+  for (int ci = 0; ci < 3; ci++) {
     WordClass &c = cls_[ci];
     if (!c.n_tiles) continue;
     std::vector<uint32_t> all((size_t)c.n_tiles * c.slot), tl(c.n_tiles), wc(c.n_unique);
@@ -360,7 +368,7 @@ void GpuCtx::maybe_repack(int ci) {
   c.d_tok = new_tok; c.d_tile_len = new_len; c.d_tile_word0 = new_word0;
   c.n_tiles = n_new;
   c.ts.tok = new_tok; c.ts.tile_len = new_len; c.ts.tile_word0 = new_word0; c.ts.n_tiles = n_new;
-  n_tiles = cls_[0].n_tiles + cls_[1].n_tiles;
+  n_tiles = cls_[0].n_tiles + cls_[1].n_tiles + cls_[2].n_tiles;
   repacks++;
 }
 
@@ -453,6 +461,7 @@ void GpuCtx::pair_count() {
   ensure_table_capacity(bound);
   t_begin(KT_PAIR_COUNT);
   for (int ci = 0; ci < 2; ci++) launch_pair_count(ci, cls_[ci].ts, pt_, db_, st_);
+  launch_giant(false, cls_[2].ts, cls_[2].slot, pt_, db_, nullptr, 0, 0xffffffffu, 0, cls_[2].d_scratch, d_stats_, st_);
   t_end(KT_PAIR_COUNT, 4 * n_tokens0 + 8 * n_unique);
   unsigned int nk = 0;
   HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
@@ -697,6 +706,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
                        cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, st_);
   }
+  launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
   t_end(KT_MERGE, 0);
   merge_rounds++;
   if (getenv("YTTM_TRACE_ROUNDS")) {  // tuning aid: cumulative device stats after every round (adds a sync)

@@ -113,11 +113,12 @@ class GpuCtx {
   struct WordClass {
     TileSet ts{};
     uint32_t *d_tok = nullptr, *d_tile_len = nullptr, *d_tile_word0 = nullptr, *d_wcnt = nullptr, *d_worklist = nullptr;
+    uint32_t *d_scratch = nullptr;  // class C only (k_giant.hip)
     unsigned int *d_work_n = nullptr;
     unsigned long long n_unique = 0, n_tokens0 = 0;
     unsigned int n_tiles = 0, nom = 0, slot = 0;
   };
-  WordClass cls_[2];
+  WordClass cls_[3];  // A: words <= TILE_NOM_A tokens, B: <= TILE_NOM_B, C: longer (one workgroup per tile, k_giant.hip)
   void free_class(WordClass &c);
   void build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, unsigned int U, uint32_t space_id);
   void maybe_repack(int ci);

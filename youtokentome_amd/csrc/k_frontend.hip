@@ -251,6 +251,10 @@ __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsi
         atomicAdd(&ht_cnt[i], count);
         atomicAdd(&status[0], 1u);
         if (len_tokens > (uint32_t)TILE_NOM_A) atomicAdd(&status[2], 1u);
+        if (len_tokens > (uint32_t)TILE_NOM_B) {  // class C (very long words): count and longest
+          atomicAdd(&status[4], 1u);
+          atomicMax(&status[5], len_tokens);
+        }
         return;
       }
     }
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
                                                           const unsigned long long *__restrict__ seg_pos, unsigned long long n_segs,
                                                           unsigned long long *__restrict__ ht_key, unsigned long long *__restrict__ ht_cnt,
                                                           uint32_t *__restrict__ ht_len, unsigned long long ht_mask,
-                                                          unsigned int *__restrict__ status /* [0]=n_unique [1]=flags [2]=n_unique of class B */) {
+                                                          unsigned int *__restrict__ status /* [0]=n_unique [1]=flags [2]=n_unique of classes B+C [3]=longest class-A word [4]=n_unique of class C [5]=longest word */) {
   __shared__ unsigned long long l_key[WL_SLOTS];   // (tag:24 | pos:40) or PT_EMPTY
   __shared__ unsigned long long l_hash[WL_SLOTS];  // full hash of the word (for the flush)
   __shared__ unsigned int l_cnt[WL_SLOTS];
@@ -287,7 +291,6 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
     unsigned long long h;
     const uint32_t L = seg_scan(text, n, cpmap, pos, &h);
     if (L == 0) continue;  // segment made only of dropped chars: no word (bpe.cpp:357-380 deletes them first)
-    if (L + 1 > (uint32_t)MAX_WORD_TOKENS) { atomicOr(&status[1], 1u); continue; }
     const unsigned long long tag = h >> 40;
     if (L + 1 <= (uint32_t)TILE_NOM_A && L + 1 > l_maxlen) atomicMax(&l_maxlen, L + 1);
     bool done = false;
@@ -332,7 +335,8 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const unsigned long l
                                                            unsigned long long *__restrict__ posA, uint32_t *__restrict__ cntA,
                                                            uint32_t *__restrict__ lenA, unsigned long long *__restrict__ posB,
                                                            uint32_t *__restrict__ cntB, uint32_t *__restrict__ lenB,
-                                                           unsigned int *__restrict__ cursor /* [0]=A [1]=B */,
+                                                           unsigned long long *__restrict__ posC, uint32_t *__restrict__ cntC,
+                                                           uint32_t *__restrict__ lenC, unsigned int *__restrict__ cursor /* [0]=A [1]=B [2]=C */,
                                                            unsigned int *__restrict__ status) {
   __shared__ uint32_t scan_lds[NWAVES];
   __shared__ unsigned int blk_base;
@@ -351,7 +355,10 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const unsigned long l
     if (has) {
       unsigned long long c = ht_cnt[i];
       if (c > 0xffffffffull) atomicOr(&status[1], 2u);  // a word seen >= 2^32 times: weights are uint32
-      if (isB) {
+      if (isB && len > (uint32_t)TILE_NOM_B) {
+        unsigned int o = atomicAdd(&cursor[2], 1u);
+        posC[o] = k & WH_POS_MASK; cntC[o] = (uint32_t)c; lenC[o] = len;
+      } else if (isB) {
         unsigned int o = atomicAdd(&cursor[1], 1u);
         posB[o] = k & WH_POS_MASK; cntB[o] = (uint32_t)c; lenB[o] = len;
       } else {
@@ -515,10 +522,11 @@ void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32
 }
 void launch_compact_words(const unsigned long long *ht_key, const unsigned long long *ht_cnt, const uint32_t *ht_len,
                           unsigned long long n_slots, unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB,
-                          uint32_t *cntB, uint32_t *lenB, unsigned int *cursor, unsigned int *status, hipStream_t st) {
+                          uint32_t *cntB, uint32_t *lenB, unsigned long long *posC, uint32_t *cntC, uint32_t *lenC, unsigned int *cursor,
+                          unsigned int *status, hipStream_t st) {
   unsigned int g = grid_for(n_slots, BLOCK, 256 * 16);
   hipLaunchKernelGGL(k2c_compact_words, dim3(g), dim3(BLOCK), 0, st, ht_key, ht_cnt, ht_len, n_slots, posA, cntA, lenA, posB, cntB, lenB,
-                     cursor, status);
+                     posC, cntC, lenC, cursor, status);
 }
 void launch_exclusive_scan(const uint32_t *in, unsigned long long n, unsigned long long *out, unsigned long long *block_sums,
                            unsigned long long *total_out, hipStream_t st) {

@@ -31,7 +31,7 @@ void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32
                          unsigned long long ht_mask, unsigned int *status, hipStream_t st);
 void launch_compact_words(const unsigned long long *ht_key, const unsigned long long *ht_cnt, const uint32_t *ht_len,
                           unsigned long long n_slots, unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB,
-                          uint32_t *cntB, uint32_t *lenB, unsigned int *cursor, unsigned int *status, hipStream_t st);
+                          uint32_t *cntB, uint32_t *lenB, unsigned long long *posC, uint32_t *cntC, uint32_t *lenC, unsigned int *cursor, unsigned int *status, hipStream_t st);
 void launch_exclusive_scan(const uint32_t *in, unsigned long long n, unsigned long long *out, unsigned long long *block_sums,
                            unsigned long long *total_out, hipStream_t st);
 unsigned long long scan_scratch_blocks(unsigned long long n);
@@ -61,6 +61,10 @@ constexpr int STATS_WORDS = 32 + 8 * 1536;  // totals + one row per workgroup (k
 void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, const uint32_t *upd, unsigned int n_upd,
                         uint8_t *tokflag, uint32_t *flagbits, unsigned int *work_n_a, unsigned int *work_n_b, hipStream_t st);
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st);
+// class C (k_giant.hip): K3 (merge=false) / K4 (merge=true) for tiles of words longer than TILE_NOM_B tokens; scratch = 4*slot
+// uint32 per tile
+void launch_giant(bool merge, const TileSet &ts, unsigned int slot, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules,
+                  unsigned int rule_mask, uint32_t self_x, uint32_t self_z, uint32_t *scratch, unsigned long long *stats, hipStream_t st);
 void launch_pt_clear(const PairTable &pt, hipStream_t st);
 void launch_pt_rehash(const PairTable &src, const PairTable &dst, hipStream_t st);
 void launch_pt_zero(const PairTable &pt, const RuleSlot *rules, unsigned int n_slots, unsigned long long self_key, hipStream_t st);
