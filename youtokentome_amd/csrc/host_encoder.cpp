@@ -185,7 +185,7 @@ Status BaseEncoder::encode_device(const void *d_bytes, const void *d_offsets, un
     d.grow(d.d_counts, d.cap_counts, (size_t)n_sent);
     d.grow(d.d_out_off, d.cap_out_off, (size_t)n_sent + 1);
     d.grow(d.d_scan_tmp, d.cap_scan_tmp, (size_t)scan_scratch_blocks(n_sent));
-    unsigned int max_blocks = 256 * 2;  // 2 workgroups of 8 waves per CU (80 KB LDS each)
+    unsigned int max_blocks = 256 * 2;  // 2 workgroups per CU (80 KB LDS each)
     const unsigned long long tok_cap = std::max<unsigned long long>(ENC_LDS_TOKENS, 2 * max_sentence_bytes + 2);  // tokens per sentence
     unsigned long long stride = 0, drop_stride = 0;
     {

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
       d.wsl = drop.wsl + gw * 7 * drop_stride;
       d.ev = reinterpret_cast<unsigned long long *>(drop.wsl + gw * 7 * drop_stride + drop_stride);
     }
-    if (2 * nbytes + 2 <= (unsigned long long)ENC_WCAP) {
+    if (nbytes + 1 <= (unsigned long long)ENC_WCAP) {
       LdsArr a{lds[wave][0]}, b{lds[wave][1]}, c{lds[wave][2]};
       encode_wave(m, bloom, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx], d, sidx);
     } else {
