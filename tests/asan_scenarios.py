@@ -1,0 +1,24 @@
+"""Run by tests/test_sim_asan.py in a subprocess with the AddressSanitizer build of the emulated product sources."""
+import pathlib
+import random
+import sys
+import tempfile
+
+sys.path.insert(0, str(pathlib.Path(__file__).parent))
+sys.path.insert(0, str(pathlib.Path(__file__).parent.parent))
+import gen  # noqa: E402
+import stage_checks as S  # noqa: E402
+
+tmp = pathlib.Path(tempfile.mkdtemp())
+for name in ("readme_small", "runs", "mix_cov"):
+    S.check_golden_train(name, tmp)
+for name in S.golden_encode_names()[:3]:
+    S.check_golden_encode(name)
+rng = random.Random(3)
+words = ["".join(rng.choice("abc") for _ in range(n)) for n in (2046, 1500, 1024, 700, 300, 257, 65, 64, 63, 1)]
+text = (" ".join(words) + "\n") * 3 + gen.readme_corpus(50, 80).decode()
+model = S.check_train_vs_oracle(text.encode(), 200, tmp, tag="lw")
+S.check_encode_vs_oracle(model, [" ".join(words), "ab" * 700, "a"], flags=((0, 0, 0), (1, 1, 1)))
+S.check_very_long_words(tmp, lengths=(2047, 2048, 2049, 3000))
+S.check_encode_mixed_shapes(n_sent=60)
+print("ASAN_SCENARIOS_OK")

@@ -704,7 +704,8 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   for (int ci = 0; ci < 2; ci++) {
     if (!cls_[ci].n_tiles) continue;
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
-                       cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, st_);
+                       cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles,
+                       /*dense=*/touched_last_ != (~0ull >> 2) && touched_last_ * 10 >= (unsigned long long)n_tiles * 9, st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
   t_end(KT_MERGE, 0);

@@ -629,7 +629,7 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
     if (tj < NT) {
       ht = worklist ? worklist[tj] : (uint32_t)tj;
       hn = (int)ts.tile_len[ht];
-      hw = ts.tile_word0[ht];
+      hw = hn ? ts.tile_word0[ht] : 0u;  // an empty tile (after a repack) has no first word
     }
   };
   uint4 r[SLOT / 256];
@@ -691,14 +691,14 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
     issue_index();
     v2 = i2 < NT;
     if (v2) tile2 = worklist[i2];
-    if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = ts.tile_word0[tile1]; }
+    if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = n1 ? ts.tile_word0[tile1] : 0u; }
     tile0 = tile1; n0 = n1; w0 = w1; v0 = v1;
     tile1 = tile2; v1 = v2;
     i2 = take_index();
     issue_index();
     v2 = i2 < NT;
     if (v2) tile2 = worklist[i2];
-    if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = ts.tile_word0[tile1]; }
+    if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = n1 ? ts.tile_word0[tile1] : 0u; }
     if (v0) {
       tile_fetch<SLOT>(r, ts, tile0, n0);
       wreg_load<SLOT>(wq, ts.wcnt, w0);
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
         wreg_load<SLOT>(wq, ts.wcnt, w0);
       }
       tile1 = tile2; v1 = v2;
-      if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = ts.tile_word0[tile1]; }
+      if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = n1 ? ts.tile_word0[tile1] : 0u; }
       i2 = take_index();
       issue_index();
       v2 = v1 && i2 < NT;  // indices of a wave only grow: nothing valid follows an invalid one
@@ -1274,15 +1274,18 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
-                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, hipStream_t st) {
+                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, hipStream_t st) {
   if (!ts.n_tiles) return;
   const RuleSlot *frules = exact_filter ? rules : nullptr;
+  // dense round (nearly every tile held a site last round): the filter pass would keep everything -- the apply kernel
+  // takes all tiles and dismisses the few clean ones itself
+  if (dense) worklist = nullptr;
   // pass 1: which tiles have a merge-site candidate; pass 2: apply the batch to those
   const unsigned int kt = cls == 0 ? 2 : 1;  // tiles per wavefront and iteration (k_filter: KT)
   unsigned int fg = (ts.n_tiles + kt * NWAVES - 1) / (kt * NWAVES);
   if (fg > 256 * 5) fg = 256 * 5;  // 5 workgroups per CU are resident; each ends with one atomic on the worklist counter (measured: 1280 beats 2048)
   if (cls == 0) {
-    hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
+    if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, true>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
@@ -1291,7 +1294,7 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
                          tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
   } else {
-    hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
+    if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
