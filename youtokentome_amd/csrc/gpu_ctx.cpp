@@ -486,6 +486,7 @@ uint32_t GpuCtx::scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vec
     if (hist) memset(hist, 0, CAND_BINS * 8);
     return 0;
   }
+  flush_pending_zero();
   launch_fold_stats(d_stats_, pt_.n_keys, st_);
   HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, st_));
   if (hist) HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, st_));
@@ -563,7 +564,9 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     unsigned char *h = (unsigned char *)h_pin_;
     const uint32_t round_id = ++mail_round_;
     t_begin(KT_CAND);
-    launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_, st_);
+    launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_,
+                    pending_zero_ ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, st_);
+    pending_zero_ = false;
     t_end(KT_CAND, 20ull * listed_last_);
     {
       // the kernel's last workgroup writes header + histogram + first candidates into the pinned mailbox and then the
@@ -623,6 +626,7 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
 
 void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned long long *outv) {
   if (!n) return;
+  flush_pending_zero();
   unsigned long long *d_k = dmalloc<unsigned long long>(n), *d_o = dmalloc<unsigned long long>(n);
   HIP_CHECK(hipMemcpyAsync(d_k, keys, (size_t)n * 8, hipMemcpyHostToDevice, st_));
   launch_pt_query(pt_, d_k, n, d_o, st_);
@@ -748,7 +752,12 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   }
   // single GPU: no sync here -- the candidate filter that always follows reads n_keys back together with its results
   // (its sync also makes the pinned rule staging reusable for the next round)
-  // every occurrence of the batch's pairs has been merged (on every rank): their counts are exactly zero
+  // every occurrence of the batch's pairs has been merged (on every rank): their counts are exactly zero.  The candidate
+  // filter that follows zeroes them while it reads the hot list; any other reader goes through flush_pending_zero().
+}
+
+void GpuCtx::flush_pending_zero() {
+  if (!pending_zero_) return;
   launch_pt_zero(pt_, d_rules_, zero_cap_, zero_self_key_, st_);
   pending_zero_ = false;
 }

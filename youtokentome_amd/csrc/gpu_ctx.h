@@ -124,6 +124,7 @@ class GpuCtx {
   void maybe_repack(int ci);
   unsigned long long rounds_since_check_ = 0;
   bool pending_zero_ = false;
+  void flush_pending_zero();
   unsigned int zero_cap_ = 0;
   unsigned long long zero_self_key_ = 0;
   // pair table

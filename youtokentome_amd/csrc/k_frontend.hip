@@ -249,7 +249,7 @@ __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsi
       if (cur == PT_EMPTY) {
         ht_len[i] = len_tokens;  // read only by later kernels
         atomicAdd(&ht_cnt[i], count);
-        atomicAdd(&status[0], 1u);
+        atomicAdd(&status[0], 1u);  // `status` is the workgroup's LDS copy (k2b_insert_words): 1.6e7 bumps of one HBM counter cost ~2 ns each
         if (len_tokens > (uint32_t)TILE_NOM_A) atomicAdd(&status[2], 1u);
         if (len_tokens > (uint32_t)TILE_NOM_B) {  // class C (very long words): count and longest
           atomicAdd(&status[4], 1u);
@@ -281,7 +281,9 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
   __shared__ unsigned int l_cnt[WL_SLOTS];
   __shared__ unsigned int l_len[WL_SLOTS];
   __shared__ unsigned int l_maxlen;  // longest class-A word seen by this workgroup (one global atomicMax at the end)
+  __shared__ unsigned int l_status[8];  // this workgroup's share of status[] (added once at the end)
   for (int i = (int)threadIdx.x; i < WL_SLOTS; i += BLOCK) { l_key[i] = PT_EMPTY; l_cnt[i] = 0; }
+  if (threadIdx.x < 8) l_status[threadIdx.x] = 0;
   if (threadIdx.x == 0) l_maxlen = 0;
   __syncthreads();
   unsigned long long s = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -316,15 +318,22 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
         j = (j + 1) & (WL_SLOTS - 1);
       }
     }
-    if (!done) word_insert_global(text, n, cpmap, h, pos, L + 1, 1ull, ht_key, ht_cnt, ht_len, ht_mask, status);
+    if (!done) word_insert_global(text, n, cpmap, h, pos, L + 1, 1ull, ht_key, ht_cnt, ht_len, ht_mask, l_status);
   }
   __syncthreads();
   for (int i = (int)threadIdx.x; i < WL_SLOTS; i += BLOCK) {
     const unsigned long long k = l_key[i];
     if (k != PT_EMPTY)
-      word_insert_global(text, n, cpmap, l_hash[i], k & WH_POS_MASK, l_len[i], (unsigned long long)l_cnt[i], ht_key, ht_cnt, ht_len, ht_mask, status);
+      word_insert_global(text, n, cpmap, l_hash[i], k & WH_POS_MASK, l_len[i], (unsigned long long)l_cnt[i], ht_key, ht_cnt, ht_len, ht_mask, l_status);
   }
-  if (threadIdx.x == 0 && l_maxlen) atomicMax(&status[3], l_maxlen);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (l_maxlen) atomicMax(&status[3], l_maxlen);
+    if (l_status[0]) atomicAdd(&status[0], l_status[0]);
+    if (l_status[2]) atomicAdd(&status[2], l_status[2]);
+    if (l_status[4]) atomicAdd(&status[4], l_status[4]);
+    if (l_status[5]) atomicMax(&status[5], l_status[5]);
+  }
 }
 
 // Compact occupied hash slots into the unique-word arrays of the two tile classes (short words: block-aggregated
@@ -338,32 +347,41 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const unsigned long l
                                                            unsigned long long *__restrict__ posC, uint32_t *__restrict__ cntC,
                                                            uint32_t *__restrict__ lenC, unsigned int *__restrict__ cursor /* [0]=A [1]=B [2]=C */,
                                                            unsigned int *__restrict__ status) {
+  // The table is sized by the number of word OCCURRENCES and is mostly empty (6 % occupied at C2): this is a 2 GB stream of
+  // keys.  A workgroup takes CH consecutive slots, counts its class-A words, reserves their places with ONE atomic (a
+  // cursor bumped once per 256 slots serialised at ~11 ns per atomic: 12 ms) and writes them in a second pass over the
+  // same, now cached, slots.
+  constexpr unsigned long long CH = 64 * BLOCK;
   __shared__ uint32_t scan_lds[NWAVES];
   __shared__ unsigned int blk_base;
-  const unsigned long long n_iter = (n_slots + BLOCK - 1) / BLOCK;
-  for (unsigned long long it = blockIdx.x; it < n_iter; it += gridDim.x) {
-    unsigned long long i = it * BLOCK + threadIdx.x;
-    unsigned long long k = i < n_slots ? ht_key[i] : PT_EMPTY;
-    const bool has = k != PT_EMPTY;
-    const uint32_t len = has ? ht_len[i] : 0;
-    const bool isB = has && len > (uint32_t)TILE_NOM_A;
-    const uint32_t hasA = has && !isB;
+  for (unsigned long long c0 = (unsigned long long)blockIdx.x * CH; c0 < n_slots; c0 += (unsigned long long)gridDim.x * CH) {
+    uint32_t mine = 0;
+    for (int j = 0; j < 64; j++) {
+      const unsigned long long i = c0 + (unsigned long long)j * BLOCK + threadIdx.x;
+      if (i < n_slots && ht_key[i] != PT_EMPTY && ht_len[i] <= (uint32_t)TILE_NOM_A) mine++;
+    }
     uint32_t total;
-    uint32_t off = block_excl_scan(hasA, scan_lds, &total);
+    const uint32_t off = block_excl_scan(mine, scan_lds, &total);
     if (threadIdx.x == 0) blk_base = total ? atomicAdd(&cursor[0], total) : 0u;
     __syncthreads();
-    if (has) {
-      unsigned long long c = ht_cnt[i];
+    unsigned int o_a = blk_base + off;
+    for (int j = 0; j < 64; j++) {
+      const unsigned long long i = c0 + (unsigned long long)j * BLOCK + threadIdx.x;
+      if (i >= n_slots) break;
+      const unsigned long long k = ht_key[i];
+      if (k == PT_EMPTY) continue;
+      const uint32_t len = ht_len[i];
+      const unsigned long long c = ht_cnt[i];
       if (c > 0xffffffffull) atomicOr(&status[1], 2u);  // a word seen >= 2^32 times: weights are uint32
-      if (isB && len > (uint32_t)TILE_NOM_B) {
-        unsigned int o = atomicAdd(&cursor[2], 1u);
+      if (len > (uint32_t)TILE_NOM_B) {
+        const unsigned int o = atomicAdd(&cursor[2], 1u);
         posC[o] = k & WH_POS_MASK; cntC[o] = (uint32_t)c; lenC[o] = len;
-      } else if (isB) {
-        unsigned int o = atomicAdd(&cursor[1], 1u);
+      } else if (len > (uint32_t)TILE_NOM_A) {
+        const unsigned int o = atomicAdd(&cursor[1], 1u);
         posB[o] = k & WH_POS_MASK; cntB[o] = (uint32_t)c; lenB[o] = len;
       } else {
-        unsigned int o = blk_base + off;
-        posA[o] = k & WH_POS_MASK; cntA[o] = (uint32_t)c; lenA[o] = len;
+        posA[o_a] = k & WH_POS_MASK; cntA[o_a] = (uint32_t)c; lenA[o_a] = len;
+        o_a++;
       }
     }
     __syncthreads();

@@ -952,9 +952,18 @@ __global__ __launch_bounds__(BLOCK) void k_cand_scan(PairTable pt, unsigned long
 __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *__restrict__ out,
                                                     unsigned int cap, unsigned int *__restrict__ n_out, unsigned long long *__restrict__ hist,
                                                     unsigned int *__restrict__ done_ctr, unsigned char *__restrict__ mailbox, unsigned int fast,
-                                                    uint32_t round_id, unsigned long long *__restrict__ stats) {
+                                                    uint32_t round_id, unsigned long long *__restrict__ stats, const RuleSlot *__restrict__ zrules,
+                                                    unsigned int zmask, unsigned long long zself) {
+  // zrules != nullptr: the batch that was just applied -- every occurrence of its pairs was merged, so their counts are
+  // exactly zero now; they are all on the list (that is where they were picked from), so they are zeroed here instead of
+  // by a kernel of their own
   __shared__ unsigned int lh[CAND_BINS];
   __shared__ unsigned int live_blk;
+  __shared__ unsigned long long zkeys[FILTER_LDS_KEYS];
+  const bool zkeys_in_lds = zrules && zmask < FILTER_LDS_KEYS;
+  if (zkeys_in_lds)
+    for (unsigned int s = threadIdx.x; s <= zmask; s += BLOCK) zkeys[s] = zrules[s].key;
+  const RuleProbe zprobe{zkeys_in_lds ? zkeys : nullptr, zrules, zmask};
   for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) lh[b] = 0;
   if (threadIdx.x == 0) live_blk = 0;
   const unsigned int hn_raw = *pt.hot_n;
@@ -987,9 +996,13 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
       const uint32_t sl = pt.hot_slots[i];
       const uint4 rec = *reinterpret_cast<const uint4 *>(pt.key_p(sl));  // key and count in one 16-byte load
       c = (((unsigned long long)rec.w << 32) | rec.z) & PT_CNT;
+      k = ((unsigned long long)rec.y << 32) | rec.x;
+      if (c && zrules && (k == zself || zprobe.has((uint32_t)(k >> 32), (uint32_t)k))) {
+        *pt.cnt_p(sl) = PT_HOT;  // listed, count 0
+        c = 0;
+      }
       if (c >= pt.hot_tau) {
         live++;
-        k = ((unsigned long long)rec.y << 32) | rec.x;
         atomicAdd(&lh[cand_bin(c)], 1u);
         const uint32_t x = (uint32_t)(k >> 32), y = (uint32_t)k;
         const uint32_t mx = x > y ? x : y;
@@ -1313,9 +1326,9 @@ void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t 
 }
 void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
                      unsigned long long *hist, unsigned int *done_ctr, unsigned char *mailbox, unsigned int fast, uint32_t round_id,
-                     unsigned long long *stats, hipStream_t st) {
+                     unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, hipStream_t st) {
   hipLaunchKernelGGL(k_hot_scan, dim3(256), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id,
-                     stats);
+                     stats, zrules, zmask, zself);
 }
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st) {
   unsigned long long n_slots = pt.mask + 1;
