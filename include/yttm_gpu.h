@@ -19,6 +19,11 @@ int yttm_gpu_ctx_create(int device, yttm_ctx **out);
 void yttm_gpu_ctx_destroy(yttm_ctx *ctx);
 const char *yttm_gpu_last_error(void);
 
+/* Finished trainings keep their device buffers in a pool for the next call (hipMalloc/hipFree of ~10 GB cost several ms and
+ * synchronise the device).  This returns the cached buffers to the driver.  YTTM_NO_POOL=1 disables the pool.  (No reference
+ * counterpart: bpe.cpp allocates with new/std containers.) */
+void yttm_release_device_memory(void);
+
 /* multi-GPU: attach a communicator (yttm_comm* from include/yttm_mi355x.h, passed as void*) before the stages run;
  * the context then holds ITS shard and the pair table holds GLOBAL counts */
 int yttm_gpu_ctx_set_comm(yttm_ctx *ctx, void *comm);

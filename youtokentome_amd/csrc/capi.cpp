@@ -297,4 +297,6 @@ int yttm_gpu_candidates(yttm_ctx *c, uint64_t tau_cnt, uint32_t tau_mx, uint64_t
   })
 }
 
+void yttm_release_device_memory(void) { yttm::release_device_memory(); }
+
 }  // extern "C"

@@ -6,6 +6,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <unordered_map>
+#include <mutex>
+#include <map>
 #include <atomic>
 
 namespace yttm {
@@ -16,15 +19,115 @@ static unsigned long long pow2_at_least(unsigned long long v) {
   return c;
 }
 
+// ---- device memory pool --------------------------------------------------------------------------------------------
+// A training allocates ~10 GB in a dozen large pieces and frees them again; hipMalloc/hipFree of that size cost several
+// milliseconds (hipFree also synchronises the device) and, measured, an occasional 100 ms hiccup.  Freed blocks are kept
+// and handed out again to requests of (nearly) the same size.  A block freed by a context that is still running may
+// only be reused on that context's stream (same-stream order makes that safe); when the context is destroyed -- after
+// a stream synchronisation -- its blocks become free for everyone.  YTTM_NO_POOL=1 turns the pool off,
+// yttm_release_device_memory() (capi.cpp) returns the cached blocks to the driver.
+namespace {
+struct PoolBlock {
+  void *p;
+  size_t bytes;
+  hipStream_t owner;  // nullptr: quiescent
+  int device;
+};
+struct DevPool {
+  std::mutex mu;
+  std::multimap<size_t, PoolBlock> free_blocks;
+  std::unordered_map<void *, size_t> live;
+  size_t cached = 0;
+};
+DevPool g_pool;
+void *g_pin_cached = nullptr;  // one pinned staging buffer (PIN_BYTES) kept between contexts
+thread_local hipStream_t tl_stream = nullptr;
+thread_local int tl_device = 0;
+constexpr size_t POOL_MAX_CACHED = 48ull << 30;
+bool pool_enabled() {
+  static const bool on = !(getenv("YTTM_NO_POOL") && *getenv("YTTM_NO_POOL") == '1');
+  return on;
+}
+void *pool_alloc(size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (pool_enabled()) {
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    for (auto it = g_pool.free_blocks.lower_bound(bytes); it != g_pool.free_blocks.end() && it->first <= bytes + bytes / 4 + 65536; ++it) {
+      const PoolBlock &b = it->second;
+      if (b.device != tl_device || (b.owner != nullptr && b.owner != tl_stream)) continue;
+      void *p = b.p;
+      g_pool.live[p] = b.bytes;
+      g_pool.cached -= b.bytes;
+      g_pool.free_blocks.erase(it);
+      return p;
+    }
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess && pool_enabled()) {  // out of memory with blocks cached: give them back and retry
+    {
+      std::lock_guard<std::mutex> g(g_pool.mu);
+      for (auto &kv : g_pool.free_blocks) (void)hipFree(kv.second.p);
+      g_pool.free_blocks.clear();
+      g_pool.cached = 0;
+    }
+    e = hipMalloc(&p, bytes);
+  }
+  HIP_CHECK(e);
+  if (pool_enabled()) {
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    g_pool.live[p] = bytes;
+  }
+  return p;
+}
+void pool_free(void *p) {
+  if (!p) return;
+  if (pool_enabled()) {
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    auto it = g_pool.live.find(p);
+    if (it != g_pool.live.end()) {
+      const size_t bytes = it->second;
+      g_pool.live.erase(it);
+      if (g_pool.cached + bytes <= POOL_MAX_CACHED) {
+        g_pool.free_blocks.emplace(bytes, PoolBlock{p, bytes, tl_stream, tl_device});
+        g_pool.cached += bytes;
+        return;
+      }
+    }
+  }
+  (void)hipFree(p);
+}
+void pool_quiesce(hipStream_t st) {  // the stream was synchronised: its blocks may now go to anybody
+  std::lock_guard<std::mutex> g(g_pool.mu);
+  for (auto &kv : g_pool.free_blocks)
+    if (kv.second.owner == st) kv.second.owner = nullptr;
+}
+}  // namespace
+void release_device_memory() {
+  std::lock_guard<std::mutex> g(g_pool.mu);
+  if (g_pin_cached) {
+    (void)hipHostFree(g_pin_cached);
+    g_pin_cached = nullptr;
+  }
+  for (auto it = g_pool.free_blocks.begin(); it != g_pool.free_blocks.end();) {
+    if (it->second.owner == nullptr) {
+      (void)hipFree(it->second.p);
+      g_pool.cached -= it->second.bytes;
+      it = g_pool.free_blocks.erase(it);
+    } else {
+      ++it;
+    }
+  }
+}
+
 template <class T>
 static T *dmalloc(size_t n) {
-  void *p = nullptr;
-  HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
-  return (T *)p;
+  return (T *)pool_alloc((n ? n : 1) * sizeof(T));
 }
 #define DFREE(p)            \
   do {                      \
-    if (p) (void)hipFree((void *)(p)); \
+    if (p) pool_free((void *)(p)); \
     p = nullptr;            \
   } while (0)
 
@@ -41,7 +144,11 @@ constexpr size_t PIN_BYTES = (size_t)CAND_CAP * sizeof(CandRec) + (size_t)RULES_
 
 GpuCtx::GpuCtx(int device) : device_(device) {
   HIP_CHECK(hipSetDevice(device_));
+  tl_stream = st_;
+  tl_device = device_;
   HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  tl_stream = st_;
+  tl_device = device_;
   d_counters_ = dmalloc<unsigned long long>(64);
   d_stats_ = dmalloc<unsigned long long>(STATS_WORDS);  // [0..3] K4 counters, [8..23] per-phase cycles of a YTTM_K4_PROF build, [32..) per-workgroup rows
   HIP_CHECK(hipMemset(d_stats_, 0, STATS_WORDS * sizeof(unsigned long long)));
@@ -61,21 +168,36 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   cand_cap_ = CAND_CAP;
   d_rules_ = dmalloc<RuleSlot>(RULES_CAP);
   rules_cap_ = RULES_CAP;
-  HIP_CHECK(hipHostMalloc(&h_pin_, PIN_BYTES, hipHostMallocDefault));
+  {  // pinned staging: one buffer is kept across contexts (hipHostMalloc of 17 MB costs milliseconds)
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    h_pin_ = g_pin_cached;
+    g_pin_cached = nullptr;
+  }
+  if (!h_pin_) HIP_CHECK(hipHostMalloc(&h_pin_, PIN_BYTES, hipHostMallocDefault));
   h_pin_bytes_ = PIN_BYTES;
   memset(h_pin_, 0, 8192);  // mailbox header (k_hot_scan publishes its round id at byte 32)
 }
 
 GpuCtx::~GpuCtx() {
   (void)hipSetDevice(device_);
+  tl_stream = st_;
+  tl_device = device_;
   (void)hipStreamSynchronize(st_);
   for (auto &e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_); DFREE(d_flagbits_);
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_);
-  if (db_.recs) (void)hipFree(db_.recs);
-  if (db_.n) (void)hipFree(db_.n);
+  DFREE(db_.recs);
+  DFREE(db_.n);
   free_table(pt_);
+  pool_quiesce(st_);
+  if (h_pin_) {
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    if (!g_pin_cached && pool_enabled()) {
+      g_pin_cached = h_pin_;
+      h_pin_ = nullptr;
+    }
+  }
   if (h_pin_) (void)hipHostFree(h_pin_);
   if (st_) (void)hipStreamDestroy(st_);
 }
@@ -126,6 +248,8 @@ void GpuCtx::resolve_timers() {
 // ------------------------------------------------------------------------------------------------- corpus
 void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
   HIP_CHECK(hipSetDevice(device_));
+  tl_stream = st_;
+  tl_device = device_;
   DFREE(d_text_owned_);
   d_text_owned_ = dmalloc<uint8_t>(n + 64);
   if (n) HIP_CHECK(hipMemcpyAsync(d_text_owned_, host, n, hipMemcpyHostToDevice, st_));
@@ -136,6 +260,8 @@ void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
 }
 void GpuCtx::attach_corpus(const void *dev, unsigned long long n) {
   HIP_CHECK(hipSetDevice(device_));
+  tl_stream = st_;
+  tl_device = device_;
   DFREE(d_text_owned_);
   if (((uintptr_t)dev & 15u) != 0) throw GpuError{"attach_corpus: device pointer must be 16-byte aligned"};
   d_text_ = (const uint8_t *)dev;
@@ -146,6 +272,8 @@ void GpuCtx::attach_corpus(const void *dev, unsigned long long n) {
 // ------------------------------------------------------------------------------------------------- K1
 void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long long> &cnts, unsigned long long &n_codepoints) {
   HIP_CHECK(hipSetDevice(device_));
+  tl_stream = st_;
+  tl_device = device_;
   if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
   HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
   HIP_CHECK(hipMemsetAsync(d_counters_, 0, 64 * 8, st_));
@@ -186,6 +314,8 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
 // ------------------------------------------------------------------------------------------------- K2
 void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n_alpha, uint32_t space_id, uint32_t n_ids_cap) {
   HIP_CHECK(hipSetDevice(device_));
+  tl_stream = st_;
+  tl_device = device_;
   // code point -> class map
   {
     std::vector<uint32_t> cpmap(N_CODEPOINTS, CP_DROP);
@@ -300,8 +430,9 @@ void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, u
   unsigned long long *tile_start = dmalloc<unsigned long long>(c.n_tiles);
   c.d_tile_word0 = dmalloc<uint32_t>(c.n_tiles);
   c.d_tile_len = dmalloc<uint32_t>(c.n_tiles);
-  c.d_worklist = dmalloc<uint32_t>(c.n_tiles + 64);
-  c.d_work_n = dmalloc<unsigned int>(4);  // [0] worklist length, [1] dynamic hand-out counter
+  c.d_worklist = dmalloc<uint32_t>(8 * ((size_t)c.n_tiles + 64));  // WL_PARTS sub-lists of WL_SEG(n_tiles) entries (k_merge.hip)
+  c.d_work_n = dmalloc<unsigned int>(16);                           // their lengths [0..7], hand-out counter [8]
+  HIP_CHECK(hipMemsetAsync(c.d_work_n, 0, 64, st_));
   c.d_tok = dmalloc<uint32_t>((size_t)c.n_tiles * c.slot + 64);
   // slots are read 16 B wide past the live prefix and the staged ids index the flag table: never leave them undefined
   HIP_CHECK(hipMemsetAsync(c.d_tok, 0, ((size_t)c.n_tiles * c.slot + 64) * 4, st_));
@@ -433,6 +564,8 @@ void GpuCtx::exchange_deltas() {
 
 void GpuCtx::pair_count() {
   HIP_CHECK(hipSetDevice(device_));
+  tl_stream = st_;
+  tl_device = device_;
   free_table(pt_);
   pt_cap_ = 0;
   n_keys_host = 0;
@@ -481,6 +614,8 @@ void GpuCtx::download_pairs(std::vector<unsigned long long> &keys, std::vector<u
 
 uint32_t GpuCtx::scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist) {
   HIP_CHECK(hipSetDevice(device_));
+  tl_stream = st_;
+  tl_device = device_;
   out.clear();
   if (!pt_cap_) {
     if (hist) memset(hist, 0, CAND_BINS * 8);
@@ -545,6 +680,8 @@ void GpuCtx::rebuild_hot() {
 
 uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist) {
   HIP_CHECK(hipSetDevice(device_));
+  tl_stream = st_;
+  tl_device = device_;
   out.clear();
   if (!pt_cap_) {
     if (hist) memset(hist, 0, CAND_BINS * 8);
@@ -639,6 +776,8 @@ void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned lon
 // ------------------------------------------------------------------------------------------------- K4
 void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts) {
   HIP_CHECK(hipSetDevice(device_));
+  tl_stream = st_;
+  tl_device = device_;
   if (!k) return;
   if (!n_tiles && !(comm_ && comm_->world > 1)) return;  // a rank without words still takes part in the exchange
   if (k > RULES_CAP / 2) throw GpuError{"merge_apply: batch too large"};

@@ -27,6 +27,9 @@ struct Comm {
   virtual size_t allgather_recs(const DeltaRec *send, size_t n_local, DeltaRec *recv, size_t cap, hipStream_t st) = 0;
 };
 
+// returns the device (and pinned) memory cached by finished contexts to the driver
+void release_device_memory();
+
 struct KernelTimes {  // accumulated GPU time per kernel family, measured with HIP events on the ctx stream
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};

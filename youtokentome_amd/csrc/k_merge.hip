@@ -21,6 +21,10 @@
 namespace yttm {
 
 constexpr int AGG_SLOTS = 256;   // LDS delta aggregator shared by the waves of a workgroup (hot pairs)
+// The worklist of dirty tiles is kept in WL_PARTS sub-lists (workgroup b of the filter appends to list b % WL_PARTS, each
+// list WL_SEG(n_tiles) entries apart): one cursor bumped by all 1280 workgroups of a launch cost 14 us per round.
+constexpr uint32_t WL_PARTS = 8;
+__host__ __device__ inline size_t WL_SEG(uint32_t n_tiles) { return (size_t)n_tiles + 64; }
 constexpr uint32_t DYN_TILES_PER_WAVE = 0;  // worklists shorter than this per wavefront are handed out dynamically
 constexpr uint32_t FLAG_LDS_IDS = 32768;  // batch flags of ids below this live in an LDS bitmap (2 bits per id, 8 KB)
 
@@ -614,7 +618,18 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
   WaveLds<SLOT> &W = WL[wave];
   const uint32_t stride = gridDim.x * WPB;
   // K4 runs over the worklist of dirty tiles written by k_filter; K3 over all tiles
-  const uint32_t NT = worklist ? *work_n : ts.n_tiles;
+  uint32_t wn[WL_PARTS];  // lengths of the sub-lists
+  uint32_t NT = ts.n_tiles;
+  if (worklist) {
+    uint32_t mx = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < WL_PARTS; s++) {
+      wn[s] = work_n[s];
+      mx = wn[s] > mx ? wn[s] : mx;
+    }
+    NT = mx * WL_PARTS;  // item i = entry i / WL_PARTS of sub-list i % WL_PARTS (or nothing, past that list's end)
+  }
+  const size_t wl_seg = WL_SEG(ts.n_tiles);
   // Tile loop of this wave.  Headers (live length, first word) of the next 64 tiles are loaded with ONE vector load
   // each (lane j holds tile i+j) and handed out by shuffles, so a tile costs no header round trip.  Tokens of tile i+1
   // are fetched right after tile i has been staged into LDS and arrive while tile i is processed.  (All waits the
@@ -626,8 +641,18 @@ __global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable p
   auto load_headers = [&](uint32_t tb) {
     const unsigned long long tj = (unsigned long long)tb + (unsigned long long)lane * stride;
     hn = 0; hw = 0; ht = 0;
-    if (tj < NT) {
-      ht = worklist ? worklist[tj] : (uint32_t)tj;
+    bool have = tj < NT;
+    if (have && worklist) {
+      const uint32_t part = (uint32_t)tj % WL_PARTS, idx = (uint32_t)(tj / WL_PARTS);
+      uint32_t len = 0;
+#pragma unroll
+      for (uint32_t s = 0; s < WL_PARTS; s++) len = part == s ? wn[s] : len;
+      have = idx < len;
+      if (have) ht = worklist[part * wl_seg + idx];
+    } else if (have) {
+      ht = (uint32_t)tj;
+    }
+    if (have) {
       hn = (int)ts.tile_len[ht];
       hw = hn ? ts.tile_word0[ht] : 0u;  // an empty tile (after a repack) has no first word
     }
@@ -869,9 +894,9 @@ __global__ __launch_bounds__(BLOCK) void k_filter(TileSet ts, const uint8_t *__r
     }
     __syncthreads();
     if (dn > 1024 - KT * NWAVES) {  // one global atomic per flush per workgroup
-      if (threadIdx.x == 0) dbase = atomicAdd(work_n, dn);
+      if (threadIdx.x == 0) dbase = atomicAdd(work_n + blockIdx.x % WL_PARTS, dn);
       __syncthreads();
-      for (unsigned int i = threadIdx.x; i < dn; i += BLOCK) worklist[dbase + i] = dl[i];
+      for (unsigned int i = threadIdx.x; i < dn; i += BLOCK) worklist[(blockIdx.x % WL_PARTS) * WL_SEG(NT) + dbase + i] = dl[i];
       __syncthreads();
       if (threadIdx.x == 0) dn = 0;
       __syncthreads();
@@ -880,9 +905,9 @@ __global__ __launch_bounds__(BLOCK) void k_filter(TileSet ts, const uint8_t *__r
   if (lane == 0 && scanned) atomicAdd(&scanned_blk, scanned);
   __syncthreads();
   if (dn) {
-    if (threadIdx.x == 0) dbase = atomicAdd(work_n, dn);
+    if (threadIdx.x == 0) dbase = atomicAdd(work_n + blockIdx.x % WL_PARTS, dn);
     __syncthreads();
-    for (unsigned int i = threadIdx.x; i < dn; i += BLOCK) worklist[dbase + i] = dl[i];
+    for (unsigned int i = threadIdx.x; i < dn; i += BLOCK) worklist[(blockIdx.x % WL_PARTS) * WL_SEG(NT) + dbase + i] = dl[i];
   }
   if (threadIdx.x == 0) blk_add(stats, 2, scanned_blk);
 }
@@ -969,19 +994,24 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
   const unsigned int hn_raw = *pt.hot_n;
   const unsigned int hn = hn_raw < pt.hot_cap ? hn_raw : pt.hot_cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) n_out[2] = hn_raw;
-  {  // every workgroup folds its share of the per-workgroup statistics rows (see fold_blk_stats) into the totals
-    const int per = (BLK_ROWS + (int)gridDim.x - 1) / (int)gridDim.x;
-    if ((int)threadIdx.x < per) {
+  {  // every workgroup folds its share of the per-workgroup statistics rows (see fold_blk_stats) into the totals: its rows are
+     // summed across the first lanes of wave 0 first, so a total receives one atomic per workgroup
+    const int per = (BLK_ROWS + (int)gridDim.x - 1) / (int)gridDim.x;  // <= 64
+    if (threadIdx.x < 64) {
+      unsigned long long v[5] = {0, 0, 0, 0, 0};
       const int b = (int)blockIdx.x * per + (int)threadIdx.x;
-      if (b < BLK_ROWS) {
+      if ((int)threadIdx.x < per && b < BLK_ROWS) {
         unsigned long long *row = stats + BLK_BASE + 8 * b;
         for (int j = 0; j < 5; j++) {
-          const unsigned long long v = row[j];
-          if (v) {
-            row[j] = 0;
-            if (j < 4) atomicAdd(&stats[j], v);
-            else atomicAdd(pt.n_keys, (unsigned int)v);
-          }
+          v[j] = row[j];
+          if (v[j]) row[j] = 0;
+        }
+      }
+      for (int j = 0; j < 5; j++) {
+        const unsigned long long t = wave_sum_u64(v[j]);
+        if (threadIdx.x == 0 && t) {
+          if (j < 4) atomicAdd(&stats[j], t);
+          else atomicAdd(pt.n_keys, (unsigned int)t);
         }
       }
     }
@@ -1176,8 +1206,10 @@ __global__ __launch_bounds__(BLOCK) void k_round_begin(const RuleSlot *__restric
     }
   }
   if (tid == 0) {
-    if (work_n_a) work_n_a[0] = work_n_a[1] = 0;
-    if (work_n_b) work_n_b[0] = work_n_b[1] = 0;
+    for (uint32_t i = 0; i <= WL_PARTS; i++) {
+      if (work_n_a) work_n_a[i] = 0;
+      if (work_n_b) work_n_b[i] = 0;
+    }
   }
 }
 
@@ -1302,19 +1334,19 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, true>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + WL_PARTS, stats);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + WL_PARTS, stats);
   } else {
     if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + WL_PARTS, stats);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + 1, stats);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + WL_PARTS, stats);
   }
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
