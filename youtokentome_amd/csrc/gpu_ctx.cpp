@@ -702,7 +702,7 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     const uint32_t round_id = ++mail_round_;
     t_begin(KT_CAND);
     launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_,
-                    pending_zero_ ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, st_);
+                    pending_zero_ ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, listed_last_ ? listed_last_ + 4096 : hot_cap_, st_);
     pending_zero_ = false;
     t_end(KT_CAND, 20ull * listed_last_);
     {
@@ -848,7 +848,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     if (!cls_[ci].n_tiles) continue;
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
                        cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles,
-                       /*dense=*/touched_last_ != (~0ull >> 2) && touched_last_ * 10 >= (unsigned long long)n_tiles * 9, st_);
+                       /*dense=*/cls_[ci].n_tiles <= 8192 || (touched_last_ != (~0ull >> 2) && touched_last_ * 10 >= (unsigned long long)n_tiles * 9), st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
   t_end(KT_MERGE, 0);

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
     const unsigned long long tag = h >> 40;
     if (L + 1 <= (uint32_t)TILE_NOM_A && L + 1 > l_maxlen) atomicMax(&l_maxlen, L + 1);
     bool done = false;
-    if (L <= 8) {  // only short words are frequent enough to be worth an LDS slot
+    if (L <= 24) {  // very long words are not frequent enough to be worth an LDS slot (Zipf text: the top words reach 12+ chars)
       unsigned int j = (unsigned int)(h >> 8) & (WL_SLOTS - 1);
       for (int probe = 0; probe < 4 && !done; probe++) {
         unsigned long long cur = __hip_atomic_load(&l_key[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_read, not a flat load

@@ -1358,8 +1358,14 @@ void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t 
 }
 void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
                      unsigned long long *hist, unsigned int *done_ctr, unsigned char *mailbox, unsigned int fast, uint32_t round_id,
-                     unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, hipStream_t st) {
-  hipLaunchKernelGGL(k_hot_scan, dim3(256), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id,
+                     unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, unsigned int listed_hint,
+                     hipStream_t st) {
+  // one entry per thread; every workgroup costs ~11 ns of serialised ticket/total atomics at the end, so no more of them
+  // than the list needs (the statistics rows need >= BLK_ROWS / 64 = 24)
+  unsigned int g = (listed_hint + BLOCK - 1) / BLOCK;
+  if (g < 32) g = 32;
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(k_hot_scan, dim3(g), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id,
                      stats, zrules, zmask, zself);
 }
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st) {

@@ -55,7 +55,8 @@ void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t 
                       unsigned int *n_out, unsigned long long *hist, hipStream_t st);
 void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
                      unsigned long long *hist, unsigned int *done_ctr, unsigned char *mailbox, unsigned int fast, uint32_t round_id,
-                     unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, hipStream_t st);
+                     unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, unsigned int listed_hint,
+                     hipStream_t st);
 void launch_fold_stats(unsigned long long *stats, unsigned int *n_keys, hipStream_t st);
 constexpr int STATS_WORDS = 32 + 8 * 1536;  // totals + one row per workgroup (k_merge.hip: BLK_BASE, BLK_ROWS)
 void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, const uint32_t *upd, unsigned int n_upd,
