@@ -156,7 +156,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   // [0] n_cand, [4] n_keys | [64..) count histogram | [8192..) candidates
   d_round_ = dmalloc<unsigned char>(8192 + (size_t)CAND_CAP * sizeof(CandRec));
   hot_cap_ = std::min(env_uint("YTTM_HOT_CAP", HOT_CAP), HOT_CAP);
-  hot_target_ = env_uint("YTTM_HOT_TARGET", 1u << 15);
+  hot_target_ = env_uint("YTTM_HOT_TARGET", 1u << 13);  // measured at 1 GB: 4096..16384 equal on the abcd corpus, 8192 best on Zipf text (4279 rounds)
   hot_min_ = env_uint("YTTM_HOT_MIN", 512);
   d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);
   d_hot_n_ = dmalloc<unsigned int>(4);  // [0] list length, [1] k_hot_scan's finished-workgroup ticket, [2..3] overflow verdict (u64)
