@@ -183,7 +183,7 @@ GpuCtx::~GpuCtx() {
   tl_stream = st_;
   tl_device = device_;
   (void)hipStreamSynchronize(st_);
-  for (auto &e : evs_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (hipEvent_t e : all_events_) (void)hipEventDestroy(e);
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_); DFREE(d_flagbits_);
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_);
@@ -204,21 +204,45 @@ GpuCtx::~GpuCtx() {
 
 void GpuCtx::sync() { HIP_CHECK(hipStreamSynchronize(st_)); }
 
+// Kernel-family timers (profile mode): HIP events on the context's stream.  Events come from a process-wide pool, and an
+// interval that starts where the previous one ended shares that event (t_end(..., chain=true) followed by t_begin): a
+// merge round costs two hipEventRecord calls instead of four -- on Zipf text (4279 rounds) the four cost 17 % of a step.
+static std::vector<hipEvent_t> g_event_pool;
+static hipEvent_t event_get() {
+  {
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    if (!g_event_pool.empty()) {
+      hipEvent_t e = g_event_pool.back();
+      g_event_pool.pop_back();
+      return e;
+    }
+  }
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreate(&e));
+  return e;
+}
 void GpuCtx::t_begin(int which) {
   (void)which;
   if (!profile) return;
-  HIP_CHECK(hipEventCreate(&cur_a_));
+  if (chain_event_) {  // nothing was enqueued since the interval that ended there
+    cur_a_ = chain_event_;
+    chain_event_ = nullptr;
+    return;
+  }
+  cur_a_ = event_get();
+  all_events_.push_back(cur_a_);
   HIP_CHECK(hipEventRecord(cur_a_, st_));
 }
-void GpuCtx::t_end(int which, unsigned long long bytes) {
+void GpuCtx::t_end(int which, unsigned long long bytes, bool chain) {
   kt.launches[which]++;
   kt.bytes[which] += bytes;
   if (!profile) return;
-  hipEvent_t b;
-  HIP_CHECK(hipEventCreate(&b));
+  hipEvent_t b = event_get();
+  all_events_.push_back(b);
   HIP_CHECK(hipEventRecord(b, st_));
   evs_.push_back(Ev{cur_a_, b, which});
   cur_a_ = nullptr;
+  chain_event_ = chain ? b : nullptr;
 }
 void GpuCtx::resolve_timers() {
   sync();
@@ -238,10 +262,14 @@ void GpuCtx::resolve_timers() {
     float ms = 0;
     if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) kt.ms[e.which] += ms;
     if (trace) fprintf(trace, "%d %.4f\n", e.which, ms);
-    (void)hipEventDestroy(e.a);
-    (void)hipEventDestroy(e.b);
   }
   evs_.clear();
+  {
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    g_event_pool.insert(g_event_pool.end(), all_events_.begin(), all_events_.end());
+  }
+  all_events_.clear();
+  chain_event_ = nullptr;
   if (trace) fclose(trace);
 }
 
@@ -477,6 +505,7 @@ void GpuCtx::download_word_table(std::vector<uint32_t> &tok, std::vector<unsigne
 void GpuCtx::maybe_repack(int ci) {
   WordClass &c = cls_[ci];
   if (c.n_tiles < 2) return;
+  chain_event_ = nullptr;  // work between two timed intervals: they no longer share an event
   unsigned long long *off = dmalloc<unsigned long long>(c.n_tiles);
   unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(c.n_tiles));
   launch_exclusive_scan(c.d_tile_len, c.n_tiles, off, scan_tmp, d_counters_ + 48, st_);
@@ -524,6 +553,7 @@ void GpuCtx::free_table(PairTable &pt) {
 
 void GpuCtx::ensure_table_capacity(unsigned long long need_keys) {
   if (pt_cap_ && need_keys * 2 <= pt_cap_) return;
+  chain_event_ = nullptr;
   // load stays below 1/2; growth is by 4x (a rehash also costs a rebuild of the hot list)
   unsigned long long new_cap = pow2_at_least(std::max<unsigned long long>(1ull << 16, need_keys * 4));
   if (!pt_cap_) {
@@ -546,6 +576,7 @@ void GpuCtx::ensure_table_capacity(unsigned long long need_keys) {
 
 void GpuCtx::exchange_deltas() {
   if (!comm_ || comm_->world <= 1) return;
+  chain_event_ = nullptr;
   launch_fold_stats(d_stats_, pt_.n_keys, st_);  // the apply kernels leave their slot counts in per-workgroup rows
   unsigned long long n_local = 0;
   HIP_CHECK(hipMemcpyAsync(&n_local, db_.n, 8, hipMemcpyDeviceToHost, st_));
@@ -704,7 +735,7 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_,
                     pending_zero_ ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, listed_last_ ? listed_last_ + 4096 : hot_cap_, st_);
     pending_zero_ = false;
-    t_end(KT_CAND, 20ull * listed_last_);
+    t_end(KT_CAND, 20ull * listed_last_);  // (not chained: the host round trip that follows belongs to no kernel family)
     {
       // the kernel's last workgroup writes header + histogram + first candidates into the pinned mailbox and then the
       // round id: poll for it (a copy + stream synchronisation costs tens of microseconds per round)
@@ -841,9 +872,9 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     i = j;
   }
   prev_flag_toks_.swap(now);
+  t_begin(KT_MERGE);
   launch_round_begin(h_rules, cap, d_rules_, h_upd, n_upd, d_tokflag_, d_flagbits_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr,
                      cls_[1].n_tiles ? cls_[1].d_work_n : nullptr, st_);
-  t_begin(KT_MERGE);
   for (int ci = 0; ci < 2; ci++) {
     if (!cls_[ci].n_tiles) continue;
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
@@ -851,9 +882,10 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
                        /*dense=*/cls_[ci].n_tiles <= 8192 || (touched_last_ != (~0ull >> 2) && touched_last_ * 10 >= (unsigned long long)n_tiles * 9), st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
-  t_end(KT_MERGE, 0);
+  t_end(KT_MERGE, 0, /*chain=*/true);
   merge_rounds++;
-  if (getenv("YTTM_TRACE_ROUNDS")) {  // tuning aid: cumulative device stats after every round (adds a sync)
+  if (getenv("YTTM_TRACE_ROUNDS")) {
+    chain_event_ = nullptr;  // tuning aid: cumulative device stats after every round (adds a sync)
     unsigned long long stt[24];
     launch_fold_stats(d_stats_, pt_.n_keys, st_);
     HIP_CHECK(hipMemcpyAsync(stt, d_stats_, sizeof stt, hipMemcpyDeviceToHost, st_));
@@ -897,6 +929,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
 
 void GpuCtx::flush_pending_zero() {
   if (!pending_zero_) return;
+  chain_event_ = nullptr;
   launch_pt_zero(pt_, d_rules_, zero_cap_, zero_self_key_, st_);
   pending_zero_ = false;
 }

@@ -96,7 +96,7 @@ class GpuCtx {
   void free_table(PairTable &pt);
   void exchange_deltas();
   void t_begin(int which);
-  void t_end(int which, unsigned long long bytes);
+  void t_end(int which, unsigned long long bytes, bool chain = false);
 
   int device_;
   hipStream_t st_ = nullptr;
@@ -157,7 +157,8 @@ class GpuCtx {
 
   struct Ev { hipEvent_t a, b; int which; };
   std::vector<Ev> evs_;
-  hipEvent_t cur_a_ = nullptr;
+  hipEvent_t cur_a_ = nullptr, chain_event_ = nullptr;
+  std::vector<hipEvent_t> all_events_;  // every event this context took from the pool (each once)
 };
 
 #define HIP_CHECK(expr)                                                                                         \

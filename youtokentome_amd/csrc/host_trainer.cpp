@@ -270,7 +270,7 @@ Status train_bpe_from_device(const void *d_text, unsigned long long n, const std
   if (!st.ok()) return st;
   return guarded([&]() {
     GpuCtx g(device);
-    g.profile = profile;
+    g.profile = profile && !getenv("YTTM_NO_PROFILE");  // (tuning hook: what do the timing events themselves cost?)
     g.set_comm(comm);
     g.attach_corpus(d_text, n);
     return learn_bpe(g, vocab_size, model_path, cfg, nullptr, report);
