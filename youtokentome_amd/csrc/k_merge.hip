@@ -594,7 +594,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
 }
 
 template <int SLOT, int WPB, bool MERGE, bool LDSR>
-__global__ __launch_bounds__(WPB * 64, WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
+__global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                                                     const uint32_t *__restrict__ worklist, const unsigned int *__restrict__ work_n,
@@ -1333,10 +1333,10 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
     if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
-      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, true>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, true>), dim3(tile_grid(ts.n_tiles, 4, 5)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
                          tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + WL_PARTS, stats);
     else
-      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, false>), dim3(tile_grid(ts.n_tiles, 4, 5)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
                          tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + WL_PARTS, stats);
   } else {
     if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
