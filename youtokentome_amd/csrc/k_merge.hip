@@ -835,7 +835,7 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
 // x x of a self rule -- to the worklist that k_tiles<..., true> then processes.  Late in training a batch touches a
 // few percent of the tiles; this pass is the part that has to run at HBM speed.
 template <int SLOT>
-__global__ __launch_bounds__(BLOCK) void k_filter(TileSet ts, const uint8_t *__restrict__ tokflag, const uint32_t *__restrict__ flagbits,
+__global__ __launch_bounds__(BLOCK, SLOT <= 512 ? 6 : 1) void k_filter(TileSet ts, const uint8_t *__restrict__ tokflag, const uint32_t *__restrict__ flagbits,
                                                   const RuleSlot *__restrict__ rules, unsigned int rule_mask, uint32_t self_x,
                                                   uint32_t *__restrict__ worklist, unsigned int *__restrict__ work_n,
                                                   unsigned long long *__restrict__ stats) {
@@ -1328,7 +1328,7 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
   // pass 1: which tiles have a merge-site candidate; pass 2: apply the batch to those
   const unsigned int kt = cls == 0 ? 2 : 1;  // tiles per wavefront and iteration (k_filter: KT)
   unsigned int fg = (ts.n_tiles + kt * NWAVES - 1) / (kt * NWAVES);
-  if (fg > 256 * 5) fg = 256 * 5;  // 5 workgroups per CU are resident; each ends with one atomic on the worklist counter (measured: 1280 beats 2048)
+  if (fg > 256 * 6) fg = 256 * 6;  // 6 workgroups per CU (7 fit); must stay <= BLK_ROWS: every workgroup owns a statistics row
   if (cls == 0) {
     if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
