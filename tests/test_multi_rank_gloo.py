@@ -24,9 +24,10 @@ def free_port():
     return p
 
 
-def run_world(corpus, model, vocab, coverage, world, lib):
+def run_world(corpus, model, vocab, coverage, world, lib, extra_env=None):
     port = str(free_port())
     env = dict(os.environ, YTTM_AMD_LIB=lib)
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_train_worker.py"), str(r), str(world), port, corpus, model, str(vocab),
                                repr(coverage)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600) for p in procs]
@@ -47,3 +48,20 @@ def test_two_ranks_equal_single_oracle(tmp_path, sim_lib, world):
         run_world(corpus, m_mp, vocab, cov, world, sim_lib)
         O.train(text, m_ora, vocab, cov)
         assert filecmp.cmp(m_mp, m_ora, shallow=False), f"case {i}"
+
+
+def test_two_ranks_long_words_and_small_hot_list(tmp_path, sim_lib):
+    """Words beyond the LDS tile kernels (class C, k_giant.hip) on both ranks, and a hot list so small that it overflows and
+    is rebuilt all the time: the ranks have to agree on every rebuild (one extra all-reduce) to stay in lock step."""
+    rng = random.Random(9)
+    long_words = ["".join(rng.choice("abc") for _ in range(n)) for n in (2100, 2600, 3001)]
+    lines = []
+    for i in range(40):
+        lines.append(" ".join(["".join(rng.choice("abcd") for _ in range(rng.randint(1, 9))) for _ in range(12)] + [long_words[i % 3]]))
+    text = ("\n".join(lines) + "\n").encode()
+    corpus = str(tmp_path / "c.txt")
+    open(corpus, "wb").write(text)
+    m_mp, m_ora = str(tmp_path / "mp.model"), str(tmp_path / "ora.model")
+    run_world(corpus, m_mp, 150, 1.0, 2, sim_lib, {"YTTM_HOT_TARGET": "8", "YTTM_HOT_MIN": "3", "YTTM_HOT_CAP": "32"})
+    O.train(text, m_ora, 150, 1.0)
+    assert filecmp.cmp(m_mp, m_ora, shallow=False)
