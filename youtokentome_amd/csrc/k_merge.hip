@@ -25,7 +25,6 @@ constexpr int AGG_SLOTS = 256;   // LDS delta aggregator shared by the waves of 
 // list WL_SEG(n_tiles) entries apart): one cursor bumped by all 1280 workgroups of a launch cost 14 us per round.
 constexpr uint32_t WL_PARTS = 8;
 __host__ __device__ inline size_t WL_SEG(uint32_t n_tiles) { return (size_t)n_tiles + 64; }
-constexpr uint32_t DYN_TILES_PER_WAVE = 0;  // worklists shorter than this per wavefront are handed out dynamically
 constexpr uint32_t FLAG_LDS_IDS = 32768;  // batch flags of ids below this live in an LDS bitmap (2 bits per id, 8 KB)
 
 // Staged (LDS) token word: bit31 = first token of a word, bit30 = id is the y of some batch rule, bit29 = id is the x
@@ -479,11 +478,6 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
           if (first_site_chunk == nchunks && W.sitemask[c] != 0ull) first_site_chunk = c;
 #ifdef YTTM_K4_PROF
 #endif
-#ifdef YTTM_K4_PROF
-#define K4_SUB(k) ((void)0)
-#else
-#define K4_SUB(k) ((void)0)
-#endif
           const long long f = tile_weight_all<SLOT>(W, wreg, p, p < n);
           // Site bits of this chunk and its neighbours live in registers (every SITE() below used to be a dependent LDS
           // read), and the up to four count deltas of a lane are collected first and emitted by all lanes together: four
@@ -495,7 +489,6 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
           const bool s_p1 = lane <= 62 ? ((sm1 >> ((lane + 1) & 63)) & 1ull) : (sm2 & 1ull);
           const bool s_m2 = lane >= 2 ? ((sm1 >> ((lane - 2) & 63)) & 1ull) : ((sm0 >> ((62 + lane) & 63)) & 1ull);
           const bool s_p2 = lane <= 61 ? ((sm1 >> ((lane + 2) & 63)) & 1ull) : ((sm2 >> ((lane - 62) & 63)) & 1ull);
-          K4_SUB(10);
           bool alive = false;
           bool v0 = false, v1 = false, v2 = false, v3 = false;
           unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
@@ -550,15 +543,10 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
               }
             }
           }
-          K4_SUB(11);
           if (__ballot(v0)) { if (v0) emit<SLOT>(A, W, pt, db, k0, d0); }
-          K4_SUB(12);
           if (__ballot(v1)) { if (v1) emit<SLOT>(A, W, pt, db, k1, d1); }
-          K4_SUB(13);
           if (__ballot(v2)) { if (v2) emit<SLOT>(A, W, pt, db, k2, d2); }
-          K4_SUB(14);
           if (__ballot(v3)) { if (v3) emit<SLOT>(A, W, pt, db, k3, d3); }
-          K4_SUB(15);
           const unsigned long long am = __ballot(alive);
           if (lane == 0) {
             W.amask[c] = am;
@@ -598,11 +586,8 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                                                     const uint32_t *__restrict__ worklist, const unsigned int *__restrict__ work_n,
-                                                    unsigned int *__restrict__ work_ctr, unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
+                                                    unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
   __shared__ WaveLds<SLOT> WL[WPB];
-#ifdef YTTM_K4_PROF
-  const unsigned long long t_entry_ = (unsigned long long)clock64();
-#endif
   __shared__ AggLds A;
   __shared__ unsigned long long rkeys[LDSR ? APPLY_LDS_RULES : 1];
   __shared__ uint16_t rridx[LDSR ? APPLY_LDS_RULES : 1];
@@ -676,105 +661,40 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
     if (MERGE) K4_MARK(2);
     if (dirty) {
       K4_COUNT(8);
-#ifdef YTTM_K4_PROF
-      const unsigned long long p4_ = S.pt[4], p5_ = S.pt[5], p3_ = S.pt[3], p6_ = S.pt[6];
-#endif
       process_tile<SLOT, MERGE, LDSR>(W, A, ts, pt, db, rtab, self_x, self_z, z_base, tile, n0, w0, wcur, S);
-#ifdef YTTM_K4_PROF
-      (void)p3_; (void)p4_; (void)p5_; (void)p6_;
-#endif
       wave_sync();  // everyone is done with this tile's LDS state before it is restaged
     } else {
       S.scanned += (unsigned long long)n0;
     }
   };
-  if (MERGE && work_ctr && NT <= DYN_TILES_PER_WAVE * stride) {
-    // Short worklist (the usual case after the first ~100 rounds): a static split leaves the launch waiting for the
-    // unluckiest wavefront (measured: slowest wave 4-7x the mean).  Each wave takes its first two items statically and
-    // then pulls items from a global counter.  The chain counter -> worklist entry -> tile header -> tokens is kept
-    // four items deep, each hop issued one tile ahead of its use, so no hop is waited for.
-    const uint32_t wid = blockIdx.x * WPB + wave;
-    int seq = 0;
-    uint32_t grabbed = 0;  // lane 0: result of the pending counter read (broadcast when used)
-    auto issue_index = [&]() {
-      if (seq < 2) grabbed = wid + (uint32_t)seq * stride;
-      else if (lane == 0) grabbed = 2u * stride + atomicAdd(work_ctr, 1u);
-      seq++;
-    };
-    auto take_index = [&]() { return seq <= 2 ? grabbed : (uint32_t)__shfl((int)grabbed, 0); };  // static values are uniform
-    uint32_t i2, tile2 = 0, tile1 = 0, tile0 = 0, w1 = 0, w0 = 0;
-    int n1 = 0, n0 = 0;
-    bool v2, v1, v0;
-    // prologue: fill the pipe
-    issue_index();
-    i2 = take_index();
-    issue_index();
-    v2 = i2 < NT;
-    if (v2) tile2 = worklist[i2];
-    tile1 = tile2; v1 = v2;
-    i2 = take_index();
-    issue_index();
-    v2 = i2 < NT;
-    if (v2) tile2 = worklist[i2];
-    if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = n1 ? ts.tile_word0[tile1] : 0u; }
-    tile0 = tile1; n0 = n1; w0 = w1; v0 = v1;
-    tile1 = tile2; v1 = v2;
-    i2 = take_index();
-    issue_index();
-    v2 = i2 < NT;
-    if (v2) tile2 = worklist[i2];
-    if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = n1 ? ts.tile_word0[tile1] : 0u; }
-    if (v0) {
-      tile_fetch<SLOT>(r, ts, tile0, n0);
-      wreg_load<SLOT>(wq, ts.wcnt, w0);
-    }
-    while (v0) {
-      const bool dirty = stage_part(n0);
-      const WReg<SLOT> wcur = wq;
-      const uint32_t tile_c = tile0, w_c = w0;
-      const int n_c = n0;
-      // shift the pipe: tokens of the next tile, header of the one after, worklist entry of the third, a new index
-      tile0 = tile1; n0 = n1; w0 = w1; v0 = v1;
-      if (v0) {
-        tile_fetch<SLOT>(r, ts, tile0, n0);
-        wreg_load<SLOT>(wq, ts.wcnt, w0);
-      }
-      tile1 = tile2; v1 = v2;
-      if (v1) { n1 = (int)ts.tile_len[tile1]; w1 = n1 ? ts.tile_word0[tile1] : 0u; }
-      i2 = take_index();
-      issue_index();
-      v2 = v1 && i2 < NT;  // indices of a wave only grow: nothing valid follows an invalid one
-      if (v2) tile2 = worklist[i2];
-      process_part(dirty, tile_c, n_c, w_c, wcur);
-    }
-  } else {
-    int j = 0;
-    if (t < NT) {
+  // (A dynamic hand-out of worklist items through a global counter was tried for short worklists and was slower: the
+  // counter's latency lands in every tile because all waits are vmcnt(0).  Static striding it is.)
+  int j = 0;
+  if (t < NT) {
+    load_headers(t_batch);
+    tile_fetch<SLOT>(r, ts, __shfl(ht, 0), __shfl(hn, 0));
+    wreg_load<SLOT>(wq, ts.wcnt, __shfl(hw, 0));
+  }
+  while (t < NT) {
+    const int n0 = __shfl(hn, j);
+    const uint32_t w0 = __shfl(hw, j);
+    const uint32_t tile = __shfl(ht, j);
+    const bool dirty = stage_part(n0);
+    // next tile of this wave: header from the batch (reload the batch every 64 tiles), tokens prefetched now
+    const uint32_t t_next = t + stride;
+    j++;
+    if (j == 64 && t_next < NT) {
+      j = 0;
+      t_batch = t_next;
       load_headers(t_batch);
-      tile_fetch<SLOT>(r, ts, __shfl(ht, 0), __shfl(hn, 0));
-      wreg_load<SLOT>(wq, ts.wcnt, __shfl(hw, 0));
     }
-    while (t < NT) {
-      const int n0 = __shfl(hn, j);
-      const uint32_t w0 = __shfl(hw, j);
-      const uint32_t tile = __shfl(ht, j);
-      const bool dirty = stage_part(n0);
-      // next tile of this wave: header from the batch (reload the batch every 64 tiles), tokens prefetched now
-      const uint32_t t_next = t + stride;
-      j++;
-      if (j == 64 && t_next < NT) {
-        j = 0;
-        t_batch = t_next;
-        load_headers(t_batch);
-      }
-      const WReg<SLOT> wcur = wq;
-      if (t_next < NT) {
-        tile_fetch<SLOT>(r, ts, __shfl(ht, j), __shfl(hn, j));
-        wreg_load<SLOT>(wq, ts.wcnt, __shfl(hw, j));
-      }
-      process_part(dirty, tile, n0, w0, wcur);
-      t = t_next;
+    const WReg<SLOT> wcur = wq;
+    if (t_next < NT) {
+      tile_fetch<SLOT>(r, ts, __shfl(ht, j), __shfl(hn, j));
+      wreg_load<SLOT>(wq, ts.wcnt, __shfl(hw, j));
     }
+    process_part(dirty, tile, n0, w0, wcur);
+    t = t_next;
   }
   if (MERGE) {
     S.sites = wave_sum_u64(S.sites);
@@ -789,26 +709,6 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
   if (MERGE) K4_MARK(7);   // end of own tile loop
   __syncthreads();
   if (MERGE) K4_MARK(11);  // waiting for the other waves of the workgroup
-#endif
-#ifdef YTTM_K4_PROF
-  {
-    unsigned long long nflush_ = 0;
-    for (int s_ = (int)threadIdx.x; s_ < AGG_SLOTS; s_ += WPB * 64) {
-      const unsigned long long k_ = A.key[s_];
-      if (k_ != PT_EMPTY && (long long)A.val[s_] != 0) {
-        nflush_++;
-        // time the three steps of pt_add for this slot separately
-        const unsigned long long ta_ = (unsigned long long)clock64();
-        unsigned long long i_ = mix64(k_) & pt.mask, kk_;
-        int probes_ = 0;
-        for (;;) { kk_ = ld_agent(pt.key_p(i_)); probes_++; if (kk_ == k_ || kk_ == PT_EMPTY) break; i_ = (i_ + 1) & pt.mask; }
-        const unsigned long long tb_ = (unsigned long long)clock64();
-        if (MERGE && lane == 0) { S.pt[13] += tb_ - ta_; S.pt[14] += (unsigned long long)probes_; S.pt[15]++; }
-      }
-    }
-    (void)nflush_;
-  }
-  if (MERGE) K4_MARK(10);
 #endif
   agg_flush<WPB * 64>(A, pt, db);
   __syncthreads();
@@ -1311,11 +1211,11 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned int *)nullptr, (unsigned long long *)nullptr);
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr);
   else
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned int *)nullptr, (unsigned long long *)nullptr);
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr);
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
@@ -1334,19 +1234,19 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, true>), dim3(tile_grid(ts.n_tiles, 4, 5)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + WL_PARTS, stats);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, false>), dim3(tile_grid(ts.n_tiles, 4, 5)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + WL_PARTS, stats);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats);
   } else {
     if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + WL_PARTS, stats);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, work_n + WL_PARTS, stats);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats);
   }
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
