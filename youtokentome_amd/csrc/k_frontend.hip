@@ -232,7 +232,7 @@ __device__ inline bool seg_equal(const uint8_t *__restrict__ text, unsigned long
 }
 
 constexpr unsigned long long WH_POS_MASK = (1ull << 40) - 1;
-constexpr int WL_SLOTS = 512;  // per-workgroup LDS combiner for frequent words
+constexpr int WL_SLOTS = 128;  // per-workgroup LDS combiner for the most frequent words (measured at 1 GB, dedup ms abcd/Zipf: 32 slots 38/51, 128: 23/19, 256: 24/20, 512: 25/22, 2048: 37/31)
 
 // insert-or-add `count` occurrences of the word whose representative segment starts at `pos` into the HBM table
 __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap,
