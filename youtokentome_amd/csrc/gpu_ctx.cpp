@@ -733,7 +733,8 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     const uint32_t round_id = ++mail_round_;
     t_begin(KT_CAND);
     launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_,
-                    pending_zero_ ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, listed_last_ ? listed_last_ + 4096 : hot_cap_, st_);
+                    pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, listed_last_ ? listed_last_ + 4096 : hot_cap_,
+                    pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, st_);
     pending_zero_ = false;
     t_end(KT_CAND, 20ull * listed_last_);  // (not chained: the host round trip that follows belongs to no kernel family)
     {
@@ -871,15 +872,29 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     n_upd++;
     i = j;
   }
-  prev_flag_toks_.swap(now);
+  // Small batch and a round that runs without the filter pass: the batch goes to the kernels as an argument and nothing is
+  // uploaded (yttm_kernels.h: BatchArgs).  The flag tables in HBM then keep what the last uploaded batch left there.
+  auto dense_class = [&](int ci) {
+    return cls_[ci].n_tiles <= 8192 || (touched_last_ != (~0ull >> 2) && touched_last_ * 10 >= (unsigned long long)n_tiles * 9);
+  };
+  BatchArgs ba{};
+  const bool by_args = k <= (uint32_t)BATCH_ARGS_MAX && vmax < FLAG_LDS_IDS && !cls_[2].n_tiles && (!cls_[0].n_tiles || dense_class(0)) &&
+                       (!cls_[1].n_tiles || dense_class(1)) && !getenv("YTTM_NO_BATCH_ARGS");
+  if (by_args) {
+    ba.k = k;
+    for (uint32_t j = 0; j < k; j++) { ba.xy[2 * j] = xyz[3 * j]; ba.xy[2 * j + 1] = xyz[3 * j + 1]; }
+  } else {
+    prev_flag_toks_.swap(now);
+  }
   t_begin(KT_MERGE);
-  launch_round_begin(h_rules, cap, d_rules_, h_upd, n_upd, d_tokflag_, d_flagbits_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr,
-                     cls_[1].n_tiles ? cls_[1].d_work_n : nullptr, st_);
+  if (!by_args)
+    launch_round_begin(h_rules, cap, d_rules_, h_upd, n_upd, d_tokflag_, d_flagbits_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr,
+                       cls_[1].n_tiles ? cls_[1].d_work_n : nullptr, st_);
   for (int ci = 0; ci < 2; ci++) {
     if (!cls_[ci].n_tiles) continue;
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
-                       cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles,
-                       /*dense=*/cls_[ci].n_tiles <= 8192 || (touched_last_ != (~0ull >> 2) && touched_last_ * 10 >= (unsigned long long)n_tiles * 9), st_);
+                       cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/by_args || dense_class(ci),
+                       by_args ? &ba : nullptr, st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
   t_end(KT_MERGE, 0, /*chain=*/true);
@@ -899,6 +914,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     }
   }
   pending_zero_ = true;
+  zero_ba_ = ba;
   zero_cap_ = cap;
   zero_self_key_ = self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY;
   // repack when the tiles are less than half full.  With the hot-list filter the fill is known for free (the previous
@@ -930,6 +946,20 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
 void GpuCtx::flush_pending_zero() {
   if (!pending_zero_) return;
   chain_event_ = nullptr;
+  if (zero_ba_.k) {  // the batch never went to HBM: upload its rule hash for k_pt_zero (rare: only readers other than the hot scan)
+    std::vector<RuleSlot> tab(zero_cap_);
+    for (auto &r : tab) { r.key = PT_EMPTY; r.z = 0; r.pad = 0; }
+    for (uint32_t j = 0; j < zero_ba_.k; j++) {
+      const uint32_t x = zero_ba_.xy[2 * j], y = zero_ba_.xy[2 * j + 1];
+      if (x == y) continue;
+      const unsigned long long key = pair_key(x, y);
+      unsigned int h = (unsigned int)mix64(key) & (zero_cap_ - 1);
+      while (tab[h].key != PT_EMPTY) h = (h + 1) & (zero_cap_ - 1);
+      tab[h].key = key;
+    }
+    HIP_CHECK(hipMemcpyAsync(d_rules_, tab.data(), tab.size() * sizeof(RuleSlot), hipMemcpyHostToDevice, st_));
+    sync();
+  }
   launch_pt_zero(pt_, d_rules_, zero_cap_, zero_self_key_, st_);
   pending_zero_ = false;
 }

@@ -129,6 +129,7 @@ class GpuCtx {
   bool pending_zero_ = false;
   void flush_pending_zero();
   unsigned int zero_cap_ = 0;
+  BatchArgs zero_ba_{};  // the batch whose pairs are still to be zeroed, when it travelled as a kernel argument
   unsigned long long zero_self_key_ = 0;
   // pair table
   PairTable pt_{};

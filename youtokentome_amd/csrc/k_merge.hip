@@ -25,7 +25,6 @@ constexpr int AGG_SLOTS = 256;   // LDS delta aggregator shared by the waves of 
 // list WL_SEG(n_tiles) entries apart): one cursor bumped by all 1280 workgroups of a launch cost 14 us per round.
 constexpr uint32_t WL_PARTS = 8;
 __host__ __device__ inline size_t WL_SEG(uint32_t n_tiles) { return (size_t)n_tiles + 64; }
-constexpr uint32_t FLAG_LDS_IDS = 32768;  // batch flags of ids below this live in an LDS bitmap (2 bits per id, 8 KB)
 
 // Staged (LDS) token word: bit31 = first token of a word, bit30 = id is the y of some batch rule, bit29 = id is the x
 // of some batch rule, bits 0..28 = id.  HBM tokens carry only bit31 + id.
@@ -586,17 +585,40 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                                                     const uint32_t *__restrict__ worklist, const unsigned int *__restrict__ work_n,
-                                                    unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */) {
+                                                    unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */,
+                                                    BatchArgs ba) {
   __shared__ WaveLds<SLOT> WL[WPB];
   __shared__ AggLds A;
   __shared__ unsigned long long rkeys[LDSR ? APPLY_LDS_RULES : 1];
   __shared__ uint16_t rridx[LDSR ? APPLY_LDS_RULES : 1];
-  agg_init<WPB * 64>(A, MERGE ? flagbits : nullptr);
-  if (LDSR)
+  const bool from_args = MERGE && LDSR && ba.k != 0;  // tables built from the kernel argument, nothing read from HBM
+  agg_init<WPB * 64>(A, (MERGE && !from_args) ? flagbits : nullptr);
+  if (from_args) {
+    for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += WPB * 64) A.flagbits[s] = 0;
+    for (unsigned int i = threadIdx.x; i <= rule_mask; i += WPB * 64) rkeys[i] = PT_EMPTY;
+    __syncthreads();
+    if (threadIdx.x < ba.k) {
+      const uint32_t x = ba.xy[2 * threadIdx.x], y = ba.xy[2 * threadIdx.x + 1];
+      if (x != y) {
+        atomicOr(&A.flagbits[x >> 4], 1u << ((x & 15u) * 2));
+        atomicOr(&A.flagbits[y >> 4], 2u << ((y & 15u) * 2));
+        const unsigned long long key = pair_key(x, y);
+        unsigned int h = (unsigned int)mix64(key) & rule_mask;
+        for (;;) {
+          if (atomicCAS(&rkeys[h], PT_EMPTY, key) == PT_EMPTY) {
+            rridx[h] = (uint16_t)threadIdx.x;
+            break;
+          }
+          h = (h + 1) & rule_mask;
+        }
+      }
+    }
+  } else if (LDSR) {
     for (unsigned int i = threadIdx.x; i <= rule_mask; i += WPB * 64) {
       rkeys[i] = rules[i].key;
       rridx[i] = (uint16_t)(rules[i].z - z_base);
     }
+  }
   const RuleTab<LDSR> rtab{rkeys, rridx, rules, rule_mask, z_base};
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
@@ -878,16 +900,28 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
                                                     unsigned int cap, unsigned int *__restrict__ n_out, unsigned long long *__restrict__ hist,
                                                     unsigned int *__restrict__ done_ctr, unsigned char *__restrict__ mailbox, unsigned int fast,
                                                     uint32_t round_id, unsigned long long *__restrict__ stats, const RuleSlot *__restrict__ zrules,
-                                                    unsigned int zmask, unsigned long long zself) {
+                                                    unsigned int zmask, unsigned long long zself, BatchArgs zba) {
   // zrules != nullptr: the batch that was just applied -- every occurrence of its pairs was merged, so their counts are
   // exactly zero now; they are all on the list (that is where they were picked from), so they are zeroed here instead of
   // by a kernel of their own
   __shared__ unsigned int lh[CAND_BINS];
   __shared__ unsigned int live_blk;
   __shared__ unsigned long long zkeys[FILTER_LDS_KEYS];
-  const bool zkeys_in_lds = zrules && zmask < FILTER_LDS_KEYS;
-  if (zkeys_in_lds)
+  const bool zero_any = zrules != nullptr || zba.k != 0;
+  bool zkeys_in_lds = zrules && zmask < FILTER_LDS_KEYS;
+  if (zba.k) {  // the batch came as a kernel argument: build the key table here (128 slots for <= 32 rules)
+    zmask = 127;
+    zkeys_in_lds = true;
+    for (unsigned int s = threadIdx.x; s <= zmask; s += BLOCK) zkeys[s] = PT_EMPTY;
+    __syncthreads();
+    if (threadIdx.x < zba.k && zba.xy[2 * threadIdx.x] != zba.xy[2 * threadIdx.x + 1]) {
+      const unsigned long long key = pair_key(zba.xy[2 * threadIdx.x], zba.xy[2 * threadIdx.x + 1]);
+      unsigned int h = (unsigned int)mix64(key) & zmask;
+      while (atomicCAS(&zkeys[h], PT_EMPTY, key) != PT_EMPTY) h = (h + 1) & zmask;
+    }
+  } else if (zkeys_in_lds) {
     for (unsigned int s = threadIdx.x; s <= zmask; s += BLOCK) zkeys[s] = zrules[s].key;
+  }
   const RuleProbe zprobe{zkeys_in_lds ? zkeys : nullptr, zrules, zmask};
   for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) lh[b] = 0;
   if (threadIdx.x == 0) live_blk = 0;
@@ -927,7 +961,7 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
       const uint4 rec = *reinterpret_cast<const uint4 *>(pt.key_p(sl));  // key and count in one 16-byte load
       c = (((unsigned long long)rec.w << 32) | rec.z) & PT_CNT;
       k = ((unsigned long long)rec.y << 32) | rec.x;
-      if (c && zrules && (k == zself || zprobe.has((uint32_t)(k >> 32), (uint32_t)k))) {
+      if (c && zero_any && (k == zself || zprobe.has((uint32_t)(k >> 32), (uint32_t)k))) {
         *pt.cnt_p(sl) = PT_HOT;  // listed, count 0
         c = 0;
       }
@@ -1211,16 +1245,17 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr);
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{});
   else
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr);
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{});
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
-                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, hipStream_t st) {
+                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba, hipStream_t st) {
   if (!ts.n_tiles) return;
+  const BatchArgs bargs = ba ? *ba : BatchArgs{};
   const RuleSlot *frules = exact_filter ? rules : nullptr;
   // dense round (nearly every tile held a site last round): the filter pass would keep everything -- the apply kernel
   // takes all tiles and dismisses the few clean ones itself
@@ -1234,19 +1269,19 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, true>), dim3(tile_grid(ts.n_tiles, 4, 5)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, false>), dim3(tile_grid(ts.n_tiles, 4, 5)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
   } else {
     if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
   }
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
@@ -1259,14 +1294,14 @@ void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t 
 void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
                      unsigned long long *hist, unsigned int *done_ctr, unsigned char *mailbox, unsigned int fast, uint32_t round_id,
                      unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, unsigned int listed_hint,
-                     hipStream_t st) {
+                     const BatchArgs *zba, hipStream_t st) {
   // one entry per thread; every workgroup costs ~11 ns of serialised ticket/total atomics at the end, so no more of them
   // than the list needs (the statistics rows need >= BLK_ROWS / 64 = 24)
   unsigned int g = (listed_hint + BLOCK - 1) / BLOCK;
   if (g < 32) g = 32;
   if (g > 256) g = 256;
   hipLaunchKernelGGL(k_hot_scan, dim3(g), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id,
-                     stats, zrules, zmask, zself);
+                     stats, zrules, zmask, zself, zba ? *zba : BatchArgs{});
 }
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st) {
   unsigned long long n_slots = pt.mask + 1;

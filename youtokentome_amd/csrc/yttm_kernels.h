@@ -45,10 +45,19 @@ void launch_tile_len(const unsigned long long *tile_start, unsigned int n_tiles,
 
 // ---- merge loop (k_merge.hip)
 // cls: 0 = class A tiles (slot 1024), 1 = class B tiles (slot 4096)
+// A small batch travels as a kernel argument: the apply kernel and the candidate scan build their LDS tables (token flags, rule
+// hash) from it, and the round needs no prologue kernel, no rule upload and no flag table in HBM.  Used when the whole round
+// runs without the filter pass (small or dense tile sets), all ids fit the LDS flag bitmap and there is no class-C tile.
+constexpr int BATCH_ARGS_MAX = 32;
+constexpr uint32_t FLAG_LDS_IDS = 32768;  // batch flags of ids below this live in an LDS bitmap (2 bits per id, 8 KB)
+struct BatchArgs {
+  uint32_t k;                        // 0: not used (tables come from HBM)
+  uint32_t xy[2 * BATCH_ARGS_MAX];   // rule j of the batch merges (xy[2j], xy[2j+1]) into z_base + j; x == y: the self rule (skipped)
+};
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st);
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
-                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, hipStream_t st);
+                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba, hipStream_t st);
 void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, unsigned int nom, unsigned long long total,
                    unsigned long long *gstart, unsigned int n_new, uint32_t *new_tok, uint32_t *new_len, uint32_t *new_word0, hipStream_t st);
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
@@ -56,7 +65,7 @@ void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t 
 void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
                      unsigned long long *hist, unsigned int *done_ctr, unsigned char *mailbox, unsigned int fast, uint32_t round_id,
                      unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, unsigned int listed_hint,
-                     hipStream_t st);
+                     const BatchArgs *zba, hipStream_t st);
 void launch_fold_stats(unsigned long long *stats, unsigned int *n_keys, hipStream_t st);
 constexpr int STATS_WORDS = 32 + 8 * 1536;  // totals + one row per workgroup (k_merge.hip: BLK_BASE, BLK_ROWS)
 void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, const uint32_t *upd, unsigned int n_upd,
