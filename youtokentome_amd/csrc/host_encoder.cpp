@@ -74,6 +74,15 @@ BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *
     for (uint32_t s : {9u, 10u, 11u, 12u, 13u, 32u, 9601u}) cpmap[s] = CP_SPACE;
     dev_->d_cpmap = dalloc<uint32_t>(N_CODEPOINTS);
     HIP_CHECK(hipMemcpy(dev_->d_cpmap, cpmap.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice));
+    {  // working tokens of the encode kernel keep two flag bits: ids must stay below 2^30 - 16
+      uint32_t max_id = 0;
+      for (auto &c : char2id) max_id = std::max(max_id, c.second);
+      for (auto &r : bpe_state.rules) max_id = std::max(max_id, std::max(r.z, std::max(r.x, r.y)));
+      if (max_id >= 0x3ffffff0u) {
+        *ret_status = Status(1, "token ids of 2^30 and above are not supported by the MI355X encoder");
+        return;
+      }
+    }
     // rule hash: (x,y) -> rule index; later rules overwrite earlier duplicates like rule2id (bpe.cpp:1672-1674)
     const size_t nr = bpe_state.rules.size();
     unsigned int cap = 64;

@@ -16,7 +16,9 @@ constexpr int ENC_WAVES = ENC_WAVES_PER_BLOCK;
 constexpr int ENC_THREADS = ENC_WAVES * 64;
 constexpr uint32_t ENC_DIRTY = 0xfffffffeu;  // pair (p,p+1) must be looked up again
 constexpr uint32_t ENC_SITE = 0x80000000u;   // pair (p,p+1) is merged in this round
-constexpr uint32_t ENC_UNKP = 0x7ffffff0u;   // placeholder token for a run of unknown chars (bpe.cpp:1517-1527)
+constexpr uint32_t ENC_SENT = 0x40000000u;   // bit 30 of a working token: first token of a sentence (several sentences share a wave)
+constexpr uint32_t ENC_IDM = 0x3fffffffu;    // id bits of a working token (bit 31 = TOK_WS)
+constexpr uint32_t ENC_UNKP = 0x3ffffff0u;   // placeholder token for a run of unknown chars (bpe.cpp:1517-1527)
 constexpr uint32_t ENC_INF = 0xffffffffu;
 
 struct LdsArr {
@@ -120,7 +122,7 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
       wm.set(i, i > ws ? (uint32_t)(i - 1) : NIL);
     }
     for (int i = ws; i + 1 < we; i++) {  // bpe.cpp:1556-1558
-      const uint32_t slot = enc_rule_lookup(m, wt.get(i) & TOK_MASK, wt.get(i + 1) & TOK_MASK);
+      const uint32_t slot = enc_rule_lookup(m, wt.get(i) & ENC_IDM, wt.get(i + 1) & ENC_IDM);
       if (slot != ENC_INF) ev_insert<A>(ev, ne, ((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)i);
     }
     uint32_t draw = 0;
@@ -138,7 +140,7 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
       const uint32_t p2 = wr.get(p1);
       const unsigned long long xy = m.rule_xy[rule];
       const uint32_t t1 = wt.get(p1);
-      if (t1 == DEAD || (t1 & TOK_MASK) != (uint32_t)(xy >> 32) || p2 == NIL || (wt.get((int)p2) & TOK_MASK) != (uint32_t)xy) continue;  // :1569-1572
+      if (t1 == DEAD || (t1 & ENC_IDM) != (uint32_t)(xy >> 32) || p2 == NIL || (wt.get((int)p2) & ENC_IDM) != (uint32_t)xy) continue;  // :1569-1572
       const uint32_t p0 = wm.get(p1), p3 = wr.get((int)p2);
       wt.set((int)p2, DEAD);
       wr.set((int)p2, NIL);
@@ -146,11 +148,11 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
       wr.set(p1, p3);
       if (p3 != NIL) wm.set((int)p3, (uint32_t)p1);
       if (p0 != NIL) {
-        const uint32_t slot = enc_rule_lookup(m, wt.get((int)p0) & TOK_MASK, wt.get(p1) & TOK_MASK);
+        const uint32_t slot = enc_rule_lookup(m, wt.get((int)p0) & ENC_IDM, wt.get(p1) & ENC_IDM);
         if (slot != ENC_INF) ev_insert<A>(ev, ne, ((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)p0);
       }
       if (p3 != NIL) {
-        const uint32_t slot = enc_rule_lookup(m, wt.get(p1) & TOK_MASK, wt.get((int)p3) & TOK_MASK);
+        const uint32_t slot = enc_rule_lookup(m, wt.get(p1) & ENC_IDM, wt.get((int)p3) & ENC_IDM);
         if (slot != ENC_INF) ev_insert<A>(ev, ne, ((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)p1);
       }
     }
@@ -234,6 +236,124 @@ __device__ inline uint32_t enc_rule_z(const EncModel &m, uint32_t r) {
   return m.z_base + r + (r >= m.z_bp[0]) + (r >= m.z_bp[1]) + (r >= m.z_bp[2]) + (r >= m.z_bp[3]);
 }
 
+// Merge rounds of the deterministic encoder over the n tokens in wt (words = TOK_WS segments; sentence boundaries are word
+// boundaries, so several sentences can share the arrays).  Returns the new token count.
+template <class A>
+__device__ int merge_rounds(const EncModel &m, const uint32_t *bloom, A wt, A wr, A wm, int n) {
+  const int lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+  // wr[p] = priority (rule index) of the pair (p,p+1), ENC_INF if it has no rule, ENC_DIRTY if unknown.  Only pairs next
+  // to a merge change, so after the first round a handful of pairs per word are looked up again; a pair is first
+  // tested against the LDS-resident Bloom filter of all rules, and only a positive goes to the rule hash in L2/HBM.
+  for (int c = 0; c < ((n + 63) >> 6); c++) {
+    const int p = c * 64 + lane;
+    if (p < n) {
+      wr.set(p, ENC_DIRTY);
+      if (wt.get(p) & TOK_WS) wm.set(p, ENC_INF);
+    }
+  }
+  wave_sync();
+  for (;;) {
+    const int nchunks = (n + 63) >> 6;
+    // phase 1+2: (re)compute dirty pairs and fold every priority into its word's minimum (kept at the word's first
+    // position; reset to ENC_INF when that position was written)
+    int carry_ws = 0;
+    for (int c = 0; c < nchunks; c++) {
+      const int p = c * 64 + lane;
+      const uint32_t t0 = p < n ? wt.get(p) : 0u;
+      const bool ws = p < n && (t0 & TOK_WS);
+      const unsigned long long W = __ballot(ws);
+      int wsp = carry_ws;
+      const unsigned long long wle = W & ((2ull << lane) - 1ull);
+      if (wle) wsp = c * 64 + 63 - __clzll((long long)wle);
+      if (W) carry_ws = c * 64 + 63 - __clzll((long long)W);
+      if (p < n) {
+        uint32_t r = wr.get(p);
+        if (r == ENC_DIRTY) {
+          r = ENC_INF;
+          if (p + 1 < n) {
+            const uint32_t t1 = wt.get(p + 1);
+            const uint32_t a = t0 & ENC_IDM, b = t1 & ENC_IDM;
+            if (!(t1 & TOK_WS) && a != ENC_UNKP && b != ENC_UNKP) r = enc_pair_prio(m, bloom, a, b);
+          }
+          wr.set(p, r);
+        }
+        if (r != ENC_INF) wm.amin(wsp, r);
+      }
+    }
+    wave_sync();
+    // phase 3: merge sites = pairs carrying their word's minimum; x==x pairs only at even offsets from the run start
+    // (= the left-to-right greedy of the reference).  Marked in place (ENC_SITE) before anything moves.
+    bool any = false;
+    carry_ws = 0;
+    for (int c = 0; c < nchunks; c++) {
+      const int p = c * 64 + lane;
+      const uint32_t t0 = p < n ? wt.get(p) : 0;
+      const bool ws = p < n && (t0 & TOK_WS);
+      const unsigned long long W = __ballot(ws);
+      int wsp = carry_ws;
+      const unsigned long long wle = W & ((2ull << lane) - 1ull);
+      if (wle) wsp = c * 64 + 63 - __clzll((long long)wle);
+      if (W) carry_ws = c * 64 + 63 - __clzll((long long)W);
+      bool site = false;
+      if (p < n) {
+        const uint32_t r = wr.get(p);
+        if (r != ENC_INF && r == wm.get(wsp)) {
+          site = true;
+          const uint32_t a = t0 & ENC_IDM;
+          if ((wt.get(p + 1) & ENC_IDM) == a) {
+            int q = p;
+            while (q > 0 && !(wt.get(q) & TOK_WS) && (wt.get(q - 1) & ENC_IDM) == a) q--;
+            site = ((p - q) & 1) == 0;
+          }
+          if (site) wr.set(p, r | ENC_SITE);
+        }
+      }
+      any = any || __ballot(site) != 0;
+    }
+    wave_sync();
+    if (!any) break;
+    // phase 4: apply + compact in place (ascending chunks; writes never pass unread data).  A surviving pair keeps its
+    // priority unless one of its two tokens changed.
+    int base = 0;
+    bool prev_site = false;  // site flag of the last position of the previous chunk
+    for (int c = 0; c < nchunks; c++) {
+      const int p = c * 64 + lane;
+      uint32_t t0 = 0, r = ENC_INF, r_next = ENC_INF;
+      if (p < n) {
+        t0 = wt.get(p);
+        r = wr.get(p);
+        if (p + 1 < n) r_next = wr.get(p + 1);
+      }
+      const bool site = p < n && r != ENC_INF && r != ENC_DIRTY && (r & ENC_SITE);
+      const bool next_site = r_next != ENC_INF && r_next != ENC_DIRTY && (r_next & ENC_SITE);
+      const unsigned long long SM = __ballot(site);
+      const bool dead = lane == 0 ? prev_site : ((SM >> (lane - 1)) & 1ull);
+      const bool alive = p < n && !dead;
+      const unsigned long long AM = __ballot(alive);
+      uint32_t nt = t0, nr = r;
+      if (site) {
+        nt = enc_rule_z(m, r & ~ENC_SITE) | (t0 & (TOK_WS | ENC_SENT));
+        nr = ENC_DIRTY;
+      } else if (next_site) {
+        nr = ENC_DIRTY;
+      }
+      wave_sync();  // all lanes have read their inputs before anyone overwrites lower positions
+      if (alive) {
+        const int np = base + __popcll(AM & lt);
+        wt.set(np, nt);
+        wr.set(np, nr);
+        if (nt & TOK_WS) wm.set(np, ENC_INF);
+      }
+      base += __popcll(AM);
+      prev_site = (SM >> 63) & 1ull;
+      wave_sync();
+    }
+    n = base;
+  }
+  return n;
+}
+
 // Cooperative path: one wavefront encodes one sentence, lanes = token positions.  wt = tokens (bit31 = first token of a
 // word), wr = priority of the pair that starts at p, wm = per-word minimum priority stored at the word's first position.
 // Sentences too long for the LDS arrays run the same code on HBM scratch (GlbArr).
@@ -248,115 +368,7 @@ __device__ void encode_wave(const EncModel &m, const uint32_t *bloom, const uint
   // ---- B. merge rounds -----------------------------------------------------------------------------------------------
   if (drop.enabled) n = dropout_merge<A>(m, wt, wr, wm, n, drop, sidx);
   else {
-    // wr[p] = priority (rule index) of the pair (p,p+1), ENC_INF if it has no rule, ENC_DIRTY if unknown.  Only pairs next
-    // to a merge change, so after the first round a handful of pairs per word are looked up again; a pair is first
-    // tested against the LDS-resident Bloom filter of all rules, and only a positive goes to the rule hash in L2/HBM.
-    for (int c = 0; c < ((n + 63) >> 6); c++) {
-      const int p = c * 64 + lane;
-      if (p < n) {
-        wr.set(p, ENC_DIRTY);
-        if (wt.get(p) & TOK_WS) wm.set(p, ENC_INF);
-      }
-    }
-    wave_sync();
-    for (;;) {
-      const int nchunks = (n + 63) >> 6;
-      // phase 1+2: (re)compute dirty pairs and fold every priority into its word's minimum (kept at the word's first
-      // position; reset to ENC_INF when that position was written)
-      int carry_ws = 0;
-      for (int c = 0; c < nchunks; c++) {
-        const int p = c * 64 + lane;
-        const uint32_t t0 = p < n ? wt.get(p) : 0u;
-        const bool ws = p < n && (t0 & TOK_WS);
-        const unsigned long long W = __ballot(ws);
-        int wsp = carry_ws;
-        const unsigned long long wle = W & ((2ull << lane) - 1ull);
-        if (wle) wsp = c * 64 + 63 - __clzll((long long)wle);
-        if (W) carry_ws = c * 64 + 63 - __clzll((long long)W);
-        if (p < n) {
-          uint32_t r = wr.get(p);
-          if (r == ENC_DIRTY) {
-            r = ENC_INF;
-            if (p + 1 < n) {
-              const uint32_t t1 = wt.get(p + 1);
-              const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
-              if (!(t1 & TOK_WS) && a != ENC_UNKP && b != ENC_UNKP) r = enc_pair_prio(m, bloom, a, b);
-            }
-            wr.set(p, r);
-          }
-          if (r != ENC_INF) wm.amin(wsp, r);
-        }
-      }
-      wave_sync();
-      // phase 3: merge sites = pairs carrying their word's minimum; x==x pairs only at even offsets from the run start
-      // (= the left-to-right greedy of the reference).  Marked in place (ENC_SITE) before anything moves.
-      bool any = false;
-      carry_ws = 0;
-      for (int c = 0; c < nchunks; c++) {
-        const int p = c * 64 + lane;
-        const uint32_t t0 = p < n ? wt.get(p) : 0;
-        const bool ws = p < n && (t0 & TOK_WS);
-        const unsigned long long W = __ballot(ws);
-        int wsp = carry_ws;
-        const unsigned long long wle = W & ((2ull << lane) - 1ull);
-        if (wle) wsp = c * 64 + 63 - __clzll((long long)wle);
-        if (W) carry_ws = c * 64 + 63 - __clzll((long long)W);
-        bool site = false;
-        if (p < n) {
-          const uint32_t r = wr.get(p);
-          if (r != ENC_INF && r == wm.get(wsp)) {
-            site = true;
-            const uint32_t a = t0 & TOK_MASK;
-            if ((wt.get(p + 1) & TOK_MASK) == a) {
-              int q = p;
-              while (q > 0 && !(wt.get(q) & TOK_WS) && (wt.get(q - 1) & TOK_MASK) == a) q--;
-              site = ((p - q) & 1) == 0;
-            }
-            if (site) wr.set(p, r | ENC_SITE);
-          }
-        }
-        any = any || __ballot(site) != 0;
-      }
-      wave_sync();
-      if (!any) break;
-      // phase 4: apply + compact in place (ascending chunks; writes never pass unread data).  A surviving pair keeps its
-      // priority unless one of its two tokens changed.
-      int base = 0;
-      bool prev_site = false;  // site flag of the last position of the previous chunk
-      for (int c = 0; c < nchunks; c++) {
-        const int p = c * 64 + lane;
-        uint32_t t0 = 0, r = ENC_INF, r_next = ENC_INF;
-        if (p < n) {
-          t0 = wt.get(p);
-          r = wr.get(p);
-          if (p + 1 < n) r_next = wr.get(p + 1);
-        }
-        const bool site = p < n && r != ENC_INF && r != ENC_DIRTY && (r & ENC_SITE);
-        const bool next_site = r_next != ENC_INF && r_next != ENC_DIRTY && (r_next & ENC_SITE);
-        const unsigned long long SM = __ballot(site);
-        const bool dead = lane == 0 ? prev_site : ((SM >> (lane - 1)) & 1ull);
-        const bool alive = p < n && !dead;
-        const unsigned long long AM = __ballot(alive);
-        uint32_t nt = t0, nr = r;
-        if (site) {
-          nt = enc_rule_z(m, r & ~ENC_SITE) | (t0 & TOK_WS);
-          nr = ENC_DIRTY;
-        } else if (next_site) {
-          nr = ENC_DIRTY;
-        }
-        wave_sync();  // all lanes have read their inputs before anyone overwrites lower positions
-        if (alive) {
-          const int np = base + __popcll(AM & lt);
-          wt.set(np, nt);
-          wr.set(np, nr);
-          if (nt & TOK_WS) wm.set(np, ENC_INF);
-        }
-        base += __popcll(AM);
-        prev_site = (SM >> 63) & 1ull;
-        wave_sync();
-      }
-      n = base;
-    }
+    n = merge_rounds<A>(m, bloom, wt, wr, wm, n);
   }
   // ---- C. output (bpe.cpp:1591-1630): unknown runs -> unk_id; the id-0 quirk drops an unmerged leading "▁" whose id is 0
   const int nb = bos ? 1 : 0;
@@ -371,7 +383,7 @@ __device__ void encode_wave(const EncModel &m, const uint32_t *bloom, const uint
     }
     const unsigned long long E = __ballot(emit);
     if (emit) {
-      const uint32_t id = t0 & TOK_MASK;
+      const uint32_t id = t0 & ENC_IDM;
       wm.set(total - nb + __popcll(E & lt), id == ENC_UNKP ? (uint32_t)m.unk_id : id);
     }
     total += __popcll(E);
@@ -388,11 +400,104 @@ __device__ void encode_wave(const EncModel &m, const uint32_t *bloom, const uint
   if (lane == 0) *count_out = (uint32_t)n_ids;
 }
 
+// Several consecutive sentences share one wavefront's arrays (dropout off, LDS path): a 128-byte sentence is 129 tokens --
+// two full chunks and a third with one lane busy -- and the fixed cost of a round is per chunk.  Sentences [s, e) are
+// tokenized back to back while they fit, merged together (words are independent), and written out one by one; returns how
+// many sentences were consumed (>= 1: the caller made sure the first one fits).
+__device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8_t *__restrict__ text,
+                           const unsigned long long *__restrict__ offsets, unsigned long long s, unsigned long long e, LdsArr wt, LdsArr wr,
+                           LdsArr wm, int bos, int eos, int reverse, int32_t *__restrict__ scratch_ids, uint32_t *__restrict__ counts) {
+  const int lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+  int n = 0, consumed = 0, k = 0;
+  unsigned long long my_sid = 0;  // lane j: index of the j-th non-empty sentence of the pack
+  for (unsigned long long j = s; j < e && k < 64; j++) {
+    const unsigned long long b0 = offsets[j], nbytes = offsets[j + 1] - b0;
+    if (nbytes + 1 > (unsigned long long)(ENC_WCAP - n)) break;
+    const int n0 = n;
+    n = enc_tokenize<LdsArr>(m, text + b0, nbytes, wt, n0);
+    wave_sync();
+    if (n == n0) {  // no token at all: only bos / eos
+      const int n_ids = (bos ? 1 : 0) + (eos ? 1 : 0);
+      int32_t *out = scratch_ids + 2 * b0 + 2 * j;
+      if (lane == 0) {
+        if (bos) out[reverse ? n_ids - 1 : 0] = m.bos_id;
+        if (eos) out[reverse ? 0 : n_ids - 1] = m.eos_id;
+        counts[j] = (uint32_t)n_ids;
+      }
+    } else {
+      if (lane == 0) wt.set(n0, wt.get(n0) | ENC_SENT);
+      if (lane == k) my_sid = j;
+      k++;
+    }
+    consumed++;
+  }
+  wave_sync();
+  if (k == 0) return consumed;
+  for (int c = 0; c < ((n + 63) >> 6); c++) {
+    const int p = c * 64 + lane;
+    if (p < n) {
+      wr.set(p, ENC_DIRTY);
+      if (wt.get(p) & TOK_WS) wm.set(p, ENC_INF);
+    }
+  }
+  wave_sync();
+  n = merge_rounds<LdsArr>(m, bloom, wt, wr, wm, n);
+  // ---- output (bpe.cpp:1591-1630).  wm[o] = ids of sentence o of the pack, wr[o] = ids emitted before its first token
+  if (lane < k) wm.set(lane, 0);
+  wave_sync();
+  const int nchunks = (n + 63) >> 6;
+  int ord_carry = -1, emitted = 0;  // ordinal of the sentence the previous chunk ended in; ids emitted so far
+  for (int c = 0; c < nchunks; c++) {
+    const int p = c * 64 + lane;
+    const uint32_t t0 = p < n ? wt.get(p) : 0u;
+    const bool sent = p < n && (t0 & ENC_SENT);
+    const bool emit = p < n && (t0 & ~ENC_SENT) != TOK_WS;  // (id 0 | TOK_WS): an unmerged "▁" with id 0 is dropped
+    const unsigned long long SB = __ballot(sent), E = __ballot(emit);
+    const int ord = ord_carry + __popcll(SB & (lt | (1ull << lane)));
+    if (sent) wr.set(ord, (uint32_t)(emitted + __popcll(E & lt)));
+    if (emit) atomicAdd(&wm.p[ord], 1u);
+    ord_carry += __popcll(SB);
+    emitted += __popcll(E);
+  }
+  wave_sync();
+  ord_carry = -1;
+  emitted = 0;
+  const int nb = bos ? 1 : 0;
+  for (int c = 0; c < nchunks; c++) {
+    const int p = c * 64 + lane;
+    const uint32_t t0 = p < n ? wt.get(p) : 0u;
+    const bool sent = p < n && (t0 & ENC_SENT);
+    const bool emit = p < n && (t0 & ~ENC_SENT) != TOK_WS;
+    const unsigned long long SB = __ballot(sent), E = __ballot(emit);
+    const int ord = ord_carry + __popcll(SB & (lt | (1ull << lane)));
+    const unsigned long long sid = __shfl(my_sid, ord < 0 ? 0 : ord);
+    if (p < n) {
+      const int n_ids = (int)wm.get(ord) + nb + (eos ? 1 : 0);
+      int32_t *out = scratch_ids + 2 * offsets[sid] + 2 * sid;
+      if (emit) {
+        const int q = nb + emitted + __popcll(E & lt) - (int)wr.get(ord);
+        const uint32_t id = t0 & ENC_IDM;
+        out[reverse ? (n_ids - 1 - q) : q] = (int32_t)(id == ENC_UNKP ? (uint32_t)m.unk_id : id);
+      }
+      if (sent) {
+        if (bos) out[reverse ? n_ids - 1 : 0] = m.bos_id;
+        if (eos) out[reverse ? 0 : n_ids - 1] = m.eos_id;
+        counts[sid] = (uint32_t)n_ids;
+      }
+    }
+    ord_carry += __popcll(SB);
+    emitted += __popcll(E);
+  }
+  wave_sync();
+  return consumed;
+}
+
 __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8_t *__restrict__ text,
                                                    const unsigned long long *__restrict__ offsets, unsigned long long n_sent, int bos,
                                                    int eos, int reverse, int32_t *__restrict__ scratch_ids,
                                                    uint32_t *__restrict__ counts, uint32_t *__restrict__ work,
-                                                   unsigned long long work_stride, DropoutArgs drop, unsigned long long drop_stride) {
+                                                   unsigned long long work_stride, DropoutArgs drop, unsigned long long drop_stride, unsigned int group) {
   __shared__ uint32_t lds[ENC_WAVES][3][ENC_WCAP];
   __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
   for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += ENC_THREADS) bloom[i] = m.bloom[i];
@@ -400,24 +505,35 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
   const int wave = (int)(threadIdx.x >> 6);
   const unsigned long long gw = (unsigned long long)blockIdx.x * ENC_WAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * ENC_WAVES;
-  for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
-    const unsigned long long b0 = offsets[sidx], b1 = offsets[sidx + 1];
-    const unsigned long long nbytes = b1 - b0;
-    int32_t *out = scratch_ids + 2 * b0 + 2 * sidx;  // capacity 2*nbytes + 2 ids per sentence
-    DropoutArgs d = drop;
-    if (d.enabled) {  // per-wave slice of the dropout scratch: word starts, then the event queues
-      d.wsl = drop.wsl + gw * 7 * drop_stride;
-      d.ev = reinterpret_cast<unsigned long long *>(drop.wsl + gw * 7 * drop_stride + drop_stride);
-    }
-    if (nbytes + 1 <= (unsigned long long)ENC_WCAP) {
+  // a wavefront owns groups of `group` consecutive sentences and packs as many of a group at a time as fit its LDS arrays
+  const unsigned long long n_groups = (n_sent + group - 1) / group;
+  for (unsigned long long grp = gw; grp < n_groups; grp += n_waves) {
+    unsigned long long sidx = grp * group;
+    const unsigned long long grp_end = sidx + group < n_sent ? sidx + group : n_sent;
+    while (sidx < grp_end) {
+      const unsigned long long b0 = offsets[sidx], b1 = offsets[sidx + 1];
+      const unsigned long long nbytes = b1 - b0;
       LdsArr a{lds[wave][0]}, b{lds[wave][1]}, c{lds[wave][2]};
-      encode_wave(m, bloom, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx], d, sidx);
-    } else {
-      uint32_t *w = work + gw * 3 * work_stride;
-      GlbArr a{w}, b{w + work_stride}, c{w + 2 * work_stride};
-      encode_wave(m, bloom, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx], d, sidx);
+      if (!drop.enabled && nbytes + 1 <= (unsigned long long)ENC_WCAP) {
+        sidx += (unsigned long long)encode_pack(m, bloom, text, offsets, sidx, grp_end, a, b, c, bos, eos, reverse, scratch_ids, counts);
+        continue;
+      }
+      int32_t *out = scratch_ids + 2 * b0 + 2 * sidx;  // capacity 2*nbytes + 2 ids per sentence
+      DropoutArgs d = drop;
+      if (d.enabled) {  // per-wave slice of the dropout scratch: word starts, then the event queues
+        d.wsl = drop.wsl + gw * 7 * drop_stride;
+        d.ev = reinterpret_cast<unsigned long long *>(drop.wsl + gw * 7 * drop_stride + drop_stride);
+      }
+      if (nbytes + 1 <= (unsigned long long)ENC_WCAP) {
+        encode_wave(m, bloom, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx], d, sidx);
+      } else {
+        uint32_t *w = work + gw * 3 * work_stride;
+        GlbArr ga{w}, gb{w + work_stride}, gc{w + 2 * work_stride};
+        encode_wave(m, bloom, text + b0, nbytes, ga, gb, gc, bos, eos, reverse, out, &counts[sidx], d, sidx);
+      }
+      wave_sync();
+      sidx++;
     }
-    wave_sync();
   }
 }
 
@@ -446,8 +562,12 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   d.seed = seed;
   d.wsl = drop_scratch;
   d.ev = nullptr;
+  // sentences per wavefront group: large enough that packs are full, small enough that every wavefront of the launch has work
+  unsigned long long group = n_sent / ((unsigned long long)n_blocks * ENC_WAVES * 4);
+  if (group < 1) group = 1;
+  if (group > 24) group = 24;
   hipLaunchKernelGGL(k5_encode, dim3(n_blocks), dim3(ENC_THREADS), 0, st, m, text, offsets, n_sent, bos, eos, reverse, scratch_ids, counts, work,
-                     work_stride, d, drop_stride);
+                     work_stride, d, drop_stride, (unsigned int)group);
 }
 void launch_encode_gather(const int32_t *scratch_ids, const unsigned long long *offsets, const unsigned long long *out_off,
                           unsigned long long n_sent, int32_t *ids_out, hipStream_t st) {
