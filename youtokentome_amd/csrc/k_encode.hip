@@ -144,7 +144,7 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
       const uint32_t p0 = wm.get(p1), p3 = wr.get((int)p2);
       wt.set((int)p2, DEAD);
       wr.set((int)p2, NIL);
-      wt.set(p1, m.rule_z[rule] | (t1 & TOK_WS));
+      wt.set(p1, m.rule_z[rule] | (t1 & (TOK_WS | ENC_SENT)));
       wr.set(p1, p3);
       if (p3 != NIL) wm.set((int)p3, (uint32_t)p1);
       if (p0 != NIL) {
@@ -406,7 +406,8 @@ __device__ void encode_wave(const EncModel &m, const uint32_t *bloom, const uint
 // many sentences were consumed (>= 1: the caller made sure the first one fits).
 __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8_t *__restrict__ text,
                            const unsigned long long *__restrict__ offsets, unsigned long long s, unsigned long long e, LdsArr wt, LdsArr wr,
-                           LdsArr wm, int bos, int eos, int reverse, int32_t *__restrict__ scratch_ids, uint32_t *__restrict__ counts) {
+                           LdsArr wm, int bos, int eos, int reverse, int32_t *__restrict__ scratch_ids, uint32_t *__restrict__ counts,
+                           const DropoutArgs &drop) {
   const int lane = lane_id();
   const unsigned long long lt = lanemask_lt();
   int n = 0, consumed = 0, k = 0;
@@ -434,15 +435,20 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
   }
   wave_sync();
   if (k == 0) return consumed;
-  for (int c = 0; c < ((n + 63) >> 6); c++) {
-    const int p = c * 64 + lane;
-    if (p < n) {
-      wr.set(p, ENC_DIRTY);
-      if (wt.get(p) & TOK_WS) wm.set(p, ENC_INF);
+  if (drop.enabled) {  // BPE-dropout: one word per lane (the RNG stream is keyed by the pack's first sentence)
+    n = dropout_merge<LdsArr>(m, wt, wr, wm, n, drop, s);
+  } else {
+    for (int c = 0; c < ((n + 63) >> 6); c++) {
+      const int p = c * 64 + lane;
+      if (p < n) {
+        wr.set(p, ENC_DIRTY);
+        if (wt.get(p) & TOK_WS) wm.set(p, ENC_INF);
+      }
     }
+    wave_sync();
+    n = merge_rounds<LdsArr>(m, bloom, wt, wr, wm, n);
   }
   wave_sync();
-  n = merge_rounds<LdsArr>(m, bloom, wt, wr, wm, n);
   // ---- output (bpe.cpp:1591-1630).  wm[o] = ids of sentence o of the pack, wr[o] = ids emitted before its first token
   if (lane < k) wm.set(lane, 0);
   wave_sync();
@@ -514,23 +520,20 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
       const unsigned long long b0 = offsets[sidx], b1 = offsets[sidx + 1];
       const unsigned long long nbytes = b1 - b0;
       LdsArr a{lds[wave][0]}, b{lds[wave][1]}, c{lds[wave][2]};
-      if (!drop.enabled && nbytes + 1 <= (unsigned long long)ENC_WCAP) {
-        sidx += (unsigned long long)encode_pack(m, bloom, text, offsets, sidx, grp_end, a, b, c, bos, eos, reverse, scratch_ids, counts);
-        continue;
-      }
-      int32_t *out = scratch_ids + 2 * b0 + 2 * sidx;  // capacity 2*nbytes + 2 ids per sentence
       DropoutArgs d = drop;
       if (d.enabled) {  // per-wave slice of the dropout scratch: word starts, then the event queues
         d.wsl = drop.wsl + gw * 7 * drop_stride;
         d.ev = reinterpret_cast<unsigned long long *>(drop.wsl + gw * 7 * drop_stride + drop_stride);
       }
       if (nbytes + 1 <= (unsigned long long)ENC_WCAP) {
-        encode_wave(m, bloom, text + b0, nbytes, a, b, c, bos, eos, reverse, out, &counts[sidx], d, sidx);
-      } else {
-        uint32_t *w = work + gw * 3 * work_stride;
-        GlbArr ga{w}, gb{w + work_stride}, gc{w + 2 * work_stride};
-        encode_wave(m, bloom, text + b0, nbytes, ga, gb, gc, bos, eos, reverse, out, &counts[sidx], d, sidx);
+        sidx += (unsigned long long)encode_pack(m, bloom, text, offsets, sidx, grp_end, a, b, c, bos, eos, reverse, scratch_ids, counts, d);
+        continue;
       }
+      // too long for the LDS arrays: one sentence at a time on the wavefront's HBM scratch
+      int32_t *out = scratch_ids + 2 * b0 + 2 * sidx;  // capacity 2*nbytes + 2 ids per sentence
+      uint32_t *w = work + gw * 3 * work_stride;
+      GlbArr ga{w}, gb{w + work_stride}, gc{w + 2 * work_stride};
+      encode_wave(m, bloom, text + b0, nbytes, ga, gb, gc, bos, eos, reverse, out, &counts[sidx], d, sidx);
       wave_sync();
       sidx++;
     }
