@@ -875,7 +875,8 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // Small batch and a round that runs without the filter pass: the batch goes to the kernels as an argument and nothing is
   // uploaded (yttm_kernels.h: BatchArgs).  The flag tables in HBM then keep what the last uploaded batch left there.
   auto dense_class = [&](int ci) {
-    return cls_[ci].n_tiles <= 8192 || (touched_last_ != (~0ull >> 2) && touched_last_ * 10 >= (unsigned long long)n_tiles * 9);
+    static const int dense_pct = getenv("YTTM_DENSE_PCT") ? atoi(getenv("YTTM_DENSE_PCT")) : 0;  // tuning hook; measured at 1 GB (K4 ms): 90 % -> 217, 60 % -> 215, 30 % -> 212, 0 (never filter) -> 211
+    return cls_[ci].n_tiles <= 8192 || (touched_last_ != (~0ull >> 2) && touched_last_ * 100 >= (unsigned long long)n_tiles * (unsigned long long)dense_pct);
   };
   BatchArgs ba{};
   const bool by_args = k <= (uint32_t)BATCH_ARGS_MAX && vmax < FLAG_LDS_IDS && !cls_[2].n_tiles && (!cls_[0].n_tiles || dense_class(0)) &&
