@@ -695,13 +695,16 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
   if (t < NT) {
     load_headers(t_batch);
     tile_fetch<SLOT>(r, ts, __shfl(ht, 0), __shfl(hn, 0));
-    wreg_load<SLOT>(wq, ts.wcnt, __shfl(hw, 0));
+    if (!MERGE) wreg_load<SLOT>(wq, ts.wcnt, __shfl(hw, 0));
   }
   while (t < NT) {
     const int n0 = __shfl(hn, j);
     const uint32_t w0 = __shfl(hw, j);
     const uint32_t tile = __shfl(ht, j);
     const bool dirty = stage_part(n0);
+    // K4: most tiles are dismissed in registers late in training -- their word frequencies are never needed, so they are
+    // loaded only now, for a dirty tile, ahead of the next tile's prefetch (first use is in phase 2)
+    if (MERGE && dirty) wreg_load<SLOT>(wq, ts.wcnt, w0);
     // next tile of this wave: header from the batch (reload the batch every 64 tiles), tokens prefetched now
     const uint32_t t_next = t + stride;
     j++;
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
     const WReg<SLOT> wcur = wq;
     if (t_next < NT) {
       tile_fetch<SLOT>(r, ts, __shfl(ht, j), __shfl(hn, j));
-      wreg_load<SLOT>(wq, ts.wcnt, __shfl(hw, j));
+      if (!MERGE) wreg_load<SLOT>(wq, ts.wcnt, __shfl(hw, j));
     }
     process_part(dirty, tile, n0, w0, wcur);
     t = t_next;
