@@ -84,6 +84,17 @@ def test_very_long_words(tmp_path):
     S.check_very_long_words(tmp_path)
 
 
+def test_memory_pool_reuse_and_release(tmp_path):
+    """Trainings reuse the device buffers of earlier ones (pool in gpu_ctx.cpp): same models with dirty, recycled memory;
+    yttm_release_device_memory() hands the cache back and training still works afterwards."""
+    from youtokentome_amd import _lib
+    for rep in range(2):
+        for name in ("readme_small", "runs"):
+            S.check_golden_train(name, tmp_path)
+    _lib.load().yttm_release_device_memory()
+    S.check_golden_train("mix_cov", tmp_path)
+
+
 def test_config_errors(tmp_path):
     for kw in [dict(coverage=0.0), dict(ids=(0, 300, 2, 3)), dict(ids=(0, 1, 1, 3)), dict(vocab=5)]:
         S.check_train_vs_oracle(b"aaa bbb abab", kw.get("vocab", 50), tmp_path, kw.get("coverage", 1.0), kw.get("ids", (0, 1, 2, 3)), tag="e")
