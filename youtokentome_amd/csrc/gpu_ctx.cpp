@@ -851,7 +851,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       continue;
     }
     const unsigned long long key = pair_key(x, y);
-    unsigned int h = (unsigned int)mix64(key) & (cap - 1);
+    unsigned int h = pair_hash32(key) & (cap - 1);
     while (h_rules[h].key != PT_EMPTY) h = (h + 1) & (cap - 1);
     h_rules[h].key = key;
     h_rules[h].z = z;
@@ -954,7 +954,7 @@ void GpuCtx::flush_pending_zero() {
       const uint32_t x = zero_ba_.xy[2 * j], y = zero_ba_.xy[2 * j + 1];
       if (x == y) continue;
       const unsigned long long key = pair_key(x, y);
-      unsigned int h = (unsigned int)mix64(key) & (zero_cap_ - 1);
+      unsigned int h = pair_hash32(key) & (zero_cap_ - 1);
       while (tab[h].key != PT_EMPTY) h = (h + 1) & (zero_cap_ - 1);
       tab[h].key = key;
     }

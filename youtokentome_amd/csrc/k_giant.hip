@@ -109,7 +109,7 @@ __global__ __launch_bounds__(BLOCK) void k_giant(TileSet ts, unsigned int slot, 
               if (((p - q) & 1) == 0) s = 0xffffffffu;  // marks the self rule
             } else if (rules) {
               const unsigned long long key = pair_key(a, b);
-              unsigned int h = (unsigned int)mix64(key) & rule_mask;
+              unsigned int h = pair_hash32(key) & rule_mask;
               for (;;) {
                 const unsigned long long k = rules[h].key;
                 if (k == key) { s = rules[h].z + 1u; break; }

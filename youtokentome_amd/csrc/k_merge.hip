@@ -69,7 +69,7 @@ __device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsi
 template <int SLOT>
 __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta) {
   (void)W;
-  unsigned int h = (unsigned int)(mix64(key) >> 24) & (AGG_SLOTS - 1);
+  unsigned int h = (pair_hash32(key) >> 7) & (AGG_SLOTS - 1);
   for (int probe = 0; probe < 8; probe++) {
     unsigned long long k = __hip_atomic_load(&A.key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_read, not a flat load
     if (k == PT_EMPTY) {
@@ -198,7 +198,7 @@ struct RuleProbe {
   unsigned int mask;
   __device__ bool has(uint32_t a, uint32_t b) const {
     const unsigned long long key = pair_key(a, b);
-    unsigned int h = (unsigned int)mix64(key) & mask;
+    unsigned int h = pair_hash32(key) & mask;
     for (;;) {
       const unsigned long long k = lds_keys ? __hip_atomic_load(&lds_keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : g[h].key;
       if (k == key) return true;
@@ -223,7 +223,7 @@ struct RuleTab {
   // function the compiler waits for vmcnt(0) where they join, prefetch included.
   __device__ uint32_t find(uint32_t a, uint32_t b) const {
     const unsigned long long key = pair_key(a, b);
-    unsigned int h = (unsigned int)mix64(key) & mask;
+    unsigned int h = pair_hash32(key) & mask;
     for (;;) {
       unsigned long long k;
       if (IN_LDS) k = __hip_atomic_load(&lds_keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
         atomicOr(&A.flagbits[x >> 4], 1u << ((x & 15u) * 2));
         atomicOr(&A.flagbits[y >> 4], 2u << ((y & 15u) * 2));
         const unsigned long long key = pair_key(x, y);
-        unsigned int h = (unsigned int)mix64(key) & rule_mask;
+        unsigned int h = pair_hash32(key) & rule_mask;
         for (;;) {
           if (atomicCAS(&rkeys[h], PT_EMPTY, key) == PT_EMPTY) {
             rridx[h] = (uint16_t)threadIdx.x;
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
     __syncthreads();
     if (threadIdx.x < zba.k && zba.xy[2 * threadIdx.x] != zba.xy[2 * threadIdx.x + 1]) {
       const unsigned long long key = pair_key(zba.xy[2 * threadIdx.x], zba.xy[2 * threadIdx.x + 1]);
-      unsigned int h = (unsigned int)mix64(key) & zmask;
+      unsigned int h = pair_hash32(key) & zmask;
       while (atomicCAS(&zkeys[h], PT_EMPTY, key) != PT_EMPTY) h = (h + 1) & zmask;
     }
   } else if (zkeys_in_lds) {

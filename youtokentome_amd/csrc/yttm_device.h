@@ -92,6 +92,14 @@ __host__ __device__ inline unsigned long long mix64(unsigned long long x) {
   return x;
 }
 
+// Hash of a pair for the small per-round tables (the batch's rule hash, the LDS delta aggregator): a 64-bit mix costs ~16
+// VALU instructions, and the apply kernel hashes four keys per 64-token chunk; these tables tolerate a weaker hash.
+__host__ __device__ inline uint32_t pair_hash32(unsigned long long key) {
+  uint32_t h = (uint32_t)(key >> 32) * 0x9E3779B1u;
+  h ^= (uint32_t)key * 0x85EBCA77u;
+  h ^= h >> 15;
+  return h;
+}
 __host__ __device__ inline unsigned long long pair_key(uint32_t x, uint32_t y) {
   return ((unsigned long long)x << 32) | (unsigned long long)y;
 }
