@@ -175,15 +175,6 @@ __device__ inline void tile_fetch(uint4 (&r)[SLOT / 256], const TileSet &ts, uin
   }
 }
 
-__device__ inline uint32_t flagged_small(uint32_t tok, const uint32_t *flagbits_lds) {
-  const uint32_t id = tok & (FLAG_LDS_IDS - 1);  // ids >= FLAG_LDS_IDS are patched afterwards (rare, wave-uniform test)
-  return tok | (((flagbits_lds[id >> 4] >> ((id & 15u) * 2)) & 3u) << 29);
-}
-__device__ inline uint32_t flagged_big(uint32_t tok, const uint8_t *__restrict__ tokflag) {
-  const uint32_t id = tok & TOK_MASK & L_ID;
-  if (id < FLAG_LDS_IDS) return tok;
-  return (tok & ~(L_ISX | L_ISY)) | ((uint32_t)(tokflag[id] & 3u) << 29);
-}
 
 // Batch flags for the 16 tokens a lane holds and the merge-site candidate test, entirely in registers: a tile without
 // any (x-flagged, y-flagged) adjacency -- the common case late in training -- is never staged into LDS at all.
@@ -235,48 +226,78 @@ struct RuleTab {
   }
 };
 
+// 2-bit batch flags of a token (bit 0: x of a batch rule, bit 1: y)
+__device__ inline uint32_t flag2(uint32_t tok, const uint32_t *flagbits_lds) {
+  const uint32_t id = tok & (FLAG_LDS_IDS - 1);  // ids >= FLAG_LDS_IDS are patched afterwards (rare, wave-uniform test)
+  return (flagbits_lds[id >> 4] >> ((id & 15u) * 2)) & 3u;
+}
+__device__ inline uint32_t flag2_big(uint32_t tok, uint32_t f, const uint8_t *__restrict__ tokflag) {
+  const uint32_t id = tok & L_ID;
+  return id < FLAG_LDS_IDS ? f : (uint32_t)(tokflag[id] & 3u);
+}
+
 template <int SLOT>
 __device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds, const uint8_t *__restrict__ tokflag, uint32_t self_x,
                                       const RuleProbe probe = RuleProbe{nullptr, nullptr, 0}) {
   const int lane = lane_id();
+  // flags first, tokens untouched: most tiles are dismissed here and never need the flagged tokens.  Slots behind the live
+  // prefix hold zeros (never flagged), rows that start behind it were not loaded (zeros too): no bounds checks.
+  uint4 f[SLOT / 256];
   bool big = false;
 #pragma unroll
   for (int j = 0; j < SLOT / 256; j++) {
+    f[j] = make_uint4(0, 0, 0, 0);
     if (256 * j < n) {
       big = big || ((r[j].x | r[j].y | r[j].z | r[j].w) & TOK_MASK) >= FLAG_LDS_IDS;
-      r[j].x = flagged_small(r[j].x, flagbits_lds); r[j].y = flagged_small(r[j].y, flagbits_lds);
-      r[j].z = flagged_small(r[j].z, flagbits_lds); r[j].w = flagged_small(r[j].w, flagbits_lds);
+      f[j].x = flag2(r[j].x, flagbits_lds); f[j].y = flag2(r[j].y, flagbits_lds);
+      f[j].z = flag2(r[j].z, flagbits_lds); f[j].w = flag2(r[j].w, flagbits_lds);
     }
   }
   if (__ballot(big)) {  // some id does not fit the LDS bitmap: take its flags from the HBM byte table
 #pragma unroll
     for (int j = 0; j < SLOT / 256; j++) {
       if (256 * j < n) {
-        r[j].x = flagged_big(r[j].x, tokflag); r[j].y = flagged_big(r[j].y, tokflag);
-        r[j].z = flagged_big(r[j].z, tokflag); r[j].w = flagged_big(r[j].w, tokflag);
+        f[j].x = flag2_big(r[j].x, f[j].x, tokflag); f[j].y = flag2_big(r[j].y, f[j].y, tokflag);
+        f[j].z = flag2_big(r[j].z, f[j].z, tokflag); f[j].w = flag2_big(r[j].w, f[j].w, tokflag);
       }
     }
   }
-  bool cand = false;
-#define PAIR_TEST(T0, T1, P)                                                                        \
-  if ((P) + 1 < n && !((T1)&TOK_WS))                                                                 \
-    cand = cand || (((T0)&L_ISX) && ((T1)&L_ISY)) || ((((T0)&L_ID) == self_x) && (((T1)&L_ID) == self_x));
+  // (a,b) is a merge-site candidate iff a is an x and b is a y that does not start a word
+  uint32_t c = 0;
+#define YBIT(F, T) (((F) >> 1) & ~((T) >> 31))
 #pragma unroll
   for (int j = 0; j < SLOT / 256; j++) {
     if (256 * j < n) {
-      uint32_t nx = __shfl_down(r[j].x, 1);
-      uint32_t nx0 = TOK_WS;
-      if (j + 1 < SLOT / 256) nx0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
-      if (lane == 63) nx = nx0;
-      const int p = 256 * j + 4 * lane;
-      PAIR_TEST(r[j].x, r[j].y, p)
-      PAIR_TEST(r[j].y, r[j].z, p + 1)
-      PAIR_TEST(r[j].z, r[j].w, p + 2)
-      PAIR_TEST(r[j].w, nx, p + 3)
+      const uint32_t g0 = YBIT(f[j].x, r[j].x);  // is my first token a continuing y?  (asked by the lane to my left)
+      uint32_t gn = __shfl_down(g0, 1);
+      uint32_t g_next_row = 0;  // first token of the next row, for lane 63 (shuffles are executed by all lanes)
+      if (j + 1 < SLOT / 256) g_next_row = __shfl(YBIT(f[j + 1 < SLOT / 256 ? j + 1 : j].x, r[j + 1 < SLOT / 256 ? j + 1 : j].x), 0);
+      if (lane == 63) gn = g_next_row;
+      c |= (f[j].x & YBIT(f[j].y, r[j].y)) | (f[j].y & YBIT(f[j].z, r[j].z)) | (f[j].z & YBIT(f[j].w, r[j].w)) | (f[j].w & gn);
     }
   }
-#undef PAIR_TEST
+#undef YBIT
+  bool cand = c & 1u;
+  if (self_x != 0xffffffffu) {  // the x x of the self rule (at most one per batch; wave-uniform test)
+#define SELF(T0, T1) ((((T0)&L_ID) == self_x) && (((T1)&L_ID) == self_x) && !((T1)&TOK_WS))
+#pragma unroll
+    for (int j = 0; j < SLOT / 256; j++) {
+      if (256 * j < n) {
+        uint32_t nx = __shfl_down(r[j].x, 1);
+        uint32_t nx0 = TOK_WS;
+        if (j + 1 < SLOT / 256) nx0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
+        if (lane == 63) nx = nx0;
+        cand = cand || SELF(r[j].x, r[j].y) || SELF(r[j].y, r[j].z) || SELF(r[j].z, r[j].w) || SELF(r[j].w, nx);
+      }
+    }
+#undef SELF
+  }
   if (__ballot(cand) == 0) return false;
+  // the tile is staged (or tested exactly): now the tokens get their flag bits
+#pragma unroll
+  for (int j = 0; j < SLOT / 256; j++) {
+    r[j].x |= f[j].x << 29; r[j].y |= f[j].y << 29; r[j].z |= f[j].z << 29; r[j].w |= f[j].w << 29;
+  }
   if (!probe.g) return true;
   // some adjacency is flagged: is any of them a rule of the batch (or the x x of the self rule)?
   bool hit = false;
@@ -570,6 +591,9 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
             }
           }
         }
+        // invariant: slots behind the live prefix hold zeros (id 0 is a special token: never flagged, never part of a rule),
+        // so the register-level dismissal needs no bounds checks
+        for (int p = (int)abase + lane; p < n; p += 64) dst[p] = 0;
         if (lane == 0) ts.tile_len[t] = abase;
         st_touched++;
         st_touched_tok += (unsigned long long)n;
