@@ -141,3 +141,15 @@ static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipsim::wave_barrier()
+// wave-uniform values: readfirstlane is the identity here (the value is the same in every lane by contract); the mask
+// builtins index the uniform mask with the lane id
+#define __builtin_amdgcn_readfirstlane(v) (v)
+static inline bool __builtin_amdgcn_inverse_ballot_w64(unsigned long long m) { return (m >> (threadIdx.x & 63u)) & 1ull; }
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned lo, unsigned acc) {
+  const unsigned l = threadIdx.x & 63u;
+  return acc + (unsigned)__builtin_popcount(l >= 32 ? lo : (lo & ((1u << l) - 1u)));
+}
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned hi, unsigned acc) {
+  const unsigned l = threadIdx.x & 63u;
+  return acc + (l > 32 ? (unsigned)__builtin_popcount(hi & ((1u << (l - 32)) - 1u)) : 0u);
+}

@@ -887,6 +887,9 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   } else {
     prev_flag_toks_.swap(now);
   }
+  // sparse round: dirty tiles are queued per workgroup and processed after the streaming pass (k_tiles: dq_*)
+  static const int defer_pct = getenv("YTTM_DEFER_PCT") ? atoi(getenv("YTTM_DEFER_PCT")) : 45;
+  const bool defer = defer_pct >= 1000 /* tests: always */ || (touched_last_ != (~0ull >> 2) && touched_last_ * 100 < (unsigned long long)n_tiles * (unsigned long long)defer_pct);
   t_begin(KT_MERGE);
   if (!by_args)
     launch_round_begin(h_rules, cap, d_rules_, h_upd, n_upd, d_tokflag_, d_flagbits_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr,
@@ -894,7 +897,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   for (int ci = 0; ci < 2; ci++) {
     if (!cls_[ci].n_tiles) continue;
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
-                       cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/by_args || dense_class(ci),
+                       cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/by_args || dense_class(ci), defer,
                        by_args ? &ba : nullptr, st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
@@ -906,6 +909,15 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     launch_fold_stats(d_stats_, pt_.n_keys, st_);
     HIP_CHECK(hipMemcpyAsync(stt, d_stats_, sizeof stt, hipMemcpyDeviceToHost, st_));
     sync();
+    if (getenv("YTTM_TRACE_BLOCKS") && merge_rounds % 50 == 0) {  // PROF build: per-workgroup start / end / dirty tiles of this round
+      std::vector<unsigned long long> rows(STATS_WORDS);
+      HIP_CHECK(hipMemcpy(rows.data(), d_stats_, STATS_WORDS * 8, hipMemcpyDeviceToHost));
+      std::string name = std::string(getenv("YTTM_TRACE_BLOCKS")) + "." + std::to_string(merge_rounds);
+      if (FILE *fb = fopen(name.c_str(), "w")) {
+        for (int b = 0; b < 1536; b++) fprintf(fb, "%d %llu %llu %llu\n", b, rows[32 + 8 * b + 5], rows[32 + 8 * b + 6], rows[32 + 8 * b + 7]);
+        fclose(fb);
+      }
+    }
     FILE *f = fopen(getenv("YTTM_TRACE_ROUNDS"), merge_rounds == 1 ? "w" : "a");
     if (f) {
       fprintf(f, "%llu %u %llu %llu %llu %llu %u", merge_rounds, k, stt[0], stt[1], stt[2], stt[3], cls_[0].n_tiles);

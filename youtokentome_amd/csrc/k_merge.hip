@@ -348,6 +348,12 @@ __device__ inline uint32_t tile_word_index(const WaveLds<SLOT> &W, int p) {
   const unsigned long long le = (2ull << (p & 63)) - 1ull;  // bits 0..(p&63)
   return W.wsbase[c] + (uint32_t)__popcll(W.wsmask[c] & le) - 1u;
 }
+// the same for lane l asking about position 64 c + l (c uniform): the chunk's mask and base go through scalar registers
+template <int SLOT>
+__device__ inline uint32_t chunk_word_index(const WaveLds<SLOT> &W, int c) {
+  const unsigned long long wm = uni64(W.wsmask[c]);
+  return uni(W.wsbase[c]) + lanes_below(wm) + (lane_bit(wm) ? 1u : 0u) - 1u;
+}
 // Frequencies of ALL words of a tile travel with it in registers: lane j holds words j, j+64, ... (a class-A tile has at
 // most SLOT/2 words, a class-B tile -- words of more than TILE_NOM_A tokens -- at most 16).  They are loaded together with
 // the tokens, one tile ahead, and read by cross-lane shuffles: the gather from HBM that this replaces cost ~6 us per
@@ -363,10 +369,11 @@ __device__ inline void wreg_load(WReg<SLOT> &w, const uint32_t *__restrict__ wcn
 #pragma unroll
   for (int i = 0; i < WReg<SLOT>::N; i++) w.v[i] = wcnt[word0 + (uint32_t)(lane + 64 * i)];
 }
-// Frequency of the word that contains tile position p.  MUST be called by all lanes of the wave (ds_bpermute).
+// Frequency of the word that contains tile position 64 c + lane.  MUST be called by all lanes of the wave (ds_bpermute);
+// lanes behind the end of the tile get some word's frequency (never used).
 template <int SLOT>
-__device__ inline long long tile_weight_all(const WaveLds<SLOT> &W, const WReg<SLOT> &wreg, int p, bool valid) {
-  const uint32_t k = valid ? tile_word_index<SLOT>(W, p) : 0u;
+__device__ inline long long tile_weight_all(const WaveLds<SLOT> &W, const WReg<SLOT> &wreg, int c) {
+  const uint32_t k = chunk_word_index<SLOT>(W, c);
   uint32_t f = 0;
 #pragma unroll
   for (int i = 0; i < WReg<SLOT>::N; i++) {
@@ -381,7 +388,7 @@ __device__ inline long long tile_weight_all(const WaveLds<SLOT> &W, const WReg<S
 // adjacency counts the word frequency; a run of L equal tokens counts floor(L/2) for its self pair).
 // MERGE=true: K4, apply the batch rules (z ids are consecutive: rule j of the batch creates z_base + j) and emit the
 // exact count deltas around the merge sites.
-#ifdef YTTM_K4_PROF
+#if defined(YTTM_K4_PROF) && YTTM_K4_PROF >= 2  // PROF=2: phase marks (they cost ~100 cycles each); PROF=1: workgroup timeline only
 #define K4_MARK(k) do { const unsigned long long t_ = (unsigned long long)clock64(); S.pt[k] += t_ - S.t_last; S.t_last = t_; } while (0)
 #define K4_COUNT(k) (S.pt[k]++)
 #else
@@ -452,7 +459,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
     if (!MERGE) {
       for (int c = 0; c < nchunks; c++) {
         const int p = c * 64 + lane;
-        const long long f = tile_weight_all<SLOT>(W, wreg, p, p < n);
+        const long long f = tile_weight_all<SLOT>(W, wreg, c);
         if (p >= n) continue;
         const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
         if (t1 & TOK_WS) continue;
@@ -478,16 +485,16 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         // ---- phase 2: count deltas around the sites + survivor masks ---------------------------------------------------
         uint32_t abase = 0;
         // a chunk is active if a site starts in it or right next to it; the others (most of a tile late in training) keep
-        // all their tokens and emit nothing
-        auto chunk_active = [&](int c) {
-          return W.sitemask[c] != 0ull || (c > 0 && (W.sitemask[c - 1] >> 63)) || (c + 1 < nchunks && (W.sitemask[c + 1] & 1ull));
-        };
+        // all their tokens and emit nothing.  Site masks of the chunk and its neighbours: a rolling window in scalar registers.
         int first_site_chunk = nchunks;
-        for (int c = 0; c < nchunks; c++) {
+        unsigned long long sm0 = 0ull, sm1 = uni64(W.sitemask[0]), sm2 = 0ull;
+        for (int c = 0; c < nchunks; c++, sm0 = sm1, sm1 = sm2) {
           const int p = c * 64 + lane;
-          const bool act = chunk_active(c);
+          sm2 = c + 1 < nchunks ? uni64(W.sitemask[c + 1]) : 0ull;
+          const bool act = sm1 != 0ull || (sm0 >> 63) != 0ull || (sm2 & 1ull) != 0ull;
           if (!act) {
-            const unsigned long long am = __ballot(p < n);
+            const int left = n - c * 64;
+            const unsigned long long am = left >= 64 ? ~0ull : (1ull << left) - 1ull;  // positions of the tile in this chunk
             if (lane == 0) {
               W.amask[c] = am;
               W.abase[c] = abase;
@@ -495,21 +502,18 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
             abase += (uint32_t)__popcll(am);
             continue;
           }
-          if (first_site_chunk == nchunks && W.sitemask[c] != 0ull) first_site_chunk = c;
-#ifdef YTTM_K4_PROF
-#endif
-          const long long f = tile_weight_all<SLOT>(W, wreg, p, p < n);
+          if (first_site_chunk == nchunks && sm1 != 0ull) first_site_chunk = c;
+          K4_MARK(5);
+          const long long f = tile_weight_all<SLOT>(W, wreg, c);
+          K4_MARK(10);
           // Site bits of this chunk and its neighbours live in registers (every SITE() below used to be a dependent LDS
           // read), and the up to four count deltas of a lane are collected first and emitted by all lanes together: four
           // convergent trips through the LDS aggregator instead of nine divergent ones.
-          const unsigned long long sm0 = c > 0 ? W.sitemask[c - 1] : 0ull, sm1 = W.sitemask[c],
-                                   sm2 = c + 1 < nchunks ? W.sitemask[c + 1] : 0ull;
-          const bool sp = (sm1 >> lane) & 1ull;
-          const bool dp = lane >= 1 ? ((sm1 >> ((lane - 1) & 63)) & 1ull) : (sm0 >> 63);
-          const bool s_p1 = lane <= 62 ? ((sm1 >> ((lane + 1) & 63)) & 1ull) : (sm2 & 1ull);
-          const bool s_m2 = lane >= 2 ? ((sm1 >> ((lane - 2) & 63)) & 1ull) : ((sm0 >> ((62 + lane) & 63)) & 1ull);
-          const bool s_p2 = lane <= 61 ? ((sm1 >> ((lane + 2) & 63)) & 1ull) : ((sm2 >> ((lane - 62) & 63)) & 1ull);
-          bool alive = false;
+          const bool sp = lane_bit(sm1);                               // a site starts at p
+          const bool dp = lane_bit((sm1 << 1) | (sm0 >> 63));          // ... at p-1 (p is its y: dead)
+          const bool s_p1 = lane_bit((sm1 >> 1) | (sm2 << 63));        // ... at p+1
+          const bool s_m2 = lane_bit((sm1 << 2) | (sm0 >> 62));        // ... at p-2
+          const bool s_p2 = lane_bit((sm1 >> 2) | (sm2 << 62));        // ... at p+2
           bool v0 = false, v1 = false, v2 = false, v3 = false;
           unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
           long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
@@ -517,7 +521,6 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
             const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
             const uint32_t a = t0 & L_ID;
             const bool adj1 = !(t1 & TOK_WS);
-            alive = !dp;
             if (sp) {
               my_sites++;
               const uint32_t z = NEWTOK(p);
@@ -563,18 +566,19 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
               }
             }
           }
+          K4_MARK(13);
           if (__ballot(v0)) { if (v0) emit<SLOT>(A, W, pt, db, k0, d0); }
           if (__ballot(v1)) { if (v1) emit<SLOT>(A, W, pt, db, k1, d1); }
           if (__ballot(v2)) { if (v2) emit<SLOT>(A, W, pt, db, k2, d2); }
           if (__ballot(v3)) { if (v3) emit<SLOT>(A, W, pt, db, k3, d3); }
-          const unsigned long long am = __ballot(alive);
+          const int left = n - c * 64;
+          const unsigned long long am = (left >= 64 ? ~0ull : (1ull << left) - 1ull) & ~((sm1 << 1) | (sm0 >> 63));  // survivors: not the y of a site
           if (lane == 0) {
             W.amask[c] = am;
             W.abase[c] = abase;
           }
           abase += (uint32_t)__popcll(am);
-#ifdef YTTM_K4_PROF
-#endif
+          K4_MARK(14);
         }
         wave_sync();
         K4_MARK(5);
@@ -582,13 +586,12 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         uint32_t *dst = ts.tok + (size_t)t * SLOT;
         for (int c = first_site_chunk; c < nchunks; c++) {  // tokens before the first site neither move nor change
           const int p = c * 64 + lane;
-          if (p < n) {
-            const unsigned long long am = W.amask[c];
-            if ((am >> lane) & 1ull) {
-              const uint32_t np = W.abase[c] + (uint32_t)__popcll(am & lanemask_lt());
-              const uint32_t t0 = W.tk[p];
-              dst[np] = SITE(p) ? (NEWTOK(p) | (t0 & TOK_WS)) : (t0 & ~(L_ISX | L_ISY));
-            }
+          const unsigned long long am = uni64(W.amask[c]), smc = uni64(W.sitemask[c]);  // (amask has no bits behind the tile's end)
+          const uint32_t ab = uni(W.abase[c]);
+          if (lane_bit(am)) {
+            const uint32_t np = ab + lanes_below(am);
+            const uint32_t t0 = W.tk[p];
+            dst[np] = lane_bit(smc) ? (NEWTOK(p) | (t0 & TOK_WS)) : (t0 & ~(L_ISX | L_ISY));
           }
         }
         // invariant: slots behind the live prefix hold zeros (id 0 is a special token: never flagged, never part of a rule),
@@ -610,11 +613,24 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                                                     const uint32_t *__restrict__ worklist, const unsigned int *__restrict__ work_n,
                                                     unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */,
-                                                    BatchArgs ba) {
+                                                    BatchArgs ba, unsigned int defer) {
   __shared__ WaveLds<SLOT> WL[WPB];
   __shared__ AggLds A;
   __shared__ unsigned long long rkeys[LDSR ? APPLY_LDS_RULES : 1];
   __shared__ uint16_t rridx[LDSR ? APPLY_LDS_RULES : 1];
+  // Sparse rounds (defer != 0): a wave that finds a merge-site candidate in its tile does not stop to process it -- with
+  // tiles handed out statically, the wave that happens to own the most dirty tiles would set the duration of the launch.
+  // It queues the tile here; when all tiles have been looked at, the waves of the workgroup drain the queue together
+  // (tokens and word frequencies of the next entry in flight while the current one is processed).
+  constexpr int DQ_CAP = (MERGE && WPB > 1) ? 96 : 1;
+  __shared__ uint32_t dq_tile[DQ_CAP], dq_w0[DQ_CAP];
+  __shared__ uint16_t dq_len[DQ_CAP];
+  __shared__ unsigned int dq_n, dq_head;
+  if (threadIdx.x == 0) { dq_n = 0; dq_head = 0; }
+#ifdef YTTM_K4_PROF
+  const unsigned long long wall0_ = wall_clock64();
+#endif
+  const bool use_dq = MERGE && WPB > 1 && defer != 0;
   const bool from_args = MERGE && LDSR && ba.k != 0;  // tables built from the kernel argument, nothing read from HBM
   agg_init<WPB * 64>(A, (MERGE && !from_args) ? flagbits : nullptr);
   if (from_args) {
@@ -645,7 +661,7 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
   }
   const RuleTab<LDSR> rtab{rkeys, rridx, rules, rule_mask, z_base};
   __syncthreads();
-  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int wave = uni((int)(threadIdx.x >> 6)), lane = lane_id();
   WaveLds<SLOT> &W = WL[wave];
   const uint32_t stride = gridDim.x * WPB;
   // K4 runs over the worklist of dirty tiles written by k_filter; K3 over all tiles
@@ -695,10 +711,29 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
   S.t_last = (unsigned long long)clock64();
 #endif
   // tile i is in registers: flag/stage it; then (prefetch of tile i+1 by the caller); then process it from LDS
-  auto stage_part = [&](int n0) {
+  // sparse rounds: flagged adjacencies are looked up in the batch before the tile is staged -- the x/y flags are per token,
+  // and late in training two thirds of the tiles with a flagged adjacency hold no merge site at all
+  const RuleProbe probe = (MERGE && LDSR && defer != 0) ? RuleProbe{rkeys, rules, rule_mask} : RuleProbe{nullptr, nullptr, 0};
+  bool deferred = false;  // the tile just looked at went to the queue
+  auto stage_part = [&](int n0, uint32_t tile, uint32_t w0) {
     // K4: a tile with no (x-flagged, y-flagged) adjacency is dismissed in registers and never touches LDS
-    const bool dirty = MERGE ? reg_candidates<SLOT>(r, n0, A.flagbits, tokflag, self_x) : true;
+    bool dirty = MERGE ? reg_candidates<SLOT>(r, n0, A.flagbits, tokflag, self_x, probe) : true;
     if (MERGE) K4_MARK(0);
+    deferred = false;
+    if (use_dq && dirty) {
+      unsigned int qi = 0;
+      if (lane == 0) qi = atomicAdd(&dq_n, 1u);
+      qi = uni(__shfl(qi, 0));
+      if (qi < (unsigned int)DQ_CAP) {  // (a full queue: the tile is processed on the spot)
+        if (lane == 0) {
+          dq_tile[qi] = tile;
+          dq_w0[qi] = w0;
+          dq_len[qi] = (uint16_t)n0;
+        }
+        deferred = true;
+        dirty = false;
+      }
+    }
     if (dirty) tile_stage<SLOT>(W, r, n0);
     if (MERGE) K4_MARK(1);
     return dirty;
@@ -709,7 +744,7 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
       K4_COUNT(8);
       process_tile<SLOT, MERGE, LDSR>(W, A, ts, pt, db, rtab, self_x, self_z, z_base, tile, n0, w0, wcur, S);
       wave_sync();  // everyone is done with this tile's LDS state before it is restaged
-    } else {
+    } else if (!deferred) {
       S.scanned += (unsigned long long)n0;
     }
   };
@@ -718,14 +753,14 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
   int j = 0;
   if (t < NT) {
     load_headers(t_batch);
-    tile_fetch<SLOT>(r, ts, __shfl(ht, 0), __shfl(hn, 0));
-    if (!MERGE) wreg_load<SLOT>(wq, ts.wcnt, __shfl(hw, 0));
+    tile_fetch<SLOT>(r, ts, uni(__shfl(ht, 0)), uni(__shfl(hn, 0)));
+    if (!MERGE) wreg_load<SLOT>(wq, ts.wcnt, uni(__shfl(hw, 0)));
   }
   while (t < NT) {
-    const int n0 = __shfl(hn, j);
-    const uint32_t w0 = __shfl(hw, j);
-    const uint32_t tile = __shfl(ht, j);
-    const bool dirty = stage_part(n0);
+    const int n0 = uni(__shfl(hn, j));  // (uniform, and now the compiler knows: tile loops and branches run on the scalar unit)
+    const uint32_t w0 = uni(__shfl(hw, j));
+    const uint32_t tile = uni(__shfl(ht, j));
+    const bool dirty = stage_part(n0, tile, w0);
     // K4: most tiles are dismissed in registers late in training -- their word frequencies are never needed, so they are
     // loaded only now, for a dirty tile, ahead of the next tile's prefetch (first use is in phase 2)
     if (MERGE && dirty) wreg_load<SLOT>(wq, ts.wcnt, w0);
@@ -739,11 +774,44 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
     }
     const WReg<SLOT> wcur = wq;
     if (t_next < NT) {
-      tile_fetch<SLOT>(r, ts, __shfl(ht, j), __shfl(hn, j));
-      if (!MERGE) wreg_load<SLOT>(wq, ts.wcnt, __shfl(hw, j));
+      tile_fetch<SLOT>(r, ts, uni(__shfl(ht, j)), uni(__shfl(hn, j)));
+      if (!MERGE) wreg_load<SLOT>(wq, ts.wcnt, uni(__shfl(hw, j)));
     }
     process_part(dirty, tile, n0, w0, wcur);
     t = t_next;
+  }
+  if (use_dq) {
+    __syncthreads();  // every wave has looked at all its tiles: the queue is complete
+    const unsigned int qn0 = uni(dq_n), qn = qn0 < (unsigned int)DQ_CAP ? qn0 : (unsigned int)DQ_CAP;
+    auto pop = [&]() {
+      unsigned int i = 0;
+      if (lane == 0) i = atomicAdd(&dq_head, 1u);
+      return uni((uint32_t)__shfl(i, 0));
+    };
+    unsigned int qi = pop();
+    uint32_t q_tile = 0, q_w0 = 0;
+    int q_len = 0;
+    if (qi < qn) {
+      q_tile = uni(dq_tile[qi]); q_w0 = uni(dq_w0[qi]); q_len = uni((int)dq_len[qi]);
+      tile_fetch<SLOT>(r, ts, q_tile, q_len);
+      wreg_load<SLOT>(wq, ts.wcnt, q_w0);
+    }
+    while (qi < qn) {
+      const uint32_t tile = q_tile, w0 = q_w0;
+      const int n0 = q_len;
+      (void)reg_candidates<SLOT>(r, n0, A.flagbits, tokflag, self_x);  // known to hold a candidate: this puts the flag bits on its tokens
+      tile_stage<SLOT>(W, r, n0);
+      const WReg<SLOT> wcur = wq;
+      qi = pop();
+      if (qi < qn) {
+        q_tile = uni(dq_tile[qi]); q_w0 = uni(dq_w0[qi]); q_len = uni((int)dq_len[qi]);
+        tile_fetch<SLOT>(r, ts, q_tile, q_len);
+        wreg_load<SLOT>(wq, ts.wcnt, q_w0);
+      }
+      K4_COUNT(8);
+      process_tile<SLOT, MERGE, LDSR>(W, A, ts, pt, db, rtab, self_x, self_z, z_base, tile, n0, w0, wcur, S);
+      wave_sync();
+    }
   }
   if (MERGE) {
     S.sites = wave_sum_u64(S.sites);
@@ -767,6 +835,14 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
     if (lane == 0)
       for (int i = 0; i < 16; i++)
         if (S.pt[i]) atomicAdd(&stats[8 + i], S.pt[i]);
+  }
+#endif
+#ifdef YTTM_K4_PROF
+  if (MERGE && threadIdx.x == 0) {  // per-workgroup timeline (100 MHz wall clock) for YTTM_TRACE_ROUNDS
+    unsigned long long *row = stats + BLK_BASE + 8 * (blockIdx.x % BLK_ROWS);
+    row[5] = wall0_;
+    row[6] = wall_clock64();
+    row[7] = A.st[1];
   }
 #endif
   if (threadIdx.x == 0) {
@@ -1272,16 +1348,18 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{});
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{}, 0u);
   else
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{});
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{}, 0u);
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
-                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba, hipStream_t st) {
+                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, bool defer, const BatchArgs *ba,
+                        hipStream_t st) {
   if (!ts.n_tiles) return;
+  const unsigned int dq = defer ? 1u : 0u;
   const BatchArgs bargs = ba ? *ba : BatchArgs{};
   const RuleSlot *frules = exact_filter ? rules : nullptr;
   // dense round (nearly every tile held a site last round): the filter pass would keep everything -- the apply kernel
@@ -1296,19 +1374,19 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, true>), dim3(tile_grid(ts.n_tiles, 4, 5)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, dq);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, false>), dim3(tile_grid(ts.n_tiles, 4, 5)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, dq);
   } else {
     if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, dq);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, dq);
   }
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,

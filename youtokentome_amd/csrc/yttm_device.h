@@ -221,6 +221,21 @@ __device__ inline void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 __device__ inline unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+// Wave-uniform values.  The compiler cannot know that a value read from LDS at a uniform address, or handed out by a
+// shuffle, is the same in every lane: it keeps it in vector registers and turns every loop and branch on it into exec-mask
+// code.  uni() moves it to scalar registers (v_readfirstlane); 64-bit masks then shift and count on the scalar unit,
+// lane_bit() selects a lane's bit of a uniform mask with one v_cndmask and lanes_below() counts the bits below the lane
+// with v_mbcnt.  MUST only be used on values that are uniform across the wave.
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline unsigned long long uni64(unsigned long long v) {
+  const uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ inline bool lane_bit(unsigned long long uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(uniform_mask); }
+__device__ inline uint32_t lanes_below(unsigned long long uniform_mask) {  // popcount(mask & lanemask_lt())
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(uniform_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)uniform_mask, 0u));
+}
 
 // ---- wave / block scans (wave = 64 lanes; all lanes of the block must call) ---------------------------------------
 __device__ inline uint32_t wave_incl_scan(uint32_t v) {
