@@ -37,9 +37,8 @@ struct WaveLds {
   uint16_t ridx[SLOT];                     // merge site at p: index of its rule in the batch (z = z_base + ridx)
   unsigned long long wsmask[SLOT / 64];    // bit p: token p starts a word
   unsigned long long sitemask[SLOT / 64];  // bit p: a merge (tk[p],tk[p+1]) starts at p
-  unsigned long long amask[SLOT / 64];     // bit p: position p survives
   uint32_t wsbase[SLOT / 64];              // number of word starts before the chunk
-  uint32_t abase[SLOT / 64];               // number of survivors before the chunk
+  uint16_t sitepos[64];                    // positions of the (up to) 64 merge sites a pass of phase 2 works on
 };
 struct AggLds {
   unsigned long long key[AGG_SLOTS];
@@ -369,6 +368,17 @@ __device__ inline void wreg_load(WReg<SLOT> &w, const uint32_t *__restrict__ wcn
 #pragma unroll
   for (int i = 0; i < WReg<SLOT>::N; i++) w.v[i] = wcnt[word0 + (uint32_t)(lane + 64 * i)];
 }
+// Frequency of word k of the tile.  MUST be called by all lanes of the wave (ds_bpermute).
+template <int SLOT>
+__device__ inline long long word_weight_all(const WReg<SLOT> &wreg, uint32_t k) {
+  uint32_t f = 0;
+#pragma unroll
+  for (int i = 0; i < WReg<SLOT>::N; i++) {
+    const uint32_t fi = __shfl(wreg.v[i], (int)(k & 63u));
+    if ((k >> 6) == (uint32_t)i) f = fi;
+  }
+  return (long long)f;
+}
 // Frequency of the word that contains tile position 64 c + lane.  MUST be called by all lanes of the wave (ds_bpermute);
 // lanes behind the end of the tile get some word's frequency (never used).
 template <int SLOT>
@@ -415,6 +425,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
     // ---- phase 1a: word-start masks; (MERGE) merge-site candidates = x-flagged token followed by a y-flagged token ----
     uint32_t wbase = 0;
     bool any = false;
+    int nsites = 0, first_site_chunk = nchunks;  // (MERGE)
     for (int c = 0; c < nchunks; c++) {
       const int p = c * 64 + lane;
       bool ws = false, self_site = false;
@@ -451,7 +462,11 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         if (MERGE) W.sitemask[c] = sm;
       }
       wbase += (uint32_t)__popcll(m);
-      any = any || sm != 0;
+      if (MERGE && sm != 0ull) {
+        if (!any) first_site_chunk = c;
+        any = true;
+        nsites += __popcll(sm);
+      }
     }
     wave_sync();
     if (MERGE) K4_MARK(3);
@@ -479,120 +494,98 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
     } else {
       K4_MARK(4);
       if (any) {
-        K4_COUNT(9);
 #define SITE(q) ((q) >= 0 && (((W.sitemask[(q) >> 6] >> ((q)&63)) & 1ull) != 0))
 #define NEWTOK(q) (z_base + (uint32_t)W.ridx[(q)])
-        // ---- phase 2: count deltas around the sites + survivor masks ---------------------------------------------------
-        uint32_t abase = 0;
-        // a chunk is active if a site starts in it or right next to it; the others (most of a tile late in training) keep
-        // all their tokens and emit nothing.  Site masks of the chunk and its neighbours: a rolling window in scalar registers.
-        int first_site_chunk = nchunks;
-        unsigned long long sm0 = 0ull, sm1 = uni64(W.sitemask[0]), sm2 = 0ull;
-        for (int c = 0; c < nchunks; c++, sm0 = sm1, sm1 = sm2) {
-          const int p = c * 64 + lane;
-          sm2 = c + 1 < nchunks ? uni64(W.sitemask[c + 1]) : 0ull;
-          const bool act = sm1 != 0ull || (sm0 >> 63) != 0ull || (sm2 & 1ull) != 0ull;
-          if (!act) {
-            const int left = n - c * 64;
-            const unsigned long long am = left >= 64 ? ~0ull : (1ull << left) - 1ull;  // positions of the tile in this chunk
-            if (lane == 0) {
-              W.amask[c] = am;
-              W.abase[c] = abase;
+        // ---- phase 2: count deltas, ONE LANE PER MERGE SITE -------------------------------------------------------------
+        // The sites of the tile, 64 at a time: lane i takes site number base + i, reads the few tokens around it from LDS and
+        // works out every delta the merge causes -- what worker_doing_merge does per list node (bpe.cpp:491-812): the left
+        // neighbour's (L,x) -> (L,z), the right neighbour's (y,R) -> (z,R), runs of equal tokens losing a member, and runs of
+        // the new token.  (A pass over the tile chunk by chunk with one token per lane did the same with ~4 lanes of 64
+        // busy: sites are sparse even in the first rounds.)  The merged pair itself is not retracted site by site: every
+        // occurrence goes, its count is zeroed after the round.
+        if (lane == 0) my_sites += (unsigned long long)nsites;
+        for (int base = 0; base < nsites; base += 64) {
+          int before = 0;  // sites in the chunks already looked at
+          for (int c = first_site_chunk; c < nchunks && before < base + 64; c++) {
+            const unsigned long long smc = uni64(W.sitemask[c]);
+            const int cnt = __popcll(smc);
+            if (cnt != 0 && before + cnt > base && lane_bit(smc)) {
+              const int rk = before + (int)lanes_below(smc) - base;
+              if (rk >= 0 && rk < 64) W.sitepos[rk] = (uint16_t)(c * 64 + lane);
             }
-            abase += (uint32_t)__popcll(am);
-            continue;
+            before += cnt;
           }
-          if (first_site_chunk == nchunks && sm1 != 0ull) first_site_chunk = c;
-          K4_MARK(5);
-          const long long f = tile_weight_all<SLOT>(W, wreg, c);
-          K4_MARK(10);
-          // Site bits of this chunk and its neighbours live in registers (every SITE() below used to be a dependent LDS
-          // read), and the up to four count deltas of a lane are collected first and emitted by all lanes together: four
-          // convergent trips through the LDS aggregator instead of nine divergent ones.
-          const bool sp = lane_bit(sm1);                               // a site starts at p
-          const bool dp = lane_bit((sm1 << 1) | (sm0 >> 63));          // ... at p-1 (p is its y: dead)
-          const bool s_p1 = lane_bit((sm1 >> 1) | (sm2 << 63));        // ... at p+1
-          const bool s_m2 = lane_bit((sm1 << 2) | (sm0 >> 62));        // ... at p-2
-          const bool s_p2 = lane_bit((sm1 >> 2) | (sm2 << 62));        // ... at p+2
-          bool v0 = false, v1 = false, v2 = false, v3 = false;
-          unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
-          long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-          if (p < n) {
-            const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
-            const uint32_t a = t0 & L_ID;
-            const bool adj1 = !(t1 & TOK_WS);
-            if (sp) {
-              my_sites++;
-              const uint32_t z = NEWTOK(p);
-              // (the merged pair itself is not retracted site by site: every occurrence goes, its count is zeroed afterwards)
-              // run of new z tokens (x y x y ... or the halves of an x-run): counted floor(Lz/2) by its first site
-              const bool prev_same = p >= 2 && !(t0 & TOK_WS) && s_m2 && NEWTOK(p - 2) == z;
-              const uint32_t t2 = W.tk[p + 2];
-              if (!prev_same && !(t2 & TOK_WS) && p + 2 < n && s_p2 && NEWTOK(p + 2) == z) {
-                int q = p + 2, lz = 2;
-                while (!(W.tk[q + 2] & TOK_WS) && q + 2 < n && SITE(q + 2) && NEWTOK(q + 2) == z) { q += 2; lz++; }
-                v1 = true; k1 = pair_key(z, z); d1 = (long long)(lz / 2) * f;
+          wave_sync();
+          const bool have = base + lane < nsites;
+          const int p = have ? (int)W.sitepos[lane] : 0;
+          const long long f = word_weight_all<SLOT>(wreg, tile_word_index<SLOT>(W, p));  // (all lanes: shuffles)
+          bool v0 = false, v1 = false, v2 = false, v3 = false, v4 = false;
+          unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0;
+          long long d0 = 0, d2 = 0, d4 = 0;
+          if (have) {
+            const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1], t2 = W.tk[p + 2];
+            const uint32_t x = t0 & L_ID, y = t1 & L_ID, z = NEWTOK(p);
+            const bool hasL = p > 0 && !(t0 & TOK_WS);       // a token of the same word before the site
+            const bool hasR = p + 2 < n && !(t2 & TOK_WS);   // ... and behind it
+            const bool s_m2 = hasL && p >= 2 && SITE(p - 2);  // that token is the y of another site
+            const bool s_p2 = hasR && SITE(p + 2);            // ... the x of another site
+            if (hasL) {
+              const uint32_t L = W.tk[p - 1] & L_ID;
+              if (!s_m2) {  // L stays: (L,x) -> (L,z)
+                if (L != x) { v0 = true; k0 = pair_key(L, x); d0 = -f; }
+                v1 = true; k1 = pair_key(L, z);
               }
-              // new adjacency (z, right neighbour)
-              if (p + 2 < n && !(t2 & TOK_WS)) {
-                const uint32_t B = s_p2 ? NEWTOK(p + 2) : (t2 & L_ID);
-                if (B != z) { v2 = true; k2 = pair_key(z, B); d2 = f; }
-              }
-              // x != y rule whose x is the last token of a run of a's: the run shrinks by one
-              if (a != self_x && p > 0 && !(t0 & TOK_WS) && (W.tk[p - 1] & L_ID) == a) {
+              if (L == x && x != self_x) {  // x != y rule whose x is the last token of a run of x's: the run shrinks by one
                 int rr = p;
-                while (rr > 0 && !(W.tk[rr] & TOK_WS) && (W.tk[rr - 1] & L_ID) == a) rr--;
-                const int len = p - rr + 1;
-                if ((len & 1) == 0) { v3 = true; k3 = pair_key(a, a); d3 = -f; }
+                while (rr > 0 && !(W.tk[rr] & TOK_WS) && (W.tk[rr - 1] & L_ID) == x) rr--;
+                if (((p - rr + 1) & 1) == 0) { v0 = true; k0 = pair_key(x, x); d0 = -f; }
               }
-            } else if (!dp && adj1 && s_p1) {
-              // unmerged token whose right neighbour starts a site: (a,x) -> (a,z)
-              const uint32_t x_ = t1 & L_ID;
-              const uint32_t z = NEWTOK(p + 1);
-              if (a != x_) { v0 = true; k0 = pair_key(a, x_); d0 = -f; }
-              v1 = true; k1 = pair_key(a, z); d1 = f;
             }
-            if (dp && adj1) {
-              // p was the y of the site at p-1: its old right adjacency disappears
-              const uint32_t b_ = t1 & L_ID;
-              if (a != b_) {
-                v2 = true; k2 = pair_key(a, b_); d2 = -f;
-              } else if (a != self_x) {
-                // x != y rule whose y is the first token of a run of a's: the run shrinks by one
-                int q = p;
-                while (!(W.tk[q + 1] & TOK_WS) && (W.tk[q + 1] & L_ID) == a) q++;
-                const int len = q - p + 1;
-                if ((len & 1) == 0) { v2 = true; k2 = pair_key(a, a); d2 = -f; }
+            // run of new z tokens (x y x y ... or the halves of an x-run): counted floor(Lz/2) by its first site
+            if (s_p2 && NEWTOK(p + 2) == z && !(s_m2 && NEWTOK(p - 2) == z)) {
+              int q = p + 2, lz = 2;
+              while (!(W.tk[q + 2] & TOK_WS) && q + 2 < n && SITE(q + 2) && NEWTOK(q + 2) == z) { q += 2; lz++; }
+              v4 = true; k4 = pair_key(z, z); d4 = (long long)(lz / 2) * f;
+            }
+            if (hasR) {
+              const uint32_t R = t2 & L_ID;
+              const uint32_t B = s_p2 ? NEWTOK(p + 2) : R;  // new adjacency (z, right neighbour)
+              if (B != z) { v3 = true; k3 = pair_key(z, B); }
+              // the old adjacency (y, R) disappears
+              if (y != R) {
+                v2 = true; k2 = pair_key(y, R); d2 = -f;
+              } else if (y != self_x) {  // x != y rule whose y is the first token of a run of y's: the run shrinks by one
+                int q = p + 1;
+                while (!(W.tk[q + 1] & TOK_WS) && (W.tk[q + 1] & L_ID) == y) q++;
+                if (((q - p) & 1) == 0) { v2 = true; k2 = pair_key(y, y); d2 = -f; }
               }
             }
           }
-          K4_MARK(13);
           if (__ballot(v0)) { if (v0) emit<SLOT>(A, W, pt, db, k0, d0); }
-          if (__ballot(v1)) { if (v1) emit<SLOT>(A, W, pt, db, k1, d1); }
+          if (__ballot(v1)) { if (v1) emit<SLOT>(A, W, pt, db, k1, f); }
           if (__ballot(v2)) { if (v2) emit<SLOT>(A, W, pt, db, k2, d2); }
-          if (__ballot(v3)) { if (v3) emit<SLOT>(A, W, pt, db, k3, d3); }
-          const int left = n - c * 64;
-          const unsigned long long am = (left >= 64 ? ~0ull : (1ull << left) - 1ull) & ~((sm1 << 1) | (sm0 >> 63));  // survivors: not the y of a site
-          if (lane == 0) {
-            W.amask[c] = am;
-            W.abase[c] = abase;
-          }
-          abase += (uint32_t)__popcll(am);
-          K4_MARK(14);
+          if (__ballot(v3)) { if (v3) emit<SLOT>(A, W, pt, db, k3, f); }
+          if (__ballot(v4)) { if (v4) emit<SLOT>(A, W, pt, db, k4, d4); }
+          wave_sync();  // (the list is rebuilt by the next pass)
         }
-        wave_sync();
         K4_MARK(5);
         // ---- phase 3: compact in place (all reads come from LDS, so overwriting the slot in HBM is safe) ----------------
+        // survivors of a chunk = its positions that are not the y of a site; tokens before the first site neither move nor change
         uint32_t *dst = ts.tok + (size_t)t * SLOT;
-        for (int c = first_site_chunk; c < nchunks; c++) {  // tokens before the first site neither move nor change
+        uint32_t abase = (uint32_t)first_site_chunk * 64u;
+        unsigned long long sm_prev = 0ull;
+        for (int c = first_site_chunk; c < nchunks; c++) {
           const int p = c * 64 + lane;
-          const unsigned long long am = uni64(W.amask[c]), smc = uni64(W.sitemask[c]);  // (amask has no bits behind the tile's end)
-          const uint32_t ab = uni(W.abase[c]);
+          const unsigned long long smc = uni64(W.sitemask[c]);
+          const int left = n - c * 64;
+          const unsigned long long am = (left >= 64 ? ~0ull : (1ull << left) - 1ull) & ~((smc << 1) | (sm_prev >> 63));
           if (lane_bit(am)) {
-            const uint32_t np = ab + lanes_below(am);
+            const uint32_t np = abase + lanes_below(am);
             const uint32_t t0 = W.tk[p];
             dst[np] = lane_bit(smc) ? (NEWTOK(p) | (t0 & TOK_WS)) : (t0 & ~(L_ISX | L_ISY));
           }
+          abase += (uint32_t)__popcll(am);
+          sm_prev = smc;
         }
         // invariant: slots behind the live prefix hold zeros (id 0 is a special token: never flagged, never part of a rule),
         // so the register-level dismissal needs no bounds checks
