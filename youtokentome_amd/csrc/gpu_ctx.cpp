@@ -887,9 +887,6 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   } else {
     prev_flag_toks_.swap(now);
   }
-  // sparse round: dirty tiles are queued per workgroup and processed after the streaming pass (k_tiles: dq_*)
-  static const int defer_pct = getenv("YTTM_DEFER_PCT") ? atoi(getenv("YTTM_DEFER_PCT")) : 45;
-  const bool defer = defer_pct >= 1000 /* tests: always */ || (touched_last_ != (~0ull >> 2) && touched_last_ * 100 < (unsigned long long)n_tiles * (unsigned long long)defer_pct);
   t_begin(KT_MERGE);
   if (!by_args)
     launch_round_begin(h_rules, cap, d_rules_, h_upd, n_upd, d_tokflag_, d_flagbits_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr,
@@ -897,7 +894,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   for (int ci = 0; ci < 2; ci++) {
     if (!cls_[ci].n_tiles) continue;
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
-                       cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/by_args || dense_class(ci), defer,
+                       cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/by_args || dense_class(ci),
                        by_args ? &ba : nullptr, st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);

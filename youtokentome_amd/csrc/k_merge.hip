@@ -235,13 +235,13 @@ __device__ inline uint32_t flag2_big(uint32_t tok, uint32_t f, const uint8_t *__
   return id < FLAG_LDS_IDS ? f : (uint32_t)(tokflag[id] & 3u);
 }
 
+// per lane: does one of my (up to 16) adjacencies look like a merge site?  f[j] = the 2-bit batch flags of my tokens
 template <int SLOT>
-__device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds, const uint8_t *__restrict__ tokflag, uint32_t self_x,
-                                      const RuleProbe probe = RuleProbe{nullptr, nullptr, 0}) {
+__device__ inline bool reg_flag_test(const uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds, const uint8_t *__restrict__ tokflag, uint32_t self_x,
+                                     uint4 (&f)[SLOT / 256]) {
   const int lane = lane_id();
   // flags first, tokens untouched: most tiles are dismissed here and never need the flagged tokens.  Slots behind the live
   // prefix hold zeros (never flagged), rows that start behind it were not loaded (zeros too): no bounds checks.
-  uint4 f[SLOT / 256];
   bool big = false;
 #pragma unroll
   for (int j = 0; j < SLOT / 256; j++) {
@@ -291,6 +291,15 @@ __device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint3
     }
 #undef SELF
   }
+  return cand;
+}
+
+template <int SLOT>
+__device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds, const uint8_t *__restrict__ tokflag, uint32_t self_x,
+                                      const RuleProbe probe = RuleProbe{nullptr, nullptr, 0}) {
+  const int lane = lane_id();
+  uint4 f[SLOT / 256];
+  const bool cand = reg_flag_test<SLOT>(r, n, flagbits_lds, tokflag, self_x, f);
   if (__ballot(cand) == 0) return false;
   // the tile is staged (or tested exactly): now the tokens get their flag bits
 #pragma unroll
@@ -321,6 +330,59 @@ __device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint3
   }
 #undef PAIR_EXACT
   return __ballot(hit) != 0;
+}
+
+// K4, the tile still in registers: find the merge sites of the batch's x != y rules -- rule index to W.ridx[p], bit p of
+// W.sitemask -- with one hash lookup per flagged adjacency, before anything is staged.  Returns 0 for a tile with neither
+// such a site nor an x x of the self rule (nothing to do: the x/y flags are per token, and late in training two thirds of
+// the tiles with a flagged adjacency hold no merge site), else 1, plus 2 if the self rule may have sites (those need the
+// run they sit in and are found from LDS once the tile is staged).
+template <int SLOT, bool LDSR>
+__device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds,
+                                     const uint8_t *__restrict__ tokflag, uint32_t self_x, const RuleTab<LDSR> &rtab) {
+  const int lane = lane_id();
+  uint4 f[SLOT / 256];
+  const bool cand = reg_flag_test<SLOT>(r, n, flagbits_lds, tokflag, self_x, f);
+  if (__ballot(cand) == 0) return 0;
+  if (lane < SLOT / 64) W.sitemask[lane] = 0ull;
+  wave_sync();
+  uint32_t *sm32 = reinterpret_cast<uint32_t *>(W.sitemask);
+  bool found = false, selfp = false;
+#define PAIR_SITE(T0, T1, F0, F1, P)                                                     \
+  if (!((T1)&TOK_WS)) {                                                                  \
+    const uint32_t a_ = (T0)&L_ID, b_ = (T1)&L_ID;                                       \
+    if (a_ == self_x && b_ == self_x) {                                                  \
+      selfp = true;                                                                      \
+    } else if (((F0)&1u) && ((F1)&2u)) {                                                 \
+      const uint32_t ri = rtab.find(a_, b_);                                             \
+      if (ri != 0xffffffffu) {                                                           \
+        W.ridx[(P)] = (uint16_t)ri;                                                      \
+        atomicOr(&sm32[(P) >> 5], 1u << ((P)&31));                                       \
+        found = true;                                                                    \
+      }                                                                                  \
+    }                                                                                    \
+  }
+#pragma unroll
+  for (int j = 0; j < SLOT / 256; j++) {
+    if (256 * j < n) {
+      // first token of the lane to my right (lane 63: of the next row), and its flags; slots behind the tile's end hold zeros
+      uint32_t nx = __shfl_down(r[j].x, 1), fnx = __shfl_down(f[j].x, 1);
+      uint32_t nx0 = TOK_WS, fnx0 = 0;
+      if (j + 1 < SLOT / 256) {
+        nx0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
+        fnx0 = __shfl(f[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
+      }
+      if (lane == 63) { nx = nx0; fnx = fnx0; }
+      const int p = 256 * j + 4 * lane;
+      PAIR_SITE(r[j].x, r[j].y, f[j].x, f[j].y, p)
+      PAIR_SITE(r[j].y, r[j].z, f[j].y, f[j].z, p + 1)
+      PAIR_SITE(r[j].z, r[j].w, f[j].z, f[j].w, p + 2)
+      PAIR_SITE(r[j].w, nx, f[j].w, fnx, p + 3)
+    }
+  }
+#undef PAIR_SITE
+  wave_sync();
+  return (__ballot(found) ? 1 : 0) | (__ballot(selfp) ? 3 : 0);
 }
 
 // registers -> LDS, sentinels (wave-local)
@@ -416,13 +478,16 @@ struct TileStats {
 template <int SLOT, bool MERGE, bool LDSR>
 __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &ts, const PairTable &pt, const DeltaBuf &db,
                                     const RuleTab<LDSR> &rtab, uint32_t self_x, uint32_t self_z,
-                                    uint32_t z_base, uint32_t t, int n, uint32_t word0, const WReg<SLOT> &wreg, TileStats &S) {
+                                    uint32_t z_base, uint32_t t, int n, uint32_t word0, const WReg<SLOT> &wreg, TileStats &S,
+                                    bool self_pass /* MERGE: the tile may hold sites of the x x rule */) {
   const int lane = lane_id();
   unsigned long long &my_sites = S.sites, &st_touched = S.touched, &st_scanned = S.scanned, &st_touched_tok = S.touched_tok;
     const int nchunks = (n + 63) >> 6;
     st_scanned += (unsigned long long)n;
 
-    // ---- phase 1a: word-start masks; (MERGE) merge-site candidates = x-flagged token followed by a y-flagged token ----
+    // ---- phase 1a: word-start masks per 64-token chunk.  (MERGE) the sites of the x != y rules were found in registers
+    // (reg_find_sites); those of an x x rule are found here: left-to-right greedy inside a run of x's = the positions at an
+    // even offset from the run's start.
     uint32_t wbase = 0;
     bool any = false;
     int nsites = 0, first_site_chunk = nchunks;  // (MERGE)
@@ -432,34 +497,25 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
       if (p < n) {
         const uint32_t t0 = W.tk[p];
         ws = t0 & TOK_WS;
-        if (MERGE) {
+        if (MERGE && self_pass) {
           const uint32_t t1 = W.tk[p + 1];
-          if (!(t1 & TOK_WS)) {
-            const uint32_t a = t0 & L_ID, b = t1 & L_ID;
-            if (a == self_x && b == self_x) {
-              // x==y rule: left-to-right greedy inside the run = positions at even offset from the run start
-              int q = p;
-              while (q > 0 && !(W.tk[q] & TOK_WS) && (W.tk[q - 1] & L_ID) == a) q--;
-              if (((p - q) & 1) == 0) {
-                self_site = true;
-                W.ridx[p] = (uint16_t)(self_z - z_base);
-              }
-            } else if ((t0 & L_ISX) && (t1 & L_ISY)) {
-              const uint32_t ri = rtab.find(a, b);
-              if (ri != 0xffffffffu) {
-                self_site = true;
-                W.ridx[p] = (uint16_t)ri;
-              }
+          if (!(t1 & TOK_WS) && (t0 & L_ID) == self_x && (t1 & L_ID) == self_x) {
+            int q = p;
+            while (q > 0 && !(W.tk[q] & TOK_WS) && (W.tk[q - 1] & L_ID) == self_x) q--;
+            if (((p - q) & 1) == 0) {
+              self_site = true;
+              W.ridx[p] = (uint16_t)(self_z - z_base);
             }
           }
         }
       }
       const unsigned long long m = __ballot(ws);
-      const unsigned long long sm = MERGE ? __ballot(self_site) : 0ull;
+      unsigned long long sm = MERGE ? uni64(W.sitemask[c]) : 0ull;
+      if (MERGE && self_pass) sm |= __ballot(self_site);
       if (lane == 0) {
         W.wsmask[c] = m;
         W.wsbase[c] = wbase;
-        if (MERGE) W.sitemask[c] = sm;
+        if (MERGE && self_pass) W.sitemask[c] = sm;
       }
       wbase += (uint32_t)__popcll(m);
       if (MERGE && sm != 0ull) {
@@ -606,24 +662,14 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                                                     const uint32_t *__restrict__ worklist, const unsigned int *__restrict__ work_n,
                                                     unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */,
-                                                    BatchArgs ba, unsigned int defer) {
+                                                    BatchArgs ba) {
   __shared__ WaveLds<SLOT> WL[WPB];
   __shared__ AggLds A;
   __shared__ unsigned long long rkeys[LDSR ? APPLY_LDS_RULES : 1];
   __shared__ uint16_t rridx[LDSR ? APPLY_LDS_RULES : 1];
-  // Sparse rounds (defer != 0): a wave that finds a merge-site candidate in its tile does not stop to process it -- with
-  // tiles handed out statically, the wave that happens to own the most dirty tiles would set the duration of the launch.
-  // It queues the tile here; when all tiles have been looked at, the waves of the workgroup drain the queue together
-  // (tokens and word frequencies of the next entry in flight while the current one is processed).
-  constexpr int DQ_CAP = (MERGE && WPB > 1) ? 96 : 1;
-  __shared__ uint32_t dq_tile[DQ_CAP], dq_w0[DQ_CAP];
-  __shared__ uint16_t dq_len[DQ_CAP];
-  __shared__ unsigned int dq_n, dq_head;
-  if (threadIdx.x == 0) { dq_n = 0; dq_head = 0; }
 #ifdef YTTM_K4_PROF
   const unsigned long long wall0_ = wall_clock64();
 #endif
-  const bool use_dq = MERGE && WPB > 1 && defer != 0;
   const bool from_args = MERGE && LDSR && ba.k != 0;  // tables built from the kernel argument, nothing read from HBM
   agg_init<WPB * 64>(A, (MERGE && !from_args) ? flagbits : nullptr);
   if (from_args) {
@@ -704,29 +750,13 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
   S.t_last = (unsigned long long)clock64();
 #endif
   // tile i is in registers: flag/stage it; then (prefetch of tile i+1 by the caller); then process it from LDS
-  // sparse rounds: flagged adjacencies are looked up in the batch before the tile is staged -- the x/y flags are per token,
-  // and late in training two thirds of the tiles with a flagged adjacency hold no merge site at all
-  const RuleProbe probe = (MERGE && LDSR && defer != 0) ? RuleProbe{rkeys, rules, rule_mask} : RuleProbe{nullptr, nullptr, 0};
-  bool deferred = false;  // the tile just looked at went to the queue
-  auto stage_part = [&](int n0, uint32_t tile, uint32_t w0) {
-    // K4: a tile with no (x-flagged, y-flagged) adjacency is dismissed in registers and never touches LDS
-    bool dirty = MERGE ? reg_candidates<SLOT>(r, n0, A.flagbits, tokflag, self_x, probe) : true;
+  // tile i is in registers: look for merge sites / stage it; then (prefetch of tile i+1 by the caller); then process it from LDS
+  int site_state = 0;  // reg_find_sites() of the tile just looked at
+  auto stage_part = [&](int n0) {
+    // K4: a tile without a merge site is dismissed in registers and never touches LDS
+    site_state = MERGE ? reg_find_sites<SLOT, LDSR>(W, r, n0, A.flagbits, tokflag, self_x, rtab) : 1;
     if (MERGE) K4_MARK(0);
-    deferred = false;
-    if (use_dq && dirty) {
-      unsigned int qi = 0;
-      if (lane == 0) qi = atomicAdd(&dq_n, 1u);
-      qi = uni(__shfl(qi, 0));
-      if (qi < (unsigned int)DQ_CAP) {  // (a full queue: the tile is processed on the spot)
-        if (lane == 0) {
-          dq_tile[qi] = tile;
-          dq_w0[qi] = w0;
-          dq_len[qi] = (uint16_t)n0;
-        }
-        deferred = true;
-        dirty = false;
-      }
-    }
+    const bool dirty = site_state != 0;
     if (dirty) tile_stage<SLOT>(W, r, n0);
     if (MERGE) K4_MARK(1);
     return dirty;
@@ -735,9 +765,9 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
     if (MERGE) K4_MARK(2);
     if (dirty) {
       K4_COUNT(8);
-      process_tile<SLOT, MERGE, LDSR>(W, A, ts, pt, db, rtab, self_x, self_z, z_base, tile, n0, w0, wcur, S);
+      process_tile<SLOT, MERGE, LDSR>(W, A, ts, pt, db, rtab, self_x, self_z, z_base, tile, n0, w0, wcur, S, (site_state & 2) != 0);
       wave_sync();  // everyone is done with this tile's LDS state before it is restaged
-    } else if (!deferred) {
+    } else {
       S.scanned += (unsigned long long)n0;
     }
   };
@@ -753,7 +783,7 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
     const int n0 = uni(__shfl(hn, j));  // (uniform, and now the compiler knows: tile loops and branches run on the scalar unit)
     const uint32_t w0 = uni(__shfl(hw, j));
     const uint32_t tile = uni(__shfl(ht, j));
-    const bool dirty = stage_part(n0, tile, w0);
+    const bool dirty = stage_part(n0);
     // K4: most tiles are dismissed in registers late in training -- their word frequencies are never needed, so they are
     // loaded only now, for a dirty tile, ahead of the next tile's prefetch (first use is in phase 2)
     if (MERGE && dirty) wreg_load<SLOT>(wq, ts.wcnt, w0);
@@ -772,39 +802,6 @@ __global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_til
     }
     process_part(dirty, tile, n0, w0, wcur);
     t = t_next;
-  }
-  if (use_dq) {
-    __syncthreads();  // every wave has looked at all its tiles: the queue is complete
-    const unsigned int qn0 = uni(dq_n), qn = qn0 < (unsigned int)DQ_CAP ? qn0 : (unsigned int)DQ_CAP;
-    auto pop = [&]() {
-      unsigned int i = 0;
-      if (lane == 0) i = atomicAdd(&dq_head, 1u);
-      return uni((uint32_t)__shfl(i, 0));
-    };
-    unsigned int qi = pop();
-    uint32_t q_tile = 0, q_w0 = 0;
-    int q_len = 0;
-    if (qi < qn) {
-      q_tile = uni(dq_tile[qi]); q_w0 = uni(dq_w0[qi]); q_len = uni((int)dq_len[qi]);
-      tile_fetch<SLOT>(r, ts, q_tile, q_len);
-      wreg_load<SLOT>(wq, ts.wcnt, q_w0);
-    }
-    while (qi < qn) {
-      const uint32_t tile = q_tile, w0 = q_w0;
-      const int n0 = q_len;
-      (void)reg_candidates<SLOT>(r, n0, A.flagbits, tokflag, self_x);  // known to hold a candidate: this puts the flag bits on its tokens
-      tile_stage<SLOT>(W, r, n0);
-      const WReg<SLOT> wcur = wq;
-      qi = pop();
-      if (qi < qn) {
-        q_tile = uni(dq_tile[qi]); q_w0 = uni(dq_w0[qi]); q_len = uni((int)dq_len[qi]);
-        tile_fetch<SLOT>(r, ts, q_tile, q_len);
-        wreg_load<SLOT>(wq, ts.wcnt, q_w0);
-      }
-      K4_COUNT(8);
-      process_tile<SLOT, MERGE, LDSR>(W, A, ts, pt, db, rtab, self_x, self_z, z_base, tile, n0, w0, wcur, S);
-      wave_sync();
-    }
   }
   if (MERGE) {
     S.sites = wave_sum_u64(S.sites);
@@ -1341,18 +1338,17 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{}, 0u);
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{});
   else
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{}, 0u);
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{});
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
-                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, bool defer, const BatchArgs *ba,
+                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
                         hipStream_t st) {
   if (!ts.n_tiles) return;
-  const unsigned int dq = defer ? 1u : 0u;
   const BatchArgs bargs = ba ? *ba : BatchArgs{};
   const RuleSlot *frules = exact_filter ? rules : nullptr;
   // dense round (nearly every tile held a site last round): the filter pass would keep everything -- the apply kernel
@@ -1367,19 +1363,19 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, true>), dim3(tile_grid(ts.n_tiles, 4, 5)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, dq);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, false>), dim3(tile_grid(ts.n_tiles, 4, 5)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, dq);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
   } else {
     if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, dq);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, dq);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
   }
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
