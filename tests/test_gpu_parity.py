@@ -41,6 +41,9 @@ def test_k4_merge_apply_rounds():
     S.check_merge_rounds(gen.readme_corpus(1500, 100, seed=9), rounds=25, seed=3)
     t = ("aaaa aaaaa aaaaaaa abababab aabbaabb abcabcabc bbbbbb ab aaab baaa " + "a" * 700 + " " + "ab" * 500 + " ") * 3
     S.check_merge_rounds(t.encode(), rounds=14, seed=1)
+    # more than 64 / 128 merge sites in one class-A tile (phase 2 takes them 64 per pass)
+    words = ["ab" * k for k in range(60, 125, 7)] + ["a" * k for k in range(150, 250, 13)] + ["abc" * k for k in (50, 70, 80)]
+    S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=8, seed=4)
 
 
 @pytest.mark.parametrize("name", S.golden_train_names())

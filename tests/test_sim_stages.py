@@ -36,6 +36,12 @@ def test_merge_apply_runs():
     S.check_merge_rounds(t, rounds=12, seed=1)
 
 
+def test_merge_apply_many_sites_per_tile():
+    """More than 64 (and more than 128) merge sites in one class-A tile: phase 2 of K4 takes them 64 per pass."""
+    words = ["ab" * k for k in range(60, 125, 7)] + ["a" * k for k in range(150, 250, 13)] + ["abc" * k for k in (50, 70, 80)]
+    S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=8, seed=4)
+
+
 @pytest.mark.parametrize("name", S.golden_train_names())
 def test_golden_train(name, tmp_path):
     S.check_golden_train(name, tmp_path)

@@ -521,6 +521,10 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
       if (MERGE && sm != 0ull) {
         if (!any) first_site_chunk = c;
         any = true;
+        if (nsites < 64 && lane_bit(sm)) {  // the first 64 sites go straight to the list phase 2 works from
+          const int rk = nsites + (int)lanes_below(sm);
+          if (rk < 64) W.sitepos[rk] = (uint16_t)p;
+        }
         nsites += __popcll(sm);
       }
     }
@@ -562,7 +566,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         if (lane == 0) my_sites += (unsigned long long)nsites;
         for (int base = 0; base < nsites; base += 64) {
           int before = 0;  // sites in the chunks already looked at
-          for (int c = first_site_chunk; c < nchunks && before < base + 64; c++) {
+          for (int c = first_site_chunk; base != 0 && c < nchunks && before < base + 64; c++) {  // (pass 0: listed by phase 1a)
             const unsigned long long smc = uni64(W.sitemask[c]);
             const int cnt = __popcll(smc);
             if (cnt != 0 && before + cnt > base && lane_bit(smc)) {
@@ -657,7 +661,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
 }
 
 template <int SLOT, int WPB, bool MERGE, bool LDSR>
-__global__ __launch_bounds__(WPB * 64, (WPB == 4 && MERGE) ? 5 : WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
+__global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 3 : WPB) : WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                                                     const uint32_t *__restrict__ worklist, const unsigned int *__restrict__ work_n,
@@ -1326,6 +1330,8 @@ void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, un
   hipLaunchKernelGGL(k_repack_len, dim3((n_new + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, gstart, n_new, total, new_len);
 }
 
+// class-A apply kernel: waves per workgroup x workgroups per CU (6 x 4 = 6 waves per SIMD: <= 80 VGPRs, <= 40 KB LDS per workgroup)
+constexpr int APPLY_WPB = 8, APPLY_BPC = 3;
 static inline unsigned int tile_grid(unsigned int n_tiles, unsigned int wpb, unsigned int blocks_per_cu) {
   unsigned int need = (n_tiles + wpb - 1) / wpb;
   unsigned int g = 256u * blocks_per_cu;
@@ -1362,10 +1368,10 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
     if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
-      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, true>), dim3(tile_grid(ts.n_tiles, 4, 5)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, true>), dim3(tile_grid(ts.n_tiles, APPLY_WPB, APPLY_BPC)), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
                          tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
     else
-      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, true, false>), dim3(tile_grid(ts.n_tiles, 4, 5)), dim3(256), 0, st, ts, pt, db, rules, rule_mask,
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, false>), dim3(tile_grid(ts.n_tiles, APPLY_WPB, APPLY_BPC)), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
                          tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
   } else {
     if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
