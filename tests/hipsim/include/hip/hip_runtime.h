@@ -144,6 +144,7 @@ static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
 // wave-uniform values: readfirstlane is the identity here (the value is the same in every lane by contract); the mask
 // builtins index the uniform mask with the lane id
 #define __builtin_amdgcn_readfirstlane(v) (v)
+#define __builtin_amdgcn_readlane(v, l) __shfl((int)(v), (int)(l))
 static inline bool __builtin_amdgcn_inverse_ballot_w64(unsigned long long m) { return (m >> (threadIdx.x & 63u)) & 1ull; }
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned lo, unsigned acc) {
   const unsigned l = threadIdx.x & 63u;

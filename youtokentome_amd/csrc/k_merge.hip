@@ -339,8 +339,11 @@ __device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint3
 // run they sit in and are found from LDS once the tile is staged).
 template <int SLOT, bool LDSR>
 __device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds,
-                                     const uint8_t *__restrict__ tokflag, uint32_t self_x, const RuleTab<LDSR> &rtab) {
+                                     const uint8_t *__restrict__ tokflag, uint32_t self_x, const RuleTab<LDSR> &rtab,
+                                     uint32_t &my_cnt /* sites found by this lane */, uint32_t &my_site /* the last one: position << 16 | rule index */) {
   const int lane = lane_id();
+  my_cnt = 0;
+  my_site = 0;
   uint4 f[SLOT / 256];
   const bool cand = reg_flag_test<SLOT>(r, n, flagbits_lds, tokflag, self_x, f);
   if (__ballot(cand) == 0) return 0;
@@ -359,6 +362,8 @@ __device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 2
         W.ridx[(P)] = (uint16_t)ri;                                                      \
         atomicOr(&sm32[(P) >> 5], 1u << ((P)&31));                                       \
         found = true;                                                                    \
+        my_cnt++;                                                                        \
+        my_site = ((uint32_t)(P) << 16) | ri;                                            \
       }                                                                                  \
     }                                                                                    \
   }
@@ -383,6 +388,102 @@ __device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 2
 #undef PAIR_SITE
   wave_sync();
   return (__ballot(found) ? 1 : 0) | (__ballot(selfp) ? 3 : 0);
+}
+
+// K4, a tile with exactly ONE merge site (nine dirty tiles in ten late in training), handled where it is -- in registers:
+// the four tokens around the site and the word's frequency are fetched as wave-uniform scalars, lanes 0..3 emit the (at
+// most) four count deltas together, and the tokens behind the site move up by one with a lane-to-lane shift before the
+// rows are written back with the same 16-byte stores they were loaded with.  Nothing is staged.  Returns false (nothing
+// done) if a run of equal tokens touches the site: those cases need the run's length and go the general way.
+// site = position << 16 | rule index (uniform).
+template <int SLOT>
+__device__ inline bool single_site_tile(const uint4 (&r)[SLOT / 256], AggLds &A, WaveLds<SLOT> &W, const TileSet &ts, const PairTable &pt, const DeltaBuf &db,
+                                        uint32_t t, int n, uint32_t word0, uint32_t site, uint32_t z_base) {
+  static_assert(SLOT >= 512, "rows 0 and 1");
+  const int lane = lane_id();
+  const int p = (int)(site >> 16);
+  const uint32_t z = z_base + (site & 0xffffu);
+  // token at tile position q (uniform): component q & 3 of row q >> 8 in lane (q >> 2) & 63
+#define TOK_AT(OUT, Q)                                                                     \
+  {                                                                                        \
+    const int q_ = (Q), c_ = q_ & 3;                                                       \
+    /* (masks, not selects: a select chain over the components becomes an indexed access and puts r[] into scratch) */ \
+    const uint32_t m0_ = 0u - (uint32_t)(c_ == 0), m1_ = 0u - (uint32_t)(c_ == 1), m2_ = 0u - (uint32_t)(c_ == 2), \
+                   m3_ = 0u - (uint32_t)(c_ == 3), hi_ = 0u - (uint32_t)(q_ >> 8); /* (class A: two rows) */            \
+    const uint32_t a0_ = (r[0].x & m0_) | (r[0].y & m1_) | (r[0].z & m2_) | (r[0].w & m3_);                              \
+    const uint32_t a1_ = (r[1].x & m0_) | (r[1].y & m1_) | (r[1].z & m2_) | (r[1].w & m3_);                              \
+    const uint32_t v_ = (a1_ & hi_) | (a0_ & ~hi_);                                                                       \
+    OUT = (uint32_t)__builtin_amdgcn_readlane((int)v_, (q_ >> 2) & 63);                    \
+  }
+  uint32_t t0, t1;
+  TOK_AT(t0, p)
+  TOK_AT(t1, p + 1)
+  const uint32_t x = t0 & L_ID, y = t1 & L_ID;
+  const bool hasL = p > 0 && !(t0 & TOK_WS);
+  uint32_t L = 0, R = 0;
+  if (hasL) {
+    TOK_AT(L, p - 1)
+    L &= L_ID;
+  }
+  bool hasR = p + 2 < n;
+  if (hasR) {
+    uint32_t t2;
+    TOK_AT(t2, p + 2)
+    hasR = !(t2 & TOK_WS);
+    R = t2 & L_ID;
+  }
+#undef TOK_AT
+  if ((hasL && L == x) || (hasR && R == y)) return false;
+  // the word that contains p: number of word starts at positions <= p (lane l holds positions 256 j + 4 l + {0..3})
+  const int jp = p >> 8, lp = (p >> 2) & 63, cp = p & 3;
+  uint32_t widx = 0;
+#pragma unroll
+  for (int j = 0; j < SLOT / 256; j++) {
+    if (j <= jp) {
+      const unsigned long long m0 = __ballot(r[j].x >> 31), m1 = __ballot(r[j].y >> 31), m2 = __ballot(r[j].z >> 31), m3 = __ballot(r[j].w >> 31);
+      if (j < jp) {
+        widx += (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+      } else {
+        const unsigned long long lt = (1ull << lp) - 1ull;
+        widx += (uint32_t)(__popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt));
+        widx += (uint32_t)((m0 >> lp) & 1ull);
+        if (cp >= 1) widx += (uint32_t)((m1 >> lp) & 1ull);
+        if (cp >= 2) widx += (uint32_t)((m2 >> lp) & 1ull);
+        if (cp >= 3) widx += (uint32_t)((m3 >> lp) & 1ull);
+      }
+    }
+  }
+  const long long f = (long long)ts.wcnt[word0 + widx - 1u];
+  // ---- tokens behind the site move up by one; the site becomes z
+  const uint32_t zw = z | (t0 & TOK_WS);
+  uint4 *dst = reinterpret_cast<uint4 *>(ts.tok + (size_t)t * SLOT);
+#pragma unroll
+  for (int j = 0; j < SLOT / 256; j++) {
+    if (j >= jp && 256 * j < n) {
+      uint32_t nxt = __shfl_down(r[j].x, 1);  // first token of the lane to my right (lane 63: of the next row; zeros behind the end)
+      uint32_t nxt0 = 0;
+      if (j + 1 < SLOT / 256) nxt0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
+      if (lane == 63) nxt = nxt0;
+      const int q0 = 256 * j + 4 * lane;
+      const uint4 o = r[j];
+      uint4 v;
+      v.x = q0 < p ? o.x : (q0 == p ? zw : o.y);
+      v.y = q0 + 1 < p ? o.y : (q0 + 1 == p ? zw : o.z);
+      v.z = q0 + 2 < p ? o.z : (q0 + 2 == p ? zw : o.w);
+      v.w = q0 + 3 < p ? o.w : (q0 + 3 == p ? zw : nxt);
+      if (q0 + 3 >= p && q0 < n) dst[lane + 64 * j] = v;
+    }
+  }
+  if (lane == 0) ts.tile_len[t] = (uint32_t)(n - 1);
+  // ---- count deltas: (L,x) -> (L,z) and (y,R) -> (z,R); the merged pair itself is zeroed after the round
+  const bool v = lane < 2 ? hasL : (lane < 4 && hasR);
+  if (__ballot(v)) {
+    if (v) {
+      const unsigned long long key = lane == 0 ? pair_key(L, x) : lane == 1 ? pair_key(L, z) : lane == 2 ? pair_key(y, R) : pair_key(z, R);
+      emit<SLOT>(A, W, pt, db, key, (lane & 1) ? f : -f);
+    }
+  }
+  return true;
 }
 
 // registers -> LDS, sentinels (wave-local)
@@ -661,7 +762,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
 }
 
 template <int SLOT, int WPB, bool MERGE, bool LDSR>
-__global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 3 : WPB) : WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
+__global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WPB) : WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                                                     const uint32_t *__restrict__ worklist, const unsigned int *__restrict__ work_n,
@@ -756,11 +857,27 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 3 : WP
   // tile i is in registers: flag/stage it; then (prefetch of tile i+1 by the caller); then process it from LDS
   // tile i is in registers: look for merge sites / stage it; then (prefetch of tile i+1 by the caller); then process it from LDS
   int site_state = 0;  // reg_find_sites() of the tile just looked at
-  auto stage_part = [&](int n0) {
+  auto stage_part = [&](int n0, uint32_t tile, uint32_t w0) {
     // K4: a tile without a merge site is dismissed in registers and never touches LDS
-    site_state = MERGE ? reg_find_sites<SLOT, LDSR>(W, r, n0, A.flagbits, tokflag, self_x, rtab) : 1;
+    uint32_t my_cnt = 0, my_site = 0;
+    site_state = MERGE ? reg_find_sites<SLOT, LDSR>(W, r, n0, A.flagbits, tokflag, self_x, rtab, my_cnt, my_site) : 1;
     if (MERGE) K4_MARK(0);
-    const bool dirty = site_state != 0;
+    bool dirty = site_state != 0;
+    if (MERGE && SLOT == TILE_SLOT_A && site_state == 1) {  // sites of x != y rules only: is it a single one?
+      const unsigned long long fm = __ballot(my_cnt != 0);
+      if (__popcll(fm) == 1) {
+        const int src = __ffsll((long long)fm) - 1;
+        if (__builtin_amdgcn_readlane((int)my_cnt, src) == 1) {
+          const uint32_t site = (uint32_t)__builtin_amdgcn_readlane((int)my_site, src);
+          if (single_site_tile<SLOT>(r, A, W, ts, pt, db, tile, n0, w0, site, z_base)) {
+            dirty = false;
+            if (lane == 0) S.sites++;
+            S.touched++;
+            S.touched_tok += (unsigned long long)n0;
+          }
+        }
+      }
+    }
     if (dirty) tile_stage<SLOT>(W, r, n0);
     if (MERGE) K4_MARK(1);
     return dirty;
@@ -787,7 +904,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 3 : WP
     const int n0 = uni(__shfl(hn, j));  // (uniform, and now the compiler knows: tile loops and branches run on the scalar unit)
     const uint32_t w0 = uni(__shfl(hw, j));
     const uint32_t tile = uni(__shfl(ht, j));
-    const bool dirty = stage_part(n0);
+    const bool dirty = stage_part(n0, tile, w0);
     // K4: most tiles are dismissed in registers late in training -- their word frequencies are never needed, so they are
     // loaded only now, for a dirty tile, ahead of the next tile's prefetch (first use is in phase 2)
     if (MERGE && dirty) wreg_load<SLOT>(wq, ts.wcnt, w0);
