@@ -149,14 +149,20 @@ def main():
     if os.path.exists(pmc_file) and args.size_mb == 1000 and args.corpus == "abcd" and args.vocab == 32000 and n_gpus == 1:
         pm = json.load(open(pmc_file))
         # kernel families as the trainer times them; a family's traffic per launch = bytes of all its kernels / its launches
-        fam = {"char_hist": ("k_scan_bytes<0>",), "segments": ("k_scan_bytes<1>",), "dedup": ("k2b_insert_words",),
-               "pair_count": ("k_tiles<512, 4, false", "k_tiles<4096, 1, false"),
-               "merge_apply": ("k_filter<", "k_tiles<512, 4, true", "k_tiles<4096, 1, true"), "cand_scan": ("k_hot_scan", "k_cand_scan")}
-        for name, prefixes in fam.items():
-            ks = [k for k in pm if k.startswith(prefixes)]
+        def family(k):  # k_tiles<SLOT, WPB, MERGE, LDSR>: MERGE=false is K3 (pair count), true is K4 (merge apply)
+            if k.startswith("k_tiles<"):
+                return "merge_apply" if k[len("k_tiles<"):].split(", ")[2] == "true" else "pair_count"
+            for name, prefixes in (("char_hist", ("k_scan_bytes<0>",)), ("segments", ("k_scan_bytes<1>",)), ("dedup", ("k2b_insert_words",)),
+                                   ("merge_apply", ("k_filter<", "k_giant<true")), ("pair_count", ("k_giant<false",)),
+                                   ("cand_scan", ("k_hot_scan", "k_cand_scan"))):
+                if k.startswith(prefixes):
+                    return name
+            return None
+        for name in ("char_hist", "segments", "dedup", "pair_count", "merge_apply", "cand_scan"):
+            ks = [k for k in pm if family(k) == name]
             if ks and name in kern:
                 total = sum(pm[k]["traffic_bytes_per_launch"] * pm[k]["launches"] for k in ks)
-                traffic[name] = round(total / max(1, max(pm[k]["launches"] for k in ks)))
+                traffic[name] = round(total / max(1, kern[name]["launches"]))  # per launch of the family as the trainer counts them
     dom = max(kern, key=lambda n: kern[n]["ms_total"]) if kern else None
     roofline = None
     if dom:
