@@ -41,6 +41,10 @@ def test_k4_merge_apply_rounds():
     S.check_merge_rounds(gen.readme_corpus(1500, 100, seed=9), rounds=25, seed=3)
     t = ("aaaa aaaaa aaaaaaa abababab aabbaabb abcabcabc bbbbbb ab aaab baaa " + "a" * 700 + " " + "ab" * 500 + " ") * 3
     S.check_merge_rounds(t.encode(), rounds=14, seed=1)
+    # ids >= 32768: flags from the HBM table instead of the LDS bitmap
+    for i, t in enumerate(S.texts_small(5, n=3, size=8000)):
+        if t.strip():
+            S.check_merge_rounds(t, rounds=8, seed=i, id_shift=40000)
     # more than 64 / 128 merge sites in one class-A tile (phase 2 takes them 64 per pass)
     words = ["ab" * k for k in range(60, 125, 7)] + ["a" * k for k in range(150, 250, 13)] + ["abc" * k for k in (50, 70, 80)]
     S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=8, seed=4)
@@ -104,6 +108,15 @@ def test_zipf_corpus_vs_oracle(tmp_path):
     text = gen.zipf_corpus(3_000_000, vocab=30000)
     model = S.check_train_vs_oracle(text, 6000, tmp_path, tag="z")
     sents = [ln.decode() for ln in gen.zipf_corpus(200000, seed=11, vocab=30000).split(b"\n") if ln]
+    S.check_encode_vs_oracle(model, sents, flags=((0, 0, 0), (1, 1, 1)))
+
+
+def test_vocab_above_32768_vs_oracle(tmp_path):
+    """vocab_size 40000: token ids leave the kernels' 32768-id LDS flag bitmap (flags from the HBM table, batches uploaded
+    instead of passed as kernel arguments); the encoder works with 40000 rules."""
+    text = gen.zipf_corpus(6_000_000, seed=5, vocab=150000)
+    model = S.check_train_vs_oracle(text, 40000, tmp_path, tag="v40k")
+    sents = [ln.decode() for ln in gen.zipf_corpus(100000, seed=12, vocab=150000).split(b"\n") if ln]
     S.check_encode_vs_oracle(model, sents, flags=((0, 0, 0), (1, 1, 1)))
 
 

@@ -36,6 +36,15 @@ def test_merge_apply_runs():
     S.check_merge_rounds(t, rounds=12, seed=1)
 
 
+def test_merge_apply_ids_above_the_lds_bitmap():
+    """Token ids >= 32768 (vocab_size 50000, large alphabets): flags come from the HBM table, batches are uploaded."""
+    for i, t in enumerate(S.texts_small(5, n=2, size=1500)):
+        if t.strip():
+            S.check_merge_rounds(t, rounds=6, seed=i, id_shift=40000)
+    t = ("aaaa aaaaa abababab aabbaabb abcabcabc bbbbbb ab aaab baaa " * 3).encode()
+    S.check_merge_rounds(t, rounds=10, seed=1, id_shift=33000)
+
+
 def test_merge_apply_many_sites_per_tile():
     """More than 64 (and more than 128) merge sites in one class-A tile: phase 2 of K4 takes them 64 per pass."""
     words = ["ab" * k for k in range(60, 125, 7)] + ["a" * k for k in range(150, 250, 13)] + ["abc" * k for k in (50, 70, 80)]
