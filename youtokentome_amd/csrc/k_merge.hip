@@ -15,6 +15,8 @@
 // by the workgroup, then 64-bit atomics into the HBM pair table), compacts the tile with wave ballots and writes it
 // back in place.
 // HBM-bound integer work: no MFMA.
+#include <type_traits>
+
 #include "yttm_device.h"
 #include "yttm_kernels.h"
 
@@ -35,10 +37,12 @@ template <int SLOT>
 struct WaveLds {
   uint32_t tk[SLOT + 4];                   // staged tokens (+ sentinels)
   uint16_t ridx[SLOT];                     // merge site at p: index of its rule in the batch (z = z_base + ridx)
-  unsigned long long wsmask[SLOT / 64];    // bit p: token p starts a word
+  unsigned long long wsmask[SLOT / 64];    // K3: bit p of chunk c: token 64 c + p starts a word.  K4: the same bits as the registers hold
+                                           // them, mask 4 j + i = ballot over lanes l of "token 256 j + 4 l + i starts a word" (stage_ws_masks)
   unsigned long long sitemask[SLOT / 64];  // bit p: a merge (tk[p],tk[p+1]) starts at p
-  uint32_t wsbase[SLOT / 64];              // number of word starts before the chunk
+  uint32_t wsbase[SLOT / 64];              // number of word starts before the chunk (K4: before row j)
   uint16_t sitepos[64];                    // positions of the (up to) 64 merge sites a pass of phase 2 works on
+  unsigned int sctl[2];                    // K4: number of merge sites found in the tile, position of the first one
 };
 struct AggLds {
   unsigned long long key[AGG_SLOTS];
@@ -332,6 +336,44 @@ __device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint3
   return __ballot(hit) != 0;
 }
 
+// a merge site at position p joins the tile's list (any order; the first 64 are listed, the count goes on) and the minimum
+template <int SLOT>
+__device__ inline void site_listed(WaveLds<SLOT> &W, int p) {
+  const unsigned int idx = atomicAdd(&W.sctl[0], 1u) & 0xffffu;
+  if (idx < 64u) W.sitepos[idx] = (uint16_t)p;
+  atomicMin(&W.sctl[1], (unsigned int)p);
+}
+// K4: word-start bits of a dirty tile go to LDS the way the registers hold them (no pass over the staged tokens); the word
+// that contains position p is then tile_word_index_rl(p)
+template <int SLOT>
+__device__ inline void stage_ws_masks(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256], int n) {
+  uint32_t before = 0;
+#pragma unroll
+  for (int j = 0; j < SLOT / 256; j++) {
+    if (256 * j < n) {
+      const unsigned long long m0 = __ballot(r[j].x >> 31), m1 = __ballot(r[j].y >> 31), m2 = __ballot(r[j].z >> 31), m3 = __ballot(r[j].w >> 31);
+      if (lane_id() == 0) {
+        W.wsmask[4 * j] = m0; W.wsmask[4 * j + 1] = m1; W.wsmask[4 * j + 2] = m2; W.wsmask[4 * j + 3] = m3;
+        W.wsbase[j] = before;
+      }
+      before += (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+    }
+  }
+}
+template <int SLOT>
+__device__ inline uint32_t tile_word_index_rl(const WaveLds<SLOT> &W, int p) {
+  const int j = p >> 8, l = (p >> 2) & 63, c = p & 3;
+  const unsigned long long lt = (1ull << l) - 1ull;
+  uint32_t k = W.wsbase[j];
+#pragma unroll
+  for (int cc = 0; cc < 4; cc++) {
+    const unsigned long long m = W.wsmask[4 * j + cc];
+    k += (uint32_t)__popcll(m & lt);
+    if (cc <= c) k += (uint32_t)((m >> l) & 1ull);
+  }
+  return k - 1u;
+}
+
 // K4, the tile still in registers: find the merge sites of the batch's x != y rules -- rule index to W.ridx[p], bit p of
 // W.sitemask -- with one hash lookup per flagged adjacency, before anything is staged.  Returns 0 for a tile with neither
 // such a site nor an x x of the self rule (nothing to do: the x/y flags are per token, and late in training two thirds of
@@ -348,10 +390,19 @@ __device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 2
   const bool cand = reg_flag_test<SLOT>(r, n, flagbits_lds, tokflag, self_x, f);
   if (__ballot(cand) == 0) return 0;
   if (lane < SLOT / 64) W.sitemask[lane] = 0ull;
+  if (lane == 0) {
+    W.sctl[0] = 0u;
+    W.sctl[1] = 0xffffffffu;
+  }
   wave_sync();
   uint32_t *sm32 = reinterpret_cast<uint32_t *>(W.sitemask);
-  bool found = false, selfp = false;
-#define PAIR_SITE(T0, T1, F0, F1, P)                                                     \
+  bool selfp = false;
+  // what this lane finds: bit 4 j + i = a site starts at my token i of row j (position 256 j + 4 lane + i); the site bits,
+  // the list and the count go to LDS once, after the look-ups (a lane's positions are looked at in ascending order)
+  typedef typename std::conditional<(SLOT / 64 > 32), unsigned long long, uint32_t>::type bits_t;
+  bits_t my_bits = 0;
+  uint32_t my_ri = 0;  // rule of my last site
+#define PAIR_SITE(T0, T1, F0, F1, P, S)                                                  \
   if (!((T1)&TOK_WS)) {                                                                  \
     const uint32_t a_ = (T0)&L_ID, b_ = (T1)&L_ID;                                       \
     if (a_ == self_x && b_ == self_x) {                                                  \
@@ -360,10 +411,8 @@ __device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 2
       const uint32_t ri = rtab.find(a_, b_);                                             \
       if (ri != 0xffffffffu) {                                                           \
         W.ridx[(P)] = (uint16_t)ri;                                                      \
-        atomicOr(&sm32[(P) >> 5], 1u << ((P)&31));                                       \
-        found = true;                                                                    \
-        my_cnt++;                                                                        \
-        my_site = ((uint32_t)(P) << 16) | ri;                                            \
+        my_bits |= (bits_t)1 << (S);                                                     \
+        my_ri = ri;                                                                      \
       }                                                                                  \
     }                                                                                    \
   }
@@ -378,14 +427,33 @@ __device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 2
         fnx0 = __shfl(f[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
       }
       if (lane == 63) { nx = nx0; fnx = fnx0; }
-      const int p = 256 * j + 4 * lane;
-      PAIR_SITE(r[j].x, r[j].y, f[j].x, f[j].y, p)
-      PAIR_SITE(r[j].y, r[j].z, f[j].y, f[j].z, p + 1)
-      PAIR_SITE(r[j].z, r[j].w, f[j].z, f[j].w, p + 2)
-      PAIR_SITE(r[j].w, nx, f[j].w, fnx, p + 3)
+      int p = 256 * j + 4 * lane;
+      YTTM_OPAQUE_V(p);  // (recomputed per tile: hoisted out of the tile loop, the LDS addresses derived from it are spilled to scratch)
+      PAIR_SITE(r[j].x, r[j].y, f[j].x, f[j].y, p, 4 * j)
+      PAIR_SITE(r[j].y, r[j].z, f[j].y, f[j].z, p + 1, 4 * j + 1)
+      PAIR_SITE(r[j].z, r[j].w, f[j].z, f[j].w, p + 2, 4 * j + 2)
+      PAIR_SITE(r[j].w, nx, f[j].w, fnx, p + 3, 4 * j + 3)
     }
   }
 #undef PAIR_SITE
+  const bool found = my_bits != 0;
+  if (found) {
+#pragma unroll
+    for (int j = 0; j < SLOT / 256; j++) {
+      const uint32_t nib = (uint32_t)(my_bits >> (4 * j)) & 15u;
+      if (nib) atomicOr(&sm32[(256 * j + 4 * lane) >> 5], nib << ((4 * lane) & 31));
+    }
+    const int s_first = sizeof(bits_t) == 8 ? __ffsll((long long)my_bits) - 1 : __ffs((int)my_bits) - 1;
+    const int s_last = sizeof(bits_t) == 8 ? 63 - __clzll((long long)my_bits) : 31 - __clz((int)my_bits);
+    const uint32_t p_first = (uint32_t)(256 * (s_first >> 2) + 4 * lane + (s_first & 3));
+    my_cnt = sizeof(bits_t) == 8 ? (uint32_t)__popcll((unsigned long long)my_bits) : (uint32_t)__popc((unsigned int)my_bits);
+    my_site = ((uint32_t)(256 * (s_last >> 2) + 4 * lane + (s_last & 3)) << 16) | my_ri;
+    // the tile's site list (any order).  A lane that found more than one site only counts them and asks for the list in
+    // position order (bit 16 of the counter), which phase 2 then builds from the site masks.
+    const unsigned int idx = atomicAdd(&W.sctl[0], my_cnt | (my_cnt > 1 ? 0x10000u : 0u)) & 0xffffu;
+    if (my_cnt == 1 && idx < 64u) W.sitepos[idx] = (uint16_t)p_first;
+    atomicMin(&W.sctl[1], p_first);
+  }
   wave_sync();
   return (__ballot(found) ? 1 : 0) | (__ballot(selfp) ? 3 : 0);
 }
@@ -586,48 +654,51 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
     const int nchunks = (n + 63) >> 6;
     st_scanned += (unsigned long long)n;
 
-    // ---- phase 1a: word-start masks per 64-token chunk.  (MERGE) the sites of the x != y rules were found in registers
-    // (reg_find_sites); those of an x x rule are found here: left-to-right greedy inside a run of x's = the positions at an
-    // even offset from the run's start.
-    uint32_t wbase = 0;
+    // ---- phase 1a.  K3: word-start masks per 64-token chunk.  K4: word-start masks and the sites of the x != y rules came
+    // from the registers (stage_ws_masks, reg_find_sites); sites of an x x rule are found here: left-to-right greedy inside a
+    // run of x's = the positions at an even offset from the run's start.
     bool any = false;
     int nsites = 0, first_site_chunk = nchunks;  // (MERGE)
-    for (int c = 0; c < nchunks; c++) {
-      const int p = c * 64 + lane;
-      bool ws = false, self_site = false;
-      if (p < n) {
-        const uint32_t t0 = W.tk[p];
-        ws = t0 & TOK_WS;
-        if (MERGE && self_pass) {
-          const uint32_t t1 = W.tk[p + 1];
-          if (!(t1 & TOK_WS) && (t0 & L_ID) == self_x && (t1 & L_ID) == self_x) {
-            int q = p;
-            while (q > 0 && !(W.tk[q] & TOK_WS) && (W.tk[q - 1] & L_ID) == self_x) q--;
-            if (((p - q) & 1) == 0) {
-              self_site = true;
-              W.ridx[p] = (uint16_t)(self_z - z_base);
+    bool list_in_order = false;                  // (MERGE) phase 2 builds its site lists from the site masks
+    if (!MERGE) {
+      uint32_t wbase = 0;
+      for (int c = 0; c < nchunks; c++) {
+        const int p = c * 64 + lane;
+        const bool ws = p < n && (W.tk[p] & TOK_WS);
+        const unsigned long long m = __ballot(ws);
+        if (lane == 0) {
+          W.wsmask[c] = m;
+          W.wsbase[c] = wbase;
+        }
+        wbase += (uint32_t)__popcll(m);
+      }
+    } else {
+      if (self_pass) {
+        for (int c = 0; c < nchunks; c++) {
+          const int p = c * 64 + lane;
+          bool self_site = false;
+          if (p < n) {
+            const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
+            if (!(t1 & TOK_WS) && (t0 & L_ID) == self_x && (t1 & L_ID) == self_x) {
+              int q = p;
+              while (q > 0 && !(W.tk[q] & TOK_WS) && (W.tk[q - 1] & L_ID) == self_x) q--;
+              if (((p - q) & 1) == 0) {
+                self_site = true;
+                W.ridx[p] = (uint16_t)(self_z - z_base);
+                site_listed<SLOT>(W, p);
+              }
             }
           }
+          const unsigned long long ssm = __ballot(self_site);
+          if (ssm != 0ull && lane == 0) W.sitemask[c] |= ssm;
         }
+        wave_sync();
       }
-      const unsigned long long m = __ballot(ws);
-      unsigned long long sm = MERGE ? uni64(W.sitemask[c]) : 0ull;
-      if (MERGE && self_pass) sm |= __ballot(self_site);
-      if (lane == 0) {
-        W.wsmask[c] = m;
-        W.wsbase[c] = wbase;
-        if (MERGE && self_pass) W.sitemask[c] = sm;
-      }
-      wbase += (uint32_t)__popcll(m);
-      if (MERGE && sm != 0ull) {
-        if (!any) first_site_chunk = c;
-        any = true;
-        if (nsites < 64 && lane_bit(sm)) {  // the first 64 sites go straight to the list phase 2 works from
-          const int rk = nsites + (int)lanes_below(sm);
-          if (rk < 64) W.sitepos[rk] = (uint16_t)p;
-        }
-        nsites += __popcll(sm);
-      }
+      const uint32_t sc = uni(W.sctl[0]);
+      nsites = (int)(sc & 0xffffu);
+      list_in_order = nsites > 64 || (sc >> 16) != 0u;
+      any = nsites != 0;
+      if (any) first_site_chunk = (int)(uni(W.sctl[1]) >> 6);
     }
     wave_sync();
     if (MERGE) K4_MARK(3);
@@ -667,7 +738,8 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         if (lane == 0) my_sites += (unsigned long long)nsites;
         for (int base = 0; base < nsites; base += 64) {
           int before = 0;  // sites in the chunks already looked at
-          for (int c = first_site_chunk; base != 0 && c < nchunks && before < base + 64; c++) {  // (pass 0: listed by phase 1a)
+          // (up to 64 sites: the list made while they were found, in any order; more: the sites in position order, 64 per pass)
+          for (int c = first_site_chunk; list_in_order && c < nchunks && before < base + 64; c++) {
             const unsigned long long smc = uni64(W.sitemask[c]);
             const int cnt = __popcll(smc);
             if (cnt != 0 && before + cnt > base && lane_bit(smc)) {
@@ -679,7 +751,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
           wave_sync();
           const bool have = base + lane < nsites;
           const int p = have ? (int)W.sitepos[lane] : 0;
-          const long long f = word_weight_all<SLOT>(wreg, tile_word_index<SLOT>(W, p));  // (all lanes: shuffles)
+          const long long f = word_weight_all<SLOT>(wreg, tile_word_index_rl<SLOT>(W, p));  // (all lanes: shuffles)
           bool v0 = false, v1 = false, v2 = false, v3 = false, v4 = false;
           unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0;
           long long d0 = 0, d2 = 0, d4 = 0;
@@ -878,7 +950,10 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
         }
       }
     }
-    if (dirty) tile_stage<SLOT>(W, r, n0);
+    if (dirty) {
+      if (MERGE) stage_ws_masks<SLOT>(W, r, n0);
+      tile_stage<SLOT>(W, r, n0);
+    }
     if (MERGE) K4_MARK(1);
     return dirty;
   };

@@ -220,6 +220,13 @@ __device__ inline void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+// Makes a per-lane value opaque to the optimiser at this point (no code): keeps it from hoisting what is computed from the
+// value out of a loop and then spilling it for lack of registers.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define YTTM_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#else
+#define YTTM_OPAQUE_V(x) ((void)0)
+#endif
 __device__ inline unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 // Wave-uniform values.  The compiler cannot know that a value read from LDS at a uniform address, or handed out by a
 // shuffle, is the same in every lane: it keeps it in vector registers and turns every loop and branch on it into exec-mask
