@@ -341,6 +341,8 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
 
 // ------------------------------------------------------------------------------------------------- K2
 void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n_alpha, uint32_t space_id, uint32_t n_ids_cap) {
+  max_id_ = space_id;  // largest token id that can occur in a tile (alphabet now, new ids as they are made)
+  for (uint32_t a = 0; a < n_alpha; a++) max_id_ = std::max(max_id_, id[a]);
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
@@ -881,8 +883,10 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   BatchArgs ba{};
   const bool by_args = k <= (uint32_t)BATCH_ARGS_MAX && vmax < FLAG_LDS_IDS && !cls_[2].n_tiles && (!cls_[0].n_tiles || dense_class(0)) &&
                        (!cls_[1].n_tiles || dense_class(1)) && !getenv("YTTM_NO_BATCH_ARGS");
+  max_id_ = std::max(max_id_, vmax);
   if (by_args) {
     ba.k = k;
+    ba.small_ids = max_id_ < FLAG_LDS_IDS ? 1u : 0u;
     for (uint32_t j = 0; j < k; j++) { ba.xy[2 * j] = xyz[3 * j]; ba.xy[2 * j + 1] = xyz[3 * j + 1]; }
   } else {
     prev_flag_toks_.swap(now);

@@ -90,6 +90,7 @@ class GpuCtx {
   unsigned int *d_hot_n_ = nullptr;
   unsigned int fullscan_rounds_ = 0;
   uint32_t mail_round_ = 0;
+  uint32_t max_id_ = 0xffffffffu;  // largest token id in the tiles (unknown until the word table is built)
   unsigned long long scanned_cum_ = 0, live_tokens_last_ = 0, touched_cum_ = 0, touched_last_ = ~0ull >> 2;  // (first round: dense)
   unsigned int hot_cap_ = 0, hot_target_ = 0, hot_min_ = 0, listed_last_ = 0;
   void alloc_table(PairTable &pt, unsigned long long cap);

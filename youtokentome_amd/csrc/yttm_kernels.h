@@ -53,6 +53,7 @@ constexpr uint32_t FLAG_LDS_IDS = 32768;  // batch flags of ids below this live 
 struct BatchArgs {
   uint32_t k;                        // 0: not used (tables come from HBM)
   uint32_t xy[2 * BATCH_ARGS_MAX];   // rule j of the batch merges (xy[2j], xy[2j+1]) into z_base + j; x == y: the self rule (skipped)
+  uint32_t small_ids;                // every token id in the tiles is < FLAG_LDS_IDS: the kernels skip the test for ids behind the LDS bitmap
 };
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st);
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
