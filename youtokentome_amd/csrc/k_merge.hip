@@ -8,12 +8,15 @@
 //   pair table + candidate filter           pair2cnt_g :891, check_cnt :1099-1108, PriorityQueue :271-314 (the final
 //                                           ordered pick stays on the host: host_trainer.cpp)
 // Design: no linked lists and no per-pair position lists.  Each round the host picks a batch of mutually
-// non-intersecting rules; one streaming pass over the token tiles applies all of them at once: a
-// WAVEFRONT owns a tile (no workgroup barriers in the loop), prefetches the next tile into registers while it works on
-// the current one in LDS, finds merge sites with one cached flag test per token (+ a hash lookup on a hit), resolves
-// x==y runs by parity from the run start, emits exact count deltas only around the sites (summed in an LDS hash shared
-// by the workgroup, then 64-bit atomics into the HBM pair table), compacts the tile with wave ballots and writes it
-// back in place.
+// non-intersecting rules; one streaming pass over the token tiles applies all of them at once.  A
+// WAVEFRONT owns a tile (no workgroup barriers in the loop) and prefetches the next tile into registers while it works on
+// the current one.  K4 per tile: (1) in registers, one flag lookup per token (LDS bitmap: is the id the x / the y of a
+// batch rule) -- a tile without a flagged adjacency is dismissed here, at HBM speed; flagged adjacencies are looked up
+// in the LDS rule hash: merge sites.  (2) A tile with a single site is rewritten in registers (single_site_tile).
+// (3) Otherwise the tile is staged into LDS, x==y sites are resolved by parity from the run start, ONE LANE PER SITE
+// works out the exact count deltas around it (summed in an LDS hash shared by the workgroup, then 64-bit atomics into
+// the HBM pair table), and the tile is compacted in place from its first site on.
+// Wave-uniform values go through scalar registers (uni / lane_bit / lanes_below, yttm_device.h).
 // HBM-bound integer work: no MFMA.
 #include <type_traits>
 
