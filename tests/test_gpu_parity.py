@@ -41,6 +41,7 @@ def test_k4_merge_apply_rounds():
     S.check_merge_rounds(gen.readme_corpus(1500, 100, seed=9), rounds=25, seed=3)
     t = ("aaaa aaaaa aaaaaaa abababab aabbaabb abcabcabc bbbbbb ab aaab baaa " + "a" * 700 + " " + "ab" * 500 + " ") * 3
     S.check_merge_rounds(t.encode(), rounds=14, seed=1)
+    S.check_site_placements(trials=200, seed=9)  # a rare pair at many positions of its tile, sites 2 and 3 apart, runs next to a site
     # ids >= 32768: flags from the HBM table instead of the LDS bitmap
     for i, t in enumerate(S.texts_small(5, n=3, size=8000)):
         if t.strip():

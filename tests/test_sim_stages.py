@@ -45,6 +45,10 @@ def test_merge_apply_ids_above_the_lds_bitmap():
     S.check_merge_rounds(t, rounds=10, seed=1, id_shift=33000)
 
 
+def test_merge_apply_site_placements():
+    S.check_site_placements(trials=100, seed=3)
+
+
 def test_merge_apply_many_sites_per_tile():
     """More than 64 (and more than 128) merge sites in one class-A tile: phase 2 of K4 takes them 64 per pass."""
     words = ["ab" * k for k in range(60, 125, 7)] + ["a" * k for k in range(150, 250, 13)] + ["abc" * k for k in (50, 70, 80)]
