@@ -247,8 +247,9 @@ void GpuCtx::t_end(int which, unsigned long long bytes, bool chain) {
 void GpuCtx::resolve_timers() {
   sync();
   {
-    // K4 traffic: the filter streams the live tokens once (4 B each); the apply kernel re-reads and rewrites the tiles
-    // that had a merge site
+    // K4 algorithmic traffic: every live token is read once (4 B); the tiles that had a merge site are
+    // counted once more as re-read and rewritten (8 B per token of those -- an upper bound since single-site tiles are
+    // rewritten from the registers they were loaded into)
     unsigned long long st[8] = {0};
     if (pt_cap_) launch_fold_stats(d_stats_, pt_.n_keys, st_);
     sync();
