@@ -99,6 +99,18 @@ def test_hot_list_rebuilds(tmp_path, monkeypatch):
         S.check_train_vs_oracle(text, 150, tmp_path, tag=f"hot{target}")
 
 
+def test_worklist_mode(tmp_path, monkeypatch):
+    """K4 with a separate filter pass and a worklist of candidate tiles (off by default: the apply kernel dismisses clean
+    tiles itself) must give the same tables and models."""
+    monkeypatch.setenv("YTTM_DENSE_PCT", "1000")
+    for name in ("readme_small", "runs", "mix_cov"):
+        S.check_golden_train(name, tmp_path)
+    for i, t in enumerate(S.texts_small(7, n=2, size=1500)):
+        if t.strip():
+            S.check_merge_rounds(t, rounds=5, seed=i)
+    S.check_site_placements(trials=15, seed=5)
+
+
 def test_very_long_words(tmp_path):
     S.check_very_long_words(tmp_path)
 

@@ -158,6 +158,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   hot_cap_ = std::min(env_uint("YTTM_HOT_CAP", HOT_CAP), HOT_CAP);
   hot_target_ = env_uint("YTTM_HOT_TARGET", 1u << 13);  // measured at 1 GB: 4096..16384 equal on the abcd corpus, 8192 best on Zipf text (4279 rounds)
   hot_min_ = env_uint("YTTM_HOT_MIN", 512);
+  dense_pct_ = env_uint("YTTM_DENSE_PCT", 0);
   d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);
   d_hot_n_ = dmalloc<unsigned int>(4);  // [0] list length, [1] k_hot_scan's finished-workgroup ticket, [2..3] overflow verdict (u64)
   HIP_CHECK(hipMemset(d_hot_n_, 0, 16));
@@ -878,7 +879,9 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // Small batch and a round that runs without the filter pass: the batch goes to the kernels as an argument and nothing is
   // uploaded (yttm_kernels.h: BatchArgs).  The flag tables in HBM then keep what the last uploaded batch left there.
   auto dense_class = [&](int ci) {
-    static const int dense_pct = getenv("YTTM_DENSE_PCT") ? atoi(getenv("YTTM_DENSE_PCT")) : 0;  // tuning hook; measured at 1 GB (K4 ms): 90 % -> 217, 60 % -> 215, 30 % -> 212, 0 (never filter) -> 211
+    // tuning hook YTTM_DENSE_PCT (default 0: never run the filter pass); measured at 1 GB (K4 ms): 90 % -> 217, 60 % -> 215, 30 % -> 212, 0 -> 211
+    const unsigned int dense_pct = dense_pct_;
+    if (dense_pct >= 1000) return false;  // tests: always the filter pass + worklist
     return cls_[ci].n_tiles <= 8192 || (touched_last_ != (~0ull >> 2) && touched_last_ * 100 >= (unsigned long long)n_tiles * (unsigned long long)dense_pct);
   };
   BatchArgs ba{};

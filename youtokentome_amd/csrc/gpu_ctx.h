@@ -93,6 +93,7 @@ class GpuCtx {
   uint32_t max_id_ = 0xffffffffu;  // largest token id in the tiles (unknown until the word table is built)
   unsigned long long scanned_cum_ = 0, live_tokens_last_ = 0, touched_cum_ = 0, touched_last_ = ~0ull >> 2;  // (first round: dense)
   unsigned int hot_cap_ = 0, hot_target_ = 0, hot_min_ = 0, listed_last_ = 0;
+  unsigned int dense_pct_ = 0;  // YTTM_DENSE_PCT: share of dirty tiles below which K4 runs a separate filter pass + worklist (>= 1000: always)
   void alloc_table(PairTable &pt, unsigned long long cap);
   void free_table(PairTable &pt);
   void exchange_deltas();
