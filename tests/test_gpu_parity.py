@@ -51,6 +51,18 @@ def test_k4_merge_apply_rounds():
     S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=8, seed=4)
 
 
+def test_k4_worklist_mode(tmp_path, monkeypatch):
+    """K4 with a separate filter pass and a worklist of candidate tiles (YTTM_DENSE_PCT; off by default)."""
+    monkeypatch.setenv("YTTM_DENSE_PCT", "1000")
+    for name in ("readme_small", "runs", "mix_cov"):
+        S.check_golden_train(name, tmp_path)
+    for i, t in enumerate(S.texts_small(7, n=3, size=8000)):
+        if t.strip():
+            S.check_merge_rounds(t, rounds=8, seed=i)
+    S.check_site_placements(trials=30, seed=5)
+    S.check_train_vs_oracle(gen.zipf_corpus(2_000_000, seed=3, vocab=30000), 4000, tmp_path, tag="wl")
+
+
 @pytest.mark.parametrize("name", S.golden_train_names())
 def test_golden_train(name, tmp_path):
     S.check_golden_train(name, tmp_path)
