@@ -21,4 +21,9 @@ model = S.check_train_vs_oracle(text.encode(), 200, tmp, tag="lw")
 S.check_encode_vs_oracle(model, [" ".join(words), "ab" * 700, "a"], flags=((0, 0, 0), (1, 1, 1)))
 S.check_very_long_words(tmp, lengths=(2047, 2048, 2049, 3000))
 S.check_encode_mixed_shapes(n_sent=60)
+# K4's register paths: a rare pair at many tile positions, many sites per tile, ids behind the LDS flag bitmap
+S.check_site_placements(trials=25, seed=8)
+many = ["ab" * k for k in range(60, 125, 13)] + ["a" * k for k in range(150, 250, 29)]
+S.check_merge_rounds((" ".join(many) + " ").encode(), rounds=5, seed=4)
+S.check_merge_rounds(S.texts_small(5, n=1, size=1200)[0], rounds=4, seed=1, id_shift=40000)
 print("ASAN_SCENARIOS_OK")
