@@ -483,17 +483,71 @@ __global__ __launch_bounds__(BLOCK) void k2g_tile_len(const unsigned long long *
   tile_len[t] = (uint32_t)(e - tile_start[t]);
 }
 
+// Tokens of every unique word into its tile slot.  A wavefront takes 64 consecutive words; their slots are consecutive in
+// memory (apart from the unused tails of tiles), so the lanes decode into an LDS window and the wave stores the window with
+// coalesced 256-byte writes: a thread storing its word token by token produced 8.4 GB of HBM write traffic for 1 GB of tokens
+// (partial sectors evicted from L2 between the stores).  Words that do not fit the window (classes B and C) are written
+// directly.
+constexpr int FILL_CAP = 2048;  // tokens per wavefront window
 __global__ __launch_bounds__(BLOCK) void k2e_fill_tokens(const uint8_t *__restrict__ text, unsigned long long n,
                                                          const uint32_t *__restrict__ cpmap, uint32_t space_id,
                                                          const unsigned long long *__restrict__ uw_pos,
                                                          const unsigned long long *__restrict__ uw_off, unsigned int n_words,
                                                          unsigned int nom, unsigned int slot,
                                                          const unsigned long long *__restrict__ tile_start, uint32_t *__restrict__ tok) {
-  unsigned int u = blockIdx.x * BLOCK + threadIdx.x;
-  if (u >= n_words) return;
-  unsigned long long i = uw_pos[u];
-  const unsigned long long t = uw_off[u] / nom;
-  unsigned long long o = t * slot + (uw_off[u] - tile_start[t]);
+  __shared__ uint32_t stage_all[NWAVES][FILL_CAP];
+  const int lane = lane_id();
+  uint32_t *stage = stage_all[threadIdx.x >> 6];
+  const unsigned int u = blockIdx.x * BLOCK + threadIdx.x;
+  const bool have = u < n_words;  // (the lanes of a wave that have a word are a prefix)
+  unsigned long long i0 = 0, o = 0;
+  if (have) {
+    i0 = uw_pos[u];
+    const unsigned long long t = uw_off[u] / nom;
+    o = t * slot + (uw_off[u] - tile_start[t]);
+  }
+  const unsigned long long o_base = __shfl(o, 0);
+  for (int k = lane; k < FILL_CAP / 4; k += 64) reinterpret_cast<uint4 *>(stage)[k] = make_uint4(0, 0, 0, 0);
+  wave_sync();
+  // decode into the window; a word that does not fit sends the whole wave the direct way
+  const unsigned long long rel = o - o_base;
+  bool overflow = have && rel >= (unsigned long long)FILL_CAP;
+  uint32_t cnt = 0;
+  if (have && !overflow) {
+    const uint32_t r0 = (uint32_t)rel;
+    stage[r0] = space_id | TOK_WS;
+    cnt = 1;
+    unsigned long long i = i0;
+    while (i < n) {
+      uint32_t len;
+      const uint32_t cp = u8_decode_at(text, i, n, &len);
+      if (cp != INVALID_CP) {
+        const uint32_t id = cpmap[cp];
+        if (id == CP_SPACE) break;
+        if (id != CP_DROP) {
+          if (r0 + cnt >= (uint32_t)FILL_CAP) {
+            overflow = true;
+            break;
+          }
+          stage[r0 + cnt++] = id;
+        }
+      }
+      i += len;
+    }
+  }
+  wave_sync();
+  if (__ballot(overflow) == 0ull) {
+    uint32_t end = have ? (uint32_t)rel + cnt : 0u;  // the window ends behind the last word
+    for (int d = 32; d > 0; d >>= 1) {
+      const uint32_t other = __shfl_down(end, d);
+      end = other > end ? other : end;
+    }
+    end = __shfl(end, 0);
+    for (uint32_t k = (uint32_t)lane; k < end; k += 64) tok[o_base + k] = stage[k];  // (zeros in the gaps: tile tails are zero)
+    return;
+  }
+  if (!have) return;
+  unsigned long long i = i0;
   tok[o++] = space_id | TOK_WS;
   while (i < n) {
     uint32_t len;
