@@ -79,7 +79,7 @@ def main():
     nbytes = args.size_mb * 1_000_000
     t0 = time.time()
     if args.corpus == "abcd":
-        host = gen.abcd_corpus(nbytes, seed=19 + rank)
+        host = gen.abcd_corpus(nbytes, seed=19 + rank, survey_stream=True)  # rank 0, 1000 MB: SURVEY.md's C2 file byte for byte (md5 63857720...)
     else:
         host = gen.zipf_corpus(nbytes, seed=7 + rank, vocab=400000)
     corpus = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
@@ -132,6 +132,14 @@ def main():
         dt = float(t.item())
     total_bytes = n_local * n_gpus
     value = args.steps * total_bytes / dt / 1e6
+    pins = {}  # md5 of rank 0's corpus shard (SURVEY.md section 8d pins the generated files) and of the model file it produced
+    if rank == 0:
+        try:
+            import hashlib
+            pins["corpus_md5"] = hashlib.md5(host).hexdigest()
+            pins["model_md5"] = hashlib.md5(open(model_path, "rb").read()).hexdigest()
+        except Exception as e:  # never fail the bench line over a checksum
+            pins["pins_error"] = str(e)
     r = reports[-1]
 
     # ---- per-kernel roofline from the HIP-event times collected inside the timed steps ----------------------------------
@@ -185,7 +193,7 @@ def main():
                                f"vocab_size={args.vocab} (BASELINE.json configs[1])",
                    "corpus_bytes_per_gpu": n_local, "vocab_size": args.vocab, "unique_words": r["n_unique"],
                    "dedup_tokens": r["n_tokens"], "merge_rounds": r["rounds"], "rules": r["rules"],
-                   "input": "resident in HBM before the timed region"},
+                   "input": "resident in HBM before the timed region", **pins},
         "roofline": roofline, "roofline_pair_count": roofline_pc, "kernels": kern,
         "phases_s": {"frontend": r["seconds_frontend"], "merge_loop": r["seconds_merge"], "dump": r["seconds_io"]},
     }
@@ -210,7 +218,7 @@ def main():
 def _bench_encode(L, _lib, torch, np, gen, dev, local_rank, model_path, args, rank, world, dist, barrier):
     n_sent = args.encode_sentences
     line = 128
-    host = gen.abcd_corpus(n_sent * (line + 1), seed=123 + rank, line=line)
+    host = gen.abcd_corpus(n_sent * (line + 1), seed=123 + rank, line=line, survey_stream=True)  # SURVEY.md's C4 stream
     n_sent = len(host) // (line + 1)
     d_bytes = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
     d_off = (torch.arange(n_sent + 1, dtype=torch.int64, device=dev) * (line + 1))

@@ -13,17 +13,23 @@ def readme_corpus(n_lines=10000, n_chars=100, alphabet="abcd ", seed=19):
     return ("\n".join(out) + "\n").encode()
 
 
-def abcd_corpus(nbytes, seed=19, line=100, alphabet=b"abcd "):
-    """C2 / C4 family: uniform over the alphabet, `line` chars per row + newline (numpy default_rng, uint8 draws,
-    generated in row chunks so that 1 GB needs ~1 GB of host memory)."""
+def abcd_corpus(nbytes, seed=19, line=100, alphabet=b"abcd ", survey_stream=False):
+    """C2 / C4 family: uniform over the alphabet, `line` chars per row + newline (numpy default_rng), generated in row
+    chunks so that 1 GB needs ~1 GB of host memory.  survey_stream=False draws uint8 (fast; what the tests and their golden
+    files use).  survey_stream=True draws int64 like SURVEY.md Appendix C's gen_abcd -- chunking does not change that
+    stream -- and reproduces its files byte for byte: 999 999 990 B, seed 19 -> md5 63857720bbc611c198a8e0a3d609fbcc (C2),
+    99 999 999 B -> f35ed06647d5646121ac66dae1071cd0; bench.py uses this."""
     rng = np.random.default_rng(seed)
     alpha = np.frombuffer(alphabet, dtype=np.uint8)
     nlines = max(1, nbytes // (line + 1))
     out = np.empty((nlines, line + 1), dtype=np.uint8)
-    step = 1 << 20
+    step = 1 << 16 if survey_stream else 1 << 20
     for r0 in range(0, nlines, step):
         r1 = min(nlines, r0 + step)
-        out[r0:r1, :line] = alpha[rng.integers(0, len(alpha), size=(r1 - r0, line), dtype=np.uint8)]
+        if survey_stream:
+            out[r0:r1, :line] = alpha[rng.integers(0, len(alpha), size=(r1 - r0, line))]
+        else:
+            out[r0:r1, :line] = alpha[rng.integers(0, len(alpha), size=(r1 - r0, line), dtype=np.uint8)]
     out[:, line] = 10
     return out.tobytes()
 
