@@ -218,3 +218,21 @@ def test_dropout_distribution_vs_reference_semantics(p, tmp_path):
     sents = [ln.decode() for ln in gen.abcd_corpus(200_000 * 129, seed=77, line=128).split(b"\n") if ln]
     mean_g, mean_w, ks, chi = S.check_dropout_distribution(model, sents, p, 2000)
     print(f"dropout p={p}: ids/sentence gpu {mean_g:.3f} oracle {mean_w:.3f} KS {ks:.5f} chi2/dof {chi:.3f}")
+
+
+def test_zz_c2_100mb_model_pin(tmp_path):
+    """BASELINE.json configs[1] at a tenth of its size: the 100 MB variant of SURVEY.md's C2 file (byte-identical: md5
+    f35ed066...), vocab 32000.  The model must be the one the unmodified reference (-DDETERMINISTIC_QUEUE, n_threads=8)
+    and the oracle both produce: md5 222ef3e6..., pinned by tests/golden/c2_100mb_pin.json (made by tools/make_c2_pin.py
+    in the build container, where /root/reference exists).  Last in the file: it takes the longest."""
+    import hashlib
+    import json
+    import youtokentome_amd as yttm
+    pin = json.load(open(os.path.join(S.G, "c2_100mb_pin.json")))
+    text = gen.abcd_corpus(pin["corpus_bytes"] + 1, seed=19, survey_stream=True)
+    assert len(text) == pin["corpus_bytes"] and hashlib.md5(text).hexdigest() == pin["corpus_md5"]
+    corpus = str(tmp_path / "c2.txt")
+    open(corpus, "wb").write(text)
+    model = str(tmp_path / "c2.model")
+    yttm.BPE.train(corpus, model, pin["vocab_size"])
+    assert hashlib.md5(open(model, "rb").read()).hexdigest() == pin["model_md5"]
