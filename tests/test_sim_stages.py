@@ -45,6 +45,17 @@ def test_merge_apply_ids_above_the_lds_bitmap():
     S.check_merge_rounds(t, rounds=10, seed=1, id_shift=33000)
 
 
+def test_merge_apply_small_alphabets_random():
+    """Words over 2..5 letters (runs of equal tokens, runs of new tokens, many sites per tile), random weights and batch sizes."""
+    rng = random.Random(2024)
+    for trial in range(40):
+        alpha = "abcde"[: rng.choice([2, 2, 3, 3, 4, 5])]
+        words = ["".join(rng.choice(alpha) for _ in range(rng.choice([1, 2, 3, 5, 8, 13, 30, 80, 200]))) for _ in range(rng.randint(5, 250))]
+        words = [w for w in words for _ in range(rng.randint(1, 3))]
+        rng.shuffle(words)
+        S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=rng.randint(3, 14), seed=trial)
+
+
 def test_merge_apply_site_placements():
     S.check_site_placements(trials=100, seed=3)
 
