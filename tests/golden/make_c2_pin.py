@@ -1,14 +1,14 @@
 """Writes tests/golden/c2_100mb_pin.json: md5 of the 100 MB variant of SURVEY.md's C2 corpus and of the model the unmodified
 reference (oracle/_ref/yttm_ref_det: bpe.cpp with -DDETERMINISTIC_QUEUE, n_threads=8) trains on it at vocab_size 32000; the
 oracle (oracle/bpe_oracle.c) must give the same file.  Run in the build container (needs /root/reference for oracle/_ref).
-usage: python tools/make_c2_pin.py"""
+usage: python tests/golden/make_c2_pin.py"""
 import hashlib
 import json
 import os
 import sys
 import tempfile
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, "tests"))
 import gen  # noqa: E402
 import oracle_lib as O  # noqa: E402

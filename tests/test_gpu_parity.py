@@ -223,7 +223,7 @@ def test_dropout_distribution_vs_reference_semantics(p, tmp_path):
 def test_zz_c2_100mb_model_pin(tmp_path):
     """BASELINE.json configs[1] at a tenth of its size: the 100 MB variant of SURVEY.md's C2 file (byte-identical: md5
     f35ed066...), vocab 32000.  The model must be the one the unmodified reference (-DDETERMINISTIC_QUEUE, n_threads=8)
-    and the oracle both produce: md5 222ef3e6..., pinned by tests/golden/c2_100mb_pin.json (made by tools/make_c2_pin.py
+    and the oracle both produce: md5 222ef3e6..., pinned by tests/golden/c2_100mb_pin.json (made by tests/golden/make_c2_pin.py
     in the build container, where /root/reference exists).  Last in the file: it takes the longest."""
     import hashlib
     import json
