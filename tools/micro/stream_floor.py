@@ -11,12 +11,13 @@ sys.path.insert(0, R)
 sys.path.insert(0, os.path.join(R, "tests"))
 import gen  # noqa: E402
 from stage_lib import Ctx  # noqa: E402
-from stage_checks import alphabet_for  # noqa: E402
 
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 text = gen.abcd_corpus(mb * 1000 * 1000, seed=19)
-acp, aid, space_id = alphabet_for(text[: 1 << 20])
+acp = np.array([9601, 97, 98, 99, 100], np.uint32)  # space mark, a..d
+aid = np.array([4, 5, 6, 7, 8], np.uint32)
+space_id = 4
 c = Ctx()
 c.upload(text)
 c.char_hist()
