@@ -583,8 +583,11 @@ void GpuCtx::exchange_deltas() {
   chain_event_ = nullptr;
   launch_fold_stats(d_stats_, pt_.n_keys, st_);  // the apply kernels leave their slot counts in per-workgroup rows
   unsigned long long n_local = 0;
+  unsigned int nk_local = 0;  // keys in the table after this rank's own updates (one round trip for both numbers)
   HIP_CHECK(hipMemcpyAsync(&n_local, db_.n, 8, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&nk_local, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
   sync();
+  n_keys_host = nk_local;
   if (n_local > db_.cap) throw GpuError{"delta exchange buffer overflow"};
   size_t n_remote = comm_->allgather_recs(db_.recs, (size_t)n_local, d_recv_, (size_t)recv_cap_, st_);
   if (n_remote > recv_cap_) throw GpuError{"delta receive buffer overflow"};
@@ -947,14 +950,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     rounds_since_check_ = 0;
     for (int ci = 0; ci < 2; ci++) maybe_repack(ci);
   }
-  if (comm_ && comm_->world > 1) {
-    launch_fold_stats(d_stats_, pt_.n_keys, st_);
-    unsigned int nk = 0;
-    HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
-    sync();
-    n_keys_host = nk;
-    exchange_deltas();
-  }
+  if (comm_ && comm_->world > 1) exchange_deltas();  // (reads this rank's key count back together with its record count)
   // single GPU: no sync here -- the candidate filter that always follows reads n_keys back together with its results
   // (its sync also makes the pinned rule staging reusable for the next round)
   // every occurrence of the batch's pairs has been merged (on every rank): their counts are exactly zero.  The candidate
