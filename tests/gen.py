@@ -54,6 +54,43 @@ def zipf_corpus(nbytes, seed=7, vocab=20000, line_words=16, exponent=1.05):
     return b"\n".join(lines) + b"\n"
 
 
+def zipf_corpus_fast(nbytes, seed=7, vocab=400000, line_words=16, exponent=1.05, chunk_words=4_000_000):
+    """C3 (BASELINE.json configs[2]): the same Zipfian lexicon text as zipf_corpus, generated with array operations in fixed
+    chunks of `chunk_words` words so that 1 GB takes seconds, not minutes (bench.py --corpus zipf and the full-size pins
+    of tests/golden/full_size_pins.json use THIS stream; its bytes differ from zipf_corpus's because the draws are chunked)."""
+    rng = np.random.default_rng(seed)
+    letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", dtype=np.uint8)
+    p = np.array([12.7, 9.1, 8.2, 7.5, 7.0, 6.7, 6.3, 6.1, 6.0, 4.3, 4.0, 2.8, 2.8, 2.4, 2.4, 2.2, 2.0, 2.0, 1.9,
+                  1.5, 1.0, 0.8, 0.15, 0.15, 0.1, 0.07])
+    p /= p.sum()
+    lens = np.clip(rng.poisson(5.5, size=vocab) + 1, 1, 20).astype(np.int64)
+    lex = letters[rng.choice(26, size=(vocab, 20), p=p)]  # word i = lex[i, :lens[i]]
+    ranks = np.arange(1, vocab + 1)
+    w = 1 / ranks ** exponent
+    w /= w.sum()
+    cdf = np.cumsum(w)
+    cdf[-1] = 1.0
+    avg = float((w * (lens + 1)).sum())
+    nwords = max(1, int(nbytes / avg))
+    nwords -= nwords % line_words  # whole lines
+    nwords = max(line_words, nwords)
+    parts = []
+    col = np.arange(21, dtype=np.int64)
+    for w0 in range(0, nwords, chunk_words):
+        n = min(chunk_words, nwords - w0)
+        ids = np.searchsorted(cdf, rng.random(n), side="right").astype(np.int64)
+        np.minimum(ids, vocab - 1, out=ids)
+        l = lens[ids]
+        # each word contributes its letters + one separator (space, or newline after every line_words-th word)
+        mat = np.empty((n, 21), dtype=np.uint8)
+        mat[:, :20] = lex[ids]
+        sep = np.where((np.arange(w0, w0 + n) % line_words) == line_words - 1, 10, 32).astype(np.uint8)
+        mat[np.arange(n), l] = sep
+        keep = col[None, :] <= l[:, None]
+        parts.append(mat[keep].tobytes())
+    return b"".join(parts)
+
+
 def stress_text(rng: random.Random, n_limit=1000, train=True):
     """Random text in the spirit of the reference stress generator (tests/unit_tests/stress_test.cpp:272-311):
     short alphabet, single chars mixed with repeated segments so that long runs of equal symbols occur."""

@@ -1,0 +1,85 @@
+"""Writes tests/golden/full_size_pins.json: md5 pins of the FULL-SIZE workloads of BASELINE.json, produced by the unmodified
+reference (oracle/_ref/yttm_ref_det = bpe.cpp with -DDETERMINISTIC_QUEUE, n_threads=8; encode: oracle/_ref/yttm_ref_prod).
+
+  c2_1gb    configs[1]: 1 GB random 'abcd ' corpus (SURVEY.md Appendix C gen_abcd, seed 19), vocab 32000 -> model md5
+  c2_100mb  its 100 MB variant
+  c3_1gb    configs[2]: 1 GB Zipf ASCII corpus (tests/gen.py zipf_corpus_fast, seed 7, lexicon 400 000), vocab 32000 -> model md5
+  c3_100mb  its 100 MB variant
+  c4_10m    configs[3]: 10 M sentences of 128 chars (gen_abcd stream, seed 123) encoded with the c2_1gb model -> FNV-1a-64
+            of (length, ids...) per sentence over all 10 M, and over the first 1 M
+
+bench.py regenerates the same corpora from the same seeds on the GPU box, compares the md5 of what it generated and of
+what the GPU produced with these pins, prints the verdict in its JSON line and exits non-zero on a mismatch.
+Run in the build container (needs /root/reference for oracle/_ref): python tests/golden/make_full_pins.py [name ...]"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(R, "tests"))
+import gen  # noqa: E402
+import refbin  # noqa: E402
+
+OUT = os.path.join(R, "tests", "golden", "full_size_pins.json")
+md5f = lambda p: hashlib.md5(open(p, "rb").read()).hexdigest()  # noqa: E731
+REF = "oracle/_ref/yttm_ref_det (unmodified bpe.cpp, -DDETERMINISTIC_QUEUE), n_threads=8"
+
+
+def train_pin(name, text, desc, d):
+    corpus = os.path.join(d, name + ".txt")
+    open(corpus, "wb").write(text)
+    model = os.path.join(d, name + ".model")
+    t0 = time.time()
+    refbin.train(corpus, model, 32000, n_threads=8, kind="det")
+    dt = time.time() - t0
+    os.remove(corpus)
+    return {"corpus": desc, "corpus_bytes": len(text), "corpus_md5": hashlib.md5(text).hexdigest(), "vocab_size": 32000,
+            "model_md5": md5f(model), "model_bytes": os.path.getsize(model), "reference": REF,
+            "reference_train_seconds_build_container": round(dt, 1)}, model
+
+
+def main():
+    want = set(sys.argv[1:])
+    pins = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    assert refbin.available("det") and refbin.available("prod")
+    d = tempfile.mkdtemp(prefix="yttm_pins_")
+    c2_model = None
+    for name, nbytes in (("c2_100mb", 100_000_000), ("c2_1gb", 1_000_000_000)):
+        if want and name not in want and not (name == "c2_1gb" and "c4_10m" in want):
+            continue
+        text = gen.abcd_corpus(nbytes, seed=19, survey_stream=True)
+        pins[name], m = train_pin(name, text, f"SURVEY.md Appendix C gen_abcd(seed=19), {len(text)//101} rows of 100 chars", d)
+        if name == "c2_1gb":
+            c2_model = m
+        print(name, pins[name], flush=True)
+        json.dump(pins, open(OUT, "w"), indent=1)
+    for name, nbytes in (("c3_100mb", 100_000_000), ("c3_1gb", 1_000_000_000)):
+        if want and name not in want:
+            continue
+        text = gen.zipf_corpus_fast(nbytes, seed=7, vocab=400000)
+        pins[name], _ = train_pin(name, text, "tests/gen.py zipf_corpus_fast(seed=7, vocab=400000, exponent=1.05, 16 words per line)", d)
+        print(name, pins[name], flush=True)
+        json.dump(pins, open(OUT, "w"), indent=1)
+    if not want or "c4_10m" in want:
+        assert c2_model is not None
+        line = 128
+        host = gen.abcd_corpus(10_000_000 * (line + 1), seed=123, line=line, survey_stream=True)
+        lines = os.path.join(d, "c4.txt")
+        open(lines, "wb").write(host)
+        full = refbin.encode_bench(c2_model, lines, n_threads=8, max_lines=-1)
+        first = refbin.encode_bench(c2_model, lines, n_threads=8, max_lines=1_000_000)
+        os.remove(lines)
+        pins["c4_10m"] = {"sentences": "gen_abcd stream: default_rng(123), 10 000 000 rows of 128 chars over 'abcd '", "input_md5": hashlib.md5(host).hexdigest(),
+                          "model": "c2_1gb", "model_md5": pins["c2_1gb"]["model_md5"], "n_sentences": full["sentences"], "n_ids": full["ids"],
+                          "fnv1a64": full["fnv1a64"], "first_1m": {"n_ids": first["ids"], "fnv1a64": first["fnv1a64"]},
+                          "hash": "FNV-1a-64 over, per sentence, the little-endian bytes of uint32 length then of each int32 id (oracle/ref_driver.cpp encode_bench)",
+                          "reference": "oracle/_ref/yttm_ref_prod encode_as_ids, n_threads=8, dropout 0"}
+        print("c4_10m", pins["c4_10m"], flush=True)
+        json.dump(pins, open(OUT, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
