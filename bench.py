@@ -3,18 +3,29 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" = one full BPE.train() pass (char histogram -> word dedup -> pair count -> merge loop -> model file) over
-one synthetic corpus that is ALREADY RESIDENT IN HBM when the timed region starts.  N=1 workload = BASELINE.json
-configs[1]: 1 GB random 'abcd ' corpus, vocab_size=32000.  N>1: one process per GPU (torchrun), every rank holds its
-own 1 GB shard (weak scaling), pair-count deltas are exchanged over RCCL each round.  Rank 0 prints ONE JSON line.
-The same line carries: `roofline` (dominant kernel, HIP-event timed inside the timed region), `kernels` (per kernel
-family), `encode` (sentences/s of the batch-encode kernel on 128-char sentences with the freshly trained model) and
-`cpu_baseline` (the UNMODIFIED reference, oracle/_ref/yttm_ref_prod, n_threads=8, timed on this box's host cores on a
-bounded sample)."""
+A "step" = one full BPE.train() pass (char histogram -> word dedup -> pair count -> merge loop -> model file) over one
+synthetic corpus that is ALREADY RESIDENT IN HBM when the timed region starts.  Workload = BASELINE.json configs[1]: the
+1 GB random 'abcd ' corpus of SURVEY.md Appendix C (seed 19, md5 pinned), vocab_size=32000.  N>1: one process per GPU
+(torchrun); the SAME pinned file is cut into N byte ranges at whitespace (strong scaling -- the only way the N-GPU
+model can be compared with the reference's), pair-count deltas travel over RCCL each round.  `--scaling weak` gives
+every rank its own 1 GB instead (no pin exists for those corpora).  Rank 0 prints ONE JSON line.
+
+Parity is part of the line: the md5 of every model the GPU writes (configs[1], the Zipf corpus of configs[2]) and the
+FNV of all 10 M encoded sentences (configs[3]) are compared with tests/golden/full_size_pins.json -- outputs of the
+UNMODIFIED reference (tests/golden/make_full_pins.py) -- and a mismatch makes the process exit non-zero.
+
+Also on the line: `roofline` (dominant kernel, HIP-event timed inside the timed steps; `achieved` uses the contract's
+algorithmic bytes 8*T_touched + 8*W_touched counted at word granularity by a separate untimed measurement pass),
+`roofline_pair_count` (K3, the kernel north_star names), `kernels`, `e2e` (file -> model through yttm_train_bpe, host ->
+host encode, the Python list API), `encode` / `encode_dropout` (configs[3] / [4]), `extra.zipf` (configs[2]) and
+`cpu_baseline` (the unmodified reference, n_threads=8, pinned to 8 cores, on the SAME full inputs)."""
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -24,10 +35,52 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+PINS = os.path.join(ROOT, "tests", "golden", "full_size_pins.json")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def md5_file(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def pin_name(corpus, size_mb):
+    return {("abcd", 1000): "c2_1gb", ("abcd", 100): "c2_100mb", ("zipf", 1000): "c3_1gb", ("zipf", 100): "c3_100mb"}.get((corpus, size_mb))
+
+
+def split_points(host, world):
+    """Byte ranges per rank: size*r/W advanced to the next ASCII white space (host_trainer.cpp train_bpe; bpe.cpp:864-873)."""
+    n = len(host)
+    cuts = [0]
+    for r in range(1, world):
+        c = n * r // world
+        while c < n and host[c] not in b" \t\n\v\f\r":
+            c += 1
+        cuts.append(c)
+    cuts.append(n)
+    return cuts
+
+
+class Quiet:
+    """The trainer prints progress to stderr like the reference; keep the bench log readable."""
+
+    def __init__(self):
+        self.devnull = os.open(os.devnull, os.O_WRONLY)
+        self.saved = os.dup(2)
+        self.on = not os.environ.get("YTTM_TRACE")
+
+    def __enter__(self):
+        if self.on:
+            os.dup2(self.devnull, 2)
+
+    def __exit__(self, *a):
+        os.dup2(self.saved, 2)
 
 
 def main():
@@ -35,13 +88,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size-mb", type=int, default=1000, help="corpus MB per GPU (1000 = BASELINE configs[1])")
+    ap.add_argument("--size-mb", type=int, default=1000, help="corpus MB (1000 = BASELINE configs[1])")
     ap.add_argument("--vocab", type=int, default=32000)
     ap.add_argument("--corpus", default="abcd", choices=["abcd", "zipf"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N>1: shard ONE pinned corpus (strong) or one corpus per GPU (weak)")
     ap.add_argument("--encode-sentences", type=int, default=10_000_000)
     ap.add_argument("--no-encode", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mb", type=int, default=100)
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the Zipf (configs[2]) block")
+    ap.add_argument("--cpu-sample-mb", type=int, default=0, help="0 = the full corpus")
     args = ap.parse_args()
 
     import numpy as np
@@ -69,153 +125,262 @@ def main():
     rc, info = _lib.device_info(local_rank)
     if rank == 0:
         log("device:", info)
+    pins = json.load(open(PINS)) if os.path.exists(PINS) else {}
+    quiet = Quiet()
+    tmpdir = tempfile.mkdtemp(prefix="yttm_bench_")
+    strong = world > 1 and args.scaling == "strong"
+    ctx = dict(L=L, _lib=_lib, torch=torch, np=np, gen=gen, dev=dev, local_rank=local_rank, rank=rank, world=world, dist=dist, args=args,
+               pins=pins, quiet=quiet, tmpdir=tmpdir, strong=strong)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+    ctx["barrier"] = barrier
+    comm_handle = _init_rccl(L, dist, torch, dev, rank, world, local_rank) if world > 1 else None
+    ctx["comm"] = comm_handle
 
-    # ---- synthetic corpus shard, resident in HBM --------------------------------------------------------------------
-    nbytes = args.size_mb * 1_000_000
-    t0 = time.time()
-    if args.corpus == "abcd":
-        host = gen.abcd_corpus(nbytes, seed=19 + rank, survey_stream=True)  # rank 0, 1000 MB: SURVEY.md's C2 file byte for byte (md5 63857720...)
-    else:
-        host = gen.zipf_corpus(nbytes, seed=7 + rank, vocab=400000)
-    corpus = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
-    n_local = corpus.numel()
-    if rank == 0:
-        log(f"corpus: {args.corpus} {n_local/1e6:.1f} MB per GPU generated+uploaded in {time.time()-t0:.1f}s")
-    comm_handle = None
+    # ---- main workload: configs[1] ------------------------------------------------------------------------------------
+    main_res = _bench_train(ctx, args.corpus, args.size_mb, args.steps, args.warmup, measure_touched=(world == 1), keep_host=True)
+    out = {
+        "metric": "bpe_train_throughput", "value": main_res["value"], "unit": "MB/s", "n_gpus": n_gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
+        "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": main_res["config"], "parity": {}, "roofline": main_res["roofline"], "roofline_pair_count": main_res["roofline_pair_count"],
+        "kernels": main_res["kernels"], "phases_s": main_res["phases_s"],
+    }
+    out["parity"]["corpus_md5_matches"] = main_res["corpus_ok"]
+    out["parity"]["model_matches_reference"] = main_res["model_ok"]
     if world > 1:
-        comm_handle = _init_rccl(L, dist, torch, dev, rank, world, local_rank)
+        out["rccl_ranks"] = world
+    model_path = main_res["model_path"]
+    host = main_res.pop("host", None)
 
-    tmpdir = tempfile.mkdtemp(prefix="yttm_bench_")
-    # one model file per job: rank 0 writes it (single node), every rank's encoder loads it afterwards
-    model_path = os.path.join(tempfile.gettempdir(), "yttm_bench_%s.model" % os.environ.get("MASTER_PORT", str(os.getpid())))
+    # ---- end to end, the metric as SURVEY.md 8d words it: file -> model through the drop-in call ---------------------------
+    if world == 1 and not args.no_e2e:
+        out["e2e"] = {"train_file_to_model": _bench_e2e_train(ctx, host, main_res)}
+        out["parity"]["e2e_model_matches_reference"] = out["e2e"]["train_file_to_model"].pop("_model_ok")
+
+    # ---- encode: configs[3] (and [4]: dropout) with the model just trained --------------------------------------------------
+    if not args.no_encode:
+        enc = _bench_encode(ctx, model_path, main_res)
+        out["encode"] = enc["encode"]
+        out["encode_dropout"] = enc["dropout"]
+        out["parity"]["encode_fnv_matches"] = enc["fnv_ok"]
+        if "e2e" in enc:
+            out.setdefault("e2e", {}).update(enc["e2e"])
+
+    # ---- configs[2]: the Zipf corpus -- thousands of short rounds, per-round latency is the whole game ----------------------
+    if not args.no_extra and args.corpus == "abcd":
+        z = _bench_train(ctx, "zipf", args.size_mb, args.steps, args.warmup, measure_touched=False, keep_host=(world == 1))
+        zhost = z.pop("host", None)
+        out["extra"] = {"zipf": {"metric": "bpe_train_throughput", "value": z["value"], "unit": "MB/s", "ms_per_step": z["ms_per_step"],
+                                 "config": z["config"], "us_per_round": round(z["ms_per_step"] * 1e3 / max(1, z["config"]["merge_rounds"]), 2),
+                                 "kernels": z["kernels"], "phases_s": z["phases_s"]}}
+        out["parity"]["zipf_corpus_md5_matches"] = z["corpus_ok"]
+        out["parity"]["zipf_model_matches_reference"] = z["model_ok"]
+    else:
+        zhost = None
+
+    # ---- CPU baseline: the unmodified reference on this box's host cores (rank 0, N=1 only) --------------------------------
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = _cpu_baseline(ctx, host, zhost, model_path, out)
+    shutil.rmtree(tmpdir, ignore_errors=True)
+    bad = [k for k, v in out["parity"].items() if v is False]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+        if bad:
+            log("PARITY FAILURE:", bad)
+    if dist is not None:
+        dist.destroy_process_group()
+    if bad:
+        sys.exit(3)
+
+
+def _make_corpus(ctx, corpus, size_mb):
+    """Rank-local shard (host bytes) + what to compare its md5 with.  Strong scaling / single GPU: the pinned file."""
+    gen, args, rank, world = ctx["gen"], ctx["args"], ctx["rank"], ctx["world"]
+    nbytes = size_mb * 1_000_000
+    shared = ctx["strong"] or world == 1
+    seed_off = 0 if shared else rank
+    if corpus == "abcd":
+        host = gen.abcd_corpus(nbytes, seed=19 + seed_off, survey_stream=True)  # SURVEY.md Appendix C gen_abcd: C2 byte for byte
+    else:
+        host = gen.zipf_corpus_fast(nbytes, seed=7 + seed_off, vocab=400000)
+    pin = ctx["pins"].get(pin_name(corpus, size_mb)) if shared and args.vocab == 32000 else None
+    corpus_ok = None
+    if pin is not None:
+        corpus_ok = hashlib.md5(host).hexdigest() == pin["corpus_md5"]
+    total = len(host)
+    if ctx["strong"]:
+        cuts = split_points(host, world)
+        host = host[cuts[rank]:cuts[rank + 1]]
+    return host, pin, corpus_ok, total
+
+
+def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host):
+    L, _lib, torch, args = ctx["L"], ctx["_lib"], ctx["torch"], ctx["args"]
+    rank, world, dev, local_rank, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["local_rank"], ctx["dist"]
+    t0 = time.time()
+    host, pin, corpus_ok, total_bytes = _make_corpus(ctx, corpus, size_mb)
+    d_corpus = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+    n_local = d_corpus.numel()
+    if not ctx["strong"]:
+        total_bytes = n_local * world
+    if rank == 0:
+        log(f"corpus: {corpus} {n_local/1e6:.1f} MB on this GPU ({total_bytes/1e6:.1f} MB in all) generated+uploaded in {time.time()-t0:.1f}s")
+    model_path = os.path.join(tempfile.gettempdir(), "yttm_bench_%s_%s.model" % (corpus, os.environ.get("MASTER_PORT", str(os.getpid()))))
     err = C.create_string_buffer(_lib.ERRLEN)
-    rep = C.create_string_buffer(8192)
+    rep = C.create_string_buffer(16384)
 
     def train_step(profile):
-        if comm_handle is not None:
-            rc = L.yttm_train_bpe_from_device_comm(C.c_void_p(corpus.data_ptr()), n_local, model_path.encode(), args.vocab, 1.0,
-                                                   0, 1, 2, 3, local_rank, int(profile), comm_handle, rep, 8192, err, _lib.ERRLEN)
+        if ctx["comm"] is not None:
+            rc = L.yttm_train_bpe_from_device_comm(C.c_void_p(d_corpus.data_ptr()), n_local, model_path.encode(), args.vocab, 1.0,
+                                                   0, 1, 2, 3, local_rank, int(profile), ctx["comm"], rep, 16384, err, _lib.ERRLEN)
         else:
-            rc = L.yttm_train_bpe_from_device(C.c_void_p(corpus.data_ptr()), n_local, model_path.encode(), args.vocab, 1.0,
-                                              0, 1, 2, 3, local_rank, int(profile), rep, 8192, err, _lib.ERRLEN)
+            rc = L.yttm_train_bpe_from_device(C.c_void_p(d_corpus.data_ptr()), n_local, model_path.encode(), args.vocab, 1.0,
+                                              0, 1, 2, 3, local_rank, int(profile), rep, 16384, err, _lib.ERRLEN)
         if rc != 0:
             raise RuntimeError("train failed: " + err.value.decode())
         return json.loads(rep.value.decode())
 
-    devnull = os.open(os.devnull, os.O_WRONLY)
-    saved_err = os.dup(2)
-
-    def quiet(on):  # the trainer prints progress to stderr like the reference
-        os.dup2(devnull if on else saved_err, 2)
-
-    quiet(not os.environ.get("YTTM_TRACE"))
-    try:
-        for _ in range(args.warmup):
-            train_step(False)
-        barrier()
+    with ctx["quiet"]:
+        for _ in range(warmup):
+            train_step(0)
+        ctx["barrier"]()
         t0 = time.perf_counter()
-        reports = []
-        for _ in range(args.steps):
-            reports.append(train_step(True))
-        barrier()
+        reports = [train_step(1) for _ in range(steps)]
+        ctx["barrier"]()
         dt = time.perf_counter() - t0
-    finally:
-        quiet(False)
+        touched = train_step(2) if measure_touched else None  # measurement pass, outside the timed region
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_bytes = n_local * n_gpus
-    value = args.steps * total_bytes / dt / 1e6
-    pins = {}  # md5 of rank 0's corpus shard (SURVEY.md section 8d pins the generated files) and of the model file it produced
-    if rank == 0:
-        try:
-            import hashlib
-            pins["corpus_md5"] = hashlib.md5(host).hexdigest()
-            pins["model_md5"] = hashlib.md5(open(model_path, "rb").read()).hexdigest()
-        except Exception as e:  # never fail the bench line over a checksum
-            pins["pins_error"] = str(e)
+    value = steps * total_bytes / dt / 1e6
     r = reports[-1]
+    model_md5 = md5_file(model_path) if rank == 0 else None
+    model_ok = (model_md5 == pin["model_md5"]) if (pin is not None and rank == 0) else None
 
-    # ---- per-kernel roofline from the HIP-event times collected inside the timed steps ----------------------------------
     kern = {}
     for name, k in r["kernels"].items():
         if k["launches"] and k["ms"] > 0:
-            kern[name] = {"ms_total": round(k["ms"], 3), "launches": k["launches"],
-                          "avg_ms": round(k["ms"] / k["launches"], 4),
-                          "algorithmic_GB": round(k["bytes"] / 1e9, 4),
-                          "GBps": round(k["bytes"] / 1e9 / (k["ms"] / 1e3), 1)}
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, separate
-    # --pmc runs of this same command; tools/pmc_summary.py) -- only quoted for the exact workload they were taken on
-    traffic = {}
-    pmc_file = os.path.join(ROOT, "profiles", "r1_1gb_final_pmc_hbm.json")  # written by tools/profile_round.sh
-    if os.path.exists(pmc_file) and args.size_mb == 1000 and args.corpus == "abcd" and args.vocab == 32000 and n_gpus == 1:
-        pm = json.load(open(pmc_file))
-        # kernel families as the trainer times them; a family's traffic per launch = bytes of all its kernels / its launches
-        def family(k):  # k_tiles<SLOT, WPB, MERGE, LDSR>: MERGE=false is K3 (pair count), true is K4 (merge apply)
-            if k.startswith("k_tiles<"):
-                return "merge_apply" if k[len("k_tiles<"):].split(", ")[2] == "true" else "pair_count"
-            for name, prefixes in (("char_hist", ("k_scan_bytes<0>",)), ("segments", ("k_scan_bytes<1>",)), ("dedup", ("k2b_insert_words",)),
-                                   ("merge_apply", ("k_filter<", "k_giant<true")), ("pair_count", ("k_giant<false",)),
-                                   ("cand_scan", ("k_hot_scan", "k_cand_scan"))):
-                if k.startswith(prefixes):
-                    return name
-            return None
-        for name in ("char_hist", "segments", "dedup", "pair_count", "merge_apply", "cand_scan"):
-            ks = [k for k in pm if family(k) == name]
-            if ks and name in kern:
-                total = sum(pm[k]["traffic_bytes_per_launch"] * pm[k]["launches"] for k in ks)
-                traffic[name] = round(total / max(1, kern[name]["launches"]))  # per launch of the family as the trainer counts them
+            kern[name] = {"ms_total": round(k["ms"], 3), "launches": k["launches"], "avg_ms": round(k["ms"] / k["launches"], 4),
+                          "algorithmic_GB": round(k["bytes"] / 1e9, 4), "GBps": round(k["bytes"] / 1e9 / (k["ms"] / 1e3), 1)}
+    traffic, traffic_src = _static_traffic(kern, corpus, size_mb, args, world)
     dom = max(kern, key=lambda n: kern[n]["ms_total"]) if kern else None
     roofline = None
     if dom:
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic.get(dom),
-                    "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r1_1gb_final_pmc_hbm.json)",
+                    "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic.get(dom), "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(kern[dom]["algorithmic_GB"] * 1e9 / kern[dom]["launches"]),
                     "avg_launch_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"]}
+        if dom == "merge_apply":
+            # The contract's algorithmic bytes for K4 (SURVEY.md 8d): 8*T_touched + 8*W_touched, "touched" = the WORDS that held a
+            # merge site, counted by the untimed measurement pass.  What the kernel actually streams -- every live token once,
+            # dirty tiles twice -- is kept beside it as `streamed`.
+            streamed = {"bytes_per_launch": roofline["algorithmic_bytes_per_launch"], "GBps": roofline["achieved"], "frac": roofline["frac"],
+                        "definition": "4*(live tokens) + 8*(tokens of tiles that held a merge site)"}
+            roofline["streamed"] = streamed
+            if touched is not None and touched.get("touched_words"):
+                b8d = 8 * touched["touched_word_tokens"] + 8 * touched["touched_words"]
+                ach = b8d / 1e9 / (kern[dom]["ms_total"] / 1e3)
+                roofline.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                                 "algorithmic_bytes_per_launch": round(b8d / kern[dom]["launches"]),
+                                 "algorithmic_bytes_8d": b8d, "frac_8d": round(ach / HBM_PEAK_GBS, 4),
+                                 "definition": "8*T_touched + 8*W_touched over all launches / total K4 time; touched = words holding a merge site",
+                                 "touched_words": touched["touched_words"], "touched_word_tokens": touched["touched_word_tokens"],
+                                 "touched_tiles": touched["touched_tiles"], "touched_tile_tokens": touched["touched_tile_tokens"],
+                                 "merge_sites": touched["merge_sites"]})
+                if traffic.get(dom):
+                    roofline["traffic_over_algorithmic"] = round(traffic[dom] / max(1, roofline["algorithmic_bytes_per_launch"]), 2)
     roofline_pc = None
     if "pair_count" in kern:
         roofline_pc = {"kernel": "pair_count (K3)", "bound": "hbm", "achieved": kern["pair_count"]["GBps"], "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": round(kern["pair_count"]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic.get("pair_count"),
-                       "algorithmic_bytes_per_launch": round(kern["pair_count"]["algorithmic_GB"] * 1e9)}
-
-    out = {
-        "metric": "bpe_train_throughput", "value": round(value, 2), "unit": "MB/s", "n_gpus": n_gpus, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"{args.size_mb} MB/GPU random '{'abcd ' if args.corpus == 'abcd' else 'zipf ascii'}' corpus, "
-                               f"vocab_size={args.vocab} (BASELINE.json configs[1])",
-                   "corpus_bytes_per_gpu": n_local, "vocab_size": args.vocab, "unique_words": r["n_unique"],
-                   "dedup_tokens": r["n_tokens"], "merge_rounds": r["rounds"], "rules": r["rules"],
-                   "input": "resident in HBM before the timed region", **pins},
-        "roofline": roofline, "roofline_pair_count": roofline_pc, "kernels": kern,
-        "phases_s": {"frontend": r["seconds_frontend"], "merge_loop": r["seconds_merge"], "dump": r["seconds_io"]},
-    }
-
-    # ---- encode: sentences/s on 128-char sentences with the model just trained (BASELINE configs[3]) ---------------------
-    if not args.no_encode:
-        out["encode"] = _bench_encode(L, _lib, torch, np, gen, dev, local_rank, model_path, args, rank, world, dist, barrier)
-
-    # ---- CPU baseline: the unmodified reference on this box's host cores (rank 0, N=1 only, bounded sample) --------------
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = _cpu_baseline(host, args, tmpdir, out.get("encode"))
-    if "encode" in out:
-        out["encode"].pop("_host_sample", None)
-        out["encode"].pop("_sample_ids", None)
-        out["encode"].pop("_model_path", None)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+                       "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(kern["pair_count"]["algorithmic_GB"] * 1e9),
+                       "avg_launch_ms": kern["pair_count"]["avg_ms"]}
+    names = {"abcd": "random 'abcd ' corpus (BASELINE.json configs[1])", "zipf": "Zipf ASCII corpus, 400k-word lexicon (BASELINE.json configs[2])"}
+    cfg = {"workload": f"{size_mb} MB {names[corpus]}, vocab_size={args.vocab}"
+                       + (f", one file cut into {world} byte ranges" if ctx['strong'] else (f", {size_mb} MB per GPU" if world > 1 else "")),
+           "corpus_bytes_total": total_bytes, "corpus_bytes_this_gpu": n_local, "vocab_size": args.vocab, "unique_words": r["n_unique"],
+           "dedup_tokens": r["n_tokens"], "merge_rounds": r["rounds"], "rules": r["rules"], "input": "resident in HBM before the timed region",
+           "model_md5": model_md5, "pinned_model_md5": pin["model_md5"] if pin else None}
+    res = {"value": round(value, 2), "ms_per_step": round(dt / steps * 1e3, 2), "config": cfg, "roofline": roofline, "roofline_pair_count": roofline_pc,
+           "kernels": kern, "phases_s": {"frontend": r["seconds_frontend"], "merge_loop": r["seconds_merge"], "dump": r["seconds_io"]},
+           "corpus_ok": corpus_ok, "model_ok": model_ok, "model_path": model_path, "pin": pin}
+    if keep_host:
+        res["host"] = host
+    del d_corpus
+    torch.cuda.empty_cache()
+    return res
 
 
-def _bench_encode(L, _lib, torch, np, gen, dev, local_rank, model_path, args, rank, world, dist, barrier):
+def _static_traffic(kern, corpus, size_mb, args, world):
+    """HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, separate --pmc
+    runs of this same command; tools/pmc_summary.py).  STATIC: read from profiles/, not measured by this run."""
+    traffic = {}
+    for name in ("r2_1gb_pmc_hbm.json", "r1_1gb_final_pmc_hbm.json"):
+        pmc_file = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc_file):
+            break
+    else:
+        return traffic, None
+    if not (size_mb == 1000 and corpus == "abcd" and args.vocab == 32000 and world == 1):
+        return traffic, None
+    pm = json.load(open(pmc_file))
+
+    def family(k):  # k_tiles<SLOT, WPB, MERGE, LDSR>: MERGE=false is K3 (pair count), true is K4 (merge apply)
+        if k.startswith("k_tiles<"):
+            return "merge_apply" if k[len("k_tiles<"):].split(", ")[2] == "true" else "pair_count"
+        for name, prefixes in (("char_hist", ("k_scan_bytes<0>",)), ("segments", ("k_scan_bytes<1>",)), ("dedup", ("k2b_insert_words",)),
+                               ("merge_apply", ("k_filter<", "k_giant<true")), ("pair_count", ("k_giant<false",)),
+                               ("cand_scan", ("k_hot_scan", "k_cand_scan"))):
+            if k.startswith(prefixes):
+                return name
+        return None
+    for name in ("char_hist", "segments", "dedup", "pair_count", "merge_apply", "cand_scan"):
+        ks = [k for k in pm if family(k) == name]
+        if ks and name in kern:
+            total = sum(pm[k]["traffic_bytes_per_launch"] * pm[k]["launches"] for k in ks)
+            traffic[name] = round(total / max(1, kern[name]["launches"]))
+    return traffic, "static: bytes per launch from profiles/%s (rocprofv3 PMC passes of this command on an earlier run; not re-measured here)" % os.path.basename(pmc_file)
+
+
+def _bench_e2e_train(ctx, host, main_res):
+    """yttm_train_bpe(path -> model): open + read (page cache) + H2D + train + dump.  bpe.cpp:1368-1388 incl. :67-84."""
+    L, _lib, args = ctx["L"], ctx["_lib"], ctx["args"]
+    path = os.path.join(ctx["tmpdir"], "corpus.txt")
+    with open(path, "wb") as f:
+        f.write(host)
+    with open(path, "rb") as f:  # make sure it sits in the page cache like the CPU baseline's input
+        while f.read(1 << 24):
+            pass
+    model = os.path.join(ctx["tmpdir"], "e2e.model")
+    err = C.create_string_buffer(_lib.ERRLEN)
+    rep = C.create_string_buffer(16384)
+    times, reps = [], []
+    with ctx["quiet"]:
+        for _ in range(3):  # the first call also pins the staging chunks
+            t0 = time.perf_counter()
+            rc = L.yttm_train_bpe_ex(path.encode(), model.encode(), args.vocab, 1.0, 8, 0, 1, 2, 3, ctx["local_rank"], rep, 16384, err, _lib.ERRLEN)
+            times.append(time.perf_counter() - t0)
+            if rc != 0:
+                raise RuntimeError("e2e train failed: " + err.value.decode())
+            reps.append(json.loads(rep.value.decode()))
+    best = min(range(3), key=lambda i: times[i])
+    pin = main_res["pin"]
+    res = {"value": round(len(host) / 1e6 / times[best], 2), "unit": "MB/s", "seconds": round(times[best], 4), "all_seconds": [round(t, 4) for t in times],
+           "upload_seconds": round(reps[best]["seconds_upload"], 4), "train_seconds": round(reps[best]["seconds_total"] - reps[best]["seconds_upload"], 4),
+           "what": "wall of yttm_train_bpe_ex(path, model): file in the page cache -> pinned chunks -> HBM -> train -> model file written; best of 3",
+           "_model_ok": (md5_file(model) == pin["model_md5"]) if pin else None}
+    os.remove(path)
+    return res
+
+
+def _bench_encode(ctx, model_path, main_res):
+    L, _lib, torch, np, gen, args = ctx["L"], ctx["_lib"], ctx["torch"], ctx["np"], ctx["gen"], ctx["args"]
+    rank, world, dev, local_rank, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["local_rank"], ctx["dist"]
     n_sent = args.encode_sentences
     line = 128
     host = gen.abcd_corpus(n_sent * (line + 1), seed=123 + rank, line=line, survey_stream=True)  # SURVEY.md's C4 stream
@@ -229,98 +394,165 @@ def _bench_encode(L, _lib, torch, np, gen, dev, local_rank, model_path, args, ra
         raise RuntimeError(err.value.decode())
     n_ids = C.c_uint64()
     kms = C.c_double()
-
-    def step():
-        rc = L.yttm_encode_device(h, C.c_void_p(d_bytes.data_ptr()), C.c_void_p(d_off.data_ptr()), n_sent, d_bytes.numel(),
-                                  line + 1, 0, 0, 0, 0.0, C.byref(n_ids), C.byref(kms), err, _lib.ERRLEN)
-        if rc != 0:
-            raise RuntimeError(err.value.decode())
-    step()
-    barrier()
-    t0 = time.perf_counter()
-    k_ms = []
-    for _ in range(max(1, args.steps)):
-        step()
-        k_ms.append(kms.value)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     steps = max(1, args.steps)
-    sps = steps * n_sent * world / dt
-    alg_bytes = d_bytes.numel() + 8 * (n_sent + 1) * 2 + 4 * n_ids.value  # B_in + 16(S+1) + 4 K_out
-    kavg = sum(k_ms) / len(k_ms)
-    res = {"metric": "encode_sentences_per_s", "value": round(sps, 1), "unit": "sentences/s", "sentences_per_gpu": n_sent,
-           "sentence_chars": line, "ids_per_sentence": round(n_ids.value / n_sent, 3), "ms_per_step": round(dt / steps * 1e3, 2),
-           "kernel_ms": round(kavg, 3),
-           "roofline": {"kernel": "k5_encode", "bound": "hbm", "achieved": round(alg_bytes / 1e9 / (kavg / 1e3), 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(alg_bytes / 1e9 / (kavg / 1e3) / HBM_PEAK_GBS, 4), "traffic": None}}
-    # FNV-1a-64 of (len, ids...) per sentence over a bounded sample, for the parity line next to the CPU baseline
-    res["_host_sample"] = host[: 1_000_000 * (line + 1)]
-    res["_model_path"] = model_path
-    m = min(n_sent, 1_000_000)
+
+    def run(dropout):
+        def step():
+            rc = L.yttm_encode_device(h, C.c_void_p(d_bytes.data_ptr()), C.c_void_p(d_off.data_ptr()), n_sent, d_bytes.numel(),
+                                      line + 1, 0, 0, 0, dropout, C.byref(n_ids), C.byref(kms), err, _lib.ERRLEN)
+            if rc != 0:
+                raise RuntimeError(err.value.decode())
+        step()
+        ctx["barrier"]()
+        t0 = time.perf_counter()
+        k_ms = []
+        for _ in range(steps):
+            step()
+            k_ms.append(kms.value)
+        ctx["barrier"]()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        sps = steps * n_sent * world / dt
+        alg_bytes = d_bytes.numel() + 8 * (n_sent + 1) * 2 + 4 * n_ids.value  # B_in + 16(S+1) + 4 K_out
+        kavg = sum(k_ms) / len(k_ms)
+        return {"metric": "encode_sentences_per_s", "value": round(sps, 1), "unit": "sentences/s", "sentences_per_gpu": n_sent,
+                "sentence_chars": line, "dropout_prob": dropout, "ids_per_sentence": round(n_ids.value / n_sent, 3),
+                "ms_per_step": round(dt / steps * 1e3, 2), "kernel_ms": round(kavg, 3), "input": "sentences and offsets resident in HBM, ids left in HBM",
+                "roofline": {"kernel": "k5_encode", "bound": "hbm", "achieved": round(alg_bytes / 1e9 / (kavg / 1e3), 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(alg_bytes / 1e9 / (kavg / 1e3) / HBM_PEAK_GBS, 4), "traffic": None,
+                             "algorithmic_bytes_per_launch": alg_bytes}}
+
+    res = {"dropout": run(0.1)}  # configs[4]; parity for it is a distribution test (tests/test_gpu_parity.py), here: the rate and the mean length
+    res["encode"] = run(0.0)     # configs[3]; last, so that the ids left in the encoder are the deterministic ones
+    # ---- parity: FNV-1a-64 of (len, ids...) per sentence over ALL sentences vs the reference's (pinned) ---------------------
     ids = np.zeros(n_ids.value, dtype=np.int32)
     off = np.zeros(n_sent + 1, dtype=np.uint64)
     L.yttm_encode_fetch(h, ids.ctypes.data_as(_lib.i32p), off.ctypes.data_as(_lib.u64p), n_sent, err, _lib.ERRLEN)
-    res["_sample_ids"] = (ids[: int(off[m])], off[: m + 1])
+    pin = ctx["pins"].get("c4_10m")
+    fnv_ok = None
+    if rank == 0 and pin and main_res["pin"] is not None and main_res["pin"]["model_md5"] == pin["model_md5"] and main_res["model_ok"]:
+        if n_sent == pin["n_sentences"]:
+            got = "%016x" % L.yttm_ids_fnv1a64(ids.ctypes.data_as(_lib.i32p), off.ctypes.data_as(_lib.u64p), n_sent)
+            fnv_ok = (got == pin["fnv1a64"]) and int(n_ids.value) == pin["n_ids"]
+            res["encode"]["fnv1a64"] = got
+            res["encode"]["compared"] = "all %d sentences against the reference's encode_as_ids (tests/golden/full_size_pins.json c4_10m)" % n_sent
+        elif n_sent >= 1_000_000:
+            m = 1_000_000
+            got = "%016x" % L.yttm_ids_fnv1a64(ids.ctypes.data_as(_lib.i32p), off.ctypes.data_as(_lib.u64p), m)
+            fnv_ok = got == pin["first_1m"]["fnv1a64"]
+            res["encode"]["compared"] = "first 1 000 000 sentences against the reference (pin c4_10m.first_1m)"
+    res["fnv_ok"] = fnv_ok
+    del ids, off
+    # ---- host -> host through the drop-in call, and the Python list API (yttm.pyx:87-124) ------------------------------------
+    if world == 1 and not args.no_e2e:
+        h_off = (np.arange(n_sent + 1, dtype=np.uint64) * (line + 1))
+        blob = host
+        p_ids, p_off = _lib.i32p(), _lib.u64p()
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            rc = L.yttm_encode_as_ids(h, blob, h_off.ctypes.data_as(_lib.u64p), n_sent, 0, 0, 0, 0.0, C.byref(p_ids), C.byref(p_off), err, _lib.ERRLEN)
+            dt = time.perf_counter() - t0
+            if rc != 0:
+                raise RuntimeError(err.value.decode())
+            L.yttm_free(C.cast(p_ids, C.c_void_p))
+            L.yttm_free(C.cast(p_off, C.c_void_p))
+            best = dt if best is None else min(best, dt)
+        res["e2e"] = {"encode_host_to_host": {"value": round(n_sent / best, 1), "unit": "sentences/s", "seconds": round(best, 4),
+                                              "what": "yttm_encode_as_ids: packed host bytes+offsets -> H2D -> K5 -> D2H -> malloc'ed host ids; best of 2"}}
+        import youtokentome_amd as yttm
+        bpe = yttm.BPE(model_path)
+        m = min(n_sent, 1_000_000)
+        sents = host[: m * (line + 1)].decode().split("\n")[:m]
+        bpe.encode(sents[:1000])
+        t0 = time.perf_counter()
+        got = bpe.encode(sents, output_type=yttm.OutputType.ID)
+        dt = time.perf_counter() - t0
+        res["e2e"]["encode_python_list_api"] = {"value": round(m / dt, 1), "unit": "sentences/s", "sentences": m, "seconds": round(dt, 4),
+                                                "what": "youtokentome_amd.BPE.encode(list[str]) -> list[list[int]] (yttm.pyx:87-109 boundary)",
+                                                "ids": sum(len(s) for s in got)}
+        del got, sents
     L.yttm_encoder_destroy(h)
+    res["_host"] = host
+    ctx["_enc_host"] = host
+    del d_bytes, d_off
+    torch.cuda.empty_cache()
     return res
 
 
-def _fnv(ids, off):
-    import numpy as np
-    h = 1469598103934665603
-    mask = (1 << 64) - 1
-    ids = ids.astype(np.uint32)
-    for i in range(len(off) - 1):
-        a, b = int(off[i]), int(off[i + 1])
-        for v in [b - a] + ids[a:b].tolist():
-            for k in range(4):
-                h ^= (v >> (8 * k)) & 0xff
-                h = (h * 1099511628211) & mask
-    return "%016x" % h
+def _taskset():
+    """Pin the CPU baseline to 8 cores when taskset and >= 8 cores exist."""
+    n = os.cpu_count() or 1
+    if shutil.which("taskset") and n >= 8:
+        return ["taskset", "-c", "0-7"], 8
+    return [], min(8, n)
 
 
-def _cpu_baseline(host, args, tmpdir, enc):
-    import subprocess
+def _cpu_baseline(ctx, host, zhost, model_path, out):
+    args = ctx["args"]
     ref = os.path.join(ROOT, "oracle", "_ref", "yttm_ref_prod")
     if not os.path.exists(ref):
         return {"value": None, "unit": "MB/s", "cores": 0, "kind": "reference", "sample": "oracle/_ref/yttm_ref_prod not built"}
-    sample = host[: args.cpu_sample_mb * 1_000_000]
-    sample = sample[: sample.rfind(b"\n") + 1]
-    path = os.path.join(tmpdir, "cpu_sample.txt")
-    with open(path, "wb") as f:
-        f.write(sample)
-    model = os.path.join(tmpdir, "cpu_sample.model")
-    r = subprocess.run([ref, "train", path, model, str(args.vocab), "1.0", "8", "0", "1", "2", "3"], capture_output=True, text=True)
-    res = {"value": None, "unit": "MB/s", "cores": 8, "kind": "reference",
-           "sample": f"unmodified reference (oracle/_ref/yttm_ref_prod = bpe.cpp as shipped, -O3), n_threads=8, train on the first "
-                     f"{len(sample)/1e6:.0f} MB of the same corpus, vocab {args.vocab}; C++ boundary (train_bpe)"}
-    try:
+    pre, cores = _taskset()
+    tmpdir = ctx["tmpdir"]
+    os.makedirs(tmpdir, exist_ok=True)
+
+    def train(buf, tag):
+        sample = buf
+        if args.cpu_sample_mb:
+            sample = buf[: args.cpu_sample_mb * 1_000_000]
+            sample = sample[: sample.rfind(b"\n") + 1]
+        path = os.path.join(tmpdir, tag + ".txt")
+        with open(path, "wb") as f:
+            f.write(sample)
+        model = os.path.join(tmpdir, tag + ".model")
+        r = subprocess.run(pre + [ref, "train", path, model, str(args.vocab), "1.0", "8", "0", "1", "2", "3"], capture_output=True, text=True)
+        os.remove(path)
         j = json.loads(r.stdout.strip().splitlines()[-1])
-        res["value"] = round(len(sample) / 1e6 / j["train_seconds"], 2)
-        res["train_seconds"] = j["train_seconds"]
+        return len(sample), j["train_seconds"]
+
+    res = {"value": None, "unit": "MB/s", "cores": cores, "kind": "reference", "pinned": bool(pre)}
+    try:
+        n, secs = train(host, "cpu_c2")
+        res["value"] = round(n / 1e6 / secs, 2)
+        res["train_seconds"] = round(secs, 2)
+        res["sample"] = (f"unmodified reference (oracle/_ref/yttm_ref_prod = bpe.cpp as shipped, -O3), n_threads=8"
+                         f"{', taskset -c 0-7' if pre else ''}, train_bpe (C++ boundary: file -> model) on "
+                         f"{'the SAME full' if not args.cpu_sample_mb else 'the first'} {n/1e6:.0f} MB of the corpus, vocab {args.vocab}, 1 run")
+        res["gpu_over_cpu"] = round(out["value"] / res["value"], 1)
+        if "e2e" in out and "train_file_to_model" in out["e2e"]:
+            res["gpu_e2e_over_cpu"] = round(out["e2e"]["train_file_to_model"]["value"] / res["value"], 1)
     except Exception as e:  # noqa: BLE001
         res["error"] = str(e)
-    if enc is not None and "_host_sample" in enc:
-        lines = os.path.join(tmpdir, "enc_sample.txt")
-        with open(lines, "wb") as f:
-            f.write(enc["_host_sample"])
-        r = subprocess.run([ref, "encode_bench", enc["_model_path"], lines, "8", "0.0", "1000000"], capture_output=True, text=True)
+    if zhost is not None:
         try:
-            j = json.loads(r.stdout.strip().splitlines()[-1])
-            ids, off = enc["_sample_ids"]
-            res["encode"] = {"value": round(j["sentences"] / j["encode_seconds"], 1), "unit": "sentences/s", "cores": 8,
-                             "sample": f"{j['sentences']} sentences of 128 chars, encode_as_ids, n_threads=8",
-                             "ids_match_gpu": _fnv(ids[: int(off[j['sentences']])], off[: j['sentences'] + 1]) == j["fnv1a64"]}
+            n, secs = train(zhost, "cpu_c3")
+            res["zipf"] = {"value": round(n / 1e6 / secs, 2), "unit": "MB/s", "train_seconds": round(secs, 2), "cores": cores,
+                           "sample": f"same reference build and flags on the full {n/1e6:.0f} MB Zipf corpus (configs[2])"}
         except Exception as e:  # noqa: BLE001
-            res["encode"] = {"error": str(e)}
-    if enc is not None:
-        enc.pop("_host_sample", None)
-        enc.pop("_sample_ids", None)
-        enc.pop("_model_path", None)
+            res["zipf"] = {"error": str(e)}
+    enc_host = ctx.get("_enc_host")
+    if enc_host is not None and "encode" in out:
+        lines = os.path.join(tmpdir, "enc.txt")
+        with open(lines, "wb") as f:
+            f.write(enc_host)
+        for key, dropout, nmax in (("encode", "0.0", -1), ("encode_dropout", "0.1", 2_000_000)):
+            try:
+                r = subprocess.run(pre + [ref, "encode_bench", model_path, lines, "8", dropout, str(nmax)], capture_output=True, text=True)
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                res[key] = {"value": round(j["sentences"] / j["encode_seconds"], 1), "unit": "sentences/s", "cores": cores,
+                            "sample": f"{j['sentences']} sentences of 128 chars, encode_as_ids, n_threads=8, dropout {dropout}",
+                            "ids_per_sentence": round(j["ids"] / j["sentences"], 3)}
+                if key == "encode":
+                    res[key]["fnv1a64"] = j["fnv1a64"]
+                    res[key]["ids_match_gpu"] = (j["fnv1a64"] == out["encode"].get("fnv1a64")) if out["encode"].get("fnv1a64") else None
+            except Exception as e:  # noqa: BLE001
+                res[key] = {"error": str(e)}
+        os.remove(lines)
+    res["python_boundary"] = "not timed: the reference's Cython module cannot be built on the GPU box (/root/reference is absent there)"
     return res
 
 

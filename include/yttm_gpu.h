@@ -54,6 +54,11 @@ int yttm_gpu_download_pairs(yttm_ctx *ctx, uint64_t *pairs /* x<<32|y */, uint64
  * (rule_intersection, bpe.cpp:145-147; at most one x==y rule, last): applies them to every word and updates the
  * pair table exactly. */
 int yttm_gpu_merge_apply(yttm_ctx *ctx, const uint32_t *xyz, uint32_t k);
+/* Measurement mode of K4 (bench.py's untimed pass behind roofline.algorithmic_bytes_8d): on != 0 makes the following
+ * yttm_gpu_merge_apply calls also count the WORDS that hold a merge site and their tokens (W_touched, T_touched).
+ * out (optional) receives the totals so far: [0] merge sites, [1] tiles with a site, [2] their tokens, [3] words with a site,
+ * [4] their tokens, [5] rounds. */
+int yttm_gpu_k4_measure(yttm_ctx *ctx, int on, uint64_t out[6]);
 /* check_cnt (bpe.cpp:1099-1108): exact global count of given pairs */
 int yttm_gpu_pair_query(yttm_ctx *ctx, const uint64_t *pairs, uint32_t n, uint64_t *counts);
 /* candidate filter feeding the host's ordered pick (PriorityQueue, bpe.cpp:271-314): pairs with count > tau_cnt, or

@@ -25,6 +25,12 @@ extern "C" {
 int yttm_train_bpe(const char *input_path, const char *model_path, int vocab_size, double coverage, int n_threads,
                    int pad_id, int unk_id, int bos_id, int eos_id, char *err, int errlen);
 
+/* The same call with the device ordinal chosen by the caller and the report of the *_from_device variant below
+ * (adds "seconds_upload": file -> pinned chunks -> HBM, which replaces fast_read_file_utf8, bpe.cpp:67-84). */
+int yttm_train_bpe_ex(const char *input_path, const char *model_path, int vocab_size, double coverage, int n_threads,
+                      int pad_id, int unk_id, int bos_id, int eos_id, int device, char *report_json, int report_len,
+                      char *err, int errlen);
+
 /* Same training on a corpus that is already in host memory (no file read), or already resident in HBM
  * (`d_text` = device pointer, 16-byte aligned).  `device` = HIP device ordinal.  `report_json` (optional, may be
  * NULL) receives a JSON object with wall-time phases and per-kernel GPU time / algorithmic bytes
@@ -76,6 +82,19 @@ int yttm_vocab_size(yttm_encoder *enc);
 /* vector<string> vocabulary() const                                   bpe.h:64, bpe.cpp:1884; yttm.pyx:163-165 */
 int yttm_vocabulary(yttm_encoder *enc, char **blob, uint64_t **offsets, uint64_t *n);
 
+/* The streaming loops of the `yttm` command line.  The reference's read std::cin and write std::cout; here the file
+ * descriptors are arguments (the Python module passes 0 and 1).
+ * Status encode_cli(const string& output_type, bool stream, bool bos, bool eos, bool reverse, double dropout_prob) const
+ *                                                                     bpe.h:66-68, bpe.cpp:1942-2014; yttm.pyx:167-170
+ * batch mode: stdin in batches of >= 10 MiB of line bytes -> H2D / K5 / D2H of one batch overlapped with the formatting of
+ * the previous one (two encoder lanes) -> "<token> <token> ...\n" per sentence (utils.h:92-103); progress on stderr. */
+int yttm_encode_cli(yttm_encoder *enc, const char *output_type, int stream, int bos, int eos, int reverse, double dropout_prob,
+                    int in_fd, int out_fd, char *err, int errlen);
+/* Status decode_cli(const unordered_set<int>* ignore_ids) const       bpe.h:70, bpe.cpp:2016-2028; yttm.pyx:172-178 */
+int yttm_decode_cli(yttm_encoder *enc, const int32_t *ignore_ids, uint64_t n_ignore, int in_fd, int out_fd, char *err, int errlen);
+/* void vocab_cli(bool verbose) const                                  bpe.h:71, bpe.cpp:1896-1940; yttm.pyx:180-181 */
+int yttm_vocab_cli(yttm_encoder *enc, int verbose, int out_fd, char *err, int errlen);
+
 /* ---- multi-GPU (one process per GPU) ---------------------------------------------------------------
  * The corpus shards across ranks; the only exchanged quantities are the char histogram (once) and sparse pair-count
  * deltas (after the initial count and after every merge round) -- the RCCL form of the reference's main thread summing
@@ -98,6 +117,11 @@ int yttm_train_bpe_from_device_comm(const void *d_text, uint64_t n, const char *
 int yttm_train_bpe_from_memory_comm(const uint8_t *text, uint64_t n, const char *model_path, int vocab_size, double coverage,
                                     int pad_id, int unk_id, int bos_id, int eos_id, int device, yttm_comm *comm,
                                     char *report_json, int report_len, char *err, int errlen);
+
+/* Checksum of an encode result for comparisons across implementations: FNV-1a-64 over, per sentence, the little-endian
+ * bytes of the uint32 length and of each int32 id (no reference counterpart; oracle/ref_driver.cpp hashes the reference's
+ * encode_as_ids output the same way). */
+unsigned long long yttm_ids_fnv1a64(const int32_t *ids, const uint64_t *offsets, uint64_t n_sent);
 
 void yttm_free(void *p);
 /* "gfx950 MI355X ..." or an error text when no usable GPU is visible */

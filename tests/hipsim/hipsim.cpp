@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
+#include <mutex>
 #include <vector>
 
 namespace hipsim {
@@ -159,6 +160,8 @@ static void run_block(unsigned nthreads) {
 }
 
 void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+  static std::mutex launch_mu;  // one emulated kernel at a time (host threads of the product may launch concurrently)
+  std::lock_guard<std::mutex> lock(launch_mu);
   g_body = &body;
   g_gridDim = grid;
   g_blockDim = block;

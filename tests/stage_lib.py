@@ -80,6 +80,11 @@ class Ctx:
         r = np.ascontiguousarray(rules_xyz, np.uint32).reshape(-1)
         self._chk(self.L.yttm_gpu_merge_apply(self.h, r.ctypes.data_as(_lib.u32p), len(r) // 3))
 
+    def k4_measure(self, on=True, read=False):
+        out = np.zeros(6, np.uint64)
+        self._chk(self.L.yttm_gpu_k4_measure(self.h, int(on), out.ctypes.data_as(_lib.u64p) if read else None))
+        return dict(zip(("sites", "tiles", "tile_tokens", "words", "word_tokens", "rounds"), (int(v) for v in out)))
+
     def pair_query(self, keys):
         keys = np.ascontiguousarray(keys, np.uint64)
         out = np.zeros(len(keys), np.uint64)

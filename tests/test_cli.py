@@ -42,6 +42,25 @@ def _roundtrip(tmp_path):
     assert dec.decode().split("\n")[:-1] == want_dec  # a run of unknown chars decodes to one <UNK>
     voc = run_cli(["vocab", f"--model={model}", "--verbose"]).decode().split("\n")[:-1]
     assert len(voc) == 300 and voc[292].split("\t")[1] == "<UNK>" and "+" in voc[299]
+    # several batches through the two-lane pipeline (reader -> 2 workers -> ordered writer): same bytes as one batch
+    many = run_cli(["encode", f"--model={model}", "--output_type=id", "--bos", "--eos"], test, env={"YTTM_CLI_BATCH_BYTES": "150"})
+    assert many == out
+    many = run_cli(["encode", f"--model={model}", "--output_type=subword"], test, env={"YTTM_CLI_BATCH_BYTES": "61"})
+    assert many == run_cli(["encode", f"--model={model}", "--output_type=subword", "--stream"], test)
+    # the loops are bytes end to end: invalid UTF-8, a last line without newline, empty lines, CR
+    odd = b"ab\xffcd ef\n\n  \nabc\r\n\xe2\x82 ab\xc0\x80cd\nlast line without newline ab"
+    got = run_cli(["encode", f"--model={model}", "--output_type=id"], odd)
+    want = O.Model(m_ora).encode(odd.split(b"\n"), False, False)
+    assert got.decode() == "".join("".join(f"{t} " for t in row) + "\n" for row in want)
+    import refbin
+    if refbin.available("prod"):  # the unmodified reference's CLI loop output for the same bytes
+        lines = str(tmp_path / "odd.txt")
+        open(lines, "wb").write(odd)
+        ref_ids = refbin.encode(model, lines, n_threads=1)
+        assert got.decode() == "".join("".join(f"{t} " for t in row) + "\n" for row in ref_ids)
+        ref_sub = refbin.encode(model, lines, n_threads=1, subword=True)
+        got_sub = run_cli(["encode", f"--model={model}", "--output_type=subword"], odd)
+        assert got_sub == "".join("".join(f"{t} " for t in row) + "\n" for row in ref_sub).encode("utf-8", "surrogateescape")
 
 
 def test_cli_roundtrip_emulated(tmp_path, sim_lib):

@@ -236,3 +236,78 @@ def test_zz_c2_100mb_model_pin(tmp_path):
     model = str(tmp_path / "c2.model")
     yttm.BPE.train(corpus, model, pin["vocab_size"])
     assert hashlib.md5(open(model, "rb").read()).hexdigest() == pin["model_md5"]
+
+
+def _full_pins():
+    import json
+    return json.load(open(os.path.join(S.G, "full_size_pins.json")))
+
+
+def test_zz_c3_100mb_zipf_model_pin(tmp_path):
+    """BASELINE.json configs[2] at a tenth of its size: 100 MB of the Zipf corpus bench.py uses (gen.zipf_corpus_fast), vocab
+    32000 -- thousands of short merge rounds.  Model md5 as the unmodified reference (det queue, n_threads=8) writes it
+    (tests/golden/full_size_pins.json, made by tests/golden/make_full_pins.py)."""
+    import hashlib
+    import youtokentome_amd as yttm
+    pin = _full_pins()["c3_100mb"]
+    text = gen.zipf_corpus_fast(100_000_000, seed=7, vocab=400000)
+    assert len(text) == pin["corpus_bytes"] and hashlib.md5(text).hexdigest() == pin["corpus_md5"]
+    corpus = str(tmp_path / "c3.txt")
+    open(corpus, "wb").write(text)
+    model = str(tmp_path / "c3.model")
+    yttm.BPE.train(corpus, model, pin["vocab_size"])
+    assert hashlib.md5(open(model, "rb").read()).hexdigest() == pin["model_md5"]
+
+
+def test_zz_rccl_world_of_one(tmp_path):
+    """The RCCL transport of the multi-GPU path on the one GPU there is: a communicator of size 1 still runs every collective
+    of a round (ncclAllReduce of the char histogram and of the hot-list verdict, the grouped send/recv all-gather after K3,
+    ncclAllGather of the delta blocks) and the block fold -- the model must not change.  (N>1 logic: tests/test_multi_rank_gloo.py.)"""
+    import ctypes as C
+    import hashlib
+    from youtokentome_amd import _lib
+    L = _lib.load()
+    idbuf = (C.c_uint8 * 128)()
+    assert L.yttm_comm_rccl_unique_id(idbuf) == 0
+    comm = C.c_void_p()
+    assert L.yttm_comm_rccl_create(idbuf, 0, 1, 0, C.byref(comm)) == 0
+    err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+    try:
+        for name, text, vocab in (("readme", gen.readme_corpus(2000, 100, seed=11), 2000), ("zipf", gen.zipf_corpus(3_000_000, vocab=20000), 6000)):
+            m_gpu, m_ora = str(tmp_path / f"{name}.rccl.model"), str(tmp_path / f"{name}.ora.model")
+            rc = L.yttm_train_bpe_from_memory_comm(text, len(text), m_gpu.encode(), vocab, 1.0, 0, 1, 2, 3, 0, comm, rep, 16384, err, 2048)
+            assert rc == 0, err.value.decode()
+            O.train(text, m_ora, vocab)
+            assert filecmp.cmp(m_gpu, m_ora, shallow=False), name
+        # and at a tenth of the headline size, against the reference's pin
+        pin = _full_pins()["c2_100mb"]
+        text = gen.abcd_corpus(pin["corpus_bytes"] + 1, seed=19, survey_stream=True)
+        m_gpu = str(tmp_path / "c2.rccl.model")
+        rc = L.yttm_train_bpe_from_memory_comm(text, len(text), m_gpu.encode(), 32000, 1.0, 0, 1, 2, 3, 0, comm, rep, 16384, err, 2048)
+        assert rc == 0, err.value.decode()
+        assert hashlib.md5(open(m_gpu, "rb").read()).hexdigest() == pin["model_md5"]
+    finally:
+        L.yttm_comm_destroy(comm)
+
+
+def test_zz_encode_concurrent_threads(tmp_path):
+    """Two Python threads encode on ONE BPE object (ctypes releases the GIL): each call owns an encoder lane, results are the
+    single-threaded ones."""
+    import threading
+    import youtokentome_amd as yttm
+    model = os.path.join(S.G, "train_readme_small.model")
+    bpe = yttm.BPE(model)
+    rng = random.Random(12)
+    batches = [["".join(rng.choice("abcd  ") for _ in range(rng.randint(0, 300))) for _ in range(rng.randint(1, 400))] for _ in range(24)]
+    want = [bpe.encode(b, yttm.OutputType.ID, bos=True) for b in batches]
+    got = [None] * len(batches)
+
+    def work(k):
+        for i in range(k, len(batches), 4):
+            got[i] = bpe.encode(batches[i], yttm.OutputType.ID, bos=True)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got == want

@@ -65,3 +65,30 @@ def test_two_ranks_long_words_and_small_hot_list(tmp_path, sim_lib):
     run_world(corpus, m_mp, 150, 1.0, 2, sim_lib, {"YTTM_HOT_TARGET": "8", "YTTM_HOT_MIN": "3", "YTTM_HOT_CAP": "32"})
     O.train(text, m_ora, 150, 1.0)
     assert filecmp.cmp(m_mp, m_ora, shallow=False)
+
+
+def test_exchange_blocks_too_small_are_repeated(tmp_path, sim_lib):
+    """Per round the ranks all-gather fixed-size blocks of delta records and fold them in without a host round trip; a rank
+    whose records did not fit is skipped by everybody and the exchange is repeated with larger blocks (gpu_ctx.cpp
+    settle_exchange).  Blocks of one record force that path in nearly every round -- with and without the hot list."""
+    rng = random.Random(21)
+    text = gen.unicode_text(rng, 5000, "ascii") + gen.readme_corpus(60, 80, seed=5)
+    corpus = str(tmp_path / "c.txt")
+    open(corpus, "wb").write(text)
+    m_ora = str(tmp_path / "ora.model")
+    O.train(text, m_ora, 200, 1.0)
+    for i, env in enumerate(({"YTTM_XCHG_BLK_MIN": "2"}, {"YTTM_XCHG_BLK_MIN": "2", "YTTM_HOT_TARGET": "8", "YTTM_HOT_MIN": "3", "YTTM_HOT_CAP": "32"})):
+        m_mp = str(tmp_path / f"mp{i}.model")
+        run_world(corpus, m_mp, 200, 1.0, 3, sim_lib, env)
+        assert filecmp.cmp(m_mp, m_ora, shallow=False), env
+
+
+def test_world_of_one_runs_the_exchange_path(tmp_path, sim_lib):
+    """A communicator of size 1 still goes through every collective of the N>1 path (what the GPU suite does with RCCL)."""
+    text = gen.readme_corpus(100, 80, seed=8)
+    corpus = str(tmp_path / "c.txt")
+    open(corpus, "wb").write(text)
+    m_mp, m_ora = str(tmp_path / "mp.model"), str(tmp_path / "ora.model")
+    run_world(corpus, m_mp, 250, 1.0, 1, sim_lib)
+    O.train(text, m_ora, 250, 1.0)
+    assert filecmp.cmp(m_mp, m_ora, shallow=False)

@@ -31,6 +31,14 @@ def test_merge_apply_rounds():
             S.check_merge_rounds(t, rounds=5, seed=i)
 
 
+def test_k4_measurement_pass():
+    for i, t in enumerate(S.texts_small(3, n=2, size=1500) + [gen.readme_corpus(120, 100, seed=4)]):
+        if t.strip():
+            S.check_k4_measure(t, rounds=6, seed=i)
+    words = ["ab" * k for k in range(60, 125, 7)] + ["a" * k for k in range(150, 250, 13)]
+    S.check_k4_measure((" ".join(words) + " ").encode(), rounds=6, seed=1)
+
+
 def test_merge_apply_runs():
     t = ("aaaa aaaaa aaaaaaa abababab aabbaabb abcabcabc bbbbbb ab aaab baaa aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa " * 3).encode()
     S.check_merge_rounds(t, rounds=12, seed=1)
@@ -166,3 +174,25 @@ def test_dropout_distribution_small():
     rng = random.Random(6)
     sents = ["".join(rng.choice("abcd  ") for _ in range(60)) for _ in range(1500)]
     S.check_dropout_distribution(model, sents, 0.1, 600)
+
+
+def test_encode_concurrent_threads():
+    """Two encoder lanes behind one BPE object: concurrent encode() calls from Python threads give the single-threaded results."""
+    import os
+    import threading
+    import youtokentome_amd as yttm
+    bpe = yttm.BPE(os.path.join(S.G, "train_readme_small.model"))
+    rng = random.Random(12)
+    batches = [["".join(rng.choice("abcd  ") for _ in range(rng.randint(0, 80))) for _ in range(rng.randint(1, 12))] for _ in range(12)]
+    want = [bpe.encode(b, yttm.OutputType.ID, bos=True) for b in batches]
+    got = [None] * len(batches)
+
+    def work(k):
+        for i in range(k, len(batches), 3):
+            got[i] = bpe.encode(batches[i], yttm.OutputType.ID, bos=True)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got == want

@@ -18,9 +18,9 @@ ERRLEN = 2048
 
 EXPORTS = [
     # include/yttm_mi355x.h
-    "yttm_train_bpe", "yttm_train_bpe_from_memory", "yttm_train_bpe_from_device", "yttm_encoder_create",
+    "yttm_train_bpe", "yttm_train_bpe_ex", "yttm_train_bpe_from_memory", "yttm_train_bpe_from_device", "yttm_encoder_create",
     "yttm_encoder_destroy", "yttm_encode_as_ids", "yttm_encode_as_subwords", "yttm_encode_device", "yttm_encode_fetch",
-    "yttm_id_to_subword", "yttm_subword_to_id", "yttm_decode", "yttm_vocab_size", "yttm_vocabulary", "yttm_free",
+    "yttm_id_to_subword", "yttm_subword_to_id", "yttm_decode", "yttm_vocab_size", "yttm_vocabulary", "yttm_free", "yttm_ids_fnv1a64", "yttm_encode_cli", "yttm_decode_cli", "yttm_vocab_cli",
     "yttm_device_info", "yttm_comm_rccl_unique_id", "yttm_comm_rccl_create", "yttm_comm_callback_create",
     "yttm_comm_destroy", "yttm_train_bpe_from_device_comm", "yttm_train_bpe_from_memory_comm",
     # include/yttm_gpu.h
@@ -28,7 +28,7 @@ EXPORTS = [
     "yttm_gpu_upload_corpus",
     "yttm_gpu_attach_corpus", "yttm_gpu_char_hist", "yttm_gpu_build_word_table", "yttm_gpu_download_word_table",
     "yttm_gpu_pair_count", "yttm_gpu_download_pairs", "yttm_gpu_merge_apply", "yttm_gpu_pair_query",
-    "yttm_gpu_candidates",
+    "yttm_gpu_candidates", "yttm_gpu_k4_measure",
 ]
 
 _lib = None
@@ -45,6 +45,7 @@ def load():
     L = C.CDLL(LIB_PATH)
     cs, ci, cd, cvp = C.c_char_p, C.c_int, C.c_double, C.c_void_p
     L.yttm_train_bpe.argtypes = [cs, cs, ci, cd, ci, ci, ci, ci, ci, cs, ci]
+    L.yttm_train_bpe_ex.argtypes = [cs, cs, ci, cd, ci, ci, ci, ci, ci, ci, cs, ci, cs, ci]
     L.yttm_train_bpe_from_memory.argtypes = [cs, C.c_uint64, cs, ci, cd, ci, ci, ci, ci, ci, cs, ci, cs, ci]
     L.yttm_train_bpe_from_device.argtypes = [cvp, C.c_uint64, cs, ci, cd, ci, ci, ci, ci, ci, ci, cs, ci, cs, ci]
     L.yttm_encoder_create.argtypes = [cs, ci, ci, C.POINTER(cvp), cs, ci]
@@ -61,6 +62,11 @@ def load():
     L.yttm_decode.argtypes = [cvp, i32p, u64p, C.c_uint64, i32p, C.c_uint64, C.POINTER(cvp), C.POINTER(u64p), cs, ci]
     L.yttm_vocab_size.argtypes = [cvp]
     L.yttm_vocabulary.argtypes = [cvp, C.POINTER(cvp), C.POINTER(u64p), u64p]
+    L.yttm_encode_cli.argtypes = [cvp, cs, ci, ci, ci, ci, cd, ci, ci, cs, ci]
+    L.yttm_decode_cli.argtypes = [cvp, i32p, C.c_uint64, ci, ci, cs, ci]
+    L.yttm_vocab_cli.argtypes = [cvp, ci, ci, cs, ci]
+    L.yttm_ids_fnv1a64.argtypes = [i32p, u64p, C.c_uint64]
+    L.yttm_ids_fnv1a64.restype = C.c_ulonglong
     L.yttm_free.argtypes = [cvp]
     L.yttm_free.restype = None
     L.yttm_device_info.argtypes = [ci, cs, ci]
@@ -91,6 +97,7 @@ def load():
     L.yttm_gpu_download_pairs.argtypes = [cvp, u64p, u64p, u64p]
     L.yttm_gpu_merge_apply.argtypes = [cvp, u32p, C.c_uint32]
     L.yttm_gpu_pair_query.argtypes = [cvp, u64p, C.c_uint32, u64p]
+    L.yttm_gpu_k4_measure.argtypes = [cvp, ci, u64p]
     L.yttm_gpu_candidates.argtypes = [cvp, C.c_uint64, C.c_uint32, u64p, u64p, u32p]
     _lib = L
     return L

@@ -154,6 +154,33 @@ class _Core:
     def vocab_size(self):
         return _lib.load().yttm_vocab_size(self._h)
 
+    # ---- the command line's streaming loops (yttm.pyx:167-181): stdin -> stdout inside the library
+    def encode_cli(self, output_type, stream, bos, eos, reverse, dropout_prob, in_fd=0, out_fd=1):
+        import sys
+        sys.stdout.flush()
+        err = _err()
+        rc = _lib.load().yttm_encode_cli(self._h, output_type.encode(), int(stream), int(bos), int(eos), int(reverse),
+                                         float(dropout_prob), in_fd, out_fd, err, _lib.ERRLEN)
+        if rc != 0:
+            raise ValueError(err.value.decode())
+
+    def decode_cli(self, ignore_ids, in_fd=0, out_fd=1):
+        import sys
+        sys.stdout.flush()
+        ign = np.ascontiguousarray(sorted(set(int(i) for i in (ignore_ids or ()))), dtype=np.int32)
+        err = _err()
+        rc = _lib.load().yttm_decode_cli(self._h, ign.ctypes.data_as(_lib.i32p), len(ign), in_fd, out_fd, err, _lib.ERRLEN)
+        if rc != 0:
+            raise ValueError(err.value.decode())
+
+    def vocab_cli(self, verbose, out_fd=1):
+        import sys
+        sys.stdout.flush()
+        err = _err()
+        rc = _lib.load().yttm_vocab_cli(self._h, int(verbose), out_fd, err, _lib.ERRLEN)
+        if rc != 0:
+            raise ValueError(err.value.decode())
+
     def vocab(self):
         L = _lib.load()
         blob_p, off = C.c_void_p(), _lib.u64p()

@@ -36,11 +36,14 @@ void yttm_report_to_json(const TrainReport &r, char *buf, int len) {
   static const char *names[8] = {"char_hist", "segments", "dedup", "build", "pair_count", "merge_apply", "cand_scan", "encode"};
   std::string s = "{";
   char tmp[512];
-  snprintf(tmp, sizeof tmp, "\"seconds_total\": %.6f, \"seconds_frontend\": %.6f, \"seconds_merge\": %.6f, \"seconds_io\": %.6f, ", r.seconds_total,
-           r.seconds_frontend, r.seconds_merge, r.seconds_io);
+  snprintf(tmp, sizeof tmp, "\"seconds_total\": %.6f, \"seconds_upload\": %.6f, \"seconds_frontend\": %.6f, \"seconds_merge\": %.6f, \"seconds_io\": %.6f, ", r.seconds_total,
+           r.seconds_upload, r.seconds_frontend, r.seconds_merge, r.seconds_io);
   s += tmp;
   snprintf(tmp, sizeof tmp, "\"corpus_bytes\": %llu, \"n_unique\": %llu, \"n_tokens\": %llu, \"rounds\": %llu, \"rules\": %llu, \"cand_rescans\": %llu, \"hot_rebuilds\": %llu, \"repacks\": %llu, \"merge_sites\": %llu, ",
            r.corpus_bytes, r.n_unique, r.n_tokens, r.rounds, r.rules, r.cand_rescans, r.hot_rebuilds, r.repacks, r.merge_sites);
+  s += tmp;
+  snprintf(tmp, sizeof tmp, "\"touched_tiles\": %llu, \"touched_tile_tokens\": %llu, \"touched_words\": %llu, \"touched_word_tokens\": %llu, ",
+           r.touched_tiles, r.touched_tile_tokens, r.touched_words, r.touched_word_tokens);
   s += tmp;
   s += "\"kernels\": {";
   for (int i = 0; i < 8; i++) {
@@ -67,6 +70,14 @@ int yttm_train_bpe(const char *input_path, const char *model_path, int vocab_siz
   return finish(train_bpe(input_path, model_path, vocab_size, make_cfg(coverage, n_threads, pad_id, unk_id, bos_id, eos_id)), err, errlen);
 }
 
+int yttm_train_bpe_ex(const char *input_path, const char *model_path, int vocab_size, double coverage, int n_threads, int pad_id, int unk_id,
+                      int bos_id, int eos_id, int device, char *report_json, int report_len, char *err, int errlen) {
+  TrainReport rep;
+  Status s = train_bpe(input_path, model_path, vocab_size, make_cfg(coverage, n_threads, pad_id, unk_id, bos_id, eos_id), device, &rep);
+  if (s.ok()) yttm_report_to_json(rep, report_json, report_len);
+  return finish(s, err, errlen);
+}
+
 int yttm_train_bpe_from_memory(const uint8_t *text, uint64_t n, const char *model_path, int vocab_size, double coverage, int pad_id,
                                int unk_id, int bos_id, int eos_id, int device, char *report_json, int report_len, char *err, int errlen) {
   TrainReport rep;
@@ -79,7 +90,7 @@ int yttm_train_bpe_from_device(const void *d_text, uint64_t n, const char *model
                                int bos_id, int eos_id, int device, int profile, char *report_json, int report_len, char *err, int errlen) {
   TrainReport rep;
   Status s = train_bpe_from_device(d_text, n, model_path ? model_path : "", vocab_size, make_cfg(coverage, 1, pad_id, unk_id, bos_id, eos_id), device,
-                                   &rep, nullptr, profile != 0);
+                                   &rep, nullptr, profile);
   if (s.ok()) yttm_report_to_json(rep, report_json, report_len);
   return finish(s, err, errlen);
 }
@@ -189,6 +200,31 @@ int yttm_vocabulary(yttm_encoder *h, char **blob, uint64_t **offsets, uint64_t *
   *n = v.size();
   return 0;
 }
+int yttm_encode_cli(yttm_encoder *h, const char *output_type, int stream, int bos, int eos, int reverse, double dropout_prob, int in_fd, int out_fd,
+                    char *err, int errlen) {
+  return finish(h->enc->encode_cli(output_type, stream != 0, bos != 0, eos != 0, reverse != 0, dropout_prob, in_fd, out_fd), err, errlen);
+}
+int yttm_decode_cli(yttm_encoder *h, const int32_t *ignore_ids, uint64_t n_ignore, int in_fd, int out_fd, char *err, int errlen) {
+  std::unordered_set<int> ign;
+  for (uint64_t i = 0; i < n_ignore; i++) ign.insert(ignore_ids[i]);
+  return finish(h->enc->decode_cli(&ign, in_fd, out_fd), err, errlen);
+}
+int yttm_vocab_cli(yttm_encoder *h, int verbose, int out_fd, char *err, int errlen) {
+  return finish(h->enc->vocab_cli(verbose != 0, out_fd), err, errlen);
+}
+
+unsigned long long yttm_ids_fnv1a64(const int32_t *ids, const uint64_t *offsets, uint64_t n_sent) {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix4 = [&](uint32_t v) {
+    for (int k = 0; k < 4; k++) { h ^= (v >> (8 * k)) & 0xffu; h *= 1099511628211ull; }
+  };
+  for (uint64_t i = 0; i < n_sent; i++) {
+    mix4((uint32_t)(offsets[i + 1] - offsets[i]));
+    for (uint64_t k = offsets[i]; k < offsets[i + 1]; k++) mix4((uint32_t)ids[k]);
+  }
+  return h;
+}
+
 void yttm_free(void *p) { free(p); }
 
 int yttm_device_info(int device, char *buf, int buflen) {
@@ -294,6 +330,17 @@ int yttm_gpu_candidates(yttm_ctx *c, uint64_t tau_cnt, uint32_t tau_mx, uint64_t
     uint32_t take = std::min<uint32_t>((uint32_t)out.size(), *n_inout);
     for (uint32_t i = 0; i < take; i++) { pairs[i] = out[i].key; counts[i] = out[i].cnt; }
     *n_inout = n;
+  })
+}
+
+int yttm_gpu_k4_measure(yttm_ctx *c, int on, uint64_t out[6]) {
+  GUARD({
+    c->g->instrument = on != 0;
+    if (out) {
+      c->g->resolve_timers();
+      out[0] = c->g->merge_sites; out[1] = c->g->touched_tiles; out[2] = c->g->touched_tile_tokens;
+      out[3] = c->g->touched_words; out[4] = c->g->touched_word_tokens; out[5] = c->g->merge_rounds;
+    }
   })
 }
 

@@ -25,20 +25,54 @@ struct CallbackComm : Comm {
     HIP_CHECK(hipMemcpyAsync(dev, h_buf.data(), n * 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));
   }
-  size_t allgather_recs(const DeltaRec *send, size_t n_local, DeltaRec *recv, size_t cap, hipStream_t st) override {
-    h_send.resize(n_local * sizeof(DeltaRec) + 1);
-    if (n_local) HIP_CHECK(hipMemcpyAsync(h_send.data(), send, n_local * sizeof(DeltaRec), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    h_recv.resize(cap * sizeof(DeltaRec) + 1);
+  // the others' byte strings back to back, in rank order, through the application's callback
+  bool gather_others(const void *send, size_t nbytes, size_t cap_bytes, unsigned long long *got) {
+    h_recv.resize(cap_bytes + 1);
+    if (allgather(user, send, nbytes, h_recv.data(), cap_bytes, got) != 0) throw GpuError{"allgather callback failed"};
+    return *got <= cap_bytes;
+  }
+  bool allgather_recs(const DeltaRec *send, unsigned long long n_local, DeltaRec *recv, size_t cap, hipStream_t st, unsigned long long *need_all,
+                      size_t *n_remote) override {
+    // counts first (8 bytes per rank), so that every rank takes the same branch
     unsigned long long got = 0;
-    // the callback returns the concatenated bytes of all OTHER ranks
-    if (allgather(user, h_send.data(), n_local * sizeof(DeltaRec), h_recv.data(), cap * sizeof(DeltaRec), &got) != 0)
-      throw GpuError{"allgather callback failed"};
-    size_t n = (size_t)(got / sizeof(DeltaRec));
-    if (n > cap) return n;
-    if (n) HIP_CHECK(hipMemcpyAsync(recv, h_recv.data(), n * sizeof(DeltaRec), hipMemcpyHostToDevice, st));
+    gather_others(&n_local, 8, 8 * (size_t)world, &got);
+    unsigned long long all = n_local;
+    bool lost = n_local == ~0ull;
+    for (size_t k = 0; k < got / 8; k++) {
+      unsigned long long c;
+      memcpy(&c, h_recv.data() + 8 * k, 8);
+      if (c == ~0ull) lost = true;
+      all += c;
+    }
+    if (lost) { *need_all = ~0ull; return false; }
+    *need_all = all;
+    *n_remote = (size_t)(all - n_local);
+    if (all > cap) return false;
+    h_send.resize((size_t)n_local * sizeof(DeltaRec) + 1);
+    if (n_local) HIP_CHECK(hipMemcpyAsync(h_send.data(), send, (size_t)n_local * sizeof(DeltaRec), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    return n;
+    if (!gather_others(h_send.data(), (size_t)n_local * sizeof(DeltaRec), cap * sizeof(DeltaRec), &got)) throw GpuError{"allgather callback overflow"};
+    if (got) HIP_CHECK(hipMemcpyAsync(recv, h_recv.data(), (size_t)got, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    return true;
+  }
+  void allgather_blocks(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) override {
+    h_send.resize(bytes_per_rank);
+    HIP_CHECK(hipMemcpyAsync(h_send.data(), send, bytes_per_rank, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    unsigned long long got = 0;
+    if (!gather_others(h_send.data(), bytes_per_rank, bytes_per_rank * (size_t)world, &got) || got != bytes_per_rank * (size_t)(world - 1))
+      throw GpuError{"allgather callback returned the wrong size"};
+    size_t src = 0;
+    for (int r = 0; r < world; r++) {
+      if (r == rank) {
+        HIP_CHECK(hipMemcpyAsync((char *)recv + (size_t)r * bytes_per_rank, send, bytes_per_rank, hipMemcpyDeviceToDevice, st));
+      } else {
+        HIP_CHECK(hipMemcpyAsync((char *)recv + (size_t)r * bytes_per_rank, h_recv.data() + src, bytes_per_rank, hipMemcpyHostToDevice, st));
+        src += bytes_per_rank;
+      }
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
   }
 };
 
@@ -82,7 +116,7 @@ int yttm_train_bpe_from_device_comm(const void *d_text, uint64_t n, const char *
                                     int report_len, char *err, int errlen) {
   TrainReport rep;
   Status s = train_bpe_from_device(d_text, n, model_path ? model_path : "", vocab_size, make_cfg(coverage, pad_id, unk_id, bos_id, eos_id), device,
-                                   &rep, (Comm *)comm, profile != 0);
+                                   &rep, (Comm *)comm, profile);
   if (s.ok()) yttm_report_to_json(rep, report_json, report_len);
   else put_err(err, errlen, s.message);
   return s.code;

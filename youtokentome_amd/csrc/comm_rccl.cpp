@@ -35,16 +35,29 @@ struct RcclComm : Comm {
     NCCL_CHECK(ncclAllReduce(dev, dev, n, ncclUint64, ncclSum, comm, st));
     HIP_CHECK(hipStreamSynchronize(st));
   }
-  size_t allgather_recs(const DeltaRec *send, size_t n_local, DeltaRec *recv, size_t cap, hipStream_t st) override {
+  void allreduce_sum_u64_async(unsigned long long *dev, size_t n, hipStream_t st) override {
+    NCCL_CHECK(ncclAllReduce(dev, dev, n, ncclUint64, ncclSum, comm, st));
+  }
+  void allgather_blocks(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) override {
+    NCCL_CHECK(ncclAllGather(send, recv, bytes_per_rank / 8, ncclUint64, comm, st));
+  }
+  bool allgather_recs(const DeltaRec *send, unsigned long long n_local, DeltaRec *recv, size_t cap, hipStream_t st, unsigned long long *need_all,
+                      size_t *n_remote) override {
     unsigned long long mine = n_local;
     HIP_CHECK(hipMemcpyAsync(d_counts + rank, &mine, 8, hipMemcpyHostToDevice, st));
     NCCL_CHECK(ncclAllGather(d_counts + rank, d_counts, 1, ncclUint64, comm, st));
     HIP_CHECK(hipMemcpyAsync(h_counts.data(), d_counts, 8 * (size_t)world, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    size_t total = 0;
-    for (int r = 0; r < world; r++)
-      if (r != rank) total += (size_t)h_counts[r];
-    if (total > cap) return total;  // caller reports the overflow
+    unsigned long long all = 0;
+    size_t others = 0;
+    for (int r = 0; r < world; r++) {
+      if (h_counts[r] == ~0ull) { *need_all = ~0ull; return false; }
+      all += h_counts[r];
+      if (r != rank) others += (size_t)h_counts[r];
+    }
+    *need_all = all;
+    *n_remote = others;
+    if (all > cap) return false;  // (the same verdict on every rank: `all` and the agreed capacity are)
     NCCL_CHECK(ncclGroupStart());
     size_t off = 0;
     for (int r = 0; r < world; r++) {
@@ -54,7 +67,7 @@ struct RcclComm : Comm {
       off += (size_t)h_counts[r];
     }
     NCCL_CHECK(ncclGroupEnd());
-    return total;
+    return true;
   }
 };
 

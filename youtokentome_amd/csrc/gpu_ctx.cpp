@@ -10,6 +10,9 @@
 #include <mutex>
 #include <map>
 #include <atomic>
+#include <functional>
+#include <thread>
+#include <unistd.h>
 
 namespace yttm {
 
@@ -104,7 +107,9 @@ void pool_quiesce(hipStream_t st) {  // the stream was synchronised: its blocks 
     if (kv.second.owner == st) kv.second.owner = nullptr;
 }
 }  // namespace
+static void release_io_stage();
 void release_device_memory() {
+  release_io_stage();
   std::lock_guard<std::mutex> g(g_pool.mu);
   if (g_pin_cached) {
     (void)hipHostFree(g_pin_cached);
@@ -188,8 +193,8 @@ GpuCtx::~GpuCtx() {
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_); DFREE(d_flagbits_);
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_);
-  DFREE(db_.recs);
-  DFREE(db_.n);
+  DFREE(d_send_); DFREE(d_xstat_);
+  db_.recs = nullptr; db_.n = nullptr;
   free_table(pt_);
   pool_quiesce(st_);
   if (h_pin_) {
@@ -257,6 +262,10 @@ void GpuCtx::resolve_timers() {
     if (hipMemcpy(st, d_stats_, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
       merge_sites = st[0];
       kt.bytes[KT_MERGE] = 4 * st[2] + 8 * st[3];
+      touched_tiles = st[1];
+      touched_tile_tokens = st[3];
+      touched_words = st[4];
+      touched_word_tokens = st[5];
     }
   }
   FILE *trace = getenv("YTTM_TRACE") ? fopen(getenv("YTTM_TRACE"), "w") : nullptr;  // per-launch times for tuning
@@ -277,17 +286,136 @@ void GpuCtx::resolve_timers() {
 
 // ------------------------------------------------------------------------------------------------- corpus
 void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
+  if (n < (32u << 20) || getenv("YTTM_PLAIN_UPLOAD")) {  // small, or (tuning hook) the one-copy path for comparison
+    HIP_CHECK(hipSetDevice(device_));
+    tl_stream = st_;
+    tl_device = device_;
+    DFREE(d_text_owned_);
+    d_text_owned_ = dmalloc<uint8_t>(n + 64);
+    if (n) HIP_CHECK(hipMemcpyAsync(d_text_owned_, host, n, hipMemcpyHostToDevice, st_));
+    sync();
+    d_text_ = d_text_owned_;
+    n_text_ = n;
+    corpus_bytes = n;
+    return;
+  }
+  upload_staged(n, [&](void *dst, unsigned long long off, size_t len) {
+    memcpy(dst, host + off, len);
+    return true;
+  });
+}
+// ---- staged upload: file (or host memory) -> pinned chunks -> HBM -----------------------------------------------------
+// fast_read_file_utf8 (bpe.cpp:67-84) reads the file into one std::string; here the bytes only pass through the host.
+// A single hipMemcpy from pageable memory (an mmap of the file, a Python bytes object) is staged by the runtime through
+// one internal buffer on one thread; instead IO_THREADS workers each own two pinned chunks, fill one (pread from the page
+// cache / memcpy) while the other is on its way over PCIe on the worker's own stream.  The pinned chunks are kept for the
+// next call (pinning 128 MB costs tens of milliseconds).
+namespace {
+constexpr size_t IO_CHUNK = 8u << 20;
+constexpr int IO_MAX_THREADS = 8;
+struct IoStage {
+  std::mutex mu;
+  void *pin[2 * IO_MAX_THREADS] = {nullptr};
+  bool busy = false;
+} g_io;
+}  // namespace
+
+static void release_io_stage() {
+  std::lock_guard<std::mutex> g(g_io.mu);
+  if (g_io.busy) return;
+  for (void *&p : g_io.pin) {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+  }
+}
+
+void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *dst, unsigned long long off, size_t len)> &fill) {
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
   DFREE(d_text_owned_);
   d_text_owned_ = dmalloc<uint8_t>(n + 64);
-  if (n) HIP_CHECK(hipMemcpyAsync(d_text_owned_, host, n, hipMemcpyHostToDevice, st_));
-  sync();
   d_text_ = d_text_owned_;
   n_text_ = n;
   corpus_bytes = n;
+  if (!n) return;
+  const size_t n_chunks = (size_t)((n + IO_CHUNK - 1) / IO_CHUNK);
+  int n_threads = (int)env_uint("YTTM_IO_THREADS", 0);
+  if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), (unsigned)IO_MAX_THREADS));
+  n_threads = (int)std::min<size_t>((size_t)std::min(n_threads, IO_MAX_THREADS), n_chunks);
+  bool mine = false;
+  {
+    std::lock_guard<std::mutex> g(g_io.mu);
+    if (!g_io.busy) { g_io.busy = true; mine = true; }
+  }
+  if (!mine) {  // another context of this process is uploading through the shared chunks: plain copies for this one
+    std::vector<uint8_t> tmp(IO_CHUNK);
+    for (size_t c = 0; c < n_chunks; c++) {
+      const unsigned long long off = (unsigned long long)c * IO_CHUNK;
+      const size_t len = (size_t)std::min<unsigned long long>(IO_CHUNK, n - off);
+      if (!fill(tmp.data(), off, len)) throw GpuError{"corpus read failed"};
+      HIP_CHECK(hipMemcpy(d_text_owned_ + off, tmp.data(), len, hipMemcpyHostToDevice));
+    }
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::atomic<int> failed{0};
+  std::string first_error;
+  std::mutex err_mu;
+  auto worker = [&](int w) {
+    try {
+      HIP_CHECK(hipSetDevice(device_));
+      hipStream_t cs = nullptr;
+      HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+      hipEvent_t ev[2] = {nullptr, nullptr};
+      bool used[2] = {false, false};
+      for (int k = 0; k < 2; k++) {
+        HIP_CHECK(hipEventCreate(&ev[k]));
+        if (!g_io.pin[2 * w + k]) HIP_CHECK(hipHostMalloc(&g_io.pin[2 * w + k], IO_CHUNK, hipHostMallocDefault));
+      }
+      for (int k = 0;; k ^= 1) {
+        const size_t c = next.fetch_add(1);
+        if (c >= n_chunks || failed.load()) break;
+        const unsigned long long off = (unsigned long long)c * IO_CHUNK;
+        const size_t len = (size_t)std::min<unsigned long long>(IO_CHUNK, n - off);
+        if (used[k]) HIP_CHECK(hipEventSynchronize(ev[k]));  // the chunk's previous copy has left the buffer
+        if (!fill(g_io.pin[2 * w + k], off, len)) throw GpuError{"corpus read failed"};
+        HIP_CHECK(hipMemcpyAsync(d_text_owned_ + off, g_io.pin[2 * w + k], len, hipMemcpyHostToDevice, cs));
+        HIP_CHECK(hipEventRecord(ev[k], cs));
+        used[k] = true;
+      }
+      HIP_CHECK(hipStreamSynchronize(cs));
+      for (int k = 0; k < 2; k++) (void)hipEventDestroy(ev[k]);
+      (void)hipStreamDestroy(cs);
+    } catch (const GpuError &e) {
+      failed.store(1);
+      std::lock_guard<std::mutex> g(err_mu);
+      if (first_error.empty()) first_error = e.msg;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int w = 1; w < n_threads; w++) th.emplace_back(worker, w);
+  worker(0);
+  for (auto &t : th) t.join();
+  {
+    std::lock_guard<std::mutex> g(g_io.mu);
+    g_io.busy = false;
+  }
+  if (failed.load()) throw GpuError{first_error};
 }
+
+void GpuCtx::upload_corpus_fd(int fd, unsigned long long lo, unsigned long long n) {
+  upload_staged(n, [&](void *dst, unsigned long long off, size_t len) {
+    size_t got = 0;
+    while (got < len) {
+      const ssize_t r = pread(fd, (char *)dst + got, len - got, (off_t)(lo + off + got));
+      if (r <= 0) return false;
+      got += (size_t)r;
+    }
+    return true;
+  });
+}
+
 void GpuCtx::attach_corpus(const void *dev, unsigned long long n) {
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
@@ -314,7 +442,7 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
   HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 16, hipMemcpyDeviceToHost, st_));
   sync();
   n_segments = h_cnt[1];  // local segments (before any cross-rank reduction)
-  if (comm_ && comm_->world > 1) {
+  if (multi()) {
     comm_->allreduce_sum_u64(d_hist_, N_CODEPOINTS, st_);
     comm_->allreduce_sum_u64(d_counters_, 1, st_);
     HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 8, hipMemcpyDeviceToHost, st_));
@@ -578,8 +706,18 @@ void GpuCtx::ensure_table_capacity(unsigned long long need_keys) {
   n_keys_host = nk;
 }
 
+void GpuCtx::grow_recv(unsigned long long need) {
+  if (need <= recv_cap_) return;
+  DFREE(d_recv_);
+  recv_cap_ = need + need / 4 + 1024;
+  d_recv_ = dmalloc<DeltaRec>(recv_cap_);
+}
+
+// Set-up exchange (after K3, once per training): every rank's records, however many.  The counts travel first, so buffers
+// grow before anything is received and the verdicts (fits / overflow) are the same on every rank: nobody is left waiting in a
+// collective the others never posted.
 void GpuCtx::exchange_deltas() {
-  if (!comm_ || comm_->world <= 1) return;
+  if (!multi()) return;
   chain_event_ = nullptr;
   launch_fold_stats(d_stats_, pt_.n_keys, st_);  // the apply kernels leave their slot counts in per-workgroup rows
   unsigned long long n_local = 0;
@@ -588,9 +726,15 @@ void GpuCtx::exchange_deltas() {
   HIP_CHECK(hipMemcpyAsync(&nk_local, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
   sync();
   n_keys_host = nk_local;
-  if (n_local > db_.cap) throw GpuError{"delta exchange buffer overflow"};
-  size_t n_remote = comm_->allgather_recs(db_.recs, (size_t)n_local, d_recv_, (size_t)recv_cap_, st_);
-  if (n_remote > recv_cap_) throw GpuError{"delta receive buffer overflow"};
+  const unsigned long long mine = n_local > db_.cap ? ~0ull : n_local;
+  size_t n_remote = 0;
+  for (int attempt = 0;; attempt++) {
+    unsigned long long need_all = 0;
+    if (comm_->allgather_recs(db_.recs, mine, d_recv_, (size_t)recv_cap_, st_, &need_all, &n_remote)) break;
+    if (need_all == ~0ull) throw GpuError{"delta exchange buffer overflow (on some rank)"};
+    if (attempt) throw GpuError{"delta receive buffer could not be sized"};
+    grow_recv(need_all);
+  }
   ensure_table_capacity(n_keys_host + n_remote);
   launch_pt_apply(pt_, d_recv_, n_remote, st_);
   HIP_CHECK(hipMemsetAsync(db_.n, 0, 8, st_));
@@ -598,6 +742,16 @@ void GpuCtx::exchange_deltas() {
   HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
   sync();
   n_keys_host = nk;
+}
+
+// Per-round exchange: the first blk_ units (header + records) of every rank's send buffer are all-gathered and folded in by one
+// kernel that reads the counts on the device -- no copy to the host, no synchronisation.  What does not fit is reported through
+// the mailbox of the candidate scan that follows (candidates()), which repeats the exchange with larger blocks.
+void GpuCtx::exchange_round(unsigned long long only_mask) {
+  chain_event_ = nullptr;
+  grow_recv(blk_ * (unsigned long long)comm_->world);
+  comm_->allgather_blocks(d_send_, d_recv_, (size_t)blk_ * sizeof(DeltaRec), st_);
+  launch_pt_apply_blocks(pt_, d_recv_, blk_, comm_->world, comm_->rank, only_mask, d_xstat_, st_);
 }
 
 void GpuCtx::pair_count() {
@@ -610,23 +764,29 @@ void GpuCtx::pair_count() {
   // distinct initial pairs <= number of adjacencies <= tokens
   unsigned long long bound = std::min<unsigned long long>(n_tokens0 + 16, ((unsigned long long)n_alpha_ + 1) * (n_alpha_ + 1));
   bound = std::min<unsigned long long>(bound, 1ull << 26);
-  if (comm_ && comm_->world > 1) {
+  if (multi()) {
     bound = std::min<unsigned long long>(bound * comm_->world, 1ull << 27);
-    if (!db_.recs) {
+    if (!d_send_) {
       // worst case: every live token emits a handful of records in one pass
       db_.cap = std::max<unsigned long long>(1ull << 20, 5 * n_tokens0 + 1024);
-      db_.recs = dmalloc<DeltaRec>(db_.cap);
-      db_.n = dmalloc<unsigned long long>(2);
-      HIP_CHECK(hipMemsetAsync(db_.n, 0, 16, st_));
-      recv_cap_ = db_.cap * (unsigned long long)comm_->world;
-      d_recv_ = dmalloc<DeltaRec>(recv_cap_);
+      d_send_ = dmalloc<DeltaRec>(db_.cap + 1);
+      db_.recs = d_send_ + 1;
+      db_.n = reinterpret_cast<unsigned long long *>(d_send_);  // the count is the header of the block that travels
+      const DeltaRec hdr{0ull, (long long)db_.cap};  // {records, capacity}: the peers check the one against the other
+      HIP_CHECK(hipMemcpyAsync(d_send_, &hdr, sizeof hdr, hipMemcpyHostToDevice, st_));
+      sync();
+      d_xstat_ = dmalloc<unsigned long long>(4);
+      HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, st_));
+      blk_min_ = std::max(2u, env_uint("YTTM_XCHG_BLK_MIN", 4096));  // (tests shrink it to force the repeat path)
+      blk_ = blk_min_;
+      grow_recv(std::max<unsigned long long>(db_.cap, blk_ * (unsigned long long)comm_->world));
     }
   }
   // The candidate filter no longer streams the table, so its size costs nothing per round, while every growth step is a
   // rehash plus a hot-list rebuild: start at the size a corpus of this many tokens typically ends with.
   {
     unsigned long long guess = n_tokens0 / 16;  // keys; the table holds them at load <= 1/2
-    if (comm_ && comm_->world > 1) guess *= (unsigned long long)comm_->world;
+    if (multi()) guess *= (unsigned long long)comm_->world;
     bound = std::max(bound, std::min<unsigned long long>(guess, 1ull << 25));
   }
   ensure_table_capacity(bound);
@@ -716,6 +876,31 @@ void GpuCtx::rebuild_hot() {
   hot_state_ = HOT_ACTIVE;
 }
 
+// multi-GPU: what the fold kernel of this round's exchange reported (ranks whose block was too small, the largest record count,
+// "a rank lost records").  Repeats the exchange for the skipped ranks with blocks that fit, and sizes the next round's blocks --
+// from numbers that are the same on every rank.  True if the table changed (a scan made before that is stale).
+bool GpuCtx::settle_exchange(unsigned long long xmask, unsigned long long xmax, unsigned long long fatal) {
+  if (fatal) throw GpuError{"delta exchange buffer overflow (on some rank)"};
+  unsigned long long want = blk_min_;  // next round: twice what the busiest rank sent this round
+  while (want < 2 * xmax + 2) want <<= 1;
+  if (!xmask) {
+    if (xmax) blk_ = want;  // (xmax == 0: nothing was exchanged since the last verdict)
+    return false;
+  }
+  blk_ = blk_min_;
+  while (blk_ < xmax + 1) blk_ <<= 1;
+  exchange_round(xmask);
+  {  // that fold's own report (same blocks, so nothing new): consumed here
+    HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, st_));
+  }
+  blk_ = std::max(blk_, want);
+  exchange_retries++;
+  // the scan that came too early also zeroed the finished batch's pairs; deltas that arrived after that (k_giant.hip retracts
+  // every old adjacency of a re-counted tile, the merged pairs included) must be zeroed again
+  pending_zero_ = zero_valid_;
+  return true;
+}
+
 uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist) {
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
@@ -726,6 +911,15 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     return 0;
   }
   for (int attempt = 0;; attempt++) {
+    if (multi() && hot_state_ != HOT_ACTIVE) {
+      // whole-table scans ahead (list rebuild, or no list at all): they synchronise anyway, so the verdict of this round's
+      // exchange is fetched directly instead of travelling with the mailbox
+      unsigned long long x[4] = {0, 0, 0, 0};
+      HIP_CHECK(hipMemcpyAsync(x, d_xstat_, 32, hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, st_));
+      sync();
+      settle_exchange(x[0], x[1], x[3]);
+    }
     if (hot_state_ == HOT_FULLSCAN && ++fullscan_rounds_ >= 64) hot_state_ = HOT_INVALID;  // ties may have dissolved
     if (hot_state_ == HOT_INVALID) rebuild_hot();
     if (hot_state_ == HOT_FULLSCAN) return scan_full(tau_cnt, tau_mx, out, hist);
@@ -741,7 +935,13 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     t_begin(KT_CAND);
     launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_,
                     pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, listed_last_ ? listed_last_ + 4096 : hot_cap_,
-                    pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, st_);
+                    pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, multi() ? d_xstat_ : nullptr, st_);
+    if (multi()) {
+      // how many slots a rank's order of updates happened to put on its hot list -- and so whether the list overflowed -- is the
+      // one rank-dependent quantity of a round: the verdicts are summed in stream order, then one workgroup publishes
+      comm_->allreduce_sum_u64_async(d_xstat_ + 2, 1, st_);
+      launch_publish(pt_, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_, d_xstat_, st_);
+    }
     pending_zero_ = false;
     t_end(KT_CAND, 20ull * listed_last_);  // (not chained: the host round trip that follows belongs to no kernel family)
     {
@@ -775,20 +975,18 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     n_keys_host = hdr[1];
     listed_last_ = std::min(listed, hot_cap_);
     unsigned long long overflow = listed > hot_cap_ ? 1 : 0;
-    if (comm_ && comm_->world > 1) {
-      // how many slots were listed depends on the order in which a rank applied its deltas: agree on the overflow verdict
-      // (everything else the decision uses -- live, hot_tau, n_keys -- is the same on every rank)
-      unsigned long long *d_flag = (unsigned long long *)(d_hot_n_ + 2);
-      HIP_CHECK(hipMemcpyAsync(d_flag, &overflow, 8, hipMemcpyHostToDevice, st_));
-      comm_->allreduce_sum_u64(d_flag, 1, st_);
-      HIP_CHECK(hipMemcpyAsync(&overflow, d_flag, 8, hipMemcpyDeviceToHost, st_));
-      sync();
+    if (multi()) {
+      overflow = *(const unsigned long long *)(h + 72);  // ranks whose list overflowed
+      if (settle_exchange(*(const unsigned long long *)(h + 56), *(const unsigned long long *)(h + 64), *(const unsigned long long *)(h + 80))) {
+        attempt--;  // the table was completed: scan again
+        continue;
+      }
     }
     if (attempt < 2 && (overflow || (live < hot_min_ && pt_.hot_tau > 1))) {
       hot_state_ = HOT_INVALID;  // overflowed, or running dry: relist with a new threshold
       continue;
     }
-    if (hist) memcpy(hist, h + 64, CAND_BINS * 8);
+    if (hist) memcpy(hist, h + MB_HIST, CAND_BINS * 8);
     const unsigned int take = std::min(n, cand_cap_);
     CandRec *h_c = (CandRec *)(h + 8192);
     if (take > CAND_FAST) {
@@ -818,7 +1016,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   tl_stream = st_;
   tl_device = device_;
   if (!k) return;
-  if (!n_tiles && !(comm_ && comm_->world > 1)) return;  // a rank without words still takes part in the exchange
+  if (!n_tiles && !multi()) return;  // a rank without words still takes part in the exchange
   if (k > RULES_CAP / 2) throw GpuError{"merge_apply: batch too large"};
   // new pairs this round: every site adds <= 2 neighbours (+ the z,z run pair); distinct new keys per rule are also
   // bounded by the number of live token types on either side
@@ -888,6 +1086,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     return cls_[ci].n_tiles <= 8192 || (touched_last_ != (~0ull >> 2) && touched_last_ * 100 >= (unsigned long long)n_tiles * (unsigned long long)dense_pct);
   };
   BatchArgs ba{};
+  ba.instr = instrument ? 1u : 0u;
   const bool by_args = k <= (uint32_t)BATCH_ARGS_MAX && vmax < FLAG_LDS_IDS && !cls_[2].n_tiles && (!cls_[0].n_tiles || dense_class(0)) &&
                        (!cls_[1].n_tiles || dense_class(1)) && !getenv("YTTM_NO_BATCH_ARGS");
   max_id_ = std::max(max_id_, vmax);
@@ -898,6 +1097,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   } else {
     prev_flag_toks_.swap(now);
   }
+  if (multi()) HIP_CHECK(hipMemsetAsync(db_.n, 0, 8, st_));  // this round's records start at the head of the send block
   t_begin(KT_MERGE);
   if (!by_args)
     launch_round_begin(h_rules, cap, d_rules_, h_upd, n_upd, d_tokflag_, d_flagbits_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr,
@@ -906,7 +1106,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     if (!cls_[ci].n_tiles) continue;
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
                        cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/by_args || dense_class(ci),
-                       by_args ? &ba : nullptr, st_);
+                       &ba, st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
   t_end(KT_MERGE, 0, /*chain=*/true);
@@ -935,6 +1135,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     }
   }
   pending_zero_ = true;
+  zero_valid_ = true;
   zero_ba_ = ba;
   zero_cap_ = cap;
   zero_self_key_ = self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY;
@@ -950,7 +1151,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     rounds_since_check_ = 0;
     for (int ci = 0; ci < 2; ci++) maybe_repack(ci);
   }
-  if (comm_ && comm_->world > 1) exchange_deltas();  // (reads this rank's key count back together with its record count)
+  if (multi()) exchange_round(0);  // (stream-ordered; the candidate scan that follows reports blocks that were too small)
   // single GPU: no sync here -- the candidate filter that always follows reads n_keys back together with its results
   // (its sync also makes the pinned rule staging reusable for the next round)
   // every occurrence of the batch's pairs has been merged (on every rank): their counts are exactly zero.  The candidate

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -20,11 +21,19 @@ struct GpuError {
 struct Comm {
   int rank = 0, world = 1;
   virtual ~Comm() {}
+  // ---- set-up path (once per training; may synchronise the stream)
   // in-place sum of n uint64 values living in device memory
   virtual void allreduce_sum_u64(unsigned long long *dev, size_t n, hipStream_t st) = 0;
-  // every rank contributes n_local records; recv (device, capacity cap records) receives the records of all OTHER ranks
-  // back to back; returns their total number
-  virtual size_t allgather_recs(const DeltaRec *send, size_t n_local, DeltaRec *recv, size_t cap, hipStream_t st) = 0;
+  // every rank contributes n_local records (~0: "my send buffer overflowed"); recv (device, capacity cap records) receives the
+  // records of all OTHER ranks back to back.  *need_all = records of ALL ranks -- the same number on every rank -- or ~0 if
+  // some rank reported an overflow.  If it does not fit `cap` nothing is transferred (every rank takes that branch together)
+  // and false is returned; the caller grows its buffer and calls again.
+  virtual bool allgather_recs(const DeltaRec *send, unsigned long long n_local, DeltaRec *recv, size_t cap, hipStream_t st,
+                              unsigned long long *need_all, size_t *n_remote) = 0;
+  // ---- per-round path: stream-ordered, NO host synchronisation
+  // block r of recv (bytes_per_rank each, every rank's including this one's) = rank r's send block
+  virtual void allgather_blocks(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) = 0;
+  virtual void allreduce_sum_u64_async(unsigned long long *dev, size_t n, hipStream_t st) { allreduce_sum_u64(dev, n, st); }
 };
 
 // returns the device (and pinned) memory cached by finished contexts to the driver
@@ -45,6 +54,8 @@ class GpuCtx {
   // ---- corpus
   void upload_corpus(const uint8_t *host, unsigned long long n);
   void attach_corpus(const void *dev, unsigned long long n);
+  // bytes [lo, lo + n) of an open file, through pinned chunks filled by several host threads (gpu_ctx.cpp: upload_staged)
+  void upload_corpus_fd(int fd, unsigned long long lo, unsigned long long n);
 
   // ---- K1
   void char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long long> &cnts, unsigned long long &n_codepoints);
@@ -64,7 +75,7 @@ class GpuCtx {
   // the same over the whole table (one streaming pass)
   uint32_t scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist);
   unsigned long long hot_tau() const { return hot_state_ == HOT_ACTIVE ? pt_.hot_tau : 1; }
-  unsigned long long hot_rebuilds = 0, rehashes = 0;
+  unsigned long long hot_rebuilds = 0, rehashes = 0, exchange_retries = 0;
   unsigned long long table_capacity() const { return pt_cap_; }
 
   void sync();
@@ -79,9 +90,14 @@ class GpuCtx {
   bool profile = false;
   KernelTimes kt;
   unsigned long long merge_sites = 0, merge_rounds = 0, repacks = 0;
+  // K4 totals over the training: tiles that held a site and their tokens; with `instrument` (a measurement pass, never the
+  // timed one) also the WORDS that held a site and their tokens = W_touched / T_touched of SURVEY.md 8d
+  unsigned long long touched_tiles = 0, touched_tile_tokens = 0, touched_words = 0, touched_word_tokens = 0;
+  bool instrument = false;
   void resolve_timers();
 
  private:
+  void upload_staged(unsigned long long n, const std::function<bool(void *dst, unsigned long long off, size_t len)> &fill);
   void ensure_table_capacity(unsigned long long need_keys);
   void rebuild_hot();
   enum HotState { HOT_INVALID, HOT_ACTIVE, HOT_FULLSCAN };
@@ -128,7 +144,7 @@ class GpuCtx {
   void build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, unsigned int U, uint32_t space_id);
   void maybe_repack(int ci);
   unsigned long long rounds_since_check_ = 0;
-  bool pending_zero_ = false;
+  bool pending_zero_ = false, zero_valid_ = false;  // valid: the zero_* members still describe the last batch
   void flush_pending_zero();
   unsigned int zero_cap_ = 0;
   BatchArgs zero_ba_{};  // the batch whose pairs are still to be zeroed, when it travelled as a kernel argument
@@ -153,10 +169,16 @@ class GpuCtx {
   unsigned int cand_cap_ = 0;
   unsigned int *d_cand_n_ = nullptr;
   unsigned long long *d_cand_hist_ = nullptr;
-  // multi-GPU delta exchange
+  // multi-GPU delta exchange.  d_send_ = { header: record count, - } followed by the records the kernels append (db_ points
+  // into it); per round the first blk_ 16-byte units of every rank's d_send_ are all-gathered into d_recv_
   DeltaBuf db_{};
-  DeltaRec *d_recv_ = nullptr;
-  unsigned long long recv_cap_ = 0;
+  DeltaRec *d_send_ = nullptr, *d_recv_ = nullptr;
+  unsigned long long recv_cap_ = 0, blk_ = 4096, blk_min_ = 4096;
+  unsigned long long *d_xstat_ = nullptr;  // [0] ranks whose block overflowed, [1] largest count, [2] hot-list overflow verdicts
+  bool multi() const { return comm_ != nullptr; }  // (a communicator of world size 1 still runs the whole exchange path)
+  void exchange_round(unsigned long long only_mask);
+  bool settle_exchange(unsigned long long xmask, unsigned long long xmax, unsigned long long fatal);
+  void grow_recv(unsigned long long need);
 
   struct Ev { hipEvent_t a, b; int which; };
   std::vector<Ev> evs_;

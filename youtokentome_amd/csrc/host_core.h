@@ -57,8 +57,10 @@ void compute_alphabet(const std::vector<uint32_t> &cps, const std::vector<unsign
 Status check_config(BpeConfig &cfg, int vocab_size);  // bpe.cpp:1295-1350
 
 struct TrainReport {
-  double seconds_total = 0, seconds_frontend = 0, seconds_merge = 0, seconds_io = 0;
+  double seconds_total = 0, seconds_frontend = 0, seconds_merge = 0, seconds_io = 0, seconds_upload = 0;  // upload: file/host -> HBM (train_bpe only)
   unsigned long long corpus_bytes = 0, n_unique = 0, n_tokens = 0, rounds = 0, rules = 0, cand_rescans = 0, repacks = 0, merge_sites = 0, hot_rebuilds = 0;
+  // K4 totals: tiles with a merge site and their tokens; words with a merge site and their tokens (measurement pass only, else 0)
+  unsigned long long touched_tiles = 0, touched_tile_tokens = 0, touched_words = 0, touched_word_tokens = 0;
   // per kernel family: ms, launches, algorithmic bytes (gpu_ctx.h KT_*)
   double kt_ms[8] = {0};
   unsigned long long kt_launches[8] = {0}, kt_bytes[8] = {0};
@@ -74,7 +76,7 @@ Status train_bpe(const std::string &input_path, const std::string &model_path, i
 Status train_bpe_from_memory(const uint8_t *text, unsigned long long n, const std::string &model_path, int vocab_size, BpeConfig cfg,
                              int device = 0, TrainReport *report = nullptr, Comm *comm = nullptr);
 Status train_bpe_from_device(const void *d_text, unsigned long long n, const std::string &model_path, int vocab_size, BpeConfig cfg,
-                             int device = 0, TrainReport *report = nullptr, Comm *comm = nullptr, bool profile = false);
+                             int device = 0, TrainReport *report = nullptr, Comm *comm = nullptr, int profile = 0 /* 1: HIP-event kernel times; 2: K4 measurement pass (touched words), never timed */);
 // learn_bpe_from_string (bpe.cpp:859-1293) on an attached corpus
 Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const BpeConfig &cfg, BPEState *state, TrainReport *report);
 
@@ -108,6 +110,11 @@ class BaseEncoder {  // bpe.h:22-82
   Status decode(const std::vector<int> &ids, std::string *sentence, const std::unordered_set<int> *ignore_ids) const;  // bpe.cpp:1843
   int vocab_size() const;                                                                 // bpe.cpp:1692
   std::vector<std::string> vocabulary() const;                                            // bpe.cpp:1884
+  // the streaming loops of the `yttm` command line (host_cli.cpp); the reference's read std::cin and write std::cout
+  Status encode_cli(const std::string &output_type, bool stream, bool bos, bool eos, bool reverse, double dropout_prob, int in_fd = 0,
+                    int out_fd = 1) const;                                                // bpe.h:66-68, bpe.cpp:1942-2014
+  Status decode_cli(const std::unordered_set<int> *ignore_ids, int in_fd = 0, int out_fd = 1) const;  // bpe.h:70, bpe.cpp:2016-2028
+  Status vocab_cli(bool verbose, int out_fd = 1) const;                                   // bpe.h:71, bpe.cpp:1896-1940
 
  private:
   void fill_from_state();  // bpe.cpp:1667-1690

@@ -5,6 +5,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <random>
 
 #include "gpu_ctx.h"
 #include "host_core.h"
@@ -20,17 +23,13 @@ static T *dalloc(size_t n) {
   return (T *)p;
 }
 
-struct EncoderDevice {
+// One batch in flight: a stream and the batch buffers, reused and grown on demand.  Two lanes per encoder, so that two host
+// threads (Python threads calling encode() on one BPE object -- ctypes releases the GIL, the reference's Cython binding did
+// not --, or the two workers of encode_cli) overlap their copies and kernels instead of racing on one set of buffers.
+struct EncodeLane {
+  std::mutex mu;  // held for the whole of upload -> encode -> fetch
   hipStream_t st = nullptr;
-  uint32_t *d_cpmap = nullptr;
-  RuleSlot *d_rules = nullptr;
-  uint32_t *d_rule_z = nullptr;
-  unsigned long long *d_rule_xy = nullptr;
-  uint32_t *d_bloom = nullptr;
   uint32_t *d_drop = nullptr; size_t cap_drop = 0;
-  unsigned long long dropout_calls = 0;
-  EncModel m{};
-  // reusable batch buffers (grown on demand)
   uint8_t *d_bytes = nullptr; size_t cap_bytes = 0;
   unsigned long long *d_off = nullptr; size_t cap_off = 0;
   int32_t *d_scratch = nullptr; size_t cap_scratch = 0;
@@ -51,11 +50,41 @@ struct EncoderDevice {
     p = dalloc<T>(c);
     cap = c;
   }
-  ~EncoderDevice() {
-    for (void *p : {(void *)d_cpmap, (void *)d_rules, (void *)d_rule_z, (void *)d_rule_xy, (void *)d_bloom, (void *)d_drop, (void *)d_bytes, (void *)d_off, (void *)d_scratch, (void *)d_counts,
-                    (void *)d_out_off, (void *)d_scan_tmp, (void *)d_total, (void *)d_ids, (void *)d_work})
+  ~EncodeLane() {
+    for (void *p : {(void *)d_drop, (void *)d_bytes, (void *)d_off, (void *)d_scratch, (void *)d_counts, (void *)d_out_off, (void *)d_scan_tmp,
+                    (void *)d_total, (void *)d_ids, (void *)d_work})
       if (p) (void)hipFree(p);
     if (st) (void)hipStreamDestroy(st);
+  }
+};
+
+struct EncoderDevice {
+  uint32_t *d_cpmap = nullptr;
+  RuleSlot *d_rules = nullptr;
+  uint32_t *d_rule_z = nullptr;
+  unsigned long long *d_rule_xy = nullptr;
+  uint32_t *d_bloom = nullptr;
+  EncModel m{};
+  // BPE-dropout draws: counter-based, seeded per call from a per-encoder random salt (the reference draws from a
+  // std::random_device-independent global mt19937, bpe.cpp:1415; YTTM_DROPOUT_SEED pins the salt for reproducible runs)
+  std::atomic<unsigned long long> dropout_calls{0};
+  unsigned long long seed_salt = 0;
+  static constexpr int N_LANES = 2;
+  EncodeLane lane[N_LANES];
+  std::atomic<unsigned int> next_lane{0};
+  // a free lane, locked (falls back to waiting for the caller's turn-based choice)
+  EncodeLane &acquire(std::unique_lock<std::mutex> &lk) {
+    for (int k = 0; k < N_LANES; k++) {
+      lk = std::unique_lock<std::mutex>(lane[k].mu, std::try_to_lock);
+      if (lk.owns_lock()) return lane[k];
+    }
+    EncodeLane &l = lane[next_lane.fetch_add(1) % N_LANES];
+    lk = std::unique_lock<std::mutex>(l.mu);
+    return l;
+  }
+  ~EncoderDevice() {
+    for (void *p : {(void *)d_cpmap, (void *)d_rules, (void *)d_rule_z, (void *)d_rule_xy, (void *)d_bloom})
+      if (p) (void)hipFree(p);
   }
 };
 
@@ -66,7 +95,16 @@ BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *
   try {
     HIP_CHECK(hipSetDevice(device_));
     dev_ = new EncoderDevice();
-    HIP_CHECK(hipStreamCreateWithFlags(&dev_->st, hipStreamNonBlocking));
+    for (EncodeLane &l : dev_->lane) {
+      HIP_CHECK(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+      l.d_total = dalloc<unsigned long long>(2);
+    }
+    if (const char *sv = getenv("YTTM_DROPOUT_SEED")) {
+      dev_->seed_salt = strtoull(sv, nullptr, 10);
+    } else {
+      std::random_device rd;
+      dev_->seed_salt = ((unsigned long long)rd() << 32) ^ (unsigned long long)rd();
+    }
     // code point -> final id / CP_SPACE / CP_UNK.  is_space wins over char2id (words are split first, bpe.cpp:1509-1510).
     std::vector<uint32_t> cpmap(N_CODEPOINTS, CP_UNK);
     for (auto &c : bpe_state.char2id)
@@ -115,7 +153,6 @@ BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *
     }
     dev_->d_bloom = dalloc<uint32_t>(ENC_BLOOM_WORDS);
     HIP_CHECK(hipMemcpy(dev_->d_bloom, bloom.data(), (size_t)ENC_BLOOM_WORDS * 4, hipMemcpyHostToDevice));
-    dev_->d_total = dalloc<unsigned long long>(2);
     EncModel &m = dev_->m;
     m.bloom = dev_->d_bloom;
     m.cpmap = dev_->d_cpmap;
@@ -176,16 +213,15 @@ int BaseEncoder::vocab_size() const {
   return (int)(bpe_state.rules.size() + bpe_state.char2id.size() + bpe_state.special_tokens.n_special_tokens());
 }
 
-Status BaseEncoder::encode_device(const void *d_bytes, const void *d_offsets, unsigned long long n_sent, unsigned long long total_bytes,
-                                  unsigned long long max_sentence_bytes, bool bos, bool eos, bool reverse, double dropout_prob,
-                                  unsigned long long *n_ids_out, double *kernel_ms) const {
+// K5 on one lane (locked by the caller): input already in HBM, ids + offsets left in the lane's buffers
+static Status encode_on_lane(const BaseEncoder &enc, EncoderDevice &D, EncodeLane &d, int device, const void *d_bytes, const void *d_offsets,
+                             unsigned long long n_sent, unsigned long long total_bytes, unsigned long long max_sentence_bytes, bool bos, bool eos,
+                             bool reverse, double dropout_prob, unsigned long long *n_ids_out, double *kernel_ms) {
   // bpe.cpp:1702-1707
-  if (bos && bpe_state.special_tokens.bos_id == -1) return Status(1, "Can't add <BOS> token. Model was trained without it.");
-  if (eos && bpe_state.special_tokens.eos_id == -1) return Status(1, "Can't add <EOS> token. Model was trained without it.");
-  if (!dev_) return Status(2, "encoder has no device state");
+  if (bos && enc.bpe_state.special_tokens.bos_id == -1) return Status(1, "Can't add <BOS> token. Model was trained without it.");
+  if (eos && enc.bpe_state.special_tokens.eos_id == -1) return Status(1, "Can't add <EOS> token. Model was trained without it.");
   try {
-    HIP_CHECK(hipSetDevice(device_));
-    EncoderDevice &d = *dev_;
+    HIP_CHECK(hipSetDevice(device));
     d.last_n_sent = n_sent;
     d.last_n_ids = 0;
     if (n_ids_out) *n_ids_out = 0;
@@ -217,14 +253,14 @@ Status BaseEncoder::encode_device(const void *d_bytes, const void *d_offsets, un
       drop_stride = tok_cap;
       d.grow(d.d_drop, d.cap_drop, (size_t)(7 * drop_stride * (unsigned long long)n_blocks * ENC_WAVES_PER_BLOCK));
     }
-    const unsigned long long seed = mix64(0x5bd1e995ull + (++d.dropout_calls));
+    const unsigned long long seed = mix64(D.seed_salt + 0x5bd1e995ull * (D.dropout_calls.fetch_add(1) + 1));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (kernel_ms) {
       HIP_CHECK(hipEventCreate(&e0));
       HIP_CHECK(hipEventCreate(&e1));
       HIP_CHECK(hipEventRecord(e0, d.st));
     }
-    launch_encode(d.m, (const uint8_t *)d_bytes, (const unsigned long long *)d_offsets, n_sent, bos, eos, reverse, d.d_scratch, d.d_counts,
+    launch_encode(D.m, (const uint8_t *)d_bytes, (const unsigned long long *)d_offsets, n_sent, bos, eos, reverse, d.d_scratch, d.d_counts,
                   d.d_work, stride, n_blocks, dropout_prob, seed, d.d_drop, drop_stride, d.st);
     if (kernel_ms) HIP_CHECK(hipEventRecord(e1, d.st));
     launch_exclusive_scan(d.d_counts, n_sent, d.d_out_off, d.d_scan_tmp, d.d_total, d.st);
@@ -250,18 +286,35 @@ Status BaseEncoder::encode_device(const void *d_bytes, const void *d_offsets, un
   return Status();
 }
 
-Status BaseEncoder::fetch_device_result(int32_t *ids, unsigned long long *out_off, unsigned long long n_sent) const {
-  if (!dev_ || n_sent != dev_->last_n_sent) return Status(2, "fetch_device_result: no matching result");
+static Status fetch_lane(EncodeLane &d, int device, int32_t *ids, unsigned long long *out_off, unsigned long long n_sent) {
   try {
-    HIP_CHECK(hipSetDevice(device_));
+    HIP_CHECK(hipSetDevice(device));
     if (n_sent == 0) { if (out_off) out_off[0] = 0; return Status(); }
-    if (ids && dev_->last_n_ids) HIP_CHECK(hipMemcpyAsync(ids, dev_->d_ids, (size_t)dev_->last_n_ids * 4, hipMemcpyDeviceToHost, dev_->st));
-    if (out_off) HIP_CHECK(hipMemcpyAsync(out_off, dev_->d_out_off, (size_t)(n_sent + 1) * 8, hipMemcpyDeviceToHost, dev_->st));
-    HIP_CHECK(hipStreamSynchronize(dev_->st));
+    if (ids && d.last_n_ids) HIP_CHECK(hipMemcpyAsync(ids, d.d_ids, (size_t)d.last_n_ids * 4, hipMemcpyDeviceToHost, d.st));
+    if (out_off) HIP_CHECK(hipMemcpyAsync(out_off, d.d_out_off, (size_t)(n_sent + 1) * 8, hipMemcpyDeviceToHost, d.st));
+    HIP_CHECK(hipStreamSynchronize(d.st));
   } catch (const GpuError &e) {
     return Status(2, "GPU error: " + e.msg);
   }
   return Status();
+}
+
+// The device-resident pair (what bench.py times): encode_device leaves its result in lane 0, fetch_device_result copies it
+// out.  Each call locks the lane; the PAIR is not atomic -- one host thread at a time may use these two on an encoder.
+Status BaseEncoder::encode_device(const void *d_bytes, const void *d_offsets, unsigned long long n_sent, unsigned long long total_bytes,
+                                  unsigned long long max_sentence_bytes, bool bos, bool eos, bool reverse, double dropout_prob,
+                                  unsigned long long *n_ids_out, double *kernel_ms) const {
+  if (!dev_) return Status(2, "encoder has no device state");
+  std::lock_guard<std::mutex> lk(dev_->lane[0].mu);
+  return encode_on_lane(*this, *dev_, dev_->lane[0], device_, d_bytes, d_offsets, n_sent, total_bytes, max_sentence_bytes, bos, eos, reverse,
+                        dropout_prob, n_ids_out, kernel_ms);
+}
+
+Status BaseEncoder::fetch_device_result(int32_t *ids, unsigned long long *out_off, unsigned long long n_sent) const {
+  if (!dev_) return Status(2, "fetch_device_result: no matching result");
+  std::lock_guard<std::mutex> lk(dev_->lane[0].mu);
+  if (n_sent != dev_->lane[0].last_n_sent) return Status(2, "fetch_device_result: no matching result");
+  return fetch_lane(dev_->lane[0], device_, ids, out_off, n_sent);
 }
 
 Status BaseEncoder::encode_as_ids(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,
@@ -274,9 +327,10 @@ Status BaseEncoder::encode_as_ids(const uint8_t *bytes, const unsigned long long
   if (!dev_) return Status(2, "encoder has no device state");
   unsigned long long total_bytes = offsets[n_sent] - offsets[0], max_len = 0;
   for (unsigned long long i = 0; i < n_sent; i++) max_len = std::max(max_len, offsets[i + 1] - offsets[i]);
+  std::unique_lock<std::mutex> lk;
+  EncodeLane &d = dev_->acquire(lk);  // held until the ids are back on the host
   try {
     HIP_CHECK(hipSetDevice(device_));
-    EncoderDevice &d = *dev_;
     d.grow(d.d_bytes, d.cap_bytes, (size_t)total_bytes + 16);
     d.grow(d.d_off, d.cap_off, (size_t)n_sent + 1);
     // offsets are rebased to the first byte of the batch
@@ -289,10 +343,10 @@ Status BaseEncoder::encode_as_ids(const uint8_t *bytes, const unsigned long long
     return Status(2, "GPU error: " + e.msg);
   }
   unsigned long long n_ids = 0;
-  Status s = encode_device(dev_->d_bytes, dev_->d_off, n_sent, total_bytes, max_len, bos, eos, reverse, dropout_prob, &n_ids, nullptr);
+  Status s = encode_on_lane(*this, *dev_, d, device_, d.d_bytes, d.d_off, n_sent, total_bytes, max_len, bos, eos, reverse, dropout_prob, &n_ids, nullptr);
   if (!s.ok()) return s;
   ids->resize((size_t)n_ids);
-  return fetch_device_result(ids->data(), out_off->data(), n_sent);
+  return fetch_lane(d, device_, ids->data(), out_off->data(), n_sent);
 }
 
 Status BaseEncoder::encode_as_subwords(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,

@@ -10,7 +10,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -240,6 +239,8 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     g.resolve_timers();
     rep->repacks = g.repacks;
     rep->merge_sites = g.merge_sites;
+    rep->touched_tiles = g.touched_tiles; rep->touched_tile_tokens = g.touched_tile_tokens;
+    rep->touched_words = g.touched_words; rep->touched_word_tokens = g.touched_word_tokens;
     for (int i = 0; i < 8; i++) { rep->kt_ms[i] = g.kt.ms[i]; rep->kt_launches[i] = g.kt.launches[i]; rep->kt_bytes[i] = g.kt.bytes[i]; }
   }
   return s;
@@ -265,12 +266,13 @@ static Status guarded(F &&f) {
 }
 
 Status train_bpe_from_device(const void *d_text, unsigned long long n, const std::string &model_path, int vocab_size, BpeConfig cfg,
-                             int device, TrainReport *report, Comm *comm, bool profile) {
+                             int device, TrainReport *report, Comm *comm, int profile) {
   Status st = check_config(cfg, vocab_size);
   if (!st.ok()) return st;
   return guarded([&]() {
     GpuCtx g(device);
     g.profile = profile && !getenv("YTTM_NO_PROFILE");  // (tuning hook: what do the timing events themselves cost?)
+    g.instrument = profile == 2;
     g.set_comm(comm);
     g.attach_corpus(d_text, n);
     return learn_bpe(g, vocab_size, model_path, cfg, nullptr, report);
@@ -299,12 +301,7 @@ Status train_bpe(const std::string &input_path, const std::string &model_path, i
   if (fd < 0) return Status(1, "Failed to open file: " + input_path);  // bpe.cpp:72
   struct stat sb;
   if (fstat(fd, &sb) != 0) { close(fd); return Status(1, "Failed to open file: " + input_path); }
-  unsigned long long size = (unsigned long long)sb.st_size;
-  const uint8_t *map = nullptr;
-  if (size) {
-    map = (const uint8_t *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    if (map == MAP_FAILED) { close(fd); return Status(1, "Failed to open file: " + input_path); }
-  }
+  const unsigned long long size = (unsigned long long)sb.st_size;
   // multi-GPU: each rank takes the byte range [size*r/W, size*(r+1)/W), advanced to the next ASCII space like the
   // reference's per-thread split (bpe.cpp:864-873)
   unsigned long long lo = 0, hi = size;
@@ -312,7 +309,14 @@ Status train_bpe(const std::string &input_path, const std::string &model_path, i
     auto split = [&](int i) {
       if (i == 0) return 0ull;  // split_pos[0] = 0 (bpe.cpp:865)
       unsigned long long c = size * (unsigned long long)i / (unsigned long long)comm->world;
-      while (c < size && !(map[c] == 32 || (map[c] >= 9 && map[c] <= 13))) c++;
+      uint8_t buf[4096];
+      while (c < size) {
+        const ssize_t got = pread(fd, buf, sizeof buf, (off_t)c);
+        if (got <= 0) return size;
+        for (ssize_t k = 0; k < got; k++)
+          if (buf[k] == 32 || (buf[k] >= 9 && buf[k] <= 13)) return c + (unsigned long long)k;
+        c += (unsigned long long)got;
+      }
       return c;
     };
     lo = split(comm->rank);
@@ -322,10 +326,13 @@ Status train_bpe(const std::string &input_path, const std::string &model_path, i
   Status r = guarded([&]() {
     GpuCtx g(device);
     g.set_comm(comm);
-    g.upload_corpus(map ? map + lo : nullptr, hi - lo);
-    return learn_bpe(g, vocab_size, model_path, cfg, nullptr, report);
+    const auto t_up = clk::now();
+    g.upload_corpus_fd(fd, lo, hi - lo);  // file -> pinned chunks -> HBM (replaces fast_read_file_utf8, bpe.cpp:67-84)
+    const double s_up = since(t_up);
+    Status st2 = learn_bpe(g, vocab_size, model_path, cfg, nullptr, report);
+    if (report) { report->seconds_upload = s_up; report->seconds_total += s_up; }
+    return st2;
   });
-  if (map) munmap((void *)map, size);
   close(fd);
   return r;
 }

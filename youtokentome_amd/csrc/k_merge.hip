@@ -52,7 +52,7 @@ struct AggLds {
   unsigned long long val[AGG_SLOTS];
   uint32_t flagbits[FLAG_LDS_IDS / 16];  // 2 bits per token id: bit0 = x of a batch rule, bit1 = y of a batch rule
   unsigned int new_keys;                 // slots claimed by this workgroup (added to pt.n_keys once, at the end)
-  unsigned long long st[4];              // workgroup-local stats (one global atomic each at the end)
+  unsigned long long st[6];              // workgroup-local stats (one global atomic each at the end); [4],[5]: measurement pass only
 #ifdef YTTM_K4_PROF
   unsigned long long miss_n, miss_cyc;
 #endif
@@ -151,7 +151,7 @@ __device__ inline void agg_init(AggLds &A, const uint32_t *__restrict__ flagbits
     for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += NT) A.flagbits[s] = flagbits_g[s];
   if (threadIdx.x == 0) {
     A.new_keys = 0;
-    A.st[0] = A.st[1] = A.st[2] = A.st[3] = 0;
+    A.st[0] = A.st[1] = A.st[2] = A.st[3] = A.st[4] = A.st[5] = 0;
 #ifdef YTTM_K4_PROF
     A.miss_n = A.miss_cyc = 0;
 #endif
@@ -646,6 +646,7 @@ struct TileStats {
   unsigned long long pt[16] = {0}, t_last = 0;
 #endif
   unsigned long long sites = 0, touched = 0, scanned = 0, touched_tok = 0;
+  unsigned long long words_hit = 0, words_hit_tok = 0;  // measurement pass (BatchArgs::instr): words with a merge site, their tokens
 };
 
 // everything that happens to one staged tile (K3 count or K4 merge)
@@ -653,7 +654,7 @@ template <int SLOT, bool MERGE, bool LDSR>
 __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &ts, const PairTable &pt, const DeltaBuf &db,
                                     const RuleTab<LDSR> &rtab, uint32_t self_x, uint32_t self_z,
                                     uint32_t z_base, uint32_t t, int n, uint32_t word0, const WReg<SLOT> &wreg, TileStats &S,
-                                    bool self_pass /* MERGE: the tile may hold sites of the x x rule */) {
+                                    bool self_pass /* MERGE: the tile may hold sites of the x x rule */, bool instr = false) {
   const int lane = lane_id();
   unsigned long long &my_sites = S.sites, &st_touched = S.touched, &st_scanned = S.scanned, &st_touched_tok = S.touched_tok;
     const int nchunks = (n + 63) >> 6;
@@ -807,6 +808,33 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
           wave_sync();  // (the list is rebuilt by the next pass)
         }
         K4_MARK(5);
+        if (instr) {
+          // measurement pass: the words that hold a site, and how many tokens they have (what the contract's roofline formula
+          // calls W_touched and T_touched).  A class-A tile has at most SLOT/2 words: their bits fit the site list's space.
+          uint32_t *bm = reinterpret_cast<uint32_t *>(W.sitepos);
+          if (lane < 32) bm[lane] = 0u;
+          wave_sync();
+          for (int c = first_site_chunk; c < nchunks; c++) {
+            const int p = c * 64 + lane;
+            if (p < n && SITE(p)) {
+              const uint32_t w = tile_word_index_rl<SLOT>(W, p) & 1023u;
+              atomicOr(&bm[w >> 5], 1u << (w & 31u));
+            }
+          }
+          wave_sync();
+          for (int c = 0; c < nchunks; c++) {
+            const int p = c * 64 + lane;
+            bool hit = false, start = false;
+            if (p < n) {
+              const uint32_t w = tile_word_index_rl<SLOT>(W, p) & 1023u;
+              hit = (bm[w >> 5] >> (w & 31u)) & 1u;
+              start = hit && (W.tk[p] & TOK_WS);
+            }
+            S.words_hit_tok += (unsigned long long)__popcll(__ballot(hit));
+            S.words_hit += (unsigned long long)__popcll(__ballot(start));
+          }
+          wave_sync();
+        }
         // ---- phase 3: compact in place (all reads come from LDS, so overwriting the slot in HBM is safe) ----------------
         // survivors of a chunk = its positions that are not the y of a site; tokens before the first site neither move nor change
         uint32_t *dst = ts.tok + (size_t)t * SLOT;
@@ -940,7 +968,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     site_state = MERGE ? reg_find_sites<SLOT, LDSR>(W, r, n0, A.flagbits, tokflag, self_x, rtab, my_cnt, my_site, ba.small_ids != 0) : 1;
     if (MERGE) K4_MARK(0);
     bool dirty = site_state != 0;
-    if (MERGE && SLOT == TILE_SLOT_A && site_state == 1) {  // sites of x != y rules only: is it a single one?
+    if (MERGE && SLOT == TILE_SLOT_A && site_state == 1 && !ba.instr) {  // sites of x != y rules only: is it a single one?
       const unsigned long long fm = __ballot(my_cnt != 0);
       if (__popcll(fm) == 1) {
         const int src = __ffsll((long long)fm) - 1;
@@ -968,7 +996,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     if (MERGE) K4_MARK(2);
     if (dirty) {
       K4_COUNT(8);
-      process_tile<SLOT, MERGE, LDSR>(W, A, ts, pt, db, rtab, self_x, self_z, z_base, tile, n0, w0, wcur, S, (site_state & 2) != 0);
+      process_tile<SLOT, MERGE, LDSR>(W, A, ts, pt, db, rtab, self_x, self_z, z_base, tile, n0, w0, wcur, S, (site_state & 2) != 0, MERGE && ba.instr != 0);
       wave_sync();  // everyone is done with this tile's LDS state before it is restaged
     } else {
       S.scanned += (unsigned long long)n0;
@@ -1013,6 +1041,8 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
       if (S.touched) atomicAdd(&A.st[1], S.touched);
       if (S.scanned && !worklist) atomicAdd(&A.st[2], S.scanned);
       if (S.touched_tok) atomicAdd(&A.st[3], S.touched_tok);
+      if (S.words_hit) atomicAdd(&A.st[4], S.words_hit);
+      if (S.words_hit_tok) atomicAdd(&A.st[5], S.words_hit_tok);
     }
   }
 #ifdef YTTM_K4_PROF
@@ -1042,6 +1072,10 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     if (MERGE) {
       blk_add(stats, 4, A.new_keys);
       for (int i = 0; i < 4; i++) blk_add(stats, i, A.st[i]);
+      if (ba.instr) {  // (measurement pass: plain global atomics)
+        if (A.st[4]) atomicAdd(&stats[4], A.st[4]);
+        if (A.st[5]) atomicAdd(&stats[5], A.st[5]);
+      }
     } else if (A.new_keys) {
       atomicAdd(pt.n_keys, A.new_keys);  // K3: one launch
     }
@@ -1186,6 +1220,59 @@ __global__ __launch_bounds__(BLOCK) void k_cand_scan(PairTable pt, unsigned long
   }
 }
 
+// One workgroup copies header, histogram and the first `fast` candidates of a finished candidate scan into the host's pinned
+// mailbox, publishes `round_id` there (system-scope release) and clears the device-side counters for the next call: the host
+// polls the mailbox instead of paying a copy + stream synchronisation every round.  Mailbox: [0..15] n_out[0..3], [32] round
+// id, [40] tokens streamed so far, [48] tiles touched so far, [56..79] xstat (multi-GPU: ranks whose delta block overflowed,
+// largest record count of a rank this round, number of ranks whose hot list overflowed, "a rank's send buffer overflowed"),
+// histogram at byte MB_HIST = 128, candidates at byte 8192.
+__device__ inline void publish_round(const PairTable &pt, CandRec *__restrict__ out, unsigned int cap, unsigned int *__restrict__ n_out,
+                                     unsigned long long *__restrict__ hist, unsigned int *__restrict__ done_ctr, unsigned char *__restrict__ mailbox,
+                                     unsigned int fast, uint32_t round_id, unsigned long long *__restrict__ stats,
+                                     unsigned long long *__restrict__ xstat) {
+  if (threadIdx.x == 0) n_out[1] = __hip_atomic_load(pt.n_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const unsigned int n = __hip_atomic_load(&n_out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned int *mb_hdr = reinterpret_cast<unsigned int *>(mailbox);
+  unsigned long long *mb_hist = reinterpret_cast<unsigned long long *>(mailbox + MB_HIST);
+  uint4 *mb_out = reinterpret_cast<uint4 *>(mailbox + 8192);
+  if (threadIdx.x < 4) mb_hdr[threadIdx.x] = __hip_atomic_load(&n_out[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 4)  // tokens streamed by the K4 filters so far: the host derives the tiles' fill from it (repack trigger)
+    *reinterpret_cast<unsigned long long *>(mailbox + 40) = __hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 5)  // tiles that held a merge site so far: a dense round skips the filter's exact rule test
+    *reinterpret_cast<unsigned long long *>(mailbox + 48) = __hip_atomic_load(&stats[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x >= 6 && threadIdx.x < 10) {
+    const int k = (int)threadIdx.x - 6;
+    unsigned long long v = 0;
+    if (xstat) {
+      v = __hip_atomic_load(&xstat[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      xstat[k] = 0;
+    }
+    *reinterpret_cast<unsigned long long *>(mailbox + 56 + 8 * k) = v;
+  }
+  for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) {
+    mb_hist[b] = __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hist[b] = 0;
+  }
+  unsigned int take = n < cap ? n : cap;
+  if (take > fast) take = fast;
+  const unsigned long long *src = reinterpret_cast<const unsigned long long *>(out);
+  for (unsigned int i = threadIdx.x; i < take; i += BLOCK) {
+    uint4 v;
+    const unsigned long long a = __hip_atomic_load(&src[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(&src[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.x = (uint32_t)a; v.y = (uint32_t)(a >> 32); v.z = (uint32_t)b; v.w = (uint32_t)(b >> 32);
+    mb_out[i] = v;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    n_out[0] = n_out[1] = n_out[2] = n_out[3] = 0;
+    *done_ctr = 0;
+    __hip_atomic_store(&mb_hdr[8], round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // Candidate filter over the hot list: same outputs as k_cand_scan, but only the listed slots are inspected and the
 // histogram covers the counts >= hot_tau.  n_out: [0] candidates, [1] n_keys, [2] list length, [3] listed slots that
 // are still >= hot_tau.
@@ -1196,7 +1283,8 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
                                                     unsigned int cap, unsigned int *__restrict__ n_out, unsigned long long *__restrict__ hist,
                                                     unsigned int *__restrict__ done_ctr, unsigned char *__restrict__ mailbox, unsigned int fast,
                                                     uint32_t round_id, unsigned long long *__restrict__ stats, const RuleSlot *__restrict__ zrules,
-                                                    unsigned int zmask, unsigned long long zself, BatchArgs zba) {
+                                                    unsigned int zmask, unsigned long long zself, BatchArgs zba,
+                                                    unsigned long long *__restrict__ xstat /* multi-GPU: leave the result for k_publish */) {
   // zrules != nullptr: the batch that was just applied -- every occurrence of its pairs was merged, so their counts are
   // exactly zero now; they are all on the list (that is where they were picked from), so they are zeroed here instead of
   // by a kernel of their own
@@ -1290,7 +1378,7 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
     if (v) atomicAdd(&hist[b], (unsigned long long)v);
   }
   if (threadIdx.x == 0 && live_blk) atomicAdd(&n_out[3], live_blk);
-  // ---- last workgroup: publish
+  // ---- last workgroup: publish (single GPU), or leave the verdict on the list's overflow for the ranks' all-reduce
   __shared__ unsigned int is_last;
   __threadfence();
   __syncthreads();
@@ -1298,38 +1386,22 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
   __syncthreads();
   if (!is_last) return;
   __threadfence();
-  if (threadIdx.x == 0) n_out[1] = __hip_atomic_load(pt.n_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  const unsigned int n = __hip_atomic_load(&n_out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned int *mb_hdr = reinterpret_cast<unsigned int *>(mailbox);
-  unsigned long long *mb_hist = reinterpret_cast<unsigned long long *>(mailbox + 64);
-  uint4 *mb_out = reinterpret_cast<uint4 *>(mailbox + 8192);
-  if (threadIdx.x < 4) mb_hdr[threadIdx.x] = __hip_atomic_load(&n_out[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (threadIdx.x == 4)  // tokens streamed by the K4 filters so far: the host derives the tiles' fill from it (repack trigger)
-    *reinterpret_cast<unsigned long long *>(mailbox + 40) = __hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (threadIdx.x == 5)  // tiles that held a merge site so far: a dense round skips the filter's exact rule test
-    *reinterpret_cast<unsigned long long *>(mailbox + 48) = __hip_atomic_load(&stats[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) {
-    mb_hist[b] = __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    hist[b] = 0;
+  if (xstat) {  // multi-GPU: k_publish runs after the all-reduce of xstat[2]
+    if (threadIdx.x == 0) {
+      xstat[2] = hn_raw > pt.hot_cap ? 1ull : 0ull;
+      *done_ctr = 0;
+    }
+    return;
   }
-  unsigned int take = n < cap ? n : cap;
-  if (take > fast) take = fast;
-  const unsigned long long *src = reinterpret_cast<const unsigned long long *>(out);
-  for (unsigned int i = threadIdx.x; i < take; i += BLOCK) {
-    uint4 v;
-    const unsigned long long a = __hip_atomic_load(&src[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(&src[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v.x = (uint32_t)a; v.y = (uint32_t)(a >> 32); v.z = (uint32_t)b; v.w = (uint32_t)(b >> 32);
-    mb_out[i] = v;
-  }
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    n_out[0] = n_out[1] = n_out[2] = n_out[3] = 0;
-    *done_ctr = 0;
-    __hip_atomic_store(&mb_hdr[8], round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  publish_round(pt, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id, stats, nullptr);
+}
+
+// multi-GPU: publishes what k_hot_scan found once the ranks have summed their list-overflow verdicts (xstat[2])
+__global__ __launch_bounds__(BLOCK) void k_publish(PairTable pt, CandRec *__restrict__ out, unsigned int cap, unsigned int *__restrict__ n_out,
+                                                   unsigned long long *__restrict__ hist, unsigned int *__restrict__ done_ctr,
+                                                   unsigned char *__restrict__ mailbox, unsigned int fast, uint32_t round_id,
+                                                   unsigned long long *__restrict__ stats, unsigned long long *__restrict__ xstat) {
+  publish_round(pt, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id, stats, xstat);
 }
 
 // (Re)build the hot list: every slot with count >= pt.hot_tau, in one streaming pass; PT_HOT is set exactly on those.
@@ -1400,6 +1472,31 @@ __global__ __launch_bounds__(BLOCK) void k_pt_apply(PairTable pt, const DeltaRec
   unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
   for (; i < n; i += stride) pt_add(pt, recs[i].key, recs[i].delta);
+}
+
+// multi-GPU, per round: the ranks' delta blocks as ncclAllGather left them -- block r = { count, -, records... } of `blk` 16-byte
+// units -- folded into the local replica.  A rank whose count does not fit its block is skipped as a whole and reported in
+// xstat[0] (bit r); the host then repeats the exchange with larger blocks for exactly those ranks (only_mask).  xstat[1] =
+// largest count seen (sizes the next round's blocks).  No host round trip: counts are read on the device.
+__global__ __launch_bounds__(BLOCK) void k_pt_apply_blocks(PairTable pt, const DeltaRec *__restrict__ blocks, unsigned long long blk, int world,
+                                                           int rank, unsigned long long only_mask, unsigned long long *__restrict__ xstat) {
+  for (int r = 0; r < world; r++) {
+    const DeltaRec *b = blocks + (size_t)r * blk;
+    const unsigned long long n = b[0].key;  // header: record count of rank r, capacity of its send buffer
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      atomicMax(&xstat[1], n);
+      if (n > (unsigned long long)b[0].delta) xstat[3] = 1ull;  // rank r lost records: every rank reads this verdict and stops
+    }
+    if (only_mask && !((only_mask >> r) & 1ull)) continue;
+    if (n > blk - 1) {  // (reported for the own block too: every rank must reach the same verdict)
+      if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&xstat[0], 1ull << r);
+      continue;
+    }
+    if (r == rank) continue;  // own deltas went into the table when they were made
+    unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
+    for (; i < n; i += stride) pt_add(pt, b[1 + i].key, b[1 + i].delta);
+  }
 }
 
 // per-round batch flags: byte table for every id + packed 2-bit copy of the first FLAG_LDS_IDS ids (staged into LDS by K4)
@@ -1593,14 +1690,24 @@ void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t 
 void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
                      unsigned long long *hist, unsigned int *done_ctr, unsigned char *mailbox, unsigned int fast, uint32_t round_id,
                      unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, unsigned int listed_hint,
-                     const BatchArgs *zba, hipStream_t st) {
+                     const BatchArgs *zba, unsigned long long *xstat, hipStream_t st) {
   // one entry per thread; every workgroup costs ~11 ns of serialised ticket/total atomics at the end, so no more of them
   // than the list needs (the statistics rows need >= BLK_ROWS / 64 = 24)
   unsigned int g = (listed_hint + BLOCK - 1) / BLOCK;
   if (g < 32) g = 32;
   if (g > 256) g = 256;
   hipLaunchKernelGGL(k_hot_scan, dim3(g), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id,
-                     stats, zrules, zmask, zself, zba ? *zba : BatchArgs{});
+                     stats, zrules, zmask, zself, zba ? *zba : BatchArgs{}, xstat);
+}
+void launch_publish(const PairTable &pt, CandRec *out, unsigned int cap, unsigned int *n_out, unsigned long long *hist, unsigned int *done_ctr,
+                    unsigned char *mailbox, unsigned int fast, uint32_t round_id, unsigned long long *stats, unsigned long long *xstat, hipStream_t st) {
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(BLOCK), 0, st, pt, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id, stats, xstat);
+}
+void launch_pt_apply_blocks(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, int rank, unsigned long long only_mask,
+                            unsigned long long *xstat, hipStream_t st) {
+  unsigned long long b = (blk + BLOCK - 1) / BLOCK;
+  if (b > 256 * 4) b = 256 * 4;
+  hipLaunchKernelGGL(k_pt_apply_blocks, dim3((unsigned int)b), dim3(BLOCK), 0, st, pt, blocks, blk, world, rank, only_mask, xstat);
 }
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st) {
   unsigned long long n_slots = pt.mask + 1;

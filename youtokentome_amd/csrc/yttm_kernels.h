@@ -54,6 +54,8 @@ struct BatchArgs {
   uint32_t k;                        // 0: not used (tables come from HBM)
   uint32_t xy[2 * BATCH_ARGS_MAX];   // rule j of the batch merges (xy[2j], xy[2j+1]) into z_base + j; x == y: the self rule (skipped)
   uint32_t small_ids;                // every token id in the tiles is < FLAG_LDS_IDS: the kernels skip the test for ids behind the LDS bitmap
+  uint32_t instr;                    // measurement pass (never timed): also count the WORDS that hold a merge site and their tokens
+                                     // (T_touched, W_touched) into stats[4], stats[5]; single-site tiles take the general path
 };
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st);
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
@@ -66,7 +68,12 @@ void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t 
 void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
                      unsigned long long *hist, unsigned int *done_ctr, unsigned char *mailbox, unsigned int fast, uint32_t round_id,
                      unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, unsigned int listed_hint,
-                     const BatchArgs *zba, hipStream_t st);
+                     const BatchArgs *zba, unsigned long long *xstat /* multi-GPU: leave the mailbox to launch_publish */, hipStream_t st);
+void launch_publish(const PairTable &pt, CandRec *out, unsigned int cap, unsigned int *n_out, unsigned long long *hist, unsigned int *done_ctr,
+                    unsigned char *mailbox, unsigned int fast, uint32_t round_id, unsigned long long *stats, unsigned long long *xstat, hipStream_t st);
+void launch_pt_apply_blocks(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, int rank, unsigned long long only_mask,
+                            unsigned long long *xstat, hipStream_t st);
+constexpr int MB_HIST = 128;  // byte offset of the count histogram in the mailbox (header + xstat before it)
 void launch_fold_stats(unsigned long long *stats, unsigned int *n_keys, hipStream_t st);
 constexpr int STATS_WORDS = 32 + 8 * 1536;  // totals + one row per workgroup (k_merge.hip: BLK_BASE, BLK_ROWS)
 void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, const uint32_t *upd, unsigned int n_upd,

@@ -2,15 +2,12 @@
 (youtokentome/yttm_cli.py:10-169: bpe | encode | decode | vocab), same stdout formats as the reference's native CLI
 loops (bpe.cpp:1942-2028, utils.h:92-103).  Run as `python -m youtokentome_amd.yttm_cli ...`.
 
-encode reads stdin in batches of >= 10 MiB of text (bpe.cpp:1976-1983) and encodes each batch with one K5 launch;
---stream encodes and flushes line by line (bpe.cpp:1952-1974)."""
-import sys
+The loops themselves are C++ (youtokentome_amd/csrc/host_cli.cpp, behind yttm_encode_cli / yttm_decode_cli / yttm_vocab_cli):
+stdin and stdout stay bytes end to end, invalid UTF-8 included."""
 
 import click
 
 from .bpe import _Core
-
-BATCH_LIMIT = 10 * 1024 * 1024  # bpe.cpp:1976
 
 
 @click.group()
@@ -34,14 +31,6 @@ def bpe(data, model, vocab_size, coverage, n_threads, pad_id, unk_id, bos_id, eo
                 unk_id=unk_id, bos_id=bos_id, eos_id=eos_id)
 
 
-def _print_rows(rows, flush):
-    out = sys.stdout
-    for row in rows:  # every token is followed by one space, utils.h:92-103
-        out.write("".join(f"{tok} " for tok in row) + "\n")
-    if flush:
-        out.flush()
-
-
 @main.command()
 @click.option("--model", type=click.Path(exists=True), required=True, help="Path to file with learned model.")
 @click.option("--output_type", type=click.Choice(["id", "subword"]), required=True, help="'id' or 'subword'.")
@@ -57,29 +46,7 @@ def encode(model, output_type, n_threads, bos, eos, reverse, stream, dropout_pro
     if n_threads < -1 or n_threads == 0:  # yttm_cli.py:110-114
         raise ValueError('Invalid value for "--n_threads": must be -1 or positive integer, not "%d"' % n_threads)
     core = _Core(model, n_threads)
-    stdin = sys.stdin.buffer
-    if stream:
-        for raw in stdin:
-            line = raw.rstrip(b"\n").decode(errors="surrogateescape")
-            _print_rows(core.encode([line], output_type, bos, eos, reverse, dropout_prob), flush=True)
-        return
-    total = 0
-    while True:
-        batch, size = [], 0
-        for raw in stdin:
-            s = raw.rstrip(b"\n")
-            batch.append(s.decode(errors="surrogateescape"))
-            size += len(s)
-            if size >= BATCH_LIMIT:
-                break
-        if batch:
-            _print_rows(core.encode(batch, output_type, bos, eos, reverse, dropout_prob), flush=False)
-        total += size
-        sys.stderr.write("\rbytes processed: %d" % total)
-        if size < BATCH_LIMIT:
-            break
-    sys.stderr.write("\n")
-    sys.stdout.flush()
+    core.encode_cli(output_type, stream, bos, eos, reverse, dropout_prob)  # the C++ loop: yttm_encode_cli (host_cli.cpp)
 
 
 def _parse_ignore_ids(ctx, param, value):
@@ -98,9 +65,7 @@ def _parse_ignore_ids(ctx, param, value):
 def decode(model, ignore_ids):
     """Decode ids to text."""
     core = _Core(model)
-    for line in sys.stdin:
-        ids = [int(t) for t in line.split()]
-        sys.stdout.write(core.decode([ids], ignore_ids)[0] + "\n")
+    core.decode_cli(ignore_ids)
 
 
 @main.command()
@@ -109,24 +74,7 @@ def decode(model, ignore_ids):
 def vocab(model, verbose):
     """Print list of learned subwords."""
     core = _Core(model)
-    rules = {}
-    if verbose:  # model file: "<n_chars> <n_rules>", char lines, then "x y z" rule lines (utils.cpp:50-66)
-        with open(model) as f:
-            n_chars, n_rules = (int(v) for v in f.readline().split())
-            for _ in range(n_chars):
-                f.readline()
-            for _ in range(n_rules):
-                x, y, z = (int(v) for v in f.readline().split())
-                rules[z] = (x, y)
-    for i in range(core.vocab_size()):
-        tok = core.id_to_subword(i)
-        line = f"{i}\t{tok}"
-        if verbose and i in rules:  # bpe.cpp:1916-1936
-            x, y = rules[i]
-            tx, ty = core.id_to_subword(x), core.id_to_subword(y)
-            used = len(tok) + 1 + len(tx) + 1 + len(ty)
-            line += f"={tx}+{ty}" + " " * max(2, 50 - used) + f"{x}+{y}"
-        sys.stdout.write(line + "\n")
+    core.vocab_cli(verbose)
 
 
 if __name__ == "__main__":
