@@ -168,8 +168,12 @@ def test_medium_corpus_vs_reference_binary(tmp_path):
     offs = np.arange(200_001, dtype=np.uint64) * 129
     ids, off = bpe.bpe_cython.encode_packed(sent_bytes, offs)
     assert len(ids) == want["ids"]
-    import bench
-    assert bench._fnv(ids, off) == want["fnv1a64"]
+    import ctypes as C
+    from youtokentome_amd import _lib
+    ids = np.ascontiguousarray(ids, np.int32)
+    off = np.ascontiguousarray(off, np.uint64)
+    got = _lib.load().yttm_ids_fnv1a64(ids.ctypes.data_as(_lib.i32p), off.ctypes.data_as(_lib.u64p), len(off) - 1)
+    assert "%016x" % got == want["fnv1a64"]
 
 
 def test_encode_properties_at_scale(tmp_path):
