@@ -107,7 +107,8 @@ def test_encode_mixed_shapes():
 def test_hot_list_rebuilds(tmp_path, monkeypatch):
     """The candidate filter reads a hot list of pairs instead of the whole pair table; shrink the list so that tiny corpora
     go through its rebuild, overflow and whole-table fallback paths, and demand the same models."""
-    for target, mn, cap in ((8, 3, 64), (4, 2, 16), (64, 8, 4096)):
+    for target, mn, cap, nofuse in ((8, 3, 64, "0"), (4, 2, 16, "0"), (64, 8, 4096, "0"), (8, 3, 64, "1"), (64, 8, 4096, "1")):
+        monkeypatch.setenv("YTTM_NO_FUSE", nofuse)  # 1: the candidate scan as a kernel of its own instead of the apply kernel's tail
         monkeypatch.setenv("YTTM_HOT_TARGET", str(target))
         monkeypatch.setenv("YTTM_HOT_MIN", str(mn))
         monkeypatch.setenv("YTTM_HOT_CAP", str(cap))

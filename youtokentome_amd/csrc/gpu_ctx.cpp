@@ -164,6 +164,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   hot_target_ = env_uint("YTTM_HOT_TARGET", 1u << 13);  // measured at 1 GB: 4096..16384 equal on the abcd corpus, 8192 best on Zipf text (4279 rounds)
   hot_min_ = env_uint("YTTM_HOT_MIN", 512);
   dense_pct_ = env_uint("YTTM_DENSE_PCT", 0);
+  fuse_enabled_ = env_uint("YTTM_NO_FUSE", 0) == 0;
   d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);
   d_hot_n_ = dmalloc<unsigned int>(4);  // [0] list length, [1] k_hot_scan's finished-workgroup ticket, [2..3] overflow verdict (u64)
   HIP_CHECK(hipMemset(d_hot_n_, 0, 16));
@@ -931,7 +932,10 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     }
     constexpr unsigned int CAND_FAST = 4096;
     unsigned char *h = (unsigned char *)h_pin_;
-    const uint32_t round_id = ++mail_round_;
+    const bool use_fused = fused_pending_ && fused_tau_ == tau_cnt && fused_mx_ == tau_mx && attempt == 0;
+    fused_pending_ = false;  // (a scan that was fused but is not wanted any more is simply ignored)
+    const uint32_t round_id = use_fused ? fused_round_ : ++mail_round_;
+    if (!use_fused) {
     t_begin(KT_CAND);
     launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_,
                     pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, listed_last_ ? listed_last_ + 4096 : hot_cap_,
@@ -944,6 +948,7 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     }
     pending_zero_ = false;
     t_end(KT_CAND, 20ull * listed_last_);  // (not chained: the host round trip that follows belongs to no kernel family)
+    }
     {
       // the kernel's last workgroup writes header + histogram + first candidates into the pinned mailbox and then the
       // round id: poll for it (a copy + stream synchronisation costs tens of microseconds per round)
@@ -973,7 +978,7 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     const unsigned int *hdr = (const unsigned int *)h;
     const unsigned int n = hdr[0], listed = hdr[2], live = hdr[3];
     n_keys_host = hdr[1];
-    listed_last_ = std::min(listed, hot_cap_);
+    listed_last_ = std::min(use_fused ? live : listed, hot_cap_);  // (the fused scan compacts the list to its live entries)
     unsigned long long overflow = listed > hot_cap_ ? 1 : 0;
     if (multi()) {
       overflow = *(const unsigned long long *)(h + 72);  // ranks whose list overflowed
@@ -1011,7 +1016,8 @@ void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned lon
 }
 
 // ------------------------------------------------------------------------------------------------- K4
-void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts) {
+void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts, const unsigned long long *next_tau_cnt,
+                         uint32_t next_tau_mx) {
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
@@ -1098,6 +1104,28 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     prev_flag_toks_.swap(now);
   }
   if (multi()) HIP_CHECK(hipMemsetAsync(db_.n, 0, 8, st_));  // this round's records start at the head of the send block
+  // one launch per round: the apply kernel's last workgroup also does the candidate scan (see gpu_ctx.h)
+  ScanArgs sa{};
+  fused_pending_ = false;
+  if (next_tau_cnt && fuse_enabled_ && !multi() && hot_state_ == HOT_ACTIVE && cls_[0].n_tiles && !cls_[1].n_tiles && !cls_[2].n_tiles && !instrument) {
+    sa.on = 1;
+    sa.tau_cnt = *next_tau_cnt;
+    sa.tau_mx = next_tau_mx;
+    if (sa.tau_cnt < pt_.hot_tau) {  // the list is complete only from hot_tau up (as in candidates())
+      sa.tau_cnt = pt_.hot_tau;
+      sa.tau_mx = 0xffffffffu;
+    }
+    sa.out = d_cand_;
+    sa.cap = cand_cap_;
+    sa.fast = 4096;
+    sa.done_ctr = d_hot_n_ + 1;
+    sa.mailbox = (unsigned char *)h_pin_;
+    sa.round_id = ++mail_round_;
+    fused_pending_ = true;
+    fused_tau_ = *next_tau_cnt;
+    fused_mx_ = next_tau_mx;
+    fused_round_ = sa.round_id;
+  }
   t_begin(KT_MERGE);
   if (!by_args)
     launch_round_begin(h_rules, cap, d_rules_, h_upd, n_upd, d_tokflag_, d_flagbits_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr,
@@ -1106,7 +1134,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     if (!cls_[ci].n_tiles) continue;
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
                        cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/by_args || dense_class(ci),
-                       &ba, st_);
+                       &ba, ci == 0 && sa.on ? &sa : nullptr, st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
   t_end(KT_MERGE, 0, /*chain=*/true);
@@ -1134,7 +1162,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       fclose(f);
     }
   }
-  pending_zero_ = true;
+  pending_zero_ = !sa.on;  // (a fused round zeroes its batch's pairs itself)
   zero_valid_ = true;
   zero_ba_ = ba;
   zero_cap_ = cap;

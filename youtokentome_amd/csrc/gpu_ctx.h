@@ -66,7 +66,11 @@ class GpuCtx {
   void pair_count();
   void download_pairs(std::vector<unsigned long long> &keys, std::vector<unsigned long long> &cnts);
   // ---- K4: apply a batch of mutually non-intersecting rules (x,y,z)*k
-  void merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts);
+  // next_tau_cnt / next_tau_mx (optional): the threshold of the candidate scan that will follow this round.  When the round is
+  // one launch (single GPU, class-A tiles only, hot list active) that scan runs inside it (k_merge.hip round_tail) and the
+  // next candidates() call with the same threshold only waits for the mailbox.
+  void merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts, const unsigned long long *next_tau_cnt = nullptr,
+                   uint32_t next_tau_mx = 0xffffffffu);
   void pair_query(const unsigned long long *keys, uint32_t n, unsigned long long *out);
   // candidate filter; returns number of candidates that passed (may exceed out.size() capacity => retry with higher tau)
   // Pairs with count > tau_cnt, or == tau_cnt and max(x,y) <= tau_mx (a complete prefix of the pick order), + histogram
@@ -106,6 +110,10 @@ class GpuCtx {
   unsigned int *d_hot_n_ = nullptr;
   unsigned int fullscan_rounds_ = 0;
   uint32_t mail_round_ = 0;
+  bool fused_pending_ = false;  // a fused scan is in flight / in the mailbox ...
+  unsigned long long fused_tau_ = 0;  // ... for this threshold
+  uint32_t fused_mx_ = 0, fused_round_ = 0;
+  bool fuse_enabled_ = true;  // YTTM_NO_FUSE=1: always the separate scan kernel (tuning hook / tests)
   uint32_t max_id_ = 0xffffffffu;  // largest token id in the tiles (unknown until the word table is built)
   unsigned long long scanned_cum_ = 0, live_tokens_last_ = 0, touched_cum_ = 0, touched_last_ = ~0ull >> 2;  // (first round: dense)
   unsigned int hot_cap_ = 0, hot_target_ = 0, hot_min_ = 0, listed_last_ = 0;

@@ -183,7 +183,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     for (uint32_t j = 0; j < k; j++) in_batch[batch_xyz[3 * j]] = in_batch[batch_xyz[3 * j + 1]] = 0;
     w_pick += since(tw1);
     auto tw2 = clk::now();
-    g.merge_apply(batch_xyz.data(), k, batch_cnt.data());
+    g.merge_apply(batch_xyz.data(), k, batch_cnt.data(), &tau_hint, MX_ALL);  // (the next scan's threshold: it can ride along)
     w_apply += since(tw2);
     for (uint32_t j = 0; j < k; j++) rules.push_back(BPE_Rule{batch_xyz[3 * j], batch_xyz[3 * j + 1], batch_xyz[3 * j + 2]});
     used_ids += k;

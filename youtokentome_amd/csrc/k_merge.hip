@@ -866,13 +866,143 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
     }
 }
 
+// ------------------------------------------------------------------------------------------------- fused candidate scan
+__device__ inline int cand_bin(unsigned long long c) {
+  if (c < 256) return (int)c;
+  int e = 63 - __clzll((long long)c);  // >= 8
+  int m3 = (int)((c >> (e - 3)) & 7ull);
+  return 256 + (e - 8) * 8 + m3;
+}
+
+
+// The tail of a merge round (ScanArgs, yttm_kernels.h), run by the LAST workgroup of the apply kernel to finish -- every other
+// workgroup has published its updates (device-scope atomics, then a fence, then its ticket), nothing else touches the pair table.
+//   1. fold the per-workgroup statistics rows into the totals and the key count
+//   2. scan the hot list: zero the pairs of the batch just applied (every occurrence was merged), histogram the live counts,
+//      collect the candidates above the host's threshold -- and COMPACT the list in place: an entry whose count fell below
+//      hot_tau leaves the list (PT_HOT cleared, so it can come back), so the list stays as long as it has live entries and one
+//      workgroup reads it in a few round trips
+//   3. publish header, histogram and the first `fast` candidates in the pinned mailbox, then the round id (system-scope release)
+// lds = at least (CAND_BINS + 80) words of scratch (the apply kernel's tile buffers are free by now).
+template <int NT>
+__device__ inline void round_tail(const PairTable &pt, const ScanArgs &sa, unsigned long long *__restrict__ stats, const RuleProbe &zprobe,
+                                  unsigned long long zself, unsigned int *lds) {
+  constexpr int NW = NT / 64;
+  unsigned int *lh = lds;                     // [CAND_BINS]
+  unsigned int *wcount = lds + CAND_BINS;     // [NW] kept entries per wave of this pass
+  unsigned int *ctl = lds + CAND_BINS + 32;   // [0] kept so far, [1] candidates, [2..11] fold accumulators (u64 x 5)
+  unsigned long long *facc = reinterpret_cast<unsigned long long *>(lds + CAND_BINS + 40);
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int b = tid; b < CAND_BINS; b += NT) lh[b] = 0;
+  if (tid < 2) ctl[tid] = 0;
+  if (tid < 5) facc[tid] = 0;
+  __syncthreads();
+  {  // ---- 1. statistics rows (written by the workgroups of this and earlier launches with plain stores)
+    unsigned long long a[5] = {0, 0, 0, 0, 0};
+    for (int b = tid; b < BLK_ROWS; b += NT) {
+      unsigned long long *row = stats + BLK_BASE + 8 * b;
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const unsigned long long v = __hip_atomic_load(&row[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a[j] += v;
+        any = any || v != 0;
+      }
+      if (any) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) row[j] = 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+      if (a[j]) atomicAdd(&facc[j], a[j]);
+    __syncthreads();
+    if (tid < 4 && facc[tid]) stats[tid] += facc[tid];
+    if (tid == 4 && facc[4]) atomicAdd(pt.n_keys, (unsigned int)facc[4]);
+  }
+  // ---- 2. the hot list
+  const unsigned int hn_raw = __hip_atomic_load(pt.hot_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool overflow = hn_raw > pt.hot_cap;  // entries were dropped: the host rebuilds the list, nothing to scan
+  const unsigned int hn = overflow ? 0u : hn_raw;
+  uint4 *mb_out = reinterpret_cast<uint4 *>(sa.mailbox + 8192);
+  for (unsigned int base = 0; base < hn; base += NT) {
+    const unsigned int i = base + (unsigned int)tid;
+    const bool valid = i < hn;
+    uint32_t sl = 0;
+    unsigned long long k = PT_EMPTY, c = 0;
+    if (valid) {
+      sl = __hip_atomic_load(&pt.hot_slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      k = ld_agent(pt.key_p(sl));
+      c = ld_agent(pt.cnt_p(sl)) & PT_CNT;
+      if (c && (k == zself || zprobe.has((uint32_t)(k >> 32), (uint32_t)k))) c = 0;  // a pair of the finished batch
+    }
+    const bool keep = valid && c >= pt.hot_tau && c > 0;
+    if (valid) *pt.cnt_p(sl) = keep ? (c | PT_HOT) : c;  // (a count that was zeroed is stored as 0; a dropped entry loses PT_HOT)
+    bool pass = false;
+    if (keep) {
+      atomicAdd(&lh[cand_bin(c)], 1u);
+      const uint32_t x = (uint32_t)(k >> 32), y = (uint32_t)k;
+      const uint32_t mx = x > y ? x : y;
+      pass = c > sa.tau_cnt || (c == sa.tau_cnt && mx <= sa.tau_mx);
+    }
+    const unsigned long long km = __ballot(keep), pm = __ballot(pass);
+    if (lane == 0) wcount[wave] = (unsigned int)__popcll(km);
+    if (pm) {
+      unsigned int ob = 0;
+      if (lane == 0) ob = atomicAdd(&ctl[1], (unsigned int)__popcll(pm));
+      ob = __shfl(ob, 0);
+      if (pass) {
+        const unsigned int o = ob + (unsigned int)__popcll(pm & lanemask_lt());
+        if (o < sa.cap) {
+          sa.out[o].key = k;
+          sa.out[o].cnt = c;
+        }
+        if (o < sa.fast) {
+          uint4 v;
+          v.x = (uint32_t)k; v.y = (uint32_t)(k >> 32); v.z = (uint32_t)c; v.w = (uint32_t)(c >> 32);
+          mb_out[o] = v;
+        }
+      }
+    }
+    __syncthreads();  // every entry of this pass has been read: the kept ones move down
+    unsigned int before = ctl[0];
+    for (int w = 0; w < wave; w++) before += wcount[w];
+    if (keep) pt.hot_slots[before + (unsigned int)__popcll(km & lanemask_lt())] = sl;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned int t = 0;
+      for (int w = 0; w < NW; w++) t += wcount[w];
+      ctl[0] += t;
+    }
+    __syncthreads();
+  }
+  // ---- 3. publish
+  unsigned int *mb_hdr = reinterpret_cast<unsigned int *>(sa.mailbox);
+  unsigned long long *mb_hist = reinterpret_cast<unsigned long long *>(sa.mailbox + MB_HIST);
+  if (tid == 0) {
+    mb_hdr[0] = ctl[1];                                                                          // candidates
+    mb_hdr[1] = __hip_atomic_load(pt.n_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // keys in the table
+    mb_hdr[2] = hn_raw;                                                                          // listed (before the compaction)
+    mb_hdr[3] = ctl[0];                                                                          // still >= hot_tau
+    *reinterpret_cast<unsigned long long *>(sa.mailbox + 40) = stats[2];  // tokens streamed so far (repack trigger)
+    *reinterpret_cast<unsigned long long *>(sa.mailbox + 48) = stats[1];  // tiles that held a merge site so far
+    if (!overflow) *pt.hot_n = ctl[0];
+    *sa.done_ctr = 0;
+  }
+  if (tid >= 6 && tid < 10) *reinterpret_cast<unsigned long long *>(sa.mailbox + 56 + 8 * (tid - 6)) = 0;  // (multi-GPU fields)
+  for (int b = tid; b < CAND_BINS; b += NT) mb_hist[b] = (unsigned long long)lh[b];
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(&mb_hdr[8], sa.round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int SLOT, int WPB, bool MERGE, bool LDSR>
 __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WPB) : WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                                                     const uint32_t *__restrict__ worklist, const unsigned int *__restrict__ work_n,
                                                     unsigned long long *__restrict__ stats /* [0]=sites [1]=tiles touched [2]=tokens scanned [3]=tokens in touched tiles */,
-                                                    BatchArgs ba) {
+                                                    BatchArgs ba, ScanArgs sa) {
   __shared__ WaveLds<SLOT> WL[WPB];
   __shared__ AggLds A;
   __shared__ unsigned long long rkeys[LDSR ? APPLY_LDS_RULES : 1];
@@ -1080,6 +1210,19 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
       atomicAdd(pt.n_keys, A.new_keys);  // K3: one launch
     }
   }
+  if (MERGE && sa.on) {  // the round's candidate scan, by the last workgroup to get here (round_tail)
+    __shared__ unsigned int is_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(sa.done_ctr, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (is_last) {
+      __threadfence();
+      static_assert(sizeof(WL) >= (CAND_BINS + 80) * sizeof(unsigned int), "tile buffers double as the tail's scratch");
+      const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
+      round_tail<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]));
+    }
+  }
 }
 
 // K4 filter: streams every tile once with maximal occupancy (no per-wave LDS, two tiles in flight per wave) and writes
@@ -1165,13 +1308,6 @@ __global__ __launch_bounds__(BLOCK, SLOT <= 512 ? 6 : 1) void k_filter(TileSet t
 }
 
 // ------------------------------------------------------------------------------------------------- pair table kernels
-__device__ inline int cand_bin(unsigned long long c) {
-  if (c < 256) return (int)c;
-  int e = 63 - __clzll((long long)c);  // >= 8
-  int m3 = (int)((c >> (e - 3)) & 7ull);
-  return 256 + (e - 8) * 8 + m3;
-}
-
 // Candidate filter: appends every pair with (count > tau_cnt) or (count == tau_cnt and max(x,y) <= tau_mx) and
 // histograms all live counts (CAND_BINS log-ish bins) so the host can choose the next threshold.
 __global__ __launch_bounds__(BLOCK) void k_cand_scan(PairTable pt, unsigned long long tau_cnt, uint32_t tau_mx,
@@ -1640,18 +1776,19 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{});
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{}, ScanArgs{});
   else
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
-                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{});
+                       (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{}, ScanArgs{});
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                         uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
-                        hipStream_t st) {
+                        const ScanArgs *scan, hipStream_t st) {
   if (!ts.n_tiles) return;
   const BatchArgs bargs = ba ? *ba : BatchArgs{};
+  const ScanArgs sargs = (scan && cls == 0) ? *scan : ScanArgs{};
   const RuleSlot *frules = exact_filter ? rules : nullptr;
   // dense round (nearly every tile held a site last round): the filter pass would keep everything -- the apply kernel
   // takes all tiles and dismisses the few clean ones itself
@@ -1665,19 +1802,19 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, true>), dim3(tile_grid(ts.n_tiles, APPLY_WPB, APPLY_BPC)), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, false>), dim3(tile_grid(ts.n_tiles, APPLY_WPB, APPLY_BPC)), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
   } else {
     if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, ScanArgs{});
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs);
+                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, ScanArgs{});
   }
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,

@@ -57,10 +57,24 @@ struct BatchArgs {
   uint32_t instr;                    // measurement pass (never timed): also count the WORDS that hold a merge site and their tokens
                                      // (T_touched, W_touched) into stats[4], stats[5]; single-site tiles take the general path
 };
+// The candidate scan that follows a merge round, done by the round's own apply kernel: the last workgroup to finish folds the
+// statistics rows, zeroes the batch's pairs, scans (and compacts) the hot list and publishes header + histogram + candidates
+// in the host's pinned mailbox -- one launch per round instead of two, and no second trip through the launch path.
+struct ScanArgs {
+  uint32_t on;  // 0: no scan in this launch
+  uint32_t tau_mx;
+  unsigned long long tau_cnt;  // candidates: count > tau_cnt, or == tau_cnt and max(x,y) <= tau_mx
+  CandRec *out;                // [cap] all candidates (the first `fast` also go to the mailbox)
+  unsigned int cap, fast;
+  unsigned int *done_ctr;      // ticket of finished workgroups (left at 0)
+  unsigned char *mailbox;
+  uint32_t round_id;
+};
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st);
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
-                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba, hipStream_t st);
+                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
+                        const ScanArgs *scan /* class A only */, hipStream_t st);
 void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, unsigned int nom, unsigned long long total,
                    unsigned long long *gstart, unsigned int n_new, uint32_t *new_tok, uint32_t *new_len, uint32_t *new_word0, hipStream_t st);
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
