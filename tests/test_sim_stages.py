@@ -1,6 +1,7 @@
 """Kernel-logic tests on GPU-less machines: the UNMODIFIED product sources (youtokentome_amd/csrc) built against the
 HIP emulator (tests/hipsim), driven through the same C ABI and checked against the oracle / golden fixtures.
 (The parity tests proper are tests/test_gpu_parity.py, -m gpu, on a real MI355X.)"""
+import os
 import random
 
 import pytest
@@ -117,6 +118,33 @@ def test_hot_list_rebuilds(tmp_path, monkeypatch):
         rng = random.Random(target)
         text = gen.unicode_text(rng, 3000, "ascii")
         S.check_train_vs_oracle(text, 150, tmp_path, tag=f"hot{target}")
+
+
+def test_hot_list_overflow_in_a_fused_round(tmp_path, monkeypatch):
+    """The hot list overflows while the candidate scan rides in the apply kernel's tail (which then has no complete list to
+    zero the finished batch's pairs through): the rebuild that follows must still see those pairs at zero."""
+    import ctypes as C
+    import json
+    import filecmp
+    from youtokentome_amd import _lib
+    L = _lib.load()
+    monkeypatch.setenv("YTTM_HOT_MIN", "1")  # never "running dry": only overflows rebuild the list
+    seen = 0
+    for target, cap in ((40, 128), (100, 256), (16, 40), (300, 640)):
+        monkeypatch.setenv("YTTM_HOT_TARGET", str(target))
+        monkeypatch.setenv("YTTM_HOT_CAP", str(cap))
+        for name in ("zipf", "readme_small", "mix_cov"):
+            a = json.load(open(os.path.join(S.G, f"train_{name}.args.json")))
+            out = str(tmp_path / f"{name}.model")
+            err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+            rc = L.yttm_train_bpe_ex(os.path.join(S.G, f"train_{name}.txt").encode(), out.encode(), a["vocab"], a["coverage"], 1, a["pad"], a["unk"],
+                                     a["bos"], a["eos"], 0, rep, 16384, err, 2048)
+            assert rc == 0, err.value
+            assert filecmp.cmp(out, os.path.join(S.G, f"train_{name}.model"), shallow=False), (name, target, cap)
+            r = json.loads(rep.value.decode())
+            assert r["fused_rounds"] > 0
+            seen += r["fused_overflows"]
+    assert seen > 0, "no configuration overflowed the list during a fused round: the test does not test what it says"
 
 
 def test_worklist_mode(tmp_path, monkeypatch):

@@ -164,7 +164,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   hot_target_ = env_uint("YTTM_HOT_TARGET", 1u << 13);  // measured at 1 GB: 4096..16384 equal on the abcd corpus, 8192 best on Zipf text (4279 rounds)
   hot_min_ = env_uint("YTTM_HOT_MIN", 512);
   dense_pct_ = env_uint("YTTM_DENSE_PCT", 0);
-  fuse_enabled_ = env_uint("YTTM_NO_FUSE", 0) == 0;
+  fuse_enabled_ = env_uint("YTTM_NO_FUSE", 0) == 0 && env_uint("YTTM_FUSE", 0) != 0;  // (off until the tail scans a short list: measured slower)
   d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);
   d_hot_n_ = dmalloc<unsigned int>(4);  // [0] list length, [1] k_hot_scan's finished-workgroup ticket, [2..3] overflow verdict (u64)
   HIP_CHECK(hipMemset(d_hot_n_, 0, 16));
@@ -980,6 +980,18 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     n_keys_host = hdr[1];
     listed_last_ = std::min(use_fused ? live : listed, hot_cap_);  // (the fused scan compacts the list to its live entries)
     unsigned long long overflow = listed > hot_cap_ ? 1 : 0;
+    if (use_fused) {
+      fused_rounds++;
+      const unsigned long long *tm = (const unsigned long long *)(h + 96);  // round_tail's marks (100 MHz wall clock)
+      tail_ticks[0] += tm[1] - tm[0];
+      tail_ticks[1] += tm[2] - tm[1];
+      tail_ticks[2] += tm[3] - tm[2];
+      tail_listed += listed;
+    }
+    if (use_fused && overflow) {
+      pending_zero_ = true;  // the tail had no complete list to zero the batch's pairs through: k_pt_zero does it by key
+      fused_overflows++;
+    }
     if (multi()) {
       overflow = *(const unsigned long long *)(h + 72);  // ranks whose list overflowed
       if (settle_exchange(*(const unsigned long long *)(h + 56), *(const unsigned long long *)(h + 64), *(const unsigned long long *)(h + 80))) {
@@ -999,6 +1011,17 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
       sync();
     }
     out.assign(h_c, h_c + take);
+    if (const char *dbg = getenv("YTTM_DBG_CAND")) {  // debugging aid: one line per scan, comparable across scan implementations
+      static FILE *f = nullptr;
+      if (!f) f = fopen(dbg, "w");
+      unsigned long long hx = 0, hsum = 0;
+      for (unsigned int i = 0; i < take; i++) hx ^= mix64(out[i].key * 31 + out[i].cnt);
+      const unsigned long long *hh = (const unsigned long long *)(h + MB_HIST);
+      for (int b = 0; b < CAND_BINS; b++) hsum += hh[b] * (unsigned long long)(b + 1);
+      if (f) fprintf(f, "r=%llu fused=%d tau=%llu mx=%u hot_tau=%llu n=%u live=%u nkeys=%u cand=%016llx hist=%llu\n", merge_rounds, (int)use_fused, t, tm,
+                     pt_.hot_tau, n, live, hdr[1], hx, hsum);
+      if (f) fflush(f);
+    }
     return n;
   }
 }
@@ -1108,7 +1131,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   ScanArgs sa{};
   fused_pending_ = false;
   if (next_tau_cnt && fuse_enabled_ && !multi() && hot_state_ == HOT_ACTIVE && cls_[0].n_tiles && !cls_[1].n_tiles && !cls_[2].n_tiles && !instrument) {
-    sa.on = 1;
+    sa.on = getenv("YTTM_TAIL_NOCOMPACT") ? 3u : 1u;
     sa.tau_cnt = *next_tau_cnt;
     sa.tau_mx = next_tau_mx;
     if (sa.tau_cnt < pt_.hot_tau) {  // the list is complete only from hot_tau up (as in candidates())

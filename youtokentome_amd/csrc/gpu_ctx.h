@@ -80,6 +80,8 @@ class GpuCtx {
   uint32_t scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist);
   unsigned long long hot_tau() const { return hot_state_ == HOT_ACTIVE ? pt_.hot_tau : 1; }
   unsigned long long hot_rebuilds = 0, rehashes = 0, exchange_retries = 0;
+  unsigned long long tail_ticks[3] = {0, 0, 0}, tail_listed = 0;  // round_tail: fold / list scan / publish, in 10 ns ticks; entries it read
+  unsigned long long fused_rounds = 0, fused_overflows = 0;  // rounds whose candidate scan ran in the apply kernel's tail; of those, with a hot-list overflow
   unsigned long long table_capacity() const { return pt_cap_; }
 
   void sync();

@@ -104,7 +104,10 @@ __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, co
 // are serial), and one workgroup folds the rows into the totals when somebody needs them (fold_blk_stats).
 constexpr int BLK_BASE = 32, BLK_ROWS = 1536;  // >= the largest grid of k_filter / k_tiles<.., true>  // j: 0..3 = the K4 counters, 4 = pair-table slots claimed
 __device__ inline void blk_add(unsigned long long *stats, int j, unsigned long long v) {
-  if (v) stats[BLK_BASE + 8 * (blockIdx.x % BLK_ROWS) + j] += v;
+  // (the row is this workgroup's alone; the store is write-through because the round's tail may read it from another XCD before
+  // any cache write-back -- see round_tail)
+  unsigned long long *p = &stats[BLK_BASE + 8 * (blockIdx.x % BLK_ROWS) + j];
+  if (v) __hip_atomic_store(p, *p + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // called by ONE workgroup of 256 threads, all threads; ends with the totals in stats[0..3] and *n_keys
 __device__ inline void fold_blk_stats(unsigned long long *stats, unsigned int *n_keys) {
@@ -893,8 +896,9 @@ __device__ inline void round_tail(const PairTable &pt, const ScanArgs &sa, unsig
   unsigned int *ctl = lds + CAND_BINS + 32;   // [0] kept so far, [1] candidates, [2..11] fold accumulators (u64 x 5)
   unsigned long long *facc = reinterpret_cast<unsigned long long *>(lds + CAND_BINS + 40);
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long tm0 = (unsigned long long)wall_clock64();  // 100 MHz; the marks travel in the mailbox (bytes 96..127)
   for (int b = tid; b < CAND_BINS; b += NT) lh[b] = 0;
-  if (tid < 2) ctl[tid] = 0;
+  if (tid < 3) ctl[tid] = 0;
   if (tid < 5) facc[tid] = 0;
   __syncthreads();
   {  // ---- 1. statistics rows (written by the workgroups of this and earlier launches with plain stores)
@@ -920,54 +924,71 @@ __device__ inline void round_tail(const PairTable &pt, const ScanArgs &sa, unsig
     if (tid < 4 && facc[tid]) stats[tid] += facc[tid];
     if (tid == 4 && facc[4]) atomicAdd(pt.n_keys, (unsigned int)facc[4]);
   }
-  // ---- 2. the hot list
+  const unsigned long long tm1 = (unsigned long long)wall_clock64();
+  // ---- 2. the hot list.  A pass takes NT * TAIL_E entries, TAIL_E per thread, and has two dependent memory round trips (the slot
+  // numbers, then the records) however many entries it takes: all loads of a round trip are in flight together.
   const unsigned int hn_raw = __hip_atomic_load(pt.hot_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const bool overflow = hn_raw > pt.hot_cap;  // entries were dropped: the host rebuilds the list, nothing to scan
   const unsigned int hn = overflow ? 0u : hn_raw;
   uint4 *mb_out = reinterpret_cast<uint4 *>(sa.mailbox + 8192);
-  for (unsigned int base = 0; base < hn; base += NT) {
-    const unsigned int i = base + (unsigned int)tid;
-    const bool valid = i < hn;
-    uint32_t sl = 0;
-    unsigned long long k = PT_EMPTY, c = 0;
-    if (valid) {
-      sl = __hip_atomic_load(&pt.hot_slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      k = ld_agent(pt.key_p(sl));
-      c = ld_agent(pt.cnt_p(sl)) & PT_CNT;
-      if (c && (k == zself || zprobe.has((uint32_t)(k >> 32), (uint32_t)k))) c = 0;  // a pair of the finished batch
+  constexpr int TAIL_E = 8;
+  for (unsigned int base = 0; base < hn; base += NT * TAIL_E) {
+    uint32_t sl[TAIL_E];
+    unsigned long long k[TAIL_E], c[TAIL_E];
+#pragma unroll
+    for (int e = 0; e < TAIL_E; e++) {
+      const unsigned int i = base + (unsigned int)(e * NT + tid);
+      sl[e] = i < hn ? __hip_atomic_load(&pt.hot_slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
     }
-    const bool keep = valid && c >= pt.hot_tau && c > 0;
-    if (valid) *pt.cnt_p(sl) = keep ? (c | PT_HOT) : c;  // (a count that was zeroed is stored as 0; a dropped entry loses PT_HOT)
-    bool pass = false;
-    if (keep) {
-      atomicAdd(&lh[cand_bin(c)], 1u);
-      const uint32_t x = (uint32_t)(k >> 32), y = (uint32_t)k;
-      const uint32_t mx = x > y ? x : y;
-      pass = c > sa.tau_cnt || (c == sa.tau_cnt && mx <= sa.tau_mx);
+#pragma unroll
+    for (int e = 0; e < TAIL_E; e++) {
+      k[e] = PT_EMPTY;
+      c[e] = 0;
+      if (sl[e] != 0xffffffffu) {
+        k[e] = ld_agent(pt.key_p(sl[e]));
+        c[e] = ld_agent(pt.cnt_p(sl[e]));
+      }
     }
-    const unsigned long long km = __ballot(keep), pm = __ballot(pass);
-    if (lane == 0) wcount[wave] = (unsigned int)__popcll(km);
-    if (pm) {
-      unsigned int ob = 0;
-      if (lane == 0) ob = atomicAdd(&ctl[1], (unsigned int)__popcll(pm));
-      ob = __shfl(ob, 0);
-      if (pass) {
-        const unsigned int o = ob + (unsigned int)__popcll(pm & lanemask_lt());
-        if (o < sa.cap) {
-          sa.out[o].key = k;
-          sa.out[o].cnt = c;
-        }
-        if (o < sa.fast) {
-          uint4 v;
-          v.x = (uint32_t)k; v.y = (uint32_t)(k >> 32); v.z = (uint32_t)c; v.w = (uint32_t)(c >> 32);
-          mb_out[o] = v;
+    uint32_t keepm = 0;  // bit e: entry e stays on the list
+#pragma unroll
+    for (int e = 0; e < TAIL_E; e++) {
+      if (sl[e] == 0xffffffffu) continue;
+      unsigned long long cc = c[e] & PT_CNT;
+      if (cc && (k[e] == zself || zprobe.has((uint32_t)(k[e] >> 32), (uint32_t)k[e]))) cc = 0;  // a pair of the finished batch
+      const bool live_e = cc >= pt.hot_tau && cc > 0;
+      const bool keep = (sa.on & 2u) ? true : live_e;  // (bit 1 of `on`, a debugging aid: no compaction, every entry stays listed)
+      const unsigned long long want = keep ? (cc | PT_HOT) : cc;  // a dropped entry loses PT_HOT and can come back; a zeroed count is stored
+      if (want != c[e]) *pt.cnt_p(sl[e]) = want;
+      if (keep) keepm |= 1u << e;
+      if (live_e) {
+        atomicAdd(&lh[cand_bin(cc)], 1u);
+        atomicAdd(&ctl[2], 1u);
+        const uint32_t x = (uint32_t)(k[e] >> 32), y = (uint32_t)k[e];
+        const uint32_t mx = x > y ? x : y;
+        if (cc > sa.tau_cnt || (cc == sa.tau_cnt && mx <= sa.tau_mx)) {
+          const unsigned int o = atomicAdd(&ctl[1], 1u);
+          if (o < sa.cap) {
+            sa.out[o].key = k[e];
+            sa.out[o].cnt = cc;
+          }
+          if (o < sa.fast) {
+            uint4 v;
+            v.x = (uint32_t)k[e]; v.y = (uint32_t)(k[e] >> 32); v.z = (uint32_t)cc; v.w = (uint32_t)(cc >> 32);
+            mb_out[o] = v;
+          }
         }
       }
     }
-    __syncthreads();  // every entry of this pass has been read: the kept ones move down
-    unsigned int before = ctl[0];
-    for (int w = 0; w < wave; w++) before += wcount[w];
-    if (keep) pt.hot_slots[before + (unsigned int)__popcll(km & lanemask_lt())] = sl;
+    // compaction: the kept entries of this pass move down behind those of the earlier passes (any order)
+    const uint32_t mine = (uint32_t)__popc(keepm);
+    const uint32_t incl = wave_incl_scan(mine);
+    if (lane == 63) wcount[wave] = incl;
+    __syncthreads();  // every entry of this pass has been read
+    unsigned int pos = ctl[0] + incl - mine;
+    for (int w = 0; w < wave; w++) pos += wcount[w];
+#pragma unroll
+    for (int e = 0; e < TAIL_E; e++)
+      if ((keepm >> e) & 1u) pt.hot_slots[pos++] = sl[e];
     __syncthreads();
     if (tid == 0) {
       unsigned int t = 0;
@@ -977,17 +998,20 @@ __device__ inline void round_tail(const PairTable &pt, const ScanArgs &sa, unsig
     __syncthreads();
   }
   // ---- 3. publish
+  const unsigned long long tm2 = (unsigned long long)wall_clock64();
   unsigned int *mb_hdr = reinterpret_cast<unsigned int *>(sa.mailbox);
   unsigned long long *mb_hist = reinterpret_cast<unsigned long long *>(sa.mailbox + MB_HIST);
   if (tid == 0) {
     mb_hdr[0] = ctl[1];                                                                          // candidates
     mb_hdr[1] = __hip_atomic_load(pt.n_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // keys in the table
     mb_hdr[2] = hn_raw;                                                                          // listed (before the compaction)
-    mb_hdr[3] = ctl[0];                                                                          // still >= hot_tau
+    mb_hdr[3] = ctl[2];                                                                          // still >= hot_tau
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 40) = stats[2];  // tokens streamed so far (repack trigger)
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 48) = stats[1];  // tiles that held a merge site so far
     if (!overflow) *pt.hot_n = ctl[0];
     *sa.done_ctr = 0;
+    unsigned long long *mb_t = reinterpret_cast<unsigned long long *>(sa.mailbox + 96);
+    mb_t[0] = tm0; mb_t[1] = tm1; mb_t[2] = tm2; mb_t[3] = (unsigned long long)wall_clock64();
   }
   if (tid >= 6 && tid < 10) *reinterpret_cast<unsigned long long *>(sa.mailbox + 56 + 8 * (tid - 6)) = 0;  // (multi-GPU fields)
   for (int b = tid; b < CAND_BINS; b += NT) mb_hist[b] = (unsigned long long)lh[b];
@@ -1211,13 +1235,16 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     }
   }
   if (MERGE && sa.on) {  // the round's candidate scan, by the last workgroup to get here (round_tail)
+    // Everything this workgroup leaves for the tail went out as device-scope atomics or write-through stores (pair table, hot
+    // list, statistics row), so the ticket only has to wait until those have completed -- a workgroup-scope release: an
+    // agent-scope one would also write the XCD's L2 back, once per workgroup (measured: +150 us per round at 768 workgroups).
     __shared__ unsigned int is_last;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) is_last = atomicAdd(sa.done_ctr, 1u) == gridDim.x - 1;
     __syncthreads();
     if (is_last) {
-      __threadfence();
+      __threadfence();  // (acquire: nothing stale in this CU's caches)
       static_assert(sizeof(WL) >= (CAND_BINS + 80) * sizeof(unsigned int), "tile buffers double as the tail's scratch");
       const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
       round_tail<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]));

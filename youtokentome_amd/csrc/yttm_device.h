@@ -133,7 +133,9 @@ __device__ inline void pt_add(const PairTable &pt, unsigned long long key, long 
           const unsigned long long o2 = atomicOr(pt.cnt_p(i), PT_HOT);
           if (!(o2 & PT_HOT)) {
             const unsigned int j = atomicAdd(pt.hot_n, 1u);
-            if (j < pt.hot_cap) pt.hot_slots[j] = (uint32_t)i;
+            // (a write-through store: the workgroup that scans the list at the end of THIS launch -- k_merge.hip round_tail -- may
+            // sit on another XCD, whose L2 does not see plain stores before a cache write-back)
+            if (j < pt.hot_cap) __hip_atomic_store(&pt.hot_slots[j], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       } else {
