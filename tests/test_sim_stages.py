@@ -120,19 +120,19 @@ def test_hot_list_rebuilds(tmp_path, monkeypatch):
         S.check_train_vs_oracle(text, 150, tmp_path, tag=f"hot{target}")
 
 
-def test_hot_list_overflow_in_a_fused_round(tmp_path, monkeypatch):
-    """The hot list overflows while the candidate scan rides in the apply kernel's tail (which then has no complete list to
-    zero the finished batch's pairs through): the rebuild that follows must still see those pairs at zero."""
+def test_list_overflow_in_a_fused_round(tmp_path, monkeypatch):
+    """The top list overflows while the candidate scan rides in the apply kernel's tail (which then has no complete list to zero
+    the finished batch's pairs through): the refill that follows must still see those pairs at zero.  Same for the hot list."""
     import ctypes as C
     import json
     import filecmp
     from youtokentome_amd import _lib
     L = _lib.load()
-    monkeypatch.setenv("YTTM_HOT_MIN", "1")  # never "running dry": only overflows rebuild the list
-    seen = 0
-    for target, cap in ((40, 128), (100, 256), (16, 40), (300, 640)):
-        monkeypatch.setenv("YTTM_HOT_TARGET", str(target))
-        monkeypatch.setenv("YTTM_HOT_CAP", str(cap))
+    seen = fused = 0
+    # (hot target, hot cap, top target, top cap, top min)
+    for ht, hc, tt, tc, tm in ((400, 4096, 8, 24, 1), (400, 4096, 30, 80, 1), (40, 128, 8, 24, 1), (100, 256, 16, 40, 4)):
+        for k, v in (("YTTM_HOT_TARGET", ht), ("YTTM_HOT_CAP", hc), ("YTTM_HOT_MIN", 1), ("YTTM_TOP_TARGET", tt), ("YTTM_TOP_CAP", tc), ("YTTM_TOP_MIN", tm)):
+            monkeypatch.setenv(k, str(v))
         for name in ("zipf", "readme_small", "mix_cov"):
             a = json.load(open(os.path.join(S.G, f"train_{name}.args.json")))
             out = str(tmp_path / f"{name}.model")
@@ -140,11 +140,11 @@ def test_hot_list_overflow_in_a_fused_round(tmp_path, monkeypatch):
             rc = L.yttm_train_bpe_ex(os.path.join(S.G, f"train_{name}.txt").encode(), out.encode(), a["vocab"], a["coverage"], 1, a["pad"], a["unk"],
                                      a["bos"], a["eos"], 0, rep, 16384, err, 2048)
             assert rc == 0, err.value
-            assert filecmp.cmp(out, os.path.join(S.G, f"train_{name}.model"), shallow=False), (name, target, cap)
+            assert filecmp.cmp(out, os.path.join(S.G, f"train_{name}.model"), shallow=False), (name, ht, hc, tt, tc)
             r = json.loads(rep.value.decode())
-            assert r["fused_rounds"] > 0
+            fused += r["fused_rounds"]
             seen += r["fused_overflows"]
-    assert seen > 0, "no configuration overflowed the list during a fused round: the test does not test what it says"
+    assert fused > 0 and seen > 0, "no configuration overflowed the top list during a fused round: the test does not test what it says"
 
 
 def test_worklist_mode(tmp_path, monkeypatch):

@@ -138,6 +138,7 @@ static T *dmalloc(size_t n) {
 
 constexpr unsigned int CAND_CAP = 1u << 20;
 constexpr unsigned int HOT_CAP = 1u << 18;  // hot-list slots (entries appended between rebuilds included)
+constexpr unsigned int TOP_CAP = 1u << 13;  // top-list slots
 // a rebuild picks the threshold that lists about HOT_TARGET pairs; fewer live entries than HOT_MIN: lower the threshold.
 // YTTM_HOT_TARGET / YTTM_HOT_MIN / YTTM_HOT_CAP override them (the test-suite shrinks them to exercise rebuilds on tiny corpora).
 static unsigned int env_uint(const char *name, unsigned int dflt) {
@@ -164,10 +165,16 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   hot_target_ = env_uint("YTTM_HOT_TARGET", 1u << 13);  // measured at 1 GB: 4096..16384 equal on the abcd corpus, 8192 best on Zipf text (4279 rounds)
   hot_min_ = env_uint("YTTM_HOT_MIN", 512);
   dense_pct_ = env_uint("YTTM_DENSE_PCT", 0);
-  fuse_enabled_ = env_uint("YTTM_NO_FUSE", 0) == 0 && env_uint("YTTM_FUSE", 0) != 0;  // (off until the tail scans a short list: measured slower)
+  fuse_enabled_ = env_uint("YTTM_NO_FUSE", 0) == 0;
   d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);
   d_hot_n_ = dmalloc<unsigned int>(4);  // [0] list length, [1] k_hot_scan's finished-workgroup ticket, [2..3] overflow verdict (u64)
   HIP_CHECK(hipMemset(d_hot_n_, 0, 16));
+  top_cap_ = std::max(16u, std::min(env_uint("YTTM_TOP_CAP", TOP_CAP), TOP_CAP));
+  top_target_ = env_uint("YTTM_TOP_TARGET", 1024);  // about four times what the host looks at per round
+  top_min_ = env_uint("YTTM_TOP_MIN", 192);
+  d_top_slots_ = dmalloc<uint32_t>(TOP_CAP);
+  d_top_n_ = dmalloc<unsigned int>(4);
+  HIP_CHECK(hipMemset(d_top_n_, 0, 16));
   HIP_CHECK(hipMemset(d_round_, 0, 8192));  // k_hot_scan leaves its counters zeroed for the next call
   d_cand_n_ = (unsigned int *)d_round_;
   d_cand_hist_ = (unsigned long long *)(d_round_ + 64);
@@ -193,7 +200,7 @@ GpuCtx::~GpuCtx() {
   for (hipEvent_t e : all_events_) (void)hipEventDestroy(e);
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_); DFREE(d_flagbits_);
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
-  DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_);
+  DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_); DFREE(d_top_slots_); DFREE(d_top_n_); DFREE(d_box_);
   DFREE(d_send_); DFREE(d_xstat_);
   db_.recs = nullptr; db_.n = nullptr;
   free_table(pt_);
@@ -674,7 +681,12 @@ void GpuCtx::alloc_table(PairTable &pt, unsigned long long cap) {
   pt.hot_slots = d_hot_slots_;
   pt.hot_n = d_hot_n_;
   pt.hot_cap = hot_cap_;
+  pt.top_tau = ~0ull;
+  pt.top_slots = d_top_slots_;
+  pt.top_n = d_top_n_;
+  pt.top_cap = top_cap_;
   hot_state_ = HOT_INVALID;
+  top_state_ = TOP_INVALID;
   launch_pt_clear(pt, st_);
   HIP_CHECK(hipMemsetAsync(pt.n_keys, 0, 16, st_));
 }
@@ -777,6 +789,7 @@ void GpuCtx::pair_count() {
       HIP_CHECK(hipMemcpyAsync(d_send_, &hdr, sizeof hdr, hipMemcpyHostToDevice, st_));
       sync();
       d_xstat_ = dmalloc<unsigned long long>(4);
+      if (!d_box_) d_box_ = dmalloc<unsigned char>(8192 + 4096 * sizeof(CandRec));  // a scan result waiting for the ranks' verdicts
       HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, st_));
       blk_min_ = std::max(2u, env_uint("YTTM_XCHG_BLK_MIN", 4096));  // (tests shrink it to force the repeat path)
       blk_ = blk_min_;
@@ -854,6 +867,8 @@ void GpuCtx::rebuild_hot() {
   std::vector<CandRec> none;
   unsigned long long hist[CAND_BINS];
   pt_.hot_tau = ~0ull;
+  pt_.top_tau = ~0ull;  // (the top list is refilled from the new hot list; k_hot_rebuild clears every PT_TOP)
+  top_state_ = TOP_INVALID;
   scan_full(~0ull >> 1, 0, none, hist);
   unsigned long long acc = 0;
   int chosen = -1;
@@ -875,6 +890,7 @@ void GpuCtx::rebuild_hot() {
   launch_hot_rebuild(pt_, st_);
   t_end(KT_CAND, 8 * pt_cap_);
   hot_state_ = HOT_ACTIVE;
+  hot_just_rebuilt_ = true;
 }
 
 // multi-GPU: what the fold kernel of this round's exchange reported (ranks whose block was too small, the largest record count,
@@ -902,6 +918,101 @@ bool GpuCtx::settle_exchange(unsigned long long xmask, unsigned long long xmax, 
   return true;
 }
 
+// Waits for `round_id` in the pinned mailbox: the kernel that publishes it writes header + histogram + first candidates there
+// first (a copy + stream synchronisation would cost tens of microseconds per round).
+void GpuCtx::poll_mailbox(uint32_t round_id) {
+  unsigned char *h = (unsigned char *)h_pin_;
+  volatile uint32_t *flag = (volatile uint32_t *)(h + 32);
+  for (unsigned long long spins = 0; *flag != round_id; spins++) {
+    if ((spins & 0x3fff) == 0x3fff) {
+      const hipError_t q = hipStreamQuery(st_);
+      if (q == hipSuccess) {
+        if (*flag != round_id) throw GpuError{"candidate mailbox was not published"};
+      } else if (q != hipErrorNotReady) {
+        throw GpuError{std::string("candidate filter: ") + hipGetErrorString(q)};
+      }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const unsigned long long cum = *(const unsigned long long *)(h + 40);
+  if (cum != scanned_cum_) {  // a merge round ran since the last call: that is how many tokens its filters streamed
+    live_tokens_last_ = cum - scanned_cum_;
+    scanned_cum_ = cum;
+    const unsigned long long touched = *(const unsigned long long *)(h + 48);
+    touched_last_ = touched - touched_cum_;
+    touched_cum_ = touched;
+  }
+}
+
+// One scan of the hot list (L1) by k_hot_scan -- every listed slot, many workgroups: candidates above (t, tm), histogram of the
+// live counts, the pending zeroing of the finished batch's pairs.  Leaves the result in the mailbox.  False: the exchange of
+// this round had to be completed first (multi-GPU), scan again.
+bool GpuCtx::scan_hot(unsigned long long t, uint32_t tm) {
+  constexpr unsigned int CAND_FAST = 4096;
+  unsigned char *h = (unsigned char *)h_pin_;
+  const uint32_t round_id = ++mail_round_;
+  t_begin(KT_CAND);
+  launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_,
+                  pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, listed_last_ ? listed_last_ + 4096 : hot_cap_,
+                  pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, multi() ? d_xstat_ : nullptr, st_);
+  if (multi()) {
+    // how many slots a rank's order of updates happened to put on its lists -- and so whether a list overflowed -- is the one
+    // rank-dependent quantity of a round: the verdicts are summed in stream order, then one workgroup publishes
+    comm_->allreduce_sum_u64_async(d_xstat_ + 2, 1, st_);
+    launch_publish(pt_, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_, d_xstat_, st_);
+  }
+  pending_zero_ = false;
+  t_end(KT_CAND, 20ull * listed_last_);  // (not chained: the host round trip that follows belongs to no kernel family)
+  poll_mailbox(round_id);
+  const unsigned int *hdr = (const unsigned int *)h;
+  n_keys_host = hdr[1];
+  listed_last_ = std::min(hdr[2], hot_cap_);
+  if (multi() && settle_exchange(*(const unsigned long long *)(h + 56), *(const unsigned long long *)(h + 64), *(const unsigned long long *)(h + 80))) return false;
+  return true;
+}
+
+// Refill of the top list (L2) from the hot list (L1): one scan of L1 for the histogram of its live counts, the threshold that
+// puts about top_target_ of them on the top list, one pass that lists them.  False: L1 itself has to be rebuilt first (it
+// overflowed or ran dry; hot_state_ says so) or the scan has to be repeated.
+bool GpuCtx::refill_top() {
+  unsigned char *h = (unsigned char *)h_pin_;
+  if (!scan_hot(~0ull >> 2, 0)) return false;
+  const unsigned int *hdr = (const unsigned int *)h;
+  const unsigned int listed = hdr[2], live = hdr[3];
+  const unsigned long long over = multi() ? (*(const unsigned long long *)(h + 72) & 0xffffffffull) : (listed > hot_cap_ ? 1ull : 0ull);
+  if (over || (live < hot_min_ && pt_.hot_tau > 1 && !hot_just_rebuilt_)) {
+    hot_state_ = HOT_INVALID;  // overflowed, or running dry: relist with a new threshold (a list that is short right after its
+    return false;              // rebuild stays: ties kept the threshold up)
+  }
+  hot_just_rebuilt_ = false;
+  const unsigned long long *hist = (const unsigned long long *)(h + MB_HIST);
+  unsigned long long acc = 0;
+  int chosen = -1;
+  for (int b = CAND_BINS - 1; b >= 1; b--) {
+    if (acc + hist[b] > top_cap_ / 2) break;
+    acc += hist[b];
+    chosen = b;
+    if (acc >= top_target_) break;
+  }
+  top_refills++;
+  if (chosen < 0 || (acc < top_min_ && acc < live)) {  // ties too large for the top list right below its first few entries: scan the hot list itself for a while
+    pt_.top_tau = ~0ull;
+    top_state_ = TOP_BYPASS;
+    bypass_rounds_ = 0;
+    return true;
+  }
+  pt_.top_tau = std::max<unsigned long long>(pt_.hot_tau, cand_bin_lower(chosen));
+  HIP_CHECK(hipMemsetAsync(d_top_n_, 0, 4, st_));
+  t_begin(KT_CAND);
+  launch_top_rebuild(pt_, listed_last_, st_);
+  t_end(KT_CAND, 20ull * listed_last_);
+  top_state_ = TOP_ACTIVE;
+  return true;
+}
+
+// Candidates for the host's pick (see gpu_ctx.h).  Three tiers: the top list (about a thousand slots, read by one workgroup --
+// in the tail of the round's apply kernel when the round is one launch), refilled from the hot list (tens of thousands, read by a
+// kernel of its own) when it runs dry or overflows, which is rebuilt from the whole table when IT runs dry or overflows.
 uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist) {
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
@@ -911,7 +1022,14 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     if (hist) memset(hist, 0, CAND_BINS * 8);
     return 0;
   }
+  constexpr unsigned int CAND_FAST = 4096;
+  unsigned char *h = (unsigned char *)h_pin_;
+  const bool fused_ok = fused_pending_ && fused_tau_ == tau_cnt && fused_mx_ == tau_mx;
+  fused_pending_ = false;  // (a scan that was fused but is not wanted any more is simply ignored)
+  int dry_refills = 0, dry_rebuilds = 0;
   for (int attempt = 0;; attempt++) {
+    if (attempt > 24) throw GpuError{"candidate lists do not settle"};
+    const bool use_fused = fused_ok && attempt == 0 && top_state_ == TOP_ACTIVE && hot_state_ == HOT_ACTIVE;
     if (multi() && hot_state_ != HOT_ACTIVE) {
       // whole-table scans ahead (list rebuild, or no list at all): they synchronise anyway, so the verdict of this round's
       // exchange is fetched directly instead of travelling with the mailbox
@@ -922,86 +1040,104 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
       settle_exchange(x[0], x[1], x[3]);
     }
     if (hot_state_ == HOT_FULLSCAN && ++fullscan_rounds_ >= 64) hot_state_ = HOT_INVALID;  // ties may have dissolved
-    if (hot_state_ == HOT_INVALID) rebuild_hot();
+    if (hot_state_ == HOT_INVALID) {
+      rebuild_hot();
+      top_state_ = TOP_INVALID;
+      pt_.top_tau = ~0ull;
+    }
     if (hot_state_ == HOT_FULLSCAN) return scan_full(tau_cnt, tau_mx, out, hist);
+    if (top_state_ == TOP_BYPASS && ++bypass_rounds_ >= 64) top_state_ = TOP_INVALID;
+    if (top_state_ == TOP_INVALID && !refill_top()) continue;
     unsigned long long t = tau_cnt;
     uint32_t tm = tau_mx;
-    if (t < pt_.hot_tau) {  // the list is complete only from hot_tau up
-      t = pt_.hot_tau;
+    const unsigned long long floor_tau = top_state_ == TOP_ACTIVE ? pt_.top_tau : pt_.hot_tau;
+    if (t < floor_tau) {  // a list is complete only from its threshold up
+      t = floor_tau;
       tm = 0xffffffffu;
     }
-    constexpr unsigned int CAND_FAST = 4096;
-    unsigned char *h = (unsigned char *)h_pin_;
-    const bool use_fused = fused_pending_ && fused_tau_ == tau_cnt && fused_mx_ == tau_mx && attempt == 0;
-    fused_pending_ = false;  // (a scan that was fused but is not wanted any more is simply ignored)
-    const uint32_t round_id = use_fused ? fused_round_ : ++mail_round_;
-    if (!use_fused) {
-    t_begin(KT_CAND);
-    launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_,
-                    pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, listed_last_ ? listed_last_ + 4096 : hot_cap_,
-                    pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, multi() ? d_xstat_ : nullptr, st_);
-    if (multi()) {
-      // how many slots a rank's order of updates happened to put on its hot list -- and so whether the list overflowed -- is the
-      // one rank-dependent quantity of a round: the verdicts are summed in stream order, then one workgroup publishes
-      comm_->allreduce_sum_u64_async(d_xstat_ + 2, 1, st_);
-      launch_publish(pt_, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_, d_xstat_, st_);
-    }
-    pending_zero_ = false;
-    t_end(KT_CAND, 20ull * listed_last_);  // (not chained: the host round trip that follows belongs to no kernel family)
-    }
-    {
-      // the kernel's last workgroup writes header + histogram + first candidates into the pinned mailbox and then the
-      // round id: poll for it (a copy + stream synchronisation costs tens of microseconds per round)
-      volatile uint32_t *flag = (volatile uint32_t *)(h + 32);
-      for (unsigned long long spins = 0; *flag != round_id; spins++) {
-        if ((spins & 0x3fff) == 0x3fff) {
-          const hipError_t q = hipStreamQuery(st_);
-          if (q == hipSuccess) {
-            if (*flag != round_id) throw GpuError{"candidate mailbox was not published"};
-          } else if (q != hipErrorNotReady) {
-            throw GpuError{std::string("candidate filter: ") + hipGetErrorString(q)};
-          }
-        }
-      }
-      std::atomic_thread_fence(std::memory_order_acquire);
-    }
-    {
-      const unsigned long long cum = *(const unsigned long long *)(h + 40);
-      if (cum != scanned_cum_) {  // a merge round ran since the last call: that is how many tokens its filters streamed
-        live_tokens_last_ = cum - scanned_cum_;
-        scanned_cum_ = cum;
-        const unsigned long long touched = *(const unsigned long long *)(h + 48);
-        touched_last_ = touched - touched_cum_;
-        touched_cum_ = touched;
-      }
-    }
-    const unsigned int *hdr = (const unsigned int *)h;
-    const unsigned int n = hdr[0], listed = hdr[2], live = hdr[3];
-    n_keys_host = hdr[1];
-    listed_last_ = std::min(use_fused ? live : listed, hot_cap_);  // (the fused scan compacts the list to its live entries)
-    unsigned long long overflow = listed > hot_cap_ ? 1 : 0;
-    if (use_fused) {
-      fused_rounds++;
-      const unsigned long long *tm = (const unsigned long long *)(h + 96);  // round_tail's marks (100 MHz wall clock)
-      tail_ticks[0] += tm[1] - tm[0];
-      tail_ticks[1] += tm[2] - tm[1];
-      tail_ticks[2] += tm[3] - tm[2];
-      tail_listed += listed;
-    }
-    if (use_fused && overflow) {
-      pending_zero_ = true;  // the tail had no complete list to zero the batch's pairs through: k_pt_zero does it by key
-      fused_overflows++;
-    }
-    if (multi()) {
-      overflow = *(const unsigned long long *)(h + 72);  // ranks whose list overflowed
-      if (settle_exchange(*(const unsigned long long *)(h + 56), *(const unsigned long long *)(h + 64), *(const unsigned long long *)(h + 80))) {
-        attempt--;  // the table was completed: scan again
+    unsigned int n = 0, live = 0;
+    bool hot_over = false, top_over = false;
+    if (top_state_ == TOP_BYPASS) {
+      if (!scan_hot(t, tm)) continue;
+      const unsigned int *hdr = (const unsigned int *)h;
+      n = hdr[0];
+      live = hdr[3];
+      hot_over = multi() ? (*(const unsigned long long *)(h + 72) & 0xffffffffull) != 0 : hdr[2] > hot_cap_;
+      if (hot_over || (live < hot_min_ && pt_.hot_tau > 1 && dry_rebuilds < 1)) {
+        if (!hot_over) dry_rebuilds++;
+        hot_state_ = HOT_INVALID;
         continue;
       }
-    }
-    if (attempt < 2 && (overflow || (live < hot_min_ && pt_.hot_tau > 1))) {
-      hot_state_ = HOT_INVALID;  // overflowed, or running dry: relist with a new threshold
-      continue;
+    } else {
+      const uint32_t round_id = use_fused ? fused_round_ : ++mail_round_;
+      if (!use_fused) {
+        ScanArgs sa{};
+        sa.on = 1;
+        sa.tau_cnt = t;
+        sa.tau_mx = tm;
+        sa.out = d_cand_;
+        sa.cap = cand_cap_;
+        sa.fast = CAND_FAST;
+        sa.done_ctr = nullptr;
+        sa.mailbox = multi() ? d_box_ : h;
+        sa.round_id = multi() ? 0u : round_id;
+        t_begin(KT_CAND);
+        launch_top_scan(pt_, sa, d_stats_, pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_,
+                        pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, multi() ? d_xstat_ : nullptr, st_);
+        if (multi()) {
+          comm_->allreduce_sum_u64_async(d_xstat_ + 2, 1, st_);  // the ranks' list-overflow verdicts (see scan_hot)
+          launch_publish_box(d_box_, h, CAND_FAST, round_id, d_xstat_, st_);
+        }
+        pending_zero_ = false;
+        t_end(KT_CAND, 20ull * top_listed_last_);
+      }
+      poll_mailbox(round_id);
+      const unsigned int *hdr = (const unsigned int *)h;
+      n = hdr[0];
+      n_keys_host = hdr[1];
+      const unsigned int top_listed = hdr[2], hot_listed = hdr[4];
+      live = hdr[3];
+      top_listed_last_ = std::min(live, top_cap_);
+      hot_over = hot_listed > hot_cap_;
+      top_over = top_listed > top_cap_;
+      if (use_fused) {
+        fused_rounds++;
+        const unsigned long long *tmk = (const unsigned long long *)(h + 96);  // scan_top's marks (100 MHz wall clock)
+        tail_ticks[0] += tmk[1] - tmk[0];
+        tail_ticks[1] += tmk[2] - tmk[1];
+        tail_ticks[2] += tmk[3] - tmk[2];
+        tail_listed += top_listed;
+        if (top_over) fused_overflows++;
+      }
+      if (multi()) {
+        const unsigned long long v = *(const unsigned long long *)(h + 72);  // ranks whose hot list / top list overflowed
+        hot_over = (v & 0xffffffffull) != 0;
+        top_over = (v >> 32) != 0;
+      }
+      // a scan that found its list overflowed read nothing -- and so did not zero the finished batch's pairs: k_pt_zero /
+      // the next scan does it (the batch is still described by the zero_* members)
+      if (top_over) pending_zero_ = zero_valid_;
+      if (multi() && settle_exchange(*(const unsigned long long *)(h + 56), *(const unsigned long long *)(h + 64), *(const unsigned long long *)(h + 80))) continue;
+      if (hot_over) {
+        hot_state_ = HOT_INVALID;
+        continue;
+      }
+      if (top_over) {
+        top_state_ = TOP_INVALID;
+        continue;
+      }
+      if (live < top_min_) {  // running dry: a lower threshold for the top list; at the hot list's own threshold, for that one
+        if (pt_.top_tau > pt_.hot_tau && dry_refills < 1) {  // (once per call: large ties can leave a refilled list short)
+          dry_refills++;
+          top_state_ = TOP_INVALID;
+          continue;
+        }
+        if (pt_.top_tau <= pt_.hot_tau && live < hot_min_ && pt_.hot_tau > 1 && dry_rebuilds < 1) {
+          dry_rebuilds++;
+          hot_state_ = HOT_INVALID;
+          continue;
+        }
+      }
     }
     if (hist) memcpy(hist, h + MB_HIST, CAND_BINS * 8);
     const unsigned int take = std::min(n, cand_cap_);
@@ -1014,12 +1150,10 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     if (const char *dbg = getenv("YTTM_DBG_CAND")) {  // debugging aid: one line per scan, comparable across scan implementations
       static FILE *f = nullptr;
       if (!f) f = fopen(dbg, "w");
-      unsigned long long hx = 0, hsum = 0;
+      unsigned long long hx = 0;
       for (unsigned int i = 0; i < take; i++) hx ^= mix64(out[i].key * 31 + out[i].cnt);
-      const unsigned long long *hh = (const unsigned long long *)(h + MB_HIST);
-      for (int b = 0; b < CAND_BINS; b++) hsum += hh[b] * (unsigned long long)(b + 1);
-      if (f) fprintf(f, "r=%llu fused=%d tau=%llu mx=%u hot_tau=%llu n=%u live=%u nkeys=%u cand=%016llx hist=%llu\n", merge_rounds, (int)use_fused, t, tm,
-                     pt_.hot_tau, n, live, hdr[1], hx, hsum);
+      if (f) fprintf(f, "r=%llu fused=%d tau=%llu mx=%u hot_tau=%llu top_tau=%llu n=%u live=%u nkeys=%llu cand=%016llx\n", merge_rounds, (int)use_fused, t, tm,
+                     pt_.hot_tau, pt_.top_tau, n, live, n_keys_host, hx);
       if (f) fflush(f);
     }
     return n;
@@ -1130,12 +1264,13 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // one launch per round: the apply kernel's last workgroup also does the candidate scan (see gpu_ctx.h)
   ScanArgs sa{};
   fused_pending_ = false;
-  if (next_tau_cnt && fuse_enabled_ && !multi() && hot_state_ == HOT_ACTIVE && cls_[0].n_tiles && !cls_[1].n_tiles && !cls_[2].n_tiles && !instrument) {
-    sa.on = getenv("YTTM_TAIL_NOCOMPACT") ? 3u : 1u;
+  if (next_tau_cnt && fuse_enabled_ && !multi() && hot_state_ == HOT_ACTIVE && top_state_ == TOP_ACTIVE && cls_[0].n_tiles && !cls_[1].n_tiles &&
+      !cls_[2].n_tiles && !instrument) {
+    sa.on = 1u;
     sa.tau_cnt = *next_tau_cnt;
     sa.tau_mx = next_tau_mx;
-    if (sa.tau_cnt < pt_.hot_tau) {  // the list is complete only from hot_tau up (as in candidates())
-      sa.tau_cnt = pt_.hot_tau;
+    if (sa.tau_cnt < pt_.top_tau) {  // the list is complete only from top_tau up (as in candidates())
+      sa.tau_cnt = pt_.top_tau;
       sa.tau_mx = 0xffffffffu;
     }
     sa.out = d_cand_;

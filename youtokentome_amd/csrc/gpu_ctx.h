@@ -79,7 +79,7 @@ class GpuCtx {
   // the same over the whole table (one streaming pass)
   uint32_t scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist);
   unsigned long long hot_tau() const { return hot_state_ == HOT_ACTIVE ? pt_.hot_tau : 1; }
-  unsigned long long hot_rebuilds = 0, rehashes = 0, exchange_retries = 0;
+  unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0;
   unsigned long long tail_ticks[3] = {0, 0, 0}, tail_listed = 0;  // round_tail: fold / list scan / publish, in 10 ns ticks; entries it read
   unsigned long long fused_rounds = 0, fused_overflows = 0;  // rounds whose candidate scan ran in the apply kernel's tail; of those, with a hot-list overflow
   unsigned long long table_capacity() const { return pt_cap_; }
@@ -108,6 +108,16 @@ class GpuCtx {
   void rebuild_hot();
   enum HotState { HOT_INVALID, HOT_ACTIVE, HOT_FULLSCAN };
   HotState hot_state_ = HOT_INVALID;
+  enum TopState { TOP_INVALID, TOP_ACTIVE, TOP_BYPASS };  // BYPASS: ties too large for the top list, the hot list is scanned instead
+  TopState top_state_ = TOP_INVALID;
+  uint32_t *d_top_slots_ = nullptr;
+  unsigned int *d_top_n_ = nullptr;
+  unsigned int top_cap_ = 0, top_target_ = 0, top_min_ = 0, top_listed_last_ = 0, bypass_rounds_ = 0;
+  unsigned char *d_box_ = nullptr;  // multi-GPU: staging block of a top-list scan (mailbox layout)
+  void poll_mailbox(uint32_t round_id);
+  bool scan_hot(unsigned long long t, uint32_t tm);
+  bool refill_top();
+  bool hot_just_rebuilt_ = false;
   uint32_t *d_hot_slots_ = nullptr;
   unsigned int *d_hot_n_ = nullptr;
   unsigned int fullscan_rounds_ = 0;

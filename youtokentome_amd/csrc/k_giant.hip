@@ -4,8 +4,9 @@
 // k_merge.hip keep a whole tile in LDS and stop at 2048 tokens per word.  Class C uses the same tile layout with a
 // run-time slot size (nominal = the longest word, slot = twice that) and ONE WORKGROUP per tile working in HBM.  Such
 // words are rare and their weight is almost always 1, so this path is written for exactness and simplicity, not speed:
-// a tile that contains a merge site is re-counted -- every adjacency of the old token sequence is retracted and every
-// adjacency of the new one is added, which nets out to exactly the deltas the tile kernels compute around the sites
+// a tile that contains a merge site is re-counted -- every adjacency of the old token sequence (but the merged pairs, which
+// are zeroed after the round) is retracted and every adjacency of the new one is added, which nets out to exactly the deltas the
+// tile kernels compute around the sites
 // (worker_doing_merge, bpe.cpp:491-812) without any of their case analysis.
 #include "yttm_device.h"
 #include "yttm_kernels.h"
@@ -30,15 +31,33 @@ __device__ inline void giant_emit(const PairTable &pt, const DeltaBuf &db, unsig
 
 // weighted adjacency counts of tok[0..n) (a run of L equal tokens counts floor(L/2) for its self pair,
 // emitted by the run's first token), each times sign * (frequency of its word)
+// `rules` / `self_x` (retraction pass only): the pairs of the batch being applied are left alone -- every occurrence of them is
+// merged and their counts are zeroed after the round, like in the tile kernels; retracting them here as well would depend on
+// the retraction reaching the table before that zeroing (multi-GPU: a delta block repeated after the first scan would not).
 __device__ inline void count_pairs(const uint32_t *tok, const uint32_t *wgt, int n, long long sign, const PairTable &pt, const DeltaBuf &db,
-                                   unsigned int *new_keys) {
+                                   unsigned int *new_keys, const RuleSlot *__restrict__ rules = nullptr, unsigned int rule_mask = 0,
+                                   uint32_t self_x = 0xffffffffu) {
   for (int p = (int)threadIdx.x; p + 1 < n; p += (int)blockDim.x) {
     const uint32_t t0 = ld32(&tok[p]), t1 = ld32(&tok[p + 1]);
     if (t1 & TOK_WS) continue;
     const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
     const long long f = sign * (long long)ld32(&wgt[p]);
     if (a != b) {
+      if (rules) {
+        const unsigned long long key = pair_key(a, b);
+        unsigned int h = pair_hash32(key) & rule_mask;
+        bool in_batch = false;
+        for (;;) {
+          const unsigned long long k = rules[h].key;
+          if (k == key) { in_batch = true; break; }
+          if (k == PT_EMPTY) break;
+          h = (h + 1) & rule_mask;
+        }
+        if (in_batch) continue;
+      }
       giant_emit(pt, db, pair_key(a, b), f, new_keys);
+    } else if (a == self_x) {
+      continue;
     } else {
       const bool run_start = (t0 & TOK_WS) || p == 0 || (ld32(&tok[p - 1]) & TOK_MASK) != a;
       if (run_start) {
@@ -127,7 +146,7 @@ __global__ __launch_bounds__(BLOCK) void k_giant(TileSet ts, unsigned int slot, 
       if (any_site) {  // uniform
         word_weights(tok, wgt, n, ts.wcnt, word0, scan_lds);
         __syncthreads();
-        count_pairs(tok, wgt, n, -1, pt, db, &new_keys);
+        count_pairs(tok, wgt, n, -1, pt, db, &new_keys, rules, rule_mask, self_x);
         __syncthreads();
         // ---- apply + compact into tok2 / wgt2 (rules of a batch cannot overlap; self-rule sites are two apart)
         if (threadIdx.x == 0) carry = 0;

@@ -878,67 +878,81 @@ __device__ inline int cand_bin(unsigned long long c) {
 }
 
 
-// The tail of a merge round (ScanArgs, yttm_kernels.h), run by the LAST workgroup of the apply kernel to finish -- every other
-// workgroup has published its updates (device-scope atomics, then a fence, then its ticket), nothing else touches the pair table.
+// The candidate scan of a merge round: ONE workgroup reads the top list (PairTable::top_slots, about a thousand entries).
+// Run by the LAST workgroup of the apply kernel to finish (ScanArgs, yttm_kernels.h; every other workgroup has published its
+// updates as device-scope atomics or write-through stores and then taken its ticket, nothing else touches the pair table), or as
+// a kernel of its own (k_top_scan) where a round is more than one launch.
 //   1. fold the per-workgroup statistics rows into the totals and the key count
-//   2. scan the hot list: zero the pairs of the batch just applied (every occurrence was merged), histogram the live counts,
-//      collect the candidates above the host's threshold -- and COMPACT the list in place: an entry whose count fell below
-//      hot_tau leaves the list (PT_HOT cleared, so it can come back), so the list stays as long as it has live entries and one
-//      workgroup reads it in a few round trips
-//   3. publish header, histogram and the first `fast` candidates in the pinned mailbox, then the round id (system-scope release)
+//   2. the top list: zero the pairs of the batch just applied (every occurrence was merged), histogram the live counts, collect
+//      the candidates above the host's threshold, and COMPACT the list in place: an entry whose count fell below top_tau leaves
+//      the list (PT_TOP cleared, so it can come back).  TAIL_E entries per thread and pass, two dependent memory round trips
+//      per pass (slot numbers, then records) with all loads of a round trip in flight together.
+//   3. header, histogram and the first `fast` candidates go to `box` -- the host's pinned mailbox (then the round id is
+//      published there, system-scope release: the host polls instead of copying and synchronising), or, multi-GPU, a staging
+//      block in HBM that k_publish forwards after the ranks' all-reduce.
+// Box layout: [0] candidates, [4] keys in the table, [8] top-list entries before the scan, [12] of those still >= top_tau,
+// [16] hot-list entries (overflow check), [32] round id, [40] tokens streamed so far, [48] tiles with a site so far, [56..87]
+// xstat (multi-GPU), [96..127] timing marks (100 MHz), [MB_HIST..) histogram, [8192..) candidates.
 // lds = at least (CAND_BINS + 80) words of scratch (the apply kernel's tile buffers are free by now).
 template <int NT>
-__device__ inline void round_tail(const PairTable &pt, const ScanArgs &sa, unsigned long long *__restrict__ stats, const RuleProbe &zprobe,
-                                  unsigned long long zself, unsigned int *lds) {
+__device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigned long long *__restrict__ stats, const RuleProbe &zprobe,
+                                unsigned long long zself, unsigned int *lds, unsigned long long *__restrict__ xstat) {
   constexpr int NW = NT / 64;
   unsigned int *lh = lds;                     // [CAND_BINS]
   unsigned int *wcount = lds + CAND_BINS;     // [NW] kept entries per wave of this pass
-  unsigned int *ctl = lds + CAND_BINS + 32;   // [0] kept so far, [1] candidates, [2..11] fold accumulators (u64 x 5)
-  unsigned long long *facc = reinterpret_cast<unsigned long long *>(lds + CAND_BINS + 40);
+  unsigned int *ctl = lds + CAND_BINS + 32;   // [0] kept so far, [1] candidates, [2] live entries
+  unsigned long long *facc = reinterpret_cast<unsigned long long *>(lds + CAND_BINS + 40);  // [5] fold accumulators
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned long long tm0 = (unsigned long long)wall_clock64();  // 100 MHz; the marks travel in the mailbox (bytes 96..127)
+  const unsigned long long tm0 = (unsigned long long)wall_clock64();
   for (int b = tid; b < CAND_BINS; b += NT) lh[b] = 0;
   if (tid < 3) ctl[tid] = 0;
   if (tid < 5) facc[tid] = 0;
   __syncthreads();
-  {  // ---- 1. statistics rows (written by the workgroups of this and earlier launches with plain stores)
+  {  // ---- 1. statistics rows (left by the workgroups of this and earlier launches, write-through): all loads in flight together
+    constexpr int RPT = (BLK_ROWS + NT - 1) / NT;
+    unsigned long long v[RPT][5];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      const int b = tid + r * NT;
+#pragma unroll
+      for (int jj = 0; jj < 5; jj++)
+        v[r][jj] = b < BLK_ROWS ? __hip_atomic_load(&stats[BLK_BASE + 8 * b + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
     unsigned long long a[5] = {0, 0, 0, 0, 0};
-    for (int b = tid; b < BLK_ROWS; b += NT) {
-      unsigned long long *row = stats + BLK_BASE + 8 * b;
-      bool any = false;
 #pragma unroll
-      for (int j = 0; j < 5; j++) {
-        const unsigned long long v = __hip_atomic_load(&row[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a[j] += v;
-        any = any || v != 0;
-      }
-      if (any) {
+    for (int r = 0; r < RPT; r++) {
+      const int b = tid + r * NT;
 #pragma unroll
-        for (int j = 0; j < 5; j++) row[j] = 0;
+      for (int jj = 0; jj < 5; jj++) {
+        a[jj] += v[r][jj];
+        if (v[r][jj]) stats[BLK_BASE + 8 * b + jj] = 0;
       }
     }
 #pragma unroll
-    for (int j = 0; j < 5; j++)
-      if (a[j]) atomicAdd(&facc[j], a[j]);
+    for (int jj = 0; jj < 5; jj++) {
+      const unsigned long long t = wave_sum_u64(a[jj]);
+      if (lane == 0 && t) atomicAdd(&facc[jj], t);
+    }
     __syncthreads();
     if (tid < 4 && facc[tid]) stats[tid] += facc[tid];
     if (tid == 4 && facc[4]) atomicAdd(pt.n_keys, (unsigned int)facc[4]);
   }
   const unsigned long long tm1 = (unsigned long long)wall_clock64();
-  // ---- 2. the hot list.  A pass takes NT * TAIL_E entries, TAIL_E per thread, and has two dependent memory round trips (the slot
-  // numbers, then the records) however many entries it takes: all loads of a round trip are in flight together.
-  const unsigned int hn_raw = __hip_atomic_load(pt.hot_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const bool overflow = hn_raw > pt.hot_cap;  // entries were dropped: the host rebuilds the list, nothing to scan
-  const unsigned int hn = overflow ? 0u : hn_raw;
-  uint4 *mb_out = reinterpret_cast<uint4 *>(sa.mailbox + 8192);
+  // ---- 2. the top list
+  const unsigned int tn_raw = __hip_atomic_load(pt.top_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned int hot_raw = __hip_atomic_load(pt.hot_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool overflow = tn_raw > pt.top_cap;  // entries were dropped: the host refills the list, nothing to scan
+  const unsigned int tn = overflow ? 0u : tn_raw;
+  uint4 *box_out = reinterpret_cast<uint4 *>(sa.mailbox + 8192);
   constexpr int TAIL_E = 8;
-  for (unsigned int base = 0; base < hn; base += NT * TAIL_E) {
+  unsigned int my_live = 0;
+  for (unsigned int base = 0; base < tn; base += NT * TAIL_E) {
     uint32_t sl[TAIL_E];
     unsigned long long k[TAIL_E], c[TAIL_E];
 #pragma unroll
     for (int e = 0; e < TAIL_E; e++) {
       const unsigned int i = base + (unsigned int)(e * NT + tid);
-      sl[e] = i < hn ? __hip_atomic_load(&pt.hot_slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+      sl[e] = i < tn ? __hip_atomic_load(&pt.top_slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
     }
 #pragma unroll
     for (int e = 0; e < TAIL_E; e++) {
@@ -955,14 +969,13 @@ __device__ inline void round_tail(const PairTable &pt, const ScanArgs &sa, unsig
       if (sl[e] == 0xffffffffu) continue;
       unsigned long long cc = c[e] & PT_CNT;
       if (cc && (k[e] == zself || zprobe.has((uint32_t)(k[e] >> 32), (uint32_t)k[e]))) cc = 0;  // a pair of the finished batch
-      const bool live_e = cc >= pt.hot_tau && cc > 0;
-      const bool keep = (sa.on & 2u) ? true : live_e;  // (bit 1 of `on`, a debugging aid: no compaction, every entry stays listed)
-      const unsigned long long want = keep ? (cc | PT_HOT) : cc;  // a dropped entry loses PT_HOT and can come back; a zeroed count is stored
+      const bool keep = cc >= pt.top_tau && cc > 0;
+      const unsigned long long want = (c[e] & PT_HOT) | (keep ? PT_TOP : 0ull) | cc;  // a dropped entry loses PT_TOP and can come back
       if (want != c[e]) *pt.cnt_p(sl[e]) = want;
-      if (keep) keepm |= 1u << e;
-      if (live_e) {
+      if (keep) {
+        keepm |= 1u << e;
+        my_live++;
         atomicAdd(&lh[cand_bin(cc)], 1u);
-        atomicAdd(&ctl[2], 1u);
         const uint32_t x = (uint32_t)(k[e] >> 32), y = (uint32_t)k[e];
         const uint32_t mx = x > y ? x : y;
         if (cc > sa.tau_cnt || (cc == sa.tau_cnt && mx <= sa.tau_mx)) {
@@ -972,9 +985,9 @@ __device__ inline void round_tail(const PairTable &pt, const ScanArgs &sa, unsig
             sa.out[o].cnt = cc;
           }
           if (o < sa.fast) {
-            uint4 v;
-            v.x = (uint32_t)k[e]; v.y = (uint32_t)(k[e] >> 32); v.z = (uint32_t)cc; v.w = (uint32_t)(cc >> 32);
-            mb_out[o] = v;
+            uint4 vv;
+            vv.x = (uint32_t)k[e]; vv.y = (uint32_t)(k[e] >> 32); vv.z = (uint32_t)cc; vv.w = (uint32_t)(cc >> 32);
+            box_out[o] = vv;
           }
         }
       }
@@ -988,7 +1001,7 @@ __device__ inline void round_tail(const PairTable &pt, const ScanArgs &sa, unsig
     for (int w = 0; w < wave; w++) pos += wcount[w];
 #pragma unroll
     for (int e = 0; e < TAIL_E; e++)
-      if ((keepm >> e) & 1u) pt.hot_slots[pos++] = sl[e];
+      if ((keepm >> e) & 1u) pt.top_slots[pos++] = sl[e];
     __syncthreads();
     if (tid == 0) {
       unsigned int t = 0;
@@ -997,27 +1010,35 @@ __device__ inline void round_tail(const PairTable &pt, const ScanArgs &sa, unsig
     }
     __syncthreads();
   }
+  {
+    const unsigned long long t = wave_sum_u64((unsigned long long)my_live);
+    if (lane == 0 && t) atomicAdd(&ctl[2], (unsigned int)t);
+  }
+  __syncthreads();
   // ---- 3. publish
   const unsigned long long tm2 = (unsigned long long)wall_clock64();
-  unsigned int *mb_hdr = reinterpret_cast<unsigned int *>(sa.mailbox);
-  unsigned long long *mb_hist = reinterpret_cast<unsigned long long *>(sa.mailbox + MB_HIST);
+  unsigned int *hdr = reinterpret_cast<unsigned int *>(sa.mailbox);
+  unsigned long long *box_hist = reinterpret_cast<unsigned long long *>(sa.mailbox + MB_HIST);
   if (tid == 0) {
-    mb_hdr[0] = ctl[1];                                                                          // candidates
-    mb_hdr[1] = __hip_atomic_load(pt.n_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // keys in the table
-    mb_hdr[2] = hn_raw;                                                                          // listed (before the compaction)
-    mb_hdr[3] = ctl[2];                                                                          // still >= hot_tau
+    hdr[0] = ctl[1];
+    hdr[1] = __hip_atomic_load(pt.n_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hdr[2] = tn_raw;
+    hdr[3] = ctl[2];
+    hdr[4] = hot_raw;
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 40) = stats[2];  // tokens streamed so far (repack trigger)
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 48) = stats[1];  // tiles that held a merge site so far
-    if (!overflow) *pt.hot_n = ctl[0];
-    *sa.done_ctr = 0;
-    unsigned long long *mb_t = reinterpret_cast<unsigned long long *>(sa.mailbox + 96);
-    mb_t[0] = tm0; mb_t[1] = tm1; mb_t[2] = tm2; mb_t[3] = (unsigned long long)wall_clock64();
+    if (!overflow) *pt.top_n = ctl[0];
+    if (sa.done_ctr) *sa.done_ctr = 0;
+    if (xstat) xstat[2] = (hot_raw > pt.hot_cap ? 1ull : 0ull) + (overflow ? (1ull << 32) : 0ull);  // this rank's list verdicts (summed over the ranks)
+    unsigned long long *tmark = reinterpret_cast<unsigned long long *>(sa.mailbox + 96);
+    tmark[0] = tm0; tmark[1] = tm1; tmark[2] = tm2; tmark[3] = (unsigned long long)wall_clock64();
   }
-  if (tid >= 6 && tid < 10) *reinterpret_cast<unsigned long long *>(sa.mailbox + 56 + 8 * (tid - 6)) = 0;  // (multi-GPU fields)
-  for (int b = tid; b < CAND_BINS; b += NT) mb_hist[b] = (unsigned long long)lh[b];
+  if (tid >= 6 && tid < 10) *reinterpret_cast<unsigned long long *>(sa.mailbox + 56 + 8 * (tid - 6)) = 0;  // (multi-GPU fields: k_publish fills them)
+  for (int b = tid; b < CAND_BINS; b += NT) box_hist[b] = (unsigned long long)lh[b];
+  if (!sa.round_id) return;  // staging block: k_publish forwards it
   __threadfence_system();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(&mb_hdr[8], sa.round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid == 0) __hip_atomic_store(&hdr[8], sa.round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int SLOT, int WPB, bool MERGE, bool LDSR>
@@ -1234,7 +1255,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
       atomicAdd(pt.n_keys, A.new_keys);  // K3: one launch
     }
   }
-  if (MERGE && sa.on) {  // the round's candidate scan, by the last workgroup to get here (round_tail)
+  if (MERGE && sa.on) {  // the round's candidate scan, by the last workgroup to get here (scan_top)
     // Everything this workgroup leaves for the tail went out as device-scope atomics or write-through stores (pair table, hot
     // list, statistics row), so the ticket only has to wait until those have completed -- a workgroup-scope release: an
     // agent-scope one would also write the XCD's L2 back, once per workgroup (measured: +150 us per round at 768 workgroups).
@@ -1247,7 +1268,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
       __threadfence();  // (acquire: nothing stale in this CU's caches)
       static_assert(sizeof(WL) >= (CAND_BINS + 80) * sizeof(unsigned int), "tile buffers double as the tail's scratch");
       const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
-      round_tail<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]));
+      scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
     }
   }
 }
@@ -1509,7 +1530,7 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
       c = (((unsigned long long)rec.w << 32) | rec.z) & PT_CNT;
       k = ((unsigned long long)rec.y << 32) | rec.x;
       if (c && zero_any && (k == zself || zprobe.has((uint32_t)(k >> 32), (uint32_t)k))) {
-        *pt.cnt_p(sl) = PT_HOT;  // listed, count 0
+        *pt.cnt_p(sl) = (((unsigned long long)rec.w << 32) | rec.z) & PT_FLAGS;  // count 0, still on the lists it was on
         c = 0;
       }
       if (c >= pt.hot_tau) {
@@ -1565,6 +1586,92 @@ __global__ __launch_bounds__(BLOCK) void k_publish(PairTable pt, CandRec *__rest
                                                    unsigned char *__restrict__ mailbox, unsigned int fast, uint32_t round_id,
                                                    unsigned long long *__restrict__ stats, unsigned long long *__restrict__ xstat) {
   publish_round(pt, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id, stats, xstat);
+}
+
+// The scan of the top list as a kernel of its own (ONE workgroup): rounds that are more than one launch (multi-GPU exchange,
+// class-B / class-C tiles), rescans with another threshold, and the first scan after a refill.  zrules / zba: the batch whose
+// pairs are still to be zeroed (as for k_hot_scan).
+constexpr int TOP_SCAN_NT = 512;
+__global__ __launch_bounds__(TOP_SCAN_NT) void k_top_scan(PairTable pt, ScanArgs sa, unsigned long long *__restrict__ stats, const RuleSlot *__restrict__ zrules,
+                                                          unsigned int zmask, unsigned long long zself, BatchArgs zba, unsigned long long *__restrict__ xstat) {
+  __shared__ unsigned long long zkeys[FILTER_LDS_KEYS];
+  __shared__ unsigned int scratch[CAND_BINS + 80];
+  bool zkeys_in_lds = zrules && zmask < FILTER_LDS_KEYS;
+  if (zba.k) {
+    zmask = 127;
+    zkeys_in_lds = true;
+    for (unsigned int s = threadIdx.x; s <= zmask; s += TOP_SCAN_NT) zkeys[s] = PT_EMPTY;
+    __syncthreads();
+    if (threadIdx.x < zba.k && zba.xy[2 * threadIdx.x] != zba.xy[2 * threadIdx.x + 1]) {
+      const unsigned long long key = pair_key(zba.xy[2 * threadIdx.x], zba.xy[2 * threadIdx.x + 1]);
+      unsigned int h = pair_hash32(key) & zmask;
+      while (atomicCAS(&zkeys[h], PT_EMPTY, key) != PT_EMPTY) h = (h + 1) & zmask;
+    }
+  } else if (zkeys_in_lds) {
+    for (unsigned int s = threadIdx.x; s <= zmask; s += TOP_SCAN_NT) zkeys[s] = zrules[s].key;
+  } else if (!zrules) {  // nothing to zero: an empty table
+    zmask = 0;
+    zkeys_in_lds = true;
+    if (threadIdx.x == 0) zkeys[0] = PT_EMPTY;
+  }
+  __syncthreads();
+  const RuleProbe zprobe{zkeys_in_lds ? zkeys : nullptr, zrules, zmask};
+  scan_top<TOP_SCAN_NT>(pt, sa, stats, zprobe, zself, scratch, xstat);
+}
+
+// Refill of the top list from the hot list: PT_TOP is set exactly on the listed slots with count >= pt.top_tau, and those are
+// appended (pt.top_n was reset by the host).
+__global__ __launch_bounds__(BLOCK) void k_top_rebuild(PairTable pt) {
+  const unsigned int hn_raw = *pt.hot_n;
+  const unsigned int hn = hn_raw < pt.hot_cap ? hn_raw : pt.hot_cap;
+  for (unsigned int i0 = blockIdx.x * BLOCK; i0 < hn; i0 += gridDim.x * BLOCK) {
+    const unsigned int i = i0 + threadIdx.x;
+    bool top = false;
+    uint32_t sl = 0;
+    if (i < hn) {
+      sl = pt.hot_slots[i];
+      const unsigned long long raw = *pt.cnt_p(sl), c = raw & PT_CNT;
+      top = c >= pt.top_tau && c > 0;
+      const unsigned long long want = (raw & ~PT_TOP) | (top ? PT_TOP : 0ull);
+      if (want != raw) *pt.cnt_p(sl) = want;
+    }
+    const unsigned long long m = __ballot(top);
+    if (m) {
+      unsigned int base = 0;
+      if (lane_id() == 0) base = atomicAdd(pt.top_n, (unsigned int)__popcll(m));
+      base = __shfl(base, 0);
+      if (top) {
+        const unsigned int o = base + (unsigned int)__popcll(m & lanemask_lt());
+        if (o < pt.top_cap) pt.top_slots[o] = sl;
+      }
+    }
+  }
+}
+
+// multi-GPU: forwards a staged scan result (box, written by k_top_scan) to the host's mailbox once the ranks have summed their
+// list verdicts into xstat[2], together with the exchange's report (xstat), and publishes the round id.
+__global__ __launch_bounds__(BLOCK) void k_publish_box(const unsigned char *__restrict__ box, unsigned char *__restrict__ mailbox, unsigned int fast,
+                                                       uint32_t round_id, unsigned long long *__restrict__ xstat) {
+  const unsigned int *bh = reinterpret_cast<const unsigned int *>(box);
+  unsigned int *mh = reinterpret_cast<unsigned int *>(mailbox);
+  if (threadIdx.x < 5) mh[threadIdx.x] = bh[threadIdx.x];
+  if (threadIdx.x >= 10 && threadIdx.x < 14) mh[threadIdx.x] = bh[threadIdx.x];  // bytes 40..55
+  if (threadIdx.x >= 6 && threadIdx.x < 10) {
+    const int k = (int)threadIdx.x - 6;
+    *reinterpret_cast<unsigned long long *>(mailbox + 56 + 8 * k) = xstat[k];
+    xstat[k] = 0;
+  }
+  if (threadIdx.x >= 24 && threadIdx.x < 32) mh[threadIdx.x] = bh[threadIdx.x];  // bytes 96..127: timing marks
+  const unsigned long long *bhist = reinterpret_cast<const unsigned long long *>(box + MB_HIST);
+  unsigned long long *mhist = reinterpret_cast<unsigned long long *>(mailbox + MB_HIST);
+  for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) mhist[b] = bhist[b];
+  unsigned int take = bh[0] < fast ? bh[0] : fast;
+  const uint4 *src = reinterpret_cast<const uint4 *>(box + 8192);
+  uint4 *dst = reinterpret_cast<uint4 *>(mailbox + 8192);
+  for (unsigned int i = threadIdx.x; i < take; i += BLOCK) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&mh[8], round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // (Re)build the hot list: every slot with count >= pt.hot_tau, in one streaming pass; PT_HOT is set exactly on those.
@@ -1625,7 +1732,7 @@ __global__ __launch_bounds__(BLOCK) void k_pt_zero(PairTable pt, const RuleSlot 
   for (;;) {
     const unsigned long long k = (*pt.key_p(j));
     if (k == PT_EMPTY) return;
-    if (k == key) { (*pt.cnt_p(j)) &= PT_HOT; return; }  // a listed slot stays listed (once)
+    if (k == key) { (*pt.cnt_p(j)) &= PT_FLAGS; return; }  // a listed slot stays listed (once)
     j = (j + 1) & pt.mask;
   }
 }
@@ -1872,6 +1979,19 @@ void launch_pt_apply_blocks(const PairTable &pt, const DeltaRec *blocks, unsigne
   unsigned long long b = (blk + BLOCK - 1) / BLOCK;
   if (b > 256 * 4) b = 256 * 4;
   hipLaunchKernelGGL(k_pt_apply_blocks, dim3((unsigned int)b), dim3(BLOCK), 0, st, pt, blocks, blk, world, rank, only_mask, xstat);
+}
+void launch_top_scan(const PairTable &pt, const ScanArgs &sa, unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself,
+                     const BatchArgs *zba, unsigned long long *xstat, hipStream_t st) {
+  hipLaunchKernelGGL(k_top_scan, dim3(1), dim3(TOP_SCAN_NT), 0, st, pt, sa, stats, zrules, zmask, zself, zba ? *zba : BatchArgs{}, xstat);
+}
+void launch_top_rebuild(const PairTable &pt, unsigned int listed_hint, hipStream_t st) {
+  unsigned int g = (listed_hint + BLOCK - 1) / BLOCK;
+  if (g < 1) g = 1;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(k_top_rebuild, dim3(g), dim3(BLOCK), 0, st, pt);
+}
+void launch_publish_box(const unsigned char *box, unsigned char *mailbox, unsigned int fast, uint32_t round_id, unsigned long long *xstat, hipStream_t st) {
+  hipLaunchKernelGGL(k_publish_box, dim3(1), dim3(BLOCK), 0, st, box, mailbox, fast, round_id, xstat);
 }
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st) {
   unsigned long long n_slots = pt.mask + 1;

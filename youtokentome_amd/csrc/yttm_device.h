@@ -38,13 +38,17 @@ constexpr int NWAVES = BLOCK / 64;
 
 constexpr unsigned long long PT_EMPTY = ~0ull;
 
-// Bit 63 of a count marks a slot that is on the hot list (candidate filter): the list holds every slot whose count
-// reached hot_tau since the list was built, so a round inspects tens of thousands of slots instead of the whole table.
+// Two flag bits of a count mark the candidate lists a slot is on.  The HOT list (L1) holds every slot whose count reached
+// hot_tau since the list was built -- tens of thousands of slots instead of the whole table; the TOP list (L2) holds those of
+// them that reached top_tau >= hot_tau -- about a thousand, few enough for ONE workgroup to read at the end of a merge round
+// (k_merge.hip round_tail).  The scan of a round reads L2; L2 is refilled from L1 when it runs dry, L1 from the table.
 constexpr unsigned long long PT_HOT = 1ull << 63;
-constexpr unsigned long long PT_CNT = PT_HOT - 1;
+constexpr unsigned long long PT_TOP = 1ull << 62;
+constexpr unsigned long long PT_FLAGS = PT_HOT | PT_TOP;
+constexpr unsigned long long PT_CNT = PT_TOP - 1;
 
 struct PairTable {
-  unsigned long long *slots;  // [2 * capacity]: slot i = { key (PT_EMPTY = free), count (bits 0..62) | PT_HOT } -- one 16-byte
+  unsigned long long *slots;  // [2 * capacity]: slot i = { key (PT_EMPTY = free), count (bits 0..61) | flags } -- one 16-byte
                               // record, so the probe of a key and the update of its count touch the same HBM sector
   unsigned long long mask;    // capacity - 1 (capacity is a power of two)
   __host__ __device__ unsigned long long *key_p(unsigned long long i) const { return slots + 2 * i; }
@@ -54,6 +58,10 @@ struct PairTable {
   uint32_t *hot_slots;         // [hot_cap]
   unsigned int *hot_n;         // appended entries (may exceed hot_cap: then the list is rebuilt)
   unsigned int hot_cap;
+  unsigned int top_cap;
+  unsigned long long top_tau;  // ... and this, on the top list (~0ull: list off)
+  uint32_t *top_slots;         // [top_cap]
+  unsigned int *top_n;
 };
 
 struct TileSet {
@@ -126,16 +134,24 @@ __device__ inline void pt_add(const PairTable &pt, unsigned long long key, long 
     }
     if (k == key) {
       if (delta > 0 && pt.hot_tau != ~0ull) {
-        // only an increase can cross the threshold; the adder that observes the crossing (exactly one: the adds on a
-        // slot are serialised) sets PT_HOT, and whoever sets it first appends the slot
+        // only an increase can cross a threshold; the adder that observes the crossing (exactly one: the adds on a slot are
+        // serialised) sets the list's flag, and whoever sets it first appends the slot.  (Write-through stores: the workgroup
+        // that scans a list at the end of THIS launch -- k_merge.hip round_tail -- may sit on another XCD, whose L2 does not see
+        // plain stores before a cache write-back.)
         const unsigned long long old = atomicAdd(pt.cnt_p(i), (unsigned long long)delta);
-        if (!(old & PT_HOT) && (old & PT_CNT) + (unsigned long long)delta >= pt.hot_tau) {
-          const unsigned long long o2 = atomicOr(pt.cnt_p(i), PT_HOT);
-          if (!(o2 & PT_HOT)) {
+        const unsigned long long now = (old & PT_CNT) + (unsigned long long)delta;
+        unsigned long long want = 0;
+        if (!(old & PT_HOT) && now >= pt.hot_tau) want |= PT_HOT;
+        if (!(old & PT_TOP) && now >= pt.top_tau) want |= PT_TOP;
+        if (want) {
+          const unsigned long long fresh = want & ~atomicOr(pt.cnt_p(i), want);
+          if (fresh & PT_HOT) {
             const unsigned int j = atomicAdd(pt.hot_n, 1u);
-            // (a write-through store: the workgroup that scans the list at the end of THIS launch -- k_merge.hip round_tail -- may
-            // sit on another XCD, whose L2 does not see plain stores before a cache write-back)
             if (j < pt.hot_cap) __hip_atomic_store(&pt.hot_slots[j], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (fresh & PT_TOP) {
+            const unsigned int j = atomicAdd(pt.top_n, 1u);
+            if (j < pt.top_cap) __hip_atomic_store(&pt.top_slots[j], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       } else {

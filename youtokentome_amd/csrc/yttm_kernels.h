@@ -61,15 +61,19 @@ struct BatchArgs {
 // statistics rows, zeroes the batch's pairs, scans (and compacts) the hot list and publishes header + histogram + candidates
 // in the host's pinned mailbox -- one launch per round instead of two, and no second trip through the launch path.
 struct ScanArgs {
-  uint32_t on;  // 0: no scan in this launch
+  uint32_t on;  // 0: no scan in this launch (k_tiles)
   uint32_t tau_mx;
   unsigned long long tau_cnt;  // candidates: count > tau_cnt, or == tau_cnt and max(x,y) <= tau_mx
   CandRec *out;                // [cap] all candidates (the first `fast` also go to the mailbox)
   unsigned int cap, fast;
-  unsigned int *done_ctr;      // ticket of finished workgroups (left at 0)
-  unsigned char *mailbox;
-  uint32_t round_id;
+  unsigned int *done_ctr;      // ticket of finished workgroups (left at 0); nullptr: a single-workgroup launch
+  unsigned char *mailbox;      // the host's pinned mailbox, or (round_id == 0) a staging block in HBM with the same layout
+  uint32_t round_id;           // published in the mailbox when everything else is there; 0: nothing is published
 };
+void launch_top_scan(const PairTable &pt, const ScanArgs &sa, unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself,
+                     const BatchArgs *zba, unsigned long long *xstat, hipStream_t st);
+void launch_top_rebuild(const PairTable &pt, unsigned int listed_hint, hipStream_t st);
+void launch_publish_box(const unsigned char *box, unsigned char *mailbox, unsigned int fast, uint32_t round_id, unsigned long long *xstat, hipStream_t st);
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st);
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
