@@ -166,6 +166,9 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   hot_min_ = env_uint("YTTM_HOT_MIN", 512);
   dense_pct_ = env_uint("YTTM_DENSE_PCT", 0);
   fuse_enabled_ = env_uint("YTTM_NO_FUSE", 0) == 0;
+  no_batch_args_ = getenv("YTTM_NO_BATCH_ARGS") != nullptr;  // (read once per context: a round has no time for getenv)
+  trace_rounds_ = getenv("YTTM_TRACE_ROUNDS");
+  dbg_cand_ = getenv("YTTM_DBG_CAND");
   d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);
   d_hot_n_ = dmalloc<unsigned int>(4);  // [0] list length, [1] k_hot_scan's finished-workgroup ticket, [2..3] overflow verdict (u64)
   HIP_CHECK(hipMemset(d_hot_n_, 0, 16));
@@ -831,14 +834,17 @@ uint32_t GpuCtx::scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vec
   out.clear();
   if (!pt_cap_) {
     if (hist) memset(hist, 0, CAND_BINS * 8);
+    memset(hist_buf_, 0, sizeof hist_buf_);
+    last_hist_ = hist_buf_;
+    last_live_ = 0;
     return 0;
   }
   flush_pending_zero();
   launch_fold_stats(d_stats_, pt_.n_keys, st_);
   HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, st_));
-  if (hist) HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, st_));
+  HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, st_));
   t_begin(KT_CAND);
-  launch_cand_scan(pt_, tau_cnt, tau_mx, d_cand_, cand_cap_, d_cand_n_, hist ? d_cand_hist_ : nullptr, st_);
+  launch_cand_scan(pt_, tau_cnt, tau_mx, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, st_);  // (always with the histogram: last_hist())
   t_end(KT_CAND, 16 * pt_cap_);
   // ONE device-to-host copy per round: header + histogram + the first CAND_FAST candidates; a second copy only when
   // more candidates passed (the host rarely looks past a few thousand)
@@ -849,6 +855,10 @@ uint32_t GpuCtx::scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vec
   const unsigned int n = *(unsigned int *)h;
   n_keys_host = *(unsigned int *)(h + 4);
   if (hist) memcpy(hist, h + 64, CAND_BINS * 8);
+  memcpy(hist_buf_, h + 64, CAND_BINS * 8);
+  last_hist_ = hist_buf_;
+  last_live_ = 0;
+  for (int b = 1; b < CAND_BINS; b++) last_live_ += hist_buf_[b];
   const unsigned int take = std::min(n, cand_cap_);
   CandRec *h_c = (CandRec *)(h + 8192);
   if (take > CAND_FAST) {
@@ -1020,6 +1030,9 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
   out.clear();
   if (!pt_cap_) {
     if (hist) memset(hist, 0, CAND_BINS * 8);
+    memset(hist_buf_, 0, sizeof hist_buf_);
+    last_hist_ = hist_buf_;
+    last_live_ = 0;
     return 0;
   }
   constexpr unsigned int CAND_FAST = 4096;
@@ -1140,6 +1153,8 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
       }
     }
     if (hist) memcpy(hist, h + MB_HIST, CAND_BINS * 8);
+    last_hist_ = (const unsigned long long *)(h + MB_HIST);
+    last_live_ = live;
     const unsigned int take = std::min(n, cand_cap_);
     CandRec *h_c = (CandRec *)(h + 8192);
     if (take > CAND_FAST) {
@@ -1147,7 +1162,7 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
       sync();
     }
     out.assign(h_c, h_c + take);
-    if (const char *dbg = getenv("YTTM_DBG_CAND")) {  // debugging aid: one line per scan, comparable across scan implementations
+    if (const char *dbg = dbg_cand_) {  // debugging aid: one line per scan, comparable across scan implementations
       static FILE *f = nullptr;
       if (!f) f = fopen(dbg, "w");
       unsigned long long hx = 0;
@@ -1195,7 +1210,9 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     unsigned long long by_count = rule_counts ? 3 * rule_counts[j] : by_tokens;
     bound_new += std::min(by_tokens, by_count);
   }
-  ensure_table_capacity(n_keys_host + bound_new);
+  // (the key count the scans report is one round old -- they fold the statistics after publishing: the previous round's bound covers it)
+  ensure_table_capacity(n_keys_host + bound_prev_ + bound_new);
+  bound_prev_ = bound_new;
 
   // rule hash (x != y rules) + at most one x == y rule passed by value
   unsigned int cap = 64;
@@ -1203,12 +1220,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   char *pin = (char *)h_pin_ + (1u << 16) + (size_t)CAND_CAP * sizeof(CandRec);  // after the read-back area of candidates()
   RuleSlot *h_rules = (RuleSlot *)pin;
   uint32_t *h_upd = (uint32_t *)(pin + (size_t)RULES_CAP * sizeof(RuleSlot));
-  for (unsigned int i = 0; i < cap; i++) { h_rules[i].key = PT_EMPTY; h_rules[i].z = 0; h_rules[i].pad = 0; }
   uint32_t self_x = 0xffffffffu, self_z = 0;
-  std::vector<std::pair<uint32_t, uint8_t>> flags;
-  flags.reserve(2 * k + prev_flag_toks_.size());
-  for (uint32_t t : prev_flag_toks_) flags.push_back({t, 0});
-  std::vector<uint32_t> now;
   for (uint32_t j = 0; j < k; j++) {
     const uint32_t x = xyz[3 * j], y = xyz[3 * j + 1], z = xyz[3 * j + 2];
     if (x >= tokflag_cap_ || y >= tokflag_cap_ || z >= tokflag_cap_) throw GpuError{"merge_apply: token id out of range"};
@@ -1216,29 +1228,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       if (self_x != 0xffffffffu) throw GpuError{"merge_apply: more than one x==y rule in a batch"};
       self_x = x;
       self_z = z;
-      continue;
     }
-    const unsigned long long key = pair_key(x, y);
-    unsigned int h = pair_hash32(key) & (cap - 1);
-    while (h_rules[h].key != PT_EMPTY) h = (h + 1) & (cap - 1);
-    h_rules[h].key = key;
-    h_rules[h].z = z;
-    flags.push_back({x, 1});
-    flags.push_back({y, 2});
-    now.push_back(x);
-    now.push_back(y);
-  }
-  // final flag value per token (clears of the previous batch first, then ORs of this batch)
-  std::sort(flags.begin(), flags.end(), [](const std::pair<uint32_t, uint8_t> &a, const std::pair<uint32_t, uint8_t> &b) { return a.first < b.first; });
-  unsigned int n_upd = 0;
-  for (size_t i = 0; i < flags.size();) {
-    size_t j = i;
-    uint8_t v = 0;
-    while (j < flags.size() && flags[j].first == flags[i].first) v |= flags[j++].second;
-    h_upd[2 * n_upd] = flags[i].first;
-    h_upd[2 * n_upd + 1] = v;
-    n_upd++;
-    i = j;
   }
   // Small batch and a round that runs without the filter pass: the batch goes to the kernels as an argument and nothing is
   // uploaded (yttm_kernels.h: BatchArgs).  The flag tables in HBM then keep what the last uploaded batch left there.
@@ -1248,17 +1238,49 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     if (dense_pct >= 1000) return false;  // tests: always the filter pass + worklist
     return cls_[ci].n_tiles <= 8192 || (touched_last_ != (~0ull >> 2) && touched_last_ * 100 >= (unsigned long long)n_tiles * (unsigned long long)dense_pct);
   };
+  const bool no_batch_args = no_batch_args_;
+  const bool by_args = k <= (uint32_t)BATCH_ARGS_MAX && vmax < FLAG_LDS_IDS && !cls_[2].n_tiles && (!cls_[0].n_tiles || dense_class(0)) &&
+                       (!cls_[1].n_tiles || dense_class(1)) && !no_batch_args;
+  unsigned int n_upd = 0;
+  if (!by_args) {  // (the common small batch needs none of this: the host's share of a round is on the critical path)
+    for (unsigned int i = 0; i < cap; i++) { h_rules[i].key = PT_EMPTY; h_rules[i].z = 0; h_rules[i].pad = 0; }
+    flag_work_.clear();
+    for (uint32_t t : prev_flag_toks_) flag_work_.push_back({t, 0});
+    flag_now_.clear();
+    for (uint32_t j = 0; j < k; j++) {
+      const uint32_t x = xyz[3 * j], y = xyz[3 * j + 1], z = xyz[3 * j + 2];
+      if (x == y) continue;
+      const unsigned long long key = pair_key(x, y);
+      unsigned int h = pair_hash32(key) & (cap - 1);
+      while (h_rules[h].key != PT_EMPTY) h = (h + 1) & (cap - 1);
+      h_rules[h].key = key;
+      h_rules[h].z = z;
+      flag_work_.push_back({x, 1});
+      flag_work_.push_back({y, 2});
+      flag_now_.push_back(x);
+      flag_now_.push_back(y);
+    }
+    // final flag value per token (clears of the previous batch first, then ORs of this batch)
+    std::sort(flag_work_.begin(), flag_work_.end(), [](const std::pair<uint32_t, uint8_t> &a, const std::pair<uint32_t, uint8_t> &b) { return a.first < b.first; });
+    for (size_t i = 0; i < flag_work_.size();) {
+      size_t jj = i;
+      uint8_t v = 0;
+      while (jj < flag_work_.size() && flag_work_[jj].first == flag_work_[i].first) v |= flag_work_[jj++].second;
+      h_upd[2 * n_upd] = flag_work_[i].first;
+      h_upd[2 * n_upd + 1] = v;
+      n_upd++;
+      i = jj;
+    }
+  }
   BatchArgs ba{};
   ba.instr = instrument ? 1u : 0u;
-  const bool by_args = k <= (uint32_t)BATCH_ARGS_MAX && vmax < FLAG_LDS_IDS && !cls_[2].n_tiles && (!cls_[0].n_tiles || dense_class(0)) &&
-                       (!cls_[1].n_tiles || dense_class(1)) && !getenv("YTTM_NO_BATCH_ARGS");
   max_id_ = std::max(max_id_, vmax);
   if (by_args) {
     ba.k = k;
     ba.small_ids = max_id_ < FLAG_LDS_IDS ? 1u : 0u;
     for (uint32_t j = 0; j < k; j++) { ba.xy[2 * j] = xyz[3 * j]; ba.xy[2 * j + 1] = xyz[3 * j + 1]; }
   } else {
-    prev_flag_toks_.swap(now);
+    prev_flag_toks_.swap(flag_now_);
   }
   if (multi()) HIP_CHECK(hipMemsetAsync(db_.n, 0, 8, st_));  // this round's records start at the head of the send block
   // one launch per round: the apply kernel's last workgroup also does the candidate scan (see gpu_ctx.h)
@@ -1297,7 +1319,8 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
   t_end(KT_MERGE, 0, /*chain=*/true);
   merge_rounds++;
-  if (getenv("YTTM_TRACE_ROUNDS")) {
+  const char *trace_rounds = trace_rounds_;
+  if (trace_rounds) {
     chain_event_ = nullptr;  // tuning aid: cumulative device stats after every round (adds a sync)
     unsigned long long stt[24];
     launch_fold_stats(d_stats_, pt_.n_keys, st_);

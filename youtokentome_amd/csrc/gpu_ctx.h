@@ -79,6 +79,10 @@ class GpuCtx {
   // the same over the whole table (one streaming pass)
   uint32_t scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist);
   unsigned long long hot_tau() const { return hot_state_ == HOT_ACTIVE ? pt_.hot_tau : 1; }
+  // histogram (CAND_BINS bins) and number of the counts the last candidates() / scan_full() call looked at; the histogram lives in
+  // the pinned mailbox until the next scan
+  const unsigned long long *last_hist() const { return last_hist_; }
+  unsigned long long last_live() const { return last_live_; }
   unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0;
   unsigned long long tail_ticks[3] = {0, 0, 0}, tail_listed = 0;  // round_tail: fold / list scan / publish, in 10 ns ticks; entries it read
   unsigned long long fused_rounds = 0, fused_overflows = 0;  // rounds whose candidate scan ran in the apply kernel's tail; of those, with a hot-list overflow
@@ -118,6 +122,9 @@ class GpuCtx {
   bool scan_hot(unsigned long long t, uint32_t tm);
   bool refill_top();
   bool hot_just_rebuilt_ = false;
+  const unsigned long long *last_hist_ = nullptr;
+  unsigned long long last_live_ = 0, hist_buf_[CAND_BINS] = {0};
+  unsigned long long bound_prev_ = 0;  // new-key bound of the previous round (see merge_apply)
   uint32_t *d_hot_slots_ = nullptr;
   unsigned int *d_hot_n_ = nullptr;
   unsigned int fullscan_rounds_ = 0;
@@ -125,6 +132,8 @@ class GpuCtx {
   bool fused_pending_ = false;  // a fused scan is in flight / in the mailbox ...
   unsigned long long fused_tau_ = 0;  // ... for this threshold
   uint32_t fused_mx_ = 0, fused_round_ = 0;
+  bool no_batch_args_ = false;
+  const char *trace_rounds_ = nullptr, *dbg_cand_ = nullptr;
   bool fuse_enabled_ = true;  // YTTM_NO_FUSE=1: always the separate scan kernel (tuning hook / tests)
   uint32_t max_id_ = 0xffffffffu;  // largest token id in the tiles (unknown until the word table is built)
   unsigned long long scanned_cum_ = 0, live_tokens_last_ = 0, touched_cum_ = 0, touched_last_ = ~0ull >> 2;  // (first round: dense)
@@ -182,7 +191,8 @@ class GpuCtx {
   unsigned long long *d_stats_ = nullptr;
   void *h_pin_ = nullptr;  // pinned staging (rules + flag updates + candidate header)
   size_t h_pin_bytes_ = 0;
-  std::vector<uint32_t> prev_flag_toks_;
+  std::vector<uint32_t> prev_flag_toks_, flag_now_;
+  std::vector<std::pair<uint32_t, uint8_t>> flag_work_;
   // candidates
   unsigned char *d_round_ = nullptr;
   CandRec *d_cand_ = nullptr;

@@ -43,11 +43,9 @@ struct HeapCmp {  // std heap keeps the "largest" on top: largest = picked first
   bool operator()(const Cand &a, const Cand &b) const { return before(b, a); }
 };
 
-// threshold such that about `target` pairs have count >= tau (from the device histogram of live counts)
-unsigned long long choose_tau(const unsigned long long *hist, unsigned long long target, unsigned long long *total_out) {
-  unsigned long long total = 0;
-  for (int b = 1; b < CAND_BINS; b++) total += hist[b];
-  if (total_out) *total_out = total;
+// threshold such that about `target` pairs have count >= tau (from the device histogram of live counts, read from the top:
+// only its first few lines of the pinned mailbox are touched)
+unsigned long long choose_tau(const unsigned long long *hist, unsigned long long target) {
   unsigned long long acc = 0;
   for (int b = CAND_BINS - 1; b >= 1; b--) {
     acc += hist[b];
@@ -108,7 +106,6 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   std::vector<Cand> heap;
   std::vector<uint32_t> batch_xyz;
   std::vector<unsigned long long> batch_cnt;
-  unsigned long long hist[CAND_BINS];
   unsigned long long rounds = 0, rescans = 0;
   double w_cand = 0, w_pick = 0, w_apply = 0;
   std::vector<uint8_t> in_batch((size_t)vocab_size + 1, 0);  // bit0: token is the x of a batch rule, bit1: the y
@@ -116,11 +113,12 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     // Candidate set = every pair with count > tau, or count == tau and max(x,y) <= tau_mx: a complete prefix of the
     // global order, so the batch built from it is exact.  The threshold only trades list length against early batch ends.
     auto tw0 = clk::now();
-    uint32_t n = g.candidates(tau, tau_mx, recs, hist);
+    uint32_t n = g.candidates(tau, tau_mx, recs, nullptr);
     w_cand += since(tw0);
     auto tw1 = clk::now();
-    unsigned long long total_pairs = 0;
-    const unsigned long long tau_hint = choose_tau(hist, TARGET, &total_pairs);
+    const unsigned long long *hist = g.last_hist();  // (of the counts the scan looked at; valid until the next scan)
+    const unsigned long long total_pairs = g.last_live();
+    const unsigned long long tau_hint = choose_tau(hist, TARGET);
     if (total_pairs == 0) {
       if (root) fprintf(stderr, "WARNING merged only: %llu pairs of tokens\n", (unsigned long long)used_ids);  // bpe.cpp:1139
       break;
@@ -130,7 +128,8 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       tau_mx = MX_ALL;
       rescans++;
       if (n == 0) continue;
-      n = g.candidates(tau, tau_mx, recs, hist);
+      n = g.candidates(tau, tau_mx, recs, nullptr);
+      hist = g.last_hist();
     }
     if (n > recs.size()) {
       // More candidates than the buffer holds (rare: huge ties).  Raise the count threshold by the histogram, then
@@ -195,7 +194,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   if (rep) {
     rep->seconds_merge = since(t_merge);
     if (getenv("YTTM_TRACE") && g.fused_rounds)
-      fprintf(stderr, "[yttm] fused rounds %llu: tail fold %.2f us, list scan %.2f us (%.0f entries), publish %.2f us per round\n", g.fused_rounds,
+      fprintf(stderr, "[yttm] fused rounds %llu: tail set-up %.2f us, top-list scan %.2f us (%.0f entries), publish %.2f us per round\n", g.fused_rounds,
               g.tail_ticks[0] * 0.01 / g.fused_rounds, g.tail_ticks[1] * 0.01 / g.fused_rounds, (double)g.tail_listed / g.fused_rounds,
               g.tail_ticks[2] * 0.01 / g.fused_rounds);
     if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu, hot rebuilds %llu, pair table %llu keys in %llu slots (%llu rehashes)\n",

@@ -882,14 +882,14 @@ __device__ inline int cand_bin(unsigned long long c) {
 // Run by the LAST workgroup of the apply kernel to finish (ScanArgs, yttm_kernels.h; every other workgroup has published its
 // updates as device-scope atomics or write-through stores and then taken its ticket, nothing else touches the pair table), or as
 // a kernel of its own (k_top_scan) where a round is more than one launch.
-//   1. fold the per-workgroup statistics rows into the totals and the key count
-//   2. the top list: zero the pairs of the batch just applied (every occurrence was merged), histogram the live counts, collect
+//   1. the top list: zero the pairs of the batch just applied (every occurrence was merged), histogram the live counts, collect
 //      the candidates above the host's threshold, and COMPACT the list in place: an entry whose count fell below top_tau leaves
 //      the list (PT_TOP cleared, so it can come back).  TAIL_E entries per thread and pass, two dependent memory round trips
 //      per pass (slot numbers, then records) with all loads of a round trip in flight together.
-//   3. header, histogram and the first `fast` candidates go to `box` -- the host's pinned mailbox (then the round id is
+//   2. header, histogram and the first `fast` candidates go to `box` -- the host's pinned mailbox (then the round id is
 //      published there, system-scope release: the host polls instead of copying and synchronising), or, multi-GPU, a staging
-//      block in HBM that k_publish forwards after the ranks' all-reduce.
+//      block in HBM that k_publish_box forwards after the ranks' all-reduce.
+//   3. last, off the critical path: the per-workgroup statistics rows are folded into the totals and the key count
 // Box layout: [0] candidates, [4] keys in the table, [8] top-list entries before the scan, [12] of those still >= top_tau,
 // [16] hot-list entries (overflow check), [32] round id, [40] tokens streamed so far, [48] tiles with a site so far, [56..87]
 // xstat (multi-GPU), [96..127] timing marks (100 MHz), [MB_HIST..) histogram, [8192..) candidates.
@@ -908,35 +908,6 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
   if (tid < 3) ctl[tid] = 0;
   if (tid < 5) facc[tid] = 0;
   __syncthreads();
-  {  // ---- 1. statistics rows (left by the workgroups of this and earlier launches, write-through): all loads in flight together
-    constexpr int RPT = (BLK_ROWS + NT - 1) / NT;
-    unsigned long long v[RPT][5];
-#pragma unroll
-    for (int r = 0; r < RPT; r++) {
-      const int b = tid + r * NT;
-#pragma unroll
-      for (int jj = 0; jj < 5; jj++)
-        v[r][jj] = b < BLK_ROWS ? __hip_atomic_load(&stats[BLK_BASE + 8 * b + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    }
-    unsigned long long a[5] = {0, 0, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < RPT; r++) {
-      const int b = tid + r * NT;
-#pragma unroll
-      for (int jj = 0; jj < 5; jj++) {
-        a[jj] += v[r][jj];
-        if (v[r][jj]) stats[BLK_BASE + 8 * b + jj] = 0;
-      }
-    }
-#pragma unroll
-    for (int jj = 0; jj < 5; jj++) {
-      const unsigned long long t = wave_sum_u64(a[jj]);
-      if (lane == 0 && t) atomicAdd(&facc[jj], t);
-    }
-    __syncthreads();
-    if (tid < 4 && facc[tid]) stats[tid] += facc[tid];
-    if (tid == 4 && facc[4]) atomicAdd(pt.n_keys, (unsigned int)facc[4]);
-  }
   const unsigned long long tm1 = (unsigned long long)wall_clock64();
   // ---- 2. the top list
   const unsigned int tn_raw = __hip_atomic_load(pt.top_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1035,10 +1006,42 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
   }
   if (tid >= 6 && tid < 10) *reinterpret_cast<unsigned long long *>(sa.mailbox + 56 + 8 * (tid - 6)) = 0;  // (multi-GPU fields: k_publish fills them)
   for (int b = tid; b < CAND_BINS; b += NT) box_hist[b] = (unsigned long long)lh[b];
-  if (!sa.round_id) return;  // staging block: k_publish forwards it
-  __threadfence_system();
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(&hdr[8], sa.round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (sa.round_id) {  // (0: a staging block, k_publish_box forwards it)
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&hdr[8], sa.round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // ---- 4. the statistics rows, AFTER the host has its candidates: the fold is off the round's critical path (the key count
+  // and the token totals in the header are therefore one round old; the host allows for that)
+  {  // statistics rows (left by the workgroups of this and earlier launches, write-through): all loads in flight together
+    constexpr int RPT = (BLK_ROWS + NT - 1) / NT;
+    unsigned long long v[RPT][5];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      const int b = tid + r * NT;
+#pragma unroll
+      for (int jj = 0; jj < 5; jj++)
+        v[r][jj] = b < BLK_ROWS ? __hip_atomic_load(&stats[BLK_BASE + 8 * b + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+    unsigned long long a[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      const int b = tid + r * NT;
+#pragma unroll
+      for (int jj = 0; jj < 5; jj++) {
+        a[jj] += v[r][jj];
+        if (v[r][jj]) stats[BLK_BASE + 8 * b + jj] = 0;
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 5; jj++) {
+      const unsigned long long t = wave_sum_u64(a[jj]);
+      if (lane == 0 && t) atomicAdd(&facc[jj], t);
+    }
+    __syncthreads();
+    if (tid < 4 && facc[tid]) stats[tid] += facc[tid];
+    if (tid == 4 && facc[4]) atomicAdd(pt.n_keys, (unsigned int)facc[4]);
+  }
 }
 
 template <int SLOT, int WPB, bool MERGE, bool LDSR>
@@ -1125,7 +1128,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     }
     if (have) {
       hn = (int)ts.tile_len[ht];
-      hw = hn ? ts.tile_word0[ht] : 0u;  // an empty tile (after a repack) has no first word
+      hw = ts.tile_word0[ht];  // (independent of the length, so that the two loads share a round trip; an empty tile's is never used)
     }
   };
   uint4 r[SLOT / 256];
