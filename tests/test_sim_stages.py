@@ -225,3 +225,27 @@ def test_encode_concurrent_threads():
     for t in th:
         t.join()
     assert got == want
+
+
+def test_word_table_overflow_is_redone(tmp_path):
+    """K2 sizes its word table for far fewer distinct words than occurrences; a corpus of (nearly) all distinct words overflows
+    it and the dedup is redone with the worst-case size -- same model as the oracle's."""
+    import ctypes as C
+    import filecmp
+    import json
+    from youtokentome_amd import _lib
+    import oracle_lib as O
+    rng = random.Random(31)
+    words = set()
+    while len(words) < 36000:
+        words.add("".join(rng.choice("abcdefgh") for _ in range(rng.randint(6, 9))))
+    text = (" ".join(words) + "\n").encode()
+    corpus, m_gpu, m_ora = str(tmp_path / "u.txt"), str(tmp_path / "gpu.model"), str(tmp_path / "ora.model")
+    open(corpus, "wb").write(text)
+    L = _lib.load()
+    err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+    rc = L.yttm_train_bpe_ex(corpus.encode(), m_gpu.encode(), 40, 1.0, 1, 0, 1, 2, 3, 0, rep, 16384, err, 2048)
+    assert rc == 0, err.value
+    assert json.loads(rep.value.decode())["word_table_retries"] == 1
+    O.train(text, m_ora, 40)
+    assert filecmp.cmp(m_gpu, m_ora, shallow=False)

@@ -484,6 +484,9 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
 void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n_alpha, uint32_t space_id, uint32_t n_ids_cap) {
   max_id_ = space_id;  // largest token id that can occur in a tile (alphabet now, new ids as they are made)
   for (uint32_t a = 0; a < n_alpha; a++) max_id_ = std::max(max_id_, id[a]);
+  id_min_ = space_id;  // (K3 counts the pairs of a small id range in a dense table)
+  for (uint32_t a = 0; a < n_alpha; a++) id_min_ = std::min(id_min_, id[a]);
+  id_max_ = max_id_;
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
@@ -521,24 +524,34 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   t_begin(KT_SEGS);
   launch_seg_write(d_text_, n_text_, d_seg, d_counters_ + 16, st_);
   t_end(KT_SEGS, n_text_ + 8 * n_segs);
-  // hash dedup
-  const unsigned long long ht_cap = pow2_at_least(n_segs + n_segs / 2 + 1024);
-  unsigned long long *ht_key = dmalloc<unsigned long long>(ht_cap);
-  unsigned long long *ht_cnt = dmalloc<unsigned long long>(ht_cap);
-  uint32_t *ht_len = dmalloc<uint32_t>(ht_cap);
-  launch_fill_u64(ht_key, PT_EMPTY, ht_cap, st_);
-  HIP_CHECK(hipMemsetAsync(ht_cnt, 0, ht_cap * 8, st_));
+  // hash dedup.  The table is sized for an eighth as many distinct words as there are occurrences (natural text and the
+  // benchmark corpora have far fewer: Heaps' law) -- the compaction pass streams it, and a small table keeps the frequent words'
+  // slots cache-resident; a corpus of mostly distinct words overflows it (probe chains beyond WH_MAX_PROBES) and is redone
+  // with the worst-case size.
+  unsigned long long *ht = nullptr;
+  unsigned long long ht_cap = 0;
   unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
-  HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
-  t_begin(KT_DEDUP);
-  launch_insert_words(d_text_, n_text_, d_cpmap_, d_seg, n_segs, ht_key, ht_cnt, ht_len, ht_cap - 1, d_status, st_);
-  t_end(KT_DEDUP, n_text_ + 8 * n_segs);
   unsigned int h_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
-  sync();
+  for (int attempt = 0;; attempt++) {
+    ht_cap = attempt == 0 && !getenv("YTTM_WORD_TABLE_FULL") ? pow2_at_least(std::max<unsigned long long>(n_segs / 4, 1ull << 16))
+                                                              : pow2_at_least(n_segs + n_segs / 2 + 1024);
+    ht = dmalloc<unsigned long long>(2 * ht_cap);
+    launch_word_table_clear(ht, ht_cap, st_);
+    HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
+    t_begin(KT_DEDUP);
+    launch_insert_words(d_text_, n_text_, d_cpmap_, d_seg, n_segs, ht, ht_cap - 1, d_status, st_);
+    t_end(KT_DEDUP, n_text_ + 8 * n_segs);
+    HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
+    sync();
+    // (more than half full counts as overflow too: the merge loop's tiles do not care, but probe chains do)
+    if (!h_status[6] && (attempt || (unsigned long long)h_status[0] * 2 <= ht_cap)) break;
+    if (attempt) { DFREE(ht); DFREE(d_seg); throw GpuError{"word table overflow"}; }
+    DFREE(ht);
+    word_table_retries++;
+  }
   DFREE(d_seg);
   if (h_status[5] >= (1u << 28)) {
-    DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len);
+    DFREE(ht);
     throw GpuError{"a word of 2^28 or more characters is not supported"};
   }
   const unsigned int U = h_status[0], UC = h_status[4], UB = h_status[2] - UC, UA = U - UB - UC;
@@ -550,7 +563,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   // slots as full as the longest word allows (HBM pages are then read densely and there are fewer tiles to visit).
   if (h_status[3] > 0 && h_status[3] < (unsigned int)TILE_NOM_A) cls_[0].nom = (unsigned int)TILE_SLOT_A - h_status[3];
   n_unique = U;
-  if (U == 0) { DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len); return; }
+  if (U == 0) { DFREE(ht); return; }
   unsigned long long *posA = dmalloc<unsigned long long>(UA), *posB = dmalloc<unsigned long long>(UB), *posC = dmalloc<unsigned long long>(UC);
   uint32_t *lenA = dmalloc<uint32_t>(UA), *lenB = dmalloc<uint32_t>(UB), *lenC = dmalloc<uint32_t>(UC);
   cls_[2].d_wcnt = dmalloc<uint32_t>(UC + 256);
@@ -559,11 +572,11 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   unsigned int *d_cursor = (unsigned int *)(d_counters_ + 32);
   HIP_CHECK(hipMemsetAsync(d_cursor, 0, 16, st_));
   t_begin(KT_BUILD);
-  launch_compact_words(ht_key, ht_cnt, ht_len, ht_cap, posA, cls_[0].d_wcnt, lenA, posB, cls_[1].d_wcnt, lenB, posC, cls_[2].d_wcnt, lenC, d_cursor,
+  launch_compact_words(d_text_, n_text_, d_cpmap_, ht, ht_cap, posA, cls_[0].d_wcnt, lenA, posB, cls_[1].d_wcnt, lenB, posC, cls_[2].d_wcnt, lenC, d_cursor,
                        d_status, st_);
   HIP_CHECK(hipMemcpyAsync(h_status, d_status, 16, hipMemcpyDeviceToHost, st_));
   sync();
-  DFREE(ht_key); DFREE(ht_cnt); DFREE(ht_len);
+  DFREE(ht);
   if (h_status[1] & 2u) { DFREE(posA); DFREE(posB); DFREE(lenA); DFREE(lenB); DFREE(posC); DFREE(lenC); throw GpuError{"a word occurs >= 2^32 times (uint32 word weights)"}; }
   build_class(0, posA, lenA, UA, space_id);
   build_class(1, posB, lenB, UB, space_id);
@@ -808,7 +821,7 @@ void GpuCtx::pair_count() {
   }
   ensure_table_capacity(bound);
   t_begin(KT_PAIR_COUNT);
-  for (int ci = 0; ci < 2; ci++) launch_pair_count(ci, cls_[ci].ts, pt_, db_, st_);
+  for (int ci = 0; ci < 2; ci++) launch_pair_count(ci, cls_[ci].ts, pt_, db_, id_min_, id_max_ >= id_min_ ? id_max_ - id_min_ + 1 : 0, st_);
   launch_giant(false, cls_[2].ts, cls_[2].slot, pt_, db_, nullptr, 0, 0xffffffffu, 0, cls_[2].d_scratch, d_stats_, st_);
   t_end(KT_PAIR_COUNT, 4 * n_tokens0 + 8 * n_unique);
   unsigned int nk = 0;
@@ -1317,7 +1330,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
                        &ba, ci == 0 && sa.on ? &sa : nullptr, st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
-  t_end(KT_MERGE, 0, /*chain=*/true);
+  t_end(KT_MERGE, 0, /*chain=*/!sa.on);  // (a fused round is followed by the host's turn, not by another kernel: its end event must not start the next interval)
   merge_rounds++;
   const char *trace_rounds = trace_rounds_;
   if (trace_rounds) {

@@ -83,6 +83,7 @@ class GpuCtx {
   // the pinned mailbox until the next scan
   const unsigned long long *last_hist() const { return last_hist_; }
   unsigned long long last_live() const { return last_live_; }
+  unsigned long long word_table_retries = 0;  // K2: the word table had to be redone with the worst-case size
   unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0;
   unsigned long long tail_ticks[3] = {0, 0, 0}, tail_listed = 0;  // round_tail: fold / list scan / publish, in 10 ns ticks; entries it read
   unsigned long long fused_rounds = 0, fused_overflows = 0;  // rounds whose candidate scan ran in the apply kernel's tail; of those, with a hot-list overflow
@@ -135,6 +136,7 @@ class GpuCtx {
   bool no_batch_args_ = false;
   const char *trace_rounds_ = nullptr, *dbg_cand_ = nullptr;
   bool fuse_enabled_ = true;  // YTTM_NO_FUSE=1: always the separate scan kernel (tuning hook / tests)
+  uint32_t id_min_ = 0, id_max_ = 0;  // id range of the alphabet (K3)
   uint32_t max_id_ = 0xffffffffu;  // largest token id in the tiles (unknown until the word table is built)
   unsigned long long scanned_cum_ = 0, live_tokens_last_ = 0, touched_cum_ = 0, touched_last_ = ~0ull >> 2;  // (first round: dense)
   unsigned int hot_cap_ = 0, hot_target_ = 0, hot_min_ = 0, listed_last_ = 0;

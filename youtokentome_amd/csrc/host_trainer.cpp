@@ -98,7 +98,11 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   // ---- merge loop
   std::vector<BPE_Rule> rules;
   rules.reserve((size_t)vocab_size);
-  const unsigned long long TARGET = getenv("YTTM_CAND_TARGET") ? strtoull(getenv("YTTM_CAND_TARGET"), nullptr, 10) : 256;  // candidates kept above the threshold (tuning hook)
+  // Candidates asked for per scan: about four times the recent batch size -- what the host does not look at still travels
+  // through the mailbox and the heap (natural text: batches of ~8 rules, random text: ~50).  YTTM_CAND_TARGET fixes it (tuning hook).
+  const unsigned long long target_fixed = getenv("YTTM_CAND_TARGET") ? strtoull(getenv("YTTM_CAND_TARGET"), nullptr, 10) : 0;
+  unsigned long long TARGET = target_fixed ? target_fixed : 256;
+  double batch_ema = 64;
   const uint32_t MX_ALL = 0xffffffffu;
   unsigned long long tau = 1;
   uint32_t tau_mx = MX_ALL;
@@ -179,6 +183,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       if (c.x == c.y) break;  // a self-pair rule must be the last of its batch
     }
     const uint32_t k = (uint32_t)batch_cnt.size();
+    const bool exhausted = heap.empty();  // the batch ended for lack of candidates, not at an intersection: ask for more next time
     for (uint32_t j = 0; j < k; j++) in_batch[batch_xyz[3 * j]] = in_batch[batch_xyz[3 * j + 1]] = 0;
     w_pick += since(tw1);
     auto tw2 = clk::now();
@@ -187,6 +192,10 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     for (uint32_t j = 0; j < k; j++) rules.push_back(BPE_Rule{batch_xyz[3 * j], batch_xyz[3 * j + 1], batch_xyz[3 * j + 2]});
     used_ids += k;
     rounds++;
+    if (!target_fixed) {
+      batch_ema = exhausted ? std::max(batch_ema, 2.0 * (double)k) : 0.9 * batch_ema + 0.1 * (double)k;
+      TARGET = (unsigned long long)std::min(512.0, std::max(32.0, 4.0 * batch_ema));
+    }
     // next threshold: keep about TARGET candidates above it (any threshold is valid, see above)
     tau = tau_hint;
     tau_mx = MX_ALL;
@@ -197,14 +206,16 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       fprintf(stderr, "[yttm] fused rounds %llu: tail set-up %.2f us, top-list scan %.2f us (%.0f entries), publish %.2f us per round\n", g.fused_rounds,
               g.tail_ticks[0] * 0.01 / g.fused_rounds, g.tail_ticks[1] * 0.01 / g.fused_rounds, (double)g.tail_listed / g.fused_rounds,
               g.tail_ticks[2] * 0.01 / g.fused_rounds);
-    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu, hot rebuilds %llu, pair table %llu keys in %llu slots (%llu rehashes)\n",
-                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.hot_rebuilds, g.n_keys_host, g.table_capacity(), g.rehashes);
+    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu, hot rebuilds %llu, top refills %llu, pair table %llu keys in %llu slots (%llu rehashes)\n",
+                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.hot_rebuilds, g.top_refills, g.n_keys_host, g.table_capacity(), g.rehashes);
     rep->rounds = rounds;
     rep->cand_rescans = rescans;
     rep->hot_rebuilds = g.hot_rebuilds;
     rep->fused_rounds = g.fused_rounds;
     rep->fused_overflows = g.fused_overflows;
     rep->exchange_retries = g.exchange_retries;
+    rep->word_table_retries = g.word_table_retries;
+    rep->top_refills = g.top_refills;
     rep->rules = rules.size();
     rep->n_unique = g.n_unique;
     rep->n_tokens = g.n_tokens0;

@@ -233,22 +233,28 @@ __device__ inline bool seg_equal(const uint8_t *__restrict__ text, unsigned long
 
 constexpr unsigned long long WH_POS_MASK = (1ull << 40) - 1;
 constexpr int WL_SLOTS = 128;  // per-workgroup LDS combiner for the most frequent words (measured at 1 GB, dedup ms abcd/Zipf: 32 slots 38/51, 128: 23/19, 256: 24/20, 512: 25/22, 2048: 37/31)
+// Word table in HBM: 16-byte slots { key, count } -- the probe of a word and the update of its count touch ONE sector.
+//   key = tag:8 | min(tokens, 0xffff):16 | byte offset of the representative segment:40   (PT_EMPTY = free)
+// A probe compares tag and length first (24 bits) and then, always, the representative's bytes: the dedup is exact.
+constexpr uint32_t WH_LEN_CAP = 0xffffu;
+__device__ inline unsigned long long wh_key(unsigned long long h, uint32_t len_tokens, unsigned long long pos) {
+  const unsigned long long l16 = len_tokens < WH_LEN_CAP ? len_tokens : WH_LEN_CAP;
+  return ((h >> 56) << 56) | (l16 << 40) | pos;
+}
+constexpr int WH_MAX_PROBES = 4096;  // longer than this: the table was sized too small for this corpus (status[6]; the host retries)
 
 // insert-or-add `count` occurrences of the word whose representative segment starts at `pos` into the HBM table
 __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap,
                                           unsigned long long h, unsigned long long pos, uint32_t len_tokens, unsigned long long count,
-                                          unsigned long long *__restrict__ ht_key, unsigned long long *__restrict__ ht_cnt,
-                                          uint32_t *__restrict__ ht_len, unsigned long long ht_mask, unsigned int *__restrict__ status) {
-  const unsigned long long tag = h >> 40;
-  const unsigned long long mine = (tag << 40) | pos;
-  unsigned long long i = h & ht_mask;
-  for (;;) {
-    unsigned long long cur = ld_agent(&ht_key[i]);
+                                          unsigned long long *__restrict__ ht, unsigned long long ht_mask, unsigned int *__restrict__ status) {
+  const unsigned long long mine = wh_key(h, len_tokens, pos);
+  unsigned long long i = (h >> 8) & ht_mask;
+  for (int probes = 0; probes < WH_MAX_PROBES; probes++) {
+    unsigned long long cur = ld_agent(&ht[2 * i]);
     if (cur == PT_EMPTY) {
-      cur = atomicCAS(&ht_key[i], PT_EMPTY, mine);
+      cur = atomicCAS(&ht[2 * i], PT_EMPTY, mine);
       if (cur == PT_EMPTY) {
-        ht_len[i] = len_tokens;  // read only by later kernels
-        atomicAdd(&ht_cnt[i], count);
+        atomicAdd(&ht[2 * i + 1], count);
         atomicAdd(&status[0], 1u);  // `status` is the workgroup's LDS copy (k2b_insert_words): 1.6e7 bumps of one HBM counter cost ~2 ns each
         if (len_tokens > (uint32_t)TILE_NOM_A) atomicAdd(&status[2], 1u);
         if (len_tokens > (uint32_t)TILE_NOM_B) {  // class C (very long words): count and longest
@@ -258,12 +264,13 @@ __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsi
         return;
       }
     }
-    if ((cur >> 40) == tag && seg_equal(text, n, cpmap, cur & WH_POS_MASK, pos)) {
-      atomicAdd(&ht_cnt[i], count);
+    if ((cur >> 40) == (mine >> 40) && seg_equal(text, n, cpmap, cur & WH_POS_MASK, pos)) {
+      atomicAdd(&ht[2 * i + 1], count);
       return;
     }
     i = (i + 1) & ht_mask;
   }
+  atomicOr(&status[6], 1u);
 }
 
 // One thread per segment.  Frequent (short) words would otherwise hammer a handful of HBM addresses with atomics, so
@@ -273,9 +280,8 @@ __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsi
 __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restrict__ text, unsigned long long n,
                                                           const uint32_t *__restrict__ cpmap,
                                                           const unsigned long long *__restrict__ seg_pos, unsigned long long n_segs,
-                                                          unsigned long long *__restrict__ ht_key, unsigned long long *__restrict__ ht_cnt,
-                                                          uint32_t *__restrict__ ht_len, unsigned long long ht_mask,
-                                                          unsigned int *__restrict__ status /* [0]=n_unique [1]=flags [2]=n_unique of classes B+C [3]=longest class-A word [4]=n_unique of class C [5]=longest word */) {
+                                                          unsigned long long *__restrict__ ht, unsigned long long ht_mask,
+                                                          unsigned int *__restrict__ status /* [0]=n_unique [1]=flags [2]=n_unique of classes B+C [3]=longest class-A word [4]=n_unique of class C [5]=longest word [6]=table too small */) {
   __shared__ unsigned long long l_key[WL_SLOTS];   // (tag:24 | pos:40) or PT_EMPTY
   __shared__ unsigned long long l_hash[WL_SLOTS];  // full hash of the word (for the flush)
   __shared__ unsigned int l_cnt[WL_SLOTS];
@@ -318,13 +324,13 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
         j = (j + 1) & (WL_SLOTS - 1);
       }
     }
-    if (!done) word_insert_global(text, n, cpmap, h, pos, L + 1, 1ull, ht_key, ht_cnt, ht_len, ht_mask, l_status);
+    if (!done) word_insert_global(text, n, cpmap, h, pos, L + 1, 1ull, ht, ht_mask, l_status);
   }
   __syncthreads();
   for (int i = (int)threadIdx.x; i < WL_SLOTS; i += BLOCK) {
     const unsigned long long k = l_key[i];
     if (k != PT_EMPTY)
-      word_insert_global(text, n, cpmap, l_hash[i], k & WH_POS_MASK, l_len[i], (unsigned long long)l_cnt[i], ht_key, ht_cnt, ht_len, ht_mask, l_status);
+      word_insert_global(text, n, cpmap, l_hash[i], k & WH_POS_MASK, l_len[i], (unsigned long long)l_cnt[i], ht, ht_mask, l_status);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -333,32 +339,37 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
     if (l_status[2]) atomicAdd(&status[2], l_status[2]);
     if (l_status[4]) atomicAdd(&status[4], l_status[4]);
     if (l_status[5]) atomicMax(&status[5], l_status[5]);
+    if (l_status[6]) atomicOr(&status[6], 1u);
   }
 }
 
 // Compact occupied hash slots into the unique-word arrays of the two tile classes (short words: block-aggregated
 // append; long words are rare: one atomic each).  Order is not significant.
-__global__ __launch_bounds__(BLOCK) void k2c_compact_words(const unsigned long long *__restrict__ ht_key,
-                                                           const unsigned long long *__restrict__ ht_cnt,
-                                                           const uint32_t *__restrict__ ht_len, unsigned long long n_slots,
+__global__ __launch_bounds__(BLOCK) void k2c_compact_words(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap,
+                                                           const unsigned long long *__restrict__ ht, unsigned long long n_slots,
                                                            unsigned long long *__restrict__ posA, uint32_t *__restrict__ cntA,
                                                            uint32_t *__restrict__ lenA, unsigned long long *__restrict__ posB,
                                                            uint32_t *__restrict__ cntB, uint32_t *__restrict__ lenB,
                                                            unsigned long long *__restrict__ posC, uint32_t *__restrict__ cntC,
                                                            uint32_t *__restrict__ lenC, unsigned int *__restrict__ cursor /* [0]=A [1]=B [2]=C */,
                                                            unsigned int *__restrict__ status) {
-  // The table is sized by the number of word OCCURRENCES and is mostly empty (6 % occupied at C2): this is a 2 GB stream of
-  // keys.  A workgroup takes CH consecutive slots, counts its class-A words, reserves their places with ONE atomic (a
-  // cursor bumped once per 256 slots serialised at ~11 ns per atomic: 12 ms) and writes them in a second pass over the
-  // same, now cached, slots.
+  // A workgroup takes CH consecutive slots (16-byte loads), counts its class-A words, reserves their places with ONE atomic (a
+  // cursor bumped once per 256 slots serialised at ~11 ns per atomic: 12 ms) and writes them in a second pass over the same,
+  // now cached, slots.  The table is sized by an estimate of the number of distinct words, not by the number of occurrences.
   constexpr unsigned long long CH = 64 * BLOCK;
   __shared__ uint32_t scan_lds[NWAVES];
   __shared__ unsigned int blk_base;
+  const uint4 *slots = reinterpret_cast<const uint4 *>(ht);
   for (unsigned long long c0 = (unsigned long long)blockIdx.x * CH; c0 < n_slots; c0 += (unsigned long long)gridDim.x * CH) {
     uint32_t mine = 0;
     for (int j = 0; j < 64; j++) {
       const unsigned long long i = c0 + (unsigned long long)j * BLOCK + threadIdx.x;
-      if (i < n_slots && ht_key[i] != PT_EMPTY && ht_len[i] <= (uint32_t)TILE_NOM_A) mine++;
+      if (i < n_slots) {
+        const uint4 v = slots[i];
+        const bool used = !(v.x == 0xffffffffu && v.y == 0xffffffffu);
+        const uint32_t l16 = (v.y >> 8) & 0xffffu;
+        if (used && l16 <= (uint32_t)TILE_NOM_A) mine++;
+      }
     }
     uint32_t total;
     const uint32_t off = block_excl_scan(mine, scan_lds, &total);
@@ -368,10 +379,14 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const unsigned long l
     for (int j = 0; j < 64; j++) {
       const unsigned long long i = c0 + (unsigned long long)j * BLOCK + threadIdx.x;
       if (i >= n_slots) break;
-      const unsigned long long k = ht_key[i];
-      if (k == PT_EMPTY) continue;
-      const uint32_t len = ht_len[i];
-      const unsigned long long c = ht_cnt[i];
+      const uint4 v = slots[i];
+      if (v.x == 0xffffffffu && v.y == 0xffffffffu) continue;
+      const unsigned long long k = ((unsigned long long)v.y << 32) | v.x, c = ((unsigned long long)v.w << 32) | v.z;
+      uint32_t len = (uint32_t)(k >> 40) & 0xffffu;
+      if (len >= WH_LEN_CAP) {  // (a word of 65535 tokens or more: its exact length from the representative)
+        unsigned long long hh;
+        len = seg_scan(text, n, cpmap, k & WH_POS_MASK, &hh) + 1u;
+      }
       if (c > 0xffffffffull) atomicOr(&status[1], 2u);  // a word seen >= 2^32 times: weights are uint32
       if (len > (uint32_t)TILE_NOM_B) {
         const unsigned int o = atomicAdd(&cursor[2], 1u);
@@ -386,6 +401,14 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const unsigned long l
     }
     __syncthreads();
   }
+}
+
+// {PT_EMPTY, 0} in every slot of the word table
+__global__ __launch_bounds__(BLOCK) void k_wh_clear(uint4 *__restrict__ slots, unsigned long long n) {
+  unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
+  const uint4 e{0xffffffffu, 0xffffffffu, 0u, 0u};
+  for (; i < n; i += stride) slots[i] = e;
 }
 
 // ---- generic exclusive scan of uint32 -> uint64 (3 kernels: block sums, scan of sums, add) ------------------------
@@ -585,20 +608,21 @@ void launch_hist_compact(const unsigned long long *hist, uint32_t *cps, unsigned
                          unsigned int cap, hipStream_t st) {
   hipLaunchKernelGGL(k_hist_compact, dim3((N_CODEPOINTS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, hist, cps, cnts, n_out, cap);
 }
-void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *seg_pos,
-                         unsigned long long n_segs, unsigned long long *ht_key, unsigned long long *ht_cnt, uint32_t *ht_len,
-                         unsigned long long ht_mask, unsigned int *status, hipStream_t st) {
-  unsigned int g = grid_for(n_segs, BLOCK, 256 * 32);
-  hipLaunchKernelGGL(k2b_insert_words, dim3(g), dim3(BLOCK), 0, st, text, n, cpmap, seg_pos, n_segs, ht_key, ht_cnt, ht_len,
-                     ht_mask, status);
-}
-void launch_compact_words(const unsigned long long *ht_key, const unsigned long long *ht_cnt, const uint32_t *ht_len,
-                          unsigned long long n_slots, unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB,
-                          uint32_t *cntB, uint32_t *lenB, unsigned long long *posC, uint32_t *cntC, uint32_t *lenC, unsigned int *cursor,
-                          unsigned int *status, hipStream_t st) {
+void launch_word_table_clear(unsigned long long *ht, unsigned long long n_slots, hipStream_t st) {
   unsigned int g = grid_for(n_slots, BLOCK, 256 * 16);
-  hipLaunchKernelGGL(k2c_compact_words, dim3(g), dim3(BLOCK), 0, st, ht_key, ht_cnt, ht_len, n_slots, posA, cntA, lenA, posB, cntB, lenB,
-                     posC, cntC, lenC, cursor, status);
+  hipLaunchKernelGGL(k_wh_clear, dim3(g), dim3(BLOCK), 0, st, reinterpret_cast<uint4 *>(ht), n_slots);
+}
+void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *seg_pos,
+                         unsigned long long n_segs, unsigned long long *ht, unsigned long long ht_mask, unsigned int *status, hipStream_t st) {
+  unsigned int g = grid_for(n_segs, BLOCK, 256 * 32);
+  hipLaunchKernelGGL(k2b_insert_words, dim3(g), dim3(BLOCK), 0, st, text, n, cpmap, seg_pos, n_segs, ht, ht_mask, status);
+}
+void launch_compact_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *ht, unsigned long long n_slots,
+                          unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB, uint32_t *cntB, uint32_t *lenB,
+                          unsigned long long *posC, uint32_t *cntC, uint32_t *lenC, unsigned int *cursor, unsigned int *status, hipStream_t st) {
+  unsigned int g = grid_for(n_slots, BLOCK, 256 * 16);
+  hipLaunchKernelGGL(k2c_compact_words, dim3(g), dim3(BLOCK), 0, st, text, n, cpmap, ht, n_slots, posA, cntA, lenA, posB, cntB, lenB, posC, cntC, lenC,
+                     cursor, status);
 }
 void launch_exclusive_scan(const uint32_t *in, unsigned long long n, unsigned long long *out, unsigned long long *block_sums,
                            unsigned long long *total_out, hipStream_t st) {

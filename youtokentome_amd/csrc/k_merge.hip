@@ -720,15 +720,21 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         const uint32_t t0 = W.tk[p], t1 = W.tk[p + 1];
         if (t1 & TOK_WS) continue;
         const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
+        // K3 on a small alphabet (self_z = smallest id, z_base = number of ids, <= 32): the pair IS the index of a dense table of
+        // counts in LDS -- one ds_add_u64 per adjacency instead of a hash probe (compare, CAS, add)
+        unsigned long long *dense = reinterpret_cast<unsigned long long *>(A.flagbits);
+        const bool use_dense = z_base != 0;
         if (a != b) {
-          emit<SLOT>(A, W, pt, db, pair_key(a, b), f);
+          if (use_dense) atomicAdd(&dense[(a - self_z) * z_base + (b - self_z)], (unsigned long long)f);
+          else emit<SLOT>(A, W, pt, db, pair_key(a, b), f);
         } else {
           const bool run_start = (t0 & TOK_WS) || p == 0 || (W.tk[p - 1] & TOK_MASK) != a;
           if (run_start) {
             int q = p + 1;
             while (!(W.tk[q + 1] & TOK_WS) && (W.tk[q + 1] & TOK_MASK) == a) q++;
             const long long len = q - p + 1;
-            emit<SLOT>(A, W, pt, db, pair_key(a, a), (len / 2) * f);
+            if (use_dense) atomicAdd(&dense[(a - self_z) * z_base + (a - self_z)], (unsigned long long)((len / 2) * f));
+            else emit<SLOT>(A, W, pt, db, pair_key(a, a), (len / 2) * f);
           }
         }
       }
@@ -1086,6 +1092,11 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
       rridx[i] = (uint16_t)(rules[i].z - z_base);
     }
   }
+  if (!MERGE && z_base) {  // K3, small alphabet: the dense pair table (see process_tile) lives where K4 keeps its flag bitmap
+    static_assert(FLAG_LDS_IDS / 16 * sizeof(uint32_t) >= 32 * 32 * sizeof(unsigned long long), "32 x 32 counts");
+    unsigned long long *dense = reinterpret_cast<unsigned long long *>(A.flagbits);
+    for (unsigned int i = threadIdx.x; i < z_base * z_base; i += WPB * 64) dense[i] = 0;
+  }
   const RuleTab<LDSR> rtab{rkeys, rridx, rules, rule_mask, z_base};
   __syncthreads();
   const int wave = uni((int)(threadIdx.x >> 6)), lane = lane_id();
@@ -1229,6 +1240,13 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
   if (MERGE) K4_MARK(11);  // waiting for the other waves of the workgroup
 #endif
   agg_flush<WPB * 64>(A, pt, db);
+  if (!MERGE && z_base) {  // (after agg_flush's barrier: every wave is done counting)
+    const unsigned long long *dense = reinterpret_cast<const unsigned long long *>(A.flagbits);
+    for (unsigned int i = threadIdx.x; i < z_base * z_base; i += WPB * 64) {
+      const unsigned long long v = dense[i];
+      if (v) global_emit(pt, db, pair_key(self_z + i / z_base, self_z + i % z_base), (long long)v, &A.new_keys);
+    }
+  }
   __syncthreads();
 #ifdef YTTM_K4_PROF
   if (MERGE) {
@@ -1908,15 +1926,16 @@ static inline unsigned int tile_grid(unsigned int n_tiles, unsigned int wpb, uns
   return g ? g : 1u;
 }
 
-void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st) {
+void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, uint32_t id_min, uint32_t n_ids, hipStream_t st) {
   if (!ts.n_tiles) return;
+  if (n_ids > 32) n_ids = 0;  // (the dense table holds 32 x 32 counts; larger alphabets go through the LDS hash)
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
-                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
+                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, id_min, n_ids,
                        (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{}, ScanArgs{});
   else
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, false, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db,
-                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, 0u, 0u,
+                       (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, id_min, n_ids,
                        (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{}, ScanArgs{});
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,

@@ -26,12 +26,13 @@ void launch_char_hist(const uint8_t *text, unsigned long long n, unsigned long l
 void launch_seg_write(const uint8_t *text, unsigned long long n, unsigned long long *seg_pos, unsigned long long *seg_cursor, hipStream_t st);
 void launch_hist_compact(const unsigned long long *hist, uint32_t *cps, unsigned long long *cnts, unsigned int *n_out, unsigned int cap,
                          hipStream_t st);
+// word table (K2b/K2c): n_slots 16-byte slots { key, count }, see k_frontend.hip
+void launch_word_table_clear(unsigned long long *ht, unsigned long long n_slots, hipStream_t st);
 void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *seg_pos,
-                         unsigned long long n_segs, unsigned long long *ht_key, unsigned long long *ht_cnt, uint32_t *ht_len,
-                         unsigned long long ht_mask, unsigned int *status, hipStream_t st);
-void launch_compact_words(const unsigned long long *ht_key, const unsigned long long *ht_cnt, const uint32_t *ht_len,
-                          unsigned long long n_slots, unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB,
-                          uint32_t *cntB, uint32_t *lenB, unsigned long long *posC, uint32_t *cntC, uint32_t *lenC, unsigned int *cursor, unsigned int *status, hipStream_t st);
+                         unsigned long long n_segs, unsigned long long *ht, unsigned long long ht_mask, unsigned int *status, hipStream_t st);
+void launch_compact_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *ht, unsigned long long n_slots,
+                          unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB, uint32_t *cntB, uint32_t *lenB,
+                          unsigned long long *posC, uint32_t *cntC, uint32_t *lenC, unsigned int *cursor, unsigned int *status, hipStream_t st);
 void launch_exclusive_scan(const uint32_t *in, unsigned long long n, unsigned long long *out, unsigned long long *block_sums,
                            unsigned long long *total_out, hipStream_t st);
 unsigned long long scan_scratch_blocks(unsigned long long n);
@@ -74,7 +75,9 @@ void launch_top_scan(const PairTable &pt, const ScanArgs &sa, unsigned long long
                      const BatchArgs *zba, unsigned long long *xstat, hipStream_t st);
 void launch_top_rebuild(const PairTable &pt, unsigned int listed_hint, hipStream_t st);
 void launch_publish_box(const unsigned char *box, unsigned char *mailbox, unsigned int fast, uint32_t round_id, unsigned long long *xstat, hipStream_t st);
-void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, hipStream_t st);
+// id_min / n_ids: the token ids in the tiles are id_min .. id_min + n_ids - 1 (K3 runs before any merge: the alphabet); n_ids <= 32
+// counts pairs in a dense LDS table, 0 (unknown / larger) in the LDS hash
+void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, uint32_t id_min, uint32_t n_ids, hipStream_t st);
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                         uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
