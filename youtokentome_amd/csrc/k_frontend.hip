@@ -233,7 +233,8 @@ __device__ inline bool seg_equal(const uint8_t *__restrict__ text, unsigned long
 
 constexpr unsigned long long WH_POS_MASK = (1ull << 40) - 1;
 constexpr int WL_SLOTS = 128;  // per-workgroup LDS combiner for the most frequent words (measured at 1 GB, dedup ms abcd/Zipf: 32 slots 38/51, 128: 23/19, 256: 24/20, 512: 25/22, 2048: 37/31)
-// Word table in HBM: 16-byte slots { key, count } -- the probe of a word and the update of its count touch ONE sector.
+// Word table in HBM: keys in ht[0 .. cap), counts in ht[cap .. 2 cap).  (One 16-byte slot per word was measured 2.3x slower:
+// the atomics on a frequent word's count then serialise with every other workgroup's read of its key -- same cache line.)
 //   key = tag:8 | min(tokens, 0xffff):16 | byte offset of the representative segment:40   (PT_EMPTY = free)
 // A probe compares tag and length first (24 bits) and then, always, the representative's bytes: the dedup is exact.
 constexpr uint32_t WH_LEN_CAP = 0xffffu;
@@ -250,11 +251,11 @@ __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsi
   const unsigned long long mine = wh_key(h, len_tokens, pos);
   unsigned long long i = (h >> 8) & ht_mask;
   for (int probes = 0; probes < WH_MAX_PROBES; probes++) {
-    unsigned long long cur = ld_agent(&ht[2 * i]);
+    unsigned long long cur = ld_agent(&ht[i]);
     if (cur == PT_EMPTY) {
-      cur = atomicCAS(&ht[2 * i], PT_EMPTY, mine);
+      cur = atomicCAS(&ht[i], PT_EMPTY, mine);
       if (cur == PT_EMPTY) {
-        atomicAdd(&ht[2 * i + 1], count);
+        atomicAdd(&ht[ht_mask + 1 + i], count);
         atomicAdd(&status[0], 1u);  // `status` is the workgroup's LDS copy (k2b_insert_words): 1.6e7 bumps of one HBM counter cost ~2 ns each
         if (len_tokens > (uint32_t)TILE_NOM_A) atomicAdd(&status[2], 1u);
         if (len_tokens > (uint32_t)TILE_NOM_B) {  // class C (very long words): count and longest
@@ -265,7 +266,7 @@ __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsi
       }
     }
     if ((cur >> 40) == (mine >> 40) && seg_equal(text, n, cpmap, cur & WH_POS_MASK, pos)) {
-      atomicAdd(&ht[2 * i + 1], count);
+      atomicAdd(&ht[ht_mask + 1 + i], count);
       return;
     }
     i = (i + 1) & ht_mask;
@@ -353,22 +354,20 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const uint8_t *__rest
                                                            unsigned long long *__restrict__ posC, uint32_t *__restrict__ cntC,
                                                            uint32_t *__restrict__ lenC, unsigned int *__restrict__ cursor /* [0]=A [1]=B [2]=C */,
                                                            unsigned int *__restrict__ status) {
-  // A workgroup takes CH consecutive slots (16-byte loads), counts its class-A words, reserves their places with ONE atomic (a
+  // A workgroup takes CH consecutive slots, counts its class-A words, reserves their places with ONE atomic (a
   // cursor bumped once per 256 slots serialised at ~11 ns per atomic: 12 ms) and writes them in a second pass over the same,
   // now cached, slots.  The table is sized by an estimate of the number of distinct words, not by the number of occurrences.
   constexpr unsigned long long CH = 64 * BLOCK;
   __shared__ uint32_t scan_lds[NWAVES];
   __shared__ unsigned int blk_base;
-  const uint4 *slots = reinterpret_cast<const uint4 *>(ht);
+  const unsigned long long *keys = ht, *cnts = ht + n_slots;
   for (unsigned long long c0 = (unsigned long long)blockIdx.x * CH; c0 < n_slots; c0 += (unsigned long long)gridDim.x * CH) {
     uint32_t mine = 0;
     for (int j = 0; j < 64; j++) {
       const unsigned long long i = c0 + (unsigned long long)j * BLOCK + threadIdx.x;
       if (i < n_slots) {
-        const uint4 v = slots[i];
-        const bool used = !(v.x == 0xffffffffu && v.y == 0xffffffffu);
-        const uint32_t l16 = (v.y >> 8) & 0xffffu;
-        if (used && l16 <= (uint32_t)TILE_NOM_A) mine++;
+        const unsigned long long k = keys[i];
+        if (k != PT_EMPTY && ((uint32_t)(k >> 40) & 0xffffu) <= (uint32_t)TILE_NOM_A) mine++;
       }
     }
     uint32_t total;
@@ -379,9 +378,9 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const uint8_t *__rest
     for (int j = 0; j < 64; j++) {
       const unsigned long long i = c0 + (unsigned long long)j * BLOCK + threadIdx.x;
       if (i >= n_slots) break;
-      const uint4 v = slots[i];
-      if (v.x == 0xffffffffu && v.y == 0xffffffffu) continue;
-      const unsigned long long k = ((unsigned long long)v.y << 32) | v.x, c = ((unsigned long long)v.w << 32) | v.z;
+      const unsigned long long k = keys[i];
+      if (k == PT_EMPTY) continue;
+      const unsigned long long c = cnts[i];
       uint32_t len = (uint32_t)(k >> 40) & 0xffffu;
       if (len >= WH_LEN_CAP) {  // (a word of 65535 tokens or more: its exact length from the representative)
         unsigned long long hh;
@@ -403,12 +402,11 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const uint8_t *__rest
   }
 }
 
-// {PT_EMPTY, 0} in every slot of the word table
-__global__ __launch_bounds__(BLOCK) void k_wh_clear(uint4 *__restrict__ slots, unsigned long long n) {
+// keys = PT_EMPTY, counts = 0
+__global__ __launch_bounds__(BLOCK) void k_wh_clear(unsigned long long *__restrict__ ht, unsigned long long n_slots) {
   unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
-  const uint4 e{0xffffffffu, 0xffffffffu, 0u, 0u};
-  for (; i < n; i += stride) slots[i] = e;
+  for (; i < 2 * n_slots; i += stride) ht[i] = i < n_slots ? PT_EMPTY : 0ull;
 }
 
 // ---- generic exclusive scan of uint32 -> uint64 (3 kernels: block sums, scan of sums, add) ------------------------
@@ -610,7 +608,7 @@ void launch_hist_compact(const unsigned long long *hist, uint32_t *cps, unsigned
 }
 void launch_word_table_clear(unsigned long long *ht, unsigned long long n_slots, hipStream_t st) {
   unsigned int g = grid_for(n_slots, BLOCK, 256 * 16);
-  hipLaunchKernelGGL(k_wh_clear, dim3(g), dim3(BLOCK), 0, st, reinterpret_cast<uint4 *>(ht), n_slots);
+  hipLaunchKernelGGL(k_wh_clear, dim3(g), dim3(BLOCK), 0, st, ht, n_slots);
 }
 void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *seg_pos,
                          unsigned long long n_segs, unsigned long long *ht, unsigned long long ht_mask, unsigned int *status, hipStream_t st) {
