@@ -105,15 +105,6 @@ def test_encode_mixed_shapes():
     S.check_encode_mixed_shapes(n_sent=150)
 
 
-def test_encode_cooperative_rounds_for_every_pack(monkeypatch):
-    """K5 merges the words of a pack one per lane; packs with a word of more than 64 tokens (and, with YTTM_ENC_COOP, all packs)
-    take the cooperative rounds, lanes = token positions.  Both must give the reference's ids."""
-    monkeypatch.setenv("YTTM_ENC_COOP", "1")
-    S.check_encode_mixed_shapes(n_sent=60, seed=5)
-    for name in ("readme_small", "nopad", "mix_cov"):
-        S.check_golden_encode(name)
-
-
 def test_hot_list_rebuilds(tmp_path, monkeypatch):
     """The candidate filter reads a hot list of pairs instead of the whole pair table; shrink the list so that tiny corpora
     go through its rebuild, overflow and whole-table fallback paths, and demand the same models."""

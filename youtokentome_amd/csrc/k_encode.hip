@@ -6,8 +6,6 @@
 // wavefront runs those rounds for ALL words of its sentence at once: lanes = token positions, word-segmented minimum
 // through LDS atomics, x==x runs resolved by parity from the run start, in-place compaction with wave ballots.
 // Working arrays live in LDS (3 x 4 B per token); sentences too long for LDS use an HBM scratch with the same code.
-#include <stdlib.h>
-
 #include "yttm_device.h"
 #include "yttm_kernels.h"
 
@@ -356,114 +354,6 @@ __device__ int merge_rounds(const EncModel &m, const uint32_t *bloom, A wt, A wr
   return n;
 }
 
-// Merging with ONE WORD PER LANE (LDS path, dropout off).  The cooperative rounds above cost (rounds of the slowest word) x
-// (chunks of the pack) whatever the words look like; sentences of natural length are packs of ~100 short words whose merges are
-// independent, so here every lane takes a word and merges it sequentially in its own slice of the LDS arrays -- the reference's
-// per-word loop (bpe.cpp:1532-1589): the smallest rule index among the word's adjacent pairs, all its occurrences left to right,
-// again -- with no cross-lane traffic at all; the words of a pack are handed out 64 at a time.  Words longer than
-// ENC_LANE_WORD tokens keep the cooperative path (whole pack).  wr[i] = priority of the pair (i, i+1) or ENC_INF / ENC_DIRTY;
-// afterwards wr[word start] = the word's new length and the pack is compacted cooperatively.  Returns the new token count,
-// or -1 if the pack has a word that is too long (nothing modified).
-constexpr int ENC_LANE_WORD = 64;
-__device__ int merge_words_per_lane(const EncModel &m, const uint32_t *bloom, LdsArr wt, LdsArr wr, LdsArr wm, int n) {
-  const int lane = lane_id();
-  const unsigned long long lt = lanemask_lt();
-  // word starts -> wm[0 .. nw)   (a pack of n tokens has at most n words; wm has ENC_WCAP entries)
-  int nw = 0;
-  int prev_ws = 0;
-  bool too_long = false;
-  for (int c = 0; c < ((n + 63) >> 6); c++) {
-    const int p = c * 64 + lane;
-    const bool ws = p < n && (wt.get(p) & TOK_WS);
-    const unsigned long long W = __ballot(ws);
-    if (ws) wm.set(nw + __popcll(W & lt), (uint32_t)p);
-    // longest word: distance between consecutive starts
-    if (W) {
-      unsigned long long rest = W;
-      int last = prev_ws;
-      while (rest) {  // (uniform loop: a chunk has few word starts compared with a per-lane search)
-        const int j = __ffsll((long long)rest) - 1;
-        if (c * 64 + j - last > ENC_LANE_WORD) too_long = true;
-        last = c * 64 + j;
-        rest &= rest - 1;
-      }
-      prev_ws = last;
-    }
-    nw += __popcll(W);
-  }
-  if (n - prev_ws > ENC_LANE_WORD) too_long = true;
-  if (too_long) return -1;
-  wave_sync();
-  for (int w0 = 0; w0 < nw; w0 += 64) {
-    const int w = w0 + lane;
-    if (w < nw) {
-      const int ws = (int)wm.get(w);
-      const int we = w + 1 < nw ? (int)wm.get(w + 1) : n;
-      int len = we - ws;
-      for (int i = 0; i < len; i++) wr.set(ws + i, i + 1 < len ? ENC_DIRTY : ENC_INF);
-      for (;;) {
-        // smallest rule index among the word's pairs (pairs next to the last merges are looked up now)
-        uint32_t rmin = ENC_INF;
-        for (int i = 0; i + 1 < len; i++) {
-          uint32_t r = wr.get(ws + i);
-          if (r == ENC_DIRTY) {
-            const uint32_t a = wt.get(ws + i) & ENC_IDM, b = wt.get(ws + i + 1) & ENC_IDM;
-            r = (a == ENC_UNKP || b == ENC_UNKP) ? ENC_INF : enc_pair_prio(m, bloom, a, b);
-            wr.set(ws + i, r);
-          }
-          rmin = r < rmin ? r : rmin;
-        }
-        if (rmin == ENC_INF) break;
-        // all its occurrences, left to right (x x x: the first two, like the reference's position order), compacting in place
-        const uint32_t z = enc_rule_z(m, rmin);
-        int o = 0;
-        for (int i = 0; i < len;) {
-          const uint32_t t0 = wt.get(ws + i);
-          if (i + 1 < len && wr.get(ws + i) == rmin) {
-            wt.set(ws + o, z | (t0 & (TOK_WS | ENC_SENT)));
-            if (o > 0) wr.set(ws + o - 1, ENC_DIRTY);
-            // the pair that starts at the new token: unknown if something follows (i + 2 < len), none otherwise
-            const uint32_t after = i + 2 < len ? ENC_DIRTY : ENC_INF;
-            i += 2;
-            wr.set(ws + o, after);
-          } else {
-            const uint32_t r = wr.get(ws + i);
-            wt.set(ws + o, t0);
-            wr.set(ws + o, r);
-            i += 1;
-          }
-          o++;
-        }
-        len = o;
-        wr.set(ws + len - 1, ENC_INF);
-      }
-      wr.set(ws, (uint32_t)len);  // (priorities are not needed any more: the word's new length, at its first position)
-    }
-  }
-  wave_sync();
-  // compaction, chunk by chunk in position order (writes never pass unread data): a token survives iff its offset in its word
-  // is below the word's new length.  What lies behind that in a word's old slice are stale copies of non-first tokens: they
-  // never carry TOK_WS, so the word starts are still exactly the TOK_WS positions.
-  int base = 0, carry_ws = 0;
-  for (int c = 0; c < ((n + 63) >> 6); c++) {
-    const int p = c * 64 + lane;
-    const uint32_t t0 = p < n ? wt.get(p) : 0u;
-    const bool ws = p < n && (t0 & TOK_WS);
-    const unsigned long long W = __ballot(ws);
-    int wsp = carry_ws;
-    const unsigned long long wle = W & ((2ull << lane) - 1ull);
-    if (wle) wsp = c * 64 + 63 - __clzll((long long)wle);
-    if (W) carry_ws = c * 64 + 63 - __clzll((long long)W);
-    const bool alive = p < n && (uint32_t)(p - wsp) < wr.get(wsp);
-    const unsigned long long AM = __ballot(alive);
-    wave_sync();  // all lanes have read their inputs before anyone overwrites lower positions
-    if (alive) wt.set(base + __popcll(AM & lt), t0);
-    base += __popcll(AM);
-    wave_sync();
-  }
-  return base;
-}
-
 // Cooperative path: one wavefront encodes one sentence, lanes = token positions.  wt = tokens (bit31 = first token of a
 // word), wr = priority of the pair that starts at p, wm = per-word minimum priority stored at the word's first position.
 // Sentences too long for the LDS arrays run the same code on HBM scratch (GlbArr).
@@ -517,7 +407,7 @@ __device__ void encode_wave(const EncModel &m, const uint32_t *bloom, const uint
 __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8_t *__restrict__ text,
                            const unsigned long long *__restrict__ offsets, unsigned long long s, unsigned long long e, LdsArr wt, LdsArr wr,
                            LdsArr wm, int bos, int eos, int reverse, int32_t *__restrict__ scratch_ids, uint32_t *__restrict__ counts,
-                           const DropoutArgs &drop, bool lane_words) {
+                           const DropoutArgs &drop) {
   const int lane = lane_id();
   const unsigned long long lt = lanemask_lt();
   int n = 0, consumed = 0, k = 0;
@@ -548,20 +438,15 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
   if (drop.enabled) {  // BPE-dropout: one word per lane (the RNG stream is keyed by the pack's first sentence)
     n = dropout_merge<LdsArr>(m, wt, wr, wm, n, drop, s);
   } else {
-    const int n_lane = lane_words ? merge_words_per_lane(m, bloom, wt, wr, wm, n) : -1;
-    if (n_lane >= 0) {
-      n = n_lane;
-    } else {  // a word too long for one lane: the cooperative rounds, lanes = token positions
-      for (int c = 0; c < ((n + 63) >> 6); c++) {
-        const int p = c * 64 + lane;
-        if (p < n) {
-          wr.set(p, ENC_DIRTY);
-          if (wt.get(p) & TOK_WS) wm.set(p, ENC_INF);
-        }
+    for (int c = 0; c < ((n + 63) >> 6); c++) {
+      const int p = c * 64 + lane;
+      if (p < n) {
+        wr.set(p, ENC_DIRTY);
+        if (wt.get(p) & TOK_WS) wm.set(p, ENC_INF);
       }
-      wave_sync();
-      n = merge_rounds<LdsArr>(m, bloom, wt, wr, wm, n);
     }
+    wave_sync();
+    n = merge_rounds<LdsArr>(m, bloom, wt, wr, wm, n);
   }
   wave_sync();
   // ---- output (bpe.cpp:1591-1630).  wm[o] = ids of sentence o of the pack, wr[o] = ids emitted before its first token
@@ -627,12 +512,10 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
   const unsigned long long gw = (unsigned long long)blockIdx.x * ENC_WAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * ENC_WAVES;
   // a wavefront owns groups of `group` consecutive sentences and packs as many of a group at a time as fit its LDS arrays
-  // (bit 31 of `group`: tuning / test hook YTTM_ENC_COOP=1 -- the cooperative merge rounds for every pack)
-  const unsigned int group_n = group & 0x7fffffffu;
-  const unsigned long long n_groups = (n_sent + group_n - 1) / group_n;
+  const unsigned long long n_groups = (n_sent + group - 1) / group;
   for (unsigned long long grp = gw; grp < n_groups; grp += n_waves) {
-    unsigned long long sidx = grp * group_n;
-    const unsigned long long grp_end = sidx + group_n < n_sent ? sidx + group_n : n_sent;
+    unsigned long long sidx = grp * group;
+    const unsigned long long grp_end = sidx + group < n_sent ? sidx + group : n_sent;
     while (sidx < grp_end) {
       const unsigned long long b0 = offsets[sidx], b1 = offsets[sidx + 1];
       const unsigned long long nbytes = b1 - b0;
@@ -643,7 +526,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
         d.ev = reinterpret_cast<unsigned long long *>(drop.wsl + gw * 7 * drop_stride + drop_stride);
       }
       if (nbytes + 1 <= (unsigned long long)ENC_WCAP) {
-        sidx += (unsigned long long)encode_pack(m, bloom, text, offsets, sidx, grp_end, a, b, c, bos, eos, reverse, scratch_ids, counts, d, (group >> 31) == 0);
+        sidx += (unsigned long long)encode_pack(m, bloom, text, offsets, sidx, grp_end, a, b, c, bos, eos, reverse, scratch_ids, counts, d);
         continue;
       }
       // too long for the LDS arrays: one sentence at a time on the wavefront's HBM scratch
@@ -686,8 +569,6 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   unsigned long long group = n_sent / ((unsigned long long)n_blocks * ENC_WAVES * 4);
   if (group < 1) group = 1;
   if (group > 24) group = 24;
-  const bool coop = getenv("YTTM_ENC_COOP") != nullptr;  // (tuning / test hook: the cooperative merge rounds for every pack)
-  if (coop) group |= 0x80000000ull;
   hipLaunchKernelGGL(k5_encode, dim3(n_blocks), dim3(ENC_THREADS), 0, st, m, text, offsets, n_sent, bos, eos, reverse, scratch_ids, counts, work,
                      work_stride, d, drop_stride, (unsigned int)group);
 }
