@@ -249,3 +249,36 @@ def test_word_table_overflow_is_redone(tmp_path):
     assert json.loads(rep.value.decode())["word_table_retries"] == 1
     O.train(text, m_ora, 40)
     assert filecmp.cmp(m_gpu, m_ora, shallow=False)
+
+
+def test_worklists_from_the_pair_index(tmp_path, monkeypatch):
+    """Late rounds take their tiles from the pair index (pair -> tiles that hold it, built from the hot list) instead of streaming
+    every tile.  Forced on here for every round the batch allows, on corpora of several tiles, with the index rebuilt at every
+    hot-list rebuild and repack: same models as the oracle / the golden files."""
+    import ctypes as C
+    import filecmp
+    import json
+    from youtokentome_amd import _lib
+    import oracle_lib as O
+    L = _lib.load()
+    monkeypatch.setenv("YTTM_INDEX_ALWAYS", "1")
+    gathered = builds = 0
+    rng = random.Random(77)
+    cases = [(gen.readme_corpus(300, 100, seed=6), 900), (gen.zipf_corpus(120000, vocab=3000), 700),
+             (gen.unicode_text(rng, 30000, "ascii"), 400), (("aaaa aaaaa abababab aabbaabb bbbbbb ab aaab baaa " * 400).encode(), 60)]
+    for hot in (None, (40, 4, 400)):  # default lists, and small ones: many rebuilds -> many index builds
+        if hot:
+            for k, v in zip(("YTTM_HOT_TARGET", "YTTM_HOT_MIN", "YTTM_HOT_CAP"), hot):
+                monkeypatch.setenv(k, str(v))
+        for i, (text, vocab) in enumerate(cases):
+            corpus, m_gpu, m_ora = str(tmp_path / f"c{i}.txt"), str(tmp_path / f"g{i}.model"), str(tmp_path / f"o{i}.model")
+            open(corpus, "wb").write(text)
+            err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+            rc = L.yttm_train_bpe_ex(corpus.encode(), m_gpu.encode(), vocab, 1.0, 1, 0, 1, 2, 3, 0, rep, 16384, err, 2048)
+            assert rc == 0, err.value
+            O.train(text, m_ora, vocab)
+            assert filecmp.cmp(m_gpu, m_ora, shallow=False), (i, hot)
+            r = json.loads(rep.value.decode())
+            gathered += r["gathered_rounds"]
+            builds += r["index_builds"]
+    assert gathered > 50 and builds > 4, (gathered, builds)

@@ -166,6 +166,9 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   hot_min_ = env_uint("YTTM_HOT_MIN", 512);
   dense_pct_ = env_uint("YTTM_DENSE_PCT", 0);
   fuse_enabled_ = env_uint("YTTM_NO_FUSE", 0) == 0;
+  idx_enabled_ = env_uint("YTTM_NO_INDEX", 0) == 0;
+  idx_min_tiles_ = env_uint("YTTM_INDEX_MIN_TILES", 16384);
+  idx_force_ = env_uint("YTTM_INDEX_ALWAYS", 0) != 0;  // (tests: worklists from the index whenever the batch allows, however few tiles)
   no_batch_args_ = getenv("YTTM_NO_BATCH_ARGS") != nullptr;  // (read once per context: a round has no time for getenv)
   trace_rounds_ = getenv("YTTM_TRACE_ROUNDS");
   dbg_cand_ = getenv("YTTM_DBG_CAND");
@@ -207,6 +210,7 @@ GpuCtx::~GpuCtx() {
   DFREE(d_send_); DFREE(d_xstat_);
   db_.recs = nullptr; db_.n = nullptr;
   free_table(pt_);
+  free_index();
   pool_quiesce(st_);
   if (h_pin_) {
     std::lock_guard<std::mutex> g(g_pool.mu);
@@ -686,6 +690,10 @@ void GpuCtx::maybe_repack(int ci) {
   c.ts.tok = new_tok; c.ts.tile_len = new_len; c.ts.tile_word0 = new_word0; c.ts.n_tiles = n_new;
   n_tiles = cls_[0].n_tiles + cls_[1].n_tiles + cls_[2].n_tiles;
   repacks++;
+  if (ci == 0) {  // tile numbers changed: the pair index is void until it is built again
+    idx_valid_ = false;
+    idx_pending_ = true;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------- pair table
@@ -892,6 +900,8 @@ void GpuCtx::rebuild_hot() {
   pt_.hot_tau = ~0ull;
   pt_.top_tau = ~0ull;  // (the top list is refilled from the new hot list; k_hot_rebuild clears every PT_TOP)
   top_state_ = TOP_INVALID;
+  idx_valid_ = false;  // (the pair index holds the OLD list's pairs)
+  idx_pending_ = true;
   scan_full(~0ull >> 1, 0, none, hist);
   unsigned long long acc = 0;
   int chosen = -1;
@@ -1201,6 +1211,70 @@ void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned lon
 }
 
 // ------------------------------------------------------------------------------------------------- K4
+void GpuCtx::free_index() {
+  DFREE(idx_.key); DFREE(idx_.cnt); DFREE(idx_.off); DFREE(idx_.bloom); DFREE(idx_.post); DFREE(d_stamp_);
+  idx_cap_ = post_cap_ = 0;
+  stamp_cap_ = 0;
+  idx_valid_ = false;
+}
+
+// (Re)builds the pair index from the hot list as it is now and the class-A tiles as they are now (see k_merge.hip PairIndex).
+// Called between rounds, when the last round touched few tiles; gives up -- the rounds keep streaming every tile -- if the
+// postings would not be much smaller than the tiles themselves.
+void GpuCtx::build_index(uint32_t z_next) {
+  idx_pending_ = false;
+  idx_valid_ = false;
+  WordClass &c = cls_[0];
+  if (!c.n_tiles || hot_state_ != HOT_ACTIVE) return;
+  chain_event_ = nullptr;
+  unsigned int listed = 0;  // (the list has grown since the scan that last reported its length)
+  HIP_CHECK(hipMemcpyAsync(&listed, d_hot_n_, 4, hipMemcpyDeviceToHost, st_));
+  sync();
+  if (listed > hot_cap_) return;  // overflowed: the next scan rebuilds the list, and the index after it
+  unsigned long long want = 1024;
+  while (want < 4ull * ((unsigned long long)listed + 256)) want <<= 1;
+  if (want > idx_cap_) {
+    DFREE(idx_.key); DFREE(idx_.cnt); DFREE(idx_.off);
+    idx_.key = dmalloc<unsigned long long>(want);
+    idx_.cnt = dmalloc<uint32_t>(want);
+    idx_.off = dmalloc<uint32_t>(want + 1);
+    idx_cap_ = want;
+  }
+  if (!idx_.bloom) idx_.bloom = dmalloc<uint32_t>(ENC_BLOOM_WORDS);
+  idx_.mask = (unsigned int)(want - 1);
+  launch_fill_u64(idx_.key, PT_EMPTY, want, st_);
+  HIP_CHECK(hipMemsetAsync(idx_.cnt, 0, want * 4, st_));
+  HIP_CHECK(hipMemsetAsync(idx_.bloom, 0, ENC_BLOOM_WORDS * 4, st_));
+  t_begin(KT_CAND);
+  launch_idx_seed(pt_, idx_, listed, st_);
+  launch_idx_stream(0, false, c.ts, idx_, st_);
+  launch_idx_scan(idx_, d_counters_ + 56, st_);
+  unsigned long long total = 0;
+  HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 56, 8, hipMemcpyDeviceToHost, st_));
+  sync();
+  index_builds++;
+  // worth it only if a round's postings are few: all of them together must stay well below one posting per live token
+  if (total == 0 || total > 0xfffffff0ull || (!idx_force_ && total > (unsigned long long)c.n_tiles * 64)) {
+    t_end(KT_CAND, 4ull * c.n_tiles * c.nom);
+    return;
+  }
+  if (total > post_cap_) {
+    DFREE(idx_.post);
+    post_cap_ = total + total / 4 + 1024;
+    idx_.post = dmalloc<uint32_t>(post_cap_);
+  }
+  launch_idx_stream(0, true, c.ts, idx_, st_);
+  t_end(KT_CAND, 8ull * c.n_tiles * c.nom);
+  if (c.n_tiles > stamp_cap_) {
+    DFREE(d_stamp_);
+    stamp_cap_ = c.n_tiles + c.n_tiles / 8 + 64;
+    d_stamp_ = dmalloc<uint32_t>(stamp_cap_);
+  }
+  HIP_CHECK(hipMemsetAsync(d_stamp_, 0, (size_t)stamp_cap_ * 4, st_));
+  idx_valid_ = true;
+  idx_zbuild_ = z_next;
+}
+
 void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts, const unsigned long long *next_tau_cnt,
                          uint32_t next_tau_mx) {
   HIP_CHECK(hipSetDevice(device_));
@@ -1226,6 +1300,16 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // (the key count the scans report is one round old -- they fold the statistics after publishing: the previous round's bound covers it)
   ensure_table_capacity(n_keys_host + bound_prev_ + bound_new);
   bound_prev_ = bound_new;
+
+  // Worklist from the pair index instead of a pass over every tile?  Only when every rule of the batch is in the index (pairs of
+  // tokens older than the index; candidates come from the hot list, whose pairs were its keys), the last round touched few tiles,
+  // and once in a while not: a streamed round refreshes the live-token count the repack trigger needs.
+  const bool sparse = idx_enabled_ && !instrument && cls_[0].n_tiles && !cls_[2].n_tiles && hot_state_ == HOT_ACTIVE && dense_pct_ < 1000 &&
+                      (idx_force_ || (cls_[0].n_tiles >= idx_min_tiles_ && touched_last_ != (~0ull >> 2) && touched_last_ * 4 < cls_[0].n_tiles));
+  if (sparse && idx_pending_) build_index(z_base);
+  bool gathered = sparse && idx_valid_ && rounds_since_dense_ < 32;
+  for (uint32_t j = 0; j < k && gathered; j++) gathered = std::max(xyz[3 * j], xyz[3 * j + 1]) < idx_zbuild_;
+  rounds_since_dense_ = gathered ? rounds_since_dense_ + 1 : 0;
 
   // rule hash (x != y rules) + at most one x == y rule passed by value
   unsigned int cap = 64;
@@ -1323,11 +1407,18 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   if (!by_args)
     launch_round_begin(h_rules, cap, d_rules_, h_upd, n_upd, d_tokflag_, d_flagbits_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr,
                        cls_[1].n_tiles ? cls_[1].d_work_n : nullptr, st_);
+  if (gathered) {  // class A: the tiles of the batch's postings, each once
+    HIP_CHECK(hipMemsetAsync(cls_[0].d_work_n, 0, 64, st_));
+    launch_gather(idx_, d_rules_, cap, by_args ? &ba : nullptr, self_x, d_stamp_, (uint32_t)(merge_rounds + 1), cls_[0].d_worklist, cls_[0].n_tiles,
+                  cls_[0].d_work_n, st_);
+    gathered_rounds++;
+  }
   for (int ci = 0; ci < 2; ci++) {
     if (!cls_[ci].n_tiles) continue;
+    const bool wl_gathered = gathered && ci == 0;
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
-                       cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/by_args || dense_class(ci),
-                       &ba, ci == 0 && sa.on ? &sa : nullptr, st_);
+                       cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/!wl_gathered && (by_args || dense_class(ci)),
+                       &ba, ci == 0 && sa.on ? &sa : nullptr, wl_gathered, st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
   t_end(KT_MERGE, 0, /*chain=*/!sa.on);  // (a fused round is followed by the host's turn, not by another kernel: its end event must not start the next interval)

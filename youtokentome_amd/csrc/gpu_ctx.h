@@ -83,6 +83,7 @@ class GpuCtx {
   // the pinned mailbox until the next scan
   const unsigned long long *last_hist() const { return last_hist_; }
   unsigned long long last_live() const { return last_live_; }
+  unsigned long long index_builds = 0, gathered_rounds = 0;  // K4 rounds whose worklist came from the pair index
   unsigned long long word_table_retries = 0;  // K2: the word table had to be redone with the worst-case size
   unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0;
   unsigned long long tail_ticks[3] = {0, 0, 0}, tail_listed = 0;  // round_tail: fold / list scan / publish, in 10 ns ticks; entries it read
@@ -174,6 +175,16 @@ class GpuCtx {
   void free_class(WordClass &c);
   void build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, unsigned int U, uint32_t space_id);
   void maybe_repack(int ci);
+  // pair index for K4's worklists (k_merge.hip: PairIndex): keys = the hot list when it was built, postings = class-A tiles
+  PairIndexArgs idx_{};
+  unsigned long long idx_cap_ = 0, post_cap_ = 0;
+  uint32_t *d_stamp_ = nullptr;   // [class-A tiles] round that claimed the tile for its worklist last
+  unsigned int stamp_cap_ = 0;
+  bool idx_valid_ = false, idx_pending_ = false, idx_enabled_ = true, idx_force_ = false;
+  uint32_t idx_zbuild_ = 0;       // token ids below this existed when the index was built
+  unsigned int rounds_since_dense_ = 0, idx_min_tiles_ = 16384;
+  void build_index(uint32_t z_next);
+  void free_index();
   unsigned long long rounds_since_check_ = 0;
   bool pending_zero_ = false, zero_valid_ = false;  // valid: the zero_* members still describe the last batch
   void flush_pending_zero();

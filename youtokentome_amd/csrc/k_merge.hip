@@ -1105,6 +1105,9 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
   // K4 runs over the worklist of dirty tiles written by k_filter; K3 over all tiles
   uint32_t wn[WL_PARTS];  // lengths of the sub-lists
   uint32_t NT = ts.n_tiles;
+  // (a worklist gathered from the pair index -- k_gather -- that could not find one of the batch's pairs there is not used:
+  // the launch takes every tile instead; work_n[WL_PARTS + 1] is that verdict)
+  if (worklist && work_n[WL_PARTS + 1]) worklist = nullptr;
   if (worklist) {
     uint32_t mx = 0;
 #pragma unroll
@@ -1824,7 +1827,7 @@ __global__ __launch_bounds__(BLOCK) void k_round_begin(const RuleSlot *__restric
     }
   }
   if (tid == 0) {
-    for (uint32_t i = 0; i <= WL_PARTS; i++) {
+    for (uint32_t i = 0; i <= WL_PARTS + 1; i++) {  // sub-list lengths, hand-out counter, "worklist incomplete" verdict
       if (work_n_a) work_n_a[i] = 0;
       if (work_n_b) work_n_b[i] = 0;
     }
@@ -1835,6 +1838,158 @@ __global__ __launch_bounds__(BLOCK) void k_fill_u64(unsigned long long *__restri
   unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
   for (; i < n; i += stride) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------- pair index (K4 worklists)
+// Late in training a batch touches a few percent of the tiles, and which ones cannot be told from the tokens a tile holds (random
+// text: every tile holds both halves of nearly every late rule).  So the pairs that can still be merged -- the hot list -- get an
+// inverted index, pair -> tiles that hold it (the reference's pair2pos, bpe.cpp:438/:626/:694, at tile granularity): built with two
+// streaming passes (count, fill) when the hot list is rebuilt, exact for pairs of tokens that existed then (a merge only creates
+// adjacencies of its NEW token, and tokens never change tiles until a repack, which invalidates the index).  A round whose rules
+// are all in the index gathers their posting lists into the worklist of the apply kernel instead of streaming every tile.
+struct PairIndex {
+  unsigned long long *key;  // [mask + 1] open addressing, PT_EMPTY = free
+  uint32_t *cnt;            // [mask + 1] postings per key (count pass), then the fill cursor
+  uint32_t *off;            // [mask + 2] start of a key's postings
+  uint32_t *bloom;          // [ENC_BLOOM_WORDS] blocked Bloom filter of the keys (staged into LDS by the streaming passes)
+  uint32_t *post;           // tile ids
+  unsigned int mask;
+};
+__device__ inline uint32_t idx_find(const PairIndex &ix, unsigned long long key, uint32_t h) {
+  uint32_t s = h & ix.mask;
+  for (;;) {
+    const unsigned long long k = ix.key[s];
+    if (k == key) return s;
+    if (k == PT_EMPTY) return 0xffffffffu;
+    s = (s + 1) & ix.mask;
+  }
+}
+// every hot-list slot that is still at or above hot_tau becomes a key of the index
+__global__ __launch_bounds__(BLOCK) void k_idx_seed(PairTable pt, PairIndex ix) {
+  const unsigned int hn_raw = *pt.hot_n;
+  const unsigned int hn = hn_raw < pt.hot_cap ? hn_raw : pt.hot_cap;
+  for (unsigned int i = blockIdx.x * BLOCK + threadIdx.x; i < hn; i += gridDim.x * BLOCK) {
+    const uint32_t sl = pt.hot_slots[i];
+    const unsigned long long c = *pt.cnt_p(sl) & PT_CNT;
+    if (c < pt.hot_tau || c == 0) continue;
+    const unsigned long long key = *pt.key_p(sl);
+    const uint32_t h = enc_hash((uint32_t)(key >> 32), (uint32_t)key);
+    uint32_t s = h & ix.mask;
+    for (;;) {
+      const unsigned long long k = atomicCAS(&ix.key[s], PT_EMPTY, key);
+      if (k == PT_EMPTY || k == key) break;
+      s = (s + 1) & ix.mask;
+    }
+    atomicOr(&ix.bloom[enc_bloom_word(h)], enc_bloom_bits(h));
+  }
+}
+// One wavefront per tile, tokens in registers: every adjacency whose pair is a key of the index is counted (FILL = false) or has
+// its tile appended to the key's postings (FILL = true; one posting per adjacency: duplicates of a tile are harmless, the gather
+// claims a tile once).
+template <int SLOT, bool FILL>
+__global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) {
+  __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
+  for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += BLOCK) bloom[i] = ix.bloom[i];
+  __syncthreads();
+  const int lane = lane_id();
+  const uint32_t stride = gridDim.x * NWAVES;
+  for (uint32_t t = blockIdx.x * NWAVES + (threadIdx.x >> 6); t < ts.n_tiles; t += stride) {
+    const int n = (int)ts.tile_len[t];
+    uint4 r[SLOT / 256];
+    tile_fetch<SLOT>(r, ts, t, n);
+#define IDX_PAIR(T0, T1)                                                              \
+  if (!((T1)&TOK_WS)) {                                                                \
+    const uint32_t a_ = (T0)&TOK_MASK, b_ = (T1)&TOK_MASK;                             \
+    const uint32_t h_ = enc_hash(a_, b_);                                              \
+    const uint32_t bits_ = enc_bloom_bits(h_);                                         \
+    if ((bloom[enc_bloom_word(h_)] & bits_) == bits_) {                                \
+      const uint32_t s_ = idx_find(ix, pair_key(a_, b_), h_);                          \
+      if (s_ != 0xffffffffu) {                                                         \
+        if (FILL) ix.post[ix.off[s_] + atomicAdd(&ix.cnt[s_], 1u)] = t;                \
+        else atomicAdd(&ix.cnt[s_], 1u);                                               \
+      }                                                                                \
+    }                                                                                  \
+  }
+#pragma unroll
+    for (int j = 0; j < SLOT / 256; j++) {
+      if (256 * j < n) {
+        uint32_t nx = __shfl_down(r[j].x, 1);
+        uint32_t nx0 = TOK_WS;
+        if (j + 1 < SLOT / 256) nx0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
+        if (lane == 63) nx = nx0;
+        // (slots behind the live prefix hold zeros: id 0 is a special token, never part of a pair of the index)
+        IDX_PAIR(r[j].x, r[j].y)
+        IDX_PAIR(r[j].y, r[j].z)
+        IDX_PAIR(r[j].z, r[j].w)
+        IDX_PAIR(r[j].w, nx)
+      }
+    }
+#undef IDX_PAIR
+  }
+}
+// exclusive scan of the postings counts (one workgroup), total to *total; the counts become the fill cursors (zero)
+__global__ __launch_bounds__(1024) void k_idx_scan(PairIndex ix, unsigned long long *__restrict__ total) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const unsigned int n = ix.mask + 1;
+  for (unsigned int b0 = 0; b0 < n; b0 += 1024) {
+    const unsigned int i = b0 + threadIdx.x;
+    const unsigned long long v = i < n ? ix.cnt[i] : 0;
+    unsigned long long inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long tt = __shfl_up(inc, o);
+      if (lane_id() >= o) inc += tt;
+    }
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    unsigned long long base = carry;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); k++) base += wsum[k];
+    if (i < n) {
+      const unsigned long long o = base + inc - v;
+      ix.off[i] = o > 0xffffffffull ? 0xffffffffu : (uint32_t)o;
+      ix.cnt[i] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = base + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    ix.off[n] = carry > 0xffffffffull ? 0xffffffffu : (uint32_t)carry;
+    *total = carry;
+  }
+}
+// One workgroup per rule of the batch (slot of the batch's rule hash, or index into the kernel-argument batch): the tiles of its
+// postings join the round's worklist -- each tile once (stamp = the round that claimed it last).  A pair that is not in the index
+// raises work_n[WL_PARTS + 1]: the apply kernel then ignores the worklist and takes every tile.
+__global__ __launch_bounds__(BLOCK) void k_gather(PairIndex ix, const RuleSlot *__restrict__ rules, unsigned int n_slots, BatchArgs ba, uint32_t self_x,
+                                                  uint32_t *__restrict__ stamp, uint32_t round_id, uint32_t *__restrict__ worklist, size_t wl_seg,
+                                                  unsigned int *__restrict__ work_n) {
+  unsigned long long key = PT_EMPTY;
+  const unsigned int n_rules = ba.k ? ba.k : n_slots;
+  if (blockIdx.x < n_rules) {
+    if (ba.k) {
+      const uint32_t x = ba.xy[2 * blockIdx.x], y = ba.xy[2 * blockIdx.x + 1];
+      if (x != y) key = pair_key(x, y);
+    } else {
+      key = rules[blockIdx.x].key;
+    }
+  } else if (blockIdx.x == n_rules && self_x != 0xffffffffu) {
+    key = pair_key(self_x, self_x);
+  }
+  if (key == PT_EMPTY) return;
+  const uint32_t s = idx_find(ix, key, enc_hash((uint32_t)(key >> 32), (uint32_t)key));
+  if (s == 0xffffffffu) {
+    if (threadIdx.x == 0) work_n[WL_PARTS + 1] = 1u;
+    return;
+  }
+  const uint32_t o0 = ix.off[s], o1 = ix.off[s + 1];
+  const uint32_t part = blockIdx.x % WL_PARTS;
+  for (uint32_t i = o0 + threadIdx.x; i < o1; i += BLOCK) {
+    const uint32_t t = ix.post[i];
+    if (atomicExch(&stamp[t], round_id) != round_id) worklist[part * wl_seg + atomicAdd(&work_n[part], 1u)] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------- tile repack
@@ -1941,7 +2096,7 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                         uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
-                        const ScanArgs *scan, hipStream_t st) {
+                        const ScanArgs *scan, bool wl_gathered, hipStream_t st) {
   if (!ts.n_tiles) return;
   const BatchArgs bargs = ba ? *ba : BatchArgs{};
   const ScanArgs sargs = (scan && cls == 0) ? *scan : ScanArgs{};
@@ -1954,7 +2109,7 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
   unsigned int fg = (ts.n_tiles + kt * NWAVES - 1) / (kt * NWAVES);
   if (fg > 256 * 6) fg = 256 * 6;  // 6 workgroups per CU (7 fit); must stay <= BLK_ROWS: every workgroup owns a statistics row
   if (cls == 0) {
-    if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
+    if (!dense && !wl_gathered) hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, true>), dim3(tile_grid(ts.n_tiles, APPLY_WPB, APPLY_BPC)), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
@@ -1963,7 +2118,7 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, false>), dim3(tile_grid(ts.n_tiles, APPLY_WPB, APPLY_BPC)), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
                          tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
   } else {
-    if (!dense) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
+    if (!dense && !wl_gathered) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
@@ -2014,6 +2169,37 @@ void launch_top_rebuild(const PairTable &pt, unsigned int listed_hint, hipStream
 }
 void launch_publish_box(const unsigned char *box, unsigned char *mailbox, unsigned int fast, uint32_t round_id, unsigned long long *xstat, hipStream_t st) {
   hipLaunchKernelGGL(k_publish_box, dim3(1), dim3(BLOCK), 0, st, box, mailbox, fast, round_id, xstat);
+}
+void launch_idx_seed(const PairTable &pt, const PairIndexArgs &a, unsigned int listed_hint, hipStream_t st) {
+  const PairIndex ix{a.key, a.cnt, a.off, a.bloom, a.post, a.mask};
+  unsigned int g = (listed_hint + BLOCK - 1) / BLOCK;
+  if (g < 1) g = 1;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(k_idx_seed, dim3(g), dim3(BLOCK), 0, st, pt, ix);
+}
+void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st) {
+  if (!ts.n_tiles) return;
+  const PairIndex ix{a.key, a.cnt, a.off, a.bloom, a.post, a.mask};
+  unsigned int g = (ts.n_tiles + NWAVES - 1) / NWAVES;
+  if (g > 256 * 6) g = 256 * 6;
+  if (cls == 0) {
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+  } else {
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, true>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+  }
+}
+void launch_idx_scan(const PairIndexArgs &a, unsigned long long *total, hipStream_t st) {
+  const PairIndex ix{a.key, a.cnt, a.off, a.bloom, a.post, a.mask};
+  hipLaunchKernelGGL(k_idx_scan, dim3(1), dim3(1024), 0, st, ix, total);
+}
+void launch_gather(const PairIndexArgs &a, const RuleSlot *rules, unsigned int n_slots, const BatchArgs *ba, uint32_t self_x, uint32_t *stamp,
+                   uint32_t round_id, uint32_t *worklist, unsigned int n_tiles, unsigned int *work_n, hipStream_t st) {
+  const PairIndex ix{a.key, a.cnt, a.off, a.bloom, a.post, a.mask};
+  const BatchArgs b = ba ? *ba : BatchArgs{};
+  const unsigned int n_rules = b.k ? b.k : n_slots;
+  hipLaunchKernelGGL(k_gather, dim3(n_rules + 1), dim3(BLOCK), 0, st, ix, rules, n_slots, b, self_x, stamp, round_id, worklist, WL_SEG(n_tiles), work_n);
 }
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st) {
   unsigned long long n_slots = pt.mask + 1;

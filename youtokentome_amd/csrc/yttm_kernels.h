@@ -81,7 +81,19 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                         uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
-                        const ScanArgs *scan /* class A only */, hipStream_t st);
+                        const ScanArgs *scan /* class A only */, bool wl_gathered /* the worklist was filled by launch_gather: no filter pass */,
+                        hipStream_t st);
+// pair index for K4's worklists (k_merge.hip: PairIndex)
+struct PairIndexArgs {
+  unsigned long long *key;
+  uint32_t *cnt, *off, *bloom, *post;
+  unsigned int mask;
+};
+void launch_idx_seed(const PairTable &pt, const PairIndexArgs &a, unsigned int listed_hint, hipStream_t st);
+void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st);
+void launch_idx_scan(const PairIndexArgs &a, unsigned long long *total, hipStream_t st);
+void launch_gather(const PairIndexArgs &a, const RuleSlot *rules, unsigned int n_slots, const BatchArgs *ba, uint32_t self_x, uint32_t *stamp,
+                   uint32_t round_id, uint32_t *worklist, unsigned int n_tiles, unsigned int *work_n, hipStream_t st);
 void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, unsigned int nom, unsigned long long total,
                    unsigned long long *gstart, unsigned int n_new, uint32_t *new_tok, uint32_t *new_len, uint32_t *new_word0, hipStream_t st);
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
