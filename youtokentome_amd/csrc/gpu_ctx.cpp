@@ -168,6 +168,9 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   fuse_enabled_ = env_uint("YTTM_NO_FUSE", 0) == 0;
   idx_enabled_ = env_uint("YTTM_NO_INDEX", 0) == 0;
   idx_min_tiles_ = env_uint("YTTM_INDEX_MIN_TILES", 16384);
+  idx_post_per_tile_ = env_uint("YTTM_INDEX_POST_PER_TILE", 64);  // (tuning hooks: give up on an index with more postings than this per tile,
+  idx_sparse_div_ = env_uint("YTTM_INDEX_SPARSE_DIV", 8);         //  use the index when the last round touched fewer than 1/this of the tiles;
+                                                                  //  measured at 1 GB, K4 + candidate family ms: no index 151.1, 64/4 147.3, 128/4 148.8, 64/8 145.1, 32/8 147.8, 256/3 160.6)
   idx_force_ = env_uint("YTTM_INDEX_ALWAYS", 0) != 0;  // (tests: worklists from the index whenever the batch allows, however few tiles)
   no_batch_args_ = getenv("YTTM_NO_BATCH_ARGS") != nullptr;  // (read once per context: a round has no time for getenv)
   trace_rounds_ = getenv("YTTM_TRACE_ROUNDS");
@@ -1212,7 +1215,7 @@ void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned lon
 
 // ------------------------------------------------------------------------------------------------- K4
 void GpuCtx::free_index() {
-  DFREE(idx_.key); DFREE(idx_.cnt); DFREE(idx_.off); DFREE(idx_.bloom); DFREE(idx_.post); DFREE(d_stamp_);
+  DFREE(idx_.key); DFREE(idx_.cnt); DFREE(idx_.off); DFREE(idx_.bloom); DFREE(idx_.post); DFREE(d_stamp_); DFREE(idx_scan_tmp_);
   idx_cap_ = post_cap_ = 0;
   stamp_cap_ = 0;
   idx_valid_ = false;
@@ -1232,12 +1235,14 @@ void GpuCtx::build_index(uint32_t z_next) {
   sync();
   if (listed > hot_cap_) return;  // overflowed: the next scan rebuilds the list, and the index after it
   unsigned long long want = 1024;
-  while (want < 4ull * ((unsigned long long)listed + 256)) want <<= 1;
+  while (want < 2ull * ((unsigned long long)listed + 256)) want <<= 1;
   if (want > idx_cap_) {
     DFREE(idx_.key); DFREE(idx_.cnt); DFREE(idx_.off);
     idx_.key = dmalloc<unsigned long long>(want);
-    idx_.cnt = dmalloc<uint32_t>(want);
-    idx_.off = dmalloc<uint32_t>(want + 1);
+    idx_.cnt = dmalloc<uint32_t>(want + 1);
+    idx_.off = dmalloc<unsigned long long>(want + 2);
+    DFREE(idx_scan_tmp_);
+    idx_scan_tmp_ = dmalloc<unsigned long long>(scan_scratch_blocks(want + 1));
     idx_cap_ = want;
   }
   if (!idx_.bloom) idx_.bloom = dmalloc<uint32_t>(ENC_BLOOM_WORDS);
@@ -1248,13 +1253,17 @@ void GpuCtx::build_index(uint32_t z_next) {
   t_begin(KT_CAND);
   launch_idx_seed(pt_, idx_, listed, st_);
   launch_idx_stream(0, false, c.ts, idx_, st_);
-  launch_idx_scan(idx_, d_counters_ + 56, st_);
+  // offsets = exclusive scan of the counts (one extra zero count behind the last slot: off[mask + 1] = the total)
+  HIP_CHECK(hipMemsetAsync(idx_.cnt + want, 0, 4, st_));
+  launch_exclusive_scan(idx_.cnt, want + 1, idx_.off, idx_scan_tmp_, d_counters_ + 56, st_);
+  HIP_CHECK(hipMemsetAsync(idx_.cnt, 0, want * 4, st_));  // the fill pass's cursors
   unsigned long long total = 0;
   HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 56, 8, hipMemcpyDeviceToHost, st_));
   sync();
   index_builds++;
+  if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] index build at round %llu: %u listed pairs, %llu postings, %u tiles, last round touched %llu tiles\n", merge_rounds, listed, total, c.n_tiles, touched_last_);
   // worth it only if a round's postings are few: all of them together must stay well below one posting per live token
-  if (total == 0 || total > 0xfffffff0ull || (!idx_force_ && total > (unsigned long long)c.n_tiles * 64)) {
+  if (total == 0 || total > 0xfffffff0ull || (!idx_force_ && total > (unsigned long long)c.n_tiles * idx_post_per_tile_)) {
     t_end(KT_CAND, 4ull * c.n_tiles * c.nom);
     return;
   }
@@ -1305,7 +1314,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // tokens older than the index; candidates come from the hot list, whose pairs were its keys), the last round touched few tiles,
   // and once in a while not: a streamed round refreshes the live-token count the repack trigger needs.
   const bool sparse = idx_enabled_ && !instrument && cls_[0].n_tiles && !cls_[2].n_tiles && hot_state_ == HOT_ACTIVE && dense_pct_ < 1000 &&
-                      (idx_force_ || (cls_[0].n_tiles >= idx_min_tiles_ && touched_last_ != (~0ull >> 2) && touched_last_ * 4 < cls_[0].n_tiles));
+                      (idx_force_ || (cls_[0].n_tiles >= idx_min_tiles_ && touched_last_ != (~0ull >> 2) && touched_last_ * idx_sparse_div_ < cls_[0].n_tiles));
   if (sparse && idx_pending_) build_index(z_base);
   bool gathered = sparse && idx_valid_ && rounds_since_dense_ < 32;
   for (uint32_t j = 0; j < k && gathered; j++) gathered = std::max(xyz[3 * j], xyz[3 * j + 1]) < idx_zbuild_;

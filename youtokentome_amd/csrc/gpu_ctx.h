@@ -178,11 +178,12 @@ class GpuCtx {
   // pair index for K4's worklists (k_merge.hip: PairIndex): keys = the hot list when it was built, postings = class-A tiles
   PairIndexArgs idx_{};
   unsigned long long idx_cap_ = 0, post_cap_ = 0;
+  unsigned long long *idx_scan_tmp_ = nullptr;
   uint32_t *d_stamp_ = nullptr;   // [class-A tiles] round that claimed the tile for its worklist last
   unsigned int stamp_cap_ = 0;
   bool idx_valid_ = false, idx_pending_ = false, idx_enabled_ = true, idx_force_ = false;
   uint32_t idx_zbuild_ = 0;       // token ids below this existed when the index was built
-  unsigned int rounds_since_dense_ = 0, idx_min_tiles_ = 16384;
+  unsigned int rounds_since_dense_ = 0, idx_min_tiles_ = 16384, idx_post_per_tile_ = 64, idx_sparse_div_ = 8;
   void build_index(uint32_t z_next);
   void free_index();
   unsigned long long rounds_since_check_ = 0;

@@ -1196,11 +1196,13 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
   };
   // (A dynamic hand-out of worklist items through a global counter was tried for short worklists and was slower: the
   // counter's latency lands in every tile because all waits are vmcnt(0).  Static striding it is.)
+  // word frequencies travel with the tile's prefetch when (nearly) every tile will need them: K3, and K4 over a worklist
+  const bool eager_w = !MERGE || worklist != nullptr;
   int j = 0;
   if (t < NT) {
     load_headers(t_batch);
     tile_fetch<SLOT>(r, ts, uni(__shfl(ht, 0)), uni(__shfl(hn, 0)));
-    if (!MERGE) wreg_load<SLOT>(wq, ts.wcnt, uni(__shfl(hw, 0)));
+    if (eager_w) wreg_load<SLOT>(wq, ts.wcnt, uni(__shfl(hw, 0)));
   }
   while (t < NT) {
     const int n0 = uni(__shfl(hn, j));  // (uniform, and now the compiler knows: tile loops and branches run on the scalar unit)
@@ -1209,7 +1211,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     const bool dirty = stage_part(n0, tile, w0);
     // K4: most tiles are dismissed in registers late in training -- their word frequencies are never needed, so they are
     // loaded only now, for a dirty tile, ahead of the next tile's prefetch (first use is in phase 2)
-    if (MERGE && dirty) wreg_load<SLOT>(wq, ts.wcnt, w0);
+    if (MERGE && dirty && !eager_w) wreg_load<SLOT>(wq, ts.wcnt, w0);
     // next tile of this wave: header from the batch (reload the batch every 64 tiles), tokens prefetched now
     const uint32_t t_next = t + stride;
     j++;
@@ -1221,7 +1223,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     const WReg<SLOT> wcur = wq;
     if (t_next < NT) {
       tile_fetch<SLOT>(r, ts, uni(__shfl(ht, j)), uni(__shfl(hn, j)));
-      if (!MERGE) wreg_load<SLOT>(wq, ts.wcnt, uni(__shfl(hw, j)));
+      if (eager_w) wreg_load<SLOT>(wq, ts.wcnt, uni(__shfl(hw, j)));
     }
     process_part(dirty, tile, n0, w0, wcur);
     t = t_next;
@@ -1850,7 +1852,7 @@ __global__ __launch_bounds__(BLOCK) void k_fill_u64(unsigned long long *__restri
 struct PairIndex {
   unsigned long long *key;  // [mask + 1] open addressing, PT_EMPTY = free
   uint32_t *cnt;            // [mask + 1] postings per key (count pass), then the fill cursor
-  uint32_t *off;            // [mask + 2] start of a key's postings
+  unsigned long long *off;  // [mask + 2] start of a key's postings (launch_exclusive_scan of the counts; off[mask + 1] = their total)
   uint32_t *bloom;          // [ENC_BLOOM_WORDS] blocked Bloom filter of the keys (staged into LDS by the streaming passes)
   uint32_t *post;           // tile ids
   unsigned int mask;
@@ -1927,39 +1929,6 @@ __global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) 
 #undef IDX_PAIR
   }
 }
-// exclusive scan of the postings counts (one workgroup), total to *total; the counts become the fill cursors (zero)
-__global__ __launch_bounds__(1024) void k_idx_scan(PairIndex ix, unsigned long long *__restrict__ total) {
-  __shared__ unsigned long long wsum[16];
-  __shared__ unsigned long long carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  const unsigned int n = ix.mask + 1;
-  for (unsigned int b0 = 0; b0 < n; b0 += 1024) {
-    const unsigned int i = b0 + threadIdx.x;
-    const unsigned long long v = i < n ? ix.cnt[i] : 0;
-    unsigned long long inc = v;
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned long long tt = __shfl_up(inc, o);
-      if (lane_id() >= o) inc += tt;
-    }
-    if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    unsigned long long base = carry;
-    for (int k = 0; k < (int)(threadIdx.x >> 6); k++) base += wsum[k];
-    if (i < n) {
-      const unsigned long long o = base + inc - v;
-      ix.off[i] = o > 0xffffffffull ? 0xffffffffu : (uint32_t)o;
-      ix.cnt[i] = 0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = base + inc;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    ix.off[n] = carry > 0xffffffffull ? 0xffffffffu : (uint32_t)carry;
-    *total = carry;
-  }
-}
 // One workgroup per rule of the batch (slot of the batch's rule hash, or index into the kernel-argument batch): the tiles of its
 // postings join the round's worklist -- each tile once (stamp = the round that claimed it last).  A pair that is not in the index
 // raises work_n[WL_PARTS + 1]: the apply kernel then ignores the worklist and takes every tile.
@@ -1984,9 +1953,9 @@ __global__ __launch_bounds__(BLOCK) void k_gather(PairIndex ix, const RuleSlot *
     if (threadIdx.x == 0) work_n[WL_PARTS + 1] = 1u;
     return;
   }
-  const uint32_t o0 = ix.off[s], o1 = ix.off[s + 1];
+  const unsigned long long o0 = ix.off[s], o1 = ix.off[s + 1];
   const uint32_t part = blockIdx.x % WL_PARTS;
-  for (uint32_t i = o0 + threadIdx.x; i < o1; i += BLOCK) {
+  for (unsigned long long i = o0 + threadIdx.x; i < o1; i += BLOCK) {
     const uint32_t t = ix.post[i];
     if (atomicExch(&stamp[t], round_id) != round_id) worklist[part * wl_seg + atomicAdd(&work_n[part], 1u)] = t;
   }
@@ -2189,10 +2158,6 @@ void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArg
     if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, true>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
     else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
   }
-}
-void launch_idx_scan(const PairIndexArgs &a, unsigned long long *total, hipStream_t st) {
-  const PairIndex ix{a.key, a.cnt, a.off, a.bloom, a.post, a.mask};
-  hipLaunchKernelGGL(k_idx_scan, dim3(1), dim3(1024), 0, st, ix, total);
 }
 void launch_gather(const PairIndexArgs &a, const RuleSlot *rules, unsigned int n_slots, const BatchArgs *ba, uint32_t self_x, uint32_t *stamp,
                    uint32_t round_id, uint32_t *worklist, unsigned int n_tiles, unsigned int *work_n, hipStream_t st) {

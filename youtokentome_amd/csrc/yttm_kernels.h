@@ -85,13 +85,12 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
                         hipStream_t st);
 // pair index for K4's worklists (k_merge.hip: PairIndex)
 struct PairIndexArgs {
-  unsigned long long *key;
-  uint32_t *cnt, *off, *bloom, *post;
+  unsigned long long *key, *off;
+  uint32_t *cnt, *bloom, *post;
   unsigned int mask;
 };
 void launch_idx_seed(const PairTable &pt, const PairIndexArgs &a, unsigned int listed_hint, hipStream_t st);
 void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st);
-void launch_idx_scan(const PairIndexArgs &a, unsigned long long *total, hipStream_t st);
 void launch_gather(const PairIndexArgs &a, const RuleSlot *rules, unsigned int n_slots, const BatchArgs *ba, uint32_t self_x, uint32_t *stamp,
                    uint32_t round_id, uint32_t *worklist, unsigned int n_tiles, unsigned int *work_n, hipStream_t st);
 void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, unsigned int nom, unsigned long long total,
