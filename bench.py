@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the Zipf (configs[2]) block")
+    ap.add_argument("--no-touched-pass", action="store_true", help="skip the untimed K4 measurement pass (profiling runs: one training per process)")
     ap.add_argument("--cpu-sample-mb", type=int, default=0, help="0 = the full corpus")
     args = ap.parse_args()
 
@@ -137,11 +138,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
     ctx["barrier"] = barrier
-    comm_handle = _init_rccl(L, dist, torch, dev, rank, world, local_rank) if world > 1 else None
+    # (YTTM_BENCH_FORCE_COMM=1: a communicator even for one rank -- the N>1 code path of this script and of the library, with every
+    # collective of a round, on the one GPU a test box has)
+    comm_handle = _init_rccl(L, dist, torch, dev, rank, world, local_rank) if (world > 1 or os.environ.get("YTTM_BENCH_FORCE_COMM")) else None
     ctx["comm"] = comm_handle
 
     # ---- main workload: configs[1] ------------------------------------------------------------------------------------
-    main_res = _bench_train(ctx, args.corpus, args.size_mb, args.steps, args.warmup, measure_touched=(world == 1), keep_host=True)
+    main_res = _bench_train(ctx, args.corpus, args.size_mb, args.steps, args.warmup, measure_touched=(world == 1 and not args.no_touched_pass), keep_host=True)
     out = {
         "metric": "bpe_train_throughput", "value": main_res["value"], "unit": "MB/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
@@ -151,7 +154,7 @@ def main():
     }
     out["parity"]["corpus_md5_matches"] = main_res["corpus_ok"]
     out["parity"]["model_matches_reference"] = main_res["model_ok"]
-    if world > 1:
+    if comm_handle is not None:
         out["rccl_ranks"] = world
     model_path = main_res["model_path"]
     host = main_res.pop("host", None)
@@ -335,7 +338,7 @@ def _static_traffic(kern, corpus, size_mb, args, world):
             return "merge_apply" if k[len("k_tiles<"):].split(", ")[2] == "true" else "pair_count"
         for name, prefixes in (("char_hist", ("k_scan_bytes<0>",)), ("segments", ("k_scan_bytes<1>",)), ("dedup", ("k2b_insert_words",)),
                                ("merge_apply", ("k_filter<", "k_giant<true")), ("pair_count", ("k_giant<false",)),
-                               ("cand_scan", ("k_hot_scan", "k_cand_scan"))):
+                               ("cand_scan", ("k_hot_scan", "k_cand_scan", "k_top_scan", "k_top_rebuild", "k_hot_rebuild", "k_idx_", "k_gather"))):
             if k.startswith(prefixes):
                 return name
         return None
@@ -562,9 +565,10 @@ def _init_rccl(L, dist, torch, dev, rank, world, local_rank):
     if rank == 0:
         if L.yttm_comm_rccl_unique_id(idbuf) != 0:
             raise RuntimeError("ncclGetUniqueId failed")
-    t = torch.tensor(list(idbuf), dtype=torch.uint8, device=dev)
-    dist.broadcast(t, src=0)
-    idbuf = (C.c_uint8 * 128)(*t.cpu().tolist())
+    if dist is not None:
+        t = torch.tensor(list(idbuf), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)
+        idbuf = (C.c_uint8 * 128)(*t.cpu().tolist())
     h = C.c_void_p()
     if L.yttm_comm_rccl_create(idbuf, rank, world, local_rank, C.byref(h)) != 0:
         raise RuntimeError("ncclCommInitRank failed")
