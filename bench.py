@@ -101,6 +101,10 @@ def main():
     ap.add_argument("--cpu-sample-mb", type=int, default=0, help="0 = the full corpus")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON: libraries that print banners there (RCCL does when a communicator is created) go to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -191,7 +195,8 @@ def main():
     shutil.rmtree(tmpdir, ignore_errors=True)
     bad = [k for k, v in out["parity"].items() if v is False]
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
         if bad:
             log("PARITY FAILURE:", bad)
     if dist is not None:
