@@ -22,6 +22,26 @@ def test_word_table_and_pair_count():
         S.check_word_table_and_pairs(t, coverage=1.0 if i % 2 == 0 else 0.9)
 
 
+def test_word_table_fast_and_exact_scans_agree():
+    """K2 scans the common word -- a few ASCII letters, nothing dropped -- 16 bytes at a time and compares such words as bytes;
+    everything else takes the exact char-by-char walk.  The same word must dedup across the two paths: with and without an
+    invalid byte inside, with a char that coverage drops, at every length around the 8/16-byte loads, at the very end of the text."""
+    rng = random.Random(13)
+    base = ["a" * k for k in (1, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 32, 33, 40)] + ["abcdefgh" * 3, "abcab", "x"]
+    words = []
+    for w in base:
+        words += [w.encode()] * rng.randint(1, 3)
+        words.append(w[: len(w) // 2].encode() + b"\xff" + w[len(w) // 2:].encode())      # invalid byte inside: same tokens
+        words.append(w.encode() + b"\xc3")                                                # truncated char at the end: same tokens
+        words.append(w[:1].encode() + "й".encode() + w[1:].encode())                       # a rare char (dropped below at coverage 0.9)
+        words.append(w.encode() + "日".encode())
+    rng.shuffle(words)
+    for tail in (b"", b" ab", b" abcabcabcabcabcabcabcab", b"\n"):
+        text = b" ".join(words) + tail
+        S.check_word_table_and_pairs(text, coverage=1.0)
+        S.check_word_table_and_pairs(text, coverage=0.9)
+
+
 def test_word_table_multi_tile():
     S.check_word_table_and_pairs(gen.readme_corpus(150, 100, seed=3))  # ~10k dedup tokens: several tiles
 

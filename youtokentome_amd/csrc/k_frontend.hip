@@ -231,24 +231,119 @@ __device__ inline bool seg_equal(const uint8_t *__restrict__ text, unsigned long
   }
 }
 
+// ---- the common case without byte-serial loads -------------------------------------------------------------------------------
+// seg_scan / seg_equal walk a segment char by char: per char a byte load and a cpmap load, each waiting for the one before.  Most
+// words are a few ASCII letters, none dropped: then the word's tokens ARE its bytes ("pure").  The 16 bytes at the segment start
+// come with three aligned 8-byte loads, the ASCII half of cpmap sits in LDS, and two pure words of equal length are compared as
+// bytes -- one wide load of the representative instead of a walk.  Anything else (a byte >= 0x80, a dropped char, a word longer
+// than what the wide loads cover, the last bytes of the text) continues in / falls back to the exact walk.
+__device__ inline void load16(const uint8_t *__restrict__ text, unsigned long long pos, unsigned long long &w0, unsigned long long &w1) {
+  const unsigned long long *base = reinterpret_cast<const unsigned long long *>(text + (pos & ~7ull));
+  const unsigned long long lo = base[0], mid = base[1], hi = base[2];
+  const unsigned int sh = (unsigned int)(pos & 7ull) * 8u;
+  w0 = sh ? (lo >> sh) | (mid << (64u - sh)) : lo;
+  w1 = sh ? (mid >> sh) | (hi << (64u - sh)) : mid;
+}
+// like seg_scan; *pure = the word is L single-byte chars, consecutive from pos, none dropped (so its bytes identify it)
+__device__ inline uint32_t seg_scan_fast(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap,
+                                         const uint32_t *cp_ascii /* LDS: cpmap[0..128) */, unsigned long long pos, unsigned long long *hash_out,
+                                         bool *pure) {
+  unsigned long long h = 0xcbf29ce484222325ull;
+  uint32_t L = 0;
+  unsigned long long i = pos;
+  bool is_pure = true, done = false;
+  while (!done && i + 24 <= n) {  // 16 bytes at a time while they are ASCII
+    unsigned long long w0, w1;
+    load16(text, i, w0, w1);
+    int k = 0;
+    for (; k < 16; k++) {
+      const uint32_t b = (uint32_t)((k < 8 ? w0 >> (8 * k) : w1 >> (8 * (k - 8))) & 0xffull);
+      if (b >= 0x80u) break;
+      const uint32_t id = cp_ascii[b];
+      if (id == CP_SPACE) { done = true; break; }
+      if (id == CP_DROP) { is_pure = false; continue; }
+      h = word_hash_step(h, id);
+      L++;
+    }
+    i += (unsigned long long)k;
+    if (k < 16) break;  // a space (done) or a byte that needs the exact decode
+  }
+  if (!done) {  // the exact walk from where the fast one stopped
+    while (i < n) {
+      uint32_t len;
+      const uint32_t cp = u8_decode_at(text, i, n, &len);
+      if (cp != INVALID_CP) {
+        const uint32_t id = cpmap[cp];
+        if (id == CP_SPACE) break;
+        if (id != CP_DROP) { h = word_hash_step(h, id); L++; }
+        else is_pure = false;
+        if (len != 1) is_pure = false;
+      } else {
+        is_pure = false;
+      }
+      i += len;
+    }
+  }
+  *hash_out = mix64(h ^ ((unsigned long long)L << 48));
+  *pure = is_pure;
+  return L;
+}
+// two PURE words of L chars each: equal iff their L bytes are
+__device__ inline bool bytes_equal(const uint8_t *__restrict__ text, unsigned long long n, unsigned long long a, unsigned long long b, uint32_t L) {
+  if (a == b) return true;
+  uint32_t done = 0;
+  while (done < L) {
+    if (a + done + 24 > n || b + done + 24 > n) {  // the last bytes of the text: one at a time
+      for (; done < L; done++)
+        if (text[a + done] != text[b + done]) return false;
+      return true;
+    }
+    unsigned long long a0, a1, b0, b1;
+    load16(text, a + done, a0, a1);
+    load16(text, b + done, b0, b1);
+    const uint32_t left = L - done;
+    if (left >= 16) {
+      if (a0 != b0 || a1 != b1) return false;
+    } else if (left > 8) {
+      const unsigned long long m = ~0ull >> (8 * (16 - left));
+      if (a0 != b0 || ((a1 ^ b1) & m)) return false;
+    } else {
+      const unsigned long long m = ~0ull >> (8 * (8 - left));
+      if ((a0 ^ b0) & m) return false;
+    }
+    done += 16;
+  }
+  return true;
+}
+
 constexpr unsigned long long WH_POS_MASK = (1ull << 40) - 1;
 constexpr int WL_SLOTS = 128;  // per-workgroup LDS combiner for the most frequent words (measured at 1 GB, dedup ms abcd/Zipf: 32 slots 38/51, 128: 23/19, 256: 24/20, 512: 25/22, 2048: 37/31)
 // Word table in HBM: keys in ht[0 .. cap), counts in ht[cap .. 2 cap).  (One 16-byte slot per word was measured 2.3x slower:
 // the atomics on a frequent word's count then serialise with every other workgroup's read of its key -- same cache line.)
-//   key = tag:8 | min(tokens, 0xffff):16 | byte offset of the representative segment:40   (PT_EMPTY = free)
-// A probe compares tag and length first (24 bits) and then, always, the representative's bytes: the dedup is exact.
+//   key = pure:1 | tag:7 | min(tokens, 0xffff):16 | byte offset of the representative segment:40   (PT_EMPTY = free)
+// A probe compares tag and length first (23 bits) and then, always, the representative itself -- as bytes when both words are
+// "pure" (seg_scan_fast), token by token otherwise: the dedup is exact.  (The pure bit is not part of the comparison: the same
+// word can occur pure and, say, with an invalid byte in it.)
 constexpr uint32_t WH_LEN_CAP = 0xffffu;
-__device__ inline unsigned long long wh_key(unsigned long long h, uint32_t len_tokens, unsigned long long pos) {
+constexpr unsigned long long WH_PURE = 1ull << 63, WH_CMP_MASK = (1ull << 63) - 1;
+__device__ inline unsigned long long wh_key(unsigned long long h, uint32_t len_tokens, unsigned long long pos, bool pure) {
   const unsigned long long l16 = len_tokens < WH_LEN_CAP ? len_tokens : WH_LEN_CAP;
-  return ((h >> 56) << 56) | (l16 << 40) | pos;
+  return (pure ? WH_PURE : 0ull) | ((h >> 57) << 56) | (l16 << 40) | pos;
+}
+// is the word at `pos` (key `mine`, L chars) the word whose key `cur` sits in a slot?
+__device__ inline bool wh_same(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap, unsigned long long cur,
+                               unsigned long long mine, unsigned long long pos, uint32_t L) {
+  if (((cur ^ mine) & WH_CMP_MASK) >> 40) return false;  // tag or length differ
+  if ((cur & mine & WH_PURE) && L + 1 < WH_LEN_CAP) return bytes_equal(text, n, cur & WH_POS_MASK, pos, L);
+  return seg_equal(text, n, cpmap, cur & WH_POS_MASK, pos);
 }
 constexpr int WH_MAX_PROBES = 4096;  // longer than this: the table was sized too small for this corpus (status[6]; the host retries)
 
 // insert-or-add `count` occurrences of the word whose representative segment starts at `pos` into the HBM table
 __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap,
-                                          unsigned long long h, unsigned long long pos, uint32_t len_tokens, unsigned long long count,
+                                          unsigned long long h, unsigned long long pos, uint32_t len_tokens, bool pure, unsigned long long count,
                                           unsigned long long *__restrict__ ht, unsigned long long ht_mask, unsigned int *__restrict__ status) {
-  const unsigned long long mine = wh_key(h, len_tokens, pos);
+  const unsigned long long mine = wh_key(h, len_tokens, pos, pure);
   unsigned long long i = (h >> 8) & ht_mask;
   for (int probes = 0; probes < WH_MAX_PROBES; probes++) {
     unsigned long long cur = ld_agent(&ht[i]);
@@ -265,7 +360,7 @@ __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsi
         return;
       }
     }
-    if ((cur >> 40) == (mine >> 40) && seg_equal(text, n, cpmap, cur & WH_POS_MASK, pos)) {
+    if (wh_same(text, n, cpmap, cur, mine, pos, len_tokens - 1u)) {
       atomicAdd(&ht[ht_mask + 1 + i], count);
       return;
     }
@@ -283,13 +378,15 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
                                                           const unsigned long long *__restrict__ seg_pos, unsigned long long n_segs,
                                                           unsigned long long *__restrict__ ht, unsigned long long ht_mask,
                                                           unsigned int *__restrict__ status /* [0]=n_unique [1]=flags [2]=n_unique of classes B+C [3]=longest class-A word [4]=n_unique of class C [5]=longest word [6]=table too small */) {
-  __shared__ unsigned long long l_key[WL_SLOTS];   // (tag:24 | pos:40) or PT_EMPTY
+  __shared__ uint32_t cp_ascii[128];               // cpmap[0..128): the fast scan's table
+  __shared__ unsigned long long l_key[WL_SLOTS];   // a word-table key (wh_key) or PT_EMPTY
   __shared__ unsigned long long l_hash[WL_SLOTS];  // full hash of the word (for the flush)
   __shared__ unsigned int l_cnt[WL_SLOTS];
   __shared__ unsigned int l_len[WL_SLOTS];
   __shared__ unsigned int l_maxlen;  // longest class-A word seen by this workgroup (one global atomicMax at the end)
   __shared__ unsigned int l_status[8];  // this workgroup's share of status[] (added once at the end)
   for (int i = (int)threadIdx.x; i < WL_SLOTS; i += BLOCK) { l_key[i] = PT_EMPTY; l_cnt[i] = 0; }
+  if (threadIdx.x < 128) cp_ascii[threadIdx.x] = cpmap[threadIdx.x];
   if (threadIdx.x < 8) l_status[threadIdx.x] = 0;
   if (threadIdx.x == 0) l_maxlen = 0;
   __syncthreads();
@@ -298,9 +395,10 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
   for (; s < n_segs; s += stride) {
     const unsigned long long pos = seg_pos[s];
     unsigned long long h;
-    const uint32_t L = seg_scan(text, n, cpmap, pos, &h);
+    bool pure;
+    const uint32_t L = seg_scan_fast(text, n, cpmap, cp_ascii, pos, &h, &pure);
     if (L == 0) continue;  // segment made only of dropped chars: no word (bpe.cpp:357-380 deletes them first)
-    const unsigned long long tag = h >> 40;
+    const unsigned long long mine = wh_key(h, L + 1, pos, pure);
     if (L + 1 <= (uint32_t)TILE_NOM_A && L + 1 > l_maxlen) atomicMax(&l_maxlen, L + 1);
     bool done = false;
     if (L <= 24) {  // very long words are not frequent enough to be worth an LDS slot (Zipf text: the top words reach 12+ chars)
@@ -308,7 +406,7 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
       for (int probe = 0; probe < 4 && !done; probe++) {
         unsigned long long cur = __hip_atomic_load(&l_key[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_read, not a flat load
         if (cur == PT_EMPTY) {
-          cur = atomicCAS(&l_key[j], PT_EMPTY, (tag << 40) | pos);
+          cur = atomicCAS(&l_key[j], PT_EMPTY, mine);
           if (cur == PT_EMPTY) {
             l_hash[j] = h;
             l_len[j] = L + 1;
@@ -317,7 +415,7 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
             break;
           }
         }
-        if ((cur >> 40) == tag && seg_equal(text, n, cpmap, cur & WH_POS_MASK, pos)) {
+        if (wh_same(text, n, cpmap, cur, mine, pos, L)) {
           atomicAdd(&l_cnt[j], 1u);
           done = true;
           break;
@@ -325,13 +423,13 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
         j = (j + 1) & (WL_SLOTS - 1);
       }
     }
-    if (!done) word_insert_global(text, n, cpmap, h, pos, L + 1, 1ull, ht, ht_mask, l_status);
+    if (!done) word_insert_global(text, n, cpmap, h, pos, L + 1, pure, 1ull, ht, ht_mask, l_status);
   }
   __syncthreads();
   for (int i = (int)threadIdx.x; i < WL_SLOTS; i += BLOCK) {
     const unsigned long long k = l_key[i];
     if (k != PT_EMPTY)
-      word_insert_global(text, n, cpmap, l_hash[i], k & WH_POS_MASK, l_len[i], (unsigned long long)l_cnt[i], ht, ht_mask, l_status);
+      word_insert_global(text, n, cpmap, l_hash[i], k & WH_POS_MASK, l_len[i], (k & WH_PURE) != 0, (unsigned long long)l_cnt[i], ht, ht_mask, l_status);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
