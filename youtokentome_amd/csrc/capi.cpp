@@ -121,12 +121,10 @@ void yttm_encoder_destroy(yttm_encoder *h) {
 
 int yttm_encode_as_ids(yttm_encoder *h, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_sent, int bos, int eos, int reverse,
                        double dropout_prob, int32_t **ids, uint64_t **out_offsets, char *err, int errlen) {
-  std::vector<int32_t> v;
-  std::vector<unsigned long long> off;
-  Status s = h->enc->encode_as_ids(bytes, (const unsigned long long *)offsets, n_sent, bos, eos, reverse, dropout_prob, &v, &off);
+  unsigned long long *off = nullptr;
+  Status s = h->enc->encode_as_ids_malloc(bytes, (const unsigned long long *)offsets, n_sent, bos, eos, reverse, dropout_prob, ids, &off);
   if (!s.ok()) return finish(s, err, errlen);
-  *ids = to_malloc(v);
-  *out_offsets = (uint64_t *)to_malloc(off);
+  *out_offsets = (uint64_t *)off;
   return 0;
 }
 

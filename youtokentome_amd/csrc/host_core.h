@@ -96,6 +96,8 @@ class BaseEncoder {  // bpe.h:22-82
   // packed batch API (bytes + offsets[S+1]); ids/out_off are filled on the host
   Status encode_as_ids(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos, bool reverse,
                        double dropout_prob, std::vector<int32_t> *ids, std::vector<unsigned long long> *out_off) const;
+  Status encode_as_ids_malloc(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos, bool reverse,
+                              double dropout_prob, int32_t **ids, unsigned long long **out_off) const;
   Status encode_as_subwords(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,
                             bool reverse, double dropout_prob, std::vector<std::string> *pieces,
                             std::vector<unsigned long long> *piece_off) const;

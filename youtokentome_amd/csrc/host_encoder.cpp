@@ -317,36 +317,74 @@ Status BaseEncoder::fetch_device_result(int32_t *ids, unsigned long long *out_of
   return fetch_lane(dev_->lane[0], device_, ids, out_off, n_sent);
 }
 
-Status BaseEncoder::encode_as_ids(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,
-                                  bool reverse, double dropout_prob, std::vector<int32_t> *ids, std::vector<unsigned long long> *out_off) const {
-  if (bos && bpe_state.special_tokens.bos_id == -1) return Status(1, "Can't add <BOS> token. Model was trained without it.");
-  if (eos && bpe_state.special_tokens.eos_id == -1) return Status(1, "Can't add <EOS> token. Model was trained without it.");
-  ids->clear();
-  out_off->assign((size_t)n_sent + 1, 0);
-  if (n_sent == 0) return Status();
-  if (!dev_) return Status(2, "encoder has no device state");
+// upload -> K5 -> download on one lane; the output arrays come from the caller's allocator once their sizes are known
+template <class AllocIds, class AllocOff>
+static Status encode_host_to_host(const BaseEncoder &enc, EncoderDevice *dev, int device, const uint8_t *bytes, const unsigned long long *offsets,
+                                  unsigned long long n_sent, bool bos, bool eos, bool reverse, double dropout_prob, AllocIds alloc_ids, AllocOff alloc_off) {
+  if (bos && enc.bpe_state.special_tokens.bos_id == -1) return Status(1, "Can't add <BOS> token. Model was trained without it.");
+  if (eos && enc.bpe_state.special_tokens.eos_id == -1) return Status(1, "Can't add <EOS> token. Model was trained without it.");
+  if (n_sent == 0) {
+    unsigned long long *o = alloc_off(1);
+    if (o) o[0] = 0;
+    (void)alloc_ids(0);
+    return Status();
+  }
+  if (!dev) return Status(2, "encoder has no device state");
   unsigned long long total_bytes = offsets[n_sent] - offsets[0], max_len = 0;
   for (unsigned long long i = 0; i < n_sent; i++) max_len = std::max(max_len, offsets[i + 1] - offsets[i]);
   std::unique_lock<std::mutex> lk;
-  EncodeLane &d = dev_->acquire(lk);  // held until the ids are back on the host
+  EncodeLane &d = dev->acquire(lk);  // held until the ids are back on the host
   try {
-    HIP_CHECK(hipSetDevice(device_));
+    HIP_CHECK(hipSetDevice(device));
     d.grow(d.d_bytes, d.cap_bytes, (size_t)total_bytes + 16);
     d.grow(d.d_off, d.cap_off, (size_t)n_sent + 1);
-    // offsets are rebased to the first byte of the batch
-    std::vector<unsigned long long> rel((size_t)n_sent + 1);
-    for (unsigned long long i = 0; i <= n_sent; i++) rel[i] = offsets[i] - offsets[0];
     if (total_bytes) HIP_CHECK(hipMemcpyAsync(d.d_bytes, bytes + offsets[0], (size_t)total_bytes, hipMemcpyHostToDevice, d.st));
-    HIP_CHECK(hipMemcpyAsync(d.d_off, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, d.st));
-    HIP_CHECK(hipStreamSynchronize(d.st));
+    if (offsets[0] == 0) {
+      HIP_CHECK(hipMemcpyAsync(d.d_off, offsets, ((size_t)n_sent + 1) * 8, hipMemcpyHostToDevice, d.st));
+      HIP_CHECK(hipStreamSynchronize(d.st));
+    } else {  // offsets are rebased to the first byte of the batch
+      std::vector<unsigned long long> rel((size_t)n_sent + 1);
+      for (unsigned long long i = 0; i <= n_sent; i++) rel[i] = offsets[i] - offsets[0];
+      HIP_CHECK(hipMemcpyAsync(d.d_off, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, d.st));
+      HIP_CHECK(hipStreamSynchronize(d.st));
+    }
   } catch (const GpuError &e) {
     return Status(2, "GPU error: " + e.msg);
   }
   unsigned long long n_ids = 0;
-  Status s = encode_on_lane(*this, *dev_, d, device_, d.d_bytes, d.d_off, n_sent, total_bytes, max_len, bos, eos, reverse, dropout_prob, &n_ids, nullptr);
+  Status s = encode_on_lane(enc, *dev, d, device, d.d_bytes, d.d_off, n_sent, total_bytes, max_len, bos, eos, reverse, dropout_prob, &n_ids, nullptr);
   if (!s.ok()) return s;
-  ids->resize((size_t)n_ids);
-  return fetch_lane(d, device_, ids->data(), out_off->data(), n_sent);
+  int32_t *ids = alloc_ids((size_t)n_ids);
+  unsigned long long *off = alloc_off((size_t)n_sent + 1);
+  if ((n_ids && !ids) || !off) return Status(2, "out of memory");
+  return fetch_lane(d, device, ids, off, n_sent);
+}
+
+Status BaseEncoder::encode_as_ids(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,
+                                  bool reverse, double dropout_prob, std::vector<int32_t> *ids, std::vector<unsigned long long> *out_off) const {
+  ids->clear();
+  out_off->clear();
+  return encode_host_to_host(
+      *this, dev_, device_, bytes, offsets, n_sent, bos, eos, reverse, dropout_prob,
+      [&](size_t n) { ids->resize(n); return ids->data(); }, [&](size_t n) { out_off->assign(n, 0); return out_off->data(); });
+}
+
+// the same into malloc'ed arrays (released by the caller with free()): what the C ABI hands out, without a copy in between
+Status BaseEncoder::encode_as_ids_malloc(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,
+                                         bool reverse, double dropout_prob, int32_t **ids, unsigned long long **out_off) const {
+  *ids = nullptr;
+  *out_off = nullptr;
+  Status s = encode_host_to_host(
+      *this, dev_, device_, bytes, offsets, n_sent, bos, eos, reverse, dropout_prob,
+      [&](size_t n) { *ids = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t)); return *ids; },
+      [&](size_t n) { *out_off = (unsigned long long *)malloc((n ? n : 1) * sizeof(unsigned long long)); return *out_off; });
+  if (!s.ok()) {
+    free(*ids);
+    free(*out_off);
+    *ids = nullptr;
+    *out_off = nullptr;
+  }
+  return s;
 }
 
 Status BaseEncoder::encode_as_subwords(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,
