@@ -882,6 +882,7 @@ uint32_t GpuCtx::scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vec
   memcpy(hist_buf_, h + 64, CAND_BINS * 8);
   last_hist_ = hist_buf_;
   last_live_ = 0;
+  last_top_bin_ = CAND_BINS - 1;
   for (int b = 1; b < CAND_BINS; b++) last_live_ += hist_buf_[b];
   const unsigned int take = std::min(n, cand_cap_);
   CandRec *h_c = (CandRec *)(h + 8192);
@@ -1181,6 +1182,7 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     if (hist) memcpy(hist, h + MB_HIST, CAND_BINS * 8);
     last_hist_ = (const unsigned long long *)(h + MB_HIST);
     last_live_ = live;
+    last_top_bin_ = top_state_ == TOP_ACTIVE ? std::min<unsigned int>(((const unsigned int *)h)[5], CAND_BINS - 1) : CAND_BINS - 1;
     const unsigned int take = std::min(n, cand_cap_);
     CandRec *h_c = (CandRec *)(h + 8192);
     if (take > CAND_FAST) {

@@ -83,6 +83,7 @@ class GpuCtx {
   // the pinned mailbox until the next scan
   const unsigned long long *last_hist() const { return last_hist_; }
   unsigned long long last_live() const { return last_live_; }
+  int last_top_bin() const { return (int)last_top_bin_; }  // no bin above this one is in use
   unsigned long long index_builds = 0, gathered_rounds = 0;  // K4 rounds whose worklist came from the pair index
   unsigned long long word_table_retries = 0;  // K2: the word table had to be redone with the worst-case size
   unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0;
@@ -126,6 +127,7 @@ class GpuCtx {
   bool hot_just_rebuilt_ = false;
   const unsigned long long *last_hist_ = nullptr;
   unsigned long long last_live_ = 0, hist_buf_[CAND_BINS] = {0};
+  unsigned int last_top_bin_ = CAND_BINS - 1;
   unsigned long long bound_prev_ = 0;  // new-key bound of the previous round (see merge_apply)
   uint32_t *d_hot_slots_ = nullptr;
   unsigned int *d_hot_n_ = nullptr;

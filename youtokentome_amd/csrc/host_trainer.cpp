@@ -45,9 +45,9 @@ struct HeapCmp {  // std heap keeps the "largest" on top: largest = picked first
 
 // threshold such that about `target` pairs have count >= tau (from the device histogram of live counts, read from the top:
 // only its first few lines of the pinned mailbox are touched)
-unsigned long long choose_tau(const unsigned long long *hist, unsigned long long target) {
+unsigned long long choose_tau(const unsigned long long *hist, unsigned long long target, int top_bin) {
   unsigned long long acc = 0;
-  for (int b = CAND_BINS - 1; b >= 1; b--) {
+  for (int b = top_bin; b >= 1; b--) {
     acc += hist[b];
     if (acc >= target) return std::max<unsigned long long>(1, cand_bin_lower(b));
   }
@@ -122,7 +122,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     auto tw1 = clk::now();
     const unsigned long long *hist = g.last_hist();  // (of the counts the scan looked at; valid until the next scan)
     const unsigned long long total_pairs = g.last_live();
-    const unsigned long long tau_hint = choose_tau(hist, TARGET);
+    const unsigned long long tau_hint = choose_tau(hist, TARGET, g.last_top_bin());
     if (total_pairs == 0) {
       if (root) fprintf(stderr, "WARNING merged only: %llu pairs of tokens\n", (unsigned long long)used_ids);  // bpe.cpp:1139
       break;
@@ -140,7 +140,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       // bisect the exact count, then bisect the max(x,y) bound inside the overflowing count.
       rescans++;
       if (tau_hint > tau) { tau = tau_hint; tau_mx = MX_ALL; continue; }
-      int top = CAND_BINS - 1;
+      int top = g.last_top_bin();
       while (top > 1 && hist[top] == 0) top--;
       unsigned long long lo = tau, hi = cand_bin_lower(top + 1 < CAND_BINS ? top + 1 : top) * 2 + 1;
       while (hi - lo > 1) {

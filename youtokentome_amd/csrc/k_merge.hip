@@ -18,6 +18,8 @@
 // the HBM pair table), and the tile is compacted in place from its first site on.
 // Wave-uniform values go through scalar registers (uni / lane_bit / lanes_below, yttm_device.h).
 // HBM-bound integer work: no MFMA.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "yttm_device.h"
@@ -911,7 +913,7 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long tm0 = (unsigned long long)wall_clock64();
   for (int b = tid; b < CAND_BINS; b += NT) lh[b] = 0;
-  if (tid < 3) ctl[tid] = 0;
+  if (tid < 4) ctl[tid] = 0;  // ([3]: highest histogram bin in use)
   if (tid < 5) facc[tid] = 0;
   __syncthreads();
   const unsigned long long tm1 = (unsigned long long)wall_clock64();
@@ -952,7 +954,9 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
       if (keep) {
         keepm |= 1u << e;
         my_live++;
-        atomicAdd(&lh[cand_bin(cc)], 1u);
+        const int bin = cand_bin(cc);
+        atomicAdd(&lh[bin], 1u);
+        if ((unsigned int)bin > ctl[3]) atomicMax(&ctl[3], (unsigned int)bin);
         const uint32_t x = (uint32_t)(k[e] >> 32), y = (uint32_t)k[e];
         const uint32_t mx = x > y ? x : y;
         if (cc > sa.tau_cnt || (cc == sa.tau_cnt && mx <= sa.tau_mx)) {
@@ -1002,6 +1006,7 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
     hdr[2] = tn_raw;
     hdr[3] = ctl[2];
     hdr[4] = hot_raw;
+    hdr[5] = ctl[3];  // the host reads the histogram from here down (every line of the pinned mailbox it touches is a cache miss)
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 40) = stats[2];  // tokens streamed so far (repack trigger)
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 48) = stats[1];  // tiles that held a merge site so far
     if (!overflow) *pt.top_n = ctl[0];
@@ -1680,7 +1685,7 @@ __global__ __launch_bounds__(BLOCK) void k_publish_box(const unsigned char *__re
                                                        uint32_t round_id, unsigned long long *__restrict__ xstat) {
   const unsigned int *bh = reinterpret_cast<const unsigned int *>(box);
   unsigned int *mh = reinterpret_cast<unsigned int *>(mailbox);
-  if (threadIdx.x < 5) mh[threadIdx.x] = bh[threadIdx.x];
+  if (threadIdx.x < 6) mh[threadIdx.x] = bh[threadIdx.x];
   if (threadIdx.x >= 10 && threadIdx.x < 14) mh[threadIdx.x] = bh[threadIdx.x];  // bytes 40..55
   if (threadIdx.x >= 6 && threadIdx.x < 10) {
     const int k = (int)threadIdx.x - 6;
@@ -2077,14 +2082,23 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
   const unsigned int kt = cls == 0 ? 2 : 1;  // tiles per wavefront and iteration (k_filter: KT)
   unsigned int fg = (ts.n_tiles + kt * NWAVES - 1) / (kt * NWAVES);
   if (fg > 256 * 6) fg = 256 * 6;  // 6 workgroups per CU (7 fit); must stay <= BLK_ROWS: every workgroup owns a statistics row
+  // class-A grid: APPLY_BPC workgroups per CU when there are tiles for all of them; a small tile set (natural-language corpora:
+  // a few thousand tiles) gets fewer workgroups with several tiles per wave -- every workgroup costs a prologue (44 KB of LDS set-up)
+  // and a serialised ticket at the end (~11 ns each), which a round of ~15 us notices.  YTTM_APPLY_GRID overrides (tuning hook).
+  unsigned int grid_a = tile_grid(ts.n_tiles, APPLY_WPB, APPLY_BPC);
+  {
+    static const char *g_env = getenv("YTTM_APPLY_GRID");
+    const unsigned int small = g_env ? (unsigned int)atoi(g_env) : 256u;
+    if (ts.n_tiles <= 16384 && small && grid_a > small) grid_a = small;
+  }
   if (cls == 0) {
     if (!dense && !wl_gathered) hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
-      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, true>), dim3(tile_grid(ts.n_tiles, APPLY_WPB, APPLY_BPC)), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, true>), dim3(grid_a), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
                          tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
     else
-      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, false>), dim3(tile_grid(ts.n_tiles, APPLY_WPB, APPLY_BPC)), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, false>), dim3(grid_a), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
                          tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
   } else {
     if (!dense && !wl_gathered) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
