@@ -186,6 +186,9 @@ def main():
                                  "kernels": z["kernels"], "phases_s": z["phases_s"]}}
         out["parity"]["zipf_corpus_md5_matches"] = z["corpus_ok"]
         out["parity"]["zipf_model_matches_reference"] = z["model_ok"]
+        if world == 1 and not args.no_encode and zhost is not None:
+            # natural-language-like sentences: the corpus' own lines (16 Zipf words each) through K5 with the model just trained
+            out["extra"]["zipf"]["encode"] = _bench_encode_lines(ctx, z["model_path"], zhost)
     else:
         zhost = None
 
@@ -491,6 +494,53 @@ def _bench_encode(ctx, model_path, main_res):
     return res
 
 
+def _bench_encode_lines(ctx, model_path, text):
+    """Device-resident encode of the newline-separated lines of `text` (bytes); FNV of the result for the on-box comparison with the reference."""
+    L, _lib, torch, np, args = ctx["L"], ctx["_lib"], ctx["torch"], ctx["np"], ctx["args"]
+    dev, local_rank = ctx["dev"], ctx["local_rank"]
+    arr = np.frombuffer(text, dtype=np.uint8)
+    ends = np.flatnonzero(arr == 10).astype(np.int64)
+    n_sent = len(ends)
+    # sentence i = bytes [off[i], off[i+1]): the newline stays at the end of its line (white space, like in the abcd stream)
+    off = np.zeros(n_sent + 1, dtype=np.int64)
+    off[1:] = ends + 1
+    d_bytes = torch.frombuffer(bytearray(text[: int(off[-1])]), dtype=torch.uint8).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    max_len = int((off[1:] - off[:-1]).max())
+    err = C.create_string_buffer(_lib.ERRLEN)
+    h = C.c_void_p()
+    if L.yttm_encoder_create(model_path.encode(), 1, local_rank, C.byref(h), err, _lib.ERRLEN) != 0:
+        raise RuntimeError(err.value.decode())
+    n_ids, kms = C.c_uint64(), C.c_double()
+
+    def step():
+        rc = L.yttm_encode_device(h, C.c_void_p(d_bytes.data_ptr()), C.c_void_p(d_off.data_ptr()), n_sent, d_bytes.numel(), max_len, 0, 0, 0, 0.0,
+                                  C.byref(n_ids), C.byref(kms), err, _lib.ERRLEN)
+        if rc != 0:
+            raise RuntimeError(err.value.decode())
+    step()
+    ctx["barrier"]()
+    steps = max(1, args.steps)
+    t0 = time.perf_counter()
+    k_ms = []
+    for _ in range(steps):
+        step()
+        k_ms.append(kms.value)
+    ctx["barrier"]()
+    dt = time.perf_counter() - t0
+    ids = np.zeros(n_ids.value, dtype=np.int32)
+    o64 = np.zeros(n_sent + 1, dtype=np.uint64)
+    L.yttm_encode_fetch(h, ids.ctypes.data_as(_lib.i32p), o64.ctypes.data_as(_lib.u64p), n_sent, err, _lib.ERRLEN)
+    fnv = "%016x" % L.yttm_ids_fnv1a64(ids.ctypes.data_as(_lib.i32p), o64.ctypes.data_as(_lib.u64p), n_sent)
+    L.yttm_encoder_destroy(h)
+    del d_bytes, d_off
+    torch.cuda.empty_cache()
+    return {"metric": "encode_sentences_per_s", "value": round(steps * n_sent / dt, 1), "unit": "sentences/s", "sentences": n_sent,
+            "mean_sentence_bytes": round(float(off[-1]) / n_sent, 1), "ids_per_sentence": round(n_ids.value / n_sent, 3),
+            "kernel_ms": round(sum(k_ms) / len(k_ms), 3), "bytes_per_s": round(steps * float(off[-1]) / dt, 1), "fnv1a64": fnv,
+            "input": "the lines of the Zipf corpus, resident in HBM; ids left in HBM"}
+
+
 def _taskset():
     """Pin the CPU baseline to 8 cores when taskset and >= 8 cores exist."""
     n = os.cpu_count() or 1
@@ -559,6 +609,22 @@ def _cpu_baseline(ctx, host, zhost, model_path, out):
                     res[key]["ids_match_gpu"] = (j["fnv1a64"] == out["encode"].get("fnv1a64")) if out["encode"].get("fnv1a64") else None
             except Exception as e:  # noqa: BLE001
                 res[key] = {"error": str(e)}
+        os.remove(lines)
+    zenc = out.get("extra", {}).get("zipf", {}).get("encode")
+    if zhost is not None and zenc is not None:
+        lines = os.path.join(tmpdir, "zenc.txt")
+        with open(lines, "wb") as f:
+            f.write(zhost)
+        try:
+            zmodel = os.path.join(tempfile.gettempdir(), "yttm_bench_zipf_%s.model" % os.environ.get("MASTER_PORT", str(os.getpid())))
+            r = subprocess.run(pre + [ref, "encode_bench", zmodel, lines, "8", "0.0", "-1"], capture_output=True, text=True)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            res.setdefault("zipf", {})["encode"] = {"value": round(j["sentences"] / j["encode_seconds"], 1), "unit": "sentences/s", "cores": cores,
+                                                    "sample": f"{j['sentences']} lines of the Zipf corpus, encode_as_ids, n_threads=8",
+                                                    "fnv1a64": j["fnv1a64"], "ids_match_gpu": j["fnv1a64"] == zenc["fnv1a64"]}
+            out["parity"]["zipf_encode_fnv_matches_reference_on_this_box"] = res["zipf"]["encode"]["ids_match_gpu"]
+        except Exception as e:  # noqa: BLE001
+            res.setdefault("zipf", {})["encode"] = {"error": str(e)}
         os.remove(lines)
     res["python_boundary"] = "not timed: the reference's Cython module cannot be built on the GPU box (/root/reference is absent there)"
     return res
