@@ -211,7 +211,7 @@ GpuCtx::~GpuCtx() {
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_); DFREE(d_top_slots_); DFREE(d_top_n_); DFREE(d_box_);
   DFREE(d_send_); DFREE(d_xstat_);
-  db_.recs = nullptr; db_.n = nullptr;
+  DFREE(db_.keys); DFREE(db_.vals); DFREE(db_.touched); DFREE(db_.n);
   free_table(pt_);
   free_index();
   pool_quiesce(st_);
@@ -760,24 +760,24 @@ void GpuCtx::exchange_deltas() {
   if (!multi()) return;
   chain_event_ = nullptr;
   launch_fold_stats(d_stats_, pt_.n_keys, st_);  // the apply kernels leave their slot counts in per-workgroup rows
+  pack_deltas();
   unsigned long long n_local = 0;
   unsigned int nk_local = 0;  // keys in the table after this rank's own updates (one round trip for both numbers)
-  HIP_CHECK(hipMemcpyAsync(&n_local, db_.n, 8, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&n_local, d_send_, 8, hipMemcpyDeviceToHost, st_));
   HIP_CHECK(hipMemcpyAsync(&nk_local, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
   sync();
   n_keys_host = nk_local;
-  const unsigned long long mine = n_local > db_.cap ? ~0ull : n_local;
+  const unsigned long long mine = n_local > send_cap_ ? ~0ull : n_local;
   size_t n_remote = 0;
   for (int attempt = 0;; attempt++) {
     unsigned long long need_all = 0;
-    if (comm_->allgather_recs(db_.recs, mine, d_recv_, (size_t)recv_cap_, st_, &need_all, &n_remote)) break;
+    if (comm_->allgather_recs(d_send_ + 1, mine, d_recv_, (size_t)recv_cap_, st_, &need_all, &n_remote)) break;
     if (need_all == ~0ull) throw GpuError{"delta exchange buffer overflow (on some rank)"};
     if (attempt) throw GpuError{"delta receive buffer could not be sized"};
     grow_recv(need_all);
   }
   ensure_table_capacity(n_keys_host + n_remote);
   launch_pt_apply(pt_, d_recv_, n_remote, st_);
-  HIP_CHECK(hipMemsetAsync(db_.n, 0, 8, st_));
   unsigned int nk = 0;
   HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
   sync();
@@ -787,8 +787,15 @@ void GpuCtx::exchange_deltas() {
 // Per-round exchange: the first blk_ units (header + records) of every rank's send buffer are all-gathered and folded in by one
 // kernel that reads the counts on the device -- no copy to the host, no synchronisation.  What does not fit is reported through
 // the mailbox of the candidate scan that follows (candidates()), which repeats the exchange with larger blocks.
+// the round's delta table -> the send block (and the table is free again)
+void GpuCtx::pack_deltas() {
+  launch_dt_pack(db_, d_send_, send_cap_, last_pack_hint_, st_);
+  HIP_CHECK(hipMemsetAsync(db_.n, 0, 8, st_));
+}
+
 void GpuCtx::exchange_round(unsigned long long only_mask) {
   chain_event_ = nullptr;
+  if (!only_mask) pack_deltas();  // (a repeat gathers the same block again, wider)
   grow_recv(blk_ * (unsigned long long)comm_->world);
   comm_->allgather_blocks(d_send_, d_recv_, (size_t)blk_ * sizeof(DeltaRec), st_);
   launch_pt_apply_blocks(pt_, d_recv_, blk_, comm_->world, comm_->rank, only_mask, d_xstat_, st_);
@@ -807,12 +814,22 @@ void GpuCtx::pair_count() {
   if (multi()) {
     bound = std::min<unsigned long long>(bound * comm_->world, 1ull << 27);
     if (!d_send_) {
-      // worst case: every live token emits a handful of records in one pass
-      db_.cap = std::max<unsigned long long>(1ull << 20, 5 * n_tokens0 + 1024);
-      d_send_ = dmalloc<DeltaRec>(db_.cap + 1);
-      db_.recs = d_send_ + 1;
-      db_.n = reinterpret_cast<unsigned long long *>(d_send_);  // the count is the header of the block that travels
-      const DeltaRec hdr{0ull, (long long)db_.cap};  // {records, capacity}: the peers check the one against the other
+      // distinct pairs a round of this rank can touch: bounded by its updates (a handful per live token); sized for a
+      // quarter of that -- dense rounds touch few distinct pairs, sparse rounds few tokens -- and checked: a rank whose table or
+      // send block overflowed says so in its block's header and every rank stops
+      unsigned long long cap = 1ull << 20;
+      while (cap < n_tokens0 / 2 && cap < (1ull << 27)) cap <<= 1;
+      db_.keys = dmalloc<unsigned long long>(cap);
+      db_.vals = dmalloc<long long>(cap);
+      db_.touched = dmalloc<uint32_t>(cap);
+      db_.n = dmalloc<unsigned long long>(2);
+      db_.mask = cap - 1;
+      launch_fill_u64(db_.keys, PT_EMPTY, cap, st_);
+      HIP_CHECK(hipMemsetAsync(db_.vals, 0, cap * 8, st_));
+      HIP_CHECK(hipMemsetAsync(db_.n, 0, 16, st_));
+      send_cap_ = cap / 2;  // (a table more than half full counts as overflow)
+      d_send_ = dmalloc<DeltaRec>(send_cap_ + 1);
+      const DeltaRec hdr{0ull, (long long)send_cap_};  // {records, capacity}: the peers check the one against the other
       HIP_CHECK(hipMemcpyAsync(d_send_, &hdr, sizeof hdr, hipMemcpyHostToDevice, st_));
       sync();
       d_xstat_ = dmalloc<unsigned long long>(4);
@@ -820,7 +837,7 @@ void GpuCtx::pair_count() {
       HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, st_));
       blk_min_ = std::max(2u, env_uint("YTTM_XCHG_BLK_MIN", 4096));  // (tests shrink it to force the repeat path)
       blk_ = blk_min_;
-      grow_recv(std::max<unsigned long long>(db_.cap, blk_ * (unsigned long long)comm_->world));
+      grow_recv(std::max<unsigned long long>(send_cap_, blk_ * (unsigned long long)comm_->world));
     }
   }
   // The candidate filter no longer streams the table, so its size costs nothing per round, while every growth step is a
@@ -1390,7 +1407,6 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   } else {
     prev_flag_toks_.swap(flag_now_);
   }
-  if (multi()) HIP_CHECK(hipMemsetAsync(db_.n, 0, 8, st_));  // this round's records start at the head of the send block
   // one launch per round: the apply kernel's last workgroup also does the candidate scan (see gpu_ctx.h)
   ScanArgs sa{};
   fused_pending_ = false;

@@ -215,11 +215,14 @@ class GpuCtx {
   unsigned int cand_cap_ = 0;
   unsigned int *d_cand_n_ = nullptr;
   unsigned long long *d_cand_hist_ = nullptr;
-  // multi-GPU delta exchange.  d_send_ = { header: record count, - } followed by the records the kernels append (db_ points
-  // into it); per round the first blk_ 16-byte units of every rank's d_send_ are all-gathered into d_recv_
+  // multi-GPU delta exchange.  db_ = the round's delta table (yttm_device.h); d_send_ = { header: record count, capacity } followed by
+  // the table's records as k_dt_pack left them; per round the first blk_ 16-byte units of every rank's d_send_ are all-gathered
+  // into d_recv_
   DeltaBuf db_{};
   DeltaRec *d_send_ = nullptr, *d_recv_ = nullptr;
-  unsigned long long recv_cap_ = 0, blk_ = 4096, blk_min_ = 4096;
+  unsigned long long recv_cap_ = 0, blk_ = 4096, blk_min_ = 4096, send_cap_ = 0;
+  unsigned int last_pack_hint_ = 1u << 16;
+  void pack_deltas();
   unsigned long long *d_xstat_ = nullptr;  // [0] ranks whose block overflowed, [1] largest count, [2] hot-list overflow verdicts
   bool multi() const { return comm_ != nullptr; }  // (a communicator of world size 1 still runs the whole exchange path)
   void exchange_round(unsigned long long only_mask);

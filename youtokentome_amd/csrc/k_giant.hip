@@ -20,13 +20,7 @@ __device__ inline void st32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, 
 
 __device__ inline void giant_emit(const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta, unsigned int *new_keys) {
   pt_add(pt, key, delta, new_keys);
-  if (db.recs) {
-    const unsigned long long i = atomicAdd(db.n, 1ull);
-    if (i < db.cap) {
-      db.recs[i].key = key;
-      db.recs[i].delta = delta;
-    }
-  }
+  dt_add(db, key, delta);
 }
 
 // weighted adjacency counts of tok[0..n) (a run of L equal tokens counts floor(L/2) for its self pair,

@@ -62,13 +62,7 @@ struct AggLds {
 
 __device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta, unsigned int *new_keys) {
   pt_add(pt, key, delta, new_keys);
-  if (db.recs) {
-    unsigned long long i = atomicAdd(db.n, 1ull);
-    if (i < db.cap) {
-      db.recs[i].key = key;
-      db.recs[i].delta = delta;
-    }
-  }
+  dt_add(db, key, delta);  // (multi-GPU: the same update, for the other ranks)
 }
 
 // Count deltas of hot pairs are summed in a small LDS hash shared by the workgroup before they become HBM atomics
@@ -1775,6 +1769,26 @@ __global__ __launch_bounds__(BLOCK) void k_pt_apply(PairTable pt, const DeltaRec
   for (; i < n; i += stride) pt_add(pt, recs[i].key, recs[i].delta);
 }
 
+// multi-GPU: the delta table of the round that just ran -> the contiguous send block { {count, capacity}, records... }; the claimed
+// slots are freed for the next round.  *db.n is reset by the host (stream-ordered memset) afterwards.
+__global__ __launch_bounds__(BLOCK) void k_dt_pack(DeltaBuf db, DeltaRec *__restrict__ send, unsigned long long send_cap) {
+  const unsigned long long n_raw = *db.n;
+  const unsigned long long n = n_raw <= db.mask + 1 ? n_raw : db.mask + 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    send[0].key = n_raw;                    // (a count beyond the capacity tells every rank that this one lost updates)
+    send[0].delta = (long long)send_cap;
+  }
+  for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * BLOCK) {
+    const uint32_t sl = db.touched[i];
+    if (i < send_cap) {
+      send[1 + i].key = db.keys[sl];
+      send[1 + i].delta = db.vals[sl];
+    }
+    db.keys[sl] = PT_EMPTY;
+    db.vals[sl] = 0;
+  }
+}
+
 // multi-GPU, per round: the ranks' delta blocks as ncclAllGather left them -- block r = { count, -, records... } of `blk` 16-byte
 // units -- folded into the local replica.  A rank whose count does not fit its block is skipped as a whole and reported in
 // xstat[0] (bit r); the host then repeats the exchange with larger blocks for exactly those ranks (only_mask).  xstat[1] =
@@ -1796,7 +1810,8 @@ __global__ __launch_bounds__(BLOCK) void k_pt_apply_blocks(PairTable pt, const D
     if (r == rank) continue;  // own deltas went into the table when they were made
     unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
     const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
-    for (; i < n; i += stride) pt_add(pt, b[1 + i].key, b[1 + i].delta);
+    for (; i < n; i += stride)
+      if (b[1 + i].delta) pt_add(pt, b[1 + i].key, b[1 + i].delta);  // (updates of a round often cancel)
   }
 }
 
@@ -2133,6 +2148,12 @@ void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t t
 void launch_publish(const PairTable &pt, CandRec *out, unsigned int cap, unsigned int *n_out, unsigned long long *hist, unsigned int *done_ctr,
                     unsigned char *mailbox, unsigned int fast, uint32_t round_id, unsigned long long *stats, unsigned long long *xstat, hipStream_t st) {
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(BLOCK), 0, st, pt, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id, stats, xstat);
+}
+void launch_dt_pack(const DeltaBuf &db, DeltaRec *send, unsigned long long send_cap, unsigned int n_hint, hipStream_t st) {
+  unsigned int g = (n_hint + BLOCK - 1) / BLOCK;
+  if (g < 8) g = 8;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_dt_pack, dim3(g), dim3(BLOCK), 0, st, db, send, send_cap);
 }
 void launch_pt_apply_blocks(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, int rank, unsigned long long only_mask,
                             unsigned long long *xstat, hipStream_t st) {

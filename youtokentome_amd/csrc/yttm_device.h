@@ -85,10 +85,17 @@ struct DeltaRec {
   long long delta;
 };
 
+// Multi-GPU: what a rank's merge round changes, summed by pair before it travels -- a rank-local open-addressing table
+// pair -> signed delta that every count update of a round is added to as well (dt_add), and a list of the slots the round
+// claimed.  After the round k_dt_pack turns the claimed slots into the contiguous block of (pair, delta) records that the
+// ranks all-gather, and frees them.  (A record per update instead -- the first version -- put every update of a round through one
+// global cursor: 0.9 ms per round at 1 GB with a communicator of one rank, and ten times the bytes on the links.)
 struct DeltaBuf {
-  DeltaRec *recs;          // nullptr = single-GPU mode (no records kept)
-  unsigned long long cap;
-  unsigned long long *n;   // append cursor; may run past cap (overflow is reported by the host)
+  unsigned long long *keys;  // [mask + 1], PT_EMPTY = free; nullptr = single-GPU mode (nothing is kept)
+  long long *vals;           // [mask + 1]
+  uint32_t *touched;         // [mask + 1] slots claimed this round, in claim order
+  unsigned long long *n;     // number of claimed slots (may run past the capacity: reported, the training stops)
+  unsigned long long mask;
 };
 
 __host__ __device__ inline unsigned long long mix64(unsigned long long x) {
@@ -171,6 +178,28 @@ __device__ inline unsigned long long pt_get(const PairTable &pt, unsigned long l
     if (k == key) return *pt.cnt_p(i) & PT_CNT;
     i = (i + 1) & pt.mask;
   }
+}
+
+__device__ inline void dt_add(const DeltaBuf &db, unsigned long long key, long long delta) {
+  if (!db.keys) return;
+  unsigned long long i = mix64(key * 0x9e3779b97f4a7c15ull) & db.mask;
+  for (unsigned long long probes = 0; probes <= db.mask; probes++) {
+    unsigned long long k = ld_agent(&db.keys[i]);
+    if (k == PT_EMPTY) {
+      k = atomicCAS(&db.keys[i], PT_EMPTY, key);
+      if (k == PT_EMPTY) {
+        const unsigned long long j = atomicAdd(db.n, 1ull);
+        if (j <= db.mask) db.touched[j] = (uint32_t)i;
+        k = key;
+      }
+    }
+    if (k == key) {
+      atomicAdd(reinterpret_cast<unsigned long long *>(&db.vals[i]), (unsigned long long)delta);
+      return;
+    }
+    i = (i + 1) & db.mask;
+  }
+  atomicAdd(db.n, db.mask + 2);  // table full (the count then exceeds the capacity: the host stops the training)
 }
 
 // ---- UTF-8 (utf8.cpp:14-74), device version ----------------------------------------------------------------------

@@ -103,6 +103,7 @@ void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t t
                      const BatchArgs *zba, unsigned long long *xstat /* multi-GPU: leave the mailbox to launch_publish */, hipStream_t st);
 void launch_publish(const PairTable &pt, CandRec *out, unsigned int cap, unsigned int *n_out, unsigned long long *hist, unsigned int *done_ctr,
                     unsigned char *mailbox, unsigned int fast, uint32_t round_id, unsigned long long *stats, unsigned long long *xstat, hipStream_t st);
+void launch_dt_pack(const DeltaBuf &db, DeltaRec *send, unsigned long long send_cap, unsigned int n_hint, hipStream_t st);
 void launch_pt_apply_blocks(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, int rank, unsigned long long only_mask,
                             unsigned long long *xstat, hipStream_t st);
 constexpr int MB_HIST = 128;  // byte offset of the count histogram in the mailbox (header + xstat before it)
