@@ -648,6 +648,14 @@ struct TileStats {
   unsigned long long words_hit = 0, words_hit_tok = 0;  // measurement pass (BatchArgs::instr): words with a merge site, their tokens
 };
 
+// K3's dense pair table: how many copies of an n x n table fit in the 1024 counters (a power of two, at most one per lane)
+__device__ inline uint32_t dense_copies(uint32_t n) {
+  if (n == 0) return 1u;
+  uint32_t c = 1024u / (n * n);
+  if (c > 64u) c = 64u;
+  return c ? 1u << (31 - __clz(c)) : 1u;
+}
+
 // everything that happens to one staged tile (K3 count or K4 merge)
 template <int SLOT, bool MERGE, bool LDSR>
 __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &ts, const PairTable &pt, const DeltaBuf &db,
@@ -718,7 +726,9 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         const uint32_t a = t0 & TOK_MASK, b = t1 & TOK_MASK;
         // K3 on a small alphabet (self_z = smallest id, z_base = number of ids, <= 32): the pair IS the index of a dense table of
         // counts in LDS -- one ds_add_u64 per adjacency instead of a hash probe (compare, CAS, add)
-        unsigned long long *dense = reinterpret_cast<unsigned long long *>(A.flagbits);
+        // -- and a lane adds into its own copy of the table when the alphabet leaves room for copies (dense_copies), so the lanes
+        // of one instruction (on 'abcd ': 64 lanes, 25 pairs) do not queue up on one address
+        unsigned long long *dense = reinterpret_cast<unsigned long long *>(A.flagbits) + (size_t)(lane & (dense_copies(z_base) - 1)) * (z_base * z_base);
         const bool use_dense = z_base != 0;
         if (a != b) {
           if (use_dense) atomicAdd(&dense[(a - self_z) * z_base + (b - self_z)], (unsigned long long)f);
@@ -1094,7 +1104,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
   if (!MERGE && z_base) {  // K3, small alphabet: the dense pair table (see process_tile) lives where K4 keeps its flag bitmap
     static_assert(FLAG_LDS_IDS / 16 * sizeof(uint32_t) >= 32 * 32 * sizeof(unsigned long long), "32 x 32 counts");
     unsigned long long *dense = reinterpret_cast<unsigned long long *>(A.flagbits);
-    for (unsigned int i = threadIdx.x; i < z_base * z_base; i += WPB * 64) dense[i] = 0;
+    for (unsigned int i = threadIdx.x; i < z_base * z_base * dense_copies(z_base); i += WPB * 64) dense[i] = 0;
   }
   const RuleTab<LDSR> rtab{rkeys, rridx, rules, rule_mask, z_base};
   __syncthreads();
@@ -1247,7 +1257,8 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
   if (!MERGE && z_base) {  // (after agg_flush's barrier: every wave is done counting)
     const unsigned long long *dense = reinterpret_cast<const unsigned long long *>(A.flagbits);
     for (unsigned int i = threadIdx.x; i < z_base * z_base; i += WPB * 64) {
-      const unsigned long long v = dense[i];
+      unsigned long long v = 0;
+      for (uint32_t c = 0; c < dense_copies(z_base); c++) v += dense[c * z_base * z_base + i];
       if (v) global_emit(pt, db, pair_key(self_z + i / z_base, self_z + i % z_base), (long long)v, &A.new_keys);
     }
   }
@@ -2073,8 +2084,10 @@ static inline unsigned int tile_grid(unsigned int n_tiles, unsigned int wpb, uns
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, uint32_t id_min, uint32_t n_ids, hipStream_t st) {
   if (!ts.n_tiles) return;
   if (n_ids > 32) n_ids = 0;  // (the dense table holds 32 x 32 counts; larger alphabets go through the LDS hash)
+  unsigned int bpc = 4;
+  if (const char *e = getenv("YTTM_K3_BPC")) bpc = (unsigned int)atoi(e);  // (tuning aid; one launch per training)
   if (cls == 0)
-    hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false, false>), dim3(tile_grid(ts.n_tiles, 4, 4)), dim3(256), 0, st, ts, pt, db,
+    hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false, false>), dim3(tile_grid(ts.n_tiles, 4, bpc)), dim3(256), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, id_min, n_ids,
                        (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{}, ScanArgs{});
   else
