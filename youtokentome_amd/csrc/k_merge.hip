@@ -2074,6 +2074,89 @@ void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, un
 
 // class-A apply kernel: waves per workgroup x workgroups per CU (6 x 4 = 6 waves per SIMD: <= 80 VGPRs, <= 40 KB LDS per workgroup)
 constexpr int APPLY_WPB = 8, APPLY_BPC = 3;
+// ------------------------------------------------------------------------------------------------- K3, small alphabets
+// The pair count of class-A tiles when the alphabet has at most K3D_MAX_IDS symbols (any corpus of one script; 'abcd ': 5): no
+// LDS staging, no hash.  A wave holds its tile in registers position-major (lane l: tokens 64 c + l), one tile ahead; the
+// right neighbour comes by a lane shift, the word of a position from the ballot of the word-start bits, its frequency from
+// the tile's window of word counts (registers, one ds_bpermute), and a run of equal tokens contributes floor(L/2)
+// (bpe.cpp:461-475) through its pairs at an even offset from the run's start -- picked with carry arithmetic on the ballot of
+// "equal to the right neighbour" (scalar unit) instead of a walk along the run.  Every adjacency is then ONE ds_add_u64 into
+// a dense n x n table, kept in as many lane-indexed copies as fit (the 64 lanes of an instruction hit ~25 addresses on
+// 'abcd ').  Measured on the 1 GB 'abcd ' table: the general kernel (k_tiles<.., false, ..>) issues 2 530 VALU + 1 740 SALU + 520 LDS
+// instructions per tile and is bound by them (0.87 ms, 16 % of HBM); this one ~ 400.
+constexpr uint32_t K3D_MAX_IDS = 64, K3D_COUNTERS = 4096;
+__device__ inline uint32_t k3d_copies(uint32_t n) {
+  uint32_t c = K3D_COUNTERS / (n * n);
+  if (c > 64u) c = 64u;
+  return 1u << (31 - __clz(c));
+}
+template <int SLOT>
+__global__ __launch_bounds__(256) void k_pair_count_dense(TileSet ts, PairTable pt, DeltaBuf db, uint32_t id_min, uint32_t n_ids) {
+  constexpr int NC = SLOT / 64;
+  __shared__ unsigned long long dense[K3D_COUNTERS];
+  __shared__ unsigned int new_keys;
+  const uint32_t nn = n_ids * n_ids, copies = k3d_copies(n_ids);
+  for (unsigned int i = threadIdx.x; i < nn * copies; i += 256) dense[i] = 0;
+  if (threadIdx.x == 0) new_keys = 0;
+  __syncthreads();
+  const int lane = lane_id();
+  unsigned long long *mine = dense + (size_t)((uint32_t)lane & (copies - 1)) * nn;
+  const uint32_t n_waves = gridDim.x * 4u;
+  uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
+  uint32_t r[NC], rn[NC];
+  WReg<SLOT> w, wn;
+  auto fetch = [&](uint32_t (&dst)[NC], WReg<SLOT> &wd, uint32_t tile) {
+    const int n = (int)ts.tile_len[tile];
+    const uint32_t *src = ts.tok + (size_t)tile * SLOT;
+#pragma unroll
+    for (int c = 0; c < NC; c++) dst[c] = 64 * c + lane < n ? src[64 * c + lane] : TOK_WS;  // (behind the end: "a word starts here")
+    wreg_load<SLOT>(wd, ts.wcnt, ts.tile_word0[tile]);
+  };
+  if (t < ts.n_tiles) fetch(r, w, t);
+  for (; t < ts.n_tiles; t += n_waves) {
+    if (t + n_waves < ts.n_tiles) fetch(rn, wn, t + n_waves);
+    uint32_t wbase = 0;
+    bool cont = false, cont_even = false;  // the run of equal tokens at the end of the previous chunk goes on / its next pair is at an even offset
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const uint32_t t0 = r[c];
+      uint32_t t1 = __shfl_down(t0, 1);
+      const uint32_t first_next = c + 1 < NC ? (uint32_t)__shfl(r[c + 1 < NC ? c + 1 : c], 0) : TOK_WS;
+      if (lane == 63) t1 = first_next;
+      const unsigned long long m_ws = __ballot((t0 & TOK_WS) != 0u);
+      const uint32_t k = wbase + lanes_below(m_ws) + ((t0 & TOK_WS) ? 1u : 0u) - 1u;  // word of this position (word starts <= p, minus one)
+      wbase += (uint32_t)__popcll(m_ws);
+      const long long f = word_weight_all<SLOT>(w, k);
+      const bool adj = !(t1 & TOK_WS);
+      const uint32_t a = (t0 & TOK_MASK) - id_min, b = (t1 & TOK_MASK) - id_min;
+      const unsigned long long E = __ballot(adj && a == b);
+      // runs of E = pairs inside a run of equal tokens.  S: the runs' first bits; those at an even position (or going on from the
+      // previous chunk at an even offset) make their whole run carry out in E + S_e; such runs take their even positions, the
+      // others their odd ones.
+      const unsigned long long S = E & ~((E << 1) | (cont ? 1ull : 0ull));
+      const unsigned long long S_e = (S & 0x5555555555555555ull) | (cont_even ? (E & 1ull) : 0ull);
+      const unsigned long long D = (E + S_e) ^ E;
+      const unsigned long long sel = (D & E & 0x5555555555555555ull) | (~D & E & 0xaaaaaaaaaaaaaaaaull);
+      cont = (E >> 63) != 0ull;
+      cont_even = cont && !(sel >> 63);
+      if (adj && (a != b || lane_bit(sel))) atomicAdd(&mine[a * n_ids + b], (unsigned long long)f);
+    }
+    if (t + n_waves < ts.n_tiles) {
+#pragma unroll
+      for (int c = 0; c < NC; c++) r[c] = rn[c];
+      w = wn;
+    }
+  }
+  __syncthreads();
+  for (unsigned int i = threadIdx.x; i < nn; i += 256) {
+    unsigned long long v = 0;
+    for (uint32_t c = 0; c < copies; c++) v += dense[c * nn + i];
+    if (v) global_emit(pt, db, pair_key(id_min + i / n_ids, id_min + i % n_ids), (long long)v, &new_keys);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && new_keys) atomicAdd(pt.n_keys, new_keys);
+}
+
 static inline unsigned int tile_grid(unsigned int n_tiles, unsigned int wpb, unsigned int blocks_per_cu) {
   unsigned int need = (n_tiles + wpb - 1) / wpb;
   unsigned int g = 256u * blocks_per_cu;
@@ -2083,9 +2166,14 @@ static inline unsigned int tile_grid(unsigned int n_tiles, unsigned int wpb, uns
 
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, uint32_t id_min, uint32_t n_ids, hipStream_t st) {
   if (!ts.n_tiles) return;
-  if (n_ids > 32) n_ids = 0;  // (the dense table holds 32 x 32 counts; larger alphabets go through the LDS hash)
   unsigned int bpc = 4;
-  if (const char *e = getenv("YTTM_K3_BPC")) bpc = (unsigned int)atoi(e);  // (tuning aid; one launch per training)
+  if (const char *e = getenv("YTTM_K3_BPC")) bpc = (unsigned int)atoi(e);  // (tuning aids; one launch per training)
+  const bool general = getenv("YTTM_K3_GENERAL") != nullptr;
+  if (cls == 0 && n_ids && n_ids <= K3D_MAX_IDS && !general) {
+    hipLaunchKernelGGL((k_pair_count_dense<TILE_SLOT_A>), dim3(tile_grid(ts.n_tiles, 4, bpc)), dim3(256), 0, st, ts, pt, db, id_min, n_ids);
+    return;
+  }
+  if (n_ids > 32) n_ids = 0;  // (k_tiles' dense table holds 32 x 32 counts; larger alphabets go through the LDS hash)
   if (cls == 0)
     hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, 4, false, false>), dim3(tile_grid(ts.n_tiles, 4, bpc)), dim3(256), 0, st, ts, pt, db,
                        (const RuleSlot *)nullptr, 0u, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0xffffffffu, id_min, n_ids,
