@@ -26,6 +26,24 @@ def texts_small(seed=0, n=6, size=3000):
     return out
 
 
+def texts_by_alphabet_size(sizes=(2, 5, 31, 33, 45, 63, 64, 70), seed=5, n_words=600):
+    """words over alphabets of the given sizes (the space mark included), with long runs of one symbol, odd and even"""
+    rng = random.Random(seed)
+    out = []
+    for n_sym in sizes:
+        syms = [chr(0x430 + i) for i in range(n_sym - 1)]
+        words = []
+        for _ in range(n_words):
+            k = rng.randint(1, 40)
+            if rng.random() < 0.4:
+                w = rng.choice(syms) * rng.randint(1, 9) + "".join(rng.choice(syms) for _ in range(k % 5)) + rng.choice(syms) * rng.randint(2, 140)
+            else:
+                w = "".join(rng.choice(syms[: rng.randint(1, len(syms))]) for _ in range(k))
+            words.append(w)
+        out.append((" ".join(words) + "\n").encode())
+    return out
+
+
 def alphabet_for(text, coverage=1.0, n_special=4):
     cps, cnts, dl = O.char_hist(text)
     acp, aid, rem = O.alphabet(cps, cnts, dl, coverage, n_special)

@@ -32,6 +32,8 @@ def test_k2_k3_word_table_and_pair_count():
         S.check_word_table_and_pairs(t, coverage=1.0 if i % 2 == 0 else 0.9)
     S.check_word_table_and_pairs(gen.readme_corpus(3000, 100, seed=3))
     S.check_word_table_and_pairs(gen.zipf_corpus(400000, vocab=8000))
+    for t in S.texts_by_alphabet_size(n_words=5000):  # K3's kernels: up to 32 symbols, up to 64, beyond
+        S.check_word_table_and_pairs(t)
 
 
 def test_k4_merge_apply_rounds():

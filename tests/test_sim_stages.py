@@ -22,6 +22,13 @@ def test_word_table_and_pair_count():
         S.check_word_table_and_pairs(t, coverage=1.0 if i % 2 == 0 else 0.9)
 
 
+def test_pair_count_by_alphabet_size():
+    """K3 has a kernel of its own for alphabets of up to 64 symbols (two table sizes: up to 32, up to 64) and the general tile kernel
+    beyond; runs of equal tokens cross its 64-token chunks at every offset."""
+    for t in S.texts_by_alphabet_size():
+        S.check_word_table_and_pairs(t)
+
+
 def test_word_table_fast_and_exact_scans_agree():
     """K2 scans the common word -- a few ASCII letters, nothing dropped -- 16 bytes at a time and compares such words as bytes;
     everything else takes the exact char-by-char walk.  The same word must dedup across the two paths: with and without an

@@ -5,9 +5,9 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 CMD="python $R/tools/dbg/frontend_time.py abcd 1000"
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES \
-  --kernel-include-regex "k_tiles" --output-format csv -d $R/gpurun_out/pmc_tiles_a -- $CMD > $R/gpurun_out/pmc_tiles_a.log 2>&1
+  --kernel-include-regex "${KREGEX:-k_tiles}" --output-format csv -d $R/gpurun_out/pmc_tiles_a -- $CMD > $R/gpurun_out/pmc_tiles_a.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_WAVES \
-  --kernel-include-regex "k_tiles" --output-format csv -d $R/gpurun_out/pmc_tiles_b -- $CMD > $R/gpurun_out/pmc_tiles_b.log 2>&1
+  --kernel-include-regex "${KREGEX:-k_tiles}" --output-format csv -d $R/gpurun_out/pmc_tiles_b -- $CMD > $R/gpurun_out/pmc_tiles_b.log 2>&1
 python - <<'PY'
 import csv, glob, os, collections
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")

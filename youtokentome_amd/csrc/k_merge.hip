@@ -2082,54 +2082,89 @@ constexpr int APPLY_WPB = 8, APPLY_BPC = 3;
 // (bpe.cpp:461-475) through its pairs at an even offset from the run's start -- picked with carry arithmetic on the ballot of
 // "equal to the right neighbour" (scalar unit) instead of a walk along the run.  Every adjacency is then ONE ds_add_u64 into
 // a dense n x n table, kept in as many lane-indexed copies as fit (the 64 lanes of an instruction hit ~25 addresses on
-// 'abcd ').  Measured on the 1 GB 'abcd ' table: the general kernel (k_tiles<.., false, ..>) issues 2 530 VALU + 1 740 SALU + 520 LDS
-// instructions per tile and is bound by them (0.87 ms, 16 % of HBM); this one ~ 400.
-constexpr uint32_t K3D_MAX_IDS = 64, K3D_COUNTERS = 4096;
-__device__ inline uint32_t k3d_copies(uint32_t n) {
-  uint32_t c = K3D_COUNTERS / (n * n);
-  if (c > 64u) c = 64u;
-  return 1u << (31 - __clz(c));
+// 'abcd ').  Measured on the 1 GB 'abcd ' table (546 k tiles, 252 M tokens, 16 M words): the general kernel (k_tiles<.., false, ..>)
+// issues 610 VALU + 420 SALU + 125 LDS instructions per tile and is bound by them (0.87 ms, 16 % of HBM by the algorithmic bytes);
+// this one 222 + 220 + 17 and takes 0.43 ms (33 %), of which 0.27 ms are its loads alone (the same loop with the arithmetic
+// taken out; tools/micro/stream_bw reads the same pattern from a hot array in 0.17 ms).
+constexpr uint32_t K3D_MAX_IDS = 64;
+// the table's row stride: the alphabet size rounded up to a power of two (index = a << sh | b, no multiply)
+__host__ __device__ inline uint32_t k3d_shift(uint32_t n) {
+  uint32_t sh = 0;
+  while ((1u << sh) < n) sh++;
+  return sh;
 }
-template <int SLOT>
+// COUNTERS: 2048 (16 KB: LDS does not limit the waves per CU) for up to 32 symbols, 4096 beyond
+__host__ __device__ inline uint32_t k3d_copies(uint32_t n, uint32_t counters) {
+  uint32_t c = counters >> (2 * k3d_shift(n));
+  if (c > 64u) c = 64u;
+  uint32_t p = 1;
+  while (2 * p <= c) p *= 2;
+  return p;
+}
+template <int SLOT, uint32_t COUNTERS>
 __global__ __launch_bounds__(256) void k_pair_count_dense(TileSet ts, PairTable pt, DeltaBuf db, uint32_t id_min, uint32_t n_ids) {
-  constexpr int NC = SLOT / 64;
-  __shared__ unsigned long long dense[K3D_COUNTERS];
+  constexpr int NC = SLOT / 64, NW = WReg<SLOT>::N;
+  __shared__ unsigned long long dense[COUNTERS];  // [1 << 2 sh][copies]
+  __shared__ uint32_t wwin[4][64 * NW];           // per wave: the word counts of its tile
   __shared__ unsigned int new_keys;
-  const uint32_t nn = n_ids * n_ids, copies = k3d_copies(n_ids);
+  const uint32_t sh = k3d_shift(n_ids), nn = 1u << (2 * sh), copies = k3d_copies(n_ids, COUNTERS);
   for (unsigned int i = threadIdx.x; i < nn * copies; i += 256) dense[i] = 0;
   if (threadIdx.x == 0) new_keys = 0;
   __syncthreads();
   const int lane = lane_id();
-  unsigned long long *mine = dense + (size_t)((uint32_t)lane & (copies - 1)) * nn;
+  // (the copies of one counter are neighbours -- lanes adding to the same pair hit different banks, and two lanes share a bank only
+  // through lane and lane + 32.  Index of pair (a, b) for this lane: base + ((a << sh) + b) * copies with the raw ids; the base takes
+  // id_min off both.)
+  const uint32_t lc = k3d_shift(copies);
+  const uint32_t base = ((uint32_t)lane & (copies - 1)) - (((id_min << sh) + id_min) << lc);
+  uint32_t *lw = wwin[threadIdx.x >> 6];
   const uint32_t n_waves = gridDim.x * 4u;
-  uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
+  uint32_t t = uni(blockIdx.x * 4u + (threadIdx.x >> 6));  // (uniform: lengths and first words come by scalar loads)
   uint32_t r[NC], rn[NC];
   WReg<SLOT> w, wn;
-  auto fetch = [&](uint32_t (&dst)[NC], WReg<SLOT> &wd, uint32_t tile) {
-    const int n = (int)ts.tile_len[tile];
+  // (length and first word of a tile are read two tiles ahead, so that the loads of the tile itself never wait for them)
+  auto head = [&](uint32_t tile, int &n, uint32_t &w0) {
+    n = tile < ts.n_tiles ? (int)ts.tile_len[tile] : 0;
+    w0 = tile < ts.n_tiles ? ts.tile_word0[tile] : 0u;
+  };
+  auto fetch = [&](uint32_t (&dst)[NC], WReg<SLOT> &wd, uint32_t tile, int n, uint32_t w0) {
     const uint32_t *src = ts.tok + (size_t)tile * SLOT;
 #pragma unroll
-    for (int c = 0; c < NC; c++) dst[c] = 64 * c + lane < n ? src[64 * c + lane] : TOK_WS;  // (behind the end: "a word starts here")
-    wreg_load<SLOT>(wd, ts.wcnt, ts.tile_word0[tile]);
+    for (int c = 0; c < NC; c++) {  // (the whole slot is readable; behind the end of the tile: "a word starts here")
+      const uint32_t v = src[64 * c + lane];
+      dst[c] = 64 * c + lane < n ? v : TOK_WS;
+    }
+    wreg_load<SLOT>(wd, ts.wcnt, w0);
   };
-  if (t < ts.n_tiles) fetch(r, w, t);
+  int n1, n2;
+  uint32_t w01, w02;
+  head(t, n1, w01);
+  head(t + n_waves, n2, w02);
+  if (t < ts.n_tiles) fetch(r, w, t, n1, w01);
   for (; t < ts.n_tiles; t += n_waves) {
-    if (t + n_waves < ts.n_tiles) fetch(rn, wn, t + n_waves);
-    uint32_t wbase = 0;
+    n1 = n2;
+    w01 = w02;
+    head(t + 2 * n_waves, n2, w02);
+    if (t + n_waves < ts.n_tiles) fetch(rn, wn, t + n_waves, n1, w01);
+    wave_sync();  // (the previous tile's reads of the window are done: DS operations of a wave execute in order)
+#pragma unroll
+    for (int i = 0; i < NW; i++) lw[lane + 64 * i] = w.v[i];
+    wave_sync();
+    uint32_t wbase = 0xffffffffu;  // word starts so far, minus one
     bool cont = false, cont_even = false;  // the run of equal tokens at the end of the previous chunk goes on / its next pair is at an even offset
 #pragma unroll
     for (int c = 0; c < NC; c++) {
       const uint32_t t0 = r[c];
-      uint32_t t1 = __shfl_down(t0, 1);
-      const uint32_t first_next = c + 1 < NC ? (uint32_t)__shfl(r[c + 1 < NC ? c + 1 : c], 0) : TOK_WS;
+      uint32_t t1 = from_lane_right(t0);
+      const uint32_t first_next = c + 1 < NC ? from_lane0(r[c + 1 < NC ? c + 1 : c]) : TOK_WS;
       if (lane == 63) t1 = first_next;
-      const unsigned long long m_ws = __ballot((t0 & TOK_WS) != 0u);
-      const uint32_t k = wbase + lanes_below(m_ws) + ((t0 & TOK_WS) ? 1u : 0u) - 1u;  // word of this position (word starts <= p, minus one)
+      const unsigned long long m_ws = ballot_b((int)t0 < 0);
+      const uint32_t k = wbase + lanes_below(m_ws) + (t0 >> 31);  // word of this position (word starts <= p, minus one)
       wbase += (uint32_t)__popcll(m_ws);
-      const long long f = word_weight_all<SLOT>(w, k);
-      const bool adj = !(t1 & TOK_WS);
-      const uint32_t a = (t0 & TOK_MASK) - id_min, b = (t1 & TOK_MASK) - id_min;
-      const unsigned long long E = __ballot(adj && a == b);
+      const bool adj = (int)t1 >= 0;  // the right neighbour belongs to the same word
+      const uint32_t a = t0 & TOK_MASK;
+      const bool eq = a == t1;  // (t1 without the word-start bit is its id)
+      const unsigned long long E = ballot_b(adj && eq);
       // runs of E = pairs inside a run of equal tokens.  S: the runs' first bits; those at an even position (or going on from the
       // previous chunk at an even offset) make their whole run carry out in E + S_e; such runs take their even positions, the
       // others their odd ones.
@@ -2139,7 +2174,7 @@ __global__ __launch_bounds__(256) void k_pair_count_dense(TileSet ts, PairTable 
       const unsigned long long sel = (D & E & 0x5555555555555555ull) | (~D & E & 0xaaaaaaaaaaaaaaaaull);
       cont = (E >> 63) != 0ull;
       cont_even = cont && !(sel >> 63);
-      if (adj && (a != b || lane_bit(sel))) atomicAdd(&mine[a * n_ids + b], (unsigned long long)f);
+      if (adj && (!eq || lane_bit(sel))) atomicAdd(&dense[base + (((a << sh) + t1) << lc)], (unsigned long long)lw[k]);
     }
     if (t + n_waves < ts.n_tiles) {
 #pragma unroll
@@ -2149,9 +2184,10 @@ __global__ __launch_bounds__(256) void k_pair_count_dense(TileSet ts, PairTable 
   }
   __syncthreads();
   for (unsigned int i = threadIdx.x; i < nn; i += 256) {
+    const uint32_t x = i >> sh, y = i & ((1u << sh) - 1u);
     unsigned long long v = 0;
-    for (uint32_t c = 0; c < copies; c++) v += dense[c * nn + i];
-    if (v) global_emit(pt, db, pair_key(id_min + i / n_ids, id_min + i % n_ids), (long long)v, &new_keys);
+    for (uint32_t c = 0; c < copies; c++) v += dense[(i << lc) + c];
+    if (v) global_emit(pt, db, pair_key(id_min + x, id_min + y), (long long)v, &new_keys);
   }
   __syncthreads();
   if (threadIdx.x == 0 && new_keys) atomicAdd(pt.n_keys, new_keys);
@@ -2170,7 +2206,10 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
   if (const char *e = getenv("YTTM_K3_BPC")) bpc = (unsigned int)atoi(e);  // (tuning aids; one launch per training)
   const bool general = getenv("YTTM_K3_GENERAL") != nullptr;
   if (cls == 0 && n_ids && n_ids <= K3D_MAX_IDS && !general) {
-    hipLaunchKernelGGL((k_pair_count_dense<TILE_SLOT_A>), dim3(tile_grid(ts.n_tiles, 4, bpc)), dim3(256), 0, st, ts, pt, db, id_min, n_ids);
+    if (n_ids <= 32u)
+      hipLaunchKernelGGL((k_pair_count_dense<TILE_SLOT_A, 2048u>), dim3(tile_grid(ts.n_tiles, 4, bpc)), dim3(256), 0, st, ts, pt, db, id_min, n_ids);
+    else
+      hipLaunchKernelGGL((k_pair_count_dense<TILE_SLOT_A, 4096u>), dim3(tile_grid(ts.n_tiles, 4, bpc)), dim3(256), 0, st, ts, pt, db, id_min, n_ids);
     return;
   }
   if (n_ids > 32) n_ids = 0;  // (k_tiles' dense table holds 32 x 32 counts; larger alphabets go through the LDS hash)

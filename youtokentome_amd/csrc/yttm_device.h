@@ -286,6 +286,31 @@ __device__ inline unsigned long long uni64(unsigned long long v) {
   const uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
   return ((unsigned long long)hi << 32) | lo;
 }
+// ballot of a condition the compiler already holds as a lane mask (__ballot takes an int and makes the compiler turn the mask
+// into 0/1 values and compare them again)
+__device__ inline unsigned long long ballot_b(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(p);
+#else
+  return __ballot(p ? 1 : 0);
+#endif
+}
+// the value the lane to the right (lane + 1) holds; lane 63 gets an unspecified one.  A DPP wave shift: no LDS crossbar trip.
+__device__ inline uint32_t from_lane_right(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+#else
+  return __shfl_down(v, 1);
+#endif
+}
+// lane 0's value, for every lane (v_readlane: the scalar unit holds it)
+__device__ inline uint32_t from_lane0(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+#else
+  return __shfl(v, 0);
+#endif
+}
 __device__ inline bool lane_bit(unsigned long long uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(uniform_mask); }
 __device__ inline uint32_t lanes_below(unsigned long long uniform_mask) {  // popcount(mask & lanemask_lt())
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(uniform_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)uniform_mask, 0u));
