@@ -437,7 +437,14 @@ def _bench_encode(ctx, model_path, main_res):
                              "algorithmic_bytes_per_launch": alg_bytes}}
 
     res = {"dropout": run(0.1)}  # configs[4]; parity for it is a distribution test (tests/test_gpu_parity.py), here: the rate and the mean length
-    res["encode"] = run(0.0)     # configs[3]; last, so that the ids left in the encoder are the deterministic ones
+    L.yttm_encoder_set_cache(h, 0, 0)
+    direct = run(0.0)            # every word occurrence through K5, as the reference does
+    L.yttm_encoder_set_cache(h, 2, 4 << 20)
+    res["encode"] = run(0.0)     # configs[3], the library's default path (word cache); last: its ids are the ones checked below
+    words = int(L.yttm_encode_cache_words(h))
+    res["encode"]["word_cache"] = {"distinct_words": words, "without_cache_sentences_per_s": direct["value"], "without_cache_kernel_ms": direct["kernel_ms"],
+                                   "gain": round(res["encode"]["value"] / direct["value"], 3)}
+    res["encode"]["roofline"]["kernel"] = "k5w_insert + k5_encode (distinct words) + k5w_count + k5w_scatter" if words else "k5_encode"
     # ---- parity: FNV-1a-64 of (len, ids...) per sentence over ALL sentences vs the reference's (pinned) ---------------------
     ids = np.zeros(n_ids.value, dtype=np.int32)
     off = np.zeros(n_sent + 1, dtype=np.uint64)
@@ -518,16 +525,23 @@ def _bench_encode_lines(ctx, model_path, text):
                                   C.byref(n_ids), C.byref(kms), err, _lib.ERRLEN)
         if rc != 0:
             raise RuntimeError(err.value.decode())
-    step()
-    ctx["barrier"]()
     steps = max(1, args.steps)
-    t0 = time.perf_counter()
-    k_ms = []
-    for _ in range(steps):
+
+    def timed():
         step()
-        k_ms.append(kms.value)
-    ctx["barrier"]()
-    dt = time.perf_counter() - t0
+        ctx["barrier"]()
+        t0 = time.perf_counter()
+        k_ms = []
+        for _ in range(steps):
+            step()
+            k_ms.append(kms.value)
+        ctx["barrier"]()
+        return time.perf_counter() - t0, k_ms
+    L.yttm_encoder_set_cache(h, 0, 0)  # every word occurrence through K5
+    dt_direct, k_direct = timed()
+    L.yttm_encoder_set_cache(h, 2, 4 << 20)  # the default: distinct words once
+    dt, k_ms = timed()
+    words = int(L.yttm_encode_cache_words(h))
     ids = np.zeros(n_ids.value, dtype=np.int32)
     o64 = np.zeros(n_sent + 1, dtype=np.uint64)
     L.yttm_encode_fetch(h, ids.ctypes.data_as(_lib.i32p), o64.ctypes.data_as(_lib.u64p), n_sent, err, _lib.ERRLEN)
@@ -538,6 +552,8 @@ def _bench_encode_lines(ctx, model_path, text):
     return {"metric": "encode_sentences_per_s", "value": round(steps * n_sent / dt, 1), "unit": "sentences/s", "sentences": n_sent,
             "mean_sentence_bytes": round(float(off[-1]) / n_sent, 1), "ids_per_sentence": round(n_ids.value / n_sent, 3),
             "kernel_ms": round(sum(k_ms) / len(k_ms), 3), "bytes_per_s": round(steps * float(off[-1]) / dt, 1), "fnv1a64": fnv,
+            "word_cache": {"distinct_words": words, "without_cache_sentences_per_s": round(steps * n_sent / dt_direct, 1),
+                           "without_cache_kernel_ms": round(sum(k_direct) / len(k_direct), 3), "gain": round(dt_direct / dt, 3)},
             "input": "the lines of the Zipf corpus, resident in HBM; ids left in HBM"}
 
 

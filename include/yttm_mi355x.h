@@ -69,6 +69,13 @@ int yttm_encode_device(yttm_encoder *enc, const void *d_bytes, const void *d_off
                        double dropout_prob, uint64_t *n_ids, double *kernel_ms, char *err, int errlen);
 int yttm_encode_fetch(yttm_encoder *enc, int32_t *ids, uint64_t *out_offsets, uint64_t n_sent, char *err, int errlen);
 
+/* Word-level encode cache (SURVEY.md 8f "N4"; the reference has no counterpart: bpe.cpp:1497-1632 encodes every word occurrence).
+ * mode 0: every batch goes straight through the encode kernel; 1: distinct words are encoded once whenever that is possible
+ * (dropout_prob == 0); 2 (default): the same for batches of at least min_bytes.  The ids are identical either way.
+ * yttm_encode_cache_words: distinct words of the last yttm_encode_device batch, 0 if it did not go through the cache. */
+int yttm_encoder_set_cache(yttm_encoder *enc, int mode, uint64_t min_bytes);
+uint64_t yttm_encode_cache_words(yttm_encoder *enc);
+
 /* Status id_to_subword(int id, string* subword, bool replace_space) bpe.h:48, bpe.cpp:1774; yttm.pyx:129-134 */
 int yttm_id_to_subword(yttm_encoder *enc, int id, char **subword, char *err, int errlen);
 /* int subword_to_id(const string& token) const                       bpe.h:50, bpe.cpp:1809; yttm.pyx:126-127 */

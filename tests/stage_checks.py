@@ -308,6 +308,60 @@ def check_encode_vs_oracle(model_path, sentences, flags=((0, 0, 0), (1, 1, 0), (
         assert bpe.encode(sentences, yttm.OutputType.ID, bos=b, eos=e, reverse=r) == want
 
 
+def check_encode_word_cache(n_sent=120, seed=17, model="readme_small"):
+    """N4: the batch encoder's word cache gives the ids of the direct path (= the oracle's) on the shapes that steer it: words of 1..7
+    bytes (their own key) and of 8, 9, 16, 17 ... bytes (hash + byte compare), repeated and distinct ones, words with invalid bytes and
+    unknown chars inside, multi-byte spaces, words too long to cache, empty sentences, sentences that follow each other without a
+    separator, more distinct words than the first table holds."""
+    import random
+    import numpy as np
+    import youtokentome_amd as yttm
+    rng = random.Random(seed)
+    model_path = os.path.join(G, f"train_{model}.model")
+    core = yttm.BPE(model_path).bpe_cython
+    m = O.Model(model_path)
+    vocab = [("".join(rng.choice("abcd") for _ in range(k))).encode() for k in (1, 2, 3, 6, 7, 8, 9, 15, 16, 17, 31, 40) for _ in range(3)]
+    vocab += [b"ab\xffcd", b"\xffab", b"ab\xfe", b"a\xe2\x82", "aёb".encode(), "ыыыы".encode(), b"aaaaaaa", b"aaaaaaaa", b"aaaaaaaaa"]
+    seps = [b" ", b"  ", b"\t", "\u2581".encode(), b" \xff "]
+    sents = [b"", b" ", b"a", b"a b", b"ab", b"c", b"\xff", b"abcd" * 20000, b"x " + b"abcd" * 17000 + b" y"]
+    for i in range(n_sent):
+        words = [rng.choice(vocab) if rng.random() < 0.7 else ("".join(rng.choice("abcd") for _ in range(rng.randint(1, 24)))).encode()
+                 for _ in range(rng.randint(0, 30))]
+        s = b""
+        for w in words:
+            s += w + rng.choice(seps)
+        sents.append(s if rng.random() < 0.5 else s.rstrip())
+    # many distinct words: more than the smallest table (1024 slots) holds -> the insert pass is redone with a larger one
+    sents.append(b" ".join(("".join(rng.choice("abcd") for _ in range(10))).encode() for _ in range(3000)))
+    blob = b"".join(sents)
+    offs = np.zeros(len(sents) + 1, np.uint64)
+    np.cumsum([len(x) for x in sents], out=offs[1:])
+    for b, e, r in ((0, 0, 0), (1, 1, 0), (1, 0, 1), (1, 1, 1)):
+        want_ids, want_off = m.encode_blob(blob, offs, b, e, r)
+        core.set_cache(0)
+        ids0, off0 = core.encode_packed(blob, offs, b, e, r)
+        assert core.cache_words() == 0
+        core.set_cache(1)
+        ids1, off1 = core.encode_packed(blob, offs, b, e, r)
+        assert core.cache_words() > 1000
+        assert off0.tolist() == want_off.tolist() and ids0.tolist() == want_ids.tolist()
+        assert off1.tolist() == want_off.tolist()
+        assert ids1.tolist() == want_ids.tolist()
+    # as many distinct words as the table has slots (one per four bytes of text): the insert pass is redone with twice the slots
+    import itertools
+    letters = "abcdefghijklmnopqrstuvwxyzABCDEF"
+    blob2 = " ".join("".join(t) for t in itertools.product(letters, repeat=3)).encode()
+    offs2 = np.array([0, len(blob2)], np.uint64)
+    want_ids, want_off = m.encode_blob(blob2, offs2, 0, 0, 0)
+    core.set_cache(1)
+    ids2, off2 = core.encode_packed(blob2, offs2, 0, 0, 0)
+    assert core.cache_words() == 32 ** 3
+    assert ids2.tolist() == want_ids.tolist() and off2.tolist() == want_off.tolist()
+    # dropout never goes through the cache
+    core.encode_packed(blob, offs, 0, 0, 0, 0.5)
+    assert core.cache_words() == 0
+
+
 def check_encode_mixed_shapes(n_sent=150, seed=11, model="readme_small"):
     """Shapes that steer the encode kernels: many short sentences per wavefront group, sentences that only partly fit a
     wavefront's LDS region, sentences beyond it (cooperative kernel on HBM scratch), words of every length class

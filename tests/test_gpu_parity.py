@@ -36,6 +36,10 @@ def test_k2_k3_word_table_and_pair_count():
         S.check_word_table_and_pairs(t)
 
 
+def test_k5_word_cache():
+    S.check_encode_word_cache(n_sent=2000)
+
+
 def test_k4_merge_apply_rounds():
     for i, t in enumerate(S.texts_small(2, n=6, size=8000)):
         if t.strip():

@@ -132,6 +132,10 @@ def test_encode_mixed_shapes():
     S.check_encode_mixed_shapes(n_sent=150)
 
 
+def test_encode_word_cache():
+    S.check_encode_word_cache()
+
+
 def test_hot_list_rebuilds(tmp_path, monkeypatch):
     """The candidate filter reads a hot list of pairs instead of the whole pair table; shrink the list so that tiny corpora
     go through its rebuild, overflow and whole-table fallback paths, and demand the same models."""

@@ -21,6 +21,7 @@ EXPORTS = [
     "yttm_train_bpe", "yttm_train_bpe_ex", "yttm_train_bpe_from_memory", "yttm_train_bpe_from_device", "yttm_encoder_create",
     "yttm_encoder_destroy", "yttm_encode_as_ids", "yttm_encode_as_subwords", "yttm_encode_device", "yttm_encode_fetch",
     "yttm_id_to_subword", "yttm_subword_to_id", "yttm_decode", "yttm_vocab_size", "yttm_vocabulary", "yttm_free", "yttm_ids_fnv1a64", "yttm_encode_cli", "yttm_decode_cli", "yttm_vocab_cli",
+    "yttm_encoder_set_cache", "yttm_encode_cache_words",
     "yttm_device_info", "yttm_comm_rccl_unique_id", "yttm_comm_rccl_create", "yttm_comm_callback_create",
     "yttm_comm_destroy", "yttm_train_bpe_from_device_comm", "yttm_train_bpe_from_memory_comm",
     # include/yttm_gpu.h
@@ -57,6 +58,9 @@ def load():
     L.yttm_encode_device.argtypes = [cvp, cvp, cvp, C.c_uint64, C.c_uint64, C.c_uint64, ci, ci, ci, cd, u64p,
                                      C.POINTER(cd), cs, ci]
     L.yttm_encode_fetch.argtypes = [cvp, i32p, u64p, C.c_uint64, cs, ci]
+    L.yttm_encoder_set_cache.argtypes = [cvp, ci, C.c_uint64]
+    L.yttm_encode_cache_words.argtypes = [cvp]
+    L.yttm_encode_cache_words.restype = C.c_uint64
     L.yttm_id_to_subword.argtypes = [cvp, ci, C.POINTER(cvp), cs, ci]
     L.yttm_subword_to_id.argtypes = [cvp, cs]
     L.yttm_decode.argtypes = [cvp, i32p, u64p, C.c_uint64, i32p, C.c_uint64, C.POINTER(cvp), C.POINTER(u64p), cs, ci]

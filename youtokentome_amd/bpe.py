@@ -69,6 +69,13 @@ class _Core:
         if rc != 0:
             raise ValueError(err.value.decode())  # yttm.pyx:84-85
 
+    # ---- word cache of the batch encoder (include/yttm_mi355x.h): 0 off, 1 whenever possible, 2 (default) from min_bytes up
+    def set_cache(self, mode, min_bytes=4 << 20):
+        _lib.load().yttm_encoder_set_cache(self._h, int(mode), int(min_bytes))
+
+    def cache_words(self):
+        return int(_lib.load().yttm_encode_cache_words(self._h))
+
     # ---- packed fast path: bytes + offsets -> numpy ids + offsets
     def encode_packed(self, blob: bytes, offsets, bos=False, eos=False, reverse=False, dropout_prob=0.0):
         L = _lib.load()

@@ -170,6 +170,12 @@ int yttm_encode_fetch(yttm_encoder *h, int32_t *ids, uint64_t *out_offsets, uint
   return finish(h->enc->fetch_device_result(ids, (unsigned long long *)out_offsets, n_sent), err, errlen);
 }
 
+int yttm_encoder_set_cache(yttm_encoder *h, int mode, uint64_t min_bytes) {
+  h->enc->set_cache(mode, min_bytes);
+  return 0;
+}
+uint64_t yttm_encode_cache_words(yttm_encoder *h) { return h->enc->cache_words(); }
+
 int yttm_id_to_subword(yttm_encoder *h, int id, char **subword, char *err, int errlen) {
   std::string s;
   Status st = h->enc->id_to_subword(id, &s);

@@ -106,6 +106,8 @@ class BaseEncoder {  // bpe.h:22-82
                        unsigned long long max_sentence_bytes, bool bos, bool eos, bool reverse, double dropout_prob,
                        unsigned long long *n_ids_out, double *kernel_ms) const;
   Status fetch_device_result(int32_t *ids, unsigned long long *out_off, unsigned long long n_sent) const;
+  void set_cache(int mode, unsigned long long min_bytes) const;  // word cache of the batch encoder: 0 off, 1 always, 2 from min_bytes up
+  unsigned long long cache_words() const;                          // distinct words of the last encode_device batch (0: not cached)
 
   Status id_to_subword(int id, std::string *subword, bool replace_space = false) const;  // bpe.cpp:1774-1807
   int subword_to_id(const std::string &token) const;                                      // bpe.cpp:1809-1826

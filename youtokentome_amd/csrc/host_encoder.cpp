@@ -39,7 +39,22 @@ struct EncodeLane {
   unsigned long long *d_total = nullptr;
   int32_t *d_ids = nullptr; size_t cap_ids = 0;
   uint32_t *d_work = nullptr; size_t cap_work = 0;
+  // word cache (k_wcache.hip): the batch's table of distinct words, the slot of every occurrence, the list K5 encodes, its ids
+  unsigned long long *d_wc_slot = nullptr; size_t cap_wc_slot = 0;
+  unsigned long long *d_wc_pos = nullptr; size_t cap_wc_pos = 0;
+  uint32_t *d_wc_occ = nullptr; size_t cap_wc_occ = 0;
+  unsigned long long *d_wc_extra = nullptr; size_t cap_wc_extra = 0;
+  unsigned int *d_wc_misc = nullptr;  // [0] number of uncached words, [1] status
+  uint32_t *d_wc_blk = nullptr; size_t cap_wc_blk = 0;
+  unsigned long long *d_wc_blk_off = nullptr; size_t cap_wc_blk_off = 0;
+  unsigned long long *d_ustart = nullptr; size_t cap_ustart = 0;
+  unsigned long long *d_uend = nullptr; size_t cap_uend = 0;
+  uint32_t *d_uslot = nullptr; size_t cap_uslot = 0;
+  uint32_t *d_ucounts = nullptr; size_t cap_ucounts = 0;
+  unsigned long long *d_uoff = nullptr; size_t cap_uoff = 0;
+  int32_t *d_uids = nullptr; size_t cap_uids = 0;
   unsigned long long last_n_ids = 0, last_n_sent = 0;
+  unsigned long long last_distinct_words = 0;  // of the last cached batch (0: the batch went straight through K5)
 
   template <class T>
   void grow(T *&p, size_t &cap, size_t need) {
@@ -52,7 +67,9 @@ struct EncodeLane {
   }
   ~EncodeLane() {
     for (void *p : {(void *)d_drop, (void *)d_bytes, (void *)d_off, (void *)d_scratch, (void *)d_counts, (void *)d_out_off, (void *)d_scan_tmp,
-                    (void *)d_total, (void *)d_ids, (void *)d_work})
+                    (void *)d_total, (void *)d_ids, (void *)d_work, (void *)d_wc_slot, (void *)d_wc_pos, (void *)d_wc_occ, (void *)d_wc_extra,
+                    (void *)d_wc_misc, (void *)d_wc_blk, (void *)d_wc_blk_off, (void *)d_ustart, (void *)d_uend, (void *)d_uslot, (void *)d_ucounts,
+                    (void *)d_uoff, (void *)d_uids})
       if (p) (void)hipFree(p);
     if (st) (void)hipStreamDestroy(st);
   }
@@ -69,6 +86,10 @@ struct EncoderDevice {
   // std::random_device-independent global mt19937, bpe.cpp:1415; YTTM_DROPOUT_SEED pins the salt for reproducible runs)
   std::atomic<unsigned long long> dropout_calls{0};
   unsigned long long seed_salt = 0;
+  // word cache: 0 = never, 1 = whenever it applies (no dropout), 2 = for batches of at least cache_min_bytes (YTTM_ENCODE_CACHE = 0 | 1;
+  // YTTM_ENCODE_CACHE_MIN_MB moves the threshold)
+  int cache_mode = 2;
+  unsigned long long cache_min_bytes = 4ull << 20;
   static constexpr int N_LANES = 2;
   EncodeLane lane[N_LANES];
   std::atomic<unsigned int> next_lane{0};
@@ -98,7 +119,10 @@ BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *
     for (EncodeLane &l : dev_->lane) {
       HIP_CHECK(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
       l.d_total = dalloc<unsigned long long>(2);
+      l.d_wc_misc = dalloc<unsigned int>(2);
     }
+    if (const char *cv = getenv("YTTM_ENCODE_CACHE")) dev_->cache_mode = atoi(cv) ? 1 : 0;
+    if (const char *cv = getenv("YTTM_ENCODE_CACHE_MIN_MB")) dev_->cache_min_bytes = strtoull(cv, nullptr, 10) << 20;
     if (const char *sv = getenv("YTTM_DROPOUT_SEED")) {
       dev_->seed_salt = strtoull(sv, nullptr, 10);
     } else {
@@ -213,6 +237,114 @@ int BaseEncoder::vocab_size() const {
   return (int)(bpe_state.rules.size() + bpe_state.char2id.size() + bpe_state.special_tokens.n_special_tokens());
 }
 
+// One K5 launch over n_items items of the text (sentences back to back, or the word cache's distinct words [offsets[j], ends[j])):
+// ids into the lane's scratch, counts into `counts`.
+static void k5_pass(EncoderDevice &D, EncodeLane &d, const void *d_bytes, const unsigned long long *d_offsets, const unsigned long long *d_ends,
+                    unsigned long long n_items, unsigned long long total_bytes, unsigned long long max_item_bytes, bool bos, bool eos, bool reverse,
+                    double dropout_prob, uint32_t *counts) {
+  d.grow(d.d_scratch, d.cap_scratch, (size_t)(2 * total_bytes + 2 * n_items + 2));
+  unsigned int max_blocks = 256 * 2;  // 2 workgroups per CU (80 KB LDS each)
+  const unsigned long long tok_cap = std::max<unsigned long long>(ENC_LDS_TOKENS, 2 * max_item_bytes + 2);  // tokens per item
+  unsigned long long stride = 0, drop_stride = 0;
+  {
+    // per-wave HBM scratch: 3 working arrays for items that do not fit LDS, + (dropout) word starts and event queues
+    unsigned long long per_wave = 0;
+    if (tok_cap > (unsigned long long)ENC_LDS_TOKENS) per_wave += 3 * tok_cap * 4;
+    if (dropout_prob > 0) per_wave += 7 * tok_cap * 4;
+    if (per_wave) {
+      unsigned long long waves = std::max<unsigned long long>(1, (4ull << 30) / per_wave);
+      max_blocks = (unsigned int)std::max<unsigned long long>(1, std::min<unsigned long long>(max_blocks, waves / ENC_WAVES_PER_BLOCK));
+    }
+  }
+  unsigned long long nb = (n_items + ENC_WAVES_PER_BLOCK - 1) / ENC_WAVES_PER_BLOCK;
+  const unsigned int n_blocks = (unsigned int)std::min<unsigned long long>(nb, max_blocks);
+  if (tok_cap > (unsigned long long)ENC_LDS_TOKENS) {
+    stride = tok_cap;
+    d.grow(d.d_work, d.cap_work, (size_t)(3 * stride * (unsigned long long)n_blocks * ENC_WAVES_PER_BLOCK));
+  }
+  if (dropout_prob > 0) {
+    drop_stride = tok_cap;
+    d.grow(d.d_drop, d.cap_drop, (size_t)(7 * drop_stride * (unsigned long long)n_blocks * ENC_WAVES_PER_BLOCK));
+  }
+  const unsigned long long seed = mix64(D.seed_salt + 0x5bd1e995ull * (D.dropout_calls.fetch_add(1) + 1));
+  launch_encode(D.m, (const uint8_t *)d_bytes, d_offsets, d_ends, n_items, bos, eos, reverse, d.d_scratch, counts, d.d_work, stride, n_blocks,
+                dropout_prob, seed, d.d_drop, drop_stride, d.st);
+}
+
+// counts -> offsets (exclusive scan, the total behind the last one and on the host)
+static unsigned long long scan_counts(EncodeLane &d, const uint32_t *counts, unsigned long long n, unsigned long long *off) {
+  d.grow(d.d_scan_tmp, d.cap_scan_tmp, (size_t)scan_scratch_blocks(n));
+  launch_exclusive_scan(counts, n, off, d.d_scan_tmp, d.d_total, d.st);
+  unsigned long long total = 0;
+  HIP_CHECK(hipMemcpyAsync(&total, d.d_total, 8, hipMemcpyDeviceToHost, d.st));
+  HIP_CHECK(hipStreamSynchronize(d.st));
+  HIP_CHECK(hipMemcpyAsync(off + n, &total, 8, hipMemcpyHostToDevice, d.st));
+  return total;
+}
+
+// N4, the word cache (k_wcache.hip): distinct words of the batch -> K5 -> the sentences' ids by lookup.  Leaves ids + offsets in the
+// lane's buffers like the direct path.
+static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, const unsigned long long *d_offsets, unsigned long long n_sent,
+                          unsigned long long total_bytes, unsigned long long max_sentence_bytes, bool bos, bool eos, bool reverse,
+                          unsigned long long *n_ids_out) {
+  const uint8_t *text = (const uint8_t *)d_bytes;
+  unsigned long long cap = 1024;
+  while (cap < total_bytes / 4 && cap < (1ull << 31)) cap <<= 1;
+  WordCache wc{};
+  unsigned long long n_table = 0;
+  unsigned int misc[2] = {0, 0};
+  for (;;) {
+    d.grow(d.d_wc_slot, d.cap_wc_slot, (size_t)cap);
+    d.grow(d.d_wc_pos, d.cap_wc_pos, (size_t)cap);
+    d.grow(d.d_wc_occ, d.cap_wc_occ, (size_t)((total_bytes + n_sent) / 2 + 2));
+    const unsigned long long extra_cap = total_bytes / 65536 + 2;
+    d.grow(d.d_wc_extra, d.cap_wc_extra, (size_t)(2 * extra_cap));
+    wc.slot = d.d_wc_slot;
+    wc.pos = d.d_wc_pos;
+    wc.mask = cap - 1;
+    wc.occ = d.d_wc_occ;
+    wc.extra = d.d_wc_extra;
+    wc.extra_n = d.d_wc_misc;
+    wc.extra_cap = (unsigned int)extra_cap;
+    wc.status = d.d_wc_misc + 1;
+    launch_fill_u64(wc.slot, PT_EMPTY, cap, d.st);
+    HIP_CHECK(hipMemsetAsync(d.d_wc_misc, 0, 8, d.st));
+    launch_wcache_insert(D.m, text, total_bytes, d_offsets, n_sent, wc, d.st);
+    const unsigned long long n_blk = wcache_count_blocks(wc);
+    d.grow(d.d_wc_blk, d.cap_wc_blk, (size_t)n_blk);
+    d.grow(d.d_wc_blk_off, d.cap_wc_blk_off, (size_t)n_blk + 1);
+    launch_wcache_count_slots(wc, d.d_wc_blk, d.st);
+    HIP_CHECK(hipMemcpyAsync(misc, d.d_wc_misc, 8, hipMemcpyDeviceToHost, d.st));
+    n_table = scan_counts(d, d.d_wc_blk, n_blk, d.d_wc_blk_off);  // (syncs)
+    if (!(misc[1] & 1u)) break;
+    if (cap >= (1ull << 31)) throw GpuError{"encode: the word table does not fit"};
+    cap <<= 1;  // too full for the probe limit: start over with twice the slots
+  }
+  const unsigned long long n_extra = misc[0], n_words = n_table + n_extra;
+  d.last_distinct_words = n_words;
+  d.grow(d.d_ustart, d.cap_ustart, (size_t)n_words + 1);
+  d.grow(d.d_uend, d.cap_uend, (size_t)n_words + 1);
+  d.grow(d.d_uslot, d.cap_uslot, (size_t)n_table + 1);
+  d.grow(d.d_ucounts, d.cap_ucounts, (size_t)n_words + 1);
+  d.grow(d.d_uoff, d.cap_uoff, (size_t)n_words + 2);
+  launch_wcache_list(wc, d.d_wc_blk_off, n_table, d.d_ustart, d.d_uend, d.d_uslot, d.st);
+  unsigned long long n_uids = 0;
+  if (n_words) {
+    k5_pass(D, d, d_bytes, d.d_ustart, d.d_uend, n_words, total_bytes, max_sentence_bytes, false, false, false, 0.0, d.d_ucounts);
+    n_uids = scan_counts(d, d.d_ucounts, n_words, d.d_uoff);
+    d.grow(d.d_uids, d.cap_uids, (size_t)n_uids + 1);
+    launch_encode_gather(d.d_scratch, d.d_ustart, d.d_uend, d.d_uoff, n_words, d.d_uids, d.st);
+    launch_wcache_publish(wc, n_table, n_words, d.d_uslot, d.d_uoff, d.st);
+  }
+  launch_wcache_count(D.m, text, d_offsets, n_sent, wc, (bos ? 1 : 0) + (eos ? 1 : 0), d.d_counts, d.st);
+  const unsigned long long total = scan_counts(d, d.d_counts, n_sent, d.d_out_off);
+  d.grow(d.d_ids, d.cap_ids, (size_t)total + 1);
+  launch_wcache_scatter(D.m, text, d_offsets, n_sent, wc, d.d_uids, bos, eos, reverse, d.d_out_off, d.d_ids, d.st);
+  HIP_CHECK(hipStreamSynchronize(d.st));
+  d.last_n_ids = total;
+  if (n_ids_out) *n_ids_out = total;
+}
+
 // K5 on one lane (locked by the caller): input already in HBM, ids + offsets left in the lane's buffers
 static Status encode_on_lane(const BaseEncoder &enc, EncoderDevice &D, EncodeLane &d, int device, const void *d_bytes, const void *d_offsets,
                              unsigned long long n_sent, unsigned long long total_bytes, unsigned long long max_sentence_bytes, bool bos, bool eos,
@@ -226,50 +358,37 @@ static Status encode_on_lane(const BaseEncoder &enc, EncoderDevice &D, EncodeLan
     d.last_n_ids = 0;
     if (n_ids_out) *n_ids_out = 0;
     if (n_sent == 0) return Status();
-    d.grow(d.d_scratch, d.cap_scratch, (size_t)(2 * total_bytes + 2 * n_sent));
     d.grow(d.d_counts, d.cap_counts, (size_t)n_sent);
     d.grow(d.d_out_off, d.cap_out_off, (size_t)n_sent + 1);
-    d.grow(d.d_scan_tmp, d.cap_scan_tmp, (size_t)scan_scratch_blocks(n_sent));
-    unsigned int max_blocks = 256 * 2;  // 2 workgroups per CU (80 KB LDS each)
-    const unsigned long long tok_cap = std::max<unsigned long long>(ENC_LDS_TOKENS, 2 * max_sentence_bytes + 2);  // tokens per sentence
-    unsigned long long stride = 0, drop_stride = 0;
-    {
-      // per-wave HBM scratch: 3 working arrays for sentences that do not fit LDS, + (dropout) word starts and event queues
-      unsigned long long per_wave = 0;
-      if (tok_cap > (unsigned long long)ENC_LDS_TOKENS) per_wave += 3 * tok_cap * 4;
-      if (dropout_prob > 0) per_wave += 7 * tok_cap * 4;
-      if (per_wave) {
-        unsigned long long waves = std::max<unsigned long long>(1, (4ull << 30) / per_wave);
-        max_blocks = (unsigned int)std::max<unsigned long long>(1, std::min<unsigned long long>(max_blocks, waves / ENC_WAVES_PER_BLOCK));
-      }
-    }
-    unsigned long long nb = (n_sent + ENC_WAVES_PER_BLOCK - 1) / ENC_WAVES_PER_BLOCK;
-    const unsigned int n_blocks = (unsigned int)std::min<unsigned long long>(nb, max_blocks);
-    if (tok_cap > (unsigned long long)ENC_LDS_TOKENS) {
-      stride = tok_cap;
-      d.grow(d.d_work, d.cap_work, (size_t)(3 * stride * (unsigned long long)n_blocks * ENC_WAVES_PER_BLOCK));
-    }
-    if (dropout_prob > 0) {
-      drop_stride = tok_cap;
-      d.grow(d.d_drop, d.cap_drop, (size_t)(7 * drop_stride * (unsigned long long)n_blocks * ENC_WAVES_PER_BLOCK));
-    }
-    const unsigned long long seed = mix64(D.seed_salt + 0x5bd1e995ull * (D.dropout_calls.fetch_add(1) + 1));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (kernel_ms) {
       HIP_CHECK(hipEventCreate(&e0));
       HIP_CHECK(hipEventCreate(&e1));
       HIP_CHECK(hipEventRecord(e0, d.st));
     }
-    launch_encode(D.m, (const uint8_t *)d_bytes, (const unsigned long long *)d_offsets, n_sent, bos, eos, reverse, d.d_scratch, d.d_counts,
-                  d.d_work, stride, n_blocks, dropout_prob, seed, d.d_drop, drop_stride, d.st);
+    // the word cache: no dropout (its draws are per occurrence), a batch worth the extra passes, a buffer the 8-byte loads can walk
+    const bool cached = dropout_prob <= 0 && D.cache_mode != 0 && (D.cache_mode == 1 || total_bytes >= D.cache_min_bytes) &&
+                        ((uintptr_t)d_bytes & 7u) == 0 && total_bytes < (1ull << 40) && total_bytes > 0;
+    d.last_distinct_words = 0;
+    if (cached) {
+      encode_cached(D, d, d_bytes, (const unsigned long long *)d_offsets, n_sent, total_bytes, max_sentence_bytes, bos, eos, reverse, n_ids_out);
+      if (kernel_ms) {
+        HIP_CHECK(hipEventRecord(e1, d.st));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *kernel_ms = ms;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+      }
+      return Status();
+    }
+    k5_pass(D, d, d_bytes, (const unsigned long long *)d_offsets, nullptr, n_sent, total_bytes, max_sentence_bytes, bos, eos, reverse, dropout_prob,
+            d.d_counts);
     if (kernel_ms) HIP_CHECK(hipEventRecord(e1, d.st));
-    launch_exclusive_scan(d.d_counts, n_sent, d.d_out_off, d.d_scan_tmp, d.d_total, d.st);
-    unsigned long long total = 0;
-    HIP_CHECK(hipMemcpyAsync(&total, d.d_total, 8, hipMemcpyDeviceToHost, d.st));
-    HIP_CHECK(hipStreamSynchronize(d.st));
-    HIP_CHECK(hipMemcpyAsync(d.d_out_off + n_sent, &total, 8, hipMemcpyHostToDevice, d.st));
+    const unsigned long long total = scan_counts(d, d.d_counts, n_sent, d.d_out_off);
     d.grow(d.d_ids, d.cap_ids, (size_t)total);
-    launch_encode_gather(d.d_scratch, (const unsigned long long *)d_offsets, d.d_out_off, n_sent, d.d_ids, d.st);
+    launch_encode_gather(d.d_scratch, (const unsigned long long *)d_offsets, nullptr, d.d_out_off, n_sent, d.d_ids, d.st);
     HIP_CHECK(hipStreamSynchronize(d.st));
     if (kernel_ms) {
       float ms = 0;
@@ -308,6 +427,17 @@ Status BaseEncoder::encode_device(const void *d_bytes, const void *d_offsets, un
   std::lock_guard<std::mutex> lk(dev_->lane[0].mu);
   return encode_on_lane(*this, *dev_, dev_->lane[0], device_, d_bytes, d_offsets, n_sent, total_bytes, max_sentence_bytes, bos, eos, reverse,
                         dropout_prob, n_ids_out, kernel_ms);
+}
+
+void BaseEncoder::set_cache(int mode, unsigned long long min_bytes) const {
+  if (!dev_) return;
+  dev_->cache_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  dev_->cache_min_bytes = min_bytes;
+}
+unsigned long long BaseEncoder::cache_words() const {
+  if (!dev_) return 0;
+  std::lock_guard<std::mutex> lk(dev_->lane[0].mu);
+  return dev_->lane[0].last_distinct_words;
 }
 
 Status BaseEncoder::fetch_device_result(int32_t *ids, unsigned long long *out_off, unsigned long long n_sent) const {

@@ -400,12 +400,21 @@ __device__ void encode_wave(const EncModel &m, const uint32_t *bloom, const uint
   if (lane == 0) *count_out = (uint32_t)n_ids;
 }
 
+// What K5 encodes: sentence j = bytes [off[j], off[j + 1]) of the text, its ids go to scratch + 2 off[j] + 2 j (room for 2 B + 2 ids:
+// B + 1 tokens, bos, eos).  Or, for the word cache (k_wcache.hip), word j = bytes [off[j], end[j]) in any order, ids at scratch + 2 off[j].
+struct SentView {
+  const unsigned long long *off, *end;  // end == nullptr: sentences back to back
+  __device__ unsigned long long lo(unsigned long long j) const { return off[j]; }
+  __device__ unsigned long long hi(unsigned long long j) const { return end ? end[j] : off[j + 1]; }
+  __device__ unsigned long long spos(unsigned long long j) const { return end ? 2 * off[j] : 2 * off[j] + 2 * j; }
+};
+
 // Several consecutive sentences share one wavefront's arrays (dropout off, LDS path): a 128-byte sentence is 129 tokens --
 // two full chunks and a third with one lane busy -- and the fixed cost of a round is per chunk.  Sentences [s, e) are
 // tokenized back to back while they fit, merged together (words are independent), and written out one by one; returns how
 // many sentences were consumed (>= 1: the caller made sure the first one fits).
 __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8_t *__restrict__ text,
-                           const unsigned long long *__restrict__ offsets, unsigned long long s, unsigned long long e, LdsArr wt, LdsArr wr,
+                           const SentView &sv, unsigned long long s, unsigned long long e, LdsArr wt, LdsArr wr,
                            LdsArr wm, int bos, int eos, int reverse, int32_t *__restrict__ scratch_ids, uint32_t *__restrict__ counts,
                            const DropoutArgs &drop) {
   const int lane = lane_id();
@@ -413,14 +422,14 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
   int n = 0, consumed = 0, k = 0;
   unsigned long long my_sid = 0;  // lane j: index of the j-th non-empty sentence of the pack
   for (unsigned long long j = s; j < e && k < 64; j++) {
-    const unsigned long long b0 = offsets[j], nbytes = offsets[j + 1] - b0;
+    const unsigned long long b0 = sv.lo(j), nbytes = sv.hi(j) - b0;
     if (nbytes + 1 > (unsigned long long)(ENC_WCAP - n)) break;
     const int n0 = n;
     n = enc_tokenize<LdsArr>(m, text + b0, nbytes, wt, n0);
     wave_sync();
     if (n == n0) {  // no token at all: only bos / eos
       const int n_ids = (bos ? 1 : 0) + (eos ? 1 : 0);
-      int32_t *out = scratch_ids + 2 * b0 + 2 * j;
+      int32_t *out = scratch_ids + sv.spos(j);
       if (lane == 0) {
         if (bos) out[reverse ? n_ids - 1 : 0] = m.bos_id;
         if (eos) out[reverse ? 0 : n_ids - 1] = m.eos_id;
@@ -480,7 +489,7 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
     const unsigned long long sid = __shfl(my_sid, ord < 0 ? 0 : ord);
     if (p < n) {
       const int n_ids = (int)wm.get(ord) + nb + (eos ? 1 : 0);
-      int32_t *out = scratch_ids + 2 * offsets[sid] + 2 * sid;
+      int32_t *out = scratch_ids + sv.spos(sid);
       if (emit) {
         const int q = nb + emitted + __popcll(E & lt) - (int)wr.get(ord);
         const uint32_t id = t0 & ENC_IDM;
@@ -500,7 +509,7 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
 }
 
 __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8_t *__restrict__ text,
-                                                   const unsigned long long *__restrict__ offsets, unsigned long long n_sent, int bos,
+                                                   SentView sv, unsigned long long n_sent, int bos,
                                                    int eos, int reverse, int32_t *__restrict__ scratch_ids,
                                                    uint32_t *__restrict__ counts, uint32_t *__restrict__ work,
                                                    unsigned long long work_stride, DropoutArgs drop, unsigned long long drop_stride, unsigned int group) {
@@ -517,7 +526,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
     unsigned long long sidx = grp * group;
     const unsigned long long grp_end = sidx + group < n_sent ? sidx + group : n_sent;
     while (sidx < grp_end) {
-      const unsigned long long b0 = offsets[sidx], b1 = offsets[sidx + 1];
+      const unsigned long long b0 = sv.lo(sidx), b1 = sv.hi(sidx);
       const unsigned long long nbytes = b1 - b0;
       LdsArr a{lds[wave][0]}, b{lds[wave][1]}, c{lds[wave][2]};
       DropoutArgs d = drop;
@@ -526,11 +535,11 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
         d.ev = reinterpret_cast<unsigned long long *>(drop.wsl + gw * 7 * drop_stride + drop_stride);
       }
       if (nbytes + 1 <= (unsigned long long)ENC_WCAP) {
-        sidx += (unsigned long long)encode_pack(m, bloom, text, offsets, sidx, grp_end, a, b, c, bos, eos, reverse, scratch_ids, counts, d);
+        sidx += (unsigned long long)encode_pack(m, bloom, text, sv, sidx, grp_end, a, b, c, bos, eos, reverse, scratch_ids, counts, d);
         continue;
       }
       // too long for the LDS arrays: one sentence at a time on the wavefront's HBM scratch
-      int32_t *out = scratch_ids + 2 * b0 + 2 * sidx;  // capacity 2*nbytes + 2 ids per sentence
+      int32_t *out = scratch_ids + sv.spos(sidx);  // capacity 2*nbytes + 2 ids per sentence
       uint32_t *w = work + gw * 3 * work_stride;
       GlbArr ga{w}, gb{w + work_stride}, gc{w + 2 * work_stride};
       encode_wave(m, bloom, text + b0, nbytes, ga, gb, gc, bos, eos, reverse, out, &counts[sidx], d, sidx);
@@ -541,19 +550,20 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
 }
 
 // copy ids from the over-allocated scratch to the packed output (one wave per sentence)
-__global__ __launch_bounds__(BLOCK) void k5_gather(const int32_t *__restrict__ scratch_ids, const unsigned long long *__restrict__ offsets,
+__global__ __launch_bounds__(BLOCK) void k5_gather(const int32_t *__restrict__ scratch_ids, SentView sv,
                                                    const unsigned long long *__restrict__ out_off, unsigned long long n_sent,
                                                    int32_t *__restrict__ ids_out) {
   const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
   const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
   for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
-    const int32_t *src = scratch_ids + 2 * offsets[sidx] + 2 * sidx;
+    const int32_t *src = scratch_ids + sv.spos(sidx);
     const unsigned long long o0 = out_off[sidx], o1 = out_off[sidx + 1];
     for (unsigned long long k = lane_id(); k < o1 - o0; k += 64) ids_out[o0 + k] = src[k];
   }
 }
 
-void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long long *offsets, unsigned long long n_sent, int bos,
+void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long long *offsets, const unsigned long long *ends,
+                   unsigned long long n_sent, int bos,
                    int eos, int reverse, int32_t *scratch_ids, uint32_t *counts, uint32_t *work, unsigned long long work_stride,
                    unsigned int n_blocks, double dropout_prob, unsigned long long seed, uint32_t *drop_scratch,
                    unsigned long long drop_stride, hipStream_t st) {
@@ -569,15 +579,15 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   unsigned long long group = n_sent / ((unsigned long long)n_blocks * ENC_WAVES * 4);
   if (group < 1) group = 1;
   if (group > 24) group = 24;
-  hipLaunchKernelGGL(k5_encode, dim3(n_blocks), dim3(ENC_THREADS), 0, st, m, text, offsets, n_sent, bos, eos, reverse, scratch_ids, counts, work,
+  hipLaunchKernelGGL(k5_encode, dim3(n_blocks), dim3(ENC_THREADS), 0, st, m, text, SentView{offsets, ends}, n_sent, bos, eos, reverse, scratch_ids, counts, work,
                      work_stride, d, drop_stride, (unsigned int)group);
 }
-void launch_encode_gather(const int32_t *scratch_ids, const unsigned long long *offsets, const unsigned long long *out_off,
-                          unsigned long long n_sent, int32_t *ids_out, hipStream_t st) {
+void launch_encode_gather(const int32_t *scratch_ids, const unsigned long long *offsets, const unsigned long long *ends,
+                          const unsigned long long *out_off, unsigned long long n_sent, int32_t *ids_out, hipStream_t st) {
   if (!n_sent) return;
   unsigned long long b = (n_sent + NWAVES - 1) / NWAVES;
   if (b > 256 * 16) b = 256 * 16;
-  hipLaunchKernelGGL(k5_gather, dim3((unsigned int)b), dim3(BLOCK), 0, st, scratch_ids, offsets, out_off, n_sent, ids_out);
+  hipLaunchKernelGGL(k5_gather, dim3((unsigned int)b), dim3(BLOCK), 0, st, scratch_ids, SentView{offsets, ends}, out_off, n_sent, ids_out);
 }
 
 }  // namespace yttm

@@ -1,0 +1,302 @@
+// k_wcache.hip -- N4: word-level cache for the batch encoder (the reference has no counterpart).
+//
+// The reference encodes every word of every sentence from scratch (bpe.cpp:1497-1632: a word's merges depend on nothing but
+// the word).  In text most word occurrences repeat a few thousand distinct words, so a batch is encoded in three steps:
+//   1. k5w_insert   every word occurrence of the batch -> its slot in a batch-local hash table of distinct words (words of up to
+//                   7 bytes ARE their key; longer ones are keyed by hash tag + length + position of the first occurrence and
+//                   compared as bytes), the slot remembered per occurrence;
+//   2. the distinct words, compacted out of the table, go through K5 (k_encode.hip) as if each were a sentence -- the same
+//                   tokenizer, the same merge rounds, so the ids are K5's ids by construction;
+//   3. k5w_count / k5w_scatter   per sentence: the words' ids, looked up through the table, are laid end to end.
+// BPE-dropout draws per occurrence and never comes here.  A "word" is what enc_tokenize makes of the bytes: a maximal run of
+// valid non-space chars; invalid bytes inside it are part of its key (two spellings of one word then take two slots, which is
+// only less sharing).
+#include "yttm_device.h"
+#include "yttm_kernels.h"
+
+namespace yttm {
+
+constexpr unsigned long long WC_LONG = 1ull << 63;       // key of a word of 8 .. WC_MAX_LEN bytes: WC_LONG | tag:7 | len:16 | pos:40
+constexpr unsigned long long WC_POS_MASK = (1ull << 40) - 1ull;
+constexpr uint32_t WC_MAX_LEN = 0xffffu;                 // longer words are not cached: every occurrence is encoded (list `extra`)
+constexpr uint32_t WC_EXTRA = 0x80000000u;               // occ value: index into `extra` instead of a table slot
+constexpr int WC_MAX_PROBES = 512;
+constexpr unsigned int WC_CBLK = BLOCK * 8;              // table slots per workgroup of the compaction kernels
+
+// bytes [pos, pos + 8) of the text, for any alignment of pos (text itself is 8-byte aligned, 24 bytes behind pos & ~7 readable)
+__device__ inline unsigned long long wc_load8(const uint8_t *__restrict__ text, unsigned long long pos) {
+  const unsigned long long *base = reinterpret_cast<const unsigned long long *>(text + (pos & ~7ull));
+  const unsigned long long lo = base[0], hi = base[1];
+  const unsigned int sh = (unsigned int)(pos & 7ull) * 8u;
+  return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+}
+// the first min(len, 8) bytes of the word in the low bytes of the result, the rest zero
+__device__ inline unsigned long long wc_head(const uint8_t *__restrict__ text, unsigned long long total, unsigned long long pos, uint32_t len) {
+  unsigned long long w = 0;
+  if ((pos & ~7ull) + 16 <= total) {
+    w = wc_load8(text, pos);
+  } else {  // the last bytes of the buffer: one at a time
+    for (uint32_t k = 0; k < 8 && pos + k < total; k++) w |= (unsigned long long)text[pos + k] << (8 * k);
+  }
+  return len >= 8 ? w : w & ((1ull << (8 * len)) - 1ull);
+}
+__device__ inline unsigned long long wc_hash_long(const uint8_t *__restrict__ text, unsigned long long total, unsigned long long pos, uint32_t len) {
+  unsigned long long h = 0x9e3779b97f4a7c15ull ^ len;
+  for (uint32_t done = 0; done < len; done += 8) h = (h ^ wc_head(text, total, pos + done, len - done)) * 0xff51afd7ed558ccdull + (h >> 29);
+  return mix64(h);
+}
+__device__ inline bool wc_bytes_equal(const uint8_t *__restrict__ text, unsigned long long total, unsigned long long a, unsigned long long b, uint32_t len) {
+  if (a == b) return true;
+  for (uint32_t done = 0; done < len; done += 8)
+    if (wc_head(text, total, a + done, len - done) != wc_head(text, total, b + done, len - done)) return false;
+  return true;
+}
+
+// One 64-byte step of the walk over a sentence's words: lane = byte b0 + lane; position nbytes acts as a space behind the text.
+// Returns true in the lane that CLOSES a word (the space behind it), with the word's bytes [*ws, *we).  Same classification as
+// enc_tokenize (k_encode.hip): chars by the reference's left-to-right decode, invalid bytes dropped, spaces by cpmap.
+struct WordWalk {
+  bool carry_space = true;             // class of the last valid char so far (the start of a sentence acts like a space)
+  unsigned long long carry_start = 0;  // first byte of the word that is open at the end of the previous step
+};
+__device__ inline bool wc_walk_step(const EncModel &m, const uint8_t *__restrict__ s, unsigned long long nbytes, unsigned long long b0, WordWalk &st,
+                                    unsigned long long *ws, unsigned long long *we) {
+  const int lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+  const unsigned long long i = b0 + (unsigned long long)lane;
+  bool valid = false, space = false;
+  if (i < nbytes) {
+    if (u8_is_start(s, i, nbytes)) {
+      uint32_t len;
+      const uint32_t cp = u8_decode_at(s, i, nbytes, &len);
+      if (cp != INVALID_CP) {
+        valid = true;
+        space = m.cpmap[cp] == CP_SPACE;
+      }
+    }
+  } else if (i == nbytes) {
+    valid = space = true;
+  }
+  const unsigned long long V = __ballot(valid), S = __ballot(space);
+  bool prev_space = st.carry_space;
+  const unsigned long long pv = V & lt;
+  if (pv) prev_space = (S >> (63 - __clzll((long long)pv))) & 1ull;
+  const bool wstart = valid && !space && prev_space;
+  const bool closing = valid && space && !prev_space;
+  const unsigned long long WSM = __ballot(wstart);
+  unsigned long long start = st.carry_start;
+  const unsigned long long wlt = WSM & lt;
+  if (wlt) start = b0 + (unsigned long long)(63 - __clzll((long long)wlt));
+  *ws = start;
+  *we = i;
+  if (V) st.carry_space = (S >> (63 - __clzll((long long)V))) & 1ull;
+  if (WSM) st.carry_start = b0 + (unsigned long long)(63 - __clzll((long long)WSM));
+  return closing;
+}
+
+// ---- 1. every word occurrence -> table slot ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k5w_insert(EncModel m, const uint8_t *__restrict__ text, unsigned long long total,
+                                                    const unsigned long long *__restrict__ offsets, unsigned long long n_sent, WordCache wc) {
+  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
+  const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
+  for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
+    const unsigned long long b_lo = offsets[sidx], nbytes = offsets[sidx + 1] - b_lo;
+    const uint8_t *s = text + b_lo;
+    WordWalk st;
+    for (unsigned long long b0 = 0; b0 <= nbytes; b0 += 64) {
+      unsigned long long ws, we;
+      if (!wc_walk_step(m, s, nbytes, b0, st, &ws, &we)) continue;
+      const unsigned long long pos = b_lo + ws, len64 = we - ws;
+      if (len64 > WC_MAX_LEN) {
+        const unsigned int e = atomicAdd(wc.extra_n, 1u);
+        if (e < wc.extra_cap) {
+          wc.extra[2 * e] = pos;
+          wc.extra[2 * e + 1] = pos + len64;
+        }
+        wc.occ[(pos + sidx) >> 1] = WC_EXTRA | e;
+        continue;
+      }
+      const uint32_t len = (uint32_t)len64;
+      unsigned long long key, h;
+      if (len < 8) {
+        key = ((unsigned long long)len << 56) | wc_head(text, total, pos, len);
+        h = mix64(key);
+      } else {
+        h = wc_hash_long(text, total, pos, len);
+        key = WC_LONG | ((h >> 57) << 56) | ((unsigned long long)len << 40) | pos;
+      }
+      unsigned long long i = h & wc.mask;
+      uint32_t found = 0xffffffffu;
+      for (int probes = 0; probes < WC_MAX_PROBES; probes++) {
+        unsigned long long cur = ld_agent(&wc.slot[i]);
+        if (cur == PT_EMPTY) {
+          cur = atomicCAS(&wc.slot[i], PT_EMPTY, key);
+          if (cur == PT_EMPTY) {  // this occurrence is the word's first: it lends the word its bytes
+            wc.pos[i] = pos;
+            found = (uint32_t)i;
+            break;
+          }
+        }
+        if (len < 8 ? cur == key : ((cur ^ key) >> 40) == 0ull && wc_bytes_equal(text, total, cur & WC_POS_MASK, pos, len)) {
+          found = (uint32_t)i;
+          break;
+        }
+        i = (i + 1) & wc.mask;
+      }
+      if (found == 0xffffffffu) atomicOr(wc.status, 1u);  // table too full: the host doubles it and starts over
+      wc.occ[(pos + sidx) >> 1] = found;
+    }
+  }
+}
+
+// ---- 2. the table's words as a list ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k5w_count_slots(WordCache wc, uint32_t *__restrict__ blk_cnt) {
+  __shared__ unsigned int acc;
+  if (threadIdx.x == 0) acc = 0;
+  __syncthreads();
+  const unsigned long long base = (unsigned long long)blockIdx.x * WC_CBLK;
+  unsigned int c = 0;
+  for (unsigned int k = 0; k < 8; k++) {
+    const unsigned long long i = base + k * BLOCK + threadIdx.x;
+    if (i <= wc.mask && wc.slot[i] != PT_EMPTY) c++;
+  }
+  if (c) atomicAdd(&acc, c);
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = acc;
+}
+// word u of the list: bytes [ustart[u], uend[u]), table slot uslot[u]; the uncached words follow the table's
+__global__ __launch_bounds__(BLOCK) void k5w_list(WordCache wc, const unsigned long long *__restrict__ blk_off, unsigned long long n_table,
+                                                  unsigned long long *__restrict__ ustart, unsigned long long *__restrict__ uend,
+                                                  uint32_t *__restrict__ uslot) {
+  __shared__ uint32_t scan_lds[NWAVES];
+  const unsigned long long base = (unsigned long long)blockIdx.x * WC_CBLK;
+  unsigned long long out = blk_off[blockIdx.x];
+  for (unsigned int k = 0; k < 8; k++) {
+    const unsigned long long i = base + k * BLOCK + threadIdx.x;
+    const unsigned long long key = i <= wc.mask ? wc.slot[i] : PT_EMPTY;
+    const bool used = key != PT_EMPTY;
+    uint32_t tot;
+    const uint32_t r = block_excl_scan(used ? 1u : 0u, scan_lds, &tot);
+    if (used) {
+      const unsigned long long u = out + r, p = wc.pos[i];
+      const unsigned long long len = (key & WC_LONG) ? (key >> 40) & 0xffffull : key >> 56;
+      ustart[u] = p;
+      uend[u] = p + len;
+      uslot[u] = (uint32_t)i;
+    }
+    out += tot;
+  }
+  if (blockIdx.x == 0) {
+    const unsigned int n_extra = *wc.extra_n;
+    for (unsigned int e = threadIdx.x; e < n_extra; e += BLOCK) {
+      ustart[n_table + e] = wc.extra[2 * e];
+      uend[n_table + e] = wc.extra[2 * e + 1];
+    }
+  }
+}
+// after K5 has encoded the list: the table slot (the `extra` entry) of a word now holds where its ids are -- offset << 24 | count
+__global__ __launch_bounds__(BLOCK) void k5w_publish(WordCache wc, unsigned long long n_table, unsigned long long n_words, const uint32_t *__restrict__ uslot,
+                                                     const unsigned long long *__restrict__ uoff) {
+  const unsigned long long u = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (u >= n_words) return;
+  const unsigned long long o = uoff[u], n = uoff[u + 1] - o;
+  if (u < n_table) {
+    wc.slot[uslot[u]] = (o << 24) | n;
+  } else {
+    wc.extra[2 * (u - n_table)] = o;
+    wc.extra[2 * (u - n_table) + 1] = n;
+  }
+}
+
+// ---- 3. per sentence: the words' ids end to end ------------------------------------------------------------------------------
+__device__ inline void wc_result(const WordCache &wc, unsigned long long pos, unsigned long long sidx, unsigned long long *off, uint32_t *n) {
+  const uint32_t o = wc.occ[(pos + sidx) >> 1];  // (word starts of a sentence are two bytes apart, those of consecutive sentences one)
+  if (o & WC_EXTRA) {
+    *off = wc.extra[2 * (o & ~WC_EXTRA)];
+    *n = (uint32_t)wc.extra[2 * (o & ~WC_EXTRA) + 1];
+  } else {
+    const unsigned long long r = wc.slot[o];
+    *off = r >> 24;
+    *n = (uint32_t)(r & 0xffffffull);
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k5w_count(EncModel m, const uint8_t *__restrict__ text, const unsigned long long *__restrict__ offsets,
+                                                   unsigned long long n_sent, WordCache wc, int n_fixed /* bos + eos */, uint32_t *__restrict__ counts) {
+  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
+  const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
+  for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
+    const unsigned long long b_lo = offsets[sidx], nbytes = offsets[sidx + 1] - b_lo;
+    WordWalk st;
+    unsigned long long mine = 0;
+    for (unsigned long long b0 = 0; b0 <= nbytes; b0 += 64) {
+      unsigned long long ws, we, off;
+      uint32_t n = 0;
+      if (wc_walk_step(m, text + b_lo, nbytes, b0, st, &ws, &we)) wc_result(wc, b_lo + ws, sidx, &off, &n);
+      mine += n;
+    }
+    const unsigned long long tot = wave_sum_u64(mine);
+    if (lane_id() == 0) counts[sidx] = (uint32_t)tot + (uint32_t)n_fixed;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k5w_scatter(EncModel m, const uint8_t *__restrict__ text, const unsigned long long *__restrict__ offsets,
+                                                     unsigned long long n_sent, WordCache wc, const int32_t *__restrict__ uids, int bos, int eos,
+                                                     int reverse, const unsigned long long *__restrict__ out_off, int32_t *__restrict__ ids_out) {
+  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
+  const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
+  const int lane = lane_id();
+  for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
+    const unsigned long long b_lo = offsets[sidx], nbytes = offsets[sidx + 1] - b_lo;
+    const unsigned long long o0 = out_off[sidx], n_ids = out_off[sidx + 1] - o0;
+    int32_t *out = ids_out + o0;
+    if (lane == 0) {
+      if (bos) out[reverse ? n_ids - 1 : 0] = m.bos_id;
+      if (eos) out[reverse ? 0 : n_ids - 1] = m.eos_id;
+    }
+    WordWalk st;
+    unsigned long long q = bos ? 1 : 0;  // ids of the sentence laid down so far
+    for (unsigned long long b0 = 0; b0 <= nbytes; b0 += 64) {
+      unsigned long long ws, we, off = 0;
+      uint32_t n = 0;
+      if (wc_walk_step(m, text + b_lo, nbytes, b0, st, &ws, &we)) wc_result(wc, b_lo + ws, sidx, &off, &n);
+      const uint32_t inc = wave_incl_scan(n);
+      const unsigned long long mine = q + inc - n;
+      for (uint32_t k = 0; k < n; k++) out[reverse ? n_ids - 1 - (mine + k) : mine + k] = uids[off + k];
+      q += (unsigned long long)__shfl(inc, 63);
+    }
+  }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------------------------
+static inline unsigned int wave_grid(unsigned long long n_items, unsigned int max_blocks) {
+  unsigned long long b = (n_items + NWAVES - 1) / NWAVES;
+  if (b > max_blocks) b = max_blocks;
+  return b ? (unsigned int)b : 1u;
+}
+unsigned long long wcache_count_blocks(const WordCache &wc) { return (wc.mask + WC_CBLK) / WC_CBLK; }
+void launch_wcache_insert(const EncModel &m, const uint8_t *text, unsigned long long total, const unsigned long long *offsets, unsigned long long n_sent,
+                          const WordCache &wc, hipStream_t st) {
+  hipLaunchKernelGGL(k5w_insert, dim3(wave_grid(n_sent, 256 * 16)), dim3(BLOCK), 0, st, m, text, total, offsets, n_sent, wc);
+}
+void launch_wcache_count_slots(const WordCache &wc, uint32_t *blk_cnt, hipStream_t st) {
+  hipLaunchKernelGGL(k5w_count_slots, dim3((unsigned int)wcache_count_blocks(wc)), dim3(BLOCK), 0, st, wc, blk_cnt);
+}
+void launch_wcache_list(const WordCache &wc, const unsigned long long *blk_off, unsigned long long n_table, unsigned long long *ustart,
+                        unsigned long long *uend, uint32_t *uslot, hipStream_t st) {
+  hipLaunchKernelGGL(k5w_list, dim3((unsigned int)wcache_count_blocks(wc)), dim3(BLOCK), 0, st, wc, blk_off, n_table, ustart, uend, uslot);
+}
+void launch_wcache_publish(const WordCache &wc, unsigned long long n_table, unsigned long long n_words, const uint32_t *uslot,
+                           const unsigned long long *uoff, hipStream_t st) {
+  if (!n_words) return;
+  hipLaunchKernelGGL(k5w_publish, dim3((unsigned int)((n_words + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, wc, n_table, n_words, uslot, uoff);
+}
+void launch_wcache_count(const EncModel &m, const uint8_t *text, const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc,
+                         int n_fixed, uint32_t *counts, hipStream_t st) {
+  hipLaunchKernelGGL(k5w_count, dim3(wave_grid(n_sent, 256 * 16)), dim3(BLOCK), 0, st, m, text, offsets, n_sent, wc, n_fixed, counts);
+}
+void launch_wcache_scatter(const EncModel &m, const uint8_t *text, const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc,
+                           const int32_t *uids, int bos, int eos, int reverse, const unsigned long long *out_off, int32_t *ids_out, hipStream_t st) {
+  hipLaunchKernelGGL(k5w_scatter, dim3(wave_grid(n_sent, 256 * 16)), dim3(BLOCK), 0, st, m, text, offsets, n_sent, wc, uids, bos, eos, reverse, out_off,
+                     ids_out);
+}
+
+}  // namespace yttm
