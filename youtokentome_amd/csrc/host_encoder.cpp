@@ -308,6 +308,7 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
     wc.extra_cap = (unsigned int)extra_cap;
     wc.status = d.d_wc_misc + 1;
     launch_fill_u64(wc.slot, PT_EMPTY, cap, d.st);
+    HIP_CHECK(hipMemsetAsync(wc.occ, 0xff, (size_t)((total_bytes + n_sent) / 2 + 2) * 4, d.st));  // (no word starts anywhere yet)
     HIP_CHECK(hipMemsetAsync(d.d_wc_misc, 0, 8, d.st));
     launch_wcache_insert(D.m, text, total_bytes, d_offsets, n_sent, wc, d.st);
     const unsigned long long n_blk = wcache_count_blocks(wc);
@@ -336,10 +337,10 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
     launch_encode_gather(d.d_scratch, d.d_ustart, d.d_uend, d.d_uoff, n_words, d.d_uids, d.st);
     launch_wcache_publish(wc, n_table, n_words, d.d_uslot, d.d_uoff, d.st);
   }
-  launch_wcache_count(D.m, text, d_offsets, n_sent, wc, (bos ? 1 : 0) + (eos ? 1 : 0), d.d_counts, d.st);
+  launch_wcache_count(d_offsets, n_sent, wc, (bos ? 1 : 0) + (eos ? 1 : 0), d.d_counts, d.st);
   const unsigned long long total = scan_counts(d, d.d_counts, n_sent, d.d_out_off);
   d.grow(d.d_ids, d.cap_ids, (size_t)total + 1);
-  launch_wcache_scatter(D.m, text, d_offsets, n_sent, wc, d.d_uids, bos, eos, reverse, d.d_out_off, d.d_ids, d.st);
+  launch_wcache_scatter(D.m, d_offsets, n_sent, wc, d.d_uids, bos, eos, reverse, d.d_out_off, d.d_ids, d.st);
   HIP_CHECK(hipStreamSynchronize(d.st));
   d.last_n_ids = total;
   if (n_ids_out) *n_ids_out = total;

@@ -20,6 +20,7 @@ constexpr unsigned long long WC_LONG = 1ull << 63;       // key of a word of 8 .
 constexpr unsigned long long WC_POS_MASK = (1ull << 40) - 1ull;
 constexpr uint32_t WC_MAX_LEN = 0xffffu;                 // longer words are not cached: every occurrence is encoded (list `extra`)
 constexpr uint32_t WC_EXTRA = 0x80000000u;               // occ value: index into `extra` instead of a table slot
+constexpr uint32_t WC_NONE = 0xffffffffu;                // occ value: no word starts here
 constexpr int WC_MAX_PROBES = 512;
 constexpr unsigned int WC_CBLK = BLOCK * 8;              // table slots per workgroup of the compaction kernels
 
@@ -65,7 +66,11 @@ __device__ inline bool wc_walk_step(const EncModel &m, const uint8_t *__restrict
   const unsigned long long lt = lanemask_lt();
   const unsigned long long i = b0 + (unsigned long long)lane;
   bool valid = false, space = false;
-  if (i < nbytes) {
+  const uint32_t byte = i < nbytes ? s[i] : 0u;
+  if (__ballot(byte >= 0x80u) == 0ull) {  // 64 ASCII bytes (the usual step): every byte is a char, the spaces are utils.cpp:99-101's
+    valid = i <= nbytes;
+    space = i == nbytes || byte == 32u || (byte - 9u) < 5u;
+  } else if (i < nbytes) {
     if (u8_is_start(s, i, nbytes)) {
       uint32_t len;
       const uint32_t cp = u8_decode_at(s, i, nbytes, &len);
@@ -95,58 +100,95 @@ __device__ inline bool wc_walk_step(const EncModel &m, const uint8_t *__restrict
 }
 
 // ---- 1. every word occurrence -> table slot ------------------------------------------------------------------------------------
+// one word: look it up / insert it, remember its slot at occ[oidx]
+__device__ inline void wc_insert_word(const uint8_t *__restrict__ text, unsigned long long total, const WordCache &wc, unsigned long long pos,
+                                      unsigned long long len64, unsigned long long oidx) {
+  if (len64 > WC_MAX_LEN) {
+    const unsigned int e = atomicAdd(wc.extra_n, 1u);
+    if (e < wc.extra_cap) {
+      wc.extra[2 * e] = pos;
+      wc.extra[2 * e + 1] = pos + len64;
+    }
+    wc.occ[oidx] = WC_EXTRA | e;
+    return;
+  }
+  const uint32_t len = (uint32_t)len64;
+  unsigned long long key, h;
+  if (len < 8) {
+    key = ((unsigned long long)len << 56) | wc_head(text, total, pos, len);
+    h = mix64(key);
+  } else {
+    h = wc_hash_long(text, total, pos, len);
+    key = WC_LONG | ((h >> 57) << 56) | ((unsigned long long)len << 40) | pos;
+  }
+  unsigned long long i = h & wc.mask;
+  uint32_t found = WC_NONE;
+  for (int probes = 0; probes < WC_MAX_PROBES; probes++) {
+    unsigned long long cur = ld_agent(&wc.slot[i]);
+    if (cur == PT_EMPTY) {
+      cur = atomicCAS(&wc.slot[i], PT_EMPTY, key);
+      if (cur == PT_EMPTY) {  // this occurrence is the word's first: it lends the word its bytes
+        wc.pos[i] = pos;
+        found = (uint32_t)i;
+        break;
+      }
+    }
+    if (len < 8 ? cur == key : ((cur ^ key) >> 40) == 0ull && wc_bytes_equal(text, total, cur & WC_POS_MASK, pos, len)) {
+      found = (uint32_t)i;
+      break;
+    }
+    i = (i + 1) & wc.mask;
+  }
+  if (found == WC_NONE) atomicOr(wc.status, 1u);  // table too full: the host doubles it and starts over
+  wc.occ[oidx] = found;
+}
+
+// A wave walks its sentences 64 bytes at a time; the words it closes (about ten per step) are queued in LDS and inserted 64 at a
+// time, one per lane -- the table probe is a chain of dependent loads from HBM, and it is paid once per 64 words instead of once
+// per step with a handful of lanes busy.
+constexpr int WC_QUEUE = 128;
 __global__ __launch_bounds__(BLOCK) void k5w_insert(EncModel m, const uint8_t *__restrict__ text, unsigned long long total,
                                                     const unsigned long long *__restrict__ offsets, unsigned long long n_sent, WordCache wc) {
-  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
+  __shared__ unsigned long long q_pos[NWAVES][WC_QUEUE], q_occ[NWAVES][WC_QUEUE];
+  __shared__ uint32_t q_len[NWAVES][WC_QUEUE];
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
+  unsigned long long *qp = q_pos[wave], *qo = q_occ[wave];
+  uint32_t *ql = q_len[wave];
+  int queued = 0;
   for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
     const unsigned long long b_lo = offsets[sidx], nbytes = offsets[sidx + 1] - b_lo;
     const uint8_t *s = text + b_lo;
     WordWalk st;
     for (unsigned long long b0 = 0; b0 <= nbytes; b0 += 64) {
       unsigned long long ws, we;
-      if (!wc_walk_step(m, s, nbytes, b0, st, &ws, &we)) continue;
-      const unsigned long long pos = b_lo + ws, len64 = we - ws;
-      if (len64 > WC_MAX_LEN) {
-        const unsigned int e = atomicAdd(wc.extra_n, 1u);
-        if (e < wc.extra_cap) {
-          wc.extra[2 * e] = pos;
-          wc.extra[2 * e + 1] = pos + len64;
-        }
-        wc.occ[(pos + sidx) >> 1] = WC_EXTRA | e;
-        continue;
+      const bool closing = wc_walk_step(m, s, nbytes, b0, st, &ws, &we);
+      const unsigned long long CM = __ballot(closing);
+      if (closing) {
+        const int k = queued + (int)__popcll(CM & lt);
+        qp[k] = b_lo + ws;
+        ql[k] = (uint32_t)(we - ws > 0xfffffffeull ? 0xffffffffull : we - ws);
+        qo[k] = (b_lo + ws + sidx) >> 1;
       }
-      const uint32_t len = (uint32_t)len64;
-      unsigned long long key, h;
-      if (len < 8) {
-        key = ((unsigned long long)len << 56) | wc_head(text, total, pos, len);
-        h = mix64(key);
-      } else {
-        h = wc_hash_long(text, total, pos, len);
-        key = WC_LONG | ((h >> 57) << 56) | ((unsigned long long)len << 40) | pos;
+      queued += (int)__popcll(CM);
+      wave_sync();
+      if (queued >= 64) {
+        wc_insert_word(text, total, wc, qp[lane], ql[lane], qo[lane]);
+        wave_sync();
+        const int rest = queued - 64;  // (< 64)
+        unsigned long long p = 0, o = 0;
+        uint32_t l = 0;
+        if (lane < rest) { p = qp[64 + lane]; l = ql[64 + lane]; o = qo[64 + lane]; }
+        wave_sync();
+        if (lane < rest) { qp[lane] = p; ql[lane] = l; qo[lane] = o; }
+        queued = rest;
+        wave_sync();
       }
-      unsigned long long i = h & wc.mask;
-      uint32_t found = 0xffffffffu;
-      for (int probes = 0; probes < WC_MAX_PROBES; probes++) {
-        unsigned long long cur = ld_agent(&wc.slot[i]);
-        if (cur == PT_EMPTY) {
-          cur = atomicCAS(&wc.slot[i], PT_EMPTY, key);
-          if (cur == PT_EMPTY) {  // this occurrence is the word's first: it lends the word its bytes
-            wc.pos[i] = pos;
-            found = (uint32_t)i;
-            break;
-          }
-        }
-        if (len < 8 ? cur == key : ((cur ^ key) >> 40) == 0ull && wc_bytes_equal(text, total, cur & WC_POS_MASK, pos, len)) {
-          found = (uint32_t)i;
-          break;
-        }
-        i = (i + 1) & wc.mask;
-      }
-      if (found == 0xffffffffu) atomicOr(wc.status, 1u);  // table too full: the host doubles it and starts over
-      wc.occ[(pos + sidx) >> 1] = found;
     }
   }
+  if (lane < queued) wc_insert_word(text, total, wc, qp[lane], ql[lane], qo[lane]);
 }
 
 // ---- 2. the table's words as a list ------------------------------------------------------------------------------------------
@@ -209,8 +251,7 @@ __global__ __launch_bounds__(BLOCK) void k5w_publish(WordCache wc, unsigned long
 }
 
 // ---- 3. per sentence: the words' ids end to end ------------------------------------------------------------------------------
-__device__ inline void wc_result(const WordCache &wc, unsigned long long pos, unsigned long long sidx, unsigned long long *off, uint32_t *n) {
-  const uint32_t o = wc.occ[(pos + sidx) >> 1];  // (word starts of a sentence are two bytes apart, those of consecutive sentences one)
+__device__ inline void wc_result(const WordCache &wc, uint32_t o, unsigned long long *off, uint32_t *n) {
   if (o & WC_EXTRA) {
     *off = wc.extra[2 * (o & ~WC_EXTRA)];
     *n = (uint32_t)wc.extra[2 * (o & ~WC_EXTRA) + 1];
@@ -220,44 +261,59 @@ __device__ inline void wc_result(const WordCache &wc, unsigned long long pos, un
     *n = (uint32_t)(r & 0xffffffull);
   }
 }
-__global__ __launch_bounds__(BLOCK) void k5w_count(EncModel m, const uint8_t *__restrict__ text, const unsigned long long *__restrict__ offsets,
-                                                   unsigned long long n_sent, WordCache wc, int n_fixed /* bos + eos */, uint32_t *__restrict__ counts) {
+// A sentence's word occurrences are the entries of occ between its first and last possible index that are not WC_NONE (the host
+// clears the array before k5w_insert): the second and third walk over the text are scans of that array, 64 entries = 128 bytes of
+// text per step, no UTF-8.
+__device__ inline void wc_occ_range(const unsigned long long *__restrict__ offsets, unsigned long long sidx, unsigned long long *lo, unsigned long long *hi) {
+  const unsigned long long b_lo = offsets[sidx], b_hi = offsets[sidx + 1];
+  *lo = (b_lo + sidx) >> 1;
+  *hi = b_hi > b_lo ? ((b_hi - 1 + sidx) >> 1) + 1 : *lo;  // (exclusive)
+}
+__global__ __launch_bounds__(BLOCK) void k5w_count(const unsigned long long *__restrict__ offsets, unsigned long long n_sent, WordCache wc,
+                                                   int n_fixed /* bos + eos */, uint32_t *__restrict__ counts) {
   const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
   const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
   for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
-    const unsigned long long b_lo = offsets[sidx], nbytes = offsets[sidx + 1] - b_lo;
-    WordWalk st;
+    unsigned long long lo, hi;
+    wc_occ_range(offsets, sidx, &lo, &hi);
     unsigned long long mine = 0;
-    for (unsigned long long b0 = 0; b0 <= nbytes; b0 += 64) {
-      unsigned long long ws, we, off;
-      uint32_t n = 0;
-      if (wc_walk_step(m, text + b_lo, nbytes, b0, st, &ws, &we)) wc_result(wc, b_lo + ws, sidx, &off, &n);
-      mine += n;
+    for (unsigned long long i = lo + (unsigned long long)lane_id(); i < hi; i += 64) {
+      const uint32_t o = wc.occ[i];
+      if (o != WC_NONE) {
+        unsigned long long off;
+        uint32_t n;
+        wc_result(wc, o, &off, &n);
+        mine += n;
+      }
     }
     const unsigned long long tot = wave_sum_u64(mine);
     if (lane_id() == 0) counts[sidx] = (uint32_t)tot + (uint32_t)n_fixed;
   }
 }
-__global__ __launch_bounds__(BLOCK) void k5w_scatter(EncModel m, const uint8_t *__restrict__ text, const unsigned long long *__restrict__ offsets,
-                                                     unsigned long long n_sent, WordCache wc, const int32_t *__restrict__ uids, int bos, int eos,
-                                                     int reverse, const unsigned long long *__restrict__ out_off, int32_t *__restrict__ ids_out) {
+__global__ __launch_bounds__(BLOCK) void k5w_scatter(EncModel m, const unsigned long long *__restrict__ offsets, unsigned long long n_sent, WordCache wc,
+                                                     const int32_t *__restrict__ uids, int bos, int eos, int reverse,
+                                                     const unsigned long long *__restrict__ out_off, int32_t *__restrict__ ids_out) {
   const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
   const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
   const int lane = lane_id();
   for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
-    const unsigned long long b_lo = offsets[sidx], nbytes = offsets[sidx + 1] - b_lo;
+    unsigned long long lo, hi;
+    wc_occ_range(offsets, sidx, &lo, &hi);
     const unsigned long long o0 = out_off[sidx], n_ids = out_off[sidx + 1] - o0;
     int32_t *out = ids_out + o0;
     if (lane == 0) {
       if (bos) out[reverse ? n_ids - 1 : 0] = m.bos_id;
       if (eos) out[reverse ? 0 : n_ids - 1] = m.eos_id;
     }
-    WordWalk st;
     unsigned long long q = bos ? 1 : 0;  // ids of the sentence laid down so far
-    for (unsigned long long b0 = 0; b0 <= nbytes; b0 += 64) {
-      unsigned long long ws, we, off = 0;
+    for (unsigned long long i0 = lo; i0 < hi; i0 += 64) {
+      const unsigned long long i = i0 + (unsigned long long)lane;
+      unsigned long long off = 0;
       uint32_t n = 0;
-      if (wc_walk_step(m, text + b_lo, nbytes, b0, st, &ws, &we)) wc_result(wc, b_lo + ws, sidx, &off, &n);
+      if (i < hi) {
+        const uint32_t o = wc.occ[i];
+        if (o != WC_NONE) wc_result(wc, o, &off, &n);
+      }
       const uint32_t inc = wave_incl_scan(n);
       const unsigned long long mine = q + inc - n;
       for (uint32_t k = 0; k < n; k++) out[reverse ? n_ids - 1 - (mine + k) : mine + k] = uids[off + k];
@@ -289,14 +345,12 @@ void launch_wcache_publish(const WordCache &wc, unsigned long long n_table, unsi
   if (!n_words) return;
   hipLaunchKernelGGL(k5w_publish, dim3((unsigned int)((n_words + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, wc, n_table, n_words, uslot, uoff);
 }
-void launch_wcache_count(const EncModel &m, const uint8_t *text, const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc,
-                         int n_fixed, uint32_t *counts, hipStream_t st) {
-  hipLaunchKernelGGL(k5w_count, dim3(wave_grid(n_sent, 256 * 16)), dim3(BLOCK), 0, st, m, text, offsets, n_sent, wc, n_fixed, counts);
+void launch_wcache_count(const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc, int n_fixed, uint32_t *counts, hipStream_t st) {
+  hipLaunchKernelGGL(k5w_count, dim3(wave_grid(n_sent, 256 * 16)), dim3(BLOCK), 0, st, offsets, n_sent, wc, n_fixed, counts);
 }
-void launch_wcache_scatter(const EncModel &m, const uint8_t *text, const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc,
-                           const int32_t *uids, int bos, int eos, int reverse, const unsigned long long *out_off, int32_t *ids_out, hipStream_t st) {
-  hipLaunchKernelGGL(k5w_scatter, dim3(wave_grid(n_sent, 256 * 16)), dim3(BLOCK), 0, st, m, text, offsets, n_sent, wc, uids, bos, eos, reverse, out_off,
-                     ids_out);
+void launch_wcache_scatter(const EncModel &m, const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc, const int32_t *uids, int bos,
+                           int eos, int reverse, const unsigned long long *out_off, int32_t *ids_out, hipStream_t st) {
+  hipLaunchKernelGGL(k5w_scatter, dim3(wave_grid(n_sent, 256 * 16)), dim3(BLOCK), 0, st, m, offsets, n_sent, wc, uids, bos, eos, reverse, out_off, ids_out);
 }
 
 }  // namespace yttm
