@@ -51,8 +51,6 @@ struct EncodeLane {
   unsigned long long *d_uend = nullptr; size_t cap_uend = 0;
   uint32_t *d_uslot = nullptr; size_t cap_uslot = 0;
   uint32_t *d_ucounts = nullptr; size_t cap_ucounts = 0;
-  unsigned long long *d_uoff = nullptr; size_t cap_uoff = 0;
-  int32_t *d_uids = nullptr; size_t cap_uids = 0;
   unsigned long long last_n_ids = 0, last_n_sent = 0;
   unsigned long long last_distinct_words = 0;  // of the last cached batch (0: the batch went straight through K5)
 
@@ -68,8 +66,7 @@ struct EncodeLane {
   ~EncodeLane() {
     for (void *p : {(void *)d_drop, (void *)d_bytes, (void *)d_off, (void *)d_scratch, (void *)d_counts, (void *)d_out_off, (void *)d_scan_tmp,
                     (void *)d_total, (void *)d_ids, (void *)d_work, (void *)d_wc_slot, (void *)d_wc_pos, (void *)d_wc_occ, (void *)d_wc_extra,
-                    (void *)d_wc_misc, (void *)d_wc_blk, (void *)d_wc_blk_off, (void *)d_ustart, (void *)d_uend, (void *)d_uslot, (void *)d_ucounts,
-                    (void *)d_uoff, (void *)d_uids})
+                    (void *)d_wc_misc, (void *)d_wc_blk, (void *)d_wc_blk_off, (void *)d_ustart, (void *)d_uend, (void *)d_uslot, (void *)d_ucounts})
       if (p) (void)hipFree(p);
     if (st) (void)hipStreamDestroy(st);
   }
@@ -289,7 +286,7 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
                           unsigned long long *n_ids_out) {
   const uint8_t *text = (const uint8_t *)d_bytes;
   unsigned long long cap = 1024;
-  while (cap < total_bytes / 4 && cap < (1ull << 31)) cap <<= 1;
+  while (cap < total_bytes / 8 && cap < (1ull << 31)) cap <<= 1;  // (a slot per 8 bytes of text; text has far fewer distinct words)
   WordCache wc{};
   unsigned long long n_table = 0;
   unsigned int misc[2] = {0, 0};
@@ -327,20 +324,15 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
   d.grow(d.d_uend, d.cap_uend, (size_t)n_words + 1);
   d.grow(d.d_uslot, d.cap_uslot, (size_t)n_table + 1);
   d.grow(d.d_ucounts, d.cap_ucounts, (size_t)n_words + 1);
-  d.grow(d.d_uoff, d.cap_uoff, (size_t)n_words + 2);
   launch_wcache_list(wc, d.d_wc_blk_off, n_table, d.d_ustart, d.d_uend, d.d_uslot, d.st);
-  unsigned long long n_uids = 0;
-  if (n_words) {
+  if (n_words) {  // (the distinct words' ids stay where K5 puts them, in the lane's scratch: the sentences are assembled from there)
     k5_pass(D, d, d_bytes, d.d_ustart, d.d_uend, n_words, total_bytes, max_sentence_bytes, false, false, false, 0.0, d.d_ucounts);
-    n_uids = scan_counts(d, d.d_ucounts, n_words, d.d_uoff);
-    d.grow(d.d_uids, d.cap_uids, (size_t)n_uids + 1);
-    launch_encode_gather(d.d_scratch, d.d_ustart, d.d_uend, d.d_uoff, n_words, d.d_uids, d.st);
-    launch_wcache_publish(wc, n_table, n_words, d.d_uslot, d.d_uoff, d.st);
+    launch_wcache_publish(wc, n_table, n_words, d.d_uslot, d.d_ustart, d.d_ucounts, d.st);
   }
   launch_wcache_count(d_offsets, n_sent, wc, (bos ? 1 : 0) + (eos ? 1 : 0), d.d_counts, d.st);
   const unsigned long long total = scan_counts(d, d.d_counts, n_sent, d.d_out_off);
   d.grow(d.d_ids, d.cap_ids, (size_t)total + 1);
-  launch_wcache_scatter(D.m, d_offsets, n_sent, wc, d.d_uids, bos, eos, reverse, d.d_out_off, d.d_ids, d.st);
+  launch_wcache_scatter(D.m, d_offsets, n_sent, wc, d.d_scratch, bos, eos, reverse, d.d_out_off, d.d_ids, d.st);
   HIP_CHECK(hipStreamSynchronize(d.st));
   d.last_n_ids = total;
   if (n_ids_out) *n_ids_out = total;

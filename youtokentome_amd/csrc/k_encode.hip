@@ -421,7 +421,113 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
   const unsigned long long lt = lanemask_lt();
   int n = 0, consumed = 0, k = 0;
   unsigned long long my_sid = 0;  // lane j: index of the j-th non-empty sentence of the pack
-  for (unsigned long long j = s; j < e && k < 64; j++) {
+  if (sv.end) {
+    // The word cache's distinct words: dozens of items of a few bytes each per pack.  Tokenizing them one after the other (the loop
+    // below) is a chain of dependent loads per item -- bounds, bytes, cpmap -- with a handful of lanes busy; here the items of the
+    // pack are laid end to end and tokenized 64 bytes at a time whichever item a byte belongs to.  (wr and wm are free until the
+    // merge rounds start: wm[j] = first byte of item j in the concatenation, wr = the items' addresses, token counts, index map.)
+    const unsigned long long avail = e - s < 64ull ? e - s : 64ull;
+    unsigned long long lo = 0;
+    uint32_t len = 0;
+    if ((unsigned long long)lane < avail) {
+      lo = sv.lo(s + lane);
+      len = (uint32_t)(sv.hi(s + lane) - lo);  // (the caller saw that the first item fits; a longer one ends the pack)
+      if (sv.hi(s + lane) - lo >= (unsigned long long)ENC_WCAP) len = ENC_WCAP;
+    }
+    const uint32_t need = (unsigned long long)lane < avail ? len + 1u : 0u;
+    const uint32_t pre = wave_incl_scan(need);
+    const unsigned long long FIT = __ballot((unsigned long long)lane < avail && pre <= (uint32_t)ENC_WCAP);
+    const int cnt = (int)__popcll(FIT);  // items 0 .. cnt-1 fit (the sizes add up: a prefix of the lanes)
+    const uint32_t base = pre - need - (uint32_t)lane;  // bytes before item `lane`
+    if (lane < cnt) {
+      wm.set(lane, base);
+      wr.set(2 * lane, (uint32_t)lo);
+      wr.set(2 * lane + 1, (uint32_t)(lo >> 32));
+      wr.set(128 + lane, 0u);
+    }
+    const uint32_t T = (uint32_t)__shfl(base + len, cnt - 1);  // bytes in all
+    if (lane == 0) wm.set(cnt, T);
+    wave_sync();
+    bool carry_space = true, carry_unk = false;
+    int carry_item = -1;
+    for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+      const uint32_t t = t0 + (uint32_t)lane;
+      int it = 0;
+      bool valid = false, space = false, unk = false;
+      uint32_t id = 0;
+      if (t < T) {
+        int a = 0, b = cnt;  // item of byte t: the last one that starts at or before it
+        while (b - a > 1) {
+          const int mid = (a + b) >> 1;
+          if (wm.get(mid) <= t) a = mid; else b = mid;
+        }
+        it = a;
+        const uint32_t i = t - wm.get(it), nb = wm.get(it + 1) - wm.get(it);
+        const uint8_t *sp = text + (((unsigned long long)wr.get(2 * it + 1) << 32) | wr.get(2 * it));
+        if (u8_is_start(sp, i, nb)) {
+          uint32_t clen;
+          const uint32_t cp = u8_decode_at(sp, i, nb, &clen);
+          if (cp != INVALID_CP) {
+            valid = true;
+            id = m.cpmap[cp];
+            space = id == CP_SPACE;
+            unk = id == CP_UNK;
+          }
+        }
+      }
+      const unsigned long long V = __ballot(valid), S = __ballot(space), U = __ballot(unk);
+      bool prev_space = carry_space, prev_unk = carry_unk;
+      int prev_item = carry_item;
+      const unsigned long long pv = V & lt;
+      const int jj = pv ? 63 - __clzll((long long)pv) : 0;
+      const int item_jj = __shfl(it, jj);
+      if (pv) {
+        prev_space = (S >> jj) & 1ull;
+        prev_unk = (U >> jj) & 1ull;
+        prev_item = item_jj;
+      }
+      const bool item_first = prev_item != it;  // no valid char of this item before this one
+      if (item_first) { prev_space = true; prev_unk = false; }
+      int emit = 0;
+      if (valid && !space) {
+        const bool wstart = prev_space;
+        if (unk && prev_unk && !wstart) emit = 0;
+        else emit = wstart ? 2 : 1;
+      }
+      const unsigned long long e1 = __ballot(emit >= 1), e2 = __ballot(emit == 2);
+      const int pos = n + __popcll(e1 & lt) + __popcll(e2 & lt);
+      const uint32_t tv = unk ? ENC_UNKP : id;
+      if (emit == 2) {
+        wt.set(pos, m.space_id | TOK_WS | (item_first ? ENC_SENT : 0u));
+        wt.set(pos + 1, tv);
+      } else if (emit == 1) {
+        wt.set(pos, tv);
+      }
+      if (emit) atomicAdd(&wr.p[128 + it], 1u);
+      n += __popcll(e1) + __popcll(e2);
+      if (V) {
+        const int j2 = 63 - __clzll((long long)V);
+        carry_space = (S >> j2) & 1ull;
+        carry_unk = (U >> j2) & 1ull;
+        carry_item = __shfl(it, j2);
+      }
+    }
+    wave_sync();
+    const bool nonempty = lane < cnt && wr.get(128 + lane) != 0u;
+    const unsigned long long NE = __ballot(nonempty);
+    if (lane < cnt && !nonempty) counts[s + lane] = 0u;  // (word mode runs without bos / eos)
+    if (nonempty) {
+      const int r = (int)__popcll(NE & lt);
+      wr.set(192 + 2 * r, (uint32_t)(s + lane));
+      wr.set(193 + 2 * r, (uint32_t)((s + lane) >> 32));
+    }
+    wave_sync();
+    k = (int)__popcll(NE);
+    if (lane < k) my_sid = ((unsigned long long)wr.get(193 + 2 * lane) << 32) | wr.get(192 + 2 * lane);
+    consumed = cnt;
+    wave_sync();
+  }
+  for (unsigned long long j = s; !sv.end && j < e && k < 64; j++) {
     const unsigned long long b0 = sv.lo(j), nbytes = sv.hi(j) - b0;
     if (nbytes + 1 > (unsigned long long)(ENC_WCAP - n)) break;
     const int n0 = n;

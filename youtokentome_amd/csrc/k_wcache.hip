@@ -236,14 +236,15 @@ __global__ __launch_bounds__(BLOCK) void k5w_list(WordCache wc, const unsigned l
     }
   }
 }
-// after K5 has encoded the list: the table slot (the `extra` entry) of a word now holds where its ids are -- offset << 24 | count
+// after K5 has encoded the list: the table slot (the `extra` entry) of a word now says where its ids are -- K5 left those of word u at
+// scratch + 2 ustart[u] (k_encode.hip SentView), counts[u] of them: offset << 20 | count (a cached word has at most 65 536 ids)
 __global__ __launch_bounds__(BLOCK) void k5w_publish(WordCache wc, unsigned long long n_table, unsigned long long n_words, const uint32_t *__restrict__ uslot,
-                                                     const unsigned long long *__restrict__ uoff) {
+                                                     const unsigned long long *__restrict__ ustart, const uint32_t *__restrict__ ucounts) {
   const unsigned long long u = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
   if (u >= n_words) return;
-  const unsigned long long o = uoff[u], n = uoff[u + 1] - o;
+  const unsigned long long o = 2 * ustart[u], n = ucounts[u];
   if (u < n_table) {
-    wc.slot[uslot[u]] = (o << 24) | n;
+    wc.slot[uslot[u]] = (o << 20) | n;
   } else {
     wc.extra[2 * (u - n_table)] = o;
     wc.extra[2 * (u - n_table) + 1] = n;
@@ -257,8 +258,8 @@ __device__ inline void wc_result(const WordCache &wc, uint32_t o, unsigned long 
     *n = (uint32_t)wc.extra[2 * (o & ~WC_EXTRA) + 1];
   } else {
     const unsigned long long r = wc.slot[o];
-    *off = r >> 24;
-    *n = (uint32_t)(r & 0xffffffull);
+    *off = r >> 20;
+    *n = (uint32_t)(r & 0xfffffull);
   }
 }
 // A sentence's word occurrences are the entries of occ between its first and last possible index that are not WC_NONE (the host
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(BLOCK) void k5w_count(const unsigned long long *__r
   }
 }
 __global__ __launch_bounds__(BLOCK) void k5w_scatter(EncModel m, const unsigned long long *__restrict__ offsets, unsigned long long n_sent, WordCache wc,
-                                                     const int32_t *__restrict__ uids, int bos, int eos, int reverse,
+                                                     const int32_t *__restrict__ uids /* K5's scratch */, int bos, int eos, int reverse,
                                                      const unsigned long long *__restrict__ out_off, int32_t *__restrict__ ids_out) {
   const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
   const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
@@ -341,9 +342,9 @@ void launch_wcache_list(const WordCache &wc, const unsigned long long *blk_off, 
   hipLaunchKernelGGL(k5w_list, dim3((unsigned int)wcache_count_blocks(wc)), dim3(BLOCK), 0, st, wc, blk_off, n_table, ustart, uend, uslot);
 }
 void launch_wcache_publish(const WordCache &wc, unsigned long long n_table, unsigned long long n_words, const uint32_t *uslot,
-                           const unsigned long long *uoff, hipStream_t st) {
+                           const unsigned long long *ustart, const uint32_t *ucounts, hipStream_t st) {
   if (!n_words) return;
-  hipLaunchKernelGGL(k5w_publish, dim3((unsigned int)((n_words + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, wc, n_table, n_words, uslot, uoff);
+  hipLaunchKernelGGL(k5w_publish, dim3((unsigned int)((n_words + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, wc, n_table, n_words, uslot, ustart, ucounts);
 }
 void launch_wcache_count(const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc, int n_fixed, uint32_t *counts, hipStream_t st) {
   hipLaunchKernelGGL(k5w_count, dim3(wave_grid(n_sent, 256 * 16)), dim3(BLOCK), 0, st, offsets, n_sent, wc, n_fixed, counts);

@@ -170,7 +170,7 @@ void launch_encode_gather(const int32_t *scratch_ids, const unsigned long long *
 
 // ---- N4: word cache of the batch encoder (k_wcache.hip) ----
 struct WordCache {
-  unsigned long long *slot;   // [mask + 1] key of a distinct word (PT_EMPTY = free); after launch_wcache_publish: ids offset << 24 | count
+  unsigned long long *slot;   // [mask + 1] key of a distinct word (PT_EMPTY = free); after launch_wcache_publish: ids offset << 20 | count
   unsigned long long *pos;    // [mask + 1] first byte of the word's first occurrence
   unsigned long long mask;
   uint32_t *occ;              // [(bytes + sentences) / 2 + 2] per word occurrence (index (first byte + sentence) / 2): its slot; 0xffffffff elsewhere
@@ -186,7 +186,7 @@ void launch_wcache_count_slots(const WordCache &wc, uint32_t *blk_cnt, hipStream
 void launch_wcache_list(const WordCache &wc, const unsigned long long *blk_off, unsigned long long n_table, unsigned long long *ustart,
                         unsigned long long *uend, uint32_t *uslot, hipStream_t st);
 void launch_wcache_publish(const WordCache &wc, unsigned long long n_table, unsigned long long n_words, const uint32_t *uslot,
-                           const unsigned long long *uoff, hipStream_t st);
+                           const unsigned long long *ustart, const uint32_t *ucounts, hipStream_t st);
 void launch_wcache_count(const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc, int n_fixed, uint32_t *counts, hipStream_t st);
 void launch_wcache_scatter(const EncModel &m, const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc, const int32_t *uids, int bos,
                            int eos, int reverse, const unsigned long long *out_off, int32_t *ids_out, hipStream_t st);
