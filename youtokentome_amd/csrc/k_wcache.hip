@@ -60,13 +60,12 @@ struct WordWalk {
   bool carry_space = true;             // class of the last valid char so far (the start of a sentence acts like a space)
   unsigned long long carry_start = 0;  // first byte of the word that is open at the end of the previous step
 };
-__device__ inline bool wc_walk_step(const EncModel &m, const uint8_t *__restrict__ s, unsigned long long nbytes, unsigned long long b0, WordWalk &st,
-                                    unsigned long long *ws, unsigned long long *we) {
+__device__ inline bool wc_walk_step(const EncModel &m, const uint8_t *__restrict__ s, unsigned long long nbytes, unsigned long long b0, uint32_t byte /* s[b0 + lane], 0 behind the end */,
+                                    WordWalk &st, unsigned long long *ws, unsigned long long *we) {
   const int lane = lane_id();
   const unsigned long long lt = lanemask_lt();
   const unsigned long long i = b0 + (unsigned long long)lane;
   bool valid = false, space = false;
-  const uint32_t byte = i < nbytes ? s[i] : 0u;
   if (__ballot(byte >= 0x80u) == 0ull) {  // 64 ASCII bytes (the usual step): every byte is a char, the spaces are utils.cpp:99-101's
     valid = i <= nbytes;
     space = i == nbytes || byte == 32u || (byte - 9u) < 5u;
@@ -158,35 +157,60 @@ __global__ __launch_bounds__(BLOCK) void k5w_insert(EncModel m, const uint8_t *_
   unsigned long long *qp = q_pos[wave], *qo = q_occ[wave];
   uint32_t *ql = q_len[wave];
   int queued = 0;
-  for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
-    const unsigned long long b_lo = offsets[sidx], nbytes = offsets[sidx + 1] - b_lo;
-    const uint8_t *s = text + b_lo;
-    WordWalk st;
-    for (unsigned long long b0 = 0; b0 <= nbytes; b0 += 64) {
-      unsigned long long ws, we;
-      const bool closing = wc_walk_step(m, s, nbytes, b0, st, &ws, &we);
-      const unsigned long long CM = __ballot(closing);
-      if (closing) {
-        const int k = queued + (int)__popcll(CM & lt);
-        qp[k] = b_lo + ws;
-        ql[k] = (uint32_t)(we - ws > 0xfffffffeull ? 0xffffffffull : we - ws);
-        qo[k] = (b_lo + ws + sidx) >> 1;
-      }
-      queued += (int)__popcll(CM);
-      wave_sync();
-      if (queued >= 64) {
-        wc_insert_word(text, total, wc, qp[lane], ql[lane], qo[lane]);
-        wave_sync();
-        const int rest = queued - 64;  // (< 64)
-        unsigned long long p = 0, o = 0;
-        uint32_t l = 0;
-        if (lane < rest) { p = qp[64 + lane]; l = ql[64 + lane]; o = qo[64 + lane]; }
-        wave_sync();
-        if (lane < rest) { qp[lane] = p; ql[lane] = l; qo[lane] = o; }
-        queued = rest;
-        wave_sync();
-      }
+  // (the bytes of the next step -- of this sentence or the first of the wave's next one -- are on their way while this one is
+  // worked on: with ASCII text the byte is the step's only load)
+  unsigned long long sidx = gw;
+  if (sidx >= n_sent) return;
+  unsigned long long b_lo = offsets[sidx], nbytes = offsets[sidx + 1] - b_lo, b0 = 0;
+  unsigned long long nx_lo = 0, nx_n = 0;  // the wave's next sentence
+  if (sidx + n_waves < n_sent) { nx_lo = offsets[sidx + n_waves]; nx_n = offsets[sidx + n_waves + 1] - nx_lo; }
+  uint32_t byte = (unsigned long long)lane < nbytes ? text[b_lo + lane] : 0u;
+  WordWalk st;
+  for (;;) {
+    // where the next step is
+    const bool same = b0 + 64 <= nbytes;
+    const unsigned long long n_sidx = same ? sidx : sidx + n_waves;
+    const bool more = n_sidx < n_sent;
+    const unsigned long long n_lo = same ? b_lo : nx_lo, n_n = same ? nbytes : nx_n, n_b0 = same ? b0 + 64 : 0;
+    uint32_t n_byte = 0;
+    if (more && n_b0 + (unsigned long long)lane < n_n) n_byte = text[n_lo + n_b0 + lane];
+    unsigned long long nn_lo = nx_lo, nn_n = nx_n;
+    if (!same && more && n_sidx + n_waves < n_sent) { nn_lo = offsets[n_sidx + n_waves]; nn_n = offsets[n_sidx + n_waves + 1] - nn_lo; }
+    // this step
+    unsigned long long ws, we;
+    const bool closing = wc_walk_step(m, text + b_lo, nbytes, b0, byte, st, &ws, &we);
+    const unsigned long long CM = __ballot(closing);
+    if (closing) {
+      const int k = queued + (int)__popcll(CM & lt);
+      qp[k] = b_lo + ws;
+      ql[k] = (uint32_t)(we - ws > 0xfffffffeull ? 0xffffffffull : we - ws);
+      qo[k] = (b_lo + ws + sidx) >> 1;
     }
+    queued += (int)__popcll(CM);
+    wave_sync();
+    if (queued >= 64) {
+      wc_insert_word(text, total, wc, qp[lane], ql[lane], qo[lane]);
+      wave_sync();
+      const int rest = queued - 64;  // (< 64)
+      unsigned long long p = 0, o = 0;
+      uint32_t l = 0;
+      if (lane < rest) { p = qp[64 + lane]; l = ql[64 + lane]; o = qo[64 + lane]; }
+      wave_sync();
+      if (lane < rest) { qp[lane] = p; ql[lane] = l; qo[lane] = o; }
+      queued = rest;
+      wave_sync();
+    }
+    if (!more) break;
+    if (!same) {
+      st = WordWalk();
+      nx_lo = nn_lo;
+      nx_n = nn_n;
+    }
+    sidx = n_sidx;
+    b_lo = n_lo;
+    nbytes = n_n;
+    b0 = n_b0;
+    byte = n_byte;
   }
   if (lane < queued) wc_insert_word(text, total, wc, qp[lane], ql[lane], qo[lane]);
 }
