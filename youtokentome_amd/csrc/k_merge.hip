@@ -815,12 +815,14 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
               }
             }
           }
+          K4_MARK(13);  // (PROF=2: phase 2 up to here = the sites' context and deltas; from here to mark 5 = the emits)
           if (__ballot(v0)) { if (v0) emit<SLOT>(A, W, pt, db, k0, d0); }
           if (__ballot(v1)) { if (v1) emit<SLOT>(A, W, pt, db, k1, f); }
           if (__ballot(v2)) { if (v2) emit<SLOT>(A, W, pt, db, k2, d2); }
           if (__ballot(v3)) { if (v3) emit<SLOT>(A, W, pt, db, k3, f); }
           if (__ballot(v4)) { if (v4) emit<SLOT>(A, W, pt, db, k4, d4); }
           wave_sync();  // (the list is rebuilt by the next pass)
+          K4_MARK(5);
         }
         K4_MARK(5);
         if (instr) {
@@ -1269,6 +1271,10 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     if (lane == 0)
       for (int i = 0; i < 16; i++)
         if (S.pt[i]) atomicAdd(&stats[8 + i], S.pt[i]);
+    if (threadIdx.x == 0 && A.miss_n) {  // emits that found no room in the workgroup's LDS hash (they went to the HBM table one by one)
+      atomicAdd(&stats[8 + 14], A.miss_n);
+      atomicAdd(&stats[8 + 15], A.miss_cyc);
+    }
   }
 #endif
 #ifdef YTTM_K4_PROF
