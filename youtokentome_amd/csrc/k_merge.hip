@@ -27,7 +27,9 @@
 
 namespace yttm {
 
-constexpr int AGG_SLOTS = 256;   // LDS delta aggregator shared by the waves of a workgroup (hot pairs)
+constexpr int AGG_SLOTS = 512;   // LDS delta aggregator shared by the waves of a workgroup (hot pairs).  256 slots: 1.05e8 emits of rounds 12-100 at 1 GB
+                                 // found no room and went to the HBM table one by one (K4 135 ms); 512: 123 ms; 704: 124; 1024 (two workgroups per CU): 156.
+                                 // The probe loop stays at 8, unrolled: 12 -> 127 ms, 24 -> 253 (!), not unrolled -> 135
 // The worklist of dirty tiles is kept in WL_PARTS sub-lists (workgroup b of the filter appends to list b % WL_PARTS, each
 // list WL_SEG(n_tiles) entries apart): one cursor bumped by all 1280 workgroups of a launch cost 14 us per round.
 constexpr uint32_t WL_PARTS = 8;
