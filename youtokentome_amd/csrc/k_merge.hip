@@ -276,9 +276,9 @@ __device__ inline bool reg_flag_test(const uint4 (&r)[SLOT / 256], int n, const 
   for (int j = 0; j < SLOT / 256; j++) {
     if (256 * j < n) {
       const uint32_t g0 = YBIT(f[j].x, r[j].x);  // is my first token a continuing y?  (asked by the lane to my left)
-      uint32_t gn = __shfl_down(g0, 1);
+      uint32_t gn = from_lane_right(g0);
       uint32_t g_next_row = 0;  // first token of the next row, for lane 63 (shuffles are executed by all lanes)
-      if (j + 1 < SLOT / 256) g_next_row = __shfl(YBIT(f[j + 1 < SLOT / 256 ? j + 1 : j].x, r[j + 1 < SLOT / 256 ? j + 1 : j].x), 0);
+      if (j + 1 < SLOT / 256) g_next_row = from_lane0(YBIT(f[j + 1 < SLOT / 256 ? j + 1 : j].x, r[j + 1 < SLOT / 256 ? j + 1 : j].x));
       if (lane == 63) gn = g_next_row;
       c |= (f[j].x & YBIT(f[j].y, r[j].y)) | (f[j].y & YBIT(f[j].z, r[j].z)) | (f[j].z & YBIT(f[j].w, r[j].w)) | (f[j].w & gn);
     }
@@ -290,9 +290,9 @@ __device__ inline bool reg_flag_test(const uint4 (&r)[SLOT / 256], int n, const 
 #pragma unroll
     for (int j = 0; j < SLOT / 256; j++) {
       if (256 * j < n) {
-        uint32_t nx = __shfl_down(r[j].x, 1);
+        uint32_t nx = from_lane_right(r[j].x);
         uint32_t nx0 = TOK_WS;
-        if (j + 1 < SLOT / 256) nx0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
+        if (j + 1 < SLOT / 256) nx0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
         if (lane == 63) nx = nx0;
         cand = cand || SELF(r[j].x, r[j].y) || SELF(r[j].y, r[j].z) || SELF(r[j].z, r[j].w) || SELF(r[j].w, nx);
       }
@@ -325,9 +325,9 @@ __device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint3
 #pragma unroll
   for (int j = 0; j < SLOT / 256; j++) {
     if (256 * j < n) {
-      uint32_t nx = __shfl_down(r[j].x, 1);
+      uint32_t nx = from_lane_right(r[j].x);
       uint32_t nx0 = TOK_WS;
-      if (j + 1 < SLOT / 256) nx0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
+      if (j + 1 < SLOT / 256) nx0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
       if (lane == 63) nx = nx0;
       const int p = 256 * j + 4 * lane;
       PAIR_EXACT(r[j].x, r[j].y, p)
@@ -426,11 +426,11 @@ __device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 2
   for (int j = 0; j < SLOT / 256; j++) {
     if (256 * j < n) {
       // first token of the lane to my right (lane 63: of the next row), and its flags; slots behind the tile's end hold zeros
-      uint32_t nx = __shfl_down(r[j].x, 1), fnx = __shfl_down(f[j].x, 1);
+      uint32_t nx = from_lane_right(r[j].x), fnx = from_lane_right(f[j].x);
       uint32_t nx0 = TOK_WS, fnx0 = 0;
       if (j + 1 < SLOT / 256) {
-        nx0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
-        fnx0 = __shfl(f[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
+        nx0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
+        fnx0 = from_lane0(f[j + 1 < SLOT / 256 ? j + 1 : j].x);
       }
       if (lane == 63) { nx = nx0; fnx = fnx0; }
       int p = 256 * j + 4 * lane;
@@ -534,9 +534,9 @@ __device__ inline bool single_site_tile(const uint4 (&r)[SLOT / 256], AggLds &A,
 #pragma unroll
   for (int j = 0; j < SLOT / 256; j++) {
     if (j >= jp && 256 * j < n) {
-      uint32_t nxt = __shfl_down(r[j].x, 1);  // first token of the lane to my right (lane 63: of the next row; zeros behind the end)
+      uint32_t nxt = from_lane_right(r[j].x);  // first token of the lane to my right (lane 63: of the next row; zeros behind the end)
       uint32_t nxt0 = 0;
-      if (j + 1 < SLOT / 256) nxt0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
+      if (j + 1 < SLOT / 256) nxt0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
       if (lane == 63) nxt = nxt0;
       const int q0 = 256 * j + 4 * lane;
       const uint4 o = r[j];
@@ -1214,8 +1214,8 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
   int j = 0;
   if (t < NT) {
     load_headers(t_batch);
-    tile_fetch<SLOT>(r, ts, uni(__shfl(ht, 0)), uni(__shfl(hn, 0)));
-    if (eager_w) wreg_load<SLOT>(wq, ts.wcnt, uni(__shfl(hw, 0)));
+    tile_fetch<SLOT>(r, ts, uni(from_lane0(ht)), uni(from_lane0(hn)));
+    if (eager_w) wreg_load<SLOT>(wq, ts.wcnt, uni(from_lane0(hw)));
   }
   while (t < NT) {
     const int n0 = uni(__shfl(hn, j));  // (uniform, and now the compiler knows: tile loops and branches run on the scalar unit)
@@ -1429,7 +1429,7 @@ __global__ __launch_bounds__(BLOCK) void k_cand_scan(PairTable pt, unsigned long
     if (m) {
       unsigned int base = 0;
       if (lane_id() == 0) base = atomicAdd(n_out, (unsigned int)__popcll(m));
-      base = __shfl(base, 0);
+      base = from_lane0(base);
       if (pass) {
         unsigned int o = base + (unsigned int)__popcll(m & lanemask_lt());
         if (o < cap) {
@@ -1589,7 +1589,7 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
     if (m) {
       unsigned int base = 0;
       if (lane_id() == 0) base = atomicAdd(n_out, (unsigned int)__popcll(m));
-      base = __shfl(base, 0);
+      base = from_lane0(base);
       if (pass) {
         const unsigned int o = base + (unsigned int)__popcll(m & lanemask_lt());
         if (o < cap) {
@@ -1683,7 +1683,7 @@ __global__ __launch_bounds__(BLOCK) void k_top_rebuild(PairTable pt) {
     if (m) {
       unsigned int base = 0;
       if (lane_id() == 0) base = atomicAdd(pt.top_n, (unsigned int)__popcll(m));
-      base = __shfl(base, 0);
+      base = from_lane0(base);
       if (top) {
         const unsigned int o = base + (unsigned int)__popcll(m & lanemask_lt());
         if (o < pt.top_cap) pt.top_slots[o] = sl;
@@ -1735,7 +1735,7 @@ __global__ __launch_bounds__(BLOCK) void k_hot_rebuild(PairTable pt) {
     if (m) {
       unsigned int base = 0;
       if (lane_id() == 0) base = atomicAdd(pt.hot_n, (unsigned int)__popcll(m));
-      base = __shfl(base, 0);
+      base = from_lane0(base);
       if (hot) {
         const unsigned int o = base + (unsigned int)__popcll(m & lanemask_lt());
         if (o < pt.hot_cap) pt.hot_slots[o] = (uint32_t)i;
@@ -1954,9 +1954,9 @@ __global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) 
 #pragma unroll
     for (int j = 0; j < SLOT / 256; j++) {
       if (256 * j < n) {
-        uint32_t nx = __shfl_down(r[j].x, 1);
+        uint32_t nx = from_lane_right(r[j].x);
         uint32_t nx0 = TOK_WS;
-        if (j + 1 < SLOT / 256) nx0 = __shfl(r[j + 1 < SLOT / 256 ? j + 1 : j].x, 0);
+        if (j + 1 < SLOT / 256) nx0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
         if (lane == 63) nx = nx0;
         // (slots behind the live prefix hold zeros: id 0 is a special token, never part of a pair of the index)
         IDX_PAIR(r[j].x, r[j].y)
