@@ -439,7 +439,7 @@ def _bench_encode(ctx, model_path, main_res):
     res = {"dropout": run(0.1)}  # configs[4]; parity for it is a distribution test (tests/test_gpu_parity.py), here: the rate and the mean length
     L.yttm_encoder_set_cache(h, 0, 0)
     direct = run(0.0)            # every word occurrence through K5, as the reference does
-    L.yttm_encoder_set_cache(h, 2, 4 << 20)
+    L.yttm_encoder_set_cache(h, 2, 8 << 20)
     res["encode"] = run(0.0)     # configs[3], the library's default path (word cache); last: its ids are the ones checked below
     words = int(L.yttm_encode_cache_words(h))
     res["encode"]["word_cache"] = {"distinct_words": words, "without_cache_sentences_per_s": direct["value"], "without_cache_kernel_ms": direct["kernel_ms"],
@@ -539,7 +539,7 @@ def _bench_encode_lines(ctx, model_path, text):
         return time.perf_counter() - t0, k_ms
     L.yttm_encoder_set_cache(h, 0, 0)  # every word occurrence through K5
     dt_direct, k_direct = timed()
-    L.yttm_encoder_set_cache(h, 2, 4 << 20)  # the default: distinct words once
+    L.yttm_encoder_set_cache(h, 2, 8 << 20)  # the default: distinct words once
     dt, k_ms = timed()
     words = int(L.yttm_encode_cache_words(h))
     ids = np.zeros(n_ids.value, dtype=np.int32)

@@ -70,7 +70,7 @@ class _Core:
             raise ValueError(err.value.decode())  # yttm.pyx:84-85
 
     # ---- word cache of the batch encoder (include/yttm_mi355x.h): 0 off, 1 whenever possible, 2 (default) from min_bytes up
-    def set_cache(self, mode, min_bytes=4 << 20):
+    def set_cache(self, mode, min_bytes=8 << 20):
         _lib.load().yttm_encoder_set_cache(self._h, int(mode), int(min_bytes))
 
     def cache_words(self):

@@ -86,7 +86,7 @@ struct EncoderDevice {
   // word cache: 0 = never, 1 = whenever it applies (no dropout), 2 = for batches of at least cache_min_bytes (YTTM_ENCODE_CACHE = 0 | 1;
   // YTTM_ENCODE_CACHE_MIN_MB moves the threshold)
   int cache_mode = 2;
-  unsigned long long cache_min_bytes = 4ull << 20;
+  unsigned long long cache_min_bytes = 8ull << 20;  // (tools/dbg/cache_crossover.py: text 0.9x at 4 MB, 1.1x at 8, 2.3x at 32, 3.2x at 128; random words break even at ~10 MB)
   static constexpr int N_LANES = 2;
   EncodeLane lane[N_LANES];
   std::atomic<unsigned int> next_lane{0};
