@@ -223,6 +223,8 @@ class GpuCtx {
   unsigned long long recv_cap_ = 0, blk_ = 4096, blk_min_ = 4096, send_cap_ = 0;
   unsigned int last_pack_hint_ = 1u << 16;
   void pack_deltas();
+  bool pt_fresh_ = false;  // build_class(0) left an empty pair table of the initial size
+  unsigned long long initial_table_keys(unsigned long long n_tok) const;
   unsigned long long *d_xstat_ = nullptr;  // [0] ranks whose block overflowed, [1] largest count, [2] hot-list overflow verdicts
   bool multi() const { return comm_ != nullptr; }  // (a communicator of world size 1 still runs the whole exchange path)
   void exchange_round(unsigned long long only_mask);
