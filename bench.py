@@ -160,6 +160,7 @@ def main():
     out["parity"]["model_matches_reference"] = main_res["model_ok"]
     if comm_handle is not None:
         out["rccl_ranks"] = world
+        out["config"]["parallelism"] = "one process per GPU; the corpus cut into %d byte ranges at white space; every rank keeps the whole pair table; per round one RCCL all-gather of per-pair delta blocks + one 8-byte all-reduce" % world
     model_path = main_res["model_path"]
     host = main_res.pop("host", None)
 
