@@ -317,7 +317,9 @@ __device__ inline bool bytes_equal(const uint8_t *__restrict__ text, unsigned lo
 }
 
 constexpr unsigned long long WH_POS_MASK = (1ull << 40) - 1;
-constexpr int WL_SLOTS = 128;  // per-workgroup LDS combiner for the most frequent words (measured at 1 GB, dedup ms abcd/Zipf: 32 slots 38/51, 128: 23/19, 256: 24/20, 512: 25/22, 2048: 37/31)
+constexpr int WL_SLOTS = 512;  // per-workgroup LDS combiner for the frequent words.  Dedup ms at 1 GB, abcd / Zipf -- round 1's kernel: 32 slots 38/51, 128: 23/19,
+                               // 256: 24/20, 512: 25/22, 2048: 37/31; with the 16-byte scan of round 2: 128: 13.4/10.4, 256: 9.9/6.5, 512: 9.9/5.8, 1024: 9.8/5.9,
+                               // 2048: 14.4/8.5 (LDS then limits the workgroups per CU); 512 slots with 8 probes instead of 4: 10.9/6.6
 // Word table in HBM: keys in ht[0 .. cap), counts in ht[cap .. 2 cap).  (One 16-byte slot per word was measured 2.3x slower:
 // the atomics on a frequent word's count then serialise with every other workgroup's read of its key -- same cache line.)
 //   key = pure:1 | tag:7 | min(tokens, 0xffff):16 | byte offset of the representative segment:40   (PT_EMPTY = free)
@@ -710,7 +712,7 @@ void launch_word_table_clear(unsigned long long *ht, unsigned long long n_slots,
 }
 void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *seg_pos,
                          unsigned long long n_segs, unsigned long long *ht, unsigned long long ht_mask, unsigned int *status, hipStream_t st) {
-  unsigned int g = grid_for(n_segs, BLOCK, 256 * 32);
+  unsigned int g = grid_for(n_segs, BLOCK, 256 * 32);  // (256 * 8: dedup 11.6 ms at 1 GB instead of 9.9; 256 * 64: 9.6)
   hipLaunchKernelGGL(k2b_insert_words, dim3(g), dim3(BLOCK), 0, st, text, n, cpmap, seg_pos, n_segs, ht, ht_mask, status);
 }
 void launch_compact_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *ht, unsigned long long n_slots,
