@@ -26,4 +26,8 @@ S.check_site_placements(trials=25, seed=8)
 many = ["ab" * k for k in range(60, 125, 13)] + ["a" * k for k in range(150, 250, 29)]
 S.check_merge_rounds((" ".join(many) + " ").encode(), rounds=5, seed=4)
 S.check_merge_rounds(S.texts_small(5, n=1, size=1200)[0], rounds=4, seed=1, id_shift=40000)
+# N4: the word cache's table, occurrence array, queues and the end-to-end tokenizer of K5's word mode
+S.check_encode_word_cache(n_sent=40)
+for t in S.texts_by_alphabet_size(sizes=(5, 33, 64, 70), n_words=200):  # K3's kernels
+    S.check_word_table_and_pairs(t)
 print("ASAN_SCENARIOS_OK")
