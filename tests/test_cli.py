@@ -47,11 +47,15 @@ def _roundtrip(tmp_path):
     assert many == out
     many = run_cli(["encode", f"--model={model}", "--output_type=subword"], test, env={"YTTM_CLI_BATCH_BYTES": "61"})
     assert many == run_cli(["encode", f"--model={model}", "--output_type=subword", "--stream"], test)
+    # the same through the batch encoder's word cache (batches of 8 MB and more take it by themselves)
+    assert run_cli(["encode", f"--model={model}", "--output_type=id", "--bos", "--eos"], test, env={"YTTM_ENCODE_CACHE": "1"}) == out
+    assert run_cli(["encode", f"--model={model}", "--output_type=subword"], test, env={"YTTM_ENCODE_CACHE": "1", "YTTM_CLI_BATCH_BYTES": "400"}) == many
     # the loops are bytes end to end: invalid UTF-8, a last line without newline, empty lines, CR
     odd = b"ab\xffcd ef\n\n  \nabc\r\n\xe2\x82 ab\xc0\x80cd\nlast line without newline ab"
     got = run_cli(["encode", f"--model={model}", "--output_type=id"], odd)
     want = O.Model(m_ora).encode(odd.split(b"\n"), False, False)
     assert got.decode() == "".join("".join(f"{t} " for t in row) + "\n" for row in want)
+    assert run_cli(["encode", f"--model={model}", "--output_type=id"], odd, env={"YTTM_ENCODE_CACHE": "1"}) == got
     import refbin
     if refbin.available("prod"):  # the unmodified reference's CLI loop output for the same bytes
         lines = str(tmp_path / "odd.txt")
