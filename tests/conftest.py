@@ -27,7 +27,10 @@ def sim_lib():
     """Builds tests/hipsim/_build/libyttm_sim.so (g++, product sources + emulator).  Skips when a real GPU is used."""
     if HAVE_GPU:
         pytest.skip("real GPU present: the emulator build is only used on GPU-less machines")
-    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "hipsim"), "-j8"], capture_output=True, text=True)
+    import fcntl
+    with open(os.path.join(ROOT, "tests", "hipsim", ".build.lock"), "w") as lock:  # (pytest-xdist: one worker builds, the others wait)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "hipsim"), "-j8"], capture_output=True, text=True)
     if r.returncode != 0:
         pytest.fail("hipsim build failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
     return SIM_LIB
