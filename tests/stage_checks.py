@@ -362,6 +362,46 @@ def check_encode_word_cache(n_sent=120, seed=17, model="readme_small"):
     assert core.cache_words() == 0
 
 
+def check_encode_word_cache_fuzz(tmp_path, trials=6, seed=23):
+    """N4 on models of other scripts: random multi-script text with invalid bytes, multi-byte spaces, unknown chars, sentences cut
+    at arbitrary byte positions (so that they start and end inside UTF-8 sequences) -- cache on == cache off == oracle."""
+    import random
+    import numpy as np
+    import youtokentome_amd as yttm
+    rng = random.Random(seed)
+    for it in range(trials):
+        kind = list(gen.UNICODE_ALPHABETS)[it % len(gen.UNICODE_ALPHABETS)]
+        text = gen.unicode_text(rng, rng.randint(1500, 4000), kind, p_invalid=0.02 if it % 2 else 0.0)
+        model = check_train_vs_oracle(text, rng.randint(60, 120), tmp_path, 0.9 if it % 2 else 1.0, (0, 1, 2, 3), tag=f"wc{it}")
+        if not model:
+            continue
+        # fresh text of the same script (+ chars the model does not know), U+2581 and tabs as extra spaces
+        raw = gen.unicode_text(rng, rng.randint(3000, 9000), kind, p_invalid=0.03)
+        other = gen.unicode_text(rng, 400, list(gen.UNICODE_ALPHABETS)[(it + 1) % len(gen.UNICODE_ALPHABETS)])
+        blob = bytearray()
+        for chunk in range(0, len(raw), 97):
+            blob += raw[chunk:chunk + 97]
+            r = rng.random()
+            if r < 0.3:
+                blob += rng.choice([b" ", b"\t", "\u2581".encode(), b"  "])
+            elif r < 0.4:
+                blob += other[rng.randint(0, 300):][:rng.randint(1, 12)]
+        blob = bytes(blob)
+        cuts = sorted(set([0, len(blob)] + [rng.randint(0, len(blob)) for _ in range(rng.randint(1, 60))]))
+        offs = np.array(cuts, np.uint64)
+        core = yttm.BPE(model).bpe_cython
+        m = O.Model(model)
+        for b, e, r in ((0, 0, 0), (1, 1, 1)):
+            want_ids, want_off = m.encode_blob(blob, offs, b, e, r)
+            core.set_cache(1)
+            ids1, off1 = core.encode_packed(blob, offs, b, e, r)
+            assert core.cache_words() > 0
+            core.set_cache(0)
+            ids0, off0 = core.encode_packed(blob, offs, b, e, r)
+            assert off1.tolist() == want_off.tolist() and ids1.tolist() == want_ids.tolist(), (it, kind, b, e, r)
+            assert off0.tolist() == want_off.tolist() and ids0.tolist() == want_ids.tolist(), (it, kind, b, e, r)
+
+
 def check_encode_mixed_shapes(n_sent=150, seed=11, model="readme_small"):
     """Shapes that steer the encode kernels: many short sentences per wavefront group, sentences that only partly fit a
     wavefront's LDS region, sentences beyond it (cooperative kernel on HBM scratch), words of every length class
