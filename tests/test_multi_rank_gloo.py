@@ -92,3 +92,21 @@ def test_world_of_one_runs_the_exchange_path(tmp_path, sim_lib):
     run_world(corpus, m_mp, 250, 1.0, 1, sim_lib)
     O.train(text, m_ora, 250, 1.0)
     assert filecmp.cmp(m_mp, m_ora, shallow=False)
+
+
+def test_delta_table_overflow_stops_every_rank(tmp_path, sim_lib):
+    """A rank whose per-round delta table (or send block) is too small cannot tell its peers what it changed: the record count in its
+    block's header says so, every rank reads it in the same all-gathered blocks and stops with the same error -- nobody is left waiting in a
+    collective the others never post (a hang instead of an error)."""
+    text = gen.readme_corpus(100, 80, seed=11)
+    corpus = str(tmp_path / "c.txt")
+    open(corpus, "wb").write(text)
+    port = str(free_port())
+    env = dict(os.environ, YTTM_AMD_LIB=sim_lib, YTTM_XCHG_TABLE_CAP="8")
+    world = 3
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_train_worker.py"), str(r), str(world), port, corpus, str(tmp_path / "m.model"), "250",
+                               "1.0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]  # (a hang would end here)
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 3, (p.returncode, o, e[-2000:])
+        assert "ERR" in o and "delta exchange" in o, o

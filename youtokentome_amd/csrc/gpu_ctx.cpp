@@ -832,6 +832,7 @@ void GpuCtx::pair_count() {
       // send block overflowed says so in its block's header and every rank stops
       unsigned long long cap = 1ull << 20;
       while (cap < n_tokens0 / 2 && cap < (1ull << 27)) cap <<= 1;
+      if (const unsigned int forced = env_uint("YTTM_XCHG_TABLE_CAP", 0)) cap = pow2_at_least(std::max(forced, 4u));  // (tests: a table that overflows)
       db_.keys = dmalloc<unsigned long long>(cap);
       db_.vals = dmalloc<long long>(cap);
       db_.touched = dmalloc<uint32_t>(cap);
