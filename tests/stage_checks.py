@@ -362,6 +362,40 @@ def check_encode_word_cache(n_sent=120, seed=17, model="readme_small"):
     assert core.cache_words() == 0
 
 
+def check_dropout_heap_equals_array(model="readme_small", seed=29):
+    """BPE-dropout keeps a word's merge events in a sorted array (short words) or a binary heap (words of 256 tokens and more: the array
+    costs O(events) per step).  Both hand the events out in the same order, so with the same seed the ids are the same -- for every word length,
+    probability and the two extremes; and a single word of 60 000 chars now takes no longer than the sentence around it."""
+    import random
+    import time
+    import youtokentome_amd as yttm
+    rng = random.Random(seed)
+    model_path = os.path.join(G, f"train_{model}.model")
+    sents = [" ".join("".join(rng.choice("abcd") for _ in range(rng.choice((1, 2, 3, 5, 8, 13, 40, 200, 255, 256, 257, 700)))) for _ in range(rng.randint(1, 6)))
+             for _ in range(60)] + ["", "a", "ab" * 300, "abcd" * 1500]
+    old = {k: os.environ.get(k) for k in ("YTTM_DROPOUT_SEED", "YTTM_DROPOUT_HEAP_FROM")}
+    try:
+        os.environ["YTTM_DROPOUT_SEED"] = "12345"
+        for p in (0.0, 0.1, 0.5, 0.9, 1.0):
+            got = []
+            for heap_from in ("1000000000", "0", "256"):
+                os.environ["YTTM_DROPOUT_HEAP_FROM"] = heap_from
+                bpe = yttm.BPE(model_path)  # (a fresh encoder: the draws are numbered per encoder and call)
+                got.append(bpe.encode(sents, yttm.OutputType.ID, dropout_prob=p))
+            assert got[0] == got[1] == got[2], p
+        os.environ["YTTM_DROPOUT_HEAP_FROM"] = "256"
+        bpe = yttm.BPE(model_path)
+        t0 = time.time()
+        ids = bpe.encode(["abcd" * 15000 + " ab"], yttm.OutputType.ID, dropout_prob=0.1)
+        assert len(ids[0]) > 1000 and time.time() - t0 < 60
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def check_encode_word_cache_fuzz(tmp_path, trials=6, seed=23):
     """N4 on models of other scripts: random multi-script text with invalid bytes, multi-byte spaces, unknown chars, sentences cut
     at arbitrary byte positions (so that they start and end inside UTF-8 sequences) -- cache on == cache off == oracle."""

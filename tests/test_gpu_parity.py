@@ -36,6 +36,10 @@ def test_k2_k3_word_table_and_pair_count():
         S.check_word_table_and_pairs(t)
 
 
+def test_k5_dropout_heap_equals_array():
+    S.check_dropout_heap_equals_array()
+
+
 def test_k5_word_cache():
     S.check_encode_word_cache(n_sent=2000)
 

@@ -232,6 +232,10 @@ def test_dropout_extremes_and_roundtrip():
     S.check_dropout_extremes(model, sents)
 
 
+def test_dropout_heap_equals_array():
+    S.check_dropout_heap_equals_array()
+
+
 def test_dropout_distribution_small():
     import os
     model = os.path.join(S.G, "train_readme_small.model")

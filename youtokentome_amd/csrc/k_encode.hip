@@ -79,6 +79,7 @@ struct DropoutArgs {
   unsigned long long thr;   // skip iff hash < thr  (thr = p * 2^64); always_skip for p == 1
   unsigned long long seed;
   int enabled, always_skip;
+  int heap_from;            // words of at least this many tokens keep their events in a binary heap instead of a sorted array
   uint32_t *wsl;            // [cap] word start positions
   unsigned long long *ev;   // [3*cap] sorted event queues, word w owns [3*ws, 3*we)
 };
@@ -94,6 +95,34 @@ __device__ inline void ev_insert(unsigned long long *ev, int &ne, unsigned long 
   int j = ne++;
   while (j > 0 && ev[j - 1] > key) { ev[j] = ev[j - 1]; j--; }
   ev[j] = key;
+}
+
+// The same queue as a binary min-heap, for long words: the sorted array costs O(queue) per insertion and removal -- a single word of
+// 80 000 chars (a base64 blob in the input) kept one lane busy for minutes.  Pops come in the same ascending order, so the draws
+// and the result are those of the array (DropoutQueue itself is a std::priority_queue plus the skipped events, bpe.cpp:1417-1453).
+__device__ inline void heap_push(unsigned long long *ev, int &nh, unsigned long long key) {
+  int i = nh++;
+  while (i > 0) {
+    const int p = (i - 1) >> 1;
+    if (ev[p] <= key) break;
+    ev[i] = ev[p];
+    i = p;
+  }
+  ev[i] = key;
+}
+__device__ inline unsigned long long heap_pop(unsigned long long *ev, int &nh) {
+  const unsigned long long top = ev[0], last = ev[--nh];
+  int i = 0;
+  for (;;) {
+    int c = 2 * i + 1;
+    if (c >= nh) break;
+    if (c + 1 < nh && ev[c + 1] < ev[c]) c++;
+    if (ev[c] >= last) break;
+    ev[i] = ev[c];
+    i = c;
+  }
+  if (nh > 0) ev[i] = last;
+  return top;
 }
 
 template <class A>
@@ -116,25 +145,45 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
     const int ws = (int)__hip_atomic_load(&d.wsl[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int we = w + 1 < nw ? (int)__hip_atomic_load(&d.wsl[w + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n;
     unsigned long long *ev = d.ev + 3 * (size_t)ws;
+    const int cap = 3 * (we - ws);             // the word's share of the queue space: every event it can ever hold
+    const bool heap = we - ws >= d.heap_from;  // (skipped events of a pop wait at the top end of that space)
     int ne = 0;
     for (int i = ws; i < we; i++) {
       wr.set(i, i + 1 < we ? (uint32_t)(i + 1) : NIL);
       wm.set(i, i > ws ? (uint32_t)(i - 1) : NIL);
     }
+    auto add = [&](unsigned long long key) {
+      if (heap) heap_push(ev, ne, key);
+      else ev_insert<A>(ev, ne, key);
+    };
     for (int i = ws; i + 1 < we; i++) {  // bpe.cpp:1556-1558
       const uint32_t slot = enc_rule_lookup(m, wt.get(i) & ENC_IDM, wt.get(i + 1) & ENC_IDM);
-      if (slot != ENC_INF) ev_insert<A>(ev, ne, ((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)i);
+      if (slot != ENC_INF) add(((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)i);
     }
     uint32_t draw = 0;
     for (;;) {
-      int acc = -1;
-      for (int j = 0; j < ne; j++) {
-        if (!drop_skip(d, sidx, (uint32_t)w, draw++)) { acc = j; break; }
+      unsigned long long e = 0;
+      if (heap) {
+        int ns = 0;
+        bool found = false;
+        while (ne > 0) {
+          e = heap_pop(ev, ne);
+          if (!drop_skip(d, sidx, (uint32_t)w, draw++)) { found = true; break; }
+          ev[cap - 1 - ns] = e;
+          ns++;
+        }
+        for (int k = 0; k < ns; k++) heap_push(ev, ne, ev[cap - 1 - k]);
+        if (!found) break;
+      } else {
+        int acc = -1;
+        for (int j = 0; j < ne; j++) {
+          if (!drop_skip(d, sidx, (uint32_t)w, draw++)) { acc = j; break; }
+        }
+        if (acc < 0) break;  // every event skipped: the word is finished (bpe.cpp:1431-1437)
+        e = ev[acc];
+        for (int j = acc; j + 1 < ne; j++) ev[j] = ev[j + 1];
+        ne--;
       }
-      if (acc < 0) break;  // every event skipped: the word is finished (bpe.cpp:1431-1437)
-      const unsigned long long e = ev[acc];
-      for (int j = acc; j + 1 < ne; j++) ev[j] = ev[j + 1];
-      ne--;
       const uint32_t rule = (uint32_t)(e >> 32);
       const int p1 = (int)(uint32_t)e;
       const uint32_t p2 = wr.get(p1);
@@ -149,11 +198,11 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
       if (p3 != NIL) wm.set((int)p3, (uint32_t)p1);
       if (p0 != NIL) {
         const uint32_t slot = enc_rule_lookup(m, wt.get((int)p0) & ENC_IDM, wt.get(p1) & ENC_IDM);
-        if (slot != ENC_INF) ev_insert<A>(ev, ne, ((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)p0);
+        if (slot != ENC_INF) add(((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)p0);
       }
       if (p3 != NIL) {
         const uint32_t slot = enc_rule_lookup(m, wt.get(p1) & ENC_IDM, wt.get((int)p3) & ENC_IDM);
-        if (slot != ENC_INF) ev_insert<A>(ev, ne, ((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)p1);
+        if (slot != ENC_INF) add(((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)p1);
       }
     }
   }
@@ -679,6 +728,7 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   d.always_skip = dropout_prob >= 1.0;
   d.thr = d.always_skip ? ~0ull : (unsigned long long)(dropout_prob * 18446744073709551616.0);
   d.seed = seed;
+  d.heap_from = getenv("YTTM_DROPOUT_HEAP_FROM") ? atoi(getenv("YTTM_DROPOUT_HEAP_FROM")) : 256;  // (tests: 0 = every word)
   d.wsl = drop_scratch;
   d.ev = nullptr;
   // sentences per wavefront group: large enough that packs are full, small enough that every wavefront of the launch has work
