@@ -734,7 +734,7 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   // sentences per wavefront group: large enough that packs are full, small enough that every wavefront of the launch has work
   unsigned long long group = n_sent / ((unsigned long long)n_blocks * ENC_WAVES * 4);
   if (group < 1) group = 1;
-  if (group > 24) group = 24;
+  if (group > (ends ? 64ull : 24ull)) group = ends ? 64 : 24;  // (the word cache's items are a few bytes each: a pack takes up to 64 of them)
   hipLaunchKernelGGL(k5_encode, dim3(n_blocks), dim3(ENC_THREADS), 0, st, m, text, SentView{offsets, ends}, n_sent, bos, eos, reverse, scratch_ids, counts, work,
                      work_stride, d, drop_stride, (unsigned int)group);
 }
