@@ -140,6 +140,15 @@ def check_merge_rounds(text, rounds=6, seed=0, coverage=1.0, id_shift=0):
     c.close()
 
 
+def check_many_words_per_tile(tmp_path):
+    """A tile whose words were merged down to one or two tokens and re-dealt by a repack holds more than the 256 words whose frequencies
+    K4 keeps in registers (here: 276 words in 447 tokens): the sites of the words behind them take theirs from HBM.  The corpus was found by
+    tools/soak_sim.py -- its model differed from the reference's from rule 217 on (those sites had been applied with frequency 0)."""
+    text = open(os.path.join(G, "soak_many_short_words.txt"), "rb").read()
+    check_merge_rounds(text, rounds=150, seed=0)
+    assert check_train_vs_oracle(text, 283, tmp_path, 1.0, (3, 2, 1, 0), tag="many")
+
+
 def check_k4_measure(text, rounds=6, seed=0):
     """The measurement pass behind bench.py's roofline.algorithmic_bytes_8d: words that hold a merge site and their tokens,
     summed over the rounds, against a count on the oracle's word table (and the tables still equal the oracle's)."""

@@ -48,6 +48,10 @@ def test_k5_word_cache_fuzz(tmp_path):
     S.check_encode_word_cache_fuzz(tmp_path, trials=12)
 
 
+def test_k4_many_words_per_tile(tmp_path):
+    S.check_many_words_per_tile(tmp_path)
+
+
 def test_k4_merge_apply_rounds():
     for i, t in enumerate(S.texts_small(2, n=6, size=8000)):
         if t.strip():

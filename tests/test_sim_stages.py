@@ -140,6 +140,10 @@ def test_encode_word_cache_fuzz(tmp_path):
     S.check_encode_word_cache_fuzz(tmp_path)
 
 
+def test_many_words_per_tile(tmp_path):
+    S.check_many_words_per_tile(tmp_path)
+
+
 def test_hot_list_rebuilds(tmp_path, monkeypatch):
     """The candidate filter reads a hot list of pairs instead of the whole pair table; shrink the list so that tiny corpora
     go through its rebuild, overflow and whole-table fallback paths, and demand the same models."""

@@ -1,0 +1,47 @@
+"""CPU soak: random corpora through the product sources under the HIP emulator against the oracle (byte-identical model files, identical
+encode ids with and without the word cache).  usage: python tools/soak_sim.py [seconds] [seed]"""
+import os, pathlib, random, sys, tempfile, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("YTTM_AMD_LIB", os.path.join(R, "tests", "hipsim", "_build", "libyttm_sim.so"))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import gen
+import stage_checks as S
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = random.Random(seed)
+tmp = pathlib.Path(tempfile.mkdtemp())
+t0, n = time.time(), 0
+devnull = os.open(os.devnull, os.O_WRONLY)
+os.dup2(devnull, 2)  # (the trainers print the reference's progress lines)
+while time.time() - t0 < budget:
+    kind = rng.choice(list(gen.UNICODE_ALPHABETS))
+    r = rng.random()
+    if r < 0.4:
+        text = gen.unicode_text(rng, rng.randint(200, 6000), kind, p_invalid=0.02 if rng.random() < 0.3 else 0.0)
+        cov = rng.choice([1.0, 1.0, 0.95, 0.9, 0.7])
+        if b"\xff" in text or cov == 1.0 and any(b >= 0x80 for b in text) and rng.random() < 0.0:
+            pass
+        if cov == 1.0 and any(x in text for x in (b"\x80", b"\xbf", b"\xc0", b"\xe2", b"\xf0", b"\xff", b"\xed")) and kind == "ascii":
+            cov = 0.9
+    elif r < 0.7:
+        text = gen.readme_corpus(rng.randint(20, 400), rng.randint(20, 120), rng.choice(["abcd ", "ab ", "abcdefgh  "]), seed=rng.randint(0, 10 ** 6))
+        cov = 1.0
+    else:
+        text = gen.zipf_corpus(rng.randint(5000, 80000), vocab=rng.randint(50, 3000), seed=rng.randint(0, 10 ** 6))
+        cov = 1.0
+    vocab = rng.randint(30, 400)
+    ids = rng.choice([(0, 1, 2, 3), (3, 2, 1, 0), (-1, 0, -1, -1), (5, 7, -1, 2)])
+    try:
+        model = S.check_train_vs_oracle(text, vocab, tmp, cov, ids, tag=f"s{n}")
+    except Exception:
+        open(tmp / f"FAIL_{n}.txt", "wb").write(text)
+        print("FAIL train", n, kind, vocab, cov, ids, tmp, flush=True)
+        raise
+    if model and rng.random() < 0.5:
+        sents = [gen.unicode_text(rng, rng.randint(0, 80), kind).decode(errors="ignore").replace("\n", " ") for _ in range(12)] + ["", " "]
+        for cache in ("0", "1"):
+            os.environ["YTTM_ENCODE_CACHE"] = cache
+            S.check_encode_vs_oracle(model, sents)
+    n += 1
+print("soak ok:", n, "corpora in %.0f s" % (time.time() - t0), flush=True)

@@ -774,7 +774,12 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
           wave_sync();
           const bool have = base + lane < nsites;
           const int p = have ? (int)W.sitepos[lane] : 0;
-          const long long f = word_weight_all<SLOT>(wreg, tile_word_index_rl<SLOT>(W, p));  // (all lanes: shuffles)
+          const uint32_t widx = tile_word_index_rl<SLOT>(W, p);
+          long long f = word_weight_all<SLOT>(wreg, widx);  // (all lanes: shuffles)
+          // The registers hold the frequencies of the tile's first 64 N words -- every word of a fresh tile (a word has at least two
+          // tokens then).  Merged down to one or two tokens and re-dealt by a repack, more words than that can share a tile: theirs come
+          // from HBM.  (Found by tools/soak_sim.py: 276 words in one tile, the sites of words 256.. applied with frequency 0.)
+          if (have && widx >= 64u * (uint32_t)WReg<SLOT>::N) f = (long long)ts.wcnt[word0 + widx];
           bool v0 = false, v1 = false, v2 = false, v3 = false, v4 = false;
           unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0;
           long long d0 = 0, d2 = 0, d4 = 0;
