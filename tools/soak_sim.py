@@ -1,5 +1,5 @@
 """CPU soak: random corpora through the product sources under the HIP emulator against the oracle (byte-identical model files, identical
-encode ids with and without the word cache).  usage: python tools/soak_sim.py [seconds] [seed]"""
+encode ids with and without the word cache).  usage: python tools/soak_sim.py [seconds] [seed] [big]"""
 import os, pathlib, random, sys, tempfile, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("YTTM_AMD_LIB", os.path.join(R, "tests", "hipsim", "_build", "libyttm_sim.so"))
@@ -9,6 +9,7 @@ import stage_checks as S
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 rng = random.Random(seed)
 tmp = pathlib.Path(tempfile.mkdtemp())
 t0, n = time.time(), 0
@@ -31,12 +32,23 @@ while time.time() - t0 < budget:
         text = gen.zipf_corpus(rng.randint(5000, 80000), vocab=rng.randint(50, 3000), seed=rng.randint(0, 10 ** 6))
         cov = 1.0
     vocab = rng.randint(30, 400)
+    if big:  # larger tables (several tiles, repacks, the pair index) and the tuning hooks that force the rare paths
+        if r >= 0.7:
+            text = gen.zipf_corpus(rng.randint(60000, 400000), vocab=rng.randint(500, 20000), seed=rng.randint(0, 10 ** 6))
+        vocab = rng.randint(200, 3000)
+        for k in ("YTTM_INDEX_ALWAYS", "YTTM_NO_FUSE", "YTTM_HOT_TARGET", "YTTM_HOT_MIN", "YTTM_HOT_CAP", "YTTM_TOP_TARGET", "YTTM_TOP_MIN", "YTTM_TOP_CAP",
+                  "YTTM_INDEX_MIN_TILES", "YTTM_WORD_TABLE_FULL"):
+            os.environ.pop(k, None)
+        hooks = rng.choice([{}, {"YTTM_INDEX_ALWAYS": "1", "YTTM_INDEX_MIN_TILES": "1"}, {"YTTM_NO_FUSE": "1"},
+                            {"YTTM_HOT_TARGET": "8", "YTTM_HOT_MIN": "3", "YTTM_HOT_CAP": "32"}, {"YTTM_TOP_TARGET": "4", "YTTM_TOP_MIN": "2", "YTTM_TOP_CAP": "16"},
+                            {"YTTM_INDEX_ALWAYS": "1", "YTTM_INDEX_MIN_TILES": "1", "YTTM_TOP_TARGET": "16", "YTTM_TOP_MIN": "4", "YTTM_TOP_CAP": "64"}])
+        os.environ.update(hooks)
     ids = rng.choice([(0, 1, 2, 3), (3, 2, 1, 0), (-1, 0, -1, -1), (5, 7, -1, 2)])
     try:
         model = S.check_train_vs_oracle(text, vocab, tmp, cov, ids, tag=f"s{n}")
     except Exception:
         open(tmp / f"FAIL_{n}.txt", "wb").write(text)
-        print("FAIL train", n, kind, vocab, cov, ids, tmp, flush=True)
+        print("FAIL train", n, kind, vocab, cov, ids, tmp, {k: v for k, v in os.environ.items() if k.startswith("YTTM_")}, flush=True)
         raise
     if model and rng.random() < 0.5:
         sents = [gen.unicode_text(rng, rng.randint(0, 80), kind).decode(errors="ignore").replace("\n", " ") for _ in range(12)] + ["", " "]
