@@ -1,5 +1,5 @@
 """CPU soak: random corpora through the product sources under the HIP emulator against the oracle (byte-identical model files, identical
-encode ids with and without the word cache).  usage: python tools/soak_sim.py [seconds] [seed] [big]"""
+encode ids with and without the word cache).  usage: python tools/soak_sim.py [seconds] [seed] [big|long]"""
 import os, pathlib, random, sys, tempfile, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("YTTM_AMD_LIB", os.path.join(R, "tests", "hipsim", "_build", "libyttm_sim.so"))
@@ -10,6 +10,7 @@ import stage_checks as S
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
+long_words = len(sys.argv) > 3 and sys.argv[3] == "long"
 rng = random.Random(seed)
 tmp = pathlib.Path(tempfile.mkdtemp())
 t0, n = time.time(), 0
@@ -32,6 +33,20 @@ while time.time() - t0 < budget:
         text = gen.zipf_corpus(rng.randint(5000, 80000), vocab=rng.randint(50, 3000), seed=rng.randint(0, 10 ** 6))
         cov = 1.0
     vocab = rng.randint(30, 400)
+    if long_words:  # words of the tile classes B (257 .. 2048 tokens) and C (longer), many of them, merged far down: repacks of class B
+        sigma = rng.choice(["ab", "abc", "abcd"])
+        ws = []
+        for _ in range(rng.randint(20, 260)):
+            n_ch = rng.choice([rng.randint(250, 300), rng.randint(300, 700), rng.randint(1, 30), rng.randint(2040, 2060), rng.randint(2100, 5000)] if rng.random() < 0.15
+                              else [rng.randint(256, 420), rng.randint(1, 40)])
+            if rng.random() < 0.3:
+                w = (rng.choice(sigma) * rng.randint(1, 5) + rng.choice(sigma) * rng.randint(1, 5)) * (n_ch // 4 + 1)
+            else:
+                w = "".join(rng.choice(sigma) for _ in range(n_ch))
+            ws.append(w[:n_ch])
+        text = (" ".join(ws) + "\n").encode() * rng.randint(1, 3)
+        cov = 1.0
+        vocab = rng.randint(100, 2500)
     if big:  # larger tables (several tiles, repacks, the pair index) and the tuning hooks that force the rare paths
         if r >= 0.7:
             text = gen.zipf_corpus(rng.randint(60000, 400000), vocab=rng.randint(500, 20000), seed=rng.randint(0, 10 ** 6))
