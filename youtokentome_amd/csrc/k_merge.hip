@@ -590,8 +590,10 @@ __device__ inline uint32_t chunk_word_index(const WaveLds<SLOT> &W, int c) {
   const unsigned long long wm = uni64(W.wsmask[c]);
   return uni(W.wsbase[c]) + lanes_below(wm) + (lane_bit(wm) ? 1u : 0u) - 1u;
 }
-// Frequencies of ALL words of a tile travel with it in registers: lane j holds words j, j+64, ... (a class-A tile has at
-// most SLOT/2 words, a class-B tile -- words of more than TILE_NOM_A tokens -- at most 16).  They are loaded together with
+// Frequencies of the first 64 N words of a tile travel with it in registers: lane j holds words j, j+64, ... -- ALL words of a
+// freshly built tile (a class-A tile then has at most SLOT/2 words, a class-B tile -- words of more than TILE_NOM_A tokens -- at
+// most 16); once words have been merged down and a repack has re-dealt them a tile can hold more, and phase 2 reads the
+// frequencies of those behind the window from HBM (process_tile).  They are loaded together with
 // the tokens, one tile ahead, and read by cross-lane shuffles: the gather from HBM that this replaces cost ~6 us per
 // active chunk late in training (random 4-byte reads into a 64 MB array: a TLB miss almost every time).
 template <int SLOT>
@@ -834,7 +836,8 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
         K4_MARK(5);
         if (instr) {
           // measurement pass: the words that hold a site, and how many tokens they have (what the contract's roofline formula
-          // calls W_touched and T_touched).  A class-A tile has at most SLOT/2 words: their bits fit the site list's space.
+          // calls W_touched and T_touched).  One bit per word of the tile in the site list's space: 1024 bits, enough for every class-A
+          // tile (<= SLOT words); a re-dealt class-B tile with more words than that would only blur this statistic.
           uint32_t *bm = reinterpret_cast<uint32_t *>(W.sitepos);
           if (lane < 32) bm[lane] = 0u;
           wave_sync();
