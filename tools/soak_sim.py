@@ -19,7 +19,10 @@ os.dup2(devnull, 2)  # (the trainers print the reference's progress lines)
 while time.time() - t0 < budget:
     kind = rng.choice(list(gen.UNICODE_ALPHABETS))
     r = rng.random()
-    if r < 0.4:
+    if not big and not long_words and rng.random() < 0.25:  # the reference's own stress generator (stress_test.cpp:272-311), longer
+        text = ("\n".join(gen.stress_text(rng, rng.randint(50, 1000), True) for _ in range(rng.randint(1, 12))) + "\n").encode()
+        cov = 1.0
+    elif r < 0.4:
         text = gen.unicode_text(rng, rng.randint(200, 6000), kind, p_invalid=0.02 if rng.random() < 0.3 else 0.0)
         cov = rng.choice([1.0, 1.0, 0.95, 0.9, 0.7])
         if b"\xff" in text or cov == 1.0 and any(b >= 0x80 for b in text) and rng.random() < 0.0:
