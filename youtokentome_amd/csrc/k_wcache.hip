@@ -24,7 +24,8 @@ constexpr uint32_t WC_NONE = 0xffffffffu;                // occ value: no word s
 constexpr int WC_MAX_PROBES = 512;
 constexpr unsigned int WC_CBLK = BLOCK * 8;              // table slots per workgroup of the compaction kernels
 
-// bytes [pos, pos + 8) of the text, for any alignment of pos (text itself is 8-byte aligned, 24 bytes behind pos & ~7 readable)
+// bytes [pos, pos + 8) of the text, for any alignment of pos (the text itself is 8-byte aligned; the caller has checked that the 16 bytes from
+// pos & ~7 on lie inside it)
 __device__ inline unsigned long long wc_load8(const uint8_t *__restrict__ text, unsigned long long pos) {
   const unsigned long long *base = reinterpret_cast<const unsigned long long *>(text + (pos & ~7ull));
   const unsigned long long lo = base[0], hi = base[1];
