@@ -1,5 +1,5 @@
 """CPU soak: random corpora through the product sources under the HIP emulator against the oracle (byte-identical model files, identical
-encode ids with and without the word cache).  usage: python tools/soak_sim.py [seconds] [seed] [big|long]"""
+encode ids with and without the word cache).  usage: python tools/soak_sim.py [seconds] [seed] [big|long|rounds]"""
 import os, pathlib, random, sys, tempfile, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("YTTM_AMD_LIB", os.path.join(R, "tests", "hipsim", "_build", "libyttm_sim.so"))
@@ -11,6 +11,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
 long_words = len(sys.argv) > 3 and sys.argv[3] == "long"
+rounds_mode = len(sys.argv) > 3 and sys.argv[3] == "rounds"
 rng = random.Random(seed)
 tmp = pathlib.Path(tempfile.mkdtemp())
 t0, n = time.time(), 0
@@ -36,6 +37,17 @@ while time.time() - t0 < budget:
         text = gen.zipf_corpus(rng.randint(5000, 80000), vocab=rng.randint(50, 3000), seed=rng.randint(0, 10 ** 6))
         cov = 1.0
     vocab = rng.randint(30, 400)
+    if rounds_mode:  # K4 alone: random batches, the whole pair table and word table against an oracle recount after every round; ids
+        # around and beyond the 32 768 that fit the kernels' LDS flag bitmap
+        try:
+            S.check_merge_rounds(text, rounds=rng.randint(3, 60), seed=rng.randint(0, 10 ** 6), coverage=cov if cov in (1.0, 0.9) else 1.0,
+                                 id_shift=rng.choice([0, 0, 32700, 32760, 40000, 1 << 20]))
+        except Exception:
+            open(tmp / f"FAIL_{n}.txt", "wb").write(text)
+            print("FAIL rounds", n, kind, tmp, flush=True)
+            raise
+        n += 1
+        continue
     if long_words:  # words of the tile classes B (257 .. 2048 tokens) and C (longer), many of them, merged far down: repacks of class B
         sigma = rng.choice(["ab", "abc", "abcd"])
         ws = []
