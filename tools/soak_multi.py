@@ -1,5 +1,5 @@
 """CPU soak of the N>1 path: random corpora trained by 2-4 ranks (gloo, product sources under the HIP emulator) against the oracle on the
-whole corpus.  usage: python tools/soak_multi.py [seconds] [seed]"""
+whole corpus.  usage: python tools/soak_multi.py [seconds] [seed] [big]"""
 import filecmp, os, pathlib, random, sys, tempfile, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -10,6 +10,7 @@ import test_multi_rank_gloo as M
 lib = os.path.join(R, "tests", "hipsim", "_build", "libyttm_sim.so")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 tmp = pathlib.Path(tempfile.mkdtemp())
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
@@ -21,7 +22,11 @@ while time.time() - t0 < budget:
     else:
         text = gen.zipf_corpus(rng.randint(5000, 60000), vocab=rng.randint(50, 2000), seed=rng.randint(0, 10 ** 6))
     vocab, world = rng.randint(30, 400), rng.choice([2, 2, 3, 4])
-    env = rng.choice([{}, {"YTTM_XCHG_BLK_MIN": "2"}, {"YTTM_HOT_TARGET": "8", "YTTM_HOT_MIN": "3", "YTTM_HOT_CAP": "32"}, {"YTTM_TOP_TARGET": "4", "YTTM_TOP_MIN": "2", "YTTM_TOP_CAP": "16"}])
+    if big:
+        if r >= 0.7:
+            text = gen.zipf_corpus(rng.randint(60000, 300000), vocab=rng.randint(500, 20000), seed=rng.randint(0, 10 ** 6))
+        vocab = rng.randint(200, 2500)
+    env = rng.choice([{}, {"YTTM_XCHG_BLK_MIN": "2"}, {"YTTM_INDEX_ALWAYS": "1", "YTTM_INDEX_MIN_TILES": "1"}, {"YTTM_XCHG_BLK_MIN": "2", "YTTM_INDEX_ALWAYS": "1", "YTTM_INDEX_MIN_TILES": "1"}, {"YTTM_HOT_TARGET": "8", "YTTM_HOT_MIN": "3", "YTTM_HOT_CAP": "32"}, {"YTTM_TOP_TARGET": "4", "YTTM_TOP_MIN": "2", "YTTM_TOP_CAP": "16"}])
     corpus, m_mp, m_ora = str(tmp / f"c{n}.txt"), str(tmp / f"mp{n}.model"), str(tmp / f"ora{n}.model")
     open(corpus, "wb").write(text)
     try:
