@@ -92,6 +92,35 @@ def test_merge_apply_small_alphabets_random():
         S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=rng.randint(3, 14), seed=trial)
 
 
+def test_merge_apply_position_parallel_kernel(monkeypatch):
+    """YTTM_K4_PM=1: class-A tiles through k_apply.hip (pair filter, position-major site search, site records applied 64 at a time)
+    instead of k_tiles -- the same checks: word table and whole pair table against an oracle recount after every round."""
+    monkeypatch.setenv("YTTM_K4_PM", "1")
+    for i, t in enumerate(S.texts_small(2, n=3, size=1500)):
+        if t.strip():
+            S.check_merge_rounds(t, rounds=5, seed=i)
+    t = ("aaaa aaaaa aaaaaaa abababab aabbaabb abcabcabc bbbbbb ab aaab baaa aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa " * 3).encode()
+    S.check_merge_rounds(t, rounds=12, seed=1)
+    S.check_merge_rounds(t, rounds=10, seed=1, id_shift=33000)
+    rng = random.Random(2025)
+    for trial in range(25):
+        alpha = "abcde"[: rng.choice([2, 2, 3, 3, 4, 5])]
+        words = ["".join(rng.choice(alpha) for _ in range(rng.choice([1, 2, 3, 5, 8, 13, 30, 80, 200]))) for _ in range(rng.randint(5, 250))]
+        words = [w for w in words for _ in range(rng.randint(1, 3))]
+        rng.shuffle(words)
+        S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=rng.randint(3, 14), seed=trial)
+    S.check_site_placements(trials=40, seed=5)
+    words = ["ab" * k for k in range(60, 125, 7)] + ["a" * k for k in range(150, 250, 13)] + ["abc" * k for k in (50, 70, 80)]
+    S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=8, seed=4)
+
+
+def test_train_position_parallel_kernel(monkeypatch, tmp_path):
+    monkeypatch.setenv("YTTM_K4_PM", "1")
+    for name in ("readme_small", "runs", "zipf", "stress3"):
+        S.check_golden_train(name, tmp_path)
+    assert S.check_many_words_per_tile(tmp_path) is None
+
+
 def test_merge_apply_site_placements():
     S.check_site_placements(trials=100, seed=3)
 

@@ -138,7 +138,7 @@ static T *dmalloc(size_t n) {
 
 constexpr unsigned int CAND_CAP = 1u << 20;
 constexpr unsigned int HOT_CAP = 1u << 18;  // hot-list slots (entries appended between rebuilds included)
-constexpr unsigned int TOP_CAP = 1u << 13;  // top-list slots
+constexpr unsigned int TOP_CAP = 1u << 15;  // top-list slots
 // a rebuild picks the threshold that lists about HOT_TARGET pairs; fewer live entries than HOT_MIN: lower the threshold.
 // YTTM_HOT_TARGET / YTTM_HOT_MIN / YTTM_HOT_CAP override them (the test-suite shrinks them to exercise rebuilds on tiny corpora).
 static unsigned int env_uint(const char *name, unsigned int dflt) {
@@ -172,13 +172,14 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   idx_sparse_div_ = env_uint("YTTM_INDEX_SPARSE_DIV", 8);         //  use the index when the last round touched fewer than 1/this of the tiles;
                                                                   //  measured at 1 GB, K4 + candidate family ms: no index 151.1, 64/4 147.3, 128/4 148.8, 64/8 145.1, 32/8 147.8, 256/3 160.6)
   idx_force_ = env_uint("YTTM_INDEX_ALWAYS", 0) != 0;  // (tests: worklists from the index whenever the batch allows, however few tiles)
+  use_pm_ = env_uint("YTTM_K4_PM", 0) != 0;
   no_batch_args_ = getenv("YTTM_NO_BATCH_ARGS") != nullptr;  // (read once per context: a round has no time for getenv)
   trace_rounds_ = getenv("YTTM_TRACE_ROUNDS");
   dbg_cand_ = getenv("YTTM_DBG_CAND");
   d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);
   d_hot_n_ = dmalloc<unsigned int>(4);  // [0] list length, [1] k_hot_scan's finished-workgroup ticket, [2..3] overflow verdict (u64)
   HIP_CHECK(hipMemset(d_hot_n_, 0, 16));
-  top_cap_ = std::max(16u, std::min(env_uint("YTTM_TOP_CAP", TOP_CAP), TOP_CAP));
+  top_cap_ = std::max(16u, std::min(env_uint("YTTM_TOP_CAP", 1u << 13), TOP_CAP));
   top_target_ = env_uint("YTTM_TOP_TARGET", 1024);  // about four times what the host looks at per round
   top_min_ = env_uint("YTTM_TOP_MIN", 192);
   d_top_slots_ = dmalloc<uint32_t>(TOP_CAP);
@@ -210,7 +211,7 @@ GpuCtx::~GpuCtx() {
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_); DFREE(d_flagbits_);
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_); DFREE(d_top_slots_); DFREE(d_top_n_); DFREE(d_box_);
-  DFREE(d_send_); DFREE(d_xstat_);
+  DFREE(d_send_); DFREE(d_xstat_); DFREE(d_bloom_);
   DFREE(db_.keys); DFREE(db_.vals); DFREE(db_.touched); DFREE(db_.n);
   free_table(pt_);
   free_index();
@@ -1377,8 +1378,12 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     return cls_[ci].n_tiles <= 8192 || (touched_last_ != (~0ull >> 2) && touched_last_ * 100 >= (unsigned long long)n_tiles * (unsigned long long)dense_pct);
   };
   const bool no_batch_args = no_batch_args_;
-  const bool by_args = k <= (uint32_t)BATCH_ARGS_MAX && vmax < FLAG_LDS_IDS && !cls_[2].n_tiles && (!cls_[0].n_tiles || dense_class(0)) &&
-                       (!cls_[1].n_tiles || dense_class(1)) && !no_batch_args;
+  // class A goes through the position-parallel kernel (k_apply.hip: its own pair filter, no flag tables, no filter pass) unless this
+  // is the measurement pass (the word statistics live in the old kernel) or YTTM_K4_OLD asks for the old one (A/B runs)
+  const bool pm = use_pm_ && !instrument;
+  const bool by_args = k <= (uint32_t)BATCH_ARGS_MAX && !cls_[2].n_tiles && !no_batch_args &&
+                       (pm || (vmax < FLAG_LDS_IDS && (!cls_[0].n_tiles || dense_class(0)))) &&
+                       (!cls_[1].n_tiles || (vmax < FLAG_LDS_IDS && dense_class(1)));
   unsigned int n_upd = 0;
   if (!by_args) {  // (the common small batch needs none of this: the host's share of a round is on the critical path)
     for (unsigned int i = 0; i < cap; i++) { h_rules[i].key = PT_EMPTY; h_rules[i].z = 0; h_rules[i].pad = 0; }
@@ -1444,9 +1449,16 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     fused_round_ = sa.round_id;
   }
   t_begin(KT_MERGE);
-  if (!by_args)
+  if (!by_args) {
+    uint32_t *h_bloom = nullptr;
+    if (pm && cap > 512 && cls_[0].n_tiles) {  // (more slots than the apply kernel's LDS rule hash: the batch's pair filter comes from here)
+      h_bloom = (uint32_t *)(pin + (size_t)RULES_CAP * sizeof(RuleSlot) + 8 * (size_t)RULES_CAP * sizeof(uint32_t));
+      pm_bloom_host(h_bloom, xyz, k);
+      if (!d_bloom_) d_bloom_ = dmalloc<uint32_t>(PM_BLOOM_WORDS_H);
+    }
     launch_round_begin(h_rules, cap, d_rules_, h_upd, n_upd, d_tokflag_, d_flagbits_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr,
-                       cls_[1].n_tiles ? cls_[1].d_work_n : nullptr, st_);
+                       cls_[1].n_tiles ? cls_[1].d_work_n : nullptr, h_bloom, d_bloom_, st_);
+  }
   if (gathered) {  // class A: the tiles of the batch's postings, each once
     HIP_CHECK(hipMemsetAsync(cls_[0].d_work_n, 0, 64, st_));
     launch_gather(idx_, d_rules_, cap, by_args ? &ba : nullptr, self_x, d_stamp_, (uint32_t)(merge_rounds + 1), cls_[0].d_worklist, cls_[0].n_tiles,
@@ -1456,6 +1468,13 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   for (int ci = 0; ci < 2; ci++) {
     if (!cls_[ci].n_tiles) continue;
     const bool wl_gathered = gathered && ci == 0;
+    if (ci == 0 && pm) {
+      const bool eager_w = touched_last_ == (~0ull >> 2) || touched_last_ * 2 >= cls_[0].n_tiles;
+      pm_rounds++;
+      launch_apply_pm(cls_[0].ts, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, wl_gathered ? cls_[0].d_worklist : nullptr,
+                      cls_[0].d_work_n, d_stats_, &ba, sa.on ? &sa : nullptr, eager_w, st_);
+      continue;
+    }
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
                        cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/!wl_gathered && (by_args || dense_class(ci)),
                        &ba, ci == 0 && sa.on ? &sa : nullptr, wl_gathered, st_);

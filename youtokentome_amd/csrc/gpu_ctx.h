@@ -84,7 +84,7 @@ class GpuCtx {
   const unsigned long long *last_hist() const { return last_hist_; }
   unsigned long long last_live() const { return last_live_; }
   int last_top_bin() const { return (int)last_top_bin_; }  // no bin above this one is in use
-  unsigned long long index_builds = 0, gathered_rounds = 0;  // K4 rounds whose worklist came from the pair index
+  unsigned long long index_builds = 0, gathered_rounds = 0, pm_rounds = 0;  // K4 rounds whose worklist came from the pair index
   unsigned long long word_table_retries = 0;  // K2: the word table had to be redone with the worst-case size
   unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0;
   unsigned long long tail_ticks[3] = {0, 0, 0}, tail_listed = 0;  // round_tail: fold / list scan / publish, in 10 ns ticks; entries it read
@@ -137,6 +137,8 @@ class GpuCtx {
   unsigned long long fused_tau_ = 0;  // ... for this threshold
   uint32_t fused_mx_ = 0, fused_round_ = 0;
   bool no_batch_args_ = false;
+  bool use_pm_ = false;           // YTTM_K4_PM=1: class-A tiles through the position-parallel kernel (k_apply.hip) instead of k_tiles
+  uint32_t *d_bloom_ = nullptr;   // pair filter of a batch too large for the apply kernel's LDS rule hash
   const char *trace_rounds_ = nullptr, *dbg_cand_ = nullptr;
   bool fuse_enabled_ = true;  // YTTM_NO_FUSE=1: always the separate scan kernel (tuning hook / tests)
   uint32_t id_min_ = 0, id_max_ = 0;  // id range of the alphabet (K3)

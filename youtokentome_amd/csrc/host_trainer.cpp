@@ -102,6 +102,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   // through the mailbox and the heap (natural text: batches of ~8 rules, random text: ~50).  YTTM_CAND_TARGET fixes it (tuning hook).
   const unsigned long long target_fixed = getenv("YTTM_CAND_TARGET") ? strtoull(getenv("YTTM_CAND_TARGET"), nullptr, 10) : 0;
   unsigned long long TARGET = target_fixed ? target_fixed : 256;
+  const double target_max = getenv("YTTM_CAND_MAX") ? atof(getenv("YTTM_CAND_MAX")) : 512.0;
   double batch_ema = 64;
   const uint32_t MX_ALL = 0xffffffffu;
   unsigned long long tau = 1;
@@ -110,7 +111,9 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   std::vector<Cand> heap;
   std::vector<uint32_t> batch_xyz;
   std::vector<unsigned long long> batch_cnt;
-  unsigned long long rounds = 0, rescans = 0;
+  unsigned long long rounds = 0, rescans = 0, rounds_exhausted = 0, batch_extensions = 0;
+  const bool extend_on = !getenv("YTTM_NO_EXTEND");  // (tuning hook / A-B runs)
+  std::vector<unsigned long long> batch_keys;
   double w_cand = 0, w_pick = 0, w_apply = 0;
   std::vector<uint8_t> in_batch((size_t)vocab_size + 1, 0);  // bit0: token is the x of a batch rule, bit1: the y
   while (used_ids < (uint64_t)vocab_size) {
@@ -165,13 +168,16 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     batch_xyz.clear();
     batch_cnt.clear();
     const size_t max_batch = 4096;
+    bool closed = false;  // by an intersection, an x x rule, or because the vocabulary is full
+    int extensions_this_round = 0;
+    for (;;) {
     while (!heap.empty() && used_ids + batch_cnt.size() < (uint64_t)vocab_size && batch_cnt.size() < max_batch) {
       std::pop_heap(heap.begin(), heap.end(), HeapCmp());
       const Cand c = heap.back();
       heap.pop_back();
       // rule_intersection (bpe.cpp:145-147) against every earlier rule of the batch: x == some y_j or y == some x_j
       const bool intersects = (in_batch[c.x] & 2) || (in_batch[c.y] & 1);
-      if (intersects) break;  // its exact count after the earlier rules is unknown: close the batch here
+      if (intersects) { closed = true; break; }  // its exact count after the earlier rules is unknown: close the batch here
       in_batch[c.x] |= 1;
       in_batch[c.y] |= 2;
       const uint32_t z = (uint32_t)(used_ids + batch_cnt.size());
@@ -180,10 +186,39 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       batch_xyz.push_back(z);
       batch_cnt.push_back(c.cnt);
       if (root && z % 1000 == 0) fprintf(stderr, "id: %u=%u+%u  freq: %llu\n", z, c.x, c.y, c.cnt);  // cf. bpe.cpp:1198-1219
-      if (c.x == c.y) break;  // a self-pair rule must be the last of its batch
+      if (c.x == c.y) { closed = true; break; }  // a self-pair rule must be the last of its batch
+    }
+      if (used_ids + batch_cnt.size() >= (uint64_t)vocab_size || batch_cnt.size() >= max_batch) closed = true;
+      if (closed || !heap.empty()) break;
+      // The candidates ran out before an intersection closed the batch: the rules picked so far are exact, and so is every further
+      // one taken from a LARGER complete prefix of the order -- the counts have not changed, nothing was applied yet.  One more scan
+      // with a lower threshold (a launch of its own, ~20 us) instead of a whole merge round for what may be a handful of rules.
+      if (heap.empty() && extend_on && !closed && extensions_this_round < 4 && used_ids + batch_cnt.size() < (uint64_t)vocab_size &&
+          batch_cnt.size() < max_batch && total_pairs > n) {
+        const unsigned long long want = std::max<unsigned long long>(4ull * n, 2048ull);
+        const unsigned long long tau2 = choose_tau(g.last_hist(), want, g.last_top_bin());
+        if (tau2 < tau) {
+          const uint32_t n2 = g.candidates(tau2, MX_ALL, recs, nullptr);
+          extensions_this_round++;
+          if (n2 > n && n2 <= recs.size()) {
+            batch_extensions++;
+            batch_keys.clear();
+            for (size_t j = 0; j < batch_cnt.size(); j++) batch_keys.push_back(((unsigned long long)batch_xyz[3 * j] << 32) | batch_xyz[3 * j + 1]);
+            std::sort(batch_keys.begin(), batch_keys.end());
+            for (uint32_t i = 0; i < n2; i++)
+              if (!std::binary_search(batch_keys.begin(), batch_keys.end(), recs[i].key))
+                heap.push_back(Cand{recs[i].cnt, (uint32_t)(recs[i].key >> 32), (uint32_t)recs[i].key});
+            std::make_heap(heap.begin(), heap.end(), HeapCmp());
+            n = n2;
+            tau = tau2;
+          }
+        }
+      }
+      if (heap.empty()) break;
     }
     const uint32_t k = (uint32_t)batch_cnt.size();
-    const bool exhausted = heap.empty();  // the batch ended for lack of candidates, not at an intersection: ask for more next time
+    const bool exhausted = !closed;  // the batch ended for lack of candidates, not at an intersection: ask for more next time
+    if (exhausted) rounds_exhausted++;
     for (uint32_t j = 0; j < k; j++) in_batch[batch_xyz[3 * j]] = in_batch[batch_xyz[3 * j + 1]] = 0;
     w_pick += since(tw1);
     auto tw2 = clk::now();
@@ -194,22 +229,26 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     rounds++;
     if (!target_fixed) {
       batch_ema = exhausted ? std::max(batch_ema, 2.0 * (double)k) : 0.9 * batch_ema + 0.1 * (double)k;
-      TARGET = (unsigned long long)std::min(512.0, std::max(32.0, 4.0 * batch_ema));
+      TARGET = (unsigned long long)std::min(target_max, std::max(32.0, 4.0 * batch_ema));
     }
     // next threshold: keep about TARGET candidates above it (any threshold is valid, see above)
     tau = tau_hint;
     tau_mx = MX_ALL;
   }
-  if (rep) {
-    rep->seconds_merge = since(t_merge);
+  {
+    if (rep) rep->seconds_merge = since(t_merge);
     if (getenv("YTTM_TRACE") && g.fused_rounds)
       fprintf(stderr, "[yttm] fused rounds %llu: tail set-up %.2f us, top-list scan %.2f us (%.0f entries), publish %.2f us per round\n", g.fused_rounds,
               g.tail_ticks[0] * 0.01 / g.fused_rounds, g.tail_ticks[1] * 0.01 / g.fused_rounds, (double)g.tail_listed / g.fused_rounds,
               g.tail_ticks[2] * 0.01 / g.fused_rounds);
-    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu, hot rebuilds %llu, top refills %llu, index builds %llu (%llu rounds from the index), pair table %llu keys in %llu slots (%llu rehashes)\n",
-                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.hot_rebuilds, g.top_refills, g.index_builds, g.gathered_rounds, g.n_keys_host, g.table_capacity(), g.rehashes);
+    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu, hot rebuilds %llu, top refills %llu, index builds %llu (%llu rounds from the index, %llu through k_apply_pm), pair table %llu keys in %llu slots (%llu rehashes)\n",
+                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.hot_rebuilds, g.top_refills, g.index_builds, g.gathered_rounds, g.pm_rounds, g.n_keys_host, g.table_capacity(), g.rehashes);
+  }
+  if (rep) {
     rep->rounds = rounds;
     rep->cand_rescans = rescans;
+    rep->rounds_exhausted = rounds_exhausted;
+    rep->batch_extensions = batch_extensions;
     rep->hot_rebuilds = g.hot_rebuilds;
     rep->fused_rounds = g.fused_rounds;
     rep->fused_overflows = g.fused_overflows;

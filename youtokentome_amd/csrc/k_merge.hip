@@ -24,16 +24,10 @@
 
 #include "yttm_device.h"
 #include "yttm_kernels.h"
+#include "k_merge_shared.h"
 
 namespace yttm {
 
-constexpr int AGG_SLOTS = 512;   // LDS delta aggregator shared by the waves of a workgroup (hot pairs).  256 slots: 1.05e8 emits of rounds 12-100 at 1 GB
-                                 // found no room and went to the HBM table one by one (K4 135 ms); 512: 123 ms; 704: 124; 1024 (two workgroups per CU): 156.
-                                 // The probe loop stays at 8, unrolled: 12 -> 127 ms, 24 -> 253 (!), not unrolled -> 135
-// The worklist of dirty tiles is kept in WL_PARTS sub-lists (workgroup b of the filter appends to list b % WL_PARTS, each
-// list WL_SEG(n_tiles) entries apart): one cursor bumped by all 1280 workgroups of a launch cost 14 us per round.
-constexpr uint32_t WL_PARTS = 8;
-__host__ __device__ inline size_t WL_SEG(uint32_t n_tiles) { return (size_t)n_tiles + 64; }
 
 // Staged (LDS) token word: bit31 = first token of a word, bit30 = id is the y of some batch rule, bit29 = id is the x
 // of some batch rule, bits 0..28 = id.  HBM tokens carry only bit31 + id.
@@ -62,10 +56,6 @@ struct AggLds {
 #endif
 };
 
-__device__ inline void global_emit(const PairTable &pt, const DeltaBuf &db, unsigned long long key, long long delta, unsigned int *new_keys) {
-  pt_add(pt, key, delta, new_keys);
-  dt_add(db, key, delta);  // (multi-GPU: the same update, for the other ranks)
-}
 
 // Count deltas of hot pairs are summed in a small LDS hash shared by the workgroup before they become HBM atomics
 // (cdna guide, Guideline 12): early in training there are few distinct pairs with huge counts, and without the hash
@@ -96,51 +86,6 @@ __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, co
 #endif
 }
 
-// Per-workgroup statistics.  A launch of >= 1024 workgroups that each bump the same global counters serialises at
-// ~11 ns per atomic (measured: +10 us per launch at 1024 workgroups, +47 us at 4096), a floor under every short kernel of
-// a late round.  So workgroup b adds to its own row stats[BLK_BASE + 8 b + j] with plain stores (launches on the stream
-// are serial), and one workgroup folds the rows into the totals when somebody needs them (fold_blk_stats).
-constexpr int BLK_BASE = 32, BLK_ROWS = 1536;  // >= the largest grid of k_filter / k_tiles<.., true>  // j: 0..3 = the K4 counters, 4 = pair-table slots claimed
-__device__ inline void blk_add(unsigned long long *stats, int j, unsigned long long v) {
-  // (the row is this workgroup's alone; the store is write-through because the round's tail may read it from another XCD before
-  // any cache write-back -- see round_tail)
-  unsigned long long *p = &stats[BLK_BASE + 8 * (blockIdx.x % BLK_ROWS) + j];
-  if (v) __hip_atomic_store(p, *p + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// called by ONE workgroup of 256 threads, all threads; ends with the totals in stats[0..3] and *n_keys
-__device__ inline void fold_blk_stats(unsigned long long *stats, unsigned int *n_keys) {
-  __shared__ unsigned long long fold_acc[5];
-  if (threadIdx.x < 5) fold_acc[threadIdx.x] = 0;
-  __syncthreads();
-  unsigned long long a[5] = {0, 0, 0, 0, 0};
-  for (int b = (int)threadIdx.x; b < BLK_ROWS; b += (int)blockDim.x) {
-    unsigned long long *row = stats + BLK_BASE + 8 * b;  // written by earlier kernels: plain 16-byte loads
-    const uint4 v01 = *reinterpret_cast<const uint4 *>(row), v23 = *reinterpret_cast<const uint4 *>(row + 2);
-    const unsigned long long v4 = row[4];
-    const unsigned long long v[5] = {((unsigned long long)v01.y << 32) | v01.x, ((unsigned long long)v01.w << 32) | v01.z,
-                                     ((unsigned long long)v23.y << 32) | v23.x, ((unsigned long long)v23.w << 32) | v23.z, v4};
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      a[j] += v[j];
-      any = any || v[j] != 0;
-    }
-    if (any) {
-      const uint4 z{0u, 0u, 0u, 0u};
-      *reinterpret_cast<uint4 *>(row) = z;
-      *reinterpret_cast<uint4 *>(row + 2) = z;
-      row[4] = 0;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 5; j++)
-    if (a[j]) atomicAdd(&fold_acc[j], a[j]);
-  __syncthreads();
-  if (threadIdx.x < 4 && fold_acc[threadIdx.x]) stats[threadIdx.x] += fold_acc[threadIdx.x];
-  if (threadIdx.x == 4 && fold_acc[4]) *n_keys += (unsigned int)fold_acc[4];
-  __threadfence();
-  __syncthreads();
-}
 
 template <int NT>
 __device__ inline void agg_init(AggLds &A, const uint32_t *__restrict__ flagbits_g) {
@@ -189,22 +134,6 @@ __device__ inline void tile_fetch(uint4 (&r)[SLOT / 256], const TileSet &ts, uin
 // Exact membership test of a pair in the batch (k_filter): the x/y flags are per token, so with k rules in the batch up
 // to k*k flagged adjacencies exist of which k are rules; late in training two thirds of the flag-dirty tiles hold no
 // merge site at all.  Keys of the batch's rule hash sit in LDS when they fit (FILTER_LDS_KEYS slots), else in L2.
-constexpr unsigned int FILTER_LDS_KEYS = 1024;
-struct RuleProbe {
-  const unsigned long long *lds_keys;  // [mask+1] or nullptr
-  const RuleSlot *g;                   // the same hash in HBM; nullptr = no exact test
-  unsigned int mask;
-  __device__ bool has(uint32_t a, uint32_t b) const {
-    const unsigned long long key = pair_key(a, b);
-    unsigned int h = pair_hash32(key) & mask;
-    for (;;) {
-      const unsigned long long k = lds_keys ? __hip_atomic_load(&lds_keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : g[h].key;
-      if (k == key) return true;
-      if (k == PT_EMPTY) return false;
-      h = (h + 1) & mask;
-    }
-  }
-};
 
 // The batch's rule hash as the apply kernel sees it: in LDS when it fits (the usual case: <= APPLY_LDS_RULES/2 rules), so
 // that processing a tile issues NO global load -- any such load would also wait (vmcnt is in-order) for the prefetch of
@@ -893,183 +822,6 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
     }
 }
 
-// ------------------------------------------------------------------------------------------------- fused candidate scan
-__device__ inline int cand_bin(unsigned long long c) {
-  if (c < 256) return (int)c;
-  int e = 63 - __clzll((long long)c);  // >= 8
-  int m3 = (int)((c >> (e - 3)) & 7ull);
-  return 256 + (e - 8) * 8 + m3;
-}
-
-
-// The candidate scan of a merge round: ONE workgroup reads the top list (PairTable::top_slots, about a thousand entries).
-// Run by the LAST workgroup of the apply kernel to finish (ScanArgs, yttm_kernels.h; every other workgroup has published its
-// updates as device-scope atomics or write-through stores and then taken its ticket, nothing else touches the pair table), or as
-// a kernel of its own (k_top_scan) where a round is more than one launch.
-//   1. the top list: zero the pairs of the batch just applied (every occurrence was merged), histogram the live counts, collect
-//      the candidates above the host's threshold, and COMPACT the list in place: an entry whose count fell below top_tau leaves
-//      the list (PT_TOP cleared, so it can come back).  TAIL_E entries per thread and pass, two dependent memory round trips
-//      per pass (slot numbers, then records) with all loads of a round trip in flight together.
-//   2. header, histogram and the first `fast` candidates go to `box` -- the host's pinned mailbox (then the round id is
-//      published there, system-scope release: the host polls instead of copying and synchronising), or, multi-GPU, a staging
-//      block in HBM that k_publish_box forwards after the ranks' all-reduce.
-//   3. last, off the critical path: the per-workgroup statistics rows are folded into the totals and the key count
-// Box layout: [0] candidates, [4] keys in the table, [8] top-list entries before the scan, [12] of those still >= top_tau,
-// [16] hot-list entries (overflow check), [32] round id, [40] tokens streamed so far, [48] tiles with a site so far, [56..87]
-// xstat (multi-GPU), [96..127] timing marks (100 MHz), [MB_HIST..) histogram, [8192..) candidates.
-// lds = at least (CAND_BINS + 80) words of scratch (the apply kernel's tile buffers are free by now).
-template <int NT>
-__device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigned long long *__restrict__ stats, const RuleProbe &zprobe,
-                                unsigned long long zself, unsigned int *lds, unsigned long long *__restrict__ xstat) {
-  constexpr int NW = NT / 64;
-  unsigned int *lh = lds;                     // [CAND_BINS]
-  unsigned int *wcount = lds + CAND_BINS;     // [NW] kept entries per wave of this pass
-  unsigned int *ctl = lds + CAND_BINS + 32;   // [0] kept so far, [1] candidates, [2] live entries
-  unsigned long long *facc = reinterpret_cast<unsigned long long *>(lds + CAND_BINS + 40);  // [5] fold accumulators
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned long long tm0 = (unsigned long long)wall_clock64();
-  for (int b = tid; b < CAND_BINS; b += NT) lh[b] = 0;
-  if (tid < 4) ctl[tid] = 0;  // ([3]: highest histogram bin in use)
-  if (tid < 5) facc[tid] = 0;
-  __syncthreads();
-  const unsigned long long tm1 = (unsigned long long)wall_clock64();
-  // ---- 2. the top list
-  const unsigned int tn_raw = __hip_atomic_load(pt.top_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned int hot_raw = __hip_atomic_load(pt.hot_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const bool overflow = tn_raw > pt.top_cap;  // entries were dropped: the host refills the list, nothing to scan
-  const unsigned int tn = overflow ? 0u : tn_raw;
-  uint4 *box_out = reinterpret_cast<uint4 *>(sa.mailbox + 8192);
-  constexpr int TAIL_E = 8;
-  unsigned int my_live = 0;
-  for (unsigned int base = 0; base < tn; base += NT * TAIL_E) {
-    uint32_t sl[TAIL_E];
-    unsigned long long k[TAIL_E], c[TAIL_E];
-#pragma unroll
-    for (int e = 0; e < TAIL_E; e++) {
-      const unsigned int i = base + (unsigned int)(e * NT + tid);
-      sl[e] = i < tn ? __hip_atomic_load(&pt.top_slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-    }
-#pragma unroll
-    for (int e = 0; e < TAIL_E; e++) {
-      k[e] = PT_EMPTY;
-      c[e] = 0;
-      if (sl[e] != 0xffffffffu) {
-        k[e] = ld_agent(pt.key_p(sl[e]));
-        c[e] = ld_agent(pt.cnt_p(sl[e]));
-      }
-    }
-    uint32_t keepm = 0;  // bit e: entry e stays on the list
-#pragma unroll
-    for (int e = 0; e < TAIL_E; e++) {
-      if (sl[e] == 0xffffffffu) continue;
-      unsigned long long cc = c[e] & PT_CNT;
-      if (cc && (k[e] == zself || zprobe.has((uint32_t)(k[e] >> 32), (uint32_t)k[e]))) cc = 0;  // a pair of the finished batch
-      const bool keep = cc >= pt.top_tau && cc > 0;
-      const unsigned long long want = (c[e] & PT_HOT) | (keep ? PT_TOP : 0ull) | cc;  // a dropped entry loses PT_TOP and can come back
-      if (want != c[e]) *pt.cnt_p(sl[e]) = want;
-      if (keep) {
-        keepm |= 1u << e;
-        my_live++;
-        const int bin = cand_bin(cc);
-        atomicAdd(&lh[bin], 1u);
-        if ((unsigned int)bin > ctl[3]) atomicMax(&ctl[3], (unsigned int)bin);
-        const uint32_t x = (uint32_t)(k[e] >> 32), y = (uint32_t)k[e];
-        const uint32_t mx = x > y ? x : y;
-        if (cc > sa.tau_cnt || (cc == sa.tau_cnt && mx <= sa.tau_mx)) {
-          const unsigned int o = atomicAdd(&ctl[1], 1u);
-          if (o < sa.cap) {
-            sa.out[o].key = k[e];
-            sa.out[o].cnt = cc;
-          }
-          if (o < sa.fast) {
-            uint4 vv;
-            vv.x = (uint32_t)k[e]; vv.y = (uint32_t)(k[e] >> 32); vv.z = (uint32_t)cc; vv.w = (uint32_t)(cc >> 32);
-            box_out[o] = vv;
-          }
-        }
-      }
-    }
-    // compaction: the kept entries of this pass move down behind those of the earlier passes (any order)
-    const uint32_t mine = (uint32_t)__popc(keepm);
-    const uint32_t incl = wave_incl_scan(mine);
-    if (lane == 63) wcount[wave] = incl;
-    __syncthreads();  // every entry of this pass has been read
-    unsigned int pos = ctl[0] + incl - mine;
-    for (int w = 0; w < wave; w++) pos += wcount[w];
-#pragma unroll
-    for (int e = 0; e < TAIL_E; e++)
-      if ((keepm >> e) & 1u) pt.top_slots[pos++] = sl[e];
-    __syncthreads();
-    if (tid == 0) {
-      unsigned int t = 0;
-      for (int w = 0; w < NW; w++) t += wcount[w];
-      ctl[0] += t;
-    }
-    __syncthreads();
-  }
-  {
-    const unsigned long long t = wave_sum_u64((unsigned long long)my_live);
-    if (lane == 0 && t) atomicAdd(&ctl[2], (unsigned int)t);
-  }
-  __syncthreads();
-  // ---- 3. publish
-  const unsigned long long tm2 = (unsigned long long)wall_clock64();
-  unsigned int *hdr = reinterpret_cast<unsigned int *>(sa.mailbox);
-  unsigned long long *box_hist = reinterpret_cast<unsigned long long *>(sa.mailbox + MB_HIST);
-  if (tid == 0) {
-    hdr[0] = ctl[1];
-    hdr[1] = __hip_atomic_load(pt.n_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    hdr[2] = tn_raw;
-    hdr[3] = ctl[2];
-    hdr[4] = hot_raw;
-    hdr[5] = ctl[3];  // the host reads the histogram from here down (every line of the pinned mailbox it touches is a cache miss)
-    *reinterpret_cast<unsigned long long *>(sa.mailbox + 40) = stats[2];  // tokens streamed so far (repack trigger)
-    *reinterpret_cast<unsigned long long *>(sa.mailbox + 48) = stats[1];  // tiles that held a merge site so far
-    if (!overflow) *pt.top_n = ctl[0];
-    if (sa.done_ctr) *sa.done_ctr = 0;
-    if (xstat) xstat[2] = (hot_raw > pt.hot_cap ? 1ull : 0ull) + (overflow ? (1ull << 32) : 0ull);  // this rank's list verdicts (summed over the ranks)
-    unsigned long long *tmark = reinterpret_cast<unsigned long long *>(sa.mailbox + 96);
-    tmark[0] = tm0; tmark[1] = tm1; tmark[2] = tm2; tmark[3] = (unsigned long long)wall_clock64();
-  }
-  if (tid >= 6 && tid < 10) *reinterpret_cast<unsigned long long *>(sa.mailbox + 56 + 8 * (tid - 6)) = 0;  // (multi-GPU fields: k_publish fills them)
-  for (int b = tid; b < CAND_BINS; b += NT) box_hist[b] = (unsigned long long)lh[b];
-  if (sa.round_id) {  // (0: a staging block, k_publish_box forwards it)
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(&hdr[8], sa.round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  // ---- 4. the statistics rows, AFTER the host has its candidates: the fold is off the round's critical path (the key count
-  // and the token totals in the header are therefore one round old; the host allows for that)
-  {  // statistics rows (left by the workgroups of this and earlier launches, write-through): all loads in flight together
-    constexpr int RPT = (BLK_ROWS + NT - 1) / NT;
-    unsigned long long v[RPT][5];
-#pragma unroll
-    for (int r = 0; r < RPT; r++) {
-      const int b = tid + r * NT;
-#pragma unroll
-      for (int jj = 0; jj < 5; jj++)
-        v[r][jj] = b < BLK_ROWS ? __hip_atomic_load(&stats[BLK_BASE + 8 * b + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    }
-    unsigned long long a[5] = {0, 0, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < RPT; r++) {
-      const int b = tid + r * NT;
-#pragma unroll
-      for (int jj = 0; jj < 5; jj++) {
-        a[jj] += v[r][jj];
-        if (v[r][jj]) stats[BLK_BASE + 8 * b + jj] = 0;
-      }
-    }
-#pragma unroll
-    for (int jj = 0; jj < 5; jj++) {
-      const unsigned long long t = wave_sum_u64(a[jj]);
-      if (lane == 0 && t) atomicAdd(&facc[jj], t);
-    }
-    __syncthreads();
-    if (tid < 4 && facc[tid]) stats[tid] += facc[tid];
-    if (tid == 4 && facc[4]) atomicAdd(pt.n_keys, (unsigned int)facc[4]);
-  }
-}
 
 template <int SLOT, int WPB, bool MERGE, bool LDSR>
 __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WPB) : WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
@@ -1862,8 +1614,11 @@ __global__ __launch_bounds__(BLOCK) void k_set_tokflag(uint8_t *__restrict__ tok
 __global__ __launch_bounds__(BLOCK) void k_round_begin(const RuleSlot *__restrict__ src_rules, unsigned int n_slots, RuleSlot *__restrict__ dst_rules,
                                                        const uint32_t *__restrict__ upd, unsigned int n_upd, uint8_t *__restrict__ tokflag,
                                                        uint32_t *__restrict__ flagbits, unsigned int *__restrict__ work_n_a,
-                                                       unsigned int *__restrict__ work_n_b) {
+                                                       unsigned int *__restrict__ work_n_b, const uint32_t *__restrict__ src_bloom,
+                                                       uint32_t *__restrict__ dst_bloom) {
   const unsigned int tid = blockIdx.x * BLOCK + threadIdx.x, nt = gridDim.x * BLOCK;
+  if (src_bloom)  // (k_apply.hip: the pair filter of a batch too large for the apply kernel's LDS rule hash)
+    for (unsigned int i = tid; i < (unsigned int)PM_BLOOM_WORDS_H; i += nt) dst_bloom[i] = src_bloom[i];
   for (unsigned int i = tid; i < n_slots; i += nt)
     reinterpret_cast<uint4 *>(dst_rules)[i] = reinterpret_cast<const uint4 *>(src_rules)[i];
   for (unsigned int i = tid; i < n_upd; i += nt) {
@@ -2402,12 +2157,15 @@ void launch_set_tokflag(uint8_t *tokflag, uint32_t *flagbits, const uint32_t *up
   hipLaunchKernelGGL(k_set_tokflag, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, tokflag, flagbits, upd, n);
 }
 void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, const uint32_t *upd, unsigned int n_upd,
-                        uint8_t *tokflag, uint32_t *flagbits, unsigned int *work_n_a, unsigned int *work_n_b, hipStream_t st) {
+                        uint8_t *tokflag, uint32_t *flagbits, unsigned int *work_n_a, unsigned int *work_n_b, const uint32_t *src_bloom,
+                        uint32_t *dst_bloom, hipStream_t st) {
   unsigned int work = n_slots > n_upd ? n_slots : n_upd;
+  if (src_bloom && work < (unsigned int)PM_BLOOM_WORDS_H) work = PM_BLOOM_WORDS_H;
   unsigned int b = (work + BLOCK - 1) / BLOCK;
   if (b < 1) b = 1;
   if (b > 64) b = 64;
-  hipLaunchKernelGGL(k_round_begin, dim3(b), dim3(BLOCK), 0, st, src_rules, n_slots, dst_rules, upd, n_upd, tokflag, flagbits, work_n_a, work_n_b);
+  hipLaunchKernelGGL(k_round_begin, dim3(b), dim3(BLOCK), 0, st, src_rules, n_slots, dst_rules, upd, n_upd, tokflag, flagbits, work_n_a, work_n_b, src_bloom,
+                     dst_bloom);
 }
 __global__ __launch_bounds__(BLOCK) void k_pt_clear(uint4 *__restrict__ slots, unsigned long long n) {
   unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;

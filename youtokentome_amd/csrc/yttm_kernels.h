@@ -83,6 +83,14 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
                         uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
                         const ScanArgs *scan /* class A only */, bool wl_gathered /* the worklist was filled by launch_gather: no filter pass */,
                         hipStream_t st);
+// class-A tiles: the position-parallel apply kernel (k_apply.hip).  bloom_g: the batch's pair filter when the batch is too large
+// for the kernel to build it from its LDS rule hash (rule_mask >= 512 slots; PM_BLOOM_WORDS words, made by pm_bloom_host), else unused.
+// eager_w: most tiles of the launch will hold a site (their word frequencies are loaded together with the tokens).
+constexpr int PM_BLOOM_WORDS_H = 2048;
+void pm_bloom_host(uint32_t *bloom, const uint32_t *xyz, uint32_t k);
+void launch_apply_pm(const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
+                     uint32_t self_x, uint32_t self_z, uint32_t z_base, const uint32_t *worklist, const unsigned int *work_n, unsigned long long *stats,
+                     const BatchArgs *ba, const ScanArgs *scan, bool eager_w, hipStream_t st);
 // pair index for K4's worklists (k_merge.hip: PairIndex)
 struct PairIndexArgs {
   unsigned long long *key, *off;
@@ -110,7 +118,8 @@ constexpr int MB_HIST = 128;  // byte offset of the count histogram in the mailb
 void launch_fold_stats(unsigned long long *stats, unsigned int *n_keys, hipStream_t st);
 constexpr int STATS_WORDS = 32 + 8 * 1536;  // totals + one row per workgroup (k_merge.hip: BLK_BASE, BLK_ROWS)
 void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, const uint32_t *upd, unsigned int n_upd,
-                        uint8_t *tokflag, uint32_t *flagbits, unsigned int *work_n_a, unsigned int *work_n_b, hipStream_t st);
+                        uint8_t *tokflag, uint32_t *flagbits, unsigned int *work_n_a, unsigned int *work_n_b, const uint32_t *src_bloom,
+                        uint32_t *dst_bloom, hipStream_t st);
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st);
 // class C (k_giant.hip): K3 (merge=false) / K4 (merge=true) for tiles of words longer than TILE_NOM_B tokens; scratch = 4*slot
 // uint32 per tile
