@@ -69,6 +69,32 @@ def test_k4_merge_apply_rounds():
     S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=8, seed=4)
 
 
+def test_k4_measurement_pass():
+    """The instrument behind bench.py's roofline.algorithmic_bytes_8d (words that held a merge site and their tokens, SURVEY.md 8d:
+    W_touched / T_touched) against a count on the oracle's word table -- on the MI355X, not only on the emulator."""
+    for i, t in enumerate(S.texts_small(3, n=3, size=8000) + [gen.readme_corpus(1500, 100, seed=4)]):
+        if t.strip():
+            S.check_k4_measure(t, rounds=10, seed=i)
+    words = ["ab" * k for k in range(60, 125, 7)] + ["a" * k for k in range(150, 250, 13)]
+    S.check_k4_measure((" ".join(words) + " ").encode(), rounds=6, seed=1)
+
+
+def test_k4_position_parallel_kernel(tmp_path, monkeypatch):
+    """YTTM_K4_PM=1: class-A tiles through k_apply.hip instead of k_tiles (opt-in): same parity bar."""
+    monkeypatch.setenv("YTTM_K4_PM", "1")
+    for i, t in enumerate(S.texts_small(2, n=4, size=8000)):
+        if t.strip():
+            S.check_merge_rounds(t, rounds=8, seed=i)
+    S.check_merge_rounds(gen.readme_corpus(1500, 100, seed=9), rounds=25, seed=3)
+    t = ("aaaa aaaaa aaaaaaa abababab aabbaabb abcabcabc bbbbbb ab aaab baaa " + "a" * 700 + " " + "ab" * 500 + " ") * 3
+    S.check_merge_rounds(t.encode(), rounds=14, seed=1)
+    S.check_site_placements(trials=100, seed=9)
+    S.check_merge_rounds(S.texts_small(5, n=1, size=8000)[0], rounds=8, seed=0, id_shift=40000)
+    for name in ("readme_small", "runs", "mix_cov", "zipf"):
+        S.check_golden_train(name, tmp_path)
+    S.check_train_vs_oracle(gen.zipf_corpus(2_000_000, seed=3, vocab=30000), 4000, tmp_path, tag="pm")
+
+
 def test_k4_worklist_mode(tmp_path, monkeypatch):
     """K4 with a separate filter pass and a worklist of candidate tiles (YTTM_DENSE_PCT; off by default)."""
     monkeypatch.setenv("YTTM_DENSE_PCT", "1000")

@@ -843,8 +843,8 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += WPB * 64) A.flagbits[s] = 0;
     for (unsigned int i = threadIdx.x; i <= rule_mask; i += WPB * 64) rkeys[i] = PT_EMPTY;
     __syncthreads();
-    if (threadIdx.x < ba.k) {
-      const uint32_t x = ba.xy[2 * threadIdx.x], y = ba.xy[2 * threadIdx.x + 1];
+    for (unsigned int j = threadIdx.x; j < ba.k; j += WPB * 64) {  // (class B: one wave per workgroup)
+      const uint32_t x = ba.xy[2 * j], y = ba.xy[2 * j + 1];
       if (x != y) {
         atomicOr(&A.flagbits[x >> 4], 1u << ((x & 15u) * 2));
         atomicOr(&A.flagbits[y >> 4], 2u << ((y & 15u) * 2));
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
         unsigned int h = pair_hash32(key) & rule_mask;
         for (;;) {
           if (atomicCAS(&rkeys[h], PT_EMPTY, key) == PT_EMPTY) {
-            rridx[h] = (uint16_t)threadIdx.x;
+            rridx[h] = (uint16_t)j;
             break;
           }
           h = (h + 1) & rule_mask;
@@ -1063,7 +1063,14 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     // Everything this workgroup leaves for the tail went out as device-scope atomics or write-through stores (pair table, hot
     // list, statistics row), so the ticket only has to wait until those have completed -- a workgroup-scope release: an
     // agent-scope one would also write the XCD's L2 back, once per workgroup (measured: +150 us per round at 768 workgroups).
+    // (Publishing needs those operations COMPLETE: every wave drains its memory operations -- s_waitcnt vmcnt(0), written out because
+    // the compiler may drop the wait of a fence it thinks has nothing to wait for -- before one lane takes the ticket with an agent-scope
+    // atomic.  MI355X_MICROARCH.md lists "sc1 payload -> vmcnt(0) -> flag" among the valid cross-CU hand-offs; the reader side is the
+    // agent-scope acquire below plus agent-scope loads.  tools/dbg/fuse_check.py diffs the candidate traces of fused and unfused runs.)
     __shared__ unsigned int is_last;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) is_last = atomicAdd(sa.done_ctr, 1u) == gridDim.x - 1;
@@ -1281,12 +1288,12 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
   __shared__ unsigned long long zkeys[FILTER_LDS_KEYS];
   const bool zero_any = zrules != nullptr || zba.k != 0;
   bool zkeys_in_lds = zrules && zmask < FILTER_LDS_KEYS;
-  if (zba.k) {  // the batch came as a kernel argument: build the key table here (128 slots for <= 32 rules)
-    zmask = 127;
+  if (zba.k) {  // the batch came as a kernel argument: build the key table here (4 slots per possible rule)
+    zmask = 4 * BATCH_ARGS_MAX - 1;
     zkeys_in_lds = true;
     for (unsigned int s = threadIdx.x; s <= zmask; s += BLOCK) zkeys[s] = PT_EMPTY;
     __syncthreads();
-    if (threadIdx.x < zba.k && zba.xy[2 * threadIdx.x] != zba.xy[2 * threadIdx.x + 1]) {
+    if (threadIdx.x < zba.k && zba.xy[2 * threadIdx.x] != zba.xy[2 * threadIdx.x + 1]) {  // (BATCH_ARGS_MAX <= the block size)
       const unsigned long long key = pair_key(zba.xy[2 * threadIdx.x], zba.xy[2 * threadIdx.x + 1]);
       unsigned int h = pair_hash32(key) & zmask;
       while (atomicCAS(&zkeys[h], PT_EMPTY, key) != PT_EMPTY) h = (h + 1) & zmask;
@@ -1402,11 +1409,11 @@ __global__ __launch_bounds__(TOP_SCAN_NT) void k_top_scan(PairTable pt, ScanArgs
   __shared__ unsigned int scratch[CAND_BINS + 80];
   bool zkeys_in_lds = zrules && zmask < FILTER_LDS_KEYS;
   if (zba.k) {
-    zmask = 127;
+    zmask = 4 * BATCH_ARGS_MAX - 1;
     zkeys_in_lds = true;
     for (unsigned int s = threadIdx.x; s <= zmask; s += TOP_SCAN_NT) zkeys[s] = PT_EMPTY;
     __syncthreads();
-    if (threadIdx.x < zba.k && zba.xy[2 * threadIdx.x] != zba.xy[2 * threadIdx.x + 1]) {
+    if (threadIdx.x < zba.k && zba.xy[2 * threadIdx.x] != zba.xy[2 * threadIdx.x + 1]) {  // (BATCH_ARGS_MAX <= the block size)
       const unsigned long long key = pair_key(zba.xy[2 * threadIdx.x], zba.xy[2 * threadIdx.x + 1]);
       unsigned int h = pair_hash32(key) & zmask;
       while (atomicCAS(&zkeys[h], PT_EMPTY, key) != PT_EMPTY) h = (h + 1) & zmask;
@@ -2008,7 +2015,7 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                         uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
-                        const ScanArgs *scan, bool wl_gathered, hipStream_t st) {
+                        const ScanArgs *scan, bool wl_gathered, unsigned int work_hint, hipStream_t st) {
   if (!ts.n_tiles) return;
   const BatchArgs bargs = ba ? *ba : BatchArgs{};
   const ScanArgs sargs = (scan && cls == 0) ? *scan : ScanArgs{};
@@ -2027,7 +2034,9 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
   {
     static const char *g_env = getenv("YTTM_APPLY_GRID");
     const unsigned int small = g_env ? (unsigned int)atoi(g_env) : 256u;
-    if (ts.n_tiles <= 16384 && small && grid_a > small) grid_a = small;
+    // (a worklist gathered from the pair index is a small tile set too, however many tiles there are: work_hint = what the last round touched)
+    const unsigned int work = wl_gathered && work_hint ? work_hint : ts.n_tiles;
+    if (work <= 16384 && small && grid_a > small) grid_a = small;
   }
   if (cls == 0) {
     if (!dense && !wl_gathered) hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,

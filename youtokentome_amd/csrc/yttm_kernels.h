@@ -49,7 +49,7 @@ void launch_tile_len(const unsigned long long *tile_start, unsigned int n_tiles,
 // A small batch travels as a kernel argument: the apply kernel and the candidate scan build their LDS tables (token flags, rule
 // hash) from it, and the round needs no prologue kernel, no rule upload and no flag table in HBM.  Used when the whole round
 // runs without the filter pass (small or dense tile sets), all ids fit the LDS flag bitmap and there is no class-C tile.
-constexpr int BATCH_ARGS_MAX = 32;
+constexpr int BATCH_ARGS_MAX = 128;  // (1 KB of kernel arguments; 32 until round 3: the late rounds of random text have batches of 30 .. 100 rules)
 constexpr uint32_t FLAG_LDS_IDS = 32768;  // batch flags of ids below this live in an LDS bitmap (2 bits per id, 8 KB)
 struct BatchArgs {
   uint32_t k;                        // 0: not used (tables come from HBM)
@@ -82,7 +82,7 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                         uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
                         const ScanArgs *scan /* class A only */, bool wl_gathered /* the worklist was filled by launch_gather: no filter pass */,
-                        hipStream_t st);
+                        unsigned int work_hint /* wl_gathered: about how many tiles the worklist will hold (0: unknown) */, hipStream_t st);
 // class-A tiles: the position-parallel apply kernel (k_apply.hip).  bloom_g: the batch's pair filter when the batch is too large
 // for the kernel to build it from its LDS rule hash (rule_mask >= 512 slots; PM_BLOOM_WORDS words, made by pm_bloom_host), else unused.
 // eager_w: most tiles of the launch will hold a site (their word frequencies are loaded together with the tokens).
