@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the Zipf (configs[2]) block")
     ap.add_argument("--no-touched-pass", action="store_true", help="skip the untimed K4 measurement pass (profiling runs: one training per process)")
     ap.add_argument("--cpu-sample-mb", type=int, default=0, help="0 = the full corpus")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="runs of the reference's train_bpe per corpus (the median is reported)")
     args = ap.parse_args()
 
     # stdout carries ONE line, the JSON: libraries that print banners there (RCCL does when a communicator is created) go to stderr
@@ -168,6 +169,9 @@ def main():
     if world == 1 and not args.no_e2e:
         out["e2e"] = {"train_file_to_model": _bench_e2e_train(ctx, host, main_res)}
         out["parity"]["e2e_model_matches_reference"] = out["e2e"]["train_file_to_model"].pop("_model_ok")
+        # `value` follows the bench contract (input resident in HBM when the timed region starts); the metric as SURVEY.md 8d words it --
+        # file bytes / wall from the call to the model file closed -- is this one, and it is what cpu_baseline is compared with
+        out["value_file_to_model"] = out["e2e"]["train_file_to_model"]["value"]
 
     # ---- encode: configs[3] (and [4]: dropout) with the model just trained --------------------------------------------------
     if not args.no_encode:
@@ -175,6 +179,7 @@ def main():
         out["encode"] = enc["encode"]
         out["encode_dropout"] = enc["dropout"]
         out["parity"]["encode_fnv_matches"] = enc["fnv_ok"]
+        out["parity"]["dropout_distribution_matches"] = enc["dropout_ok"]
         if "e2e" in enc:
             out.setdefault("e2e", {}).update(enc["e2e"])
 
@@ -437,7 +442,19 @@ def _bench_encode(ctx, model_path, main_res):
                              "unit": "GB/s", "frac": round(alg_bytes / 1e9 / (kavg / 1e3) / HBM_PEAK_GBS, 4), "traffic": None,
                              "algorithmic_bytes_per_launch": alg_bytes}}
 
-    res = {"dropout": run(0.1)}  # configs[4]; parity for it is a distribution test (tests/test_gpu_parity.py), here: the rate and the mean length
+    res = {"dropout": run(0.1)}  # configs[4]: per-lane RNG, so parity is a distribution match against the reference (n_threads=1) -- below
+    res["dropout_ok"] = None
+    c5 = os.path.join(ROOT, "tests", "golden", "c5_dropout_pin.json")
+    if rank == 0 and os.path.exists(c5) and main_res["pin"] is not None and main_res["model_ok"]:
+        pin5 = json.load(open(c5))
+        m5 = pin5["sentences"]
+        if pin5["model_md5"] == main_res["pin"]["model_md5"] and n_sent >= m5 and hashlib.md5(host[: m5 * (line + 1)]).hexdigest() == pin5["input_md5_first_1m"]:
+            ids = np.zeros(n_ids.value, dtype=np.int32)
+            off = np.zeros(n_sent + 1, dtype=np.uint64)
+            L.yttm_encode_fetch(h, ids.ctypes.data_as(_lib.i32p), off.ctypes.data_as(_lib.u64p), n_sent, err, _lib.ERRLEN)
+            res["dropout"]["distribution"] = _dropout_distribution(np, ids, off, m5, pin5)
+            res["dropout_ok"] = res["dropout"]["distribution"]["matches"]
+            del ids, off
     L.yttm_encoder_set_cache(h, 0, 0)
     direct = run(0.0)            # every word occurrence through K5, as the reference does
     L.yttm_encoder_set_cache(h, 2, 8 << 20)
@@ -500,6 +517,33 @@ def _bench_encode(ctx, model_path, main_res):
     del d_bytes, d_off
     torch.cuda.empty_cache()
     return res
+
+
+def _dropout_distribution(np, ids, off, m, pin):
+    """BASELINE.json configs[4] / SURVEY.md 8d C5: the GPU's BPE-dropout output against the reference's (unmodified, n_threads=1, fresh
+    process; tests/golden/c5_dropout_pin.json, made by tests/golden/make_full_pins.py c5) on the SAME first `m` sentences: mean ids per
+    sentence within 1 %, two-sample KS on the sentence lengths (alpha ~ 0.001), chi-square per degree of freedom on the unigram id
+    counts (bins with >= 20 counts).  The rest of the GPU's 10 M sentences is reported too (same process, more text)."""
+    lens_all = np.diff(off.astype(np.int64))
+    lens = lens_all[:m]
+    n_ids_m = int(off[m])
+    hw_len = np.asarray(pin["len_hist"], dtype=np.float64)
+    hg_len = np.bincount(lens, minlength=len(hw_len)).astype(np.float64)
+    k = max(len(hw_len), len(hg_len))
+    hw_len = np.pad(hw_len, (0, k - len(hw_len)))
+    hg_len = np.pad(hg_len, (0, k - len(hg_len)))
+    ks = float(np.abs(np.cumsum(hw_len) / hw_len.sum() - np.cumsum(hg_len) / hg_len.sum()).max())
+    ks_crit = 1.95 * float(np.sqrt((hw_len.sum() + hg_len.sum()) / (hw_len.sum() * hg_len.sum())))
+    hw = np.asarray(pin["id_hist"], dtype=np.float64)
+    hg = np.bincount(ids[:n_ids_m], minlength=len(hw)).astype(np.float64)[: len(hw)]
+    mask = (hw + hg) >= 20
+    chi = float((((hg[mask] - hw[mask]) ** 2) / (hg[mask] + hw[mask])).sum() / max(1, int(mask.sum()) - 1))
+    mean_g, mean_w = n_ids_m / m, pin["ids"] / pin["sentences"]
+    ok = abs(mean_g - mean_w) / mean_w < 0.01 and ks < ks_crit and chi < 1.5
+    return {"matches": bool(ok), "sentences_compared": m, "ids_per_sentence_gpu": round(mean_g, 4), "ids_per_sentence_reference": round(mean_w, 4),
+            "ks_sentence_lengths": round(ks, 6), "ks_critical_alpha_0.001": round(ks_crit, 6), "chi2_per_dof_unigram_ids": round(chi, 4),
+            "chi2_bins": int(mask.sum()), "chi2_limit": 1.5, "ids_per_sentence_gpu_all": round(float(lens_all.mean()), 4),
+            "reference": pin["reference"]}
 
 
 def _bench_encode_lines(ctx, model_path, text):
@@ -575,6 +619,8 @@ def _cpu_baseline(ctx, host, zhost, model_path, out):
     tmpdir = ctx["tmpdir"]
     os.makedirs(tmpdir, exist_ok=True)
 
+    runs = max(1, args.cpu_runs)
+
     def train(buf, tag):
         sample = buf
         if args.cpu_sample_mb:
@@ -584,19 +630,23 @@ def _cpu_baseline(ctx, host, zhost, model_path, out):
         with open(path, "wb") as f:
             f.write(sample)
         model = os.path.join(tmpdir, tag + ".model")
-        r = subprocess.run(pre + [ref, "train", path, model, str(args.vocab), "1.0", "8", "0", "1", "2", "3"], capture_output=True, text=True)
+        secs = []
+        for _ in range(runs):  # 3 runs, median, page cache warm
+            r = subprocess.run(pre + [ref, "train", path, model, str(args.vocab), "1.0", "8", "0", "1", "2", "3"], capture_output=True, text=True)
+            secs.append(json.loads(r.stdout.strip().splitlines()[-1])["train_seconds"])
         os.remove(path)
-        j = json.loads(r.stdout.strip().splitlines()[-1])
-        return len(sample), j["train_seconds"]
+        secs.sort()
+        return len(sample), secs[len(secs) // 2], secs
 
     res = {"value": None, "unit": "MB/s", "cores": cores, "kind": "reference", "pinned": bool(pre)}
     try:
-        n, secs = train(host, "cpu_c2")
+        n, secs, all_secs = train(host, "cpu_c2")
         res["value"] = round(n / 1e6 / secs, 2)
         res["train_seconds"] = round(secs, 2)
+        res["all_train_seconds"] = [round(x, 2) for x in all_secs]
         res["sample"] = (f"unmodified reference (oracle/_ref/yttm_ref_prod = bpe.cpp as shipped, -O3), n_threads=8"
                          f"{', taskset -c 0-7' if pre else ''}, train_bpe (C++ boundary: file -> model) on "
-                         f"{'the SAME full' if not args.cpu_sample_mb else 'the first'} {n/1e6:.0f} MB of the corpus, vocab {args.vocab}, 1 run")
+                         f"{'the SAME full' if not args.cpu_sample_mb else 'the first'} {n/1e6:.0f} MB of the corpus, vocab {args.vocab}, median of {runs} runs")
         res["gpu_over_cpu"] = round(out["value"] / res["value"], 1)
         if "e2e" in out and "train_file_to_model" in out["e2e"]:
             res["gpu_e2e_over_cpu"] = round(out["e2e"]["train_file_to_model"]["value"] / res["value"], 1)
@@ -604,8 +654,8 @@ def _cpu_baseline(ctx, host, zhost, model_path, out):
         res["error"] = str(e)
     if zhost is not None:
         try:
-            n, secs = train(zhost, "cpu_c3")
-            res["zipf"] = {"value": round(n / 1e6 / secs, 2), "unit": "MB/s", "train_seconds": round(secs, 2), "cores": cores,
+            n, secs, all_secs = train(zhost, "cpu_c3")
+            res["zipf"] = {"value": round(n / 1e6 / secs, 2), "unit": "MB/s", "train_seconds": round(secs, 2), "all_train_seconds": [round(x, 2) for x in all_secs], "cores": cores,
                            "sample": f"same reference build and flags on the full {n/1e6:.0f} MB Zipf corpus (configs[2])"}
         except Exception as e:  # noqa: BLE001
             res["zipf"] = {"error": str(e)}
@@ -643,7 +693,80 @@ def _cpu_baseline(ctx, host, zhost, model_path, out):
         except Exception as e:  # noqa: BLE001
             res.setdefault("zipf", {})["encode"] = {"error": str(e)}
         os.remove(lines)
-    res["python_boundary"] = "not timed: the reference's Cython module cannot be built on the GPU box (/root/reference is absent there)"
+    res["python_boundary"] = _python_boundary(ctx, pre, cores, model_path, enc_host, zhost, out)
+    return res
+
+
+def _python_boundary(ctx, pre, cores, model_path, enc_host, zhost, out):
+    """The reference's OWN Python boundary and command line on this box (its Cython module, compiled from the unmodified sources by
+    oracle/Makefile into oracle/_ref/pyref, travels with the tree): youtokentome.BPE.encode(list[str]) (yttm.pyx:87-109) and
+    `yttm encode` stdin -> stdout (bpe.cpp:1942-2014, what benchmark.md's "Tokenization" times), beside the drop-in's through shim/."""
+    pyref = os.path.join(ROOT, "oracle", "_ref", "pyref")
+    if not os.path.exists(os.path.join(pyref, "_youtokentome_cython.so")):
+        return {"error": "oracle/_ref/pyref not built (make -C oracle ref, where /root/reference exists)"}
+    tmpdir = ctx["tmpdir"]
+    res = {}
+    script = os.path.join(ROOT, "tools", "python_boundary.py")
+    shim = os.path.join(ROOT, "shim")
+
+    def env_for(which):
+        e = dict(os.environ)
+        e["PYTHONPATH"] = (pyref if which == "reference" else shim + os.pathsep + ROOT) + os.pathsep + e.get("PYTHONPATH", "")
+        return e
+    if enc_host is not None:
+        lines = os.path.join(tmpdir, "pb.txt")
+        m = 1_000_000
+        with open(lines, "wb") as f:
+            f.write(enc_host[: m * 129])
+        for which in ("reference", "drop_in"):
+            try:
+                r = subprocess.run((pre if which == "reference" else []) + [sys.executable, script, model_path, lines, str(m), "8", "3"],
+                                   capture_output=True, text=True, env=env_for(which))
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                res["encode_list_" + which] = {"value": round(j["sentences"] / j["median_seconds"], 1), "unit": "sentences/s", "sentences": j["sentences"],
+                                               "ids": j["ids"], "seconds": [round(x, 3) for x in j["seconds"]], "module": os.path.relpath(j["module"], ROOT),
+                                               "what": "youtokentome.BPE(model, n_threads=8).encode(list[str], OutputType.ID) -> list[list[int]], median of 3"
+                                                       + (", taskset -c 0-7" if (pre and which == "reference") else "")}
+            except Exception as e:  # noqa: BLE001
+                res["encode_list_" + which] = {"error": str(e), "stderr": (r.stderr[-300:] if "r" in dir() else "")}
+        a, b = res.get("encode_list_drop_in", {}), res.get("encode_list_reference", {})
+        if a.get("value") and b.get("value"):
+            res["encode_list_drop_in_over_reference"] = round(a["value"] / b["value"], 2)
+            res["encode_list_ids_equal"] = a["ids"] == b["ids"]
+        os.remove(lines)
+    if zhost is not None and out.get("extra", {}).get("zipf"):
+        # N1: `yttm encode` on the Zipf corpus' lines, stdin -> stdout (a file; /dev/null would hide the writer)
+        zin = os.path.join(tmpdir, "cli_in.txt")
+        with open(zin, "wb") as f:
+            f.write(zhost)
+        zmodel = os.path.join(tempfile.gettempdir(), "yttm_bench_zipf_%s.model" % os.environ.get("MASTER_PORT", str(os.getpid())))
+        n_lines = zhost.count(b"\n")
+        sums = {}
+        for which in ("reference", "drop_in"):
+            zout = os.path.join(tmpdir, "cli_out_%s.txt" % which)
+            code = "import sys; from youtokentome.yttm_cli import main; sys.argv = ['yttm', 'encode', '--model', %r, '--output_type', 'id', '--n_threads', '8']; main()" % zmodel
+            try:
+                t0 = time.perf_counter()
+                with open(zin, "rb") as fi, open(zout, "wb") as fo:
+                    r = subprocess.run((pre if which == "reference" else []) + [sys.executable, "-c", code], stdin=fi, stdout=fo, stderr=subprocess.PIPE, env=env_for(which))
+                dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    raise RuntimeError(r.stderr.decode()[-300:])
+                sums[which] = md5_file(zout)
+                res["cli_encode_" + which] = {"value": round(n_lines / dt, 1), "unit": "sentences/s", "MBps_in": round(len(zhost) / 1e6 / dt, 1), "seconds": round(dt, 3),
+                                              "output_bytes": os.path.getsize(zout),
+                                              "what": "`yttm encode --output_type id --n_threads 8` < the %d lines of the Zipf corpus > file; process start to exit (model load%s included)"
+                                                      % (n_lines, ", GPU context" if which == "drop_in" else "")}
+                os.remove(zout)
+            except Exception as e:  # noqa: BLE001
+                res["cli_encode_" + which] = {"error": str(e)}
+        if len(sums) == 2:
+            res["cli_outputs_identical"] = sums["reference"] == sums["drop_in"]
+            out["parity"]["cli_encode_output_identical_to_reference"] = res["cli_outputs_identical"]
+        a, b = res.get("cli_encode_drop_in", {}), res.get("cli_encode_reference", {})
+        if a.get("value") and b.get("value"):
+            res["cli_encode_drop_in_over_reference"] = round(a["value"] / b["value"], 2)
+        os.remove(zin)
     return res
 
 

@@ -14,6 +14,7 @@
 //   yttm_ref train  <corpus> <model> <vocab> <coverage> <n_threads> <pad> <unk> <bos> <eos>
 //   yttm_ref encode <model> <lines.txt> <out.txt|-> <n_threads> <bos> <eos> <reverse> <dropout> [subword]
 //   yttm_ref encode_bench <model> <lines.txt> <n_threads> <dropout> [max_lines]
+//   yttm_ref encode_hist <model> <lines.txt> <n_threads> <dropout> <max_lines> <out.json>
 //   yttm_ref decode <model> <ids.txt> <out.txt>
 //   yttm_ref vocab  <model> <out.txt>
 // All timing lines go to stdout as one JSON object; reference chatter stays on stderr.
@@ -114,6 +115,36 @@ int main(int argc, char **argv) {
     }
     printf("{\"ok\": true, \"sentences\": %zu, \"ids\": %llu, \"encode_seconds\": %.6f, \"fnv1a64\": \"%016llx\"}\n",
            lines.size(), (unsigned long long)n_ids, secs(t0, t1), (unsigned long long)h);
+    return 0;
+  }
+  if (cmd == "encode_hist") {  // <model> <lines.txt> <n_threads> <dropout> <max_lines> <out.json>: sentence-length and unigram-id histograms
+    if (argc != 8) return 2;
+    vkcom::Status st;
+    vkcom::BaseEncoder enc(argv[2], atoi(argv[4]), &st);
+    if (!st.ok()) { printf("{\"ok\": false, \"message\": \"%s\"}\n", st.error_message().c_str()); return 1; }
+    auto lines = read_lines(argv[3], atol(argv[6]));
+    std::vector<std::vector<int>> res;
+    auto t0 = clk::now();
+    st = enc.encode_as_ids(lines, &res, false, false, false, atof(argv[5]));
+    auto t1 = clk::now();
+    if (!st.ok()) { printf("{\"ok\": false, \"message\": \"%s\"}\n", st.error_message().c_str()); return 1; }
+    std::vector<unsigned long long> len_hist, id_hist((size_t)enc.vocab_size(), 0);
+    unsigned long long n_ids = 0;
+    for (auto &sv : res) {
+      if (sv.size() >= len_hist.size()) len_hist.resize(sv.size() + 1, 0);
+      len_hist[sv.size()]++;
+      for (int id : sv) id_hist[(size_t)id]++;
+      n_ids += sv.size();
+    }
+    FILE *out = fopen(argv[7], "wb");
+    if (!out) return 2;
+    fprintf(out, "{\"sentences\": %zu, \"ids\": %llu, \"len_hist\": [", lines.size(), n_ids);
+    for (size_t i = 0; i < len_hist.size(); i++) fprintf(out, "%s%llu", i ? "," : "", len_hist[i]);
+    fprintf(out, "], \"id_hist\": [");
+    for (size_t i = 0; i < id_hist.size(); i++) fprintf(out, "%s%llu", i ? "," : "", id_hist[i]);
+    fprintf(out, "]}\n");
+    fclose(out);
+    printf("{\"ok\": true, \"sentences\": %zu, \"ids\": %llu, \"encode_seconds\": %.6f}\n", lines.size(), n_ids, secs(t0, t1));
     return 0;
   }
   if (cmd == "decode") {

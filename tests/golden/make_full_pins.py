@@ -5,6 +5,8 @@ reference (oracle/_ref/yttm_ref_det = bpe.cpp with -DDETERMINISTIC_QUEUE, n_thre
   c2_100mb  its 100 MB variant
   c3_1gb    configs[2]: 1 GB Zipf ASCII corpus (tests/gen.py zipf_corpus_fast, seed 7, lexicon 400 000), vocab 32000 -> model md5
   c3_100mb  its 100 MB variant
+  c5        configs[4]: histograms (sentence lengths, unigram ids) of the reference's BPE-dropout output, p = 0.1, n_threads=1, on the
+            first 1 M sentences of the C4 stream with the c2_1gb model -> tests/golden/c5_dropout_pin.json
   c4_10m    configs[3]: 10 M sentences of 128 chars (gen_abcd stream, seed 123) encoded with the c2_1gb model -> FNV-1a-64
             of (length, ids...) per sentence over all 10 M, and over the first 1 M
 
@@ -48,7 +50,7 @@ def main():
     d = tempfile.mkdtemp(prefix="yttm_pins_")
     c2_model = None
     for name, nbytes in (("c2_100mb", 100_000_000), ("c2_1gb", 1_000_000_000)):
-        if want and name not in want and not (name == "c2_1gb" and "c4_10m" in want):
+        if want and name not in want and not (name == "c2_1gb" and ("c4_10m" in want or "c5" in want)):
             continue
         text = gen.abcd_corpus(nbytes, seed=19, survey_stream=True)
         pins[name], m = train_pin(name, text, f"SURVEY.md Appendix C gen_abcd(seed=19), {len(text)//101} rows of 100 chars", d)
@@ -78,6 +80,28 @@ def main():
                           "hash": "FNV-1a-64 over, per sentence, the little-endian bytes of uint32 length then of each int32 id (oracle/ref_driver.cpp encode_bench)",
                           "reference": "oracle/_ref/yttm_ref_prod encode_as_ids, n_threads=8, dropout 0"}
         print("c4_10m", pins["c4_10m"], flush=True)
+    if "c5" in want:
+        # configs[4]: BPE-dropout p = 0.1 on the first 10^6 sentences of the C4 stream with the c2_1gb model -- the reference as shipped,
+        # n_threads=1, a fresh process (one global mt19937, seed 5489: bpe.cpp:1415; with threads its output is a data race).
+        # The fixture holds the histograms (sentence lengths, unigram ids) bench.py compares its own 10 M-sentence output with.
+        import subprocess
+        assert c2_model is not None
+        line, m = 128, 1_000_000
+        host = gen.abcd_corpus(m * (line + 1), seed=123, line=line, survey_stream=True)
+        lines = os.path.join(d, "c5.txt")
+        open(lines, "wb").write(host)
+        hist = os.path.join(d, "c5_hist.json")
+        t0 = time.time()
+        r = subprocess.run([os.path.join(R, "oracle", "_ref", "yttm_ref_prod"), "encode_hist", c2_model, lines, "1", "0.1", str(m), hist], capture_output=True, text=True, check=True)
+        h = json.load(open(hist))
+        os.remove(lines)
+        pin = {"what": "BASELINE.json configs[4]: histograms of encode_as_ids(dropout_prob=0.1) over the first 1 000 000 sentences of the C4 stream (gen_abcd, default_rng(123), 128 chars)",
+               "model": "c2_1gb", "model_md5": pins["c2_1gb"]["model_md5"], "input_md5_first_1m": hashlib.md5(host).hexdigest(), "dropout_prob": 0.1,
+               "reference": "oracle/_ref/yttm_ref_prod (unmodified bpe.cpp as shipped), n_threads=1, fresh process (std::mt19937 seed 5489)",
+               "reference_seconds_build_container": round(time.time() - t0, 1), "sentences": h["sentences"], "ids": h["ids"],
+               "ids_per_sentence": round(h["ids"] / h["sentences"], 4), "len_hist": h["len_hist"], "id_hist": h["id_hist"]}
+        json.dump(pin, open(os.path.join(R, "tests", "golden", "c5_dropout_pin.json"), "w"))
+        print("c5", {k: v for k, v in pin.items() if k not in ("len_hist", "id_hist")}, flush=True)
         json.dump(pins, open(OUT, "w"), indent=1)
 
 

@@ -41,3 +41,12 @@ def test_no_gpu_means_loud_failure():
     r = subprocess.run(["python", "-c", code], capture_output=True, text=True)
     assert "TRAINED" not in r.stdout
     assert "ERR" in r.stdout and "GPU" in r.stdout
+
+
+def test_python_list_boundary_extension_is_built():
+    """csrc/pyapi.c (the C side of BPE.encode(list[str]) -> list[list[int]], yttm.pyx:87-109) is built next to the library and imports."""
+    so = os.path.join(ROOT, "youtokentome_amd", "_yttm_pyapi.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "youtokentome_amd", "csrc"), "../_yttm_pyapi.so"], check=True, capture_output=True)
+    from youtokentome_amd import bpe
+    assert bpe._pyapi is not None and hasattr(bpe._pyapi, "encode_ids")

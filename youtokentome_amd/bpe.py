@@ -10,6 +10,11 @@ import numpy as np
 
 from . import _lib
 
+try:  # csrc/pyapi.c, built next to the HIP library; without it the list API marshals in Python (slower, same results)
+    from . import _yttm_pyapi as _pyapi
+except ImportError:  # pragma: no cover
+    _pyapi = None
+
 
 class OutputType(Enum):  # youtokentome.py:6-8
     ID = 1
@@ -100,6 +105,12 @@ class _Core:
         else:
             assert isinstance(sentences, list) or isinstance(sentences, tuple)
             batch = list(sentences)
+        if output_type == "id" and _pyapi is not None:
+            # list[str] -> blob + offsets -> yttm_encode_as_ids -> list[list[int]] in C (csrc/pyapi.c: what yttm.pyx:87-109 does in Cython)
+            L = _lib.load()
+            out = _pyapi.encode_ids(C.cast(L.yttm_encode_as_ids, C.c_void_p).value, C.cast(L.yttm_free, C.c_void_p).value, self._h.value,
+                                    batch, bool(bos), bool(eos), bool(reverse), float(dropout_prob))
+            return out[0] if single else out
         blob, offs = _pack(batch)
         if output_type == "id":
             ids, off = self.encode_packed(blob, offs, bos, eos, reverse, dropout_prob)

@@ -834,20 +834,13 @@ void GpuCtx::pair_count() {
       // send block overflowed says so in its block's header and every rank stops
       unsigned long long cap = 1ull << 20;
       while (cap < n_tokens0 / 2 && cap < (1ull << 27)) cap <<= 1;
-      if (const unsigned int forced = env_uint("YTTM_XCHG_TABLE_CAP", 0)) cap = pow2_at_least(std::max(forced, 4u));  // (tests: a table that overflows)
-      db_.keys = dmalloc<unsigned long long>(cap);
-      db_.vals = dmalloc<long long>(cap);
-      db_.touched = dmalloc<uint32_t>(cap);
-      db_.n = dmalloc<unsigned long long>(2);
-      db_.mask = cap - 1;
-      launch_fill_u64(db_.keys, PT_EMPTY, cap, st_);
-      HIP_CHECK(hipMemsetAsync(db_.vals, 0, cap * 8, st_));
-      HIP_CHECK(hipMemsetAsync(db_.n, 0, 16, st_));
-      send_cap_ = cap / 2;  // (a table more than half full counts as overflow)
-      d_send_ = dmalloc<DeltaRec>(send_cap_ + 1);
-      const DeltaRec hdr{0ull, (long long)send_cap_};  // {records, capacity}: the peers check the one against the other
-      HIP_CHECK(hipMemcpyAsync(d_send_, &hdr, sizeof hdr, hipMemcpyHostToDevice, st_));
-      sync();
+      // (... and never less than twice the distinct pairs K3 itself can produce on this rank: a large alphabet on a small corpus)
+      while (cap < 2 * initial_table_keys(n_tokens0) && cap < (1ull << 28)) cap <<= 1;
+      if (const unsigned int forced = env_uint("YTTM_XCHG_TABLE_CAP", 0)) {  // (tests: a table that overflows)
+        cap = pow2_at_least(std::max(forced, 4u));
+        delta_cap_forced_ = true;
+      }
+      alloc_delta_table(cap);
       d_xstat_ = dmalloc<unsigned long long>(4);
       if (!d_box_) d_box_ = dmalloc<unsigned char>(8192 + 4096 * sizeof(CandRec));  // a scan result waiting for the ranks' verdicts
       HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, st_));
@@ -872,6 +865,28 @@ void GpuCtx::pair_count() {
   sync();
   n_keys_host = nk;
   exchange_deltas();
+}
+
+// multi-GPU: the round's delta table (pair -> this rank's summed count change) and the send block made from it, for `cap` slots; a
+// table more than half full counts as overflow.  Called at set-up and, from merge_apply, when a round's bound on the distinct pairs it
+// can touch does not fit -- between rounds the table is empty (k_dt_pack frees what a round claimed).
+void GpuCtx::alloc_delta_table(unsigned long long cap) {
+  DFREE(db_.keys); DFREE(db_.vals); DFREE(db_.touched); DFREE(d_send_);
+  db_.keys = dmalloc<unsigned long long>(cap);
+  db_.vals = dmalloc<long long>(cap);
+  db_.touched = dmalloc<uint32_t>(cap);
+  if (!db_.n) {
+    db_.n = dmalloc<unsigned long long>(2);
+    HIP_CHECK(hipMemsetAsync(db_.n, 0, 16, st_));
+  }
+  db_.mask = cap - 1;
+  launch_fill_u64(db_.keys, PT_EMPTY, cap, st_);
+  HIP_CHECK(hipMemsetAsync(db_.vals, 0, cap * 8, st_));
+  send_cap_ = cap / 2;
+  d_send_ = dmalloc<DeltaRec>(send_cap_ + 1);
+  const DeltaRec hdr{0ull, (long long)send_cap_};  // {records, capacity}: the peers check the one against the other
+  HIP_CHECK(hipMemcpyAsync(d_send_, &hdr, sizeof hdr, hipMemcpyHostToDevice, st_));
+  sync();
 }
 
 void GpuCtx::download_pairs(std::vector<unsigned long long> &keys, std::vector<unsigned long long> &cnts) {
@@ -1343,6 +1358,20 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // (the key count the scans report is one round old -- they fold the statistics after publishing: the previous round's bound covers it)
   ensure_table_capacity(n_keys_host + bound_prev_ + bound_new);
   bound_prev_ = bound_new;
+  if (multi() && !delta_cap_forced_) {
+    // distinct pairs this rank's round can touch: per rule at most five updates per site (sites <= the pair's global count) and at most
+    // four pairs per token type ((a,x), (a,z), (y,b), (z,b)) plus the self pairs.  The same number on every rank (it is computed from the
+    // batch and the global counts), so every rank regrows its table in the same round -- an overflow is a bug, not a workload.
+    unsigned long long dt_bound = 0;
+    for (uint32_t j = 0; j < k; j++) dt_bound += std::min<unsigned long long>(rule_counts ? 5 * rule_counts[j] : ~0ull >> 8, 4ull * (vmax + 1) + 4);
+    if (dt_bound > send_cap_) {
+      unsigned long long cap = db_.mask + 1;
+      while (cap / 2 < dt_bound) cap <<= 1;
+      chain_event_ = nullptr;
+      alloc_delta_table(cap);
+      delta_regrows++;
+    }
+  }
 
   // Worklist from the pair index instead of a pass over every tile?  Only when every rule of the batch is in the index (pairs of
   // tokens older than the index; candidates come from the hot list, whose pairs were its keys), the last round touched few tiles,

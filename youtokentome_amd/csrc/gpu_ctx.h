@@ -86,7 +86,7 @@ class GpuCtx {
   int last_top_bin() const { return (int)last_top_bin_; }  // no bin above this one is in use
   unsigned long long index_builds = 0, gathered_rounds = 0, pm_rounds = 0;  // K4 rounds whose worklist came from the pair index
   unsigned long long word_table_retries = 0;  // K2: the word table had to be redone with the worst-case size
-  unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0;
+  unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0, delta_regrows = 0;
   unsigned long long tail_ticks[3] = {0, 0, 0}, tail_listed = 0;  // round_tail: fold / list scan / publish, in 10 ns ticks; entries it read
   unsigned long long fused_rounds = 0, fused_overflows = 0;  // rounds whose candidate scan ran in the apply kernel's tail; of those, with a hot-list overflow
   unsigned long long table_capacity() const { return pt_cap_; }
@@ -226,6 +226,8 @@ class GpuCtx {
   unsigned long long recv_cap_ = 0, blk_ = 4096, blk_min_ = 4096, send_cap_ = 0;
   unsigned int last_pack_hint_ = 1u << 16;
   void pack_deltas();
+  void alloc_delta_table(unsigned long long cap);
+  bool delta_cap_forced_ = false;  // YTTM_XCHG_TABLE_CAP (tests: the overflow verdict)
   bool pt_fresh_ = false;  // build_class(0) left an empty pair table of the initial size
   unsigned long long initial_table_keys(unsigned long long n_tok) const;
   unsigned long long *d_xstat_ = nullptr;  // [0] ranks whose block overflowed, [1] largest count, [2] hot-list overflow verdicts

@@ -13,9 +13,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <poll.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -40,12 +42,22 @@ unsigned long long batch_limit() {
 class LineReader {
  public:
   explicit LineReader(int fd) : fd_(fd), buf_(1u << 20) {}
+  // (the batch loop's reader thread: a set flag ends the input -- also while it waits for a slow or interactive stdin)
+  void stop_when(const std::atomic<bool> *flag) { stop_ = flag; }
   // appends the next line (without its '\n') to out; false at end of input
   bool next(std::string *out) {
     bool any = false;
     for (;;) {
       if (pos_ == len_) {
         if (eof_) return any;
+        if (stop_) {  // wait for input in slices, so that the flag is seen while nothing arrives
+          for (;;) {
+            if (stop_->load(std::memory_order_relaxed)) { eof_ = true; return any; }
+            struct pollfd pf{fd_, POLLIN, 0};
+            const int pr = poll(&pf, 1, 100);
+            if (pr != 0) break;  // readable, closed, or an error that read() will report
+          }
+        }
         ssize_t r;
         do r = read(fd_, buf_.data(), buf_.size()); while (r < 0 && errno == EINTR);
         if (r <= 0) { eof_ = true; return any; }
@@ -70,6 +82,7 @@ class LineReader {
   std::vector<char> buf_;
   size_t pos_ = 0, len_ = 0;
   bool eof_ = false;
+  const std::atomic<bool> *stop_ = nullptr;
 };
 
 bool write_all(int fd, const char *p, size_t n) {
@@ -156,6 +169,8 @@ Status BaseEncoder::encode_cli(const std::string &output_type_str, bool stream, 
   std::condition_variable cv;
   std::deque<std::unique_ptr<Batch>> todo, done;  // reader -> workers -> writer
   bool reader_finished = false, abort = false;
+  std::atomic<bool> stop_reader{false};  // set together with abort: the reader may be inside read() or its line loop, not at the condition variable
+  in.stop_when(&stop_reader);
   unsigned long long n_batches = 0;
   constexpr size_t MAX_AHEAD = 3;  // batches read but not yet written
   size_t in_flight = 0;
@@ -170,7 +185,7 @@ Status BaseEncoder::encode_cli(const std::string &output_type_str, bool stream, 
       std::string line;
       while (b->processed < BATCH_LIMIT) {
         line.clear();
-        if (!in.next(&line)) break;
+        if (stop_reader.load(std::memory_order_relaxed) || !in.next(&line)) break;
         b->processed += line.size();
         b->bytes += line;
         b->off.push_back(b->bytes.size());
@@ -229,6 +244,7 @@ Status BaseEncoder::encode_cli(const std::string &output_type_str, bool stream, 
     else if (!write_all(out_fd, b->out.data(), b->out.size())) result = Status(1, "write to the output failed");
     if (!result.ok()) {
       { std::lock_guard<std::mutex> lk(mu); abort = true; }
+      stop_reader.store(true);
       cv.notify_all();
       break;
     }

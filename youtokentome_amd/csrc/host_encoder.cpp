@@ -90,13 +90,16 @@ struct EncoderDevice {
   static constexpr int N_LANES = 2;
   EncodeLane lane[N_LANES];
   std::atomic<unsigned int> next_lane{0};
+  std::atomic<unsigned long long> last_distinct_words{0};  // of the most recent batch (cache_words())
   // a free lane, locked (falls back to waiting for the caller's turn-based choice)
+  // (Lane 0 last: the device-resident pair encode_device / fetch_device_result keeps its result there, unlocked, between the two
+  // calls -- a host-to-host encode from another thread in between takes another lane while one is free.)
   EncodeLane &acquire(std::unique_lock<std::mutex> &lk) {
-    for (int k = 0; k < N_LANES; k++) {
+    for (int k = N_LANES - 1; k >= 0; k--) {
       lk = std::unique_lock<std::mutex>(lane[k].mu, std::try_to_lock);
       if (lk.owns_lock()) return lane[k];
     }
-    EncodeLane &l = lane[next_lane.fetch_add(1) % N_LANES];
+    EncodeLane &l = lane[N_LANES - 1 - next_lane.fetch_add(1) % N_LANES];
     lk = std::unique_lock<std::mutex>(l.mu);
     return l;
   }
@@ -273,9 +276,9 @@ static unsigned long long scan_counts(EncodeLane &d, const uint32_t *counts, uns
   d.grow(d.d_scan_tmp, d.cap_scan_tmp, (size_t)scan_scratch_blocks(n));
   launch_exclusive_scan(counts, n, off, d.d_scan_tmp, d.d_total, d.st);
   unsigned long long total = 0;
+  HIP_CHECK(hipMemcpyAsync(off + n, d.d_total, 8, hipMemcpyDeviceToDevice, d.st));  // (device to device: no host source that must outlive the call)
   HIP_CHECK(hipMemcpyAsync(&total, d.d_total, 8, hipMemcpyDeviceToHost, d.st));
   HIP_CHECK(hipStreamSynchronize(d.st));
-  HIP_CHECK(hipMemcpyAsync(off + n, &total, 8, hipMemcpyHostToDevice, d.st));
   return total;
 }
 
@@ -320,6 +323,7 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
   }
   const unsigned long long n_extra = misc[0], n_words = n_table + n_extra;
   d.last_distinct_words = n_words;
+  D.last_distinct_words.store(n_words);
   d.grow(d.d_ustart, d.cap_ustart, (size_t)n_words + 1);
   d.grow(d.d_uend, d.cap_uend, (size_t)n_words + 1);
   d.grow(d.d_uslot, d.cap_uslot, (size_t)n_table + 1);
@@ -363,6 +367,7 @@ static Status encode_on_lane(const BaseEncoder &enc, EncoderDevice &D, EncodeLan
     const bool cached = dropout_prob <= 0 && D.cache_mode != 0 && (D.cache_mode == 1 || total_bytes >= D.cache_min_bytes) &&
                         ((uintptr_t)d_bytes & 7u) == 0 && total_bytes < (1ull << 40) && total_bytes > 0;
     d.last_distinct_words = 0;
+    D.last_distinct_words.store(0);
     if (cached) {
       encode_cached(D, d, d_bytes, (const unsigned long long *)d_offsets, n_sent, total_bytes, max_sentence_bytes, bos, eos, reverse, n_ids_out);
       if (kernel_ms) {
@@ -429,8 +434,7 @@ void BaseEncoder::set_cache(int mode, unsigned long long min_bytes) const {
 }
 unsigned long long BaseEncoder::cache_words() const {
   if (!dev_) return 0;
-  std::lock_guard<std::mutex> lk(dev_->lane[0].mu);
-  return dev_->lane[0].last_distinct_words;
+  return dev_->last_distinct_words.load();  // (of the most recent batch, whichever lane ran it)
 }
 
 Status BaseEncoder::fetch_device_result(int32_t *ids, unsigned long long *out_off, unsigned long long n_sent) const {
