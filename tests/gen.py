@@ -91,6 +91,55 @@ def zipf_corpus_fast(nbytes, seed=7, vocab=400000, line_words=16, exponent=1.05,
     return b"".join(parts)
 
 
+def cjk_corpus_fast(nbytes, seed=11, n_chars=4096, lexicon=300000, chunk_words=4_000_000):
+    """A large-alphabet corpus in the shape of Chinese / Japanese text (the reference's slowest published cases, benchmark.md:23,39):
+    `n_chars` ideographs (U+4E00 ..., three UTF-8 bytes each, Zipfian), a lexicon of 1-3 char words (Zipfian), written WITHOUT spaces
+    between words; a clause ends after about ten words with a comma (no space) or a full stop followed by a space or a newline -- so the
+    space-delimited "words" the trainer sees are whole sentences of some tens of chars, nearly all of them unique."""
+    rng = np.random.default_rng(seed)
+    cw = 1 / np.arange(1, n_chars + 1) ** 0.9
+    cw /= cw.sum()
+    lens = rng.choice([1, 2, 3], size=lexicon, p=[0.3, 0.5, 0.2]).astype(np.int64)
+    cp = 0x4E00 + rng.choice(n_chars, size=(lexicon, 3), p=cw)
+    lexb = np.empty((lexicon, 9), dtype=np.uint8)  # word i = lexb[i, :3 * lens[i]]
+    for k in range(3):
+        c = cp[:, k]
+        lexb[:, 3 * k] = 0xE0 | (c >> 12)
+        lexb[:, 3 * k + 1] = 0x80 | ((c >> 6) & 0x3F)
+        lexb[:, 3 * k + 2] = 0x80 | (c & 0x3F)
+    w = 1 / np.arange(1, lexicon + 1) ** 1.0
+    w /= w.sum()
+    cdf = np.cumsum(w)
+    cdf[-1] = 1.0
+    # separators behind a word: nothing (0.9), "," U+FF0C (0.05), "." U+3002 + space (0.04), "." + newline (0.01)
+    seps = np.zeros((4, 4), dtype=np.uint8)
+    seps[1, :3] = (0xEF, 0xBC, 0x8C)
+    seps[2] = (0xE3, 0x80, 0x82, 32)
+    seps[3] = (0xE3, 0x80, 0x82, 10)
+    sep_len = np.array([0, 3, 4, 4], dtype=np.int64)
+    avg = float((w * 3 * lens).sum()) + 0.05 * 3 + 0.05 * 4
+    nwords = max(1, int(nbytes / avg))
+    parts = []
+    col = np.arange(13, dtype=np.int64)
+    for w0 in range(0, nwords, chunk_words):
+        n = min(chunk_words, nwords - w0)
+        ids = np.searchsorted(cdf, rng.random(n), side="right").astype(np.int64)
+        np.minimum(ids, lexicon - 1, out=ids)
+        kind = np.searchsorted(np.array([0.9, 0.95, 0.99, 1.0]), rng.random(n), side="right").astype(np.int64)
+        np.minimum(kind, 3, out=kind)
+        if w0 + n >= nwords:
+            kind[-1] = 3  # the text ends with a full stop and a newline
+        l = 3 * lens[ids]
+        mat = np.zeros((n, 13), dtype=np.uint8)
+        mat[:, :9] = lexb[ids]
+        rows = np.arange(n)
+        for k in range(4):
+            mat[rows, l + k] = np.where(k < sep_len[kind], seps[kind, k], mat[rows, np.minimum(l + k, 12)])
+        keep = col[None, :] < (l + sep_len[kind])[:, None]
+        parts.append(mat[keep].tobytes())
+    return b"".join(parts)
+
+
 def stress_text(rng: random.Random, n_limit=1000, train=True):
     """Random text in the spirit of the reference stress generator (tests/unit_tests/stress_test.cpp:272-311):
     short alphabet, single chars mixed with repeated segments so that long runs of equal symbols occur."""

@@ -65,6 +65,18 @@ def main():
         pins[name], _ = train_pin(name, text, "tests/gen.py zipf_corpus_fast(seed=7, vocab=400000, exponent=1.05, 16 words per line)", d)
         print(name, pins[name], flush=True)
         json.dump(pins, open(OUT, "w"), indent=1)
+    # SURVEY.md 8a / the round-2 verdict: workloads between and beyond the two BASELINE corpora -- a large alphabet (the reference's slowest
+    # published cases are zh / ja) and an enwik-like Zipf instance (lexicon 4 * 10^6, exponent 1.0: U ~ 2-3 * 10^6, T ~ 2-3 * 10^7)
+    for name, make, desc in (("c6_cjk_1gb", lambda: gen.cjk_corpus_fast(1_000_000_000, seed=11), "tests/gen.py cjk_corpus_fast(seed=11, n_chars=4096, lexicon=300000)"),
+                             ("c7_zipf4m_1gb", lambda: gen.zipf_corpus_fast(1_000_000_000, seed=7, vocab=4_000_000, exponent=1.0),
+                              "tests/gen.py zipf_corpus_fast(seed=7, vocab=4000000, exponent=1.0, 16 words per line)"),
+                             ("c6_cjk_100mb", lambda: gen.cjk_corpus_fast(100_000_000, seed=11), "tests/gen.py cjk_corpus_fast(seed=11, n_chars=4096, lexicon=300000)")):
+        if name not in want:
+            continue
+        text = make()
+        pins[name], _ = train_pin(name, text, desc, d)
+        print(name, pins[name], flush=True)
+        json.dump(pins, open(OUT, "w"), indent=1)
     if not want or "c4_10m" in want:
         assert c2_model is not None
         line = 128

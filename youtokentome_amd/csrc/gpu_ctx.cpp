@@ -173,6 +173,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
                                                                   //  measured at 1 GB, K4 + candidate family ms: no index 151.1, 64/4 147.3, 128/4 148.8, 64/8 145.1, 32/8 147.8, 256/3 160.6)
   idx_force_ = env_uint("YTTM_INDEX_ALWAYS", 0) != 0;  // (tests: worklists from the index whenever the batch allows, however few tiles)
   use_pm_ = env_uint("YTTM_K4_PM", 0) != 0;
+  bloom_mode_ = env_uint("YTTM_K4_BLOOM", 1) != 0;
   gather_grid_ = env_uint("YTTM_GATHER_GRID", 0) != 0;  // (measured at 1 GB: 65.6 vs 62.7 us per late round -- the smaller grid is not faster)
   no_batch_args_ = getenv("YTTM_NO_BATCH_ARGS") != nullptr;  // (read once per context: a round has no time for getenv)
   trace_rounds_ = getenv("YTTM_TRACE_ROUNDS");
@@ -1411,9 +1412,10 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // class A goes through the position-parallel kernel (k_apply.hip: its own pair filter, no flag tables, no filter pass) unless this
   // is the measurement pass (the word statistics live in the old kernel) or YTTM_K4_OLD asks for the old one (A/B runs)
   const bool pm = use_pm_ && !instrument;
+  // (token flags live in an LDS bitmap of FLAG_LDS_IDS ids; the pair filter -- bloom_mode_ -- has no such limit)
   const bool by_args = k <= (uint32_t)BATCH_ARGS_MAX && !cls_[2].n_tiles && !no_batch_args &&
-                       (pm || (vmax < FLAG_LDS_IDS && (!cls_[0].n_tiles || dense_class(0)))) &&
-                       (!cls_[1].n_tiles || (vmax < FLAG_LDS_IDS && dense_class(1)));
+                       (pm || ((bloom_mode_ || vmax < FLAG_LDS_IDS) && (!cls_[0].n_tiles || dense_class(0)))) &&
+                       (!cls_[1].n_tiles || ((bloom_mode_ || vmax < FLAG_LDS_IDS) && dense_class(1)));
   unsigned int n_upd = 0;
   if (!by_args) {  // (the common small batch needs none of this: the host's share of a round is on the critical path)
     for (unsigned int i = 0; i < cap; i++) { h_rules[i].key = PT_EMPTY; h_rules[i].z = 0; h_rules[i].pad = 0; }
@@ -1447,6 +1449,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   }
   BatchArgs ba{};
   ba.instr = instrument ? 1u : 0u;
+  ba.bloom = bloom_mode_ ? 1u : 0u;
   max_id_ = std::max(max_id_, vmax);
   if (by_args) {
     ba.k = k;
@@ -1481,7 +1484,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   t_begin(KT_MERGE);
   if (!by_args) {
     uint32_t *h_bloom = nullptr;
-    if (pm && cap > 512 && cls_[0].n_tiles) {  // (more slots than the apply kernel's LDS rule hash: the batch's pair filter comes from here)
+    if (bloom_mode_ || (pm && cap > 512 && cls_[0].n_tiles)) {  // the batch's pair filter for the apply kernels (built here: a few hundred hashes)
       h_bloom = (uint32_t *)(pin + (size_t)RULES_CAP * sizeof(RuleSlot) + 8 * (size_t)RULES_CAP * sizeof(uint32_t));
       pm_bloom_host(h_bloom, xyz, k);
       if (!d_bloom_) d_bloom_ = dmalloc<uint32_t>(PM_BLOOM_WORDS_H);
@@ -1508,7 +1511,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
                        cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/!wl_gathered && (by_args || dense_class(ci)),
                        &ba, ci == 0 && sa.on ? &sa : nullptr, wl_gathered,
-                       gather_grid_ && touched_last_ < (1ull << 30) ? (unsigned int)(2 * touched_last_) : 0u, st_);
+                       gather_grid_ && touched_last_ < (1ull << 30) ? (unsigned int)(2 * touched_last_) : 0u, d_bloom_, st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
   t_end(KT_MERGE, 0, /*chain=*/!sa.on);  // (a fused round is followed by the host's turn, not by another kernel: its end event must not start the next interval)

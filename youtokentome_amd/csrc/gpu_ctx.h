@@ -138,6 +138,7 @@ class GpuCtx {
   uint32_t fused_mx_ = 0, fused_round_ = 0;
   bool no_batch_args_ = false;
   bool gather_grid_ = false;      // YTTM_GATHER_GRID=1: a round from the pair index launches a grid sized for its worklist (tuning hook)
+  bool bloom_mode_ = true;        // k_tiles finds its merge-site candidates with the batch's pair filter (YTTM_K4_BLOOM=0: per-token x / y flags)
   bool use_pm_ = false;           // YTTM_K4_PM=1: class-A tiles through the position-parallel kernel (k_apply.hip) instead of k_tiles
   uint32_t *d_bloom_ = nullptr;   // pair filter of a batch too large for the apply kernel's LDS rule hash
   const char *trace_rounds_ = nullptr, *dbg_cand_ = nullptr;

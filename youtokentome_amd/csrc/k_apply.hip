@@ -26,20 +26,6 @@
 
 namespace yttm {
 
-// ---- Bloom filter of the batch's pairs.  24-bit multiplies (full rate; v_mul_lo_u32 is a quarter-rate instruction): ids beyond
-// 2^24 only lose selectivity.  Word = top 11 bits, two bit positions from the next 10.
-constexpr int PM_BLOOM_WORDS = PM_BLOOM_WORDS_H;
-__host__ __device__ inline uint32_t pm_mul24(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __umul24(a, b);
-#else
-  return (a & 0xffffffu) * (b & 0xffffffu);
-#endif
-}
-constexpr uint32_t PM_K1 = 0x9E3779u, PM_K2 = 0x85EBCBu;
-__host__ __device__ inline uint32_t pm_hash(uint32_t a, uint32_t b) { return pm_mul24(a, PM_K1) ^ pm_mul24(b, PM_K2); }
-__host__ __device__ inline uint32_t pm_word(uint32_t h) { return h >> 21; }
-__host__ __device__ inline uint32_t pm_bits(uint32_t h) { return (1u << ((h >> 16) & 31u)) | (1u << ((h >> 11) & 31u)); }
 void pm_bloom_host(uint32_t *bloom, const uint32_t *xyz, uint32_t k) {  // (batches too large for the LDS rule hash: built by the host)
   for (int i = 0; i < PM_BLOOM_WORDS; i++) bloom[i] = 0;
   for (uint32_t j = 0; j < k; j++) {

@@ -307,6 +307,43 @@ __device__ inline uint32_t tile_word_index_rl(const WaveLds<SLOT> &W, int p) {
   return k - 1u;
 }
 
+// The same decision with the batch's PAIR filter (k_merge_shared.h: Bloom filter of the batch's pairs, two bits per rule in one word;
+// BatchArgs::bloom): bit 4 j + i of `hb` = the adjacency that starts at my token i of row j passes the filter.  The x / y flags are per
+// token -- with k rules up to k * k flagged adjacencies, of which k are rules: from the middle of a training on, two thirds of the
+// flag-dirty tiles hold no merge site, and every flagged adjacency costs an exact look-up.  The pair filter's hits are nearly all sites.
+template <int SLOT, class bits_t>
+__device__ inline bool reg_bloom_test(const uint4 (&r)[SLOT / 256], int n, const uint32_t *bloom, uint32_t self_x, bits_t &hb) {
+  const int lane = lane_id();
+  hb = 0;
+  bool selfc = false;
+  const bool has_self = self_x != 0xffffffffu;
+#define BLOOM_BIT(HA, HB, T1, S)                                                                  \
+  {                                                                                               \
+    const uint32_t h_ = (HA) ^ (HB);                                                              \
+    const uint32_t bits_ = pm_bits(h_);                                                           \
+    if ((bloom[pm_word(h_)] & bits_) == bits_ && !((T1) >> 31)) hb |= (bits_t)1 << (S);           \
+  }
+#pragma unroll
+  for (int j = 0; j < SLOT / 256; j++) {
+    if (256 * j < n) {
+      uint32_t nx = from_lane_right(r[j].x);
+      uint32_t nx0 = TOK_WS;
+      if (j + 1 < SLOT / 256) nx0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
+      if (lane == 63) nx = nx0;
+      const uint32_t a0 = r[j].x & TOK_MASK, a1 = r[j].y & TOK_MASK, a2 = r[j].z & TOK_MASK, a3 = r[j].w & TOK_MASK, a4 = nx & TOK_MASK;
+      BLOOM_BIT(pm_mul24(a0, PM_K1), pm_mul24(a1, PM_K2), r[j].y, 4 * j)
+      BLOOM_BIT(pm_mul24(a1, PM_K1), pm_mul24(a2, PM_K2), r[j].z, 4 * j + 1)
+      BLOOM_BIT(pm_mul24(a2, PM_K1), pm_mul24(a3, PM_K2), r[j].w, 4 * j + 2)
+      BLOOM_BIT(pm_mul24(a3, PM_K1), pm_mul24(a4, PM_K2), nx, 4 * j + 3)
+      if (has_self)
+        selfc = selfc || (a0 == self_x && a1 == self_x && !(r[j].y >> 31)) || (a1 == self_x && a2 == self_x && !(r[j].z >> 31)) ||
+                (a2 == self_x && a3 == self_x && !(r[j].w >> 31)) || (a3 == self_x && a4 == self_x && !(nx >> 31));
+    }
+  }
+#undef BLOOM_BIT
+  return hb != 0 || selfc;
+}
+
 // K4, the tile still in registers: find the merge sites of the batch's x != y rules -- rule index to W.ridx[p], bit p of
 // W.sitemask -- with one hash lookup per flagged adjacency, before anything is staged.  Returns 0 for a tile with neither
 // such a site nor an x x of the self rule (nothing to do: the x/y flags are per token, and late in training two thirds of
@@ -316,12 +353,31 @@ template <int SLOT, bool LDSR>
 __device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds,
                                      const uint8_t *__restrict__ tokflag, uint32_t self_x, const RuleTab<LDSR> &rtab,
                                      uint32_t &my_cnt /* sites found by this lane */, uint32_t &my_site /* the last one: position << 16 | rule index */,
-                                     bool small_ids) {
+                                     bool small_ids, bool use_bloom /* flagbits_lds holds the batch's pair filter, not token flags */) {
   const int lane = lane_id();
   my_cnt = 0;
   my_site = 0;
-  uint4 f[SLOT / 256];
-  const bool cand = reg_flag_test<SLOT>(r, n, flagbits_lds, tokflag, self_x, f, small_ids);
+  typedef typename std::conditional<(SLOT / 64 > 32), unsigned long long, uint32_t>::type bits_t;
+  bits_t hb = 0;  // bit 4 j + i: the adjacency that starts at my token i of row j may be a rule of the batch
+  bool cand;
+  if (use_bloom) {
+    cand = reg_bloom_test<SLOT, bits_t>(r, n, flagbits_lds, self_x, hb);
+  } else {
+    uint4 f[SLOT / 256];
+    cand = reg_flag_test<SLOT>(r, n, flagbits_lds, tokflag, self_x, f, small_ids);
+    if (__ballot(cand) != 0) {
+#pragma unroll
+      for (int j = 0; j < SLOT / 256; j++) {
+        if (256 * j < n) {
+          uint32_t fnx = from_lane_right(f[j].x), fnx0 = 0;
+          if (j + 1 < SLOT / 256) fnx0 = from_lane0(f[j + 1 < SLOT / 256 ? j + 1 : j].x);
+          if (lane == 63) fnx = fnx0;
+          const uint32_t b0 = f[j].x & (f[j].y >> 1) & 1u, b1 = f[j].y & (f[j].z >> 1) & 1u, b2 = f[j].z & (f[j].w >> 1) & 1u, b3 = f[j].w & (fnx >> 1) & 1u;
+          hb |= (bits_t)(b0 | (b1 << 1) | (b2 << 2) | (b3 << 3)) << (4 * j);
+        }
+      }
+    }
+  }
   if (__ballot(cand) == 0) return 0;
   if (lane < SLOT / 64) W.sitemask[lane] = 0ull;
   if (lane == 0) {
@@ -333,16 +389,15 @@ __device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 2
   bool selfp = false;
   // what this lane finds: bit 4 j + i = a site starts at my token i of row j (position 256 j + 4 lane + i); the site bits,
   // the list and the count go to LDS once, after the look-ups (a lane's positions are looked at in ascending order)
-  typedef typename std::conditional<(SLOT / 64 > 32), unsigned long long, uint32_t>::type bits_t;
   bits_t my_bits = 0;
   uint32_t my_ri = 0;  // rule of my last site
   const bool has_self = self_x != 0xffffffffu;  // (uniform: most batches have no x x rule)
-#define PAIR_SITE(T0, T1, F0, F1, P, S)                                                  \
+#define PAIR_SITE(T0, T1, P, S)                                                              \
   if (!((T1)&TOK_WS)) {                                                                  \
     const uint32_t a_ = (T0)&L_ID, b_ = (T1)&L_ID;                                       \
     if (has_self && a_ == self_x && b_ == self_x) {                                      \
       selfp = true;                                                                      \
-    } else if (((F0)&1u) && ((F1)&2u)) {                                                 \
+    } else if ((hb >> (S)) & 1u) {                                                        \
       const uint32_t ri = rtab.find(a_, b_);                                             \
       if (ri != 0xffffffffu) {                                                           \
         W.ridx[(P)] = (uint16_t)ri;                                                      \
@@ -355,19 +410,16 @@ __device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 2
   for (int j = 0; j < SLOT / 256; j++) {
     if (256 * j < n) {
       // first token of the lane to my right (lane 63: of the next row), and its flags; slots behind the tile's end hold zeros
-      uint32_t nx = from_lane_right(r[j].x), fnx = from_lane_right(f[j].x);
-      uint32_t nx0 = TOK_WS, fnx0 = 0;
-      if (j + 1 < SLOT / 256) {
-        nx0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
-        fnx0 = from_lane0(f[j + 1 < SLOT / 256 ? j + 1 : j].x);
-      }
-      if (lane == 63) { nx = nx0; fnx = fnx0; }
+      uint32_t nx = from_lane_right(r[j].x);
+      uint32_t nx0 = TOK_WS;
+      if (j + 1 < SLOT / 256) nx0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
+      if (lane == 63) nx = nx0;
       int p = 256 * j + 4 * lane;
       YTTM_OPAQUE_V(p);  // (recomputed per tile: hoisted out of the tile loop, the LDS addresses derived from it are spilled to scratch)
-      PAIR_SITE(r[j].x, r[j].y, f[j].x, f[j].y, p, 4 * j)
-      PAIR_SITE(r[j].y, r[j].z, f[j].y, f[j].z, p + 1, 4 * j + 1)
-      PAIR_SITE(r[j].z, r[j].w, f[j].z, f[j].w, p + 2, 4 * j + 2)
-      PAIR_SITE(r[j].w, nx, f[j].w, fnx, p + 3, 4 * j + 3)
+      PAIR_SITE(r[j].x, r[j].y, p, 4 * j)
+      PAIR_SITE(r[j].y, r[j].z, p + 1, 4 * j + 1)
+      PAIR_SITE(r[j].z, r[j].w, p + 2, 4 * j + 2)
+      PAIR_SITE(r[j].w, nx, p + 3, 4 * j + 3)
     }
   }
 #undef PAIR_SITE
@@ -846,8 +898,13 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     for (unsigned int j = threadIdx.x; j < ba.k; j += WPB * 64) {  // (class B: one wave per workgroup)
       const uint32_t x = ba.xy[2 * j], y = ba.xy[2 * j + 1];
       if (x != y) {
-        atomicOr(&A.flagbits[x >> 4], 1u << ((x & 15u) * 2));
-        atomicOr(&A.flagbits[y >> 4], 2u << ((y & 15u) * 2));
+        if (ba.bloom) {
+          const uint32_t bh = pm_hash(x, y);
+          atomicOr(&A.flagbits[pm_word(bh)], pm_bits(bh));
+        } else {
+          atomicOr(&A.flagbits[x >> 4], 1u << ((x & 15u) * 2));
+          atomicOr(&A.flagbits[y >> 4], 2u << ((y & 15u) * 2));
+        }
         const unsigned long long key = pair_key(x, y);
         unsigned int h = pair_hash32(key) & rule_mask;
         for (;;) {
@@ -930,7 +987,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
   auto stage_part = [&](int n0, uint32_t tile, uint32_t w0) {
     // K4: a tile without a merge site is dismissed in registers and never touches LDS
     uint32_t my_cnt = 0, my_site = 0;
-    site_state = MERGE ? reg_find_sites<SLOT, LDSR>(W, r, n0, A.flagbits, tokflag, self_x, rtab, my_cnt, my_site, ba.small_ids != 0) : 1;
+    site_state = MERGE ? reg_find_sites<SLOT, LDSR>(W, r, n0, A.flagbits, tokflag, self_x, rtab, my_cnt, my_site, ba.small_ids != 0, ba.bloom != 0) : 1;
     if (MERGE) K4_MARK(0);
     bool dirty = site_state != 0;
     if (MERGE && SLOT == TILE_SLOT_A && site_state == 1 && !ba.instr) {  // sites of x != y rules only: is it a single one?
@@ -2015,9 +2072,10 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                         uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
-                        const ScanArgs *scan, bool wl_gathered, unsigned int work_hint, hipStream_t st) {
+                        const ScanArgs *scan, bool wl_gathered, unsigned int work_hint, const uint32_t *bloom_g, hipStream_t st) {
   if (!ts.n_tiles) return;
   const BatchArgs bargs = ba ? *ba : BatchArgs{};
+  const uint32_t *tflags = bargs.bloom ? bloom_g : flagbits;  // what the apply kernel stages into LDS (the filter pass keeps the token flags)
   const ScanArgs sargs = (scan && cls == 0) ? *scan : ScanArgs{};
   const RuleSlot *frules = exact_filter ? rules : nullptr;
   // dense round (nearly every tile held a site last round): the filter pass would keep everything -- the apply kernel
@@ -2043,19 +2101,19 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, true>), dim3(grid_a), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
+                         tokflag, tflags, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, false>), dim3(grid_a), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
+                         tokflag, tflags, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
   } else {
     if (!dense && !wl_gathered) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
                        stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, ScanArgs{});
+                         tokflag, tflags, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, ScanArgs{});
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, flagbits, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, ScanArgs{});
+                         tokflag, tflags, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, ScanArgs{});
   }
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,

@@ -7,6 +7,22 @@
 
 namespace yttm {
 
+// ---- Bloom filter of the batch's pairs.  24-bit multiplies (full rate; v_mul_lo_u32 is a quarter-rate instruction): ids beyond
+// 2^24 only lose selectivity.  Word = top 11 bits, two bit positions from the next 10.
+constexpr int PM_BLOOM_WORDS = PM_BLOOM_WORDS_H;
+static_assert(PM_BLOOM_WORDS * 16 == (int)FLAG_LDS_IDS, "the filter lives where k_tiles keeps its flag bitmap");
+__host__ __device__ inline uint32_t pm_mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(a, b);
+#else
+  return (a & 0xffffffu) * (b & 0xffffffu);
+#endif
+}
+constexpr uint32_t PM_K1 = 0x9E3779u, PM_K2 = 0x85EBCBu;
+__host__ __device__ inline uint32_t pm_hash(uint32_t a, uint32_t b) { return pm_mul24(a, PM_K1) ^ pm_mul24(b, PM_K2); }
+__host__ __device__ inline uint32_t pm_word(uint32_t h) { return h >> 21; }
+__host__ __device__ inline uint32_t pm_bits(uint32_t h) { return (1u << ((h >> 16) & 31u)) | (1u << ((h >> 11) & 31u)); }
+
 constexpr int AGG_SLOTS = 512;   // LDS delta aggregator shared by the waves of a workgroup (hot pairs).  256 slots: 1.05e8 emits of rounds 12-100 at 1 GB
                                  // found no room and went to the HBM table one by one (K4 135 ms); 512: 123 ms; 704: 124; 1024 (two workgroups per CU): 156.
                                  // The probe loop stays at 8, unrolled: 12 -> 127 ms, 24 -> 253 (!), not unrolled -> 135

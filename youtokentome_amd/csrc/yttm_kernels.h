@@ -55,6 +55,8 @@ struct BatchArgs {
   uint32_t k;                        // 0: not used (tables come from HBM)
   uint32_t xy[2 * BATCH_ARGS_MAX];   // rule j of the batch merges (xy[2j], xy[2j+1]) into z_base + j; x == y: the self rule (skipped)
   uint32_t small_ids;                // every token id in the tiles is < FLAG_LDS_IDS: the kernels skip the test for ids behind the LDS bitmap
+  uint32_t bloom;                    // k_tiles<.., true>: merge-site candidates by the batch's PAIR filter (k_merge_shared.h pm_hash; built in the kernel
+                                     // from xy, or copied from the table `flagbits` then points to) instead of per-token x / y flags
   uint32_t instr;                    // measurement pass (never timed): also count the WORDS that hold a merge site and their tokens
                                      // (T_touched, W_touched) into stats[4], stats[5]; single-site tiles take the general path
 };
@@ -82,7 +84,8 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
                         const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                         uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
                         const ScanArgs *scan /* class A only */, bool wl_gathered /* the worklist was filled by launch_gather: no filter pass */,
-                        unsigned int work_hint /* wl_gathered: about how many tiles the worklist will hold (0: unknown) */, hipStream_t st);
+                        unsigned int work_hint /* wl_gathered: about how many tiles the worklist will hold (0: unknown) */,
+                        const uint32_t *bloom_g /* ba->bloom and the batch not in ba: the batch's pair filter (pm_bloom_host) */, hipStream_t st);
 // class-A tiles: the position-parallel apply kernel (k_apply.hip).  bloom_g: the batch's pair filter when the batch is too large
 // for the kernel to build it from its LDS rule hash (rule_mask >= 512 slots; PM_BLOOM_WORDS words, made by pm_bloom_host), else unused.
 // eager_w: most tiles of the launch will hold a site (their word frequencies are loaded together with the tokens).
