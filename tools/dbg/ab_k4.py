@@ -15,9 +15,10 @@ pins = json.load(open(os.path.join(R, "tests", "golden", "full_size_pins.json"))
 from youtokentome_amd import _lib
 L = _lib.load()
 res = {}
-for kind in (["abcd", "zipf"] if which == "both" else [which]):
-    text = gen.abcd_corpus(mb * 1_000_000, seed=19, survey_stream=True) if kind == "abcd" else gen.zipf_corpus_fast(mb * 1_000_000, seed=7, vocab=400000)
-    pin = pins.get(("c2_" if kind == "abcd" else "c3_") + ("1gb" if mb == 1000 else "%dmb" % mb), {})
+for kind in (["abcd", "zipf"] if which == "both" else which.split("+")):
+    text = {"abcd": lambda: gen.abcd_corpus(mb * 1_000_000, seed=19, survey_stream=True), "zipf": lambda: gen.zipf_corpus_fast(mb * 1_000_000, seed=7, vocab=400000),
+            "cjk": lambda: gen.cjk_corpus_fast(mb * 1_000_000, seed=11), "zipf4m": lambda: gen.zipf_corpus_fast(mb * 1_000_000, seed=7, vocab=4_000_000, exponent=1.0)}[kind]()
+    pin = pins.get({"abcd": "c2_", "zipf": "c3_", "cjk": "c6_cjk_", "zipf4m": "c7_zipf4m_"}[kind] + ("1gb" if mb == 1000 else "%dmb" % mb), {})
     d = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
     del text
     for name, env in variants:

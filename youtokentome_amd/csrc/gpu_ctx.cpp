@@ -173,7 +173,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
                                                                   //  measured at 1 GB, K4 + candidate family ms: no index 151.1, 64/4 147.3, 128/4 148.8, 64/8 145.1, 32/8 147.8, 256/3 160.6)
   idx_force_ = env_uint("YTTM_INDEX_ALWAYS", 0) != 0;  // (tests: worklists from the index whenever the batch allows, however few tiles)
   use_pm_ = env_uint("YTTM_K4_PM", 0) != 0;
-  bloom_mode_ = env_uint("YTTM_K4_BLOOM", 1) != 0;
+  bloom_mode_ = true;  // (the per-token flag variant of k_tiles is gone; the flag tables still serve the separate filter pass, YTTM_DENSE_PCT)
   gather_grid_ = env_uint("YTTM_GATHER_GRID", 0) != 0;  // (measured at 1 GB: 65.6 vs 62.7 us per late round -- the smaller grid is not faster)
   no_batch_args_ = getenv("YTTM_NO_BATCH_ARGS") != nullptr;  // (read once per context: a round has no time for getenv)
   trace_rounds_ = getenv("YTTM_TRACE_ROUNDS");
@@ -456,8 +456,23 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
   if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
   HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
   HIP_CHECK(hipMemsetAsync(d_counters_, 0, 64 * 8, st_));
+  // a look at four 4 KB samples of the text: lead bytes of three- and four-byte chars (>= 0xE0) above 1 % pick the kernel variant that
+  // counts such chars in LDS (only speed depends on the verdict)
+  bool wide_chars = false;
+  if (n_text_ >= (1u << 16)) {
+    static thread_local uint8_t smp[4][4096];
+    for (int i = 0; i < 4; i++) HIP_CHECK(hipMemcpyAsync(smp[i], d_text_ + (n_text_ / 4) * (unsigned long long)i, 4096, hipMemcpyDeviceToHost, st_));
+    sync();
+    unsigned int wide = 0;
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4096; j++) wide += smp[i][j] >= 0xE0u;
+    wide_chars = wide * 100u > 4u * 4096u;
+  } else {
+    wide_chars = true;  // (small inputs: tests of both variants run on them through YTTM_K1_WIDE)
+  }
+  if (const char *e = getenv("YTTM_K1_WIDE")) wide_chars = atoi(e) != 0;
   t_begin(KT_CHAR_HIST);
-  if (n_text_) launch_char_hist(d_text_, n_text_, d_hist_, d_counters_, st_);
+  if (n_text_) launch_char_hist(d_text_, n_text_, d_hist_, d_counters_, wide_chars, st_);
   t_end(KT_CHAR_HIST, n_text_);
   unsigned long long h_cnt[2] = {0, 0};
   HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 16, hipMemcpyDeviceToHost, st_));
@@ -1461,7 +1476,9 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // one launch per round: the apply kernel's last workgroup also does the candidate scan (see gpu_ctx.h)
   ScanArgs sa{};
   fused_pending_ = false;
-  if (next_tau_cnt && fuse_enabled_ && !multi() && hot_state_ == HOT_ACTIVE && top_state_ == TOP_ACTIVE && cls_[0].n_tiles && !cls_[1].n_tiles &&
+  // (class-A and class-B tiles: the scan rides in the round's last launch; class-C tiles -- words of more than 2048 tokens -- keep the separate scan)
+  const int last_cls = cls_[1].n_tiles ? 1 : 0;
+  if (next_tau_cnt && fuse_enabled_ && !multi() && hot_state_ == HOT_ACTIVE && top_state_ == TOP_ACTIVE && (cls_[0].n_tiles || cls_[1].n_tiles) &&
       !cls_[2].n_tiles && !instrument) {
     sa.on = 1u;
     sa.tau_cnt = *next_tau_cnt;
@@ -1505,12 +1522,12 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       const bool eager_w = touched_last_ == (~0ull >> 2) || touched_last_ * 2 >= cls_[0].n_tiles;
       pm_rounds++;
       launch_apply_pm(cls_[0].ts, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, wl_gathered ? cls_[0].d_worklist : nullptr,
-                      cls_[0].d_work_n, d_stats_, &ba, sa.on ? &sa : nullptr, eager_w, st_);
+                      cls_[0].d_work_n, d_stats_, &ba, sa.on && last_cls == 0 ? &sa : nullptr, eager_w, st_);
       continue;
     }
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
                        cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/!wl_gathered && (by_args || dense_class(ci)),
-                       &ba, ci == 0 && sa.on ? &sa : nullptr, wl_gathered,
+                       &ba, ci == last_cls && sa.on ? &sa : nullptr, wl_gathered,
                        gather_grid_ && touched_last_ < (1ull << 30) ? (unsigned int)(2 * touched_last_) : 0u, d_bloom_, st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);

@@ -247,23 +247,25 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
   // ---- 4. the statistics rows, AFTER the host has its candidates: the fold is off the round's critical path (the key count
   // and the token totals in the header are therefore one round old; the host allows for that)
   {  // statistics rows (left by the workgroups of this and earlier launches, write-through): all loads in flight together
-    constexpr int RPT = (BLK_ROWS + NT - 1) / NT;
-    unsigned long long v[RPT][5];
-#pragma unroll
-    for (int r = 0; r < RPT; r++) {
-      const int b = tid + r * NT;
-#pragma unroll
-      for (int jj = 0; jj < 5; jj++)
-        v[r][jj] = b < BLK_ROWS ? __hip_atomic_load(&stats[BLK_BASE + 8 * b + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    }
+    constexpr int RPT = NT >= 512 ? (BLK_ROWS + NT - 1) / NT : 3;  // rows per thread in flight together (a one-wave workgroup -- class-B tiles -- takes its rows in groups)
     unsigned long long a[5] = {0, 0, 0, 0, 0};
+    for (int b0 = 0; b0 < BLK_ROWS; b0 += RPT * NT) {
+      unsigned long long v[RPT][5];
 #pragma unroll
-    for (int r = 0; r < RPT; r++) {
-      const int b = tid + r * NT;
+      for (int r = 0; r < RPT; r++) {
+        const int b = b0 + tid + r * NT;
 #pragma unroll
-      for (int jj = 0; jj < 5; jj++) {
-        a[jj] += v[r][jj];
-        if (v[r][jj]) stats[BLK_BASE + 8 * b + jj] = 0;
+        for (int jj = 0; jj < 5; jj++)
+          v[r][jj] = b < BLK_ROWS ? __hip_atomic_load(&stats[BLK_BASE + 8 * b + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      }
+#pragma unroll
+      for (int r = 0; r < RPT; r++) {
+        const int b = b0 + tid + r * NT;
+#pragma unroll
+        for (int jj = 0; jj < 5; jj++) {
+          a[jj] += v[r][jj];
+          if (v[r][jj]) stats[BLK_BASE + 8 * b + jj] = 0;
+        }
       }
     }
 #pragma unroll

@@ -22,7 +22,9 @@ inline unsigned long long cand_bin_lower(int bin) {
 }
 
 // ---- front end (k_frontend.hip)
-void launch_char_hist(const uint8_t *text, unsigned long long n, unsigned long long *hist, unsigned long long *counters, hipStream_t st);
+// wide_chars: many chars beyond U+07FF (three- and four-byte UTF-8): they are counted in an LDS hash instead of global atomics
+void launch_char_hist(const uint8_t *text, unsigned long long n, unsigned long long *hist, unsigned long long *counters, bool wide_chars,
+                      hipStream_t st);
 void launch_seg_write(const uint8_t *text, unsigned long long n, unsigned long long *seg_pos, unsigned long long *seg_cursor, hipStream_t st);
 void launch_hist_compact(const unsigned long long *hist, uint32_t *cps, unsigned long long *cnts, unsigned int *n_out, unsigned int cap,
                          hipStream_t st);
