@@ -323,6 +323,17 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
            "corpus_bytes_total": total_bytes, "corpus_bytes_this_gpu": n_local, "vocab_size": args.vocab, "unique_words": r["n_unique"],
            "dedup_tokens": r["n_tokens"], "merge_rounds": r["rounds"], "rules": r["rules"], "input": "resident in HBM before the timed region",
            "model_md5": model_md5, "pinned_model_md5": pin["model_md5"] if pin else None}
+    if ctx["comm"] is not None:
+        cfg["multi_gpu_mode"] = ("replicated merge loop: shards gathered once after the local dedup, every rank runs the merge loop alone, no per-round collective"
+                                 if r.get("replicated_merge_loop") else "sharded merge loop: every rank applies the batch to its words, per-pair count deltas all-gathered every round")
+        k4_ms = kern.get("merge_apply", {}).get("ms_total", 0.0)
+        if dist is not None:
+            t = torch.zeros(world, dtype=torch.float64, device=dev)
+            t[rank] = k4_ms
+            dist.all_reduce(t)
+            cfg["merge_apply_ms_per_rank"] = [round(float(x), 2) for x in t.tolist()]
+        else:
+            cfg["merge_apply_ms_per_rank"] = [k4_ms]
     res = {"value": round(value, 2), "ms_per_step": round(dt / steps * 1e3, 2), "config": cfg, "roofline": roofline, "roofline_pair_count": roofline_pc,
            "kernels": kern, "phases_s": {"frontend": r["seconds_frontend"], "merge_loop": r["seconds_merge"], "dump": r["seconds_io"]},
            "corpus_ok": corpus_ok, "model_ok": model_ok, "model_path": model_path, "pin": pin}

@@ -24,9 +24,13 @@ def free_port():
     return p
 
 
-def run_world(corpus, model, vocab, coverage, world, lib, extra_env=None):
+def run_world(corpus, model, vocab, coverage, world, lib, extra_env=None, sharded=True):
+    """sharded=True: the per-round delta exchange (YTTM_REPLICATE_MAX_TOKENS=0 -- these corpora are far below the size from which the
+    library shards the merge loop by itself); False: the library's choice for small word tables, the replicated merge loop."""
     port = str(free_port())
     env = dict(os.environ, YTTM_AMD_LIB=lib)
+    if sharded:
+        env["YTTM_REPLICATE_MAX_TOKENS"] = "0"
     env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_train_worker.py"), str(r), str(world), port, corpus, model, str(vocab),
                                repr(coverage)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
@@ -46,6 +50,25 @@ def test_two_ranks_equal_single_oracle(tmp_path, sim_lib, world):
         open(corpus, "wb").write(text)
         m_mp, m_ora = str(tmp_path / f"mp{i}.model"), str(tmp_path / f"ora{i}.model")
         run_world(corpus, m_mp, vocab, cov, world, sim_lib)
+        O.train(text, m_ora, vocab, cov)
+        assert filecmp.cmp(m_mp, m_ora, shallow=False), f"case {i}"
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_replicated_merge_loop_equals_single_oracle(tmp_path, sim_lib, world):
+    """Small word tables (the library's own choice below 2^26 dedup tokens): the ranks dedup their shards, gather the shards into the
+    whole corpus on every rank and run the merge loop alone -- no collective per round (bpe.cpp:1029-1044: merge the shards' maps once,
+    then loop); rank 0 writes the model, byte-identical to the oracle's on the whole corpus."""
+    rng = random.Random(40 + world)
+    cases = [(gen.readme_corpus(120, 80, seed=3), 300, 1.0),
+             (gen.unicode_text(rng, 4000, "mix", p_invalid=0.01), 90, 0.9),
+             (gen.zipf_corpus(60000, vocab=900, seed=5), 400, 1.0),
+             (("aaaa aaaaa abababab aabbaabb bbbbbb ab aaab baaa " * 12).encode(), 40, 1.0)]
+    for i, (text, vocab, cov) in enumerate(cases):
+        corpus = str(tmp_path / f"c{i}.txt")
+        open(corpus, "wb").write(text)
+        m_mp, m_ora = str(tmp_path / f"mp{i}.model"), str(tmp_path / f"ora{i}.model")
+        run_world(corpus, m_mp, vocab, cov, world, sim_lib, sharded=False)
         O.train(text, m_ora, vocab, cov)
         assert filecmp.cmp(m_mp, m_ora, shallow=False), f"case {i}"
 
@@ -102,7 +125,7 @@ def test_delta_table_overflow_stops_every_rank(tmp_path, sim_lib):
     corpus = str(tmp_path / "c.txt")
     open(corpus, "wb").write(text)
     port = str(free_port())
-    env = dict(os.environ, YTTM_AMD_LIB=sim_lib, YTTM_XCHG_TABLE_CAP="8")
+    env = dict(os.environ, YTTM_AMD_LIB=sim_lib, YTTM_XCHG_TABLE_CAP="8", YTTM_REPLICATE_MAX_TOKENS="0")
     world = 3
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_train_worker.py"), str(r), str(world), port, corpus, str(tmp_path / "m.model"), "250",
                                "1.0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]

@@ -56,6 +56,9 @@ class GpuCtx {
   void attach_corpus(const void *dev, unsigned long long n);
   // bytes [lo, lo + n) of an open file, through pinned chunks filled by several host threads (gpu_ctx.cpp: upload_staged)
   void upload_corpus_fd(int fd, unsigned long long lo, unsigned long long n);
+  // multi-GPU: the ranks' shards gathered into one corpus on every rank (gpu_ctx.cpp); a value summed over the ranks
+  void gather_full_corpus();
+  unsigned long long allreduce_scalar(unsigned long long v);
 
   // ---- K1
   void char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long long> &cnts, unsigned long long &n_codepoints);

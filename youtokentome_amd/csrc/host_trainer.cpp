@@ -60,6 +60,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   const auto t_all = clk::now();
   Comm *comm = g.comm();
   const bool root = !comm || comm->rank == 0;
+  bool replicated = false;  // multi-GPU, small word tables: the merge loop runs on every rank alone (see below)
   // ---- K1 + alphabet (bpe.cpp:941-944, :1013-1021)
   std::vector<uint32_t> cps;
   std::vector<unsigned long long> cnts;
@@ -90,6 +91,27 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     std::vector<uint32_t> a_cp(alpha.size()), a_id(alpha.size());
     for (size_t i = 0; i < alpha.size(); i++) { a_cp[i] = alpha[i].first; a_id[i] = alpha[i].second; }
     g.build_word_table(a_cp.data(), a_id.data(), (uint32_t)alpha.size(), /*space_id=*/n_special, (uint32_t)vocab_size);
+    // Multi-GPU, two modes.  A LARGE word table (random text: hundreds of millions of dedup tokens) stays sharded: every
+    // round's apply pass is divided by the ranks and pays one exchange of count deltas.  A SMALL one (natural text: a few million tokens,
+    // thousands of latency-bound rounds) would only get slower -- there the reference's own scheme applies (bpe.cpp:1029-1044: merge the
+    // shards' word maps once, then loop): the shards are gathered (the ranks' byte ranges in rank order are the file), every rank dedups
+    // the whole text and runs the merge loop alone, with NO collective per round; rank 0 writes the model.  The choice is made from the
+    // summed local token counts (an upper bound of the merged table), the same number on every rank.
+    if (comm) {
+      static const unsigned long long rep_max = getenv("YTTM_REPLICATE_MAX_TOKENS") ? strtoull(getenv("YTTM_REPLICATE_MAX_TOKENS"), nullptr, 10) : (1ull << 26);
+      const unsigned long long t_sum = g.allreduce_scalar(g.n_tokens0);
+      if (t_sum <= rep_max) {
+        g.gather_full_corpus();
+        g.set_comm(nullptr);
+        replicated = true;
+        std::vector<uint32_t> cps2;
+        std::vector<unsigned long long> cnts2;
+        unsigned long long len2 = 0;
+        g.char_hist(cps2, cnts2, len2);  // (the segment count of the whole text; the histogram is the reduced one again)
+        if (len2 != data_len) return Status(2, "multi-GPU: the gathered corpus differs from the sum of the shards");
+        g.build_word_table(a_cp.data(), a_id.data(), (uint32_t)alpha.size(), /*space_id=*/n_special, (uint32_t)vocab_size);
+      }
+    }
   }
   g.pair_count();
   if (rep) rep->seconds_frontend = since(t_all);
@@ -248,6 +270,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     rep->rounds = rounds;
     rep->cand_rescans = rescans;
     rep->rounds_exhausted = rounds_exhausted;
+    rep->replicated_merge_loop = replicated ? 1 : 0;
     rep->batch_extensions = batch_extensions;
     rep->hot_rebuilds = g.hot_rebuilds;
     rep->fused_rounds = g.fused_rounds;
