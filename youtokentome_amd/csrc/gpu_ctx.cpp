@@ -173,6 +173,9 @@ GpuCtx::GpuCtx(int device) : device_(device) {
                                                                   //  measured at 1 GB, K4 + candidate family ms: no index 151.1, 64/4 147.3, 128/4 148.8, 64/8 145.1, 32/8 147.8, 256/3 160.6)
   idx_force_ = env_uint("YTTM_INDEX_ALWAYS", 0) != 0;  // (tests: worklists from the index whenever the batch allows, however few tiles)
   use_pm_ = env_uint("YTTM_K4_PM", 0) != 0;
+  words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end, worklists of tiles from the pair index)
+  word_div_ = env_uint("YTTM_WORD_DIV", 24);
+  word_min_tiles_ = env_uint("YTTM_WORD_MIN_TILES", 16384);  // (tests: 0 = switch as soon as the hot list is active)
   bloom_mode_ = true;  // (the per-token flag variant of k_tiles is gone; the flag tables still serve the separate filter pass, YTTM_DENSE_PCT)
   gather_grid_ = env_uint("YTTM_GATHER_GRID", 0) != 0;  // (measured at 1 GB: 65.6 vs 62.7 us per late round -- the smaller grid is not faster)
   no_batch_args_ = getenv("YTTM_NO_BATCH_ARGS") != nullptr;  // (read once per context: a round has no time for getenv)
@@ -217,6 +220,7 @@ GpuCtx::~GpuCtx() {
   DFREE(db_.keys); DFREE(db_.vals); DFREE(db_.touched); DFREE(db_.n);
   free_table(pt_);
   free_index();
+  free_words();
   pool_quiesce(st_);
   if (h_pin_) {
     std::lock_guard<std::mutex> g(g_pool.mu);
@@ -572,6 +576,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
     HIP_CHECK(hipMemcpyAsync(d_cpmap_, cpmap.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, st_));
     sync();
   }
+  free_words();
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   cls_[0].nom = TILE_NOM_A; cls_[0].slot = TILE_SLOT_A;
   cls_[1].nom = TILE_NOM_B; cls_[1].slot = TILE_SLOT_B;
@@ -723,6 +728,20 @@ void GpuCtx::download_word_table(std::vector<uint32_t> &tok, std::vector<unsigne
     HIP_CHECK(hipMemcpyAsync(tl.data(), c.d_tile_len, (size_t)c.n_tiles * 4, hipMemcpyDeviceToHost, st_));
     HIP_CHECK(hipMemcpyAsync(wc.data(), c.d_wcnt, (size_t)c.n_unique * 4, hipMemcpyDeviceToHost, st_));
     sync();
+    if (ci == 0 && word_mode_) {  // class A in word mode: the words are where wmeta says
+      std::vector<unsigned long long> wm(c.n_unique);
+      HIP_CHECK(hipMemcpy(wm.data(), d_wmeta_, (size_t)c.n_unique * 8, hipMemcpyDeviceToHost));
+      for (unsigned long long w = 0; w < c.n_unique; w++) {
+        const unsigned long long o = wm[w] >> 16, len = wm[w] & 0xffffull;
+        for (unsigned long long p = 0; p < len; p++) {
+          const uint32_t v = all[o + p];
+          if (p == 0 && !tok.empty()) off.push_back(tok.size());
+          tok.push_back(v & TOK_MASK);
+        }
+      }
+      cnt.insert(cnt.end(), wc.begin(), wc.end());
+      continue;
+    }
     for (unsigned int t = 0; t < c.n_tiles; t++) {
       for (uint32_t p = 0; p < tl[t]; p++) {
         uint32_t v = all[(size_t)t * c.slot + p];
@@ -740,6 +759,7 @@ void GpuCtx::download_word_table(std::vector<uint32_t> &tok, std::vector<unsigne
 void GpuCtx::maybe_repack(int ci) {
   WordClass &c = cls_[ci];
   if (c.n_tiles < 2) return;
+  if (ci == 0 && word_mode_) return;  // (the words live in fixed slots now)
   chain_event_ = nullptr;  // work between two timed intervals: they no longer share an event
   unsigned long long *off = dmalloc<unsigned long long>(c.n_tiles);
   unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(c.n_tiles));
@@ -1088,6 +1108,11 @@ void GpuCtx::poll_mailbox(uint32_t round_id) {
     touched_last_ = touched - touched_cum_;
     touched_cum_ = touched;
   }
+  const unsigned long long sites = *(const unsigned long long *)(h + 88);  // (published by scan_top only; one round old, like the token counts)
+  if (sites > sites_cum_) {
+    sites_last_ = sites - sites_cum_;
+    sites_cum_ = sites;
+  }
 }
 
 // One scan of the hot list (L1) by k_hot_scan -- every listed slot, many workgroups: candidates above (t, tm), histogram of the
@@ -1325,6 +1350,52 @@ void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned lon
 }
 
 // ------------------------------------------------------------------------------------------------- K4
+void GpuCtx::free_words() {
+  DFREE(d_wmeta_); DFREE(d_gm_); DFREE(d_xyz_); DFREE(d_wworklist_);
+  DFREE(tl_.base); DFREE(tl_.cap); DFREE(tl_.fill); DFREE(tl_.rec_word); DFREE(tl_.rec_l); DFREE(tl_.rec_r); DFREE(tl_.cursor);
+  tl_ = TokLists{};
+  word_mode_ = false;
+  sites_last_ = ~0ull;
+}
+
+// The switch to word mode (k_merge.hip: k_words): from here on class-A words live in the slots they have now and a round visits the words
+// that hold a merge site.  Called between rounds.
+void GpuCtx::enter_word_mode(uint32_t z_next) {
+  WordClass &c = cls_[0];
+  chain_event_ = nullptr;
+  d_wmeta_ = dmalloc<unsigned long long>(c.n_unique + 1);
+  launch_words_init(c.ts, d_wmeta_, st_);
+  d_wworklist_ = dmalloc<uint32_t>(c.n_unique + 64);
+  d_gm_ = dmalloc<unsigned int>(WGATHER_MAXK + 4);
+  HIP_CHECK(hipMemsetAsync(d_gm_, 0, (WGATHER_MAXK + 4) * 4, st_));
+  d_xyz_ = dmalloc<uint32_t>(3 * (size_t)RULES_CAP);
+  tl_.base = dmalloc<unsigned long long>(tokflag_cap_);
+  tl_.cap = dmalloc<uint32_t>(tokflag_cap_);
+  tl_.fill = dmalloc<uint32_t>(tokflag_cap_);
+  HIP_CHECK(hipMemsetAsync(tl_.base, 0, (size_t)tokflag_cap_ * 8, st_));
+  HIP_CHECK(hipMemsetAsync(tl_.cap, 0, (size_t)tokflag_cap_ * 4, st_));
+  HIP_CHECK(hipMemsetAsync(tl_.fill, 0, (size_t)tokflag_cap_ * 4, st_));
+  tl_.cursor = dmalloc<unsigned long long>(2);
+  HIP_CHECK(hipMemsetAsync(tl_.cursor, 0, 16, st_));
+  // every record ever matched is a site at most once through each of its two neighbours, and a site removes a token: a few records per
+  // live token bound the log between two index builds; should it fill up all the same, the round says so and the index is rebuilt
+  const unsigned long long live = std::max<unsigned long long>(live_tokens_last_, 1ull << 16);
+  static const unsigned long long log_env = getenv("YTTM_WORD_LOG") ? strtoull(getenv("YTTM_WORD_LOG"), nullptr, 10) : 0;  // (tests: a log that overflows)
+  tl_.log_cap = log_env ? log_env : 2 * live + (1ull << 20);
+  tl_.rec_word = dmalloc<uint32_t>(tl_.log_cap);
+  tl_.rec_l = dmalloc<uint32_t>(tl_.log_cap);
+  tl_.rec_r = dmalloc<uint32_t>(tl_.log_cap);
+  tl_.broken = (unsigned int *)((unsigned char *)h_pin_ + 7168);  // (a free corner of the mailbox page: the kernels write it with system-scope stores)
+  *(volatile unsigned int *)tl_.broken = 0;
+  word_mode_ = true;
+  word_switch_round = merge_rounds;
+  idx_valid_ = false;
+  idx_pending_ = true;
+  if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] word mode from round %llu on: %llu words, last round %llu sites, %llu tokens streamed; log %llu records\n", merge_rounds,
+                                  c.n_unique, sites_last_, live_tokens_last_, tl_.log_cap);
+  build_index(z_next);
+}
+
 void GpuCtx::free_index() {
   DFREE(idx_.key); DFREE(idx_.cnt); DFREE(idx_.off); DFREE(idx_.bloom); DFREE(idx_.post); DFREE(d_stamp_); DFREE(idx_scan_tmp_);
   idx_cap_ = post_cap_ = 0;
@@ -1363,7 +1434,7 @@ void GpuCtx::build_index(uint32_t z_next) {
   HIP_CHECK(hipMemsetAsync(idx_.bloom, 0, ENC_BLOOM_WORDS * 4, st_));
   t_begin(KT_CAND);
   launch_idx_seed(pt_, idx_, listed, st_);
-  launch_idx_stream(0, false, c.ts, idx_, st_);
+  launch_idx_stream(0, false, c.ts, idx_, st_, word_mode_);
   // offsets = exclusive scan of the counts (one extra zero count behind the last slot: off[mask + 1] = the total)
   HIP_CHECK(hipMemsetAsync(idx_.cnt + want, 0, 4, st_));
   launch_exclusive_scan(idx_.cnt, want + 1, idx_.off, idx_scan_tmp_, d_counters_ + 56, st_);
@@ -1374,7 +1445,7 @@ void GpuCtx::build_index(uint32_t z_next) {
   index_builds++;
   if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] index build at round %llu: %u listed pairs, %llu postings, %u tiles, last round touched %llu tiles\n", merge_rounds, listed, total, c.n_tiles, touched_last_);
   // worth it only if a round's postings are few: all of them together must stay well below one posting per live token
-  if (total == 0 || total > 0xfffffff0ull || (!idx_force_ && total > (unsigned long long)c.n_tiles * idx_post_per_tile_)) {
+  if (total == 0 || total > 0xfffffff0ull || (!idx_force_ && !word_mode_ && total > (unsigned long long)c.n_tiles * idx_post_per_tile_)) {
     t_end(KT_CAND, 4ull * c.n_tiles * c.nom);
     return;
   }
@@ -1383,14 +1454,20 @@ void GpuCtx::build_index(uint32_t z_next) {
     post_cap_ = total + total / 4 + 1024;
     idx_.post = dmalloc<uint32_t>(post_cap_);
   }
-  launch_idx_stream(0, true, c.ts, idx_, st_);
+  launch_idx_stream(0, true, c.ts, idx_, st_, word_mode_);
   t_end(KT_CAND, 8ull * c.n_tiles * c.nom);
-  if (c.n_tiles > stamp_cap_) {
+  const unsigned long long stamps = word_mode_ ? c.n_unique : c.n_tiles;  // (word mode: a posting is a word, and a round claims words)
+  if (stamps > stamp_cap_) {
     DFREE(d_stamp_);
-    stamp_cap_ = c.n_tiles + c.n_tiles / 8 + 64;
+    stamp_cap_ = (unsigned int)(stamps + stamps / 8 + 64);
     d_stamp_ = dmalloc<uint32_t>(stamp_cap_);
   }
   HIP_CHECK(hipMemsetAsync(d_stamp_, 0, (size_t)stamp_cap_ * 4, st_));
+  if (word_mode_) {  // every token that exists now is covered by the postings: the instance lists start over
+    HIP_CHECK(hipMemsetAsync(tl_.cursor, 0, 16, st_));
+    sync();
+    *(volatile unsigned int *)tl_.broken = 0;
+  }
   idx_valid_ = true;
   idx_zbuild_ = z_next;
 }
@@ -1438,7 +1515,16 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // Worklist from the pair index instead of a pass over every tile?  Only when every rule of the batch is in the index (pairs of
   // tokens older than the index; candidates come from the hot list, whose pairs were its keys), the last round touched few tiles,
   // and once in a while not: a streamed round refreshes the live-token count the repack trigger needs.
-  const bool sparse = idx_enabled_ && !instrument && cls_[0].n_tiles && !cls_[2].n_tiles && hot_state_ == HOT_ACTIVE && dense_pct_ < 1000 &&
+  // word mode: on when the last round's merge sites are few against the tokens a pass over the tiles streams (and then for good)
+  if (!word_mode_ && words_enabled_ && idx_enabled_ && !instrument && cls_[0].n_tiles >= word_min_tiles_ && cls_[0].n_tiles && hot_state_ == HOT_ACTIVE &&
+      dense_pct_ < 1000 && sites_last_ != ~0ull && live_tokens_last_ &&
+      (word_div_ == 0 || sites_last_ * (unsigned long long)word_div_ < live_tokens_last_))
+    enter_word_mode(z_base);
+  if (word_mode_) {
+    if (*(volatile unsigned int *)tl_.broken) idx_pending_ = true;  // (the last round is over: its mailbox has been read)
+    if (idx_pending_) build_index(z_base);
+  }
+  const bool sparse = idx_enabled_ && !words_enabled_ && !instrument && cls_[0].n_tiles && !cls_[2].n_tiles && hot_state_ == HOT_ACTIVE && dense_pct_ < 1000 &&
                       (idx_force_ || (cls_[0].n_tiles >= idx_min_tiles_ && touched_last_ != (~0ull >> 2) && touched_last_ * idx_sparse_div_ < cls_[0].n_tiles));
   if (sparse && idx_pending_) build_index(z_base);
   bool gathered = sparse && idx_valid_ && rounds_since_dense_ < 32;
@@ -1475,7 +1561,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   const bool pm = use_pm_ && !instrument;
   // (token flags live in an LDS bitmap of FLAG_LDS_IDS ids; the pair filter -- bloom_mode_ -- has no such limit)
   const bool by_args = k <= (uint32_t)BATCH_ARGS_MAX && !cls_[2].n_tiles && !no_batch_args &&
-                       (pm || ((bloom_mode_ || vmax < FLAG_LDS_IDS) && (!cls_[0].n_tiles || dense_class(0)))) &&
+                       (pm || word_mode_ || ((bloom_mode_ || vmax < FLAG_LDS_IDS) && (!cls_[0].n_tiles || dense_class(0)))) &&
                        (!cls_[1].n_tiles || ((bloom_mode_ || vmax < FLAG_LDS_IDS) && dense_class(1)));
   unsigned int n_upd = 0;
   if (!by_args) {  // (the common small batch needs none of this: the host's share of a round is on the critical path)
@@ -1565,6 +1651,47 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   }
   for (int ci = 1; ci >= 0; ci--) {
     if (!cls_[ci].n_tiles) continue;
+    if (ci == 0 && word_mode_) {
+      // the batch's rules -> worklist of words (k_wgather; it also allots the new tokens' instance lists), then the words (k_words)
+      WordClass &c = cls_[0];
+      const uint32_t *d_xyz = nullptr;
+      if (!by_args) {
+        uint32_t *h_xyz = (uint32_t *)(pin + (size_t)RULES_CAP * sizeof(RuleSlot) + 8 * (size_t)RULES_CAP * sizeof(uint32_t) + 16384);
+        memcpy(h_xyz, xyz, (size_t)k * 12);
+        HIP_CHECK(hipMemcpyAsync(d_xyz_, h_xyz, (size_t)k * 12, hipMemcpyHostToDevice, st_));
+        d_xyz = d_xyz_;
+      }
+      if (k > WGATHER_MAXK) throw GpuError{"merge_apply: batch too large for the word-mode gather"};
+      HIP_CHECK(hipMemsetAsync(c.d_work_n, 0, 64, st_));
+      WGatherArgs ga{};
+      ga.ix = idx_;
+      ga.ix_valid = idx_valid_ ? 1u : 0u;
+      ga.z_static = idx_valid_ ? idx_zbuild_ : 0xffffffffu;  // (no index: every rule is "not found", the round takes every word)
+      ga.tl = tl_;
+      ga.stamp = d_stamp_;
+      ga.round_id = (uint32_t)(merge_rounds + 1);
+      ga.worklist = d_wworklist_;
+      ga.wl_seg = c.n_unique + 64;
+      ga.work_n = c.d_work_n;
+      ga.gm = d_gm_;
+      ga.done_ctr = d_gm_ + WGATHER_MAXK;
+      ga.xyz = d_xyz;
+      ga.k = k;
+      ga.z_base = z_base;
+      if (!d_stamp_) {  // (the index could not be built yet: no stamps either -- the gather must not claim words)
+        stamp_cap_ = (unsigned int)(c.n_unique + c.n_unique / 8 + 64);
+        d_stamp_ = dmalloc<uint32_t>(stamp_cap_);
+        HIP_CHECK(hipMemsetAsync(d_stamp_, 0, (size_t)stamp_cap_ * 4, st_));
+        ga.stamp = d_stamp_;
+      }
+      launch_wgather(ga, by_args ? &ba : nullptr, st_);
+      const WordSet wset{c.d_tok, d_wmeta_, c.d_wcnt, (uint32_t)c.n_unique};
+      launch_words_apply(wset, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, &ba,
+                         sa.on && last_cls == 0 ? &sa : nullptr, sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + 4096, 1ull << 30) : 0u, st_);
+      word_rounds++;
+      if (!idx_valid_) word_all_rounds++;
+      continue;
+    }
     const bool wl_gathered = gathered && ci == 0;
     if (ci == 0 && pm) {
       const bool eager_w = touched_last_ == (~0ull >> 2) || touched_last_ * 2 >= cls_[0].n_tiles;

@@ -87,7 +87,7 @@ class GpuCtx {
   const unsigned long long *last_hist() const { return last_hist_; }
   unsigned long long last_live() const { return last_live_; }
   int last_top_bin() const { return (int)last_top_bin_; }  // no bin above this one is in use
-  unsigned long long index_builds = 0, gathered_rounds = 0, pm_rounds = 0;  // K4 rounds whose worklist came from the pair index
+  unsigned long long index_builds = 0, gathered_rounds = 0, pm_rounds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0;  // K4 rounds whose worklist came from the pair index
   unsigned long long word_table_retries = 0;  // K2: the word table had to be redone with the worst-case size
   unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0, delta_regrows = 0;
   unsigned long long tail_ticks[3] = {0, 0, 0}, tail_listed = 0;  // round_tail: fold / list scan / publish, in 10 ns ticks; entries it read
@@ -195,6 +195,18 @@ class GpuCtx {
   unsigned int rounds_since_dense_ = 0, idx_min_tiles_ = 16384, idx_post_per_tile_ = 64, idx_sparse_div_ = 8;
   void build_index(uint32_t z_next);
   void free_index();
+  // word mode (k_merge.hip: k_words): class-A words processed one by one from a worklist of the words that hold a merge site
+  bool word_mode_ = false, words_enabled_ = true;
+  unsigned int word_div_ = 24;     // switch when (merge sites of the last round) * word_div_ < (tokens a pass over the tiles streams)
+  unsigned int word_min_tiles_ = 16384;
+  unsigned long long *d_wmeta_ = nullptr;
+  unsigned int *d_gm_ = nullptr;   // [WGATHER_MAXK] + the gather's ticket
+  uint32_t *d_xyz_ = nullptr;      // a batch too large for BatchArgs, as (x, y, z) triples
+  uint32_t *d_wworklist_ = nullptr;  // [n_unique + 64] the round's words
+  TokLists tl_{};
+  unsigned long long sites_cum_ = 0, sites_last_ = ~0ull;
+  void enter_word_mode(uint32_t z_next);
+  void free_words();
   unsigned long long rounds_since_check_ = 0;
   bool pending_zero_ = false, zero_valid_ = false;  // valid: the zero_* members still describe the last batch
   void flush_pending_zero();

@@ -263,8 +263,8 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       fprintf(stderr, "[yttm] fused rounds %llu: tail set-up %.2f us, top-list scan %.2f us (%.0f entries), publish %.2f us per round\n", g.fused_rounds,
               g.tail_ticks[0] * 0.01 / g.fused_rounds, g.tail_ticks[1] * 0.01 / g.fused_rounds, (double)g.tail_listed / g.fused_rounds,
               g.tail_ticks[2] * 0.01 / g.fused_rounds);
-    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu, hot rebuilds %llu, top refills %llu, index builds %llu (%llu rounds from the index, %llu through k_apply_pm), pair table %llu keys in %llu slots (%llu rehashes)\n",
-                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.hot_rebuilds, g.top_refills, g.index_builds, g.gathered_rounds, g.pm_rounds, g.n_keys_host, g.table_capacity(), g.rehashes);
+    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu, hot rebuilds %llu, top refills %llu, index builds %llu (%llu rounds from the index, %llu through k_apply_pm, %llu in word mode from round %llu on, %llu of them over every word), pair table %llu keys in %llu slots (%llu rehashes)\n",
+                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.hot_rebuilds, g.top_refills, g.index_builds, g.gathered_rounds, g.pm_rounds, g.word_rounds, g.word_switch_round, g.word_all_rounds, g.n_keys_host, g.table_capacity(), g.rehashes);
   }
   if (rep) {
     rep->rounds = rounds;
@@ -280,6 +280,9 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     rep->top_refills = g.top_refills;
     rep->index_builds = g.index_builds;
     rep->gathered_rounds = g.gathered_rounds;
+    rep->word_rounds = g.word_rounds;
+    rep->word_switch_round = g.word_switch_round;
+    rep->word_all_rounds = g.word_all_rounds;
     rep->rules = rules.size();
     rep->n_unique = g.n_unique;
     rep->n_tokens = g.n_tokens0;

@@ -625,7 +625,7 @@ __device__ inline uint32_t dense_copies(uint32_t n) {
 }
 
 // everything that happens to one staged tile (K3 count or K4 merge)
-template <int SLOT, bool MERGE, bool LDSR>
+template <int SLOT, bool MERGE, bool LDSR, bool WORDS = false>
 __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &ts, const PairTable &pt, const DeltaBuf &db,
                                     const RuleTab<LDSR> &rtab, uint32_t self_x, uint32_t self_z,
                                     uint32_t z_base, uint32_t t, int n, uint32_t word0, const WReg<SLOT> &wreg, TileStats &S,
@@ -826,6 +826,8 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
           }
           wave_sync();
         }
+        // (word mode, k_words: the gathered words go back to their own slots -- words_out() -- not to a tile)
+        if (WORDS) return;
         // ---- phase 3: compact in place (all reads come from LDS, so overwriting the slot in HBM is safe) ----------------
         // survivors of a chunk = its positions that are not the y of a site; tokens before the first site neither move nor change
         uint32_t *dst = ts.tok + (size_t)t * SLOT;
@@ -1507,7 +1509,7 @@ __global__ __launch_bounds__(BLOCK) void k_publish_box(const unsigned char *__re
     *reinterpret_cast<unsigned long long *>(mailbox + 56 + 8 * k) = xstat[k];
     xstat[k] = 0;
   }
-  if (threadIdx.x >= 24 && threadIdx.x < 32) mh[threadIdx.x] = bh[threadIdx.x];  // bytes 96..127: timing marks
+  if (threadIdx.x >= 22 && threadIdx.x < 32) mh[threadIdx.x] = bh[threadIdx.x];  // bytes 88..95: merge sites so far; 96..127: timing marks
   const unsigned long long *bhist = reinterpret_cast<const unsigned long long *>(box + MB_HIST);
   unsigned long long *mhist = reinterpret_cast<unsigned long long *>(mailbox + MB_HIST);
   for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) mhist[b] = bhist[b];
@@ -1732,7 +1734,7 @@ __global__ __launch_bounds__(BLOCK) void k_idx_seed(PairTable pt, PairIndex ix) 
 // One wavefront per tile, tokens in registers: every adjacency whose pair is a key of the index is counted (FILL = false) or has
 // its tile appended to the key's postings (FILL = true; one posting per adjacency: duplicates of a tile are harmless, the gather
 // claims a tile once).
-template <int SLOT, bool FILL>
+template <int SLOT, bool FILL, bool WORDS>
 __global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) {
   __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
   for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += BLOCK) bloom[i] = ix.bloom[i];
@@ -1743,7 +1745,11 @@ __global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) 
     const int n = (int)ts.tile_len[t];
     uint4 r[SLOT / 256];
     tile_fetch<SLOT>(r, ts, t, n);
-#define IDX_PAIR(T0, T1)                                                              \
+    // WORDS: a posting is the WORD that holds the adjacency (word mode: the tile may hold TOK_HOLEs -- word-start bit set, so never the
+    // second token of an adjacency; never counted as a word start).  wb = word starts before my first token of the row.
+    uint32_t wrow = WORDS ? ts.tile_word0[t] : 0u;
+    (void)wrow;
+#define IDX_PAIR(T0, T1, WIDX)                                                        \
   if (!((T1)&TOK_WS)) {                                                                \
     const uint32_t a_ = (T0)&TOK_MASK, b_ = (T1)&TOK_MASK;                             \
     const uint32_t h_ = enc_hash(a_, b_);                                              \
@@ -1751,7 +1757,7 @@ __global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) 
     if ((bloom[enc_bloom_word(h_)] & bits_) == bits_) {                                \
       const uint32_t s_ = idx_find(ix, pair_key(a_, b_), h_);                          \
       if (s_ != 0xffffffffu) {                                                         \
-        if (FILL) ix.post[ix.off[s_] + atomicAdd(&ix.cnt[s_], 1u)] = t;                \
+        if (FILL) ix.post[ix.off[s_] + atomicAdd(&ix.cnt[s_], 1u)] = WORDS ? (WIDX) : t; \
         else atomicAdd(&ix.cnt[s_], 1u);                                               \
       }                                                                                \
     }                                                                                  \
@@ -1763,11 +1769,23 @@ __global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) 
         uint32_t nx0 = TOK_WS;
         if (j + 1 < SLOT / 256) nx0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
         if (lane == 63) nx = nx0;
+        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // word of my token i (WORDS && FILL)
+        if (WORDS && FILL) {
+          const bool s0 = tok_is_ws(r[j].x), s1 = tok_is_ws(r[j].y), s2 = tok_is_ws(r[j].z), s3 = tok_is_ws(r[j].w);
+          const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1), m2 = __ballot(s2), m3 = __ballot(s3);
+          const unsigned long long lt = lanemask_lt();
+          const uint32_t wb = wrow + (uint32_t)(__popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt));
+          w0 = wb + (s0 ? 1u : 0u) - 1u;
+          w1 = w0 + (s1 ? 1u : 0u);
+          w2 = w1 + (s2 ? 1u : 0u);
+          w3 = w2 + (s3 ? 1u : 0u);
+          wrow += (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+        }
         // (slots behind the live prefix hold zeros: id 0 is a special token, never part of a pair of the index)
-        IDX_PAIR(r[j].x, r[j].y)
-        IDX_PAIR(r[j].y, r[j].z)
-        IDX_PAIR(r[j].z, r[j].w)
-        IDX_PAIR(r[j].w, nx)
+        IDX_PAIR(r[j].x, r[j].y, w0)
+        IDX_PAIR(r[j].y, r[j].z, w1)
+        IDX_PAIR(r[j].z, r[j].w, w2)
+        IDX_PAIR(r[j].w, nx, w3)
       }
     }
 #undef IDX_PAIR
@@ -1802,6 +1820,525 @@ __global__ __launch_bounds__(BLOCK) void k_gather(PairIndex ix, const RuleSlot *
   for (unsigned long long i = o0 + threadIdx.x; i < o1; i += BLOCK) {
     const uint32_t t = ix.post[i];
     if (atomicExch(&stamp[t], round_id) != round_id) worklist[part * wl_seg + atomicAdd(&work_n[part], 1u)] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- word mode
+// Once a round's merge sites are few against the tokens a pass over the tiles streams, class-A words leave the tiles (yttm_device.h:
+// WordSet): a round then (1) k_wgather looks the batch's rules up -- postings of the pair index, or the instance list of the pair's
+// younger token -- and claims each word that may hold a site once; (2) k_words gathers those words, 64 at a time, into a wave's LDS
+// tile, runs the same site search and count-delta code as a tile does (reg_find_sites, process_tile), writes the shrunk words back
+// into their slots and records every new token instance in its token's list.  Work follows the merge sites (the reference's
+// pair2pos, bpe.cpp:438/:626/:694), not the table.
+
+// tile -> wmeta of its words (the switch; one wave per tile)
+template <int SLOT>
+__global__ __launch_bounds__(BLOCK) void k_words_init(TileSet ts, unsigned long long *__restrict__ wmeta) {
+  const int lane = lane_id();
+  constexpr int NC = SLOT / 64;
+  const uint32_t stride = gridDim.x * NWAVES;
+  for (uint32_t t = blockIdx.x * NWAVES + (threadIdx.x >> 6); t < ts.n_tiles; t += stride) {
+    const int n = (int)ts.tile_len[t];
+    const uint32_t *src = ts.tok + (size_t)t * SLOT;
+    unsigned long long m[NC];
+    uint32_t wbase[NC];
+    uint32_t acc = ts.tile_word0[t];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const int p = c * 64 + lane;
+      m[c] = __ballot(p < n && (src[p] & TOK_WS));
+      wbase[c] = acc;
+      acc += (uint32_t)__popcll(m[c]);
+    }
+    int next_start = n;  // first word start behind the chunk
+#pragma unroll
+    for (int c = NC - 1; c >= 0; c--) {
+      const unsigned long long mc = m[c];
+      if ((mc >> lane) & 1ull) {
+        const int p = c * 64 + lane;
+        const unsigned long long after = mc & ~((2ull << lane) - 1ull);
+        const int end = after ? c * 64 + (__ffsll((long long)after) - 1) : next_start;
+        const uint32_t w = wbase[c] + (uint32_t)__popcll(mc & lanemask_lt());
+        wmeta[w] = (((unsigned long long)t * SLOT + (unsigned long long)p) << 16) | (unsigned long long)(end - p);
+      }
+      if (mc) next_start = c * 64 + (__ffsll((long long)mc) - 1);
+    }
+  }
+}
+
+// The rules of the batch -> the round's worklist of words.  Every workgroup works out where each rule's candidates are (a posting
+// run of the index, or the instance list of the younger token and the neighbour to look for), lays the runs end to end and takes its
+// share of the whole -- a rule with a million records and one with ten cost the same per record.  The last workgroup to finish allots
+// the instance lists of the batch's new tokens (at most one record per record matched: every site was one of them).
+constexpr int WG_NT = 512, WG_BUF = 4096;
+__global__ __launch_bounds__(WG_NT) void k_wgather(WGatherArgs g, BatchArgs ba) {
+  __shared__ unsigned long long s_base[WGATHER_MAXK];
+  __shared__ unsigned long long s_pref[WGATHER_MAXK + 1];
+  __shared__ uint32_t s_filt[WGATHER_MAXK];
+  __shared__ uint32_t s_cnt[WGATHER_MAXK];
+  __shared__ uint8_t s_mode[WGATHER_MAXK];  // 0: postings (word ids), 1: records whose left neighbour is s_filt, 2: ... right neighbour
+  __shared__ uint32_t s_buf[WG_BUF];
+  __shared__ unsigned long long s_wsum[WG_NT / 64];
+  __shared__ unsigned int s_n, s_gbase, s_last;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t k = g.k;
+  const PairIndex ix{g.ix.key, g.ix.cnt, g.ix.off, g.ix.bloom, g.ix.post, g.ix.mask};
+  if (tid == 0) s_n = 0;
+  // ---- the rules' runs; thread t owns rules [t * per, (t + 1) * per)
+  const uint32_t per = (k + WG_NT - 1) / WG_NT;
+  unsigned long long mine = 0;
+  for (uint32_t j = (uint32_t)tid * per; j < ((uint32_t)tid + 1) * per && j < k; j++) {
+    const uint32_t x = g.xyz ? g.xyz[3 * j] : ba.xy[2 * j], y = g.xyz ? g.xyz[3 * j + 1] : ba.xy[2 * j + 1];
+    const uint32_t m = x > y ? x : y;
+    unsigned long long base = 0, len = 0;
+    uint32_t filt = 0, mode = 0;
+    if (m < g.z_static) {
+      uint32_t s = 0xffffffffu;
+      if (g.ix_valid) s = idx_find(ix, pair_key(x, y), enc_hash(x, y));
+      if (s == 0xffffffffu) {
+        g.work_n[WL_PARTS + 1] = 1u;  // not in the index: this round takes every word
+      } else {
+        base = ix.off[s];
+        len = ix.off[s + 1] - base;
+      }
+    } else {
+      base = g.tl.base[m];
+      const uint32_t f = g.tl.fill[m], c = g.tl.cap[m];
+      len = f < c ? f : c;
+      if (x > y) { mode = 2; filt = y; } else { mode = 1; filt = x; }
+    }
+    s_base[j] = base;
+    s_pref[j] = len;
+    s_filt[j] = filt;
+    s_mode[j] = (uint8_t)mode;
+    s_cnt[j] = 0;
+    mine += len;
+  }
+  {  // exclusive scan of the run lengths over the workgroup
+    unsigned long long inc = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    unsigned long long before = inc - mine;
+    for (int w = 0; w < wave; w++) before += s_wsum[w];
+    for (uint32_t j = (uint32_t)tid * per; j < ((uint32_t)tid + 1) * per && j < k; j++) {
+      const unsigned long long l = s_pref[j];
+      s_pref[j] = before;
+      before += l;
+    }
+    if (tid == WG_NT - 1) s_pref[k] = before;  // (the last thread's runs end the sequence, whether it owns rules or not)
+    __syncthreads();
+  }
+  const unsigned long long total = s_pref[k];
+  const unsigned long long chunk = (total + gridDim.x - 1) / gridDim.x;
+  const unsigned long long lo = (unsigned long long)blockIdx.x * chunk, hi = lo + chunk < total ? lo + chunk : total;
+  const uint32_t part = 0;  // (word mode keeps ONE list: a workgroup appends once, at its end)
+  for (unsigned long long i0 = lo; i0 < hi; i0 += WG_NT) {
+    const unsigned long long i = i0 + (unsigned long long)tid;
+    bool hit = false;
+    uint32_t w = 0;
+    if (i < hi) {
+      uint32_t a = 0, b = k;  // the rule whose run holds record i: the last j with s_pref[j] <= i
+      while (b - a > 1) {
+        const uint32_t mid = (a + b) >> 1;
+        if (s_pref[mid] <= i) a = mid; else b = mid;
+      }
+      const unsigned long long at = s_base[a] + (i - s_pref[a]);
+      const uint32_t mode = s_mode[a];
+      bool match = true;
+      if (mode == 0) {
+        w = ix.post[at];
+      } else {
+        match = (mode == 1 ? g.tl.rec_l[at] : g.tl.rec_r[at]) == s_filt[a];
+        if (match) w = g.tl.rec_word[at];
+      }
+      if (match) {
+        atomicAdd(&s_cnt[a], 1u);
+        hit = atomicExch(&g.stamp[w], g.round_id) != g.round_id;  // each word once per round
+      }
+    }
+    const unsigned long long hm = __ballot(hit);
+    if (hm) {
+      unsigned int b0 = 0;
+      const int first = __ffsll((long long)hm) - 1;
+      if (lane == first) b0 = atomicAdd(&s_n, (unsigned int)__popcll(hm));
+      b0 = (unsigned int)__shfl((int)b0, first);
+      if (hit) {
+        const unsigned int pos = b0 + (unsigned int)__popcll(hm & lanemask_lt());
+        if (pos < (unsigned int)WG_BUF) s_buf[pos] = w;
+        else g.worklist[part * g.wl_seg + atomicAdd(&g.work_n[part], 1u)] = w;  // (the buffer is full: one by one)
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned int nbuf = s_n < (unsigned int)WG_BUF ? s_n : (unsigned int)WG_BUF;
+  if (tid == 0 && nbuf) s_gbase = atomicAdd(&g.work_n[part], nbuf);
+  __syncthreads();
+  for (unsigned int i = (unsigned int)tid; i < nbuf; i += WG_NT) g.worklist[part * g.wl_seg + s_gbase + i] = s_buf[i];
+  for (uint32_t j = (uint32_t)tid; j < k; j += WG_NT)
+    if (s_cnt[j]) atomicAdd(&g.gm[j], s_cnt[j]);
+  // ---- the last workgroup allots the new tokens' lists (the counts went out as device-scope atomics: see k_tiles on the ticket)
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(g.done_ctr, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  unsigned long long mine2 = 0;
+  for (uint32_t j = (uint32_t)tid * per; j < ((uint32_t)tid + 1) * per && j < k; j++) {
+    const unsigned int c = __hip_atomic_load(&g.gm[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_cnt[j] = c;
+    mine2 += c;
+  }
+  unsigned long long inc = mine2;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) s_wsum[wave] = inc;
+  __syncthreads();
+  unsigned long long before = inc - mine2, all = 0;
+  for (int w = 0; w < WG_NT / 64; w++) {
+    if (w < wave) before += s_wsum[w];
+    all += s_wsum[w];
+  }
+  const unsigned long long cur = *g.tl.cursor;
+  const bool fits = cur + all <= g.tl.log_cap && !g.work_n[WL_PARTS + 1];
+  for (uint32_t j = (uint32_t)tid * per; j < ((uint32_t)tid + 1) * per && j < k; j++) {
+    const uint32_t z = g.z_base + j;
+    g.tl.base[z] = cur + before;
+    g.tl.cap[z] = fits ? s_cnt[j] : 0u;
+    g.tl.fill[z] = 0u;
+    before += s_cnt[j];
+    g.gm[j] = 0u;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (fits) *g.tl.cursor = cur + all;
+    else __hip_atomic_store(g.tl.broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (log full, or a round that took every word: its matches say nothing about its sites)
+    *g.done_ctr = 0u;
+  }
+}
+
+// per-wave state of k_words on top of the tile state
+struct WordsLds {
+  unsigned long long lin[TILE_SLOT_A / 64];      // bit p: a word starts at position p of the gathered tile
+  unsigned long long newsite[TILE_SLOT_A / 64];  // bit q: the token at position q of the compacted tile is a new one
+  uint32_t wnew[66];                             // start of word i in the compacted tile; [nw] = its length
+};
+constexpr int WORDS_RB = 1024;  // new-instance records buffered per workgroup (flushed once, at the end: one cursor bump per new token and workgroup)
+struct RecBuf {
+  uint32_t zr[WORDS_RB], word[WORDS_RB], l[WORDS_RB], r[WORDS_RB];
+  unsigned int n;
+};
+__device__ inline void rec_direct(const TokLists &tl, uint32_t z, uint32_t word, uint32_t l, uint32_t r) {
+  const uint32_t at = atomicAdd(&tl.fill[z], 1u);
+  if (at < tl.cap[z]) {
+    const unsigned long long o = tl.base[z] + at;
+    tl.rec_word[o] = word;
+    tl.rec_l[o] = l;
+    tl.rec_r[o] = r;
+  } else {
+    __hip_atomic_store(tl.broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+template <int WPB, bool LDSR>
+__global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules, unsigned int rule_mask,
+                                                    const uint32_t *__restrict__ bloom_g, uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules,
+                                                    const uint32_t *__restrict__ worklist, unsigned long long wl_seg,
+                                                    const unsigned int *__restrict__ work_n, unsigned long long *__restrict__ stats, TokLists tl,
+                                                    BatchArgs ba, ScanArgs sa) {
+  constexpr int SLOT = TILE_SLOT_A;
+  __shared__ WaveLds<SLOT> WL[WPB];
+  __shared__ WordsLds XL[WPB];
+  __shared__ AggLds A;
+  __shared__ RecBuf RB;
+  __shared__ unsigned long long rkeys[LDSR ? APPLY_LDS_RULES : 1];
+  __shared__ uint16_t rridx[LDSR ? APPLY_LDS_RULES : 1];
+  const bool from_args = LDSR && ba.k != 0;
+  agg_init<WPB * 64>(A, from_args ? nullptr : bloom_g);  // (A.flagbits holds the batch's pair filter)
+  if (threadIdx.x == 0) RB.n = 0;
+  if (from_args) {
+    for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += WPB * 64) A.flagbits[s] = 0;
+    for (unsigned int i = threadIdx.x; i <= rule_mask; i += WPB * 64) rkeys[i] = PT_EMPTY;
+    __syncthreads();
+    for (unsigned int j = threadIdx.x; j < ba.k; j += WPB * 64) {
+      const uint32_t x = ba.xy[2 * j], y = ba.xy[2 * j + 1];
+      if (x != y) {
+        const uint32_t bh = pm_hash(x, y);
+        atomicOr(&A.flagbits[pm_word(bh)], pm_bits(bh));
+        const unsigned long long key = pair_key(x, y);
+        unsigned int h = pair_hash32(key) & rule_mask;
+        for (;;) {
+          if (atomicCAS(&rkeys[h], PT_EMPTY, key) == PT_EMPTY) {
+            rridx[h] = (uint16_t)j;
+            break;
+          }
+          h = (h + 1) & rule_mask;
+        }
+      }
+    }
+  } else if (LDSR) {
+    for (unsigned int i = threadIdx.x; i <= rule_mask; i += WPB * 64) {
+      rkeys[i] = rules[i].key;
+      rridx[i] = (uint16_t)(rules[i].z - z_base);
+    }
+  }
+  const RuleTab<LDSR> rtab{rkeys, rridx, rules, rule_mask, z_base};
+  __syncthreads();
+  const int wave = uni((int)(threadIdx.x >> 6)), lane = lane_id();
+  WaveLds<SLOT> &W = WL[wave];
+  WordsLds &X = XL[wave];
+  const TileSet ts{ws.tok, nullptr, nullptr, ws.wcnt, 0u};
+  // work items: runs of 64 worklist entries, or of 64 words
+  if (worklist && work_n[WL_PARTS + 1]) worklist = nullptr;
+  const uint32_t wl_n = worklist ? work_n[0] : 0u;
+  const unsigned long long n_items = worklist ? ((unsigned long long)wl_n + 63ull) / 64ull : ((unsigned long long)ws.n_words + 63ull) / 64ull;
+  (void)wl_seg;
+  TileStats S;
+  for (unsigned long long item = (unsigned long long)blockIdx.x * WPB + (unsigned long long)wave; item < n_items; item += (unsigned long long)gridDim.x * WPB) {
+    // ---- my word (lane l: entry l of the run)
+    bool have;
+    uint32_t wid = 0;
+    {
+      const unsigned long long wi = item * 64ull + (unsigned long long)lane;
+      have = wi < (worklist ? (unsigned long long)wl_n : (unsigned long long)ws.n_words);
+      wid = (uint32_t)wi;
+      if (worklist && have) wid = worklist[wi];
+    }
+    unsigned long long meta = 0;
+    uint32_t wfreq = 0;
+    if (have) {
+      meta = ws.wmeta[wid];
+      wfreq = ws.wcnt[wid];
+    }
+    const uint32_t wlen = (uint32_t)(meta & 0xffffull);
+    const unsigned long long woff = meta >> 16;
+    const uint32_t incl = wave_incl_scan(wlen);
+    int first = 0;
+    while (first < 64) {
+      // ---- the next words of the run that fit one tile: lanes first .. first + nw - 1
+      const uint32_t before = first ? (uint32_t)__shfl((int)incl, first - 1) : 0u;
+      const bool in = lane >= first && have && incl - before <= (uint32_t)SLOT;
+      const unsigned long long inm = __ballot(in);
+      const int nw = __popcll(inm);
+      if (!nw) break;
+      const int n = (int)((uint32_t)__shfl((int)incl, first + nw - 1) - before);
+      const uint32_t my_start = incl - wlen - before;
+      wave_sync();  // (the tile state of the words before these is no longer needed)
+      if (lane < SLOT / 64) X.lin[lane] = 0ull;
+      wave_sync();
+      if (in && wlen) atomicOr(&X.lin[my_start >> 6], 1ull << (my_start & 63u));
+      wave_sync();
+      if (n == 0) { first += nw; continue; }
+      // position-major gather: lane l takes positions 64 c + l; the word of a position from the start bits, its address from the
+      // word's lane; all loads of the tile in flight together
+      uint32_t v[SLOT / 64];
+      {
+        uint32_t cb = 0;
+#pragma unroll
+        for (int c = 0; c < SLOT / 64; c++) {
+          const unsigned long long m = uni64(X.lin[c]);
+          const int p = c * 64 + lane;
+          // (words of length 0 -- none exist: every word keeps its first token -- would break the rank below)
+          const uint32_t rank = cb + lanes_below(m) + (lane_bit(m) ? 1u : 0u);  // words that start at or before p
+          // the rank-th word with tokens: ranks count non-empty words only, and they are exactly the lanes of the run (wlen >= 1)
+          const int src = first + (int)rank - 1;
+          const uint32_t o_lo = (uint32_t)__shfl((int)(uint32_t)woff, src), o_hi = (uint32_t)__shfl((int)(uint32_t)(woff >> 32), src);
+          const uint32_t st0 = (uint32_t)__shfl((int)my_start, src);
+          v[c] = 0;
+          if (p < n) v[c] = ws.tok[(((unsigned long long)o_hi << 32) | o_lo) + (unsigned long long)((uint32_t)p - st0)];
+          cb += (uint32_t)__popcll(m);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < SLOT / 64; c++) W.tk[c * 64 + lane] = v[c];
+      wave_sync();
+      uint4 r[SLOT / 256];
+#pragma unroll
+      for (int j = 0; j < SLOT / 256; j++) r[j] = reinterpret_cast<const uint4 *>(W.tk)[lane + 64 * j];
+      WReg<SLOT> wq{};
+      wq.v[0] = (uint32_t)__shfl((int)wfreq, (first + lane) & 63);  // lane i: frequency of word i of the tile
+      uint32_t my_cnt = 0, my_site = 0;
+      const int site_state = reg_find_sites<SLOT, LDSR>(W, r, n, A.flagbits, nullptr, self_x, rtab, my_cnt, my_site, false, true);
+      S.scanned += (unsigned long long)n;
+      if (site_state) {
+        stage_ws_masks<SLOT>(W, r, n);
+        if (lane == 0) {
+          W.tk[n] = TOK_WS;
+          W.tk[n + 1] = TOK_WS;
+          W.tk[n + 2] = TOK_WS;
+        }
+        wave_sync();
+        process_tile<SLOT, true, LDSR, true>(W, A, ts, pt, db, rtab, self_x, self_z, z_base, 0u, n, 0u, wq, S, (site_state & 2) != 0, false);
+        wave_sync();
+        const int nsites = (int)(uni(W.sctl[0]) & 0xffffu);
+        if (nsites) {
+          // ---- compact the tile where it is (LDS); remember which of the new positions hold a new token
+          const int nchunks = (n + 63) >> 6;
+          const int fsc = (int)(uni(W.sctl[1]) >> 6);
+          if (lane < SLOT / 64) X.newsite[lane] = 0ull;
+          wave_sync();
+          uint32_t abase = (uint32_t)fsc * 64u;
+          unsigned long long sm_prev = 0ull;
+          for (int c = fsc; c < nchunks; c++) {
+            const int p = c * 64 + lane;
+            const unsigned long long smc = uni64(W.sitemask[c]);
+            const int left = n - c * 64;
+            const unsigned long long am = (left >= 64 ? ~0ull : (1ull << left) - 1ull) & ~((smc << 1) | (sm_prev >> 63));
+            const bool surv = lane_bit(am), site = lane_bit(smc);
+            const uint32_t np = abase + lanes_below(am);
+            uint32_t val = 0;
+            if (surv) {
+              const uint32_t t0 = W.tk[p];
+              val = site ? ((z_base + (uint32_t)W.ridx[p]) | (t0 & TOK_WS)) : (t0 & ~(L_ISX | L_ISY));
+            }
+            wave_sync();  // (every lane has read its token before any lane overwrites one: np <= p)
+            if (surv) {
+              W.tk[np] = val;
+              if (site) atomicOr(&X.newsite[np >> 6], 1ull << (np & 63u));
+            }
+            abase += (uint32_t)__popcll(am);
+            sm_prev = smc;
+          }
+          const int n2 = (int)abase;
+          wave_sync();
+          // ---- where the words start now (every word keeps its first token, so word i of the tile is still the i-th start)
+          {
+            uint32_t cb = 0;
+            for (int c = 0; c < ((n2 + 63) >> 6); c++) {
+              const int q = c * 64 + lane;
+              const bool wsb = q < n2 && (W.tk[q] & TOK_WS);
+              const unsigned long long m = __ballot(wsb);
+              if (wsb) X.wnew[cb + (uint32_t)__popcll(m & lanemask_lt())] = (uint32_t)q;
+              cb += (uint32_t)__popcll(m);
+            }
+            if (lane == 0) X.wnew[nw] = (uint32_t)n2;
+          }
+          wave_sync();
+          // my word's new length (lane first + i: word i)
+          uint32_t newlen = wlen;
+          if (in) newlen = X.wnew[lane - first + 1] - X.wnew[lane - first];
+          const bool changed = in && newlen != wlen;
+          // ---- tokens of the changed words back to their slots; records of the new instances
+          {
+            uint32_t cb = 0;
+            for (int c = 0; c < ((n2 + 63) >> 6); c++) {
+              const int q = c * 64 + lane;
+              const uint32_t tq = q < n2 ? W.tk[q] : 0u;
+              const bool wsb = q < n2 && (tq & TOK_WS);
+              const unsigned long long m = __ballot(wsb);
+              const uint32_t wi = cb + (uint32_t)__popcll(m & lanemask_lt()) + (wsb ? 1u : 0u) - 1u;  // my word of the tile
+              const int src = (first + (int)wi) & 63;
+              const uint32_t o_lo = (uint32_t)__shfl((int)(uint32_t)woff, src), o_hi = (uint32_t)__shfl((int)(uint32_t)(woff >> 32), src);
+              const bool ch = __shfl((int)changed, src) != 0;
+              const uint32_t word_id = (uint32_t)__shfl((int)wid, src);
+              if (q < n2 && ch) ws.tok[(((unsigned long long)o_hi << 32) | o_lo) + (unsigned long long)((uint32_t)q - X.wnew[wi])] = tq;
+              const bool isnew = q < n2 && ((X.newsite[c] >> lane) & 1ull);
+              const unsigned long long nm = __ballot(isnew);
+              if (nm) {
+                unsigned int b0 = 0;
+                const int fl = __ffsll((long long)nm) - 1;
+                if (lane == fl) b0 = atomicAdd(&RB.n, (unsigned int)__popcll(nm));
+                b0 = (unsigned int)__shfl((int)b0, fl);
+                if (isnew) {
+                  const uint32_t z = tq & L_ID;
+                  const uint32_t lnb = (tq & TOK_WS) ? NBR_NONE : (W.tk[q - 1] & L_ID);
+                  const uint32_t tr = q + 1 < n2 ? W.tk[q + 1] : TOK_WS;
+                  const uint32_t rnb = (tr & TOK_WS) ? NBR_NONE : (tr & L_ID);
+                  const unsigned int pos = b0 + (unsigned int)__popcll(nm & lanemask_lt());
+                  if (pos < (unsigned int)WORDS_RB) {
+                    RB.zr[pos] = z - z_base;
+                    RB.word[pos] = word_id;
+                    RB.l[pos] = lnb;
+                    RB.r[pos] = rnb;
+                  } else {
+                    rec_direct(tl, z, word_id, lnb, rnb);
+                  }
+                }
+              }
+              cb += (uint32_t)__popcll(m);
+            }
+          }
+          if (changed) {
+            for (uint32_t i = newlen; i < wlen; i++) ws.tok[woff + i] = TOK_HOLE;
+            ws.wmeta[wid] = (woff << 16) | (unsigned long long)newlen;
+          }
+          S.touched++;
+          S.touched_tok += (unsigned long long)n;
+        }
+      }
+      first += nw;
+    }
+  }
+  {
+    S.sites = wave_sum_u64(S.sites);
+    if (lane == 0) {
+      if (S.sites) atomicAdd(&A.st[0], S.sites);
+      if (S.touched) atomicAdd(&A.st[1], S.touched);
+      if (S.touched_tok) atomicAdd(&A.st[3], S.touched_tok);
+    }
+  }
+  agg_flush<WPB * 64>(A, pt, db);
+  // ---- the workgroup's records: one bump of a token's fill count per workgroup (the tile buffers are free: counts per rule live there)
+  {
+    static_assert(sizeof(WL) >= WGATHER_MAXK * sizeof(uint32_t), "per-rule counters of the record flush");
+    uint32_t *rcnt = reinterpret_cast<uint32_t *>(&WL[0]);
+    __syncthreads();
+    const unsigned int nrec = RB.n < (unsigned int)WORDS_RB ? RB.n : (unsigned int)WORDS_RB;
+    if (nrec) {  // (uniform)
+      const uint32_t kk = k_rules < WGATHER_MAXK ? k_rules : WGATHER_MAXK;
+      for (uint32_t j = threadIdx.x; j < kk; j += WPB * 64) rcnt[j] = 0;
+      __syncthreads();
+      for (unsigned int i = threadIdx.x; i < nrec; i += WPB * 64) {
+        const uint32_t zr = RB.zr[i] & 0xfffu;
+        RB.zr[i] = zr | (atomicAdd(&rcnt[zr], 1u) << 12);
+      }
+      __syncthreads();
+      for (uint32_t j = threadIdx.x; j < kk; j += WPB * 64)
+        if (rcnt[j]) rcnt[j] = atomicAdd(&tl.fill[z_base + j], rcnt[j]);
+      __syncthreads();
+      for (unsigned int i = threadIdx.x; i < nrec; i += WPB * 64) {
+        const uint32_t zr = RB.zr[i] & 0xfffu, z = z_base + zr;
+        const uint32_t at = rcnt[zr] + (RB.zr[i] >> 12);
+        if (at < tl.cap[z]) {
+          const unsigned long long o = tl.base[z] + at;
+          tl.rec_word[o] = RB.word[i];
+          tl.rec_l[o] = RB.l[i];
+          tl.rec_r[o] = RB.r[i];
+        } else {
+          __hip_atomic_store(tl.broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    blk_add(stats, 4, A.new_keys);
+    for (int i = 0; i < 4; i++) blk_add(stats, i, A.st[i]);
+  }
+  if (sa.on) {  // the round's candidate scan, by the last workgroup to get here (see k_tiles)
+    __shared__ unsigned int is_last;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(sa.done_ctr, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (is_last) {
+      __threadfence();
+      const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
+      scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
+    }
   }
 }
 
@@ -2149,18 +2686,53 @@ void launch_idx_seed(const PairTable &pt, const PairIndexArgs &a, unsigned int l
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(k_idx_seed, dim3(g), dim3(BLOCK), 0, st, pt, ix);
 }
-void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st) {
+void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st, bool words) {
   if (!ts.n_tiles) return;
   const PairIndex ix{a.key, a.cnt, a.off, a.bloom, a.post, a.mask};
   unsigned int g = (ts.n_tiles + NWAVES - 1) / NWAVES;
   if (g > 256 * 6) g = 256 * 6;
-  if (cls == 0) {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+  if (cls == 0 && words) {
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, true>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, true>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+  } else if (cls == 0) {
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
   } else {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, true>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, true, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, false, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
   }
+}
+void launch_words_init(const TileSet &ts, unsigned long long *wmeta, hipStream_t st) {
+  if (!ts.n_tiles) return;
+  unsigned int g = (ts.n_tiles + NWAVES - 1) / NWAVES;
+  if (g > 256 * 8) g = 256 * 8;
+  hipLaunchKernelGGL((k_words_init<TILE_SLOT_A>), dim3(g), dim3(BLOCK), 0, st, ts, wmeta);
+}
+void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, hipStream_t st) {
+  static const char *g_env = getenv("YTTM_WGATHER_GRID");
+  const unsigned int g = g_env ? (unsigned int)atoi(g_env) : 256u;
+  hipLaunchKernelGGL(k_wgather, dim3(g ? g : 1u), dim3(WG_NT), 0, st, a, ba ? *ba : BatchArgs{});
+}
+void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
+                        uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules, const uint32_t *worklist, unsigned long long wl_seg,
+                        const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, const BatchArgs *ba, const ScanArgs *scan,
+                        unsigned int work_hint, hipStream_t st) {
+  if (!ws.n_words) return;
+  const BatchArgs bargs = ba ? *ba : BatchArgs{};
+  const ScanArgs sargs = scan ? *scan : ScanArgs{};
+  // one run of 64 words per wave and iteration; work_hint = about how many words the round will visit (0: unknown / every word)
+  static const char *g_env = getenv("YTTM_WORDS_GRID");
+  const unsigned int gmax = g_env ? (unsigned int)atoi(g_env) : 512u;
+  unsigned long long items = worklist && work_hint ? ((unsigned long long)work_hint + 63) / 64 + 1 : ((unsigned long long)ws.n_words + 63) / 64;
+  unsigned long long g = (items + APPLY_WPB - 1) / APPLY_WPB;
+  if (g > gmax) g = gmax;
+  if (g < 1) g = 1;
+  if (rule_mask < APPLY_LDS_RULES)
+    hipLaunchKernelGGL((k_words<APPLY_WPB, true>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
+                       k_rules, worklist, wl_seg, work_n, stats, tl, bargs, sargs);
+  else
+    hipLaunchKernelGGL((k_words<APPLY_WPB, false>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
+                       k_rules, worklist, wl_seg, work_n, stats, tl, bargs, sargs);
 }
 void launch_gather(const PairIndexArgs &a, const RuleSlot *rules, unsigned int n_slots, const BatchArgs *ba, uint32_t self_x, uint32_t *stamp,
                    uint32_t round_id, uint32_t *worklist, unsigned int n_tiles, unsigned int *work_n, hipStream_t st) {

@@ -72,6 +72,34 @@ struct TileSet {
   uint32_t n_tiles;
 };
 
+// ---- word mode (k_merge.hip: k_words).  Once a merge round touches few of the words, class-A words are no longer processed tile by
+// tile: every word keeps the slot it had in the tile array at that moment (wmeta: first token, live length) and shrinks IN PLACE --
+// the tokens a merge frees become TOK_HOLE (word-start bit AND bit 30: no kernel takes a hole for a token, an adjacency or a word
+// start) -- and a round visits only the words that hold a merge site.
+constexpr uint32_t TOK_HOLE = 0xC0000000u;
+constexpr uint32_t NBR_NONE = 0xffffffffu;  // "no neighbour inside the word" in an instance record
+__host__ __device__ inline bool tok_is_ws(uint32_t t) { return (t >> 30) == 2u; }
+struct WordSet {
+  uint32_t *tok;               // the class-A token array (tile slots as they were at the switch)
+  unsigned long long *wmeta;   // [n_words] index of the word's first token << 16 | live tokens
+  const uint32_t *wcnt;        // [n_words] word frequencies
+  uint32_t n_words;
+};
+// Where the sites of a rule (x,y) are.  Pairs of tokens that existed when the pair index was last built: its postings (word ids).
+// Pairs with a younger token: every instance of a token z created since then has ONE record {word, left neighbour, right neighbour
+// after its round} in list(z), a contiguous run of the record arrays allotted when z's rule was gathered; an adjacency (a,b) is found
+// in the list of its YOUNGER token (the larger id: when that instance was made the other one was already its neighbour -- a neighbour
+// made later would itself be the younger one).  Stale records (an instance merged away since) cost a look at the word, nothing else.
+struct TokLists {
+  unsigned long long *base;    // [n_ids] start of list(z)
+  uint32_t *cap, *fill;        // [n_ids] records allotted / written
+  uint32_t *rec_word, *rec_l, *rec_r;  // [log_cap]
+  unsigned long long *cursor;  // records allotted so far
+  unsigned long long log_cap;
+  unsigned int *broken;        // in the host's pinned memory; != 0: records were dropped (log full) or a round took every word -- the host
+                               // rebuilds the index (which covers every token that exists then) before the next round
+};
+
 // one slot of the per-round rule table uploaded by the host (key = x<<32|y)
 struct RuleSlot {
   unsigned long long key;

@@ -103,9 +103,31 @@ struct PairIndexArgs {
   unsigned int mask;
 };
 void launch_idx_seed(const PairTable &pt, const PairIndexArgs &a, unsigned int listed_hint, hipStream_t st);
-void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st);
+void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st, bool words = false /* postings are word ids; the tiles may hold TOK_HOLEs */);
 void launch_gather(const PairIndexArgs &a, const RuleSlot *rules, unsigned int n_slots, const BatchArgs *ba, uint32_t self_x, uint32_t *stamp,
                    uint32_t round_id, uint32_t *worklist, unsigned int n_tiles, unsigned int *work_n, hipStream_t st);
+// ---- word mode (k_merge.hip)
+void launch_words_init(const TileSet &ts, unsigned long long *wmeta, hipStream_t st);
+struct WGatherArgs {
+  PairIndexArgs ix;
+  uint32_t ix_valid, z_static;   // tokens below z_static existed when the index was built
+  TokLists tl;
+  uint32_t *stamp;               // [n_words] round that claimed the word last
+  uint32_t round_id;
+  uint32_t *worklist;            // WL_PARTS sub-lists, wl_seg entries apart; work_n[0..WL_PARTS) their lengths, work_n[WL_PARTS + 1] != 0: take every word
+  unsigned long long wl_seg;
+  unsigned int *work_n;
+  unsigned int *gm;              // [WGATHER_MAXK] records matched per rule (left at zero)
+  unsigned int *done_ctr;
+  const uint32_t *xyz;           // rule j = (xyz[3j], xyz[3j+1]) -> z_base + j, in HBM; nullptr: the batch is in the BatchArgs
+  uint32_t k, z_base;
+};
+constexpr unsigned int WGATHER_MAXK = 4096;
+void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, hipStream_t st);
+void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
+                        uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules, const uint32_t *worklist /* nullptr: every word */, unsigned long long wl_seg,
+                        const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, const BatchArgs *ba, const ScanArgs *scan,
+                        unsigned int work_hint, hipStream_t st);
 void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, unsigned int nom, unsigned long long total,
                    unsigned long long *gstart, unsigned int n_new, uint32_t *new_tok, uint32_t *new_len, uint32_t *new_word0, hipStream_t st);
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
