@@ -1351,7 +1351,7 @@ void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned lon
 
 // ------------------------------------------------------------------------------------------------- K4
 void GpuCtx::free_words() {
-  DFREE(d_wmeta_); DFREE(d_gm_); DFREE(d_xyz_); DFREE(d_wworklist_);
+  DFREE(d_wmeta_); DFREE(d_gm_); DFREE(d_xyz_); DFREE(d_wworklist_); DFREE(d_drec_); DFREE(d_drec_n_);
   DFREE(tl_.base); DFREE(tl_.cap); DFREE(tl_.fill); DFREE(tl_.rec_word); DFREE(tl_.rec_l); DFREE(tl_.rec_r); DFREE(tl_.cursor);
   tl_ = TokLists{};
   word_mode_ = false;
@@ -1369,6 +1369,9 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
   d_gm_ = dmalloc<unsigned int>(WGATHER_MAXK + 4);
   HIP_CHECK(hipMemsetAsync(d_gm_, 0, (WGATHER_MAXK + 4) * 4, st_));
   d_xyz_ = dmalloc<uint32_t>(3 * (size_t)RULES_CAP);
+  drec_cap_ = env_uint("YTTM_WORD_DREC", 1u << 15);  // (tests: a region that overflows)
+  d_drec_ = dmalloc<DeltaRec>((size_t)WORDS_MAX_GRID * drec_cap_);
+  d_drec_n_ = dmalloc<unsigned int>(WORDS_MAX_GRID);
   tl_.base = dmalloc<unsigned long long>(tokflag_cap_);
   tl_.cap = dmalloc<uint32_t>(tokflag_cap_);
   tl_.fill = dmalloc<uint32_t>(tokflag_cap_);
@@ -1421,24 +1424,24 @@ void GpuCtx::build_index(uint32_t z_next) {
   if (want > idx_cap_) {
     DFREE(idx_.key); DFREE(idx_.cnt); DFREE(idx_.off);
     idx_.key = dmalloc<unsigned long long>(want);
-    idx_.cnt = dmalloc<uint32_t>(want + 1);
-    idx_.off = dmalloc<unsigned long long>(want + 2);
+    idx_.cnt = dmalloc<uint32_t>(want * IDX_SHARDS + 1);
+    idx_.off = dmalloc<unsigned long long>(want * IDX_SHARDS + 2);
     DFREE(idx_scan_tmp_);
-    idx_scan_tmp_ = dmalloc<unsigned long long>(scan_scratch_blocks(want + 1));
+    idx_scan_tmp_ = dmalloc<unsigned long long>(scan_scratch_blocks(want * IDX_SHARDS + 1));
     idx_cap_ = want;
   }
   if (!idx_.bloom) idx_.bloom = dmalloc<uint32_t>(ENC_BLOOM_WORDS);
   idx_.mask = (unsigned int)(want - 1);
   launch_fill_u64(idx_.key, PT_EMPTY, want, st_);
-  HIP_CHECK(hipMemsetAsync(idx_.cnt, 0, want * 4, st_));
+  HIP_CHECK(hipMemsetAsync(idx_.cnt, 0, want * IDX_SHARDS * 4, st_));
   HIP_CHECK(hipMemsetAsync(idx_.bloom, 0, ENC_BLOOM_WORDS * 4, st_));
   t_begin(KT_CAND);
   launch_idx_seed(pt_, idx_, listed, st_);
   launch_idx_stream(0, false, c.ts, idx_, st_, word_mode_);
   // offsets = exclusive scan of the counts (one extra zero count behind the last slot: off[mask + 1] = the total)
-  HIP_CHECK(hipMemsetAsync(idx_.cnt + want, 0, 4, st_));
-  launch_exclusive_scan(idx_.cnt, want + 1, idx_.off, idx_scan_tmp_, d_counters_ + 56, st_);
-  HIP_CHECK(hipMemsetAsync(idx_.cnt, 0, want * 4, st_));  // the fill pass's cursors
+  HIP_CHECK(hipMemsetAsync(idx_.cnt + want * IDX_SHARDS, 0, 4, st_));
+  launch_exclusive_scan(idx_.cnt, want * IDX_SHARDS + 1, idx_.off, idx_scan_tmp_, d_counters_ + 56, st_);
+  HIP_CHECK(hipMemsetAsync(idx_.cnt, 0, want * IDX_SHARDS * 4, st_));  // the fill pass's cursors
   unsigned long long total = 0;
   HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 56, 8, hipMemcpyDeviceToHost, st_));
   sync();
@@ -1686,7 +1689,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       }
       launch_wgather(ga, by_args ? &ba : nullptr, st_);
       const WordSet wset{c.d_tok, d_wmeta_, c.d_wcnt, (uint32_t)c.n_unique};
-      launch_words_apply(wset, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, &ba,
+      launch_words_apply(wset, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, &ba,
                          sa.on && last_cls == 0 ? &sa : nullptr, sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + 4096, 1ull << 30) : 0u, st_);
       word_rounds++;
       if (!idx_valid_) word_all_rounds++;

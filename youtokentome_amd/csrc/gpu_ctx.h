@@ -203,6 +203,8 @@ class GpuCtx {
   unsigned int *d_gm_ = nullptr;   // [WGATHER_MAXK] + the gather's ticket
   uint32_t *d_xyz_ = nullptr;      // a batch too large for BatchArgs, as (x, y, z) triples
   uint32_t *d_wworklist_ = nullptr;  // [n_unique + 64] the round's words
+  DeltaRec *d_drec_ = nullptr;       // [WORDS_MAX_GRID * drec_cap_] the round's count updates, a region per workgroup of k_words
+  unsigned int *d_drec_n_ = nullptr, drec_cap_ = 0;
   TokLists tl_{};
   unsigned long long sites_cum_ = 0, sites_last_ = ~0ull;
   void enter_word_mode(uint32_t z_next);

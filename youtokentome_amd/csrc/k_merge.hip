@@ -20,6 +20,8 @@
 // HBM-bound integer work: no MFMA.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include <type_traits>
 
 #include "yttm_device.h"
@@ -86,6 +88,60 @@ __device__ inline void emit(AggLds &A, WaveLds<SLOT> &W, const PairTable &pt, co
 #endif
 }
 
+
+// The LDS half of an emit alone: false if the workgroup's aggregator had no room for the key (word mode batches what is left, below).
+__device__ inline bool agg_try(AggLds &A, unsigned long long key, long long delta) {
+  unsigned int h = (pair_hash32(key) >> 7) & (AGG_SLOTS - 1);
+  for (int probe = 0; probe < 8; probe++) {
+    unsigned long long k = __hip_atomic_load(&A.key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k == PT_EMPTY) {
+      k = atomicCAS(&A.key[h], PT_EMPTY, key);
+      if (k == PT_EMPTY) k = key;
+    }
+    if (k == key) {
+      atomicAdd(&A.val[h], (unsigned long long)delta);
+      return true;
+    }
+    h = (h + 1) & (AGG_SLOTS - 1);
+  }
+  return false;
+}
+
+// ---- word mode: count updates leave k_words as RECORDS.  k_words gathers words from all over the table, so its deltas are mostly of
+// pairs the workgroup's aggregator has never seen, and pt_add's way -- probe, then an add whose old value tells whether the count crossed
+// a list threshold -- made the wave wait two dependent trips per emit, five emits per pass, behind every other add to the same pair
+// (measured: 9 us per emit call with a miss; adds that return nothing only move the wait to the wave's next load: one in-order counter).
+// So what the aggregator does not take is written to the workgroup's region of a record buffer -- plain 16-byte stores, positions from an
+// LDS counter -- and k_delta_apply, one thread per record, puts the records into the pair table after the words are done.
+struct DeltaOut {
+  DeltaRec *recs;          // this workgroup's region
+  unsigned int *n;         // (LDS) records written / asked for
+  unsigned int cap;
+};
+template <int N>
+__device__ inline void rec_emit_batch(const DeltaOut &D, const PairTable &pt, const DeltaBuf &db, const unsigned long long (&key)[N],
+                                      const long long (&delta)[N], const bool (&miss)[N], unsigned int *new_keys) {
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const unsigned long long m = __ballot(miss[j]);
+    if (!m) continue;
+    unsigned int b0 = 0;
+    const int fl = __ffsll((long long)m) - 1;
+    if (lane_id() == fl) b0 = atomicAdd(D.n, (unsigned int)__popcll(m));
+    b0 = (unsigned int)__shfl((int)b0, fl);
+    if (miss[j]) {
+      const unsigned int at = b0 + (unsigned int)__popcll(m & lanemask_lt());
+      if (at < D.cap) {
+        DeltaRec r;
+        r.key = key[j];
+        r.delta = delta[j];
+        D.recs[at] = r;
+      } else {
+        global_emit(pt, db, key[j], delta[j], new_keys);  // (the region is full: the slow way)
+      }
+    }
+  }
+}
 
 template <int NT>
 __device__ inline void agg_init(AggLds &A, const uint32_t *__restrict__ flagbits_g) {
@@ -629,7 +685,8 @@ template <int SLOT, bool MERGE, bool LDSR, bool WORDS = false>
 __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &ts, const PairTable &pt, const DeltaBuf &db,
                                     const RuleTab<LDSR> &rtab, uint32_t self_x, uint32_t self_z,
                                     uint32_t z_base, uint32_t t, int n, uint32_t word0, const WReg<SLOT> &wreg, TileStats &S,
-                                    bool self_pass /* MERGE: the tile may hold sites of the x x rule */, bool instr = false) {
+                                    bool self_pass /* MERGE: the tile may hold sites of the x x rule */, bool instr = false,
+                                    const DeltaOut *dout = nullptr /* WORDS: where the count updates go (rec_emit_batch) */) {
   const int lane = lane_id();
   unsigned long long &my_sites = S.sites, &st_touched = S.touched, &st_scanned = S.scanned, &st_touched_tok = S.touched_tok;
     const int nchunks = (n + 63) >> 6;
@@ -789,11 +846,30 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
             }
           }
           K4_MARK(13);  // (PROF=2: phase 2 up to here = the sites' context and deltas; from here to mark 5 = the emits)
+          if (WORDS) {
+            const unsigned long long ks[5] = {k0, k1, k2, k3, k4};
+            const long long ds[5] = {d0, f, d2, f, d4};
+            const bool ms[5] = {v0 && !agg_try(A, k0, d0), v1 && !agg_try(A, k1, f), v2 && !agg_try(A, k2, d2), v3 && !agg_try(A, k3, f),
+                                v4 && !agg_try(A, k4, d4)};
+            if (__ballot(ms[0] || ms[1] || ms[2] || ms[3] || ms[4])) {
+#ifdef YTTM_K4_PROF
+              const unsigned long long t0_ = (unsigned long long)clock64();
+#endif
+              rec_emit_batch<5>(*dout, pt, db, ks, ds, ms, &A.new_keys);
+#ifdef YTTM_K4_PROF
+              if (ms[0] || ms[1] || ms[2] || ms[3] || ms[4]) {
+                atomicAdd(&A.miss_n, (unsigned long long)((int)ms[0] + (int)ms[1] + (int)ms[2] + (int)ms[3] + (int)ms[4]));
+                atomicAdd(&A.miss_cyc, (unsigned long long)clock64() - t0_);
+              }
+#endif
+            }
+          } else {
           if (__ballot(v0)) { if (v0) emit<SLOT>(A, W, pt, db, k0, d0); }
           if (__ballot(v1)) { if (v1) emit<SLOT>(A, W, pt, db, k1, f); }
           if (__ballot(v2)) { if (v2) emit<SLOT>(A, W, pt, db, k2, d2); }
           if (__ballot(v3)) { if (v3) emit<SLOT>(A, W, pt, db, k3, f); }
           if (__ballot(v4)) { if (v4) emit<SLOT>(A, W, pt, db, k4, d4); }
+          }
           wave_sync();  // (the list is rebuilt by the next pass)
           K4_MARK(5);
         }
@@ -1697,8 +1773,8 @@ __global__ __launch_bounds__(BLOCK) void k_fill_u64(unsigned long long *__restri
 // are all in the index gathers their posting lists into the worklist of the apply kernel instead of streaming every tile.
 struct PairIndex {
   unsigned long long *key;  // [mask + 1] open addressing, PT_EMPTY = free
-  uint32_t *cnt;            // [mask + 1] postings per key (count pass), then the fill cursor
-  unsigned long long *off;  // [mask + 2] start of a key's postings (launch_exclusive_scan of the counts; off[mask + 1] = their total)
+  uint32_t *cnt;            // [(mask + 1) * IDX_SHARDS] postings per key and shard (count pass), then the fill cursors
+  unsigned long long *off;  // [(mask + 1) * IDX_SHARDS + 2] start of a (key, shard)'s postings (launch_exclusive_scan of the counts; the last = their total)
   uint32_t *bloom;          // [ENC_BLOOM_WORDS] blocked Bloom filter of the keys (staged into LDS by the streaming passes)
   uint32_t *post;           // tile ids
   unsigned int mask;
@@ -1741,6 +1817,7 @@ __global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) 
   __syncthreads();
   const int lane = lane_id();
   const uint32_t stride = gridDim.x * NWAVES;
+  const uint32_t shard = (blockIdx.x * NWAVES + (threadIdx.x >> 6)) % IDX_SHARDS;
   for (uint32_t t = blockIdx.x * NWAVES + (threadIdx.x >> 6); t < ts.n_tiles; t += stride) {
     const int n = (int)ts.tile_len[t];
     uint4 r[SLOT / 256];
@@ -1757,8 +1834,9 @@ __global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) 
     if ((bloom[enc_bloom_word(h_)] & bits_) == bits_) {                                \
       const uint32_t s_ = idx_find(ix, pair_key(a_, b_), h_);                          \
       if (s_ != 0xffffffffu) {                                                         \
-        if (FILL) ix.post[ix.off[s_] + atomicAdd(&ix.cnt[s_], 1u)] = WORDS ? (WIDX) : t; \
-        else atomicAdd(&ix.cnt[s_], 1u);                                               \
+        const size_t cs_ = (size_t)s_ * IDX_SHARDS + shard;                            \
+        if (FILL) ix.post[ix.off[cs_] + atomicAdd(&ix.cnt[cs_], 1u)] = WORDS ? (WIDX) : t; \
+        else atomicAdd(&ix.cnt[cs_], 1u);                                              \
       }                                                                                \
     }                                                                                  \
   }
@@ -1815,7 +1893,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(PairIndex ix, const RuleSlot *
     if (threadIdx.x == 0) work_n[WL_PARTS + 1] = 1u;
     return;
   }
-  const unsigned long long o0 = ix.off[s], o1 = ix.off[s + 1];
+  const unsigned long long o0 = ix.off[(size_t)s * IDX_SHARDS], o1 = ix.off[((size_t)s + 1) * IDX_SHARDS];
   const uint32_t part = blockIdx.x % WL_PARTS;
   for (unsigned long long i = o0 + threadIdx.x; i < o1; i += BLOCK) {
     const uint32_t t = ix.post[i];
@@ -1898,8 +1976,8 @@ __global__ __launch_bounds__(WG_NT) void k_wgather(WGatherArgs g, BatchArgs ba) 
       if (s == 0xffffffffu) {
         g.work_n[WL_PARTS + 1] = 1u;  // not in the index: this round takes every word
       } else {
-        base = ix.off[s];
-        len = ix.off[s + 1] - base;
+        base = ix.off[(size_t)s * IDX_SHARDS];
+        len = ix.off[((size_t)s + 1) * IDX_SHARDS] - base;
       }
     } else {
       base = g.tl.base[m];
@@ -2033,32 +2111,22 @@ struct WordsLds {
   unsigned long long newsite[TILE_SLOT_A / 64];  // bit q: the token at position q of the compacted tile is a new one
   uint32_t wnew[66];                             // start of word i in the compacted tile; [nw] = its length
 };
-constexpr int WORDS_RB = 1024;  // new-instance records buffered per workgroup (flushed once, at the end: one cursor bump per new token and workgroup)
+constexpr int WORDS_RB = 512;   // new-instance records buffered per workgroup (flushed once, at the end: one cursor bump per new token and workgroup)
 struct RecBuf {
   uint32_t zr[WORDS_RB], word[WORDS_RB], l[WORDS_RB], r[WORDS_RB];
   unsigned int n;
 };
-__device__ inline void rec_direct(const TokLists &tl, uint32_t z, uint32_t word, uint32_t l, uint32_t r) {
-  const uint32_t at = atomicAdd(&tl.fill[z], 1u);
-  if (at < tl.cap[z]) {
-    const unsigned long long o = tl.base[z] + at;
-    tl.rec_word[o] = word;
-    tl.rec_l[o] = l;
-    tl.rec_r[o] = r;
-  } else {
-    __hip_atomic_store(tl.broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
 template <int WPB, bool LDSR>
 __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules, unsigned int rule_mask,
                                                     const uint32_t *__restrict__ bloom_g, uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules,
                                                     const uint32_t *__restrict__ worklist, unsigned long long wl_seg,
                                                     const unsigned int *__restrict__ work_n, unsigned long long *__restrict__ stats, TokLists tl,
-                                                    BatchArgs ba, ScanArgs sa) {
+                                                    DeltaRec *__restrict__ drec, unsigned int drec_cap /* per workgroup */, unsigned int *__restrict__ drec_n,
+                                                    BatchArgs ba) {
   constexpr int SLOT = TILE_SLOT_A;
   __shared__ WaveLds<SLOT> WL[WPB];
   __shared__ WordsLds XL[WPB];
+  __shared__ unsigned int dn;  // records of this workgroup
   __shared__ AggLds A;
   __shared__ RecBuf RB;
   __shared__ unsigned long long rkeys[LDSR ? APPLY_LDS_RULES : 1];
@@ -2066,6 +2134,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   const bool from_args = LDSR && ba.k != 0;
   agg_init<WPB * 64>(A, from_args ? nullptr : bloom_g);  // (A.flagbits holds the batch's pair filter)
   if (threadIdx.x == 0) RB.n = 0;
+  if (threadIdx.x == 0) dn = 0;
   if (from_args) {
     for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += WPB * 64) A.flagbits[s] = 0;
     for (unsigned int i = threadIdx.x; i <= rule_mask; i += WPB * 64) rkeys[i] = PT_EMPTY;
@@ -2098,12 +2167,16 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   WaveLds<SLOT> &W = WL[wave];
   WordsLds &X = XL[wave];
   const TileSet ts{ws.tok, nullptr, nullptr, ws.wcnt, 0u};
+  const DeltaOut dout{drec + (size_t)blockIdx.x * drec_cap, &dn, drec_cap};
   // work items: runs of 64 worklist entries, or of 64 words
   if (worklist && work_n[WL_PARTS + 1]) worklist = nullptr;
   const uint32_t wl_n = worklist ? work_n[0] : 0u;
   const unsigned long long n_items = worklist ? ((unsigned long long)wl_n + 63ull) / 64ull : ((unsigned long long)ws.n_words + 63ull) / 64ull;
   (void)wl_seg;
   TileStats S;
+#ifdef YTTM_K4_PROF
+  S.t_last = (unsigned long long)clock64();
+#endif
   for (unsigned long long item = (unsigned long long)blockIdx.x * WPB + (unsigned long long)wave; item < n_items; item += (unsigned long long)gridDim.x * WPB) {
     // ---- my word (lane l: entry l of the run)
     bool have;
@@ -2162,6 +2235,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
 #pragma unroll
       for (int c = 0; c < SLOT / 64; c++) W.tk[c * 64 + lane] = v[c];
       wave_sync();
+      K4_MARK(9);  // (PROF=2: worklist -> word headers -> tokens in LDS)
       uint4 r[SLOT / 256];
 #pragma unroll
       for (int j = 0; j < SLOT / 256; j++) r[j] = reinterpret_cast<const uint4 *>(W.tk)[lane + 64 * j];
@@ -2170,7 +2244,9 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
       uint32_t my_cnt = 0, my_site = 0;
       const int site_state = reg_find_sites<SLOT, LDSR>(W, r, n, A.flagbits, nullptr, self_x, rtab, my_cnt, my_site, false, true);
       S.scanned += (unsigned long long)n;
+      K4_MARK(0);
       if (site_state) {
+        K4_COUNT(8);
         stage_ws_masks<SLOT>(W, r, n);
         if (lane == 0) {
           W.tk[n] = TOK_WS;
@@ -2178,7 +2254,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
           W.tk[n + 2] = TOK_WS;
         }
         wave_sync();
-        process_tile<SLOT, true, LDSR, true>(W, A, ts, pt, db, rtab, self_x, self_z, z_base, 0u, n, 0u, wq, S, (site_state & 2) != 0, false);
+        process_tile<SLOT, true, LDSR, true>(W, A, ts, pt, db, rtab, self_x, self_z, z_base, 0u, n, 0u, wq, S, (site_state & 2) != 0, false, &dout);
         wave_sync();
         const int nsites = (int)(uni(W.sctl[0]) & 0xffffu);
         if (nsites) {
@@ -2249,11 +2325,13 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
                 const int fl = __ffsll((long long)nm) - 1;
                 if (lane == fl) b0 = atomicAdd(&RB.n, (unsigned int)__popcll(nm));
                 b0 = (unsigned int)__shfl((int)b0, fl);
+                const uint32_t z = isnew ? (tq & L_ID) : 0u;
+                uint32_t lnb = NBR_NONE, rnb = NBR_NONE;
+                bool direct = false;
                 if (isnew) {
-                  const uint32_t z = tq & L_ID;
-                  const uint32_t lnb = (tq & TOK_WS) ? NBR_NONE : (W.tk[q - 1] & L_ID);
+                  if (!(tq & TOK_WS)) lnb = W.tk[q - 1] & L_ID;
                   const uint32_t tr = q + 1 < n2 ? W.tk[q + 1] : TOK_WS;
-                  const uint32_t rnb = (tr & TOK_WS) ? NBR_NONE : (tr & L_ID);
+                  if (!(tr & TOK_WS)) rnb = tr & L_ID;
                   const unsigned int pos = b0 + (unsigned int)__popcll(nm & lanemask_lt());
                   if (pos < (unsigned int)WORDS_RB) {
                     RB.zr[pos] = z - z_base;
@@ -2261,8 +2339,31 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
                     RB.l[pos] = lnb;
                     RB.r[pos] = rnb;
                   } else {
-                    rec_direct(tl, z, word_id, lnb, rnb);
+                    direct = true;
                   }
+                }
+                // the buffer is full (a round with many sites per workgroup): straight to the lists, one bump of a token's fill count for
+                // all the lanes that hold an instance of it (a handful of rules with thousands of sites each: one address per rule)
+                unsigned long long dm = __ballot(direct);
+                while (dm) {
+                  const int ld = __ffsll((long long)dm) - 1;
+                  const uint32_t z0 = (uint32_t)__shfl((int)z, ld);
+                  const unsigned long long same = __ballot(direct && z == z0);
+                  uint32_t at0 = 0;
+                  if (lane == ld) at0 = atomicAdd(&tl.fill[z0], (uint32_t)__popcll(same));
+                  at0 = (uint32_t)__shfl((int)at0, ld);
+                  if (direct && z == z0) {
+                    const uint32_t at = at0 + (uint32_t)__popcll(same & lanemask_lt());
+                    if (at < tl.cap[z0]) {
+                      const unsigned long long o = tl.base[z0] + at;
+                      tl.rec_word[o] = word_id;
+                      tl.rec_l[o] = lnb;
+                      tl.rec_r[o] = rnb;
+                    } else {
+                      __hip_atomic_store(tl.broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                  }
+                  dm &= ~same;
                 }
               }
               cb += (uint32_t)__popcll(m);
@@ -2274,6 +2375,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
           }
           S.touched++;
           S.touched_tok += (unsigned long long)n;
+          K4_MARK(6);  // (compaction, write-back, records)
         }
       }
       first += nw;
@@ -2287,7 +2389,24 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
       if (S.touched_tok) atomicAdd(&A.st[3], S.touched_tok);
     }
   }
-  agg_flush<WPB * 64>(A, pt, db);
+#ifdef YTTM_K4_PROF
+  K4_MARK(7);
+  __syncthreads();
+  K4_MARK(11);
+#endif
+  __syncthreads();
+  for (int sl = (int)threadIdx.x; sl < AGG_SLOTS; sl += WPB * 64) {  // the aggregator's sums are records too
+    const unsigned long long k = A.key[sl];
+    const long long v = k != PT_EMPTY ? (long long)A.val[sl] : 0;
+    const unsigned long long ks[1] = {k};
+    const long long ds[1] = {v};
+    const bool ms[1] = {v != 0};
+    rec_emit_batch<1>(dout, pt, db, ks, ds, ms, &A.new_keys);
+  }
+#ifdef YTTM_K4_PROF
+  __syncthreads();
+  K4_MARK(12);
+#endif
   // ---- the workgroup's records: one bump of a token's fill count per workgroup (the tile buffers are free: counts per rule live there)
   {
     static_assert(sizeof(WL) >= WGATHER_MAXK * sizeof(uint32_t), "per-rule counters of the record flush");
@@ -2321,25 +2440,71 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
     }
   }
   __syncthreads();
+#ifdef YTTM_K4_PROF
+  K4_MARK(10);  // (record flush)
+  if (lane == 0)
+    for (int i = 0; i < 16; i++)
+      if (S.pt[i]) atomicAdd(&stats[8 + i], S.pt[i]);
+  if (threadIdx.x == 0 && A.miss_n) {
+    atomicAdd(&stats[8 + 14], A.miss_n);
+    atomicAdd(&stats[8 + 15], A.miss_cyc);
+  }
+#endif
   if (threadIdx.x == 0) {
     blk_add(stats, 4, A.new_keys);
     for (int i = 0; i < 4; i++) blk_add(stats, i, A.st[i]);
   }
-  if (sa.on) {  // the round's candidate scan, by the last workgroup to get here (see k_tiles)
-    __shared__ unsigned int is_last;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(sa.done_ctr, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (is_last) {
-      __threadfence();
-      const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
-      scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
-    }
+  if (threadIdx.x == 0) drec_n[blockIdx.x] = dn < drec_cap ? dn : drec_cap;
+}
+
+// The records of a word-mode round -> the pair table: region r (k_words' workgroup r) is shared by `parts` workgroups, one thread per
+// record.  The round's candidate scan rides in this launch (the last workgroup to finish, as in k_tiles).
+constexpr int DAPPLY_NT = 256;
+__global__ __launch_bounds__(DAPPLY_NT) void k_delta_apply(PairTable pt, DeltaBuf db, const DeltaRec *__restrict__ drec, unsigned int drec_cap,
+                                                          const unsigned int *__restrict__ drec_n, unsigned int parts,
+                                                          unsigned long long *__restrict__ stats, const RuleSlot *__restrict__ zrules, unsigned int zmask,
+                                                          unsigned long long zself, BatchArgs zba, ScanArgs sa) {
+  __shared__ unsigned int new_keys, is_last;
+  __shared__ unsigned long long zkeys[FILTER_LDS_KEYS];
+  __shared__ unsigned int scratch[CAND_BINS + 80];
+  if (threadIdx.x == 0) new_keys = 0;
+  __syncthreads();
+  const unsigned int r = blockIdx.x / parts, p = blockIdx.x % parts;
+  const unsigned int n = drec_n[r];
+  const DeltaRec *reg = drec + (size_t)r * drec_cap;
+  for (unsigned int i = p * DAPPLY_NT + threadIdx.x; i < n; i += parts * DAPPLY_NT) {
+    const DeltaRec rec = reg[i];
+    global_emit(pt, db, rec.key, rec.delta, &new_keys);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) blk_add(stats, 4, new_keys);
+  if (!sa.on) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(sa.done_ctr, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  bool zkeys_in_lds = zrules && zmask < FILTER_LDS_KEYS;  // (the finished batch's pairs, to be zeroed: as in k_top_scan)
+  if (zba.k) {
+    zmask = 4 * BATCH_ARGS_MAX - 1;
+    zkeys_in_lds = true;
+    for (unsigned int sl = threadIdx.x; sl <= zmask; sl += DAPPLY_NT) zkeys[sl] = PT_EMPTY;
+    __syncthreads();
+    if (threadIdx.x < zba.k && zba.xy[2 * threadIdx.x] != zba.xy[2 * threadIdx.x + 1]) {  // (BATCH_ARGS_MAX <= the block size)
+      const unsigned long long key = pair_key(zba.xy[2 * threadIdx.x], zba.xy[2 * threadIdx.x + 1]);
+      unsigned int h = pair_hash32(key) & zmask;
+      while (atomicCAS(&zkeys[h], PT_EMPTY, key) != PT_EMPTY) h = (h + 1) & zmask;
+    }
+  } else if (zkeys_in_lds) {
+    for (unsigned int sl = threadIdx.x; sl <= zmask; sl += DAPPLY_NT) zkeys[sl] = zrules[sl].key;
+  }
+  __syncthreads();
+  const RuleProbe zprobe{zkeys_in_lds ? zkeys : nullptr, zrules, zmask};
+  scan_top<DAPPLY_NT>(pt, sa, stats, zprobe, zself, scratch, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------- tile repack
@@ -2715,24 +2880,28 @@ void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, hipStream_t st) {
 }
 void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
                         uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules, const uint32_t *worklist, unsigned long long wl_seg,
-                        const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, const BatchArgs *ba, const ScanArgs *scan,
-                        unsigned int work_hint, hipStream_t st) {
+                        const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, DeltaRec *drec, unsigned int drec_cap, unsigned int *drec_n,
+                        const BatchArgs *ba, const ScanArgs *scan, unsigned int work_hint, hipStream_t st) {
   if (!ws.n_words) return;
   const BatchArgs bargs = ba ? *ba : BatchArgs{};
   const ScanArgs sargs = scan ? *scan : ScanArgs{};
   // one run of 64 words per wave and iteration; work_hint = about how many words the round will visit (0: unknown / every word)
   static const char *g_env = getenv("YTTM_WORDS_GRID");
-  const unsigned int gmax = g_env ? (unsigned int)atoi(g_env) : 512u;
+  const unsigned int gmax = std::min(g_env ? (unsigned int)atoi(g_env) : 512u, (unsigned int)WORDS_MAX_GRID);
   unsigned long long items = worklist && work_hint ? ((unsigned long long)work_hint + 63) / 64 + 1 : ((unsigned long long)ws.n_words + 63) / 64;
   unsigned long long g = (items + APPLY_WPB - 1) / APPLY_WPB;
   if (g > gmax) g = gmax;
   if (g < 1) g = 1;
   if (rule_mask < APPLY_LDS_RULES)
     hipLaunchKernelGGL((k_words<APPLY_WPB, true>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
-                       k_rules, worklist, wl_seg, work_n, stats, tl, bargs, sargs);
+                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, bargs);
   else
     hipLaunchKernelGGL((k_words<APPLY_WPB, false>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
-                       k_rules, worklist, wl_seg, work_n, stats, tl, bargs, sargs);
+                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, bargs);
+  // the records -> the pair table, then the round's candidate scan (every workgroup owns a statistics row: at most BLK_ROWS of them)
+  const unsigned int parts = std::max(1u, std::min(8u, (unsigned int)BLK_ROWS / (unsigned int)g));
+  hipLaunchKernelGGL(k_delta_apply, dim3((unsigned int)g * parts), dim3(DAPPLY_NT), 0, st, pt, db, (const DeltaRec *)drec, drec_cap, (const unsigned int *)drec_n, parts,
+                     stats, bargs.k ? (const RuleSlot *)nullptr : rules, rule_mask, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, bargs, sargs);
 }
 void launch_gather(const PairIndexArgs &a, const RuleSlot *rules, unsigned int n_slots, const BatchArgs *ba, uint32_t self_x, uint32_t *stamp,
                    uint32_t round_id, uint32_t *worklist, unsigned int n_tiles, unsigned int *work_n, hipStream_t st) {

@@ -97,6 +97,10 @@ void launch_apply_pm(const TileSet &ts, const PairTable &pt, const DeltaBuf &db,
                      uint32_t self_x, uint32_t self_z, uint32_t z_base, const uint32_t *worklist, const unsigned int *work_n, unsigned long long *stats,
                      const BatchArgs *ba, const ScanArgs *scan, bool eager_w, hipStream_t st);
 // pair index for K4's worklists (k_merge.hip: PairIndex)
+// A key's posting count / fill cursor is kept in IDX_SHARDS copies (a wave adds to copy (its number) % IDX_SHARDS): a pair with a million
+// adjacencies is a million atomics on ONE address otherwise (~12 ns each: 6.5 ms per pass at the word-mode switch of the 1 GB corpus).
+// The copies' runs are adjacent, so a key's postings are still one run: [off[s * IDX_SHARDS], off[(s + 1) * IDX_SHARDS]).
+constexpr unsigned int IDX_SHARDS = 16;
 struct PairIndexArgs {
   unsigned long long *key, *off;
   uint32_t *cnt, *bloom, *post;
@@ -126,8 +130,10 @@ constexpr unsigned int WGATHER_MAXK = 4096;
 void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, hipStream_t st);
 void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
                         uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules, const uint32_t *worklist /* nullptr: every word */, unsigned long long wl_seg,
-                        const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, const BatchArgs *ba, const ScanArgs *scan,
-                        unsigned int work_hint, hipStream_t st);
+                        const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, DeltaRec *drec /* [WORDS_MAX_GRID * drec_cap] */,
+                        unsigned int drec_cap, unsigned int *drec_n /* [WORDS_MAX_GRID] */, const BatchArgs *ba, const ScanArgs *scan, unsigned int work_hint,
+                        hipStream_t st);
+constexpr unsigned int WORDS_MAX_GRID = 512;  // workgroups of k_words: each owns a region of the round's count-update records
 void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, unsigned int nom, unsigned long long total,
                    unsigned long long *gstart, unsigned int n_new, uint32_t *new_tok, uint32_t *new_len, uint32_t *new_word0, hipStream_t st);
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
