@@ -334,6 +334,7 @@ def test_worklists_from_the_pair_index(tmp_path, monkeypatch):
     import oracle_lib as O
     L = _lib.load()
     monkeypatch.setenv("YTTM_INDEX_ALWAYS", "1")
+    monkeypatch.setenv("YTTM_WORD_MODE", "0")  # (tiles to the end; word mode has its own test below)
     gathered = builds = 0
     rng = random.Random(77)
     cases = [(gen.readme_corpus(300, 100, seed=6), 900), (gen.zipf_corpus(120000, vocab=3000), 700),
@@ -354,3 +355,41 @@ def test_worklists_from_the_pair_index(tmp_path, monkeypatch):
             gathered += r["gathered_rounds"]
             builds += r["index_builds"]
     assert gathered > 50 and builds > 4, (gathered, builds)
+
+
+def test_word_mode(tmp_path, monkeypatch):
+    """Word mode (k_wgather + k_words + k_delta_apply: class-A words in fixed slots, a round visits the words that hold a merge site, found
+    through the pair index at word granularity or the instance list of the pair's younger token) forced on from the second round, on
+    corpora of several tiles; then with tiny hot lists (an index build per rebuild, rounds over every word while the list is overflowed),
+    a record log and record regions that overflow: same models as the oracle."""
+    import ctypes as C
+    import filecmp
+    import json
+    from youtokentome_amd import _lib
+    import oracle_lib as O
+    L = _lib.load()
+    monkeypatch.setenv("YTTM_WORD_MIN_TILES", "0")
+    monkeypatch.setenv("YTTM_WORD_DIV", "0")
+    rng = random.Random(78)
+    cases = [(gen.readme_corpus(300, 100, seed=6), 900), (gen.zipf_corpus(120000, vocab=3000), 700),
+             (gen.unicode_text(rng, 30000, "ascii"), 400), (("aaaa aaaaa abababab aabbaabb bbbbbb ab aaab baaa " * 400).encode(), 60),
+             (gen.unicode_text(rng, 20000, "cjk"), 600)]
+    word_rounds = all_rounds = builds = 0
+    for cfg in (None, {"YTTM_HOT_TARGET": 40, "YTTM_HOT_MIN": 4, "YTTM_HOT_CAP": 400, "YTTM_WORD_DREC": 64}, {"YTTM_WORD_LOG": 300}):
+        for k, v in (cfg or {}).items():
+            monkeypatch.setenv(k, str(v))
+        for i, (text, vocab) in enumerate(cases):
+            corpus, m_gpu, m_ora = str(tmp_path / f"c{i}.txt"), str(tmp_path / f"g{i}.model"), str(tmp_path / f"o{i}.model")
+            open(corpus, "wb").write(text)
+            err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+            rc = L.yttm_train_bpe_ex(corpus.encode(), m_gpu.encode(), vocab, 1.0, 1, 0, 1, 2, 3, 0, rep, 16384, err, 2048)
+            assert rc == 0, err.value
+            O.train(text, m_ora, vocab)
+            assert filecmp.cmp(m_gpu, m_ora, shallow=False), (i, cfg)
+            r = json.loads(rep.value.decode())
+            word_rounds += r["word_rounds"]
+            all_rounds += r["word_all_rounds"]
+            builds += r["index_builds"]
+        for k in (cfg or {}):
+            monkeypatch.delenv(k)
+    assert word_rounds > 500 and all_rounds > 10 and builds > 20, (word_rounds, all_rounds, builds)

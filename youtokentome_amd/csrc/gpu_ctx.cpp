@@ -1351,7 +1351,7 @@ void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned lon
 
 // ------------------------------------------------------------------------------------------------- K4
 void GpuCtx::free_words() {
-  DFREE(d_wmeta_); DFREE(d_gm_); DFREE(d_xyz_); DFREE(d_wworklist_); DFREE(d_drec_); DFREE(d_drec_n_);
+  DFREE(d_wmeta_); DFREE(d_gm_); DFREE(d_xyz_); DFREE(d_wworklist_); DFREE(d_drec_); DFREE(d_drec_n_); DFREE(d_irec_);
   DFREE(tl_.base); DFREE(tl_.cap); DFREE(tl_.fill); DFREE(tl_.rec_word); DFREE(tl_.rec_l); DFREE(tl_.rec_r); DFREE(tl_.cursor);
   tl_ = TokLists{};
   word_mode_ = false;
@@ -1366,12 +1366,14 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
   d_wmeta_ = dmalloc<unsigned long long>(c.n_unique + 1);
   launch_words_init(c.ts, d_wmeta_, st_);
   d_wworklist_ = dmalloc<uint32_t>(c.n_unique + 64);
+  HIP_CHECK(hipMemsetAsync(c.d_work_n, 0, 64, st_));
   d_gm_ = dmalloc<unsigned int>(WGATHER_MAXK + 4);
   HIP_CHECK(hipMemsetAsync(d_gm_, 0, (WGATHER_MAXK + 4) * 4, st_));
   d_xyz_ = dmalloc<uint32_t>(3 * (size_t)RULES_CAP);
   drec_cap_ = env_uint("YTTM_WORD_DREC", 1u << 15);  // (tests: a region that overflows)
   d_drec_ = dmalloc<DeltaRec>((size_t)WORDS_MAX_GRID * drec_cap_);
   d_drec_n_ = dmalloc<unsigned int>(WORDS_MAX_GRID);
+  d_irec_ = dmalloc<uint4>((size_t)WORDS_MAX_GRID * drec_cap_);
   tl_.base = dmalloc<unsigned long long>(tokflag_cap_);
   tl_.cap = dmalloc<uint32_t>(tokflag_cap_);
   tl_.fill = dmalloc<uint32_t>(tokflag_cap_);
@@ -1665,8 +1667,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
         d_xyz = d_xyz_;
       }
       if (k > WGATHER_MAXK) throw GpuError{"merge_apply: batch too large for the word-mode gather"};
-      HIP_CHECK(hipMemsetAsync(c.d_work_n, 0, 64, st_));
-      WGatherArgs ga{};
+      WGatherArgs ga{};  // (the worklist's length is at zero: enter_word_mode, then every round's k_delta_apply)
       ga.ix = idx_;
       ga.ix_valid = idx_valid_ ? 1u : 0u;
       ga.z_static = idx_valid_ ? idx_zbuild_ : 0xffffffffu;  // (no index: every rule is "not found", the round takes every word)
@@ -1689,7 +1690,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       }
       launch_wgather(ga, by_args ? &ba : nullptr, st_);
       const WordSet wset{c.d_tok, d_wmeta_, c.d_wcnt, (uint32_t)c.n_unique};
-      launch_words_apply(wset, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, &ba,
+      launch_words_apply(wset, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, d_irec_, &ba,
                          sa.on && last_cls == 0 ? &sa : nullptr, sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + 4096, 1ull << 30) : 0u, st_);
       word_rounds++;
       if (!idx_valid_) word_all_rounds++;

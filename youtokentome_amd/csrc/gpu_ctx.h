@@ -205,6 +205,7 @@ class GpuCtx {
   uint32_t *d_wworklist_ = nullptr;  // [n_unique + 64] the round's words
   DeltaRec *d_drec_ = nullptr;       // [WORDS_MAX_GRID * drec_cap_] the round's count updates, a region per workgroup of k_words
   unsigned int *d_drec_n_ = nullptr, drec_cap_ = 0;
+  uint4 *d_irec_ = nullptr;          // [WORDS_MAX_GRID * drec_cap_] the round's new-instance records before they go to the tokens' lists
   TokLists tl_{};
   unsigned long long sites_cum_ = 0, sites_last_ = ~0ull;
   void enter_word_mode(uint32_t z_next);

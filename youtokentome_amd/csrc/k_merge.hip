@@ -1808,22 +1808,43 @@ __global__ __launch_bounds__(BLOCK) void k_idx_seed(PairTable pt, PairIndex ix) 
   }
 }
 // One wavefront per tile, tokens in registers: every adjacency whose pair is a key of the index is counted (FILL = false) or has
-// its tile appended to the key's postings (FILL = true; one posting per adjacency: duplicates of a tile are harmless, the gather
-// claims a tile once).
-template <int SLOT, bool FILL, bool WORDS>
-__global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) {
-  __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
-  for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += BLOCK) bloom[i] = ix.bloom[i];
-  __syncthreads();
+// its tile / its word appended to the key's postings (FILL = true; one posting per adjacency: duplicates are harmless, the gather
+// claims a tile / a word once).  At the word-mode switch nearly every adjacency is a posting (1 GB corpus: 78 M of 94 M tokens, 10 000
+// keys): one global atomic per posting was 6 ms per pass.  So a workgroup sums its postings per key in an LDS table first -- count pass:
+// one global add per key and workgroup; fill pass: count, reserve the workgroup's run of each key with ONE add, then go over the tiles
+// again and hand the run out from LDS cursors.  Keys that find no room in the table take the global atomic per posting as before.
+constexpr int IDXA_NT = 512, IDXA_SLOTS = 8192, IDXA_PROBES = 16;
+struct IdxAgg {
+  uint32_t key[IDXA_SLOTS];   // slot of the index (0xffffffff = free)
+  uint32_t cnt[IDXA_SLOTS];   // postings of this workgroup; fill pass, second sweep: the cursor
+  uint32_t base[IDXA_SLOTS];  // fill pass: start of this workgroup's run of the key's postings
+};
+__device__ inline int idxa_find(IdxAgg &T, uint32_t s, bool insert) {
+  uint32_t h = (s * 0x9E3779B1u) >> (32 - 13);
+  static_assert(IDXA_SLOTS == 1 << 13, "hash bits");
+  for (int p = 0; p < IDXA_PROBES; p++) {
+    uint32_t k = __hip_atomic_load(&T.key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k == 0xffffffffu && insert) {
+      k = atomicCAS(&T.key[h], 0xffffffffu, s);
+      if (k == 0xffffffffu) k = s;
+    }
+    if (k == s) return (int)h;
+    if (k == 0xffffffffu) return -1;
+    h = (h + 1) & (IDXA_SLOTS - 1);
+  }
+  return -1;
+}
+// SWEEP 0: count into the table (count pass: + global adds for what finds no room); SWEEP 1 (fill pass): write the postings
+template <int SLOT, bool FILL, bool WORDS, int SWEEP>
+__device__ inline void idx_sweep(const TileSet &ts, const PairIndex &ix, const uint32_t *bloom, IdxAgg &T, uint32_t shard) {
   const int lane = lane_id();
-  const uint32_t stride = gridDim.x * NWAVES;
-  const uint32_t shard = (blockIdx.x * NWAVES + (threadIdx.x >> 6)) % IDX_SHARDS;
-  for (uint32_t t = blockIdx.x * NWAVES + (threadIdx.x >> 6); t < ts.n_tiles; t += stride) {
+  const uint32_t stride = gridDim.x * (IDXA_NT / 64);
+  for (uint32_t t = blockIdx.x * (IDXA_NT / 64) + (threadIdx.x >> 6); t < ts.n_tiles; t += stride) {
     const int n = (int)ts.tile_len[t];
     uint4 r[SLOT / 256];
     tile_fetch<SLOT>(r, ts, t, n);
     // WORDS: a posting is the WORD that holds the adjacency (word mode: the tile may hold TOK_HOLEs -- word-start bit set, so never the
-    // second token of an adjacency; never counted as a word start).  wb = word starts before my first token of the row.
+    // second token of an adjacency; never counted as a word start).
     uint32_t wrow = WORDS ? ts.tile_word0[t] : 0u;
     (void)wrow;
 #define IDX_PAIR(T0, T1, WIDX)                                                        \
@@ -1835,8 +1856,15 @@ __global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) 
       const uint32_t s_ = idx_find(ix, pair_key(a_, b_), h_);                          \
       if (s_ != 0xffffffffu) {                                                         \
         const size_t cs_ = (size_t)s_ * IDX_SHARDS + shard;                            \
-        if (FILL) ix.post[ix.off[cs_] + atomicAdd(&ix.cnt[cs_], 1u)] = WORDS ? (WIDX) : t; \
-        else atomicAdd(&ix.cnt[cs_], 1u);                                              \
+        const int e_ = idxa_find(T, s_, SWEEP == 0);                                   \
+        if (SWEEP == 0) {                                                              \
+          if (e_ >= 0) atomicAdd(&T.cnt[e_], 1u);                                      \
+          else if (!FILL) atomicAdd(&ix.cnt[cs_], 1u);                                 \
+        } else {                                                                       \
+          const unsigned long long at_ = e_ >= 0 ? (unsigned long long)T.base[e_] + atomicAdd(&T.cnt[e_], 1u) \
+                                                 : ix.off[cs_] + atomicAdd(&ix.cnt[cs_], 1u); \
+          ix.post[at_] = WORDS ? (WIDX) : t;                                           \
+        }                                                                              \
       }                                                                                \
     }                                                                                  \
   }
@@ -1847,8 +1875,8 @@ __global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) 
         uint32_t nx0 = TOK_WS;
         if (j + 1 < SLOT / 256) nx0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
         if (lane == 63) nx = nx0;
-        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // word of my token i (WORDS && FILL)
-        if (WORDS && FILL) {
+        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // word of my token i
+        if (WORDS && SWEEP == 1) {
           const bool s0 = tok_is_ws(r[j].x), s1 = tok_is_ws(r[j].y), s2 = tok_is_ws(r[j].z), s3 = tok_is_ws(r[j].w);
           const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1), m2 = __ballot(s2), m3 = __ballot(s3);
           const unsigned long long lt = lanemask_lt();
@@ -1868,6 +1896,33 @@ __global__ __launch_bounds__(BLOCK) void k_idx_stream(TileSet ts, PairIndex ix) 
     }
 #undef IDX_PAIR
   }
+}
+template <int SLOT, bool FILL, bool WORDS>
+__global__ __launch_bounds__(IDXA_NT) void k_idx_stream(TileSet ts, PairIndex ix) {
+  __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
+  __shared__ IdxAgg T;
+  for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += IDXA_NT) bloom[i] = ix.bloom[i];
+  for (int i = (int)threadIdx.x; i < IDXA_SLOTS; i += IDXA_NT) {
+    T.key[i] = 0xffffffffu;
+    T.cnt[i] = 0;
+  }
+  __syncthreads();
+  const uint32_t shard = blockIdx.x % IDX_SHARDS;
+  idx_sweep<SLOT, FILL, WORDS, 0>(ts, ix, bloom, T, shard);
+  __syncthreads();
+  for (int i = (int)threadIdx.x; i < IDXA_SLOTS; i += IDXA_NT) {
+    const uint32_t s = T.key[i], c = T.cnt[i];
+    if (s == 0xffffffffu || !c) continue;
+    const size_t cs = (size_t)s * IDX_SHARDS + shard;
+    const uint32_t b0 = atomicAdd(&ix.cnt[cs], c);
+    if (FILL) {
+      T.base[i] = (uint32_t)ix.off[cs] + b0;  // (the postings number fewer than 2^32: build_index checks)
+      T.cnt[i] = 0;
+    }
+  }
+  if (!FILL) return;
+  __syncthreads();
+  idx_sweep<SLOT, FILL, WORDS, 1>(ts, ix, bloom, T, shard);
 }
 // One workgroup per rule of the batch (slot of the batch's rule hash, or index into the kernel-argument batch): the tiles of its
 // postings join the round's worklist -- each tile once (stamp = the round that claimed it last).  A pair that is not in the index
@@ -2111,29 +2166,25 @@ struct WordsLds {
   unsigned long long newsite[TILE_SLOT_A / 64];  // bit q: the token at position q of the compacted tile is a new one
   uint32_t wnew[66];                             // start of word i in the compacted tile; [nw] = its length
 };
-constexpr int WORDS_RB = 512;   // new-instance records buffered per workgroup (flushed once, at the end: one cursor bump per new token and workgroup)
-struct RecBuf {
-  uint32_t zr[WORDS_RB], word[WORDS_RB], l[WORDS_RB], r[WORDS_RB];
-  unsigned int n;
-};
 template <int WPB, bool LDSR>
 __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules, unsigned int rule_mask,
                                                     const uint32_t *__restrict__ bloom_g, uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules,
                                                     const uint32_t *__restrict__ worklist, unsigned long long wl_seg,
                                                     const unsigned int *__restrict__ work_n, unsigned long long *__restrict__ stats, TokLists tl,
                                                     DeltaRec *__restrict__ drec, unsigned int drec_cap /* per workgroup */, unsigned int *__restrict__ drec_n,
+                                                    uint4 *__restrict__ irec /* new-instance records, a region of drec_cap per workgroup too */,
                                                     BatchArgs ba) {
   constexpr int SLOT = TILE_SLOT_A;
   __shared__ WaveLds<SLOT> WL[WPB];
   __shared__ WordsLds XL[WPB];
   __shared__ unsigned int dn;  // records of this workgroup
   __shared__ AggLds A;
-  __shared__ RecBuf RB;
+  __shared__ unsigned int rn;  // new-instance records of this workgroup (its region of irec; put into the tokens' lists at the end)
   __shared__ unsigned long long rkeys[LDSR ? APPLY_LDS_RULES : 1];
   __shared__ uint16_t rridx[LDSR ? APPLY_LDS_RULES : 1];
   const bool from_args = LDSR && ba.k != 0;
   agg_init<WPB * 64>(A, from_args ? nullptr : bloom_g);  // (A.flagbits holds the batch's pair filter)
-  if (threadIdx.x == 0) RB.n = 0;
+  if (threadIdx.x == 0) rn = 0;
   if (threadIdx.x == 0) dn = 0;
   if (from_args) {
     for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += WPB * 64) A.flagbits[s] = 0;
@@ -2168,6 +2219,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   WordsLds &X = XL[wave];
   const TileSet ts{ws.tok, nullptr, nullptr, ws.wcnt, 0u};
   const DeltaOut dout{drec + (size_t)blockIdx.x * drec_cap, &dn, drec_cap};
+  uint4 *my_irec = irec + (size_t)blockIdx.x * drec_cap;
   // work items: runs of 64 worklist entries, or of 64 words
   if (worklist && work_n[WL_PARTS + 1]) worklist = nullptr;
   const uint32_t wl_n = worklist ? work_n[0] : 0u;
@@ -2323,7 +2375,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
               if (nm) {
                 unsigned int b0 = 0;
                 const int fl = __ffsll((long long)nm) - 1;
-                if (lane == fl) b0 = atomicAdd(&RB.n, (unsigned int)__popcll(nm));
+                if (lane == fl) b0 = atomicAdd(&rn, (unsigned int)__popcll(nm));
                 b0 = (unsigned int)__shfl((int)b0, fl);
                 const uint32_t z = isnew ? (tq & L_ID) : 0u;
                 uint32_t lnb = NBR_NONE, rnb = NBR_NONE;
@@ -2333,11 +2385,8 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
                   const uint32_t tr = q + 1 < n2 ? W.tk[q + 1] : TOK_WS;
                   if (!(tr & TOK_WS)) rnb = tr & L_ID;
                   const unsigned int pos = b0 + (unsigned int)__popcll(nm & lanemask_lt());
-                  if (pos < (unsigned int)WORDS_RB) {
-                    RB.zr[pos] = z - z_base;
-                    RB.word[pos] = word_id;
-                    RB.l[pos] = lnb;
-                    RB.r[pos] = rnb;
+                  if (pos < drec_cap) {
+                    my_irec[pos] = make_uint4(z - z_base, word_id, lnb, rnb);
                   } else {
                     direct = true;
                   }
@@ -2412,27 +2461,28 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
     static_assert(sizeof(WL) >= WGATHER_MAXK * sizeof(uint32_t), "per-rule counters of the record flush");
     uint32_t *rcnt = reinterpret_cast<uint32_t *>(&WL[0]);
     __syncthreads();
-    const unsigned int nrec = RB.n < (unsigned int)WORDS_RB ? RB.n : (unsigned int)WORDS_RB;
+    const unsigned int nrec = rn < drec_cap ? rn : drec_cap;
     if (nrec) {  // (uniform)
       const uint32_t kk = k_rules < WGATHER_MAXK ? k_rules : WGATHER_MAXK;
       for (uint32_t j = threadIdx.x; j < kk; j += WPB * 64) rcnt[j] = 0;
       __syncthreads();
-      for (unsigned int i = threadIdx.x; i < nrec; i += WPB * 64) {
-        const uint32_t zr = RB.zr[i] & 0xfffu;
-        RB.zr[i] = zr | (atomicAdd(&rcnt[zr], 1u) << 12);
+      for (unsigned int i = threadIdx.x; i < nrec; i += WPB * 64) {  // rank of the record among the workgroup's records of its token
+        const uint32_t zr = my_irec[i].x & 0xfffu;
+        my_irec[i].x = zr | (atomicAdd(&rcnt[zr], 1u) << 12);
       }
       __syncthreads();
       for (uint32_t j = threadIdx.x; j < kk; j += WPB * 64)
         if (rcnt[j]) rcnt[j] = atomicAdd(&tl.fill[z_base + j], rcnt[j]);
       __syncthreads();
       for (unsigned int i = threadIdx.x; i < nrec; i += WPB * 64) {
-        const uint32_t zr = RB.zr[i] & 0xfffu, z = z_base + zr;
-        const uint32_t at = rcnt[zr] + (RB.zr[i] >> 12);
+        const uint4 rec = my_irec[i];
+        const uint32_t zr = rec.x & 0xfffu, z = z_base + zr;
+        const uint32_t at = rcnt[zr] + (rec.x >> 12);
         if (at < tl.cap[z]) {
           const unsigned long long o = tl.base[z] + at;
-          tl.rec_word[o] = RB.word[i];
-          tl.rec_l[o] = RB.l[i];
-          tl.rec_r[o] = RB.r[i];
+          tl.rec_word[o] = rec.y;
+          tl.rec_l[o] = rec.z;
+          tl.rec_r[o] = rec.w;
         } else {
           __hip_atomic_store(tl.broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -2462,12 +2512,14 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
 constexpr int DAPPLY_NT = 256;
 __global__ __launch_bounds__(DAPPLY_NT) void k_delta_apply(PairTable pt, DeltaBuf db, const DeltaRec *__restrict__ drec, unsigned int drec_cap,
                                                           const unsigned int *__restrict__ drec_n, unsigned int parts,
+                                                          unsigned int *__restrict__ work_n /* the round's worklist is done with: left at zero for the next gather */,
                                                           unsigned long long *__restrict__ stats, const RuleSlot *__restrict__ zrules, unsigned int zmask,
                                                           unsigned long long zself, BatchArgs zba, ScanArgs sa) {
   __shared__ unsigned int new_keys, is_last;
   __shared__ unsigned long long zkeys[FILTER_LDS_KEYS];
   __shared__ unsigned int scratch[CAND_BINS + 80];
   if (threadIdx.x == 0) new_keys = 0;
+  if (blockIdx.x == 0 && threadIdx.x <= WL_PARTS + 1) work_n[threadIdx.x] = 0;
   __syncthreads();
   const unsigned int r = blockIdx.x / parts, p = blockIdx.x % parts;
   const unsigned int n = drec_n[r];
@@ -2854,17 +2906,17 @@ void launch_idx_seed(const PairTable &pt, const PairIndexArgs &a, unsigned int l
 void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st, bool words) {
   if (!ts.n_tiles) return;
   const PairIndex ix{a.key, a.cnt, a.off, a.bloom, a.post, a.mask};
-  unsigned int g = (ts.n_tiles + NWAVES - 1) / NWAVES;
-  if (g > 256 * 6) g = 256 * 6;
+  unsigned int g = (ts.n_tiles + IDXA_NT / 64 - 1) / (IDXA_NT / 64);
+  if (g > 256) g = 256;  // (one workgroup per CU: 128 KB of LDS; count and fill pass MUST use the same grid -- a workgroup's shard and tiles)
   if (cls == 0 && words) {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, true>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, true>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix);
   } else if (cls == 0) {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix);
   } else {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, true, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, false, false>), dim3(g), dim3(BLOCK), 0, st, ts, ix);
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, true, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, false, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix);
   }
 }
 void launch_words_init(const TileSet &ts, unsigned long long *wmeta, hipStream_t st) {
@@ -2881,7 +2933,7 @@ void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, hipStream_t st) {
 void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
                         uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules, const uint32_t *worklist, unsigned long long wl_seg,
                         const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, DeltaRec *drec, unsigned int drec_cap, unsigned int *drec_n,
-                        const BatchArgs *ba, const ScanArgs *scan, unsigned int work_hint, hipStream_t st) {
+                        uint4 *irec, const BatchArgs *ba, const ScanArgs *scan, unsigned int work_hint, hipStream_t st) {
   if (!ws.n_words) return;
   const BatchArgs bargs = ba ? *ba : BatchArgs{};
   const ScanArgs sargs = scan ? *scan : ScanArgs{};
@@ -2894,14 +2946,14 @@ void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &
   if (g < 1) g = 1;
   if (rule_mask < APPLY_LDS_RULES)
     hipLaunchKernelGGL((k_words<APPLY_WPB, true>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
-                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, bargs);
+                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, bargs);
   else
     hipLaunchKernelGGL((k_words<APPLY_WPB, false>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
-                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, bargs);
+                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, bargs);
   // the records -> the pair table, then the round's candidate scan (every workgroup owns a statistics row: at most BLK_ROWS of them)
   const unsigned int parts = std::max(1u, std::min(8u, (unsigned int)BLK_ROWS / (unsigned int)g));
   hipLaunchKernelGGL(k_delta_apply, dim3((unsigned int)g * parts), dim3(DAPPLY_NT), 0, st, pt, db, (const DeltaRec *)drec, drec_cap, (const unsigned int *)drec_n, parts,
-                     stats, bargs.k ? (const RuleSlot *)nullptr : rules, rule_mask, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, bargs, sargs);
+                     const_cast<unsigned int *>(work_n), stats, bargs.k ? (const RuleSlot *)nullptr : rules, rule_mask, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, bargs, sargs);
 }
 void launch_gather(const PairIndexArgs &a, const RuleSlot *rules, unsigned int n_slots, const BatchArgs *ba, uint32_t self_x, uint32_t *stamp,
                    uint32_t round_id, uint32_t *worklist, unsigned int n_tiles, unsigned int *work_n, hipStream_t st) {
