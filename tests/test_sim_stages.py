@@ -375,7 +375,7 @@ def test_word_mode(tmp_path, monkeypatch):
              (gen.unicode_text(rng, 30000, "ascii"), 400), (("aaaa aaaaa abababab aabbaabb bbbbbb ab aaab baaa " * 400).encode(), 60),
              (gen.unicode_text(rng, 20000, "cjk"), 600)]
     word_rounds = all_rounds = builds = 0
-    for cfg in (None, {"YTTM_HOT_TARGET": 40, "YTTM_HOT_MIN": 4, "YTTM_HOT_CAP": 400, "YTTM_WORD_DREC": 64}, {"YTTM_WORD_LOG": 300}):
+    for cfg in (None, {"YTTM_HOT_TARGET": 40, "YTTM_HOT_MIN": 4, "YTTM_HOT_CAP": 400, "YTTM_WORD_DREC": 64, "YTTM_INDEX_AGG_MIN": 0}, {"YTTM_WORD_LOG": 300}):
         for k, v in (cfg or {}).items():
             monkeypatch.setenv(k, str(v))
         for i, (text, vocab) in enumerate(cases):

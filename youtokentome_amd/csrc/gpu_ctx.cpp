@@ -173,6 +173,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
                                                                   //  measured at 1 GB, K4 + candidate family ms: no index 151.1, 64/4 147.3, 128/4 148.8, 64/8 145.1, 32/8 147.8, 256/3 160.6)
   idx_force_ = env_uint("YTTM_INDEX_ALWAYS", 0) != 0;  // (tests: worklists from the index whenever the batch allows, however few tiles)
   use_pm_ = env_uint("YTTM_K4_PM", 0) != 0;
+  idx_agg_min_ = env_uint("YTTM_INDEX_AGG_MIN", 16u << 20);  // (fill pass of an index build: postings from which on a workgroup sums them per key in LDS first; tests: 0)
   words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end, worklists of tiles from the pair index)
   word_div_ = env_uint("YTTM_WORD_DIV", 24);
   word_min_tiles_ = env_uint("YTTM_WORD_MIN_TILES", 16384);  // (tests: 0 = switch as soon as the hot list is active)
@@ -1459,7 +1460,7 @@ void GpuCtx::build_index(uint32_t z_next) {
     post_cap_ = total + total / 4 + 1024;
     idx_.post = dmalloc<uint32_t>(post_cap_);
   }
-  launch_idx_stream(0, true, c.ts, idx_, st_, word_mode_);
+  launch_idx_stream(0, true, c.ts, idx_, st_, word_mode_, /*agg=*/total > idx_agg_min_);
   t_end(KT_CAND, 8ull * c.n_tiles * c.nom);
   const unsigned long long stamps = word_mode_ ? c.n_unique : c.n_tiles;  // (word mode: a posting is a word, and a round claims words)
   if (stamps > stamp_cap_) {

@@ -1813,23 +1813,21 @@ __global__ __launch_bounds__(BLOCK) void k_idx_seed(PairTable pt, PairIndex ix) 
 // keys): one global atomic per posting was 6 ms per pass.  So a workgroup sums its postings per key in an LDS table first -- count pass:
 // one global add per key and workgroup; fill pass: count, reserve the workgroup's run of each key with ONE add, then go over the tiles
 // again and hand the run out from LDS cursors.  Keys that find no room in the table take the global atomic per posting as before.
-constexpr int IDXA_NT = 512, IDXA_SLOTS = 8192, IDXA_PROBES = 16;
-struct IdxAgg {
-  uint32_t key[IDXA_SLOTS];   // slot of the index (0xffffffff = free)
-  uint32_t cnt[IDXA_SLOTS];   // postings of this workgroup; fill pass, second sweep: the cursor
-  uint32_t base[IDXA_SLOTS];  // fill pass: start of this workgroup's run of the key's postings
+constexpr int IDXA_NT = 512, IDXA_SLOTS = 2048, IDXA_BITS = 11, IDXA_PROBES = 8;
+struct IdxAgg {                          // the workgroup's table: pair -> its slot of the index and this workgroup's postings of it.  The
+  unsigned long long key[IDXA_SLOTS];    // frequent pairs get in first (PT_EMPTY = free) and are then resolved without leaving the CU:
+  uint32_t slot[IDXA_SLOTS];             // no Bloom test, no probe of the index in L2
+  uint32_t cnt[IDXA_SLOTS];              // postings of this workgroup; fill pass, second sweep: the cursor
+  uint32_t base[IDXA_SLOTS];             // fill pass: start of this workgroup's run of the key's postings
 };
-__device__ inline int idxa_find(IdxAgg &T, uint32_t s, bool insert) {
-  uint32_t h = (s * 0x9E3779B1u) >> (32 - 13);
-  static_assert(IDXA_SLOTS == 1 << 13, "hash bits");
+// entry of `key` in its probe window, or -1
+__device__ inline int idxa_lookup(const IdxAgg &T, unsigned long long key) {
+  uint32_t h = pair_hash32(key) >> (32 - IDXA_BITS);
+  static_assert(IDXA_SLOTS == 1 << IDXA_BITS, "hash bits");
   for (int p = 0; p < IDXA_PROBES; p++) {
-    uint32_t k = __hip_atomic_load(&T.key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (k == 0xffffffffu && insert) {
-      k = atomicCAS(&T.key[h], 0xffffffffu, s);
-      if (k == 0xffffffffu) k = s;
-    }
-    if (k == s) return (int)h;
-    if (k == 0xffffffffu) return -1;
+    const unsigned long long k = __hip_atomic_load(&T.key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k == key) return (int)h;
+    if (k == PT_EMPTY) return -1;
     h = (h + 1) & (IDXA_SLOTS - 1);
   }
   return -1;
@@ -1850,22 +1848,43 @@ __device__ inline void idx_sweep(const TileSet &ts, const PairIndex &ix, const u
 #define IDX_PAIR(T0, T1, WIDX)                                                        \
   if (!((T1)&TOK_WS)) {                                                                \
     const uint32_t a_ = (T0)&TOK_MASK, b_ = (T1)&TOK_MASK;                             \
+    const unsigned long long key_ = pair_key(a_, b_);                                  \
     const uint32_t h_ = enc_hash(a_, b_);                                              \
     const uint32_t bits_ = enc_bloom_bits(h_);                                         \
-    if ((bloom[enc_bloom_word(h_)] & bits_) == bits_) {                                \
-      const uint32_t s_ = idx_find(ix, pair_key(a_, b_), h_);                          \
-      if (s_ != 0xffffffffu) {                                                         \
-        const size_t cs_ = (size_t)s_ * IDX_SHARDS + shard;                            \
-        const int e_ = idxa_find(T, s_, SWEEP == 0);                                   \
-        if (SWEEP == 0) {                                                              \
-          if (e_ >= 0) atomicAdd(&T.cnt[e_], 1u);                                      \
-          else if (!FILL) atomicAdd(&ix.cnt[cs_], 1u);                                 \
-        } else {                                                                       \
-          const unsigned long long at_ = e_ >= 0 ? (unsigned long long)T.base[e_] + atomicAdd(&T.cnt[e_], 1u) \
-                                                 : ix.off[cs_] + atomicAdd(&ix.cnt[cs_], 1u); \
-          ix.post[at_] = WORDS ? (WIDX) : t;                                           \
+    const bool maybe_ = (bloom[enc_bloom_word(h_)] & bits_) == bits_;  /* (late builds: few adjacencies are keys of the index) */ \
+    int e_ = maybe_ ? idxa_lookup(T, key_) : -1;                                       \
+    uint32_t s_ = 0xffffffffu;                                                         \
+    if (maybe_ && e_ < 0) {  /* not in the table: is it a key of the index at all? */   \
+      s_ = idx_find(ix, key_, h_);                                                     \
+      if (SWEEP == 0 && s_ != 0xffffffffu) {  /* a place in the table, if its probe window has one */ \
+        uint32_t w_ = pair_hash32(key_) >> (32 - IDXA_BITS);                           \
+        for (int p_ = 0; p_ < IDXA_PROBES; p_++) {                                     \
+          unsigned long long k_ = __hip_atomic_load(&T.key[w_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+          if (k_ == PT_EMPTY) {                                                        \
+            k_ = atomicCAS(&T.key[w_], PT_EMPTY, key_);                                \
+            if (k_ == PT_EMPTY) k_ = key_;                                             \
+          }                                                                            \
+          if (k_ == key_) {                                                            \
+            T.slot[w_] = s_;                                                           \
+            e_ = (int)w_;                                                              \
+            break;                                                                     \
+          }                                                                            \
+          w_ = (w_ + 1) & (IDXA_SLOTS - 1);                                            \
         }                                                                              \
       }                                                                                \
+    }                                                                                  \
+    if (SWEEP == 0) {                                                                  \
+      if (e_ >= 0) atomicAdd(&T.cnt[e_], 1u);                                          \
+      else if (!FILL && s_ != 0xffffffffu) atomicAdd(&ix.cnt[(size_t)s_ * IDX_SHARDS + shard], 1u); \
+    } else if (e_ >= 0 || s_ != 0xffffffffu) {                                         \
+      unsigned long long at_;                                                          \
+      if (e_ >= 0) {                                                                   \
+        at_ = (unsigned long long)T.base[e_] + atomicAdd(&T.cnt[e_], 1u);              \
+      } else {                                                                         \
+        const size_t cs_ = (size_t)s_ * IDX_SHARDS + shard;                            \
+        at_ = ix.off[cs_] + atomicAdd(&ix.cnt[cs_], 1u);                               \
+      }                                                                                \
+      ix.post[at_] = WORDS ? (WIDX) : t;                                               \
     }                                                                                  \
   }
 #pragma unroll
@@ -1898,22 +1917,22 @@ __device__ inline void idx_sweep(const TileSet &ts, const PairIndex &ix, const u
   }
 }
 template <int SLOT, bool FILL, bool WORDS>
-__global__ __launch_bounds__(IDXA_NT) void k_idx_stream(TileSet ts, PairIndex ix) {
-  __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
+__global__ __launch_bounds__(IDXA_NT) void k_idx_stream(TileSet ts, PairIndex ix, int agg /* fill pass: 0 = few postings, one sweep with an atomic each */) {
   __shared__ IdxAgg T;
+  __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
   for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += IDXA_NT) bloom[i] = ix.bloom[i];
   for (int i = (int)threadIdx.x; i < IDXA_SLOTS; i += IDXA_NT) {
-    T.key[i] = 0xffffffffu;
+    T.key[i] = PT_EMPTY;
     T.cnt[i] = 0;
   }
   __syncthreads();
   const uint32_t shard = blockIdx.x % IDX_SHARDS;
-  idx_sweep<SLOT, FILL, WORDS, 0>(ts, ix, bloom, T, shard);
+  if (agg) idx_sweep<SLOT, FILL, WORDS, 0>(ts, ix, bloom, T, shard);
   __syncthreads();
   for (int i = (int)threadIdx.x; i < IDXA_SLOTS; i += IDXA_NT) {
-    const uint32_t s = T.key[i], c = T.cnt[i];
-    if (s == 0xffffffffu || !c) continue;
-    const size_t cs = (size_t)s * IDX_SHARDS + shard;
+    const uint32_t c = T.cnt[i];
+    if (T.key[i] == PT_EMPTY || !c) continue;
+    const size_t cs = (size_t)T.slot[i] * IDX_SHARDS + shard;
     const uint32_t b0 = atomicAdd(&ix.cnt[cs], c);
     if (FILL) {
       T.base[i] = (uint32_t)ix.off[cs] + b0;  // (the postings number fewer than 2^32: build_index checks)
@@ -2903,20 +2922,20 @@ void launch_idx_seed(const PairTable &pt, const PairIndexArgs &a, unsigned int l
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(k_idx_seed, dim3(g), dim3(BLOCK), 0, st, pt, ix);
 }
-void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st, bool words) {
+void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st, bool words, bool agg) {
   if (!ts.n_tiles) return;
   const PairIndex ix{a.key, a.cnt, a.off, a.bloom, a.post, a.mask};
   unsigned int g = (ts.n_tiles + IDXA_NT / 64 - 1) / (IDXA_NT / 64);
-  if (g > 256) g = 256;  // (one workgroup per CU: 128 KB of LDS; count and fill pass MUST use the same grid -- a workgroup's shard and tiles)
+  if (g > 512) g = 512;  // (two workgroups per CU: 72 KB of LDS each; count and fill pass MUST use the same grid -- a workgroup's shard and tiles)
   if (cls == 0 && words) {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix);
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0);
   } else if (cls == 0) {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix);
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0);
   } else {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, true, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, false, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix);
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, true, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, false, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0);
   }
 }
 void launch_words_init(const TileSet &ts, unsigned long long *wmeta, hipStream_t st) {
