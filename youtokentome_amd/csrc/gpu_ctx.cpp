@@ -174,8 +174,9 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   idx_force_ = env_uint("YTTM_INDEX_ALWAYS", 0) != 0;  // (tests: worklists from the index whenever the batch allows, however few tiles)
   use_pm_ = env_uint("YTTM_K4_PM", 0) != 0;
   idx_agg_min_ = env_uint("YTTM_INDEX_AGG_MIN", 16u << 20);  // (fill pass of an index build: postings from which on a workgroup sums them per key in LDS first; tests: 0)
+  hot_target_words_ = env_uint("YTTM_HOT_TARGET_WORDS", 1u << 15);  // (measured at 1 GB, word mode: 8192 -> 6 rebuilds, candidate family 21.0 ms; 32768 -> 3, 16.9 ms)
   words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end, worklists of tiles from the pair index)
-  word_div_ = env_uint("YTTM_WORD_DIV", 24);
+  word_div_ = env_uint("YTTM_WORD_DIV", 200);  // (measured at 1 GB: 96 -> K4 135 ms, 150 -> 107, 200 -> 103.7, 300 -> 103.7, 500 -> 104)
   word_min_tiles_ = env_uint("YTTM_WORD_MIN_TILES", 16384);  // (tests: 0 = switch as soon as the hot list is active)
   bloom_mode_ = true;  // (the per-token flag variant of k_tiles is gone; the flag tables still serve the separate filter pass, YTTM_DENSE_PCT)
   gather_grid_ = env_uint("YTTM_GATHER_GRID", 0) != 0;  // (measured at 1 GB: 65.6 vs 62.7 us per late round -- the smaller grid is not faster)
@@ -1043,7 +1044,7 @@ void GpuCtx::rebuild_hot() {
     if (acc + hist[b] > hot_cap_ / 2) break;
     acc += hist[b];
     chosen = b;
-    if (acc >= hot_target_) break;
+    if (acc >= (word_mode_ ? std::max(hot_target_, hot_target_words_) : hot_target_)) break;  // (word mode: a rebuilt list means a rebuilt pair index -- two passes over the words)
   }
   hot_rebuilds++;
   if (chosen < 0 || (acc < hot_min_ && chosen > 1)) {  // ties too large for the list right below the few top pairs

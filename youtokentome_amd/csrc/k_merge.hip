@@ -2191,7 +2191,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
                                                     const uint32_t *__restrict__ worklist, unsigned long long wl_seg,
                                                     const unsigned int *__restrict__ work_n, unsigned long long *__restrict__ stats, TokLists tl,
                                                     DeltaRec *__restrict__ drec, unsigned int drec_cap /* per workgroup */, unsigned int *__restrict__ drec_n,
-                                                    uint4 *__restrict__ irec /* new-instance records, a region of drec_cap per workgroup too */,
+                                                    uint4 *__restrict__ irec /* new-instance records, a region of drec_cap per workgroup too */, unsigned int wpi,
                                                     BatchArgs ba) {
   constexpr int SLOT = TILE_SLOT_A;
   __shared__ WaveLds<SLOT> WL[WPB];
@@ -2242,7 +2242,10 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   // work items: runs of 64 worklist entries, or of 64 words
   if (worklist && work_n[WL_PARTS + 1]) worklist = nullptr;
   const uint32_t wl_n = worklist ? work_n[0] : 0u;
-  const unsigned long long n_items = worklist ? ((unsigned long long)wl_n + 63ull) / 64ull : ((unsigned long long)ws.n_words + 63ull) / 64ull;
+  // (wpi words per work item: 64 when there are words for every wave; fewer in the small late rounds -- a wave's time goes with the tokens
+  // of its tile, and the chip has thousands of idle wave slots then)
+  const unsigned long long n_all = worklist ? (unsigned long long)wl_n : (unsigned long long)ws.n_words;
+  const unsigned long long n_items = (n_all + wpi - 1ull) / wpi;
   (void)wl_seg;
   TileStats S;
 #ifdef YTTM_K4_PROF
@@ -2253,8 +2256,8 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
     bool have;
     uint32_t wid = 0;
     {
-      const unsigned long long wi = item * 64ull + (unsigned long long)lane;
-      have = wi < (worklist ? (unsigned long long)wl_n : (unsigned long long)ws.n_words);
+      const unsigned long long wi = item * (unsigned long long)wpi + (unsigned long long)lane;
+      have = (unsigned int)lane < wpi && wi < n_all;
       wid = (uint32_t)wi;
       if (worklist && have) wid = worklist[wi];
     }
@@ -2290,6 +2293,8 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
         uint32_t cb = 0;
 #pragma unroll
         for (int c = 0; c < SLOT / 64; c++) {
+          v[c] = 0;
+          if (c * 64 >= n) continue;  // (uniform)
           const unsigned long long m = uni64(X.lin[c]);
           const int p = c * 64 + lane;
           // (words of length 0 -- none exist: every word keeps its first token -- would break the rank below)
@@ -2298,7 +2303,6 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
           const int src = first + (int)rank - 1;
           const uint32_t o_lo = (uint32_t)__shfl((int)(uint32_t)woff, src), o_hi = (uint32_t)__shfl((int)(uint32_t)(woff >> 32), src);
           const uint32_t st0 = (uint32_t)__shfl((int)my_start, src);
-          v[c] = 0;
           if (p < n) v[c] = ws.tok[(((unsigned long long)o_hi << 32) | o_lo) + (unsigned long long)((uint32_t)p - st0)];
           cb += (uint32_t)__popcll(m);
         }
@@ -2959,16 +2963,23 @@ void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &
   // one run of 64 words per wave and iteration; work_hint = about how many words the round will visit (0: unknown / every word)
   static const char *g_env = getenv("YTTM_WORDS_GRID");
   const unsigned int gmax = std::min(g_env ? (unsigned int)atoi(g_env) : 512u, (unsigned int)WORDS_MAX_GRID);
-  unsigned long long items = worklist && work_hint ? ((unsigned long long)work_hint + 63) / 64 + 1 : ((unsigned long long)ws.n_words + 63) / 64;
+  // words per wave: 64, or fewer when that would leave most of the chip idle (work_hint words over at most gmax workgroups)
+  unsigned int wpi = 64;
+  if (worklist && work_hint) {
+    static const char *w_env = getenv("YTTM_WORDS_WPI");
+    while (wpi > 8 && (unsigned long long)work_hint < (unsigned long long)wpi * APPLY_WPB * gmax / 2) wpi >>= 1;
+    if (w_env) wpi = (unsigned int)atoi(w_env);
+  }
+  unsigned long long items = worklist && work_hint ? ((unsigned long long)work_hint + wpi - 1) / wpi + 1 : ((unsigned long long)ws.n_words + 63) / 64;
   unsigned long long g = (items + APPLY_WPB - 1) / APPLY_WPB;
   if (g > gmax) g = gmax;
   if (g < 1) g = 1;
   if (rule_mask < APPLY_LDS_RULES)
     hipLaunchKernelGGL((k_words<APPLY_WPB, true>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
-                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, bargs);
+                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, wpi, bargs);
   else
     hipLaunchKernelGGL((k_words<APPLY_WPB, false>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
-                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, bargs);
+                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, wpi, bargs);
   // the records -> the pair table, then the round's candidate scan (every workgroup owns a statistics row: at most BLK_ROWS of them)
   const unsigned int parts = std::max(1u, std::min(8u, (unsigned int)BLK_ROWS / (unsigned int)g));
   hipLaunchKernelGGL(k_delta_apply, dim3((unsigned int)g * parts), dim3(DAPPLY_NT), 0, st, pt, db, (const DeltaRec *)drec, drec_cap, (const unsigned int *)drec_n, parts,
