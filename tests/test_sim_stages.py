@@ -361,7 +361,7 @@ def test_word_mode(tmp_path, monkeypatch):
     """Word mode (k_wgather + k_words + k_delta_apply: class-A words in fixed slots, a round visits the words that hold a merge site, found
     through the pair index at word granularity or the instance list of the pair's younger token) forced on from the second round, on
     corpora of several tiles; then with tiny hot lists (an index build per rebuild, rounds over every word while the list is overflowed),
-    a record log and record regions that overflow: same models as the oracle."""
+    a record log and record regions that overflow, the count updates through k_delta_apply instead of the small rounds' own tail: same models as the oracle."""
     import ctypes as C
     import filecmp
     import json
@@ -375,7 +375,7 @@ def test_word_mode(tmp_path, monkeypatch):
              (gen.unicode_text(rng, 30000, "ascii"), 400), (("aaaa aaaaa abababab aabbaabb bbbbbb ab aaab baaa " * 400).encode(), 60),
              (gen.unicode_text(rng, 20000, "cjk"), 600)]
     word_rounds = all_rounds = builds = 0
-    for cfg in (None, {"YTTM_HOT_TARGET": 40, "YTTM_HOT_MIN": 4, "YTTM_HOT_CAP": 400, "YTTM_WORD_DREC": 64, "YTTM_INDEX_AGG_MIN": 0}, {"YTTM_WORD_LOG": 300}):
+    for cfg in (None, {"YTTM_HOT_TARGET": 40, "YTTM_HOT_MIN": 4, "YTTM_HOT_CAP": 400, "YTTM_WORD_DREC": 64, "YTTM_INDEX_AGG_MIN": 0}, {"YTTM_WORD_LOG": 300, "YTTM_WORDS_INLINE_MAX": 0}):
         for k, v in (cfg or {}).items():
             monkeypatch.setenv(k, str(v))
         for i, (text, vocab) in enumerate(cases):

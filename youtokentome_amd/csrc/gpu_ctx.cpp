@@ -175,6 +175,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   use_pm_ = env_uint("YTTM_K4_PM", 0) != 0;
   idx_agg_min_ = env_uint("YTTM_INDEX_AGG_MIN", 16u << 20);  // (fill pass of an index build: postings from which on a workgroup sums them per key in LDS first; tests: 0)
   hot_target_words_ = env_uint("YTTM_HOT_TARGET_WORDS", 1u << 15);  // (measured at 1 GB, word mode: 8192 -> 6 rebuilds, candidate family 21.0 ms; 32768 -> 3, 16.9 ms)
+  words_inline_max_ = env_uint("YTTM_WORDS_INLINE_MAX", 1u << 16);
   words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end, worklists of tiles from the pair index)
   word_div_ = env_uint("YTTM_WORD_DIV", 200);  // (measured at 1 GB: 96 -> K4 135 ms, 150 -> 107, 200 -> 103.7, 300 -> 103.7, 500 -> 104)
   word_min_tiles_ = env_uint("YTTM_WORD_MIN_TILES", 16384);  // (tests: 0 = switch as soon as the hot list is active)
@@ -1693,7 +1694,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       launch_wgather(ga, by_args ? &ba : nullptr, st_);
       const WordSet wset{c.d_tok, d_wmeta_, c.d_wcnt, (uint32_t)c.n_unique};
       launch_words_apply(wset, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, d_irec_, &ba,
-                         sa.on && last_cls == 0 ? &sa : nullptr, sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + 4096, 1ull << 30) : 0u, st_);
+                         sa.on && last_cls == 0 ? &sa : nullptr, sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + 4096, 1ull << 30) : 0u, words_inline_max_, st_);
       word_rounds++;
       if (!idx_valid_) word_all_rounds++;
       continue;

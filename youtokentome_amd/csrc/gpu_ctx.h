@@ -197,7 +197,7 @@ class GpuCtx {
   void free_index();
   // word mode (k_merge.hip: k_words): class-A words processed one by one from a worklist of the words that hold a merge site
   bool word_mode_ = false, words_enabled_ = true;
-  unsigned int hot_target_words_ = 1u << 15;
+  unsigned int hot_target_words_ = 1u << 15, words_inline_max_ = 1u << 16;
   unsigned int word_div_ = 200;    // switch when (merge sites of the last round) * word_div_ < (tokens a pass over the tiles streams)
   unsigned int word_min_tiles_ = 16384;
   unsigned long long idx_agg_min_ = 16ull << 20;

@@ -2192,7 +2192,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
                                                     const unsigned int *__restrict__ work_n, unsigned long long *__restrict__ stats, TokLists tl,
                                                     DeltaRec *__restrict__ drec, unsigned int drec_cap /* per workgroup */, unsigned int *__restrict__ drec_n,
                                                     uint4 *__restrict__ irec /* new-instance records, a region of drec_cap per workgroup too */, unsigned int wpi,
-                                                    BatchArgs ba) {
+                                                    unsigned int inline_apply /* needs sa.on */, BatchArgs ba, ScanArgs sa) {
   constexpr int SLOT = TILE_SLOT_A;
   __shared__ WaveLds<SLOT> WL[WPB];
   __shared__ WordsLds XL[WPB];
@@ -2523,11 +2523,44 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
     atomicAdd(&stats[8 + 15], A.miss_cyc);
   }
 #endif
-  if (threadIdx.x == 0) {
-    blk_add(stats, 4, A.new_keys);
-    for (int i = 0; i < 4; i++) blk_add(stats, i, A.st[i]);
+  if (!inline_apply) {  // the usual way: k_delta_apply takes the records from here (and runs the round's candidate scan)
+    if (threadIdx.x == 0) {
+      blk_add(stats, 4, A.new_keys);
+      for (int i = 0; i < 4; i++) blk_add(stats, i, A.st[i]);
+      drec_n[blockIdx.x] = dn < drec_cap ? dn : drec_cap;
+    }
+    return;
   }
-  if (threadIdx.x == 0) drec_n[blockIdx.x] = dn < drec_cap ? dn : drec_cap;
+  // A small round (a few thousand sites): this workgroup puts its own records into the pair table -- they are in L2, the wait is short
+  // when the chip is nearly idle -- and the round's candidate scan rides in this launch: one kernel less on the round's critical path.
+  {
+    const unsigned int nd = dn < drec_cap ? dn : drec_cap;
+    for (unsigned int i = threadIdx.x; i < nd; i += WPB * 64) {
+      const DeltaRec rec = dout.recs[i];
+      global_emit(pt, db, rec.key, rec.delta, &A.new_keys);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      blk_add(stats, 4, A.new_keys);
+      for (int i = 0; i < 4; i++) blk_add(stats, i, A.st[i]);
+    }
+  }
+  {  // the candidate scan, by the last workgroup to get here (as in k_tiles); it also leaves the worklist's length at zero
+    __shared__ unsigned int is_last;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(sa.done_ctr, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (is_last) {
+      __threadfence();
+      if (threadIdx.x <= WL_PARTS + 1) const_cast<unsigned int *>(work_n)[threadIdx.x] = 0;  // (every workgroup has read it)
+      const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
+      scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
+    }
+  }
 }
 
 // The records of a word-mode round -> the pair table: region r (k_words' workgroup r) is shared by `parts` workgroups, one thread per
@@ -2956,7 +2989,7 @@ void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, hipStream_t st) {
 void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
                         uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules, const uint32_t *worklist, unsigned long long wl_seg,
                         const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, DeltaRec *drec, unsigned int drec_cap, unsigned int *drec_n,
-                        uint4 *irec, const BatchArgs *ba, const ScanArgs *scan, unsigned int work_hint, hipStream_t st) {
+                        uint4 *irec, const BatchArgs *ba, const ScanArgs *scan, unsigned int work_hint, unsigned int inline_max, hipStream_t st) {
   if (!ws.n_words) return;
   const BatchArgs bargs = ba ? *ba : BatchArgs{};
   const ScanArgs sargs = scan ? *scan : ScanArgs{};
@@ -2974,14 +3007,20 @@ void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &
   unsigned long long g = (items + APPLY_WPB - 1) / APPLY_WPB;
   if (g > gmax) g = gmax;
   if (g < 1) g = 1;
+  // a small round applies its records itself and carries the candidate scan (it needs that scan: its last workgroup resets the worklist)
+  const bool inl = worklist && work_hint && work_hint <= inline_max && sargs.on;
+  const ScanArgs none{};
   if (rule_mask < APPLY_LDS_RULES)
     hipLaunchKernelGGL((k_words<APPLY_WPB, true>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
-                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, wpi, bargs);
+                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, wpi, inl ? 1u : 0u, bargs, inl ? sargs : none);
   else
     hipLaunchKernelGGL((k_words<APPLY_WPB, false>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
-                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, wpi, bargs);
+                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, wpi, inl ? 1u : 0u, bargs, inl ? sargs : none);
+  if (inl) return;
   // the records -> the pair table, then the round's candidate scan (every workgroup owns a statistics row: at most BLK_ROWS of them)
-  const unsigned int parts = std::max(1u, std::min(8u, (unsigned int)BLK_ROWS / (unsigned int)g));
+  // (every workgroup takes a ticket at the end, ~12 ns each on one address: a small round gets a small grid)
+  const bool big = !worklist || !work_hint || work_hint > (1u << 17);
+  const unsigned int parts = std::max(1u, std::min(8u, (big ? (unsigned int)BLK_ROWS : 256u) / (unsigned int)g));
   hipLaunchKernelGGL(k_delta_apply, dim3((unsigned int)g * parts), dim3(DAPPLY_NT), 0, st, pt, db, (const DeltaRec *)drec, drec_cap, (const unsigned int *)drec_n, parts,
                      const_cast<unsigned int *>(work_n), stats, bargs.k ? (const RuleSlot *)nullptr : rules, rule_mask, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, bargs, sargs);
 }

@@ -133,7 +133,7 @@ void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &
                         uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules, const uint32_t *worklist /* nullptr: every word */, unsigned long long wl_seg,
                         const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, DeltaRec *drec /* [WORDS_MAX_GRID * drec_cap] */,
                         unsigned int drec_cap, unsigned int *drec_n /* [WORDS_MAX_GRID] */, uint4 *irec /* [WORDS_MAX_GRID * drec_cap] */, const BatchArgs *ba, const ScanArgs *scan, unsigned int work_hint,
-                        hipStream_t st);
+                        unsigned int inline_max /* rounds of at most this many words (by the hint) apply their records themselves */, hipStream_t st);
 constexpr unsigned int WORDS_MAX_GRID = 512;  // workgroups of k_words: each owns a region of the round's count-update records
 void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, unsigned int nom, unsigned long long total,
                    unsigned long long *gstart, unsigned int n_new, uint32_t *new_tok, uint32_t *new_len, uint32_t *new_word0, hipStream_t st);
