@@ -321,7 +321,9 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
     cfg = {"workload": f"{size_mb} MB {names[corpus]}, vocab_size={args.vocab}"
                        + (f", one file cut into {world} byte ranges" if ctx['strong'] else (f", {size_mb} MB per GPU" if world > 1 else "")),
            "corpus_bytes_total": total_bytes, "corpus_bytes_this_gpu": n_local, "vocab_size": args.vocab, "unique_words": r["n_unique"],
-           "dedup_tokens": r["n_tokens"], "merge_rounds": r["rounds"], "rules": r["rules"], "input": "resident in HBM before the timed region",
+           "dedup_tokens": r["n_tokens"], "merge_rounds": r["rounds"], "rules": r["rules"],
+           "rounds_closed_exhausted": r.get("rounds_exhausted"), "word_mode_from_round": r.get("word_switch_round") or None, "word_mode_rounds": r.get("word_rounds"),
+           "index_builds": r.get("index_builds"), "input": "resident in HBM before the timed region",
            "model_md5": model_md5, "pinned_model_md5": pin["model_md5"] if pin else None}
     if ctx["comm"] is not None:
         cfg["multi_gpu_mode"] = ("replicated merge loop: shards gathered once after the local dedup, every rank runs the merge loop alone, no per-round collective"
@@ -348,7 +350,7 @@ def _static_traffic(kern, corpus, size_mb, args, world):
     """HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, separate --pmc
     runs of this same command; tools/pmc_summary.py).  STATIC: read from profiles/, not measured by this run."""
     traffic = {}
-    for name in ("r2_1gb_pmc_hbm.json", "r1_1gb_final_pmc_hbm.json"):
+    for name in ("r3_1gb_pmc_hbm.json", "r2_1gb_pmc_hbm.json", "r1_1gb_final_pmc_hbm.json"):
         pmc_file = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc_file):
             break
@@ -362,8 +364,9 @@ def _static_traffic(kern, corpus, size_mb, args, world):
         if k.startswith("k_tiles<"):
             return "merge_apply" if k[len("k_tiles<"):].split(", ")[2] == "true" else "pair_count"
         for name, prefixes in (("char_hist", ("k_scan_bytes<0>",)), ("segments", ("k_scan_bytes<1>",)), ("dedup", ("k2b_insert_words",)),
-                               ("merge_apply", ("k_filter<", "k_giant<true")), ("pair_count", ("k_giant<false",)),
-                               ("cand_scan", ("k_hot_scan", "k_cand_scan", "k_top_scan", "k_top_rebuild", "k_hot_rebuild", "k_idx_", "k_gather"))):
+                               ("merge_apply", ("k_filter<", "k_giant<true", "k_words<", "k_delta_apply", "k_wgather", "k_gather", "k_round_begin")),
+                               ("pair_count", ("k_giant<false", "k_pair_count_dense")),
+                               ("cand_scan", ("k_hot_scan", "k_cand_scan", "k_top_scan", "k_top_rebuild", "k_hot_rebuild", "k_idx_", "k_words_init"))):
             if k.startswith(prefixes):
                 return name
         return None

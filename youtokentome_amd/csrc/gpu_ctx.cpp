@@ -1393,12 +1393,20 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
   tl_.rec_word = dmalloc<uint32_t>(tl_.log_cap);
   tl_.rec_l = dmalloc<uint32_t>(tl_.log_cap);
   tl_.rec_r = dmalloc<uint32_t>(tl_.log_cap);
-  tl_.broken = (unsigned int *)((unsigned char *)h_pin_ + 7168);  // (a free corner of the mailbox page: the kernels write it with system-scope stores)
+  tl_.broken = (unsigned int *)((unsigned char *)h_pin_ + PIN_BYTES - 64);  // (the last line of the pinned block -- behind the mailbox, the candidates' read-back
+                                                                            // area and the batch staging; the kernels write it with system-scope stores)
   *(volatile unsigned int *)tl_.broken = 0;
   word_mode_ = true;
   word_switch_round = merge_rounds;
   idx_valid_ = false;
   idx_pending_ = true;
+  // the hot list is relisted now, with word mode's larger target: the pair index built from it then serves some hundred rounds instead
+  // of the few dozen the current list has left (1 GB: the list of round 5 ran dry at round 78 -- a second index build of 38 M postings)
+  if (!multi()) {
+    rebuild_hot();
+    top_state_ = TOP_INVALID;
+    pt_.top_tau = ~0ull;
+  }
   if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] word mode from round %llu on: %llu words, last round %llu sites, %llu tokens streamed; log %llu records\n", merge_rounds,
                                   c.n_unique, sites_last_, live_tokens_last_, tl_.log_cap);
   build_index(z_next);
@@ -1691,10 +1699,11 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
         HIP_CHECK(hipMemsetAsync(d_stamp_, 0, (size_t)stamp_cap_ * 4, st_));
         ga.stamp = d_stamp_;
       }
-      launch_wgather(ga, by_args ? &ba : nullptr, st_);
+      const unsigned int work_hint = sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + 4096, 1ull << 30) : 0u;
+      launch_wgather(ga, by_args ? &ba : nullptr, work_hint, st_);
       const WordSet wset{c.d_tok, d_wmeta_, c.d_wcnt, (uint32_t)c.n_unique};
       launch_words_apply(wset, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, d_irec_, &ba,
-                         sa.on && last_cls == 0 ? &sa : nullptr, sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + 4096, 1ull << 30) : 0u, words_inline_max_, st_);
+                         sa.on && last_cls == 0 ? &sa : nullptr, work_hint, words_inline_max_, st_);
       word_rounds++;
       if (!idx_valid_) word_all_rounds++;
       continue;

@@ -2981,9 +2981,13 @@ void launch_words_init(const TileSet &ts, unsigned long long *wmeta, hipStream_t
   if (g > 256 * 8) g = 256 * 8;
   hipLaunchKernelGGL((k_words_init<TILE_SLOT_A>), dim3(g), dim3(BLOCK), 0, st, ts, wmeta);
 }
-void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, hipStream_t st) {
+void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, unsigned int work_hint, hipStream_t st) {
+  // every workgroup looks all the rules up and takes a ticket at the end: a small round (work_hint = about how many words it will visit;
+  // 0: unknown) gets a small grid
   static const char *g_env = getenv("YTTM_WGATHER_GRID");
-  const unsigned int g = g_env ? (unsigned int)atoi(g_env) : 256u;
+  unsigned int g = 256u;
+  if (work_hint) g = std::max(16u, std::min(256u, work_hint / 1024u));
+  if (g_env) g = (unsigned int)atoi(g_env);
   hipLaunchKernelGGL(k_wgather, dim3(g ? g : 1u), dim3(WG_NT), 0, st, a, ba ? *ba : BatchArgs{});
 }
 void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,

@@ -128,7 +128,7 @@ struct WGatherArgs {
   uint32_t k, z_base;
 };
 constexpr unsigned int WGATHER_MAXK = 4096;
-void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, hipStream_t st);
+void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, unsigned int work_hint, hipStream_t st);
 void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
                         uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules, const uint32_t *worklist /* nullptr: every word */, unsigned long long wl_seg,
                         const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, DeltaRec *drec /* [WORDS_MAX_GRID * drec_cap] */,
