@@ -1400,13 +1400,6 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
   word_switch_round = merge_rounds;
   idx_valid_ = false;
   idx_pending_ = true;
-  // the hot list is relisted now, with word mode's larger target: the pair index built from it then serves some hundred rounds instead
-  // of the few dozen the current list has left (1 GB: the list of round 5 ran dry at round 78 -- a second index build of 38 M postings)
-  if (!multi()) {
-    rebuild_hot();
-    top_state_ = TOP_INVALID;
-    pt_.top_tau = ~0ull;
-  }
   if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] word mode from round %llu on: %llu words, last round %llu sites, %llu tokens streamed; log %llu records\n", merge_rounds,
                                   c.n_unique, sites_last_, live_tokens_last_, tl_.log_cap);
   build_index(z_next);
