@@ -51,7 +51,8 @@ def md5_file(path):
 
 
 def pin_name(corpus, size_mb):
-    return {("abcd", 1000): "c2_1gb", ("abcd", 100): "c2_100mb", ("zipf", 1000): "c3_1gb", ("zipf", 100): "c3_100mb"}.get((corpus, size_mb))
+    return {("abcd", 1000): "c2_1gb", ("abcd", 100): "c2_100mb", ("zipf", 1000): "c3_1gb", ("zipf", 100): "c3_100mb",
+            ("cjk", 1000): "c6_cjk_1gb", ("cjk", 100): "c6_cjk_100mb", ("zipf4m", 1000): "c7_zipf4m_1gb"}.get((corpus, size_mb))
 
 
 def split_points(host, world):
@@ -97,6 +98,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the Zipf (configs[2]) block")
+    ap.add_argument("--no-extra2", action="store_true", help="skip the large-alphabet (CJK-shaped) and enwik-like (4e6-word lexicon) training blocks")
     ap.add_argument("--no-touched-pass", action="store_true", help="skip the untimed K4 measurement pass (profiling runs: one training per process)")
     ap.add_argument("--cpu-sample-mb", type=int, default=0, help="0 = the full corpus")
     ap.add_argument("--cpu-runs", type=int, default=3, help="runs of the reference's train_bpe per corpus (the median is reported)")
@@ -195,6 +197,15 @@ def main():
         if world == 1 and not args.no_encode and zhost is not None:
             # natural-language-like sentences: the corpus' own lines (16 Zipf words each) through K5 with the model just trained
             out["extra"]["zipf"]["encode"] = _bench_encode_lines(ctx, z["model_path"], zhost)
+        # ---- a large alphabet and an enwik-like word table: train only, pinned against the reference by make_full_pins.py
+        if world == 1 and not args.no_extra2:
+            for name in ("cjk", "zipf4m"):
+                x = _bench_train(ctx, name, args.size_mb, min(args.steps, 2), 1, measure_touched=False, keep_host=False)
+                out["extra"][name] = {"metric": "bpe_train_throughput", "value": x["value"], "unit": "MB/s", "ms_per_step": x["ms_per_step"], "config": x["config"],
+                                      "us_per_round": round(x["ms_per_step"] * 1e3 / max(1, x["config"]["merge_rounds"]), 2), "kernels": x["kernels"],
+                                      "phases_s": x["phases_s"]}
+                out["parity"][name + "_corpus_md5_matches"] = x["corpus_ok"]
+                out["parity"][name + "_model_matches_reference"] = x["model_ok"]
     else:
         zhost = None
 
@@ -222,6 +233,10 @@ def _make_corpus(ctx, corpus, size_mb):
     seed_off = 0 if shared else rank
     if corpus == "abcd":
         host = gen.abcd_corpus(nbytes, seed=19 + seed_off, survey_stream=True)  # SURVEY.md Appendix C gen_abcd: C2 byte for byte
+    elif corpus == "cjk":  # large alphabet: 4096 ideographs, space-free clauses (the reference's slowest published cases, benchmark.md:23,39)
+        host = gen.cjk_corpus_fast(nbytes, seed=11 + seed_off)
+    elif corpus == "zipf4m":  # enwik-like: 4e6-word lexicon, exponent 1.0 (U ~ 2-3e6)
+        host = gen.zipf_corpus_fast(nbytes, seed=7 + seed_off, vocab=4_000_000, exponent=1.0)
     else:
         host = gen.zipf_corpus_fast(nbytes, seed=7 + seed_off, vocab=400000)
     pin = ctx["pins"].get(pin_name(corpus, size_mb)) if shared and args.vocab == 32000 else None
@@ -317,7 +332,8 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
                        "unit": "GB/s", "frac": round(kern["pair_count"]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic.get("pair_count"),
                        "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(kern["pair_count"]["algorithmic_GB"] * 1e9),
                        "avg_launch_ms": kern["pair_count"]["avg_ms"]}
-    names = {"abcd": "random 'abcd ' corpus (BASELINE.json configs[1])", "zipf": "Zipf ASCII corpus, 400k-word lexicon (BASELINE.json configs[2])"}
+    names = {"abcd": "random 'abcd ' corpus (BASELINE.json configs[1])", "zipf": "Zipf ASCII corpus, 400k-word lexicon (BASELINE.json configs[2])",
+             "cjk": "CJK-shaped corpus (4096 ideographs, clauses without spaces)", "zipf4m": "Zipf ASCII corpus, 4e6-word lexicon, exponent 1.0 (enwik-like)"}
     cfg = {"workload": f"{size_mb} MB {names[corpus]}, vocab_size={args.vocab}"
                        + (f", one file cut into {world} byte ranges" if ctx['strong'] else (f", {size_mb} MB per GPU" if world > 1 else "")),
            "corpus_bytes_total": total_bytes, "corpus_bytes_this_gpu": n_local, "vocab_size": args.vocab, "unique_words": r["n_unique"],

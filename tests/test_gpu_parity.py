@@ -107,6 +107,58 @@ def test_k4_worklist_mode(tmp_path, monkeypatch):
     S.check_train_vs_oracle(gen.zipf_corpus(2_000_000, seed=3, vocab=30000), 4000, tmp_path, tag="wl")
 
 
+def test_k4_word_mode(tmp_path, monkeypatch):
+    """Word mode (k_wgather + k_words + k_delta_apply) forced on from the second round whatever the corpus size: golden
+    corpora, random text of three scripts and a Zipf corpus against the oracle; then with tiny hot lists (index rebuilds, rounds over
+    every word), overflowing record regions and record log; then the 100 MB pins of configs[1] and of the CJK-shaped corpus with the
+    default switch rule (only the size floor lifted), single GPU and through an RCCL communicator of one rank."""
+    import ctypes as C
+    import hashlib
+    import json
+    from youtokentome_amd import _lib
+    L = _lib.load()
+    for k in ("YTTM_WORD_MIN_TILES", "YTTM_WORD_MIN_TOKENS", "YTTM_WORD_DIV"):
+        monkeypatch.setenv(k, "0")
+    rng = random.Random(5)
+    for cfg in (None, {"YTTM_HOT_TARGET": 40, "YTTM_HOT_MIN": 4, "YTTM_HOT_CAP": 400, "YTTM_WORD_DREC": 64, "YTTM_INDEX_AGG_MIN": 0},
+                {"YTTM_WORD_LOG": 3000, "YTTM_WORDS_INLINE_MAX": 0}):
+        for k, v in (cfg or {}).items():
+            monkeypatch.setenv(k, str(v))
+        for name in ("readme_small", "runs", "mix_cov", "zipf"):
+            S.check_golden_train(name, tmp_path)
+        S.check_train_vs_oracle(gen.zipf_corpus(2_000_000, seed=3, vocab=30000), 4000, tmp_path, tag="wm")
+        for kind in ("ascii", "cyr", "cjk"):
+            S.check_train_vs_oracle(gen.unicode_text(rng, 300000, kind), 1500, tmp_path, tag="wm" + kind)
+        S.check_train_vs_oracle(gen.readme_corpus(3000, 100, seed=2), 3000, tmp_path, tag="wmr")
+        for k in (cfg or {}):
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("YTTM_WORD_DIV", "200")
+    pins = _full_pins()
+    err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+    idbuf = (C.c_uint8 * 128)()
+    assert L.yttm_comm_rccl_unique_id(idbuf) == 0
+    comm = C.c_void_p()
+    assert L.yttm_comm_rccl_create(idbuf, 0, 1, 0, C.byref(comm)) == 0
+    try:
+        for pin_name, text in (("c2_100mb", gen.abcd_corpus(100_000_000, seed=19, survey_stream=True)), ("c6_cjk_100mb", gen.cjk_corpus_fast(100_000_000, seed=11))):
+            pin = pins[pin_name]
+            text = text[:pin["corpus_bytes"]]
+            assert hashlib.md5(text).hexdigest() == pin["corpus_md5"], pin_name
+            corpus, model = str(tmp_path / "wm.txt"), str(tmp_path / "wm.model")
+            open(corpus, "wb").write(text)
+            rc = L.yttm_train_bpe_ex(corpus.encode(), model.encode(), 32000, 1.0, 1, 0, 1, 2, 3, 0, rep, 16384, err, 2048)
+            assert rc == 0, err.value
+            r = json.loads(rep.value.decode())
+            assert r["word_rounds"] > 100 and r["word_all_rounds"] == 0, (pin_name, r["word_rounds"], r["word_all_rounds"])
+            assert hashlib.md5(open(model, "rb").read()).hexdigest() == pin["model_md5"], pin_name
+            rc = L.yttm_train_bpe_from_memory_comm(text, len(text), model.encode(), 32000, 1.0, 0, 1, 2, 3, 0, comm, rep, 16384, err, 2048)
+            assert rc == 0, err.value
+            assert json.loads(rep.value.decode())["word_rounds"] > 100
+            assert hashlib.md5(open(model, "rb").read()).hexdigest() == pin["model_md5"], pin_name + " (RCCL)"
+    finally:
+        L.yttm_comm_destroy(comm)
+
+
 @pytest.mark.parametrize("name", S.golden_train_names())
 def test_golden_train(name, tmp_path):
     S.check_golden_train(name, tmp_path)

@@ -369,6 +369,7 @@ def test_word_mode(tmp_path, monkeypatch):
     import oracle_lib as O
     L = _lib.load()
     monkeypatch.setenv("YTTM_WORD_MIN_TILES", "0")
+    monkeypatch.setenv("YTTM_WORD_MIN_TOKENS", "0")
     monkeypatch.setenv("YTTM_WORD_DIV", "0")
     rng = random.Random(78)
     cases = [(gen.readme_corpus(300, 100, seed=6), 900), (gen.zipf_corpus(120000, vocab=3000), 700),

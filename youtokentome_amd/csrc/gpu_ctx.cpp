@@ -179,6 +179,9 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end, worklists of tiles from the pair index)
   word_div_ = env_uint("YTTM_WORD_DIV", 200);  // (measured at 1 GB: 96 -> K4 135 ms, 150 -> 107, 200 -> 103.7, 300 -> 103.7, 500 -> 104)
   word_min_tiles_ = env_uint("YTTM_WORD_MIN_TILES", 16384);  // (tests: 0 = switch as soon as the hot list is active)
+  // a pass over the tiles must cost more than word mode's three launches: 1 GB enwik-like text (25 M tokens, 48 us per dense round) got 15 % slower
+  // in word mode, the 1 GB CJK-shaped corpus (337 M tokens) 21 % faster, random 'abcd ' (94 M tokens at the switch) 10 % faster
+  word_min_tokens_ = (unsigned long long)env_uint("YTTM_WORD_MIN_TOKENS", 48u << 20);
   bloom_mode_ = true;  // (the per-token flag variant of k_tiles is gone; the flag tables still serve the separate filter pass, YTTM_DENSE_PCT)
   gather_grid_ = env_uint("YTTM_GATHER_GRID", 0) != 0;  // (measured at 1 GB: 65.6 vs 62.7 us per late round -- the smaller grid is not faster)
   no_batch_args_ = getenv("YTTM_NO_BATCH_ARGS") != nullptr;  // (read once per context: a round has no time for getenv)
@@ -1526,7 +1529,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // and once in a while not: a streamed round refreshes the live-token count the repack trigger needs.
   // word mode: on when the last round's merge sites are few against the tokens a pass over the tiles streams (and then for good)
   if (!word_mode_ && words_enabled_ && idx_enabled_ && !instrument && cls_[0].n_tiles >= word_min_tiles_ && cls_[0].n_tiles && hot_state_ == HOT_ACTIVE &&
-      dense_pct_ < 1000 && sites_last_ != ~0ull && live_tokens_last_ &&
+      dense_pct_ < 1000 && sites_last_ != ~0ull && live_tokens_last_ && live_tokens_last_ >= word_min_tokens_ &&
       (word_div_ == 0 || sites_last_ * (unsigned long long)word_div_ < live_tokens_last_))
     enter_word_mode(z_base);
   if (word_mode_) {

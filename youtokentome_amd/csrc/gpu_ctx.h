@@ -200,7 +200,7 @@ class GpuCtx {
   unsigned int hot_target_words_ = 1u << 15, words_inline_max_ = 1u << 16;
   unsigned int word_div_ = 200;    // switch when (merge sites of the last round) * word_div_ < (tokens a pass over the tiles streams)
   unsigned int word_min_tiles_ = 16384;
-  unsigned long long idx_agg_min_ = 16ull << 20;
+  unsigned long long idx_agg_min_ = 16ull << 20, word_min_tokens_ = 48ull << 20;
   unsigned long long *d_wmeta_ = nullptr;
   unsigned int *d_gm_ = nullptr;   // [WGATHER_MAXK] + the gather's ticket
   uint32_t *d_xyz_ = nullptr;      // a batch too large for BatchArgs, as (x, y, z) triples
