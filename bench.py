@@ -285,6 +285,13 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
         ctx["barrier"]()
         dt = time.perf_counter() - t0
         touched = train_step(2) if measure_touched else None  # measurement pass, outside the timed region
+        ev_rep = None
+        if measure_touched and ctx["comm"] is None:  # the same step timed with HIP events around every merge round (cross-check, not timed)
+            os.environ["YTTM_PROFILE_EVENTS"] = "1"
+            try:
+                ev_rep = train_step(1)
+            finally:
+                del os.environ["YTTM_PROFILE_EVENTS"]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -306,7 +313,14 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic.get(dom), "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(kern[dom]["algorithmic_GB"] * 1e9 / kern[dom]["launches"]),
-                    "avg_launch_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"]}
+                    "avg_launch_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"],
+                    "duration_source": "merge rounds whose candidate scan rides in their last kernel (all but a few of a single-GPU training): the device's 100 MHz clock, "
+                                       "first workgroup of the round's first launch -> mailbox published, read from the mailbox every round in the timed region; "
+                                       "every other launch: HIP events on the context's stream"}
+        if ev_rep is not None and ev_rep["kernels"].get(dom, {}).get("launches"):
+            e = ev_rep["kernels"][dom]
+            roofline["avg_launch_ms_hip_events"] = round(e["ms"] / e["launches"], 4)
+            roofline["hip_events_note"] = "one more step outside the timed region with YTTM_PROFILE_EVENTS=1: a hipEventRecord before the round's first launch and one after its last (the interval also holds the launch latency of the first kernel)"
         if dom == "merge_apply":
             # The contract's algorithmic bytes for K4: 8*T_touched + 8*W_touched, "touched" = the WORDS that held a
             # merge site, counted by the untimed measurement pass.  What the kernel actually streams -- every live token once,

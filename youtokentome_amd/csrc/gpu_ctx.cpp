@@ -175,7 +175,8 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   use_pm_ = env_uint("YTTM_K4_PM", 0) != 0;
   idx_agg_min_ = env_uint("YTTM_INDEX_AGG_MIN", 16u << 20);  // (fill pass of an index build: postings from which on a workgroup sums them per key in LDS first; tests: 0)
   hot_target_words_ = env_uint("YTTM_HOT_TARGET_WORDS", 1u << 15);  // (measured at 1 GB, word mode: 8192 -> 6 rebuilds, candidate family 21.0 ms; 32768 -> 3, 16.9 ms)
-  words_inline_max_ = env_uint("YTTM_WORDS_INLINE_MAX", 1u << 16);
+  words_inline_max_ = env_uint("YTTM_WORDS_INLINE_MAX", 1u << 18);  // (measured at 1 GB, K4 ms: 16 k -> 97.2, 64 k -> 95.4, 256 k -> 94.1)
+  profile_events_ = env_uint("YTTM_PROFILE_EVENTS", 0) != 0;
   words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end, worklists of tiles from the pair index)
   word_div_ = env_uint("YTTM_WORD_DIV", 200);  // (measured at 1 GB: 96 -> K4 135 ms, 150 -> 107, 200 -> 103.7, 300 -> 103.7, 500 -> 104)
   word_min_tiles_ = env_uint("YTTM_WORD_MIN_TILES", 16384);  // (tests: 0 = switch as soon as the hot list is active)
@@ -306,6 +307,9 @@ void GpuCtx::resolve_timers() {
     if (trace) fprintf(trace, "%d %.4f\n", e.which, ms);
   }
   evs_.clear();
+  if (trace)  // (rounds timed by the device: already in kt.ms; listed after the event-timed ones -- nearly every round of a single-GPU training)
+    for (float ms : dev_round_ms_) fprintf(trace, "%d %.4f\n", (int)KT_MERGE, ms);
+  dev_round_ms_.clear();
   {
     std::lock_guard<std::mutex> g(g_pool.mu);
     g_event_pool.insert(g_event_pool.end(), all_events_.begin(), all_events_.end());
@@ -1282,6 +1286,11 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
       top_over = top_listed > top_cap_;
       if (use_fused) {
         fused_rounds++;
+        if (dev_timing_pending_) {  // the round's duration by the device's 100 MHz clock (merge_apply: dev_timing)
+          const double ms = (double)*(const unsigned long long *)(h + 24) * 1e-5;
+          kt.ms[KT_MERGE] += ms;
+          dev_round_ms_.push_back((float)ms);
+        }
         const unsigned long long *tmk = (const unsigned long long *)(h + 96);  // scan_top's marks (100 MHz wall clock)
         tail_ticks[0] += tmk[1] - tmk[0];
         tail_ticks[1] += tmk[2] - tmk[1];
@@ -1644,7 +1653,19 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     fused_mx_ = next_tau_mx;
     fused_round_ = sa.round_id;
   }
-  t_begin(KT_MERGE);
+  // A fused round is timed by the device itself (its first launch notes the time, the tail reports the difference in the mailbox):
+  // no hipEventRecord on the round's critical path (two per round were 4 us of host time: 8 % of a Zipf step).  YTTM_PROFILE_EVENTS=1
+  // keeps the events (cross-check).
+  const bool dev_timing = profile && sa.on && !profile_events_ && !gathered && !pm;  // (k_gather / k_apply_pm do not carry the mark)
+  bool marked = false;
+  auto first_ba = [&]() {  // the BatchArgs of the round's next launch: the first one carries the mark
+    BatchArgs b = ba;
+    if (dev_timing && !marked) { b.mark = 1u; marked = true; }
+    return b;
+  };
+  sa.timed = dev_timing ? 1u : 0u;
+  dev_timing_pending_ = dev_timing;
+  if (!dev_timing) t_begin(KT_MERGE);
   if (!by_args) {
     uint32_t *h_bloom = nullptr;
     if (bloom_mode_ || (pm && cap > 512 && cls_[0].n_tiles)) {  // the batch's pair filter for the apply kernels (built here: a few hundred hashes)
@@ -1696,7 +1717,9 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
         ga.stamp = d_stamp_;
       }
       const unsigned int work_hint = sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + 4096, 1ull << 30) : 0u;
-      launch_wgather(ga, by_args ? &ba : nullptr, work_hint, st_);
+      ga.stats = d_stats_;
+      const BatchArgs gba = first_ba();
+      launch_wgather(ga, &gba, work_hint, st_);
       const WordSet wset{c.d_tok, d_wmeta_, c.d_wcnt, (uint32_t)c.n_unique};
       launch_words_apply(wset, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, d_irec_, &ba,
                          sa.on && last_cls == 0 ? &sa : nullptr, work_hint, words_inline_max_, st_);
@@ -1712,13 +1735,15 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
                       cls_[0].d_work_n, d_stats_, &ba, sa.on && last_cls == 0 ? &sa : nullptr, eager_w, st_);
       continue;
     }
+    const BatchArgs tba = first_ba();
     launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
                        cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/!wl_gathered && (by_args || dense_class(ci)),
-                       &ba, ci == last_cls && sa.on ? &sa : nullptr, wl_gathered,
+                       &tba, ci == last_cls && sa.on ? &sa : nullptr, wl_gathered,
                        gather_grid_ && touched_last_ < (1ull << 30) ? (unsigned int)(2 * touched_last_) : 0u, d_bloom_, st_);
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
-  t_end(KT_MERGE, 0, /*chain=*/!sa.on);  // (a fused round is followed by the host's turn, not by another kernel: its end event must not start the next interval)
+  if (dev_timing) kt.launches[KT_MERGE]++;
+  else t_end(KT_MERGE, 0, /*chain=*/!sa.on);  // (a fused round is followed by the host's turn, not by another kernel: its end event must not start the next interval)
   merge_rounds++;
   const char *trace_rounds = trace_rounds_;
   if (trace_rounds) {

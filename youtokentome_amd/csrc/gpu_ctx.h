@@ -196,8 +196,10 @@ class GpuCtx {
   void build_index(uint32_t z_next);
   void free_index();
   // word mode (k_merge.hip: k_words): class-A words processed one by one from a worklist of the words that hold a merge site
+  bool profile_events_ = false, dev_timing_pending_ = false;  // (merge_apply: dev_timing)
+  std::vector<float> dev_round_ms_;
   bool word_mode_ = false, words_enabled_ = true;
-  unsigned int hot_target_words_ = 1u << 15, words_inline_max_ = 1u << 16;
+  unsigned int hot_target_words_ = 1u << 15, words_inline_max_ = 1u << 18;
   unsigned int word_div_ = 200;    // switch when (merge sites of the last round) * word_div_ < (tokens a pass over the tiles streams)
   unsigned int word_min_tiles_ = 16384;
   unsigned long long idx_agg_min_ = 16ull << 20, word_min_tokens_ = 48ull << 20;

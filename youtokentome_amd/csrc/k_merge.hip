@@ -950,6 +950,8 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
 #ifdef YTTM_K4_PROF
   const unsigned long long wall0_ = wall_clock64();
 #endif
+  if (MERGE && ba.mark && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(&stats[STAT_T0], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const bool from_args = MERGE && LDSR && ba.k != 0;  // tables built from the kernel argument, nothing read from HBM
   agg_init<WPB * 64>(A, (MERGE && !from_args) ? flagbits : nullptr);
   if (from_args) {
@@ -1578,7 +1580,7 @@ __global__ __launch_bounds__(BLOCK) void k_publish_box(const unsigned char *__re
                                                        uint32_t round_id, unsigned long long *__restrict__ xstat) {
   const unsigned int *bh = reinterpret_cast<const unsigned int *>(box);
   unsigned int *mh = reinterpret_cast<unsigned int *>(mailbox);
-  if (threadIdx.x < 6) mh[threadIdx.x] = bh[threadIdx.x];
+  if (threadIdx.x < 8) mh[threadIdx.x] = bh[threadIdx.x];  // (header; [24..31]: the round's duration on the device)
   if (threadIdx.x >= 10 && threadIdx.x < 14) mh[threadIdx.x] = bh[threadIdx.x];  // bytes 40..55
   if (threadIdx.x >= 6 && threadIdx.x < 10) {
     const int k = (int)threadIdx.x - 6;
@@ -2033,6 +2035,8 @@ __global__ __launch_bounds__(WG_NT) void k_wgather(WGatherArgs g, BatchArgs ba) 
   __shared__ unsigned long long s_wsum[WG_NT / 64];
   __shared__ unsigned int s_n, s_gbase, s_last;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (ba.mark && blockIdx.x == 0 && tid == 0)
+    __hip_atomic_store(&g.stats[STAT_T0], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t k = g.k;
   const PairIndex ix{g.ix.key, g.ix.cnt, g.ix.off, g.ix.bloom, g.ix.post, g.ix.mask};
   if (tid == 0) s_n = 0;

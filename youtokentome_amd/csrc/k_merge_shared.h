@@ -121,7 +121,7 @@ __device__ inline int cand_bin(unsigned long long c) {
 //      block in HBM that k_publish_box forwards after the ranks' all-reduce.
 //   3. last, off the critical path: the per-workgroup statistics rows are folded into the totals and the key count
 // Box layout: [0] candidates, [4] keys in the table, [8] top-list entries before the scan, [12] of those still >= top_tau,
-// [16] hot-list entries (overflow check), [88] merge sites so far, [32] round id, [40] tokens streamed so far, [48] tiles with a site so far, [56..87]
+// [16] hot-list entries (overflow check), [24] the round's duration on the device (ScanArgs::timed), [88] merge sites so far, [32] round id, [40] tokens streamed so far, [48] tiles with a site so far, [56..87]
 // xstat (multi-GPU), [96..127] timing marks (100 MHz), [MB_HIST..) histogram, [8192..) candidates.
 // lds = at least (CAND_BINS + 80) words of scratch (the apply kernel's tile buffers are free by now).
 template <int NT>
@@ -230,6 +230,7 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
     hdr[4] = hot_raw;
     hdr[5] = ctl[3];  // the host reads the histogram from here down (every line of the pinned mailbox it touches is a cache miss)
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 88) = stats[0];  // merge sites so far (word-mode switch)
+    *reinterpret_cast<unsigned long long *>(sa.mailbox + 24) = sa.timed ? (unsigned long long)wall_clock64() - ld_agent(&stats[STAT_T0]) : 0ull;  // the round on the device
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 40) = stats[2];  // tokens streamed so far (repack trigger)
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 48) = stats[1];  // tiles that held a merge site so far
     if (!overflow) *pt.top_n = ctl[0];

@@ -59,6 +59,8 @@ struct BatchArgs {
   uint32_t small_ids;                // every token id in the tiles is < FLAG_LDS_IDS: the kernels skip the test for ids behind the LDS bitmap
   uint32_t bloom;                    // k_tiles<.., true>: merge-site candidates by the batch's PAIR filter (k_merge_shared.h pm_hash; built in the kernel
                                      // from xy, or copied from the table `flagbits` then points to) instead of per-token x / y flags
+  uint32_t mark;                     // this is the round's first launch: workgroup 0 notes the time in stats[STAT_T0] (the round's duration then
+                                     // comes from the device's own clock, ScanArgs::timed -- two hipEventRecord calls per round cost 4 us of host time)
   uint32_t instr;                    // measurement pass (never timed): also count the WORDS that hold a merge site and their tokens
                                      // (T_touched, W_touched) into stats[4], stats[5]; single-site tiles take the general path
 };
@@ -74,7 +76,9 @@ struct ScanArgs {
   unsigned int *done_ctr;      // ticket of finished workgroups (left at 0); nullptr: a single-workgroup launch
   unsigned char *mailbox;      // the host's pinned mailbox, or (round_id == 0) a staging block in HBM with the same layout
   uint32_t round_id;           // published in the mailbox when everything else is there; 0: nothing is published
+  uint32_t timed;              // the round's first launch left its start time in stats[STAT_T0]: the mailbox gets the duration (100 MHz ticks)
 };
+constexpr int STAT_T0 = 6;  // stats[6]: wall_clock64() at the start of the round's first launch
 void launch_top_scan(const PairTable &pt, const ScanArgs &sa, unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself,
                      const BatchArgs *zba, unsigned long long *xstat, hipStream_t st);
 void launch_top_rebuild(const PairTable &pt, unsigned int listed_hint, hipStream_t st);
@@ -124,6 +128,7 @@ struct WGatherArgs {
   unsigned int *work_n;
   unsigned int *gm;              // [WGATHER_MAXK] records matched per rule (left at zero)
   unsigned int *done_ctr;
+  unsigned long long *stats;     // (BatchArgs::mark)
   const uint32_t *xyz;           // rule j = (xyz[3j], xyz[3j+1]) -> z_base + j, in HBM; nullptr: the batch is in the BatchArgs
   uint32_t k, z_base;
 };
