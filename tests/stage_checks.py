@@ -387,11 +387,16 @@ def check_dropout_heap_equals_array(model="readme_small", seed=29):
         os.environ["YTTM_DROPOUT_SEED"] = "12345"
         for p in (0.0, 0.1, 0.5, 0.9, 1.0):
             got = []
-            for heap_from in ("1000000000", "0", "256"):
+            for heap_from, hbm in (("1000000000", False), ("0", False), ("256", False), ("256", True), ("0", True)):
                 os.environ["YTTM_DROPOUT_HEAP_FROM"] = heap_from
+                if hbm:  # every event queue in the HBM scratch (default: sentences that fit the wave's LDS arrays keep theirs in LDS, packed)
+                    os.environ["YTTM_DROPOUT_HBM_QUEUES"] = "1"
+                else:
+                    os.environ.pop("YTTM_DROPOUT_HBM_QUEUES", None)
                 bpe = yttm.BPE(model_path)  # (a fresh encoder: the draws are numbered per encoder and call)
                 got.append(bpe.encode(sents, yttm.OutputType.ID, dropout_prob=p))
-            assert got[0] == got[1] == got[2], p
+            os.environ.pop("YTTM_DROPOUT_HBM_QUEUES", None)
+            assert all(g == got[0] for g in got), p
         os.environ["YTTM_DROPOUT_HEAP_FROM"] = "256"
         bpe = yttm.BPE(model_path)
         t0 = time.time()

@@ -184,6 +184,7 @@ BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *
     m.rule_z = dev_->d_rule_z;
     m.rule_xy = dev_->d_rule_xy;
     m.rule_mask = cap - 1;
+    m.n_rules = (uint32_t)nr;
     {  // merged tokens are numbered in rule order with the special ids skipped (bpe.cpp:814-837): z(r) without a load
       m.z_affine = nr > 0;
       m.z_base = nr ? rz[0] : 0;

@@ -80,6 +80,7 @@ struct DropoutArgs {
   unsigned long long seed;
   int enabled, always_skip;
   int heap_from;            // words of at least this many tokens keep their events in a binary heap instead of a sorted array
+  int lds_queues;           // packs of up to ENC_DROP_WCAP tokens keep their event queues in LDS (EvLds)
   uint32_t *wsl;            // [cap] word start positions
   unsigned long long *ev;   // [3*cap] sorted event queues, word w owns [3*ws, 3*we)
 };
@@ -90,43 +91,77 @@ __device__ inline bool drop_skip(const DropoutArgs &d, unsigned long long sidx, 
   return r < d.thr;
 }
 
-template <class A>
-__device__ inline void ev_insert(unsigned long long *ev, int &ne, unsigned long long key) {
+// Where a word's event queue lives.  Sentences that fit the wavefront's LDS arrays (the common case) keep it in LDS, an event packed into
+// 32 bits (rule index << 9 | position: positions are below 512 there; EncModel: fewer than 2^23 rules) -- the queue in HBM made every
+// insertion, shift and pop a chain of dependent global round trips (10^7 sentences of 128 chars: 381 ms against 62 ms without dropout).
+// Long sentences (HBM working arrays) keep 64-bit events in the per-wave HBM scratch.  Same order of pops either way.
+struct EvGlb {
+  unsigned long long *p;
+  __device__ unsigned long long get(int i) const { return p[i]; }
+  __device__ void set(int i, unsigned long long v) const { p[i] = v; }
+  __device__ EvGlb at(size_t off) const { return EvGlb{p + off}; }
+};
+struct EvLds {
+  uint32_t *p;
+  __device__ unsigned long long get(int i) const {
+    const uint32_t v = p[i];
+    return ((unsigned long long)(v >> 9) << 32) | (unsigned long long)(v & 511u);
+  }
+  __device__ void set(int i, unsigned long long v) const { p[i] = ((uint32_t)(v >> 32) << 9) | ((uint32_t)v & 511u); }
+  __device__ EvLds at(size_t off) const { return EvLds{p + off}; }
+};
+constexpr int ENC_DROP_WCAP = 256;  // dropout: tokens of a pack whose event queues fit the wave's LDS share (3 events per token)
+
+template <class Q>
+__device__ inline void ev_insert(const Q &ev, int &ne, unsigned long long key) {
   int j = ne++;
-  while (j > 0 && ev[j - 1] > key) { ev[j] = ev[j - 1]; j--; }
-  ev[j] = key;
+  while (j > 0) {
+    const unsigned long long prev = ev.get(j - 1);
+    if (prev <= key) break;
+    ev.set(j, prev);
+    j--;
+  }
+  ev.set(j, key);
 }
 
 // The same queue as a binary min-heap, for long words: the sorted array costs O(queue) per insertion and removal -- a single word of
 // 80 000 chars (a base64 blob in the input) kept one lane busy for minutes.  Pops come in the same ascending order, so the draws
 // and the result are those of the array (DropoutQueue itself is a std::priority_queue plus the skipped events, bpe.cpp:1417-1453).
-__device__ inline void heap_push(unsigned long long *ev, int &nh, unsigned long long key) {
+template <class Q>
+__device__ inline void heap_push(const Q &ev, int &nh, unsigned long long key) {
   int i = nh++;
   while (i > 0) {
     const int p = (i - 1) >> 1;
-    if (ev[p] <= key) break;
-    ev[i] = ev[p];
+    const unsigned long long pv = ev.get(p);
+    if (pv <= key) break;
+    ev.set(i, pv);
     i = p;
   }
-  ev[i] = key;
+  ev.set(i, key);
 }
-__device__ inline unsigned long long heap_pop(unsigned long long *ev, int &nh) {
-  const unsigned long long top = ev[0], last = ev[--nh];
+template <class Q>
+__device__ inline unsigned long long heap_pop(const Q &ev, int &nh) {
+  const unsigned long long top = ev.get(0), last = ev.get(--nh);
   int i = 0;
   for (;;) {
     int c = 2 * i + 1;
     if (c >= nh) break;
-    if (c + 1 < nh && ev[c + 1] < ev[c]) c++;
-    if (ev[c] >= last) break;
-    ev[i] = ev[c];
+    unsigned long long cv = ev.get(c);
+    if (c + 1 < nh) {
+      const unsigned long long c1 = ev.get(c + 1);
+      if (c1 < cv) { c++; cv = c1; }
+    }
+    if (cv >= last) break;
+    ev.set(i, cv);
     i = c;
   }
-  if (nh > 0) ev[i] = last;
+  if (nh > 0) ev.set(i, last);
   return top;
 }
 
-template <class A>
-__device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev*/, int n, const DropoutArgs &d, unsigned long long sidx) {
+template <class A, class WS, class Q>
+__device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev*/, int n, const DropoutArgs &d, unsigned long long sidx,
+                             WS wsl /* [words] word start positions */, Q evq /* [3 * tokens] the words' event queues, word w owns [3 ws, 3 we) */) {
   const int lane = lane_id();
   const unsigned long long lt = lanemask_lt();
   constexpr uint32_t DEAD = 0xffffffffu, NIL = 0xffffffffu;
@@ -136,15 +171,14 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
     const int p = c * 64 + lane;
     const bool ws = p < n && (wt.get(p) & TOK_WS);
     const unsigned long long W = __ballot(ws);
-    if (ws) d.wsl[nw + __popcll(W & lt)] = (uint32_t)p;
+    if (ws) wsl.set(nw + __popcll(W & lt), (uint32_t)p);
     nw += __popcll(W);
   }
   wave_sync();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
   for (int w = lane; w < nw; w += 64) {
-    const int ws = (int)__hip_atomic_load(&d.wsl[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int we = w + 1 < nw ? (int)__hip_atomic_load(&d.wsl[w + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n;
-    unsigned long long *ev = d.ev + 3 * (size_t)ws;
+    const int ws = (int)wsl.get(w);
+    const int we = w + 1 < nw ? (int)wsl.get(w + 1) : n;
+    const Q ev = evq.at(3 * (size_t)ws);
     const int cap = 3 * (we - ws);             // the word's share of the queue space: every event it can ever hold
     const bool heap = we - ws >= d.heap_from;  // (skipped events of a pop wait at the top end of that space)
     int ne = 0;
@@ -154,7 +188,7 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
     }
     auto add = [&](unsigned long long key) {
       if (heap) heap_push(ev, ne, key);
-      else ev_insert<A>(ev, ne, key);
+      else ev_insert(ev, ne, key);
     };
     for (int i = ws; i + 1 < we; i++) {  // bpe.cpp:1556-1558
       const uint32_t slot = enc_rule_lookup(m, wt.get(i) & ENC_IDM, wt.get(i + 1) & ENC_IDM);
@@ -169,10 +203,10 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
         while (ne > 0) {
           e = heap_pop(ev, ne);
           if (!drop_skip(d, sidx, (uint32_t)w, draw++)) { found = true; break; }
-          ev[cap - 1 - ns] = e;
+          ev.set(cap - 1 - ns, e);
           ns++;
         }
-        for (int k = 0; k < ns; k++) heap_push(ev, ne, ev[cap - 1 - k]);
+        for (int k = 0; k < ns; k++) heap_push(ev, ne, ev.get(cap - 1 - k));
         if (!found) break;
       } else {
         int acc = -1;
@@ -180,8 +214,8 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
           if (!drop_skip(d, sidx, (uint32_t)w, draw++)) { acc = j; break; }
         }
         if (acc < 0) break;  // every event skipped: the word is finished (bpe.cpp:1431-1437)
-        e = ev[acc];
-        for (int j = acc; j + 1 < ne; j++) ev[j] = ev[j + 1];
+        e = ev.get(acc);
+        for (int j = acc; j + 1 < ne; j++) ev.set(j, ev.get(j + 1));
         ne--;
       }
       const uint32_t rule = (uint32_t)(e >> 32);
@@ -415,7 +449,7 @@ __device__ void encode_wave(const EncModel &m, const uint32_t *bloom, const uint
   int n = enc_tokenize<A>(m, s, nbytes, wt, 0);
   wave_sync();
   // ---- B. merge rounds -----------------------------------------------------------------------------------------------
-  if (drop.enabled) n = dropout_merge<A>(m, wt, wr, wm, n, drop, sidx);
+  if (drop.enabled) n = dropout_merge<A, GlbArr, EvGlb>(m, wt, wr, wm, n, drop, sidx, GlbArr{drop.wsl}, EvGlb{drop.ev});  // (HBM scratch; the fence of old: GlbArr reads at agent scope)
   else {
     n = merge_rounds<A>(m, bloom, wt, wr, wm, n);
   }
@@ -465,7 +499,7 @@ struct SentView {
 __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8_t *__restrict__ text,
                            const SentView &sv, unsigned long long s, unsigned long long e, LdsArr wt, LdsArr wr,
                            LdsArr wm, int bos, int eos, int reverse, int32_t *__restrict__ scratch_ids, uint32_t *__restrict__ counts,
-                           const DropoutArgs &drop) {
+                           const DropoutArgs &drop, int wcap /* tokens a pack may hold */, LdsArr dws, EvLds dq /* dropout: word starts, event queues */) {
   const int lane = lane_id();
   const unsigned long long lt = lanemask_lt();
   int n = 0, consumed = 0, k = 0;
@@ -578,7 +612,7 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
   }
   for (unsigned long long j = s; !sv.end && j < e && k < 64; j++) {
     const unsigned long long b0 = sv.lo(j), nbytes = sv.hi(j) - b0;
-    if (nbytes + 1 > (unsigned long long)(ENC_WCAP - n)) break;
+    if (nbytes + 1 > (unsigned long long)(wcap - n)) break;
     const int n0 = n;
     n = enc_tokenize<LdsArr>(m, text + b0, nbytes, wt, n0);
     wave_sync();
@@ -600,7 +634,7 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
   wave_sync();
   if (k == 0) return consumed;
   if (drop.enabled) {  // BPE-dropout: one word per lane (the RNG stream is keyed by the pack's first sentence)
-    n = dropout_merge<LdsArr>(m, wt, wr, wm, n, drop, s);
+    n = dropout_merge<LdsArr, LdsArr, EvLds>(m, wt, wr, wm, n, drop, s, dws, dq);
   } else {
     for (int c = 0; c < ((n + 63) >> 6); c++) {
       const int p = c * 64 + lane;
@@ -663,18 +697,28 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
   return consumed;
 }
 
+// DROP: the BPE-dropout instantiation -- no Bloom filter of the rules (its look-ups go to the rule hash), the wave's LDS share holds the
+// word starts and event queues of a pack of up to ENC_DROP_WCAP tokens instead (72 KB per workgroup: two per CU, as without dropout).
+template <bool DROP>
 __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8_t *__restrict__ text,
                                                    SentView sv, unsigned long long n_sent, int bos,
                                                    int eos, int reverse, int32_t *__restrict__ scratch_ids,
                                                    uint32_t *__restrict__ counts, uint32_t *__restrict__ work,
                                                    unsigned long long work_stride, DropoutArgs drop, unsigned long long drop_stride, unsigned int group) {
   __shared__ uint32_t lds[ENC_WAVES][3][ENC_WCAP];
-  __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
-  for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += ENC_THREADS) bloom[i] = m.bloom[i];
-  __syncthreads();
+  __shared__ uint32_t bloom[DROP ? 1 : ENC_BLOOM_WORDS];
+  __shared__ uint32_t dq_lds[DROP ? ENC_WAVES : 1][DROP ? 3 * ENC_DROP_WCAP : 1];
+  __shared__ uint32_t dws_lds[DROP ? ENC_WAVES : 1][DROP ? ENC_DROP_WCAP : 1];
+  if (!DROP) {
+    for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += ENC_THREADS) bloom[i] = m.bloom[i];
+    __syncthreads();
+  }
   const int wave = (int)(threadIdx.x >> 6);
   const unsigned long long gw = (unsigned long long)blockIdx.x * ENC_WAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * ENC_WAVES;
+  // tokens a pack may hold: the LDS arrays; with dropout what the LDS event queues take (0: every sentence through the HBM scratch --
+  // a model with 2^23 rules or more, whose rule indices do not fit the packed events)
+  const int wcap = DROP ? (drop.lds_queues ? ENC_DROP_WCAP : 0) : ENC_WCAP;
   // a wavefront owns groups of `group` consecutive sentences and packs as many of a group at a time as fit its LDS arrays
   const unsigned long long n_groups = (n_sent + group - 1) / group;
   for (unsigned long long grp = gw; grp < n_groups; grp += n_waves) {
@@ -685,12 +729,13 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
       const unsigned long long nbytes = b1 - b0;
       LdsArr a{lds[wave][0]}, b{lds[wave][1]}, c{lds[wave][2]};
       DropoutArgs d = drop;
-      if (d.enabled) {  // per-wave slice of the dropout scratch: word starts, then the event queues
+      if (d.enabled) {  // per-wave slice of the dropout scratch (long sentences): word starts, then the event queues
         d.wsl = drop.wsl + gw * 7 * drop_stride;
         d.ev = reinterpret_cast<unsigned long long *>(drop.wsl + gw * 7 * drop_stride + drop_stride);
       }
-      if (nbytes + 1 <= (unsigned long long)ENC_WCAP) {
-        sidx += (unsigned long long)encode_pack(m, bloom, text, sv, sidx, grp_end, a, b, c, bos, eos, reverse, scratch_ids, counts, d);
+      if (nbytes + 1 <= (unsigned long long)wcap) {
+        sidx += (unsigned long long)encode_pack(m, bloom, text, sv, sidx, grp_end, a, b, c, bos, eos, reverse, scratch_ids, counts, d, wcap,
+                                                LdsArr{dws_lds[DROP ? wave : 0]}, EvLds{dq_lds[DROP ? wave : 0]});
         continue;
       }
       // too long for the LDS arrays: one sentence at a time on the wavefront's HBM scratch
@@ -735,8 +780,13 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   unsigned long long group = n_sent / ((unsigned long long)n_blocks * ENC_WAVES * 4);
   if (group < 1) group = 1;
   if (group > (ends ? 64ull : 24ull)) group = ends ? 64 : 24;  // (the word cache's items are a few bytes each: a pack takes up to 64 of them)
-  hipLaunchKernelGGL(k5_encode, dim3(n_blocks), dim3(ENC_THREADS), 0, st, m, text, SentView{offsets, ends}, n_sent, bos, eos, reverse, scratch_ids, counts, work,
-                     work_stride, d, drop_stride, (unsigned int)group);
+  d.lds_queues = m.n_rules < (1u << 23) && !getenv("YTTM_DROPOUT_HBM_QUEUES");  // (tests: every queue in the HBM scratch)
+  if (d.enabled)
+    hipLaunchKernelGGL(k5_encode<true>, dim3(n_blocks), dim3(ENC_THREADS), 0, st, m, text, SentView{offsets, ends}, n_sent, bos, eos, reverse, scratch_ids, counts,
+                       work, work_stride, d, drop_stride, (unsigned int)group);
+  else
+    hipLaunchKernelGGL(k5_encode<false>, dim3(n_blocks), dim3(ENC_THREADS), 0, st, m, text, SentView{offsets, ends}, n_sent, bos, eos, reverse, scratch_ids, counts,
+                       work, work_stride, d, drop_stride, (unsigned int)group);
 }
 void launch_encode_gather(const int32_t *scratch_ids, const unsigned long long *offsets, const unsigned long long *ends,
                           const unsigned long long *out_off, unsigned long long n_sent, int32_t *ids_out, hipStream_t st) {

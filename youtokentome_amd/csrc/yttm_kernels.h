@@ -202,6 +202,7 @@ struct EncModel {
   const unsigned long long *rule_xy;  // [n_rules] x<<32|y of rule i
   const uint32_t *bloom;      // [ENC_BLOOM_WORDS] blocked Bloom filter of the rule keys (staged into LDS)
   unsigned int rule_mask;
+  uint32_t n_rules;
   uint32_t z_affine, z_base, z_bp[4];  // rule_z[r] == z_base + r + #{k : z_bp[k] <= r} when z_affine 
   uint32_t space_id;
   int unk_id, bos_id, eos_id;
