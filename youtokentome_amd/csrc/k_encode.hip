@@ -706,9 +706,11 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
                                                    uint32_t *__restrict__ counts, uint32_t *__restrict__ work,
                                                    unsigned long long work_stride, DropoutArgs drop, unsigned long long drop_stride, unsigned int group) {
   __shared__ uint32_t lds[ENC_WAVES][3][ENC_WCAP];
-  __shared__ uint32_t bloom[DROP ? 1 : ENC_BLOOM_WORDS];
-  __shared__ uint32_t dq_lds[DROP ? ENC_WAVES : 1][DROP ? 3 * ENC_DROP_WCAP : 1];
-  __shared__ uint32_t dws_lds[DROP ? ENC_WAVES : 1][DROP ? ENC_DROP_WCAP : 1];
+  // 32 KB beside the working arrays -- 80 KB in all, two workgroups per CU (one byte more and it is one): the rules' Bloom filter, or with
+  // dropout the waves' event queues (3 x 256 packed events each) and word starts (256 each)
+  __shared__ uint32_t aux[ENC_BLOOM_WORDS];
+  static_assert(ENC_WAVES * (3 * ENC_DROP_WCAP + ENC_DROP_WCAP) <= ENC_BLOOM_WORDS, "the dropout queues take the Bloom filter's place");
+  uint32_t *bloom = aux;
   if (!DROP) {
     for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += ENC_THREADS) bloom[i] = m.bloom[i];
     __syncthreads();
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
       }
       if (nbytes + 1 <= (unsigned long long)wcap) {
         sidx += (unsigned long long)encode_pack(m, bloom, text, sv, sidx, grp_end, a, b, c, bos, eos, reverse, scratch_ids, counts, d, wcap,
-                                                LdsArr{dws_lds[DROP ? wave : 0]}, EvLds{dq_lds[DROP ? wave : 0]});
+                                                LdsArr{aux + ENC_WAVES * 3 * ENC_DROP_WCAP + wave * ENC_DROP_WCAP}, EvLds{aux + wave * 3 * ENC_DROP_WCAP});
         continue;
       }
       // too long for the LDS arrays: one sentence at a time on the wavefront's HBM scratch
