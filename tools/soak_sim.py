@@ -1,5 +1,6 @@
 """CPU soak: random corpora through the product sources under the HIP emulator against the oracle (byte-identical model files, identical
-encode ids with and without the word cache).  usage: python tools/soak_sim.py [seconds] [seed] [big|long|rounds]"""
+encode ids with and without the word cache).  usage: python tools/soak_sim.py [seconds] [seed] [big|long|rounds|words]
+(words: the larger tables of `big` with K4's word mode forced on from the second round and the hooks that force its rare paths)"""
 import os, pathlib, random, sys, tempfile, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("YTTM_AMD_LIB", os.path.join(R, "tests", "hipsim", "_build", "libyttm_sim.so"))
@@ -9,7 +10,8 @@ import stage_checks as S
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-big = len(sys.argv) > 3 and sys.argv[3] == "big"
+words_mode = len(sys.argv) > 3 and sys.argv[3] == "words"
+big = len(sys.argv) > 3 and sys.argv[3] in ("big", "words")
 long_words = len(sys.argv) > 3 and sys.argv[3] == "long"
 rounds_mode = len(sys.argv) > 3 and sys.argv[3] == "rounds"
 rng = random.Random(seed)
@@ -73,6 +75,14 @@ while time.time() - t0 < budget:
                             {"YTTM_HOT_TARGET": "8", "YTTM_HOT_MIN": "3", "YTTM_HOT_CAP": "32"}, {"YTTM_TOP_TARGET": "4", "YTTM_TOP_MIN": "2", "YTTM_TOP_CAP": "16"},
                             {"YTTM_INDEX_ALWAYS": "1", "YTTM_INDEX_MIN_TILES": "1", "YTTM_TOP_TARGET": "16", "YTTM_TOP_MIN": "4", "YTTM_TOP_CAP": "64"}])
         os.environ.update(hooks)
+        if words_mode:
+            for k in ("YTTM_WORD_LOG", "YTTM_WORD_DREC", "YTTM_WORDS_INLINE_MAX", "YTTM_INDEX_AGG_MIN", "YTTM_WORDS_WPI"):
+                os.environ.pop(k, None)
+            os.environ.update({"YTTM_WORD_MIN_TILES": "0", "YTTM_WORD_MIN_TOKENS": "0", "YTTM_WORD_DIV": rng.choice(["0", "0", "2", "8"])})
+            os.environ.pop("YTTM_INDEX_ALWAYS", None)
+            os.environ.update(rng.choice([{}, {"YTTM_WORD_LOG": str(rng.choice([50, 300, 2000]))}, {"YTTM_WORD_DREC": str(rng.choice([8, 64]))},
+                                          {"YTTM_WORDS_INLINE_MAX": "0"}, {"YTTM_INDEX_AGG_MIN": "0"},
+                                          {"YTTM_WORD_LOG": "200", "YTTM_WORD_DREC": "16", "YTTM_WORDS_INLINE_MAX": "0", "YTTM_INDEX_AGG_MIN": "0"}]))
     ids = rng.choice([(0, 1, 2, 3), (3, 2, 1, 0), (-1, 0, -1, -1), (5, 7, -1, 2)])
     try:
         model = S.check_train_vs_oracle(text, vocab, tmp, cov, ids, tag=f"s{n}")

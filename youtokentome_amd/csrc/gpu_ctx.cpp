@@ -220,7 +220,7 @@ GpuCtx::~GpuCtx() {
   tl_device = device_;
   (void)hipStreamSynchronize(st_);
   for (hipEvent_t e : all_events_) (void)hipEventDestroy(e);
-  DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_); DFREE(d_flagbits_);
+  DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_chunk_segs_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_); DFREE(d_flagbits_);
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_); DFREE(d_top_slots_); DFREE(d_top_n_); DFREE(d_box_);
   DFREE(d_send_); DFREE(d_xstat_); DFREE(d_bloom_);
@@ -532,7 +532,9 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
   }
   if (const char *e = getenv("YTTM_K1_WIDE")) wide_chars = atoi(e) != 0;
   t_begin(KT_CHAR_HIST);
-  if (n_text_) launch_char_hist(d_text_, n_text_, d_hist_, d_counters_, wide_chars, st_);
+  DFREE(d_chunk_segs_);
+  d_chunk_segs_ = dmalloc<uint32_t>(fe_chunks(n_text_) + 1);
+  if (n_text_) launch_char_hist(d_text_, n_text_, d_hist_, d_counters_, wide_chars, d_chunk_segs_, st_);
   t_end(KT_CHAR_HIST, n_text_);
   unsigned long long h_cnt[2] = {0, 0};
   HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 16, hipMemcpyDeviceToHost, st_));
@@ -606,10 +608,19 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   if (n_segs == 0 || n_text_ == 0) return;
   // segment starts
   unsigned long long *d_seg = dmalloc<unsigned long long>(n_segs);
-  HIP_CHECK(hipMemsetAsync(d_counters_ + 16, 0, 8, st_));
-  t_begin(KT_SEGS);
-  launch_seg_write(d_text_, n_text_, d_seg, d_counters_ + 16, st_);
-  t_end(KT_SEGS, n_text_ + 8 * n_segs);
+  {
+    // where each 4 KB chunk's segments go: exclusive scan of the counts K1 left (no cursor, and the starts come out in text order)
+    const unsigned long long nch = fe_chunks(n_text_);
+    unsigned long long *d_chunk_off = dmalloc<unsigned long long>(nch + 1);
+    unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(nch));
+    t_begin(KT_SEGS);
+    launch_exclusive_scan(d_chunk_segs_, nch, d_chunk_off, scan_tmp, d_counters_ + 16, st_);
+    launch_seg_write(d_text_, n_text_, d_seg, d_chunk_off, st_);
+    t_end(KT_SEGS, n_text_ + 8 * n_segs);
+    sync();
+    DFREE(d_chunk_off);
+    DFREE(scan_tmp);
+  }
   // hash dedup.  The table is sized for an eighth as many distinct words as there are occurrences (natural text and the
   // benchmark corpora have far fewer: Heaps' law) -- the compaction pass streams it, and a small table keeps the frequent words'
   // slots cache-resident; a corpus of mostly distinct words overflows it (probe chains beyond WH_MAX_PROBES) and is redone

@@ -167,6 +167,7 @@ class GpuCtx {
   unsigned long long n_text_ = 0;
   // K1
   unsigned long long *d_hist_ = nullptr;      // [N_CODEPOINTS]
+  uint32_t *d_chunk_segs_ = nullptr;          // [fe_chunks(n_text_)] segment starts per 4 KB chunk (K1 counts them, K2a places them)
   unsigned long long *d_counters_ = nullptr;  // small scratch of u64 counters
   // K2
   uint32_t *d_cpmap_ = nullptr;  // [N_CODEPOINTS]

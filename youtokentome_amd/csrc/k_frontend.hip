@@ -29,12 +29,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan_bytes(const uint8_t *__restrict_
                                                       unsigned long long *__restrict__ hist,
                                                       unsigned long long *__restrict__ counters /* [0]=steps [1]=segs */,
                                                       unsigned long long *__restrict__ seg_pos,
-                                                      unsigned long long *__restrict__ seg_cursor) {
+                                                      const unsigned long long *__restrict__ chunk_off /* MODE 1: segments before the chunk */,
+                                                      uint32_t *__restrict__ chunk_segs /* MODE 0: segments of the chunk (out) */) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[FE_CHUNK + 16];  // [0..3] halo before, [4..4+FE_CHUNK) main, then halo after
   __shared__ unsigned int lh[MODE == 0 ? LH_BINS : 1];
   __shared__ unsigned int hkey[HK ? HK : 1], hval[HK ? HK : 1];
   __shared__ uint32_t scan_lds[NWAVES];
-  __shared__ unsigned long long blk_base;
+  __shared__ uint32_t seg_part[NWAVES];  // MODE 0: the waves' segment counts of the chunk just scanned
   const int tid = (int)threadIdx.x;
   if (MODE == 0) {
     for (int b = tid; b < LH_BINS; b += BLOCK) lh[b] = 0;
@@ -45,6 +46,11 @@ __global__ __launch_bounds__(BLOCK) void k_scan_bytes(const uint8_t *__restrict_
   for (unsigned long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const unsigned long long c0 = chunk * FE_CHUNK;
     __syncthreads();  // previous iteration done with `stage`
+    if (MODE == 0 && tid == 0 && chunk != blockIdx.x) {  // the previous chunk's segment count (its waves' parts are in: the barrier above)
+      uint32_t t = 0;
+      for (int w = 0; w < NWAVES; w++) t += seg_part[w];
+      chunk_segs[chunk - gridDim.x] = t;
+    }
     {
       // coalesced 16 B/lane load of the chunk (text base is 256 B aligned: hipMalloc), zero fill past the end
       unsigned long long g = c0 + (unsigned long long)tid * 16;
@@ -155,12 +161,18 @@ __global__ __launch_bounds__(BLOCK) void k_scan_bytes(const uint8_t *__restrict_
     my_steps += n_starts;
     const uint32_t nseg = (uint32_t)__popc(seg_mask);
     my_segs += nseg;
+    if (MODE == 0) {
+      // Per chunk, for the pass that writes the segment starts: where a chunk's segments go is then known without a cursor -- one returning
+      // atomic per chunk on ONE address (244 k of them at 1 GB, ~12 ns each) was 2.9 of that pass's 3.5 ms.  (The count rides on the
+      // barrier the next iteration starts with.)
+      uint32_t ws = nseg;
+      for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o);
+      if (lane_id() == 0) seg_part[tid >> 6] = ws;
+    }
     if (MODE == 1) {
       uint32_t total;
       uint32_t off = block_excl_scan(nseg, scan_lds, &total);
-      if (tid == 0) blk_base = total ? atomicAdd(seg_cursor, (unsigned long long)total) : 0ull;
-      __syncthreads();
-      unsigned long long o = blk_base + off;
+      unsigned long long o = chunk_off[chunk] + off;
       uint32_t m = seg_mask;
       while (m) {
         int j = __ffs((int)m) - 1;
@@ -170,6 +182,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan_bytes(const uint8_t *__restrict_
     }
   }
   if (MODE == 0) {
+    __syncthreads();
+    if (tid == 0 && n_chunks > blockIdx.x) {  // the last chunk this block scanned
+      uint32_t t = 0;
+      for (int w = 0; w < NWAVES; w++) t += seg_part[w];
+      const unsigned long long last = blockIdx.x + ((n_chunks - 1 - blockIdx.x) / gridDim.x) * (unsigned long long)gridDim.x;
+      chunk_segs[last] = t;
+    }
     unsigned long long s = wave_sum_u64(my_steps);
     unsigned long long g = wave_sum_u64(my_segs);
     if (lane_id() == 0) {
@@ -721,22 +740,23 @@ static inline unsigned int grid_for(unsigned long long items, unsigned int per_b
 }
 
 void launch_char_hist(const uint8_t *text, unsigned long long n, unsigned long long *hist, unsigned long long *counters, bool wide_chars,
-                      hipStream_t st) {
+                      uint32_t *chunk_segs, hipStream_t st) {
   if (wide_chars) {  // (76 KB of LDS per workgroup: two per CU)
     unsigned int g = grid_for(n, FE_CHUNK, 256 * 2);
     hipLaunchKernelGGL((k_scan_bytes<0, 8192>), dim3(g), dim3(BLOCK), 0, st, text, n, hist, counters, (unsigned long long *)nullptr,
-                       (unsigned long long *)nullptr);
+                       (const unsigned long long *)nullptr, chunk_segs);
     return;
   }
   unsigned int g = grid_for(n, FE_CHUNK, 256 * 8);
   hipLaunchKernelGGL((k_scan_bytes<0, 0>), dim3(g), dim3(BLOCK), 0, st, text, n, hist, counters, (unsigned long long *)nullptr,
-                     (unsigned long long *)nullptr);
+                     (const unsigned long long *)nullptr, chunk_segs);
 }
-void launch_seg_write(const uint8_t *text, unsigned long long n, unsigned long long *seg_pos, unsigned long long *seg_cursor,
+unsigned long long fe_chunks(unsigned long long n) { return (n + FE_CHUNK - 1) / FE_CHUNK; }
+void launch_seg_write(const uint8_t *text, unsigned long long n, unsigned long long *seg_pos, const unsigned long long *chunk_off,
                       hipStream_t st) {
   unsigned int g = grid_for(n, FE_CHUNK, 256 * 8);
   hipLaunchKernelGGL((k_scan_bytes<1, 0>), dim3(g), dim3(BLOCK), 0, st, text, n, (unsigned long long *)nullptr,
-                     (unsigned long long *)nullptr, seg_pos, seg_cursor);
+                     (unsigned long long *)nullptr, seg_pos, chunk_off, (uint32_t *)nullptr);
 }
 void launch_hist_compact(const unsigned long long *hist, uint32_t *cps, unsigned long long *cnts, unsigned int *n_out,
                          unsigned int cap, hipStream_t st) {

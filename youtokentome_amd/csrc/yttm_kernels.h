@@ -23,9 +23,11 @@ inline unsigned long long cand_bin_lower(int bin) {
 
 // ---- front end (k_frontend.hip)
 // wide_chars: many chars beyond U+07FF (three- and four-byte UTF-8): they are counted in an LDS hash instead of global atomics
+// chunk_segs [fe_chunks(n)]: segment starts per 4 KB chunk of the text (out); the segment pass takes their exclusive scan
 void launch_char_hist(const uint8_t *text, unsigned long long n, unsigned long long *hist, unsigned long long *counters, bool wide_chars,
-                      hipStream_t st);
-void launch_seg_write(const uint8_t *text, unsigned long long n, unsigned long long *seg_pos, unsigned long long *seg_cursor, hipStream_t st);
+                      uint32_t *chunk_segs, hipStream_t st);
+unsigned long long fe_chunks(unsigned long long n);
+void launch_seg_write(const uint8_t *text, unsigned long long n, unsigned long long *seg_pos, const unsigned long long *chunk_off, hipStream_t st);
 void launch_hist_compact(const unsigned long long *hist, uint32_t *cps, unsigned long long *cnts, unsigned int *n_out, unsigned int cap,
                          hipStream_t st);
 // word table (K2b/K2c): ht[0 .. n_slots) keys, ht[n_slots .. 2 n_slots) counts, see k_frontend.hip
