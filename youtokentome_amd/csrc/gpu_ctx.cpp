@@ -1429,7 +1429,7 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
 }
 
 void GpuCtx::free_index() {
-  DFREE(idx_.key); DFREE(idx_.cnt); DFREE(idx_.off); DFREE(idx_.bloom); DFREE(idx_.post); DFREE(d_stamp_); DFREE(idx_scan_tmp_);
+  DFREE(idx_.key); DFREE(idx_.cnt); DFREE(idx_.off); DFREE(idx_.bloom); DFREE(idx_.post); DFREE(d_stamp_); DFREE(idx_scan_tmp_); DFREE(idx_save_);
   idx_cap_ = post_cap_ = 0;
   stamp_cap_ = 0;
   idx_valid_ = false;
@@ -1466,7 +1466,8 @@ void GpuCtx::build_index(uint32_t z_next) {
   HIP_CHECK(hipMemsetAsync(idx_.bloom, 0, ENC_BLOOM_WORDS * 4, st_));
   t_begin(KT_CAND);
   launch_idx_seed(pt_, idx_, listed, st_);
-  launch_idx_stream(0, false, c.ts, idx_, st_, word_mode_);
+  if (!idx_save_) idx_save_ = dmalloc<unsigned char>(idx_save_bytes());
+  launch_idx_stream(0, false, c.ts, idx_, st_, word_mode_, true, idx_save_);
   // offsets = exclusive scan of the counts (one extra zero count behind the last slot: off[mask + 1] = the total)
   HIP_CHECK(hipMemsetAsync(idx_.cnt + want * IDX_SHARDS, 0, 4, st_));
   launch_exclusive_scan(idx_.cnt, want * IDX_SHARDS + 1, idx_.off, idx_scan_tmp_, d_counters_ + 56, st_);
@@ -1486,7 +1487,7 @@ void GpuCtx::build_index(uint32_t z_next) {
     post_cap_ = total + total / 4 + 1024;
     idx_.post = dmalloc<uint32_t>(post_cap_);
   }
-  launch_idx_stream(0, true, c.ts, idx_, st_, word_mode_, /*agg=*/total > idx_agg_min_);
+  launch_idx_stream(0, true, c.ts, idx_, st_, word_mode_, /*agg=*/total > idx_agg_min_, idx_save_);
   t_end(KT_CAND, 8ull * c.n_tiles * c.nom);
   const unsigned long long stamps = word_mode_ ? c.n_unique : c.n_tiles;  // (word mode: a posting is a word, and a round claims words)
   if (stamps > stamp_cap_) {

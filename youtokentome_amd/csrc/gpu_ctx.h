@@ -189,6 +189,7 @@ class GpuCtx {
   PairIndexArgs idx_{};
   unsigned long long idx_cap_ = 0, post_cap_ = 0;
   unsigned long long *idx_scan_tmp_ = nullptr;
+  unsigned char *idx_save_ = nullptr;  // the index count pass's per-workgroup tables (k_idx_stream)
   uint32_t *d_stamp_ = nullptr;   // [class-A tiles] round that claimed the tile for its worklist last
   unsigned int stamp_cap_ = 0;
   bool idx_valid_ = false, idx_pending_ = false, idx_enabled_ = true, idx_force_ = false;

@@ -1918,21 +1918,32 @@ __device__ inline void idx_sweep(const TileSet &ts, const PairIndex &ix, const u
 #undef IDX_PAIR
   }
 }
+// `save` [gridDim.x]: the count pass leaves every workgroup's table there, and the fill pass of a build with many postings (agg) starts from
+// it instead of counting again (same grid, same tiles per workgroup: the table is exactly what that sweep would rebuild -- a third of the
+// build's work).
 template <int SLOT, bool FILL, bool WORDS>
-__global__ __launch_bounds__(IDXA_NT) void k_idx_stream(TileSet ts, PairIndex ix, int agg /* fill pass: 0 = few postings, one sweep with an atomic each */) {
+__global__ __launch_bounds__(IDXA_NT) void k_idx_stream(TileSet ts, PairIndex ix, int agg /* fill pass: 0 = few postings, one sweep with an atomic each */,
+                                                        IdxAgg *__restrict__ save) {
   __shared__ IdxAgg T;
   __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
   for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += IDXA_NT) bloom[i] = ix.bloom[i];
+  const bool reload = FILL && agg && save;
   for (int i = (int)threadIdx.x; i < IDXA_SLOTS; i += IDXA_NT) {
-    T.key[i] = PT_EMPTY;
-    T.cnt[i] = 0;
+    T.key[i] = reload ? save[blockIdx.x].key[i] : PT_EMPTY;
+    T.cnt[i] = reload ? save[blockIdx.x].cnt[i] : 0u;
+    if (reload) T.slot[i] = save[blockIdx.x].slot[i];
   }
   __syncthreads();
   const uint32_t shard = blockIdx.x % IDX_SHARDS;
-  if (agg) idx_sweep<SLOT, FILL, WORDS, 0>(ts, ix, bloom, T, shard);
+  if (!FILL || (agg && !reload)) idx_sweep<SLOT, FILL, WORDS, 0>(ts, ix, bloom, T, shard);
   __syncthreads();
   for (int i = (int)threadIdx.x; i < IDXA_SLOTS; i += IDXA_NT) {
     const uint32_t c = T.cnt[i];
+    if (!FILL && save) {
+      save[blockIdx.x].key[i] = T.key[i];
+      save[blockIdx.x].slot[i] = T.slot[i];
+      save[blockIdx.x].cnt[i] = c;
+    }
     if (T.key[i] == PT_EMPTY || !c) continue;
     const size_t cs = (size_t)T.slot[i] * IDX_SHARDS + shard;
     const uint32_t b0 = atomicAdd(&ix.cnt[cs], c);
@@ -2963,20 +2974,22 @@ void launch_idx_seed(const PairTable &pt, const PairIndexArgs &a, unsigned int l
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(k_idx_seed, dim3(g), dim3(BLOCK), 0, st, pt, ix);
 }
-void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st, bool words, bool agg) {
+size_t idx_save_bytes() { return (size_t)512 * sizeof(IdxAgg); }
+void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st, bool words, bool agg, void *save_) {
+  IdxAgg *save = reinterpret_cast<IdxAgg *>(save_);
   if (!ts.n_tiles) return;
   const PairIndex ix{a.key, a.cnt, a.off, a.bloom, a.post, a.mask};
   unsigned int g = (ts.n_tiles + IDXA_NT / 64 - 1) / (IDXA_NT / 64);
   if (g > 512) g = 512;  // (two workgroups per CU: 72 KB of LDS each; count and fill pass MUST use the same grid -- a workgroup's shard and tiles)
   if (cls == 0 && words) {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0);
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
   } else if (cls == 0) {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0);
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
   } else {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, true, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, false, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0);
+    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, true, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
+    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, false, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
   }
 }
 void launch_words_init(const TileSet &ts, unsigned long long *wmeta, hipStream_t st) {

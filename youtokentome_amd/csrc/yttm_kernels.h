@@ -114,7 +114,9 @@ struct PairIndexArgs {
 };
 void launch_idx_seed(const PairTable &pt, const PairIndexArgs &a, unsigned int listed_hint, hipStream_t st);
 void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st, bool words = false /* postings are word ids; the tiles may hold TOK_HOLEs */,
-                       bool agg = true /* fill pass: sum a workgroup's postings per key in LDS first (worth a second sweep only when they are many) */);
+                       bool agg = true /* fill pass: sum a workgroup's postings per key in LDS first (worth a second sweep only when they are many) */,
+                       void *save = nullptr /* [idx_save_bytes()] the count pass's per-workgroup tables, reused by an agg fill pass */);
+size_t idx_save_bytes();
 void launch_gather(const PairIndexArgs &a, const RuleSlot *rules, unsigned int n_slots, const BatchArgs *ba, uint32_t self_x, uint32_t *stamp,
                    uint32_t round_id, uint32_t *worklist, unsigned int n_tiles, unsigned int *work_n, hipStream_t st);
 // ---- word mode (k_merge.hip)
