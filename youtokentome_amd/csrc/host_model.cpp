@@ -222,14 +222,42 @@ Status check_config(BpeConfig &c, int vocab_size) {  // bpe.cpp:1295-1350; messa
 }
 
 // ------------------------------------------------------------------------------------------------- model file
+// decimal digits of v at p; returns the end.  (The model file is 32 000 lines of three numbers: fprintf took 3.5 ms of a 142 ms training.)
+static inline char *put_u32(char *p, uint32_t v) {
+  char tmp[10];
+  int n = 0;
+  do { tmp[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+  while (n) *p++ = tmp[--n];
+  return p;
+}
+static inline char *put_i32(char *p, int v) {
+  if (v < 0) { *p++ = '-'; return put_u32(p, (uint32_t)(-(long long)v)); }
+  return put_u32(p, (uint32_t)v);
+}
+
 Status BPEState::dump(const std::string &file_name) const {  // utils.cpp:50-66, :10-13
   FILE *f = fopen(file_name.c_str(), "wb");
   if (!f) return Status(1, "Can't open file: " + file_name);
-  fprintf(f, "%zu %zu\n", char2id.size(), rules.size());
-  for (auto &c : char2id) fprintf(f, "%u %u\n", c.first, c.second);
-  for (auto &r : rules) fprintf(f, "%u %u %u\n", r.x, r.y, r.z);
-  fprintf(f, "%d %d %d %d\n", special_tokens.unk_id, special_tokens.pad_id, special_tokens.bos_id, special_tokens.eos_id);
-  fclose(f);
+  std::string buf;
+  buf.resize(64 + 24 * char2id.size() + 36 * rules.size() + 64);
+  char *p = &buf[0];
+  p += sprintf(p, "%zu %zu\n", char2id.size(), rules.size());
+  for (auto &c : char2id) {
+    p = put_u32(p, c.first); *p++ = ' ';
+    p = put_u32(p, c.second); *p++ = '\n';
+  }
+  for (auto &r : rules) {
+    p = put_u32(p, r.x); *p++ = ' ';
+    p = put_u32(p, r.y); *p++ = ' ';
+    p = put_u32(p, r.z); *p++ = '\n';
+  }
+  p = put_i32(p, special_tokens.unk_id); *p++ = ' ';
+  p = put_i32(p, special_tokens.pad_id); *p++ = ' ';
+  p = put_i32(p, special_tokens.bos_id); *p++ = ' ';
+  p = put_i32(p, special_tokens.eos_id); *p++ = '\n';
+  const size_t len = (size_t)(p - &buf[0]);
+  const bool ok = fwrite(buf.data(), 1, len, f) == len;
+  if (fclose(f) != 0 || !ok) return Status(1, "Can't write file: " + file_name);
   return Status();
 }
 
