@@ -1506,7 +1506,7 @@ void GpuCtx::build_index(uint32_t z_next) {
 }
 
 void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts, const unsigned long long *next_tau_cnt,
-                         uint32_t next_tau_mx) {
+                         uint32_t next_tau_mx, uint32_t next_want) {
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
@@ -1657,6 +1657,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     sa.out = d_cand_;
     sa.cap = cand_cap_;
     sa.fast = 4096;
+    sa.want = next_want;  // (the scan may raise the threshold to about this many candidates: scan_top)
     sa.done_ctr = d_hot_n_ + 1;
     sa.mailbox = (unsigned char *)h_pin_;
     sa.round_id = ++mail_round_;

@@ -72,8 +72,10 @@ class GpuCtx {
   // next_tau_cnt / next_tau_mx (optional): the threshold of the candidate scan that will follow this round.  When the round is
   // one launch (single GPU, class-A tiles only, hot list active) that scan runs inside it (k_merge.hip round_tail) and the
   // next candidates() call with the same threshold only waits for the mailbox.
+  // next_want != 0: about that many candidates are wanted from the fused scan -- it may then raise the threshold by itself; the caller reads
+  // the threshold that was used back as the smallest count among the candidates (they are every pair at or above it)
   void merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts, const unsigned long long *next_tau_cnt = nullptr,
-                   uint32_t next_tau_mx = 0xffffffffu);
+                   uint32_t next_tau_mx = 0xffffffffu, uint32_t next_want = 0);
   void pair_query(const unsigned long long *keys, uint32_t n, unsigned long long *out);
   // candidate filter; returns number of candidates that passed (may exceed out.size() capacity => retry with higher tau)
   // Pairs with count > tau_cnt, or == tau_cnt and max(x,y) <= tau_mx (a complete prefix of the pick order), + histogram

@@ -135,8 +135,11 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   std::vector<unsigned long long> batch_cnt;
   unsigned long long rounds = 0, rescans = 0, rounds_exhausted = 0, batch_extensions = 0;
   const bool extend_on = !getenv("YTTM_NO_EXTEND");  // (tuning hook / A-B runs)
+  const bool refine_on = !getenv("YTTM_NO_REFINE");  // (the same: the fused scan keeps the host's threshold)
   std::vector<unsigned long long> batch_keys;
-  double w_cand = 0, w_pick = 0, w_apply = 0;
+  double w_cand = 0, w_pick = 0, w_apply = 0, w_pick_a = 0, w_pick_b = 0;  // (YTTM_TRACE: pick = threshold + heap build | pops)
+  const bool trace_pick = getenv("YTTM_TRACE") != nullptr;
+  unsigned long long n_cand_sum = 0;
   std::vector<uint8_t> in_batch((size_t)vocab_size + 1, 0);  // bit0: token is the x of a batch rule, bit1: the y
   while (used_ids < (uint64_t)vocab_size) {
     // Candidate set = every pair with count > tau, or count == tau and max(x,y) <= tau_mx: a complete prefix of the
@@ -144,6 +147,13 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     auto tw0 = clk::now();
     uint32_t n = g.candidates(tau, tau_mx, recs, nullptr);
     w_cand += since(tw0);
+    if (n && n <= recs.size()) {
+      // The fused scan may have raised the threshold (ScanArgs::want): what came back is every pair at or above the smallest count listed --
+      // a complete prefix of the order all the same -- and that count is the threshold the rest of this round reasons with.
+      unsigned long long mn = ~0ull;
+      for (uint32_t i = 0; i < n; i++) mn = std::min<unsigned long long>(mn, recs[i].cnt);
+      if (mn > tau) { tau = mn; tau_mx = MX_ALL; }
+    }
     auto tw1 = clk::now();
     const unsigned long long *hist = g.last_hist();  // (of the counts the scan looked at; valid until the next scan)
     const unsigned long long total_pairs = g.last_live();
@@ -184,9 +194,13 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       n = g.candidates(tau, tau_mx, recs, nullptr);
       if (n == 0 || n > recs.size()) return Status(2, "candidate filter could not be fitted (more than 2^20 exact ties)");
     }
+    if (trace_pick) w_pick_a += since(tw1);
+    n_cand_sum += n;
+    const auto tw1b = clk::now();
     heap.resize(n);
     for (uint32_t i = 0; i < n; i++) heap[i] = Cand{recs[i].cnt, (uint32_t)(recs[i].key >> 32), (uint32_t)recs[i].key};
     std::make_heap(heap.begin(), heap.end(), HeapCmp());
+    if (trace_pick) w_pick_b += since(tw1b);
     batch_xyz.clear();
     batch_cnt.clear();
     const size_t max_batch = 4096;
@@ -244,7 +258,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     for (uint32_t j = 0; j < k; j++) in_batch[batch_xyz[3 * j]] = in_batch[batch_xyz[3 * j + 1]] = 0;
     w_pick += since(tw1);
     auto tw2 = clk::now();
-    g.merge_apply(batch_xyz.data(), k, batch_cnt.data(), &tau_hint, MX_ALL);  // (the next scan's threshold: it can ride along)
+    g.merge_apply(batch_xyz.data(), k, batch_cnt.data(), &tau_hint, MX_ALL, refine_on ? (uint32_t)TARGET : 0u);  // (the next scan's threshold rides along)
     w_apply += since(tw2);
     for (uint32_t j = 0; j < k; j++) rules.push_back(BPE_Rule{batch_xyz[3 * j], batch_xyz[3 * j + 1], batch_xyz[3 * j + 2]});
     used_ids += k;
@@ -263,6 +277,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       fprintf(stderr, "[yttm] fused rounds %llu: tail set-up %.2f us, top-list scan %.2f us (%.0f entries), publish %.2f us per round\n", g.fused_rounds,
               g.tail_ticks[0] * 0.01 / g.fused_rounds, g.tail_ticks[1] * 0.01 / g.fused_rounds, (double)g.tail_listed / g.fused_rounds,
               g.tail_ticks[2] * 0.01 / g.fused_rounds);
+    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] host pick: threshold %.1f ms, heap build %.1f ms of the %.1f; %.0f candidates per round\n", w_pick_a * 1e3, w_pick_b * 1e3, w_pick * 1e3, (double)n_cand_sum / (double)std::max<unsigned long long>(rounds, 1));
     if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu, hot rebuilds %llu, top refills %llu, index builds %llu (%llu rounds from the index, %llu through k_apply_pm, %llu in word mode from round %llu on, %llu of them over every word), pair table %llu keys in %llu slots (%llu rehashes)\n",
                                        w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.hot_rebuilds, g.top_refills, g.index_builds, g.gathered_rounds, g.pm_rounds, g.word_rounds, g.word_switch_round, g.word_all_rounds, g.n_keys_host, g.table_capacity(), g.rehashes);
   }

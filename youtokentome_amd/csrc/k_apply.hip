@@ -537,7 +537,7 @@ __global__ __launch_bounds__(WPB * 64) void k_apply_pm(TileSet ts, PairTable pt,
     __syncthreads();
     if (is_last) {
       __threadfence();  // (acquire: nothing stale in this CU's caches)
-      static_assert(sizeof(WL) >= (CAND_BINS + 80) * sizeof(unsigned int), "tile buffers double as the tail's scratch");
+      static_assert(sizeof(WL) >= (CAND_BINS + 160) * sizeof(unsigned int), "tile buffers double as the tail's scratch");
       const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
       scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
     }

@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     __syncthreads();
     if (is_last) {
       __threadfence();  // (acquire: nothing stale in this CU's caches)
-      static_assert(sizeof(WL) >= (CAND_BINS + 80) * sizeof(unsigned int), "tile buffers double as the tail's scratch");
+      static_assert(sizeof(WL) >= (CAND_BINS + 160) * sizeof(unsigned int), "tile buffers double as the tail's scratch");
       const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
       scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
     }
@@ -1521,7 +1521,7 @@ constexpr int TOP_SCAN_NT = 512;
 __global__ __launch_bounds__(TOP_SCAN_NT) void k_top_scan(PairTable pt, ScanArgs sa, unsigned long long *__restrict__ stats, const RuleSlot *__restrict__ zrules,
                                                           unsigned int zmask, unsigned long long zself, BatchArgs zba, unsigned long long *__restrict__ xstat) {
   __shared__ unsigned long long zkeys[FILTER_LDS_KEYS];
-  __shared__ unsigned int scratch[CAND_BINS + 80];
+  __shared__ unsigned int scratch[CAND_BINS + 160];
   bool zkeys_in_lds = zrules && zmask < FILTER_LDS_KEYS;
   if (zba.k) {
     zmask = 4 * BATCH_ARGS_MAX - 1;
@@ -2588,7 +2588,7 @@ __global__ __launch_bounds__(DAPPLY_NT) void k_delta_apply(PairTable pt, DeltaBu
                                                           unsigned long long zself, BatchArgs zba, ScanArgs sa) {
   __shared__ unsigned int new_keys, is_last;
   __shared__ unsigned long long zkeys[FILTER_LDS_KEYS];
-  __shared__ unsigned int scratch[CAND_BINS + 80];
+  __shared__ unsigned int scratch[CAND_BINS + 160];
   if (threadIdx.x == 0) new_keys = 0;
   if (blockIdx.x == 0 && threadIdx.x <= WL_PARTS + 1) work_n[threadIdx.x] = 0;
   __syncthreads();

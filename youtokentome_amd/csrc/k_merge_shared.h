@@ -123,7 +123,7 @@ __device__ inline int cand_bin(unsigned long long c) {
 // Box layout: [0] candidates, [4] keys in the table, [8] top-list entries before the scan, [12] of those still >= top_tau,
 // [16] hot-list entries (overflow check), [24] the round's duration on the device (ScanArgs::timed), [88] merge sites so far, [32] round id, [40] tokens streamed so far, [48] tiles with a site so far, [56..87]
 // xstat (multi-GPU), [96..127] timing marks (100 MHz), [MB_HIST..) histogram, [8192..) candidates.
-// lds = at least (CAND_BINS + 80) words of scratch (the apply kernel's tile buffers are free by now).
+// lds = at least (CAND_BINS + 160) words of scratch (the apply kernel's tile buffers are free by now).
 template <int NT>
 __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigned long long *__restrict__ stats, const RuleProbe &zprobe,
                                 unsigned long long zself, unsigned int *lds, unsigned long long *__restrict__ xstat) {
@@ -132,9 +132,11 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
   unsigned int *wcount = lds + CAND_BINS;     // [NW] kept entries per wave of this pass
   unsigned int *ctl = lds + CAND_BINS + 32;   // [0] kept so far, [1] candidates, [2] live entries
   unsigned long long *facc = reinterpret_cast<unsigned long long *>(lds + CAND_BINS + 40);  // [5] fold accumulators
+  unsigned int *sub = lds + CAND_BINS + 64;   // [64] counts inside the boundary bin, [64..67] the refined threshold (lo, hi), boundary bin, entries above it
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long tm0 = (unsigned long long)wall_clock64();
   for (int b = tid; b < CAND_BINS; b += NT) lh[b] = 0;
+  if (tid < 68) sub[tid] = 0;
   if (tid < 4) ctl[tid] = 0;  // ([3]: highest histogram bin in use)
   if (tid < 5) facc[tid] = 0;
   __syncthreads();
@@ -147,6 +149,12 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
   uint4 *box_out = reinterpret_cast<uint4 *>(sa.mailbox + 8192);
   constexpr int TAIL_E = 8;
   unsigned int my_live = 0;
+  // The host wants about `want` candidates (four times its recent batch), and the count histogram it picks its threshold from is too
+  // coarse for that (8 bins per power of two): on natural text the top list's counts sit in one or two bins, and every round sent the
+  // WHOLE list -- 570 candidates on Zipf text for batches of 8 -- through the mailbox and the host's heap.  When the list fits one pass the
+  // scan refines the threshold itself: boundary bin from the histogram, 64 sub-bins inside it, candidates = every entry at or above the
+  // refined count (a complete prefix of the order, as the host needs; it reads the threshold back as the smallest count it got).
+  const bool refine = sa.want != 0 && tn != 0 && tn <= (unsigned int)(NT * TAIL_E);
   for (unsigned int base = 0; base < tn; base += NT * TAIL_E) {
     uint32_t sl[TAIL_E];
     unsigned long long k[TAIL_E], c[TAIL_E];
@@ -179,19 +187,92 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
         const int bin = cand_bin(cc);
         atomicAdd(&lh[bin], 1u);
         if ((unsigned int)bin > ctl[3]) atomicMax(&ctl[3], (unsigned int)bin);
-        const uint32_t x = (uint32_t)(k[e] >> 32), y = (uint32_t)k[e];
-        const uint32_t mx = x > y ? x : y;
-        if (cc > sa.tau_cnt || (cc == sa.tau_cnt && mx <= sa.tau_mx)) {
-          const unsigned int o = atomicAdd(&ctl[1], 1u);
-          if (o < sa.cap) {
-            sa.out[o].key = k[e];
-            sa.out[o].cnt = cc;
+        c[e] = cc;  // (the live count, for the emission below)
+      }
+    }
+    unsigned long long tau_ref = 0;  // candidates must also reach this count
+    if (refine) {  // (uniform; one pass: the histogram is complete after the barrier)
+      __syncthreads();
+      if (wave == 0) {  // the bin in which the `want`-th largest count lies: lane l owns bins [11 l, 11 l + 11), summed from the top lane down
+        static_assert(CAND_BINS == 64 * 11, "eleven bins per lane");
+        unsigned int mine_b = 0;
+        for (int b = 0; b < 11; b++) mine_b += lh[lane * 11 + b];
+        unsigned int above = 0;  // entries in the bins of the lanes above me
+        {
+          unsigned int v = mine_b;
+          for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t = __shfl_down(v, o);
+            if (lane + o < 64) v += t;
           }
-          if (o < sa.fast) {
-            uint4 vv;
-            vv.x = (uint32_t)k[e]; vv.y = (uint32_t)(k[e] >> 32); vv.z = (uint32_t)cc; vv.w = (uint32_t)(cc >> 32);
-            box_out[o] = vv;
+          above = v - mine_b;
+        }
+        if (above < sa.want && above + mine_b >= sa.want) {  // (exactly one lane, if the list holds `want` entries at all)
+          unsigned int acc = above;
+          for (int b = 10; b >= 0; b--) {
+            const unsigned int h = lh[lane * 11 + b];
+            if (acc + h >= sa.want) {
+              sub[66] = (unsigned int)(lane * 11 + b) + 1u;  // boundary bin + 1 (0: none)
+              sub[67] = acc;
+              break;
+            }
+            acc += h;
           }
+        }
+      }
+      __syncthreads();
+      const unsigned int bb = sub[66];
+      if (bb) {
+        const int B = (int)bb - 1;
+        unsigned long long lo = (unsigned long long)B;
+        int shift = 0;
+        bool wide = false;
+        if (B >= 256) {
+          const int ex = 8 + (B - 256) / 8, m3 = (B - 256) % 8;
+          lo = (unsigned long long)(8 + m3) << (ex - 3);
+          wide = true;
+          shift = ex - 3 > 6 ? ex - 3 - 6 : 0;  // (the bin is 2^(ex-3) counts wide: 64 sub-bins)
+        }
+        tau_ref = lo;
+        if (wide) {
+#pragma unroll
+          for (int e = 0; e < TAIL_E; e++)
+            if (((keepm >> e) & 1u) && cand_bin(c[e]) == B) atomicAdd(&sub[(unsigned int)((c[e] - lo) >> shift) & 63u], 1u);
+          __syncthreads();
+          if (wave == 0) {  // lane s: entries of the sub-bins s .. 63 plus those above the bin; the highest s that reaches `want` is the threshold
+            unsigned int v = sub[lane];
+            for (int o = 1; o < 64; o <<= 1) {
+              const unsigned int t = __shfl_down(v, o);
+              if (lane + o < 64) v += t;
+            }
+            const unsigned long long ok = __ballot(sub[67] + v >= sa.want);  // (lane 0 always: the bin was chosen so)
+            const int sb = ok ? 63 - __clzll((long long)ok) : 0;
+            if (lane == 0) {
+              const unsigned long long t = lo + ((unsigned long long)sb << shift);
+              sub[64] = (unsigned int)t;
+              sub[65] = (unsigned int)(t >> 32);
+            }
+          }
+          __syncthreads();
+          tau_ref = ((unsigned long long)sub[65] << 32) | sub[64];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < TAIL_E; e++) {
+      if (!((keepm >> e) & 1u)) continue;
+      const unsigned long long cc = c[e];
+      const uint32_t x = (uint32_t)(k[e] >> 32), y = (uint32_t)k[e];
+      const uint32_t mx = x > y ? x : y;
+      if (cc >= tau_ref && (cc > sa.tau_cnt || (cc == sa.tau_cnt && mx <= sa.tau_mx))) {
+        const unsigned int o = atomicAdd(&ctl[1], 1u);
+        if (o < sa.cap) {
+          sa.out[o].key = k[e];
+          sa.out[o].cnt = cc;
+        }
+        if (o < sa.fast) {
+          uint4 vv;
+          vv.x = (uint32_t)k[e]; vv.y = (uint32_t)(k[e] >> 32); vv.z = (uint32_t)cc; vv.w = (uint32_t)(cc >> 32);
+          box_out[o] = vv;
         }
       }
     }

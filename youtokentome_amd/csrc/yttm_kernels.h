@@ -78,6 +78,7 @@ struct ScanArgs {
   unsigned int *done_ctr;      // ticket of finished workgroups (left at 0); nullptr: a single-workgroup launch
   unsigned char *mailbox;      // the host's pinned mailbox, or (round_id == 0) a staging block in HBM with the same layout
   uint32_t round_id;           // published in the mailbox when everything else is there; 0: nothing is published
+  uint32_t want;               // != 0: about this many candidates are wanted -- the scan may raise the threshold by itself (scan_top: refine)
   uint32_t timed;              // the round's first launch left its start time in stats[STAT_T0]: the mailbox gets the duration (100 MHz ticks)
 };
 constexpr int STAT_T0 = 6;  // stats[6]: wall_clock64() at the start of the round's first launch
