@@ -108,7 +108,7 @@ def test_k4_worklist_mode(tmp_path, monkeypatch):
 
 
 def test_k4_word_mode(tmp_path, monkeypatch):
-    """Word mode (k_wgather + k_words + k_delta_apply) forced on from the second round whatever the corpus size: golden
+    """Word mode (one launch per round, k_words<FUSED>, and k_wgather + k_words + k_delta_apply) forced on from the second round whatever the corpus size: golden
     corpora, random text of three scripts and a Zipf corpus against the oracle; then with tiny hot lists (index rebuilds, rounds over
     every word), overflowing record regions and record log; then the 100 MB pins of configs[1] and of the CJK-shaped corpus with the
     default switch rule (only the size floor lifted), single GPU and through an RCCL communicator of one rank."""
@@ -120,8 +120,8 @@ def test_k4_word_mode(tmp_path, monkeypatch):
     for k in ("YTTM_WORD_MIN_TILES", "YTTM_WORD_MIN_TOKENS", "YTTM_WORD_DIV"):
         monkeypatch.setenv(k, "0")
     rng = random.Random(5)
-    for cfg in (None, {"YTTM_HOT_TARGET": 40, "YTTM_HOT_MIN": 4, "YTTM_HOT_CAP": 400, "YTTM_WORD_DREC": 64, "YTTM_INDEX_AGG_MIN": 0},
-                {"YTTM_WORD_LOG": 3000, "YTTM_WORDS_INLINE_MAX": 0}):
+    for cfg in (None, {"YTTM_WORDS_FUSE_MAX": 0}, {"YTTM_HOT_TARGET": 40, "YTTM_HOT_MIN": 4, "YTTM_HOT_CAP": 400, "YTTM_WORD_DREC": 64, "YTTM_INDEX_AGG_MIN": 0},
+                {"YTTM_WORD_LOG": 3000, "YTTM_WORDS_INLINE_MAX": 0, "YTTM_WORDS_FUSE_MAX": 0}, {"YTTM_WORD_LOG": 3000, "YTTM_WORD_DREC": 16, "YTTM_WORDS_GRID": 3}):
         for k, v in (cfg or {}).items():
             monkeypatch.setenv(k, str(v))
         for name in ("readme_small", "runs", "mix_cov", "zipf"):

@@ -358,10 +358,12 @@ def test_worklists_from_the_pair_index(tmp_path, monkeypatch):
 
 
 def test_word_mode(tmp_path, monkeypatch):
-    """Word mode (k_wgather + k_words + k_delta_apply: class-A words in fixed slots, a round visits the words that hold a merge site, found
-    through the pair index at word granularity or the instance list of the pair's younger token) forced on from the second round, on
-    corpora of several tiles; then with tiny hot lists (an index build per rebuild, rounds over every word while the list is overflowed),
-    a record log and record regions that overflow, the count updates through k_delta_apply instead of the small rounds' own tail: same models as the oracle."""
+    """Word mode (class-A words in fixed slots, a round visits the words that hold a merge site, found through the pair index at word
+    granularity or the instance list of the pair's younger token) forced on from the second round, on corpora of several tiles: the round
+    as ONE launch (k_words<FUSED>, the default) and as k_wgather + k_words + k_delta_apply (YTTM_WORDS_FUSE_MAX=0); then with tiny hot lists
+    (an index build per rebuild, rounds over every word while the list is overflowed), a record log and record regions that overflow, in
+    both forms, the count updates through k_delta_apply instead of the small rounds' own tail, few workgroups (several gather passes per
+    workgroup): same models as the oracle."""
     import ctypes as C
     import filecmp
     import json
@@ -375,11 +377,21 @@ def test_word_mode(tmp_path, monkeypatch):
     cases = [(gen.readme_corpus(300, 100, seed=6), 900), (gen.zipf_corpus(120000, vocab=3000), 700),
              (gen.unicode_text(rng, 30000, "ascii"), 400), (("aaaa aaaaa abababab aabbaabb bbbbbb ab aaab baaa " * 400).encode(), 60),
              (gen.unicode_text(rng, 20000, "cjk"), 600)]
-    word_rounds = all_rounds = builds = 0
-    for cfg in (None, {"YTTM_HOT_TARGET": 40, "YTTM_HOT_MIN": 4, "YTTM_HOT_CAP": 400, "YTTM_WORD_DREC": 64, "YTTM_INDEX_AGG_MIN": 0}, {"YTTM_WORD_LOG": 300, "YTTM_WORDS_INLINE_MAX": 0}):
+    word_rounds = all_rounds = builds = fused = 0
+    # (the emulator's time goes with the workgroups it runs: the grids the launchers would pick on two corpora only, a few workgroups --
+    # several gather passes each -- elsewhere)
+    small = {"YTTM_WORDS_GRID": 3, "YTTM_WGATHER_GRID": 2}
+    tiny_hot = {"YTTM_HOT_TARGET": 40, "YTTM_HOT_MIN": 4, "YTTM_HOT_CAP": 400, "YTTM_WORD_DREC": 64}
+    for cfg, which in ((None, (1, 3)), ({"YTTM_WORDS_FUSE_MAX": 0}, (3, 4)), (small, (0, 1, 2, 3, 4)), ({"YTTM_WORDS_FUSE_MAX": 0, **small}, (0, 1, 2, 3, 4)),
+                       ({"YTTM_INDEX_AGG_MIN": 0, **tiny_hot, **small}, (0, 1, 2, 3, 4)), ({"YTTM_WORDS_FUSE_MAX": 0, **tiny_hot, **small}, (0, 2, 4)),
+                       ({"YTTM_WORD_LOG": 300, "YTTM_WORDS_INLINE_MAX": 0, "YTTM_WORDS_FUSE_MAX": 0, **small}, (0, 1, 2, 4)),
+                       ({"YTTM_WORD_LOG": 300, "YTTM_WORD_DREC": 16, **small}, (0, 1, 2, 4)),
+                       ({"YTTM_WORDS_FUSE_MAX": 4400, "YTTM_WORDS_GRID": 1, "YTTM_WGATHER_GRID": 1}, (0, 1, 2, 4))):
         for k, v in (cfg or {}).items():
             monkeypatch.setenv(k, str(v))
         for i, (text, vocab) in enumerate(cases):
+            if i not in which:
+                continue
             corpus, m_gpu, m_ora = str(tmp_path / f"c{i}.txt"), str(tmp_path / f"g{i}.model"), str(tmp_path / f"o{i}.model")
             open(corpus, "wb").write(text)
             err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
@@ -391,6 +403,7 @@ def test_word_mode(tmp_path, monkeypatch):
             word_rounds += r["word_rounds"]
             all_rounds += r["word_all_rounds"]
             builds += r["index_builds"]
+            fused += r["word_fused_rounds"]
         for k in (cfg or {}):
             monkeypatch.delenv(k)
-    assert word_rounds > 500 and all_rounds > 10 and builds > 20, (word_rounds, all_rounds, builds)
+    assert word_rounds > 1000 and all_rounds > 10 and builds > 20 and 500 < fused < word_rounds - 500, (word_rounds, all_rounds, builds, fused)

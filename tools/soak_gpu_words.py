@@ -12,7 +12,7 @@ L = _lib.load()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 HOOKS = ("YTTM_WORD_MODE", "YTTM_WORD_DIV", "YTTM_WORD_MIN_TOKENS", "YTTM_WORD_MIN_TILES", "YTTM_WORDS_INLINE_MAX", "YTTM_WORD_DREC", "YTTM_WORD_LOG",
-         "YTTM_INDEX_AGG_MIN", "YTTM_HOT_TARGET", "YTTM_HOT_TARGET_WORDS", "YTTM_NO_FUSE", "YTTM_NO_REFINE")
+         "YTTM_WORDS_FUSE_MAX", "YTTM_WORDS_GRID", "YTTM_INDEX_AGG_MIN", "YTTM_HOT_TARGET", "YTTM_HOT_TARGET_WORDS", "YTTM_NO_FUSE", "YTTM_NO_REFINE")
 
 
 def train(d, vocab, out, env):
@@ -25,7 +25,7 @@ def train(d, vocab, out, env):
     return json.loads(rep.value.decode())
 
 
-t0, n, wr, ar = time.time(), 0, 0, 0
+t0, n, wr, ar, fr = time.time(), 0, 0, 0, 0
 while time.time() - t0 < budget:
     mb = rng.choice([3, 8, 20, 40, 60])
     kind = rng.choice(["abcd", "abcd", "ab", "zipf", "zipfbig", "cjk"])
@@ -44,6 +44,7 @@ while time.time() - t0 < budget:
     d = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
     env = {"YTTM_WORD_MIN_TOKENS": "0", "YTTM_WORD_MIN_TILES": "0", "YTTM_WORD_DIV": rng.choice(["0", "4", "50", "200"])}
     env.update(rng.choice([{}, {}, {"YTTM_WORDS_INLINE_MAX": "0"}, {"YTTM_WORD_DREC": str(rng.choice([64, 1024]))}, {"YTTM_WORD_LOG": str(rng.choice([20000, 500000]))},
+                           {"YTTM_WORDS_FUSE_MAX": "0"}, {"YTTM_WORDS_FUSE_MAX": "200000"}, {"YTTM_WORDS_FUSE_MAX": "200000", "YTTM_WORDS_GRID": str(rng.choice([1, 7, 64]))},
                            {"YTTM_INDEX_AGG_MIN": "0"}, {"YTTM_HOT_TARGET": "512", "YTTM_HOT_TARGET_WORDS": "1024"}, {"YTTM_NO_FUSE": "1"}, {"YTTM_NO_REFINE": "1"}]))
     r = train(d, vocab, "/tmp/sgw_w.model", env)
     train(d, vocab, "/tmp/sgw_t.model", {"YTTM_WORD_MODE": "0"})
@@ -54,5 +55,6 @@ while time.time() - t0 < budget:
     n += 1
     wr += r["word_rounds"]
     ar += r["word_all_rounds"]
+    fr += r["word_fused_rounds"]
     del d
-print("gpu word-mode soak ok: %d corpora, %d word-mode rounds (%d of them over every word) in %.0f s" % (n, wr, ar, time.time() - t0), flush=True)
+print("gpu word-mode soak ok: %d corpora, %d word-mode rounds (%d of them one launch each, %d over every word) in %.0f s" % (n, wr, fr, ar, time.time() - t0), flush=True)

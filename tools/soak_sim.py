@@ -76,12 +76,14 @@ while time.time() - t0 < budget:
                             {"YTTM_INDEX_ALWAYS": "1", "YTTM_INDEX_MIN_TILES": "1", "YTTM_TOP_TARGET": "16", "YTTM_TOP_MIN": "4", "YTTM_TOP_CAP": "64"}])
         os.environ.update(hooks)
         if words_mode:
-            for k in ("YTTM_WORD_LOG", "YTTM_WORD_DREC", "YTTM_WORDS_INLINE_MAX", "YTTM_INDEX_AGG_MIN", "YTTM_WORDS_WPI"):
+            for k in ("YTTM_WORD_LOG", "YTTM_WORD_DREC", "YTTM_WORDS_INLINE_MAX", "YTTM_INDEX_AGG_MIN", "YTTM_WORDS_WPI", "YTTM_WORDS_FUSE_MAX", "YTTM_WORDS_GRID"):
                 os.environ.pop(k, None)
             os.environ.update({"YTTM_WORD_MIN_TILES": "0", "YTTM_WORD_MIN_TOKENS": "0", "YTTM_WORD_DIV": rng.choice(["0", "0", "2", "8"])})
             os.environ.pop("YTTM_INDEX_ALWAYS", None)
             os.environ.update(rng.choice([{}, {"YTTM_WORD_LOG": str(rng.choice([50, 300, 2000]))}, {"YTTM_WORD_DREC": str(rng.choice([8, 64]))},
-                                          {"YTTM_WORDS_INLINE_MAX": "0"}, {"YTTM_INDEX_AGG_MIN": "0"},
+                                          {"YTTM_WORDS_INLINE_MAX": "0"}, {"YTTM_INDEX_AGG_MIN": "0"}, {"YTTM_WORDS_FUSE_MAX": "0"},
+                                          {"YTTM_WORDS_FUSE_MAX": str(rng.choice([4200, 4500, 6000]))}, {"YTTM_WORDS_GRID": str(rng.choice([1, 2, 5]))},
+                                          {"YTTM_WORDS_FUSE_MAX": "4400", "YTTM_WORD_LOG": "500", "YTTM_WORDS_GRID": "2"},
                                           {"YTTM_WORD_LOG": "200", "YTTM_WORD_DREC": "16", "YTTM_WORDS_INLINE_MAX": "0", "YTTM_INDEX_AGG_MIN": "0"}]))
     ids = rng.choice([(0, 1, 2, 3), (3, 2, 1, 0), (-1, 0, -1, -1), (5, 7, -1, 2)])
     try:

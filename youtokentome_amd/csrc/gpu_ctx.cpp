@@ -175,6 +175,9 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   use_pm_ = env_uint("YTTM_K4_PM", 0) != 0;
   idx_agg_min_ = env_uint("YTTM_INDEX_AGG_MIN", 16u << 20);  // (fill pass of an index build: postings from which on a workgroup sums them per key in LDS first; tests: 0)
   hot_target_words_ = env_uint("YTTM_HOT_TARGET_WORDS", 1u << 15);  // (measured at 1 GB, word mode: 8192 -> 6 rebuilds, candidate family 21.0 ms; 32768 -> 3, 16.9 ms)
+  // rounds of at most this many words (by the hint) whose batch travels in the kernel arguments are ONE launch, k_words<FUSED>; 0: never.
+  // (1 GB random text, wall / K4 ms: never 138.3 / 86.0, 32 k 136.6 / 83.3, 256 k 133.1 / 80.2, 2 M 125.9 / 73.5, every round 125.0 / 72.5)
+  words_fuse_max_ = env_uint("YTTM_WORDS_FUSE_MAX", 1u << 30);
   words_inline_max_ = env_uint("YTTM_WORDS_INLINE_MAX", 1u << 18);  // (measured at 1 GB, K4 ms: 16 k -> 97.2, 64 k -> 95.4, 256 k -> 94.1)
   profile_events_ = env_uint("YTTM_PROFILE_EVENTS", 0) != 0;
   words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end, worklists of tiles from the pair index)
@@ -1411,7 +1414,7 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
   // every record ever matched is a site at most once through each of its two neighbours, and a site removes a token: a few records per
   // live token bound the log between two index builds; should it fill up all the same, the round says so and the index is rebuilt
   const unsigned long long live = std::max<unsigned long long>(live_tokens_last_, 1ull << 16);
-  static const unsigned long long log_env = getenv("YTTM_WORD_LOG") ? strtoull(getenv("YTTM_WORD_LOG"), nullptr, 10) : 0;  // (tests: a log that overflows)
+  const unsigned long long log_env = getenv("YTTM_WORD_LOG") ? strtoull(getenv("YTTM_WORD_LOG"), nullptr, 10) : 0;  // (tests: a log that overflows)
   tl_.log_cap = log_env ? log_env : 2 * live + (1ull << 20);
   tl_.rec_word = dmalloc<uint32_t>(tl_.log_cap);
   tl_.rec_l = dmalloc<uint32_t>(tl_.log_cap);
@@ -1723,6 +1726,8 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       ga.xyz = d_xyz;
       ga.k = k;
       ga.z_base = z_base;
+      if (by_args)
+        for (uint32_t j = 0; j < k; j++) ga.cnt[j] = rule_counts ? (uint32_t)std::min<unsigned long long>(rule_counts[j], 0xffffffffull) : 0xffffffffu;
       if (!d_stamp_) {  // (the index could not be built yet: no stamps either -- the gather must not claim words)
         stamp_cap_ = (unsigned int)(c.n_unique + c.n_unique / 8 + 64);
         d_stamp_ = dmalloc<uint32_t>(stamp_cap_);
@@ -1732,10 +1737,10 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       const unsigned int work_hint = sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + 4096, 1ull << 30) : 0u;
       ga.stats = d_stats_;
       const BatchArgs gba = first_ba();
-      launch_wgather(ga, &gba, work_hint, st_);
       const WordSet wset{c.d_tok, d_wmeta_, c.d_wcnt, (uint32_t)c.n_unique};
-      launch_words_apply(wset, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, d_irec_, &ba,
-                         sa.on && last_cls == 0 ? &sa : nullptr, work_hint, words_inline_max_, st_);
+      if (launch_words_apply(wset, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, d_irec_, &gba,
+                             sa.on && last_cls == 0 ? &sa : nullptr, work_hint, words_inline_max_, &ga, words_fuse_max_, st_))
+        word_fused_rounds++;
       word_rounds++;
       if (!idx_valid_) word_all_rounds++;
       continue;

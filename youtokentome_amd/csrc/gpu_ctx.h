@@ -89,7 +89,7 @@ class GpuCtx {
   const unsigned long long *last_hist() const { return last_hist_; }
   unsigned long long last_live() const { return last_live_; }
   int last_top_bin() const { return (int)last_top_bin_; }  // no bin above this one is in use
-  unsigned long long index_builds = 0, gathered_rounds = 0, pm_rounds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0;  // K4 rounds whose worklist came from the pair index
+  unsigned long long index_builds = 0, gathered_rounds = 0, pm_rounds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0, word_fused_rounds = 0;  // K4 rounds whose worklist came from the pair index
   unsigned long long word_table_retries = 0;  // K2: the word table had to be redone with the worst-case size
   unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0, delta_regrows = 0;
   unsigned long long tail_ticks[3] = {0, 0, 0}, tail_listed = 0;  // round_tail: fold / list scan / publish, in 10 ns ticks; entries it read
@@ -203,7 +203,7 @@ class GpuCtx {
   bool profile_events_ = false, dev_timing_pending_ = false;  // (merge_apply: dev_timing)
   std::vector<float> dev_round_ms_;
   bool word_mode_ = false, words_enabled_ = true;
-  unsigned int hot_target_words_ = 1u << 15, words_inline_max_ = 1u << 18;
+  unsigned int hot_target_words_ = 1u << 15, words_inline_max_ = 1u << 18, words_fuse_max_ = 1u << 30;
   unsigned int word_div_ = 200;    // switch when (merge sites of the last round) * word_div_ < (tokens a pass over the tiles streams)
   unsigned int word_min_tiles_ = 16384;
   unsigned long long idx_agg_min_ = 16ull << 20, word_min_tokens_ = 48ull << 20;

@@ -298,6 +298,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     rep->word_rounds = g.word_rounds;
     rep->word_switch_round = g.word_switch_round;
     rep->word_all_rounds = g.word_all_rounds;
+    rep->word_fused_rounds = g.word_fused_rounds;
     rep->rules = rules.size();
     rep->n_unique = g.n_unique;
     rep->n_tokens = g.n_tokens0;

@@ -2176,7 +2176,7 @@ __global__ __launch_bounds__(WG_NT) void k_wgather(WGatherArgs g, BatchArgs ba) 
     if (w < wave) before += s_wsum[w];
     all += s_wsum[w];
   }
-  const unsigned long long cur = *g.tl.cursor;
+  const unsigned long long cur = g.tl.cursor[g.round_id & 1u];  // (a round reads the cursor of its parity and leaves the other one: k_words<FUSED>)
   const bool fits = cur + all <= g.tl.log_cap && !g.work_n[WL_PARTS + 1];
   for (uint32_t j = (uint32_t)tid * per; j < ((uint32_t)tid + 1) * per && j < k; j++) {
     const uint32_t z = g.z_base + j;
@@ -2188,8 +2188,8 @@ __global__ __launch_bounds__(WG_NT) void k_wgather(WGatherArgs g, BatchArgs ba) 
   }
   __syncthreads();
   if (tid == 0) {
-    if (fits) *g.tl.cursor = cur + all;
-    else __hip_atomic_store(g.tl.broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (log full, or a round that took every word: its matches say nothing about its sites)
+    g.tl.cursor[(g.round_id + 1u) & 1u] = fits ? cur + all : cur;
+    if (!fits) __hip_atomic_store(g.tl.broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (log full, or a round that took every word: its matches say nothing about its sites)
     *g.done_ctr = 0u;
   }
 }
@@ -2200,15 +2200,32 @@ struct WordsLds {
   unsigned long long newsite[TILE_SLOT_A / 64];  // bit q: the token at position q of the compacted tile is a new one
   uint32_t wnew[66];                             // start of word i in the compacted tile; [nw] = its length
 };
-template <int WPB, bool LDSR>
+// FUSED (a small round, a batch that travels in the kernel arguments): no k_wgather before this kernel and no worklist in HBM -- every
+// workgroup looks the rules up itself, takes its share of their runs, claims the words (stamps) into a list in LDS and works through that
+// list.  The new tokens' lists are allotted without a count of the matches: rule j gets min(its run's length, the pair's count the host
+// picked it by) records -- no fewer than its sites (a site is a candidate record, and every site adds at least one to the count) --
+// from the cursor of the round's parity; every workgroup works that out alike and workgroup 0 writes it down for the rounds to come.
+// (Moving the records AFTER the candidates were published, by the last workgroup, was tried: that tail -- one workgroup reading every
+// region across XCDs -- took 40 us a round, far longer than the host's turn it was meant to hide in.)
+constexpr int FUSE_LIST = 4096, FUSE_PASS = 2048, FUSE_WORD_COST = 32;  // (words claimed go to a list in LDS, FUSE_PASS candidate records at a time; the words are worked on when another pass might not fit)
+template <int WPB, bool LDSR, bool FUSED>
 __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules, unsigned int rule_mask,
                                                     const uint32_t *__restrict__ bloom_g, uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules,
                                                     const uint32_t *__restrict__ worklist, unsigned long long wl_seg,
                                                     const unsigned int *__restrict__ work_n, unsigned long long *__restrict__ stats, TokLists tl,
                                                     DeltaRec *__restrict__ drec, unsigned int drec_cap /* per workgroup */, unsigned int *__restrict__ drec_n,
                                                     uint4 *__restrict__ irec /* new-instance records, a region of drec_cap per workgroup too */, unsigned int wpi,
-                                                    unsigned int inline_apply /* needs sa.on */, BatchArgs ba, ScanArgs sa) {
+                                                    unsigned int inline_apply /* needs sa.on */, BatchArgs ba, ScanArgs sa, WGatherArgs g /* FUSED */) {
   constexpr int SLOT = TILE_SLOT_A;
+  static_assert(!FUSED || (LDSR && BATCH_ARGS_MAX <= WPB * 64 && FUSE_PASS % (WPB * 64) == 0 && FUSE_PASS <= FUSE_LIST), "the fused round: rules from the arguments, one thread per rule");
+  __shared__ unsigned long long f_base[FUSED ? BATCH_ARGS_MAX : 1], f_pref[FUSED ? BATCH_ARGS_MAX + 1 : 1];
+  __shared__ uint32_t f_filt[FUSED ? BATCH_ARGS_MAX : 1], f_list[FUSED ? FUSE_LIST : 1];
+  __shared__ uint8_t f_mode[FUSED ? BATCH_ARGS_MAX : 1];
+  __shared__ unsigned long long f_lbase[FUSED ? BATCH_ARGS_MAX : 1];  // the new tokens' lists: allotted by every workgroup alike, from the same numbers
+  __shared__ uint32_t f_lcap[FUSED ? BATCH_ARGS_MAX : 1];
+  __shared__ unsigned long long f_wpref[FUSED ? BATCH_ARGS_MAX + 1 : 1];  // the runs' cost (records to read + words to work on), summed like f_pref
+  __shared__ unsigned long long f_tmp[4];
+  __shared__ unsigned int f_n, f_every;
   __shared__ WaveLds<SLOT> WL[WPB];
   __shared__ WordsLds XL[WPB];
   __shared__ unsigned int dn;  // records of this workgroup
@@ -2247,26 +2264,182 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
     }
   }
   const RuleTab<LDSR> rtab{rkeys, rridx, rules, rule_mask, z_base};
+  if (FUSED && threadIdx.x == 0) {
+    f_n = 0;
+    f_every = 0;
+    if (ba.mark && blockIdx.x == 0) __hip_atomic_store(&stats[STAT_T0], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
   const int wave = uni((int)(threadIdx.x >> 6)), lane = lane_id();
+  if (FUSED) {  // where each rule's candidates are (as k_wgather: a posting run of the index, or the younger token's instance list)
+    const PairIndex ix{g.ix.key, g.ix.cnt, g.ix.off, g.ix.bloom, g.ix.post, g.ix.mask};
+    const uint32_t j = threadIdx.x;
+    unsigned long long len = 0, lcap = 0;
+    bool f_mode_of_mine = false;
+    if (j < ba.k) {
+      const uint32_t x = ba.xy[2 * j], y = ba.xy[2 * j + 1];
+      const uint32_t m = x > y ? x : y;
+      unsigned long long base = 0;
+      uint32_t filt = 0, mode = 0;
+      bool found = true;
+      if (m < g.z_static) {
+        uint32_t s = 0xffffffffu;
+        if (g.ix_valid) s = idx_find(ix, pair_key(x, y), enc_hash(x, y));
+        if (s == 0xffffffffu) {
+          f_every = 1u;  // not in the index: this round takes every word
+          found = false;
+        } else {
+          base = ix.off[(size_t)s * IDX_SHARDS];
+          len = ix.off[((size_t)s + 1) * IDX_SHARDS] - base;
+        }
+      } else {
+        base = g.tl.base[m];
+        const uint32_t f = g.tl.fill[m], c = g.tl.cap[m];
+        len = f < c ? f : c;
+        if (x > y) { mode = 2; filt = y; } else { mode = 1; filt = x; }
+      }
+      f_base[j] = base;
+      f_filt[j] = filt;
+      f_mode[j] = (uint8_t)mode;
+      f_mode_of_mine = mode != 0;
+      const unsigned long long cj = g.cnt[j];
+      lcap = found && len < cj ? len : cj;
+    }
+    static_assert(BATCH_ARGS_MAX <= 128, "two waves scan the runs");
+    // what a run costs: a record to read each, and FUSE_WORD_COST of those per word to work on -- every posting's word, but only the
+    // records of an instance list that have the right neighbour (about as many as the pair's count says)
+    const unsigned long long wgt = len + (unsigned long long)FUSE_WORD_COST * (f_mode_of_mine ? lcap : len);
+    unsigned long long inc = len, cinc = lcap, winc = wgt;
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long t = __shfl_up(inc, o), tc = __shfl_up(cinc, o), tw = __shfl_up(winc, o);
+      if (lane >= o) { inc += t; cinc += tc; winc += tw; }
+    }
+    if (threadIdx.x == 63) { f_tmp[0] = inc; f_tmp[1] = cinc; f_tmp[2] = winc; }  // (wave 0's sums)
+    if (threadIdx.x == 127) f_tmp[3] = cinc;                                      // (wave 1's sum of the allotments)
+    __syncthreads();
+    const unsigned long long w0 = f_tmp[0], wc0 = f_tmp[1], ww0 = f_tmp[2];
+    const unsigned long long call = wc0 + f_tmp[3];
+    if (wave == 1) { inc += w0; cinc += wc0; winc += ww0; }
+    const unsigned long long cur = g.tl.cursor[g.round_id & 1u];
+    const bool fits = cur + call <= g.tl.log_cap;
+    if (j < ba.k) {
+      f_pref[j] = inc - len;
+      f_wpref[j] = winc - wgt;
+      f_lbase[j] = cur + (cinc - lcap);
+      f_lcap[j] = fits ? (uint32_t)lcap : 0u;
+      if (blockIdx.x == 0) {
+        g.tl.base[z_base + j] = cur + (cinc - lcap);
+        g.tl.cap[z_base + j] = fits ? (uint32_t)lcap : 0u;  // (their fill counts are at zero: enter_word_mode -- a token is new once)
+      }
+    }
+    if (j + 1 == ba.k) { f_pref[ba.k] = inc; f_wpref[ba.k] = winc; }
+    if (ba.k == 0 && j == 0) { f_pref[0] = 0; f_wpref[0] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      g.tl.cursor[(g.round_id + 1u) & 1u] = fits ? cur + call : cur;
+      if (!fits) __hip_atomic_store(g.tl.broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (log full: the index is rebuilt)
+    }
+    __syncthreads();
+  }
   WaveLds<SLOT> &W = WL[wave];
   WordsLds &X = XL[wave];
   const TileSet ts{ws.tok, nullptr, nullptr, ws.wcnt, 0u};
   const DeltaOut dout{drec + (size_t)blockIdx.x * drec_cap, &dn, drec_cap};
   uint4 *my_irec = irec + (size_t)blockIdx.x * drec_cap;
   // work items: runs of 64 worklist entries, or of 64 words
-  if (worklist && work_n[WL_PARTS + 1]) worklist = nullptr;
+  const bool listed = FUSED && !f_every;  // (uniform; a fused round that must take every word walks them like an unfused one)
+  if (FUSED) worklist = nullptr;
+  else if (worklist && work_n[WL_PARTS + 1]) worklist = nullptr;
   const uint32_t wl_n = worklist ? work_n[0] : 0u;
   // (wpi words per work item: 64 when there are words for every wave; fewer in the small late rounds -- a wave's time goes with the tokens
   // of its tile, and the chip has thousands of idle wave slots then)
-  const unsigned long long n_all = worklist ? (unsigned long long)wl_n : (unsigned long long)ws.n_words;
-  const unsigned long long n_items = (n_all + wpi - 1ull) / wpi;
+  const unsigned long long n_glob = worklist ? (unsigned long long)wl_n : (unsigned long long)ws.n_words;
   (void)wl_seg;
+  // fused: my share of the rules' runs laid end to end -- one stretch of records (the words of neighbouring postings are neighbours in
+  // HBM; shares dealt out in small blocks cost the big rounds of random text 180 -> 270 us), cut by COST, not by records: the words
+  // are what takes the time, and a posting is a word where a record of an instance list mostly is not (equal record counts left some
+  // workgroups with all the words: CJK-shaped text, rounds 200 .. 700, 260 -> 440 us)
+  const unsigned long long f_total = listed ? f_pref[ba.k] : 0ull;
+  unsigned long long f_pos = 0, f_hi = 0;
+  if (listed) {
+    const unsigned long long wtotal = f_wpref[ba.k], wchunk = (wtotal + gridDim.x - 1) / gridDim.x;
+    auto rec_of = [&](unsigned long long w) -> unsigned long long {  // the record at cost w from the start (monotonic)
+      if (w >= wtotal) return f_total;
+      uint32_t a = 0, b = ba.k;
+      while (b - a > 1) {
+        const uint32_t mid = (a + b) >> 1;
+        if (f_wpref[mid] <= w) a = mid; else b = mid;
+      }
+      const unsigned long long wa = f_wpref[a + 1] - f_wpref[a], la = f_pref[a + 1] - f_pref[a];
+      if (!wa) return f_pref[a];
+      unsigned long long off = (unsigned long long)((double)(w - f_wpref[a]) / (double)wa * (double)la);
+      if (off > la) off = la;
+      return f_pref[a] + off;
+    };
+    const unsigned long long lo_w = (unsigned long long)blockIdx.x * wchunk < wtotal ? (unsigned long long)blockIdx.x * wchunk : wtotal;
+    f_pos = rec_of(lo_w);
+    f_hi = rec_of(lo_w + wchunk);
+  }
   TileStats S;
 #ifdef YTTM_K4_PROF
   S.t_last = (unsigned long long)clock64();
 #endif
-  for (unsigned long long item = (unsigned long long)blockIdx.x * WPB + (unsigned long long)wave; item < n_items; item += (unsigned long long)gridDim.x * WPB) {
+  for (;;) {  // (once; fused: once per list of claimed words)
+  unsigned long long n_all = n_glob, item0 = (unsigned long long)blockIdx.x * WPB + (unsigned long long)wave, istride = (unsigned long long)gridDim.x * WPB;
+  if (listed) {
+    while (f_pos < f_hi) {  // gather: FUSE_PASS records of my share at a time, until the list could not take another pass
+    const unsigned long long pend = f_pos + FUSE_PASS < f_hi ? f_pos + FUSE_PASS : f_hi;
+    constexpr int NIT = FUSE_PASS / (WPB * 64);
+    uint32_t cw[NIT];
+    bool cok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {  // the records: all loads of the pass in flight together
+      const unsigned long long i = f_pos + (unsigned long long)(it * WPB * 64) + (unsigned long long)threadIdx.x;
+      cw[it] = 0;
+      cok[it] = false;
+      if (i < pend) {
+        uint32_t a = 0, b = ba.k;  // the rule whose run holds record i: the last j with f_pref[j] <= i
+        while (b - a > 1) {
+          const uint32_t mid = (a + b) >> 1;
+          if (f_pref[mid] <= i) a = mid; else b = mid;
+        }
+        const unsigned long long at = f_base[a] + (i - f_pref[a]);
+        const uint32_t mode = f_mode[a];
+        if (mode == 0) {
+          cw[it] = g.ix.post[at];
+          cok[it] = true;
+        } else {
+          cok[it] = (mode == 1 ? g.tl.rec_l[at] : g.tl.rec_r[at]) == f_filt[a];
+          if (cok[it]) cw[it] = g.tl.rec_word[at];
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++)  // each word once per round
+      if (cok[it]) cok[it] = atomicExch(&g.stamp[cw[it]], g.round_id) != g.round_id;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const unsigned long long hm = __ballot(cok[it]);
+      if (hm) {
+        unsigned int b0 = 0;
+        const int fl = __ffsll((long long)hm) - 1;
+        if (lane == fl) b0 = atomicAdd(&f_n, (unsigned int)__popcll(hm));
+        b0 = (unsigned int)__shfl((int)b0, fl);
+        if (cok[it]) f_list[b0 + (unsigned int)__popcll(hm & lanemask_lt())] = cw[it];  // (there is room: see the loop's end)
+      }
+    }
+    f_pos = pend;
+    __syncthreads();
+    const unsigned int n_now = f_n;
+    __syncthreads();  // (every thread has read the length before the next pass adds to it: the decision is the workgroup's)
+    if (n_now > (unsigned int)(FUSE_LIST - FUSE_PASS)) break;
+    }
+    n_all = f_n;
+    if (!n_all) break;  // (my share is done)
+    item0 = (unsigned long long)wave;
+    istride = WPB;
+  }
+  const unsigned long long n_items = (n_all + wpi - 1ull) / wpi;
+  for (unsigned long long item = item0; item < n_items; item += istride) {
     // ---- my word (lane l: entry l of the run)
     bool have;
     uint32_t wid = 0;
@@ -2274,7 +2447,11 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
       const unsigned long long wi = item * (unsigned long long)wpi + (unsigned long long)lane;
       have = (unsigned int)lane < wpi && wi < n_all;
       wid = (uint32_t)wi;
-      if (worklist && have) wid = worklist[wi];
+      if (listed) {
+        if (have) wid = f_list[wi];
+      } else if (worklist && have) {
+        wid = worklist[wi];
+      }
     }
     unsigned long long meta = 0;
     uint32_t wfreq = 0;
@@ -2441,8 +2618,8 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
                   at0 = (uint32_t)__shfl((int)at0, ld);
                   if (direct && z == z0) {
                     const uint32_t at = at0 + (uint32_t)__popcll(same & lanemask_lt());
-                    if (at < tl.cap[z0]) {
-                      const unsigned long long o = tl.base[z0] + at;
+                    if (at < (FUSED ? f_lcap[z0 - z_base] : tl.cap[z0])) {
+                      const unsigned long long o = (FUSED ? f_lbase[z0 - z_base] : tl.base[z0]) + at;
                       tl.rec_word[o] = word_id;
                       tl.rec_l[o] = lnb;
                       tl.rec_r[o] = rnb;
@@ -2467,6 +2644,11 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
       }
       first += nw;
     }
+  }
+  if (!listed) break;
+  __syncthreads();  // (every wave is done with the list)
+  if (threadIdx.x == 0) f_n = 0;
+  __syncthreads();
   }
   {
     S.sites = wave_sum_u64(S.sites);
@@ -2516,8 +2698,8 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
         const uint4 rec = my_irec[i];
         const uint32_t zr = rec.x & 0xfffu, z = z_base + zr;
         const uint32_t at = rcnt[zr] + (rec.x >> 12);
-        if (at < tl.cap[z]) {
-          const unsigned long long o = tl.base[z] + at;
+        if (at < (FUSED ? f_lcap[zr] : tl.cap[z])) {
+          const unsigned long long o = (FUSED ? f_lbase[zr] : tl.base[z]) + at;
           tl.rec_word[o] = rec.y;
           tl.rec_l[o] = rec.z;
           tl.rec_r[o] = rec.w;
@@ -3001,26 +3183,31 @@ void launch_words_init(const TileSet &ts, unsigned long long *wmeta, hipStream_t
 void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, unsigned int work_hint, hipStream_t st) {
   // every workgroup looks all the rules up and takes a ticket at the end: a small round (work_hint = about how many words it will visit;
   // 0: unknown) gets a small grid
-  static const char *g_env = getenv("YTTM_WGATHER_GRID");
+  const char *g_env = getenv("YTTM_WGATHER_GRID");
   unsigned int g = 256u;
   if (work_hint) g = std::max(16u, std::min(256u, work_hint / 1024u));
   if (g_env) g = (unsigned int)atoi(g_env);
   hipLaunchKernelGGL(k_wgather, dim3(g ? g : 1u), dim3(WG_NT), 0, st, a, ba ? *ba : BatchArgs{});
 }
-void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
+bool launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
                         uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules, const uint32_t *worklist, unsigned long long wl_seg,
                         const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, DeltaRec *drec, unsigned int drec_cap, unsigned int *drec_n,
-                        uint4 *irec, const BatchArgs *ba, const ScanArgs *scan, unsigned int work_hint, unsigned int inline_max, hipStream_t st) {
-  if (!ws.n_words) return;
-  const BatchArgs bargs = ba ? *ba : BatchArgs{};
+                        uint4 *irec, const BatchArgs *ba, const ScanArgs *scan, unsigned int work_hint, unsigned int inline_max, const WGatherArgs *ga,
+                        unsigned int fuse_max, hipStream_t st) {
+  if (!ws.n_words) return false;
+  BatchArgs bargs = ba ? *ba : BatchArgs{};
   const ScanArgs sargs = scan ? *scan : ScanArgs{};
+  // the worklist first (k_wgather) -- unless the round is small enough for k_words to find its words itself (one launch a round)
+  const bool fused = ga && worklist && work_hint && work_hint <= fuse_max && sargs.on && bargs.k != 0 && !ga->xyz && rule_mask < APPLY_LDS_RULES;
+  if (ga && !fused) launch_wgather(*ga, &bargs, work_hint, st);
+  if (!fused) bargs.mark = 0u;  // (the round's first launch carries the mark)
   // one run of 64 words per wave and iteration; work_hint = about how many words the round will visit (0: unknown / every word)
-  static const char *g_env = getenv("YTTM_WORDS_GRID");
+  const char *g_env = getenv("YTTM_WORDS_GRID");
   const unsigned int gmax = std::min(g_env ? (unsigned int)atoi(g_env) : 512u, (unsigned int)WORDS_MAX_GRID);
   // words per wave: 64, or fewer when that would leave most of the chip idle (work_hint words over at most gmax workgroups)
   unsigned int wpi = 64;
   if (worklist && work_hint) {
-    static const char *w_env = getenv("YTTM_WORDS_WPI");
+    const char *w_env = getenv("YTTM_WORDS_WPI");
     while (wpi > 8 && (unsigned long long)work_hint < (unsigned long long)wpi * APPLY_WPB * gmax / 2) wpi >>= 1;
     if (w_env) wpi = (unsigned int)atoi(w_env);
   }
@@ -3029,21 +3216,26 @@ void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &
   if (g > gmax) g = gmax;
   if (g < 1) g = 1;
   // a small round applies its records itself and carries the candidate scan (it needs that scan: its last workgroup resets the worklist)
-  const bool inl = worklist && work_hint && work_hint <= inline_max && sargs.on;
+  const bool inl = fused || (worklist && work_hint && work_hint <= inline_max && sargs.on);
   const ScanArgs none{};
-  if (rule_mask < APPLY_LDS_RULES)
-    hipLaunchKernelGGL((k_words<APPLY_WPB, true>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
-                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, wpi, inl ? 1u : 0u, bargs, inl ? sargs : none);
+  const WGatherArgs gnone{};
+  if (fused)
+    hipLaunchKernelGGL((k_words<APPLY_WPB, true, true>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
+                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, wpi, 1u, bargs, sargs, *ga);
+  else if (rule_mask < APPLY_LDS_RULES)
+    hipLaunchKernelGGL((k_words<APPLY_WPB, true, false>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
+                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, wpi, inl ? 1u : 0u, bargs, inl ? sargs : none, gnone);
   else
-    hipLaunchKernelGGL((k_words<APPLY_WPB, false>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
-                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, wpi, inl ? 1u : 0u, bargs, inl ? sargs : none);
-  if (inl) return;
+    hipLaunchKernelGGL((k_words<APPLY_WPB, false, false>), dim3((unsigned int)g), dim3(64 * APPLY_WPB), 0, st, ws, pt, db, rules, rule_mask, bloom_g, self_x, self_z, z_base,
+                       k_rules, worklist, wl_seg, work_n, stats, tl, drec, drec_cap, drec_n, irec, wpi, inl ? 1u : 0u, bargs, inl ? sargs : none, gnone);
+  if (inl) return fused;
   // the records -> the pair table, then the round's candidate scan (every workgroup owns a statistics row: at most BLK_ROWS of them)
   // (every workgroup takes a ticket at the end, ~12 ns each on one address: a small round gets a small grid)
   const bool big = !worklist || !work_hint || work_hint > (1u << 17);
   const unsigned int parts = std::max(1u, std::min(8u, (big ? (unsigned int)BLK_ROWS : 256u) / (unsigned int)g));
   hipLaunchKernelGGL(k_delta_apply, dim3((unsigned int)g * parts), dim3(DAPPLY_NT), 0, st, pt, db, (const DeltaRec *)drec, drec_cap, (const unsigned int *)drec_n, parts,
                      const_cast<unsigned int *>(work_n), stats, bargs.k ? (const RuleSlot *)nullptr : rules, rule_mask, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, bargs, sargs);
+  return false;
 }
 void launch_gather(const PairIndexArgs &a, const RuleSlot *rules, unsigned int n_slots, const BatchArgs *ba, uint32_t self_x, uint32_t *stamp,
                    uint32_t round_id, uint32_t *worklist, unsigned int n_tiles, unsigned int *work_n, hipStream_t st) {

@@ -136,14 +136,17 @@ struct WGatherArgs {
   unsigned long long *stats;     // (BatchArgs::mark)
   const uint32_t *xyz;           // rule j = (xyz[3j], xyz[3j+1]) -> z_base + j, in HBM; nullptr: the batch is in the BatchArgs
   uint32_t k, z_base;
+  uint32_t cnt[BATCH_ARGS_MAX];  // k_words<FUSED>: the count the host picked rule j by (saturated): no rule has more sites than that
 };
 constexpr unsigned int WGATHER_MAXK = 4096;
 void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, unsigned int work_hint, hipStream_t st);
-void launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
+bool launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
                         uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules, const uint32_t *worklist /* nullptr: every word */, unsigned long long wl_seg,
                         const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, DeltaRec *drec /* [WORDS_MAX_GRID * drec_cap] */,
                         unsigned int drec_cap, unsigned int *drec_n /* [WORDS_MAX_GRID] */, uint4 *irec /* [WORDS_MAX_GRID * drec_cap] */, const BatchArgs *ba, const ScanArgs *scan, unsigned int work_hint,
-                        unsigned int inline_max /* rounds of at most this many words (by the hint) apply their records themselves */, hipStream_t st);
+                        unsigned int inline_max /* rounds of at most this many words (by the hint) apply their records themselves */,
+                        const WGatherArgs *ga /* the round's gather: launched here (k_wgather) ... */,
+                        unsigned int fuse_max /* ... unless the hint is at most this and the batch is in the arguments: k_words gathers itself */, hipStream_t st);
 constexpr unsigned int WORDS_MAX_GRID = 512;  // workgroups of k_words: each owns a region of the round's count-update records
 void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, unsigned int nom, unsigned long long total,
                    unsigned long long *gstart, unsigned int n_new, uint32_t *new_tok, uint32_t *new_len, uint32_t *new_word0, hipStream_t st);
