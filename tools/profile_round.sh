@@ -16,6 +16,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/writ
 cd $R
 python tools/pmc_summary.py kernel-stats $OUT/stats profiles/${TAG}_kernel_stats.csv
 python tools/pmc_summary.py pmc $OUT/fetch $OUT/write profiles/${TAG}_pmc_hbm.json
-python bench.py > profiles/${TAG}_bench.json 2> $OUT/bench.err
+python bench.py ${BENCH_ARGS:-} > profiles/${TAG}_bench.json 2> $OUT/bench.err   # (BENCH_ARGS: e.g. "--cpu-runs 1" when GPU minutes are short)
 cp profiles/${TAG}_*.* $R/gpurun_out/ 2>/dev/null
 tail -c 600 profiles/${TAG}_bench.json
