@@ -61,15 +61,23 @@ def main():
     comm = C.c_void_p()
     assert L.yttm_comm_callback_create(rank, world, ar, ag, None, C.byref(comm)) == 0
     err = C.create_string_buffer(2048)
-    rep = C.create_string_buffer(8192)
+    rep = C.create_string_buffer(16384)
     rc = L.yttm_train_bpe_from_memory_comm(shard, len(shard), model_out.encode() if rank == 0 else b"", vocab, coverage, 0, 1, 2, 3, 0,
-                                           comm, rep, 8192, err, 2048)
+                                           comm, rep, 16384, err, 2048)
     L.yttm_comm_destroy(comm)
     dist.barrier()
     dist.destroy_process_group()
     if rc != 0:
         print("ERR", err.value.decode())
         sys.exit(3)
+    for want in filter(None, os.environ.get("YTTM_TEST_EXPECT", "").split(",")):  # e.g. "word_rounds>0,word_fused_rounds==0": checks on this rank's report
+        import json
+        import re
+        key, op, val = re.match(r"(\w+)(>|==)(\d+)$", want).groups()
+        got = json.loads(rep.value.decode())[key]
+        if not (got > int(val) if op == ">" else got == int(val)):
+            print("ERR report", want, "got", got)
+            sys.exit(4)
     print("OK", rank)
 
 

@@ -77,18 +77,22 @@ def test_replicated_merge_loop_equals_single_oracle(tmp_path, sim_lib, world):
 def test_word_mode_on_every_rank(tmp_path, sim_lib, world):
     """K4's word mode is rank-local -- it changes which words a rank's apply pass visits, not what the ranks exchange: forced
     on from the second round on every rank of the sharded merge loop (and, second pass, with the record regions and the record log
-    overflowing), same model as the oracle on the whole corpus."""
+    overflowing), then on every rank of the replicated loop (where a round is one launch, k_words<FUSED>): same model as the oracle on
+    the whole corpus."""
     rng = random.Random(70 + world)
     cases = [(gen.readme_corpus(200, 90, seed=4), 400, 1.0),
              (gen.zipf_corpus(40000, vocab=700, seed=6), 300, 1.0),
              (gen.unicode_text(rng, 6000, "mix", p_invalid=0.01), 90, 0.9)]
     force = {"YTTM_WORD_MIN_TILES": "0", "YTTM_WORD_MIN_TOKENS": "0", "YTTM_WORD_DIV": "0"}
-    for extra in ({}, {"YTTM_WORD_DREC": "16", "YTTM_WORD_LOG": "200", "YTTM_HOT_TARGET": "16", "YTTM_HOT_MIN": "4", "YTTM_HOT_CAP": "64"}):
+    small = {"YTTM_WORDS_GRID": "3", "YTTM_WGATHER_GRID": "2"}  # (the emulator's time goes with the workgroups)
+    for extra, sharded in (({}, True), (dict(small, YTTM_WORD_DREC="16", YTTM_WORD_LOG="200", YTTM_HOT_TARGET="16", YTTM_HOT_MIN="4", YTTM_HOT_CAP="64"), True),
+                           (small, False), (dict(small, YTTM_WORD_DREC="16", YTTM_WORD_LOG="200"), False)):
         for i, (text, vocab, cov) in enumerate(cases):
             corpus = str(tmp_path / f"c{i}.txt")
             open(corpus, "wb").write(text)
             m_mp, m_ora = str(tmp_path / f"mp{i}.model"), str(tmp_path / f"ora{i}.model")
-            run_world(corpus, m_mp, vocab, cov, world, sim_lib, dict(force, **extra))
+            expect = "word_rounds>0,word_fused_rounds==0" if sharded else "word_rounds>0,word_fused_rounds>0"  # (every rank's own report)
+            run_world(corpus, m_mp, vocab, cov, world, sim_lib, dict(force, YTTM_TEST_EXPECT=expect, **extra), sharded=sharded)
             O.train(text, m_ora, vocab, cov)
             assert filecmp.cmp(m_mp, m_ora, shallow=False), (i, extra)
 
