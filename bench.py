@@ -352,7 +352,7 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
                        + (f", one file cut into {world} byte ranges" if ctx['strong'] else (f", {size_mb} MB per GPU" if world > 1 else "")),
            "corpus_bytes_total": total_bytes, "corpus_bytes_this_gpu": n_local, "vocab_size": args.vocab, "unique_words": r["n_unique"],
            "dedup_tokens": r["n_tokens"], "merge_rounds": r["rounds"], "rules": r["rules"],
-           "rounds_closed_exhausted": r.get("rounds_exhausted"), "word_mode_from_round": r.get("word_switch_round") or None, "word_mode_rounds": r.get("word_rounds"),
+           "rounds_closed_exhausted": r.get("rounds_exhausted"), "word_mode_from_round": r.get("word_switch_round") or None, "word_mode_rounds": r.get("word_rounds"), "word_mode_one_launch_rounds": r.get("word_fused_rounds"),
            "index_builds": r.get("index_builds"), "input": "resident in HBM before the timed region",
            "model_md5": model_md5, "pinned_model_md5": pin["model_md5"] if pin else None}
     if ctx["comm"] is not None:
