@@ -131,6 +131,45 @@ def test_merge_apply_many_sites_per_tile():
     S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=8, seed=4)
 
 
+def test_word_mode_batch_split(tmp_path, monkeypatch):
+    """A batch of 129 .. 256 rules in word mode goes as two rounds (its first 128 rules are one launch; host_trainer.cpp): corpora whose
+    second round merges a few hundred disjoint pairs at once -- word i is three fresh ideographs a b c (and a b, a b c d beside it) -- same
+    models as the oracle, with the split on (at least one batch cut) and off."""
+    import ctypes as C
+    import filecmp
+    import json
+    from youtokentome_amd import _lib
+    import oracle_lib as O
+    L = _lib.load()
+    for k in ("YTTM_WORD_MIN_TILES", "YTTM_WORD_MIN_TOKENS", "YTTM_WORD_DIV"):
+        monkeypatch.setenv(k, "0")
+    monkeypatch.setenv("YTTM_WORDS_GRID", "3")
+
+    def corpus(n):
+        out = []
+        for i in range(n):
+            a, b, c, d = (chr(0x4E00 + 4 * i + j) for j in range(4))
+            out.append((a + b + " ") * 3 + (a + b + c + " ") * (2 + i % 3) + (a + b + c + d + " ") * (1 + i % 2))
+        return "".join(out).encode()
+    splits = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("YTTM_NO_BATCH_SPLIT", "1")
+        splits[off] = 0
+        for n, vocab in ((200, 4 + 800 + 500), (300, 4 + 1200 + 700)):
+            text = corpus(n)
+            cp, mg, mo = str(tmp_path / "c.txt"), str(tmp_path / "g.model"), str(tmp_path / "o.model")
+            open(cp, "wb").write(text)
+            err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+            assert L.yttm_train_bpe_ex(cp.encode(), mg.encode(), vocab, 1.0, 1, 0, 1, 2, 3, 0, rep, 16384, err, 2048) == 0, err.value
+            O.train(text, mo, vocab)
+            assert filecmp.cmp(mg, mo, shallow=False), (n, off)
+            r = json.loads(rep.value.decode())
+            assert r["word_fused_rounds"] > 100, r
+            splits[off] += r["batch_splits"]
+    assert splits[False] >= 2 and splits[True] == 0, splits
+
+
 @pytest.mark.parametrize("name", S.golden_train_names())
 def test_golden_train(name, tmp_path):
     S.check_golden_train(name, tmp_path)

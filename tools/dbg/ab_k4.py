@@ -41,7 +41,7 @@ for kind in (["abcd", "zipf"] if which == "both" else which.split("+")):
             if seg:
                 segs["%d-%d" % (a + 1, min(b, len(k4)))] = [round(sum(seg), 2), round(1e3 * sum(seg) / len(seg), 1)]
         row = {"wall_s": round(min(walls), 4), "rounds": r["rounds"], "seconds_merge": r["seconds_merge"], "seconds_frontend": r["seconds_frontend"],
-               "gathered_rounds": r.get("gathered_rounds"), "word_rounds": r.get("word_rounds"), "word_switch_round": r.get("word_switch_round"), "word_all_rounds": r.get("word_all_rounds"), "word_fused_rounds": r.get("word_fused_rounds"), "index_builds": r.get("index_builds"), "repacks": r.get("repacks"), "rounds_exhausted": r.get("rounds_exhausted"), "batch_extensions": r.get("batch_extensions"),
+               "gathered_rounds": r.get("gathered_rounds"), "word_rounds": r.get("word_rounds"), "word_switch_round": r.get("word_switch_round"), "word_all_rounds": r.get("word_all_rounds"), "word_fused_rounds": r.get("word_fused_rounds"), "index_builds": r.get("index_builds"), "repacks": r.get("repacks"), "rounds_exhausted": r.get("rounds_exhausted"), "batch_extensions": r.get("batch_extensions"), "batch_splits": r.get("batch_splits"),
                "cand_rescans": r.get("cand_rescans"), "top_refills": r.get("top_refills"), "hot_rebuilds": r.get("hot_rebuilds"),
                "kernels_ms": {k: [round(v["ms"], 3), v["launches"]] for k, v in r["kernels"].items() if v["launches"]}, "touched_tiles": r["touched_tiles"],
                "touched_tile_tokens": r["touched_tile_tokens"], "merge_sites": r["merge_sites"], "k4_launches": len(k4), "k4_ms_by_rounds[sum,avg_us]": segs,

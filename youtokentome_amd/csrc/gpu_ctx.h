@@ -203,6 +203,10 @@ class GpuCtx {
   bool profile_events_ = false, dev_timing_pending_ = false;  // (merge_apply: dev_timing)
   std::vector<float> dev_round_ms_;
   bool word_mode_ = false, words_enabled_ = true;
+ public:
+  // class A is in word mode, and a batch of at most this many rules is one launch there (k_words<FUSED>): the trainer's batch split
+  bool one_launch_rounds() const { return word_mode_ && words_fuse_max_ != 0 && !multi(); }
+ private:
   unsigned int hot_target_words_ = 1u << 15, words_inline_max_ = 1u << 18, words_fuse_max_ = 1u << 30;
   unsigned int word_div_ = 200;    // switch when (merge sites of the last round) * word_div_ < (tokens a pass over the tiles streams)
   unsigned int word_min_tiles_ = 16384;

@@ -133,8 +133,9 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   std::vector<Cand> heap;
   std::vector<uint32_t> batch_xyz;
   std::vector<unsigned long long> batch_cnt;
-  unsigned long long rounds = 0, rescans = 0, rounds_exhausted = 0, batch_extensions = 0;
+  unsigned long long rounds = 0, rescans = 0, rounds_exhausted = 0, batch_extensions = 0, batch_splits = 0;
   const bool extend_on = !getenv("YTTM_NO_EXTEND");  // (tuning hook / A-B runs)
+  const bool split_on = !getenv("YTTM_NO_BATCH_SPLIT");
   const bool refine_on = !getenv("YTTM_NO_REFINE");  // (the same: the fused scan keeps the host's threshold)
   std::vector<unsigned long long> batch_keys;
   double w_cand = 0, w_pick = 0, w_apply = 0, w_pick_a = 0, w_pick_b = 0;  // (YTTM_TRACE: pick = threshold + heap build | pops)
@@ -221,7 +222,6 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       batch_xyz.push_back(c.y);
       batch_xyz.push_back(z);
       batch_cnt.push_back(c.cnt);
-      if (root && z % 1000 == 0) fprintf(stderr, "id: %u=%u+%u  freq: %llu\n", z, c.x, c.y, c.cnt);  // cf. bpe.cpp:1198-1219
       if (c.x == c.y) { closed = true; break; }  // a self-pair rule must be the last of its batch
     }
       if (used_ids + batch_cnt.size() >= (uint64_t)vocab_size || batch_cnt.size() >= max_batch) closed = true;
@@ -252,10 +252,24 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       }
       if (heap.empty()) break;
     }
-    const uint32_t k = (uint32_t)batch_cnt.size();
+    uint32_t k = (uint32_t)batch_cnt.size();
+    for (uint32_t j = 0; j < k; j++) in_batch[batch_xyz[3 * j]] = in_batch[batch_xyz[3 * j + 1]] = 0;
+    // Word mode runs a batch that fits the kernel arguments as ONE launch (~70 us a round late in training) and a larger one as four
+    // (~200 us): a batch of up to twice that many rules goes as two rounds -- its first BATCH_ARGS_MAX rules now (a prefix of a batch
+    // is a batch), the others come back with the next scan, their counts untouched (nothing of this batch intersects them).
+    if (split_on && g.one_launch_rounds() && k > (uint32_t)BATCH_ARGS_MAX && k <= 2u * (uint32_t)BATCH_ARGS_MAX) {
+      k = (uint32_t)BATCH_ARGS_MAX;
+      batch_xyz.resize(3 * (size_t)k);
+      batch_cnt.resize(k);
+      closed = true;
+      batch_splits++;
+    }
+    if (root)
+      for (uint32_t j = 0; j < k; j++)
+        if (batch_xyz[3 * j + 2] % 1000 == 0)
+          fprintf(stderr, "id: %u=%u+%u  freq: %llu\n", batch_xyz[3 * j + 2], batch_xyz[3 * j], batch_xyz[3 * j + 1], batch_cnt[j]);  // cf. bpe.cpp:1198-1219
     const bool exhausted = !closed;  // the batch ended for lack of candidates, not at an intersection: ask for more next time
     if (exhausted) rounds_exhausted++;
-    for (uint32_t j = 0; j < k; j++) in_batch[batch_xyz[3 * j]] = in_batch[batch_xyz[3 * j + 1]] = 0;
     w_pick += since(tw1);
     auto tw2 = clk::now();
     g.merge_apply(batch_xyz.data(), k, batch_cnt.data(), &tau_hint, MX_ALL, refine_on ? (uint32_t)TARGET : 0u);  // (the next scan's threshold rides along)
@@ -287,6 +301,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     rep->rounds_exhausted = rounds_exhausted;
     rep->replicated_merge_loop = replicated ? 1 : 0;
     rep->batch_extensions = batch_extensions;
+    rep->batch_splits = batch_splits;
     rep->hot_rebuilds = g.hot_rebuilds;
     rep->fused_rounds = g.fused_rounds;
     rep->fused_overflows = g.fused_overflows;
