@@ -30,4 +30,19 @@ S.check_merge_rounds(S.texts_small(5, n=1, size=1200)[0], rounds=4, seed=1, id_s
 S.check_encode_word_cache(n_sent=40)
 for t in S.texts_by_alphabet_size(sizes=(5, 33, 64, 70), n_words=200):  # K3's kernels
     S.check_word_table_and_pairs(t)
+# K4's word mode (k_words<FUSED>: rule runs, claimed-word list and list allotment in LDS; k_wgather + k_words + k_delta_apply; record regions
+# and a record log that overflow; a batch of hundreds of disjoint pairs cut in two)
+import os  # noqa: E402
+os.environ.update({"YTTM_WORD_MIN_TILES": "0", "YTTM_WORD_MIN_TOKENS": "0", "YTTM_WORD_DIV": "0", "YTTM_WORDS_GRID": "3", "YTTM_WGATHER_GRID": "2"})
+wm_text = gen.readme_corpus(200, 90, seed=8)
+for cfg in ({}, {"YTTM_WORDS_FUSE_MAX": "0"}, {"YTTM_WORD_LOG": "300", "YTTM_WORD_DREC": "16"}, {"YTTM_WORDS_FUSE_MAX": "0", "YTTM_WORDS_INLINE_MAX": "0", "YTTM_WORD_DREC": "16"}):
+    os.environ.update(cfg)
+    S.check_train_vs_oracle(wm_text, 500, tmp, tag="wm")
+    for k in cfg:
+        del os.environ[k]
+disjoint = "".join((a + b + " ") * 3 + (a + b + c + " ") * (2 + i % 3) + (a + b + c + d + " ") * (1 + i % 2)
+                   for i, (a, b, c, d) in enumerate(tuple(chr(0x4E00 + 4 * i + j) for j in range(4)) for i in range(200)))
+S.check_train_vs_oracle(disjoint.encode(), 4 + 800 + 500, tmp, tag="wmsplit")
+for k in ("YTTM_WORD_MIN_TILES", "YTTM_WORD_MIN_TOKENS", "YTTM_WORD_DIV", "YTTM_WORDS_GRID", "YTTM_WGATHER_GRID"):
+    del os.environ[k]
 print("ASAN_SCENARIOS_OK")
