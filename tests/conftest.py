@@ -15,6 +15,10 @@ HAVE_GPU = os.path.exists("/dev/kfd")
 SIM_LIB = os.path.join(ROOT, "tests", "hipsim", "_build", "libyttm_sim.so")
 if not HAVE_GPU and "YTTM_AMD_LIB" not in os.environ:
     os.environ["YTTM_AMD_LIB"] = SIM_LIB
+if not HAVE_GPU:
+    # the emulator's time goes with the workgroups it runs: word-mode rounds sized for a few thousand words instead of the 16 k the
+    # MI355X is given (a grid size only -- the kernels are the same)
+    os.environ.setdefault("YTTM_WORD_HINT_FLOOR", "2048")
 
 
 def pytest_configure(config):

@@ -8,6 +8,7 @@ import oracle_lib as O
 import test_multi_rank_gloo as M
 
 lib = os.path.join(R, "tests", "hipsim", "_build", "libyttm_sim.so")
+os.environ.setdefault("YTTM_WORD_HINT_FLOOR", "2048")  # (inherited by the ranks: smaller grids for the small word-mode rounds under the emulator)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 big = len(sys.argv) > 3 and sys.argv[3] == "big"

@@ -4,6 +4,7 @@ encode ids with and without the word cache).  usage: python tools/soak_sim.py [s
 import os, pathlib, random, sys, tempfile, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("YTTM_AMD_LIB", os.path.join(R, "tests", "hipsim", "_build", "libyttm_sim.so"))
+os.environ.setdefault("YTTM_WORD_HINT_FLOOR", "2048")  # (the emulator's time goes with the workgroups: smaller grids for the small word-mode rounds)
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import gen
 import stage_checks as S

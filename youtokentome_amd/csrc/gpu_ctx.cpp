@@ -178,6 +178,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   // rounds of at most this many words (by the hint) whose batch travels in the kernel arguments are ONE launch, k_words<FUSED>; 0: never.
   // (1 GB random text, wall / K4 ms: never 138.3 / 86.0, 32 k 136.6 / 83.3, 256 k 133.1 / 80.2, 2 M 125.9 / 73.5, every round 125.0 / 72.5)
   words_fuse_max_ = env_uint("YTTM_WORDS_FUSE_MAX", 1u << 30);
+  word_hint_floor_ = env_uint("YTTM_WORD_HINT_FLOOR", 16384);  // (the words a round is sized for beyond twice the last round's sites; 1 GB random text, K4 ms on the device clock: 1024 -> 73.6, 4096 -> 72.7, 16384 -> 72.1)
   words_inline_max_ = env_uint("YTTM_WORDS_INLINE_MAX", 1u << 18);  // (measured at 1 GB, K4 ms: 16 k -> 97.2, 64 k -> 95.4, 256 k -> 94.1)
   profile_events_ = env_uint("YTTM_PROFILE_EVENTS", 0) != 0;
   words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end, worklists of tiles from the pair index)
@@ -1734,7 +1735,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
         HIP_CHECK(hipMemsetAsync(d_stamp_, 0, (size_t)stamp_cap_ * 4, st_));
         ga.stamp = d_stamp_;
       }
-      const unsigned int work_hint = sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + 4096, 1ull << 30) : 0u;
+      const unsigned int work_hint = sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + word_hint_floor_, 1ull << 30) : 0u;
       ga.stats = d_stats_;
       const BatchArgs gba = first_ba();
       const WordSet wset{c.d_tok, d_wmeta_, c.d_wcnt, (uint32_t)c.n_unique};
