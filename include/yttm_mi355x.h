@@ -34,7 +34,10 @@ int yttm_train_bpe_ex(const char *input_path, const char *model_path, int vocab_
 /* Same training on a corpus that is already in host memory (no file read), or already resident in HBM
  * (`d_text` = device pointer, 16-byte aligned).  `device` = HIP device ordinal.  `report_json` (optional, may be
  * NULL) receives a JSON object with wall-time phases and per-kernel GPU time / algorithmic bytes
- * (profile != 0 times every kernel with HIP events on the launch stream). */
+ * (profile != 0 times every kernel with HIP events on the launch stream), and counters of the merge loop: "rounds",
+ * "rules", "rounds_exhausted", "batch_extensions", "batch_splits" (word-mode batches of 129 .. 256 rules cut to their first
+ * 128), "word_switch_round" / "word_rounds" / "word_fused_rounds" (rounds in K4's word mode; of those, one launch each) /
+ * "word_all_rounds" (rounds that had to visit every word), "index_builds", "hot_rebuilds", "top_refills", "repacks". */
 int yttm_train_bpe_from_memory(const uint8_t *text, uint64_t n, const char *model_path, int vocab_size, double coverage,
                                int pad_id, int unk_id, int bos_id, int eos_id, int device, char *report_json,
                                int report_len, char *err, int errlen);
