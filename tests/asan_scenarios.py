@@ -40,9 +40,7 @@ for cfg in ({}, {"YTTM_WORDS_FUSE_MAX": "0"}, {"YTTM_WORD_LOG": "300", "YTTM_WOR
     S.check_train_vs_oracle(wm_text, 500, tmp, tag="wm")
     for k in cfg:
         del os.environ[k]
-disjoint = "".join((a + b + " ") * 3 + (a + b + c + " ") * (2 + i % 3) + (a + b + c + d + " ") * (1 + i % 2)
-                   for i, (a, b, c, d) in enumerate(tuple(chr(0x4E00 + 4 * i + j) for j in range(4)) for i in range(200)))
-S.check_train_vs_oracle(disjoint.encode(), 4 + 800 + 500, tmp, tag="wmsplit")
+S.check_train_vs_oracle(gen.disjoint_words_corpus(200), 4 + 800 + 500, tmp, tag="wmsplit")
 for k in ("YTTM_WORD_MIN_TILES", "YTTM_WORD_MIN_TOKENS", "YTTM_WORD_DIV", "YTTM_WORDS_GRID", "YTTM_WGATHER_GRID"):
     del os.environ[k]
 print("ASAN_SCENARIOS_OK")

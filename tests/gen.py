@@ -140,6 +140,19 @@ def cjk_corpus_fast(nbytes, seed=11, n_chars=4096, lexicon=300000, chunk_words=4
     return b"".join(parts)
 
 
+def disjoint_words_corpus(n_words=200, first_cp=0x4E00, shuffle_seed=None):
+    """Word i = four fresh code points a b c d; the text holds "a b" three times, "a b c" 2 .. 4 times and "a b c d" once or twice.  The
+    first merge round takes every (a, b) at once, the second every (ab, c): batches of n_words disjoint rules -- the batch sizes a
+    corpus of natural or random text only reaches at gigabytes (host_trainer.cpp: batches of 129 .. 256 rules in word mode are cut in two)."""
+    parts = []
+    for i in range(n_words):
+        a, b, c, d = (chr(first_cp + 4 * i + j) for j in range(4))
+        parts.append((a + b + " ") * 3 + (a + b + c + " ") * (2 + i % 3) + (a + b + c + d + " ") * (1 + i % 2))
+    if shuffle_seed is not None:
+        random.Random(shuffle_seed).shuffle(parts)
+    return "".join(parts).encode()
+
+
 def stress_text(rng: random.Random, n_limit=1000, train=True):
     """Random text in the spirit of the reference stress generator (tests/unit_tests/stress_test.cpp:272-311):
     short alphabet, single chars mixed with repeated segments so that long runs of equal symbols occur."""

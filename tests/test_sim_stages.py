@@ -144,20 +144,13 @@ def test_word_mode_batch_split(tmp_path, monkeypatch):
     for k in ("YTTM_WORD_MIN_TILES", "YTTM_WORD_MIN_TOKENS", "YTTM_WORD_DIV"):
         monkeypatch.setenv(k, "0")
     monkeypatch.setenv("YTTM_WORDS_GRID", "3")
-
-    def corpus(n):
-        out = []
-        for i in range(n):
-            a, b, c, d = (chr(0x4E00 + 4 * i + j) for j in range(4))
-            out.append((a + b + " ") * 3 + (a + b + c + " ") * (2 + i % 3) + (a + b + c + d + " ") * (1 + i % 2))
-        return "".join(out).encode()
     splits = {}
     for off in (False, True):
         if off:
             monkeypatch.setenv("YTTM_NO_BATCH_SPLIT", "1")
         splits[off] = 0
         for n, vocab in ((200, 4 + 800 + 500), (300, 4 + 1200 + 700)):
-            text = corpus(n)
+            text = gen.disjoint_words_corpus(n)
             cp, mg, mo = str(tmp_path / "c.txt"), str(tmp_path / "g.model"), str(tmp_path / "o.model")
             open(cp, "wb").write(text)
             err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)

@@ -86,6 +86,9 @@ while time.time() - t0 < budget:
                                           {"YTTM_WORDS_FUSE_MAX": str(rng.choice([4200, 4500, 6000]))}, {"YTTM_WORDS_GRID": str(rng.choice([1, 2, 5]))},
                                           {"YTTM_WORDS_FUSE_MAX": "4400", "YTTM_WORD_LOG": "500", "YTTM_WORDS_GRID": "2"},
                                           {"YTTM_WORD_LOG": "200", "YTTM_WORD_DREC": "16", "YTTM_WORDS_INLINE_MAX": "0", "YTTM_INDEX_AGG_MIN": "0"}]))
+    if words_mode and rng.random() < 0.1:  # batches of hundreds of disjoint rules (the trainer's batch split)
+        nw = rng.randint(130, 400)
+        text, cov, vocab = gen.disjoint_words_corpus(nw, shuffle_seed=rng.randint(0, 10 ** 6)), 1.0, 8 + 4 * nw + rng.randint(nw, 3 * nw)
     ids = rng.choice([(0, 1, 2, 3), (3, 2, 1, 0), (-1, 0, -1, -1), (5, 7, -1, 2)])
     try:
         model = S.check_train_vs_oracle(text, vocab, tmp, cov, ids, tag=f"s{n}")
