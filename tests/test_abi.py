@@ -3,6 +3,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "youtokentome_amd", "libyttm_mi355x.so")
@@ -45,8 +46,9 @@ def test_no_gpu_means_loud_failure():
 
 def test_python_list_boundary_extension_is_built():
     """csrc/pyapi.c (the C side of BPE.encode(list[str]) -> list[list[int]], yttm.pyx:87-109) is built next to the library and imports."""
-    so = os.path.join(ROOT, "youtokentome_amd", "_yttm_pyapi.so")
+    import sysconfig
+    so = os.path.join(ROOT, "youtokentome_amd", "_yttm_pyapi" + sysconfig.get_config_var("EXT_SUFFIX"))  # (named with this interpreter's ABI tag)
     if not os.path.exists(so):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "youtokentome_amd", "csrc"), "../_yttm_pyapi.so"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "youtokentome_amd", "csrc"), "pyapi", "PYTHON=" + sys.executable], check=True, capture_output=True)
     from youtokentome_amd import bpe
     assert bpe._pyapi is not None and hasattr(bpe._pyapi, "encode_ids")
