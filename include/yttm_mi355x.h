@@ -121,6 +121,11 @@ typedef int (*yttm_allgather_bytes_fn)(void *user, const void *send, size_t send
 int yttm_comm_callback_create(int rank, int world, yttm_allreduce_u64_fn allreduce, yttm_allgather_bytes_fn allgather,
                               void *user, yttm_comm **out);
 void yttm_comm_destroy(yttm_comm *comm);
+/* train_bpe (bpe.h:19) on a node of GPUs: every rank passes the SAME file and reads its own byte range of it, cut at white space like the
+ * reference's per-thread split (bpe.cpp:864-873).  comm == NULL: one GPU (yttm_train_bpe_ex with the per-kernel timers: profile = 1). */
+int yttm_train_bpe_comm(const char *input_path, const char *model_path, int vocab_size, double coverage, int n_threads, int pad_id,
+                        int unk_id, int bos_id, int eos_id, int device, int profile, yttm_comm *comm, char *report_json,
+                        int report_len, char *err, int errlen);
 int yttm_train_bpe_from_device_comm(const void *d_text, uint64_t n, const char *model_path, int vocab_size, double coverage,
                                     int pad_id, int unk_id, int bos_id, int eos_id, int device, int profile,
                                     yttm_comm *comm, char *report_json, int report_len, char *err, int errlen);

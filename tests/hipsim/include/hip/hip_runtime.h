@@ -68,6 +68,7 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
   p->multiProcessorCount = 1;
   return hipSuccess;
 }
+static inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = (size_t)64 << 30; *tot = (size_t)288 << 30; return hipSuccess; }  // (the emulator's "HBM" is host memory)
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorUnknown; }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = calloc(n ? n : 1, 1); return hipSuccess; }

@@ -42,6 +42,8 @@ def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     corpus, model_out, vocab, coverage = sys.argv[4], sys.argv[5], int(sys.argv[6]), float(sys.argv[7])
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    if os.environ.get("YTTM_TEST_FREE_BYTES_RANK%d" % rank):  # (tests: this rank alone is short of device memory)
+        os.environ["YTTM_TEST_FREE_BYTES"] = os.environ["YTTM_TEST_FREE_BYTES_RANK%d" % rank]
     import torch
     import torch.distributed as dist
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)

@@ -79,34 +79,6 @@ def test_k4_measurement_pass():
     S.check_k4_measure((" ".join(words) + " ").encode(), rounds=6, seed=1)
 
 
-def test_k4_position_parallel_kernel(tmp_path, monkeypatch):
-    """YTTM_K4_PM=1: class-A tiles through k_apply.hip instead of k_tiles (opt-in): same parity bar."""
-    monkeypatch.setenv("YTTM_K4_PM", "1")
-    for i, t in enumerate(S.texts_small(2, n=4, size=8000)):
-        if t.strip():
-            S.check_merge_rounds(t, rounds=8, seed=i)
-    S.check_merge_rounds(gen.readme_corpus(1500, 100, seed=9), rounds=25, seed=3)
-    t = ("aaaa aaaaa aaaaaaa abababab aabbaabb abcabcabc bbbbbb ab aaab baaa " + "a" * 700 + " " + "ab" * 500 + " ") * 3
-    S.check_merge_rounds(t.encode(), rounds=14, seed=1)
-    S.check_site_placements(trials=100, seed=9)
-    S.check_merge_rounds(S.texts_small(5, n=1, size=8000)[0], rounds=8, seed=0, id_shift=40000)
-    for name in ("readme_small", "runs", "mix_cov", "zipf"):
-        S.check_golden_train(name, tmp_path)
-    S.check_train_vs_oracle(gen.zipf_corpus(2_000_000, seed=3, vocab=30000), 4000, tmp_path, tag="pm")
-
-
-def test_k4_worklist_mode(tmp_path, monkeypatch):
-    """K4 with a separate filter pass and a worklist of candidate tiles (YTTM_DENSE_PCT; off by default)."""
-    monkeypatch.setenv("YTTM_DENSE_PCT", "1000")
-    for name in ("readme_small", "runs", "mix_cov"):
-        S.check_golden_train(name, tmp_path)
-    for i, t in enumerate(S.texts_small(7, n=3, size=8000)):
-        if t.strip():
-            S.check_merge_rounds(t, rounds=8, seed=i)
-    S.check_site_placements(trials=30, seed=5)
-    S.check_train_vs_oracle(gen.zipf_corpus(2_000_000, seed=3, vocab=30000), 4000, tmp_path, tag="wl")
-
-
 def test_k4_word_mode(tmp_path, monkeypatch):
     """Word mode (one launch per round, k_words<FUSED>, and k_wgather + k_words + k_delta_apply) forced on from the second round whatever the corpus size: golden
     corpora, random text of three scripts and a Zipf corpus against the oracle; then with tiny hot lists (index rebuilds, rounds over

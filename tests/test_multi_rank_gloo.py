@@ -73,12 +73,25 @@ def test_replicated_merge_loop_equals_single_oracle(tmp_path, sim_lib, world):
         assert filecmp.cmp(m_mp, m_ora, shallow=False), f"case {i}"
 
 
+def test_replication_needs_memory_on_every_rank(tmp_path, sim_lib):
+    """the replicated loop gathers the WHOLE corpus on every rank.  Few dedup tokens alone must not choose it: the
+    gathered text and the second dedup have to fit beside the shard on every rank, and the verdict is collective -- one rank short of
+    memory (YTTM_TEST_FREE_BYTES on rank 1 only) keeps EVERY rank in the sharded loop (nobody waits in a gather the others skipped)."""
+    text = gen.zipf_corpus(60000, vocab=900, seed=5)
+    corpus = str(tmp_path / "c.txt")
+    open(corpus, "wb").write(text)
+    m_mp, m_ora = str(tmp_path / "mp.model"), str(tmp_path / "ora.model")
+    run_world(corpus, m_mp, 400, 1.0, 3, sim_lib, {"YTTM_TEST_EXPECT": "replicated_merge_loop==1"}, sharded=False)
+    run_world(corpus, m_mp, 400, 1.0, 3, sim_lib, {"YTTM_TEST_EXPECT": "replicated_merge_loop==0", "YTTM_TEST_FREE_BYTES_RANK1": "1000"}, sharded=False)
+    O.train(text, m_ora, 400, 1.0)
+    assert filecmp.cmp(m_mp, m_ora, shallow=False)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_word_mode_on_every_rank(tmp_path, sim_lib, world):
-    """K4's word mode is rank-local -- it changes which words a rank's apply pass visits, not what the ranks exchange: forced
-    on from the second round on every rank of the sharded merge loop (and, second pass, with the record regions and the record log
-    overflowing), then on every rank of the replicated loop (where a round is one launch, k_words<FUSED>): same model as the oracle on
-    the whole corpus."""
+    """K4's word mode changes which words a rank's apply pass visits, not what the ranks exchange: forced on from the second
+    round on every rank of the sharded merge loop, one launch per round there too (k_words<FUSED>; and, second pass, with the record
+    regions and the record log overflowing), then on every rank of the replicated loop: same model as the oracle on the whole corpus."""
     rng = random.Random(70 + world)
     cases = [(gen.readme_corpus(200, 90, seed=4), 400, 1.0),
              (gen.zipf_corpus(40000, vocab=700, seed=6), 300, 1.0),
@@ -91,15 +104,40 @@ def test_word_mode_on_every_rank(tmp_path, sim_lib, world):
             corpus = str(tmp_path / f"c{i}.txt")
             open(corpus, "wb").write(text)
             m_mp, m_ora = str(tmp_path / f"mp{i}.model"), str(tmp_path / f"ora{i}.model")
-            expect = "word_rounds>0,word_fused_rounds==0" if sharded else "word_rounds>0,word_fused_rounds>0"  # (every rank's own report)
+            expect = "word_rounds>0,word_fused_rounds>0"  # (every rank's own report: one-launch rounds in the sharded loop too)
             run_world(corpus, m_mp, vocab, cov, world, sim_lib, dict(force, YTTM_TEST_EXPECT=expect, **extra), sharded=sharded)
             O.train(text, m_ora, vocab, cov)
             assert filecmp.cmp(m_mp, m_ora, shallow=False), (i, extra)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_word_mode_switch_is_one_decision(tmp_path, sim_lib, world):
+    """the switch to word mode -- and with it the hot list's target, so the thresholds of every later candidate scan,
+    and the batch split -- must not be taken from rank-local numbers.  Shards of very different shape: the first ranks hold many distinct
+    words (many class-A tiles, many merge sites), the last one a handful of words repeated (one tile) or nothing but white space.  With
+    thresholds between the two (YTTM_WORD_MIN_TILES) a rank-local rule would switch the big ranks and not the small one; the decision is
+    taken from the sums over the ranks' block headers instead, the same on every rank in the same round: every rank with words reports
+    word-mode rounds, the model is the oracle's.  Also with the per-round pack as a kernel of its own (YTTM_XCHG_TAIL_PACK=0)."""
+    rng = random.Random(300 + world)
+    big = b" ".join("".join(rng.choice("abcdefgh") for _ in range(rng.randint(2, 14))).encode() for _ in range(9000)) + b"\n"
+    few = (b"abab cdcd abcd " * (len(big) // (15 * (world - 1)))) + b"\n"
+    blank = b" \n" * (len(big) // (2 * (world - 1)))
+    hooks = {"YTTM_WORD_MIN_TILES": "6", "YTTM_WORD_MIN_TOKENS": "0", "YTTM_WORD_DIV": "0", "YTTM_HOT_TARGET": "24", "YTTM_HOT_MIN": "6",
+             "YTTM_HOT_TARGET_WORDS": "96", "YTTM_WORDS_GRID": "3", "YTTM_WGATHER_GRID": "2"}
+    for i, (tail, extra, expect) in enumerate(((few, {}, "word_rounds>0"), (few, {"YTTM_XCHG_TAIL_PACK": "0"}, "word_rounds>0"), (blank, {}, ""))):
+        text = big * (world - 1) + tail  # rank world-1 gets (nearly) only the tail
+        corpus = str(tmp_path / f"c{i}.txt")
+        open(corpus, "wb").write(text)
+        m_mp, m_ora = str(tmp_path / f"mp{i}.model"), str(tmp_path / f"ora{i}.model")
+        run_world(corpus, m_mp, 260, 1.0, world, sim_lib, dict(hooks, YTTM_TEST_EXPECT=expect, **extra))
+        O.train(text, m_ora, 260, 1.0)
+        assert filecmp.cmp(m_mp, m_ora, shallow=False), i
+
+
 def test_two_ranks_long_words_and_small_hot_list(tmp_path, sim_lib):
     """Words beyond the LDS tile kernels (class C, k_giant.hip) on both ranks, and a hot list so small that it overflows and
-    is rebuilt all the time: the ranks have to agree on every rebuild (one extra all-reduce) to stay in lock step."""
+    is rebuilt all the time: every rank must reach the same verdict on every overflow (the lists hold the same pairs on every rank:
+    k_fold_list) to stay in lock step."""
     rng = random.Random(9)
     long_words = ["".join(rng.choice("abc") for _ in range(n)) for n in (2100, 2600, 3001)]
     lines = []

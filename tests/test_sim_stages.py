@@ -92,35 +92,6 @@ def test_merge_apply_small_alphabets_random():
         S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=rng.randint(3, 14), seed=trial)
 
 
-def test_merge_apply_position_parallel_kernel(monkeypatch):
-    """YTTM_K4_PM=1: class-A tiles through k_apply.hip (pair filter, position-major site search, site records applied 64 at a time)
-    instead of k_tiles -- the same checks: word table and whole pair table against an oracle recount after every round."""
-    monkeypatch.setenv("YTTM_K4_PM", "1")
-    for i, t in enumerate(S.texts_small(2, n=3, size=1500)):
-        if t.strip():
-            S.check_merge_rounds(t, rounds=5, seed=i)
-    t = ("aaaa aaaaa aaaaaaa abababab aabbaabb abcabcabc bbbbbb ab aaab baaa aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa " * 3).encode()
-    S.check_merge_rounds(t, rounds=12, seed=1)
-    S.check_merge_rounds(t, rounds=10, seed=1, id_shift=33000)
-    rng = random.Random(2025)
-    for trial in range(25):
-        alpha = "abcde"[: rng.choice([2, 2, 3, 3, 4, 5])]
-        words = ["".join(rng.choice(alpha) for _ in range(rng.choice([1, 2, 3, 5, 8, 13, 30, 80, 200]))) for _ in range(rng.randint(5, 250))]
-        words = [w for w in words for _ in range(rng.randint(1, 3))]
-        rng.shuffle(words)
-        S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=rng.randint(3, 14), seed=trial)
-    S.check_site_placements(trials=40, seed=5)
-    words = ["ab" * k for k in range(60, 125, 7)] + ["a" * k for k in range(150, 250, 13)] + ["abc" * k for k in (50, 70, 80)]
-    S.check_merge_rounds((" ".join(words) + " ").encode(), rounds=8, seed=4)
-
-
-def test_train_position_parallel_kernel(monkeypatch, tmp_path):
-    monkeypatch.setenv("YTTM_K4_PM", "1")
-    for name in ("readme_small", "runs", "zipf", "stress3"):
-        S.check_golden_train(name, tmp_path)
-    assert S.check_many_words_per_tile(tmp_path) is None
-
-
 def test_merge_apply_site_placements():
     S.check_site_placements(trials=100, seed=3)
 
@@ -247,18 +218,6 @@ def test_list_overflow_in_a_fused_round(tmp_path, monkeypatch):
     assert fused > 0 and seen > 0, "no configuration overflowed the top list during a fused round: the test does not test what it says"
 
 
-def test_worklist_mode(tmp_path, monkeypatch):
-    """K4 with a separate filter pass and a worklist of candidate tiles (off by default: the apply kernel dismisses clean
-    tiles itself) must give the same tables and models."""
-    monkeypatch.setenv("YTTM_DENSE_PCT", "1000")
-    for name in ("readme_small", "runs", "mix_cov"):
-        S.check_golden_train(name, tmp_path)
-    for i, t in enumerate(S.texts_small(7, n=2, size=1500)):
-        if t.strip():
-            S.check_merge_rounds(t, rounds=5, seed=i)
-    S.check_site_placements(trials=15, seed=5)
-
-
 def test_very_long_words(tmp_path):
     S.check_very_long_words(tmp_path)
 
@@ -353,40 +312,6 @@ def test_word_table_overflow_is_redone(tmp_path):
     assert json.loads(rep.value.decode())["word_table_retries"] == 1
     O.train(text, m_ora, 40)
     assert filecmp.cmp(m_gpu, m_ora, shallow=False)
-
-
-def test_worklists_from_the_pair_index(tmp_path, monkeypatch):
-    """Late rounds take their tiles from the pair index (pair -> tiles that hold it, built from the hot list) instead of streaming
-    every tile.  Forced on here for every round the batch allows, on corpora of several tiles, with the index rebuilt at every
-    hot-list rebuild and repack: same models as the oracle / the golden files."""
-    import ctypes as C
-    import filecmp
-    import json
-    from youtokentome_amd import _lib
-    import oracle_lib as O
-    L = _lib.load()
-    monkeypatch.setenv("YTTM_INDEX_ALWAYS", "1")
-    monkeypatch.setenv("YTTM_WORD_MODE", "0")  # (tiles to the end; word mode has its own test below)
-    gathered = builds = 0
-    rng = random.Random(77)
-    cases = [(gen.readme_corpus(300, 100, seed=6), 900), (gen.zipf_corpus(120000, vocab=3000), 700),
-             (gen.unicode_text(rng, 30000, "ascii"), 400), (("aaaa aaaaa abababab aabbaabb bbbbbb ab aaab baaa " * 400).encode(), 60)]
-    for hot in (None, (40, 4, 400)):  # default lists, and small ones: many rebuilds -> many index builds
-        if hot:
-            for k, v in zip(("YTTM_HOT_TARGET", "YTTM_HOT_MIN", "YTTM_HOT_CAP"), hot):
-                monkeypatch.setenv(k, str(v))
-        for i, (text, vocab) in enumerate(cases):
-            corpus, m_gpu, m_ora = str(tmp_path / f"c{i}.txt"), str(tmp_path / f"g{i}.model"), str(tmp_path / f"o{i}.model")
-            open(corpus, "wb").write(text)
-            err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
-            rc = L.yttm_train_bpe_ex(corpus.encode(), m_gpu.encode(), vocab, 1.0, 1, 0, 1, 2, 3, 0, rep, 16384, err, 2048)
-            assert rc == 0, err.value
-            O.train(text, m_ora, vocab)
-            assert filecmp.cmp(m_gpu, m_ora, shallow=False), (i, hot)
-            r = json.loads(rep.value.decode())
-            gathered += r["gathered_rounds"]
-            builds += r["index_builds"]
-    assert gathered > 50 and builds > 4, (gathered, builds)
 
 
 def test_word_mode(tmp_path, monkeypatch):

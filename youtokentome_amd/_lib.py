@@ -23,7 +23,7 @@ EXPORTS = [
     "yttm_id_to_subword", "yttm_subword_to_id", "yttm_decode", "yttm_vocab_size", "yttm_vocabulary", "yttm_free", "yttm_ids_fnv1a64", "yttm_encode_cli", "yttm_decode_cli", "yttm_vocab_cli",
     "yttm_encoder_set_cache", "yttm_encode_cache_words",
     "yttm_device_info", "yttm_comm_rccl_unique_id", "yttm_comm_rccl_create", "yttm_comm_callback_create",
-    "yttm_comm_destroy", "yttm_train_bpe_from_device_comm", "yttm_train_bpe_from_memory_comm",
+    "yttm_comm_destroy", "yttm_train_bpe_comm", "yttm_train_bpe_from_device_comm", "yttm_train_bpe_from_memory_comm",
     # include/yttm_gpu.h
     "yttm_gpu_ctx_create", "yttm_gpu_ctx_destroy", "yttm_gpu_ctx_set_comm", "yttm_gpu_last_error", "yttm_release_device_memory",
     "yttm_gpu_upload_corpus",
@@ -82,6 +82,7 @@ def load():
     L.yttm_comm_destroy.restype = None
     L.yttm_train_bpe_from_device_comm.argtypes = [cvp, C.c_uint64, cs, ci, cd, ci, ci, ci, ci, ci, ci, cvp, cs, ci, cs, ci]
     L.yttm_train_bpe_from_memory_comm.argtypes = [cs, C.c_uint64, cs, ci, cd, ci, ci, ci, ci, ci, cvp, cs, ci, cs, ci]
+    L.yttm_train_bpe_comm.argtypes = [cs, cs, ci, cd, ci, ci, ci, ci, ci, ci, ci, cvp, cs, ci, cs, ci]
     if hasattr(L, "yttm_comm_rccl_create"):  # absent from the emulator build (no RCCL there)
         L.yttm_comm_rccl_unique_id.argtypes = [u8p]
         L.yttm_comm_rccl_create.argtypes = [u8p, ci, ci, ci, C.POINTER(cvp)]

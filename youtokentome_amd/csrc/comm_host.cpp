@@ -122,6 +122,17 @@ int yttm_train_bpe_from_device_comm(const void *d_text, uint64_t n, const char *
   return s.code;
 }
 
+int yttm_train_bpe_comm(const char *input_path, const char *model_path, int vocab_size, double coverage, int n_threads, int pad_id, int unk_id, int bos_id,
+                        int eos_id, int device, int profile, yttm_comm *comm, char *report_json, int report_len, char *err, int errlen) {
+  TrainReport rep;
+  BpeConfig cfg = make_cfg(coverage, pad_id, unk_id, bos_id, eos_id);
+  cfg.n_threads = n_threads;
+  Status s = train_bpe(input_path, model_path ? model_path : "", vocab_size, cfg, device, &rep, (Comm *)comm, profile);
+  if (s.ok()) yttm_report_to_json(rep, report_json, report_len);
+  else put_err(err, errlen, s.message);
+  return s.code;
+}
+
 int yttm_train_bpe_from_memory_comm(const uint8_t *text, uint64_t n, const char *model_path, int vocab_size, double coverage, int pad_id,
                                     int unk_id, int bos_id, int eos_id, int device, yttm_comm *comm, char *report_json, int report_len,
                                     char *err, int errlen) {

@@ -35,9 +35,6 @@ struct RcclComm : Comm {
     NCCL_CHECK(ncclAllReduce(dev, dev, n, ncclUint64, ncclSum, comm, st));
     HIP_CHECK(hipStreamSynchronize(st));
   }
-  void allreduce_sum_u64_async(unsigned long long *dev, size_t n, hipStream_t st) override {
-    NCCL_CHECK(ncclAllReduce(dev, dev, n, ncclUint64, ncclSum, comm, st));
-  }
   void allgather_blocks(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) override {
     NCCL_CHECK(ncclAllGather(send, recv, bytes_per_rank / 8, ncclUint64, comm, st));
   }

@@ -164,15 +164,8 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   hot_cap_ = std::min(env_uint("YTTM_HOT_CAP", HOT_CAP), HOT_CAP);
   hot_target_ = env_uint("YTTM_HOT_TARGET", 1u << 13);  // measured at 1 GB: 4096..16384 equal on the abcd corpus, 8192 best on Zipf text (4279 rounds)
   hot_min_ = env_uint("YTTM_HOT_MIN", 512);
-  dense_pct_ = env_uint("YTTM_DENSE_PCT", 0);
   fuse_enabled_ = env_uint("YTTM_NO_FUSE", 0) == 0;
-  idx_enabled_ = env_uint("YTTM_NO_INDEX", 0) == 0;
-  idx_min_tiles_ = env_uint("YTTM_INDEX_MIN_TILES", 16384);
-  idx_post_per_tile_ = env_uint("YTTM_INDEX_POST_PER_TILE", 64);  // (tuning hooks: give up on an index with more postings than this per tile,
-  idx_sparse_div_ = env_uint("YTTM_INDEX_SPARSE_DIV", 8);         //  use the index when the last round touched fewer than 1/this of the tiles;
-                                                                  //  measured at 1 GB, K4 + candidate family ms: no index 151.1, 64/4 147.3, 128/4 148.8, 64/8 145.1, 32/8 147.8, 256/3 160.6)
-  idx_force_ = env_uint("YTTM_INDEX_ALWAYS", 0) != 0;  // (tests: worklists from the index whenever the batch allows, however few tiles)
-  use_pm_ = env_uint("YTTM_K4_PM", 0) != 0;
+  idx_enabled_ = env_uint("YTTM_NO_INDEX", 0) == 0;  // (no pair index: no word mode either)
   idx_agg_min_ = env_uint("YTTM_INDEX_AGG_MIN", 16u << 20);  // (fill pass of an index build: postings from which on a workgroup sums them per key in LDS first; tests: 0)
   hot_target_words_ = env_uint("YTTM_HOT_TARGET_WORDS", 1u << 15);  // (measured at 1 GB, word mode: 8192 -> 6 rebuilds, candidate family 21.0 ms; 32768 -> 3, 16.9 ms)
   // rounds of at most this many words (by the hint) whose batch travels in the kernel arguments are ONE launch, k_words<FUSED>; 0: never.
@@ -181,14 +174,13 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   word_hint_floor_ = env_uint("YTTM_WORD_HINT_FLOOR", 16384);  // (the words a round is sized for beyond twice the last round's sites; 1 GB random text, K4 ms on the device clock: 1024 -> 73.6, 4096 -> 72.7, 16384 -> 72.1)
   words_inline_max_ = env_uint("YTTM_WORDS_INLINE_MAX", 1u << 18);  // (measured at 1 GB, K4 ms: 16 k -> 97.2, 64 k -> 95.4, 256 k -> 94.1)
   profile_events_ = env_uint("YTTM_PROFILE_EVENTS", 0) != 0;
-  words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end, worklists of tiles from the pair index)
+  words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end)
+  xch_pack_tail_max_ = env_uint("YTTM_XCHG_TAIL_PACK", 2048);  // (multi-GPU: rounds of at most this many delta records pack them in the apply kernel's tail; 0: never)
   word_div_ = env_uint("YTTM_WORD_DIV", 200);  // (measured at 1 GB: 96 -> K4 135 ms, 150 -> 107, 200 -> 103.7, 300 -> 103.7, 500 -> 104)
   word_min_tiles_ = env_uint("YTTM_WORD_MIN_TILES", 16384);  // (tests: 0 = switch as soon as the hot list is active)
   // a pass over the tiles must cost more than word mode's three launches: 1 GB enwik-like text (25 M tokens, 48 us per dense round) got 15 % slower
   // in word mode, the 1 GB CJK-shaped corpus (337 M tokens) 21 % faster, random 'abcd ' (94 M tokens at the switch) 10 % faster
   word_min_tokens_ = (unsigned long long)env_uint("YTTM_WORD_MIN_TOKENS", 48u << 20);
-  bloom_mode_ = true;  // (the per-token flag variant of k_tiles is gone; the flag tables still serve the separate filter pass, YTTM_DENSE_PCT)
-  gather_grid_ = env_uint("YTTM_GATHER_GRID", 0) != 0;  // (measured at 1 GB: 65.6 vs 62.7 us per late round -- the smaller grid is not faster)
   no_batch_args_ = getenv("YTTM_NO_BATCH_ARGS") != nullptr;  // (read once per context: a round has no time for getenv)
   trace_rounds_ = getenv("YTTM_TRACE_ROUNDS");
   dbg_cand_ = getenv("YTTM_DBG_CAND");
@@ -224,11 +216,11 @@ GpuCtx::~GpuCtx() {
   tl_device = device_;
   (void)hipStreamSynchronize(st_);
   for (hipEvent_t e : all_events_) (void)hipEventDestroy(e);
-  DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_chunk_segs_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_); DFREE(d_tokflag_); DFREE(d_flagbits_);
+  DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_chunk_segs_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_);
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
-  DFREE(d_flag_upd_); DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_); DFREE(d_top_slots_); DFREE(d_top_n_); DFREE(d_box_);
+  DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_); DFREE(d_top_slots_); DFREE(d_top_n_);
   DFREE(d_send_); DFREE(d_xstat_); DFREE(d_bloom_);
-  DFREE(db_.keys); DFREE(db_.vals); DFREE(db_.touched); DFREE(db_.n);
+  DFREE(db_.keys); DFREE(db_.vals); DFREE(db_.touched); DFREE(d_dbn_);
   free_table(pt_);
   free_index();
   free_words();
@@ -465,6 +457,13 @@ unsigned long long GpuCtx::allreduce_scalar(unsigned long long v) {
   sync();
   return out;
 }
+unsigned long long GpuCtx::free_device_bytes() const {
+  if (const char *e = getenv("YTTM_TEST_FREE_BYTES")) return strtoull(e, nullptr, 10);
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> g(g_pool.mu);
+  return (unsigned long long)fr + (unsigned long long)g_pool.cached;
+}
 void GpuCtx::gather_full_corpus() {
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
@@ -598,15 +597,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   cls_[1].nom = TILE_NOM_B; cls_[1].slot = TILE_SLOT_B;
   n_alpha_ = n_alpha;
   n_unique = 0; n_tokens0 = 0; n_tiles = 0;
-  tokflag_cap_ = n_ids_cap + 64;
-  DFREE(d_tokflag_);
-  d_tokflag_ = dmalloc<uint8_t>(tokflag_cap_);
-  HIP_CHECK(hipMemsetAsync(d_tokflag_, 0, tokflag_cap_, st_));
-  if (!d_flagbits_) d_flagbits_ = dmalloc<uint32_t>(32768 / 16);
-  HIP_CHECK(hipMemsetAsync(d_flagbits_, 0, 32768 / 16 * 4, st_));
-  DFREE(d_flag_upd_);
-  d_flag_upd_ = dmalloc<uint32_t>(4 * (size_t)RULES_CAP);
-  prev_flag_toks_.clear();
+  id_cap_ = n_ids_cap + 64;
 
   const unsigned long long n_segs = n_segments;
   if (n_segs == 0 || n_text_ == 0) return;
@@ -691,7 +682,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
 }
 
 void GpuCtx::free_class(WordClass &c) {
-  DFREE(c.d_tok); DFREE(c.d_tile_len); DFREE(c.d_tile_word0); DFREE(c.d_wcnt); DFREE(c.d_worklist); DFREE(c.d_work_n); DFREE(c.d_scratch);
+  DFREE(c.d_tok); DFREE(c.d_tile_len); DFREE(c.d_tile_word0); DFREE(c.d_wcnt); DFREE(c.d_work_n); DFREE(c.d_scratch);
   c.ts = TileSet{};
   c.n_unique = c.n_tokens0 = 0;
   c.n_tiles = 0;
@@ -715,8 +706,7 @@ void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, u
   unsigned long long *tile_start = dmalloc<unsigned long long>(c.n_tiles);
   c.d_tile_word0 = dmalloc<uint32_t>(c.n_tiles);
   c.d_tile_len = dmalloc<uint32_t>(c.n_tiles);
-  c.d_worklist = dmalloc<uint32_t>(8 * ((size_t)c.n_tiles + 64));  // WL_PARTS sub-lists of WL_SEG(n_tiles) entries (k_merge.hip)
-  c.d_work_n = dmalloc<unsigned int>(16);                           // their lengths [0..7], hand-out counter [8]
+  c.d_work_n = dmalloc<unsigned int>(16);  // word mode: the round's worklist length [0], "take every word" [WL_PARTS + 1]
   HIP_CHECK(hipMemsetAsync(c.d_work_n, 0, 64, st_));
   if (ci == 0 && !multi()) {
     // The pair table is allocated and cleared HERE, ahead of the token fill, not right before K3: K3 then does not start on the
@@ -888,34 +878,51 @@ void GpuCtx::exchange_deltas() {
   size_t n_remote = 0;
   for (int attempt = 0;; attempt++) {
     unsigned long long need_all = 0;
-    if (comm_->allgather_recs(d_send_ + 1, mine, d_recv_, (size_t)recv_cap_, st_, &need_all, &n_remote)) break;
+    if (comm_->allgather_recs(d_send_ + XHDR, mine, d_recv_, (size_t)recv_cap_, st_, &need_all, &n_remote)) break;
     if (need_all == ~0ull) throw GpuError{"delta exchange buffer overflow (on some rank)"};
     if (attempt) throw GpuError{"delta receive buffer could not be sized"};
     grow_recv(need_all);
   }
   ensure_table_capacity(n_keys_host + n_remote);
-  launch_pt_apply(pt_, d_recv_, n_remote, st_);
+  launch_pt_apply(pt_, d_recv_, n_remote, st_);  // (no candidate list exists yet: nothing is listed)
   unsigned int nk = 0;
   HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
   sync();
   n_keys_host = nk;
 }
 
-// Per-round exchange: the first blk_ units (header + records) of every rank's send buffer are all-gathered and folded in by one
-// kernel that reads the counts on the device -- no copy to the host, no synchronisation.  What does not fit is reported through
-// the mailbox of the candidate scan that follows (candidates()), which repeats the exchange with larger blocks.
-// the round's delta table -> the send block (and the table is free again)
+// Per-round exchange, all stream-ordered, no host round trip:
+//   [k_dt_pack, unless the round's last apply launch packed in its tail] -> ncclAllGather of the first blk_ units (header + records) of
+//   every rank's send block -> k_pt_apply_blocks (phase 1: the other ranks' deltas into the replica, thresholds off) -> k_fold_list (phase 2:
+//   the lists, by the final counts; then -- `scan` -- the round's candidate scan straight into the host's mailbox).
+// ONE collective per round.  What does not fit a block is reported through the mailbox (xstat), and candidates() repeats the exchange
+// for exactly those ranks with larger blocks.
+// the round's delta table -> the send block (and the table is free again); the claim counters of two rounds alternate
 void GpuCtx::pack_deltas() {
-  launch_dt_pack(db_, d_send_, send_cap_, last_pack_hint_, st_);
-  HIP_CHECK(hipMemsetAsync(db_.n, 0, 8, st_));
+  launch_dt_pack(db_, d_send_, send_cap_, last_pack_hint_, d_stats_, cls_[0].n_tiles, st_);
+}
+PairTable GpuCtx::pt_nolist() const {
+  PairTable p = pt_;
+  p.hot_tau = ~0ull;
+  p.top_tau = ~0ull;
+  return p;
 }
 
-void GpuCtx::exchange_round(unsigned long long only_mask) {
+void GpuCtx::exchange_round(unsigned long long only_mask, const ScanArgs *scan) {
   chain_event_ = nullptr;
-  if (!only_mask) pack_deltas();  // (a repeat gathers the same block again, wider)
+  if (!only_mask) {  // (a repeat gathers the same block again, wider)
+    if (!xch_tail_pack_) pack_deltas();
+    xch_tail_pack_ = false;
+    xch_parity_ ^= 1u;  // the next round claims through the other counter (left at zero by this round's pack)
+    db_.n = d_dbn_ + xch_parity_;
+    db_.n_next = d_dbn_ + (xch_parity_ ^ 1u);
+  }
   grow_recv(blk_ * (unsigned long long)comm_->world);
   comm_->allgather_blocks(d_send_, d_recv_, (size_t)blk_ * sizeof(DeltaRec), st_);
-  launch_pt_apply_blocks(pt_, d_recv_, blk_, comm_->world, comm_->rank, only_mask, d_xstat_, st_);
+  launch_pt_apply_blocks(pt_nolist(), d_recv_, blk_, comm_->world, comm_->rank, only_mask, d_xstat_, st_);
+  launch_fold_list(pt_, d_recv_, blk_, comm_->world, only_mask, scan, d_stats_, pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_,
+                   pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, d_xstat_, d_hot_n_ + 1, st_);
+  if (scan) pending_zero_ = false;  // (the scan zeroes the finished batch's pairs)
 }
 
 // keys the pair table is sized for before the first merge: distinct initial pairs <= adjacencies <= tokens, and -- the candidate filter
@@ -948,10 +955,9 @@ void GpuCtx::pair_count() {
         delta_cap_forced_ = true;
       }
       alloc_delta_table(cap);
-      d_xstat_ = dmalloc<unsigned long long>(4);
-      if (!d_box_) d_box_ = dmalloc<unsigned char>(8192 + 4096 * sizeof(CandRec));  // a scan result waiting for the ranks' verdicts
-      HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, st_));
-      blk_min_ = std::max(2u, env_uint("YTTM_XCHG_BLK_MIN", 4096));  // (tests shrink it to force the repeat path)
+      d_xstat_ = dmalloc<unsigned long long>(XSTAT_WORDS);
+      HIP_CHECK(hipMemsetAsync(d_xstat_, 0, XSTAT_WORDS * 8, st_));
+      blk_min_ = std::max(2u * XHDR, env_uint("YTTM_XCHG_BLK_MIN", 4096));  // (tests shrink it to force the repeat path)
       blk_ = blk_min_;
       grow_recv(std::max<unsigned long long>(send_cap_, blk_ * (unsigned long long)comm_->world));
     }
@@ -982,17 +988,20 @@ void GpuCtx::alloc_delta_table(unsigned long long cap) {
   db_.keys = dmalloc<unsigned long long>(cap);
   db_.vals = dmalloc<long long>(cap);
   db_.touched = dmalloc<uint32_t>(cap);
-  if (!db_.n) {
-    db_.n = dmalloc<unsigned long long>(2);
-    HIP_CHECK(hipMemsetAsync(db_.n, 0, 16, st_));
+  if (!d_dbn_) {
+    d_dbn_ = dmalloc<unsigned long long>(2);
+    HIP_CHECK(hipMemsetAsync(d_dbn_, 0, 16, st_));
+    xch_parity_ = 0;
   }
+  db_.n = d_dbn_ + xch_parity_;
+  db_.n_next = d_dbn_ + (xch_parity_ ^ 1u);
   db_.mask = cap - 1;
   launch_fill_u64(db_.keys, PT_EMPTY, cap, st_);
   HIP_CHECK(hipMemsetAsync(db_.vals, 0, cap * 8, st_));
   send_cap_ = cap / 2;
-  d_send_ = dmalloc<DeltaRec>(send_cap_ + 1);
-  const DeltaRec hdr{0ull, (long long)send_cap_};  // {records, capacity}: the peers check the one against the other
-  HIP_CHECK(hipMemcpyAsync(d_send_, &hdr, sizeof hdr, hipMemcpyHostToDevice, st_));
+  d_send_ = dmalloc<DeltaRec>(send_cap_ + XHDR);
+  const DeltaRec hdr[XHDR] = {{0ull, (long long)send_cap_}, {0ull, 0ll}, {0ull, 0ll}, {0ull, 0ll}};  // {records, capacity}: the peers check the one against the other
+  HIP_CHECK(hipMemcpyAsync(d_send_, hdr, sizeof hdr, hipMemcpyHostToDevice, st_));
   sync();
 }
 
@@ -1067,7 +1076,9 @@ void GpuCtx::rebuild_hot() {
     if (acc + hist[b] > hot_cap_ / 2) break;
     acc += hist[b];
     chosen = b;
-    if (acc >= (word_mode_ ? std::max(hot_target_, hot_target_words_) : hot_target_)) break;  // (word mode: a rebuilt list means a rebuilt pair index -- two passes over the words)
+    // (word mode: a rebuilt list means a rebuilt pair index -- two passes over the words.  word_global_, not word_mode_: the threshold this
+    // picks shapes the candidate lists, which must come out alike on every rank of a sharded training)
+    if (acc >= (word_global_ ? std::max(hot_target_, hot_target_words_) : hot_target_)) break;
   }
   hot_rebuilds++;
   if (chosen < 0 || (acc < hot_min_ && chosen > 1)) {  // ties too large for the list right below the few top pairs
@@ -1090,14 +1101,15 @@ void GpuCtx::rebuild_hot() {
 bool GpuCtx::settle_exchange(unsigned long long xmask, unsigned long long xmax, unsigned long long fatal) {
   if (fatal) throw GpuError{"delta exchange buffer overflow (on some rank)"};
   unsigned long long want = blk_min_;  // next round: twice what the busiest rank sent this round
-  while (want < 2 * xmax + 2) want <<= 1;
+  while (want < 2 * xmax + 2 * XHDR) want <<= 1;
+  if (xmax || xmask) xmax_last_ = xmax;  // (decides whether the next round packs in its apply kernel's tail: the same number on every rank)
   if (!xmask) {
     if (xmax) blk_ = want;  // (xmax == 0: nothing was exchanged since the last verdict)
     return false;
   }
   blk_ = blk_min_;
-  while (blk_ < xmax + 1) blk_ <<= 1;
-  exchange_round(xmask);
+  while (blk_ < xmax + XHDR) blk_ <<= 1;
+  exchange_round(xmask, nullptr);
   {  // that fold's own report (same blocks, so nothing new): consumed here
     HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, st_));
   }
@@ -1138,6 +1150,14 @@ void GpuCtx::poll_mailbox(uint32_t round_id) {
     sites_last_ = sites - sites_cum_;
     sites_cum_ = sites;
   }
+  if (multi()) {  // the same numbers summed over the ranks' block headers: what the switch to word mode is decided from
+    const unsigned long long *xs = (const unsigned long long *)(h + MB_XSUM);
+    if (xs[3] == (unsigned long long)comm_->world) {  // (a scan that ran before any exchange leaves zeros)
+      if (xs[0] > g_sites_cum_) { g_sites_last_ = xs[0] - g_sites_cum_; g_sites_cum_ = xs[0]; }
+      if (xs[1] > g_tokens_cum_) { g_tokens_last_ = xs[1] - g_tokens_cum_; g_tokens_cum_ = xs[1]; }
+      g_tiles_a_ = xs[2];
+    }
+  }
 }
 
 // One scan of the hot list (L1) by k_hot_scan -- every listed slot, many workgroups: candidates above (t, tm), histogram of the
@@ -1151,12 +1171,6 @@ bool GpuCtx::scan_hot(unsigned long long t, uint32_t tm) {
   launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_,
                   pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, listed_last_ ? listed_last_ + 4096 : hot_cap_,
                   pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, multi() ? d_xstat_ : nullptr, st_);
-  if (multi()) {
-    // how many slots a rank's order of updates happened to put on its lists -- and so whether a list overflowed -- is the one
-    // rank-dependent quantity of a round: the verdicts are summed in stream order, then one workgroup publishes
-    comm_->allreduce_sum_u64_async(d_xstat_ + 2, 1, st_);
-    launch_publish(pt_, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_, d_xstat_, st_);
-  }
   pending_zero_ = false;
   t_end(KT_CAND, 20ull * listed_last_);  // (not chained: the host round trip that follows belongs to no kernel family)
   poll_mailbox(round_id);
@@ -1175,7 +1189,7 @@ bool GpuCtx::refill_top() {
   if (!scan_hot(~0ull >> 2, 0)) return false;
   const unsigned int *hdr = (const unsigned int *)h;
   const unsigned int listed = hdr[2], live = hdr[3];
-  const unsigned long long over = multi() ? (*(const unsigned long long *)(h + 72) & 0xffffffffull) : (listed > hot_cap_ ? 1ull : 0ull);
+  const bool over = listed > hot_cap_;  // (multi-GPU: the lists hold the same pairs on every rank -- k_fold_list -- so this verdict is every rank's)
   if (over || (live < hot_min_ && pt_.hot_tau > 1 && !hot_just_rebuilt_)) {
     hot_state_ = HOT_INVALID;  // overflowed, or running dry: relist with a new threshold (a list that is short right after its
     return false;              // rebuild stays: ties kept the threshold up)
@@ -1261,7 +1275,7 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
       const unsigned int *hdr = (const unsigned int *)h;
       n = hdr[0];
       live = hdr[3];
-      hot_over = multi() ? (*(const unsigned long long *)(h + 72) & 0xffffffffull) != 0 : hdr[2] > hot_cap_;
+      hot_over = hdr[2] > hot_cap_;
       if (hot_over || (live < hot_min_ && pt_.hot_tau > 1 && dry_rebuilds < 1)) {
         if (!hot_over) dry_rebuilds++;
         hot_state_ = HOT_INVALID;
@@ -1278,15 +1292,11 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
         sa.cap = cand_cap_;
         sa.fast = CAND_FAST;
         sa.done_ctr = nullptr;
-        sa.mailbox = multi() ? d_box_ : h;
-        sa.round_id = multi() ? 0u : round_id;
+        sa.mailbox = h;
+        sa.round_id = round_id;
         t_begin(KT_CAND);
         launch_top_scan(pt_, sa, d_stats_, pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_,
                         pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, multi() ? d_xstat_ : nullptr, st_);
-        if (multi()) {
-          comm_->allreduce_sum_u64_async(d_xstat_ + 2, 1, st_);  // the ranks' list-overflow verdicts (see scan_hot)
-          launch_publish_box(d_box_, h, CAND_FAST, round_id, d_xstat_, st_);
-        }
         pending_zero_ = false;
         t_end(KT_CAND, 20ull * top_listed_last_);
       }
@@ -1302,8 +1312,15 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
       if (use_fused) {
         fused_rounds++;
         if (dev_timing_pending_) {  // the round's duration by the device's 100 MHz clock (merge_apply: dev_timing)
-          const double ms = (double)*(const unsigned long long *)(h + 24) * 1e-5;
+          double ms = (double)*(const unsigned long long *)(h + 24) * 1e-5;
+          if (multi()) {  // the apply kernels, and what follows them (pack, all-gather, fold, scan), apart
+            const double k4 = std::min(ms, (double)*(const unsigned long long *)(h + MB_XSUM + 32) * 1e-5);
+            kt.ms[KT_XCHG] += ms - k4;
+            kt.launches[KT_XCHG]++;
+            ms = k4;
+          }
           kt.ms[KT_MERGE] += ms;
+          if (word_mode_) { merge_ms_words += ms; merge_launches_words++; }
           dev_round_ms_.push_back((float)ms);
         }
         const unsigned long long *tmk = (const unsigned long long *)(h + 96);  // scan_top's marks (100 MHz wall clock)
@@ -1312,11 +1329,6 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
         tail_ticks[2] += tmk[3] - tmk[2];
         tail_listed += top_listed;
         if (top_over) fused_overflows++;
-      }
-      if (multi()) {
-        const unsigned long long v = *(const unsigned long long *)(h + 72);  // ranks whose hot list / top list overflowed
-        hot_over = (v & 0xffffffffull) != 0;
-        top_over = (v >> 32) != 0;
       }
       // a scan that found its list overflowed read nothing -- and so did not zero the finished batch's pairs: k_pt_zero /
       // the next scan does it (the batch is still described by the zero_* members)
@@ -1385,7 +1397,10 @@ void GpuCtx::free_words() {
   DFREE(tl_.base); DFREE(tl_.cap); DFREE(tl_.fill); DFREE(tl_.rec_word); DFREE(tl_.rec_l); DFREE(tl_.rec_r); DFREE(tl_.cursor);
   tl_ = TokLists{};
   word_mode_ = false;
+  word_global_ = false;
   sites_last_ = ~0ull;
+  g_sites_last_ = ~0ull;
+  g_sites_cum_ = g_tokens_cum_ = g_tokens_last_ = g_tiles_a_ = 0;
 }
 
 // The switch to word mode (k_merge.hip: k_words): from here on class-A words live in the slots they have now and a round visits the words
@@ -1404,12 +1419,12 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
   d_drec_ = dmalloc<DeltaRec>((size_t)WORDS_MAX_GRID * drec_cap_);
   d_drec_n_ = dmalloc<unsigned int>(WORDS_MAX_GRID);
   d_irec_ = dmalloc<uint4>((size_t)WORDS_MAX_GRID * drec_cap_);
-  tl_.base = dmalloc<unsigned long long>(tokflag_cap_);
-  tl_.cap = dmalloc<uint32_t>(tokflag_cap_);
-  tl_.fill = dmalloc<uint32_t>(tokflag_cap_);
-  HIP_CHECK(hipMemsetAsync(tl_.base, 0, (size_t)tokflag_cap_ * 8, st_));
-  HIP_CHECK(hipMemsetAsync(tl_.cap, 0, (size_t)tokflag_cap_ * 4, st_));
-  HIP_CHECK(hipMemsetAsync(tl_.fill, 0, (size_t)tokflag_cap_ * 4, st_));
+  tl_.base = dmalloc<unsigned long long>(id_cap_);
+  tl_.cap = dmalloc<uint32_t>(id_cap_);
+  tl_.fill = dmalloc<uint32_t>(id_cap_);
+  HIP_CHECK(hipMemsetAsync(tl_.base, 0, (size_t)id_cap_ * 8, st_));
+  HIP_CHECK(hipMemsetAsync(tl_.cap, 0, (size_t)id_cap_ * 4, st_));
+  HIP_CHECK(hipMemsetAsync(tl_.fill, 0, (size_t)id_cap_ * 4, st_));
   tl_.cursor = dmalloc<unsigned long long>(2);
   HIP_CHECK(hipMemsetAsync(tl_.cursor, 0, 16, st_));
   // every record ever matched is a site at most once through each of its two neighbours, and a site removes a token: a few records per
@@ -1424,6 +1439,7 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
                                                                             // area and the batch staging; the kernels write it with system-scope stores)
   *(volatile unsigned int *)tl_.broken = 0;
   word_mode_ = true;
+  word_global_ = true;
   word_switch_round = merge_rounds;
   idx_valid_ = false;
   idx_pending_ = true;
@@ -1439,14 +1455,13 @@ void GpuCtx::free_index() {
   idx_valid_ = false;
 }
 
-// (Re)builds the pair index from the hot list as it is now and the class-A tiles as they are now (see k_merge.hip PairIndex).
-// Called between rounds, when the last round touched few tiles; gives up -- the rounds keep streaming every tile -- if the
-// postings would not be much smaller than the tiles themselves.
+// (Re)builds the pair index of word mode from the hot list as it is now and the class-A words as they are now (see k_merge.hip PairIndex).
+// Called between rounds.
 void GpuCtx::build_index(uint32_t z_next) {
   idx_pending_ = false;
   idx_valid_ = false;
   WordClass &c = cls_[0];
-  if (!c.n_tiles || hot_state_ != HOT_ACTIVE) return;
+  if (!c.n_tiles || hot_state_ != HOT_ACTIVE || !word_mode_) return;
   chain_event_ = nullptr;
   unsigned int listed = 0;  // (the list has grown since the scan that last reported its length)
   HIP_CHECK(hipMemcpyAsync(&listed, d_hot_n_, 4, hipMemcpyDeviceToHost, st_));
@@ -1471,7 +1486,7 @@ void GpuCtx::build_index(uint32_t z_next) {
   t_begin(KT_CAND);
   launch_idx_seed(pt_, idx_, listed, st_);
   if (!idx_save_) idx_save_ = dmalloc<unsigned char>(idx_save_bytes());
-  launch_idx_stream(0, false, c.ts, idx_, st_, word_mode_, true, idx_save_);
+  launch_idx_stream(false, c.ts, idx_, st_, true, idx_save_);
   // offsets = exclusive scan of the counts (one extra zero count behind the last slot: off[mask + 1] = the total)
   HIP_CHECK(hipMemsetAsync(idx_.cnt + want * IDX_SHARDS, 0, 4, st_));
   launch_exclusive_scan(idx_.cnt, want * IDX_SHARDS + 1, idx_.off, idx_scan_tmp_, d_counters_ + 56, st_);
@@ -1481,8 +1496,7 @@ void GpuCtx::build_index(uint32_t z_next) {
   sync();
   index_builds++;
   if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] index build at round %llu: %u listed pairs, %llu postings, %u tiles, last round touched %llu tiles\n", merge_rounds, listed, total, c.n_tiles, touched_last_);
-  // worth it only if a round's postings are few: all of them together must stay well below one posting per live token
-  if (total == 0 || total > 0xfffffff0ull || (!idx_force_ && !word_mode_ && total > (unsigned long long)c.n_tiles * idx_post_per_tile_)) {
+  if (total == 0 || total > 0xfffffff0ull) {  // (no postings, or more than the 32-bit run offsets hold: the rounds take every word)
     t_end(KT_CAND, 4ull * c.n_tiles * c.nom);
     return;
   }
@@ -1491,16 +1505,16 @@ void GpuCtx::build_index(uint32_t z_next) {
     post_cap_ = total + total / 4 + 1024;
     idx_.post = dmalloc<uint32_t>(post_cap_);
   }
-  launch_idx_stream(0, true, c.ts, idx_, st_, word_mode_, /*agg=*/total > idx_agg_min_, idx_save_);
+  launch_idx_stream(true, c.ts, idx_, st_, /*agg=*/total > idx_agg_min_, idx_save_);
   t_end(KT_CAND, 8ull * c.n_tiles * c.nom);
-  const unsigned long long stamps = word_mode_ ? c.n_unique : c.n_tiles;  // (word mode: a posting is a word, and a round claims words)
+  const unsigned long long stamps = c.n_unique;  // (a posting is a word, and a round claims words)
   if (stamps > stamp_cap_) {
     DFREE(d_stamp_);
     stamp_cap_ = (unsigned int)(stamps + stamps / 8 + 64);
     d_stamp_ = dmalloc<uint32_t>(stamp_cap_);
   }
   HIP_CHECK(hipMemsetAsync(d_stamp_, 0, (size_t)stamp_cap_ * 4, st_));
-  if (word_mode_) {  // every token that exists now is covered by the postings: the instance lists start over
+  {  // every token that exists now is covered by the postings: the instance lists start over
     HIP_CHECK(hipMemsetAsync(tl_.cursor, 0, 16, st_));
     sync();
     *(volatile unsigned int *)tl_.broken = 0;
@@ -1549,63 +1563,50 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     }
   }
 
-  // Worklist from the pair index instead of a pass over every tile?  Only when every rule of the batch is in the index (pairs of
-  // tokens older than the index; candidates come from the hot list, whose pairs were its keys), the last round touched few tiles,
-  // and once in a while not: a streamed round refreshes the live-token count the repack trigger needs.
-  // word mode: on when the last round's merge sites are few against the tokens a pass over the tiles streams (and then for good)
-  if (!word_mode_ && words_enabled_ && idx_enabled_ && !instrument && cls_[0].n_tiles >= word_min_tiles_ && cls_[0].n_tiles && hot_state_ == HOT_ACTIVE &&
-      dense_pct_ < 1000 && sites_last_ != ~0ull && live_tokens_last_ && live_tokens_last_ >= word_min_tokens_ &&
-      (word_div_ == 0 || sites_last_ * (unsigned long long)word_div_ < live_tokens_last_))
-    enter_word_mode(z_base);
+  // Word mode: on when the last round's merge sites are few against the tokens a pass over the tiles streams, and a pass is expensive
+  // (and then for good).  Single GPU: this context's numbers.  Multi-GPU: the ranks' numbers summed (block headers -> mailbox), per rank on
+  // average -- the same verdict on every rank in the same round; a rank without class-A tiles follows the decision without switching.
+  if (!word_global_ && words_enabled_ && idx_enabled_ && !instrument && hot_state_ == HOT_ACTIVE) {
+    bool go;
+    if (multi()) {
+      const unsigned long long W = (unsigned long long)comm_->world;
+      go = g_tiles_a_ >= (unsigned long long)word_min_tiles_ * W && g_tiles_a_ && g_sites_last_ != ~0ull && g_tokens_last_ && g_tokens_last_ >= word_min_tokens_ * W &&
+           (word_div_ == 0 || g_sites_last_ * (unsigned long long)word_div_ < g_tokens_last_);
+    } else {
+      go = cls_[0].n_tiles >= word_min_tiles_ && cls_[0].n_tiles && sites_last_ != ~0ull && live_tokens_last_ && live_tokens_last_ >= word_min_tokens_ &&
+           (word_div_ == 0 || sites_last_ * (unsigned long long)word_div_ < live_tokens_last_);
+    }
+    if (go) {
+      word_global_ = true;
+      if (cls_[0].n_tiles) enter_word_mode(z_base);
+      else word_switch_round = merge_rounds;
+    }
+  }
   if (word_mode_) {
     if (*(volatile unsigned int *)tl_.broken) idx_pending_ = true;  // (the last round is over: its mailbox has been read)
     if (idx_pending_) build_index(z_base);
   }
-  const bool sparse = idx_enabled_ && !words_enabled_ && !instrument && cls_[0].n_tiles && !cls_[2].n_tiles && hot_state_ == HOT_ACTIVE && dense_pct_ < 1000 &&
-                      (idx_force_ || (cls_[0].n_tiles >= idx_min_tiles_ && touched_last_ != (~0ull >> 2) && touched_last_ * idx_sparse_div_ < cls_[0].n_tiles));
-  if (sparse && idx_pending_) build_index(z_base);
-  bool gathered = sparse && idx_valid_ && rounds_since_dense_ < 32;
-  for (uint32_t j = 0; j < k && gathered; j++) gathered = std::max(xyz[3 * j], xyz[3 * j + 1]) < idx_zbuild_;
-  rounds_since_dense_ = gathered ? rounds_since_dense_ + 1 : 0;
 
   // rule hash (x != y rules) + at most one x == y rule passed by value
   unsigned int cap = 64;
   while (cap < 2 * k) cap <<= 1;
   char *pin = (char *)h_pin_ + (1u << 16) + (size_t)CAND_CAP * sizeof(CandRec);  // after the read-back area of candidates()
   RuleSlot *h_rules = (RuleSlot *)pin;
-  uint32_t *h_upd = (uint32_t *)(pin + (size_t)RULES_CAP * sizeof(RuleSlot));
   uint32_t self_x = 0xffffffffu, self_z = 0;
   for (uint32_t j = 0; j < k; j++) {
     const uint32_t x = xyz[3 * j], y = xyz[3 * j + 1], z = xyz[3 * j + 2];
-    if (x >= tokflag_cap_ || y >= tokflag_cap_ || z >= tokflag_cap_) throw GpuError{"merge_apply: token id out of range"};
+    if (x >= id_cap_ || y >= id_cap_ || z >= id_cap_) throw GpuError{"merge_apply: token id out of range"};
     if (x == y) {
       if (self_x != 0xffffffffu) throw GpuError{"merge_apply: more than one x==y rule in a batch"};
       self_x = x;
       self_z = z;
     }
   }
-  // Small batch and a round that runs without the filter pass: the batch goes to the kernels as an argument and nothing is
-  // uploaded (yttm_kernels.h: BatchArgs).  The flag tables in HBM then keep what the last uploaded batch left there.
-  auto dense_class = [&](int ci) {
-    // tuning hook YTTM_DENSE_PCT (default 0: never run the filter pass); measured at 1 GB (K4 ms): 90 % -> 217, 60 % -> 215, 30 % -> 212, 0 -> 211
-    const unsigned int dense_pct = dense_pct_;
-    if (dense_pct >= 1000) return false;  // tests: always the filter pass + worklist
-    return cls_[ci].n_tiles <= 8192 || (touched_last_ != (~0ull >> 2) && touched_last_ * 100 >= (unsigned long long)n_tiles * (unsigned long long)dense_pct);
-  };
-  const bool no_batch_args = no_batch_args_;
-  // class A goes through the position-parallel kernel (k_apply.hip: its own pair filter, no flag tables, no filter pass) unless this
-  // is the measurement pass (the word statistics live in the old kernel) or YTTM_K4_OLD asks for the old one (A/B runs)
-  const bool pm = use_pm_ && !instrument;
-  // (token flags live in an LDS bitmap of FLAG_LDS_IDS ids; the pair filter -- bloom_mode_ -- has no such limit)
-  const bool by_args = k <= (uint32_t)BATCH_ARGS_MAX && !cls_[2].n_tiles && !no_batch_args &&
-                       (pm || word_mode_ || ((bloom_mode_ || vmax < FLAG_LDS_IDS) && (!cls_[0].n_tiles || dense_class(0)))) &&
-                       (!cls_[1].n_tiles || ((bloom_mode_ || vmax < FLAG_LDS_IDS) && dense_class(1)));
-  unsigned int n_upd = 0;
+  // A small batch goes to the kernels as an argument and nothing is uploaded (yttm_kernels.h: BatchArgs); a larger one (or any, with
+  // class-C tiles: k_giant reads the rule hash from HBM) travels through k_round_begin.
+  const bool by_args = k <= (uint32_t)BATCH_ARGS_MAX && !cls_[2].n_tiles && !no_batch_args_;
   if (!by_args) {  // (the common small batch needs none of this: the host's share of a round is on the critical path)
     for (unsigned int i = 0; i < cap; i++) { h_rules[i].key = PT_EMPTY; h_rules[i].z = 0; h_rules[i].pad = 0; }
-    flag_work_.clear();
-    for (uint32_t t : prev_flag_toks_) flag_work_.push_back({t, 0});
-    flag_now_.clear();
     for (uint32_t j = 0; j < k; j++) {
       const uint32_t x = xyz[3 * j], y = xyz[3 * j + 1], z = xyz[3 * j + 2];
       if (x == y) continue;
@@ -1614,43 +1615,25 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       while (h_rules[h].key != PT_EMPTY) h = (h + 1) & (cap - 1);
       h_rules[h].key = key;
       h_rules[h].z = z;
-      flag_work_.push_back({x, 1});
-      flag_work_.push_back({y, 2});
-      flag_now_.push_back(x);
-      flag_now_.push_back(y);
-    }
-    // final flag value per token (clears of the previous batch first, then ORs of this batch)
-    std::sort(flag_work_.begin(), flag_work_.end(), [](const std::pair<uint32_t, uint8_t> &a, const std::pair<uint32_t, uint8_t> &b) { return a.first < b.first; });
-    for (size_t i = 0; i < flag_work_.size();) {
-      size_t jj = i;
-      uint8_t v = 0;
-      while (jj < flag_work_.size() && flag_work_[jj].first == flag_work_[i].first) v |= flag_work_[jj++].second;
-      h_upd[2 * n_upd] = flag_work_[i].first;
-      h_upd[2 * n_upd + 1] = v;
-      n_upd++;
-      i = jj;
     }
   }
   BatchArgs ba{};
   ba.instr = instrument ? 1u : 0u;
-  ba.bloom = bloom_mode_ ? 1u : 0u;
+  ba.bloom = 1u;
   max_id_ = std::max(max_id_, vmax);
   if (by_args) {
     ba.k = k;
     ba.small_ids = max_id_ < FLAG_LDS_IDS ? 1u : 0u;
     for (uint32_t j = 0; j < k; j++) { ba.xy[2 * j] = xyz[3 * j]; ba.xy[2 * j + 1] = xyz[3 * j + 1]; }
-  } else {
-    prev_flag_toks_.swap(flag_now_);
   }
-  // one launch per round: the apply kernel's last workgroup also does the candidate scan (see gpu_ctx.h)
+  // One launch per round: the candidate scan rides in the tail of the round's last kernel -- single GPU: the apply kernel of class A (class
+  // B goes first: the one-wave workgroups of class B took longer over the tail than the launch it saved; class-C tiles -- words of more
+  // than 2048 tokens -- keep the separate scan); multi-GPU: the fold kernel behind the all-gather (exchange_round), whatever the classes.
   ScanArgs sa{};
   fused_pending_ = false;
-  // (class-A and class-B tiles: the scan rides in the round's last launch; class-C tiles -- words of more than 2048 tokens -- keep the separate scan)
-  // class B goes first: the scan then rides in the class-A launch, whose 512-thread workgroup reads the list in one pass (the one-wave
-  // workgroups of class B took longer over the tail than the launch it saved: 1 GB CJK-shaped text, merge loop 0.80 -> 0.84 s)
   const int last_cls = cls_[0].n_tiles ? 0 : 1;
-  if (next_tau_cnt && fuse_enabled_ && !multi() && hot_state_ == HOT_ACTIVE && top_state_ == TOP_ACTIVE && (cls_[0].n_tiles || cls_[1].n_tiles) &&
-      !cls_[2].n_tiles && !instrument) {
+  if (next_tau_cnt && fuse_enabled_ && hot_state_ == HOT_ACTIVE && top_state_ == TOP_ACTIVE && !instrument &&
+      (multi() || ((cls_[0].n_tiles || cls_[1].n_tiles) && !cls_[2].n_tiles))) {
     sa.on = 1u;
     sa.tau_cnt = *next_tau_cnt;
     sa.tau_mx = next_tau_mx;
@@ -1670,10 +1653,21 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     fused_mx_ = next_tau_mx;
     fused_round_ = sa.round_id;
   }
+  // Multi-GPU: what the apply launches get instead of the scan -- the exchange tail (ScanArgs::on == 2): a small round packs its delta table
+  // in the last apply launch's tail (decided from last round's largest record count: the same on every rank, not that it had to be).
+  ScanArgs xa{};
+  if (multi()) {
+    xa.on = 2u;
+    xa.done_ctr = d_hot_n_ + 1;
+    xa.xsend = d_send_;
+    xa.xsend_cap = send_cap_;
+    xa.xtiles = cls_[0].n_tiles;
+    xa.xpack = xch_pack_tail_max_ && xmax_last_ <= xch_pack_tail_max_ && !cls_[2].n_tiles ? 1u : 0u;  // (k_giant runs behind the tile classes' launches)
+  }
   // A fused round is timed by the device itself (its first launch notes the time, the tail reports the difference in the mailbox):
   // no hipEventRecord on the round's critical path (two per round were 4 us of host time: 8 % of a Zipf step).  YTTM_PROFILE_EVENTS=1
   // keeps the events (cross-check).
-  const bool dev_timing = profile && sa.on && !profile_events_ && !gathered && !pm;  // (k_gather / k_apply_pm do not carry the mark)
+  const bool dev_timing = profile && sa.on && !profile_events_;
   bool marked = false;
   auto first_ba = [&]() {  // the BatchArgs of the round's next launch: the first one carries the mark
     BatchArgs b = ba;
@@ -1684,21 +1678,19 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   dev_timing_pending_ = dev_timing;
   if (!dev_timing) t_begin(KT_MERGE);
   if (!by_args) {
-    uint32_t *h_bloom = nullptr;
-    if (bloom_mode_ || (pm && cap > 512 && cls_[0].n_tiles)) {  // the batch's pair filter for the apply kernels (built here: a few hundred hashes)
-      h_bloom = (uint32_t *)(pin + (size_t)RULES_CAP * sizeof(RuleSlot) + 8 * (size_t)RULES_CAP * sizeof(uint32_t));
-      pm_bloom_host(h_bloom, xyz, k);
-      if (!d_bloom_) d_bloom_ = dmalloc<uint32_t>(PM_BLOOM_WORDS_H);
-    }
-    launch_round_begin(h_rules, cap, d_rules_, h_upd, n_upd, d_tokflag_, d_flagbits_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr,
-                       cls_[1].n_tiles ? cls_[1].d_work_n : nullptr, h_bloom, d_bloom_, st_);
+    uint32_t *h_bloom = (uint32_t *)(pin + (size_t)RULES_CAP * sizeof(RuleSlot) + 8 * (size_t)RULES_CAP * sizeof(uint32_t));
+    pm_bloom_host(h_bloom, xyz, k);  // the batch's pair filter for the apply kernels (built here: a few hundred hashes)
+    if (!d_bloom_) d_bloom_ = dmalloc<uint32_t>(PM_BLOOM_WORDS_H);
+    launch_round_begin(h_rules, cap, d_rules_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr, cls_[1].n_tiles ? cls_[1].d_work_n : nullptr, h_bloom, d_bloom_, st_);
   }
-  if (gathered) {  // class A: the tiles of the batch's postings, each once
-    HIP_CHECK(hipMemsetAsync(cls_[0].d_work_n, 0, 64, st_));
-    launch_gather(idx_, d_rules_, cap, by_args ? &ba : nullptr, self_x, d_stamp_, (uint32_t)(merge_rounds + 1), cls_[0].d_worklist, cls_[0].n_tiles,
-                  cls_[0].d_work_n, st_);
-    gathered_rounds++;
-  }
+  const PairTable kpt = multi() ? pt_nolist() : pt_;  // (multi-GPU: the lists are filled behind the exchange, by the final counts -- k_fold_list)
+  // the tail of class ci's launch: the scan (single GPU) or the exchange tail (multi-GPU) in the round's last tile-class launch, nothing elsewhere
+  auto tail_of = [&](int ci) -> const ScanArgs * {
+    if (ci != last_cls) return nullptr;
+    if (multi()) return xa.xpack || (ci == 0 && word_mode_) ? &xa : nullptr;  // (a tail is a ticket per workgroup: a big tile round that packs by a kernel of its own has none)
+    return sa.on ? &sa : nullptr;
+  };
+  bool tail_packed = false;
   for (int ci = 1; ci >= 0; ci--) {
     if (!cls_[ci].n_tiles) continue;
     if (ci == 0 && word_mode_) {
@@ -1739,28 +1731,19 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       ga.stats = d_stats_;
       const BatchArgs gba = first_ba();
       const WordSet wset{c.d_tok, d_wmeta_, c.d_wcnt, (uint32_t)c.n_unique};
-      if (launch_words_apply(wset, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, d_irec_, &gba,
-                             sa.on && last_cls == 0 ? &sa : nullptr, work_hint, words_inline_max_, &ga, words_fuse_max_, st_))
+      if (launch_words_apply(wset, kpt, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, d_irec_, &gba,
+                             tail_of(0), work_hint, words_inline_max_, &ga, words_fuse_max_, st_))
         word_fused_rounds++;
+      if (multi() && xa.xpack) tail_packed = true;  // (every form of the word-mode round ends in a launch that carries the tail)
       word_rounds++;
       if (!idx_valid_) word_all_rounds++;
       continue;
     }
-    const bool wl_gathered = gathered && ci == 0;
-    if (ci == 0 && pm) {
-      const bool eager_w = touched_last_ == (~0ull >> 2) || touched_last_ * 2 >= cls_[0].n_tiles;
-      pm_rounds++;
-      launch_apply_pm(cls_[0].ts, pt_, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, wl_gathered ? cls_[0].d_worklist : nullptr,
-                      cls_[0].d_work_n, d_stats_, &ba, sa.on && last_cls == 0 ? &sa : nullptr, eager_w, st_);
-      continue;
-    }
     const BatchArgs tba = first_ba();
-    launch_merge_apply(ci, cls_[ci].ts, pt_, db_, d_rules_, cap - 1, d_tokflag_, d_flagbits_, self_x, self_z, z_base, cls_[ci].d_worklist,
-                       cls_[ci].d_work_n, d_stats_, /*exact_filter=*/touched_last_ * 2 < n_tiles, /*dense=*/!wl_gathered && (by_args || dense_class(ci)),
-                       &tba, ci == last_cls && sa.on ? &sa : nullptr, wl_gathered,
-                       gather_grid_ && touched_last_ < (1ull << 30) ? (unsigned int)(2 * touched_last_) : 0u, d_bloom_, st_);
+    launch_merge_apply(ci, cls_[ci].ts, kpt, db_, d_rules_, cap - 1, self_x, self_z, z_base, d_stats_, &tba, tail_of(ci), d_bloom_, st_);
+    if (multi() && xa.xpack && ci == last_cls) tail_packed = true;
   }
-  launch_giant(true, cls_[2].ts, cls_[2].slot, pt_, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
+  launch_giant(true, cls_[2].ts, cls_[2].slot, kpt, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
   if (dev_timing) kt.launches[KT_MERGE]++;
   else t_end(KT_MERGE, 0, /*chain=*/!sa.on);  // (a fused round is followed by the host's turn, not by another kernel: its end event must not start the next interval)
   merge_rounds++;
@@ -1788,7 +1771,16 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       fclose(f);
     }
   }
-  pending_zero_ = !sa.on;  // (a fused round zeroes its batch's pairs itself)
+  if (instrument && split_round && merge_rounds == split_round) {  // (measurement pass only: a sync does not matter)
+    unsigned long long st[8] = {0};
+    launch_fold_stats(d_stats_, pt_.n_keys, st_);
+    HIP_CHECK(hipMemcpyAsync(st, d_stats_, sizeof st, hipMemcpyDeviceToHost, st_));
+    sync();
+    split_sites = st[0];
+    split_touched_words = st[4];
+    split_touched_word_tokens = st[5];
+  }
+  pending_zero_ = !sa.on || multi();  // (a fused round zeroes its batch's pairs itself; multi-GPU: exchange_round hands the batch to the fold's scan)
   zero_valid_ = true;
   zero_ba_ = ba;
   zero_cap_ = cap;
@@ -1805,7 +1797,10 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     rounds_since_check_ = 0;
     for (int ci = 0; ci < 2; ci++) maybe_repack(ci);
   }
-  if (multi()) exchange_round(0);  // (stream-ordered; the candidate scan that follows reports blocks that were too small)
+  if (multi()) {  // (stream-ordered; the scan in the fold's tail reports blocks that were too small)
+    xch_tail_pack_ = tail_packed;
+    exchange_round(0, sa.on ? &sa : nullptr);
+  }
   // single GPU: no sync here -- the candidate filter that always follows reads n_keys back together with its results
   // (its sync also makes the pinned rule staging reusable for the next round)
   // every occurrence of the batch's pairs has been merged (on every rank): their counts are exactly zero.  The candidate

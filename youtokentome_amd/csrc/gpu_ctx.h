@@ -33,7 +33,6 @@ struct Comm {
   // ---- per-round path: stream-ordered, NO host synchronisation
   // block r of recv (bytes_per_rank each, every rank's including this one's) = rank r's send block
   virtual void allgather_blocks(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) = 0;
-  virtual void allreduce_sum_u64_async(unsigned long long *dev, size_t n, hipStream_t st) { allreduce_sum_u64(dev, n, st); }
 };
 
 // returns the device (and pinned) memory cached by finished contexts to the driver
@@ -44,7 +43,7 @@ struct KernelTimes {  // accumulated GPU time per kernel family, measured with H
   unsigned long long launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // algorithmic bytes
 };
-enum { KT_CHAR_HIST = 0, KT_SEGS = 1, KT_DEDUP = 2, KT_BUILD = 3, KT_PAIR_COUNT = 4, KT_MERGE = 5, KT_CAND = 6, KT_ENCODE = 7 };
+enum { KT_CHAR_HIST = 0, KT_SEGS = 1, KT_DEDUP = 2, KT_BUILD = 3, KT_PAIR_COUNT = 4, KT_MERGE = 5, KT_CAND = 6, KT_XCHG = 7 };  // XCHG (multi-GPU): pack + all-gather + fold + the round's scan, on the device clock
 
 class GpuCtx {
  public:
@@ -59,6 +58,8 @@ class GpuCtx {
   // multi-GPU: the ranks' shards gathered into one corpus on every rank (gpu_ctx.cpp); a value summed over the ranks
   void gather_full_corpus();
   unsigned long long allreduce_scalar(unsigned long long v);
+  // HBM this context could still allocate: what the driver reports free plus the blocks the pool holds (YTTM_TEST_FREE_BYTES: tests)
+  unsigned long long free_device_bytes() const;
 
   // ---- K1
   void char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long long> &cnts, unsigned long long &n_codepoints);
@@ -89,7 +90,7 @@ class GpuCtx {
   const unsigned long long *last_hist() const { return last_hist_; }
   unsigned long long last_live() const { return last_live_; }
   int last_top_bin() const { return (int)last_top_bin_; }  // no bin above this one is in use
-  unsigned long long index_builds = 0, gathered_rounds = 0, pm_rounds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0, word_fused_rounds = 0;  // K4 rounds whose worklist came from the pair index
+  unsigned long long index_builds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0, word_fused_rounds = 0;  // K4 rounds whose worklist came from the pair index
   unsigned long long word_table_retries = 0;  // K2: the word table had to be redone with the worst-case size
   unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0, delta_regrows = 0;
   unsigned long long tail_ticks[3] = {0, 0, 0}, tail_listed = 0;  // round_tail: fold / list scan / publish, in 10 ns ticks; entries it read
@@ -112,6 +113,11 @@ class GpuCtx {
   // timed one) also the WORDS that held a site and their tokens = W_touched / T_touched of SURVEY.md 8d
   unsigned long long touched_tiles = 0, touched_tile_tokens = 0, touched_words = 0, touched_word_tokens = 0;
   bool instrument = false;
+  // measurement pass: the totals above as they stood after this many rounds (bench: the round the timed run switched to word mode at, so
+  // that the contract's bytes can be stated for the tile rounds and the word-mode rounds apart); 0: no snapshot
+  unsigned long long split_round = 0, split_touched_words = 0, split_touched_word_tokens = 0, split_sites = 0;
+  double merge_ms_words = 0;               // device-clock time of the word-mode rounds (part of kt.ms[KT_MERGE])
+  unsigned long long merge_launches_words = 0;
   void resolve_timers();
 
  private:
@@ -125,7 +131,6 @@ class GpuCtx {
   uint32_t *d_top_slots_ = nullptr;
   unsigned int *d_top_n_ = nullptr;
   unsigned int top_cap_ = 0, top_target_ = 0, top_min_ = 0, top_listed_last_ = 0, bypass_rounds_ = 0;
-  unsigned char *d_box_ = nullptr;  // multi-GPU: staging block of a top-list scan (mailbox layout)
   void poll_mailbox(uint32_t round_id);
   bool scan_hot(unsigned long long t, uint32_t tm);
   bool refill_top();
@@ -142,17 +147,13 @@ class GpuCtx {
   unsigned long long fused_tau_ = 0;  // ... for this threshold
   uint32_t fused_mx_ = 0, fused_round_ = 0;
   bool no_batch_args_ = false;
-  bool gather_grid_ = false;      // YTTM_GATHER_GRID=1: a round from the pair index launches a grid sized for its worklist (tuning hook)
-  bool bloom_mode_ = true;        // k_tiles finds its merge-site candidates with the batch's pair filter (YTTM_K4_BLOOM=0: per-token x / y flags)
-  bool use_pm_ = false;           // YTTM_K4_PM=1: class-A tiles through the position-parallel kernel (k_apply.hip) instead of k_tiles
-  uint32_t *d_bloom_ = nullptr;   // pair filter of a batch too large for the apply kernel's LDS rule hash
+  uint32_t *d_bloom_ = nullptr;   // pair filter of a batch that does not travel in the kernel arguments
   const char *trace_rounds_ = nullptr, *dbg_cand_ = nullptr;
   bool fuse_enabled_ = true;  // YTTM_NO_FUSE=1: always the separate scan kernel (tuning hook / tests)
   uint32_t id_min_ = 0, id_max_ = 0;  // id range of the alphabet (K3)
   uint32_t max_id_ = 0xffffffffu;  // largest token id in the tiles (unknown until the word table is built)
   unsigned long long scanned_cum_ = 0, live_tokens_last_ = 0, touched_cum_ = 0, touched_last_ = ~0ull >> 2;  // (first round: dense)
   unsigned int hot_cap_ = 0, hot_target_ = 0, hot_min_ = 0, listed_last_ = 0;
-  unsigned int dense_pct_ = 0;  // YTTM_DENSE_PCT: share of dirty tiles below which K4 runs a separate filter pass + worklist (>= 1000: always)
   void alloc_table(PairTable &pt, unsigned long long cap);
   void free_table(PairTable &pt);
   void exchange_deltas();
@@ -177,7 +178,7 @@ class GpuCtx {
   // token tiles: class 0 = short words (slot 1024), class 1 = long words (slot 4096)
   struct WordClass {
     TileSet ts{};
-    uint32_t *d_tok = nullptr, *d_tile_len = nullptr, *d_tile_word0 = nullptr, *d_wcnt = nullptr, *d_worklist = nullptr;
+    uint32_t *d_tok = nullptr, *d_tile_len = nullptr, *d_tile_word0 = nullptr, *d_wcnt = nullptr;
     uint32_t *d_scratch = nullptr;  // class C only (k_giant.hip)
     unsigned int *d_work_n = nullptr;
     unsigned long long n_unique = 0, n_tokens0 = 0;
@@ -187,25 +188,29 @@ class GpuCtx {
   void free_class(WordClass &c);
   void build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, unsigned int U, uint32_t space_id);
   void maybe_repack(int ci);
-  // pair index for K4's worklists (k_merge.hip: PairIndex): keys = the hot list when it was built, postings = class-A tiles
+  // pair index of word mode (k_merge.hip: PairIndex): keys = the hot list when it was built, postings = class-A words
   PairIndexArgs idx_{};
   unsigned long long idx_cap_ = 0, post_cap_ = 0;
   unsigned long long *idx_scan_tmp_ = nullptr;
   unsigned char *idx_save_ = nullptr;  // the index count pass's per-workgroup tables (k_idx_stream)
-  uint32_t *d_stamp_ = nullptr;   // [class-A tiles] round that claimed the tile for its worklist last
+  uint32_t *d_stamp_ = nullptr;   // [class-A words] round that claimed the word for its worklist last
   unsigned int stamp_cap_ = 0;
-  bool idx_valid_ = false, idx_pending_ = false, idx_enabled_ = true, idx_force_ = false;
+  bool idx_valid_ = false, idx_pending_ = false, idx_enabled_ = true;
   uint32_t idx_zbuild_ = 0;       // token ids below this existed when the index was built
-  unsigned int rounds_since_dense_ = 0, idx_min_tiles_ = 16384, idx_post_per_tile_ = 64, idx_sparse_div_ = 8;
   void build_index(uint32_t z_next);
   void free_index();
   // word mode (k_merge.hip: k_words): class-A words processed one by one from a worklist of the words that hold a merge site
   bool profile_events_ = false, dev_timing_pending_ = false;  // (merge_apply: dev_timing)
   std::vector<float> dev_round_ms_;
   bool word_mode_ = false, words_enabled_ = true;
+  // The DECISION that class A runs in word mode.  Single GPU: word_mode_ itself.  Multi-GPU: taken from numbers summed over the ranks'
+  // block headers (the same on every rank, in the same round) -- everything that shapes the candidate lists or the batches (the hot
+  // list's target, the batch split) follows this flag, never the rank-local word_mode_ (a rank without class-A words stays on tiles).
+  bool word_global_ = false;
+  unsigned long long g_sites_cum_ = 0, g_tokens_cum_ = 0, g_sites_last_ = ~0ull, g_tokens_last_ = 0, g_tiles_a_ = 0;
  public:
   // class A is in word mode, and a batch of at most this many rules is one launch there (k_words<FUSED>): the trainer's batch split
-  bool one_launch_rounds() const { return word_mode_ && words_fuse_max_ != 0 && !multi(); }
+  bool one_launch_rounds() const { return word_global_ && words_fuse_max_ != 0; }
  private:
   unsigned int hot_target_words_ = 1u << 15, words_inline_max_ = 1u << 18, words_fuse_max_ = 1u << 30, word_hint_floor_ = 16384;
   unsigned int word_div_ = 200;    // switch when (merge sites of the last round) * word_div_ < (tokens a pass over the tiles streams)
@@ -234,15 +239,10 @@ class GpuCtx {
   // per-round staging
   RuleSlot *d_rules_ = nullptr;
   unsigned int rules_cap_ = 0;
-  uint8_t *d_tokflag_ = nullptr;
-  uint32_t *d_flagbits_ = nullptr;
-  uint32_t tokflag_cap_ = 0;
-  uint32_t *d_flag_upd_ = nullptr;
+  uint32_t id_cap_ = 0;  // token ids are below this (vocab_size + slack)
   unsigned long long *d_stats_ = nullptr;
   void *h_pin_ = nullptr;  // pinned staging (rules + flag updates + candidate header)
   size_t h_pin_bytes_ = 0;
-  std::vector<uint32_t> prev_flag_toks_, flag_now_;
-  std::vector<std::pair<uint32_t, uint8_t>> flag_work_;
   // candidates
   unsigned char *d_round_ = nullptr;
   CandRec *d_cand_ = nullptr;
@@ -261,9 +261,15 @@ class GpuCtx {
   bool delta_cap_forced_ = false;  // YTTM_XCHG_TABLE_CAP (tests: the overflow verdict)
   bool pt_fresh_ = false;  // build_class(0) left an empty pair table of the initial size
   unsigned long long initial_table_keys(unsigned long long n_tok) const;
-  unsigned long long *d_xstat_ = nullptr;  // [0] ranks whose block overflowed, [1] largest count, [2] hot-list overflow verdicts
+  unsigned long long *d_xstat_ = nullptr;  // [XSTAT_WORDS] the fold's report on a round's exchange (yttm_kernels.h)
+  unsigned long long *d_dbn_ = nullptr;    // [2] the delta table's claim counters: rounds alternate, whoever packs one zeroes the other
+  unsigned int xch_parity_ = 0;
+  bool xch_tail_pack_ = false;             // the round's last apply launch packs the delta table in its tail (small rounds)
+  unsigned int xch_pack_tail_max_ = 2048;  // ... when the busiest rank sent at most this many records last round
+  unsigned long long xmax_last_ = ~0ull;
   bool multi() const { return comm_ != nullptr; }  // (a communicator of world size 1 still runs the whole exchange path)
-  void exchange_round(unsigned long long only_mask);
+  PairTable pt_nolist() const;  // pt_ with the list thresholds off (multi-GPU: the apply kernels and phase 1 of the fold list nothing)
+  void exchange_round(unsigned long long only_mask, const ScanArgs *scan);
   bool settle_exchange(unsigned long long xmask, unsigned long long xmax, unsigned long long fatal);
   void grow_recv(unsigned long long need);
 

@@ -58,11 +58,14 @@ Status check_config(BpeConfig &cfg, int vocab_size);  // bpe.cpp:1295-1350
 
 struct TrainReport {
   double seconds_total = 0, seconds_frontend = 0, seconds_merge = 0, seconds_io = 0, seconds_upload = 0;  // upload: file/host -> HBM (train_bpe only)
-  unsigned long long corpus_bytes = 0, n_unique = 0, n_tokens = 0, rounds = 0, rules = 0, cand_rescans = 0, repacks = 0, merge_sites = 0, hot_rebuilds = 0, fused_rounds = 0, fused_overflows = 0, exchange_retries = 0, word_table_retries = 0, top_refills = 0, index_builds = 0, gathered_rounds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0, word_fused_rounds = 0,
+  unsigned long long corpus_bytes = 0, n_unique = 0, n_tokens = 0, rounds = 0, rules = 0, cand_rescans = 0, repacks = 0, merge_sites = 0, hot_rebuilds = 0, fused_rounds = 0, fused_overflows = 0, exchange_retries = 0, word_table_retries = 0, top_refills = 0, index_builds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0, word_fused_rounds = 0,
                      rounds_exhausted = 0 /* batches closed for lack of candidates, not at an intersection */, batch_extensions = 0 /* extra scans that refilled the pick */, batch_splits = 0 /* batches cut to the first BATCH_ARGS_MAX rules: word mode, two one-launch rounds instead of a four-launch one */,
                      replicated_merge_loop = 0 /* multi-GPU: the shards were gathered, every rank ran the merge loop alone (no per-round collective) */;
   // K4 totals: tiles with a merge site and their tokens; words with a merge site and their tokens (measurement pass only, else 0)
   unsigned long long touched_tiles = 0, touched_tile_tokens = 0, touched_words = 0, touched_word_tokens = 0;
+  // ... the same after `split_round` rounds (YTTM_MEASURE_SPLIT_ROUND; 0: none), and the device-clock time of the word-mode rounds
+  unsigned long long split_round = 0, split_touched_words = 0, split_touched_word_tokens = 0, split_sites = 0, merge_launches_words = 0;
+  double merge_ms_words = 0;
   // per kernel family: ms, launches, algorithmic bytes (gpu_ctx.h KT_*)
   double kt_ms[8] = {0};
   unsigned long long kt_launches[8] = {0}, kt_bytes[8] = {0};
@@ -73,7 +76,7 @@ struct Comm;
 
 // bpe.h:19 train_bpe -- file based.  `device` = HIP device ordinal.
 Status train_bpe(const std::string &input_path, const std::string &model_path, int vocab_size, BpeConfig cfg, int device = 0,
-                 TrainReport *report = nullptr, Comm *comm = nullptr);
+                 TrainReport *report = nullptr, Comm *comm = nullptr, int profile = 0 /* 1: per-kernel timers in the report */);
 // same, corpus already in host memory / already resident in HBM (bench: timed region starts with the bytes in HBM)
 Status train_bpe_from_memory(const uint8_t *text, unsigned long long n, const std::string &model_path, int vocab_size, BpeConfig cfg,
                              int device = 0, TrainReport *report = nullptr, Comm *comm = nullptr);

@@ -100,7 +100,19 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     if (comm) {
       static const unsigned long long rep_max = getenv("YTTM_REPLICATE_MAX_TOKENS") ? strtoull(getenv("YTTM_REPLICATE_MAX_TOKENS"), nullptr, 10) : (1ull << 26);
       const unsigned long long t_sum = g.allreduce_scalar(g.n_tokens0);
+      // ... and only if the whole corpus fits beside the shard on EVERY rank: the gather holds the shard, the padded blocks of all ranks and
+      // the assembled text at once (about twice the whole corpus), the second dedup its segment starts and word table on top.  A large,
+      // repetitive corpus (logs; natural text of tens of GB over 8 ranks) has few dedup tokens and would qualify by tokens alone.  The
+      // verdict is collective (summed "does not fit" flags): a rank that would run out of memory must not leave the others waiting in
+      // the gather.
+      bool fits_everywhere = true;
       if (t_sum <= rep_max) {
+        const unsigned long long total_bytes = g.allreduce_scalar(g.corpus_bytes);
+        const unsigned long long need = 3 * total_bytes + total_bytes / 2 + (64ull << 20);
+        const unsigned long long no_fit = g.allreduce_scalar(need > g.free_device_bytes() / 10 * 9 ? 1ull : 0ull);
+        fits_everywhere = no_fit == 0;
+      }
+      if (t_sum <= rep_max && fits_everywhere) {
         g.gather_full_corpus();
         g.set_comm(nullptr);
         replicated = true;
@@ -292,8 +304,8 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
               g.tail_ticks[0] * 0.01 / g.fused_rounds, g.tail_ticks[1] * 0.01 / g.fused_rounds, (double)g.tail_listed / g.fused_rounds,
               g.tail_ticks[2] * 0.01 / g.fused_rounds);
     if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] host pick: threshold %.1f ms, heap build %.1f ms of the %.1f; %.0f candidates per round\n", w_pick_a * 1e3, w_pick_b * 1e3, w_pick * 1e3, (double)n_cand_sum / (double)std::max<unsigned long long>(rounds, 1));
-    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu, hot rebuilds %llu, top refills %llu, index builds %llu (%llu rounds from the index, %llu through k_apply_pm, %llu in word mode from round %llu on, %llu of them over every word), pair table %llu keys in %llu slots (%llu rehashes)\n",
-                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.hot_rebuilds, g.top_refills, g.index_builds, g.gathered_rounds, g.pm_rounds, g.word_rounds, g.word_switch_round, g.word_all_rounds, g.n_keys_host, g.table_capacity(), g.rehashes);
+    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu, hot rebuilds %llu, top refills %llu, index builds %llu (%llu rounds in word mode from round %llu on, %llu of them over every word), pair table %llu keys in %llu slots (%llu rehashes)\n",
+                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.hot_rebuilds, g.top_refills, g.index_builds, g.word_rounds, g.word_switch_round, g.word_all_rounds, g.n_keys_host, g.table_capacity(), g.rehashes);
   }
   if (rep) {
     rep->rounds = rounds;
@@ -309,7 +321,6 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     rep->word_table_retries = g.word_table_retries;
     rep->top_refills = g.top_refills;
     rep->index_builds = g.index_builds;
-    rep->gathered_rounds = g.gathered_rounds;
     rep->word_rounds = g.word_rounds;
     rep->word_switch_round = g.word_switch_round;
     rep->word_all_rounds = g.word_all_rounds;
@@ -356,6 +367,8 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     rep->merge_sites = g.merge_sites;
     rep->touched_tiles = g.touched_tiles; rep->touched_tile_tokens = g.touched_tile_tokens;
     rep->touched_words = g.touched_words; rep->touched_word_tokens = g.touched_word_tokens;
+    rep->split_round = g.split_round; rep->split_touched_words = g.split_touched_words; rep->split_touched_word_tokens = g.split_touched_word_tokens;
+    rep->split_sites = g.split_sites; rep->merge_ms_words = g.merge_ms_words; rep->merge_launches_words = g.merge_launches_words;
     for (int i = 0; i < 8; i++) { rep->kt_ms[i] = g.kt.ms[i]; rep->kt_launches[i] = g.kt.launches[i]; rep->kt_bytes[i] = g.kt.bytes[i]; }
   }
   return s;
@@ -388,6 +401,7 @@ Status train_bpe_from_device(const void *d_text, unsigned long long n, const std
     GpuCtx g(device);
     g.profile = profile && !getenv("YTTM_NO_PROFILE");  // (tuning hook: what do the timing events themselves cost?)
     g.instrument = profile == 2;
+    if (g.instrument && getenv("YTTM_MEASURE_SPLIT_ROUND")) g.split_round = strtoull(getenv("YTTM_MEASURE_SPLIT_ROUND"), nullptr, 10);
     g.set_comm(comm);
     g.attach_corpus(d_text, n);
     return learn_bpe(g, vocab_size, model_path, cfg, nullptr, report);
@@ -407,7 +421,7 @@ Status train_bpe_from_memory(const uint8_t *text, unsigned long long n, const st
 }
 
 Status train_bpe(const std::string &input_path, const std::string &model_path, int vocab_size, BpeConfig cfg, int device,
-                 TrainReport *report, Comm *comm) {
+                 TrainReport *report, Comm *comm, int profile) {
   Status st = check_config(cfg, vocab_size);
   if (!st.ok()) return st;
   print_config(input_path, model_path, vocab_size, cfg);
@@ -440,6 +454,7 @@ Status train_bpe(const std::string &input_path, const std::string &model_path, i
   fprintf(stderr, "learning bpe...\n");
   Status r = guarded([&]() {
     GpuCtx g(device);
+    g.profile = profile && !getenv("YTTM_NO_PROFILE");
     g.set_comm(comm);
     const auto t_up = clk::now();
     g.upload_corpus_fd(fd, lo, hi - lo);  // file -> pinned chunks -> HBM (replaces fast_read_file_utf8, bpe.cpp:67-84)

@@ -184,13 +184,6 @@ __device__ inline void tile_fetch(uint4 (&r)[SLOT / 256], const TileSet &ts, uin
 }
 
 
-// Batch flags for the 16 tokens a lane holds and the merge-site candidate test, entirely in registers: a tile without
-// any (x-flagged, y-flagged) adjacency -- the common case late in training -- is never staged into LDS at all.
-// Lane l holds tokens 256 j + 4 l + {0,1,2,3} in r[j]; the right neighbour of a lane's last token comes by shuffle.
-// Exact membership test of a pair in the batch (k_filter): the x/y flags are per token, so with k rules in the batch up
-// to k*k flagged adjacencies exist of which k are rules; late in training two thirds of the flag-dirty tiles hold no
-// merge site at all.  Keys of the batch's rule hash sit in LDS when they fit (FILTER_LDS_KEYS slots), else in L2.
-
 // The batch's rule hash as the apply kernel sees it: in LDS when it fits (the usual case: <= APPLY_LDS_RULES/2 rules), so
 // that processing a tile issues NO global load -- any such load would also wait (vmcnt is in-order) for the prefetch of
 // the wave's next tile, a random HBM access that costs several microseconds late in training.
@@ -217,113 +210,6 @@ struct RuleTab {
     }
   }
 };
-
-// 2-bit batch flags of a token (bit 0: x of a batch rule, bit 1: y)
-__device__ inline uint32_t flag2(uint32_t tok, const uint32_t *flagbits_lds) {
-  const uint32_t id = tok & (FLAG_LDS_IDS - 1);  // ids >= FLAG_LDS_IDS are patched afterwards (rare, wave-uniform test)
-  return (flagbits_lds[id >> 4] >> ((id & 15u) * 2)) & 3u;
-}
-__device__ inline uint32_t flag2_big(uint32_t tok, uint32_t f, const uint8_t *__restrict__ tokflag) {
-  const uint32_t id = tok & L_ID;
-  return id < FLAG_LDS_IDS ? f : (uint32_t)(tokflag[id] & 3u);
-}
-
-// per lane: does one of my (up to 16) adjacencies look like a merge site?  f[j] = the 2-bit batch flags of my tokens
-template <int SLOT>
-__device__ inline bool reg_flag_test(const uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds, const uint8_t *__restrict__ tokflag, uint32_t self_x,
-                                     uint4 (&f)[SLOT / 256], bool small_ids = false /* uniform: no id >= FLAG_LDS_IDS anywhere */) {
-  const int lane = lane_id();
-  // flags first, tokens untouched: most tiles are dismissed here and never need the flagged tokens.  Slots behind the live
-  // prefix hold zeros (never flagged), rows that start behind it were not loaded (zeros too): no bounds checks.
-  bool big = false;
-#pragma unroll
-  for (int j = 0; j < SLOT / 256; j++) {
-    f[j] = make_uint4(0, 0, 0, 0);
-    if (256 * j < n) {
-      if (!small_ids) big = big || ((r[j].x | r[j].y | r[j].z | r[j].w) & TOK_MASK) >= FLAG_LDS_IDS;
-      f[j].x = flag2(r[j].x, flagbits_lds); f[j].y = flag2(r[j].y, flagbits_lds);
-      f[j].z = flag2(r[j].z, flagbits_lds); f[j].w = flag2(r[j].w, flagbits_lds);
-    }
-  }
-  if (!small_ids && __ballot(big)) {  // some id does not fit the LDS bitmap: take its flags from the HBM byte table
-#pragma unroll
-    for (int j = 0; j < SLOT / 256; j++) {
-      if (256 * j < n) {
-        f[j].x = flag2_big(r[j].x, f[j].x, tokflag); f[j].y = flag2_big(r[j].y, f[j].y, tokflag);
-        f[j].z = flag2_big(r[j].z, f[j].z, tokflag); f[j].w = flag2_big(r[j].w, f[j].w, tokflag);
-      }
-    }
-  }
-  // (a,b) is a merge-site candidate iff a is an x and b is a y that does not start a word
-  uint32_t c = 0;
-#define YBIT(F, T) (((F) >> 1) & ~((T) >> 31))
-#pragma unroll
-  for (int j = 0; j < SLOT / 256; j++) {
-    if (256 * j < n) {
-      const uint32_t g0 = YBIT(f[j].x, r[j].x);  // is my first token a continuing y?  (asked by the lane to my left)
-      uint32_t gn = from_lane_right(g0);
-      uint32_t g_next_row = 0;  // first token of the next row, for lane 63 (shuffles are executed by all lanes)
-      if (j + 1 < SLOT / 256) g_next_row = from_lane0(YBIT(f[j + 1 < SLOT / 256 ? j + 1 : j].x, r[j + 1 < SLOT / 256 ? j + 1 : j].x));
-      if (lane == 63) gn = g_next_row;
-      c |= (f[j].x & YBIT(f[j].y, r[j].y)) | (f[j].y & YBIT(f[j].z, r[j].z)) | (f[j].z & YBIT(f[j].w, r[j].w)) | (f[j].w & gn);
-    }
-  }
-#undef YBIT
-  bool cand = c & 1u;
-  if (self_x != 0xffffffffu) {  // the x x of the self rule (at most one per batch; wave-uniform test)
-#define SELF(T0, T1) ((((T0)&L_ID) == self_x) && (((T1)&L_ID) == self_x) && !((T1)&TOK_WS))
-#pragma unroll
-    for (int j = 0; j < SLOT / 256; j++) {
-      if (256 * j < n) {
-        uint32_t nx = from_lane_right(r[j].x);
-        uint32_t nx0 = TOK_WS;
-        if (j + 1 < SLOT / 256) nx0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
-        if (lane == 63) nx = nx0;
-        cand = cand || SELF(r[j].x, r[j].y) || SELF(r[j].y, r[j].z) || SELF(r[j].z, r[j].w) || SELF(r[j].w, nx);
-      }
-    }
-#undef SELF
-  }
-  return cand;
-}
-
-template <int SLOT>
-__device__ inline bool reg_candidates(uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds, const uint8_t *__restrict__ tokflag, uint32_t self_x,
-                                      const RuleProbe probe = RuleProbe{nullptr, nullptr, 0}) {
-  const int lane = lane_id();
-  uint4 f[SLOT / 256];
-  const bool cand = reg_flag_test<SLOT>(r, n, flagbits_lds, tokflag, self_x, f);
-  if (__ballot(cand) == 0) return false;
-  // the tile is staged (or tested exactly): now the tokens get their flag bits
-#pragma unroll
-  for (int j = 0; j < SLOT / 256; j++) {
-    r[j].x |= f[j].x << 29; r[j].y |= f[j].y << 29; r[j].z |= f[j].z << 29; r[j].w |= f[j].w << 29;
-  }
-  if (!probe.g) return true;
-  // some adjacency is flagged: is any of them a rule of the batch (or the x x of the self rule)?
-  bool hit = false;
-#define PAIR_EXACT(T0, T1, P)                                                                                     \
-  if (!hit && (P) + 1 < n && !((T1)&TOK_WS)) {                                                                     \
-    if ((((T0)&L_ID) == self_x) && (((T1)&L_ID) == self_x)) hit = true;                                            \
-    else if (((T0)&L_ISX) && ((T1)&L_ISY)) hit = probe.has((T0)&L_ID, (T1)&L_ID);                                  \
-  }
-#pragma unroll
-  for (int j = 0; j < SLOT / 256; j++) {
-    if (256 * j < n) {
-      uint32_t nx = from_lane_right(r[j].x);
-      uint32_t nx0 = TOK_WS;
-      if (j + 1 < SLOT / 256) nx0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
-      if (lane == 63) nx = nx0;
-      const int p = 256 * j + 4 * lane;
-      PAIR_EXACT(r[j].x, r[j].y, p)
-      PAIR_EXACT(r[j].y, r[j].z, p + 1)
-      PAIR_EXACT(r[j].z, r[j].w, p + 2)
-      PAIR_EXACT(r[j].w, nx, p + 3)
-    }
-  }
-#undef PAIR_EXACT
-  return __ballot(hit) != 0;
-}
 
 // a merge site at position p joins the tile's list (any order; the first 64 are listed, the count goes on) and the minimum
 template <int SLOT>
@@ -415,7 +301,7 @@ __device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 2
   my_site = 0;
   typedef typename std::conditional<(SLOT / 64 > 32), unsigned long long, uint32_t>::type bits_t;
   bits_t hb = 0;  // bit 4 j + i: the adjacency that starts at my token i of row j may be a rule of the batch
-  (void)tokflag; (void)small_ids; (void)use_bloom;  // (the per-token flag test this replaced lives on in k_filter; measured at 1 GB: K4 123.3 -> 116.5 ms)
+  (void)tokflag; (void)small_ids; (void)use_bloom;  // (the per-token flag test this replaced is gone; measured at 1 GB: K4 123.3 -> 116.5 ms)
   const bool cand = reg_bloom_test<SLOT, bits_t>(r, n, flagbits_lds, self_x, hb);
   if (__ballot(cand) == 0) return 0;
   if (lane < SLOT / 64) W.sitemask[lane] = 0ull;
@@ -1193,92 +1079,14 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     if (is_last) {
       __threadfence();  // (acquire: nothing stale in this CU's caches)
       static_assert(sizeof(WL) >= (CAND_BINS + 160) * sizeof(unsigned int), "tile buffers double as the tail's scratch");
-      const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
-      scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
-    }
-  }
-}
-
-// K4 filter: streams every tile once with maximal occupancy (no per-wave LDS, two tiles in flight per wave) and writes
-// the ids of the tiles that contain a merge-site candidate -- an x-flagged token followed by a y-flagged one, or the
-// x x of a self rule -- to the worklist that k_tiles<..., true> then processes.  Late in training a batch touches a
-// few percent of the tiles; this pass is the part that has to run at HBM speed.
-template <int SLOT>
-__global__ __launch_bounds__(BLOCK, SLOT <= 512 ? 6 : 1) void k_filter(TileSet ts, const uint8_t *__restrict__ tokflag, const uint32_t *__restrict__ flagbits,
-                                                  const RuleSlot *__restrict__ rules, unsigned int rule_mask, uint32_t self_x,
-                                                  uint32_t *__restrict__ worklist, unsigned int *__restrict__ work_n,
-                                                  unsigned long long *__restrict__ stats) {
-  __shared__ uint32_t fb[FLAG_LDS_IDS / 16];
-  __shared__ unsigned long long rkeys[FILTER_LDS_KEYS];
-  for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += BLOCK) fb[s] = flagbits[s];
-  const bool keys_in_lds = rules && rule_mask < FILTER_LDS_KEYS;  // rules == nullptr: flag test only (dense rounds)
-  if (keys_in_lds)
-    for (unsigned int s = threadIdx.x; s <= rule_mask; s += BLOCK) rkeys[s] = rules[s].key;
-  const RuleProbe probe{keys_in_lds ? rkeys : nullptr, rules, rule_mask};
-  __syncthreads();
-  __shared__ uint32_t dl[1024];  // dirty tiles found by this workgroup since the last flush
-  __shared__ unsigned int dn, dbase;
-  __shared__ unsigned long long scanned_blk;
-  if (threadIdx.x == 0) { dn = 0; scanned_blk = 0; }
-  __syncthreads();
-  const int lane = lane_id();
-  const uint32_t stride = gridDim.x * NWAVES;
-  const uint32_t NT = ts.n_tiles;
-  unsigned long long scanned = 0;
-  // KT tiles per wavefront and iteration are in flight together, and their lengths were loaded one iteration earlier:
-  // an iteration exposes ONE memory round trip for 4-8 KB per wave (the first version had two tiles and a dependent
-  // length load in front of every fetch, and streamed at 2 TB/s).  All waves of the workgroup run the same number of
-  // iterations, so the block-level flush below is convergent.
-  constexpr int KT = SLOT <= 512 ? 2 : 1;
-  const uint32_t first = blockIdx.x * NWAVES + (threadIdx.x >> 6);
-  int nn[KT];
-#pragma unroll
-  for (int k = 0; k < KT; k++) {
-    const uint32_t t = first + (uint32_t)k * stride;
-    nn[k] = t < NT ? (int)ts.tile_len[t] : 0;
-  }
-  for (uint32_t tb = blockIdx.x * NWAVES; tb < NT; tb += KT * stride) {
-    const uint32_t t0 = tb + (threadIdx.x >> 6);
-    uint4 r[KT][SLOT / 256];
-    int n[KT];
-#pragma unroll
-    for (int k = 0; k < KT; k++) {
-      n[k] = nn[k];
-      const uint32_t t = t0 + (uint32_t)k * stride;
-      if (t < NT) tile_fetch<SLOT>(r[k], ts, t, n[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < KT; k++) {  // lengths for the next iteration
-      const unsigned long long t = (unsigned long long)t0 + (unsigned long long)(KT + k) * stride;
-      nn[k] = t < NT ? (int)ts.tile_len[t] : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < KT; k++) {
-      const uint32_t t = t0 + (uint32_t)k * stride;
-      if (t < NT) {
-        const bool d = reg_candidates<SLOT>(r[k], n[k], fb, tokflag, self_x, probe);
-        scanned += (unsigned long long)n[k];
-        if (d && lane == 0) dl[atomicAdd(&dn, 1u)] = t;
+      if (sa.on == 2u) {  // multi-GPU: the delta table -> the send block; the scan comes after the exchange (k_fold_list)
+        exchange_tail<WPB * 64>(db, sa, stats);
+      } else {
+        const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
+        scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
       }
     }
-    __syncthreads();
-    if (dn > 1024 - KT * NWAVES) {  // one global atomic per flush per workgroup
-      if (threadIdx.x == 0) dbase = atomicAdd(work_n + blockIdx.x % WL_PARTS, dn);
-      __syncthreads();
-      for (unsigned int i = threadIdx.x; i < dn; i += BLOCK) worklist[(blockIdx.x % WL_PARTS) * WL_SEG(NT) + dbase + i] = dl[i];
-      __syncthreads();
-      if (threadIdx.x == 0) dn = 0;
-      __syncthreads();
-    }
   }
-  if (lane == 0 && scanned) atomicAdd(&scanned_blk, scanned);
-  __syncthreads();
-  if (dn) {
-    if (threadIdx.x == 0) dbase = atomicAdd(work_n + blockIdx.x % WL_PARTS, dn);
-    __syncthreads();
-    for (unsigned int i = threadIdx.x; i < dn; i += BLOCK) worklist[(blockIdx.x % WL_PARTS) * WL_SEG(NT) + dbase + i] = dl[i];
-  }
-  if (threadIdx.x == 0) blk_add(stats, 2, scanned_blk);
 }
 
 // ------------------------------------------------------------------------------------------------- pair table kernels
@@ -1351,15 +1159,7 @@ __device__ inline void publish_round(const PairTable &pt, CandRec *__restrict__ 
     *reinterpret_cast<unsigned long long *>(mailbox + 40) = __hip_atomic_load(&stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 5)  // tiles that held a merge site so far: a dense round skips the filter's exact rule test
     *reinterpret_cast<unsigned long long *>(mailbox + 48) = __hip_atomic_load(&stats[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (threadIdx.x >= 6 && threadIdx.x < 10) {
-    const int k = (int)threadIdx.x - 6;
-    unsigned long long v = 0;
-    if (xstat) {
-      v = __hip_atomic_load(&xstat[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      xstat[k] = 0;
-    }
-    *reinterpret_cast<unsigned long long *>(mailbox + 56 + 8 * k) = v;
-  }
+  xstat_forward(mailbox, xstat, (int)threadIdx.x - 6);
   for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) {
     mb_hist[b] = __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     hist[b] = 0;
@@ -1394,7 +1194,7 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
                                                     unsigned int *__restrict__ done_ctr, unsigned char *__restrict__ mailbox, unsigned int fast,
                                                     uint32_t round_id, unsigned long long *__restrict__ stats, const RuleSlot *__restrict__ zrules,
                                                     unsigned int zmask, unsigned long long zself, BatchArgs zba,
-                                                    unsigned long long *__restrict__ xstat /* multi-GPU: leave the result for k_publish */) {
+                                                    unsigned long long *__restrict__ xstat /* multi-GPU: the exchange's report, forwarded */) {
   // zrules != nullptr: the batch that was just applied -- every occurrence of its pairs was merged, so their counts are
   // exactly zero now; they are all on the list (that is where they were picked from), so they are zeroed here instead of
   // by a kernel of their own
@@ -1488,7 +1288,7 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
     if (v) atomicAdd(&hist[b], (unsigned long long)v);
   }
   if (threadIdx.x == 0 && live_blk) atomicAdd(&n_out[3], live_blk);
-  // ---- last workgroup: publish (single GPU), or leave the verdict on the list's overflow for the ranks' all-reduce
+  // ---- last workgroup: publish
   __shared__ unsigned int is_last;
   __threadfence();
   __syncthreads();
@@ -1496,21 +1296,6 @@ __global__ __launch_bounds__(BLOCK) void k_hot_scan(PairTable pt, unsigned long 
   __syncthreads();
   if (!is_last) return;
   __threadfence();
-  if (xstat) {  // multi-GPU: k_publish runs after the all-reduce of xstat[2]
-    if (threadIdx.x == 0) {
-      xstat[2] = hn_raw > pt.hot_cap ? 1ull : 0ull;
-      *done_ctr = 0;
-    }
-    return;
-  }
-  publish_round(pt, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id, stats, nullptr);
-}
-
-// multi-GPU: publishes what k_hot_scan found once the ranks have summed their list-overflow verdicts (xstat[2])
-__global__ __launch_bounds__(BLOCK) void k_publish(PairTable pt, CandRec *__restrict__ out, unsigned int cap, unsigned int *__restrict__ n_out,
-                                                   unsigned long long *__restrict__ hist, unsigned int *__restrict__ done_ctr,
-                                                   unsigned char *__restrict__ mailbox, unsigned int fast, uint32_t round_id,
-                                                   unsigned long long *__restrict__ stats, unsigned long long *__restrict__ xstat) {
   publish_round(pt, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id, stats, xstat);
 }
 
@@ -1572,32 +1357,6 @@ __global__ __launch_bounds__(BLOCK) void k_top_rebuild(PairTable pt) {
       }
     }
   }
-}
-
-// multi-GPU: forwards a staged scan result (box, written by k_top_scan) to the host's mailbox once the ranks have summed their
-// list verdicts into xstat[2], together with the exchange's report (xstat), and publishes the round id.
-__global__ __launch_bounds__(BLOCK) void k_publish_box(const unsigned char *__restrict__ box, unsigned char *__restrict__ mailbox, unsigned int fast,
-                                                       uint32_t round_id, unsigned long long *__restrict__ xstat) {
-  const unsigned int *bh = reinterpret_cast<const unsigned int *>(box);
-  unsigned int *mh = reinterpret_cast<unsigned int *>(mailbox);
-  if (threadIdx.x < 8) mh[threadIdx.x] = bh[threadIdx.x];  // (header; [24..31]: the round's duration on the device)
-  if (threadIdx.x >= 10 && threadIdx.x < 14) mh[threadIdx.x] = bh[threadIdx.x];  // bytes 40..55
-  if (threadIdx.x >= 6 && threadIdx.x < 10) {
-    const int k = (int)threadIdx.x - 6;
-    *reinterpret_cast<unsigned long long *>(mailbox + 56 + 8 * k) = xstat[k];
-    xstat[k] = 0;
-  }
-  if (threadIdx.x >= 22 && threadIdx.x < 32) mh[threadIdx.x] = bh[threadIdx.x];  // bytes 88..95: merge sites so far; 96..127: timing marks
-  const unsigned long long *bhist = reinterpret_cast<const unsigned long long *>(box + MB_HIST);
-  unsigned long long *mhist = reinterpret_cast<unsigned long long *>(mailbox + MB_HIST);
-  for (int b = (int)threadIdx.x; b < CAND_BINS; b += BLOCK) mhist[b] = bhist[b];
-  unsigned int take = bh[0] < fast ? bh[0] : fast;
-  const uint4 *src = reinterpret_cast<const uint4 *>(box + 8192);
-  uint4 *dst = reinterpret_cast<uint4 *>(mailbox + 8192);
-  for (unsigned int i = threadIdx.x; i < take; i += BLOCK) dst[i] = src[i];
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(&mh[8], round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // (Re)build the hot list: every slot with count >= pt.hot_tau, in one streaming pass; PT_HOT is set exactly on those.
@@ -1670,32 +1429,36 @@ __global__ __launch_bounds__(BLOCK) void k_pt_apply(PairTable pt, const DeltaRec
   for (; i < n; i += stride) pt_add(pt, recs[i].key, recs[i].delta);
 }
 
-// multi-GPU: the delta table of the round that just ran -> the contiguous send block { {count, capacity}, records... }; the claimed
-// slots are freed for the next round.  *db.n is reset by the host (stream-ordered memset) afterwards.
-__global__ __launch_bounds__(BLOCK) void k_dt_pack(DeltaBuf db, DeltaRec *__restrict__ send, unsigned long long send_cap) {
+// multi-GPU: the delta table of the round that just ran -> the contiguous send block { header, records... } (k_merge_shared.h: dt_pack_*);
+// the claimed slots are freed for the next round.  (A small round's last apply launch does this in its tail instead: ScanArgs::xpack.)
+__global__ __launch_bounds__(BLOCK) void k_dt_pack(DeltaBuf db, DeltaRec *__restrict__ send, unsigned long long send_cap, unsigned long long *__restrict__ stats,
+                                                   uint32_t tiles_a) {
   const unsigned long long n_raw = *db.n;
   const unsigned long long n = n_raw <= db.mask + 1 ? n_raw : db.mask + 1;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    send[0].key = n_raw;                    // (a count beyond the capacity tells every rank that this one lost updates)
-    send[0].delta = (long long)send_cap;
-  }
-  for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * BLOCK) {
-    const uint32_t sl = db.touched[i];
-    if (i < send_cap) {
-      send[1 + i].key = db.keys[sl];
-      send[1 + i].delta = db.vals[sl];
-    }
-    db.keys[sl] = PT_EMPTY;
-    db.vals[sl] = 0;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) dt_pack_header(db, send, send_cap, n_raw, stats, tiles_a);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * BLOCK) dt_pack_rec(db, send, send_cap, i);
 }
 
-// multi-GPU, per round: the ranks' delta blocks as ncclAllGather left them -- block r = { count, -, records... } of `blk` 16-byte
-// units -- folded into the local replica.  A rank whose count does not fit its block is skipped as a whole and reported in
-// xstat[0] (bit r); the host then repeats the exchange with larger blocks for exactly those ranks (only_mask).  xstat[1] =
-// largest count seen (sizes the next round's blocks).  No host round trip: counts are read on the device.
+// multi-GPU, per round, phase 1: the ranks' delta blocks as ncclAllGather left them -- block r = { header, records... } of `blk` 16-byte
+// units -- and the OTHER ranks' deltas folded into the local replica (pt comes with its list thresholds off: nothing is listed here, see
+// k_fold_list).  A rank whose count does not fit its block is skipped as a whole and reported in xstat[0] (bit r); the host then repeats
+// the exchange with larger blocks for exactly those ranks (only_mask).  xstat[1] = largest count seen (sizes the next round's blocks),
+// xstat[4..7] = sums over the headers.  No host round trip: counts are read on the device.
 __global__ __launch_bounds__(BLOCK) void k_pt_apply_blocks(PairTable pt, const DeltaRec *__restrict__ blocks, unsigned long long blk, int world,
                                                            int rank, unsigned long long only_mask, unsigned long long *__restrict__ xstat) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && !only_mask) {  // (a repeat gathers the same headers again)
+    unsigned long long sites = 0, toks = 0, tiles = 0;
+    for (int r = 0; r < world; r++) {
+      const DeltaRec *b = blocks + (size_t)r * blk;
+      sites += b[1].key;
+      toks += (unsigned long long)b[1].delta;
+      tiles += b[2].key;
+    }
+    xstat[4] = sites;
+    xstat[5] = toks;
+    xstat[6] = tiles;
+    xstat[7] = (unsigned long long)world;
+  }
   for (int r = 0; r < world; r++) {
     const DeltaRec *b = blocks + (size_t)r * blk;
     const unsigned long long n = b[0].key;  // header: record count of rank r, capacity of its send buffer
@@ -1704,7 +1467,7 @@ __global__ __launch_bounds__(BLOCK) void k_pt_apply_blocks(PairTable pt, const D
       if (n > (unsigned long long)b[0].delta) xstat[3] = 1ull;  // rank r lost records: every rank reads this verdict and stops
     }
     if (only_mask && !((only_mask >> r) & 1ull)) continue;
-    if (n > blk - 1) {  // (reported for the own block too: every rank must reach the same verdict)
+    if (n > blk - XHDR) {  // (reported for the own block too: every rank must reach the same verdict)
       if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&xstat[0], 1ull << r);
       continue;
     }
@@ -1712,46 +1475,108 @@ __global__ __launch_bounds__(BLOCK) void k_pt_apply_blocks(PairTable pt, const D
     unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
     const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
     for (; i < n; i += stride)
-      if (b[1 + i].delta) pt_add(pt, b[1 + i].key, b[1 + i].delta);  // (updates of a round often cancel)
+      if (b[XHDR + i].delta) pt_add(pt, b[XHDR + i].key, b[XHDR + i].delta);  // (updates of a round often cancel)
   }
 }
 
-// per-round batch flags: byte table for every id + packed 2-bit copy of the first FLAG_LDS_IDS ids (staged into LDS by K4)
-__global__ __launch_bounds__(BLOCK) void k_set_tokflag(uint8_t *__restrict__ tokflag, uint32_t *__restrict__ flagbits,
-                                                       const uint32_t *__restrict__ upd, unsigned int n) {
-  unsigned int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t id = upd[2 * i], v = upd[2 * i + 1] & 3u;
-  tokflag[id] = (uint8_t)v;
-  if (id < 32768u) {
-    const uint32_t sh = (id & 15u) * 2;
-    atomicAnd(&flagbits[id >> 4], ~(3u << sh));
-    atomicOr(&flagbits[id >> 4], v << sh);
+// multi-GPU, per round, phase 2 (behind phase 1's kernel boundary: every rank's deltas are in the table).  A count that reached a list
+// threshold during this round puts its slot on that list HERE, judged by the FINAL count -- the same on every rank -- and not by whichever
+// adder happened to see a crossing (the apply kernels and phase 1 run with the thresholds off): a transient crossing -- this rank's +5
+// before another's -3 -- would list the slot on one rank and not on the other, and the lists' lengths (so: whether one overflowed) would
+// have to be agreed on by a collective of their own every round.  Only a pair some rank raised can have crossed: every record with a
+// positive delta of every block, this rank's included, is looked up; several ranks' records of one pair meet at the flag (atomicOr:
+// whoever sets it appends).  Then the round's candidate scan, by the last workgroup (scan_top, straight into the host's mailbox), with
+// the fold's report on the exchange (xstat).
+constexpr int FOLD_NT = 512;
+__global__ __launch_bounds__(FOLD_NT) void k_fold_list(PairTable pt, const DeltaRec *__restrict__ blocks, unsigned long long blk, int world,
+                                                        unsigned long long only_mask, ScanArgs sa, unsigned long long *__restrict__ stats,
+                                                        const RuleSlot *__restrict__ zrules, unsigned int zmask, unsigned long long zself, BatchArgs zba,
+                                                        unsigned long long *__restrict__ xstat, unsigned int *__restrict__ done_ctr) {
+  __shared__ unsigned long long zkeys[FILTER_LDS_KEYS];
+  __shared__ unsigned int scratch[CAND_BINS + 160];
+  __shared__ unsigned int is_last;
+  if (pt.hot_tau != ~0ull) {
+    for (int r = 0; r < world; r++) {
+      const DeltaRec *b = blocks + (size_t)r * blk;
+      const unsigned long long n = b[0].key;
+      if (only_mask && !((only_mask >> r) & 1ull)) continue;
+      if (n > blk - XHDR) continue;  // (skipped by phase 1 as well; the repeat brings it)
+      for (unsigned long long i = (unsigned long long)blockIdx.x * FOLD_NT + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * FOLD_NT) {
+        if (b[XHDR + i].delta <= 0) continue;
+        const unsigned long long key = b[XHDR + i].key;
+        unsigned long long j = mix64(key) & pt.mask;
+        for (;;) {
+          const unsigned long long k = ld_agent(pt.key_p(j));
+          if (k == PT_EMPTY) break;  // (cannot happen: a positive delta was added, so the key is there)
+          if (k == key) {
+            const unsigned long long raw = ld_agent(pt.cnt_p(j)), c = raw & PT_CNT;
+            unsigned long long want = 0;
+            if (!(raw & PT_HOT) && c >= pt.hot_tau) want |= PT_HOT;
+            if (!(raw & PT_TOP) && c >= pt.top_tau) want |= PT_TOP;
+            if (want) {
+              const unsigned long long fresh = want & ~atomicOr(pt.cnt_p(j), want);
+              if (fresh & PT_HOT) {
+                const unsigned int o = atomicAdd(pt.hot_n, 1u);
+                if (o < pt.hot_cap) __hip_atomic_store(&pt.hot_slots[o], (uint32_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              if (fresh & PT_TOP) {
+                const unsigned int o = atomicAdd(pt.top_n, 1u);
+                if (o < pt.top_cap) __hip_atomic_store(&pt.top_slots[o], (uint32_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+            break;
+          }
+          j = (j + 1) & pt.mask;
+        }
+      }
+    }
   }
+  if (!sa.on) return;
+  // ---- the round's candidate scan, by the last workgroup to get here (the ticket: as in k_tiles)
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(done_ctr, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  bool zkeys_in_lds = zrules && zmask < FILTER_LDS_KEYS;  // (the finished batch's pairs, to be zeroed: as in k_top_scan)
+  if (zba.k) {
+    zmask = 4 * BATCH_ARGS_MAX - 1;
+    zkeys_in_lds = true;
+    for (unsigned int sl = threadIdx.x; sl <= zmask; sl += FOLD_NT) zkeys[sl] = PT_EMPTY;
+    __syncthreads();
+    if (threadIdx.x < zba.k && zba.xy[2 * threadIdx.x] != zba.xy[2 * threadIdx.x + 1]) {  // (BATCH_ARGS_MAX <= the block size)
+      const unsigned long long key = pair_key(zba.xy[2 * threadIdx.x], zba.xy[2 * threadIdx.x + 1]);
+      unsigned int h = pair_hash32(key) & zmask;
+      while (atomicCAS(&zkeys[h], PT_EMPTY, key) != PT_EMPTY) h = (h + 1) & zmask;
+    }
+  } else if (zkeys_in_lds) {
+    for (unsigned int sl = threadIdx.x; sl <= zmask; sl += FOLD_NT) zkeys[sl] = zrules[sl].key;
+  } else if (!zrules) {  // nothing to zero: an empty table
+    zmask = 0;
+    zkeys_in_lds = true;
+    if (threadIdx.x == 0) zkeys[0] = PT_EMPTY;
+  }
+  __syncthreads();
+  const RuleProbe zprobe{zkeys_in_lds ? zkeys : nullptr, zrules, zmask};
+  ScanArgs sb = sa;
+  sb.done_ctr = done_ctr;  // (scan_top leaves the ticket at zero)
+  scan_top<FOLD_NT>(pt, sb, stats, zprobe, zself, scratch, xstat);
 }
 
-// Start of a merge round, one launch instead of two copies, a kernel and two memsets: the batch's rule hash and the token
-// flag updates are read straight from the host's pinned staging area (a few KB over PCIe), the worklist counters are
-// reset.
+// Start of a merge round whose batch does not fit the kernel arguments, one launch instead of copies and memsets: the batch's rule hash
+// and its pair filter are read straight from the host's pinned staging area (a few KB over PCIe), the worklist counters are reset.
 __global__ __launch_bounds__(BLOCK) void k_round_begin(const RuleSlot *__restrict__ src_rules, unsigned int n_slots, RuleSlot *__restrict__ dst_rules,
-                                                       const uint32_t *__restrict__ upd, unsigned int n_upd, uint8_t *__restrict__ tokflag,
-                                                       uint32_t *__restrict__ flagbits, unsigned int *__restrict__ work_n_a,
-                                                       unsigned int *__restrict__ work_n_b, const uint32_t *__restrict__ src_bloom,
-                                                       uint32_t *__restrict__ dst_bloom) {
+                                                       unsigned int *__restrict__ work_n_a, unsigned int *__restrict__ work_n_b,
+                                                       const uint32_t *__restrict__ src_bloom, uint32_t *__restrict__ dst_bloom) {
   const unsigned int tid = blockIdx.x * BLOCK + threadIdx.x, nt = gridDim.x * BLOCK;
-  if (src_bloom)  // (k_apply.hip: the pair filter of a batch too large for the apply kernel's LDS rule hash)
+  if (src_bloom)
     for (unsigned int i = tid; i < (unsigned int)PM_BLOOM_WORDS_H; i += nt) dst_bloom[i] = src_bloom[i];
   for (unsigned int i = tid; i < n_slots; i += nt)
     reinterpret_cast<uint4 *>(dst_rules)[i] = reinterpret_cast<const uint4 *>(src_rules)[i];
-  for (unsigned int i = tid; i < n_upd; i += nt) {
-    const uint32_t id = upd[2 * i], v = upd[2 * i + 1] & 3u;
-    tokflag[id] = (uint8_t)v;
-    if (id < FLAG_LDS_IDS) {
-      const uint32_t sh = (id & 15u) * 2;
-      atomicAnd(&flagbits[id >> 4], ~(3u << sh));
-      atomicOr(&flagbits[id >> 4], v << sh);
-    }
-  }
   if (tid == 0) {
     for (uint32_t i = 0; i <= WL_PARTS + 1; i++) {  // sub-list lengths, hand-out counter, "worklist incomplete" verdict
       if (work_n_a) work_n_a[i] = 0;
@@ -1956,38 +1781,6 @@ __global__ __launch_bounds__(IDXA_NT) void k_idx_stream(TileSet ts, PairIndex ix
   __syncthreads();
   idx_sweep<SLOT, FILL, WORDS, 1>(ts, ix, bloom, T, shard);
 }
-// One workgroup per rule of the batch (slot of the batch's rule hash, or index into the kernel-argument batch): the tiles of its
-// postings join the round's worklist -- each tile once (stamp = the round that claimed it last).  A pair that is not in the index
-// raises work_n[WL_PARTS + 1]: the apply kernel then ignores the worklist and takes every tile.
-__global__ __launch_bounds__(BLOCK) void k_gather(PairIndex ix, const RuleSlot *__restrict__ rules, unsigned int n_slots, BatchArgs ba, uint32_t self_x,
-                                                  uint32_t *__restrict__ stamp, uint32_t round_id, uint32_t *__restrict__ worklist, size_t wl_seg,
-                                                  unsigned int *__restrict__ work_n) {
-  unsigned long long key = PT_EMPTY;
-  const unsigned int n_rules = ba.k ? ba.k : n_slots;
-  if (blockIdx.x < n_rules) {
-    if (ba.k) {
-      const uint32_t x = ba.xy[2 * blockIdx.x], y = ba.xy[2 * blockIdx.x + 1];
-      if (x != y) key = pair_key(x, y);
-    } else {
-      key = rules[blockIdx.x].key;
-    }
-  } else if (blockIdx.x == n_rules && self_x != 0xffffffffu) {
-    key = pair_key(self_x, self_x);
-  }
-  if (key == PT_EMPTY) return;
-  const uint32_t s = idx_find(ix, key, enc_hash((uint32_t)(key >> 32), (uint32_t)key));
-  if (s == 0xffffffffu) {
-    if (threadIdx.x == 0) work_n[WL_PARTS + 1] = 1u;
-    return;
-  }
-  const unsigned long long o0 = ix.off[(size_t)s * IDX_SHARDS], o1 = ix.off[((size_t)s + 1) * IDX_SHARDS];
-  const uint32_t part = blockIdx.x % WL_PARTS;
-  for (unsigned long long i = o0 + threadIdx.x; i < o1; i += BLOCK) {
-    const uint32_t t = ix.post[i];
-    if (atomicExch(&stamp[t], round_id) != round_id) worklist[part * wl_seg + atomicAdd(&work_n[part], 1u)] = t;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------- word mode
 // Once a round's merge sites are few against the tokens a pass over the tiles streams, class-A words leave the tiles (yttm_device.h:
 // WordSet): a round then (1) k_wgather looks the batch's rules up -- postings of the pair index, or the instance list of the pair's
@@ -2754,8 +2547,12 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
     if (is_last) {
       __threadfence();
       if (threadIdx.x <= WL_PARTS + 1) const_cast<unsigned int *>(work_n)[threadIdx.x] = 0;  // (every workgroup has read it)
-      const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
-      scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
+      if (sa.on == 2u) {  // multi-GPU (see k_tiles)
+        exchange_tail<WPB * 64>(db, sa, stats);
+      } else {
+        const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
+        scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
+      }
     }
   }
 }
@@ -2793,6 +2590,10 @@ __global__ __launch_bounds__(DAPPLY_NT) void k_delta_apply(PairTable pt, DeltaBu
   __syncthreads();
   if (!is_last) return;
   __threadfence();
+  if (sa.on == 2u) {  // multi-GPU (see k_tiles)
+    exchange_tail<DAPPLY_NT>(db, sa, stats);
+    return;
+  }
   bool zkeys_in_lds = zrules && zmask < FILTER_LDS_KEYS;  // (the finished batch's pairs, to be zeroed: as in k_top_scan)
   if (zba.k) {
     zmask = 4 * BATCH_ARGS_MAX - 1;
@@ -3025,6 +2826,16 @@ __global__ __launch_bounds__(256) void k_pair_count_dense(TileSet ts, PairTable 
   if (threadIdx.x == 0 && new_keys) atomicAdd(pt.n_keys, new_keys);
 }
 
+void pm_bloom_host(uint32_t *bloom, const uint32_t *xyz, uint32_t k) {  // (a batch that does not travel in the kernel arguments: its pair filter, built by the host)
+  for (int i = 0; i < PM_BLOOM_WORDS; i++) bloom[i] = 0;
+  for (uint32_t j = 0; j < k; j++) {
+    const uint32_t x = xyz[3 * j], y = xyz[3 * j + 1];
+    if (x == y) continue;
+    const uint32_t h = pm_hash(x, y);
+    bloom[pm_word(h)] |= pm_bits(h);
+  }
+}
+
 static inline unsigned int tile_grid(unsigned int n_tiles, unsigned int wpb, unsigned int blocks_per_cu) {
   unsigned int need = (n_tiles + wpb - 1) / wpb;
   unsigned int g = 256u * blocks_per_cu;
@@ -3055,21 +2866,14 @@ void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const De
                        (const uint32_t *)nullptr, (const unsigned int *)nullptr, (unsigned long long *)nullptr, BatchArgs{}, ScanArgs{});
 }
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
-                        const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
-                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
-                        const ScanArgs *scan, bool wl_gathered, unsigned int work_hint, const uint32_t *bloom_g, hipStream_t st) {
+                        uint32_t self_x, uint32_t self_z, uint32_t z_base, unsigned long long *stats, const BatchArgs *ba, const ScanArgs *scan,
+                        const uint32_t *bloom_g, hipStream_t st) {
   if (!ts.n_tiles) return;
   const BatchArgs bargs = ba ? *ba : BatchArgs{};
-  const uint32_t *tflags = bargs.bloom ? bloom_g : flagbits;  // what the apply kernel stages into LDS (the filter pass keeps the token flags)
   const ScanArgs sargs = scan ? *scan : ScanArgs{};  // (the caller hands the scan to the round's LAST launch)
-  const RuleSlot *frules = exact_filter ? rules : nullptr;
-  // dense round (nearly every tile held a site last round): the filter pass would keep everything -- the apply kernel
-  // takes all tiles and dismisses the few clean ones itself
-  if (dense) worklist = nullptr;
-  // pass 1: which tiles have a merge-site candidate; pass 2: apply the batch to those
-  const unsigned int kt = cls == 0 ? 2 : 1;  // tiles per wavefront and iteration (k_filter: KT)
-  unsigned int fg = (ts.n_tiles + kt * NWAVES - 1) / (kt * NWAVES);
-  if (fg > 256 * 6) fg = 256 * 6;  // 6 workgroups per CU (7 fit); must stay <= BLK_ROWS: every workgroup owns a statistics row
+  // One pass: the apply kernel takes every tile and dismisses the clean ones itself, in registers (a separate filter pass with a
+  // worklist of dirty tiles was measured slower at every share of dirty tiles and is gone, like the worklists of tiles from the pair
+  // index: class A leaves the tiles for word mode before either could pay).
   // class-A grid: APPLY_BPC workgroups per CU when there are tiles for all of them; a small tile set (natural-language corpora:
   // a few thousand tiles) gets fewer workgroups with several tiles per wave -- every workgroup costs a prologue (44 KB of LDS set-up)
   // and a serialised ticket at the end (~11 ns each), which a round of ~15 us notices.  YTTM_APPLY_GRID overrides (tuning hook).
@@ -3077,28 +2881,25 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
   {
     static const char *g_env = getenv("YTTM_APPLY_GRID");
     const unsigned int small = g_env ? (unsigned int)atoi(g_env) : 256u;
-    // (a worklist gathered from the pair index is a small tile set too, however many tiles there are: work_hint = what the last round touched)
-    const unsigned int work = wl_gathered && work_hint ? work_hint : ts.n_tiles;
-    if (work <= 16384 && small && grid_a > small) grid_a = small;
+    if (ts.n_tiles <= 16384 && small && grid_a > small) grid_a = small;
   }
+  const uint8_t *no_flags = nullptr;
+  const uint32_t *no_list = nullptr;
+  const unsigned int *no_n = nullptr;
   if (cls == 0) {
-    if (!dense && !wl_gathered) hipLaunchKernelGGL((k_filter<TILE_SLOT_A>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
-                       stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, true>), dim3(grid_a), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, tflags, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
+                         no_flags, bloom_g, self_x, self_z, z_base, no_list, no_n, stats, bargs, sargs);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, false>), dim3(grid_a), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, tflags, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
+                         no_flags, bloom_g, self_x, self_z, z_base, no_list, no_n, stats, bargs, sargs);
   } else {
-    if (!dense && !wl_gathered) hipLaunchKernelGGL((k_filter<TILE_SLOT_B>), dim3(fg), dim3(BLOCK), 0, st, ts, tokflag, flagbits, frules, rule_mask, self_x, worklist, work_n,
-                       stats);
     if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, tflags, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
+                         no_flags, bloom_g, self_x, self_z, z_base, no_list, no_n, stats, bargs, sargs);
     else
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
-                         tokflag, tflags, self_x, self_z, z_base, (const uint32_t *)worklist, (const unsigned int *)work_n, stats, bargs, sargs);
+                         no_flags, bloom_g, self_x, self_z, z_base, no_list, no_n, stats, bargs, sargs);
   }
 }
 void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap,
@@ -3120,21 +2921,28 @@ void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t t
   hipLaunchKernelGGL(k_hot_scan, dim3(g), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id,
                      stats, zrules, zmask, zself, zba ? *zba : BatchArgs{}, xstat);
 }
-void launch_publish(const PairTable &pt, CandRec *out, unsigned int cap, unsigned int *n_out, unsigned long long *hist, unsigned int *done_ctr,
-                    unsigned char *mailbox, unsigned int fast, uint32_t round_id, unsigned long long *stats, unsigned long long *xstat, hipStream_t st) {
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(BLOCK), 0, st, pt, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id, stats, xstat);
-}
-void launch_dt_pack(const DeltaBuf &db, DeltaRec *send, unsigned long long send_cap, unsigned int n_hint, hipStream_t st) {
+void launch_dt_pack(const DeltaBuf &db, DeltaRec *send, unsigned long long send_cap, unsigned int n_hint, unsigned long long *stats, uint32_t tiles_a, hipStream_t st) {
   unsigned int g = (n_hint + BLOCK - 1) / BLOCK;
   if (g < 8) g = 8;
   if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(k_dt_pack, dim3(g), dim3(BLOCK), 0, st, db, send, send_cap);
+  hipLaunchKernelGGL(k_dt_pack, dim3(g), dim3(BLOCK), 0, st, db, send, send_cap, stats, tiles_a);
 }
 void launch_pt_apply_blocks(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, int rank, unsigned long long only_mask,
                             unsigned long long *xstat, hipStream_t st) {
   unsigned long long b = (blk + BLOCK - 1) / BLOCK;
   if (b > 256 * 4) b = 256 * 4;
+  if (world == 1 && b > 1) b = 1;  // (a communicator of one rank: only the headers are looked at)
   hipLaunchKernelGGL(k_pt_apply_blocks, dim3((unsigned int)b), dim3(BLOCK), 0, st, pt, blocks, blk, world, rank, only_mask, xstat);
+}
+void launch_fold_list(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, unsigned long long only_mask, const ScanArgs *scan,
+                      unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, const BatchArgs *zba,
+                      unsigned long long *xstat, unsigned int *done_ctr, hipStream_t st) {
+  // every workgroup takes a ticket at the end (~12 ns each on one address), and the last one scans: no more of them than the blocks need
+  unsigned long long b = (blk + FOLD_NT - 1) / FOLD_NT;
+  if (b > 256 * 2) b = 256 * 2;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(k_fold_list, dim3((unsigned int)b), dim3(FOLD_NT), 0, st, pt, blocks, blk, world, only_mask, scan ? *scan : ScanArgs{}, stats, zrules, zmask, zself,
+                     zba ? *zba : BatchArgs{}, xstat, done_ctr);
 }
 void launch_top_scan(const PairTable &pt, const ScanArgs &sa, unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself,
                      const BatchArgs *zba, unsigned long long *xstat, hipStream_t st) {
@@ -3146,9 +2954,6 @@ void launch_top_rebuild(const PairTable &pt, unsigned int listed_hint, hipStream
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(k_top_rebuild, dim3(g), dim3(BLOCK), 0, st, pt);
 }
-void launch_publish_box(const unsigned char *box, unsigned char *mailbox, unsigned int fast, uint32_t round_id, unsigned long long *xstat, hipStream_t st) {
-  hipLaunchKernelGGL(k_publish_box, dim3(1), dim3(BLOCK), 0, st, box, mailbox, fast, round_id, xstat);
-}
 void launch_idx_seed(const PairTable &pt, const PairIndexArgs &a, unsigned int listed_hint, hipStream_t st) {
   const PairIndex ix{a.key, a.cnt, a.off, a.bloom, a.post, a.mask};
   unsigned int g = (listed_hint + BLOCK - 1) / BLOCK;
@@ -3157,22 +2962,14 @@ void launch_idx_seed(const PairTable &pt, const PairIndexArgs &a, unsigned int l
   hipLaunchKernelGGL(k_idx_seed, dim3(g), dim3(BLOCK), 0, st, pt, ix);
 }
 size_t idx_save_bytes() { return (size_t)512 * sizeof(IdxAgg); }
-void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st, bool words, bool agg, void *save_) {
+void launch_idx_stream(bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st, bool agg, void *save_) {
   IdxAgg *save = reinterpret_cast<IdxAgg *>(save_);
   if (!ts.n_tiles) return;
   const PairIndex ix{a.key, a.cnt, a.off, a.bloom, a.post, a.mask};
   unsigned int g = (ts.n_tiles + IDXA_NT / 64 - 1) / (IDXA_NT / 64);
   if (g > 512) g = 512;  // (two workgroups per CU: 72 KB of LDS each; count and fill pass MUST use the same grid -- a workgroup's shard and tiles)
-  if (cls == 0 && words) {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
-  } else if (cls == 0) {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
-  } else {
-    if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, true, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
-    else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_B, false, false>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
-  }
+  if (fill) hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, true, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
+  else hipLaunchKernelGGL((k_idx_stream<TILE_SLOT_A, false, true>), dim3(g), dim3(IDXA_NT), 0, st, ts, ix, agg ? 1 : 0, save);
 }
 void launch_words_init(const TileSet &ts, unsigned long long *wmeta, hipStream_t st) {
   if (!ts.n_tiles) return;
@@ -3237,13 +3034,6 @@ bool launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &
                      const_cast<unsigned int *>(work_n), stats, bargs.k ? (const RuleSlot *)nullptr : rules, rule_mask, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, bargs, sargs);
   return false;
 }
-void launch_gather(const PairIndexArgs &a, const RuleSlot *rules, unsigned int n_slots, const BatchArgs *ba, uint32_t self_x, uint32_t *stamp,
-                   uint32_t round_id, uint32_t *worklist, unsigned int n_tiles, unsigned int *work_n, hipStream_t st) {
-  const PairIndex ix{a.key, a.cnt, a.off, a.bloom, a.post, a.mask};
-  const BatchArgs b = ba ? *ba : BatchArgs{};
-  const unsigned int n_rules = b.k ? b.k : n_slots;
-  hipLaunchKernelGGL(k_gather, dim3(n_rules + 1), dim3(BLOCK), 0, st, ix, rules, n_slots, b, self_x, stamp, round_id, worklist, WL_SEG(n_tiles), work_n);
-}
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st) {
   unsigned long long n_slots = pt.mask + 1;
   unsigned long long b = (n_slots + BLOCK - 1) / BLOCK;
@@ -3272,20 +3062,14 @@ void launch_pt_apply(const PairTable &pt, const DeltaRec *recs, unsigned long lo
   if (b > 256 * 16) b = 256 * 16;
   hipLaunchKernelGGL(k_pt_apply, dim3((unsigned int)b), dim3(BLOCK), 0, st, pt, recs, n);
 }
-void launch_set_tokflag(uint8_t *tokflag, uint32_t *flagbits, const uint32_t *upd, unsigned int n, hipStream_t st) {
-  if (!n) return;
-  hipLaunchKernelGGL(k_set_tokflag, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, tokflag, flagbits, upd, n);
-}
-void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, const uint32_t *upd, unsigned int n_upd,
-                        uint8_t *tokflag, uint32_t *flagbits, unsigned int *work_n_a, unsigned int *work_n_b, const uint32_t *src_bloom,
-                        uint32_t *dst_bloom, hipStream_t st) {
-  unsigned int work = n_slots > n_upd ? n_slots : n_upd;
+void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, unsigned int *work_n_a, unsigned int *work_n_b,
+                        const uint32_t *src_bloom, uint32_t *dst_bloom, hipStream_t st) {
+  unsigned int work = n_slots;
   if (src_bloom && work < (unsigned int)PM_BLOOM_WORDS_H) work = PM_BLOOM_WORDS_H;
   unsigned int b = (work + BLOCK - 1) / BLOCK;
   if (b < 1) b = 1;
   if (b > 64) b = 64;
-  hipLaunchKernelGGL(k_round_begin, dim3(b), dim3(BLOCK), 0, st, src_rules, n_slots, dst_rules, upd, n_upd, tokflag, flagbits, work_n_a, work_n_b, src_bloom,
-                     dst_bloom);
+  hipLaunchKernelGGL(k_round_begin, dim3(b), dim3(BLOCK), 0, st, src_rules, n_slots, dst_rules, work_n_a, work_n_b, src_bloom, dst_bloom);
 }
 __global__ __launch_bounds__(BLOCK) void k_pt_clear(uint4 *__restrict__ slots, unsigned long long n) {
   unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;

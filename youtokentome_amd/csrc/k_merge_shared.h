@@ -99,6 +99,56 @@ struct RuleProbe {
   }
 };
 
+// ------------------------------------------------------------------------------------------------- multi-GPU pieces of a round
+// What the fold of this round's exchange left in xstat (yttm_kernels.h: XSTAT_WORDS) goes to the host with the scan's result: the verdict
+// words [0..3] are consumed (zeroed), the sums [4..7] stay.  Called with k = 0 .. 7 by eight threads; xstat == nullptr: zeros (single GPU).
+__device__ inline void xstat_forward(unsigned char *mailbox, unsigned long long *__restrict__ xstat, int k) {
+  if (k < 0 || k >= XSTAT_WORDS || (!xstat && k >= 4)) return;
+  unsigned long long v = 0;
+  if (xstat) {
+    v = ld_agent(&xstat[k]);
+    if (k < 4) xstat[k] = 0;
+  }
+  if (k < 4) *reinterpret_cast<unsigned long long *>(mailbox + 56 + 8 * k) = v;
+  else *reinterpret_cast<unsigned long long *>(mailbox + MB_XSUM + 8 * (k - 4)) = v;
+}
+
+// The delta table of the round that just ran -> the contiguous send block { header, records... }; the claimed slots are freed for the
+// next round and the next round's counter is left at zero.  The header part, by ONE thread of the launch / workgroup.
+__device__ inline void dt_pack_header(const DeltaBuf &db, DeltaRec *__restrict__ send, unsigned long long send_cap, unsigned long long n_raw,
+                                      unsigned long long *__restrict__ stats, uint32_t tiles_a) {
+  send[0].key = n_raw;  // (a count beyond the capacity tells every rank that this one lost updates)
+  send[0].delta = (long long)send_cap;
+  send[1].key = stats ? ld_agent(&stats[0]) : 0ull;                 // merge sites so far (folded by the scans: a round or two old)
+  send[1].delta = (long long)(stats ? ld_agent(&stats[2]) : 0ull);  // tokens streamed so far
+  send[2].key = tiles_a;
+  send[2].delta = 0;
+  send[3].key = 0;
+  send[3].delta = 0;
+  *db.n_next = 0ull;
+  if (stats) __hip_atomic_store(&stats[STAT_T1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the apply kernels are done)
+}
+__device__ inline void dt_pack_rec(const DeltaBuf &db, DeltaRec *__restrict__ send, unsigned long long send_cap, unsigned long long i) {
+  const uint32_t sl = __hip_atomic_load(&db.touched[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (i < send_cap) {
+    send[XHDR + i].key = ld_agent(&db.keys[sl]);
+    send[XHDR + i].delta = (long long)ld_agent(reinterpret_cast<const unsigned long long *>(&db.vals[sl]));
+  }
+  db.keys[sl] = PT_EMPTY;
+  db.vals[sl] = 0;
+}
+// The exchange tail of a round's last apply launch (ScanArgs::on == 2), run by its last workgroup: see yttm_kernels.h.
+template <int NT>
+__device__ inline void exchange_tail(const DeltaBuf &db, const ScanArgs &sa, unsigned long long *__restrict__ stats) {
+  if (sa.xpack && db.keys) {
+    const unsigned long long n_raw = ld_agent(db.n);
+    const unsigned long long n = n_raw <= db.mask + 1 ? n_raw : db.mask + 1;
+    for (unsigned long long i = threadIdx.x; i < n; i += NT) dt_pack_rec(db, sa.xsend, sa.xsend_cap, i);
+    if (threadIdx.x == 0) dt_pack_header(db, sa.xsend, sa.xsend_cap, n_raw, stats, sa.xtiles);
+  }
+  if (threadIdx.x == 0 && sa.done_ctr) *sa.done_ctr = 0;
+}
+
 // ------------------------------------------------------------------------------------------------- fused candidate scan
 __device__ inline int cand_bin(unsigned long long c) {
   if (c < 256) return (int)c;
@@ -117,12 +167,13 @@ __device__ inline int cand_bin(unsigned long long c) {
 //      the list (PT_TOP cleared, so it can come back).  TAIL_E entries per thread and pass, two dependent memory round trips
 //      per pass (slot numbers, then records) with all loads of a round trip in flight together.
 //   2. header, histogram and the first `fast` candidates go to `box` -- the host's pinned mailbox (then the round id is
-//      published there, system-scope release: the host polls instead of copying and synchronising), or, multi-GPU, a staging
-//      block in HBM that k_publish_box forwards after the ranks' all-reduce.
+//      published there, system-scope release: the host polls instead of copying and synchronising).  Multi-GPU: the same -- the lists
+//      hold the same pairs on every rank (k_fold_list), so no verdict on them has to be exchanged first; `xstat` (the fold's report on
+//      the exchange itself) rides along.
 //   3. last, off the critical path: the per-workgroup statistics rows are folded into the totals and the key count
 // Box layout: [0] candidates, [4] keys in the table, [8] top-list entries before the scan, [12] of those still >= top_tau,
 // [16] hot-list entries (overflow check), [24] the round's duration on the device (ScanArgs::timed), [88] merge sites so far, [32] round id, [40] tokens streamed so far, [48] tiles with a site so far, [56..87]
-// xstat (multi-GPU), [96..127] timing marks (100 MHz), [MB_HIST..) histogram, [8192..) candidates.
+// xstat verdicts (multi-GPU; the sums at MB_XSUM), [96..127] timing marks (100 MHz), [MB_HIST..) histogram, [8192..) candidates.
 // lds = at least (CAND_BINS + 160) words of scratch (the apply kernel's tile buffers are free by now).
 template <int NT>
 __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigned long long *__restrict__ stats, const RuleProbe &zprobe,
@@ -316,13 +367,13 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 48) = stats[1];  // tiles that held a merge site so far
     if (!overflow) *pt.top_n = ctl[0];
     if (sa.done_ctr) *sa.done_ctr = 0;
-    if (xstat) xstat[2] = (hot_raw > pt.hot_cap ? 1ull : 0ull) + (overflow ? (1ull << 32) : 0ull);  // this rank's list verdicts (summed over the ranks)
     unsigned long long *tmark = reinterpret_cast<unsigned long long *>(sa.mailbox + 96);
     tmark[0] = tm0; tmark[1] = tm1; tmark[2] = tm2; tmark[3] = (unsigned long long)wall_clock64();
   }
-  if (tid >= 6 && tid < 10) *reinterpret_cast<unsigned long long *>(sa.mailbox + 56 + 8 * (tid - 6)) = 0;  // (multi-GPU fields: k_publish fills them)
+  xstat_forward(sa.mailbox, xstat, tid - 6);  // (multi-GPU: the exchange's report)
+  if (xstat && tid == 14) *reinterpret_cast<unsigned long long *>(sa.mailbox + MB_XSUM + 32) = sa.timed ? ld_agent(&stats[STAT_T1]) - ld_agent(&stats[STAT_T0]) : 0ull;
   for (int b = tid; b < CAND_BINS; b += NT) box_hist[b] = (unsigned long long)lh[b];
-  if (sa.round_id) {  // (0: a staging block, k_publish_box forwards it)
+  if (sa.round_id) {
     __threadfence_system();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&hdr[8], sa.round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -123,8 +123,14 @@ struct DeltaBuf {
   long long *vals;           // [mask + 1]
   uint32_t *touched;         // [mask + 1] slots claimed this round, in claim order
   unsigned long long *n;     // number of claimed slots (may run past the capacity: reported, the training stops)
+  unsigned long long *n_next;  // the counter of the NEXT round (the two alternate): whoever packs this round's table leaves it at zero, so
+                               // that no memset sits between two rounds
   unsigned long long mask;
 };
+// A rank's send block of a round, in 16-byte units: XHDR header units, then the records.  Header: [0] = {records, capacity of the rank's
+// send buffer}, [1] = {merge sites so far, tokens streamed so far} on that rank, [2] = {its class-A tiles, -}: every rank sees every
+// header after the all-gather, so what is decided from them (block overflow, the switch to word mode) is decided alike everywhere.
+constexpr unsigned int XHDR = 4;
 
 __host__ __device__ inline unsigned long long mix64(unsigned long long x) {
   x ^= x >> 33;
@@ -217,7 +223,7 @@ __device__ inline void dt_add(const DeltaBuf &db, unsigned long long key, long l
       k = atomicCAS(&db.keys[i], PT_EMPTY, key);
       if (k == PT_EMPTY) {
         const unsigned long long j = atomicAdd(db.n, 1ull);
-        if (j <= db.mask) db.touched[j] = (uint32_t)i;
+        if (j <= db.mask) __hip_atomic_store(&db.touched[j], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (write-through: the round's tail may pack the table from another XCD)
         k = key;
       }
     }

@@ -70,7 +70,9 @@ struct BatchArgs {
 // statistics rows, zeroes the batch's pairs, scans (and compacts) the hot list and publishes header + histogram + candidates
 // in the host's pinned mailbox -- one launch per round instead of two, and no second trip through the launch path.
 struct ScanArgs {
-  uint32_t on;  // 0: no scan in this launch (k_tiles)
+  uint32_t on;  // 0: no tail in this launch; 1: the candidate scan; 2 (multi-GPU): the exchange tail -- the last workgroup leaves the worklist
+                // counters at zero and, with xpack, packs the round's delta table into the send block (a small round: one launch less
+                // before the all-gather); the scan then rides in the fold kernel behind the all-gather (k_fold_list)
   uint32_t tau_mx;
   unsigned long long tau_cnt;  // candidates: count > tau_cnt, or == tau_cnt and max(x,y) <= tau_mx
   CandRec *out;                // [cap] all candidates (the first `fast` also go to the mailbox)
@@ -80,29 +82,25 @@ struct ScanArgs {
   uint32_t round_id;           // published in the mailbox when everything else is there; 0: nothing is published
   uint32_t want;               // != 0: about this many candidates are wanted -- the scan may raise the threshold by itself (scan_top: refine)
   uint32_t timed;              // the round's first launch left its start time in stats[STAT_T0]: the mailbox gets the duration (100 MHz ticks)
+  uint32_t xpack;              // on == 2: pack the delta table here (dt_pack_wg)
+  DeltaRec *xsend;             // the send block (XHDR header units + records)
+  unsigned long long xsend_cap;
+  uint32_t xtiles;             // this rank's class-A tiles (for the header)
 };
 constexpr int STAT_T0 = 6;  // stats[6]: wall_clock64() at the start of the round's first launch
+constexpr int STAT_T1 = 7;  // stats[7] (multi-GPU): ... when the round's apply kernels were done (noted by whoever packs the delta table)
 void launch_top_scan(const PairTable &pt, const ScanArgs &sa, unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself,
-                     const BatchArgs *zba, unsigned long long *xstat, hipStream_t st);
+                     const BatchArgs *zba, unsigned long long *xstat /* multi-GPU: the exchange's report, forwarded to the mailbox */, hipStream_t st);
 void launch_top_rebuild(const PairTable &pt, unsigned int listed_hint, hipStream_t st);
-void launch_publish_box(const unsigned char *box, unsigned char *mailbox, unsigned int fast, uint32_t round_id, unsigned long long *xstat, hipStream_t st);
 // id_min / n_ids: the token ids in the tiles are id_min .. id_min + n_ids - 1 (K3 runs before any merge: the alphabet); n_ids <= 32
 // counts pairs in a dense LDS table, 0 (unknown / larger) in the LDS hash
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, uint32_t id_min, uint32_t n_ids, hipStream_t st);
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
-                        const uint8_t *tokflag, const uint32_t *flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
-                        uint32_t *worklist, unsigned int *work_n, unsigned long long *stats, bool exact_filter, bool dense, const BatchArgs *ba,
-                        const ScanArgs *scan /* class A only */, bool wl_gathered /* the worklist was filled by launch_gather: no filter pass */,
-                        unsigned int work_hint /* wl_gathered: about how many tiles the worklist will hold (0: unknown) */,
-                        const uint32_t *bloom_g /* ba->bloom and the batch not in ba: the batch's pair filter (pm_bloom_host) */, hipStream_t st);
-// class-A tiles: the position-parallel apply kernel (k_apply.hip).  bloom_g: the batch's pair filter when the batch is too large
-// for the kernel to build it from its LDS rule hash (rule_mask >= 512 slots; PM_BLOOM_WORDS words, made by pm_bloom_host), else unused.
-// eager_w: most tiles of the launch will hold a site (their word frequencies are loaded together with the tokens).
+                        uint32_t self_x, uint32_t self_z, uint32_t z_base, unsigned long long *stats, const BatchArgs *ba,
+                        const ScanArgs *scan /* the round's last launch only */,
+                        const uint32_t *bloom_g /* the batch not in ba: the batch's pair filter (pm_bloom_host) */, hipStream_t st);
 constexpr int PM_BLOOM_WORDS_H = 2048;
 void pm_bloom_host(uint32_t *bloom, const uint32_t *xyz, uint32_t k);
-void launch_apply_pm(const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
-                     uint32_t self_x, uint32_t self_z, uint32_t z_base, const uint32_t *worklist, const unsigned int *work_n, unsigned long long *stats,
-                     const BatchArgs *ba, const ScanArgs *scan, bool eager_w, hipStream_t st);
 // pair index for K4's worklists (k_merge.hip: PairIndex)
 // A key's posting count / fill cursor is kept in IDX_SHARDS copies (a wave adds to copy (its number) % IDX_SHARDS): a pair with a million
 // adjacencies is a million atomics on ONE address otherwise (~12 ns each: 6.5 ms per pass at the word-mode switch of the 1 GB corpus).
@@ -114,12 +112,11 @@ struct PairIndexArgs {
   unsigned int mask;
 };
 void launch_idx_seed(const PairTable &pt, const PairIndexArgs &a, unsigned int listed_hint, hipStream_t st);
-void launch_idx_stream(int cls, bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st, bool words = false /* postings are word ids; the tiles may hold TOK_HOLEs */,
+// (class-A token slots in word mode: postings are word ids, the slots may hold TOK_HOLEs)
+void launch_idx_stream(bool fill, const TileSet &ts, const PairIndexArgs &a, hipStream_t st,
                        bool agg = true /* fill pass: sum a workgroup's postings per key in LDS first (worth a second sweep only when they are many) */,
                        void *save = nullptr /* [idx_save_bytes()] the count pass's per-workgroup tables, reused by an agg fill pass */);
 size_t idx_save_bytes();
-void launch_gather(const PairIndexArgs &a, const RuleSlot *rules, unsigned int n_slots, const BatchArgs *ba, uint32_t self_x, uint32_t *stamp,
-                   uint32_t round_id, uint32_t *worklist, unsigned int n_tiles, unsigned int *work_n, hipStream_t st);
 // ---- word mode (k_merge.hip)
 void launch_words_init(const TileSet &ts, unsigned long long *wmeta, hipStream_t st);
 struct WGatherArgs {
@@ -155,18 +152,26 @@ void launch_cand_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t 
 void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t tau_mx, CandRec *out, unsigned int cap, unsigned int *n_out,
                      unsigned long long *hist, unsigned int *done_ctr, unsigned char *mailbox, unsigned int fast, uint32_t round_id,
                      unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, unsigned int listed_hint,
-                     const BatchArgs *zba, unsigned long long *xstat /* multi-GPU: leave the mailbox to launch_publish */, hipStream_t st);
-void launch_publish(const PairTable &pt, CandRec *out, unsigned int cap, unsigned int *n_out, unsigned long long *hist, unsigned int *done_ctr,
-                    unsigned char *mailbox, unsigned int fast, uint32_t round_id, unsigned long long *stats, unsigned long long *xstat, hipStream_t st);
-void launch_dt_pack(const DeltaBuf &db, DeltaRec *send, unsigned long long send_cap, unsigned int n_hint, hipStream_t st);
+                     const BatchArgs *zba, unsigned long long *xstat /* multi-GPU: the exchange's report, forwarded to the mailbox */, hipStream_t st);
+// ---- multi-GPU, per round: K4 -> [k_dt_pack] -> ncclAllGather -> k_pt_apply_blocks -> k_fold_list (+ the round's candidate scan)
+void launch_dt_pack(const DeltaBuf &db, DeltaRec *send, unsigned long long send_cap, unsigned int n_hint, unsigned long long *stats, uint32_t tiles_a, hipStream_t st);
+// phase 1: the OTHER ranks' count deltas into the local replica (no list appends: pass a PairTable with the thresholds off)
 void launch_pt_apply_blocks(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, int rank, unsigned long long only_mask,
                             unsigned long long *xstat, hipStream_t st);
+// phase 2, behind phase 1's kernel boundary: every record of every rank's block (this rank's too) whose pair ended the round at or above a
+// list threshold joins that list -- judged by the FINAL count, the same on every rank, so the lists hold the same pairs everywhere and
+// no verdict on them has to be exchanged.  The last workgroup runs the round's candidate scan (scan != nullptr) straight into the mailbox.
+void launch_fold_list(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, unsigned long long only_mask, const ScanArgs *scan,
+                      unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, const BatchArgs *zba,
+                      unsigned long long *xstat, unsigned int *done_ctr, hipStream_t st);
 constexpr int MB_HIST = 128;  // byte offset of the count histogram in the mailbox (header + xstat before it)
+constexpr int MB_XSUM = 6144; // multi-GPU, behind the histogram: sums over the ranks' block headers -- [0] merge sites so far, [8] tokens streamed so far,
+                              // [16] class-A tiles, [24] ranks; [32] the round's apply kernels on the device clock (ticks; ScanArgs::timed)
+constexpr int XSTAT_WORDS = 8;  // d_xstat: [0] ranks whose block did not fit (bit r), [1] largest record count, [2] -, [3] a rank lost records, [4..7] the sums above
 void launch_fold_stats(unsigned long long *stats, unsigned int *n_keys, hipStream_t st);
 constexpr int STATS_WORDS = 32 + 8 * 1536;  // totals + one row per workgroup (k_merge.hip: BLK_BASE, BLK_ROWS)
-void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, const uint32_t *upd, unsigned int n_upd,
-                        uint8_t *tokflag, uint32_t *flagbits, unsigned int *work_n_a, unsigned int *work_n_b, const uint32_t *src_bloom,
-                        uint32_t *dst_bloom, hipStream_t st);
+void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, unsigned int *work_n_a, unsigned int *work_n_b,
+                        const uint32_t *src_bloom, uint32_t *dst_bloom, hipStream_t st);
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st);
 // class C (k_giant.hip): K3 (merge=false) / K4 (merge=true) for tiles of words longer than TILE_NOM_B tokens; scratch = 4*slot
 // uint32 per tile
@@ -177,7 +182,6 @@ void launch_pt_rehash(const PairTable &src, const PairTable &dst, hipStream_t st
 void launch_pt_zero(const PairTable &pt, const RuleSlot *rules, unsigned int n_slots, unsigned long long self_key, hipStream_t st);
 void launch_pt_query(const PairTable &pt, const unsigned long long *keys, unsigned int n, unsigned long long *out, hipStream_t st);
 void launch_pt_apply(const PairTable &pt, const DeltaRec *recs, unsigned long long n, hipStream_t st);
-void launch_set_tokflag(uint8_t *tokflag, uint32_t *flagbits, const uint32_t *upd, unsigned int n, hipStream_t st);
 void launch_fill_u64(unsigned long long *p, unsigned long long v, unsigned long long n, hipStream_t st);
 
 // ---- batch encode (k_encode.hip)
