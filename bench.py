@@ -3,21 +3,23 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" = one full BPE.train() pass (char histogram -> word dedup -> pair count -> merge loop -> model file) over one
-synthetic corpus that is ALREADY RESIDENT IN HBM when the timed region starts.  Workload = BASELINE.json configs[1]: the
-1 GB random 'abcd ' corpus of SURVEY.md Appendix C (seed 19, md5 pinned), vocab_size=32000.  N>1: one process per GPU
-(torchrun); the SAME pinned file is cut into N byte ranges at whitespace (strong scaling -- the only way the N-GPU
-model can be compared with the reference's), pair-count deltas travel over RCCL each round.  `--scaling weak` gives
-every rank its own 1 GB instead (no pin exists for those corpora).  Rank 0 prints ONE JSON line.
+A "step" = one full BPE.train() -- SURVEY.md 8d's metric: file bytes / wall from the call to the model file closed.  The corpus FILE
+sits in the page cache (like the CPU baseline's input); a step is yttm_train_bpe_comm(path -> model): open, pread into pinned chunks,
+H2D, char histogram -> word dedup -> pair count -> merge loop -> model file.  That is `value`.  The same steps with the corpus ALREADY
+RESIDENT IN HBM are timed right after and reported beside it (`value_hbm_resident`; the kernel table and the roofline come from the
+timed file steps -- the kernels are the same).  Workload = BASELINE.json configs[1]: the 1 GB random 'abcd ' corpus of SURVEY.md
+Appendix C (seed 19, md5 pinned), vocab_size=32000.  N>1: one process per GPU (torchrun); every rank reads ITS byte range of the SAME
+pinned file, cut at whitespace (strong scaling -- the only way the N-GPU model can be compared with the reference's), pair-count
+deltas travel over RCCL each round.  `--scaling weak` gives every rank its own 1 GB instead (HBM-resident only; no pin exists for those
+corpora).  Rank 0 prints ONE JSON line.
 
 Parity is part of the line: the md5 of every model the GPU writes (configs[1], the Zipf corpus of configs[2]) and the
 FNV of all 10 M encoded sentences (configs[3]) are compared with tests/golden/full_size_pins.json -- outputs of the
 UNMODIFIED reference (tests/golden/make_full_pins.py) -- and a mismatch makes the process exit non-zero.
 
-Also on the line: `roofline` (dominant kernel, HIP-event timed inside the timed steps; `achieved` uses the contract's
-algorithmic bytes 8*T_touched + 8*W_touched counted at word granularity by a separate untimed measurement pass),
-`roofline_pair_count` (K3, the kernel north_star names), `kernels`, `e2e` (file -> model through yttm_train_bpe, host ->
-host encode, the Python list API), `encode` / `encode_dropout` (configs[3] / [4]), `extra.zipf` (configs[2]) and
+Also on the line: `roofline` (dominant kernel; `achieved` = the contract's algorithmic bytes 8*T_touched + 8*W_touched, counted at word
+granularity by a separate untimed measurement pass, over the kernel's time by HIP events -- the device-clock figure of the timed steps beside it),
+`roofline_pair_count` (K3, the kernel north_star names), `kernels`, `e2e` (host -> host encode, the Python list API), `encode` / `encode_dropout` (configs[3] / [4]), `extra.zipf` (configs[2]) and
 `cpu_baseline` (the unmodified reference, n_threads=8, pinned to 8 cores, on the SAME full inputs)."""
 import argparse
 import ctypes as C
@@ -159,21 +161,17 @@ def main():
         "config": main_res["config"], "parity": {}, "roofline": main_res["roofline"], "roofline_pair_count": main_res["roofline_pair_count"],
         "kernels": main_res["kernels"], "phases_s": main_res["phases_s"],
     }
+    if main_res.get("hbm_resident"):
+        out["value_hbm_resident"] = main_res["hbm_resident"]["value"]
+        out["hbm_resident"] = main_res["hbm_resident"]
+        out["parity"]["hbm_resident_model_matches_reference"] = main_res["hbm_resident"].pop("_model_ok")
     out["parity"]["corpus_md5_matches"] = main_res["corpus_ok"]
     out["parity"]["model_matches_reference"] = main_res["model_ok"]
     if comm_handle is not None:
         out["rccl_ranks"] = world
-        out["config"]["parallelism"] = "one process per GPU; the corpus cut into %d byte ranges at white space; every rank keeps the whole pair table; per round one RCCL all-gather of per-pair delta blocks + one 8-byte all-reduce" % world
+        out["config"]["parallelism"] = "one process per GPU; the corpus cut into %d byte ranges at white space; every rank keeps the whole pair table; per round ONE collective: an RCCL all-gather of per-pair delta blocks" % world
     model_path = main_res["model_path"]
     host = main_res.pop("host", None)
-
-    # ---- end to end, the metric as SURVEY.md 8d words it: file -> model through the drop-in call ---------------------------
-    if world == 1 and not args.no_e2e:
-        out["e2e"] = {"train_file_to_model": _bench_e2e_train(ctx, host, main_res)}
-        out["parity"]["e2e_model_matches_reference"] = out["e2e"]["train_file_to_model"].pop("_model_ok")
-        # `value` follows the bench contract (input resident in HBM when the timed region starts); the metric as SURVEY.md 8d words it --
-        # file bytes / wall from the call to the model file closed -- is this one, and it is what cpu_baseline is compared with
-        out["value_file_to_model"] = out["e2e"]["train_file_to_model"]["value"]
 
     # ---- encode: configs[3] (and [4]: dropout) with the model just trained --------------------------------------------------
     if not args.no_encode:
@@ -184,6 +182,8 @@ def main():
         out["parity"]["dropout_distribution_matches"] = enc["dropout_ok"]
         if "e2e" in enc:
             out.setdefault("e2e", {}).update(enc["e2e"])
+            # (what compares with the reference's encode_as_ids -- host strings in, host ids out -- is this one, not the device-resident rate)
+            out["encode"]["value_host_to_host"] = enc["e2e"]["encode_host_to_host"]["value"]
 
     # ---- configs[2]: the Zipf corpus -- thousands of short rounds, per-round latency is the whole game ----------------------
     if not args.no_extra and args.corpus == "abcd":
@@ -244,62 +244,108 @@ def _make_corpus(ctx, corpus, size_mb):
     if pin is not None:
         corpus_ok = hashlib.md5(host).hexdigest() == pin["corpus_md5"]
     total = len(host)
+    full = host if shared else None  # (the file of the file -> model steps: one file, every rank reads its byte range of it)
     if ctx["strong"]:
         cuts = split_points(host, world)
         host = host[cuts[rank]:cuts[rank + 1]]
-    return host, pin, corpus_ok, total
+    return host, pin, corpus_ok, total, full
 
 
 def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host):
     L, _lib, torch, args = ctx["L"], ctx["_lib"], ctx["torch"], ctx["args"]
     rank, world, dev, local_rank, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["local_rank"], ctx["dist"]
     t0 = time.time()
-    host, pin, corpus_ok, total_bytes = _make_corpus(ctx, corpus, size_mb)
+    host, pin, corpus_ok, total_bytes, full = _make_corpus(ctx, corpus, size_mb)
     d_corpus = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
     n_local = d_corpus.numel()
     if not ctx["strong"]:
         total_bytes = n_local * world
+    tag = os.environ.get("MASTER_PORT", str(os.getpid()))
+    model_path = os.path.join(tempfile.gettempdir(), "yttm_bench_%s_%s.model" % (corpus, tag))
+    # the corpus FILE of the file -> model steps: written by rank 0, read back once so that it sits in the page cache like the CPU baseline's input
+    corpus_path = os.path.join(tempfile.gettempdir(), "yttm_bench_%s_%s.txt" % (corpus, tag)) if full is not None else None
+    if corpus_path and rank == 0:
+        with open(corpus_path, "wb") as f:
+            f.write(full)
+    del full
+    if corpus_path:
+        ctx["barrier"]()
+        with open(corpus_path, "rb") as f:
+            while f.read(1 << 24):
+                pass
     if rank == 0:
-        log(f"corpus: {corpus} {n_local/1e6:.1f} MB on this GPU ({total_bytes/1e6:.1f} MB in all) generated+uploaded in {time.time()-t0:.1f}s")
-    model_path = os.path.join(tempfile.gettempdir(), "yttm_bench_%s_%s.model" % (corpus, os.environ.get("MASTER_PORT", str(os.getpid()))))
+        log(f"corpus: {corpus} {n_local/1e6:.1f} MB on this GPU ({total_bytes/1e6:.1f} MB in all) generated+uploaded+written in {time.time()-t0:.1f}s")
     err = C.create_string_buffer(_lib.ERRLEN)
     rep = C.create_string_buffer(16384)
+    dev_model_path = model_path + ".hbm"
 
-    def train_step(profile):
+    def file_step(profile):  # SURVEY.md 8d's metric: yttm_train_bpe_comm(path -> model); with a communicator every rank reads its byte range
+        rc = L.yttm_train_bpe_comm(corpus_path.encode(), model_path.encode(), args.vocab, 1.0, 8, 0, 1, 2, 3, local_rank, int(profile), ctx["comm"], rep, 16384, err, _lib.ERRLEN)
+        if rc != 0:
+            raise RuntimeError("train (file -> model) failed: " + err.value.decode())
+        return json.loads(rep.value.decode())
+
+    def train_step(profile, out_model=None):  # the same training with the corpus (this rank's shard) already resident in HBM
+        out_model = out_model or dev_model_path
         if ctx["comm"] is not None:
-            rc = L.yttm_train_bpe_from_device_comm(C.c_void_p(d_corpus.data_ptr()), n_local, model_path.encode(), args.vocab, 1.0,
+            rc = L.yttm_train_bpe_from_device_comm(C.c_void_p(d_corpus.data_ptr()), n_local, out_model.encode(), args.vocab, 1.0,
                                                    0, 1, 2, 3, local_rank, int(profile), ctx["comm"], rep, 16384, err, _lib.ERRLEN)
         else:
-            rc = L.yttm_train_bpe_from_device(C.c_void_p(d_corpus.data_ptr()), n_local, model_path.encode(), args.vocab, 1.0,
+            rc = L.yttm_train_bpe_from_device(C.c_void_p(d_corpus.data_ptr()), n_local, out_model.encode(), args.vocab, 1.0,
                                               0, 1, 2, 3, local_rank, int(profile), rep, 16384, err, _lib.ERRLEN)
         if rc != 0:
             raise RuntimeError("train failed: " + err.value.decode())
         return json.loads(rep.value.decode())
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    timed_step = file_step if corpus_path else train_step  # (--scaling weak: every rank has its own corpus, there is no one file)
     with ctx["quiet"]:
         for _ in range(warmup):
-            train_step(0)
+            timed_step(0)
         ctx["barrier"]()
         t0 = time.perf_counter()
-        reports = [train_step(1) for _ in range(steps)]
+        reports = [timed_step(1) for _ in range(steps)]
         ctx["barrier"]()
-        dt = time.perf_counter() - t0
-        touched = train_step(2) if measure_touched else None  # measurement pass, outside the timed region
+        dt = max_over_ranks(time.perf_counter() - t0)
+        hbm = None
+        if corpus_path:  # the same steps without the read and the upload: input resident in HBM when the timed region starts
+            train_step(0)
+            ctx["barrier"]()
+            t0 = time.perf_counter()
+            dev_reports = [train_step(1) for _ in range(steps)]
+            ctx["barrier"]()
+            dt_dev = max_over_ranks(time.perf_counter() - t0)
+            dr = dev_reports[-1]
+            hbm = {"value": round(steps * total_bytes / dt_dev / 1e6, 2), "unit": "MB/s", "ms_per_step": round(dt_dev / steps * 1e3, 2), "steps": steps,
+                   "input": "this rank's shard resident in HBM before the timed region (yttm_train_bpe_from_device)",
+                   "phases_s": {"frontend": dr["seconds_frontend"], "merge_loop": dr["seconds_merge"], "dump": dr["seconds_io"]},
+                   "_model_ok": (md5_file(dev_model_path) == pin["model_md5"]) if (pin is not None and rank == 0) else None}
+        touched = None
+        if measure_touched:  # measurement pass, outside the timed regions (tiles to the end; the totals also as they stood at the word-mode switch)
+            os.environ["YTTM_MEASURE_SPLIT_ROUND"] = str(max(0, int(reports[-1].get("word_switch_round") or 0)))
+            try:
+                touched = train_step(2)
+            finally:
+                del os.environ["YTTM_MEASURE_SPLIT_ROUND"]
         ev_rep = None
-        if measure_touched and ctx["comm"] is None:  # the same step timed with HIP events around every merge round (cross-check, not timed)
+        if measure_touched and ctx["comm"] is None:  # the same step timed with HIP events around every merge round (not timed)
             os.environ["YTTM_PROFILE_EVENTS"] = "1"
             try:
                 ev_rep = train_step(1)
             finally:
                 del os.environ["YTTM_PROFILE_EVENTS"]
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     value = steps * total_bytes / dt / 1e6
     r = reports[-1]
     model_md5 = md5_file(model_path) if rank == 0 else None
     model_ok = (model_md5 == pin["model_md5"]) if (pin is not None and rank == 0) else None
+    if corpus_path and rank == 0:  # (every rank is past the barrier behind its last read)
+        os.remove(corpus_path)
 
     kern = {}
     for name, k in r["kernels"].items():
@@ -317,10 +363,12 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
                     "duration_source": "merge rounds whose candidate scan rides in their last kernel (all but a few of a single-GPU training): the device's 100 MHz clock, "
                                        "first workgroup of the round's first launch -> mailbox published, read from the mailbox every round in the timed region; "
                                        "every other launch: HIP events on the context's stream"}
+        ev_ms = None
         if ev_rep is not None and ev_rep["kernels"].get(dom, {}).get("launches"):
             e = ev_rep["kernels"][dom]
+            ev_ms = e["ms"]
             roofline["avg_launch_ms_hip_events"] = round(e["ms"] / e["launches"], 4)
-            roofline["hip_events_note"] = "one more step outside the timed region with YTTM_PROFILE_EVENTS=1: a hipEventRecord before the round's first launch and one after its last (the interval also holds the launch latency of the first kernel)"
+            roofline["hip_events_note"] = "one more step outside the timed region with YTTM_PROFILE_EVENTS=1: a hipEventRecord before the round's first launch and one after its last (the interval also holds the launch latency of the first kernel); `achieved` / `frac` use THIS time (it agrees with rocprofv3's kernel durations, profiles/), the device-clock figure of the timed steps is in `device_clock`"
         if dom == "merge_apply":
             # The contract's algorithmic bytes for K4: 8*T_touched + 8*W_touched, "touched" = the WORDS that held a
             # merge site, counted by the untimed measurement pass.  What the kernel actually streams -- every live token once,
@@ -330,16 +378,35 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
             roofline["streamed"] = streamed
             if touched is not None and touched.get("touched_words"):
                 b8d = 8 * touched["touched_word_tokens"] + 8 * touched["touched_words"]
-                ach = b8d / 1e9 / (kern[dom]["ms_total"] / 1e3)
+                ms_dev = kern[dom]["ms_total"]
+                ms_used = ev_ms if ev_ms else ms_dev
+                ach = b8d / 1e9 / (ms_used / 1e3)
                 roofline.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
                                  "algorithmic_bytes_per_launch": round(b8d / kern[dom]["launches"]),
                                  "algorithmic_bytes_8d": b8d, "frac_8d": round(ach / HBM_PEAK_GBS, 4),
                                  "definition": "8*T_touched + 8*W_touched over all launches / total K4 time; touched = words holding a merge site",
+                                 "time_source": "HIP events (one untimed step)" if ev_ms else "device clock of the timed steps",
+                                 "device_clock": {"ms_total": ms_dev, "avg_launch_ms": kern[dom]["avg_ms"], "achieved": round(b8d / 1e9 / (ms_dev / 1e3), 1),
+                                                  "frac": round(b8d / 1e9 / (ms_dev / 1e3) / HBM_PEAK_GBS, 4),
+                                                  "note": "first workgroup of the round's first launch -> mailbox published; leaves out the launch latency"},
                                  "touched_words": touched["touched_words"], "touched_word_tokens": touched["touched_word_tokens"],
                                  "touched_tiles": touched["touched_tiles"], "touched_tile_tokens": touched["touched_tile_tokens"],
                                  "merge_sites": touched["merge_sites"]})
                 if traffic.get(dom):
                     roofline["traffic_over_algorithmic"] = round(traffic[dom] / max(1, roofline["algorithmic_bytes_per_launch"]), 2)
+                # the two halves of K4 apart: the rounds on tiles (streamed) and the word-mode rounds (work follows the sites)
+                sr = touched.get("split_round") or 0
+                wl, wms = r.get("merge_launches_word_rounds") or 0, r.get("merge_ms_word_rounds") or 0.0
+                if sr and wl and kern[dom]["launches"] > wl:
+                    bt = 8 * touched["split_touched_word_tokens"] + 8 * touched["split_touched_words"]
+                    bw = b8d - bt
+                    tl, tms = kern[dom]["launches"] - wl, ms_dev - wms
+                    roofline["halves"] = {
+                        "tile_rounds": {"launches": tl, "ms_device_clock": round(tms, 3), "algorithmic_bytes_per_launch": round(bt / tl),
+                                        "achieved_GBps": round(bt / 1e9 / (tms / 1e3), 1), "frac": round(bt / 1e9 / (tms / 1e3) / HBM_PEAK_GBS, 4)},
+                        "word_mode_rounds": {"launches": wl, "ms_device_clock": round(wms, 3), "algorithmic_bytes_per_launch": round(bw / wl),
+                                             "achieved_GBps": round(bw / 1e9 / (wms / 1e3), 1), "frac": round(bw / 1e9 / (wms / 1e3) / HBM_PEAK_GBS, 4)},
+                        "note": "contract bytes 8*T_touched + 8*W_touched of the rounds before / from the word-mode switch (round %d), device-clock time of the timed steps" % sr}
     roofline_pc = None
     if "pair_count" in kern:
         roofline_pc = {"kernel": "pair_count (K3)", "bound": "hbm", "achieved": kern["pair_count"]["GBps"], "peak": HBM_PEAK_GBS,
@@ -353,7 +420,9 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
            "corpus_bytes_total": total_bytes, "corpus_bytes_this_gpu": n_local, "vocab_size": args.vocab, "unique_words": r["n_unique"],
            "dedup_tokens": r["n_tokens"], "merge_rounds": r["rounds"], "rules": r["rules"],
            "rounds_closed_exhausted": r.get("rounds_exhausted"), "word_mode_from_round": r.get("word_switch_round") or None, "word_mode_rounds": r.get("word_rounds"), "word_mode_one_launch_rounds": r.get("word_fused_rounds"),
-           "index_builds": r.get("index_builds"), "input": "resident in HBM before the timed region",
+           "index_builds": r.get("index_builds"),
+           "input": ("file in the page cache -> yttm_train_bpe_comm(path, model): open + pread into pinned chunks + H2D + train + model file closed (SURVEY.md 8d); "
+                     "the HBM-resident figure is `value_hbm_resident`") if corpus_path else "resident in HBM before the timed region (--scaling weak: one corpus per rank, no single file)",
            "model_md5": model_md5, "pinned_model_md5": pin["model_md5"] if pin else None}
     if ctx["comm"] is not None:
         cfg["multi_gpu_mode"] = ("replicated merge loop: shards gathered once after the local dedup, every rank runs the merge loop alone, no per-round collective"
@@ -367,8 +436,8 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
         else:
             cfg["merge_apply_ms_per_rank"] = [k4_ms]
     res = {"value": round(value, 2), "ms_per_step": round(dt / steps * 1e3, 2), "config": cfg, "roofline": roofline, "roofline_pair_count": roofline_pc,
-           "kernels": kern, "phases_s": {"frontend": r["seconds_frontend"], "merge_loop": r["seconds_merge"], "dump": r["seconds_io"]},
-           "corpus_ok": corpus_ok, "model_ok": model_ok, "model_path": model_path, "pin": pin}
+           "kernels": kern, "phases_s": {"upload": r.get("seconds_upload", 0.0), "frontend": r["seconds_frontend"], "merge_loop": r["seconds_merge"], "dump": r["seconds_io"]},
+           "corpus_ok": corpus_ok, "model_ok": model_ok, "model_path": model_path, "pin": pin, "hbm_resident": hbm}
     if keep_host:
         res["host"] = host
     del d_corpus
@@ -380,7 +449,7 @@ def _static_traffic(kern, corpus, size_mb, args, world):
     """HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, separate --pmc
     runs of this same command; tools/pmc_summary.py).  STATIC: read from profiles/, not measured by this run."""
     traffic = {}
-    for name in ("r3_1gb_pmc_hbm.json", "r2_1gb_pmc_hbm.json", "r1_1gb_final_pmc_hbm.json"):
+    for name in ("r4_1gb_pmc_hbm.json", "r3_1gb_pmc_hbm.json", "r2_1gb_pmc_hbm.json", "r1_1gb_final_pmc_hbm.json"):
         pmc_file = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc_file):
             break
@@ -394,7 +463,7 @@ def _static_traffic(kern, corpus, size_mb, args, world):
         if k.startswith("k_tiles<"):
             return "merge_apply" if k[len("k_tiles<"):].split(", ")[2] == "true" else "pair_count"
         for name, prefixes in (("char_hist", ("k_scan_bytes<0>",)), ("segments", ("k_scan_bytes<1>",)), ("dedup", ("k2b_insert_words",)),
-                               ("merge_apply", ("k_filter<", "k_giant<true", "k_words<", "k_delta_apply", "k_wgather", "k_gather", "k_round_begin")),
+                               ("merge_apply", ("k_giant<true", "k_words<", "k_delta_apply", "k_wgather", "k_round_begin")),
                                ("pair_count", ("k_giant<false", "k_pair_count_dense")),
                                ("cand_scan", ("k_hot_scan", "k_cand_scan", "k_top_scan", "k_top_rebuild", "k_hot_rebuild", "k_idx_", "k_words_init"))):
             if k.startswith(prefixes):
@@ -405,38 +474,7 @@ def _static_traffic(kern, corpus, size_mb, args, world):
         if ks and name in kern:
             total = sum(pm[k]["traffic_bytes_per_launch"] * pm[k]["launches"] for k in ks)
             traffic[name] = round(total / max(1, kern[name]["launches"]))
-    return traffic, "static: bytes per launch from profiles/%s (rocprofv3 PMC passes of this command on an earlier run; not re-measured here)" % os.path.basename(pmc_file)
-
-
-def _bench_e2e_train(ctx, host, main_res):
-    """yttm_train_bpe(path -> model): open + read (page cache) + H2D + train + dump.  bpe.cpp:1368-1388 incl. :67-84."""
-    L, _lib, args = ctx["L"], ctx["_lib"], ctx["args"]
-    path = os.path.join(ctx["tmpdir"], "corpus.txt")
-    with open(path, "wb") as f:
-        f.write(host)
-    with open(path, "rb") as f:  # make sure it sits in the page cache like the CPU baseline's input
-        while f.read(1 << 24):
-            pass
-    model = os.path.join(ctx["tmpdir"], "e2e.model")
-    err = C.create_string_buffer(_lib.ERRLEN)
-    rep = C.create_string_buffer(16384)
-    times, reps = [], []
-    with ctx["quiet"]:
-        for _ in range(3):  # the first call also pins the staging chunks
-            t0 = time.perf_counter()
-            rc = L.yttm_train_bpe_ex(path.encode(), model.encode(), args.vocab, 1.0, 8, 0, 1, 2, 3, ctx["local_rank"], rep, 16384, err, _lib.ERRLEN)
-            times.append(time.perf_counter() - t0)
-            if rc != 0:
-                raise RuntimeError("e2e train failed: " + err.value.decode())
-            reps.append(json.loads(rep.value.decode()))
-    best = min(range(3), key=lambda i: times[i])
-    pin = main_res["pin"]
-    res = {"value": round(len(host) / 1e6 / times[best], 2), "unit": "MB/s", "seconds": round(times[best], 4), "all_seconds": [round(t, 4) for t in times],
-           "upload_seconds": round(reps[best]["seconds_upload"], 4), "train_seconds": round(reps[best]["seconds_total"] - reps[best]["seconds_upload"], 4),
-           "what": "wall of yttm_train_bpe_ex(path, model): file in the page cache -> pinned chunks -> HBM -> train -> model file written; best of 3",
-           "_model_ok": (md5_file(model) == pin["model_md5"]) if pin else None}
-    os.remove(path)
-    return res
+    return traffic, "static: bytes per launch from profiles/%s (rocprofv3 --pmc passes of this command, tools/profile_round.sh; a PMC pass cannot share a run with the timed region, so it is not re-measured here)" % os.path.basename(pmc_file)
 
 
 def _bench_encode(ctx, model_path, main_res):
@@ -691,9 +729,9 @@ def _cpu_baseline(ctx, host, zhost, model_path, out):
         res["sample"] = (f"unmodified reference (oracle/_ref/yttm_ref_prod = bpe.cpp as shipped, -O3), n_threads=8"
                          f"{', taskset -c 0-7' if pre else ''}, train_bpe (C++ boundary: file -> model) on "
                          f"{'the SAME full' if not args.cpu_sample_mb else 'the first'} {n/1e6:.0f} MB of the corpus, vocab {args.vocab}, median of {runs} runs")
-        res["gpu_over_cpu"] = round(out["value"] / res["value"], 1)
-        if "e2e" in out and "train_file_to_model" in out["e2e"]:
-            res["gpu_e2e_over_cpu"] = round(out["e2e"]["train_file_to_model"]["value"] / res["value"], 1)
+        res["gpu_over_cpu"] = round(out["value"] / res["value"], 1)  # file -> model on both sides
+        if out.get("value_hbm_resident"):
+            res["gpu_hbm_resident_over_cpu"] = round(out["value_hbm_resident"] / res["value"], 1)
     except Exception as e:  # noqa: BLE001
         res["error"] = str(e)
     if zhost is not None:

@@ -362,6 +362,47 @@ def test_zz_rccl_world_of_one(tmp_path):
         L.yttm_comm_destroy(comm)
 
 
+@pytest.mark.parametrize("use_comm", [0, 1])
+def test_zz_fused_tail_ordering(tmp_path, use_comm):
+    """The round's candidate scan rides in the tail of the round's last kernel: the LAST workgroup to take its ticket reads what every
+    other workgroup -- on other XCDs -- published before taking its own (device-scope atomics, write-through stores, a workgroup-scope
+    release + s_waitcnt vmcnt(0); k_merge.hip k_tiles / k_words / k_fold_list).  The emulator cannot show that ordering; this does: the
+    100 MB variant of configs[1] (1 500 workgroups per launch in the tile rounds, word mode after them) trained with the fused tail and
+    with the scan as a kernel of its own (YTTM_NO_FUSE=1: ordered by a kernel boundary), three times: the candidate traces
+    (YTTM_DBG_CAND: one line per scan -- thresholds, list lengths, key count, a hash of the candidates) must agree line by line and the
+    models must be the reference's pin.  use_comm=1: through an RCCL communicator of one rank -- the multi-GPU round, whose scan sits in
+    the fold kernel's tail behind the all-gather."""
+    import hashlib
+    import re
+    import subprocess
+    import sys
+    pin = _full_pins()["c2_100mb"]
+    text = gen.abcd_corpus(pin["corpus_bytes"] + 1, seed=19, survey_stream=True)
+    assert hashlib.md5(text).hexdigest() == pin["corpus_md5"]
+    corpus = str(tmp_path / "c2.txt")
+    open(corpus, "wb").write(text)
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_train_worker.py")
+
+    def run(tag, env):
+        model, trace = str(tmp_path / (tag + ".model")), str(tmp_path / (tag + ".cand"))
+        r = subprocess.run([sys.executable, worker, corpus, model, "32000", str(use_comm)], env=dict(os.environ, YTTM_DBG_CAND=trace, **env), capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert hashlib.md5(open(model, "rb").read()).hexdigest() == pin["model_md5"], tag
+        lines = [re.sub(r"fused=\d ", "", ln) for ln in open(trace).read().split("\n") if ln]
+        return lines, json.loads(r.stdout.strip().splitlines()[-1])
+    import json
+    # (YTTM_NO_REFINE=1 on both sides: the fused scan otherwise raises the host's threshold by itself -- fewer candidates travel, same batches --
+    # and the traces would differ in their candidate counts for that reason alone)
+    ref, rep0 = run("nofuse", {"YTTM_NO_FUSE": "1", "YTTM_NO_REFINE": "1"})
+    assert rep0["fused_rounds"] == 0
+    for i in range(3):
+        got, rep = run("fuse%d" % i, {"YTTM_NO_REFINE": "1"})
+        assert rep["fused_rounds"] > 100 and rep["word_fused_rounds"] > 100, (rep["fused_rounds"], rep["word_fused_rounds"])
+        assert len(got) == len(ref), (len(got), len(ref))
+        for n, (a, b) in enumerate(zip(ref, got)):
+            assert a == b, "scan %d differs (run %d):\n  separate scan: %s\n  fused tail:    %s" % (n, i, a, b)
+
+
 def test_zz_encode_concurrent_threads(tmp_path):
     """Two Python threads encode on ONE BPE object (ctypes releases the GIL): each call owns an encoder lane, results are the
     single-threaded ones."""
