@@ -25,7 +25,7 @@ def main():
     if rc != 0:
         print("ERR", err.value.decode())
         sys.exit(3)
-    print(rep.value.decode())
+    print("REPORT " + rep.value.decode(), flush=True)  # (RCCL prints a banner of its own to stdout)
 
 
 if __name__ == "__main__":

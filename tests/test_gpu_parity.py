@@ -389,14 +389,17 @@ def test_zz_fused_tail_ordering(tmp_path, use_comm):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         assert hashlib.md5(open(model, "rb").read()).hexdigest() == pin["model_md5"], tag
         lines = [re.sub(r"fused=\d ", "", ln) for ln in open(trace).read().split("\n") if ln]
-        return lines, json.loads(r.stdout.strip().splitlines()[-1])
+        return lines, json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("REPORT ")][-1][7:])
     import json
     # (YTTM_NO_REFINE=1 on both sides: the fused scan otherwise raises the host's threshold by itself -- fewer candidates travel, same batches --
     # and the traces would differ in their candidate counts for that reason alone)
-    ref, rep0 = run("nofuse", {"YTTM_NO_FUSE": "1", "YTTM_NO_REFINE": "1"})
+    # YTTM_WORD_MIN_TOKENS=0: word mode (and its one-launch rounds) also at a tenth of the headline size, where a pass over the tiles is
+    # still cheap enough for the library to stay on them by itself
+    hooks = {"YTTM_NO_REFINE": "1", "YTTM_WORD_MIN_TOKENS": "0"}
+    ref, rep0 = run("nofuse", dict(hooks, YTTM_NO_FUSE="1"))
     assert rep0["fused_rounds"] == 0
     for i in range(3):
-        got, rep = run("fuse%d" % i, {"YTTM_NO_REFINE": "1"})
+        got, rep = run("fuse%d" % i, hooks)
         assert rep["fused_rounds"] > 100 and rep["word_fused_rounds"] > 100, (rep["fused_rounds"], rep["word_fused_rounds"])
         assert len(got) == len(ref), (len(got), len(ref))
         for n, (a, b) in enumerate(zip(ref, got)):

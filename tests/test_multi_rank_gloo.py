@@ -162,7 +162,12 @@ def test_exchange_blocks_too_small_are_repeated(tmp_path, sim_lib):
     open(corpus, "wb").write(text)
     m_ora = str(tmp_path / "ora.model")
     O.train(text, m_ora, 200, 1.0)
-    for i, env in enumerate(({"YTTM_XCHG_BLK_MIN": "2"}, {"YTTM_XCHG_BLK_MIN": "2", "YTTM_HOT_TARGET": "8", "YTTM_HOT_MIN": "3", "YTTM_HOT_CAP": "32"})):
+    # (blocks are sized from a prediction with a margin of three: a margin of 0.05 and a floor of one record make nearly every round's too small)
+    small = {"YTTM_XCHG_BLK_MIN": "2", "YTTM_XCHG_MARGIN": "0.05", "YTTM_TEST_EXPECT": "exchange_retries>20"}
+    # YTTM_XCHG_NOTES=2: the adds' notes of the slots that may have crossed a list threshold overflow in nearly every round -- the fold then
+    # walks every delta record of every block instead (and must keep doing so across a repeat)
+    for i, env in enumerate((small, dict(small, YTTM_HOT_TARGET="8", YTTM_HOT_MIN="3", YTTM_HOT_CAP="32"),
+                             dict(small, YTTM_HOT_TARGET="8", YTTM_HOT_MIN="3", YTTM_HOT_CAP="32", YTTM_XCHG_NOTES="2"), {"YTTM_XCHG_NOTES": "2"})):
         m_mp = str(tmp_path / f"mp{i}.model")
         run_world(corpus, m_mp, 200, 1.0, 3, sim_lib, env)
         assert filecmp.cmp(m_mp, m_ora, shallow=False), env

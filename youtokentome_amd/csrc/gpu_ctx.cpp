@@ -175,7 +175,6 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   words_inline_max_ = env_uint("YTTM_WORDS_INLINE_MAX", 1u << 18);  // (measured at 1 GB, K4 ms: 16 k -> 97.2, 64 k -> 95.4, 256 k -> 94.1)
   profile_events_ = env_uint("YTTM_PROFILE_EVENTS", 0) != 0;
   words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end)
-  xch_pack_tail_max_ = env_uint("YTTM_XCHG_TAIL_PACK", 2048);  // (multi-GPU: rounds of at most this many delta records pack them in the apply kernel's tail; 0: never)
   word_div_ = env_uint("YTTM_WORD_DIV", 200);  // (measured at 1 GB: 96 -> K4 135 ms, 150 -> 107, 200 -> 103.7, 300 -> 103.7, 500 -> 104)
   word_min_tiles_ = env_uint("YTTM_WORD_MIN_TILES", 16384);  // (tests: 0 = switch as soon as the hot list is active)
   // a pass over the tiles must cost more than word mode's three launches: 1 GB enwik-like text (25 M tokens, 48 us per dense round) got 15 % slower
@@ -219,7 +218,7 @@ GpuCtx::~GpuCtx() {
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_chunk_segs_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_);
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_); DFREE(d_top_slots_); DFREE(d_top_n_);
-  DFREE(d_send_); DFREE(d_xstat_); DFREE(d_bloom_);
+  DFREE(d_send_); DFREE(d_xstat_); DFREE(d_bloom_); DFREE(d_maybe_); DFREE(d_maybe_n_);
   DFREE(db_.keys); DFREE(db_.vals); DFREE(db_.touched); DFREE(d_dbn_);
   free_table(pt_);
   free_index();
@@ -903,6 +902,11 @@ void GpuCtx::pack_deltas() {
 }
 PairTable GpuCtx::pt_nolist() const {
   PairTable p = pt_;
+  p.maybe = d_maybe_;  // (the adds note the slots that may have crossed a threshold: k_fold_list looks at those, by their final counts)
+  p.maybe_n = d_maybe_n_;
+  p.maybe_cap = maybe_cap_;
+  p.maybe_hot = pt_.hot_tau;
+  p.maybe_top = pt_.top_tau;
   p.hot_tau = ~0ull;
   p.top_tau = ~0ull;
   return p;
@@ -911,17 +915,21 @@ PairTable GpuCtx::pt_nolist() const {
 void GpuCtx::exchange_round(unsigned long long only_mask, const ScanArgs *scan) {
   chain_event_ = nullptr;
   if (!only_mask) {  // (a repeat gathers the same block again, wider)
-    if (!xch_tail_pack_) pack_deltas();
-    xch_tail_pack_ = false;
+    pack_deltas();
     xch_parity_ ^= 1u;  // the next round claims through the other counter (left at zero by this round's pack)
     db_.n = d_dbn_ + xch_parity_;
     db_.n_next = d_dbn_ + (xch_parity_ ^ 1u);
   }
   grow_recv(blk_ * (unsigned long long)comm_->world);
   comm_->allgather_blocks(d_send_, d_recv_, (size_t)blk_ * sizeof(DeltaRec), st_);
-  launch_pt_apply_blocks(pt_nolist(), d_recv_, blk_, comm_->world, comm_->rank, only_mask, d_xstat_, st_);
-  launch_fold_list(pt_, d_recv_, blk_, comm_->world, only_mask, scan, d_stats_, pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_,
-                   pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, d_xstat_, d_hot_n_ + 1, st_);
+  const bool alone = comm_->world == 1;  // (no other rank's block: phase 1 has nothing to add, the fold kernel reads the header itself)
+  if (!alone) launch_pt_apply_blocks(pt_nolist(), d_recv_, blk_, comm_->world, comm_->rank, only_mask, d_xstat_, st_);
+  PairTable fpt = pt_;  // (the real thresholds, and the notes to go through)
+  fpt.maybe = d_maybe_;
+  fpt.maybe_n = d_maybe_n_;
+  fpt.maybe_cap = maybe_cap_;
+  launch_fold_list(fpt, d_recv_, blk_, comm_->world, only_mask, scan, d_stats_, pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_,
+                   pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, d_xstat_, alone, st_);
   if (scan) pending_zero_ = false;  // (the scan zeroes the finished batch's pairs)
 }
 
@@ -957,6 +965,10 @@ void GpuCtx::pair_count() {
       alloc_delta_table(cap);
       d_xstat_ = dmalloc<unsigned long long>(XSTAT_WORDS);
       HIP_CHECK(hipMemsetAsync(d_xstat_, 0, XSTAT_WORDS * 8, st_));
+      maybe_cap_ = std::max(1u, env_uint("YTTM_XCHG_NOTES", 1u << 16));  // (tests shrink it: the fold then walks every record)
+      d_maybe_ = dmalloc<uint32_t>(maybe_cap_);
+      d_maybe_n_ = dmalloc<unsigned int>(4);
+      HIP_CHECK(hipMemsetAsync(d_maybe_n_, 0, 16, st_));
       blk_min_ = std::max(2u * XHDR, env_uint("YTTM_XCHG_BLK_MIN", 4096));  // (tests shrink it to force the repeat path)
       blk_ = blk_min_;
       grow_recv(std::max<unsigned long long>(send_cap_, blk_ * (unsigned long long)comm_->world));
@@ -1100,13 +1112,15 @@ void GpuCtx::rebuild_hot() {
 // from numbers that are the same on every rank.  True if the table changed (a scan made before that is stale).
 bool GpuCtx::settle_exchange(unsigned long long xmask, unsigned long long xmax, unsigned long long fatal) {
   if (fatal) throw GpuError{"delta exchange buffer overflow (on some rank)"};
-  unsigned long long want = blk_min_;  // next round: twice what the busiest rank sent this round
+  unsigned long long want = blk_min_;  // (after a repeat: twice what the busiest rank sent this round)
   while (want < 2 * xmax + 2 * XHDR) want <<= 1;
-  if (xmax || xmask) xmax_last_ = xmax;  // (decides whether the next round packs in its apply kernel's tail: the same number on every rank)
-  if (!xmask) {
-    if (xmax) blk_ = want;  // (xmax == 0: nothing was exchanged since the last verdict)
-    return false;
+  if (xmax || xmask) {
+    // records per merge site of the round that was just exchanged (its batch's summed pair counts = its sites, over all ranks): what the
+    // next rounds' blocks are sized from (merge_apply) -- rounds differ by a factor of four in their batches, much less in this rate
+    xrate_[1] = xrate_[0];
+    xrate_[0] = xch_sites_ ? (double)xmax / (double)xch_sites_ : 5.0;
   }
+  if (!xmask) return false;
   blk_ = blk_min_;
   while (blk_ < xmax + XHDR) blk_ <<= 1;
   exchange_round(xmask, nullptr);
@@ -1653,16 +1667,31 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     fused_mx_ = next_tau_mx;
     fused_round_ = sa.round_id;
   }
-  // Multi-GPU: what the apply launches get instead of the scan -- the exchange tail (ScanArgs::on == 2): a small round packs its delta table
-  // in the last apply launch's tail (decided from last round's largest record count: the same on every rank, not that it had to be).
+  if (multi()) {
+    // this round's blocks: sized for what the busiest rank will send, predicted from the batch -- its summed pair counts are its merge sites
+    // over all ranks -- and the records per site of the last two rounds, with a margin of three (a block that is too small costs a second
+    // exchange and a scan of its own, ~60 us; one that is too large costs bytes on the links); never more than the round can touch at all
+    // (dt_bound above: the same formula).  Every input is the same on every rank.
+    unsigned long long sites = 0, bound = 0;
+    for (uint32_t j = 0; j < k; j++) {
+      sites += rule_counts ? rule_counts[j] : 0;
+      bound += std::min<unsigned long long>(rule_counts ? 5 * rule_counts[j] : ~0ull >> 8, 4ull * (vmax + 1) + 4);
+    }
+    xch_sites_ = sites;
+    static const double margin = getenv("YTTM_XCHG_MARGIN") ? atof(getenv("YTTM_XCHG_MARGIN")) : 3.0;  // (tests: a margin below one forces the repeat path)
+    const double pred = rule_counts ? std::max(xrate_[0], xrate_[1]) * (double)sites * margin : (double)bound;
+    unsigned long long need = (unsigned long long)std::min((double)std::min<unsigned long long>(bound, send_cap_), pred) + XHDR;
+    unsigned long long b2 = blk_min_;
+    while (b2 < need) b2 <<= 1;
+    blk_ = b2;
+  }
+  // Multi-GPU: what the word-mode launches get instead of the scan (ScanArgs::on == 2): the round's last workgroup only leaves the
+  // worklist counters at zero; a one-launch round has not even that to do (launch_words_apply: on = 3).  (Packing the delta table in this
+  // tail as well was measured: ONE workgroup walking ten thousand claimed slots across XCDs took 45 us -- k_dt_pack's hundred take 6.)
   ScanArgs xa{};
   if (multi()) {
     xa.on = 2u;
     xa.done_ctr = d_hot_n_ + 1;
-    xa.xsend = d_send_;
-    xa.xsend_cap = send_cap_;
-    xa.xtiles = cls_[0].n_tiles;
-    xa.xpack = xch_pack_tail_max_ && xmax_last_ <= xch_pack_tail_max_ && !cls_[2].n_tiles ? 1u : 0u;  // (k_giant runs behind the tile classes' launches)
   }
   // A fused round is timed by the device itself (its first launch notes the time, the tail reports the difference in the mailbox):
   // no hipEventRecord on the round's critical path (two per round were 4 us of host time: 8 % of a Zipf step).  YTTM_PROFILE_EVENTS=1
@@ -1687,10 +1716,9 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // the tail of class ci's launch: the scan (single GPU) or the exchange tail (multi-GPU) in the round's last tile-class launch, nothing elsewhere
   auto tail_of = [&](int ci) -> const ScanArgs * {
     if (ci != last_cls) return nullptr;
-    if (multi()) return xa.xpack || (ci == 0 && word_mode_) ? &xa : nullptr;  // (a tail is a ticket per workgroup: a big tile round that packs by a kernel of its own has none)
+    if (multi()) return ci == 0 && word_mode_ ? &xa : nullptr;  // (the tile kernels have nothing to do in a tail)
     return sa.on ? &sa : nullptr;
   };
-  bool tail_packed = false;
   for (int ci = 1; ci >= 0; ci--) {
     if (!cls_[ci].n_tiles) continue;
     if (ci == 0 && word_mode_) {
@@ -1734,14 +1762,12 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       if (launch_words_apply(wset, kpt, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, d_irec_, &gba,
                              tail_of(0), work_hint, words_inline_max_, &ga, words_fuse_max_, st_))
         word_fused_rounds++;
-      if (multi() && xa.xpack) tail_packed = true;  // (every form of the word-mode round ends in a launch that carries the tail)
       word_rounds++;
       if (!idx_valid_) word_all_rounds++;
       continue;
     }
     const BatchArgs tba = first_ba();
     launch_merge_apply(ci, cls_[ci].ts, kpt, db_, d_rules_, cap - 1, self_x, self_z, z_base, d_stats_, &tba, tail_of(ci), d_bloom_, st_);
-    if (multi() && xa.xpack && ci == last_cls) tail_packed = true;
   }
   launch_giant(true, cls_[2].ts, cls_[2].slot, kpt, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
   if (dev_timing) kt.launches[KT_MERGE]++;
@@ -1798,7 +1824,6 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     for (int ci = 0; ci < 2; ci++) maybe_repack(ci);
   }
   if (multi()) {  // (stream-ordered; the scan in the fold's tail reports blocks that were too small)
-    xch_tail_pack_ = tail_packed;
     exchange_round(0, sa.on ? &sa : nullptr);
   }
   // single GPU: no sync here -- the candidate filter that always follows reads n_keys back together with its results

@@ -264,9 +264,10 @@ class GpuCtx {
   unsigned long long *d_xstat_ = nullptr;  // [XSTAT_WORDS] the fold's report on a round's exchange (yttm_kernels.h)
   unsigned long long *d_dbn_ = nullptr;    // [2] the delta table's claim counters: rounds alternate, whoever packs one zeroes the other
   unsigned int xch_parity_ = 0;
-  bool xch_tail_pack_ = false;             // the round's last apply launch packs the delta table in its tail (small rounds)
-  unsigned int xch_pack_tail_max_ = 2048;  // ... when the busiest rank sent at most this many records last round
-  unsigned long long xmax_last_ = ~0ull;
+  uint32_t *d_maybe_ = nullptr;            // slots whose count an add of this round saw at or above a list threshold (PairTable::maybe)
+  unsigned int *d_maybe_n_ = nullptr, maybe_cap_ = 0;
+  unsigned long long xch_sites_ = 0;       // merge sites (summed pair counts of the batch) of the round whose exchange is under way
+  double xrate_[2] = {5.0, 5.0};           // delta records of the busiest rank per merge site, last two rounds
   bool multi() const { return comm_ != nullptr; }  // (a communicator of world size 1 still runs the whole exchange path)
   PairTable pt_nolist() const;  // pt_ with the list thresholds off (multi-GPU: the apply kernels and phase 1 of the fold list nothing)
   void exchange_round(unsigned long long only_mask, const ScanArgs *scan);

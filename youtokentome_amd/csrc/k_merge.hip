@@ -1079,12 +1079,8 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     if (is_last) {
       __threadfence();  // (acquire: nothing stale in this CU's caches)
       static_assert(sizeof(WL) >= (CAND_BINS + 160) * sizeof(unsigned int), "tile buffers double as the tail's scratch");
-      if (sa.on == 2u) {  // multi-GPU: the delta table -> the send block; the scan comes after the exchange (k_fold_list)
-        exchange_tail<WPB * 64>(db, sa, stats);
-      } else {
-        const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
-        scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
-      }
+      const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
+      scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
     }
   }
 }
@@ -1430,7 +1426,7 @@ __global__ __launch_bounds__(BLOCK) void k_pt_apply(PairTable pt, const DeltaRec
 }
 
 // multi-GPU: the delta table of the round that just ran -> the contiguous send block { header, records... } (k_merge_shared.h: dt_pack_*);
-// the claimed slots are freed for the next round.  (A small round's last apply launch does this in its tail instead: ScanArgs::xpack.)
+// the claimed slots are freed for the next round.
 __global__ __launch_bounds__(BLOCK) void k_dt_pack(DeltaBuf db, DeltaRec *__restrict__ send, unsigned long long send_cap, unsigned long long *__restrict__ stats,
                                                    uint32_t tiles_a) {
   const unsigned long long n_raw = *db.n;
@@ -1444,33 +1440,40 @@ __global__ __launch_bounds__(BLOCK) void k_dt_pack(DeltaBuf db, DeltaRec *__rest
 // k_fold_list).  A rank whose count does not fit its block is skipped as a whole and reported in xstat[0] (bit r); the host then repeats
 // the exchange with larger blocks for exactly those ranks (only_mask).  xstat[1] = largest count seen (sizes the next round's blocks),
 // xstat[4..7] = sums over the headers.  No host round trip: counts are read on the device.
-__global__ __launch_bounds__(BLOCK) void k_pt_apply_blocks(PairTable pt, const DeltaRec *__restrict__ blocks, unsigned long long blk, int world,
-                                                           int rank, unsigned long long only_mask, unsigned long long *__restrict__ xstat) {
-  if (blockIdx.x == 0 && threadIdx.x == 0 && !only_mask) {  // (a repeat gathers the same headers again)
-    unsigned long long sites = 0, toks = 0, tiles = 0;
-    for (int r = 0; r < world; r++) {
-      const DeltaRec *b = blocks + (size_t)r * blk;
-      sites += b[1].key;
-      toks += (unsigned long long)b[1].delta;
-      tiles += b[2].key;
-    }
+// the ranks' block headers -> xstat (one thread of the fold): sums, largest count, blocks that did not fit, "a rank lost records"
+__device__ inline void fold_headers(const DeltaRec *__restrict__ blocks, unsigned long long blk, int world, unsigned long long only_mask,
+                                    unsigned long long *__restrict__ xstat) {
+  unsigned long long sites = 0, toks = 0, tiles = 0, xmask = 0, xmax = 0, lost = 0;
+  for (int r = 0; r < world; r++) {
+    const DeltaRec *b = blocks + (size_t)r * blk;
+    const unsigned long long n = b[0].key;  // header: record count of rank r, capacity of its send buffer
+    sites += b[1].key;
+    toks += (unsigned long long)b[1].delta;
+    tiles += b[2].key;
+    xmax = n > xmax ? n : xmax;
+    if (n > (unsigned long long)b[0].delta) lost = 1ull;  // rank r lost records: every rank reads this verdict and stops
+    if (only_mask && !((only_mask >> r) & 1ull)) continue;
+    if (n > blk - XHDR) xmask |= 1ull << r;  // (reported for the own block too: every rank must reach the same verdict)
+  }
+  if (!only_mask) {  // (a repeat gathers the same headers again)
     xstat[4] = sites;
     xstat[5] = toks;
     xstat[6] = tiles;
     xstat[7] = (unsigned long long)world;
   }
+  atomicMax(&xstat[1], xmax);
+  if (lost) xstat[3] = 1ull;
+  if (xmask) atomicOr(&xstat[0], xmask);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pt_apply_blocks(PairTable pt, const DeltaRec *__restrict__ blocks, unsigned long long blk, int world,
+                                                           int rank, unsigned long long only_mask, unsigned long long *__restrict__ xstat) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) fold_headers(blocks, blk, world, only_mask, xstat);
   for (int r = 0; r < world; r++) {
     const DeltaRec *b = blocks + (size_t)r * blk;
-    const unsigned long long n = b[0].key;  // header: record count of rank r, capacity of its send buffer
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      atomicMax(&xstat[1], n);
-      if (n > (unsigned long long)b[0].delta) xstat[3] = 1ull;  // rank r lost records: every rank reads this verdict and stops
-    }
+    const unsigned long long n = b[0].key;
     if (only_mask && !((only_mask >> r) & 1ull)) continue;
-    if (n > blk - XHDR) {  // (reported for the own block too: every rank must reach the same verdict)
-      if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&xstat[0], 1ull << r);
-      continue;
-    }
+    if (n > blk - XHDR) continue;  // (reported by fold_headers: the repeat brings it)
     if (r == rank) continue;  // own deltas went into the table when they were made
     unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
     const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
@@ -1479,69 +1482,67 @@ __global__ __launch_bounds__(BLOCK) void k_pt_apply_blocks(PairTable pt, const D
   }
 }
 
-// multi-GPU, per round, phase 2 (behind phase 1's kernel boundary: every rank's deltas are in the table).  A count that reached a list
-// threshold during this round puts its slot on that list HERE, judged by the FINAL count -- the same on every rank -- and not by whichever
-// adder happened to see a crossing (the apply kernels and phase 1 run with the thresholds off): a transient crossing -- this rank's +5
-// before another's -3 -- would list the slot on one rank and not on the other, and the lists' lengths (so: whether one overflowed) would
-// have to be agreed on by a collective of their own every round.  Only a pair some rank raised can have crossed: every record with a
-// positive delta of every block, this rank's included, is looked up; several ranks' records of one pair meet at the flag (atomicOr:
-// whoever sets it appends).  Then the round's candidate scan, by the last workgroup (scan_top, straight into the host's mailbox), with
-// the fold's report on the exchange (xstat).
+// multi-GPU, per round, phase 2 (behind phase 1's kernel boundary: every rank's deltas are in the table), ONE workgroup.  A count that
+// reached a list threshold during this round puts its slot on that list HERE, judged by the FINAL count -- the same on every rank -- and
+// not by whichever adder happened to see a crossing (the apply kernels and phase 1 run with the thresholds off): a transient crossing
+// -- this rank's +5 before another's -3 -- would list the slot on one rank and not on the other, and the lists' lengths (so: whether one
+// overflowed) would have to be agreed on by a collective of their own every round.  Which slots to look at: the adds' notes
+// (PairTable::maybe, a superset of the slots that can have crossed; a few dozen per round); should they have overflowed, every record
+// with a positive delta of every block, this rank's included.  Several notes of one slot meet at the flag (atomicOr: whoever sets it
+// appends).  Then the round's candidate scan (scan_top, straight into the host's mailbox), with the fold's report on the exchange (xstat).
 constexpr int FOLD_NT = 512;
+__device__ inline void fold_list_slot(const PairTable &pt, unsigned long long j) {
+  const unsigned long long raw = ld_agent(pt.cnt_p(j)), c = raw & PT_CNT;
+  unsigned long long want = 0;
+  if (!(raw & PT_HOT) && c >= pt.hot_tau) want |= PT_HOT;
+  if (!(raw & PT_TOP) && c >= pt.top_tau) want |= PT_TOP;
+  if (!want) return;
+  const unsigned long long fresh = want & ~atomicOr(pt.cnt_p(j), want);
+  if (fresh & PT_HOT) {
+    const unsigned int o = atomicAdd(pt.hot_n, 1u);
+    if (o < pt.hot_cap) __hip_atomic_store(&pt.hot_slots[o], (uint32_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (fresh & PT_TOP) {
+    const unsigned int o = atomicAdd(pt.top_n, 1u);
+    if (o < pt.top_cap) __hip_atomic_store(&pt.top_slots[o], (uint32_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 __global__ __launch_bounds__(FOLD_NT) void k_fold_list(PairTable pt, const DeltaRec *__restrict__ blocks, unsigned long long blk, int world,
                                                         unsigned long long only_mask, ScanArgs sa, unsigned long long *__restrict__ stats,
                                                         const RuleSlot *__restrict__ zrules, unsigned int zmask, unsigned long long zself, BatchArgs zba,
-                                                        unsigned long long *__restrict__ xstat, unsigned int *__restrict__ done_ctr) {
+                                                        unsigned long long *__restrict__ xstat, int read_headers) {
   __shared__ unsigned long long zkeys[FILTER_LDS_KEYS];
   __shared__ unsigned int scratch[CAND_BINS + 160];
-  __shared__ unsigned int is_last;
+  // (a communicator of one rank: phase 1 was not launched -- there is no other rank's block -- and the header is read here)
+  if (read_headers && threadIdx.x == 0) fold_headers(blocks, blk, world, only_mask, xstat);
+  const unsigned int n_maybe = pt.maybe_n ? *pt.maybe_n : 0u;
   if (pt.hot_tau != ~0ull) {
-    for (int r = 0; r < world; r++) {
-      const DeltaRec *b = blocks + (size_t)r * blk;
-      const unsigned long long n = b[0].key;
-      if (only_mask && !((only_mask >> r) & 1ull)) continue;
-      if (n > blk - XHDR) continue;  // (skipped by phase 1 as well; the repeat brings it)
-      for (unsigned long long i = (unsigned long long)blockIdx.x * FOLD_NT + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * FOLD_NT) {
-        if (b[XHDR + i].delta <= 0) continue;
-        const unsigned long long key = b[XHDR + i].key;
-        unsigned long long j = mix64(key) & pt.mask;
-        for (;;) {
-          const unsigned long long k = ld_agent(pt.key_p(j));
-          if (k == PT_EMPTY) break;  // (cannot happen: a positive delta was added, so the key is there)
-          if (k == key) {
-            const unsigned long long raw = ld_agent(pt.cnt_p(j)), c = raw & PT_CNT;
-            unsigned long long want = 0;
-            if (!(raw & PT_HOT) && c >= pt.hot_tau) want |= PT_HOT;
-            if (!(raw & PT_TOP) && c >= pt.top_tau) want |= PT_TOP;
-            if (want) {
-              const unsigned long long fresh = want & ~atomicOr(pt.cnt_p(j), want);
-              if (fresh & PT_HOT) {
-                const unsigned int o = atomicAdd(pt.hot_n, 1u);
-                if (o < pt.hot_cap) __hip_atomic_store(&pt.hot_slots[o], (uint32_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-              if (fresh & PT_TOP) {
-                const unsigned int o = atomicAdd(pt.top_n, 1u);
-                if (o < pt.top_cap) __hip_atomic_store(&pt.top_slots[o], (uint32_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-            }
-            break;
+    if (n_maybe <= pt.maybe_cap) {
+      for (unsigned int e = threadIdx.x; e < n_maybe; e += FOLD_NT) fold_list_slot(pt, pt.maybe[e]);
+    } else {  // the notes overflowed (a round with tens of thousands of new candidates): every record that raised a count
+      for (int r = 0; r < world; r++) {
+        const DeltaRec *b = blocks + (size_t)r * blk;
+        const unsigned long long n = b[0].key;
+        if (n > blk - XHDR) continue;  // (skipped by phase 1 as well; the repeat brings it -- with the notes still overflowed)
+        for (unsigned long long i = threadIdx.x; i < n; i += FOLD_NT) {
+          if (b[XHDR + i].delta <= 0) continue;
+          const unsigned long long key = b[XHDR + i].key;
+          unsigned long long j = mix64(key) & pt.mask;
+          for (;;) {
+            const unsigned long long k = ld_agent(pt.key_p(j));
+            if (k == PT_EMPTY) break;  // (cannot happen: a positive delta was added, so the key is there)
+            if (k == key) { fold_list_slot(pt, j); break; }
+            j = (j + 1) & pt.mask;
           }
-          j = (j + 1) & pt.mask;
         }
       }
     }
   }
+  __syncthreads();
+  // (the notes are consumed -- unless blocks were skipped and a repeat is to come: its pass must see the overflow verdict again)
+  if (threadIdx.x == 0 && pt.maybe_n && !(n_maybe > pt.maybe_cap && ld_agent(&xstat[0]))) *pt.maybe_n = 0u;
   if (!sa.on) return;
-  // ---- the round's candidate scan, by the last workgroup to get here (the ticket: as in k_tiles)
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __syncthreads();
-  if (threadIdx.x == 0) is_last = atomicAdd(done_ctr, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
+  // ---- the round's candidate scan
   bool zkeys_in_lds = zrules && zmask < FILTER_LDS_KEYS;  // (the finished batch's pairs, to be zeroed: as in k_top_scan)
   if (zba.k) {
     zmask = 4 * BATCH_ARGS_MAX - 1;
@@ -1563,7 +1564,7 @@ __global__ __launch_bounds__(FOLD_NT) void k_fold_list(PairTable pt, const Delta
   __syncthreads();
   const RuleProbe zprobe{zkeys_in_lds ? zkeys : nullptr, zrules, zmask};
   ScanArgs sb = sa;
-  sb.done_ctr = done_ctr;  // (scan_top leaves the ticket at zero)
+  sb.done_ctr = nullptr;  // (a single-workgroup launch)
   scan_top<FOLD_NT>(pt, sb, stats, zprobe, zself, scratch, xstat);
 }
 
@@ -2535,7 +2536,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
       for (int i = 0; i < 4; i++) blk_add(stats, i, A.st[i]);
     }
   }
-  {  // the candidate scan, by the last workgroup to get here (as in k_tiles); it also leaves the worklist's length at zero
+  if (sa.on != 3u) {  // the candidate scan, by the last workgroup to get here (as in k_tiles); it also leaves the worklist's length at zero
     __shared__ unsigned int is_last;
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2547,8 +2548,8 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
     if (is_last) {
       __threadfence();
       if (threadIdx.x <= WL_PARTS + 1) const_cast<unsigned int *>(work_n)[threadIdx.x] = 0;  // (every workgroup has read it)
-      if (sa.on == 2u) {  // multi-GPU (see k_tiles)
-        exchange_tail<WPB * 64>(db, sa, stats);
+      if (sa.on == 2u) {  // multi-GPU: the scan comes behind the exchange (k_fold_list)
+        if (threadIdx.x == 0) *sa.done_ctr = 0;
       } else {
         const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};
         scan_top<WPB * 64>(pt, sa, stats, zprobe, self_x != 0xffffffffu ? pair_key(self_x, self_x) : PT_EMPTY, reinterpret_cast<unsigned int *>(&WL[0]), nullptr);
@@ -2590,8 +2591,8 @@ __global__ __launch_bounds__(DAPPLY_NT) void k_delta_apply(PairTable pt, DeltaBu
   __syncthreads();
   if (!is_last) return;
   __threadfence();
-  if (sa.on == 2u) {  // multi-GPU (see k_tiles)
-    exchange_tail<DAPPLY_NT>(db, sa, stats);
+  if (sa.on == 2u) {  // multi-GPU: the scan comes behind the exchange (k_fold_list)
+    if (threadIdx.x == 0) *sa.done_ctr = 0;
     return;
   }
   bool zkeys_in_lds = zrules && zmask < FILTER_LDS_KEYS;  // (the finished batch's pairs, to be zeroed: as in k_top_scan)
@@ -2931,18 +2932,13 @@ void launch_pt_apply_blocks(const PairTable &pt, const DeltaRec *blocks, unsigne
                             unsigned long long *xstat, hipStream_t st) {
   unsigned long long b = (blk + BLOCK - 1) / BLOCK;
   if (b > 256 * 4) b = 256 * 4;
-  if (world == 1 && b > 1) b = 1;  // (a communicator of one rank: only the headers are looked at)
   hipLaunchKernelGGL(k_pt_apply_blocks, dim3((unsigned int)b), dim3(BLOCK), 0, st, pt, blocks, blk, world, rank, only_mask, xstat);
 }
 void launch_fold_list(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, unsigned long long only_mask, const ScanArgs *scan,
                       unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, const BatchArgs *zba,
-                      unsigned long long *xstat, unsigned int *done_ctr, hipStream_t st) {
-  // every workgroup takes a ticket at the end (~12 ns each on one address), and the last one scans: no more of them than the blocks need
-  unsigned long long b = (blk + FOLD_NT - 1) / FOLD_NT;
-  if (b > 256 * 2) b = 256 * 2;
-  if (b < 1) b = 1;
-  hipLaunchKernelGGL(k_fold_list, dim3((unsigned int)b), dim3(FOLD_NT), 0, st, pt, blocks, blk, world, only_mask, scan ? *scan : ScanArgs{}, stats, zrules, zmask, zself,
-                     zba ? *zba : BatchArgs{}, xstat, done_ctr);
+                      unsigned long long *xstat, bool read_headers, hipStream_t st) {
+  hipLaunchKernelGGL(k_fold_list, dim3(1), dim3(FOLD_NT), 0, st, pt, blocks, blk, world, only_mask, scan ? *scan : ScanArgs{}, stats, zrules, zmask, zself,
+                     zba ? *zba : BatchArgs{}, xstat, read_headers ? 1 : 0);
 }
 void launch_top_scan(const PairTable &pt, const ScanArgs &sa, unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself,
                      const BatchArgs *zba, unsigned long long *xstat, hipStream_t st) {
@@ -2993,9 +2989,10 @@ bool launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &
                         unsigned int fuse_max, hipStream_t st) {
   if (!ws.n_words) return false;
   BatchArgs bargs = ba ? *ba : BatchArgs{};
-  const ScanArgs sargs = scan ? *scan : ScanArgs{};
+  ScanArgs sargs = scan ? *scan : ScanArgs{};
   // the worklist first (k_wgather) -- unless the round is small enough for k_words to find its words itself (one launch a round)
   const bool fused = ga && worklist && work_hint && work_hint <= fuse_max && sargs.on && bargs.k != 0 && !ga->xyz && rule_mask < APPLY_LDS_RULES;
+  if (fused && sargs.on == 2u) sargs.on = 3u;  // (multi-GPU: a fused round leaves no worklist behind -- there is no tail)
   if (ga && !fused) launch_wgather(*ga, &bargs, work_hint, st);
   if (!fused) bargs.mark = 0u;  // (the round's first launch carries the mark)
   // one run of 64 words per wave and iteration; work_hint = about how many words the round will visit (0: unknown / every word)

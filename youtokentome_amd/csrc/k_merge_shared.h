@@ -137,18 +137,6 @@ __device__ inline void dt_pack_rec(const DeltaBuf &db, DeltaRec *__restrict__ se
   db.keys[sl] = PT_EMPTY;
   db.vals[sl] = 0;
 }
-// The exchange tail of a round's last apply launch (ScanArgs::on == 2), run by its last workgroup: see yttm_kernels.h.
-template <int NT>
-__device__ inline void exchange_tail(const DeltaBuf &db, const ScanArgs &sa, unsigned long long *__restrict__ stats) {
-  if (sa.xpack && db.keys) {
-    const unsigned long long n_raw = ld_agent(db.n);
-    const unsigned long long n = n_raw <= db.mask + 1 ? n_raw : db.mask + 1;
-    for (unsigned long long i = threadIdx.x; i < n; i += NT) dt_pack_rec(db, sa.xsend, sa.xsend_cap, i);
-    if (threadIdx.x == 0) dt_pack_header(db, sa.xsend, sa.xsend_cap, n_raw, stats, sa.xtiles);
-  }
-  if (threadIdx.x == 0 && sa.done_ctr) *sa.done_ctr = 0;
-}
-
 // ------------------------------------------------------------------------------------------------- fused candidate scan
 __device__ inline int cand_bin(unsigned long long c) {
   if (c < 256) return (int)c;

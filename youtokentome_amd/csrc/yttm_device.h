@@ -62,6 +62,15 @@ struct PairTable {
   unsigned long long top_tau;  // ... and this, on the top list (~0ull: list off)
   uint32_t *top_slots;         // [top_cap]
   unsigned int *top_n;
+  // Multi-GPU: the apply kernels and the fold of the other ranks' deltas run with the two thresholds above OFF (~0) -- what joins a list is
+  // decided behind the exchange, by the FINAL counts, which are the same on every rank (k_fold_list).  So that this needs no pass over
+  // every delta record, an add that sees a count at or above a threshold on a slot not yet on that list notes the slot here: a
+  // rank-local superset of the slots that can have crossed (the largest partial sum of a slot's deltas is reached by a positive add,
+  // and it is at least the final count), re-examined -- by final count -- in the fold kernel's tail.  maybe_n == nullptr: not kept.
+  uint32_t *maybe;
+  unsigned int *maybe_n;
+  unsigned int maybe_cap;
+  unsigned long long maybe_hot, maybe_top;  // the thresholds the notes are taken by
 };
 
 struct TileSet {
@@ -194,6 +203,13 @@ __device__ inline void pt_add(const PairTable &pt, unsigned long long key, long 
             const unsigned int j = atomicAdd(pt.top_n, 1u);
             if (j < pt.top_cap) __hip_atomic_store(&pt.top_slots[j], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+        }
+      } else if (delta > 0 && pt.maybe_n && pt.maybe_hot != ~0ull) {
+        const unsigned long long old = atomicAdd(pt.cnt_p(i), (unsigned long long)delta);
+        const unsigned long long now = (old & PT_CNT) + (unsigned long long)delta;
+        if ((!(old & PT_HOT) && now >= pt.maybe_hot) || (!(old & PT_TOP) && now >= pt.maybe_top)) {
+          const unsigned int j = atomicAdd(pt.maybe_n, 1u);
+          if (j < pt.maybe_cap) __hip_atomic_store(&pt.maybe[j], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       } else {
         atomicAdd(pt.cnt_p(i), (unsigned long long)delta);

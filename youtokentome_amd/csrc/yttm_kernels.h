@@ -70,9 +70,9 @@ struct BatchArgs {
 // statistics rows, zeroes the batch's pairs, scans (and compacts) the hot list and publishes header + histogram + candidates
 // in the host's pinned mailbox -- one launch per round instead of two, and no second trip through the launch path.
 struct ScanArgs {
-  uint32_t on;  // 0: no tail in this launch; 1: the candidate scan; 2 (multi-GPU): the exchange tail -- the last workgroup leaves the worklist
-                // counters at zero and, with xpack, packs the round's delta table into the send block (a small round: one launch less
-                // before the all-gather); the scan then rides in the fold kernel behind the all-gather (k_fold_list)
+  uint32_t on;  // 0: no tail in this launch; 1: the candidate scan; 2 (multi-GPU, word mode): the last workgroup only leaves the worklist
+                // counters at zero -- the scan rides in the fold kernel behind the all-gather (k_fold_list); 3 (multi-GPU, set by
+                // launch_words_apply): a one-launch word round, which leaves no worklist behind -- no ticket, no tail
   uint32_t tau_mx;
   unsigned long long tau_cnt;  // candidates: count > tau_cnt, or == tau_cnt and max(x,y) <= tau_mx
   CandRec *out;                // [cap] all candidates (the first `fast` also go to the mailbox)
@@ -82,10 +82,6 @@ struct ScanArgs {
   uint32_t round_id;           // published in the mailbox when everything else is there; 0: nothing is published
   uint32_t want;               // != 0: about this many candidates are wanted -- the scan may raise the threshold by itself (scan_top: refine)
   uint32_t timed;              // the round's first launch left its start time in stats[STAT_T0]: the mailbox gets the duration (100 MHz ticks)
-  uint32_t xpack;              // on == 2: pack the delta table here (dt_pack_wg)
-  DeltaRec *xsend;             // the send block (XHDR header units + records)
-  unsigned long long xsend_cap;
-  uint32_t xtiles;             // this rank's class-A tiles (for the header)
 };
 constexpr int STAT_T0 = 6;  // stats[6]: wall_clock64() at the start of the round's first launch
 constexpr int STAT_T1 = 7;  // stats[7] (multi-GPU): ... when the round's apply kernels were done (noted by whoever packs the delta table)
@@ -157,13 +153,14 @@ void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t t
 void launch_dt_pack(const DeltaBuf &db, DeltaRec *send, unsigned long long send_cap, unsigned int n_hint, unsigned long long *stats, uint32_t tiles_a, hipStream_t st);
 // phase 1: the OTHER ranks' count deltas into the local replica (no list appends: pass a PairTable with the thresholds off)
 void launch_pt_apply_blocks(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, int rank, unsigned long long only_mask,
-                            unsigned long long *xstat, hipStream_t st);
-// phase 2, behind phase 1's kernel boundary: every record of every rank's block (this rank's too) whose pair ended the round at or above a
-// list threshold joins that list -- judged by the FINAL count, the same on every rank, so the lists hold the same pairs everywhere and
-// no verdict on them has to be exchanged.  The last workgroup runs the round's candidate scan (scan != nullptr) straight into the mailbox.
+                            unsigned long long *xstat, hipStream_t st);  // (not launched for a communicator of one rank: no other rank's block exists; k_fold_list reads the header then)
+// phase 2, behind phase 1's kernel boundary, ONE workgroup: every slot noted by an add of this round (PairTable::maybe: pt comes with its
+// real thresholds AND the notes) whose pair ended the round at or above a list threshold joins that list -- judged by the FINAL count,
+// the same on every rank, so the lists hold the same pairs everywhere and no verdict on them has to be exchanged.  Then the round's
+// candidate scan (scan != nullptr) straight into the mailbox.
 void launch_fold_list(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, unsigned long long only_mask, const ScanArgs *scan,
                       unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, const BatchArgs *zba,
-                      unsigned long long *xstat, unsigned int *done_ctr, hipStream_t st);
+                      unsigned long long *xstat, bool read_headers /* phase 1 was not launched */, hipStream_t st);
 constexpr int MB_HIST = 128;  // byte offset of the count histogram in the mailbox (header + xstat before it)
 constexpr int MB_XSUM = 6144; // multi-GPU, behind the histogram: sums over the ranks' block headers -- [0] merge sites so far, [8] tokens streamed so far,
                               // [16] class-A tiles, [24] ranks; [32] the round's apply kernels on the device clock (ticks; ScanArgs::timed)
