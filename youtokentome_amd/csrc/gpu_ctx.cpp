@@ -218,8 +218,8 @@ GpuCtx::~GpuCtx() {
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_chunk_segs_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_);
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_); DFREE(d_top_slots_); DFREE(d_top_n_);
-  DFREE(d_send_); DFREE(d_xstat_); DFREE(d_bloom_); DFREE(d_maybe_); DFREE(d_maybe_n_);
-  DFREE(db_.keys); DFREE(db_.vals); DFREE(db_.touched); DFREE(d_dbn_);
+  DFREE(d_xstat_); DFREE(d_bloom_); DFREE(d_maybe_); DFREE(d_maybe_n_);
+  DFREE(db_.keys); DFREE(db_.touched); DFREE(d_send2_[0]); DFREE(d_send2_[1]);
   free_table(pt_);
   free_index();
   free_words();
@@ -866,10 +866,10 @@ void GpuCtx::exchange_deltas() {
   if (!multi()) return;
   chain_event_ = nullptr;
   launch_fold_stats(d_stats_, pt_.n_keys, st_);  // the apply kernels leave their slot counts in per-workgroup rows
-  pack_deltas();
+  DeltaRec *cur = d_send2_[xch_parity_];  // (K3's updates went straight into the block's records: dt_add)
   unsigned long long n_local = 0;
   unsigned int nk_local = 0;  // keys in the table after this rank's own updates (one round trip for both numbers)
-  HIP_CHECK(hipMemcpyAsync(&n_local, d_send_, 8, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&n_local, cur, 8, hipMemcpyDeviceToHost, st_));
   HIP_CHECK(hipMemcpyAsync(&nk_local, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
   sync();
   n_keys_host = nk_local;
@@ -877,11 +877,12 @@ void GpuCtx::exchange_deltas() {
   size_t n_remote = 0;
   for (int attempt = 0;; attempt++) {
     unsigned long long need_all = 0;
-    if (comm_->allgather_recs(d_send_ + XHDR, mine, d_recv_, (size_t)recv_cap_, st_, &need_all, &n_remote)) break;
+    if (comm_->allgather_recs(cur + XHDR, mine, d_recv_, (size_t)recv_cap_, st_, &need_all, &n_remote)) break;
     if (need_all == ~0ull) throw GpuError{"delta exchange buffer overflow (on some rank)"};
     if (attempt) throw GpuError{"delta receive buffer could not be sized"};
     grow_recv(need_all);
   }
+  finish_block((unsigned int)std::min<unsigned long long>(n_local, 1u << 20));
   ensure_table_capacity(n_keys_host + n_remote);
   launch_pt_apply(pt_, d_recv_, n_remote, st_);  // (no candidate list exists yet: nothing is listed)
   unsigned int nk = 0;
@@ -891,14 +892,19 @@ void GpuCtx::exchange_deltas() {
 }
 
 // Per-round exchange, all stream-ordered, no host round trip:
-//   [k_dt_pack, unless the round's last apply launch packed in its tail] -> ncclAllGather of the first blk_ units (header + records) of
-//   every rank's send block -> k_pt_apply_blocks (phase 1: the other ranks' deltas into the replica, thresholds off) -> k_fold_list (phase 2:
-//   the lists, by the final counts; then -- `scan` -- the round's candidate scan straight into the host's mailbox).
+//   ncclAllGather of the first blk_ units (header + records) of every rank's send block -- the apply kernels left it complete: dt_add -- ->
+//   k_pt_apply_blocks (phase 1: the other ranks' deltas into the replica, thresholds off) -> k_fold_list (phase 2: the lists, by the final
+//   counts; then -- `scan` -- the round's candidate scan straight into the host's mailbox) -> k_dt_clean (during the host's turn).
 // ONE collective per round.  What does not fit a block is reported through the mailbox (xstat), and candidates() repeats the exchange
 // for exactly those ranks with larger blocks.
-// the round's delta table -> the send block (and the table is free again); the claim counters of two rounds alternate
-void GpuCtx::pack_deltas() {
-  launch_dt_pack(db_, d_send_, send_cap_, last_pack_hint_, d_stats_, cls_[0].n_tiles, st_);
+// behind an exchange: the table's slots of the block just sent are freed, the other block is made ready, and the next round's updates go
+// there (k_dt_clean: off the critical path -- it runs while the host picks the next batch)
+void GpuCtx::finish_block(unsigned int n_hint) {
+  db_.send = d_send2_[xch_parity_];
+  launch_dt_clean(db_, d_send2_[xch_parity_ ^ 1u], n_hint, d_stats_, cls_[0].n_tiles, d_maybe_n_ + 1, st_);
+  xch_last_ = d_send2_[xch_parity_];
+  xch_parity_ ^= 1u;
+  db_.send = d_send2_[xch_parity_];
 }
 PairTable GpuCtx::pt_nolist() const {
   PairTable p = pt_;
@@ -914,16 +920,11 @@ PairTable GpuCtx::pt_nolist() const {
 
 void GpuCtx::exchange_round(unsigned long long only_mask, const ScanArgs *scan) {
   chain_event_ = nullptr;
-  if (!only_mask) {  // (a repeat gathers the same block again, wider)
-    pack_deltas();
-    xch_parity_ ^= 1u;  // the next round claims through the other counter (left at zero by this round's pack)
-    db_.n = d_dbn_ + xch_parity_;
-    db_.n_next = d_dbn_ + (xch_parity_ ^ 1u);
-  }
+  const DeltaRec *block = only_mask ? xch_last_ : d_send2_[xch_parity_];  // (a repeat gathers the same block again, wider)
   grow_recv(blk_ * (unsigned long long)comm_->world);
-  comm_->allgather_blocks(d_send_, d_recv_, (size_t)blk_ * sizeof(DeltaRec), st_);
+  comm_->allgather_blocks(block, d_recv_, (size_t)blk_ * sizeof(DeltaRec), st_);
   const bool alone = comm_->world == 1;  // (no other rank's block: phase 1 has nothing to add, the fold kernel reads the header itself)
-  if (!alone) launch_pt_apply_blocks(pt_nolist(), d_recv_, blk_, comm_->world, comm_->rank, only_mask, d_xstat_, st_);
+  if (!alone) launch_pt_apply_blocks(pt_nolist(), d_recv_, blk_, comm_->world, comm_->rank, only_mask, d_xstat_, d_stats_, st_);
   PairTable fpt = pt_;  // (the real thresholds, and the notes to go through)
   fpt.maybe = d_maybe_;
   fpt.maybe_n = d_maybe_n_;
@@ -931,6 +932,7 @@ void GpuCtx::exchange_round(unsigned long long only_mask, const ScanArgs *scan) 
   launch_fold_list(fpt, d_recv_, blk_, comm_->world, only_mask, scan, d_stats_, pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_,
                    pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, d_xstat_, alone, st_);
   if (scan) pending_zero_ = false;  // (the scan zeroes the finished batch's pairs)
+  if (!only_mask) finish_block(last_pack_hint_);
 }
 
 // keys the pair table is sized for before the first merge: distinct initial pairs <= adjacencies <= tokens, and -- the candidate filter
@@ -950,7 +952,7 @@ void GpuCtx::pair_count() {
   unsigned long long bound = initial_table_keys(n_tokens0);
   if (multi()) {
     bound = std::min<unsigned long long>(bound * comm_->world, 1ull << 27);
-    if (!d_send_) {
+    if (!d_send2_[0]) {
       // distinct pairs a round of this rank can touch: bounded by its updates (a handful per live token); sized for a
       // quarter of that -- dense rounds touch few distinct pairs, sparse rounds few tokens -- and checked: a rank whose table or
       // send block overflowed says so in its block's header and every rank stops
@@ -996,24 +998,23 @@ void GpuCtx::pair_count() {
 // table more than half full counts as overflow.  Called at set-up and, from merge_apply, when a round's bound on the distinct pairs it
 // can touch does not fit -- between rounds the table is empty (k_dt_pack frees what a round claimed).
 void GpuCtx::alloc_delta_table(unsigned long long cap) {
-  DFREE(db_.keys); DFREE(db_.vals); DFREE(db_.touched); DFREE(d_send_);
-  db_.keys = dmalloc<unsigned long long>(cap);
-  db_.vals = dmalloc<long long>(cap);
-  db_.touched = dmalloc<uint32_t>(cap);
-  if (!d_dbn_) {
-    d_dbn_ = dmalloc<unsigned long long>(2);
-    HIP_CHECK(hipMemsetAsync(d_dbn_, 0, 16, st_));
-    xch_parity_ = 0;
-  }
-  db_.n = d_dbn_ + xch_parity_;
-  db_.n_next = d_dbn_ + (xch_parity_ ^ 1u);
+  DFREE(db_.keys); DFREE(db_.touched); DFREE(d_send2_[0]); DFREE(d_send2_[1]);
+  db_.keys = dmalloc<DtSlot>(cap);
   db_.mask = cap - 1;
-  launch_fill_u64(db_.keys, PT_EMPTY, cap, st_);
-  HIP_CHECK(hipMemsetAsync(db_.vals, 0, cap * 8, st_));
+  launch_dt_init(db_.keys, cap, st_);
   send_cap_ = cap / 2;
-  d_send_ = dmalloc<DeltaRec>(send_cap_ + XHDR);
-  const DeltaRec hdr[XHDR] = {{0ull, (long long)send_cap_}, {0ull, 0ll}, {0ull, 0ll}, {0ull, 0ll}};  // {records, capacity}: the peers check the one against the other
-  HIP_CHECK(hipMemcpyAsync(d_send_, hdr, sizeof hdr, hipMemcpyHostToDevice, st_));
+  db_.send_cap = send_cap_;
+  db_.touched = dmalloc<uint32_t>(send_cap_);
+  // the two send blocks { header, records }: all zeros but the capacity in the header -- the peers check a block's count against it
+  for (int b = 0; b < 2; b++) {
+    d_send2_[b] = dmalloc<DeltaRec>(send_cap_ + XHDR);
+    HIP_CHECK(hipMemsetAsync(d_send2_[b], 0, (send_cap_ + XHDR) * sizeof(DeltaRec), st_));
+    const long long capv = (long long)send_cap_;
+    HIP_CHECK(hipMemcpyAsync(&d_send2_[b][0].delta, &capv, 8, hipMemcpyHostToDevice, st_));
+  }
+  xch_parity_ = 0;
+  xch_last_ = d_send2_[0];
+  db_.send = d_send2_[0];
   sync();
 }
 

@@ -249,21 +249,20 @@ class GpuCtx {
   unsigned int cand_cap_ = 0;
   unsigned int *d_cand_n_ = nullptr;
   unsigned long long *d_cand_hist_ = nullptr;
-  // multi-GPU delta exchange.  db_ = the round's delta table (yttm_device.h); d_send_ = { header: record count, capacity } followed by
-  // the table's records as k_dt_pack left them; per round the first blk_ 16-byte units of every rank's d_send_ are all-gathered
-  // into d_recv_
+  // multi-GPU delta exchange.  db_ = the round's delta table and send block (yttm_device.h: DeltaBuf); per round the first blk_ 16-byte
+  // units of every rank's send block are all-gathered into d_recv_
   DeltaBuf db_{};
-  DeltaRec *d_send_ = nullptr, *d_recv_ = nullptr;
+  DeltaRec *d_send2_[2] = {nullptr, nullptr}, *d_recv_ = nullptr;  // the two send blocks (rounds alternate: yttm_device.h DeltaBuf)
+  const DeltaRec *xch_last_ = nullptr;                           // the block of the exchange under way (a repeat gathers it again)
+  void finish_block(unsigned int n_hint);
   unsigned long long recv_cap_ = 0, blk_ = 4096, blk_min_ = 4096, send_cap_ = 0;
   unsigned int last_pack_hint_ = 1u << 16;
-  void pack_deltas();
   void alloc_delta_table(unsigned long long cap);
   bool delta_cap_forced_ = false;  // YTTM_XCHG_TABLE_CAP (tests: the overflow verdict)
   bool pt_fresh_ = false;  // build_class(0) left an empty pair table of the initial size
   unsigned long long initial_table_keys(unsigned long long n_tok) const;
   unsigned long long *d_xstat_ = nullptr;  // [XSTAT_WORDS] the fold's report on a round's exchange (yttm_kernels.h)
-  unsigned long long *d_dbn_ = nullptr;    // [2] the delta table's claim counters: rounds alternate, whoever packs one zeroes the other
-  unsigned int xch_parity_ = 0;
+  unsigned int xch_parity_ = 0;            // which send block this round's updates go to
   uint32_t *d_maybe_ = nullptr;            // slots whose count an add of this round saw at or above a list threshold (PairTable::maybe)
   unsigned int *d_maybe_n_ = nullptr, maybe_cap_ = 0;
   unsigned long long xch_sites_ = 0;       // merge sites (summed pair counts of the batch) of the round whose exchange is under way

@@ -1425,14 +1425,41 @@ __global__ __launch_bounds__(BLOCK) void k_pt_apply(PairTable pt, const DeltaRec
   for (; i < n; i += stride) pt_add(pt, recs[i].key, recs[i].delta);
 }
 
-// multi-GPU: the delta table of the round that just ran -> the contiguous send block { header, records... } (k_merge_shared.h: dt_pack_*);
-// the claimed slots are freed for the next round.
-__global__ __launch_bounds__(BLOCK) void k_dt_pack(DeltaBuf db, DeltaRec *__restrict__ send, unsigned long long send_cap, unsigned long long *__restrict__ stats,
-                                                   uint32_t tiles_a) {
-  const unsigned long long n_raw = *db.n;
-  const unsigned long long n = n_raw <= db.mask + 1 ? n_raw : db.mask + 1;
-  if (blockIdx.x == 0 && threadIdx.x == 0) dt_pack_header(db, send, send_cap, n_raw, stats, tiles_a);
-  for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * BLOCK) dt_pack_rec(db, send, send_cap, i);
+// multi-GPU, behind a round's exchange and off its critical path (it runs during the host's turn): the delta table's slots of the round
+// just exchanged are freed (db.send = that round's block, which itself stays as it is: a repeat of the exchange may want it again), and
+// the OTHER block -- the round before's, long settled -- is made ready for the round to come: its records' sums zeroed, its header
+// written (no records yet; this rank's statistics for the ranks' common decisions, yttm_device.h: XHDR).
+__global__ __launch_bounds__(BLOCK) void k_dt_clean(DeltaBuf db, DeltaRec *__restrict__ other, unsigned long long *__restrict__ stats, uint32_t tiles_a,
+                                                    unsigned int *__restrict__ done_ctr) {
+  __shared__ unsigned int is_last;
+  const unsigned long long n_cur = db.send[0].key < db.send_cap ? db.send[0].key : db.send_cap;
+  const unsigned long long n_oth = other[0].key < db.send_cap ? other[0].key : db.send_cap;
+  const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
+  for (unsigned long long j = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; j < n_cur; j += stride) {
+    const uint32_t sl = db.touched[j];
+    db.keys[sl].key = PT_EMPTY;
+    db.keys[sl].idx = DT_NOIDX;
+  }
+  for (unsigned long long j = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; j < n_oth; j += stride) other[XHDR + j].delta = 0;
+  // the other block's count goes to zero when every workgroup has read it: the last one to get here
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(done_ctr, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!is_last || threadIdx.x != 0) return;
+  other[0].key = 0;
+  other[0].delta = (long long)db.send_cap;
+  other[1].key = stats ? ld_agent(&stats[0]) : 0ull;                 // merge sites so far (folded by the scans: a round or two old)
+  other[1].delta = (long long)(stats ? ld_agent(&stats[2]) : 0ull);  // tokens streamed so far
+  other[2].key = tiles_a;
+  other[2].delta = 0;
+  other[3].key = 0;
+  other[3].delta = 0;
+  *done_ctr = 0;
+}
+__global__ __launch_bounds__(BLOCK) void k_dt_init(DtSlot *__restrict__ slots, unsigned long long n) {
+  const DtSlot e{PT_EMPTY, DT_NOIDX, 0u};
+  for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * BLOCK) slots[i] = e;
 }
 
 // multi-GPU, per round, phase 1: the ranks' delta blocks as ncclAllGather left them -- block r = { header, records... } of `blk` 16-byte
@@ -1467,8 +1494,12 @@ __device__ inline void fold_headers(const DeltaRec *__restrict__ blocks, unsigne
 }
 
 __global__ __launch_bounds__(BLOCK) void k_pt_apply_blocks(PairTable pt, const DeltaRec *__restrict__ blocks, unsigned long long blk, int world,
-                                                           int rank, unsigned long long only_mask, unsigned long long *__restrict__ xstat) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) fold_headers(blocks, blk, world, only_mask, xstat);
+                                                           int rank, unsigned long long only_mask, unsigned long long *__restrict__ xstat,
+                                                           unsigned long long *__restrict__ stats) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (stats && !only_mask) __hip_atomic_store(&stats[STAT_T1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (apply kernels and all-gather are done)
+    fold_headers(blocks, blk, world, only_mask, xstat);
+  }
   for (int r = 0; r < world; r++) {
     const DeltaRec *b = blocks + (size_t)r * blk;
     const unsigned long long n = b[0].key;
@@ -1514,7 +1545,10 @@ __global__ __launch_bounds__(FOLD_NT) void k_fold_list(PairTable pt, const Delta
   __shared__ unsigned long long zkeys[FILTER_LDS_KEYS];
   __shared__ unsigned int scratch[CAND_BINS + 160];
   // (a communicator of one rank: phase 1 was not launched -- there is no other rank's block -- and the header is read here)
-  if (read_headers && threadIdx.x == 0) fold_headers(blocks, blk, world, only_mask, xstat);
+  if (read_headers && threadIdx.x == 0) {
+    if (stats && !only_mask) __hip_atomic_store(&stats[STAT_T1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fold_headers(blocks, blk, world, only_mask, xstat);
+  }
   const unsigned int n_maybe = pt.maybe_n ? *pt.maybe_n : 0u;
   if (pt.hot_tau != ~0ull) {
     if (n_maybe <= pt.maybe_cap) {
@@ -2922,17 +2956,22 @@ void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t t
   hipLaunchKernelGGL(k_hot_scan, dim3(g), dim3(BLOCK), 0, st, pt, tau_cnt, tau_mx, out, cap, n_out, hist, done_ctr, mailbox, fast, round_id,
                      stats, zrules, zmask, zself, zba ? *zba : BatchArgs{}, xstat);
 }
-void launch_dt_pack(const DeltaBuf &db, DeltaRec *send, unsigned long long send_cap, unsigned int n_hint, unsigned long long *stats, uint32_t tiles_a, hipStream_t st) {
+void launch_dt_clean(const DeltaBuf &db, DeltaRec *other, unsigned int n_hint, unsigned long long *stats, uint32_t tiles_a, unsigned int *done_ctr, hipStream_t st) {
   unsigned int g = (n_hint + BLOCK - 1) / BLOCK;
-  if (g < 8) g = 8;
-  if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(k_dt_pack, dim3(g), dim3(BLOCK), 0, st, db, send, send_cap, stats, tiles_a);
+  if (g < 4) g = 4;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(k_dt_clean, dim3(g), dim3(BLOCK), 0, st, db, other, stats, tiles_a, done_ctr);
+}
+void launch_dt_init(DtSlot *slots, unsigned long long n, hipStream_t st) {
+  unsigned long long b = (n + BLOCK - 1) / BLOCK;
+  if (b > 256 * 16) b = 256 * 16;
+  hipLaunchKernelGGL(k_dt_init, dim3((unsigned int)(b ? b : 1)), dim3(BLOCK), 0, st, slots, n);
 }
 void launch_pt_apply_blocks(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, int rank, unsigned long long only_mask,
-                            unsigned long long *xstat, hipStream_t st) {
+                            unsigned long long *xstat, unsigned long long *stats, hipStream_t st) {
   unsigned long long b = (blk + BLOCK - 1) / BLOCK;
   if (b > 256 * 4) b = 256 * 4;
-  hipLaunchKernelGGL(k_pt_apply_blocks, dim3((unsigned int)b), dim3(BLOCK), 0, st, pt, blocks, blk, world, rank, only_mask, xstat);
+  hipLaunchKernelGGL(k_pt_apply_blocks, dim3((unsigned int)b), dim3(BLOCK), 0, st, pt, blocks, blk, world, rank, only_mask, xstat, stats);
 }
 void launch_fold_list(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, unsigned long long only_mask, const ScanArgs *scan,
                       unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, const BatchArgs *zba,

@@ -113,30 +113,6 @@ __device__ inline void xstat_forward(unsigned char *mailbox, unsigned long long 
   else *reinterpret_cast<unsigned long long *>(mailbox + MB_XSUM + 8 * (k - 4)) = v;
 }
 
-// The delta table of the round that just ran -> the contiguous send block { header, records... }; the claimed slots are freed for the
-// next round and the next round's counter is left at zero.  The header part, by ONE thread of the launch / workgroup.
-__device__ inline void dt_pack_header(const DeltaBuf &db, DeltaRec *__restrict__ send, unsigned long long send_cap, unsigned long long n_raw,
-                                      unsigned long long *__restrict__ stats, uint32_t tiles_a) {
-  send[0].key = n_raw;  // (a count beyond the capacity tells every rank that this one lost updates)
-  send[0].delta = (long long)send_cap;
-  send[1].key = stats ? ld_agent(&stats[0]) : 0ull;                 // merge sites so far (folded by the scans: a round or two old)
-  send[1].delta = (long long)(stats ? ld_agent(&stats[2]) : 0ull);  // tokens streamed so far
-  send[2].key = tiles_a;
-  send[2].delta = 0;
-  send[3].key = 0;
-  send[3].delta = 0;
-  *db.n_next = 0ull;
-  if (stats) __hip_atomic_store(&stats[STAT_T1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the apply kernels are done)
-}
-__device__ inline void dt_pack_rec(const DeltaBuf &db, DeltaRec *__restrict__ send, unsigned long long send_cap, unsigned long long i) {
-  const uint32_t sl = __hip_atomic_load(&db.touched[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (i < send_cap) {
-    send[XHDR + i].key = ld_agent(&db.keys[sl]);
-    send[XHDR + i].delta = (long long)ld_agent(reinterpret_cast<const unsigned long long *>(&db.vals[sl]));
-  }
-  db.keys[sl] = PT_EMPTY;
-  db.vals[sl] = 0;
-}
 // ------------------------------------------------------------------------------------------------- fused candidate scan
 __device__ inline int cand_bin(unsigned long long c) {
   if (c < 256) return (int)c;

@@ -64,9 +64,10 @@ struct PairTable {
   unsigned int *top_n;
   // Multi-GPU: the apply kernels and the fold of the other ranks' deltas run with the two thresholds above OFF (~0) -- what joins a list is
   // decided behind the exchange, by the FINAL counts, which are the same on every rank (k_fold_list).  So that this needs no pass over
-  // every delta record, an add that sees a count at or above a threshold on a slot not yet on that list notes the slot here: a
-  // rank-local superset of the slots that can have crossed (the largest partial sum of a slot's deltas is reached by a positive add,
-  // and it is at least the final count), re-examined -- by final count -- in the fold kernel's tail.  maybe_n == nullptr: not kept.
+  // every delta record, an add that takes a count across a threshold, on a slot not yet on that list, notes the slot here: a rank-local
+  // superset of the slots that can have ended the round on the other side (a slot not on a list starts the round below the list's
+  // threshold: to end at or above it, some add of the sequence this rank applies must cross it), re-examined -- by final count -- in
+  // the fold kernel.  maybe_n == nullptr: not kept.
   uint32_t *maybe;
   unsigned int *maybe_n;
   unsigned int maybe_cap;
@@ -122,24 +123,34 @@ struct DeltaRec {
   long long delta;
 };
 
-// Multi-GPU: what a rank's merge round changes, summed by pair before it travels -- a rank-local open-addressing table
-// pair -> signed delta that every count update of a round is added to as well (dt_add), and a list of the slots the round
-// claimed.  After the round k_dt_pack turns the claimed slots into the contiguous block of (pair, delta) records that the
-// ranks all-gather, and frees them.  (A record per update instead -- the first version -- put every update of a round through one
-// global cursor: 0.9 ms per round at 1 GB with a communicator of one rank, and ten times the bytes on the links.)
-struct DeltaBuf {
-  unsigned long long *keys;  // [mask + 1], PT_EMPTY = free; nullptr = single-GPU mode (nothing is kept)
-  long long *vals;           // [mask + 1]
-  uint32_t *touched;         // [mask + 1] slots claimed this round, in claim order
-  unsigned long long *n;     // number of claimed slots (may run past the capacity: reported, the training stops)
-  unsigned long long *n_next;  // the counter of the NEXT round (the two alternate): whoever packs this round's table leaves it at zero, so
-                               // that no memset sits between two rounds
-  unsigned long long mask;
-};
 // A rank's send block of a round, in 16-byte units: XHDR header units, then the records.  Header: [0] = {records, capacity of the rank's
 // send buffer}, [1] = {merge sites so far, tokens streamed so far} on that rank, [2] = {its class-A tiles, -}: every rank sees every
 // header after the all-gather, so what is decided from them (block overflow, the switch to word mode) is decided alike everywhere.
 constexpr unsigned int XHDR = 4;
+// Multi-GPU: what a rank's merge round changes, summed by pair before it travels.  Every count update of a round is also added
+// (dt_add) to a (pair, delta) RECORD of the round's send block: a rank-local open-addressing table maps the pair to its record -- the
+// thread that claims a table slot takes the next record (the block's own header word counts them), writes the pair there and
+// publishes the record number in the slot; everybody else adds to that record.  When the round's last apply kernel is done the block
+// is what the ranks all-gather: nothing is packed, copied or counted in between (a table of (pair, sum) that a kernel of its own
+// turned into the block cost 6 us per round on the critical path; a record per update instead -- the first version -- put every update
+// of a round through one global cursor: 0.9 ms per round at 1 GB, and ten times the bytes on the links).  Two blocks alternate: behind
+// the exchange, off the critical path (k_dt_clean), the table's slots are freed and the block of the round before is zeroed for the
+// round to come, while the block just sent stays as it is for a possible repeat of the exchange with wider blocks.
+constexpr uint32_t DT_NOIDX = 0xffffffffu;  // the slot's claimant has not published the record number yet
+constexpr uint32_t DT_LOST = 0xfffffffeu;   // ... found the block full: the update is dropped, the count in the header says so, every rank stops
+struct DtSlot {
+  unsigned long long key;  // PT_EMPTY = free
+  uint32_t idx;            // record number in the send block
+  uint32_t pad;
+};
+struct DeltaBuf {
+  DtSlot *keys;              // [mask + 1]; nullptr = single-GPU mode (nothing is kept)
+  uint32_t *touched;         // [send_cap] slot of record j (for the clean-up)
+  DeltaRec *send;            // this round's send block: send[0].key = records claimed so far
+  unsigned long long send_cap;
+  unsigned long long mask;
+};
+
 
 __host__ __device__ inline unsigned long long mix64(unsigned long long x) {
   x ^= x >> 33;
@@ -207,7 +218,10 @@ __device__ inline void pt_add(const PairTable &pt, unsigned long long key, long 
       } else if (delta > 0 && pt.maybe_n && pt.maybe_hot != ~0ull) {
         const unsigned long long old = atomicAdd(pt.cnt_p(i), (unsigned long long)delta);
         const unsigned long long now = (old & PT_CNT) + (unsigned long long)delta;
-        if ((!(old & PT_HOT) && now >= pt.maybe_hot) || (!(old & PT_TOP) && now >= pt.maybe_top)) {
+        const unsigned long long was = old & PT_CNT;
+        // (the add that CROSSES a threshold, not every add above it: the flags are not set during the round, and a new pair of the first
+        // rounds takes a hundred thousand adds on its way to ten million)
+        if ((!(old & PT_HOT) && was < pt.maybe_hot && now >= pt.maybe_hot) || (!(old & PT_TOP) && was < pt.maybe_top && now >= pt.maybe_top)) {
           const unsigned int j = atomicAdd(pt.maybe_n, 1u);
           if (j < pt.maybe_cap) __hip_atomic_store(&pt.maybe[j], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -233,23 +247,37 @@ __device__ inline unsigned long long pt_get(const PairTable &pt, unsigned long l
 __device__ inline void dt_add(const DeltaBuf &db, unsigned long long key, long long delta) {
   if (!db.keys) return;
   unsigned long long i = mix64(key * 0x9e3779b97f4a7c15ull) & db.mask;
+  bool found = false;
   for (unsigned long long probes = 0; probes <= db.mask; probes++) {
-    unsigned long long k = ld_agent(&db.keys[i]);
+    unsigned long long k = ld_agent(&db.keys[i].key);
     if (k == PT_EMPTY) {
-      k = atomicCAS(&db.keys[i], PT_EMPTY, key);
-      if (k == PT_EMPTY) {
-        const unsigned long long j = atomicAdd(db.n, 1ull);
-        if (j <= db.mask) __hip_atomic_store(&db.touched[j], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (write-through: the round's tail may pack the table from another XCD)
+      k = atomicCAS(&db.keys[i].key, PT_EMPTY, key);
+      if (k == PT_EMPTY) {  // mine: the next record of the block (the claimant publishes its number HERE, inside the loop, before any lane of
+                            // its wave gets to wait for one below)
+        const unsigned long long j = atomicAdd(&db.send[0].key, 1ull);
+        if (j < db.send_cap) {
+          db.send[XHDR + j].key = key;  // (read after the kernel: by the all-gather and the clean-up)
+          db.touched[j] = (uint32_t)i;
+        }
+        __hip_atomic_store(&db.keys[i].idx, j < db.send_cap ? (uint32_t)j : DT_LOST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         k = key;
       }
     }
     if (k == key) {
-      atomicAdd(reinterpret_cast<unsigned long long *>(&db.vals[i]), (unsigned long long)delta);
-      return;
+      found = true;
+      break;
     }
     i = (i + 1) & db.mask;
   }
-  atomicAdd(db.n, db.mask + 2);  // table full (the count then exceeds the capacity: the host stops the training)
+  if (!found) {
+    atomicAdd(&db.send[0].key, db.send_cap + 2);  // table full (the count then exceeds the capacity: every rank stops the training)
+    return;
+  }
+  uint32_t j;
+  do {
+    j = __hip_atomic_load(&db.keys[i].idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } while (j == DT_NOIDX);  // (a few hundred cycles at most: between the claimant's CAS and its store)
+  if (j != DT_LOST) atomicAdd(reinterpret_cast<unsigned long long *>(&db.send[XHDR + j].delta), (unsigned long long)delta);
 }
 
 // ---- UTF-8 (utf8.cpp:14-74), device version ----------------------------------------------------------------------

@@ -84,7 +84,7 @@ struct ScanArgs {
   uint32_t timed;              // the round's first launch left its start time in stats[STAT_T0]: the mailbox gets the duration (100 MHz ticks)
 };
 constexpr int STAT_T0 = 6;  // stats[6]: wall_clock64() at the start of the round's first launch
-constexpr int STAT_T1 = 7;  // stats[7] (multi-GPU): ... when the round's apply kernels were done (noted by whoever packs the delta table)
+constexpr int STAT_T1 = 7;  // stats[7] (multi-GPU): ... when the round's apply kernels and the all-gather behind them were done (noted by the fold's first kernel)
 void launch_top_scan(const PairTable &pt, const ScanArgs &sa, unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself,
                      const BatchArgs *zba, unsigned long long *xstat /* multi-GPU: the exchange's report, forwarded to the mailbox */, hipStream_t st);
 void launch_top_rebuild(const PairTable &pt, unsigned int listed_hint, hipStream_t st);
@@ -149,11 +149,13 @@ void launch_hot_scan(const PairTable &pt, unsigned long long tau_cnt, uint32_t t
                      unsigned long long *hist, unsigned int *done_ctr, unsigned char *mailbox, unsigned int fast, uint32_t round_id,
                      unsigned long long *stats, const RuleSlot *zrules, unsigned int zmask, unsigned long long zself, unsigned int listed_hint,
                      const BatchArgs *zba, unsigned long long *xstat /* multi-GPU: the exchange's report, forwarded to the mailbox */, hipStream_t st);
-// ---- multi-GPU, per round: K4 -> [k_dt_pack] -> ncclAllGather -> k_pt_apply_blocks -> k_fold_list (+ the round's candidate scan)
-void launch_dt_pack(const DeltaBuf &db, DeltaRec *send, unsigned long long send_cap, unsigned int n_hint, unsigned long long *stats, uint32_t tiles_a, hipStream_t st);
+// ---- multi-GPU, per round: K4 -> ncclAllGather -> k_pt_apply_blocks -> k_fold_list (+ the round's candidate scan) [-> k_dt_clean, during the host's turn]
+void launch_dt_clean(const DeltaBuf &db /* .send = the block just exchanged */, DeltaRec *other /* the block of the round to come */, unsigned int n_hint,
+                     unsigned long long *stats, uint32_t tiles_a, unsigned int *done_ctr, hipStream_t st);
+void launch_dt_init(DtSlot *slots, unsigned long long n, hipStream_t st);
 // phase 1: the OTHER ranks' count deltas into the local replica (no list appends: pass a PairTable with the thresholds off)
 void launch_pt_apply_blocks(const PairTable &pt, const DeltaRec *blocks, unsigned long long blk, int world, int rank, unsigned long long only_mask,
-                            unsigned long long *xstat, hipStream_t st);  // (not launched for a communicator of one rank: no other rank's block exists; k_fold_list reads the header then)
+                            unsigned long long *xstat, unsigned long long *stats, hipStream_t st);  // (not launched for a communicator of one rank: no other rank's block exists; k_fold_list reads the header then)
 // phase 2, behind phase 1's kernel boundary, ONE workgroup: every slot noted by an add of this round (PairTable::maybe: pt comes with its
 // real thresholds AND the notes) whose pair ended the round at or above a list threshold joins that list -- judged by the FINAL count,
 // the same on every rank, so the lists hold the same pairs everywhere and no verdict on them has to be exchanged.  Then the round's
