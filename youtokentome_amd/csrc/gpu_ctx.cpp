@@ -932,7 +932,7 @@ void GpuCtx::exchange_round(unsigned long long only_mask, const ScanArgs *scan) 
   launch_fold_list(fpt, d_recv_, blk_, comm_->world, only_mask, scan, d_stats_, pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_,
                    pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, d_xstat_, alone, st_);
   if (scan) pending_zero_ = false;  // (the scan zeroes the finished batch's pairs)
-  if (!only_mask) finish_block(last_pack_hint_);
+  if (!only_mask) finish_block((unsigned int)std::min<unsigned long long>(blk_ / 2, 1u << 18));  // (about as many records as the block was sized for)
 }
 
 // keys the pair table is sized for before the first merge: distinct initial pairs <= adjacencies <= tokens, and -- the candidate filter

@@ -1441,8 +1441,9 @@ __global__ __launch_bounds__(BLOCK) void k_dt_clean(DeltaBuf db, DeltaRec *__res
     db.keys[sl].idx = DT_NOIDX;
   }
   for (unsigned long long j = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; j < n_oth; j += stride) other[XHDR + j].delta = 0;
-  // the other block's count goes to zero when every workgroup has read it: the last one to get here
-  __threadfence();
+  // the other block's count goes to zero when every workgroup has read it: the last one to get here.  (No fence: the ticket orders READS of
+  // that count -- each workgroup's are long done -- and what is written here only has to be there at the kernel's end.  An agent-scope fence
+  // per workgroup writes the XCD's L2 back: this kernel took 30 us with one.)
   __syncthreads();
   if (threadIdx.x == 0) is_last = atomicAdd(done_ctr, 1u) == gridDim.x - 1;
   __syncthreads();
