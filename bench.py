@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the Zipf (configs[2]) block")
     ap.add_argument("--no-extra2", action="store_true", help="skip the large-alphabet (CJK-shaped) and enwik-like (4e6-word lexicon) training blocks")
+    ap.add_argument("--no-big", action="store_true", help="skip the beyond-2^32 blocks: the 8 GB Zipf corpus and the corpus with a word seen 4.4e9 times (file -> model, pinned)")
     ap.add_argument("--no-touched-pass", action="store_true", help="skip the untimed K4 measurement pass (profiling runs: one training per process)")
     ap.add_argument("--cpu-sample-mb", type=int, default=0, help="0 = the full corpus")
     ap.add_argument("--cpu-runs", type=int, default=3, help="runs of the reference's train_bpe per corpus (the median is reported)")
@@ -208,6 +209,16 @@ def main():
                 out["parity"][name + "_model_matches_reference"] = x["model_ok"]
     else:
         zhost = None
+
+    # ---- beyond 2^32: more than 4 GiB of text; a word seen more than 2^32 times (file -> model, pinned against the reference) ------------
+    if world == 1 and not args.no_big and args.corpus == "abcd" and args.size_mb == 1000:
+        out.setdefault("extra", {})
+        for name in ("c3_8gb", "c8_heavy_word"):
+            b = _bench_big(ctx, name)
+            if b is not None:
+                out["extra"][name] = b
+                out["parity"][name + "_model_matches_reference"] = b.pop("_model_ok")
+                out["parity"][name + "_corpus_md5_matches"] = b.pop("_corpus_ok")
 
     # ---- CPU baseline: the unmodified reference on this box's host cores (rank 0, N=1 only) --------------------------------
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
@@ -443,6 +454,50 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
     del d_corpus
     torch.cuda.empty_cache()
     return res
+
+
+def _bench_big(ctx, name):
+    """A corpus past 2^32 -- bytes (c3_8gb: the Zipf stream at 8 GB) or occurrences of one word (c8_heavy_word: 'a' 4.4e9 times; the reference
+    counts word frequencies in uint64, bpe.cpp:382-385) -- streamed to a file (never whole in host memory), trained file -> model, the
+    model's md5 against the unmodified reference's (tests/golden/full_size_pins.json, made by tests/golden/make_full_pins.py)."""
+    L, _lib, gen, args = ctx["L"], ctx["_lib"], ctx["gen"], ctx["args"]
+    pin = ctx["pins"].get(name)
+    if pin is None or args.vocab != 32000:
+        return None
+    tmp = tempfile.gettempdir()
+    if shutil.disk_usage(tmp).free < pin["corpus_bytes"] + (2 << 30):
+        return {"skipped": "not enough room in %s for the %.1f GB corpus file" % (tmp, pin["corpus_bytes"] / 1e9), "_model_ok": None, "_corpus_ok": None}
+    path = os.path.join(tmp, "yttm_bench_%s_%d.txt" % (name, os.getpid()))
+    model = path + ".model"
+    t0 = time.time()
+    chunks = gen._zipf_chunks(8_000_000_000, seed=7, vocab=400000) if name == "c3_8gb" else gen.heavy_word_chunks(4_400_000_000)
+    nbytes, md5 = gen.stream_to_file(path, chunks)
+    t_gen = time.time() - t0
+    err = C.create_string_buffer(_lib.ERRLEN)
+    rep = C.create_string_buffer(16384)
+    times = []
+    try:
+        with ctx["quiet"]:
+            for _ in range(2):  # (the file is in the page cache: it was just written)
+                t0 = time.perf_counter()
+                rc = L.yttm_train_bpe_comm(path.encode(), model.encode(), args.vocab, 1.0, 8, 0, 1, 2, 3, ctx["local_rank"], 1, None, rep, 16384, err, _lib.ERRLEN)
+                times.append(time.perf_counter() - t0)
+                if rc != 0:
+                    return {"error": err.value.decode(), "corpus_bytes": nbytes, "_model_ok": False, "_corpus_ok": md5 == pin["corpus_md5"]}
+        r = json.loads(rep.value.decode())
+        best = min(times)
+        return {"metric": "bpe_train_throughput", "value": round(nbytes / 1e6 / best, 2), "unit": "MB/s", "seconds": round(best, 4), "all_seconds": [round(t, 4) for t in times],
+                "corpus": pin["corpus"], "corpus_bytes": nbytes, "corpus_generation_seconds": round(t_gen, 1), "unique_words": r["n_unique"], "dedup_tokens": r["n_tokens"],
+                "merge_rounds": r["rounds"], "rules": r["rules"],
+                "phases_s": {"upload": r["seconds_upload"], "frontend": r["seconds_frontend"], "merge_loop": r["seconds_merge"], "dump": r["seconds_io"]},
+                "kernels_ms": {k: round(v["ms"], 3) for k, v in r["kernels"].items() if v["launches"]},
+                "input": "file in the page cache -> yttm_train_bpe_comm(path, model), best of 2", "model_md5": md5_file(model), "pinned_model_md5": pin["model_md5"],
+                "reference_seconds_build_container": pin.get("reference_train_seconds_build_container"),
+                "_model_ok": md5_file(model) == pin["model_md5"], "_corpus_ok": md5 == pin["corpus_md5"]}
+    finally:
+        for f in (path, model):
+            if os.path.exists(f):
+                os.remove(f)
 
 
 def _static_traffic(kern, corpus, size_mb, args, world):

@@ -54,10 +54,8 @@ def zipf_corpus(nbytes, seed=7, vocab=20000, line_words=16, exponent=1.05):
     return b"\n".join(lines) + b"\n"
 
 
-def zipf_corpus_fast(nbytes, seed=7, vocab=400000, line_words=16, exponent=1.05, chunk_words=4_000_000):
-    """C3 (BASELINE.json configs[2]): the same Zipfian lexicon text as zipf_corpus, generated with array operations in fixed
-    chunks of `chunk_words` words so that 1 GB takes seconds, not minutes (bench.py --corpus zipf and the full-size pins
-    of tests/golden/full_size_pins.json use THIS stream; its bytes differ from zipf_corpus's because the draws are chunked)."""
+def _zipf_chunks(nbytes, seed=7, vocab=400000, line_words=16, exponent=1.05, chunk_words=4_000_000):
+    """The byte chunks of zipf_corpus_fast, in order (the stream is defined chunk by chunk: the draws are chunked)."""
     rng = np.random.default_rng(seed)
     letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", dtype=np.uint8)
     p = np.array([12.7, 9.1, 8.2, 7.5, 7.0, 6.7, 6.3, 6.1, 6.0, 4.3, 4.0, 2.8, 2.8, 2.4, 2.4, 2.2, 2.0, 2.0, 1.9,
@@ -74,7 +72,6 @@ def zipf_corpus_fast(nbytes, seed=7, vocab=400000, line_words=16, exponent=1.05,
     nwords = max(1, int(nbytes / avg))
     nwords -= nwords % line_words  # whole lines
     nwords = max(line_words, nwords)
-    parts = []
     col = np.arange(21, dtype=np.int64)
     for w0 in range(0, nwords, chunk_words):
         n = min(chunk_words, nwords - w0)
@@ -87,8 +84,44 @@ def zipf_corpus_fast(nbytes, seed=7, vocab=400000, line_words=16, exponent=1.05,
         sep = np.where((np.arange(w0, w0 + n) % line_words) == line_words - 1, 10, 32).astype(np.uint8)
         mat[np.arange(n), l] = sep
         keep = col[None, :] <= l[:, None]
-        parts.append(mat[keep].tobytes())
-    return b"".join(parts)
+        yield mat[keep].tobytes()
+
+
+def zipf_corpus_fast(nbytes, seed=7, vocab=400000, line_words=16, exponent=1.05, chunk_words=4_000_000):
+    """C3 (BASELINE.json configs[2]): the same Zipfian lexicon text as zipf_corpus, generated with array operations in fixed
+    chunks of `chunk_words` words so that 1 GB takes seconds, not minutes (bench.py --corpus zipf and the full-size pins
+    of tests/golden/full_size_pins.json use THIS stream; its bytes differ from zipf_corpus's because the draws are chunked)."""
+    return b"".join(_zipf_chunks(nbytes, seed, vocab, line_words, exponent, chunk_words))
+
+
+def stream_to_file(path, chunks):
+    """Writes an iterable of byte chunks to `path`; returns (bytes written, md5 of the file) -- corpora beyond host-memory comfort."""
+    import hashlib
+    h = hashlib.md5()
+    n = 0
+    with open(path, "wb") as f:
+        for c in chunks:
+            f.write(c)
+            h.update(c)
+            n += len(c)
+    return n, h.hexdigest()
+
+
+def zipf_corpus_fast_to_file(path, nbytes, **kw):
+    """zipf_corpus_fast(nbytes, ...) written straight to a file (the 8 GB corpus of the > 4 GiB pin: never whole in host memory)."""
+    return stream_to_file(path, _zipf_chunks(nbytes, **kw))
+
+
+def heavy_word_chunks(reps, seed=3):
+    """A corpus in which ONE word occurs more than 2^32 times (the reference counts word frequencies in uint64, bpe.cpp:382-385): two
+    megabytes of Zipf text, then `reps` times "a " (a line break every 2^20 words)."""
+    yield zipf_corpus_fast(2_000_000, seed=seed, vocab=5000)
+    blk = b"a " * ((1 << 20) - 1) + b"a\n"
+    full, rest = divmod(reps, 1 << 20)
+    for _ in range(full):
+        yield blk
+    if rest:
+        yield b"a " * (rest - 1) + b"a\n"
 
 
 def cjk_corpus_fast(nbytes, seed=11, n_chars=4096, lexicon=300000, chunk_words=4_000_000):

@@ -10,6 +10,9 @@ reference (oracle/_ref/yttm_ref_det = bpe.cpp with -DDETERMINISTIC_QUEUE, n_thre
   c4_10m    configs[3]: 10 M sentences of 128 chars (gen_abcd stream, seed 123) encoded with the c2_1gb model -> FNV-1a-64
             of (length, ids...) per sentence over all 10 M, and over the first 1 M
 
+  c3_8gb         the C3 stream at 8 GB (more than 2^32 bytes)
+  c8_heavy_word  a corpus in which one word occurs 4.4e9 times (more than 2^32)
+
 bench.py regenerates the same corpora from the same seeds on the GPU box, compares the md5 of what it generated and of
 what the GPU produced with these pins, prints the verdict in its JSON line and exits non-zero on a mismatch.
 Run in the build container (needs /root/reference for oracle/_ref): python tests/golden/make_full_pins.py [name ...]"""
@@ -75,6 +78,24 @@ def main():
             continue
         text = make()
         pins[name], _ = train_pin(name, text, desc, d)
+        print(name, pins[name], flush=True)
+        json.dump(pins, open(OUT, "w"), indent=1)
+    # Beyond 2^32: a corpus of more than 4 GiB (every byte offset, segment number and token index past 32 bits) and a word that occurs
+    # more than 2^32 times (the reference counts word frequencies in uint64, bpe.cpp:382-385).  Streamed to a file, never whole in
+    # host memory here; the reference itself reads the file into one std::string (bpe.cpp:67-84).
+    for name, chunks, desc in (("c3_8gb", lambda: gen._zipf_chunks(8_000_000_000, seed=7, vocab=400000), "tests/gen.py zipf_corpus_fast_to_file(8e9, seed=7, vocab=400000): the C3 stream, 8 GB"),
+                               ("c8_heavy_word", lambda: gen.heavy_word_chunks(4_400_000_000), "tests/gen.py heavy_word_chunks(4 400 000 000): 2 MB of Zipf text, then the word 'a' 4.4e9 times")):
+        if name not in want:
+            continue
+        corpus = os.path.join(d, name + ".txt")
+        nbytes, md5 = gen.stream_to_file(corpus, chunks())
+        model = os.path.join(d, name + ".model")
+        t0 = time.time()
+        refbin.train(corpus, model, 32000, n_threads=8, kind="det")
+        dt = time.time() - t0
+        os.remove(corpus)
+        pins[name] = {"corpus": desc, "corpus_bytes": nbytes, "corpus_md5": md5, "vocab_size": 32000, "model_md5": md5f(model),
+                      "model_bytes": os.path.getsize(model), "reference": REF, "reference_train_seconds_build_container": round(dt, 1)}
         print(name, pins[name], flush=True)
         json.dump(pins, open(OUT, "w"), indent=1)
     if not want or "c4_10m" in want:

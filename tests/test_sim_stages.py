@@ -218,6 +218,23 @@ def test_list_overflow_in_a_fused_round(tmp_path, monkeypatch):
     assert fused > 0 and seen > 0, "no configuration overflowed the top list during a fused round: the test does not test what it says"
 
 
+def test_words_seen_more_often_than_a_weight_holds(tmp_path, monkeypatch):
+    """The reference counts word frequencies in uint64 (bpe.cpp:382-385); the tiles keep uint32 weights.  A word seen more often than a
+    weight holds becomes several equal words whose weights add up to its count (every pair count is a sum over words).  At full scale
+    that takes a word seen 2^32 times (tests/golden/full_size_pins.json c8_heavy_word, checked on the MI355X); here the largest weight is
+    lowered to a few dozen, so that many words of ordinary corpora are split into many copies -- short, long (class B) and very long
+    (class C) ones: same models as the oracle."""
+    rng = random.Random(5)
+    long_b = "".join(rng.choice("abc") for _ in range(700))
+    long_c = "".join(rng.choice("ab") for _ in range(2500))
+    rare = " ".join("".join(rng.choice("abcd") for _ in range(rng.randint(3, 9))) for _ in range(400))
+    heavy = ["ab", "abab", "ba", "aab", "dcba", "cab", long_b, long_c]
+    for wmax, reps in (("3", 11), ("1", 4), ("37", 120), ("1000", 1001)):  # (up to a few hundred copies in all: the list of such words is short by design)
+        monkeypatch.setenv("YTTM_TEST_WCNT_MAX", wmax)
+        text = (" ".join(heavy[:6] * reps + heavy[6:] * min(reps, 11)) + " " + rare + "\n").encode()
+        S.check_train_vs_oracle(text, 120, tmp_path, tag="heavy" + wmax)
+
+
 def test_very_long_words(tmp_path):
     S.check_very_long_words(tmp_path)
 

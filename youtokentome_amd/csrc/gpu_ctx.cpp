@@ -175,6 +175,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   words_inline_max_ = env_uint("YTTM_WORDS_INLINE_MAX", 1u << 18);  // (measured at 1 GB, K4 ms: 16 k -> 97.2, 64 k -> 95.4, 256 k -> 94.1)
   profile_events_ = env_uint("YTTM_PROFILE_EVENTS", 0) != 0;
   words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end)
+  direct_enabled_ = env_uint("YTTM_K4_DIRECT", 1) != 0;  // (0: the pair filter + rule hash from the first round on; A/B runs)
   word_div_ = env_uint("YTTM_WORD_DIV", 200);  // (measured at 1 GB: 96 -> K4 135 ms, 150 -> 107, 200 -> 103.7, 300 -> 103.7, 500 -> 104)
   word_min_tiles_ = env_uint("YTTM_WORD_MIN_TILES", 16384);  // (tests: 0 = switch as soon as the hot list is active)
   // a pass over the tiles must cost more than word mode's three launches: 1 GB enwik-like text (25 M tokens, 48 us per dense round) got 15 % slower
@@ -655,23 +656,64 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   if (h_status[3] > 0 && h_status[3] < (unsigned int)TILE_NOM_A) cls_[0].nom = (unsigned int)TILE_SLOT_A - h_status[3];
   n_unique = U;
   if (U == 0) { DFREE(ht); return; }
-  unsigned long long *posA = dmalloc<unsigned long long>(UA), *posB = dmalloc<unsigned long long>(UB), *posC = dmalloc<unsigned long long>(UC);
-  uint32_t *lenA = dmalloc<uint32_t>(UA), *lenB = dmalloc<uint32_t>(UB), *lenC = dmalloc<uint32_t>(UC);
-  cls_[2].d_wcnt = dmalloc<uint32_t>(UC + 256);
-  cls_[0].d_wcnt = dmalloc<uint32_t>(UA + 256);  // padding: k_tiles loads SLOT/2 frequencies from a tile's first word unconditionally
-  cls_[1].d_wcnt = dmalloc<uint32_t>(UB + 256);
+  // (room for the extra copies of words seen more than 2^32 - 1 times: k2c_compact_words)
+  constexpr unsigned int HX = 4 * HEAVY_CAP;
+  unsigned long long *posA = dmalloc<unsigned long long>(UA + HX), *posB = dmalloc<unsigned long long>(UB + HX), *posC = dmalloc<unsigned long long>(UC + HX);
+  uint32_t *lenA = dmalloc<uint32_t>(UA + HX), *lenB = dmalloc<uint32_t>(UB + HX), *lenC = dmalloc<uint32_t>(UC + HX);
+  cls_[2].d_wcnt = dmalloc<uint32_t>(UC + HX + 256);
+  cls_[0].d_wcnt = dmalloc<uint32_t>(UA + HX + 256);  // padding: k_tiles loads SLOT/2 frequencies from a tile's first word unconditionally
+  cls_[1].d_wcnt = dmalloc<uint32_t>(UB + HX + 256);
   unsigned int *d_cursor = (unsigned int *)(d_counters_ + 32);
   HIP_CHECK(hipMemsetAsync(d_cursor, 0, 16, st_));
+  unsigned long long *d_heavy = dmalloc<unsigned long long>(3 * HEAVY_CAP);
+  const unsigned long long wmax = getenv("YTTM_TEST_WCNT_MAX") ? strtoull(getenv("YTTM_TEST_WCNT_MAX"), nullptr, 10) : 0xffffffffull;  // (tests: heavy words at toy sizes)
   t_begin(KT_BUILD);
   launch_compact_words(d_text_, n_text_, d_cpmap_, ht, ht_cap, posA, cls_[0].d_wcnt, lenA, posB, cls_[1].d_wcnt, lenB, posC, cls_[2].d_wcnt, lenC, d_cursor,
-                       d_status, st_);
+                       d_status, wmax, d_heavy, st_);
+  unsigned int h_cursor[4] = {0, 0, 0, 0};
   HIP_CHECK(hipMemcpyAsync(h_status, d_status, 16, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(h_cursor, d_cursor, 16, hipMemcpyDeviceToHost, st_));
   sync();
   DFREE(ht);
-  if (h_status[1] & 2u) { DFREE(posA); DFREE(posB); DFREE(lenA); DFREE(lenB); DFREE(posC); DFREE(lenC); throw GpuError{"a word occurs >= 2^32 times (uint32 word weights)"}; }
-  build_class(0, posA, lenA, UA, space_id);
-  build_class(1, posB, lenB, UB, space_id);
-  build_class(2, posC, lenC, UC, space_id);
+  unsigned int UA2 = UA, UB2 = UB, UC2 = UC;
+  if (h_cursor[3] && !(h_status[1] & 2u)) {
+    // words seen more than wmax times (the reference counts in uint64, bpe.cpp:382-385): more copies of the word until the weights add up
+    // to its count -- every pair count is a sum over words, so the merge loop computes what it would with one word of the whole weight
+    std::vector<unsigned long long> hv(3 * (size_t)h_cursor[3]);
+    HIP_CHECK(hipMemcpy(hv.data(), d_heavy, hv.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> xp[3];
+    std::vector<uint32_t> xl[3], xc[3];
+    bool too_many = false;
+    for (unsigned int i = 0; i < h_cursor[3]; i++) {
+      const uint32_t len = (uint32_t)hv[3 * i + 1];
+      const int ci = len > (uint32_t)TILE_NOM_B ? 2 : len > (uint32_t)TILE_NOM_A ? 1 : 0;
+      for (unsigned long long left = hv[3 * i + 2]; left;) {
+        const unsigned long long c = std::min(left, wmax);
+        xp[ci].push_back(hv[3 * i]); xl[ci].push_back(len); xc[ci].push_back((uint32_t)c);
+        left -= c;
+        if (xp[ci].size() > HX) { too_many = true; break; }
+      }
+    }
+    if (too_many) h_status[1] |= 2u;
+    else {
+      unsigned long long *pos[3] = {posA, posB, posC};
+      uint32_t *len[3] = {lenA, lenB, lenC};
+      unsigned int *U2[3] = {&UA2, &UB2, &UC2};
+      for (int ci = 0; ci < 3; ci++) {
+        if (xp[ci].empty()) continue;
+        HIP_CHECK(hipMemcpy(pos[ci] + *U2[ci], xp[ci].data(), xp[ci].size() * 8, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(len[ci] + *U2[ci], xl[ci].data(), xl[ci].size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(cls_[ci].d_wcnt + *U2[ci], xc[ci].data(), xc[ci].size() * 4, hipMemcpyHostToDevice));
+        *U2[ci] += (unsigned int)xp[ci].size();
+      }
+      n_unique = (unsigned long long)UA2 + UB2 + UC2;
+    }
+  }
+  DFREE(d_heavy);
+  if (h_status[1] & 2u) { DFREE(posA); DFREE(posB); DFREE(lenA); DFREE(lenB); DFREE(posC); DFREE(lenC); throw GpuError{"too many words seen 2^32 times or more"}; }
+  build_class(0, posA, lenA, UA2, space_id);
+  build_class(1, posB, lenB, UB2, space_id);
+  build_class(2, posC, lenC, UC2, space_id);
   if (cls_[2].n_tiles) cls_[2].d_scratch = dmalloc<uint32_t>((size_t)cls_[2].n_tiles * 4 * cls_[2].slot);
   t_end(KT_BUILD, n_text_ / 8 + 4 * (cls_[0].n_tokens0 + cls_[1].n_tokens0 + cls_[2].n_tokens0) + 16ull * U);
   sync();
@@ -1634,11 +1676,11 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   }
   BatchArgs ba{};
   ba.instr = instrument ? 1u : 0u;
-  ba.bloom = 1u;
+  const uint32_t max_in = max_id_;  // largest id a tile can hold BEFORE this round (the ids the site search looks up)
   max_id_ = std::max(max_id_, vmax);
   if (by_args) {
     ba.k = k;
-    ba.small_ids = max_id_ < FLAG_LDS_IDS ? 1u : 0u;
+    ba.direct_v = direct_enabled_ && max_in + 1 <= DIRECT_MAX_V ? max_in + 1 : 0u;  // (the first rounds of a small alphabet: k_tiles<.., DIRECT>)
     for (uint32_t j = 0; j < k; j++) { ba.xy[2 * j] = xyz[3 * j]; ba.xy[2 * j + 1] = xyz[3 * j + 1]; }
   }
   // One launch per round: the candidate scan rides in the tail of the round's last kernel -- single GPU: the apply kernel of class A (class

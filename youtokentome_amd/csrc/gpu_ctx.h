@@ -202,7 +202,7 @@ class GpuCtx {
   // word mode (k_merge.hip: k_words): class-A words processed one by one from a worklist of the words that hold a merge site
   bool profile_events_ = false, dev_timing_pending_ = false;  // (merge_apply: dev_timing)
   std::vector<float> dev_round_ms_;
-  bool word_mode_ = false, words_enabled_ = true;
+  bool word_mode_ = false, words_enabled_ = true, direct_enabled_ = true;
   // The DECISION that class A runs in word mode.  Single GPU: word_mode_ itself.  Multi-GPU: taken from numbers summed over the ranks'
   // block headers (the same on every rank, in the same round) -- everything that shapes the candidate lists or the batches (the hot
   // list's target, the batch split) follows this flag, never the rank-local word_mode_ (a rank without class-A words stays on tiles).
@@ -256,7 +256,6 @@ class GpuCtx {
   const DeltaRec *xch_last_ = nullptr;                           // the block of the exchange under way (a repeat gathers it again)
   void finish_block(unsigned int n_hint);
   unsigned long long recv_cap_ = 0, blk_ = 4096, blk_min_ = 4096, send_cap_ = 0;
-  unsigned int last_pack_hint_ = 1u << 16;
   void alloc_delta_table(unsigned long long cap);
   bool delta_cap_forced_ = false;  // YTTM_XCHG_TABLE_CAP (tests: the overflow verdict)
   bool pt_fresh_ = false;  // build_class(0) left an empty pair table of the initial size

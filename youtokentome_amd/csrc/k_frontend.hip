@@ -501,8 +501,9 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const uint8_t *__rest
                                                            uint32_t *__restrict__ lenA, unsigned long long *__restrict__ posB,
                                                            uint32_t *__restrict__ cntB, uint32_t *__restrict__ lenB,
                                                            unsigned long long *__restrict__ posC, uint32_t *__restrict__ cntC,
-                                                           uint32_t *__restrict__ lenC, unsigned int *__restrict__ cursor /* [0]=A [1]=B [2]=C */,
-                                                           unsigned int *__restrict__ status) {
+                                                           uint32_t *__restrict__ lenC, unsigned int *__restrict__ cursor /* [0]=A [1]=B [2]=C [3]=heavy */,
+                                                           unsigned int *__restrict__ status, unsigned long long wmax,
+                                                           unsigned long long *__restrict__ heavy /* [HEAVY_CAP][3]: pos, len, count still to place */) {
   // A workgroup takes CH consecutive slots, counts its class-A words, reserves their places with ONE atomic (a
   // cursor bumped once per 256 slots serialised at ~11 ns per atomic: 12 ms) and writes them in a second pass over the same,
   // now cached, slots.  The table is sized by an estimate of the number of distinct words, not by the number of occurrences.
@@ -535,15 +536,29 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const uint8_t *__rest
         unsigned long long hh;
         len = seg_scan(text, n, cpmap, k & WH_POS_MASK, &hh) + 1u;
       }
-      if (c > 0xffffffffull) atomicOr(&status[1], 2u);  // a word seen >= 2^32 times: weights are uint32
+      // Word weights are uint32 in the tiles; the reference counts in uint64 (bpe.cpp:382-385).  A word seen more than `wmax` (2^32 - 1)
+      // times is kept as SEVERAL equal words whose weights add up to its count -- every pair count is a sum over words, so nothing the
+      // merge loop computes can tell: the first copy takes wmax here, what is left goes to a short list the host turns into more copies.
+      uint32_t c32 = (uint32_t)c;
+      if (c > wmax) {
+        c32 = (uint32_t)wmax;
+        const unsigned int o = atomicAdd(&cursor[3], 1u);
+        if (o < (unsigned int)HEAVY_CAP) {
+          heavy[3 * o] = k & WH_POS_MASK;
+          heavy[3 * o + 1] = len;
+          heavy[3 * o + 2] = c - wmax;
+        } else {
+          atomicOr(&status[1], 2u);  // (more such words than a corpus that fits HBM can hold)
+        }
+      }
       if (len > (uint32_t)TILE_NOM_B) {
         const unsigned int o = atomicAdd(&cursor[2], 1u);
-        posC[o] = k & WH_POS_MASK; cntC[o] = (uint32_t)c; lenC[o] = len;
+        posC[o] = k & WH_POS_MASK; cntC[o] = c32; lenC[o] = len;
       } else if (len > (uint32_t)TILE_NOM_A) {
         const unsigned int o = atomicAdd(&cursor[1], 1u);
-        posB[o] = k & WH_POS_MASK; cntB[o] = (uint32_t)c; lenB[o] = len;
+        posB[o] = k & WH_POS_MASK; cntB[o] = c32; lenB[o] = len;
       } else {
-        posA[o_a] = k & WH_POS_MASK; cntA[o_a] = (uint32_t)c; lenA[o_a] = len;
+        posA[o_a] = k & WH_POS_MASK; cntA[o_a] = c32; lenA[o_a] = len;
         o_a++;
       }
     }
@@ -773,10 +788,11 @@ void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32
 }
 void launch_compact_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *ht, unsigned long long n_slots,
                           unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB, uint32_t *cntB, uint32_t *lenB,
-                          unsigned long long *posC, uint32_t *cntC, uint32_t *lenC, unsigned int *cursor, unsigned int *status, hipStream_t st) {
+                          unsigned long long *posC, uint32_t *cntC, uint32_t *lenC, unsigned int *cursor, unsigned int *status, unsigned long long wmax,
+                          unsigned long long *heavy, hipStream_t st) {
   unsigned int g = grid_for(n_slots, BLOCK, 256 * 16);
   hipLaunchKernelGGL(k2c_compact_words, dim3(g), dim3(BLOCK), 0, st, text, n, cpmap, ht, n_slots, posA, cntA, lenA, posB, cntB, lenB, posC, cntC, lenC,
-                     cursor, status);
+                     cursor, status, wmax, heavy);
 }
 void launch_exclusive_scan(const uint32_t *in, unsigned long long n, unsigned long long *out, unsigned long long *block_sums,
                            unsigned long long *total_out, hipStream_t st) {

@@ -291,17 +291,80 @@ __device__ inline bool reg_bloom_test(const uint4 (&r)[SLOT / 256], int n, const
 // such a site nor an x x of the self rule (nothing to do: the x/y flags are per token, and late in training two thirds of
 // the tiles with a flagged adjacency hold no merge site), else 1, plus 2 if the self rule may have sites (those need the
 // run they sit in and are found from LDS once the tile is staged).
-template <int SLOT, bool LDSR>
-__device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds,
-                                     const uint8_t *__restrict__ tokflag, uint32_t self_x, const RuleTab<LDSR> &rtab,
+template <int SLOT, bool LDSR, bool DIRECT = false>
+__device__ inline int reg_find_sites(WaveLds<SLOT> &W, const uint4 (&r)[SLOT / 256], int n, const uint32_t *flagbits_lds /* the batch's pair filter; DIRECT: the pair -> rule table */,
+                                     uint32_t self_x, const RuleTab<LDSR> &rtab,
                                      uint32_t &my_cnt /* sites found by this lane */, uint32_t &my_site /* the last one: position << 16 | rule index */,
-                                     bool small_ids, bool use_bloom /* flagbits_lds holds the batch's pair filter, not token flags */) {
+                                     uint32_t direct_v = 0) {
   const int lane = lane_id();
   my_cnt = 0;
   my_site = 0;
   typedef typename std::conditional<(SLOT / 64 > 32), unsigned long long, uint32_t>::type bits_t;
   bits_t hb = 0;  // bit 4 j + i: the adjacency that starts at my token i of row j may be a rule of the batch
-  (void)tokflag; (void)small_ids; (void)use_bloom;  // (the per-token flag test this replaced is gone; measured at 1 GB: K4 123.3 -> 116.5 ms)
+  if constexpr (DIRECT) {
+    // Small alphabets' first rounds -- every tile holds dozens of sites, every one of the lane's eight adjacencies is some lane's candidate:
+    // the pair filter only adds its cost to the hash probes.  While all ids are below direct_v the pair itself indexes a byte table in LDS
+    // (rule number, 0xff: none): one ds_read_u8 per adjacency.  (Slots behind the tile's end hold id 0, a special token: never in a rule.)
+    const uint8_t *tab = reinterpret_cast<const uint8_t *>(flagbits_lds);
+    static_assert(SLOT / 64 <= 8, "rule numbers of a lane's adjacencies: two words");
+    uint32_t ri_lo = 0xffffffffu, ri_hi = 0xffffffffu;  // byte 4 j + i: rule of the adjacency that starts at my token i of row j
+    bool selfp = false;
+    const bool has_self = self_x != 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < SLOT / 256; j++) {
+      if (256 * j < n) {
+        uint32_t nx = from_lane_right(r[j].x);
+        uint32_t nx0 = TOK_WS;
+        if (j + 1 < SLOT / 256) nx0 = from_lane0(r[j + 1 < SLOT / 256 ? j + 1 : j].x);
+        if (lane == 63) nx = nx0;
+        const uint32_t a0 = r[j].x & L_ID, a1 = r[j].y & L_ID, a2 = r[j].z & L_ID, a3 = r[j].w & L_ID, a4 = nx & L_ID;
+        const uint32_t q0 = (r[j].y >> 31) ? 0xffu : (uint32_t)tab[a0 * direct_v + a1], q1 = (r[j].z >> 31) ? 0xffu : (uint32_t)tab[a1 * direct_v + a2];
+        const uint32_t q2 = (r[j].w >> 31) ? 0xffu : (uint32_t)tab[a2 * direct_v + a3], q3 = (nx >> 31) ? 0xffu : (uint32_t)tab[a3 * direct_v + a4];
+        const uint32_t packed = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+        if (j == 0) ri_lo = packed; else ri_hi = packed;
+        if (has_self)
+          selfp = selfp || (a0 == self_x && a1 == self_x && !(r[j].y >> 31)) || (a1 == self_x && a2 == self_x && !(r[j].z >> 31)) ||
+                  (a2 == self_x && a3 == self_x && !(r[j].w >> 31)) || (a3 == self_x && a4 == self_x && !(nx >> 31));
+      }
+    }
+    // bit s of my_bits: byte s is a rule number (its top bit is clear: rule numbers are below 128)
+    const uint32_t nl = ~ri_lo & 0x80808080u, nh = ~ri_hi & 0x80808080u;
+    const bool found = (nl | nh) != 0u;
+    if (__ballot(found || selfp) == 0) return 0;
+    if (lane < SLOT / 64) W.sitemask[lane] = 0ull;
+    if (lane == 0) {
+      W.sctl[0] = 0u;
+      W.sctl[1] = 0xffffffffu;
+    }
+    wave_sync();
+    uint32_t *sm32 = reinterpret_cast<uint32_t *>(W.sitemask);
+    if (found) {
+      uint32_t my_bits = 0, my_ri = 0;
+#pragma unroll
+      for (int s = 0; s < 4 * (SLOT / 256); s++) {
+        const uint32_t ri = ((s < 4 ? ri_lo : ri_hi) >> (8 * (s & 3))) & 0xffu;
+        if (ri != 0xffu) {
+          W.ridx[256 * (s >> 2) + 4 * lane + (s & 3)] = (uint16_t)ri;
+          my_bits |= 1u << s;
+          my_ri = ri;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < SLOT / 256; j++) {
+        const uint32_t nib = (my_bits >> (4 * j)) & 15u;
+        if (nib) atomicOr(&sm32[(256 * j + 4 * lane) >> 5], nib << ((4 * lane) & 31));
+      }
+      const int s_first = __ffs((int)my_bits) - 1, s_last = 31 - __clz((int)my_bits);
+      const uint32_t p_first = (uint32_t)(256 * (s_first >> 2) + 4 * lane + (s_first & 3));
+      my_cnt = (uint32_t)__popc(my_bits);
+      my_site = ((uint32_t)(256 * (s_last >> 2) + 4 * lane + (s_last & 3)) << 16) | my_ri;
+      const unsigned int idx = atomicAdd(&W.sctl[0], my_cnt | (my_cnt > 1 ? 0x10000u : 0u)) & 0xffffu;
+      if (my_cnt == 1 && idx < 64u) W.sitepos[idx] = (uint16_t)p_first;
+      atomicMin(&W.sctl[1], p_first);
+    }
+    wave_sync();
+    return (__ballot(found) ? 1 : 0) | (__ballot(selfp) ? 3 : 0);
+  }
   const bool cand = reg_bloom_test<SLOT, bits_t>(r, n, flagbits_lds, self_x, hb);
   if (__ballot(cand) == 0) return 0;
   if (lane < SLOT / 64) W.sitemask[lane] = 0ull;
@@ -822,7 +885,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
 }
 
 
-template <int SLOT, int WPB, bool MERGE, bool LDSR>
+template <int SLOT, int WPB, bool MERGE, bool LDSR, bool DIRECT = false>
 __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WPB) : WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
@@ -841,14 +904,19 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
   const bool from_args = MERGE && LDSR && ba.k != 0;  // tables built from the kernel argument, nothing read from HBM
   agg_init<WPB * 64>(A, (MERGE && !from_args) ? flagbits : nullptr);
   if (from_args) {
-    for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += WPB * 64) A.flagbits[s] = 0;
+    // (A.flagbits: the batch's pair filter, or -- DIRECT -- the pair -> rule table: direct_v * direct_v bytes, 0xff = no rule)
+    for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += WPB * 64) A.flagbits[s] = DIRECT ? 0xffffffffu : 0u;
     for (unsigned int i = threadIdx.x; i <= rule_mask; i += WPB * 64) rkeys[i] = PT_EMPTY;
     __syncthreads();
     for (unsigned int j = threadIdx.x; j < ba.k; j += WPB * 64) {  // (class B: one wave per workgroup)
       const uint32_t x = ba.xy[2 * j], y = ba.xy[2 * j + 1];
       if (x != y) {
-        const uint32_t bh = pm_hash(x, y);  // (A.flagbits holds the batch's pair filter)
-        atomicOr(&A.flagbits[pm_word(bh)], pm_bits(bh));
+        if (DIRECT) {
+          reinterpret_cast<uint8_t *>(A.flagbits)[x * ba.direct_v + y] = (uint8_t)j;
+        } else {
+          const uint32_t bh = pm_hash(x, y);  // (A.flagbits holds the batch's pair filter)
+          atomicOr(&A.flagbits[pm_word(bh)], pm_bits(bh));
+        }
         const unsigned long long key = pair_key(x, y);
         unsigned int h = pair_hash32(key) & rule_mask;
         for (;;) {
@@ -931,7 +999,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
   auto stage_part = [&](int n0, uint32_t tile, uint32_t w0) {
     // K4: a tile without a merge site is dismissed in registers and never touches LDS
     uint32_t my_cnt = 0, my_site = 0;
-    site_state = MERGE ? reg_find_sites<SLOT, LDSR>(W, r, n0, A.flagbits, tokflag, self_x, rtab, my_cnt, my_site, ba.small_ids != 0, ba.bloom != 0) : 1;
+    site_state = MERGE ? reg_find_sites<SLOT, LDSR, DIRECT>(W, r, n0, A.flagbits, self_x, rtab, my_cnt, my_site, ba.direct_v) : 1;
     if (MERGE) K4_MARK(0);
     bool dirty = site_state != 0;
     if (MERGE && SLOT == TILE_SLOT_A && site_state == 1 && !ba.instr) {  // sites of x != y rules only: is it a single one?
@@ -2338,7 +2406,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
       WReg<SLOT> wq{};
       wq.v[0] = (uint32_t)__shfl((int)wfreq, (first + lane) & 63);  // lane i: frequency of word i of the tile
       uint32_t my_cnt = 0, my_site = 0;
-      const int site_state = reg_find_sites<SLOT, LDSR>(W, r, n, A.flagbits, nullptr, self_x, rtab, my_cnt, my_site, false, true);
+      const int site_state = reg_find_sites<SLOT, LDSR>(W, r, n, A.flagbits, self_x, rtab, my_cnt, my_site);
       S.scanned += (unsigned long long)n;
       K4_MARK(0);
       if (site_state) {
@@ -2923,7 +2991,10 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
   const uint32_t *no_list = nullptr;
   const unsigned int *no_n = nullptr;
   if (cls == 0) {
-    if (rule_mask < APPLY_LDS_RULES)
+    if (bargs.k && bargs.direct_v && rule_mask < APPLY_LDS_RULES)
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, true, true>), dim3(grid_a), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
+                         no_flags, bloom_g, self_x, self_z, z_base, no_list, no_n, stats, bargs, sargs);
+    else if (rule_mask < APPLY_LDS_RULES)
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, true>), dim3(grid_a), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
                          no_flags, bloom_g, self_x, self_z, z_base, no_list, no_n, stats, bargs, sargs);
     else

@@ -36,7 +36,11 @@ void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32
                          unsigned long long n_segs, unsigned long long *ht, unsigned long long ht_mask, unsigned int *status, hipStream_t st);
 void launch_compact_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *ht, unsigned long long n_slots,
                           unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB, uint32_t *cntB, uint32_t *lenB,
-                          unsigned long long *posC, uint32_t *cntC, uint32_t *lenC, unsigned int *cursor, unsigned int *status, hipStream_t st);
+                          unsigned long long *posC, uint32_t *cntC, uint32_t *lenC, unsigned int *cursor, unsigned int *status,
+                          unsigned long long wmax /* largest weight a word may carry (2^32 - 1; tests: less) */,
+                          unsigned long long *heavy /* [HEAVY_CAP][3] words seen more often than that: pos, tokens, count still to place; their number in cursor[3] */,
+                          hipStream_t st);
+constexpr int HEAVY_CAP = 256;  // (a word of two bytes seen 2^32 times is 8.6 GB of text: HBM holds a few dozen such words at most -- and tests lower wmax)
 void launch_exclusive_scan(const uint32_t *in, unsigned long long n, unsigned long long *out, unsigned long long *block_sums,
                            unsigned long long *total_out, hipStream_t st);
 unsigned long long scan_scratch_blocks(unsigned long long n);
@@ -54,13 +58,14 @@ void launch_tile_len(const unsigned long long *tile_start, unsigned int n_tiles,
 // hash) from it, and the round needs no prologue kernel, no rule upload and no flag table in HBM.  Used when the whole round
 // runs without the filter pass (small or dense tile sets), all ids fit the LDS flag bitmap and there is no class-C tile.
 constexpr int BATCH_ARGS_MAX = 128;  // (1 KB of kernel arguments; 32 until round 3: the late rounds of random text have batches of 30 .. 100 rules)
-constexpr uint32_t FLAG_LDS_IDS = 32768;  // batch flags of ids below this live in an LDS bitmap (2 bits per id, 8 KB)
+constexpr uint32_t FLAG_LDS_IDS = 32768;  // (8 KB of LDS: the batch's pair filter, or the direct pair -> rule table)
+constexpr uint32_t DIRECT_MAX_V = 90;     // direct table: ids below this (90 * 90 bytes <= 8 KB)
 struct BatchArgs {
   uint32_t k;                        // 0: not used (tables come from HBM)
   uint32_t xy[2 * BATCH_ARGS_MAX];   // rule j of the batch merges (xy[2j], xy[2j+1]) into z_base + j; x == y: the self rule (skipped)
-  uint32_t small_ids;                // every token id in the tiles is < FLAG_LDS_IDS: the kernels skip the test for ids behind the LDS bitmap
-  uint32_t bloom;                    // k_tiles<.., true>: merge-site candidates by the batch's PAIR filter (k_merge_shared.h pm_hash; built in the kernel
-                                     // from xy, or copied from the table `flagbits` then points to) instead of per-token x / y flags
+  uint32_t direct_v;                 // != 0 (class-A k_tiles<.., DIRECT>): every token id in the tiles is < direct_v, and direct_v^2 bytes fit the LDS table
+                                     // that maps a PAIR straight to its rule -- the first rounds of a small alphabet, the most expensive ones: one byte
+                                     // read per adjacency instead of a pair filter and a hash probe
   uint32_t mark;                     // this is the round's first launch: workgroup 0 notes the time in stats[STAT_T0] (the round's duration then
                                      // comes from the device's own clock, ScanArgs::timed -- two hipEventRecord calls per round cost 4 us of host time)
   uint32_t instr;                    // measurement pass (never timed): also count the WORDS that hold a merge site and their tokens
