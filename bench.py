@@ -101,7 +101,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the Zipf (configs[2]) block")
     ap.add_argument("--no-extra2", action="store_true", help="skip the large-alphabet (CJK-shaped) and enwik-like (4e6-word lexicon) training blocks")
-    ap.add_argument("--no-big", action="store_true", help="skip the beyond-2^32 blocks: the 8 GB Zipf corpus and the corpus with a word seen 4.4e9 times (file -> model, pinned)")
+    ap.add_argument("--no-big", action="store_true", help="skip the beyond-2^32 block: the 8.8 GB corpus with a word seen 4.4e9 times (file -> model, pinned)")
+    ap.add_argument("--big-zipf", action="store_true", help="also the 8 GB Zipf corpus (its generation alone takes two minutes: profiles/ holds a run)")
     ap.add_argument("--no-touched-pass", action="store_true", help="skip the untimed K4 measurement pass (profiling runs: one training per process)")
     ap.add_argument("--cpu-sample-mb", type=int, default=0, help="0 = the full corpus")
     ap.add_argument("--cpu-runs", type=int, default=3, help="runs of the reference's train_bpe per corpus (the median is reported)")
@@ -213,7 +214,7 @@ def main():
     # ---- beyond 2^32: more than 4 GiB of text; a word seen more than 2^32 times (file -> model, pinned against the reference) ------------
     if world == 1 and not args.no_big and args.corpus == "abcd" and args.size_mb == 1000:
         out.setdefault("extra", {})
-        for name in ("c3_8gb", "c8_heavy_word"):
+        for name in (("c3_8gb", "c8_heavy_word") if args.big_zipf else ("c8_heavy_word",)):
             b = _bench_big(ctx, name)
             if b is not None:
                 out["extra"][name] = b
