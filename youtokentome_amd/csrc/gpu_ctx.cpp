@@ -625,8 +625,11 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
   unsigned int h_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int attempt = 0;; attempt++) {
-    ht_cap = attempt == 0 && !getenv("YTTM_WORD_TABLE_FULL") ? pow2_at_least(std::max<unsigned long long>(n_segs / 4, 1ull << 16))
-                                                              : pow2_at_least(n_segs + n_segs / 2 + 1024);
+    // (long segments -- CJK-shaped text: clauses of dozens of chars between white space -- are nearly all distinct: the estimate is bound to
+    // fail there and the whole dedup would run twice; K1 knows the average segment length)
+    const bool long_segments = n_text_ / n_segs >= 16;
+    ht_cap = attempt == 0 && !long_segments && !getenv("YTTM_WORD_TABLE_FULL") ? pow2_at_least(std::max<unsigned long long>(n_segs / 4, 1ull << 16))
+                                                                                 : pow2_at_least(n_segs + n_segs / 2 + 1024);
     ht = dmalloc<unsigned long long>(2 * ht_cap);
     launch_word_table_clear(ht, ht_cap, st_);
     HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
@@ -636,7 +639,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
     HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
     sync();
     // (more than half full counts as overflow too: the merge loop's tiles do not care, but probe chains do)
-    if (!h_status[6] && (attempt || (unsigned long long)h_status[0] * 2 <= ht_cap)) break;
+    if (!h_status[6] && (attempt || long_segments || (unsigned long long)h_status[0] * 2 <= ht_cap)) break;
     if (attempt) { DFREE(ht); DFREE(d_seg); throw GpuError{"word table overflow"}; }
     DFREE(ht);
     word_table_retries++;
