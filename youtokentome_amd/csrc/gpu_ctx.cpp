@@ -343,7 +343,7 @@ void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
 // next call (pinning 128 MB costs tens of milliseconds).
 namespace {
 constexpr size_t IO_CHUNK = 8u << 20;
-constexpr int IO_MAX_THREADS = 8;
+constexpr int IO_MAX_THREADS = 32;
 struct IoStage {
   std::mutex mu;
   void *pin[2 * IO_MAX_THREADS] = {nullptr};
@@ -372,7 +372,7 @@ void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *
   if (!n) return;
   const size_t n_chunks = (size_t)((n + IO_CHUNK - 1) / IO_CHUNK);
   int n_threads = (int)env_uint("YTTM_IO_THREADS", 0);
-  if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), (unsigned)IO_MAX_THREADS));
+  if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 8u));  // (default: as many as the reference's trainer uses, bpe.cpp:1348)
   n_threads = (int)std::min<size_t>((size_t)std::min(n_threads, IO_MAX_THREADS), n_chunks);
   bool mine = false;
   {
