@@ -167,7 +167,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   fuse_enabled_ = env_uint("YTTM_NO_FUSE", 0) == 0;
   idx_enabled_ = env_uint("YTTM_NO_INDEX", 0) == 0;  // (no pair index: no word mode either)
   idx_agg_min_ = env_uint("YTTM_INDEX_AGG_MIN", 16u << 20);  // (fill pass of an index build: postings from which on a workgroup sums them per key in LDS first; tests: 0)
-  hot_target_words_ = env_uint("YTTM_HOT_TARGET_WORDS", 1u << 15);  // (measured at 1 GB, word mode: 8192 -> 6 rebuilds, candidate family 21.0 ms; 32768 -> 3, 16.9 ms)
+  hot_target_words_ = env_uint("YTTM_HOT_TARGET_WORDS", 1u << 16);  // (measured at 1 GB, word mode: 8192 -> 6 rebuilds, candidate family 21.0 ms; 32768 -> 3, 16.9 ms; round 4: 32768 -> 3, 14.6 ms; 65536 -> 2, 12.5; 131072 -> 2, 15.0)
   // rounds of at most this many words (by the hint) whose batch travels in the kernel arguments are ONE launch, k_words<FUSED>; 0: never.
   // (1 GB random text, wall / K4 ms: never 138.3 / 86.0, 32 k 136.6 / 83.3, 256 k 133.1 / 80.2, 2 M 125.9 / 73.5, every round 125.0 / 72.5)
   words_fuse_max_ = env_uint("YTTM_WORDS_FUSE_MAX", 1u << 30);
@@ -176,7 +176,8 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   profile_events_ = env_uint("YTTM_PROFILE_EVENTS", 0) != 0;
   words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end)
   direct_enabled_ = env_uint("YTTM_K4_DIRECT", 1) != 0;  // (0: the pair filter + rule hash from the first round on; A/B runs)
-  word_div_ = env_uint("YTTM_WORD_DIV", 200);  // (measured at 1 GB: 96 -> K4 135 ms, 150 -> 107, 200 -> 103.7, 300 -> 103.7, 500 -> 104)
+  word_div_ = env_uint("YTTM_WORD_DIV", 200);  // (measured at 1 GB: 96 -> K4 135 ms, 150 -> 107, 200 -> 103.7, 300 -> 103.7, 500 -> 104; round 4, merge loop ms of random 'abcd ': 80 / 100 -> 98.7 (switch at
+                                               // round 13), 120 -> 96.0 (round 20), 150 -> 96.4, 200 -> 99.4 (round 29), 400 -> 101.6 -- but the CJK-shaped corpus: 120 -> 485 ms, 200 -> 472: left at 200)
   word_min_tiles_ = env_uint("YTTM_WORD_MIN_TILES", 16384);  // (tests: 0 = switch as soon as the hot list is active)
   // a pass over the tiles must cost more than word mode's three launches: 1 GB enwik-like text (25 M tokens, 48 us per dense round) got 15 % slower
   // in word mode, the 1 GB CJK-shaped corpus (337 M tokens) 21 % faster, random 'abcd ' (94 M tokens at the switch) 10 % faster

@@ -212,7 +212,7 @@ class GpuCtx {
   // class A is in word mode, and a batch of at most this many rules is one launch there (k_words<FUSED>): the trainer's batch split
   bool one_launch_rounds() const { return word_global_ && words_fuse_max_ != 0; }
  private:
-  unsigned int hot_target_words_ = 1u << 15, words_inline_max_ = 1u << 18, words_fuse_max_ = 1u << 30, word_hint_floor_ = 16384;
+  unsigned int hot_target_words_ = 1u << 16, words_inline_max_ = 1u << 18, words_fuse_max_ = 1u << 30, word_hint_floor_ = 16384;
   unsigned int word_div_ = 200;    // switch when (merge sites of the last round) * word_div_ < (tokens a pass over the tiles streams)
   unsigned int word_min_tiles_ = 16384;
   unsigned long long idx_agg_min_ = 16ull << 20, word_min_tokens_ = 48ull << 20;
