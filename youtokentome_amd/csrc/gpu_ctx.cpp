@@ -631,7 +631,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
     const bool long_segments = n_text_ / n_segs >= 16;
     ht_cap = attempt == 0 && !long_segments && !getenv("YTTM_WORD_TABLE_FULL") ? pow2_at_least(std::max<unsigned long long>(n_segs / 4, 1ull << 16))
                                                                                  : pow2_at_least(n_segs + n_segs / 2 + 1024);
-    ht = dmalloc<unsigned long long>(2 * ht_cap);
+    ht = dmalloc<unsigned long long>(3 * ht_cap);  // keys, counts, positions of the short words' representatives (k_frontend.hip: WH_SHORT)
     launch_word_table_clear(ht, ht_cap, st_);
     HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
     t_begin(KT_DEDUP);

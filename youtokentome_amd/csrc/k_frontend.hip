@@ -322,6 +322,10 @@ __device__ inline bool seg_equal(const uint8_t *__restrict__ text, unsigned long
 // come with three aligned 8-byte loads, the ASCII half of cpmap sits in LDS, and two pure words of equal length are compared as
 // bytes -- one wide load of the representative instead of a walk.  Anything else (a byte >= 0x80, a dropped char, a word longer
 // than what the wide loads cover, the last bytes of the text) continues in / falls back to the exact walk.
+// A word of at most seven ASCII chars IS its key in the word table: bit 63 | chars:3 << 56 | the chars (below) -- equal keys, equal words, no
+// look at a representative's bytes (one of the three random HBM accesses of a probe; four words in five of random 'abcd ' text, two in
+// three of English-like text).  Where such a word's bytes are comes from the slot's entry in a third array, written by whoever claims it.
+constexpr unsigned long long WH_SHORT = 1ull << 63;
 __device__ inline void load16(const uint8_t *__restrict__ text, unsigned long long pos, unsigned long long &w0, unsigned long long &w1) {
   const unsigned long long *base = reinterpret_cast<const unsigned long long *>(text + (pos & ~7ull));
   const unsigned long long lo = base[0], mid = base[1], hi = base[2];
@@ -332,11 +336,13 @@ __device__ inline void load16(const uint8_t *__restrict__ text, unsigned long lo
 // like seg_scan; *pure = the word is L single-byte chars, consecutive from pos, none dropped (so its bytes identify it)
 __device__ inline uint32_t seg_scan_fast(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap,
                                          const uint32_t *cp_ascii /* LDS: cpmap[0..128) */, unsigned long long pos, unsigned long long *hash_out,
-                                         bool *pure) {
+                                         bool *pure, unsigned long long *short_key /* the word's key if it is at most 7 ASCII chars, else 0 */) {
   unsigned long long h = 0xcbf29ce484222325ull;
   uint32_t L = 0;
   unsigned long long i = pos;
   bool is_pure = true, done = false;
+  unsigned long long packed = 0;  // the first seven kept chars, when they are ASCII (a char and its id determine each other)
+  bool ascii_only = true;
   while (!done && i + 24 <= n) {  // 16 bytes at a time while they are ASCII
     unsigned long long w0, w1;
     load16(text, i, w0, w1);
@@ -348,6 +354,7 @@ __device__ inline uint32_t seg_scan_fast(const uint8_t *__restrict__ text, unsig
       if (id == CP_SPACE) { done = true; break; }
       if (id == CP_DROP) { is_pure = false; continue; }
       h = word_hash_step(h, id);
+      if (L < 7) packed |= (unsigned long long)b << (8 * L);
       L++;
     }
     i += (unsigned long long)k;
@@ -360,8 +367,14 @@ __device__ inline uint32_t seg_scan_fast(const uint8_t *__restrict__ text, unsig
       if (cp != INVALID_CP) {
         const uint32_t id = cpmap[cp];
         if (id == CP_SPACE) break;
-        if (id != CP_DROP) { h = word_hash_step(h, id); L++; }
-        else is_pure = false;
+        if (id != CP_DROP) {
+          h = word_hash_step(h, id);
+          if (cp >= 0x80u) ascii_only = false;
+          else if (L < 7) packed |= (unsigned long long)cp << (8 * L);
+          L++;
+        } else {
+          is_pure = false;
+        }
         if (len != 1) is_pure = false;
       } else {
         is_pure = false;
@@ -371,6 +384,7 @@ __device__ inline uint32_t seg_scan_fast(const uint8_t *__restrict__ text, unsig
   }
   *hash_out = mix64(h ^ ((unsigned long long)L << 48));
   *pure = is_pure;
+  *short_key = (ascii_only && L >= 1 && L <= 7) ? (WH_SHORT | ((unsigned long long)L << 56) | packed) : 0ull;
   return L;
 }
 // two PURE words of L chars each: equal iff their L bytes are
@@ -407,36 +421,39 @@ constexpr int WL_SLOTS = 512;  // per-workgroup LDS combiner for the frequent wo
                                // 2048: 14.4/8.5 (LDS then limits the workgroups per CU); 512 slots with 8 probes instead of 4: 10.9/6.6
 // Word table in HBM: keys in ht[0 .. cap), counts in ht[cap .. 2 cap).  (One 16-byte slot per word was measured 2.3x slower:
 // the atomics on a frequent word's count then serialise with every other workgroup's read of its key -- same cache line.)
-//   key = pure:1 | tag:7 | min(tokens, 0xffff):16 | byte offset of the representative segment:40   (PT_EMPTY = free)
+//   key = 0:1 | pure:1 | tag:6 | min(tokens, 0xffff):16 | byte offset of the representative segment:40   (PT_EMPTY = free),
+//   or WH_SHORT | chars:3 | 7 ASCII chars (above); positions of the short words' representatives in ht[2 cap .. 3 cap)
 // A probe compares tag and length first (23 bits) and then, always, the representative itself -- as bytes when both words are
 // "pure" (seg_scan_fast), token by token otherwise: the dedup is exact.  (The pure bit is not part of the comparison: the same
 // word can occur pure and, say, with an invalid byte in it.)
 constexpr uint32_t WH_LEN_CAP = 0xffffu;
-constexpr unsigned long long WH_PURE = 1ull << 63, WH_CMP_MASK = (1ull << 63) - 1;
+constexpr unsigned long long WH_PURE = 1ull << 62, WH_CMP_MASK = ~WH_PURE;
 __device__ inline unsigned long long wh_key(unsigned long long h, uint32_t len_tokens, unsigned long long pos, bool pure) {
   const unsigned long long l16 = len_tokens < WH_LEN_CAP ? len_tokens : WH_LEN_CAP;
-  return (pure ? WH_PURE : 0ull) | ((h >> 57) << 56) | (l16 << 40) | pos;
+  return (pure ? WH_PURE : 0ull) | ((h >> 58) << 56) | (l16 << 40) | pos;
 }
 // is the word at `pos` (key `mine`, L chars) the word whose key `cur` sits in a slot?
 __device__ inline bool wh_same(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap, unsigned long long cur,
                                unsigned long long mine, unsigned long long pos, uint32_t L) {
-  if (((cur ^ mine) & WH_CMP_MASK) >> 40) return false;  // tag or length differ
+  if (((cur ^ mine) & WH_CMP_MASK) >> 40) return false;  // tag or length differ (or `cur` is a short word's key)
   if ((cur & mine & WH_PURE) && L + 1 < WH_LEN_CAP) return bytes_equal(text, n, cur & WH_POS_MASK, pos, L);
   return seg_equal(text, n, cpmap, cur & WH_POS_MASK, pos);
 }
 constexpr int WH_MAX_PROBES = 4096;  // longer than this: the table was sized too small for this corpus (status[6]; the host retries)
 
-// insert-or-add `count` occurrences of the word whose representative segment starts at `pos` into the HBM table
+// insert-or-add `count` occurrences of the word whose representative segment starts at `pos` into the HBM table; `mine` = its key
+// (wh_key, or the short word's own key)
 __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap,
-                                          unsigned long long h, unsigned long long pos, uint32_t len_tokens, bool pure, unsigned long long count,
+                                          unsigned long long h, unsigned long long mine, unsigned long long pos, uint32_t len_tokens, unsigned long long count,
                                           unsigned long long *__restrict__ ht, unsigned long long ht_mask, unsigned int *__restrict__ status) {
-  const unsigned long long mine = wh_key(h, len_tokens, pos, pure);
+  const bool is_short = (mine & WH_SHORT) != 0;
   unsigned long long i = (h >> 8) & ht_mask;
   for (int probes = 0; probes < WH_MAX_PROBES; probes++) {
     unsigned long long cur = ld_agent(&ht[i]);
     if (cur == PT_EMPTY) {
       cur = atomicCAS(&ht[i], PT_EMPTY, mine);
       if (cur == PT_EMPTY) {
+        if (is_short) ht[2 * (ht_mask + 1) + i] = pos;  // (read by the compaction pass, a kernel later)
         atomicAdd(&ht[ht_mask + 1 + i], count);
         atomicAdd(&status[0], 1u);  // `status` is the workgroup's LDS copy (k2b_insert_words): 1.6e7 bumps of one HBM counter cost ~2 ns each
         if (len_tokens > (uint32_t)TILE_NOM_A) atomicAdd(&status[2], 1u);
@@ -447,7 +464,7 @@ __device__ inline void word_insert_global(const uint8_t *__restrict__ text, unsi
         return;
       }
     }
-    if (wh_same(text, n, cpmap, cur, mine, pos, len_tokens - 1u)) {
+    if (is_short ? cur == mine : wh_same(text, n, cpmap, cur, mine, pos, len_tokens - 1u)) {
       atomicAdd(&ht[ht_mask + 1 + i], count);
       return;
     }
@@ -468,6 +485,7 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
   __shared__ uint32_t cp_ascii[128];               // cpmap[0..128): the fast scan's table
   __shared__ unsigned long long l_key[WL_SLOTS];   // a word-table key (wh_key) or PT_EMPTY
   __shared__ unsigned long long l_hash[WL_SLOTS];  // full hash of the word (for the flush)
+  __shared__ unsigned long long l_pos[WL_SLOTS];   // its representative (a short word's key does not say)
   __shared__ unsigned int l_cnt[WL_SLOTS];
   __shared__ unsigned int l_len[WL_SLOTS];
   __shared__ unsigned int l_maxlen;  // longest class-A word seen by this workgroup (one global atomicMax at the end)
@@ -483,9 +501,10 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
     const unsigned long long pos = seg_pos[s];
     unsigned long long h;
     bool pure;
-    const uint32_t L = seg_scan_fast(text, n, cpmap, cp_ascii, pos, &h, &pure);
+    unsigned long long skey;
+    const uint32_t L = seg_scan_fast(text, n, cpmap, cp_ascii, pos, &h, &pure, &skey);
     if (L == 0) continue;  // segment made only of dropped chars: no word (bpe.cpp:357-380 deletes them first)
-    const unsigned long long mine = wh_key(h, L + 1, pos, pure);
+    const unsigned long long mine = skey ? skey : wh_key(h, L + 1, pos, pure);
     if (L + 1 <= (uint32_t)TILE_NOM_A && L + 1 > l_maxlen) atomicMax(&l_maxlen, L + 1);
     bool done = false;
     if (L <= 24) {  // very long words are not frequent enough to be worth an LDS slot (Zipf text: the top words reach 12+ chars)
@@ -496,13 +515,14 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
           cur = atomicCAS(&l_key[j], PT_EMPTY, mine);
           if (cur == PT_EMPTY) {
             l_hash[j] = h;
+            l_pos[j] = pos;
             l_len[j] = L + 1;
             atomicAdd(&l_cnt[j], 1u);
             done = true;
             break;
           }
         }
-        if (wh_same(text, n, cpmap, cur, mine, pos, L)) {
+        if (skey ? cur == mine : wh_same(text, n, cpmap, cur, mine, pos, L)) {
           atomicAdd(&l_cnt[j], 1u);
           done = true;
           break;
@@ -510,13 +530,12 @@ __global__ __launch_bounds__(BLOCK) void k2b_insert_words(const uint8_t *__restr
         j = (j + 1) & (WL_SLOTS - 1);
       }
     }
-    if (!done) word_insert_global(text, n, cpmap, h, pos, L + 1, pure, 1ull, ht, ht_mask, l_status);
+    if (!done) word_insert_global(text, n, cpmap, h, mine, pos, L + 1, 1ull, ht, ht_mask, l_status);
   }
   __syncthreads();
   for (int i = (int)threadIdx.x; i < WL_SLOTS; i += BLOCK) {
     const unsigned long long k = l_key[i];
-    if (k != PT_EMPTY)
-      word_insert_global(text, n, cpmap, l_hash[i], k & WH_POS_MASK, l_len[i], (k & WH_PURE) != 0, (unsigned long long)l_cnt[i], ht, ht_mask, l_status);
+    if (k != PT_EMPTY) word_insert_global(text, n, cpmap, l_hash[i], k, l_pos[i], l_len[i], (unsigned long long)l_cnt[i], ht, ht_mask, l_status);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -546,14 +565,14 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const uint8_t *__rest
   constexpr unsigned long long CH = 64 * BLOCK;
   __shared__ uint32_t scan_lds[NWAVES];
   __shared__ unsigned int blk_base;
-  const unsigned long long *keys = ht, *cnts = ht + n_slots;
+  const unsigned long long *keys = ht, *cnts = ht + n_slots, *spos = ht + 2 * n_slots;
   for (unsigned long long c0 = (unsigned long long)blockIdx.x * CH; c0 < n_slots; c0 += (unsigned long long)gridDim.x * CH) {
     uint32_t mine = 0;
     for (int j = 0; j < 64; j++) {
       const unsigned long long i = c0 + (unsigned long long)j * BLOCK + threadIdx.x;
       if (i < n_slots) {
         const unsigned long long k = keys[i];
-        if (k != PT_EMPTY && ((uint32_t)(k >> 40) & 0xffffu) <= (uint32_t)TILE_NOM_A) mine++;
+        if (k != PT_EMPTY && ((k & WH_SHORT) || ((uint32_t)(k >> 40) & 0xffffu) <= (uint32_t)TILE_NOM_A)) mine++;
       }
     }
     uint32_t total;
@@ -567,10 +586,12 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const uint8_t *__rest
       const unsigned long long k = keys[i];
       if (k == PT_EMPTY) continue;
       const unsigned long long c = cnts[i];
-      uint32_t len = (uint32_t)(k >> 40) & 0xffffu;
-      if (len >= WH_LEN_CAP) {  // (a word of 65535 tokens or more: its exact length from the representative)
+      const bool is_short = (k & WH_SHORT) != 0;
+      const unsigned long long wpos = is_short ? spos[i] : (k & WH_POS_MASK);
+      uint32_t len = is_short ? (uint32_t)((k >> 56) & 7ull) + 1u : (uint32_t)(k >> 40) & 0xffffu;
+      if (!is_short && len >= WH_LEN_CAP) {  // (a word of 65535 tokens or more: its exact length from the representative)
         unsigned long long hh;
-        len = seg_scan(text, n, cpmap, k & WH_POS_MASK, &hh) + 1u;
+        len = seg_scan(text, n, cpmap, wpos, &hh) + 1u;
       }
       // Word weights are uint32 in the tiles; the reference counts in uint64 (bpe.cpp:382-385).  A word seen more than `wmax` (2^32 - 1)
       // times is kept as SEVERAL equal words whose weights add up to its count -- every pair count is a sum over words, so nothing the
@@ -580,7 +601,7 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const uint8_t *__rest
         c32 = (uint32_t)wmax;
         const unsigned int o = atomicAdd(&cursor[3], 1u);
         if (o < (unsigned int)HEAVY_CAP) {
-          heavy[3 * o] = k & WH_POS_MASK;
+          heavy[3 * o] = wpos;
           heavy[3 * o + 1] = len;
           heavy[3 * o + 2] = c - wmax;
         } else {
@@ -589,12 +610,12 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const uint8_t *__rest
       }
       if (len > (uint32_t)TILE_NOM_B) {
         const unsigned int o = atomicAdd(&cursor[2], 1u);
-        posC[o] = k & WH_POS_MASK; cntC[o] = c32; lenC[o] = len;
+        posC[o] = wpos; cntC[o] = c32; lenC[o] = len;
       } else if (len > (uint32_t)TILE_NOM_A) {
         const unsigned int o = atomicAdd(&cursor[1], 1u);
-        posB[o] = k & WH_POS_MASK; cntB[o] = c32; lenB[o] = len;
+        posB[o] = wpos; cntB[o] = c32; lenB[o] = len;
       } else {
-        posA[o_a] = k & WH_POS_MASK; cntA[o_a] = c32; lenA[o_a] = len;
+        posA[o_a] = wpos; cntA[o_a] = c32; lenA[o_a] = len;
         o_a++;
       }
     }

@@ -30,7 +30,7 @@ unsigned long long fe_chunks(unsigned long long n);
 void launch_seg_write(const uint8_t *text, unsigned long long n, unsigned long long *seg_pos, const unsigned long long *chunk_off, hipStream_t st);
 void launch_hist_compact(const unsigned long long *hist, uint32_t *cps, unsigned long long *cnts, unsigned int *n_out, unsigned int cap,
                          hipStream_t st);
-// word table (K2b/K2c): ht[0 .. n_slots) keys, ht[n_slots .. 2 n_slots) counts, see k_frontend.hip
+// word table (K2b/K2c): ht[0 .. n_slots) keys, ht[n_slots .. 2 n_slots) counts, ht[2 n_slots .. 3 n_slots) positions of the short words, see k_frontend.hip
 void launch_word_table_clear(unsigned long long *ht, unsigned long long n_slots, hipStream_t st);
 void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *seg_pos,
                          unsigned long long n_segs, unsigned long long *ht, unsigned long long ht_mask, unsigned int *status, hipStream_t st);
