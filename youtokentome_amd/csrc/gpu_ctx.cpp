@@ -343,11 +343,17 @@ void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
 // cache / memcpy) while the other is on its way over PCIe on the worker's own stream.  The pinned chunks are kept for the
 // next call (pinning 128 MB costs tens of milliseconds).
 namespace {
-constexpr size_t IO_CHUNK = 8u << 20;
+constexpr size_t IO_CHUNK_MAX = 64u << 20;
+static size_t IO_CHUNK = 8u << 20;  // (YTTM_IO_CHUNK_MB: tuning hook, read once)
 constexpr int IO_MAX_THREADS = 32;
 struct IoStage {
   std::mutex mu;
   void *pin[2 * IO_MAX_THREADS] = {nullptr};
+  // the workers' copy streams and events are kept as well (creating and destroying a stream and two events per worker and call was
+  // a millisecond of every upload, serialised in the runtime); they belong to device `dev`
+  hipStream_t cs[IO_MAX_THREADS] = {nullptr};
+  hipEvent_t ev[2 * IO_MAX_THREADS] = {nullptr};
+  int dev = -1;
   bool busy = false;
 } g_io;
 }  // namespace
@@ -359,6 +365,15 @@ static void release_io_stage() {
     if (p) (void)hipHostFree(p);
     p = nullptr;
   }
+  for (hipEvent_t &e : g_io.ev) {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
+  for (hipStream_t &c : g_io.cs) {
+    if (c) (void)hipStreamDestroy(c);
+    c = nullptr;
+  }
+  g_io.dev = -1;
 }
 
 void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *dst, unsigned long long off, size_t len)> &fill) {
@@ -371,14 +386,31 @@ void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *
   n_text_ = n;
   corpus_bytes = n;
   if (!n) return;
+  {
+    const size_t mb = std::min<size_t>(std::max<size_t>(env_uint("YTTM_IO_CHUNK_MB", 8), 1), IO_CHUNK_MAX >> 20);
+    IO_CHUNK = mb << 20;
+  }
   const size_t n_chunks = (size_t)((n + IO_CHUNK - 1) / IO_CHUNK);
   int n_threads = (int)env_uint("YTTM_IO_THREADS", 0);
-  if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 8u));  // (default: as many as the reference's trainer uses, bpe.cpp:1348)
+  // (default 4: one thread preads 40 GB/s out of the page cache on the MI355X box, the link takes 55; eight workers measured SLOWER than three
+  // or four -- 34 - 42 ms per GB against 24 -- sixteen much slower: they queue up in the runtime)
+  if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 4u));
   n_threads = (int)std::min<size_t>((size_t)std::min(n_threads, IO_MAX_THREADS), n_chunks);
   bool mine = false;
   {
     std::lock_guard<std::mutex> g(g_io.mu);
     if (!g_io.busy) { g_io.busy = true; mine = true; }
+  }
+  if (mine && g_io.dev != device_) {  // (the cached streams and events are another device's)
+    for (hipEvent_t &e : g_io.ev) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+    for (hipStream_t &c : g_io.cs) {
+      if (c) (void)hipStreamDestroy(c);
+      c = nullptr;
+    }
+    g_io.dev = device_;
   }
   if (!mine) {  // another context of this process is uploading through the shared chunks: plain copies for this one
     std::vector<uint8_t> tmp(IO_CHUNK);
@@ -397,13 +429,13 @@ void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *
   auto worker = [&](int w) {
     try {
       HIP_CHECK(hipSetDevice(device_));
-      hipStream_t cs = nullptr;
-      HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-      hipEvent_t ev[2] = {nullptr, nullptr};
+      if (!g_io.cs[w]) HIP_CHECK(hipStreamCreateWithFlags(&g_io.cs[w], hipStreamNonBlocking));
+      hipStream_t cs = g_io.cs[w];
+      hipEvent_t *ev = &g_io.ev[2 * w];
       bool used[2] = {false, false};
       for (int k = 0; k < 2; k++) {
-        HIP_CHECK(hipEventCreate(&ev[k]));
-        if (!g_io.pin[2 * w + k]) HIP_CHECK(hipHostMalloc(&g_io.pin[2 * w + k], IO_CHUNK, hipHostMallocDefault));
+        if (!ev[k]) HIP_CHECK(hipEventCreate(&ev[k]));
+        if (!g_io.pin[2 * w + k]) HIP_CHECK(hipHostMalloc(&g_io.pin[2 * w + k], IO_CHUNK_MAX, hipHostMallocDefault));
       }
       for (int k = 0;; k ^= 1) {
         const size_t c = next.fetch_add(1);
@@ -417,8 +449,6 @@ void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *
         used[k] = true;
       }
       HIP_CHECK(hipStreamSynchronize(cs));
-      for (int k = 0; k < 2; k++) (void)hipEventDestroy(ev[k]);
-      (void)hipStreamDestroy(cs);
     } catch (const GpuError &e) {
       failed.store(1);
       std::lock_guard<std::mutex> g(err_mu);
