@@ -44,6 +44,7 @@ struct DevPool {
 };
 DevPool g_pool;
 void *g_pin_cached = nullptr;  // one pinned staging buffer (PIN_BYTES) kept between contexts
+std::vector<std::pair<int, hipStream_t>> g_streams_cached;  // streams of finished contexts, by device (creating and destroying one costs ~2 ms of a training)
 thread_local hipStream_t tl_stream = nullptr;
 thread_local int tl_device = 0;
 constexpr size_t POOL_MAX_CACHED = 48ull << 30;
@@ -115,6 +116,8 @@ void release_device_memory() {
     (void)hipHostFree(g_pin_cached);
     g_pin_cached = nullptr;
   }
+  for (auto &ds : g_streams_cached) (void)hipStreamDestroy(ds.second);
+  g_streams_cached.clear();
   for (auto it = g_pool.free_blocks.begin(); it != g_pool.free_blocks.end();) {
     if (it->second.owner == nullptr) {
       (void)hipFree(it->second.p);
@@ -152,12 +155,21 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
-  HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  if (pool_enabled()) {
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    for (size_t i = 0; i < g_streams_cached.size(); i++)
+      if (g_streams_cached[i].first == device_) {
+        st_ = g_streams_cached[i].second;
+        g_streams_cached.erase(g_streams_cached.begin() + (long)i);
+        break;
+      }
+  }
+  if (!st_) HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
   tl_stream = st_;
   tl_device = device_;
   d_counters_ = dmalloc<unsigned long long>(64);
   d_stats_ = dmalloc<unsigned long long>(STATS_WORDS);  // [0..3] K4 counters, [8..23] per-phase cycles of a YTTM_K4_PROF build, [32..) per-workgroup rows
-  HIP_CHECK(hipMemset(d_stats_, 0, STATS_WORDS * sizeof(unsigned long long)));
+  HIP_CHECK(hipMemsetAsync(d_stats_, 0, STATS_WORDS * sizeof(unsigned long long), st_));  // (stream-ordered like everything that uses them)
   // one block for everything the host reads back per round, so that it is ONE device-to-host copy:
   // [0] n_cand, [4] n_keys | [64..) count histogram | [8192..) candidates
   d_round_ = dmalloc<unsigned char>(8192 + (size_t)CAND_CAP * sizeof(CandRec));
@@ -187,14 +199,14 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   dbg_cand_ = getenv("YTTM_DBG_CAND");
   d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);
   d_hot_n_ = dmalloc<unsigned int>(4);  // [0] list length, [1] k_hot_scan's finished-workgroup ticket, [2..3] overflow verdict (u64)
-  HIP_CHECK(hipMemset(d_hot_n_, 0, 16));
+  HIP_CHECK(hipMemsetAsync(d_hot_n_, 0, 16, st_));
   top_cap_ = std::max(16u, std::min(env_uint("YTTM_TOP_CAP", 1u << 13), TOP_CAP));
   top_target_ = env_uint("YTTM_TOP_TARGET", 1024);  // about four times what the host looks at per round
   top_min_ = env_uint("YTTM_TOP_MIN", 192);
   d_top_slots_ = dmalloc<uint32_t>(TOP_CAP);
   d_top_n_ = dmalloc<unsigned int>(4);
-  HIP_CHECK(hipMemset(d_top_n_, 0, 16));
-  HIP_CHECK(hipMemset(d_round_, 0, 8192));  // k_hot_scan leaves its counters zeroed for the next call
+  HIP_CHECK(hipMemsetAsync(d_top_n_, 0, 16, st_));
+  HIP_CHECK(hipMemsetAsync(d_round_, 0, 8192, st_));  // k_hot_scan leaves its counters zeroed for the next call
   d_cand_n_ = (unsigned int *)d_round_;
   d_cand_hist_ = (unsigned long long *)(d_round_ + 64);
   d_cand_ = (CandRec *)(d_round_ + 8192);
@@ -234,6 +246,13 @@ GpuCtx::~GpuCtx() {
     }
   }
   if (h_pin_) (void)hipHostFree(h_pin_);
+  if (st_ && pool_enabled()) {  // (synchronised above: nothing is pending on it)
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    if (g_streams_cached.size() < 8) {
+      g_streams_cached.emplace_back(device_, st_);
+      st_ = nullptr;
+    }
+  }
   if (st_) (void)hipStreamDestroy(st_);
 }
 

@@ -452,8 +452,11 @@ Status train_bpe(const std::string &input_path, const std::string &model_path, i
     hi = split(comm->rank + 1);
   }
   fprintf(stderr, "learning bpe...\n");
+  const auto t_call = clk::now();
+  double s_ctor = 0, s_body = 0;
   Status r = guarded([&]() {
     GpuCtx g(device);
+    s_ctor = since(t_call);
     g.profile = profile && !getenv("YTTM_NO_PROFILE");
     g.set_comm(comm);
     const auto t_up = clk::now();
@@ -461,8 +464,10 @@ Status train_bpe(const std::string &input_path, const std::string &model_path, i
     const double s_up = since(t_up);
     Status st2 = learn_bpe(g, vocab_size, model_path, cfg, nullptr, report);
     if (report) { report->seconds_upload = s_up; report->seconds_total += s_up; }
+    s_body = since(t_call);
     return st2;
   });
+  if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] train_bpe: context set-up %.2f ms, upload + training %.2f ms, context tear-down %.2f ms\n", s_ctor * 1e3, (s_body - s_ctor) * 1e3, (since(t_call) - s_body) * 1e3);
   close(fd);
   return r;
 }
