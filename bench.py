@@ -525,10 +525,12 @@ def _static_traffic(kern, corpus, size_mb, args, world):
             if k.startswith(prefixes):
                 return name
         return None
+    # (the profiled command trains more than once per process -- the file step, the HBM-resident warm-up and step: K1 runs once per training)
+    n_train = max(1, sum(pm[k]["launches"] for k in pm if k.startswith("k_scan_bytes<0")))
     for name in ("char_hist", "segments", "dedup", "pair_count", "merge_apply", "cand_scan"):
         ks = [k for k in pm if family(k) == name]
         if ks and name in kern:
-            total = sum(pm[k]["traffic_bytes_per_launch"] * pm[k]["launches"] for k in ks)
+            total = sum(pm[k]["traffic_bytes_per_launch"] * pm[k]["launches"] for k in ks) / n_train
             traffic[name] = round(total / max(1, kern[name]["launches"]))
     return traffic, "static: bytes per launch from profiles/%s (rocprofv3 --pmc passes of this command, tools/profile_round.sh; a PMC pass cannot share a run with the timed region, so it is not re-measured here)" % os.path.basename(pmc_file)
 

@@ -47,7 +47,7 @@ void *g_pin_cached = nullptr;  // one pinned staging buffer (PIN_BYTES) kept bet
 std::vector<std::pair<int, hipStream_t>> g_streams_cached;  // streams of finished contexts, by device (creating and destroying one costs ~2 ms of a training)
 thread_local hipStream_t tl_stream = nullptr;
 thread_local int tl_device = 0;
-constexpr size_t POOL_MAX_CACHED = 48ull << 30;
+constexpr size_t POOL_MAX_CACHED = 96ull << 30;  // (a third of the HBM: the segment starts of 4.4e9 one-letter words alone are 35 GB)
 bool pool_enabled() {
   static const bool on = !(getenv("YTTM_NO_POOL") && *getenv("YTTM_NO_POOL") == '1');
   return on;
