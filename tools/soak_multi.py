@@ -27,7 +27,10 @@ while time.time() - t0 < budget:
         if r >= 0.7:
             text = gen.zipf_corpus(rng.randint(60000, 300000), vocab=rng.randint(500, 20000), seed=rng.randint(0, 10 ** 6))
         vocab = rng.randint(200, 2500)
-    env = rng.choice([{}, {"YTTM_XCHG_BLK_MIN": "2"}, {"YTTM_INDEX_ALWAYS": "1", "YTTM_INDEX_MIN_TILES": "1"}, {"YTTM_XCHG_BLK_MIN": "2", "YTTM_INDEX_ALWAYS": "1", "YTTM_INDEX_MIN_TILES": "1"}, {"YTTM_HOT_TARGET": "8", "YTTM_HOT_MIN": "3", "YTTM_HOT_CAP": "32"}, {"YTTM_TOP_TARGET": "4", "YTTM_TOP_MIN": "2", "YTTM_TOP_CAP": "16"}])
+    words = {"YTTM_WORD_MIN_TILES": "0", "YTTM_WORD_MIN_TOKENS": "0", "YTTM_WORD_DIV": "0", "YTTM_WORDS_GRID": "3", "YTTM_WGATHER_GRID": "2"}
+    env = rng.choice([{}, {"YTTM_XCHG_BLK_MIN": "2", "YTTM_XCHG_MARGIN": "0.05"}, {"YTTM_XCHG_NOTES": "2"}, words, dict(words, YTTM_XCHG_NOTES="2", YTTM_XCHG_BLK_MIN="2", YTTM_XCHG_MARGIN="0.05"),
+                      dict(words, YTTM_HOT_TARGET="8", YTTM_HOT_MIN="3", YTTM_HOT_CAP="32"), {"YTTM_HOT_TARGET": "8", "YTTM_HOT_MIN": "3", "YTTM_HOT_CAP": "32"},
+                      {"YTTM_TOP_TARGET": "4", "YTTM_TOP_MIN": "2", "YTTM_TOP_CAP": "16"}, dict(words, YTTM_WORD_DREC="16", YTTM_WORD_LOG="200")])
     corpus, m_mp, m_ora = str(tmp / f"c{n}.txt"), str(tmp / f"mp{n}.model"), str(tmp / f"ora{n}.model")
     open(corpus, "wb").write(text)
     try:

@@ -69,18 +69,18 @@ while time.time() - t0 < budget:
         if r >= 0.7:
             text = gen.zipf_corpus(rng.randint(60000, 400000), vocab=rng.randint(500, 20000), seed=rng.randint(0, 10 ** 6))
         vocab = rng.randint(200, 3000)
-        for k in ("YTTM_INDEX_ALWAYS", "YTTM_NO_FUSE", "YTTM_HOT_TARGET", "YTTM_HOT_MIN", "YTTM_HOT_CAP", "YTTM_TOP_TARGET", "YTTM_TOP_MIN", "YTTM_TOP_CAP",
+        for k in ("YTTM_K4_DIRECT", "YTTM_NO_FUSE", "YTTM_HOT_TARGET", "YTTM_HOT_MIN", "YTTM_HOT_CAP", "YTTM_TOP_TARGET", "YTTM_TOP_MIN", "YTTM_TOP_CAP",
                   "YTTM_INDEX_MIN_TILES", "YTTM_WORD_TABLE_FULL"):
             os.environ.pop(k, None)
-        hooks = rng.choice([{}, {"YTTM_INDEX_ALWAYS": "1", "YTTM_INDEX_MIN_TILES": "1"}, {"YTTM_NO_FUSE": "1"},
+        hooks = rng.choice([{}, {"YTTM_K4_DIRECT": "0"}, {"YTTM_NO_FUSE": "1"},
                             {"YTTM_HOT_TARGET": "8", "YTTM_HOT_MIN": "3", "YTTM_HOT_CAP": "32"}, {"YTTM_TOP_TARGET": "4", "YTTM_TOP_MIN": "2", "YTTM_TOP_CAP": "16"},
-                            {"YTTM_INDEX_ALWAYS": "1", "YTTM_INDEX_MIN_TILES": "1", "YTTM_TOP_TARGET": "16", "YTTM_TOP_MIN": "4", "YTTM_TOP_CAP": "64"}])
+                            {"YTTM_K4_DIRECT": "0", "YTTM_TOP_TARGET": "16", "YTTM_TOP_MIN": "4", "YTTM_TOP_CAP": "64"}])
         os.environ.update(hooks)
         if words_mode:
             for k in ("YTTM_WORD_LOG", "YTTM_WORD_DREC", "YTTM_WORDS_INLINE_MAX", "YTTM_INDEX_AGG_MIN", "YTTM_WORDS_WPI", "YTTM_WORDS_FUSE_MAX", "YTTM_WORDS_GRID"):
                 os.environ.pop(k, None)
             os.environ.update({"YTTM_WORD_MIN_TILES": "0", "YTTM_WORD_MIN_TOKENS": "0", "YTTM_WORD_DIV": rng.choice(["0", "0", "2", "8"])})
-            os.environ.pop("YTTM_INDEX_ALWAYS", None)
+            os.environ.pop("YTTM_K4_DIRECT", None)
             os.environ.update(rng.choice([{}, {"YTTM_WORD_LOG": str(rng.choice([50, 300, 2000]))}, {"YTTM_WORD_DREC": str(rng.choice([8, 64]))},
                                           {"YTTM_WORDS_INLINE_MAX": "0"}, {"YTTM_INDEX_AGG_MIN": "0"}, {"YTTM_WORDS_FUSE_MAX": "0"},
                                           {"YTTM_WORDS_FUSE_MAX": str(rng.choice([4200, 4500, 6000]))}, {"YTTM_WORDS_GRID": str(rng.choice([1, 2, 5]))},

@@ -195,6 +195,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   // in word mode, the 1 GB CJK-shaped corpus (337 M tokens) 21 % faster, random 'abcd ' (94 M tokens at the switch) 10 % faster
   word_min_tokens_ = (unsigned long long)env_uint("YTTM_WORD_MIN_TOKENS", 48u << 20);
   no_batch_args_ = getenv("YTTM_NO_BATCH_ARGS") != nullptr;  // (read once per context: a round has no time for getenv)
+  launch_env_refresh();
   trace_rounds_ = getenv("YTTM_TRACE_ROUNDS");
   dbg_cand_ = getenv("YTTM_DBG_CAND");
   d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);

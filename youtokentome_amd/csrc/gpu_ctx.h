@@ -210,7 +210,12 @@ class GpuCtx {
   unsigned long long g_sites_cum_ = 0, g_tokens_cum_ = 0, g_sites_last_ = ~0ull, g_tokens_last_ = 0, g_tiles_a_ = 0;
  public:
   // class A is in word mode, and a batch of at most this many rules is one launch there (k_words<FUSED>): the trainer's batch split
-  bool one_launch_rounds() const { return word_global_ && words_fuse_max_ != 0; }
+  // (the conditions merge_apply fuses a round under, as far as they are known before the batch is -- cutting a batch for a
+  // round that then runs unfused anyway only adds a round.  Multi-GPU: only what is the same on every rank -- the batches must be.)
+  bool one_launch_rounds() const {
+    if (!(word_global_ && words_fuse_max_ != 0 && fuse_enabled_ && !instrument && hot_state_ == HOT_ACTIVE && top_state_ == TOP_ACTIVE)) return false;
+    return multi() || (word_mode_ && idx_valid_ && !cls_[2].n_tiles);
+  }
  private:
   unsigned int hot_target_words_ = 1u << 16, words_inline_max_ = 1u << 18, words_fuse_max_ = 1u << 30, word_hint_floor_ = 16384;
   unsigned int word_div_ = 200;    // switch when (merge sites of the last round) * word_div_ < (tokens a pass over the tiles streams)

@@ -3084,13 +3084,24 @@ void launch_words_init(const TileSet &ts, unsigned long long *wmeta, hipStream_t
   if (g > 256 * 8) g = 256 * 8;
   hipLaunchKernelGGL((k_words_init<TILE_SLOT_A>), dim3(g), dim3(BLOCK), 0, st, ts, wmeta);
 }
+// The grid hooks of the word-mode launchers (tests, tuning) are read when a context is made, not every round: getenv walks the whole
+// environment, and a round's launch is on its critical path (yttm_kernels.h: launch_env_refresh).
+static int g_wgather_grid = -1, g_words_grid = -1, g_words_wpi = -1;
+void launch_env_refresh() {
+  auto rd = [](const char *name) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : -1;
+  };
+  g_wgather_grid = rd("YTTM_WGATHER_GRID");
+  g_words_grid = rd("YTTM_WORDS_GRID");
+  g_words_wpi = rd("YTTM_WORDS_WPI");
+}
 void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, unsigned int work_hint, hipStream_t st) {
   // every workgroup looks all the rules up and takes a ticket at the end: a small round (work_hint = about how many words it will visit;
   // 0: unknown) gets a small grid
-  const char *g_env = getenv("YTTM_WGATHER_GRID");
   unsigned int g = 256u;
   if (work_hint) g = std::max(16u, std::min(256u, work_hint / 1024u));
-  if (g_env) g = (unsigned int)atoi(g_env);
+  if (g_wgather_grid >= 0) g = (unsigned int)g_wgather_grid;
   hipLaunchKernelGGL(k_wgather, dim3(g ? g : 1u), dim3(WG_NT), 0, st, a, ba ? *ba : BatchArgs{});
 }
 bool launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
@@ -3107,14 +3118,12 @@ bool launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &
   if (ga && !fused) launch_wgather(*ga, &bargs, work_hint, st);
   if (!fused) bargs.mark = 0u;  // (the round's first launch carries the mark)
   // one run of 64 words per wave and iteration; work_hint = about how many words the round will visit (0: unknown / every word)
-  const char *g_env = getenv("YTTM_WORDS_GRID");
-  const unsigned int gmax = std::min(g_env ? (unsigned int)atoi(g_env) : 512u, (unsigned int)WORDS_MAX_GRID);
+  const unsigned int gmax = std::min(g_words_grid >= 0 ? (unsigned int)g_words_grid : 512u, (unsigned int)WORDS_MAX_GRID);
   // words per wave: 64, or fewer when that would leave most of the chip idle (work_hint words over at most gmax workgroups)
   unsigned int wpi = 64;
   if (worklist && work_hint) {
-    const char *w_env = getenv("YTTM_WORDS_WPI");
     while (wpi > 8 && (unsigned long long)work_hint < (unsigned long long)wpi * APPLY_WPB * gmax / 2) wpi >>= 1;
-    if (w_env) wpi = (unsigned int)atoi(w_env);
+    if (g_words_wpi >= 0) wpi = (unsigned int)g_words_wpi;
   }
   unsigned long long items = worklist && work_hint ? ((unsigned long long)work_hint + wpi - 1) / wpi + 1 : ((unsigned long long)ws.n_words + 63) / 64;
   unsigned long long g = (items + APPLY_WPB - 1) / APPLY_WPB;

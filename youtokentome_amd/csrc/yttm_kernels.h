@@ -137,6 +137,7 @@ struct WGatherArgs {
   uint32_t cnt[BATCH_ARGS_MAX];  // k_words<FUSED>: the count the host picked rule j by (saturated): no rule has more sites than that
 };
 constexpr unsigned int WGATHER_MAXK = 4096;
+void launch_env_refresh();  // re-reads the launchers' environment hooks (YTTM_WORDS_GRID, YTTM_WORDS_WPI, YTTM_WGATHER_GRID): once per context
 void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, unsigned int work_hint, hipStream_t st);
 bool launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
                         uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules, const uint32_t *worklist /* nullptr: every word */, unsigned long long wl_seg,
