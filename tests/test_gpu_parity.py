@@ -48,6 +48,15 @@ def test_k5_word_cache_fuzz(tmp_path):
     S.check_encode_word_cache_fuzz(tmp_path, trials=12)
 
 
+@pytest.mark.parametrize("lane_max", [0, 5, 1000])
+def test_k5_one_word_per_lane(lane_max, monkeypatch):
+    """the wave-wide merge rounds and merge_lanes (k_encode.hip) against the oracle: lanes never / for short words only / always"""
+    monkeypatch.setenv("YTTM_K5_LANE_WORDS", str(lane_max))
+    monkeypatch.setenv("YTTM_K5_LANE_SENT", str(lane_max))
+    S.check_encode_mixed_shapes(n_sent=1500, seed=29)
+    S.check_encode_word_cache(n_sent=1000, seed=31)
+
+
 def test_k4_many_words_per_tile(tmp_path):
     S.check_many_words_per_tile(tmp_path)
 

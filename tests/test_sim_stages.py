@@ -172,6 +172,17 @@ def test_encode_word_cache_fuzz(tmp_path):
     S.check_encode_word_cache_fuzz(tmp_path)
 
 
+@pytest.mark.parametrize("lane_max", [0, 5, 1000])
+def test_encode_one_word_per_lane(lane_max, monkeypatch):
+    """K5's two ways through the merge rounds -- the wave-wide rounds and one word per lane (merge_lanes) -- are the oracle's ids both:
+    never the lanes (0), the lanes for packs of short words only (5: most packs fall back), the lanes whatever the words (1000; the
+    default is 48).  The shapes have runs of one letter, a rule several times in a word, unknown chars, words of 1..60 chars."""
+    monkeypatch.setenv("YTTM_K5_LANE_WORDS", str(lane_max))
+    monkeypatch.setenv("YTTM_K5_LANE_SENT", str(lane_max))
+    S.check_encode_mixed_shapes(n_sent=60, seed=29)
+    S.check_encode_word_cache(n_sent=40, seed=31)
+
+
 def test_many_words_per_tile(tmp_path):
     S.check_many_words_per_tile(tmp_path)
 

@@ -312,7 +312,7 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
     HIP_CHECK(hipMemsetAsync(wc.occ, 0xff, (size_t)((total_bytes + n_sent) / 2 + 2) * 4, d.st));  // (no word starts anywhere yet)
     HIP_CHECK(hipMemsetAsync(d.d_wc_misc, 0, 8, d.st));
     launch_wcache_insert(D.m, text, total_bytes, d_offsets, n_sent, wc, d.st);
-    const unsigned long long n_blk = wcache_count_blocks(wc);
+    const unsigned long long n_blk = wcache_count_cells(wc);
     d.grow(d.d_wc_blk, d.cap_wc_blk, (size_t)n_blk);
     d.grow(d.d_wc_blk_off, d.cap_wc_blk_off, (size_t)n_blk + 1);
     launch_wcache_count_slots(wc, d.d_wc_blk, d.st);

@@ -437,6 +437,131 @@ __device__ int merge_rounds(const EncModel &m, const uint32_t *bloom, A wt, A wr
   return n;
 }
 
+// ---- merge rounds, one word per lane --------------------------------------------------------------------------------------
+// The rounds above cost three passes over every chunk of the pack, and the pack needs as many rounds as its longest word has merges,
+// however few lanes still have anything to do.  When the pack is many words of moderate length (the word cache's distinct words; the
+// words of a few packed sentences) a lane takes a word instead and walks it alone: per round a scan of ITS pairs for the smallest rule's
+// leftmost site, the merge, the tail moved up one place, and the look-ups of the two pairs the merge made (the lanes' rule-hash loads of a
+// round go out together).  No ballots, no atomics, no wave-wide passes until the words are done; the order of merges inside a word is the
+// reference's (bpe.cpp:1560-1589): by rule, then left to right.
+constexpr uint32_t ENC_DEAD = 0xffffffffu;  // a position a finished word no longer uses (never a token: id bits above ENC_UNKP)
+
+// priorities of two pairs, both rule-hash loads in flight together (w0 / w1: which of the two are asked for)
+__device__ inline void enc_pair_prio2(const EncModel &m, const uint32_t *bloom, bool w0, uint32_t a0, uint32_t b0, bool w1, uint32_t a1, uint32_t b1,
+                                      uint32_t *p0, uint32_t *p1) {
+  const uint32_t h0 = enc_hash(a0, b0), h1 = enc_hash(a1, b1);
+  const uint32_t g0 = enc_bloom_bits(h0), g1 = enc_bloom_bits(h1);
+  w0 = w0 && a0 != ENC_UNKP && b0 != ENC_UNKP && (bloom[enc_bloom_word(h0)] & g0) == g0;
+  w1 = w1 && a1 != ENC_UNKP && b1 != ENC_UNKP && (bloom[enc_bloom_word(h1)] & g1) == g1;
+  uint32_t s0 = h0 & m.rule_mask, s1 = h1 & m.rule_mask;
+  RuleSlot r0{PT_EMPTY, 0u, 0u}, r1{PT_EMPTY, 0u, 0u};
+  if (w0) r0 = enc_load_slot(m, s0);
+  if (w1) r1 = enc_load_slot(m, s1);
+  const unsigned long long k0 = pair_key(a0, b0), k1 = pair_key(a1, b1);
+  *p0 = ENC_INF;
+  *p1 = ENC_INF;
+  while (r0.key != PT_EMPTY) {
+    if (r0.key == k0) { *p0 = r0.pad; break; }
+    s0 = (s0 + 1) & m.rule_mask;
+    r0 = enc_load_slot(m, s0);
+  }
+  while (r1.key != PT_EMPTY) {
+    if (r1.key == k1) { *p1 = r1.pad; break; }
+    s1 = (s1 + 1) & m.rule_mask;
+    r1 = enc_load_slot(m, s1);
+  }
+}
+
+// Returns the new token count, or -1 when the pack is not the shape for this (a word longer than lane_max tokens: one lane would walk it
+// while 63 wait) -- nothing but wr / wm has been written then and merge_rounds takes over.
+__device__ int merge_lanes(const EncModel &m, const uint32_t *bloom, LdsArr wt, LdsArr wr, LdsArr wm, int n, int lane_max) {
+  const int lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+  const int nchunks = (n + 63) >> 6;
+  // the words: wm[w] = first token of word w, wm[nw] = n (a word has at least two tokens, so the list fits)
+  int nw = 0;
+  for (int c = 0; c < nchunks; c++) {
+    const int p = c * 64 + lane;
+    const bool ws = p < n && (wt.get(p) & TOK_WS);
+    const unsigned long long W = __ballot(ws);
+    if (ws) wm.set(nw + (int)__popcll(W & lt), (uint32_t)p);
+    nw += (int)__popcll(W);
+  }
+  if (lane == 0) wm.set(nw, (uint32_t)n);
+  wave_sync();
+  int longest = 0;
+  for (int w = lane; w < nw; w += 64) {
+    const int len = (int)(wm.get(w + 1) - wm.get(w));
+    longest = len > longest ? len : longest;
+  }
+  if (__ballot(longest > lane_max) != 0ull) return -1;
+  // every pair's priority, lanes = positions (the last pair of a word has none)
+  for (int c = 0; c < nchunks; c++) {
+    const int p = c * 64 + lane;
+    if (p < n) {
+      uint32_t r = ENC_INF;
+      if (p + 1 < n) {
+        const uint32_t t0 = wt.get(p), t1 = wt.get(p + 1);
+        const uint32_t a = t0 & ENC_IDM, b = t1 & ENC_IDM;
+        if (!(t1 & TOK_WS) && a != ENC_UNKP && b != ENC_UNKP) r = enc_pair_prio(m, bloom, a, b);
+      }
+      wr.set(p, r);
+    }
+  }
+  wave_sync();
+  for (int w0 = 0; w0 < nw; w0 += 64) {
+    const int w = w0 + lane;
+    int ws = 0, we = 0;
+    if (w < nw) {
+      ws = (int)wm.get(w);
+      we = (int)wm.get(w + 1);
+    }
+    const int we0 = we;
+    for (;;) {
+      // the word's smallest rule, leftmost site (the last token's pair has none: the scan may read it)
+      uint32_t mn = ENC_INF;
+      int at = ws;
+      for (int i = ws; i < we; i++) {
+        const uint32_t r = wr.get(i);
+        if (r < mn) {
+          mn = r;
+          at = i;
+        }
+      }
+      if (mn == ENC_INF) break;
+      // (at, at + 1) -> z, the tail moves up one place.  Another site of the same rule further right is the next round's leftmost
+      // minimum -- the pairs a merge makes rank behind the rule that made their token -- so sites go left to right like the reference's.
+      const uint32_t z = enc_rule_z(m, mn);
+      wt.set(at, z | (wt.get(at) & (TOK_WS | ENC_SENT)));
+      for (int i = at + 1; i + 1 < we; i++) {
+        wt.set(i, wt.get(i + 1));
+        wr.set(i, wr.get(i + 1));
+      }
+      we--;
+      const bool hl = at > ws, hr = at + 1 < we;
+      uint32_t pl, pr;
+      enc_pair_prio2(m, bloom, hl, hl ? wt.get(at - 1) & ENC_IDM : 0u, z, hr, z, hr ? wt.get(at + 1) & ENC_IDM : 0u, &pl, &pr);
+      if (hl) wr.set(at - 1, pl);
+      wr.set(at, pr);
+    }
+    for (int i = we; i < we0; i++) wt.set(i, ENC_DEAD);
+  }
+  wave_sync();
+  // close the gaps the words left
+  int base = 0;
+  for (int c = 0; c < nchunks; c++) {
+    const int p = c * 64 + lane;
+    const uint32_t t0 = p < n ? wt.get(p) : ENC_DEAD;
+    const bool alive = t0 != ENC_DEAD;
+    const unsigned long long AM = __ballot(alive);
+    wave_sync();
+    if (alive) wt.set(base + (int)__popcll(AM & lt), t0);
+    base += (int)__popcll(AM);
+    wave_sync();
+  }
+  return base;
+}
+
 // Cooperative path: one wavefront encodes one sentence, lanes = token positions.  wt = tokens (bit31 = first token of a
 // word), wr = priority of the pair that starts at p, wm = per-word minimum priority stored at the word's first position.
 // Sentences too long for the LDS arrays run the same code on HBM scratch (GlbArr).
@@ -499,7 +624,8 @@ struct SentView {
 __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8_t *__restrict__ text,
                            const SentView &sv, unsigned long long s, unsigned long long e, LdsArr wt, LdsArr wr,
                            LdsArr wm, int bos, int eos, int reverse, int32_t *__restrict__ scratch_ids, uint32_t *__restrict__ counts,
-                           const DropoutArgs &drop, int wcap /* tokens a pack may hold */, LdsArr dws, EvLds dq /* dropout: word starts, event queues */) {
+                           const DropoutArgs &drop, int wcap /* tokens a pack may hold */, LdsArr dws, EvLds dq /* dropout: word starts, event queues */,
+                           int lane_max /* words of up to this many tokens: one per lane (merge_lanes); 0 = never */) {
   const int lane = lane_id();
   const unsigned long long lt = lanemask_lt();
   int n = 0, consumed = 0, k = 0;
@@ -636,15 +762,8 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
   if (drop.enabled) {  // BPE-dropout: one word per lane (the RNG stream is keyed by the pack's first sentence)
     n = dropout_merge<LdsArr, LdsArr, EvLds>(m, wt, wr, wm, n, drop, s, dws, dq);
   } else {
-    for (int c = 0; c < ((n + 63) >> 6); c++) {
-      const int p = c * 64 + lane;
-      if (p < n) {
-        wr.set(p, ENC_DIRTY);
-        if (wt.get(p) & TOK_WS) wm.set(p, ENC_INF);
-      }
-    }
-    wave_sync();
-    n = merge_rounds<LdsArr>(m, bloom, wt, wr, wm, n);
+    const int nl = lane_max > 0 ? merge_lanes(m, bloom, wt, wr, wm, n, lane_max) : -1;
+    n = nl >= 0 ? nl : merge_rounds<LdsArr>(m, bloom, wt, wr, wm, n);
   }
   wave_sync();
   // ---- output (bpe.cpp:1591-1630).  wm[o] = ids of sentence o of the pack, wr[o] = ids emitted before its first token
@@ -704,7 +823,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
                                                    SentView sv, unsigned long long n_sent, int bos,
                                                    int eos, int reverse, int32_t *__restrict__ scratch_ids,
                                                    uint32_t *__restrict__ counts, uint32_t *__restrict__ work,
-                                                   unsigned long long work_stride, DropoutArgs drop, unsigned long long drop_stride, unsigned int group) {
+                                                   unsigned long long work_stride, DropoutArgs drop, unsigned long long drop_stride, unsigned int group, int lane_max) {
   __shared__ uint32_t lds[ENC_WAVES][3][ENC_WCAP];
   // 32 KB beside the working arrays -- 80 KB in all, two workgroups per CU (one byte more and it is one): the rules' Bloom filter, or with
   // dropout the waves' event queues (3 x 256 packed events each) and word starts (256 each)
@@ -737,7 +856,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
       }
       if (nbytes + 1 <= (unsigned long long)wcap) {
         sidx += (unsigned long long)encode_pack(m, bloom, text, sv, sidx, grp_end, a, b, c, bos, eos, reverse, scratch_ids, counts, d, wcap,
-                                                LdsArr{aux + ENC_WAVES * 3 * ENC_DROP_WCAP + wave * ENC_DROP_WCAP}, EvLds{aux + wave * 3 * ENC_DROP_WCAP});
+                                                LdsArr{aux + ENC_WAVES * 3 * ENC_DROP_WCAP + wave * ENC_DROP_WCAP}, EvLds{aux + wave * 3 * ENC_DROP_WCAP}, lane_max);
         continue;
       }
       // too long for the LDS arrays: one sentence at a time on the wavefront's HBM scratch
@@ -783,12 +902,16 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   if (group < 1) group = 1;
   if (group > (ends ? 64ull : 24ull)) group = ends ? 64 : 24;  // (the word cache's items are a few bytes each: a pack takes up to 64 of them)
   d.lds_queues = m.n_rules < (1u << 23) && !getenv("YTTM_DROPOUT_HBM_QUEUES");  // (tests: every queue in the HBM scratch)
+  // one word per lane (merge_lanes) for packs whose words have at most this many tokens; 0 = the wave-wide rounds only.
+  // YTTM_K5_LANE_WORDS: the word cache's distinct words, YTTM_K5_LANE_SENT: packed sentences
+  const char *lw = getenv("YTTM_K5_LANE_WORDS"), *ls = getenv("YTTM_K5_LANE_SENT");
+  const int lane_max = ends ? (lw ? atoi(lw) : 48) : (ls ? atoi(ls) : 48);
   if (d.enabled)
     hipLaunchKernelGGL(k5_encode<true>, dim3(n_blocks), dim3(ENC_THREADS), 0, st, m, text, SentView{offsets, ends}, n_sent, bos, eos, reverse, scratch_ids, counts,
-                       work, work_stride, d, drop_stride, (unsigned int)group);
+                       work, work_stride, d, drop_stride, (unsigned int)group, lane_max);
   else
     hipLaunchKernelGGL(k5_encode<false>, dim3(n_blocks), dim3(ENC_THREADS), 0, st, m, text, SentView{offsets, ends}, n_sent, bos, eos, reverse, scratch_ids, counts,
-                       work, work_stride, d, drop_stride, (unsigned int)group);
+                       work, work_stride, d, drop_stride, (unsigned int)group, lane_max);
 }
 void launch_encode_gather(const int32_t *scratch_ids, const unsigned long long *offsets, const unsigned long long *ends,
                           const unsigned long long *out_off, unsigned long long n_sent, int32_t *ids_out, hipStream_t st) {

@@ -245,7 +245,7 @@ struct WordCache {
   unsigned int extra_cap;
   unsigned int *status;       // bit 0: the table was too full
 };
-unsigned long long wcache_count_blocks(const WordCache &wc);
+unsigned long long wcache_count_cells(const WordCache &wc);  // counters launch_wcache_count_slots fills: workgroups x classes of word length
 void launch_wcache_insert(const EncModel &m, const uint8_t *text, unsigned long long total, const unsigned long long *offsets, unsigned long long n_sent,
                           const WordCache &wc, hipStream_t st);
 void launch_wcache_count_slots(const WordCache &wc, uint32_t *blk_cnt, hipStream_t st);
