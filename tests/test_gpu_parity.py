@@ -48,6 +48,23 @@ def test_k5_word_cache_fuzz(tmp_path):
     S.check_encode_word_cache_fuzz(tmp_path, trials=12)
 
 
+@pytest.mark.parametrize("sblk", [3, 64])
+def test_k5_word_cache_sentence_blocks(sblk, tmp_path, monkeypatch):
+    """the word cache's three walks over the text (k_wcache.hip: insert, count, scatter) take blocks of consecutive sentences as one run --
+    64 per wavefront in large batches, one in small ones like these tests' unless told otherwise: sentences of every length, empty ones,
+    ones that begin and end inside UTF-8 sequences, against the oracle"""
+    monkeypatch.setenv("YTTM_WC_SBLK", str(sblk))
+    S.check_encode_word_cache(n_sent=1500, seed=43)
+    S.check_encode_word_cache_fuzz(tmp_path, trials=8, seed=47)
+
+
+def test_k5_word_cache_crowded_short_region(tmp_path, monkeypatch):
+    """more distinct short words than the table's short region has slots (k_wcache.hip WC_SHORT_PROBES)"""
+    monkeypatch.setenv("YTTM_WC_SHORT_SLOTS", "16")
+    S.check_encode_word_cache(n_sent=1000, seed=37)
+    S.check_encode_word_cache_fuzz(tmp_path, trials=4, seed=41)
+
+
 @pytest.mark.parametrize("lane_max", [0, 5, 1000])
 def test_k5_one_word_per_lane(lane_max, monkeypatch):
     """the wave-wide merge rounds and merge_lanes (k_encode.hip) against the oracle: lanes never / for short words only / always"""

@@ -172,6 +172,23 @@ def test_encode_word_cache_fuzz(tmp_path):
     S.check_encode_word_cache_fuzz(tmp_path)
 
 
+@pytest.mark.parametrize("sblk", [3, 64])
+def test_encode_word_cache_sentence_blocks(sblk, tmp_path, monkeypatch):
+    """the word cache's three walks over the text (k_wcache.hip: insert, count, scatter) take blocks of consecutive sentences as one run --
+    64 per wavefront in large batches, one in small ones like these tests' unless told otherwise: sentences of every length, empty ones,
+    ones that begin and end inside UTF-8 sequences, against the oracle"""
+    monkeypatch.setenv("YTTM_WC_SBLK", str(sblk))
+    S.check_encode_word_cache(n_sent=80, seed=43)
+    S.check_encode_word_cache_fuzz(tmp_path, trials=4, seed=47)
+
+
+def test_encode_word_cache_crowded_short_region(tmp_path, monkeypatch):
+    """more distinct short words than the table's short region has slots: they go on in the whole table (k_wcache.hip WC_SHORT_PROBES)"""
+    monkeypatch.setenv("YTTM_WC_SHORT_SLOTS", "16")
+    S.check_encode_word_cache(n_sent=60, seed=37)
+    S.check_encode_word_cache_fuzz(tmp_path, trials=3, seed=41)
+
+
 @pytest.mark.parametrize("lane_max", [0, 5, 1000])
 def test_encode_one_word_per_lane(lane_max, monkeypatch):
     """K5's two ways through the merge rounds -- the wave-wide rounds and one word per lane (merge_lanes) -- are the oracle's ids both:

@@ -1,4 +1,4 @@
-"""GPU tuning aid: K5 by merge-round scheme (wave-wide rounds / one word per lane) and list order (table order / length classes), on the
+"""GPU tuning aid: K5 by merge-round scheme (wave-wide rounds / one word per lane) on the
 bench's 1e7 random 'abcd ' sentences and on Zipf text lines; FNV of the ids per variant (they must agree)."""
 import ctypes as C, os, sys, time
 import numpy as np
@@ -8,8 +8,10 @@ import gen, torch
 from youtokentome_amd import _lib
 L = _lib.load()
 err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
-VARIANTS = [("rounds, table order", "0", "0", "1"), ("rounds, classes", "0", "0", "8"), ("lanes, table order", "48", "48", "1"), ("lanes, classes", "48", "48", "8"),
-            ("lanes 32, classes", "32", "32", "8"), ("lanes 96, classes", "96", "96", "8")]
+VARIANTS = [("rounds, table order", "0", "0", "1", ""), ("rounds, classes", "0", "0", "8", ""), ("lanes, table order", "48", "48", "1", ""), ("lanes, classes", "48", "48", "8", ""),
+            ("lanes 32, classes", "32", "32", "8", ""), ("lanes 96, classes", "96", "96", "8", ""),
+            ("table order, short 2^18", "48", "48", "1", str(1 << 18)), ("table order, short 2^22", "48", "48", "1", str(1 << 22)),
+            ("table order, no short region", "48", "48", "1", str(1 << 31)), ("table order, short 2^16", "48", "48", "1", str(1 << 16))]
 n_abcd = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 KINDS = sys.argv[2].split(",") if len(sys.argv) > 2 else ["abcd", "zipf"]
 if len(sys.argv) > 3:  # variants by index
@@ -37,8 +39,11 @@ for kind in KINDS:
     d_off = torch.from_numpy(off).cuda()
     mx = int((off[1:] - off[:-1]).max())
     n_ids, kms = C.c_uint64(), C.c_double()
-    for name, lw, ls, cl in VARIANTS:
+    for name, lw, ls, cl, sh in VARIANTS:
         os.environ["YTTM_K5_LANE_WORDS"], os.environ["YTTM_K5_LANE_SENT"], os.environ["YTTM_K5_CLASSES"] = lw, ls, cl
+        os.environ.pop("YTTM_WC_SHORT_SLOTS", None)
+        if sh:
+            os.environ["YTTM_WC_SHORT_SLOTS"] = sh
         out = []
         for mode in (0, 1):
             L.yttm_encoder_set_cache(h, mode, 0)

@@ -1,0 +1,10 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $R/gpurun_out
+cd $R
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "k5 or encode or long_words" > gpurun_out/o_tests.log 2>&1
+tail -3 gpurun_out/o_tests.log
+VARIANTS="2" KIND=abcd bash tools/gpu/r4_m.sh 2>&1 | grep -E "^abcd|k5|fill"
+cd $R
+timeout 600 python tools/dbg/encode_ab.py 10000000 zipf 2 > gpurun_out/o_zipf.log 2>&1
+grep -E "^zipf" gpurun_out/o_zipf.log

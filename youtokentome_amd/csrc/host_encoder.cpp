@@ -242,7 +242,7 @@ int BaseEncoder::vocab_size() const {
 // ids into the lane's scratch, counts into `counts`.
 static void k5_pass(EncoderDevice &D, EncodeLane &d, const void *d_bytes, const unsigned long long *d_offsets, const unsigned long long *d_ends,
                     unsigned long long n_items, unsigned long long total_bytes, unsigned long long max_item_bytes, bool bos, bool eos, bool reverse,
-                    double dropout_prob, uint32_t *counts) {
+                    double dropout_prob, uint32_t *counts, const WordPublish *pub = nullptr) {
   d.grow(d.d_scratch, d.cap_scratch, (size_t)(2 * total_bytes + 2 * n_items + 2));
   unsigned int max_blocks = 256 * 2;  // 2 workgroups per CU (80 KB LDS each)
   const unsigned long long tok_cap = std::max<unsigned long long>(ENC_LDS_TOKENS, 2 * max_item_bytes + 2);  // tokens per item
@@ -261,7 +261,7 @@ static void k5_pass(EncoderDevice &D, EncodeLane &d, const void *d_bytes, const 
   const unsigned int n_blocks = (unsigned int)std::min<unsigned long long>(nb, max_blocks);
   if (tok_cap > (unsigned long long)ENC_LDS_TOKENS) {
     stride = tok_cap;
-    d.grow(d.d_work, d.cap_work, (size_t)(3 * stride * (unsigned long long)n_blocks * ENC_WAVES_PER_BLOCK));
+    d.grow(d.d_work, d.cap_work, (size_t)(3 * stride * (unsigned long long)(n_blocks + 1) * ENC_WAVES_PER_BLOCK));  // (+ 1: k5_words rounds its waves up to 16)
   }
   if (dropout_prob > 0) {
     drop_stride = tok_cap;
@@ -269,7 +269,7 @@ static void k5_pass(EncoderDevice &D, EncodeLane &d, const void *d_bytes, const 
   }
   const unsigned long long seed = mix64(D.seed_salt + 0x5bd1e995ull * (D.dropout_calls.fetch_add(1) + 1));
   launch_encode(D.m, (const uint8_t *)d_bytes, d_offsets, d_ends, n_items, bos, eos, reverse, d.d_scratch, counts, d.d_work, stride, n_blocks,
-                dropout_prob, seed, d.d_drop, drop_stride, d.st);
+                dropout_prob, seed, d.d_drop, drop_stride, d.st, pub);
 }
 
 // counts -> offsets (exclusive scan, the total behind the last one and on the host)
@@ -290,10 +290,14 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
                           unsigned long long *n_ids_out) {
   const uint8_t *text = (const uint8_t *)d_bytes;
   unsigned long long cap = 1024;
-  while (cap < total_bytes / 8 && cap < (1ull << 31)) cap <<= 1;  // (a slot per 8 bytes of text; text has far fewer distinct words)
+  // a slot per 16 bytes of text or more: text has far fewer distinct words (1e7 random 'abcd ' sentences: one per 64 bytes), and the passes
+  // over the table -- clearing it, listing its words -- cost by its size; a batch that does fill it is inserted again into twice the slots
+  while (cap < total_bytes / 16 && cap < (1ull << 31)) cap <<= 1;
   WordCache wc{};
   unsigned long long n_table = 0;
   unsigned int misc[2] = {0, 0};
+  unsigned long long short_cap = 1ull << 20;  // slots the words of up to 7 bytes start in (k_wcache.hip wc_insert_word): 8 MB of keys
+  if (const char *e = getenv("YTTM_WC_SHORT_SLOTS")) short_cap = std::max<unsigned long long>(16, strtoull(e, nullptr, 10));  // (measurements, tests; a power of two)
   for (;;) {
     d.grow(d.d_wc_slot, d.cap_wc_slot, (size_t)cap);
     d.grow(d.d_wc_pos, d.cap_wc_pos, (size_t)cap);
@@ -303,6 +307,7 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
     wc.slot = d.d_wc_slot;
     wc.pos = d.d_wc_pos;
     wc.mask = cap - 1;
+    wc.short_mask = std::min(cap, short_cap) - 1;
     wc.occ = d.d_wc_occ;
     wc.extra = d.d_wc_extra;
     wc.extra_n = d.d_wc_misc;
@@ -312,15 +317,21 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
     HIP_CHECK(hipMemsetAsync(wc.occ, 0xff, (size_t)((total_bytes + n_sent) / 2 + 2) * 4, d.st));  // (no word starts anywhere yet)
     HIP_CHECK(hipMemsetAsync(d.d_wc_misc, 0, 8, d.st));
     launch_wcache_insert(D.m, text, total_bytes, d_offsets, n_sent, wc, d.st);
-    const unsigned long long n_blk = wcache_count_cells(wc);
+    const unsigned long long n_blk = wcache_count_blocks(wc);
     d.grow(d.d_wc_blk, d.cap_wc_blk, (size_t)n_blk);
     d.grow(d.d_wc_blk_off, d.cap_wc_blk_off, (size_t)n_blk + 1);
     launch_wcache_count_slots(wc, d.d_wc_blk, d.st);
     HIP_CHECK(hipMemcpyAsync(misc, d.d_wc_misc, 8, hipMemcpyDeviceToHost, d.st));
     n_table = scan_counts(d, d.d_wc_blk, n_blk, d.d_wc_blk_off);  // (syncs)
     if (!(misc[1] & 1u)) break;
+    // too full for the probe limit: start over -- with the short words spread wider if it may have been them, else with twice the slots
+    if (short_cap < cap) {
+      short_cap = std::min(cap, short_cap << 3);
+      continue;
+    }
     if (cap >= (1ull << 31)) throw GpuError{"encode: the word table does not fit"};
-    cap <<= 1;  // too full for the probe limit: start over with twice the slots
+    cap <<= 1;
+    short_cap = cap;
   }
   const unsigned long long n_extra = misc[0], n_words = n_table + n_extra;
   d.last_distinct_words = n_words;
@@ -331,8 +342,9 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
   d.grow(d.d_ucounts, d.cap_ucounts, (size_t)n_words + 1);
   launch_wcache_list(wc, d.d_wc_blk_off, n_table, d.d_ustart, d.d_uend, d.d_uslot, d.st);
   if (n_words) {  // (the distinct words' ids stay where K5 puts them, in the lane's scratch: the sentences are assembled from there)
-    k5_pass(D, d, d_bytes, d.d_ustart, d.d_uend, n_words, total_bytes, max_sentence_bytes, false, false, false, 0.0, d.d_ucounts);
-    launch_wcache_publish(wc, n_table, n_words, d.d_uslot, d.d_ustart, d.d_ucounts, d.st);
+    // (k5_words leaves in every word's table slot where its ids are and how many)
+    const WordPublish pub{wc.slot, d.d_uslot, n_table, wc.extra};
+    k5_pass(D, d, d_bytes, d.d_ustart, d.d_uend, n_words, total_bytes, max_sentence_bytes, false, false, false, 0.0, d.d_ucounts, &pub);
   }
   launch_wcache_count(d_offsets, n_sent, wc, (bos ? 1 : 0) + (eos ? 1 : 0), d.d_counts, d.st);
   const unsigned long long total = scan_counts(d, d.d_counts, n_sent, d.d_out_off);

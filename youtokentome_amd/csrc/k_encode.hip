@@ -472,6 +472,40 @@ __device__ inline void enc_pair_prio2(const EncModel &m, const uint32_t *bloom, 
   }
 }
 
+// One lane, one word: tokens wt[ws, we), pair priorities wr[ws, we) (the last one ENC_INF).  Returns the new end.
+__device__ inline int lane_rounds(const EncModel &m, const uint32_t *bloom, LdsArr wt, LdsArr wr, int ws, int we) {
+  for (;;) {
+    // the word's smallest rule, leftmost site (the last token's pair has none: the scan may read it)
+    uint32_t mn = ENC_INF;
+    int at = ws;
+    for (int i = ws; i < we; i++) {
+      const uint32_t r = wr.get(i);
+      if (r < mn) {
+        mn = r;
+        at = i;
+      }
+    }
+    if (mn == ENC_INF) break;
+    // (at, at + 1) -> z, the tail moves up one place.  Another site of the same rule further right is the next round's leftmost
+    // minimum -- the pairs a merge makes rank behind the rule that made their token -- so sites go left to right like the reference's.
+    const uint32_t z = enc_rule_z(m, mn);
+    const uint32_t flags = wt.get(at) & (TOK_WS | ENC_SENT);
+    wt.set(at, z | flags);
+    for (int i = at + 1; i + 1 < we; i++) {
+      wt.set(i, wt.get(i + 1));
+      wr.set(i, wr.get(i + 1));
+    }
+    we--;
+    const uint32_t tr = at + 1 < we ? wt.get(at + 1) : TOK_WS;
+    const bool hl = at > ws && !(flags & TOK_WS), hr = !(tr & TOK_WS);  // (no pair across a word start)
+    uint32_t pl, pr;
+    enc_pair_prio2(m, bloom, hl, hl ? wt.get(at - 1) & ENC_IDM : 0u, z, hr, z, tr & ENC_IDM, &pl, &pr);
+    if (hl) wr.set(at - 1, pl);
+    wr.set(at, pr);
+  }
+  return we;
+}
+
 // Returns the new token count, or -1 when the pack is not the shape for this (a word longer than lane_max tokens: one lane would walk it
 // while 63 wait) -- nothing but wr / wm has been written then and merge_rounds takes over.
 __device__ int merge_lanes(const EncModel &m, const uint32_t *bloom, LdsArr wt, LdsArr wr, LdsArr wm, int n, int lane_max) {
@@ -517,33 +551,7 @@ __device__ int merge_lanes(const EncModel &m, const uint32_t *bloom, LdsArr wt, 
       we = (int)wm.get(w + 1);
     }
     const int we0 = we;
-    for (;;) {
-      // the word's smallest rule, leftmost site (the last token's pair has none: the scan may read it)
-      uint32_t mn = ENC_INF;
-      int at = ws;
-      for (int i = ws; i < we; i++) {
-        const uint32_t r = wr.get(i);
-        if (r < mn) {
-          mn = r;
-          at = i;
-        }
-      }
-      if (mn == ENC_INF) break;
-      // (at, at + 1) -> z, the tail moves up one place.  Another site of the same rule further right is the next round's leftmost
-      // minimum -- the pairs a merge makes rank behind the rule that made their token -- so sites go left to right like the reference's.
-      const uint32_t z = enc_rule_z(m, mn);
-      wt.set(at, z | (wt.get(at) & (TOK_WS | ENC_SENT)));
-      for (int i = at + 1; i + 1 < we; i++) {
-        wt.set(i, wt.get(i + 1));
-        wr.set(i, wr.get(i + 1));
-      }
-      we--;
-      const bool hl = at > ws, hr = at + 1 < we;
-      uint32_t pl, pr;
-      enc_pair_prio2(m, bloom, hl, hl ? wt.get(at - 1) & ENC_IDM : 0u, z, hr, z, hr ? wt.get(at + 1) & ENC_IDM : 0u, &pl, &pr);
-      if (hl) wr.set(at - 1, pl);
-      wr.set(at, pr);
-    }
+    we = lane_rounds(m, bloom, wt, wr, ws, we);
     for (int i = we; i < we0; i++) wt.set(i, ENC_DEAD);
   }
   wave_sync();
@@ -630,113 +638,7 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
   const unsigned long long lt = lanemask_lt();
   int n = 0, consumed = 0, k = 0;
   unsigned long long my_sid = 0;  // lane j: index of the j-th non-empty sentence of the pack
-  if (sv.end) {
-    // The word cache's distinct words: dozens of items of a few bytes each per pack.  Tokenizing them one after the other (the loop
-    // below) is a chain of dependent loads per item -- bounds, bytes, cpmap -- with a handful of lanes busy; here the items of the
-    // pack are laid end to end and tokenized 64 bytes at a time whichever item a byte belongs to.  (wr and wm are free until the
-    // merge rounds start: wm[j] = first byte of item j in the concatenation, wr = the items' addresses, token counts, index map.)
-    const unsigned long long avail = e - s < 64ull ? e - s : 64ull;
-    unsigned long long lo = 0;
-    uint32_t len = 0;
-    if ((unsigned long long)lane < avail) {
-      lo = sv.lo(s + lane);
-      len = (uint32_t)(sv.hi(s + lane) - lo);  // (the caller saw that the first item fits; a longer one ends the pack)
-      if (sv.hi(s + lane) - lo >= (unsigned long long)ENC_WCAP) len = ENC_WCAP;
-    }
-    const uint32_t need = (unsigned long long)lane < avail ? len + 1u : 0u;
-    const uint32_t pre = wave_incl_scan(need);
-    const unsigned long long FIT = __ballot((unsigned long long)lane < avail && pre <= (uint32_t)ENC_WCAP);
-    const int cnt = (int)__popcll(FIT);  // items 0 .. cnt-1 fit (the sizes add up: a prefix of the lanes)
-    const uint32_t base = pre - need - (uint32_t)lane;  // bytes before item `lane`
-    if (lane < cnt) {
-      wm.set(lane, base);
-      wr.set(2 * lane, (uint32_t)lo);
-      wr.set(2 * lane + 1, (uint32_t)(lo >> 32));
-      wr.set(128 + lane, 0u);
-    }
-    const uint32_t T = (uint32_t)__shfl(base + len, cnt - 1);  // bytes in all
-    if (lane == 0) wm.set(cnt, T);
-    wave_sync();
-    bool carry_space = true, carry_unk = false;
-    int carry_item = -1;
-    for (uint32_t t0 = 0; t0 < T; t0 += 64) {
-      const uint32_t t = t0 + (uint32_t)lane;
-      int it = 0;
-      bool valid = false, space = false, unk = false;
-      uint32_t id = 0;
-      if (t < T) {
-        int a = 0, b = cnt;  // item of byte t: the last one that starts at or before it
-        while (b - a > 1) {
-          const int mid = (a + b) >> 1;
-          if (wm.get(mid) <= t) a = mid; else b = mid;
-        }
-        it = a;
-        const uint32_t i = t - wm.get(it), nb = wm.get(it + 1) - wm.get(it);
-        const uint8_t *sp = text + (((unsigned long long)wr.get(2 * it + 1) << 32) | wr.get(2 * it));
-        if (u8_is_start(sp, i, nb)) {
-          uint32_t clen;
-          const uint32_t cp = u8_decode_at(sp, i, nb, &clen);
-          if (cp != INVALID_CP) {
-            valid = true;
-            id = m.cpmap[cp];
-            space = id == CP_SPACE;
-            unk = id == CP_UNK;
-          }
-        }
-      }
-      const unsigned long long V = __ballot(valid), S = __ballot(space), U = __ballot(unk);
-      bool prev_space = carry_space, prev_unk = carry_unk;
-      int prev_item = carry_item;
-      const unsigned long long pv = V & lt;
-      const int jj = pv ? 63 - __clzll((long long)pv) : 0;
-      const int item_jj = __shfl(it, jj);
-      if (pv) {
-        prev_space = (S >> jj) & 1ull;
-        prev_unk = (U >> jj) & 1ull;
-        prev_item = item_jj;
-      }
-      const bool item_first = prev_item != it;  // no valid char of this item before this one
-      if (item_first) { prev_space = true; prev_unk = false; }
-      int emit = 0;
-      if (valid && !space) {
-        const bool wstart = prev_space;
-        if (unk && prev_unk && !wstart) emit = 0;
-        else emit = wstart ? 2 : 1;
-      }
-      const unsigned long long e1 = __ballot(emit >= 1), e2 = __ballot(emit == 2);
-      const int pos = n + __popcll(e1 & lt) + __popcll(e2 & lt);
-      const uint32_t tv = unk ? ENC_UNKP : id;
-      if (emit == 2) {
-        wt.set(pos, m.space_id | TOK_WS | (item_first ? ENC_SENT : 0u));
-        wt.set(pos + 1, tv);
-      } else if (emit == 1) {
-        wt.set(pos, tv);
-      }
-      if (emit) atomicAdd(&wr.p[128 + it], 1u);
-      n += __popcll(e1) + __popcll(e2);
-      if (V) {
-        const int j2 = 63 - __clzll((long long)V);
-        carry_space = (S >> j2) & 1ull;
-        carry_unk = (U >> j2) & 1ull;
-        carry_item = __shfl(it, j2);
-      }
-    }
-    wave_sync();
-    const bool nonempty = lane < cnt && wr.get(128 + lane) != 0u;
-    const unsigned long long NE = __ballot(nonempty);
-    if (lane < cnt && !nonempty) counts[s + lane] = 0u;  // (word mode runs without bos / eos)
-    if (nonempty) {
-      const int r = (int)__popcll(NE & lt);
-      wr.set(192 + 2 * r, (uint32_t)(s + lane));
-      wr.set(193 + 2 * r, (uint32_t)((s + lane) >> 32));
-    }
-    wave_sync();
-    k = (int)__popcll(NE);
-    if (lane < k) my_sid = ((unsigned long long)wr.get(193 + 2 * lane) << 32) | wr.get(192 + 2 * lane);
-    consumed = cnt;
-    wave_sync();
-  }
-  for (unsigned long long j = s; !sv.end && j < e && k < 64; j++) {
+  for (unsigned long long j = s; j < e && k < 64; j++) {
     const unsigned long long b0 = sv.lo(j), nbytes = sv.hi(j) - b0;
     if (nbytes + 1 > (unsigned long long)(wcap - n)) break;
     const int n0 = n;
@@ -870,6 +772,192 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
   }
 }
 
+// ---- K5 for the word cache's distinct words (k_wcache.hip) -------------------------------------------------------------------
+// Item j = bytes [ustart[j], uend[j]) of the text: one word, its ids to scratch + 2 ustart[j], where and how many to its table slot (pub); no bos / eos,
+// no dropout.  A wavefront packs up to 64 consecutive ones -- one per lane -- into its share of the
+// LDS: tokens and pair priorities only (lane_rounds), so a pack holds ENCW_LANE_TOKENS tokens, and one workgroup of 16 waves per CU
+// shares a single copy of the rules' Bloom filter: 16 x 7.5 KB + 32 KB = 152 KB.  An item of more than lane_max tokens is walked by the
+// whole wave instead (encode_wave: thirds of the share, or the HBM scratch when even that is too small).
+__device__ inline void word_publish(const WordPublish &pub, unsigned long long u, unsigned long long ids_at, uint32_t n) {
+  if (u < pub.n_table) {
+    pub.slot[pub.uslot[u]] = (ids_at << 20) | n;  // (a cached word has at most 65 536 ids)
+  } else {
+    pub.extra[2 * (u - pub.n_table)] = ids_at;
+    pub.extra[2 * (u - pub.n_table) + 1] = n;
+  }
+}
+constexpr int ENCW_WAVES = 16;
+constexpr int ENCW_POOL = 1920;                    // LDS words per wave
+constexpr int ENCW_LANE_TOKENS = ENCW_POOL / 2;    // a pack of words, one per lane: tokens + priorities
+constexpr int ENCW_WAVE_TOKENS = ENCW_POOL / 3;    // a word the wave walks together: tokens + priorities + minima
+__global__ __launch_bounds__(ENCW_WAVES * 64) void k5_words(EncModel m, const uint8_t *__restrict__ text, const unsigned long long *__restrict__ ustart,
+                                                            const unsigned long long *__restrict__ uend, unsigned long long n_words,
+                                                            int32_t *__restrict__ scratch_ids, uint32_t *__restrict__ counts, uint32_t *__restrict__ work,
+                                                            unsigned long long work_stride, unsigned int group, int lane_max, WordPublish pub) {
+  __shared__ uint32_t pool[ENCW_WAVES][ENCW_POOL];
+  __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
+  for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += ENCW_WAVES * 64) bloom[i] = m.bloom[i];
+  __syncthreads();
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+  const unsigned long long gw = (unsigned long long)blockIdx.x * ENCW_WAVES + wave;
+  const unsigned long long n_waves = (unsigned long long)gridDim.x * ENCW_WAVES;
+  uint32_t *mine = pool[wave];
+  const LdsArr wt{mine}, wr{mine + ENCW_LANE_TOKENS};
+  DropoutArgs nodrop{};
+  const unsigned long long n_groups = (n_words + group - 1) / group;
+  for (unsigned long long grp = gw; grp < n_groups; grp += n_waves) {
+    unsigned long long sidx = grp * group;
+    const unsigned long long grp_end = sidx + group < n_words ? sidx + group : n_words;
+    while (sidx < grp_end) {
+      const unsigned long long avail = grp_end - sidx < 64ull ? grp_end - sidx : 64ull;
+      unsigned long long lo = 0, len64 = 0;
+      if ((unsigned long long)lane < avail) {
+        lo = ustart[sidx + lane];
+        len64 = uend[sidx + lane] - lo;
+      }
+      const uint32_t len = len64 > 0x7ffffffeull ? 0x7ffffffeu : (uint32_t)len64;
+      const uint32_t need = (unsigned long long)lane < avail ? len + 1u : 0u;  // a word of B bytes: at most B + 1 tokens
+      const unsigned long long LONG = __ballot(need > (uint32_t)lane_max);
+      if (LONG & 1ull) {  // the first item is a long word: the whole wave on it
+        const unsigned long long b0 = ((unsigned long long)from_lane0((uint32_t)(lo >> 32)) << 32) | from_lane0((uint32_t)lo);
+        const unsigned long long nbytes = ((unsigned long long)from_lane0((uint32_t)(len64 >> 32)) << 32) | from_lane0((uint32_t)len64);
+        int32_t *out = scratch_ids + 2 * b0;
+        if (nbytes + 1 <= (unsigned long long)ENCW_WAVE_TOKENS) {
+          encode_wave(m, bloom, text + b0, nbytes, LdsArr{mine}, LdsArr{mine + ENCW_WAVE_TOKENS}, LdsArr{mine + 2 * ENCW_WAVE_TOKENS}, 0, 0, 0, out,
+                      &counts[sidx], nodrop, sidx);
+        } else {
+          uint32_t *w = work + gw * 3 * work_stride;
+          encode_wave(m, bloom, text + b0, nbytes, GlbArr{w}, GlbArr{w + work_stride}, GlbArr{w + 2 * work_stride}, 0, 0, 0, out, &counts[sidx], nodrop,
+                      sidx);
+        }
+        wave_sync();
+        if (lane == 0) word_publish(pub, sidx, 2 * b0, counts[sidx]);
+        sidx++;
+        continue;
+      }
+      // the items before the first long one, as many as fit: their bytes laid end to end and tokenized 64 at a time whichever item a byte
+      // belongs to (wr is free until the rounds start: item j's first byte in the concatenation, its address, its number of tokens)
+      const uint32_t pre = wave_incl_scan(need);
+      const unsigned long long before_long = LONG ? (LONG & (0ull - LONG)) - 1ull : ~0ull;
+      const unsigned long long FIT = __ballot((unsigned long long)lane < avail && pre <= (uint32_t)ENCW_LANE_TOKENS) & before_long;
+      const int cnt = (int)__popcll(FIT);  // (a prefix of the lanes; >= 1: the first item is not long)
+      const uint32_t base = pre - need - (uint32_t)lane;  // bytes before item `lane`
+      if (lane < cnt) {
+        wr.set(lane, base);
+        wr.set(128 + 2 * lane, (uint32_t)lo);
+        wr.set(129 + 2 * lane, (uint32_t)(lo >> 32));
+        wr.set(256 + lane, 0u);
+      }
+      const uint32_t T = (uint32_t)__shfl((int)(base + len), cnt - 1);  // bytes in all
+      if (lane == 0) wr.set(cnt, T);
+      wave_sync();
+      int n = 0;
+      bool carry_space = true, carry_unk = false;
+      int carry_item = -1;
+      for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+        const uint32_t t = t0 + (uint32_t)lane;
+        int it = 0;
+        bool valid = false, space = false, unk = false;
+        uint32_t id = 0;
+        if (t < T) {
+          int a = 0, b = cnt;  // item of byte t: the last one that starts at or before it
+          while (b - a > 1) {
+            const int mid = (a + b) >> 1;
+            if (wr.get(mid) <= t) a = mid; else b = mid;
+          }
+          it = a;
+          const uint32_t i = t - wr.get(it), nb = wr.get(it + 1) - wr.get(it);
+          const uint8_t *sp = text + (((unsigned long long)wr.get(129 + 2 * it) << 32) | wr.get(128 + 2 * it));
+          if (u8_is_start(sp, i, nb)) {
+            uint32_t clen;
+            const uint32_t cp = u8_decode_at(sp, i, nb, &clen);
+            if (cp != INVALID_CP) {
+              valid = true;
+              id = m.cpmap[cp];
+              space = id == CP_SPACE;
+              unk = id == CP_UNK;
+            }
+          }
+        }
+        const unsigned long long V = __ballot(valid), S = __ballot(space), U = __ballot(unk);
+        bool prev_space = carry_space, prev_unk = carry_unk;
+        int prev_item = carry_item;
+        const unsigned long long pv = V & lt;
+        const int jj = pv ? 63 - __clzll((long long)pv) : 0;
+        const int item_jj = __shfl(it, jj);
+        if (pv) {
+          prev_space = (S >> jj) & 1ull;
+          prev_unk = (U >> jj) & 1ull;
+          prev_item = item_jj;
+        }
+        if (prev_item != it) {  // no valid char of this item before this one
+          prev_space = true;
+          prev_unk = false;
+        }
+        int emit = 0;
+        if (valid && !space) {
+          if (unk && prev_unk && !prev_space) emit = 0;  // continues a run of unknown chars (bpe.cpp:1517-1527)
+          else emit = prev_space ? 2 : 1;
+        }
+        const unsigned long long e1 = __ballot(emit >= 1), e2 = __ballot(emit == 2);
+        const int pos = n + (int)__popcll(e1 & lt) + (int)__popcll(e2 & lt);
+        const uint32_t tv = unk ? ENC_UNKP : id;
+        if (emit == 2) {
+          wt.set(pos, m.space_id | TOK_WS);  // every word starts with the space token (bpe.cpp:1514)
+          wt.set(pos + 1, tv);
+        } else if (emit == 1) {
+          wt.set(pos, tv);
+        }
+        if (emit) atomicAdd(&wr.p[256 + it], (uint32_t)emit);
+        n += (int)__popcll(e1) + (int)__popcll(e2);
+        if (V) {
+          const int j2 = 63 - __clzll((long long)V);
+          carry_space = (S >> j2) & 1ull;
+          carry_unk = (U >> j2) & 1ull;
+          carry_item = __shfl(it, j2);
+        }
+      }
+      wave_sync();
+      const uint32_t ntok = lane < cnt ? wr.get(256 + lane) : 0u;
+      const uint32_t tend = wave_incl_scan(ntok);
+      const int ws = (int)(tend - ntok);
+      int we = (int)tend;
+      wave_sync();
+      // every pair's priority, lanes = positions
+      for (int c = 0; c < ((n + 63) >> 6); c++) {
+        const int p = c * 64 + lane;
+        if (p < n) {
+          uint32_t r = ENC_INF;
+          if (p + 1 < n) {
+            const uint32_t ta = wt.get(p), tb = wt.get(p + 1);
+            const uint32_t a = ta & ENC_IDM, b = tb & ENC_IDM;
+            if (!(tb & TOK_WS) && a != ENC_UNKP && b != ENC_UNKP) r = enc_pair_prio(m, bloom, a, b);
+          }
+          wr.set(p, r);
+        }
+      }
+      wave_sync();
+      if (ntok) we = lane_rounds(m, bloom, wt, wr, ws, we);
+      // output (bpe.cpp:1591-1630): a lane writes its word's ids; an unmerged space token with id 0 is dropped, a run of unknown chars is unk_id
+      if (lane < cnt) {
+        int32_t *out = scratch_ids + 2 * lo;
+        uint32_t q = 0;
+        for (int i = ws; i < we; i++) {
+          const uint32_t tk = wt.get(i);
+          if (tk != TOK_WS) {
+            const uint32_t id = tk & ENC_IDM;
+            out[q++] = (int32_t)(id == ENC_UNKP ? (uint32_t)m.unk_id : id);
+          }
+        }
+        word_publish(pub, sidx + lane, 2 * lo, q);
+      }
+      wave_sync();
+      sidx += (unsigned long long)cnt;
+    }
+  }
+}
+
 // copy ids from the over-allocated scratch to the packed output (one wave per sentence)
 __global__ __launch_bounds__(BLOCK) void k5_gather(const int32_t *__restrict__ scratch_ids, SentView sv,
                                                    const unsigned long long *__restrict__ out_off, unsigned long long n_sent,
@@ -887,7 +975,7 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
                    unsigned long long n_sent, int bos,
                    int eos, int reverse, int32_t *scratch_ids, uint32_t *counts, uint32_t *work, unsigned long long work_stride,
                    unsigned int n_blocks, double dropout_prob, unsigned long long seed, uint32_t *drop_scratch,
-                   unsigned long long drop_stride, hipStream_t st) {
+                   unsigned long long drop_stride, hipStream_t st, const WordPublish *pub) {
   if (!n_sent) return;
   DropoutArgs d{};
   d.enabled = dropout_prob > 0;
@@ -900,12 +988,23 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   // sentences per wavefront group: large enough that packs are full, small enough that every wavefront of the launch has work
   unsigned long long group = n_sent / ((unsigned long long)n_blocks * ENC_WAVES * 4);
   if (group < 1) group = 1;
-  if (group > (ends ? 64ull : 24ull)) group = ends ? 64 : 24;  // (the word cache's items are a few bytes each: a pack takes up to 64 of them)
+  if (group > 24) group = 24;
   d.lds_queues = m.n_rules < (1u << 23) && !getenv("YTTM_DROPOUT_HBM_QUEUES");  // (tests: every queue in the HBM scratch)
   // one word per lane (merge_lanes) for packs whose words have at most this many tokens; 0 = the wave-wide rounds only.
   // YTTM_K5_LANE_WORDS: the word cache's distinct words, YTTM_K5_LANE_SENT: packed sentences
   const char *lw = getenv("YTTM_K5_LANE_WORDS"), *ls = getenv("YTTM_K5_LANE_SENT");
   const int lane_max = ends ? (lw ? atoi(lw) : 48) : (ls ? atoi(ls) : 48);
+  if (ends && !d.enabled && pub) {  // the word cache's distinct words
+    unsigned int wblocks = (n_blocks + 1) / 2;  // (16 waves each: never more waves than n_blocks + 1 of k5_encode's -- the HBM scratch is sized for those)
+    if (wblocks > 256) wblocks = 256;
+    const unsigned long long waves = (unsigned long long)wblocks * ENCW_WAVES;
+    unsigned long long wgroup = n_sent / (waves * 8);  // items a wave takes at a time: packs are cut at a group's end, so many packs per group,
+    wgroup = wgroup < 64 ? 64 : wgroup > 512 ? 512 : wgroup;  // and several groups per wave
+    hipLaunchKernelGGL(k5_words, dim3(wblocks), dim3(ENCW_WAVES * 64), 0, st, m, text, offsets, ends, n_sent, scratch_ids, counts, work, work_stride,
+                       (unsigned int)wgroup, lane_max < 0 ? 0 : lane_max > ENCW_LANE_TOKENS ? ENCW_LANE_TOKENS : lane_max /* 0: every word by the whole wave (tests) */,
+                       *pub);
+    return;
+  }
   if (d.enabled)
     hipLaunchKernelGGL(k5_encode<true>, dim3(n_blocks), dim3(ENC_THREADS), 0, st, m, text, SentView{offsets, ends}, n_sent, bos, eos, reverse, scratch_ids, counts,
                        work, work_stride, d, drop_stride, (unsigned int)group, lane_max);

@@ -5,8 +5,9 @@
 //   1. k5w_insert   every word occurrence of the batch -> its slot in a batch-local hash table of distinct words (words of up to
 //                   7 bytes ARE their key; longer ones are keyed by hash tag + length + position of the first occurrence and
 //                   compared as bytes), the slot remembered per occurrence;
-//   2. the distinct words, compacted out of the table, go through K5 (k_encode.hip) as if each were a sentence -- the same
-//                   tokenizer, the same merge rounds, so the ids are K5's ids by construction;
+//   2. the distinct words, compacted out of the table, go through K5 (k_encode.hip k5_words) as if each were a sentence -- the same
+//                   tokenizer, the same merges in the same order, so the ids are K5's ids by construction; a word's table slot then
+//                   says where its ids are and how many;
 //   3. k5w_count / k5w_scatter   per sentence: the words' ids, looked up through the table, are laid end to end.
 // BPE-dropout draws per occurrence and never comes here.  A "word" is what enc_tokenize makes of the bytes: a maximal run of
 // valid non-space chars; invalid bytes inside it are part of its key (two spellings of one word then take two slots, which is
@@ -22,8 +23,9 @@ constexpr uint32_t WC_MAX_LEN = 0xffffu;                 // longer words are not
 constexpr uint32_t WC_EXTRA = 0x80000000u;               // occ value: index into `extra` instead of a table slot
 constexpr uint32_t WC_NONE = 0xffffffffu;                // occ value: no word starts here
 constexpr int WC_MAX_PROBES = 512;
+constexpr int WC_SHORT_PROBES = 24;                      // slots a short word tries in the table's short region before it goes on in the whole table
+constexpr int WC_SBLK = 64;                              // sentences a wavefront of the flat walks (insert, count, scatter) takes at a time, at most
 constexpr unsigned int WC_CBLK = BLOCK * 8;              // table slots per workgroup of the compaction kernels
-constexpr int WC_CLASSES = 8;                            // classes of word length the list of distinct words is laid out in
 
 // bytes [pos, pos + 8) of the text, for any alignment of pos (the text itself is 8-byte aligned; the caller has checked that the 16 bytes from
 // pos & ~7 on lie inside it)
@@ -55,51 +57,6 @@ __device__ inline bool wc_bytes_equal(const uint8_t *__restrict__ text, unsigned
   return true;
 }
 
-// One 64-byte step of the walk over a sentence's words: lane = byte b0 + lane; position nbytes acts as a space behind the text.
-// Returns true in the lane that CLOSES a word (the space behind it), with the word's bytes [*ws, *we).  Same classification as
-// enc_tokenize (k_encode.hip): chars by the reference's left-to-right decode, invalid bytes dropped, spaces by cpmap.
-struct WordWalk {
-  bool carry_space = true;             // class of the last valid char so far (the start of a sentence acts like a space)
-  unsigned long long carry_start = 0;  // first byte of the word that is open at the end of the previous step
-};
-__device__ inline bool wc_walk_step(const EncModel &m, const uint8_t *__restrict__ s, unsigned long long nbytes, unsigned long long b0, uint32_t byte /* s[b0 + lane], 0 behind the end */,
-                                    WordWalk &st, unsigned long long *ws, unsigned long long *we) {
-  const int lane = lane_id();
-  const unsigned long long lt = lanemask_lt();
-  const unsigned long long i = b0 + (unsigned long long)lane;
-  bool valid = false, space = false;
-  if (__ballot(byte >= 0x80u) == 0ull) {  // 64 ASCII bytes (the usual step): every byte is a char, the spaces are utils.cpp:99-101's
-    valid = i <= nbytes;
-    space = i == nbytes || byte == 32u || (byte - 9u) < 5u;
-  } else if (i < nbytes) {
-    if (u8_is_start(s, i, nbytes)) {
-      uint32_t len;
-      const uint32_t cp = u8_decode_at(s, i, nbytes, &len);
-      if (cp != INVALID_CP) {
-        valid = true;
-        space = m.cpmap[cp] == CP_SPACE;
-      }
-    }
-  } else if (i == nbytes) {
-    valid = space = true;
-  }
-  const unsigned long long V = __ballot(valid), S = __ballot(space);
-  bool prev_space = st.carry_space;
-  const unsigned long long pv = V & lt;
-  if (pv) prev_space = (S >> (63 - __clzll((long long)pv))) & 1ull;
-  const bool wstart = valid && !space && prev_space;
-  const bool closing = valid && space && !prev_space;
-  const unsigned long long WSM = __ballot(wstart);
-  unsigned long long start = st.carry_start;
-  const unsigned long long wlt = WSM & lt;
-  if (wlt) start = b0 + (unsigned long long)(63 - __clzll((long long)wlt));
-  *ws = start;
-  *we = i;
-  if (V) st.carry_space = (S >> (63 - __clzll((long long)V))) & 1ull;
-  if (WSM) st.carry_start = b0 + (unsigned long long)(63 - __clzll((long long)WSM));
-  return closing;
-}
-
 // ---- 1. every word occurrence -> table slot ------------------------------------------------------------------------------------
 // one word: look it up / insert it, remember its slot at occ[oidx]
 __device__ inline void wc_insert_word(const uint8_t *__restrict__ text, unsigned long long total, const WordCache &wc, unsigned long long pos,
@@ -122,10 +79,13 @@ __device__ inline void wc_insert_word(const uint8_t *__restrict__ text, unsigned
     h = wc_hash_long(text, total, pos, len);
     key = WC_LONG | ((h >> 57) << 56) | ((unsigned long long)len << 40) | pos;
   }
-  unsigned long long i = h & wc.mask;
+  // Words of up to 7 bytes -- few distinct ones, most of the occurrences -- start their probes in the table's first short_mask + 1 slots:
+  // a few MB that stay in L2 / the Infinity Cache instead of a random line of a table of hundreds of MB per occurrence.
+  unsigned long long i = h & (len < 8 ? wc.short_mask : wc.mask);
   uint32_t found = WC_NONE;
   for (int probes = 0; probes < WC_MAX_PROBES; probes++) {
-    unsigned long long cur = ld_agent(&wc.slot[i]);
+    // (a plain load: a slot is written once, so whatever key it shows is final; an EMPTY may be stale, and the CAS settles that)
+    unsigned long long cur = wc.slot[i];
     if (cur == PT_EMPTY) {
       cur = atomicCAS(&wc.slot[i], PT_EMPTY, key);
       if (cur == PT_EMPTY) {  // this occurrence is the word's first: it lends the word its bytes
@@ -138,143 +98,162 @@ __device__ inline void wc_insert_word(const uint8_t *__restrict__ text, unsigned
       found = (uint32_t)i;
       break;
     }
-    i = (i + 1) & wc.mask;
+    // a crowded short region (more distinct short words than it was sized for): after WC_SHORT_PROBES slots of it, on through the whole table
+    if (len < 8 && probes == WC_SHORT_PROBES - 1 && wc.short_mask != wc.mask) i = (h >> 7) & wc.mask;
+    else i = (i + 1) & wc.mask;
   }
   if (found == WC_NONE) atomicOr(wc.status, 1u);  // table too full: the host doubles it and starts over
   wc.occ[oidx] = found;
 }
 
-// A wave walks its sentences 64 bytes at a time; the words it closes (about ten per step) are queued in LDS and inserted 64 at a
-// time, one per lane -- the table probe is a chain of dependent loads from HBM, and it is paid once per 64 words instead of once
-// per step with a handful of lanes busy.
+// A wavefront takes sblk consecutive sentences -- one run of bytes, the sentences lie back to back -- and walks the run 64 bytes at a time,
+// whatever the sentences' lengths (a sentence of 129 bytes walked alone is three steps, the third with one lane busy).  Same classification
+// as enc_tokenize (k_encode.hip): chars by the reference's left-to-right decode inside their sentence, invalid bytes dropped, spaces by
+// cpmap; a sentence's first byte has the sentence start in front of it, which acts like a space: it closes the word the previous sentence
+// left open and lets a new one begin.  The words a step closes (about ten) are queued in LDS and inserted 64 at a time, one per lane --
+// the table probe is a chain of dependent loads, paid once per 64 words instead of once per step with a handful of lanes busy.
 constexpr int WC_QUEUE = 128;
 __global__ __launch_bounds__(BLOCK) void k5w_insert(EncModel m, const uint8_t *__restrict__ text, unsigned long long total,
-                                                    const unsigned long long *__restrict__ offsets, unsigned long long n_sent, WordCache wc) {
+                                                    const unsigned long long *__restrict__ offsets, unsigned long long n_sent, WordCache wc, int sblk) {
   __shared__ unsigned long long q_pos[NWAVES][WC_QUEUE], q_occ[NWAVES][WC_QUEUE];
   __shared__ uint32_t q_len[NWAVES][WC_QUEUE];
+  __shared__ unsigned long long bnd_all[NWAVES][WC_SBLK + 1];
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const unsigned long long lt = lanemask_lt();
   const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
-  unsigned long long *qp = q_pos[wave], *qo = q_occ[wave];
+  unsigned long long *qp = q_pos[wave], *qo = q_occ[wave], *bnd = bnd_all[wave];
   uint32_t *ql = q_len[wave];
   int queued = 0;
-  // (the bytes of the next step -- of this sentence or the first of the wave's next one -- are on their way while this one is
-  // worked on: with ASCII text the byte is the step's only load)
-  unsigned long long sidx = gw;
-  if (sidx >= n_sent) return;
-  unsigned long long b_lo = offsets[sidx], nbytes = offsets[sidx + 1] - b_lo, b0 = 0;
-  unsigned long long nx_lo = 0, nx_n = 0;  // the wave's next sentence
-  if (sidx + n_waves < n_sent) { nx_lo = offsets[sidx + n_waves]; nx_n = offsets[sidx + n_waves + 1] - nx_lo; }
-  uint32_t byte = (unsigned long long)lane < nbytes ? text[b_lo + lane] : 0u;
-  WordWalk st;
-  for (;;) {
-    // where the next step is
-    const bool same = b0 + 64 <= nbytes;
-    const unsigned long long n_sidx = same ? sidx : sidx + n_waves;
-    const bool more = n_sidx < n_sent;
-    const unsigned long long n_lo = same ? b_lo : nx_lo, n_n = same ? nbytes : nx_n, n_b0 = same ? b0 + 64 : 0;
-    uint32_t n_byte = 0;
-    if (more && n_b0 + (unsigned long long)lane < n_n) n_byte = text[n_lo + n_b0 + lane];
-    unsigned long long nn_lo = nx_lo, nn_n = nx_n;
-    if (!same && more && n_sidx + n_waves < n_sent) { nn_lo = offsets[n_sidx + n_waves]; nn_n = offsets[n_sidx + n_waves + 1] - nn_lo; }
-    // this step
-    unsigned long long ws, we;
-    const bool closing = wc_walk_step(m, text + b_lo, nbytes, b0, byte, st, &ws, &we);
-    const unsigned long long CM = __ballot(closing);
-    if (closing) {
-      const int k = queued + (int)__popcll(CM & lt);
-      qp[k] = b_lo + ws;
-      ql[k] = (uint32_t)(we - ws > 0xfffffffeull ? 0xffffffffull : we - ws);
-      qo[k] = (b_lo + ws + sidx) >> 1;
-    }
-    queued += (int)__popcll(CM);
+  const unsigned long long n_blk = (n_sent + sblk - 1) / sblk;
+  for (unsigned long long blk = gw; blk < n_blk; blk += n_waves) {
+    const unsigned long long s0 = blk * (unsigned long long)sblk;
+    const int ns = (int)(n_sent - s0 < (unsigned long long)sblk ? n_sent - s0 : (unsigned long long)sblk);
     wave_sync();
-    if (queued >= 64) {
-      wc_insert_word(text, total, wc, qp[lane], ql[lane], qo[lane]);
+    if (lane < ns) bnd[lane] = offsets[s0 + lane];  // sentence k of the block = bytes [bnd[k], bnd[k + 1])
+    if (lane == 0) bnd[ns] = offsets[s0 + ns];
+    wave_sync();
+    const unsigned long long P0 = bnd[0], P1 = bnd[ns];
+    // the open word, if any: class of the last valid char of the current sentence so far (its start acts like a space), where the word began
+    bool carry_space = true;
+    unsigned long long carry_start = 0;
+    int carry_k = 0, kn = 1;
+    uint32_t byte = P0 + (unsigned long long)lane < P1 ? text[P0 + lane] : 0u;
+    for (unsigned long long p0 = P0; p0 <= P1; p0 += 64) {  // (the position behind the last byte has a lane too: the last sentence's end)
+      const unsigned long long p = p0 + (unsigned long long)lane;
+      const uint32_t n_byte = p + 64 < P1 ? text[p + 64] : 0u;  // (the next step's bytes: with ASCII text the step's only load)
+      // the lane's sentence: the last one that begins at or before p (empty sentences pile up on one byte: the last of them)
+      int k = kn - 1;
+      while (kn <= ns && bnd[kn] < p0 + 64) {
+        k += p >= bnd[kn] ? 1 : 0;
+        kn++;
+      }
+      const bool first = p <= P1 && p == bnd[k];  // a sentence begins here
+      bool valid = false, space = false;
+      if (__ballot(byte >= 0x80u) == 0ull) {  // 64 ASCII bytes (the usual step): every byte is a char, the spaces are utils.cpp:99-101's
+        valid = p < P1;
+        space = byte == 32u || (byte - 9u) < 5u;
+      } else if (p < P1) {
+        const unsigned long long s_lo = bnd[k], nbytes = bnd[k + 1] - s_lo;
+        if (u8_is_start(text + s_lo, p - s_lo, nbytes)) {
+          uint32_t len;
+          const uint32_t cp = u8_decode_at(text + s_lo, p - s_lo, nbytes, &len);
+          if (cp != INVALID_CP) {
+            valid = true;
+            space = m.cpmap[cp] == CP_SPACE;
+          }
+        }
+      }
+      const unsigned long long V = __ballot(valid), S = __ballot(space), F = __ballot(first);
+      // the state in front of this lane: the last valid char below it, unless a sentence began since
+      const unsigned long long pv = V & lt;
+      const int j = pv ? 63 - __clzll((long long)pv) : -1;
+      const unsigned long long since = F & lt & ~(j >= 0 ? (2ull << j) - 1ull : 0ull);
+      const bool pre_space = since ? true : (j >= 0 ? (bool)((S >> j) & 1ull) : carry_space);
+      const bool prev_space = first ? true : pre_space;  // ... and in front of this lane's own char
+      const bool wstart = valid && !space && prev_space;
+      const bool closing = (first && !pre_space) || (valid && space && !prev_space);  // by the sentence's end, or by a space
+      const unsigned long long WSM = __ballot(wstart), CM = __ballot(closing);
+      const unsigned long long wlt = WSM & lt;
+      const int wl = wlt ? 63 - __clzll((long long)wlt) : 0;
+      const int k_from = __shfl(k, wl);
+      if (closing) {
+        const unsigned long long ws = wlt ? p0 + (unsigned long long)wl : carry_start;
+        const unsigned long long sidx = s0 + (unsigned long long)(wlt ? k_from : carry_k);
+        const int at = queued + (int)__popcll(CM & lt);
+        qp[at] = ws;
+        ql[at] = (uint32_t)(p - ws > 0xfffffffeull ? 0xffffffffull : p - ws);
+        qo[at] = (ws + sidx) >> 1;
+      }
+      queued += (int)__popcll(CM);
       wave_sync();
-      const int rest = queued - 64;  // (< 64)
-      unsigned long long p = 0, o = 0;
-      uint32_t l = 0;
-      if (lane < rest) { p = qp[64 + lane]; l = ql[64 + lane]; o = qo[64 + lane]; }
-      wave_sync();
-      if (lane < rest) { qp[lane] = p; ql[lane] = l; qo[lane] = o; }
-      queued = rest;
-      wave_sync();
+      if (queued >= 64) {
+        wc_insert_word(text, total, wc, qp[lane], ql[lane], qo[lane]);
+        wave_sync();
+        const int rest = queued - 64;  // (< 64)
+        unsigned long long pp = 0, oo = 0;
+        uint32_t ll = 0;
+        if (lane < rest) { pp = qp[64 + lane]; ll = ql[64 + lane]; oo = qo[64 + lane]; }
+        wave_sync();
+        if (lane < rest) { qp[lane] = pp; ql[lane] = ll; qo[lane] = oo; }
+        queued = rest;
+        wave_sync();
+      }
+      if (V) {
+        const int jl = 63 - __clzll((long long)V);
+        carry_space = (F & ~((2ull << jl) - 1ull)) ? true : (bool)((S >> jl) & 1ull);
+      } else if (F) {
+        carry_space = true;
+      }
+      const int wh = WSM ? 63 - __clzll((long long)WSM) : 0;
+      const int k_high = __shfl(k, wh);
+      if (WSM) {
+        carry_start = p0 + (unsigned long long)wh;
+        carry_k = k_high;
+      }
+      byte = n_byte;
     }
-    if (!more) break;
-    if (!same) {
-      st = WordWalk();
-      nx_lo = nn_lo;
-      nx_n = nn_n;
-    }
-    sidx = n_sidx;
-    b_lo = n_lo;
-    nbytes = n_n;
-    b0 = n_b0;
-    byte = n_byte;
   }
+  wave_sync();
   if (lane < queued) wc_insert_word(text, total, wc, qp[lane], ql[lane], qo[lane]);
 }
 
 // ---- 2. the table's words as a list ------------------------------------------------------------------------------------------
-// The list is in classes of word length, short words first: K5 packs consecutive items into a wavefront's arrays and a pack takes as
-// many merge rounds as its longest word -- words of a kind side by side keep the lanes of a pack busy for the same number of rounds.
-// (The order inside a class is whatever the atomics make it; nothing depends on it: a word's ids are found through its table slot.)
-__device__ inline int wc_len_class(unsigned long long key, int classes) {
-  if (classes <= 1) return 0;
-  const uint32_t len = (uint32_t)((key & WC_LONG) ? (key >> 40) & 0xffffull : key >> 56);
-  return len <= 4 ? 0 : len <= 7 ? 1 : len <= 10 ? 2 : len <= 13 ? 3 : len <= 17 ? 4 : len <= 22 ? 5 : len <= 30 ? 6 : 7;
-}
-// blk_cnt[c * gridDim.x + block] = words of class c in the block's slots
-__global__ __launch_bounds__(BLOCK) void k5w_count_slots(WordCache wc, uint32_t *__restrict__ blk_cnt, int classes) {
-  __shared__ unsigned int acc[WC_CLASSES];
-  if (threadIdx.x < WC_CLASSES) acc[threadIdx.x] = 0;
+__global__ __launch_bounds__(BLOCK) void k5w_count_slots(WordCache wc, uint32_t *__restrict__ blk_cnt) {
+  __shared__ unsigned int acc;
+  if (threadIdx.x == 0) acc = 0;
   __syncthreads();
   const unsigned long long base = (unsigned long long)blockIdx.x * WC_CBLK;
+  unsigned int c = 0;
   for (unsigned int k = 0; k < 8; k++) {
     const unsigned long long i = base + k * BLOCK + threadIdx.x;
-    const unsigned long long key = i <= wc.mask ? wc.slot[i] : PT_EMPTY;
-    const bool used = key != PT_EMPTY;
-    const int c = wc_len_class(key, classes);
-    for (int q = 0; q < classes; q++) {
-      const unsigned long long M = __ballot(used && c == q);
-      if (M && lane_id() == 0) atomicAdd(&acc[q], (unsigned int)__popcll(M));
-    }
+    if (i <= wc.mask && wc.slot[i] != PT_EMPTY) c++;
   }
+  if (c) atomicAdd(&acc, c);
   __syncthreads();
-  if ((int)threadIdx.x < classes) blk_cnt[(unsigned long long)threadIdx.x * gridDim.x + blockIdx.x] = acc[threadIdx.x];
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = acc;
 }
 // word u of the list: bytes [ustart[u], uend[u]), table slot uslot[u]; the uncached words follow the table's
 __global__ __launch_bounds__(BLOCK) void k5w_list(WordCache wc, const unsigned long long *__restrict__ blk_off, unsigned long long n_table,
                                                   unsigned long long *__restrict__ ustart, unsigned long long *__restrict__ uend,
-                                                  uint32_t *__restrict__ uslot, int classes) {
-  __shared__ unsigned int next[WC_CLASSES];  // words of the class this block has listed so far
-  if (threadIdx.x < WC_CLASSES) next[threadIdx.x] = 0;
-  __syncthreads();
+                                                  uint32_t *__restrict__ uslot) {
+  __shared__ uint32_t scan_lds[NWAVES];
   const unsigned long long base = (unsigned long long)blockIdx.x * WC_CBLK;
-  const unsigned long long lt = lanemask_lt();
+  unsigned long long out = blk_off[blockIdx.x];
   for (unsigned int k = 0; k < 8; k++) {
     const unsigned long long i = base + k * BLOCK + threadIdx.x;
     const unsigned long long key = i <= wc.mask ? wc.slot[i] : PT_EMPTY;
     const bool used = key != PT_EMPTY;
-    const int c = wc_len_class(key, classes);
-    unsigned int r = 0;
-    for (int q = 0; q < classes; q++) {  // a wave takes its places of class q with one LDS atomic
-      const unsigned long long M = __ballot(used && c == q);
-      if (!M) continue;
-      unsigned int first = 0;
-      if (lane_id() == 0) first = atomicAdd(&next[q], (unsigned int)__popcll(M));
-      first = (unsigned int)__shfl((int)first, 0);
-      if (used && c == q) r = first + (unsigned int)__popcll(M & lt);
-    }
+    uint32_t tot;
+    const uint32_t r = block_excl_scan(used ? 1u : 0u, scan_lds, &tot);
     if (used) {
-      const unsigned long long u = blk_off[(unsigned long long)c * gridDim.x + blockIdx.x] + r, p = wc.pos[i];
+      const unsigned long long u = out + r, p = wc.pos[i];
       const unsigned long long len = (key & WC_LONG) ? (key >> 40) & 0xffffull : key >> 56;
       ustart[u] = p;
       uend[u] = p + len;
       uslot[u] = (uint32_t)i;
     }
+    out += tot;
   }
   if (blockIdx.x == 0) {
     const unsigned int n_extra = *wc.extra_n;
@@ -284,21 +263,6 @@ __global__ __launch_bounds__(BLOCK) void k5w_list(WordCache wc, const unsigned l
     }
   }
 }
-// after K5 has encoded the list: the table slot (the `extra` entry) of a word now says where its ids are -- K5 left those of word u at
-// scratch + 2 ustart[u] (k_encode.hip SentView), counts[u] of them: offset << 20 | count (a cached word has at most 65 536 ids)
-__global__ __launch_bounds__(BLOCK) void k5w_publish(WordCache wc, unsigned long long n_table, unsigned long long n_words, const uint32_t *__restrict__ uslot,
-                                                     const unsigned long long *__restrict__ ustart, const uint32_t *__restrict__ ucounts) {
-  const unsigned long long u = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (u >= n_words) return;
-  const unsigned long long o = 2 * ustart[u], n = ucounts[u];
-  if (u < n_table) {
-    wc.slot[uslot[u]] = (o << 20) | n;
-  } else {
-    wc.extra[2 * (u - n_table)] = o;
-    wc.extra[2 * (u - n_table) + 1] = n;
-  }
-}
-
 // ---- 3. per sentence: the words' ids end to end ------------------------------------------------------------------------------
 __device__ inline void wc_result(const WordCache &wc, uint32_t o, unsigned long long *off, uint32_t *n) {
   if (o & WC_EXTRA) {
@@ -310,103 +274,168 @@ __device__ inline void wc_result(const WordCache &wc, uint32_t o, unsigned long 
     *n = (uint32_t)(r & 0xfffffull);
   }
 }
-// A sentence's word occurrences are the entries of occ between its first and last possible index that are not WC_NONE (the host
-// clears the array before k5w_insert): the second and third walk over the text are scans of that array, 64 entries = 128 bytes of
-// text per step, no UTF-8.
-__device__ inline void wc_occ_range(const unsigned long long *__restrict__ offsets, unsigned long long sidx, unsigned long long *lo, unsigned long long *hi) {
-  const unsigned long long b_lo = offsets[sidx], b_hi = offsets[sidx + 1];
-  *lo = (b_lo + sidx) >> 1;
-  *hi = b_hi > b_lo ? ((b_hi - 1 + sidx) >> 1) + 1 : *lo;  // (exclusive)
+// A sentence's word occurrences are the entries of occ from its first possible index on that are not WC_NONE (the host clears the array
+// before k5w_insert): the second and third walk over the text are scans of that array, 64 entries = 128 bytes of text per step, no UTF-8.
+// Sentence s owns the entries [wc_occ_lo(s), wc_occ_lo(s + 1)): ((byte + s) >> 1 grows from sentence to sentence, and what lies between
+// the last word start a sentence can have and the next sentence's first index is never written.)  A wavefront takes sblk <= WC_SBLK
+// consecutive sentences (wc_sblk: fewer when the batch has few sentences, so that every wavefront still gets some) and walks their entries as ONE range, whatever the sentences' lengths -- a sentence of 129 bytes is 65 entries, two steps of
+// which the second has one lane busy; 64 of them are 65 steps, all full.  The sentence of an entry: the range's boundaries are in LDS, and
+// the entries of a step are in order, so a lane counts the boundaries at or below its entry as the wave passes them.
+__device__ inline unsigned long long wc_occ_lo(const unsigned long long *__restrict__ offsets, unsigned long long sidx) {
+  return (offsets[sidx] + sidx) >> 1;
+}
+struct SentBlock {
+  unsigned long long s0;  // first sentence
+  int ns;                 // sentences
+  unsigned long long e_lo, e_hi;  // their entries
+};
+// the block's boundaries -> bnd[0 .. ns]
+__device__ inline SentBlock wc_block_begin(const unsigned long long *__restrict__ offsets, unsigned long long n_sent, unsigned long long blk, int sblk,
+                                           unsigned long long *bnd) {
+  SentBlock B;
+  B.s0 = blk * (unsigned long long)sblk;
+  B.ns = (int)(n_sent - B.s0 < (unsigned long long)sblk ? n_sent - B.s0 : (unsigned long long)sblk);
+  const int lane = lane_id();
+  if (lane < B.ns) bnd[lane] = wc_occ_lo(offsets, B.s0 + lane);
+  if (lane == 0) bnd[B.ns] = wc_occ_lo(offsets, B.s0 + B.ns);
+  wave_sync();
+  B.e_lo = bnd[0];
+  B.e_hi = bnd[B.ns];
+  return B;
+}
+// sentence (within the block) of entry e of the step [e0, e0 + 64); kn = first boundary not yet passed (uniform, carried from step to step),
+// k0 = sentence of the entries below bnd[kn]
+__device__ inline int wc_block_sentence(const unsigned long long *bnd, int ns, unsigned long long e0, unsigned long long e, int &kn) {
+  int k = kn - 1;
+  while (kn <= ns && bnd[kn] < e0 + 64) {
+    k += e >= bnd[kn] ? 1 : 0;
+    kn++;
+  }
+  return k;
 }
 __global__ __launch_bounds__(BLOCK) void k5w_count(const unsigned long long *__restrict__ offsets, unsigned long long n_sent, WordCache wc,
-                                                   int n_fixed /* bos + eos */, uint32_t *__restrict__ counts) {
-  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
+                                                   int n_fixed /* bos + eos */, uint32_t *__restrict__ counts, int sblk) {
+  __shared__ unsigned long long bnd_all[NWAVES][WC_SBLK + 1];
+  __shared__ uint32_t acc_all[NWAVES][WC_SBLK];
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  unsigned long long *bnd = bnd_all[wave];
+  uint32_t *acc = acc_all[wave];
+  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
-  for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
-    unsigned long long lo, hi;
-    wc_occ_range(offsets, sidx, &lo, &hi);
-    unsigned long long mine = 0;
-    for (unsigned long long i = lo + (unsigned long long)lane_id(); i < hi; i += 64) {
-      const uint32_t o = wc.occ[i];
+  const unsigned long long n_blk = (n_sent + sblk - 1) / sblk;
+  for (unsigned long long blk = gw; blk < n_blk; blk += n_waves) {
+    acc[lane] = 0;
+    const SentBlock B = wc_block_begin(offsets, n_sent, blk, sblk, bnd);
+    int kn = 1;
+    // (the next step's entries are on their way while this step's table look-ups are: each step is a chain of two dependent loads)
+    uint32_t o_next = B.e_lo + (unsigned long long)lane < B.e_hi ? wc.occ[B.e_lo + lane] : WC_NONE;
+    for (unsigned long long e0 = B.e_lo; e0 < B.e_hi; e0 += 64) {
+      const unsigned long long e = e0 + (unsigned long long)lane;
+      const uint32_t o = o_next;
+      o_next = e + 64 < B.e_hi ? wc.occ[e + 64] : WC_NONE;
+      const int k = wc_block_sentence(bnd, B.ns, e0, e, kn);
       if (o != WC_NONE) {
         unsigned long long off;
         uint32_t n;
         wc_result(wc, o, &off, &n);
-        mine += n;
+        atomicAdd(&acc[k], n);
       }
     }
-    const unsigned long long tot = wave_sum_u64(mine);
-    if (lane_id() == 0) counts[sidx] = (uint32_t)tot + (uint32_t)n_fixed;
+    wave_sync();
+    if (lane < B.ns) counts[B.s0 + lane] = acc[lane] + (uint32_t)n_fixed;
+    wave_sync();
   }
 }
 __global__ __launch_bounds__(BLOCK) void k5w_scatter(EncModel m, const unsigned long long *__restrict__ offsets, unsigned long long n_sent, WordCache wc,
                                                      const int32_t *__restrict__ uids /* K5's scratch */, int bos, int eos, int reverse,
-                                                     const unsigned long long *__restrict__ out_off, int32_t *__restrict__ ids_out) {
-  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
+                                                     const unsigned long long *__restrict__ out_off, int32_t *__restrict__ ids_out, int sblk) {
+  __shared__ unsigned long long bnd_all[NWAVES][WC_SBLK + 1], oo_all[NWAVES][WC_SBLK + 1];
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  unsigned long long *bnd = bnd_all[wave], *oo = oo_all[wave];
+  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
-  const int lane = lane_id();
-  for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
-    unsigned long long lo, hi;
-    wc_occ_range(offsets, sidx, &lo, &hi);
-    const unsigned long long o0 = out_off[sidx], n_ids = out_off[sidx + 1] - o0;
-    int32_t *out = ids_out + o0;
-    if (lane == 0) {
-      if (bos) out[reverse ? n_ids - 1 : 0] = m.bos_id;
-      if (eos) out[reverse ? 0 : n_ids - 1] = m.eos_id;
+  const unsigned long long n_blk = (n_sent + sblk - 1) / sblk;
+  const unsigned long long fixed = (unsigned long long)((bos ? 1 : 0) + (eos ? 1 : 0));
+  for (unsigned long long blk = gw; blk < n_blk; blk += n_waves) {
+    const SentBlock B = wc_block_begin(offsets, n_sent, blk, sblk, bnd);
+    if (lane < B.ns) oo[lane] = out_off[B.s0 + lane];
+    if (lane == 0) oo[B.ns] = out_off[B.s0 + B.ns];
+    wave_sync();
+    if (lane < B.ns) {
+      const unsigned long long o0 = oo[lane], n_ids = oo[lane + 1] - o0;
+      if (bos) ids_out[o0 + (reverse ? n_ids - 1 : 0)] = m.bos_id;
+      if (eos) ids_out[o0 + (reverse ? 0 : n_ids - 1)] = m.eos_id;
     }
-    unsigned long long q = bos ? 1 : 0;  // ids of the sentence laid down so far
-    for (unsigned long long i0 = lo; i0 < hi; i0 += 64) {
-      const unsigned long long i = i0 + (unsigned long long)lane;
-      unsigned long long off = 0;
-      uint32_t n = 0;
-      if (i < hi) {
-        const uint32_t o = wc.occ[i];
-        if (o != WC_NONE) wc_result(wc, o, &off, &n);
-      }
+    // The block's ids without bos / eos are one run: sentence k's start at oo[k] - oo[0] - k * fixed of it.
+    unsigned long long q = 0;  // ids of the block laid down so far
+    int kn = 1;
+    // A step is a chain of three dependent loads -- the entry, the word's slot, its ids -- so the entries run two steps ahead and the
+    // slots one.
+    auto entry = [&](unsigned long long e) -> uint32_t { return e < B.e_hi ? wc.occ[e] : WC_NONE; };
+    uint32_t o_a = entry(B.e_lo + lane), o_b = entry(B.e_lo + 64 + lane);
+    unsigned long long off_a = 0;
+    uint32_t n_a = 0;
+    if (o_a != WC_NONE) wc_result(wc, o_a, &off_a, &n_a);
+    for (unsigned long long e0 = B.e_lo; e0 < B.e_hi; e0 += 64) {
+      const unsigned long long e = e0 + (unsigned long long)lane;
+      const unsigned long long off = off_a;
+      const uint32_t n = n_a;
+      // the next step's slot, the entry of the one after
+      off_a = 0;
+      n_a = 0;
+      if (o_b != WC_NONE) wc_result(wc, o_b, &off_a, &n_a);
+      o_b = entry(e + 128);
+      const int k = wc_block_sentence(bnd, B.ns, e0, e, kn);
       const uint32_t inc = wave_incl_scan(n);
-      const unsigned long long mine = q + inc - n;
-      for (uint32_t k = 0; k < n; k++) out[reverse ? n_ids - 1 - (mine + k) : mine + k] = uids[off + k];
+      if (n) {
+        const unsigned long long o0 = oo[k], n_ids = oo[k + 1] - o0;
+        const unsigned long long mine = q + inc - n - (o0 - oo[0] - (unsigned long long)k * fixed) + (bos ? 1 : 0);  // place in the sentence
+        int32_t *out = ids_out + o0;
+        for (uint32_t j = 0; j < n; j++) out[reverse ? n_ids - 1 - (mine + j) : mine + j] = uids[off + j];
+      }
       q += (unsigned long long)__shfl(inc, 63);
     }
+    wave_sync();
   }
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------------------------
+// sentences a wavefront of the flat walks takes at a time: up to WC_SBLK, fewer while that leaves wavefronts without any
+static inline int wc_sblk(unsigned long long n_sent) {
+  if (const char *e = getenv("YTTM_WC_SBLK")) {  // (tests: small batches with many sentences per wavefront)
+    const int v = atoi(e);
+    return v < 1 ? 1 : v > WC_SBLK ? WC_SBLK : v;
+  }
+  const unsigned long long per = n_sent / (256ull * 16 * NWAVES);
+  return per < 1 ? 1 : per > (unsigned long long)WC_SBLK ? WC_SBLK : (int)per;
+}
 static inline unsigned int wave_grid(unsigned long long n_items, unsigned int max_blocks) {
   unsigned long long b = (n_items + NWAVES - 1) / NWAVES;
   if (b > max_blocks) b = max_blocks;
   return b ? (unsigned int)b : 1u;
 }
-static inline unsigned int wcache_blocks(const WordCache &wc) { return (unsigned int)((wc.mask + WC_CBLK) / WC_CBLK); }
-// YTTM_K5_CLASSES=1: the list in table order (measurements)
-static int wcache_classes() {
-  const char *e = getenv("YTTM_K5_CLASSES");
-  const int c = e ? atoi(e) : WC_CLASSES;
-  return c <= 1 ? 1 : WC_CLASSES;
-}
-unsigned long long wcache_count_cells(const WordCache &wc) { return (unsigned long long)wcache_blocks(wc) * (unsigned long long)wcache_classes(); }
+unsigned long long wcache_count_blocks(const WordCache &wc) { return (wc.mask + WC_CBLK) / WC_CBLK; }
 void launch_wcache_insert(const EncModel &m, const uint8_t *text, unsigned long long total, const unsigned long long *offsets, unsigned long long n_sent,
                           const WordCache &wc, hipStream_t st) {
-  hipLaunchKernelGGL(k5w_insert, dim3(wave_grid(n_sent, 256 * 16)), dim3(BLOCK), 0, st, m, text, total, offsets, n_sent, wc);
+  const int sblk = wc_sblk(n_sent);
+  hipLaunchKernelGGL(k5w_insert, dim3(wave_grid((n_sent + sblk - 1) / sblk, 256 * 16)), dim3(BLOCK), 0, st, m, text, total, offsets, n_sent, wc, sblk);
 }
 void launch_wcache_count_slots(const WordCache &wc, uint32_t *blk_cnt, hipStream_t st) {
-  hipLaunchKernelGGL(k5w_count_slots, dim3(wcache_blocks(wc)), dim3(BLOCK), 0, st, wc, blk_cnt, wcache_classes());
+  hipLaunchKernelGGL(k5w_count_slots, dim3((unsigned int)wcache_count_blocks(wc)), dim3(BLOCK), 0, st, wc, blk_cnt);
 }
 void launch_wcache_list(const WordCache &wc, const unsigned long long *blk_off, unsigned long long n_table, unsigned long long *ustart,
                         unsigned long long *uend, uint32_t *uslot, hipStream_t st) {
-  hipLaunchKernelGGL(k5w_list, dim3(wcache_blocks(wc)), dim3(BLOCK), 0, st, wc, blk_off, n_table, ustart, uend, uslot, wcache_classes());
-}
-void launch_wcache_publish(const WordCache &wc, unsigned long long n_table, unsigned long long n_words, const uint32_t *uslot,
-                           const unsigned long long *ustart, const uint32_t *ucounts, hipStream_t st) {
-  if (!n_words) return;
-  hipLaunchKernelGGL(k5w_publish, dim3((unsigned int)((n_words + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, wc, n_table, n_words, uslot, ustart, ucounts);
+  hipLaunchKernelGGL(k5w_list, dim3((unsigned int)wcache_count_blocks(wc)), dim3(BLOCK), 0, st, wc, blk_off, n_table, ustart, uend, uslot);
 }
 void launch_wcache_count(const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc, int n_fixed, uint32_t *counts, hipStream_t st) {
-  hipLaunchKernelGGL(k5w_count, dim3(wave_grid(n_sent, 256 * 16)), dim3(BLOCK), 0, st, offsets, n_sent, wc, n_fixed, counts);
+  const int sblk = wc_sblk(n_sent);
+  hipLaunchKernelGGL(k5w_count, dim3(wave_grid((n_sent + sblk - 1) / sblk, 256 * 16)), dim3(BLOCK), 0, st, offsets, n_sent, wc, n_fixed, counts, sblk);
 }
 void launch_wcache_scatter(const EncModel &m, const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc, const int32_t *uids, int bos,
                            int eos, int reverse, const unsigned long long *out_off, int32_t *ids_out, hipStream_t st) {
-  hipLaunchKernelGGL(k5w_scatter, dim3(wave_grid(n_sent, 256 * 16)), dim3(BLOCK), 0, st, m, offsets, n_sent, wc, uids, bos, eos, reverse, out_off, ids_out);
+  const int sblk = wc_sblk(n_sent);
+  hipLaunchKernelGGL(k5w_scatter, dim3(wave_grid((n_sent + sblk - 1) / sblk, 256 * 16)), dim3(BLOCK), 0, st, m, offsets, n_sent, wc, uids, bos, eos, reverse, out_off,
+                     ids_out, sblk);
 }
 
 }  // namespace yttm

@@ -226,11 +226,19 @@ struct EncModel {
 };
 // offsets[n_sent + 1], ends == nullptr: sentences back to back.  ends != nullptr: item j is bytes [offsets[j], ends[j]), any order (the
 // word cache's distinct words); its ids land at scratch + 2 offsets[j].
+// where the ids of the word cache's distinct words are announced (k_wcache.hip): item u's table slot uslot[u] (u < n_table), or the entry
+// u - n_table of the words too long to cache, becomes ids offset << 20 | count (offset, count for the long ones)
+struct WordPublish {
+  unsigned long long *slot;
+  const uint32_t *uslot;
+  unsigned long long n_table;
+  unsigned long long *extra;
+};
 void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long long *offsets, const unsigned long long *ends,
                    unsigned long long n_sent, int bos,
                    int eos, int reverse, int32_t *scratch_ids, uint32_t *counts, uint32_t *work, unsigned long long work_stride,
                    unsigned int n_blocks, double dropout_prob, unsigned long long seed, uint32_t *drop_scratch,
-                   unsigned long long drop_stride, hipStream_t st);
+                   unsigned long long drop_stride, hipStream_t st, const WordPublish *pub = nullptr);
 void launch_encode_gather(const int32_t *scratch_ids, const unsigned long long *offsets, const unsigned long long *ends,
                           const unsigned long long *out_off, unsigned long long n_sent, int32_t *ids_out, hipStream_t st);
 
@@ -239,20 +247,19 @@ struct WordCache {
   unsigned long long *slot;   // [mask + 1] key of a distinct word (PT_EMPTY = free); after launch_wcache_publish: ids offset << 20 | count
   unsigned long long *pos;    // [mask + 1] first byte of the word's first occurrence
   unsigned long long mask;
+  unsigned long long short_mask;  // words of up to 7 bytes hash into the first short_mask + 1 slots (<= mask)
   uint32_t *occ;              // [(bytes + sentences) / 2 + 2] per word occurrence (index (first byte + sentence) / 2): its slot; 0xffffffff elsewhere
   unsigned long long *extra;  // [extra_cap][2] words too long to cache: begin, end; after publish: ids offset, count
   unsigned int *extra_n;
   unsigned int extra_cap;
   unsigned int *status;       // bit 0: the table was too full
 };
-unsigned long long wcache_count_cells(const WordCache &wc);  // counters launch_wcache_count_slots fills: workgroups x classes of word length
+unsigned long long wcache_count_blocks(const WordCache &wc);
 void launch_wcache_insert(const EncModel &m, const uint8_t *text, unsigned long long total, const unsigned long long *offsets, unsigned long long n_sent,
                           const WordCache &wc, hipStream_t st);
 void launch_wcache_count_slots(const WordCache &wc, uint32_t *blk_cnt, hipStream_t st);
 void launch_wcache_list(const WordCache &wc, const unsigned long long *blk_off, unsigned long long n_table, unsigned long long *ustart,
                         unsigned long long *uend, uint32_t *uslot, hipStream_t st);
-void launch_wcache_publish(const WordCache &wc, unsigned long long n_table, unsigned long long n_words, const uint32_t *uslot,
-                           const unsigned long long *ustart, const uint32_t *ucounts, hipStream_t st);
 void launch_wcache_count(const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc, int n_fixed, uint32_t *counts, hipStream_t st);
 void launch_wcache_scatter(const EncModel &m, const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc, const int32_t *uids, int bos,
                            int eos, int reverse, const unsigned long long *out_off, int32_t *ids_out, hipStream_t st);
