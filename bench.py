@@ -602,7 +602,7 @@ def _bench_encode(ctx, model_path, main_res):
     words = int(L.yttm_encode_cache_words(h))
     res["encode"]["word_cache"] = {"distinct_words": words, "without_cache_sentences_per_s": direct["value"], "without_cache_kernel_ms": direct["kernel_ms"],
                                    "gain": round(res["encode"]["value"] / direct["value"], 3)}
-    res["encode"]["roofline"]["kernel"] = "k5w_insert + k5_encode (distinct words) + k5w_count + k5w_scatter" if words else "k5_encode"
+    res["encode"]["roofline"]["kernel"] = "k5w_insert + k5_words (the distinct words) + k5w_count + k5w_scatter" if words else "k5_encode"
     # ---- parity: FNV-1a-64 of (len, ids...) per sentence over ALL sentences vs the reference's (pinned) ---------------------
     ids = np.zeros(n_ids.value, dtype=np.int32)
     off = np.zeros(n_sent + 1, dtype=np.uint64)

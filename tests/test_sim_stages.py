@@ -172,6 +172,15 @@ def test_encode_word_cache_fuzz(tmp_path):
     S.check_encode_word_cache_fuzz(tmp_path)
 
 
+def test_encode_host_arrays_through_pinned_chunks(monkeypatch):
+    """host -> host encode of a large batch moves its arrays through the trainer's pinned chunks, several threads at once (host_encoder.cpp
+    copy_up / copy_down, gpu_ctx.cpp staged_transfer): here every array of small batches, in chunks of 4 KB"""
+    monkeypatch.setenv("YTTM_ENC_STAGED_FROM", "1")
+    monkeypatch.setenv("YTTM_IO_CHUNK_KB", "4")
+    S.check_encode_mixed_shapes(n_sent=150, seed=53)
+    S.check_encode_word_cache(n_sent=40, seed=59)
+
+
 @pytest.mark.parametrize("sblk", [3, 64])
 def test_encode_word_cache_sentence_blocks(sblk, tmp_path, monkeypatch):
     """the word cache's three walks over the text (k_wcache.hip: insert, count, scatter) take blocks of consecutive sentences as one run --

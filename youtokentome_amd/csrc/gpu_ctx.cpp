@@ -406,9 +406,21 @@ void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *
   n_text_ = n;
   corpus_bytes = n;
   if (!n) return;
+  staged_transfer(device_, d_text_owned_, n, true, fill);
+}
+
+// n bytes between HBM and the host through the workers' pinned chunks.  to_device: host_side(chunk, off, len) FILLS the pinned chunk with
+// bytes [off, off + len) (pread, memcpy) before it goes up; else it DRAINS the chunk that has come down (memcpy to where the caller wants
+// the bytes -- several workers at once, which also spreads the page faults of a freshly allocated destination).  Returns when every byte
+// has arrived.  Throws GpuError.
+void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_device,
+                     const std::function<bool(void *chunk, unsigned long long off, size_t len)> &host_side) {
+  if (!n) return;
+  HIP_CHECK(hipSetDevice(device));
   {
     const size_t mb = std::min<size_t>(std::max<size_t>(env_uint("YTTM_IO_CHUNK_MB", 8), 1), IO_CHUNK_MAX >> 20);
     IO_CHUNK = mb << 20;
+    if (const size_t kb = env_uint("YTTM_IO_CHUNK_KB", 0)) IO_CHUNK = std::min<size_t>(kb << 10, IO_CHUNK_MAX);  // (tests: many chunks of a small batch)
   }
   const size_t n_chunks = (size_t)((n + IO_CHUNK - 1) / IO_CHUNK);
   int n_threads = (int)env_uint("YTTM_IO_THREADS", 0);
@@ -421,7 +433,7 @@ void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *
     std::lock_guard<std::mutex> g(g_io.mu);
     if (!g_io.busy) { g_io.busy = true; mine = true; }
   }
-  if (mine && g_io.dev != device_) {  // (the cached streams and events are another device's)
+  if (mine && g_io.dev != device) {  // (the cached streams and events are another device's)
     for (hipEvent_t &e : g_io.ev) {
       if (e) (void)hipEventDestroy(e);
       e = nullptr;
@@ -430,15 +442,20 @@ void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *
       if (c) (void)hipStreamDestroy(c);
       c = nullptr;
     }
-    g_io.dev = device_;
+    g_io.dev = device;
   }
-  if (!mine) {  // another context of this process is uploading through the shared chunks: plain copies for this one
+  if (!mine) {  // another thread of this process is moving bytes through the shared chunks: plain copies for this one
     std::vector<uint8_t> tmp(IO_CHUNK);
     for (size_t c = 0; c < n_chunks; c++) {
       const unsigned long long off = (unsigned long long)c * IO_CHUNK;
       const size_t len = (size_t)std::min<unsigned long long>(IO_CHUNK, n - off);
-      if (!fill(tmp.data(), off, len)) throw GpuError{"corpus read failed"};
-      HIP_CHECK(hipMemcpy(d_text_owned_ + off, tmp.data(), len, hipMemcpyHostToDevice));
+      if (to_device) {
+        if (!host_side(tmp.data(), off, len)) throw GpuError{"corpus read failed"};
+        HIP_CHECK(hipMemcpy(d_ptr + off, tmp.data(), len, hipMemcpyHostToDevice));
+      } else {
+        HIP_CHECK(hipMemcpy(tmp.data(), d_ptr + off, len, hipMemcpyDeviceToHost));
+        if (!host_side(tmp.data(), off, len)) throw GpuError{"copy to the host failed"};
+      }
     }
     return;
   }
@@ -448,26 +465,42 @@ void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *
   std::mutex err_mu;
   auto worker = [&](int w) {
     try {
-      HIP_CHECK(hipSetDevice(device_));
+      HIP_CHECK(hipSetDevice(device));
       if (!g_io.cs[w]) HIP_CHECK(hipStreamCreateWithFlags(&g_io.cs[w], hipStreamNonBlocking));
       hipStream_t cs = g_io.cs[w];
       hipEvent_t *ev = &g_io.ev[2 * w];
       bool used[2] = {false, false};
+      unsigned long long held_off[2] = {0, 0};  // (down: the bytes a buffer is receiving)
+      size_t held_len[2] = {0, 0};
       for (int k = 0; k < 2; k++) {
         if (!ev[k]) HIP_CHECK(hipEventCreate(&ev[k]));
         if (!g_io.pin[2 * w + k]) HIP_CHECK(hipHostMalloc(&g_io.pin[2 * w + k], IO_CHUNK_MAX, hipHostMallocDefault));
       }
+      auto drain = [&](int k) {
+        if (!used[k]) return;
+        HIP_CHECK(hipEventSynchronize(ev[k]));
+        used[k] = false;
+        if (!to_device && !host_side(g_io.pin[2 * w + k], held_off[k], held_len[k])) throw GpuError{"copy to the host failed"};
+      };
       for (int k = 0;; k ^= 1) {
         const size_t c = next.fetch_add(1);
         if (c >= n_chunks || failed.load()) break;
         const unsigned long long off = (unsigned long long)c * IO_CHUNK;
         const size_t len = (size_t)std::min<unsigned long long>(IO_CHUNK, n - off);
-        if (used[k]) HIP_CHECK(hipEventSynchronize(ev[k]));  // the chunk's previous copy has left the buffer
-        if (!fill(g_io.pin[2 * w + k], off, len)) throw GpuError{"corpus read failed"};
-        HIP_CHECK(hipMemcpyAsync(d_text_owned_ + off, g_io.pin[2 * w + k], len, hipMemcpyHostToDevice, cs));
+        drain(k);  // up: the buffer's previous copy has left it; down: its bytes have arrived and are handed over
+        if (to_device) {
+          if (!host_side(g_io.pin[2 * w + k], off, len)) throw GpuError{"corpus read failed"};
+          HIP_CHECK(hipMemcpyAsync(d_ptr + off, g_io.pin[2 * w + k], len, hipMemcpyHostToDevice, cs));
+        } else {
+          HIP_CHECK(hipMemcpyAsync(g_io.pin[2 * w + k], d_ptr + off, len, hipMemcpyDeviceToHost, cs));
+          held_off[k] = off;
+          held_len[k] = len;
+        }
         HIP_CHECK(hipEventRecord(ev[k], cs));
         used[k] = true;
       }
+      drain(0);
+      drain(1);
       HIP_CHECK(hipStreamSynchronize(cs));
     } catch (const GpuError &e) {
       failed.store(1);

@@ -16,6 +16,11 @@ struct GpuError {
   std::string msg;
 };
 
+// n bytes between HBM and the host through pinned chunks that several host threads fill (to_device) or drain (gpu_ctx.cpp): what a single
+// hipMemcpy from / to pageable memory does on one thread through one internal buffer.  host_side(chunk, off, len) -> false: give up.
+void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_device,
+                     const std::function<bool(void *chunk, unsigned long long off, size_t len)> &host_side);
+
 // Exchange interface for the multi-GPU path (one process per GPU).  Implementations: RCCL over xGMI
 // (comm_rccl.cpp) and a host-callback variant used by the gloo CPU tests.
 struct Comm {

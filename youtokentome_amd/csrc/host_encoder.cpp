@@ -6,6 +6,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <thread>
+#include <sys/mman.h>
+#include <chrono>
 #include <mutex>
 #include <random>
 
@@ -416,12 +419,41 @@ static Status encode_on_lane(const BaseEncoder &enc, EncoderDevice &D, EncodeLan
   return Status();
 }
 
+// Host arrays of a large batch cross the link through the trainer's pinned chunks (gpu_ctx.cpp staged_transfer; 1e7 sentences are 1.3 GB up
+// and 1.2 GB down: a plain copy from / to pageable memory moves them at a fraction of the link's rate, and the first touch of a freshly
+// allocated result array is paid by one thread); small ones as plain copies on the lane's stream.
+static size_t staged_from() {
+  const char *e = getenv("YTTM_ENC_STAGED_FROM");  // (tests: every copy through the chunks)
+  return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(16u << 20);
+}
+static void copy_up(int device, void *d_dst, const void *src, size_t n, hipStream_t st) {
+  if (n >= staged_from() && n) {
+    staged_transfer(device, (uint8_t *)d_dst, n, true, [&](void *chunk, unsigned long long off, size_t len) {
+      memcpy(chunk, (const uint8_t *)src + off, len);
+      return true;
+    });
+  } else if (n) {
+    HIP_CHECK(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, st));
+  }
+}
+static void copy_down(int device, void *dst, const void *d_src, size_t n, hipStream_t st) {
+  if (n >= staged_from() && n) {
+    staged_transfer(device, (uint8_t *)const_cast<void *>(d_src), n, false, [&](void *chunk, unsigned long long off, size_t len) {
+      memcpy((uint8_t *)dst + off, chunk, len);
+      return true;
+    });
+  } else if (n) {
+    HIP_CHECK(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, st));
+  }
+}
+
 static Status fetch_lane(EncodeLane &d, int device, int32_t *ids, unsigned long long *out_off, unsigned long long n_sent) {
   try {
     HIP_CHECK(hipSetDevice(device));
     if (n_sent == 0) { if (out_off) out_off[0] = 0; return Status(); }
-    if (ids && d.last_n_ids) HIP_CHECK(hipMemcpyAsync(ids, d.d_ids, (size_t)d.last_n_ids * 4, hipMemcpyDeviceToHost, d.st));
-    if (out_off) HIP_CHECK(hipMemcpyAsync(out_off, d.d_out_off, (size_t)(n_sent + 1) * 8, hipMemcpyDeviceToHost, d.st));
+    // (the lane's stream is idle: encode_on_lane synchronised it)
+    if (ids && d.last_n_ids) copy_down(device, ids, d.d_ids, (size_t)d.last_n_ids * 4, d.st);
+    if (out_off) copy_down(device, out_off, d.d_out_off, (size_t)(n_sent + 1) * 8, d.st);
     HIP_CHECK(hipStreamSynchronize(d.st));
   } catch (const GpuError &e) {
     return Status(2, "GPU error: " + e.msg);
@@ -470,34 +502,57 @@ static Status encode_host_to_host(const BaseEncoder &enc, EncoderDevice *dev, in
     return Status();
   }
   if (!dev) return Status(2, "encoder has no device state");
+  const bool trace = getenv("YTTM_TRACE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
   unsigned long long total_bytes = offsets[n_sent] - offsets[0], max_len = 0;
-  for (unsigned long long i = 0; i < n_sent; i++) max_len = std::max(max_len, offsets[i + 1] - offsets[i]);
+  // (the longest sentence sizes K5's scratch; a pass over 80 MB of offsets for 10^7 sentences -- on its own thread while the bytes go up)
+  std::thread scan;
+  auto longest = [&] { for (unsigned long long i = 0; i < n_sent; i++) max_len = std::max(max_len, offsets[i + 1] - offsets[i]); };
+  if (n_sent >= (1u << 20)) scan = std::thread(longest);
+  else longest();
+  struct Joiner {
+    std::thread &t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+  } joiner{scan};
   std::unique_lock<std::mutex> lk;
   EncodeLane &d = dev->acquire(lk);  // held until the ids are back on the host
+  const auto t1 = now();
   try {
     HIP_CHECK(hipSetDevice(device));
     d.grow(d.d_bytes, d.cap_bytes, (size_t)total_bytes + 16);
     d.grow(d.d_off, d.cap_off, (size_t)n_sent + 1);
-    if (total_bytes) HIP_CHECK(hipMemcpyAsync(d.d_bytes, bytes + offsets[0], (size_t)total_bytes, hipMemcpyHostToDevice, d.st));
+    copy_up(device, d.d_bytes, bytes + offsets[0], (size_t)total_bytes, d.st);
     if (offsets[0] == 0) {
-      HIP_CHECK(hipMemcpyAsync(d.d_off, offsets, ((size_t)n_sent + 1) * 8, hipMemcpyHostToDevice, d.st));
+      copy_up(device, d.d_off, offsets, ((size_t)n_sent + 1) * 8, d.st);
       HIP_CHECK(hipStreamSynchronize(d.st));
     } else {  // offsets are rebased to the first byte of the batch
       std::vector<unsigned long long> rel((size_t)n_sent + 1);
       for (unsigned long long i = 0; i <= n_sent; i++) rel[i] = offsets[i] - offsets[0];
-      HIP_CHECK(hipMemcpyAsync(d.d_off, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, d.st));
+      copy_up(device, d.d_off, rel.data(), rel.size() * 8, d.st);
       HIP_CHECK(hipStreamSynchronize(d.st));
     }
   } catch (const GpuError &e) {
     return Status(2, "GPU error: " + e.msg);
   }
+  if (scan.joinable()) scan.join();
+  const double ms_up = ms_since(t1);
+  const auto t2 = now();
   unsigned long long n_ids = 0;
   Status s = encode_on_lane(enc, *dev, d, device, d.d_bytes, d.d_off, n_sent, total_bytes, max_len, bos, eos, reverse, dropout_prob, &n_ids, nullptr);
   if (!s.ok()) return s;
+  const double ms_enc = ms_since(t2);
+  const auto t3 = now();
   int32_t *ids = alloc_ids((size_t)n_ids);
   unsigned long long *off = alloc_off((size_t)n_sent + 1);
   if ((n_ids && !ids) || !off) return Status(2, "out of memory");
-  return fetch_lane(d, device, ids, off, n_sent);
+  const double ms_alloc = ms_since(t3);
+  const auto t4 = now();
+  s = fetch_lane(d, device, ids, off, n_sent);
+  if (trace)
+    fprintf(stderr, "[yttm] encode host -> host: %llu sentences, %.1f MB up, %.1f MB down: copy up %.1f ms, encode %.1f ms, result arrays %.1f ms, copy down %.1f ms\n",
+            n_sent, (double)(total_bytes + 8 * n_sent) / 1e6, (double)(4 * n_ids + 8 * n_sent) / 1e6, ms_up, ms_enc, ms_alloc, ms_since(t4));
+  return s;
 }
 
 Status BaseEncoder::encode_as_ids(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,
@@ -509,6 +564,20 @@ Status BaseEncoder::encode_as_ids(const uint8_t *bytes, const unsigned long long
       [&](size_t n) { ids->resize(n); return ids->data(); }, [&](size_t n) { out_off->assign(n, 0); return out_off->data(); });
 }
 
+// A result array the caller releases with free().  A large one is asked for in huge pages: the first touch of 1.2 GB of fresh 4 KB pages --
+// 3e5 page faults -- took 130 ms of a 10^7-sentence call, four times the link time of the copy that does the touching (MI355X box, transparent
+// huge pages on "madvise").
+static void *result_alloc(size_t bytes) {
+  constexpr size_t HUGE = 2u << 20;
+  if (bytes < 4 * HUGE) return malloc(bytes);
+  void *p = nullptr;
+  if (posix_memalign(&p, HUGE, (bytes + HUGE - 1) / HUGE * HUGE) != 0) return malloc(bytes);
+#ifdef MADV_HUGEPAGE
+  (void)madvise(p, (bytes + HUGE - 1) / HUGE * HUGE, MADV_HUGEPAGE);
+#endif
+  return p;
+}
+
 // the same into malloc'ed arrays (released by the caller with free()): what the C ABI hands out, without a copy in between
 Status BaseEncoder::encode_as_ids_malloc(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,
                                          bool reverse, double dropout_prob, int32_t **ids, unsigned long long **out_off) const {
@@ -516,8 +585,8 @@ Status BaseEncoder::encode_as_ids_malloc(const uint8_t *bytes, const unsigned lo
   *out_off = nullptr;
   Status s = encode_host_to_host(
       *this, dev_, device_, bytes, offsets, n_sent, bos, eos, reverse, dropout_prob,
-      [&](size_t n) { *ids = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t)); return *ids; },
-      [&](size_t n) { *out_off = (unsigned long long *)malloc((n ? n : 1) * sizeof(unsigned long long)); return *out_off; });
+      [&](size_t n) { *ids = (int32_t *)result_alloc((n ? n : 1) * sizeof(int32_t)); return *ids; },
+      [&](size_t n) { *out_off = (unsigned long long *)result_alloc((n ? n : 1) * sizeof(unsigned long long)); return *out_off; });
   if (!s.ok()) {
     free(*ids);
     free(*out_off);

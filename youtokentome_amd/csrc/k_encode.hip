@@ -473,30 +473,41 @@ __device__ inline void enc_pair_prio2(const EncModel &m, const uint32_t *bloom, 
 }
 
 // One lane, one word: tokens wt[ws, we), pair priorities wr[ws, we) (the last one ENC_INF).  Returns the new end.
+// Both loops go four places at a time -- the LDS reads of a step in flight together, one wait: a lane's walk is a chain of LDS round
+// trips, and with one word per lane there is little else to hide them behind.  (Indices past the word's end are clamped to its last place,
+// whose priority is ENC_INF: read twice, never the minimum.)
 __device__ inline int lane_rounds(const EncModel &m, const uint32_t *bloom, LdsArr wt, LdsArr wr, int ws, int we) {
   for (;;) {
-    // the word's smallest rule, leftmost site (the last token's pair has none: the scan may read it)
+    // the word's smallest rule, leftmost site
     uint32_t mn = ENC_INF;
     int at = ws;
-    for (int i = ws; i < we; i++) {
-      const uint32_t r = wr.get(i);
-      if (r < mn) {
-        mn = r;
-        at = i;
-      }
+    const int last = we - 1;
+    for (int i = ws; i < we; i += 4) {
+      const int i1 = i + 1 < last ? i + 1 : last, i2 = i + 2 < last ? i + 2 : last, i3 = i + 3 < last ? i + 3 : last;
+      const uint32_t r0 = wr.get(i), r1 = wr.get(i1), r2 = wr.get(i2), r3 = wr.get(i3);
+      if (r0 < mn) { mn = r0; at = i; }
+      if (r1 < mn) { mn = r1; at = i1; }
+      if (r2 < mn) { mn = r2; at = i2; }
+      if (r3 < mn) { mn = r3; at = i3; }
     }
     if (mn == ENC_INF) break;
     // (at, at + 1) -> z, the tail moves up one place.  Another site of the same rule further right is the next round's leftmost
     // minimum -- the pairs a merge makes rank behind the rule that made their token -- so sites go left to right like the reference's.
     const uint32_t z = enc_rule_z(m, mn);
     const uint32_t flags = wt.get(at) & (TOK_WS | ENC_SENT);
+    const uint32_t tr = at + 2 < we ? wt.get(at + 2) : TOK_WS;  // the token right of the pair, if the word has one
     wt.set(at, z | flags);
-    for (int i = at + 1; i + 1 < we; i++) {
-      wt.set(i, wt.get(i + 1));
-      wr.set(i, wr.get(i + 1));
+    for (int i = at + 1; i < last; i += 4) {  // place i takes what place i + 1 holds
+      const int s1 = i + 1, s2 = i + 2 < last ? i + 2 : last, s3 = i + 3 < last ? i + 3 : last, s4 = i + 4 < last ? i + 4 : last;
+      const uint32_t t1 = wt.get(s1), t2 = wt.get(s2), t3 = wt.get(s3), t4 = wt.get(s4);
+      const uint32_t r1 = wr.get(s1), r2 = wr.get(s2), r3 = wr.get(s3), r4 = wr.get(s4);
+      wt.set(i, t1);
+      wr.set(i, r1);
+      if (i + 1 < last) { wt.set(i + 1, t2); wr.set(i + 1, r2); }
+      if (i + 2 < last) { wt.set(i + 2, t3); wr.set(i + 2, r3); }
+      if (i + 3 < last) { wt.set(i + 3, t4); wr.set(i + 3, r4); }
     }
     we--;
-    const uint32_t tr = at + 1 < we ? wt.get(at + 1) : TOK_WS;
     const bool hl = at > ws && !(flags & TOK_WS), hr = !(tr & TOK_WS);  // (no pair across a word start)
     uint32_t pl, pr;
     enc_pair_prio2(m, bloom, hl, hl ? wt.get(at - 1) & ENC_IDM : 0u, z, hr, z, tr & ENC_IDM, &pl, &pr);
