@@ -60,6 +60,11 @@ for kind in KINDS:
             out.append((min(ms), "%016x" % L.yttm_ids_fnv1a64(ids.ctypes.data_as(_lib.i32p), o64.ctypes.data_as(_lib.u64p), k)))
         print("%s %-22s direct %8.3f ms  cached %8.3f ms  (%d sentences, %d distinct words)  fnv %s %s" % (
             kind, name, out[0][0], out[1][0], k, L.yttm_encode_cache_words(h), out[0][1], out[1][1]), flush=True)
+    ms = []
+    for _ in range(3):  # BPE-dropout 0.1 (never through the word cache)
+        assert L.yttm_encode_device(h, C.c_void_p(d.data_ptr()), C.c_void_p(d_off.data_ptr()), k, int(off[-1]), mx, 0, 0, 0, 0.1, C.byref(n_ids), C.byref(kms), err, 2048) == 0, err.value
+        ms.append(kms.value)
+    print("%s dropout 0.1: %s ms, %.3f ids per sentence" % (kind, ["%.1f" % x for x in ms], n_ids.value / k), flush=True)
     L.yttm_encoder_destroy(h)
     del d, d_off
     torch.cuda.empty_cache()

@@ -42,17 +42,6 @@ __device__ inline RuleSlot enc_load_slot(const EncModel &m, uint32_t h) {  // on
   r.pad = v.w;
   return r;
 }
-// slot of the rule (a,b) in the hash, or ENC_INF
-__device__ inline uint32_t enc_rule_lookup(const EncModel &m, uint32_t a, uint32_t b) {
-  const unsigned long long key = pair_key(a, b);
-  uint32_t h = enc_hash(a, b) & m.rule_mask;
-  for (;;) {
-    const unsigned long long k = m.rules[h].key;
-    if (k == key) return h;
-    if (k == PT_EMPTY) return ENC_INF;
-    h = (h + 1) & m.rule_mask;
-  }
-}
 // priority (= rule index, smaller merges first) of the pair (a,b), or ENC_INF.  The Bloom filter in LDS answers most
 // "no such rule" cases without leaving the CU; a positive costs one 16-byte load from the rule hash (L2-resident).
 __device__ inline uint32_t enc_pair_prio(const EncModel &m, const uint32_t *bloom, uint32_t a, uint32_t b) {
@@ -66,6 +55,33 @@ __device__ inline uint32_t enc_pair_prio(const EncModel &m, const uint32_t *bloo
     if (r.key == key) return r.pad;
     if (r.key == PT_EMPTY) return ENC_INF;
     sl = (sl + 1) & m.rule_mask;
+  }
+}
+
+// priorities of two pairs, both rule-hash loads in flight together (w0 / w1: which of the two are asked for; bloom == nullptr: no filter in
+// front of the rule hash -- the dropout kernel, whose LDS holds event queues instead)
+__device__ inline void enc_pair_prio2(const EncModel &m, const uint32_t *bloom, bool w0, uint32_t a0, uint32_t b0, bool w1, uint32_t a1, uint32_t b1,
+                                      uint32_t *p0, uint32_t *p1) {
+  const uint32_t h0 = enc_hash(a0, b0), h1 = enc_hash(a1, b1);
+  const uint32_t g0 = enc_bloom_bits(h0), g1 = enc_bloom_bits(h1);
+  w0 = w0 && a0 != ENC_UNKP && b0 != ENC_UNKP && (!bloom || (bloom[enc_bloom_word(h0)] & g0) == g0);
+  w1 = w1 && a1 != ENC_UNKP && b1 != ENC_UNKP && (!bloom || (bloom[enc_bloom_word(h1)] & g1) == g1);
+  uint32_t s0 = h0 & m.rule_mask, s1 = h1 & m.rule_mask;
+  RuleSlot r0{PT_EMPTY, 0u, 0u}, r1{PT_EMPTY, 0u, 0u};
+  if (w0) r0 = enc_load_slot(m, s0);
+  if (w1) r1 = enc_load_slot(m, s1);
+  const unsigned long long k0 = pair_key(a0, b0), k1 = pair_key(a1, b1);
+  *p0 = ENC_INF;
+  *p1 = ENC_INF;
+  while (r0.key != PT_EMPTY) {
+    if (r0.key == k0) { *p0 = r0.pad; break; }
+    s0 = (s0 + 1) & m.rule_mask;
+    r0 = enc_load_slot(m, s0);
+  }
+  while (r1.key != PT_EMPTY) {
+    if (r1.key == k1) { *p1 = r1.pad; break; }
+    s1 = (s1 + 1) & m.rule_mask;
+    r1 = enc_load_slot(m, s1);
   }
 }
 
@@ -174,6 +190,30 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
     if (ws) wsl.set(nw + __popcll(W & lt), (uint32_t)p);
     nw += __popcll(W);
   }
+  // every pair's rule, lanes = positions: the words' first events (bpe.cpp:1556-1558) come from here -- one rule-hash round trip per 64
+  // pairs, where a lane looking its word's pairs up one after the other made the wave wait for as many trips as its longest word has pairs.
+  // (wm is free until a lane lays its word's links into it.)
+  for (int c = 0; c < ((n + 63) >> 6); c += 2) {
+    const int p0 = c * 64 + lane, p1 = p0 + 64;
+    uint32_t a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+    bool w0 = false, w1 = false;
+    if (p0 + 1 < n) {
+      const uint32_t t = wt.get(p0 + 1);
+      a0 = wt.get(p0) & ENC_IDM;
+      b0 = t & ENC_IDM;
+      w0 = !(t & TOK_WS);
+    }
+    if (p1 + 1 < n) {
+      const uint32_t t = wt.get(p1 + 1);
+      a1 = wt.get(p1) & ENC_IDM;
+      b1 = t & ENC_IDM;
+      w1 = !(t & TOK_WS);
+    }
+    uint32_t r0, r1;
+    enc_pair_prio2(m, nullptr, w0, a0, b0, w1, a1, b1, &r0, &r1);
+    if (p0 < n) wm.set(p0, r0);
+    if (p1 < n) wm.set(p1, r1);
+  }
   wave_sync();
   for (int w = lane; w < nw; w += 64) {
     const int ws = (int)wsl.get(w);
@@ -182,17 +222,15 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
     const int cap = 3 * (we - ws);             // the word's share of the queue space: every event it can ever hold
     const bool heap = we - ws >= d.heap_from;  // (skipped events of a pop wait at the top end of that space)
     int ne = 0;
-    for (int i = ws; i < we; i++) {
-      wr.set(i, i + 1 < we ? (uint32_t)(i + 1) : NIL);
-      wm.set(i, i > ws ? (uint32_t)(i - 1) : NIL);
-    }
     auto add = [&](unsigned long long key) {
       if (heap) heap_push(ev, ne, key);
       else ev_insert(ev, ne, key);
     };
-    for (int i = ws; i + 1 < we; i++) {  // bpe.cpp:1556-1558
-      const uint32_t slot = enc_rule_lookup(m, wt.get(i) & ENC_IDM, wt.get(i + 1) & ENC_IDM);
-      if (slot != ENC_INF) add(((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)i);
+    for (int i = ws; i < we; i++) {
+      const uint32_t r = wm.get(i);
+      if (i + 1 < we && r != ENC_INF) add(((unsigned long long)r << 32) | (unsigned long long)i);
+      wr.set(i, i + 1 < we ? (uint32_t)(i + 1) : NIL);
+      wm.set(i, i > ws ? (uint32_t)(i - 1) : NIL);
     }
     uint32_t draw = 0;
     for (;;) {
@@ -230,13 +268,12 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
       wt.set(p1, m.rule_z[rule] | (t1 & (TOK_WS | ENC_SENT)));
       wr.set(p1, p3);
       if (p3 != NIL) wm.set((int)p3, (uint32_t)p1);
-      if (p0 != NIL) {
-        const uint32_t slot = enc_rule_lookup(m, wt.get((int)p0) & ENC_IDM, wt.get(p1) & ENC_IDM);
-        if (slot != ENC_INF) add(((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)p0);
-      }
-      if (p3 != NIL) {
-        const uint32_t slot = enc_rule_lookup(m, wt.get(p1) & ENC_IDM, wt.get((int)p3) & ENC_IDM);
-        if (slot != ENC_INF) add(((unsigned long long)m.rules[slot].pad << 32) | (unsigned long long)p1);
+      {  // the two pairs the merge made (:1580-1585), their rule-hash loads in flight together
+        const uint32_t zt = wt.get(p1) & ENC_IDM;
+        uint32_t rl, rr;
+        enc_pair_prio2(m, nullptr, p0 != NIL, p0 != NIL ? wt.get((int)p0) & ENC_IDM : 0u, zt, p3 != NIL, zt, p3 != NIL ? wt.get((int)p3) & ENC_IDM : 0u, &rl, &rr);
+        if (rl != ENC_INF) add(((unsigned long long)rl << 32) | (unsigned long long)p0);
+        if (rr != ENC_INF) add(((unsigned long long)rr << 32) | (unsigned long long)p1);
       }
     }
   }
@@ -445,32 +482,6 @@ __device__ int merge_rounds(const EncModel &m, const uint32_t *bloom, A wt, A wr
 // round go out together).  No ballots, no atomics, no wave-wide passes until the words are done; the order of merges inside a word is the
 // reference's (bpe.cpp:1560-1589): by rule, then left to right.
 constexpr uint32_t ENC_DEAD = 0xffffffffu;  // a position a finished word no longer uses (never a token: id bits above ENC_UNKP)
-
-// priorities of two pairs, both rule-hash loads in flight together (w0 / w1: which of the two are asked for)
-__device__ inline void enc_pair_prio2(const EncModel &m, const uint32_t *bloom, bool w0, uint32_t a0, uint32_t b0, bool w1, uint32_t a1, uint32_t b1,
-                                      uint32_t *p0, uint32_t *p1) {
-  const uint32_t h0 = enc_hash(a0, b0), h1 = enc_hash(a1, b1);
-  const uint32_t g0 = enc_bloom_bits(h0), g1 = enc_bloom_bits(h1);
-  w0 = w0 && a0 != ENC_UNKP && b0 != ENC_UNKP && (bloom[enc_bloom_word(h0)] & g0) == g0;
-  w1 = w1 && a1 != ENC_UNKP && b1 != ENC_UNKP && (bloom[enc_bloom_word(h1)] & g1) == g1;
-  uint32_t s0 = h0 & m.rule_mask, s1 = h1 & m.rule_mask;
-  RuleSlot r0{PT_EMPTY, 0u, 0u}, r1{PT_EMPTY, 0u, 0u};
-  if (w0) r0 = enc_load_slot(m, s0);
-  if (w1) r1 = enc_load_slot(m, s1);
-  const unsigned long long k0 = pair_key(a0, b0), k1 = pair_key(a1, b1);
-  *p0 = ENC_INF;
-  *p1 = ENC_INF;
-  while (r0.key != PT_EMPTY) {
-    if (r0.key == k0) { *p0 = r0.pad; break; }
-    s0 = (s0 + 1) & m.rule_mask;
-    r0 = enc_load_slot(m, s0);
-  }
-  while (r1.key != PT_EMPTY) {
-    if (r1.key == k1) { *p1 = r1.pad; break; }
-    s1 = (s1 + 1) & m.rule_mask;
-    r1 = enc_load_slot(m, s1);
-  }
-}
 
 // One lane, one word: tokens wt[ws, we), pair priorities wr[ws, we) (the last one ENC_INF).  Returns the new end.
 // Both loops go four places at a time -- the LDS reads of a step in flight together, one wait: a lane's walk is a chain of LDS round
