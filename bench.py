@@ -435,6 +435,7 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
            "index_builds": r.get("index_builds"),
            "input": ("file in the page cache -> yttm_train_bpe_comm(path, model): open + pread into pinned chunks + H2D + train + model file closed (SURVEY.md 8d); "
                      "the HBM-resident figure is `value_hbm_resident`") if corpus_path else "resident in HBM before the timed region (--scaling weak: one corpus per rank, no single file)",
+           "front_end_under_the_upload": bool(r.get("front_end_overlapped")),  # (K1, K2a, K2b ran on the parts of the file as they landed: their time is in phases_s.upload)
            "model_md5": model_md5, "pinned_model_md5": pin["model_md5"] if pin else None}
     if ctx["comm"] is not None:
         cfg["multi_gpu_mode"] = ("replicated merge loop: shards gathered once after the local dedup, every rank runs the merge loop alone, no per-round collective"
@@ -525,8 +526,9 @@ def _static_traffic(kern, corpus, size_mb, args, world):
             if k.startswith(prefixes):
                 return name
         return None
-    # (the profiled command trains more than once per process -- the file step, the HBM-resident warm-up and step: K1 runs once per training)
-    n_train = max(1, sum(pm[k]["launches"] for k in pm if k.startswith("k_scan_bytes<0")))
+    # (the profiled command trains more than once per process -- the file step, the HBM-resident warm-up and step: the histogram is compacted
+    # once per training; K1 itself runs once per part of the text in a file step, gpu_ctx.cpp upload_fd_overlapped)
+    n_train = max(1, sum(pm[k]["launches"] for k in pm if k.startswith("k_hist_compact")))
     for name in ("char_hist", "segments", "dedup", "pair_count", "merge_apply", "cand_scan"):
         ks = [k for k in pm if family(k) == name]
         if ks and name in kern:

@@ -299,6 +299,54 @@ def check_train_vs_oracle(text, vocab, tmp_path, coverage=1.0, ids=(0, 1, 2, 3),
     return None
 
 
+def train_file_report(text, vocab, tmp_path, coverage=1.0, tag="r"):
+    """yttm_train_bpe_comm(file -> model) through the C ABI: (the model's path, the trainer's report)"""
+    import ctypes as C
+    import json
+    from youtokentome_amd import _lib
+    L = _lib.load()
+    corpus, model = str(tmp_path / f"{tag}.txt"), str(tmp_path / f"{tag}.model")
+    open(corpus, "wb").write(text)
+    err, rep = C.create_string_buffer(_lib.ERRLEN), C.create_string_buffer(16384)
+    rc = L.yttm_train_bpe_comm(corpus.encode(), model.encode(), vocab, coverage, 1, 0, 1, 2, 3, 0, 0, None, rep, 16384, err, _lib.ERRLEN)
+    assert rc == 0, err.value
+    return model, json.loads(rep.value.decode())
+
+
+def check_front_end_under_upload(tmp_path, rounds=10, seed=61):
+    """A text of some size is worked on in parts while it is still being uploaded (gpu_ctx.cpp upload_fd_overlapped): K1, K2a and a
+    dedup that compares words by code points; the word table is taken when the alphabet keeps every char (coverage 1) and made again the
+    usual way when it does not.  Here every text, in parts of 4 KB with upload chunks of 4 KB: models against the oracle's, and the
+    report says which way the word table came."""
+    import random
+    rng = random.Random(seed)
+    took = dropped = 0
+    for it in range(rounds):
+        kind = list(gen.UNICODE_ALPHABETS)[it % len(gen.UNICODE_ALPHABETS)]
+        r = it % 4
+        if r == 0:
+            text, cov = gen.unicode_text(rng, rng.randint(3000, 12000), kind, p_invalid=0.02 if it % 8 == 0 else 0.0), 1.0
+        elif r == 1:
+            text, cov = gen.unicode_text(rng, rng.randint(3000, 12000), kind), rng.choice([0.95, 0.9, 0.7])
+        elif r == 2:
+            text, cov = gen.readme_corpus(rng.randint(100, 400), rng.randint(40, 120), "abcd ", seed=rng.randint(0, 10 ** 6)), 1.0
+        else:
+            text, cov = gen.zipf_corpus(rng.randint(20000, 80000), vocab=rng.randint(50, 3000), seed=rng.randint(0, 10 ** 6)), 1.0
+        if b"\xff" in text and cov == 1.0:
+            cov = 0.9  # (invalid bytes + coverage 1 would crash the reference)
+        vocab = rng.randint(60, 200)
+        m_ora = str(tmp_path / f"fe{it}.ora.model")
+        try:
+            O.train(text, m_ora, vocab, cov, 0, 1, 2, 3)
+        except ValueError:
+            continue
+        model, rep = train_file_report(text, vocab, tmp_path, cov, tag=f"fe{it}")
+        assert filecmp.cmp(model, m_ora, shallow=False), f"model differs (round {it}, coverage {cov})"
+        took += rep["front_end_overlapped"]
+        dropped += 1 - rep["front_end_overlapped"]
+    assert took > 0 and dropped > 0, (took, dropped)
+
+
 def check_encode_vs_oracle(model_path, sentences, flags=((0, 0, 0), (1, 1, 0), (0, 0, 1), (1, 1, 1))):
     import youtokentome_amd as yttm
     bpe = yttm.BPE(model_path)

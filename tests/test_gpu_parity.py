@@ -40,6 +40,13 @@ def test_k5_dropout_heap_equals_array():
     S.check_dropout_heap_equals_array()
 
 
+def test_front_end_under_the_upload(tmp_path, monkeypatch):
+    monkeypatch.setenv("YTTM_FE_OVERLAP_MIN", "0")
+    monkeypatch.setenv("YTTM_FE_PART_KB", "4")
+    monkeypatch.setenv("YTTM_IO_CHUNK_KB", "4")
+    S.check_front_end_under_upload(tmp_path, rounds=24)
+
+
 def test_k5_word_cache():
     S.check_encode_word_cache(n_sent=2000)
 

@@ -164,6 +164,13 @@ def test_encode_mixed_shapes():
     S.check_encode_mixed_shapes(n_sent=150)
 
 
+def test_front_end_under_the_upload(tmp_path, monkeypatch):
+    monkeypatch.setenv("YTTM_FE_OVERLAP_MIN", "0")
+    monkeypatch.setenv("YTTM_FE_PART_KB", "4")
+    monkeypatch.setenv("YTTM_IO_CHUNK_KB", "4")
+    S.check_front_end_under_upload(tmp_path, rounds=12)
+
+
 def test_encode_word_cache():
     S.check_encode_word_cache()
 

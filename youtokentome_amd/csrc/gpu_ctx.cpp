@@ -10,6 +10,8 @@
 #include <mutex>
 #include <map>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <functional>
 #include <thread>
 #include <unistd.h>
@@ -229,6 +231,7 @@ GpuCtx::~GpuCtx() {
   tl_stream = st_;
   tl_device = device_;
   (void)hipStreamSynchronize(st_);
+  drop_spec();
   for (hipEvent_t e : all_events_) (void)hipEventDestroy(e);
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_chunk_segs_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_);
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
@@ -338,6 +341,7 @@ void GpuCtx::resolve_timers() {
 
 // ------------------------------------------------------------------------------------------------- corpus
 void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
+  drop_spec();
   if (n < (32u << 20) || getenv("YTTM_PLAIN_UPLOAD")) {  // small, or (tuning hook) the one-copy path for comparison
     HIP_CHECK(hipSetDevice(device_));
     tl_stream = st_;
@@ -413,15 +417,18 @@ void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *
 // bytes [off, off + len) (pread, memcpy) before it goes up; else it DRAINS the chunk that has come down (memcpy to where the caller wants
 // the bytes -- several workers at once, which also spreads the page faults of a freshly allocated destination).  Returns when every byte
 // has arrived.  Throws GpuError.
+size_t staged_chunk_bytes() {
+  const size_t mb = std::min<size_t>(std::max<size_t>(env_uint("YTTM_IO_CHUNK_MB", 8), 1), IO_CHUNK_MAX >> 20);
+  size_t c = mb << 20;
+  if (const size_t kb = env_uint("YTTM_IO_CHUNK_KB", 0)) c = std::min<size_t>(kb << 10, IO_CHUNK_MAX);  // (tests: many chunks of a small batch)
+  return c;
+}
 void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_device,
-                     const std::function<bool(void *chunk, unsigned long long off, size_t len)> &host_side) {
+                     const std::function<bool(void *chunk, unsigned long long off, size_t len)> &host_side,
+                     const std::function<void(unsigned long long off, size_t len)> &arrived) {
   if (!n) return;
   HIP_CHECK(hipSetDevice(device));
-  {
-    const size_t mb = std::min<size_t>(std::max<size_t>(env_uint("YTTM_IO_CHUNK_MB", 8), 1), IO_CHUNK_MAX >> 20);
-    IO_CHUNK = mb << 20;
-    if (const size_t kb = env_uint("YTTM_IO_CHUNK_KB", 0)) IO_CHUNK = std::min<size_t>(kb << 10, IO_CHUNK_MAX);  // (tests: many chunks of a small batch)
-  }
+  IO_CHUNK = staged_chunk_bytes();
   const size_t n_chunks = (size_t)((n + IO_CHUNK - 1) / IO_CHUNK);
   int n_threads = (int)env_uint("YTTM_IO_THREADS", 0);
   // (default 4: one thread preads 40 GB/s out of the page cache on the MI355X box, the link takes 55; eight workers measured SLOWER than three
@@ -452,6 +459,7 @@ void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_d
       if (to_device) {
         if (!host_side(tmp.data(), off, len)) throw GpuError{"corpus read failed"};
         HIP_CHECK(hipMemcpy(d_ptr + off, tmp.data(), len, hipMemcpyHostToDevice));
+        if (arrived) arrived(off, len);
       } else {
         HIP_CHECK(hipMemcpy(tmp.data(), d_ptr + off, len, hipMemcpyDeviceToHost));
         if (!host_side(tmp.data(), off, len)) throw GpuError{"copy to the host failed"};
@@ -481,6 +489,7 @@ void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_d
         HIP_CHECK(hipEventSynchronize(ev[k]));
         used[k] = false;
         if (!to_device && !host_side(g_io.pin[2 * w + k], held_off[k], held_len[k])) throw GpuError{"copy to the host failed"};
+        if (to_device && arrived) arrived(held_off[k], held_len[k]);
       };
       for (int k = 0;; k ^= 1) {
         const size_t c = next.fetch_add(1);
@@ -493,11 +502,12 @@ void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_d
           HIP_CHECK(hipMemcpyAsync(d_ptr + off, g_io.pin[2 * w + k], len, hipMemcpyHostToDevice, cs));
         } else {
           HIP_CHECK(hipMemcpyAsync(g_io.pin[2 * w + k], d_ptr + off, len, hipMemcpyDeviceToHost, cs));
-          held_off[k] = off;
-          held_len[k] = len;
         }
+        held_off[k] = off;
+        held_len[k] = len;
         HIP_CHECK(hipEventRecord(ev[k], cs));
         used[k] = true;
+        if (to_device && arrived) drain(k ^ 1);  // (somebody waits for the bytes: say that the previous chunk has landed now, not a fill later)
       }
       drain(0);
       drain(1);
@@ -519,7 +529,209 @@ void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_d
   if (failed.load()) throw GpuError{first_error};
 }
 
+void GpuCtx::drop_spec() {
+  if (spec_.ht) DFREE(spec_.ht);
+  spec_ = FrontSpec();
+}
+
+// The front end under the upload (single GPU).  A GB of file needs 18 ms on the link, and the device idles through them; K1, K2a and K2b of
+// the same GB are 10 ms of work that needs nothing but the bytes: K1 and K2a by construction, K2b -- the dedup -- if every word is compared
+// by its CODE POINTS instead of its token ids, which is the same partition of the segments into words whenever the alphabet keeps every
+// char of the text (coverage 1, the default): the ids are then an injective renaming of the chars.  So the text is worked on in parts as they
+// land -- the workers of staged_transfer report the chunks, a part is ready when every byte up to one scan chunk behind its end is there --
+// and build_word_table() takes the finished word table if the alphabet turns out to keep everything, else runs its own K2a / K2b as before.
+// A part's last segment may run on into bytes that have not arrived: it is inserted with the next part that has a segment of its own.
+void GpuCtx::upload_fd_overlapped(int fd, unsigned long long lo, unsigned long long n) {
+  HIP_CHECK(hipSetDevice(device_));
+  tl_stream = st_;
+  tl_device = device_;
+  drop_spec();
+  DFREE(d_text_owned_);
+  d_text_owned_ = dmalloc<uint8_t>(n + 64);
+  d_text_ = d_text_owned_;
+  n_text_ = n;
+  corpus_bytes = n;
+  auto fill = [&](void *dst, unsigned long long off, size_t len) {
+    size_t got = 0;
+    while (got < len) {
+      const ssize_t r = pread(fd, (char *)dst + got, len - got, (off_t)(lo + off + got));
+      if (r <= 0) return false;
+      got += (size_t)r;
+    }
+    return true;
+  };
+  // K1's variant from four samples of the FILE (char_hist samples the text in HBM, which is not there yet)
+  bool wide_chars = false;
+  if (n >= (1u << 16)) {
+    unsigned int wide = 0;
+    uint8_t smp[4096];
+    for (int i = 0; i < 4; i++) {
+      if (!fill(smp, (n / 4) * (unsigned long long)i, sizeof smp)) throw GpuError{"corpus read failed"};
+      for (size_t j = 0; j < sizeof smp; j++) wide += smp[j] >= 0xE0u;
+    }
+    wide_chars = wide * 100u > 4u * 4096u;
+  } else {
+    wide_chars = true;
+  }
+  if (const char *e = getenv("YTTM_K1_WIDE")) wide_chars = atoi(e) != 0;
+  if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
+  HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
+  HIP_CHECK(hipMemsetAsync(d_counters_, 0, 64 * 8, st_));
+  const unsigned long long nch = fe_chunks(n);
+  DFREE(d_chunk_segs_);
+  d_chunk_segs_ = dmalloc<uint32_t>(nch + 1);
+  // the speculative map: a char's id is its code point
+  uint32_t *d_cpmap_spec = dmalloc<uint32_t>(N_CODEPOINTS);
+  {
+    static std::vector<uint32_t> ident;
+    static std::once_flag once;
+    std::call_once(once, [] {
+      ident.resize(N_CODEPOINTS);
+      for (uint32_t c = 0; c < N_CODEPOINTS; c++) ident[c] = c;
+      const uint32_t spaces[] = {9, 10, 11, 12, 13, 32, 9601};
+      for (uint32_t sp : spaces) ident[sp] = CP_SPACE;
+    });
+    HIP_CHECK(hipMemcpyAsync(d_cpmap_spec, ident.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, st_));
+  }
+  unsigned long long *d_chunk_off = dmalloc<unsigned long long>(nch + 1);
+  // ---- the upload, on a thread of its own; what has landed, in order
+  const size_t io_chunk = staged_chunk_bytes();
+  const size_t n_io = (size_t)((n + io_chunk - 1) / io_chunk);
+  std::vector<uint8_t> landed(n_io, 0);
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t next_io = 0;  // chunks [0, next_io) have landed
+  bool finished = false;
+  std::string up_error;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+  double ms_link = 0;
+  std::thread up([&] {
+    try {
+      staged_transfer(device_, d_text_owned_, n, true, fill, [&](unsigned long long off, size_t) {
+        std::lock_guard<std::mutex> g(mu);
+        landed[(size_t)(off / io_chunk)] = 1;
+        bool moved = false;
+        while (next_io < n_io && landed[next_io]) { next_io++; moved = true; }
+        if (moved) cv.notify_all();
+      });
+    } catch (const GpuError &e) {
+      up_error = e.msg;
+    }
+    ms_link = ms_now();
+    std::lock_guard<std::mutex> g(mu);
+    finished = true;
+    cv.notify_all();
+  });
+  auto wait_for = [&](unsigned long long bytes) {  // until [0, bytes) has landed (or the upload is over)
+    std::unique_lock<std::mutex> g(mu);
+    cv.wait(g, [&] { return finished || std::min<unsigned long long>(n, (unsigned long long)next_io * io_chunk) >= bytes; });
+  };
+  // ---- the parts
+  const unsigned long long FC = fe_chunk_bytes();
+  unsigned long long part = (unsigned long long)env_uint("YTTM_FE_PART_KB", 32u << 10) << 10;  // (32 MB: the last part is 0.8 ms of work behind the last byte; tests: a few KB)
+  part = std::max(FC, part / FC * FC);
+  bool spec_on = !getenv("YTTM_FE_NO_SPEC");
+  const unsigned int k2b_blocks = env_uint("YTTM_FE_K2B_BLOCKS", 4096);  // (tuning hook)
+  unsigned long long *d_seg = nullptr, seg_cap = 0, base = 0;
+  unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
+  unsigned long long pending = 0;  // the last segment so far: not inserted yet
+  bool have_pending = false;
+  std::string fail;
+  try {
+    for (unsigned long long b0 = 0; b0 < n; b0 += part) {
+      const unsigned long long b1 = std::min(n, b0 + part);
+      wait_for(std::min(n, b1 + FC));
+      if (!up_error.empty()) break;
+      const unsigned long long c_lo = b0 / FC, c_hi = fe_chunks(b1);
+      t_begin(KT_CHAR_HIST);
+      launch_char_hist(d_text_, n, d_hist_, d_counters_, wide_chars, d_chunk_segs_, st_, c_lo, c_hi);
+      t_end(KT_CHAR_HIST, b1 - b0);
+      if (!spec_on) continue;
+      // the part's segments: where they go (relative to the part's first), how many
+      unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(c_hi - c_lo));
+      t_begin(KT_SEGS);
+      launch_exclusive_scan(d_chunk_segs_ + c_lo, c_hi - c_lo, d_chunk_off + c_lo, scan_tmp, d_counters_ + 16, st_);
+      unsigned long long n_p = 0;
+      HIP_CHECK(hipMemcpyAsync(&n_p, d_counters_ + 16, 8, hipMemcpyDeviceToHost, st_));
+      sync();
+      DFREE(scan_tmp);
+      if (b0 == 0) {  // sizes from the first part's density of segments (build_word_table's rules, on an estimate)
+        const double est = (double)n_p * ((double)n / (double)(b1 - b0)) * 1.1 + 1024.0;
+        seg_cap = (unsigned long long)(est * 1.1);
+        d_seg = dmalloc<unsigned long long>(seg_cap);
+        spec_.long_segments = n_p == 0 || (b1 - b0) / std::max<unsigned long long>(n_p, 1) >= 16;
+        const unsigned long long ns = (unsigned long long)est;
+        spec_.ht_cap = !spec_.long_segments && !getenv("YTTM_WORD_TABLE_FULL") ? pow2_at_least(std::max<unsigned long long>(ns / 4, 1ull << 16))
+                                                                                : pow2_at_least(ns + ns / 2 + 1024);
+        spec_.ht = dmalloc<unsigned long long>(3 * spec_.ht_cap);
+        launch_word_table_clear(spec_.ht, spec_.ht_cap, st_);
+        HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
+      }
+      if (base + n_p > seg_cap) {  // denser than the first part promised: no room for the segment starts -- the usual way then
+        t_end(KT_SEGS, 0);
+        spec_on = false;
+        continue;
+      }
+      launch_seg_write(d_text_, n, d_seg + base, d_chunk_off, st_, c_lo, c_hi);
+      t_end(KT_SEGS, (b1 - b0) + 8 * n_p);
+      if (n_p) {
+        // every segment that starts in this part but its last -- that one may run on into bytes that have not landed -- and the last of the
+        // parts before, which ended in front of this part's first segment
+        const unsigned long long from = have_pending ? pending : base, to = base + n_p - 1;
+        if (to > from) {
+          t_begin(KT_DEDUP);
+          launch_insert_words(d_text_, n, d_cpmap_spec, d_seg + from, to - from, spec_.ht, spec_.ht_cap - 1, d_status, st_, k2b_blocks);
+          t_end(KT_DEDUP, (b1 - b0) + 8 * n_p);
+        }
+        pending = to;
+        have_pending = true;
+      }
+      base += n_p;
+    }
+  } catch (const GpuError &e) {
+    fail = e.msg;
+  }
+  up.join();
+  if (fail.empty() && !up_error.empty()) fail = up_error;
+  if (fail.empty()) {
+    try {
+      if (spec_on && d_seg) {
+        if (have_pending) {
+          t_begin(KT_DEDUP);
+          launch_insert_words(d_text_, n, d_cpmap_spec, d_seg + pending, 1, spec_.ht, spec_.ht_cap - 1, d_status, st_);
+          t_end(KT_DEDUP, 0);
+        }
+        HIP_CHECK(hipMemcpyAsync(spec_.h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
+      }
+      sync();
+    } catch (const GpuError &e) {
+      fail = e.msg;
+    }
+  }
+  DFREE(d_seg);
+  DFREE(d_chunk_off);
+  DFREE(d_cpmap_spec);
+  if (!fail.empty()) {
+    drop_spec();
+    throw GpuError{fail};
+  }
+  if (getenv("YTTM_TRACE"))
+    fprintf(stderr, "[yttm] front end under the upload: the last byte landed after %.2f ms, the last part was done after %.2f ms (%llu segments, parts of %llu MB, word table %s)\n",
+            ms_link, ms_now(), base, part >> 20, spec_on && spec_.ht ? "made" : "left to build_word_table");
+  spec_.hist_done = true;
+  spec_.n_segs = base;
+  spec_.words_done = spec_on && spec_.ht != nullptr;
+  if (!spec_.words_done && spec_.ht) DFREE(spec_.ht);
+}
+
 void GpuCtx::upload_corpus_fd(int fd, unsigned long long lo, unsigned long long n) {
+  // (the front end under the upload: one GPU -- the shards of several are cut and counted together -- and a text worth the trouble)
+  if (!multi() && n >= (unsigned long long)env_uint("YTTM_FE_OVERLAP_MIN", 32u << 20) && !getenv("YTTM_FE_NO_OVERLAP")) {
+    upload_fd_overlapped(fd, lo, n);
+    return;
+  }
+  drop_spec();
   upload_staged(n, [&](void *dst, unsigned long long off, size_t len) {
     size_t got = 0;
     while (got < len) {
@@ -549,6 +761,7 @@ unsigned long long GpuCtx::free_device_bytes() const {
   return (unsigned long long)fr + (unsigned long long)g_pool.cached;
 }
 void GpuCtx::gather_full_corpus() {
+  drop_spec();
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
@@ -585,6 +798,7 @@ void GpuCtx::gather_full_corpus() {
 }
 
 void GpuCtx::attach_corpus(const void *dev, unsigned long long n) {
+  drop_spec();
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
@@ -600,6 +814,9 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
+  const bool have_k1 = spec_.hist_done && !multi();  // (upload_fd_overlapped ran K1 on the parts of the text as they arrived)
+  spec_.hist_done = false;
+  if (!have_k1) {
   if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
   HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
   HIP_CHECK(hipMemsetAsync(d_counters_, 0, 64 * 8, st_));
@@ -623,6 +840,7 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
   d_chunk_segs_ = dmalloc<uint32_t>(fe_chunks(n_text_) + 1);
   if (n_text_) launch_char_hist(d_text_, n_text_, d_hist_, d_counters_, wide_chars, d_chunk_segs_, st_);
   t_end(KT_CHAR_HIST, n_text_);
+  }
   unsigned long long h_cnt[2] = {0, 0};
   HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 16, hipMemcpyDeviceToHost, st_));
   sync();
@@ -650,6 +868,7 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
     HIP_CHECK(hipMemcpyAsync(cnts.data(), d_cnts, (size_t)k * 8, hipMemcpyDeviceToHost, st_));
     sync();
   }
+  seen_cps_ = cps;
   DFREE(d_cps);
   DFREE(d_cnts);
 }
@@ -684,7 +903,33 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   id_cap_ = n_ids_cap + 64;
 
   const unsigned long long n_segs = n_segments;
-  if (n_segs == 0 || n_text_ == 0) return;
+  if (n_segs == 0 || n_text_ == 0) { drop_spec(); return; }
+  // The word table upload_fd_overlapped made under the upload is this text's iff words compared by code points are words compared by ids:
+  // every char that occurs (and is no space) has an id of its own.  And the table must not have overflowed or filled beyond what the sizing
+  // below accepts.
+  bool take_spec = spec_.words_done && spec_.n_segs == n_segs && !multi();
+  if (take_spec) {
+    std::vector<uint32_t> kept(cp, cp + n_alpha);
+    std::sort(kept.begin(), kept.end());
+    for (uint32_t c : seen_cps_) {
+      const bool space = c == 32 || (c >= 9 && c <= 13) || c == 9601;
+      if (!space && !std::binary_search(kept.begin(), kept.end(), c)) { take_spec = false; break; }
+    }
+    if (spec_.h_status[6] || (!spec_.long_segments && (unsigned long long)spec_.h_status[0] * 2 > spec_.ht_cap)) take_spec = false;
+  }
+  unsigned long long *ht = nullptr;
+  unsigned long long ht_cap = 0;
+  unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
+  unsigned int h_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (take_spec) {
+    ht = spec_.ht;
+    ht_cap = spec_.ht_cap;
+    memcpy(h_status, spec_.h_status, sizeof h_status);
+    spec_.ht = nullptr;
+    front_end_overlapped = true;
+  }
+  drop_spec();
+  if (!take_spec) {
   // segment starts
   unsigned long long *d_seg = dmalloc<unsigned long long>(n_segs);
   {
@@ -704,10 +949,6 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   // benchmark corpora have far fewer: Heaps' law) -- the compaction pass streams it, and a small table keeps the frequent words'
   // slots cache-resident; a corpus of mostly distinct words overflows it (probe chains beyond WH_MAX_PROBES) and is redone
   // with the worst-case size.
-  unsigned long long *ht = nullptr;
-  unsigned long long ht_cap = 0;
-  unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
-  unsigned int h_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int attempt = 0;; attempt++) {
     // (long segments -- CJK-shaped text: clauses of dozens of chars between white space -- are nearly all distinct: the estimate is bound to
     // fail there and the whole dedup would run twice; K1 knows the average segment length)
@@ -729,6 +970,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
     word_table_retries++;
   }
   DFREE(d_seg);
+  }
   if (h_status[5] >= (1u << 28)) {
     DFREE(ht);
     throw GpuError{"a word of 2^28 or more characters is not supported"};

@@ -18,8 +18,11 @@ struct GpuError {
 
 // n bytes between HBM and the host through pinned chunks that several host threads fill (to_device) or drain (gpu_ctx.cpp): what a single
 // hipMemcpy from / to pageable memory does on one thread through one internal buffer.  host_side(chunk, off, len) -> false: give up.
+// arrived(off, len) (to_device only, may be empty): bytes [off, off + len) are in HBM -- called from the workers' threads, chunks in no order.
 void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_device,
-                     const std::function<bool(void *chunk, unsigned long long off, size_t len)> &host_side);
+                     const std::function<bool(void *chunk, unsigned long long off, size_t len)> &host_side,
+                     const std::function<void(unsigned long long off, size_t len)> &arrived = nullptr);
+size_t staged_chunk_bytes();  // the chunk size the next staged_transfer will use
 
 // Exchange interface for the multi-GPU path (one process per GPU).  Implementations: RCCL over xGMI
 // (comm_rccl.cpp) and a host-callback variant used by the gloo CPU tests.
@@ -97,6 +100,7 @@ class GpuCtx {
   int last_top_bin() const { return (int)last_top_bin_; }  // no bin above this one is in use
   unsigned long long index_builds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0, word_fused_rounds = 0;  // K4 rounds whose worklist came from the pair index
   unsigned long long word_table_retries = 0;  // K2: the word table had to be redone with the worst-case size
+  bool front_end_overlapped = false;          // K1, K2a, K2b ran under the upload and the word table they made was taken (upload_fd_overlapped)
   unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0, delta_regrows = 0;
   unsigned long long tail_ticks[3] = {0, 0, 0}, tail_listed = 0;  // round_tail: fold / list scan / publish, in 10 ns ticks; entries it read
   unsigned long long fused_rounds = 0, fused_overflows = 0;  // rounds whose candidate scan ran in the apply kernel's tail; of those, with a hot-list overflow
@@ -176,6 +180,20 @@ class GpuCtx {
   // K1
   unsigned long long *d_hist_ = nullptr;      // [N_CODEPOINTS]
   uint32_t *d_chunk_segs_ = nullptr;          // [fe_chunks(n_text_)] segment starts per 4 KB chunk (K1 counts them, K2a places them)
+  // What upload_corpus_fd has done of the front end while the file was still crossing the link (single GPU: K1, K2a and K2b on the parts that
+  // had arrived; see there): char_hist() / build_word_table() take it from here instead of launching the kernels.
+  struct FrontSpec {
+    bool hist_done = false;             // d_hist_, d_counters_[0..1], d_chunk_segs_ hold K1's results for the whole text
+    bool words_done = false;            // ht holds every segment's word, deduplicated under the code-point-as-id map (valid iff the alphabet keeps every char seen)
+    unsigned long long n_segs = 0;
+    unsigned long long *ht = nullptr;
+    unsigned long long ht_cap = 0;
+    unsigned int h_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool long_segments = false;
+  } spec_;
+  std::vector<uint32_t> seen_cps_;      // char_hist: the code points that occur
+  void drop_spec();
+  void upload_fd_overlapped(int fd, unsigned long long lo, unsigned long long n);
   unsigned long long *d_counters_ = nullptr;  // small scratch of u64 counters
   // K2
   uint32_t *d_cpmap_ = nullptr;  // [N_CODEPOINTS]

@@ -319,6 +319,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     rep->fused_overflows = g.fused_overflows;
     rep->exchange_retries = g.exchange_retries;
     rep->word_table_retries = g.word_table_retries;
+    rep->front_end_overlapped = g.front_end_overlapped ? 1 : 0;
     rep->top_refills = g.top_refills;
     rep->index_builds = g.index_builds;
     rep->word_rounds = g.word_rounds;

@@ -7,6 +7,7 @@
 //       build_linked_list (layout)    bpe.cpp:436-478   -> flat token tiles instead of linked lists
 // All of it is HBM-bound byte/integer work: coalesced 16 B/lane loads staged through LDS, LDS-private histograms,
 // one global atomic per wave/block for cursors.  No MFMA.
+#include <algorithm>
 #include "yttm_device.h"
 #include "yttm_kernels.h"
 
@@ -30,7 +31,9 @@ __global__ __launch_bounds__(BLOCK) void k_scan_bytes(const uint8_t *__restrict_
                                                       unsigned long long *__restrict__ counters /* [0]=steps [1]=segs */,
                                                       unsigned long long *__restrict__ seg_pos,
                                                       const unsigned long long *__restrict__ chunk_off /* MODE 1: segments before the chunk */,
-                                                      uint32_t *__restrict__ chunk_segs /* MODE 0: segments of the chunk (out) */) {
+                                                      uint32_t *__restrict__ chunk_segs /* MODE 0: segments of the chunk (out) */,
+                                                      unsigned long long chunk_lo, unsigned long long chunk_hi /* the chunks of this launch: the
+                                                      whole text, or the part of it that has arrived (gpu_ctx.cpp upload_corpus_fd) */) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[FE_CHUNK + 16];  // [0..3] halo before, [4..4+FE_CHUNK) main, then halo after
   __shared__ unsigned int lh[MODE == 0 ? LH_BINS : 1];
   // ASCII chars (nearly all of most texts, a handful of distinct values) are counted in LC_COPIES lane-indexed copies of the first 128 bins,
@@ -48,11 +51,11 @@ __global__ __launch_bounds__(BLOCK) void k_scan_bytes(const uint8_t *__restrict_
     for (int b = tid; b < HK; b += BLOCK) { hkey[b] = 0; hval[b] = 0; }
   }
   unsigned long long my_steps = 0, my_segs = 0;
-  const unsigned long long n_chunks = (n + FE_CHUNK - 1) / FE_CHUNK;
-  for (unsigned long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  const unsigned long long first_chunk = chunk_lo + blockIdx.x;
+  for (unsigned long long chunk = first_chunk; chunk < chunk_hi; chunk += gridDim.x) {
     const unsigned long long c0 = chunk * FE_CHUNK;
     __syncthreads();  // previous iteration done with `stage`
-    if (MODE == 0 && tid == 0 && chunk != blockIdx.x) {  // the previous chunk's segment count (its waves' parts are in: the barrier above)
+    if (MODE == 0 && tid == 0 && chunk != first_chunk) {  // the previous chunk's segment count (its waves' parts are in: the barrier above)
       uint32_t t = 0;
       for (int w = 0; w < NWAVES; w++) t += seg_part[w];
       chunk_segs[chunk - gridDim.x] = t;
@@ -217,10 +220,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan_bytes(const uint8_t *__restrict_
   }
   if (MODE == 0) {
     __syncthreads();
-    if (tid == 0 && n_chunks > blockIdx.x) {  // the last chunk this block scanned
+    if (tid == 0 && chunk_hi > first_chunk) {  // the last chunk this block scanned
       uint32_t t = 0;
       for (int w = 0; w < NWAVES; w++) t += seg_part[w];
-      const unsigned long long last = blockIdx.x + ((n_chunks - 1 - blockIdx.x) / gridDim.x) * (unsigned long long)gridDim.x;
+      const unsigned long long last = first_chunk + ((chunk_hi - 1 - first_chunk) / gridDim.x) * (unsigned long long)gridDim.x;
       chunk_segs[last] = t;
     }
     unsigned long long s = wave_sum_u64(my_steps);
@@ -812,23 +815,31 @@ static inline unsigned int grid_for(unsigned long long items, unsigned int per_b
 }
 
 void launch_char_hist(const uint8_t *text, unsigned long long n, unsigned long long *hist, unsigned long long *counters, bool wide_chars,
-                      uint32_t *chunk_segs, hipStream_t st) {
+                      uint32_t *chunk_segs, hipStream_t st, unsigned long long chunk_lo, unsigned long long chunk_hi) {
+  if (chunk_hi > fe_chunks(n)) chunk_hi = fe_chunks(n);
+  if (chunk_lo >= chunk_hi) return;
+  const unsigned long long bytes = (chunk_hi - chunk_lo) * FE_CHUNK;
+  // (a part of the text: at least 32 chunks per workgroup -- every workgroup ends with a flush of its LDS histograms, ~2 000 atomics)
+  const unsigned int cap = chunk_lo == 0 && chunk_hi == fe_chunks(n) ? 256u * 8 : (unsigned int)std::max<unsigned long long>(64, std::min<unsigned long long>(256 * 8, (chunk_hi - chunk_lo) / 32));
   if (wide_chars) {  // (76 KB of LDS per workgroup: two per CU)
-    unsigned int g = grid_for(n, FE_CHUNK, 256 * 2);
+    unsigned int g = grid_for(bytes, FE_CHUNK, std::min(cap, 256u * 2));
     hipLaunchKernelGGL((k_scan_bytes<0, 8192>), dim3(g), dim3(BLOCK), 0, st, text, n, hist, counters, (unsigned long long *)nullptr,
-                       (const unsigned long long *)nullptr, chunk_segs);
+                       (const unsigned long long *)nullptr, chunk_segs, chunk_lo, chunk_hi);
     return;
   }
-  unsigned int g = grid_for(n, FE_CHUNK, 256 * 8);
+  unsigned int g = grid_for(bytes, FE_CHUNK, cap);
   hipLaunchKernelGGL((k_scan_bytes<0, 0>), dim3(g), dim3(BLOCK), 0, st, text, n, hist, counters, (unsigned long long *)nullptr,
-                     (const unsigned long long *)nullptr, chunk_segs);
+                     (const unsigned long long *)nullptr, chunk_segs, chunk_lo, chunk_hi);
 }
 unsigned long long fe_chunks(unsigned long long n) { return (n + FE_CHUNK - 1) / FE_CHUNK; }
+unsigned long long fe_chunk_bytes() { return FE_CHUNK; }
 void launch_seg_write(const uint8_t *text, unsigned long long n, unsigned long long *seg_pos, const unsigned long long *chunk_off,
-                      hipStream_t st) {
-  unsigned int g = grid_for(n, FE_CHUNK, 256 * 8);
+                      hipStream_t st, unsigned long long chunk_lo, unsigned long long chunk_hi) {
+  if (chunk_hi > fe_chunks(n)) chunk_hi = fe_chunks(n);
+  if (chunk_lo >= chunk_hi) return;
+  unsigned int g = grid_for((chunk_hi - chunk_lo) * FE_CHUNK, FE_CHUNK, 256 * 8);
   hipLaunchKernelGGL((k_scan_bytes<1, 0>), dim3(g), dim3(BLOCK), 0, st, text, n, (unsigned long long *)nullptr,
-                     (unsigned long long *)nullptr, seg_pos, chunk_off, (uint32_t *)nullptr);
+                     (unsigned long long *)nullptr, seg_pos, chunk_off, (uint32_t *)nullptr, chunk_lo, chunk_hi);
 }
 void launch_hist_compact(const unsigned long long *hist, uint32_t *cps, unsigned long long *cnts, unsigned int *n_out,
                          unsigned int cap, hipStream_t st) {
@@ -839,8 +850,9 @@ void launch_word_table_clear(unsigned long long *ht, unsigned long long n_slots,
   hipLaunchKernelGGL(k_wh_clear, dim3(g), dim3(BLOCK), 0, st, ht, n_slots);
 }
 void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *seg_pos,
-                         unsigned long long n_segs, unsigned long long *ht, unsigned long long ht_mask, unsigned int *status, hipStream_t st) {
-  unsigned int g = grid_for(n_segs, BLOCK, 256 * 32);  // (256 * 8: dedup 11.6 ms at 1 GB instead of 9.9; 256 * 64: 9.6)
+                         unsigned long long n_segs, unsigned long long *ht, unsigned long long ht_mask, unsigned int *status, hipStream_t st,
+                         unsigned int max_blocks) {
+  unsigned int g = grid_for(n_segs, BLOCK, max_blocks);  // (256 * 8: dedup 11.6 ms at 1 GB instead of 9.9; 256 * 64: 9.6)
   hipLaunchKernelGGL(k2b_insert_words, dim3(g), dim3(BLOCK), 0, st, text, n, cpmap, seg_pos, n_segs, ht, ht_mask, status);
 }
 void launch_compact_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *ht, unsigned long long n_slots,

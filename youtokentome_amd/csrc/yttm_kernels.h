@@ -24,16 +24,21 @@ inline unsigned long long cand_bin_lower(int bin) {
 // ---- front end (k_frontend.hip)
 // wide_chars: many chars beyond U+07FF (three- and four-byte UTF-8): they are counted in an LDS hash instead of global atomics
 // chunk_segs [fe_chunks(n)]: segment starts per 4 KB chunk of the text (out); the segment pass takes their exclusive scan
+// [chunk_lo, chunk_hi): the 4 KB chunks of this launch -- all of them, or those of a part of the text that has arrived while the rest is still on
+// its way over the link (gpu_ctx.cpp upload_corpus_fd); counts and histogram add up over the launches
 void launch_char_hist(const uint8_t *text, unsigned long long n, unsigned long long *hist, unsigned long long *counters, bool wide_chars,
-                      uint32_t *chunk_segs, hipStream_t st);
+                      uint32_t *chunk_segs, hipStream_t st, unsigned long long chunk_lo = 0, unsigned long long chunk_hi = ~0ull);
 unsigned long long fe_chunks(unsigned long long n);
-void launch_seg_write(const uint8_t *text, unsigned long long n, unsigned long long *seg_pos, const unsigned long long *chunk_off, hipStream_t st);
+unsigned long long fe_chunk_bytes();
+void launch_seg_write(const uint8_t *text, unsigned long long n, unsigned long long *seg_pos, const unsigned long long *chunk_off, hipStream_t st,
+                      unsigned long long chunk_lo = 0, unsigned long long chunk_hi = ~0ull);
 void launch_hist_compact(const unsigned long long *hist, uint32_t *cps, unsigned long long *cnts, unsigned int *n_out, unsigned int cap,
                          hipStream_t st);
 // word table (K2b/K2c): ht[0 .. n_slots) keys, ht[n_slots .. 2 n_slots) counts, ht[2 n_slots .. 3 n_slots) positions of the short words, see k_frontend.hip
 void launch_word_table_clear(unsigned long long *ht, unsigned long long n_slots, hipStream_t st);
 void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *seg_pos,
-                         unsigned long long n_segs, unsigned long long *ht, unsigned long long ht_mask, unsigned int *status, hipStream_t st);
+                         unsigned long long n_segs, unsigned long long *ht, unsigned long long ht_mask, unsigned int *status, hipStream_t st,
+                         unsigned int max_blocks = 256 * 32 /* (a part of the segments: fewer workgroups, each ends with a flush of its LDS table) */);
 void launch_compact_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *ht, unsigned long long n_slots,
                           unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB, uint32_t *cntB, uint32_t *lenB,
                           unsigned long long *posC, uint32_t *cntC, uint32_t *lenC, unsigned int *cursor, unsigned int *status,
