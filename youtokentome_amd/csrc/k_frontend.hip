@@ -741,6 +741,9 @@ __global__ __launch_bounds__(BLOCK) void k2e_fill_tokens(const uint8_t *__restri
                                                          unsigned int nom, unsigned int slot,
                                                          const unsigned long long *__restrict__ tile_start, uint32_t *__restrict__ tok) {
   __shared__ uint32_t stage_all[NWAVES][FILL_CAP];
+  __shared__ uint32_t cp_ascii[128];  // cpmap[0..128): ASCII words are decoded 16 bytes per load (load16), not a byte and a map entry at a time
+  if (threadIdx.x < 128) cp_ascii[threadIdx.x] = cpmap[threadIdx.x];
+  __syncthreads();
   const int lane = lane_id();
   uint32_t *stage = stage_all[threadIdx.x >> 6];
   const unsigned int u = blockIdx.x * BLOCK + threadIdx.x;
@@ -763,7 +766,24 @@ __global__ __launch_bounds__(BLOCK) void k2e_fill_tokens(const uint8_t *__restri
     stage[r0] = space_id | TOK_WS;
     cnt = 1;
     unsigned long long i = i0;
-    while (i < n) {
+    bool done = false;
+    while (!done && !overflow && i + 24 <= n) {  // 16 bytes at a time while they are ASCII (cf. seg_scan_fast)
+      unsigned long long w0, w1;
+      load16(text, i, w0, w1);
+      int k = 0;
+      for (; k < 16; k++) {
+        const uint32_t b = (uint32_t)((k < 8 ? w0 >> (8 * k) : w1 >> (8 * (k - 8))) & 0xffull);
+        if (b >= 0x80u) break;
+        const uint32_t id = cp_ascii[b];
+        if (id == CP_SPACE) { done = true; break; }
+        if (id == CP_DROP) continue;
+        if (r0 + cnt >= (uint32_t)FILL_CAP) { overflow = true; break; }
+        stage[r0 + cnt++] = id;
+      }
+      i += (unsigned long long)k;
+      if (k < 16) break;  // a space (done), the window's end, or a byte that needs the exact decode
+    }
+    while (!done && !overflow && i < n) {
       uint32_t len;
       const uint32_t cp = u8_decode_at(text, i, n, &len);
       if (cp != INVALID_CP) {
