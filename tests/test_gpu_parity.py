@@ -55,6 +55,16 @@ def test_k5_word_cache_fuzz(tmp_path):
     S.check_encode_word_cache_fuzz(tmp_path, trials=12)
 
 
+def test_k5_host_to_host_in_sub_batches(monkeypatch):
+    """a very large host -> host batch goes through both lanes in sub-batches, up / encode / down at once (host_encoder.cpp encode_pipelined):
+    here every batch, in sub-batches of 1 KB, arrays through 4 KB chunks"""
+    monkeypatch.setenv("YTTM_ENC_PIPE_FROM", "1")
+    monkeypatch.setenv("YTTM_ENC_SUB_KB", "1")
+    monkeypatch.setenv("YTTM_IO_CHUNK_KB", "4")
+    S.check_encode_mixed_shapes(n_sent=2000, seed=67)
+    S.check_encode_word_cache(n_sent=500, seed=71)
+
+
 def test_k5_host_arrays_through_pinned_chunks(monkeypatch):
     """host -> host encode of a large batch moves its arrays through the trainer's pinned chunks, several threads at once (host_encoder.cpp
     copy_up / copy_down, gpu_ctx.cpp staged_transfer): here every array of small batches, in chunks of 4 KB"""

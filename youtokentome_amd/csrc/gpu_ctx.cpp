@@ -368,36 +368,39 @@ void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
 // next call (pinning 128 MB costs tens of milliseconds).
 namespace {
 constexpr size_t IO_CHUNK_MAX = 64u << 20;
-static size_t IO_CHUNK = 8u << 20;  // (YTTM_IO_CHUNK_MB: tuning hook, read once)
 constexpr int IO_MAX_THREADS = 32;
 struct IoStage {
   std::mutex mu;
   void *pin[2 * IO_MAX_THREADS] = {nullptr};
+  size_t pin_bytes[2 * IO_MAX_THREADS] = {0};
   // the workers' copy streams and events are kept as well (creating and destroying a stream and two events per worker and call was
   // a millisecond of every upload, serialised in the runtime); they belong to device `dev`
   hipStream_t cs[IO_MAX_THREADS] = {nullptr};
   hipEvent_t ev[2 * IO_MAX_THREADS] = {nullptr};
   int dev = -1;
   bool busy = false;
-} g_io;
+} g_io_dir[2];  // [0] towards the device, [1] towards the host: one transfer each way at a time goes through the chunks (the encoder's pipeline)
 }  // namespace
 
 static void release_io_stage() {
-  std::lock_guard<std::mutex> g(g_io.mu);
-  if (g_io.busy) return;
-  for (void *&p : g_io.pin) {
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
+  for (IoStage &g_io : g_io_dir) {
+    std::lock_guard<std::mutex> g(g_io.mu);
+    if (g_io.busy) continue;
+    for (int i = 0; i < 2 * IO_MAX_THREADS; i++) {
+      if (g_io.pin[i]) (void)hipHostFree(g_io.pin[i]);
+      g_io.pin[i] = nullptr;
+      g_io.pin_bytes[i] = 0;
+    }
+    for (hipEvent_t &e : g_io.ev) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+    for (hipStream_t &c : g_io.cs) {
+      if (c) (void)hipStreamDestroy(c);
+      c = nullptr;
+    }
+    g_io.dev = -1;
   }
-  for (hipEvent_t &e : g_io.ev) {
-    if (e) (void)hipEventDestroy(e);
-    e = nullptr;
-  }
-  for (hipStream_t &c : g_io.cs) {
-    if (c) (void)hipStreamDestroy(c);
-    c = nullptr;
-  }
-  g_io.dev = -1;
 }
 
 void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *dst, unsigned long long off, size_t len)> &fill) {
@@ -428,7 +431,8 @@ void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_d
                      const std::function<void(unsigned long long off, size_t len)> &arrived) {
   if (!n) return;
   HIP_CHECK(hipSetDevice(device));
-  IO_CHUNK = staged_chunk_bytes();
+  IoStage &g_io = g_io_dir[to_device ? 0 : 1];
+  const size_t IO_CHUNK = staged_chunk_bytes();
   const size_t n_chunks = (size_t)((n + IO_CHUNK - 1) / IO_CHUNK);
   int n_threads = (int)env_uint("YTTM_IO_THREADS", 0);
   // (default 4: one thread preads 40 GB/s out of the page cache on the MI355X box, the link takes 55; eight workers measured SLOWER than three
@@ -482,7 +486,13 @@ void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_d
       size_t held_len[2] = {0, 0};
       for (int k = 0; k < 2; k++) {
         if (!ev[k]) HIP_CHECK(hipEventCreate(&ev[k]));
-        if (!g_io.pin[2 * w + k]) HIP_CHECK(hipHostMalloc(&g_io.pin[2 * w + k], IO_CHUNK_MAX, hipHostMallocDefault));
+        if (g_io.pin_bytes[2 * w + k] < IO_CHUNK) {  // (pinning is slow: the chunks are kept, and only as large as they are used)
+          if (g_io.pin[2 * w + k]) (void)hipHostFree(g_io.pin[2 * w + k]);
+          g_io.pin[2 * w + k] = nullptr;
+          g_io.pin_bytes[2 * w + k] = 0;
+          HIP_CHECK(hipHostMalloc(&g_io.pin[2 * w + k], IO_CHUNK, hipHostMallocDefault));
+          g_io.pin_bytes[2 * w + k] = IO_CHUNK;
+        }
       }
       auto drain = [&](int k) {
         if (!used[k]) return;

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <thread>
 #include <sys/mman.h>
 #include <chrono>
@@ -578,11 +579,154 @@ static void *result_alloc(size_t bytes) {
   return p;
 }
 
+// A very large batch in sub-batches through both lanes: while sub-batch i is being encoded, i + 1 crosses the link upwards and the ids of
+// i - 1 downwards (three threads: up, this one, down).  One after the other the three legs of 10^7 sentences are 25 + 28 + 25 ms; the
+// link works both ways at once.  The ids' array is asked for at its upper bound -- a sentence of B bytes has at most B + 1 tokens
+// (enc_tokenize) -- in pages that are only ever touched up to the real size; returns false (nothing done) when that much address space is
+// not to be had or a lane is busy: the caller then takes the plain path.
+static bool encode_pipelined(const BaseEncoder &enc, EncoderDevice *dev, int device, const uint8_t *bytes, const unsigned long long *offsets,
+                             unsigned long long n_sent, bool bos, bool eos, bool reverse, double dropout_prob, int32_t **ids_out,
+                             unsigned long long **off_out, Status *result) {
+  const unsigned long long total_bytes = offsets[n_sent] - offsets[0];
+  unsigned long long sub_bytes = (unsigned long long)(getenv("YTTM_ENC_SUB_MB") ? std::max(1, atoi(getenv("YTTM_ENC_SUB_MB"))) : 96) << 20;
+  if (const char *e = getenv("YTTM_ENC_SUB_KB")) sub_bytes = (unsigned long long)std::max(1, atoi(e)) << 10;  // (tests)
+  const unsigned long long min_bytes = getenv("YTTM_ENC_PIPE_FROM") ? strtoull(getenv("YTTM_ENC_PIPE_FROM"), nullptr, 10) : (256ull << 20);
+  if (total_bytes < min_bytes || n_sent < 4) return false;
+  // sub-batches of about sub_bytes each, cut at sentence starts
+  std::vector<unsigned long long> cut{0};
+  while (cut.back() < n_sent) {
+    const unsigned long long want = offsets[cut.back()] + sub_bytes;
+    unsigned long long s = (unsigned long long)(std::upper_bound(offsets + cut.back() + 1, offsets + n_sent + 1, want) - offsets) - 1;
+    if (s <= cut.back()) s = cut.back() + 1;
+    cut.push_back(std::min(s, n_sent));
+  }
+  const size_t K = cut.size() - 1;
+  if (K < 2) return false;
+  std::unique_lock<std::mutex> lk0(dev->lane[0].mu, std::try_to_lock), lk1(dev->lane[1].mu, std::try_to_lock);
+  if (!lk0.owns_lock() || !lk1.owns_lock()) return false;
+  const unsigned long long ids_cap = total_bytes + n_sent * (1ull + (bos ? 1 : 0) + (eos ? 1 : 0)) + 1;
+  int32_t *ids = (int32_t *)result_alloc(ids_cap * sizeof(int32_t));
+  unsigned long long *off = (unsigned long long *)result_alloc((n_sent + 1) * sizeof(unsigned long long));
+  if (!ids || !off) {
+    free(ids);
+    free(off);
+    return false;
+  }
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<int> up_done(K, 0), enc_done(K, 0), down_done(K, 0);
+  std::vector<unsigned long long> n_ids(K, 0), max_len(K, 0);
+  bool failed = false;
+  std::string error;
+  auto fail = [&](const std::string &msg) {
+    std::lock_guard<std::mutex> g(mu);
+    if (!failed) error = msg;
+    failed = true;
+    cv.notify_all();
+  };
+  auto wait_flag = [&](std::vector<int> &flags, size_t i) {  // false: somebody failed
+    std::unique_lock<std::mutex> g(mu);
+    cv.wait(g, [&] { return failed || flags[i]; });
+    return !failed;
+  };
+  auto set_flag = [&](std::vector<int> &flags, size_t i) {
+    std::lock_guard<std::mutex> g(mu);
+    flags[i] = 1;
+    cv.notify_all();
+  };
+  std::thread up([&] {
+    try {
+      HIP_CHECK(hipSetDevice(device));
+      for (size_t i = 0; i < K; i++) {
+        if (i >= 2 && !wait_flag(down_done, i - 2)) return;  // the lane's buffers are free again
+        EncodeLane &d = dev->lane[i & 1];
+        const unsigned long long s0 = cut[i], ns = cut[i + 1] - s0, b0 = offsets[s0], nb = offsets[s0 + ns] - b0;
+        unsigned long long mx = 0;
+        for (unsigned long long j = 0; j < ns; j++) mx = std::max(mx, offsets[s0 + j + 1] - offsets[s0 + j]);
+        max_len[i] = mx;
+        d.grow(d.d_bytes, d.cap_bytes, (size_t)nb + 16);
+        d.grow(d.d_off, d.cap_off, (size_t)ns + 1);
+        if (nb)
+          staged_transfer(device, d.d_bytes, nb, true, [&](void *chunk, unsigned long long o, size_t len) {
+            memcpy(chunk, bytes + b0 + o, len);
+            return true;
+          });
+        staged_transfer(device, (uint8_t *)d.d_off, (ns + 1) * 8, true, [&](void *chunk, unsigned long long o, size_t len) {
+          unsigned long long *dst = (unsigned long long *)chunk;  // (offsets relative to the sub-batch's first byte)
+          const unsigned long long *src = offsets + s0 + o / 8;
+          for (size_t j = 0; j < len / 8; j++) dst[j] = src[j] - b0;
+          return true;
+        });
+        set_flag(up_done, i);
+      }
+    } catch (const GpuError &e) {
+      fail("GPU error: " + e.msg);
+    }
+  });
+  std::thread down([&] {
+    try {
+      HIP_CHECK(hipSetDevice(device));
+      unsigned long long ids_base = 0;
+      for (size_t i = 0; i < K; i++) {
+        if (!wait_flag(enc_done, i)) return;
+        EncodeLane &d = dev->lane[i & 1];
+        const unsigned long long s0 = cut[i], ns = cut[i + 1] - s0;
+        if (n_ids[i])
+          staged_transfer(device, (uint8_t *)d.d_ids, n_ids[i] * 4, false, [&](void *chunk, unsigned long long o, size_t len) {
+            memcpy((uint8_t *)(ids + ids_base) + o, chunk, len);
+            return true;
+          });
+        staged_transfer(device, (uint8_t *)d.d_out_off, (ns + 1) * 8, false, [&](void *chunk, unsigned long long o, size_t len) {
+          const unsigned long long *src = (const unsigned long long *)chunk;  // (the sub-batch's offsets start at 0: moved behind the ids so far;
+          unsigned long long *dst = off + s0 + o / 8;                         //  its last entry is the next one's first, written twice, the same)
+          for (size_t j = 0; j < len / 8; j++) dst[j] = src[j] + ids_base;
+          return true;
+        });
+        ids_base += n_ids[i];
+        set_flag(down_done, i);
+      }
+    } catch (const GpuError &e) {
+      fail("GPU error: " + e.msg);
+    }
+  });
+  Status st;
+  for (size_t i = 0; i < K; i++) {
+    if (!wait_flag(up_done, i)) break;
+    EncodeLane &d = dev->lane[i & 1];
+    const unsigned long long s0 = cut[i], ns = cut[i + 1] - s0, nb = offsets[s0 + ns] - offsets[s0];
+    unsigned long long got = 0;
+    st = encode_on_lane(enc, *dev, d, device, d.d_bytes, d.d_off, ns, nb, max_len[i], bos, eos, reverse, dropout_prob, &got, nullptr);
+    if (!st.ok()) {
+      fail(st.message);
+      break;
+    }
+    n_ids[i] = got;
+    set_flag(enc_done, i);
+  }
+  up.join();
+  down.join();
+  if (failed) {
+    free(ids);
+    free(off);
+    *result = st.ok() ? Status(2, error) : st;
+    return true;
+  }
+  if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] encode host -> host: %llu sentences in %zu sub-batches through both lanes\n", n_sent, K);
+  *ids_out = ids;
+  *off_out = off;
+  *result = Status();
+  return true;
+}
+
 // the same into malloc'ed arrays (released by the caller with free()): what the C ABI hands out, without a copy in between
 Status BaseEncoder::encode_as_ids_malloc(const uint8_t *bytes, const unsigned long long *offsets, unsigned long long n_sent, bool bos, bool eos,
                                          bool reverse, double dropout_prob, int32_t **ids, unsigned long long **out_off) const {
   *ids = nullptr;
   *out_off = nullptr;
+  if (dev_ && n_sent && !(bos && bpe_state.special_tokens.bos_id == -1) && !(eos && bpe_state.special_tokens.eos_id == -1)) {
+    Status piped;
+    if (encode_pipelined(*this, dev_, device_, bytes, offsets, n_sent, bos, eos, reverse, dropout_prob, ids, out_off, &piped)) return piped;
+  }
   Status s = encode_host_to_host(
       *this, dev_, device_, bytes, offsets, n_sent, bos, eos, reverse, dropout_prob,
       [&](size_t n) { *ids = (int32_t *)result_alloc((n ? n : 1) * sizeof(int32_t)); return *ids; },
