@@ -447,7 +447,9 @@ def test_zz_fused_tail_ordering(tmp_path, use_comm):
     # and the traces would differ in their candidate counts for that reason alone)
     # YTTM_WORD_MIN_TOKENS=0: word mode (and its one-launch rounds) also at a tenth of the headline size, where a pass over the tiles is
     # still cheap enough for the library to stay on them by itself
-    hooks = {"YTTM_NO_REFINE": "1", "YTTM_WORD_MIN_TOKENS": "0"}
+    # YTTM_NO_BATCH_SPLIT=1: a batch of up to twice what the kernel arguments hold is cut in two only where rounds are ONE launch
+    # (host_trainer.cpp) -- with the scan as a kernel of its own they never are, and the two sides would not have the same rounds
+    hooks = {"YTTM_NO_REFINE": "1", "YTTM_WORD_MIN_TOKENS": "0", "YTTM_NO_BATCH_SPLIT": "1"}
     ref, rep0 = run("nofuse", dict(hooks, YTTM_NO_FUSE="1"))
     assert rep0["fused_rounds"] == 0
     for i in range(3):

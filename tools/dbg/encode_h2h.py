@@ -19,10 +19,8 @@ text = gen.abcd_corpus(n_sent * 129, seed=123, line=128, survey_stream=False)
 h_off = (np.arange(n_sent + 1, dtype=np.uint64) * 129)
 h = C.c_void_p()
 assert L.yttm_encoder_create(model.encode(), 1, 0, C.byref(h), err, 2048) == 0
-for name, env in (("plain copies", {"YTTM_ENC_STAGED_FROM": str(1 << 60)}), ("chunks, 2 threads", {"YTTM_IO_THREADS": "2"}), ("chunks, 4 threads", {"YTTM_IO_THREADS": "4"}),
-                  ("chunks, 8 threads", {"YTTM_IO_THREADS": "8"}), ("chunks of 32 MB, 4 threads", {"YTTM_IO_THREADS": "4", "YTTM_IO_CHUNK_MB": "32"}),
-                  ("chunks of 2 MB, 4 threads", {"YTTM_IO_THREADS": "4", "YTTM_IO_CHUNK_MB": "2"})):
-    for k in ("YTTM_ENC_STAGED_FROM", "YTTM_IO_THREADS", "YTTM_IO_CHUNK_MB"):
+for name, env in (("one batch, chunks", {"YTTM_ENC_PIPE_FROM": str(1 << 60)}), ("sub-batches of 192 MB", {"YTTM_ENC_SUB_MB": "192"}), ("sub-batches of 320 MB", {"YTTM_ENC_SUB_MB": "320"}), ("sub-batches of 440 MB", {"YTTM_ENC_SUB_MB": "440"}), ("sub-batches of 650 MB", {"YTTM_ENC_SUB_MB": "650"}), ("sub-batches of 320 MB, 2 MB chunks", {"YTTM_ENC_SUB_MB": "320", "YTTM_IO_CHUNK_MB": "2"}), ("sub-batches of 320 MB, 2 threads", {"YTTM_ENC_SUB_MB": "320", "YTTM_IO_THREADS": "2"})):
+    for k in ("YTTM_ENC_STAGED_FROM", "YTTM_IO_THREADS", "YTTM_IO_CHUNK_MB", "YTTM_ENC_PIPE_FROM", "YTTM_ENC_SUB_MB"):
         os.environ.pop(k, None)
     os.environ.update(env)
     os.environ["YTTM_TRACE"] = "1"

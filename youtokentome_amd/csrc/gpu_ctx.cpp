@@ -428,11 +428,11 @@ size_t staged_chunk_bytes() {
 }
 void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_device,
                      const std::function<bool(void *chunk, unsigned long long off, size_t len)> &host_side,
-                     const std::function<void(unsigned long long off, size_t len)> &arrived) {
+                     const std::function<void(unsigned long long off, size_t len)> &arrived, size_t chunk_bytes) {
   if (!n) return;
   HIP_CHECK(hipSetDevice(device));
   IoStage &g_io = g_io_dir[to_device ? 0 : 1];
-  const size_t IO_CHUNK = staged_chunk_bytes();
+  const size_t IO_CHUNK = chunk_bytes && !getenv("YTTM_IO_CHUNK_MB") && !getenv("YTTM_IO_CHUNK_KB") ? std::min(chunk_bytes, IO_CHUNK_MAX) : staged_chunk_bytes();
   const size_t n_chunks = (size_t)((n + IO_CHUNK - 1) / IO_CHUNK);
   int n_threads = (int)env_uint("YTTM_IO_THREADS", 0);
   // (default 4: one thread preads 40 GB/s out of the page cache on the MI355X box, the link takes 55; eight workers measured SLOWER than three

@@ -21,8 +21,8 @@ struct GpuError {
 // arrived(off, len) (to_device only, may be empty): bytes [off, off + len) are in HBM -- called from the workers' threads, chunks in no order.
 void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_device,
                      const std::function<bool(void *chunk, unsigned long long off, size_t len)> &host_side,
-                     const std::function<void(unsigned long long off, size_t len)> &arrived = nullptr);
-size_t staged_chunk_bytes();  // the chunk size the next staged_transfer will use
+                     const std::function<void(unsigned long long off, size_t len)> &arrived = nullptr, size_t chunk_bytes = 0 /* 0: staged_chunk_bytes() */);
+size_t staged_chunk_bytes();  // the default chunk size (8 MB; YTTM_IO_CHUNK_MB / _KB)
 
 // Exchange interface for the multi-GPU path (one process per GPU).  Implementations: RCCL over xGMI
 // (comm_rccl.cpp) and a host-callback variant used by the gloo CPU tests.

@@ -423,6 +423,7 @@ static Status encode_on_lane(const BaseEncoder &enc, EncoderDevice &D, EncodeLan
 // Host arrays of a large batch cross the link through the trainer's pinned chunks (gpu_ctx.cpp staged_transfer; 1e7 sentences are 1.3 GB up
 // and 1.2 GB down: a plain copy from / to pageable memory moves them at a fraction of the link's rate, and the first touch of a freshly
 // allocated result array is paid by one thread); small ones as plain copies on the lane's stream.
+constexpr size_t ENC_CHUNK = 2u << 20;  // (the encoder's arrays in chunks of 2 MB: 10^7 sentences host -> host 79 -> 75 ms against 8 MB, 64 against 70 in sub-batches)
 static size_t staged_from() {
   const char *e = getenv("YTTM_ENC_STAGED_FROM");  // (tests: every copy through the chunks)
   return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(16u << 20);
@@ -432,7 +433,7 @@ static void copy_up(int device, void *d_dst, const void *src, size_t n, hipStrea
     staged_transfer(device, (uint8_t *)d_dst, n, true, [&](void *chunk, unsigned long long off, size_t len) {
       memcpy(chunk, (const uint8_t *)src + off, len);
       return true;
-    });
+    }, nullptr, ENC_CHUNK);
   } else if (n) {
     HIP_CHECK(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, st));
   }
@@ -442,7 +443,7 @@ static void copy_down(int device, void *dst, const void *d_src, size_t n, hipStr
     staged_transfer(device, (uint8_t *)const_cast<void *>(d_src), n, false, [&](void *chunk, unsigned long long off, size_t len) {
       memcpy((uint8_t *)dst + off, chunk, len);
       return true;
-    });
+    }, nullptr, ENC_CHUNK);
   } else if (n) {
     HIP_CHECK(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, st));
   }
@@ -581,16 +582,17 @@ static void *result_alloc(size_t bytes) {
 
 // A very large batch in sub-batches through both lanes: while sub-batch i is being encoded, i + 1 crosses the link upwards and the ids of
 // i - 1 downwards (three threads: up, this one, down).  One after the other the three legs of 10^7 sentences are 25 + 28 + 25 ms; the
-// link works both ways at once.  The ids' array is asked for at its upper bound -- a sentence of B bytes has at most B + 1 tokens
+// link works both ways at once (measured: 79 -> 64 ms in sub-batches of 320 MB; smaller ones lose it again to the word cache's fixed costs
+// and to words that recur across sub-batches).  The ids' array is asked for at its upper bound -- a sentence of B bytes has at most B + 1 tokens
 // (enc_tokenize) -- in pages that are only ever touched up to the real size; returns false (nothing done) when that much address space is
 // not to be had or a lane is busy: the caller then takes the plain path.
 static bool encode_pipelined(const BaseEncoder &enc, EncoderDevice *dev, int device, const uint8_t *bytes, const unsigned long long *offsets,
                              unsigned long long n_sent, bool bos, bool eos, bool reverse, double dropout_prob, int32_t **ids_out,
                              unsigned long long **off_out, Status *result) {
   const unsigned long long total_bytes = offsets[n_sent] - offsets[0];
-  unsigned long long sub_bytes = (unsigned long long)(getenv("YTTM_ENC_SUB_MB") ? std::max(1, atoi(getenv("YTTM_ENC_SUB_MB"))) : 96) << 20;
+  unsigned long long sub_bytes = (unsigned long long)(getenv("YTTM_ENC_SUB_MB") ? std::max(1, atoi(getenv("YTTM_ENC_SUB_MB"))) : 320) << 20;
   if (const char *e = getenv("YTTM_ENC_SUB_KB")) sub_bytes = (unsigned long long)std::max(1, atoi(e)) << 10;  // (tests)
-  const unsigned long long min_bytes = getenv("YTTM_ENC_PIPE_FROM") ? strtoull(getenv("YTTM_ENC_PIPE_FROM"), nullptr, 10) : (256ull << 20);
+  const unsigned long long min_bytes = getenv("YTTM_ENC_PIPE_FROM") ? strtoull(getenv("YTTM_ENC_PIPE_FROM"), nullptr, 10) : (512ull << 20);
   if (total_bytes < min_bytes || n_sent < 4) return false;
   // sub-batches of about sub_bytes each, cut at sentence starts
   std::vector<unsigned long long> cut{0};
@@ -650,13 +652,13 @@ static bool encode_pipelined(const BaseEncoder &enc, EncoderDevice *dev, int dev
           staged_transfer(device, d.d_bytes, nb, true, [&](void *chunk, unsigned long long o, size_t len) {
             memcpy(chunk, bytes + b0 + o, len);
             return true;
-          });
+          }, nullptr, ENC_CHUNK);
         staged_transfer(device, (uint8_t *)d.d_off, (ns + 1) * 8, true, [&](void *chunk, unsigned long long o, size_t len) {
           unsigned long long *dst = (unsigned long long *)chunk;  // (offsets relative to the sub-batch's first byte)
           const unsigned long long *src = offsets + s0 + o / 8;
           for (size_t j = 0; j < len / 8; j++) dst[j] = src[j] - b0;
           return true;
-        });
+        }, nullptr, ENC_CHUNK);
         set_flag(up_done, i);
       }
     } catch (const GpuError &e) {
@@ -675,13 +677,13 @@ static bool encode_pipelined(const BaseEncoder &enc, EncoderDevice *dev, int dev
           staged_transfer(device, (uint8_t *)d.d_ids, n_ids[i] * 4, false, [&](void *chunk, unsigned long long o, size_t len) {
             memcpy((uint8_t *)(ids + ids_base) + o, chunk, len);
             return true;
-          });
+          }, nullptr, ENC_CHUNK);
         staged_transfer(device, (uint8_t *)d.d_out_off, (ns + 1) * 8, false, [&](void *chunk, unsigned long long o, size_t len) {
           const unsigned long long *src = (const unsigned long long *)chunk;  // (the sub-batch's offsets start at 0: moved behind the ids so far;
           unsigned long long *dst = off + s0 + o / 8;                         //  its last entry is the next one's first, written twice, the same)
           for (size_t j = 0; j < len / 8; j++) dst[j] = src[j] + ids_base;
           return true;
-        });
+        }, nullptr, ENC_CHUNK);
         ids_base += n_ids[i];
         set_flag(down_done, i);
       }
