@@ -758,7 +758,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
     for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += ENC_THREADS) bloom[i] = m.bloom[i];
     __syncthreads();
   }
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = uni((int)(threadIdx.x >> 6));
   const unsigned long long gw = (unsigned long long)blockIdx.x * ENC_WAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * ENC_WAVES;
   // tokens a pack may hold: the LDS arrays; with dropout what the LDS event queues take (0: every sentence through the HBM scratch --
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(ENCW_WAVES * 64) void k5_words(EncModel m, const ui
   __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
   for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += ENCW_WAVES * 64) bloom[i] = m.bloom[i];
   __syncthreads();
-  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int wave = uni((int)(threadIdx.x >> 6)), lane = lane_id();  // (uni: the wave's number is the same in its lanes -- what follows from it stays in scalar registers)
   const unsigned long long lt = lanemask_lt();
   const unsigned long long gw = (unsigned long long)blockIdx.x * ENCW_WAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * ENCW_WAVES;
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(ENCW_WAVES * 64) void k5_words(EncModel m, const ui
 __global__ __launch_bounds__(BLOCK) void k5_gather(const int32_t *__restrict__ scratch_ids, SentView sv,
                                                    const unsigned long long *__restrict__ out_off, unsigned long long n_sent,
                                                    int32_t *__restrict__ ids_out) {
-  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
+  const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + (unsigned long long)uni((int)(threadIdx.x >> 6));
   const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
   for (unsigned long long sidx = gw; sidx < n_sent; sidx += n_waves) {
     const int32_t *src = scratch_ids + sv.spos(sidx);

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(BLOCK) void k5w_insert(EncModel m, const uint8_t *_
   __shared__ unsigned long long q_pos[NWAVES][WC_QUEUE], q_occ[NWAVES][WC_QUEUE];
   __shared__ uint32_t q_len[NWAVES][WC_QUEUE];
   __shared__ unsigned long long bnd_all[NWAVES][WC_SBLK + 1];
-  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int wave = uni((int)(threadIdx.x >> 6)), lane = lane_id();  // (uni: the wave's number is the same in its lanes -- what follows from it stays in scalar registers)
   const unsigned long long lt = lanemask_lt();
   const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
@@ -133,22 +133,28 @@ __global__ __launch_bounds__(BLOCK) void k5w_insert(EncModel m, const uint8_t *_
     if (lane < ns) bnd[lane] = offsets[s0 + lane];  // sentence k of the block = bytes [bnd[k], bnd[k + 1])
     if (lane == 0) bnd[ns] = offsets[s0 + ns];
     wave_sync();
-    const unsigned long long P0 = bnd[0], P1 = bnd[ns];
+    // (what is the same in every lane -- the block's ends, the boundary the walk has come to, the open word -- is told to the compiler with
+    // uni(): read from LDS it would be kept in vector registers, and every loop on it run under exec masks)
+    const unsigned long long P0 = uni64(bnd[0]), P1 = uni64(bnd[ns]);
     // the open word, if any: class of the last valid char of the current sentence so far (its start acts like a space), where the word began
     bool carry_space = true;
     unsigned long long carry_start = 0;
-    int carry_k = 0, kn = 1;
+    int carry_k = 0, kn = 0;          // kn: the first boundary the walk has not passed yet,
+    unsigned long long next_b = P0;   // and where it is
     uint32_t byte = P0 + (unsigned long long)lane < P1 ? text[P0 + lane] : 0u;
     for (unsigned long long p0 = P0; p0 <= P1; p0 += 64) {  // (the position behind the last byte has a lane too: the last sentence's end)
       const unsigned long long p = p0 + (unsigned long long)lane;
       const uint32_t n_byte = p + 64 < P1 ? text[p + 64] : 0u;  // (the next step's bytes: with ASCII text the step's only load)
-      // the lane's sentence: the last one that begins at or before p (empty sentences pile up on one byte: the last of them)
+      // the lane's sentence: the last one that begins at or before p (empty sentences pile up on one byte: the last of them); a sentence
+      // begins at p if a boundary lies there
       int k = kn - 1;
-      while (kn <= ns && bnd[kn] < p0 + 64) {
-        k += p >= bnd[kn] ? 1 : 0;
+      bool first = false;
+      while (kn <= ns && next_b < p0 + 64) {
+        k += p >= next_b ? 1 : 0;
+        first = first || p == next_b;
         kn++;
+        next_b = kn <= ns ? uni64(bnd[kn]) : 0ull;
       }
-      const bool first = p <= P1 && p == bnd[k];  // a sentence begins here
       bool valid = false, space = false;
       if (__ballot(byte >= 0x80u) == 0ull) {  // 64 ASCII bytes (the usual step): every byte is a char, the spaces are utils.cpp:99-101's
         valid = p < P1;
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void k5w_insert(EncModel m, const uint8_t *_
         carry_space = true;
       }
       const int wh = WSM ? 63 - __clzll((long long)WSM) : 0;
-      const int k_high = __shfl(k, wh);
+      const int k_high = uni(__shfl(k, wh));
       if (WSM) {
         carry_start = p0 + (unsigned long long)wh;
         carry_k = k_high;
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(BLOCK) void k5w_count(const unsigned long long *__r
                                                    int n_fixed /* bos + eos */, uint32_t *__restrict__ counts, int sblk) {
   __shared__ unsigned long long bnd_all[NWAVES][WC_SBLK + 1];
   __shared__ uint32_t acc_all[NWAVES][WC_SBLK];
-  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int wave = uni((int)(threadIdx.x >> 6)), lane = lane_id();  // (uni: the wave's number is the same in its lanes -- what follows from it stays in scalar registers)
   unsigned long long *bnd = bnd_all[wave];
   uint32_t *acc = acc_all[wave];
   const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + wave;
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void k5w_scatter(EncModel m, const unsigned 
                                                      const int32_t *__restrict__ uids /* K5's scratch */, int bos, int eos, int reverse,
                                                      const unsigned long long *__restrict__ out_off, int32_t *__restrict__ ids_out, int sblk) {
   __shared__ unsigned long long bnd_all[NWAVES][WC_SBLK + 1], oo_all[NWAVES][WC_SBLK + 1];
-  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int wave = uni((int)(threadIdx.x >> 6)), lane = lane_id();  // (uni: the wave's number is the same in its lanes -- what follows from it stays in scalar registers)
   unsigned long long *bnd = bnd_all[wave], *oo = oo_all[wave];
   const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
