@@ -347,7 +347,7 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
   launch_wcache_list(wc, d.d_wc_blk_off, n_table, d.d_ustart, d.d_uend, d.d_uslot, d.st);
   if (n_words) {  // (the distinct words' ids stay where K5 puts them, in the lane's scratch: the sentences are assembled from there)
     // (k5_words leaves in every word's table slot where its ids are and how many)
-    const WordPublish pub{wc.slot, d.d_uslot, n_table, wc.extra};
+    const WordPublish pub{wc.slot, d.d_uslot, n_table, wc.extra, total_bytes};
     k5_pass(D, d, d_bytes, d.d_ustart, d.d_uend, n_words, total_bytes, max_sentence_bytes, false, false, false, 0.0, d.d_ucounts, &pub);
   }
   launch_wcache_count(d_offsets, n_sent, wc, (bos ? 1 : 0) + (eos ? 1 : 0), d.d_counts, d.st);

@@ -798,7 +798,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
 // Item j = bytes [ustart[j], uend[j]) of the text: one word, its ids to scratch + 2 ustart[j], where and how many to its table slot (pub); no bos / eos,
 // no dropout.  A wavefront packs up to 64 consecutive ones -- one per lane -- into its share of the
 // LDS: tokens and pair priorities only (lane_rounds), so a pack holds ENCW_LANE_TOKENS tokens, and one workgroup of 16 waves per CU
-// shares a single copy of the rules' Bloom filter: 16 x 7.5 KB + 32 KB = 152 KB.  An item of more than lane_max tokens is walked by the
+// shares a single copy of the rules' Bloom filter: 16 x 7.5 KB + 32 KB = 152 KB (+ 512 B: the ASCII half of the char map).  An item of more than lane_max tokens is walked by the
 // whole wave instead (encode_wave: thirds of the share, or the HBM scratch when even that is too small).
 __device__ inline void word_publish(const WordPublish &pub, unsigned long long u, unsigned long long ids_at, uint32_t n) {
   if (u < pub.n_table) {
@@ -818,10 +818,11 @@ __global__ __launch_bounds__(ENCW_WAVES * 64) void k5_words(EncModel m, const ui
                                                             unsigned long long work_stride, unsigned int group, int lane_max, WordPublish pub) {
   __shared__ uint32_t pool[ENCW_WAVES][ENCW_POOL];
   __shared__ uint32_t bloom[ENC_BLOOM_WORDS];
+  __shared__ uint32_t cp_ascii[128];  // cpmap[0..128)
   for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += ENCW_WAVES * 64) bloom[i] = m.bloom[i];
+  if (threadIdx.x < 128) cp_ascii[threadIdx.x] = m.cpmap[threadIdx.x];
   __syncthreads();
   const int wave = uni((int)(threadIdx.x >> 6)), lane = lane_id();  // (uni: the wave's number is the same in its lanes -- what follows from it stays in scalar registers)
-  const unsigned long long lt = lanemask_lt();
   const unsigned long long gw = (unsigned long long)blockIdx.x * ENCW_WAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * ENCW_WAVES;
   uint32_t *mine = pool[wave];
@@ -858,93 +859,62 @@ __global__ __launch_bounds__(ENCW_WAVES * 64) void k5_words(EncModel m, const ui
         sidx++;
         continue;
       }
-      // the items before the first long one, as many as fit: their bytes laid end to end and tokenized 64 at a time whichever item a byte
-      // belongs to (wr is free until the rounds start: item j's first byte in the concatenation, its address, its number of tokens)
+      // the items before the first long one, as many as fit (by their upper bounds, bytes + 1): a lane tokenizes ITS word into its own
+      // stretch of the token array -- eight bytes per load while they are ASCII, ids from an LDS copy of the map's ASCII half; byte by byte
+      // with the exact decode otherwise -- and closes what it does not use with ENC_DEAD (a word start to every test below: no pair with
+      // it).  (Laying the pack's bytes end to end and tokenizing them 64 per step, a binary search of the item per byte, was 4 of the
+      // kernel's 9.8 ms.)
       const uint32_t pre = wave_incl_scan(need);
       const unsigned long long before_long = LONG ? (LONG & (0ull - LONG)) - 1ull : ~0ull;
       const unsigned long long FIT = __ballot((unsigned long long)lane < avail && pre <= (uint32_t)ENCW_LANE_TOKENS) & before_long;
       const int cnt = (int)__popcll(FIT);  // (a prefix of the lanes; >= 1: the first item is not long)
-      const uint32_t base = pre - need - (uint32_t)lane;  // bytes before item `lane`
+      const int n = (int)__shfl((int)pre, cnt - 1);  // places in all
+      const int ws = (int)(pre - need);
+      int we = ws;
       if (lane < cnt) {
-        wr.set(lane, base);
-        wr.set(128 + 2 * lane, (uint32_t)lo);
-        wr.set(129 + 2 * lane, (uint32_t)(lo >> 32));
-        wr.set(256 + lane, 0u);
-      }
-      const uint32_t T = (uint32_t)__shfl((int)(base + len), cnt - 1);  // bytes in all
-      if (lane == 0) wr.set(cnt, T);
-      wave_sync();
-      int n = 0;
-      bool carry_space = true, carry_unk = false;
-      int carry_item = -1;
-      for (uint32_t t0 = 0; t0 < T; t0 += 64) {
-        const uint32_t t = t0 + (uint32_t)lane;
-        int it = 0;
-        bool valid = false, space = false, unk = false;
-        uint32_t id = 0;
-        if (t < T) {
-          int a = 0, b = cnt;  // item of byte t: the last one that starts at or before it
-          while (b - a > 1) {
-            const int mid = (a + b) >> 1;
-            if (wr.get(mid) <= t) a = mid; else b = mid;
+        const uint8_t *sp = text + lo;
+        bool prev_space = true, prev_unk = false;
+        auto put = [&](uint32_t id) {  // one valid char (bpe.cpp:1497-1530): "▁" in front of a word's first, a run of unknown chars is one token
+          const bool space = id == CP_SPACE, unk = id == CP_UNK;
+          if (!space && !(unk && prev_unk && !prev_space)) {
+            if (prev_space) wt.set(we++, m.space_id | TOK_WS);
+            wt.set(we++, unk ? ENC_UNKP : id);
           }
-          it = a;
-          const uint32_t i = t - wr.get(it), nb = wr.get(it + 1) - wr.get(it);
-          const uint8_t *sp = text + (((unsigned long long)wr.get(129 + 2 * it) << 32) | wr.get(128 + 2 * it));
-          if (u8_is_start(sp, i, nb)) {
-            uint32_t clen;
-            const uint32_t cp = u8_decode_at(sp, i, nb, &clen);
-            if (cp != INVALID_CP) {
-              valid = true;
-              id = m.cpmap[cp];
-              space = id == CP_SPACE;
-              unk = id == CP_UNK;
-            }
+          prev_space = space;
+          prev_unk = unk;
+        };
+        uint32_t i = 0;
+        while (i < len) {
+          // eight bytes from sp + i (an aligned pair of loads when both lie inside the text, else byte by byte)
+          unsigned long long w = 0;
+          const unsigned long long at = lo + i;
+          uint32_t got = len - i < 8u ? len - i : 8u;
+          if ((at & ~7ull) + 16 <= pub.text_bytes) {
+            const unsigned long long *q = reinterpret_cast<const unsigned long long *>(text + (at & ~7ull));
+            const unsigned long long lo8 = q[0], hi8 = q[1];
+            const unsigned int sh = (unsigned int)(at & 7ull) * 8u;
+            w = sh ? (lo8 >> sh) | (hi8 << (64u - sh)) : lo8;
+          } else {
+            for (uint32_t k = 0; k < got; k++) w |= (unsigned long long)sp[i + k] << (8 * k);
           }
+          if (got < 8u) w &= (1ull << (8 * got)) - 1ull;
+          if ((w & 0x8080808080808080ull) == 0ull) {
+            for (uint32_t k = 0; k < got; k++) put(cp_ascii[(uint32_t)(w >> (8 * k)) & 0x7fu]);
+            i += got;
+            continue;
+          }
+          // a byte beyond ASCII: the ASCII bytes in front of it, then one char the exact way
+          uint32_t k = 0;
+          for (; k < got && !((w >> (8 * k)) & 0x80ull); k++) put(cp_ascii[(uint32_t)(w >> (8 * k)) & 0x7fu]);
+          i += k;
+          uint32_t clen;
+          const uint32_t cp = u8_decode_at(sp, i, len, &clen);
+          if (cp != INVALID_CP) put(m.cpmap[cp]);
+          i += clen;
         }
-        const unsigned long long V = __ballot(valid), S = __ballot(space), U = __ballot(unk);
-        bool prev_space = carry_space, prev_unk = carry_unk;
-        int prev_item = carry_item;
-        const unsigned long long pv = V & lt;
-        const int jj = pv ? 63 - __clzll((long long)pv) : 0;
-        const int item_jj = __shfl(it, jj);
-        if (pv) {
-          prev_space = (S >> jj) & 1ull;
-          prev_unk = (U >> jj) & 1ull;
-          prev_item = item_jj;
-        }
-        if (prev_item != it) {  // no valid char of this item before this one
-          prev_space = true;
-          prev_unk = false;
-        }
-        int emit = 0;
-        if (valid && !space) {
-          if (unk && prev_unk && !prev_space) emit = 0;  // continues a run of unknown chars (bpe.cpp:1517-1527)
-          else emit = prev_space ? 2 : 1;
-        }
-        const unsigned long long e1 = __ballot(emit >= 1), e2 = __ballot(emit == 2);
-        const int pos = n + (int)__popcll(e1 & lt) + (int)__popcll(e2 & lt);
-        const uint32_t tv = unk ? ENC_UNKP : id;
-        if (emit == 2) {
-          wt.set(pos, m.space_id | TOK_WS);  // every word starts with the space token (bpe.cpp:1514)
-          wt.set(pos + 1, tv);
-        } else if (emit == 1) {
-          wt.set(pos, tv);
-        }
-        if (emit) atomicAdd(&wr.p[256 + it], (uint32_t)emit);
-        n += (int)__popcll(e1) + (int)__popcll(e2);
-        if (V) {
-          const int j2 = 63 - __clzll((long long)V);
-          carry_space = (S >> j2) & 1ull;
-          carry_unk = (U >> j2) & 1ull;
-          carry_item = __shfl(it, j2);
-        }
+        for (int q = we; q < ws + (int)need; q++) wt.set(q, ENC_DEAD);
       }
-      wave_sync();
-      const uint32_t ntok = lane < cnt ? wr.get(256 + lane) : 0u;
-      const uint32_t tend = wave_incl_scan(ntok);
-      const int ws = (int)(tend - ntok);
-      int we = (int)tend;
+      const uint32_t ntok = (uint32_t)(we - ws);
       wave_sync();
       // every pair's priority, lanes = positions
       for (int c = 0; c < ((n + 63) >> 6); c++) {

@@ -1768,7 +1768,7 @@ template <int SLOT, bool FILL, bool WORDS, int SWEEP>
 __device__ inline void idx_sweep(const TileSet &ts, const PairIndex &ix, const uint32_t *bloom, IdxAgg &T, uint32_t shard) {
   const int lane = lane_id();
   const uint32_t stride = gridDim.x * (IDXA_NT / 64);
-  for (uint32_t t = blockIdx.x * (IDXA_NT / 64) + (threadIdx.x >> 6); t < ts.n_tiles; t += stride) {
+  for (uint32_t t = uni(blockIdx.x * (IDXA_NT / 64) + (uint32_t)(threadIdx.x >> 6)); t < ts.n_tiles; t += stride) {  // (uni: a wave's tile is the same in its lanes)
     const int n = (int)ts.tile_len[t];
     uint4 r[SLOT / 256];
     tile_fetch<SLOT>(r, ts, t, n);
@@ -1899,7 +1899,7 @@ __global__ __launch_bounds__(BLOCK) void k_words_init(TileSet ts, unsigned long 
   const int lane = lane_id();
   constexpr int NC = SLOT / 64;
   const uint32_t stride = gridDim.x * NWAVES;
-  for (uint32_t t = blockIdx.x * NWAVES + (threadIdx.x >> 6); t < ts.n_tiles; t += stride) {
+  for (uint32_t t = uni(blockIdx.x * NWAVES + (uint32_t)(threadIdx.x >> 6)); t < ts.n_tiles; t += stride) {
     const int n = (int)ts.tile_len[t];
     const uint32_t *src = ts.tok + (size_t)t * SLOT;
     unsigned long long m[NC];
@@ -2725,7 +2725,7 @@ __global__ __launch_bounds__(BLOCK) void k_repack_mark(TileSet ts, const unsigne
                                                        unsigned long long *__restrict__ gstart, uint32_t *__restrict__ gword0) {
   const int lane = lane_id();
   const uint32_t stride = gridDim.x * NWAVES;
-  for (uint32_t t = blockIdx.x * NWAVES + (threadIdx.x >> 6); t < ts.n_tiles; t += stride) {
+  for (uint32_t t = uni(blockIdx.x * NWAVES + (uint32_t)(threadIdx.x >> 6)); t < ts.n_tiles; t += stride) {
     const int n = (int)ts.tile_len[t];
     const uint32_t *src = ts.tok + (size_t)t * SLOT;
     uint32_t wbase = 0;
@@ -2761,7 +2761,7 @@ __global__ __launch_bounds__(BLOCK) void k_repack_copy(TileSet ts, const unsigne
                                                        const unsigned long long *__restrict__ gstart, uint32_t *__restrict__ new_tok) {
   const int lane = lane_id();
   const uint32_t stride = gridDim.x * NWAVES;
-  for (uint32_t t = blockIdx.x * NWAVES + (threadIdx.x >> 6); t < ts.n_tiles; t += stride) {
+  for (uint32_t t = uni(blockIdx.x * NWAVES + (uint32_t)(threadIdx.x >> 6)); t < ts.n_tiles; t += stride) {
     const int n = (int)ts.tile_len[t];
     const uint32_t *src = ts.tok + (size_t)t * SLOT;
     int carry_ws = 0;  // position of the last word start seen in earlier chunks (a tile starts with a word start)

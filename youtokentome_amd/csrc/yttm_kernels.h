@@ -238,6 +238,7 @@ struct WordPublish {
   const uint32_t *uslot;
   unsigned long long n_table;
   unsigned long long *extra;
+  unsigned long long text_bytes;  // size of the text buffer (wide loads stay inside it)
 };
 void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long long *offsets, const unsigned long long *ends,
                    unsigned long long n_sent, int bos,
