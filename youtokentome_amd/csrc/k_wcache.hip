@@ -89,7 +89,7 @@ __device__ inline void wc_insert_word(const uint8_t *__restrict__ text, unsigned
     if (cur == PT_EMPTY) {
       cur = atomicCAS(&wc.slot[i], PT_EMPTY, key);
       if (cur == PT_EMPTY) {  // this occurrence is the word's first: it lends the word its bytes
-        wc.pos[i] = pos;
+        if (len < 8) wc.pos[i] = pos;  // (a long word's key says where: one random store less for each of them)
         found = (uint32_t)i;
         break;
       }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(BLOCK) void k5w_list(WordCache wc, const unsigned l
     uint32_t tot;
     const uint32_t r = block_excl_scan(used ? 1u : 0u, scan_lds, &tot);
     if (used) {
-      const unsigned long long u = out + r, p = wc.pos[i];
+      const unsigned long long u = out + r, p = (key & WC_LONG) ? key & WC_POS_MASK : wc.pos[i];
       const unsigned long long len = (key & WC_LONG) ? (key >> 40) & 0xffffull : key >> 56;
       ustart[u] = p;
       uend[u] = p + len;
