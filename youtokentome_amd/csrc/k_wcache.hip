@@ -25,6 +25,7 @@ constexpr uint32_t WC_NONE = 0xffffffffu;                // occ value: no word s
 constexpr int WC_MAX_PROBES = 512;
 constexpr int WC_SHORT_PROBES = 24;                      // slots a short word tries in the table's short region before it goes on in the whole table
 constexpr int WC_SBLK = 64;                              // sentences a wavefront of the flat walks (insert, count, scatter) takes at a time, at most
+constexpr int WC_CLASSES = 4;                            // classes of word length the list of distinct words is laid out in
 constexpr unsigned int WC_CBLK = BLOCK * 8;              // table slots per workgroup of the compaction kernels
 
 // bytes [pos, pos + 8) of the text, for any alignment of pos (the text itself is 8-byte aligned; the caller has checked that the 16 bytes from
@@ -225,41 +226,63 @@ __global__ __launch_bounds__(BLOCK) void k5w_insert(EncModel m, const uint8_t *_
 }
 
 // ---- 2. the table's words as a list ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k5w_count_slots(WordCache wc, uint32_t *__restrict__ blk_cnt) {
-  __shared__ unsigned int acc;
-  if (threadIdx.x == 0) acc = 0;
-  __syncthreads();
-  const unsigned long long base = (unsigned long long)blockIdx.x * WC_CBLK;
-  unsigned int c = 0;
-  for (unsigned int k = 0; k < 8; k++) {
-    const unsigned long long i = base + k * BLOCK + threadIdx.x;
-    if (i <= wc.mask && wc.slot[i] != PT_EMPTY) c++;
-  }
-  if (c) atomicAdd(&acc, c);
-  __syncthreads();
-  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = acc;
+// The list is in classes of word length, short words first: K5 packs consecutive items into a wavefront's arrays and a pack takes as
+// many merge rounds as its longest word -- words of a kind side by side keep the lanes of a pack busy for the same number of rounds.
+// (The order inside a class is whatever the atomics make it; nothing depends on it: a word's ids are found through its table slot.)
+__device__ inline int wc_len_class(unsigned long long key, int classes) {
+  if (classes <= 1) return 0;
+  const uint32_t len = (uint32_t)((key & WC_LONG) ? (key >> 40) & 0xffffull : key >> 56);
+  return len <= 9 ? 0 : len <= 14 ? 1 : len <= 20 ? 2 : 3;
 }
-// word u of the list: bytes [ustart[u], uend[u]), table slot uslot[u]; the uncached words follow the table's
-__global__ __launch_bounds__(BLOCK) void k5w_list(WordCache wc, const unsigned long long *__restrict__ blk_off, unsigned long long n_table,
-                                                  unsigned long long *__restrict__ ustart, unsigned long long *__restrict__ uend,
-                                                  uint32_t *__restrict__ uslot) {
-  __shared__ uint32_t scan_lds[NWAVES];
+// blk_cnt[c * gridDim.x + block] = words of class c in the block's slots
+__global__ __launch_bounds__(BLOCK) void k5w_count_slots(WordCache wc, uint32_t *__restrict__ blk_cnt, int classes) {
+  __shared__ unsigned int acc[WC_CLASSES];
+  if (threadIdx.x < WC_CLASSES) acc[threadIdx.x] = 0;
+  __syncthreads();
   const unsigned long long base = (unsigned long long)blockIdx.x * WC_CBLK;
-  unsigned long long out = blk_off[blockIdx.x];
   for (unsigned int k = 0; k < 8; k++) {
     const unsigned long long i = base + k * BLOCK + threadIdx.x;
     const unsigned long long key = i <= wc.mask ? wc.slot[i] : PT_EMPTY;
     const bool used = key != PT_EMPTY;
-    uint32_t tot;
-    const uint32_t r = block_excl_scan(used ? 1u : 0u, scan_lds, &tot);
+    const int c = wc_len_class(key, classes);
+    for (int q = 0; q < classes; q++) {
+      const unsigned long long M = __ballot(used && c == q);
+      if (M && lane_id() == 0) atomicAdd(&acc[q], (unsigned int)__popcll(M));
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < classes) blk_cnt[(unsigned long long)threadIdx.x * gridDim.x + blockIdx.x] = acc[threadIdx.x];
+}
+// word u of the list: bytes [ustart[u], uend[u]), table slot uslot[u]; the uncached words follow the table's
+__global__ __launch_bounds__(BLOCK) void k5w_list(WordCache wc, const unsigned long long *__restrict__ blk_off, unsigned long long n_table,
+                                                  unsigned long long *__restrict__ ustart, unsigned long long *__restrict__ uend,
+                                                  uint32_t *__restrict__ uslot, int classes) {
+  __shared__ unsigned int next[WC_CLASSES];  // words of the class this block has listed so far
+  if (threadIdx.x < WC_CLASSES) next[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned long long base = (unsigned long long)blockIdx.x * WC_CBLK;
+  const unsigned long long lt = lanemask_lt();
+  for (unsigned int k = 0; k < 8; k++) {
+    const unsigned long long i = base + k * BLOCK + threadIdx.x;
+    const unsigned long long key = i <= wc.mask ? wc.slot[i] : PT_EMPTY;
+    const bool used = key != PT_EMPTY;
+    const int c = wc_len_class(key, classes);
+    unsigned int r = 0;
+    for (int q = 0; q < classes; q++) {  // a wave takes its places of class q with one LDS atomic
+      const unsigned long long M = __ballot(used && c == q);
+      if (!M) continue;
+      unsigned int first = 0;
+      if (lane_id() == 0) first = atomicAdd(&next[q], (unsigned int)__popcll(M));
+      first = (unsigned int)__shfl((int)first, 0);
+      if (used && c == q) r = first + (unsigned int)__popcll(M & lt);
+    }
     if (used) {
-      const unsigned long long u = out + r, p = (key & WC_LONG) ? key & WC_POS_MASK : wc.pos[i];
+      const unsigned long long u = blk_off[(unsigned long long)c * gridDim.x + blockIdx.x] + r, p = (key & WC_LONG) ? key & WC_POS_MASK : wc.pos[i];
       const unsigned long long len = (key & WC_LONG) ? (key >> 40) & 0xffffull : key >> 56;
       ustart[u] = p;
       uend[u] = p + len;
       uslot[u] = (uint32_t)i;
     }
-    out += tot;
   }
   if (blockIdx.x == 0) {
     const unsigned int n_extra = *wc.extra_n;
@@ -420,18 +443,24 @@ static inline unsigned int wave_grid(unsigned long long n_items, unsigned int ma
   if (b > max_blocks) b = max_blocks;
   return b ? (unsigned int)b : 1u;
 }
-unsigned long long wcache_count_blocks(const WordCache &wc) { return (wc.mask + WC_CBLK) / WC_CBLK; }
+static inline unsigned int wcache_blocks(const WordCache &wc) { return (unsigned int)((wc.mask + WC_CBLK) / WC_CBLK); }
+static int wcache_classes() {
+  const char *e = getenv("YTTM_K5_CLASSES");
+  const int c = e ? atoi(e) : WC_CLASSES;
+  return c <= 1 ? 1 : WC_CLASSES;
+}
+unsigned long long wcache_count_blocks(const WordCache &wc) { return (unsigned long long)wcache_blocks(wc) * (unsigned long long)wcache_classes(); }
 void launch_wcache_insert(const EncModel &m, const uint8_t *text, unsigned long long total, const unsigned long long *offsets, unsigned long long n_sent,
                           const WordCache &wc, hipStream_t st) {
   const int sblk = wc_sblk(n_sent);
   hipLaunchKernelGGL(k5w_insert, dim3(wave_grid((n_sent + sblk - 1) / sblk, 256 * 16)), dim3(BLOCK), 0, st, m, text, total, offsets, n_sent, wc, sblk);
 }
 void launch_wcache_count_slots(const WordCache &wc, uint32_t *blk_cnt, hipStream_t st) {
-  hipLaunchKernelGGL(k5w_count_slots, dim3((unsigned int)wcache_count_blocks(wc)), dim3(BLOCK), 0, st, wc, blk_cnt);
+  hipLaunchKernelGGL(k5w_count_slots, dim3(wcache_blocks(wc)), dim3(BLOCK), 0, st, wc, blk_cnt, wcache_classes());
 }
 void launch_wcache_list(const WordCache &wc, const unsigned long long *blk_off, unsigned long long n_table, unsigned long long *ustart,
                         unsigned long long *uend, uint32_t *uslot, hipStream_t st) {
-  hipLaunchKernelGGL(k5w_list, dim3((unsigned int)wcache_count_blocks(wc)), dim3(BLOCK), 0, st, wc, blk_off, n_table, ustart, uend, uslot);
+  hipLaunchKernelGGL(k5w_list, dim3(wcache_blocks(wc)), dim3(BLOCK), 0, st, wc, blk_off, n_table, ustart, uend, uslot, wcache_classes());
 }
 void launch_wcache_count(const unsigned long long *offsets, unsigned long long n_sent, const WordCache &wc, int n_fixed, uint32_t *counts, hipStream_t st) {
   const int sblk = wc_sblk(n_sent);
