@@ -107,13 +107,98 @@ __device__ inline void wc_insert_word(const uint8_t *__restrict__ text, unsigned
   wc.occ[oidx] = found;
 }
 
-// A wavefront takes sblk consecutive sentences -- one run of bytes, the sentences lie back to back -- and walks the run 64 bytes at a time,
-// whatever the sentences' lengths (a sentence of 129 bytes walked alone is three steps, the third with one lane busy).  Same classification
-// as enc_tokenize (k_encode.hip): chars by the reference's left-to-right decode inside their sentence, invalid bytes dropped, spaces by
-// cpmap; a sentence's first byte has the sentence start in front of it, which acts like a space: it closes the word the previous sentence
-// left open and lets a new one begin.  The words a step closes (about ten) are queued in LDS and inserted 64 at a time, one per lane --
-// the table probe is a chain of dependent loads, paid once per 64 words instead of once per step with a handful of lanes busy.
-constexpr int WC_QUEUE = 128;
+// A wavefront takes sblk consecutive sentences -- one run of bytes, the sentences lie back to back -- and walks the run whatever the
+// sentences' lengths (a sentence of 129 bytes walked alone is three 64-byte steps, the third with one lane busy).  Same classification as
+// enc_tokenize (k_encode.hip): chars by the reference's left-to-right decode inside their sentence, invalid bytes dropped, spaces by cpmap;
+// a sentence's first byte has the sentence start in front of it, which acts like a space: it closes the word the previous sentence left
+// open and lets a new one begin.  Steps of 512 bytes, EIGHT per lane, while the bytes are ASCII: white space, word starts and word ends are
+// bit masks of a lane's eight bytes (the trainer's k_scan_bytes does the same); any byte beyond ASCII sends those 512 bytes through the
+// walk of one byte per lane with the exact decode.  The words a step closes (about eighty) are queued in LDS and inserted 64 at a time,
+// one per lane -- the table probe is a chain of dependent loads, paid once per 64 words.
+constexpr int WC_QUEUE = 64 + 4 * 64 + 64;  // what a flush leaves + what a step can close (a word and its space are two bytes)
+struct WalkState {
+  bool carry_space = true;             // class of the last valid char of the current sentence so far (its start acts like a space)
+  unsigned long long carry_start = 0;  // where the open word began
+  int queued = 0;
+};
+struct WordQueue {
+  unsigned long long *pos, *occ;
+  uint32_t *len;
+};
+// the sentence (of the block: bnd[0 .. ns]) of byte p: the last one that begins at or before it (empty sentences pile up on one byte)
+__device__ inline int wc_sentence_of(const unsigned long long *bnd, int ns, unsigned long long p) {
+  int a = 0, b = ns;  // bnd[a] <= p; sentences a .. b - 1 are candidates
+  while (b - a > 1) {
+    const int mid = (a + b) >> 1;
+    if (bnd[mid] <= p) a = mid; else b = mid;
+  }
+  return a;
+}
+__device__ inline void wc_queue_push(const WordQueue &q, int at, const unsigned long long *bnd, int ns, unsigned long long s0, unsigned long long ws,
+                                     unsigned long long we) {
+  q.pos[at] = ws;
+  q.len[at] = (uint32_t)(we - ws > 0xfffffffeull ? 0xffffffffull : we - ws);
+  q.occ[at] = (ws + s0 + (unsigned long long)wc_sentence_of(bnd, ns, ws)) >> 1;
+}
+// 64 words at a time from the queue's head; what is left (< 64) moves to the front
+__device__ inline void wc_queue_drain(const uint8_t *__restrict__ text, unsigned long long total, const WordCache &wc, const WordQueue &q, int &queued) {
+  const int lane = lane_id();
+  int head = 0;
+  for (; queued - head >= 64; head += 64) wc_insert_word(text, total, wc, q.pos[head + lane], q.len[head + lane], q.occ[head + lane]);
+  if (head == 0) return;
+  const int rest = queued - head;  // (< 64)
+  unsigned long long pp = 0, oo = 0;
+  uint32_t ll = 0;
+  wave_sync();
+  if (lane < rest) { pp = q.pos[head + lane]; ll = q.len[head + lane]; oo = q.occ[head + lane]; }
+  wave_sync();
+  if (lane < rest) { q.pos[lane] = pp; q.len[lane] = ll; q.occ[lane] = oo; }
+  queued = rest;
+  wave_sync();
+}
+// one byte per lane: bytes [p0, p0 + 64) of the block [P0, P1), any UTF-8
+__device__ inline void wc_walk64(const EncModel &m, const uint8_t *__restrict__ text, const unsigned long long *bnd, int ns, unsigned long long s0,
+                                 unsigned long long P0, unsigned long long P1, unsigned long long p0, WalkState &st, const WordQueue &q) {
+  const int lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+  const unsigned long long p = p0 + (unsigned long long)lane;
+  const bool in = p >= P0 && p < P1;
+  bool valid = false, space = false, first = p == P1;  // (the position behind the block's last byte: the last sentence's end)
+  if (in) {
+    const int k = wc_sentence_of(bnd, ns, p);
+    const unsigned long long s_lo = bnd[k], nbytes = bnd[k + 1] - s_lo;
+    first = s_lo == p;
+    if (u8_is_start(text + s_lo, p - s_lo, nbytes)) {
+      uint32_t len;
+      const uint32_t cp = u8_decode_at(text + s_lo, p - s_lo, nbytes, &len);
+      if (cp != INVALID_CP) {
+        valid = true;
+        space = m.cpmap[cp] == CP_SPACE;
+      }
+    }
+  }
+  const unsigned long long V = __ballot(valid), S = __ballot(space), F = __ballot(first);
+  // the state in front of this lane: the last valid char below it, unless a sentence began since
+  const unsigned long long pv = V & lt;
+  const int j = pv ? 63 - __clzll((long long)pv) : -1;
+  const unsigned long long since = F & lt & ~(j >= 0 ? (2ull << j) - 1ull : 0ull);
+  const bool pre_space = since ? true : (j >= 0 ? (bool)((S >> j) & 1ull) : st.carry_space);
+  const bool prev_space = first ? true : pre_space;  // ... and in front of this lane's own char
+  const bool wstart = valid && !space && prev_space;
+  const bool closing = (first && !pre_space) || (valid && space && !prev_space);  // by the sentence's end, or by a space
+  const unsigned long long WSM = __ballot(wstart), CM = __ballot(closing);
+  const unsigned long long wlt = WSM & lt;
+  if (closing) wc_queue_push(q, st.queued + (int)__popcll(CM & lt), bnd, ns, s0, wlt ? p0 + (unsigned long long)(63 - __clzll((long long)wlt)) : st.carry_start, p);
+  st.queued += (int)__popcll(CM);
+  if (V) {
+    const int jl = 63 - __clzll((long long)V);
+    st.carry_space = (F & ~((2ull << jl) - 1ull)) ? true : (bool)((S >> jl) & 1ull);
+  } else if (F) {
+    st.carry_space = true;
+  }
+  if (WSM) st.carry_start = p0 + (unsigned long long)(63 - __clzll((long long)WSM));
+  wave_sync();
+}
 __global__ __launch_bounds__(BLOCK) void k5w_insert(EncModel m, const uint8_t *__restrict__ text, unsigned long long total,
                                                     const unsigned long long *__restrict__ offsets, unsigned long long n_sent, WordCache wc, int sblk) {
   __shared__ unsigned long long q_pos[NWAVES][WC_QUEUE], q_occ[NWAVES][WC_QUEUE];
@@ -123,9 +208,9 @@ __global__ __launch_bounds__(BLOCK) void k5w_insert(EncModel m, const uint8_t *_
   const unsigned long long lt = lanemask_lt();
   const unsigned long long gw = (unsigned long long)blockIdx.x * NWAVES + wave;
   const unsigned long long n_waves = (unsigned long long)gridDim.x * NWAVES;
-  unsigned long long *qp = q_pos[wave], *qo = q_occ[wave], *bnd = bnd_all[wave];
-  uint32_t *ql = q_len[wave];
-  int queued = 0;
+  unsigned long long *bnd = bnd_all[wave];
+  const WordQueue q{q_pos[wave], q_occ[wave], q_len[wave]};
+  WalkState st;
   const unsigned long long n_blk = (n_sent + sblk - 1) / sblk;
   for (unsigned long long blk = gw; blk < n_blk; blk += n_waves) {
     const unsigned long long s0 = blk * (unsigned long long)sblk;
@@ -134,95 +219,90 @@ __global__ __launch_bounds__(BLOCK) void k5w_insert(EncModel m, const uint8_t *_
     if (lane < ns) bnd[lane] = offsets[s0 + lane];  // sentence k of the block = bytes [bnd[k], bnd[k + 1])
     if (lane == 0) bnd[ns] = offsets[s0 + ns];
     wave_sync();
-    // (what is the same in every lane -- the block's ends, the boundary the walk has come to, the open word -- is told to the compiler with
-    // uni(): read from LDS it would be kept in vector registers, and every loop on it run under exec masks)
     const unsigned long long P0 = uni64(bnd[0]), P1 = uni64(bnd[ns]);
-    // the open word, if any: class of the last valid char of the current sentence so far (its start acts like a space), where the word began
-    bool carry_space = true;
-    unsigned long long carry_start = 0;
-    int carry_k = 0, kn = 0;          // kn: the first boundary the walk has not passed yet,
-    unsigned long long next_b = P0;   // and where it is
-    uint32_t byte = P0 + (unsigned long long)lane < P1 ? text[P0 + lane] : 0u;
-    for (unsigned long long p0 = P0; p0 <= P1; p0 += 64) {  // (the position behind the last byte has a lane too: the last sentence's end)
-      const unsigned long long p = p0 + (unsigned long long)lane;
-      const uint32_t n_byte = p + 64 < P1 ? text[p + 64] : 0u;  // (the next step's bytes: with ASCII text the step's only load)
-      // the lane's sentence: the last one that begins at or before p (empty sentences pile up on one byte: the last of them); a sentence
-      // begins at p if a boundary lies there
-      int k = kn - 1;
-      bool first = false;
-      while (kn <= ns && next_b < p0 + 64) {
-        k += p >= next_b ? 1 : 0;
-        first = first || p == next_b;
+    st.carry_space = true;
+    st.carry_start = 0;
+    int kn = 0;                      // the first boundary the walk has not come to yet,
+    unsigned long long next_b = P0;  // and where it is
+    for (unsigned long long base = P0 & ~7ull; base <= P1; base += 512) {  // (the position behind the last byte is walked too: the last sentence's end)
+      const unsigned long long q0 = base + 8ull * (unsigned long long)lane;
+      // the lane's eight bytes (one aligned load while it lies inside the text), what is outside the block counts as white space
+      unsigned long long w = 0x2020202020202020ull;
+      if (q0 + 8 <= total) {
+        w = *reinterpret_cast<const unsigned long long *>(text + q0);
+      } else {
+        for (int j = 0; j < 8; j++)
+          if (q0 + j < total) w = (w & ~(0xffull << (8 * j))) | ((unsigned long long)text[q0 + j] << (8 * j));
+      }
+      uint32_t inr = 0xffu;  // the bytes of the block
+      if (q0 < P0) inr &= q0 + 8 <= P0 ? 0u : 0xffu << (uint32_t)(P0 - q0);
+      if (q0 + 8 > P1) inr &= q0 >= P1 ? 0u : 0xffu >> (uint32_t)(q0 + 8 - P1);
+      if (inr != 0xffu) {
+        unsigned long long keep = 0;  // (0xff in the bytes that count)
+        for (int j = 0; j < 8; j++) keep |= ((inr >> j) & 1u) ? 0xffull << (8 * j) : 0ull;
+        w = (w & keep) | (0x2020202020202020ull & ~keep);
+      }
+      const uint32_t end_bit = P1 >= q0 && P1 < q0 + 8 ? 1u << (uint32_t)(P1 - q0) : 0u;  // (white space like everything behind the block: it closes the last word)
+      // sentence starts among the lane's bytes (the walk's boundary cursor: uniform)
+      uint32_t fb = 0;
+      const unsigned long long lim = base + 512 < P1 ? base + 512 : P1;
+      while (kn <= ns && next_b < lim) {
+        if (next_b >= q0 && next_b < q0 + 8) fb |= 1u << (uint32_t)(next_b - q0);
         kn++;
         next_b = kn <= ns ? uni64(bnd[kn]) : 0ull;
       }
-      bool valid = false, space = false;
-      if (__ballot(byte >= 0x80u) == 0ull) {  // 64 ASCII bytes (the usual step): every byte is a char, the spaces are utils.cpp:99-101's
-        valid = p < P1;
-        space = byte == 32u || (byte - 9u) < 5u;
-      } else if (p < P1) {
-        const unsigned long long s_lo = bnd[k], nbytes = bnd[k + 1] - s_lo;
-        if (u8_is_start(text + s_lo, p - s_lo, nbytes)) {
-          uint32_t len;
-          const uint32_t cp = u8_decode_at(text + s_lo, p - s_lo, nbytes, &len);
-          if (cp != INVALID_CP) {
-            valid = true;
-            space = m.cpmap[cp] == CP_SPACE;
-          }
+      if (__ballot((w & 0x8080808080808080ull) != 0ull) != 0ull) {  // beyond ASCII somewhere in these 512 bytes: one byte per lane
+        for (int sub = 0; sub < 8; sub++) {
+          const unsigned long long p0 = base + 64ull * (unsigned long long)sub;
+          if (p0 > P1) break;
+          if (p0 + 64 > P0) wc_walk64(m, text, bnd, ns, s0, P0, P1, p0, st, q);
+          wc_queue_drain(text, total, wc, q, st.queued);
         }
+        continue;
       }
-      const unsigned long long V = __ballot(valid), S = __ballot(space), F = __ballot(first);
-      // the state in front of this lane: the last valid char below it, unless a sentence began since
-      const unsigned long long pv = V & lt;
-      const int j = pv ? 63 - __clzll((long long)pv) : -1;
-      const unsigned long long since = F & lt & ~(j >= 0 ? (2ull << j) - 1ull : 0ull);
-      const bool pre_space = since ? true : (j >= 0 ? (bool)((S >> j) & 1ull) : carry_space);
-      const bool prev_space = first ? true : pre_space;  // ... and in front of this lane's own char
-      const bool wstart = valid && !space && prev_space;
-      const bool closing = (first && !pre_space) || (valid && space && !prev_space);  // by the sentence's end, or by a space
-      const unsigned long long WSM = __ballot(wstart), CM = __ballot(closing);
-      const unsigned long long wlt = WSM & lt;
-      const int wl = wlt ? 63 - __clzll((long long)wlt) : 0;
-      const int k_from = __shfl(k, wl);
-      if (closing) {
-        const unsigned long long ws = wlt ? p0 + (unsigned long long)wl : carry_start;
-        const unsigned long long sidx = s0 + (unsigned long long)(wlt ? k_from : carry_k);
-        const int at = queued + (int)__popcll(CM & lt);
-        qp[at] = ws;
-        ql[at] = (uint32_t)(p - ws > 0xfffffffeull ? 0xffffffffull : p - ws);
-        qo[at] = (ws + sidx) >> 1;
+      // white space: 0x20 or 9 .. 13 (utils.cpp:99-101), a flag per byte -> eight bits
+      uint32_t sp = 0;
+      {
+        const unsigned long long t = w ^ 0x2020202020202020ull;
+        const unsigned long long eq = ~(((t & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | t) & 0x8080808080808080ull;  // byte == 0x20
+        const unsigned long long d = (w | 0x8080808080808080ull) - 0x0909090909090909ull;                                    // bit 7 iff byte >= 9
+        const unsigned long long lt5 = ~((d & 0x7f7f7f7f7f7f7f7full) + 0x7b7b7b7b7b7b7b7bull) & 0x8080808080808080ull;         // (byte - 9) mod 128 < 5
+        const unsigned long long f = eq | (d & lt5);
+        sp = (uint32_t)((((f >> 7) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
       }
-      queued += (int)__popcll(CM);
+      // the state in front of every byte: the byte before it (all are chars here); in front of the lane's first, the lane below's last
+      uint32_t below = (uint32_t)__shfl_up((int)sp, 1);
+      const uint32_t in0 = lane == 0 ? (st.carry_space ? 1u : 0u) : (below >> 7) & 1u;
+      const uint32_t psp = ((sp << 1) | in0) & 0xffu;
+      const uint32_t ws_bits = ~sp & (psp | fb) & inr;                            // a word begins: not white space, behind white space or a sentence start
+      const uint32_t cl_bits = ((fb & ~psp) | (sp & ~(psp | fb))) & (inr | end_bit) & 0xffu;  // a word ends: by the sentence's end, or by a space
+      // where the word that is open in front of this lane began
+      const unsigned long long LW = __ballot(ws_bits != 0u);
+      const unsigned long long mylast = q0 + (unsigned long long)(31 - __clz((int)(ws_bits | 1u)));
+      const unsigned long long lw_lt = LW & lt;
+      const int src = lw_lt ? 63 - __clzll((long long)lw_lt) : 0;
+      const unsigned long long got = __shfl(mylast, src);
+      const unsigned long long open_start = lw_lt ? got : st.carry_start;
+      // the lane's closings, in order, to their places in the queue
+      const uint32_t nc = (uint32_t)__popc(cl_bits);
+      const uint32_t inc = wave_incl_scan(nc);
+      int at = st.queued + (int)(inc - nc);
+      for (uint32_t c = cl_bits; c; c &= c - 1u) {
+        const uint32_t j = (uint32_t)__ffs((int)c) - 1u;
+        const uint32_t wb = ws_bits & ((1u << j) - 1u);  // word starts of this lane in front of the closing byte
+        const unsigned long long ws = wb ? q0 + (unsigned long long)(31 - __clz((int)wb)) : open_start;
+        wc_queue_push(q, at++, bnd, ns, s0, ws, q0 + j);
+      }
+      st.queued += (int)__shfl((int)inc, 63);
+      // carry: the last byte of the step (inside the block: steps but the last are whole), the last word start
+      st.carry_space = ((uint32_t)__shfl((int)sp, 63) >> 7) & 1u;
+      if (LW) st.carry_start = __shfl(mylast, 63 - __clzll((long long)LW));
       wave_sync();
-      if (queued >= 64) {
-        wc_insert_word(text, total, wc, qp[lane], ql[lane], qo[lane]);
-        wave_sync();
-        const int rest = queued - 64;  // (< 64)
-        unsigned long long pp = 0, oo = 0;
-        uint32_t ll = 0;
-        if (lane < rest) { pp = qp[64 + lane]; ll = ql[64 + lane]; oo = qo[64 + lane]; }
-        wave_sync();
-        if (lane < rest) { qp[lane] = pp; ql[lane] = ll; qo[lane] = oo; }
-        queued = rest;
-        wave_sync();
-      }
-      if (V) {
-        const int jl = 63 - __clzll((long long)V);
-        carry_space = (F & ~((2ull << jl) - 1ull)) ? true : (bool)((S >> jl) & 1ull);
-      } else if (F) {
-        carry_space = true;
-      }
-      const int wh = WSM ? 63 - __clzll((long long)WSM) : 0;
-      const int k_high = uni(__shfl(k, wh));
-      if (WSM) {
-        carry_start = p0 + (unsigned long long)wh;
-        carry_k = k_high;
-      }
-      byte = n_byte;
+      wc_queue_drain(text, total, wc, q, st.queued);
     }
   }
   wave_sync();
-  if (lane < queued) wc_insert_word(text, total, wc, qp[lane], ql[lane], qo[lane]);
+  if (lane < st.queued) wc_insert_word(text, total, wc, q.pos[lane], q.len[lane], q.occ[lane]);
 }
 
 // ---- 2. the table's words as a list ------------------------------------------------------------------------------------------
