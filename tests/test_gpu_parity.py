@@ -418,7 +418,7 @@ def test_zz_rccl_world_of_one(tmp_path):
 def test_zz_fused_tail_ordering(tmp_path, use_comm):
     """The round's candidate scan rides in the tail of the round's last kernel: the LAST workgroup to take its ticket reads what every
     other workgroup -- on other XCDs -- published before taking its own (device-scope atomics, write-through stores, a workgroup-scope
-    release + s_waitcnt vmcnt(0); k_merge.hip k_tiles / k_words / k_fold_list).  The emulator cannot show that ordering; this does: the
+    release + s_waitcnt vmcnt(0); k_tiles.hip / k_words.hip / k_pairtable.hip k_fold_list).  The emulator cannot show that ordering; this does: the
     100 MB variant of configs[1] (1 500 workgroups per launch in the tile rounds, word mode after them) trained with the fused tail and
     with the scan as a kernel of its own (YTTM_NO_FUSE=1: ordered by a kernel boundary), three times: the candidate traces
     (YTTM_DBG_CAND: one line per scan -- thresholds, list lengths, key count, a hash of the candidates) must agree line by line and the

@@ -1799,7 +1799,7 @@ void GpuCtx::free_words() {
   g_sites_cum_ = g_tokens_cum_ = g_tokens_last_ = g_tiles_a_ = 0;
 }
 
-// The switch to word mode (k_merge.hip: k_words): from here on class-A words live in the slots they have now and a round visits the words
+// The switch to word mode (k_words.hip): from here on class-A words live in the slots they have now and a round visits the words
 // that hold a merge site.  Called between rounds.
 void GpuCtx::enter_word_mode(uint32_t z_next) {
   WordClass &c = cls_[0];
@@ -1851,7 +1851,7 @@ void GpuCtx::free_index() {
   idx_valid_ = false;
 }
 
-// (Re)builds the pair index of word mode from the hot list as it is now and the class-A words as they are now (see k_merge.hip PairIndex).
+// (Re)builds the pair index of word mode from the hot list as it is now and the class-A words as they are now (see k_index_core.h PairIndex).
 // Called between rounds.
 void GpuCtx::build_index(uint32_t z_next) {
   idx_pending_ = false;

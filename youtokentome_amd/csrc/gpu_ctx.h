@@ -79,7 +79,7 @@ class GpuCtx {
   void download_pairs(std::vector<unsigned long long> &keys, std::vector<unsigned long long> &cnts);
   // ---- K4: apply a batch of mutually non-intersecting rules (x,y,z)*k
   // next_tau_cnt / next_tau_mx (optional): the threshold of the candidate scan that will follow this round.  When the round is
-  // one launch (single GPU, class-A tiles only, hot list active) that scan runs inside it (k_merge.hip round_tail) and the
+  // one launch (single GPU, class-A tiles only, hot list active) that scan runs inside it (k_merge_shared.h scan_top) and the
   // next candidates() call with the same threshold only waits for the mailbox.
   // next_want != 0: about that many candidates are wanted from the fused scan -- it may then raise the threshold by itself; the caller reads
   // the threshold that was used back as the smallest count among the candidates (they are every pair at or above it)
@@ -211,7 +211,7 @@ class GpuCtx {
   void free_class(WordClass &c);
   void build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, unsigned int U, uint32_t space_id);
   void maybe_repack(int ci);
-  // pair index of word mode (k_merge.hip: PairIndex): keys = the hot list when it was built, postings = class-A words
+  // pair index of word mode (k_index_core.h: PairIndex): keys = the hot list when it was built, postings = class-A words
   PairIndexArgs idx_{};
   unsigned long long idx_cap_ = 0, post_cap_ = 0;
   unsigned long long *idx_scan_tmp_ = nullptr;
@@ -222,7 +222,7 @@ class GpuCtx {
   uint32_t idx_zbuild_ = 0;       // token ids below this existed when the index was built
   void build_index(uint32_t z_next);
   void free_index();
-  // word mode (k_merge.hip: k_words): class-A words processed one by one from a worklist of the words that hold a merge site
+  // word mode (k_words.hip): class-A words processed one by one from a worklist of the words that hold a merge site
   bool profile_events_ = false, dev_timing_pending_ = false;  // (merge_apply: dev_timing)
   std::vector<float> dev_round_ms_;
   bool word_mode_ = false, words_enabled_ = true, direct_enabled_ = true;

@@ -1,7 +1,7 @@
 // k_giant.hip -- K3/K4 for class C: words of more than TILE_NOM_B tokens (minified code, base64 blobs, ...).
 //
 // The reference has no length limit (its lists are per word, bpe.cpp:436-478); the wavefront-per-tile kernels of
-// k_merge.hip keep a whole tile in LDS and stop at 2048 tokens per word.  Class C uses the same tile layout with a
+// k_tiles.hip keep a whole tile in LDS and stop at 2048 tokens per word.  Class C uses the same tile layout with a
 // run-time slot size (nominal = the longest word, slot = twice that) and ONE WORKGROUP per tile working in HBM.  Such
 // words are rare and their weight is almost always 1, so this path is written for exactness and simplicity, not speed:
 // a tile that contains a merge site is re-counted -- every adjacency of the old token sequence (but the merged pairs, which

@@ -1,4 +1,4 @@
-// k_merge_shared.h -- device code shared by the merge-loop kernels (k_merge.hip: K3, class-B K4, pair table; k_apply.hip: the
+// k_merge_shared.h -- device code shared by the merge-loop kernels (k_tiles.hip: K3, K4 on tiles; k_words.hip: word mode; k_pairtable.hip: the pair table; k_giant.hip: the
 // class-A K4): the HBM side of a count update, per-workgroup statistics rows, the batch's exact rule probe, and the candidate
 // scan that the last workgroup of an apply kernel runs (scan_top).
 #pragma once

@@ -41,7 +41,7 @@ constexpr unsigned long long PT_EMPTY = ~0ull;
 // Two flag bits of a count mark the candidate lists a slot is on.  The HOT list (L1) holds every slot whose count reached
 // hot_tau since the list was built -- tens of thousands of slots instead of the whole table; the TOP list (L2) holds those of
 // them that reached top_tau >= hot_tau -- about a thousand, few enough for ONE workgroup to read at the end of a merge round
-// (k_merge.hip round_tail).  The scan of a round reads L2; L2 is refilled from L1 when it runs dry, L1 from the table.
+// (k_merge_shared.h scan_top).  The scan of a round reads L2; L2 is refilled from L1 when it runs dry, L1 from the table.
 constexpr unsigned long long PT_HOT = 1ull << 63;
 constexpr unsigned long long PT_TOP = 1ull << 62;
 constexpr unsigned long long PT_FLAGS = PT_HOT | PT_TOP;
@@ -82,7 +82,7 @@ struct TileSet {
   uint32_t n_tiles;
 };
 
-// ---- word mode (k_merge.hip: k_words).  Once a merge round touches few of the words, class-A words are no longer processed tile by
+// ---- word mode (k_words.hip).  Once a merge round touches few of the words, class-A words are no longer processed tile by
 // tile: every word keeps the slot it had in the tile array at that moment (wmeta: first token, live length) and shrinks IN PLACE --
 // the tokens a merge frees become TOK_HOLE (word-start bit AND bit 30: no kernel takes a hole for a token, an adjacency or a word
 // start) -- and a round visits only the words that hold a merge site.
@@ -197,7 +197,7 @@ __device__ inline void pt_add(const PairTable &pt, unsigned long long key, long 
       if (delta > 0 && pt.hot_tau != ~0ull) {
         // only an increase can cross a threshold; the adder that observes the crossing (exactly one: the adds on a slot are
         // serialised) sets the list's flag, and whoever sets it first appends the slot.  (Write-through stores: the workgroup
-        // that scans a list at the end of THIS launch -- k_merge.hip round_tail -- may sit on another XCD, whose L2 does not see
+        // that scans a list at the end of THIS launch -- k_merge_shared.h scan_top -- may sit on another XCD, whose L2 does not see
         // plain stores before a cache write-back.)
         const unsigned long long old = atomicAdd(pt.cnt_p(i), (unsigned long long)delta);
         const unsigned long long now = (old & PT_CNT) + (unsigned long long)delta;

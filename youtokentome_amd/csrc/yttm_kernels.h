@@ -1,4 +1,4 @@
-// yttm_kernels.h -- host-callable launchers of the gfx950 kernels (k_frontend.hip, k_merge.hip, k_encode.hip).
+// yttm_kernels.h -- host-callable launchers of the gfx950 kernels (k_frontend.hip; k_tiles.hip, k_words.hip, k_index.hip, k_pairtable.hip, k_giant.hip; k_encode.hip, k_wcache.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,7 +14,7 @@ struct CandRec {
   unsigned long long cnt;
 };
 
-// lower bound of a candidate-histogram bin (inverse of cand_bin in k_merge.hip)
+// lower bound of a candidate-histogram bin (inverse of cand_bin in k_merge_shared.h)
 inline unsigned long long cand_bin_lower(int bin) {
   if (bin < 256) return (unsigned long long)bin;
   int e = 8 + (bin - 256) / 8, m3 = (bin - 256) % 8;
@@ -57,7 +57,7 @@ void launch_tiles(const unsigned long long *uw_off, unsigned int n_words, unsign
 void launch_tile_len(const unsigned long long *tile_start, unsigned int n_tiles, unsigned long long total_tokens, uint32_t *tile_len,
                      hipStream_t st);
 
-// ---- merge loop (k_merge.hip)
+// ---- merge loop (k_tiles.hip, k_pairtable.hip)
 // cls: 0 = class A tiles (slot 1024), 1 = class B tiles (slot 4096)
 // A small batch travels as a kernel argument: the apply kernel and the candidate scan build their LDS tables (token flags, rule
 // hash) from it, and the round needs no prologue kernel, no rule upload and no flag table in HBM.  Used when the whole round
@@ -107,7 +107,7 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
                         const uint32_t *bloom_g /* the batch not in ba: the batch's pair filter (pm_bloom_host) */, hipStream_t st);
 constexpr int PM_BLOOM_WORDS_H = 2048;
 void pm_bloom_host(uint32_t *bloom, const uint32_t *xyz, uint32_t k);
-// pair index for K4's worklists (k_merge.hip: PairIndex)
+// pair index for K4's worklists (k_index_core.h: PairIndex; k_index.hip)
 // A key's posting count / fill cursor is kept in IDX_SHARDS copies (a wave adds to copy (its number) % IDX_SHARDS): a pair with a million
 // adjacencies is a million atomics on ONE address otherwise (~12 ns each: 6.5 ms per pass at the word-mode switch of the 1 GB corpus).
 // The copies' runs are adjacent, so a key's postings are still one run: [off[s * IDX_SHARDS], off[(s + 1) * IDX_SHARDS]).
@@ -123,7 +123,7 @@ void launch_idx_stream(bool fill, const TileSet &ts, const PairIndexArgs &a, hip
                        bool agg = true /* fill pass: sum a workgroup's postings per key in LDS first (worth a second sweep only when they are many) */,
                        void *save = nullptr /* [idx_save_bytes()] the count pass's per-workgroup tables, reused by an agg fill pass */);
 size_t idx_save_bytes();
-// ---- word mode (k_merge.hip)
+// ---- word mode (k_words.hip)
 void launch_words_init(const TileSet &ts, unsigned long long *wmeta, hipStream_t st);
 struct WGatherArgs {
   PairIndexArgs ix;
@@ -179,7 +179,7 @@ constexpr int MB_XSUM = 6144; // multi-GPU, behind the histogram: sums over the 
                               // [16] class-A tiles, [24] ranks; [32] the round's apply kernels on the device clock (ticks; ScanArgs::timed)
 constexpr int XSTAT_WORDS = 8;  // d_xstat: [0] ranks whose block did not fit (bit r), [1] largest record count, [2] -, [3] a rank lost records, [4..7] the sums above
 void launch_fold_stats(unsigned long long *stats, unsigned int *n_keys, hipStream_t st);
-constexpr int STATS_WORDS = 32 + 8 * 1536;  // totals + one row per workgroup (k_merge.hip: BLK_BASE, BLK_ROWS)
+constexpr int STATS_WORDS = 32 + 8 * 1536;  // totals + one row per workgroup (k_merge_shared.h: BLK_BASE, BLK_ROWS)
 void launch_round_begin(const RuleSlot *src_rules, unsigned int n_slots, RuleSlot *dst_rules, unsigned int *work_n_a, unsigned int *work_n_b,
                         const uint32_t *src_bloom, uint32_t *dst_bloom, hipStream_t st);
 void launch_hot_rebuild(const PairTable &pt, hipStream_t st);
