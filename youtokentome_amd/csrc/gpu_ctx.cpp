@@ -611,8 +611,8 @@ void GpuCtx::upload_fd_overlapped(int fd, unsigned long long lo, unsigned long l
   std::mutex mu;
   std::condition_variable cv;
   size_t next_io = 0;  // chunks [0, next_io) have landed
-  bool finished = false;
-  std::string up_error;
+  bool finished = false, up_failed = false;
+  std::string up_error;  // (read after the join)
   const auto t_start = std::chrono::steady_clock::now();
   auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
   double ms_link = 0;
@@ -626,16 +626,19 @@ void GpuCtx::upload_fd_overlapped(int fd, unsigned long long lo, unsigned long l
         if (moved) cv.notify_all();
       });
     } catch (const GpuError &e) {
+      std::lock_guard<std::mutex> g(mu);
       up_error = e.msg;
+      up_failed = true;
     }
     ms_link = ms_now();
     std::lock_guard<std::mutex> g(mu);
     finished = true;
     cv.notify_all();
   });
-  auto wait_for = [&](unsigned long long bytes) {  // until [0, bytes) has landed (or the upload is over)
+  auto wait_for = [&](unsigned long long bytes) {  // until [0, bytes) has landed (or the upload is over); false: it failed
     std::unique_lock<std::mutex> g(mu);
     cv.wait(g, [&] { return finished || std::min<unsigned long long>(n, (unsigned long long)next_io * io_chunk) >= bytes; });
+    return !up_failed;
   };
   // ---- the parts
   const unsigned long long FC = fe_chunk_bytes();
@@ -651,8 +654,7 @@ void GpuCtx::upload_fd_overlapped(int fd, unsigned long long lo, unsigned long l
   try {
     for (unsigned long long b0 = 0; b0 < n; b0 += part) {
       const unsigned long long b1 = std::min(n, b0 + part);
-      wait_for(std::min(n, b1 + FC));
-      if (!up_error.empty()) break;
+      if (!wait_for(std::min(n, b1 + FC))) break;
       const unsigned long long c_lo = b0 / FC, c_hi = fe_chunks(b1);
       t_begin(KT_CHAR_HIST);
       launch_char_hist(d_text_, n, d_hist_, d_counters_, wide_chars, d_chunk_segs_, st_, c_lo, c_hi);
