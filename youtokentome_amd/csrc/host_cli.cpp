@@ -98,14 +98,31 @@ bool write_all(int fd, const char *p, size_t n) {
   return true;
 }
 
-inline void put_int(std::string &o, int v) {  // "<v> " like `std::cout << token << " "` (utils.h:96)
-  char tmp[16];
-  int k = 15;
-  tmp[k] = ' ';
+// "<v> " like `std::cout << token << " "` (utils.h:96), at p (room for 12 chars); returns the end.  Two digits per division: the id lines of
+// a GB of text are 10^8 numbers.
+inline char *put_int(char *p, int v) {
+  static const char D2[201] =
+      "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+  char tmp[12];
+  int k = 12;
   unsigned int u = v < 0 ? 0u - (unsigned int)v : (unsigned int)v;
-  do { tmp[--k] = (char)('0' + u % 10); u /= 10; } while (u);
+  while (u >= 100) {
+    const unsigned int r = u % 100;
+    u /= 100;
+    tmp[--k] = D2[2 * r + 1];
+    tmp[--k] = D2[2 * r];
+  }
+  if (u >= 10) {
+    tmp[--k] = D2[2 * u + 1];
+    tmp[--k] = D2[2 * u];
+  } else {
+    tmp[--k] = (char)('0' + u);
+  }
   if (v < 0) tmp[--k] = '-';
-  o.append(tmp + k, (size_t)(16 - k));
+  memcpy(p, tmp + k, (size_t)(12 - k));
+  p += 12 - k;
+  *p++ = ' ';
+  return p;
 }
 
 struct Batch {
@@ -135,11 +152,13 @@ void encode_and_format(const BaseEncoder &enc, Batch &b, bool subword, bool bos,
     std::vector<unsigned long long> io;
     b.st = enc.encode_as_ids((const uint8_t *)b.bytes.data(), b.off.data(), n, bos, eos, reverse, dropout_prob, &ids, &io);
     if (!b.st.ok()) return;
-    b.out.reserve(ids.size() * 6 + n);
+    b.out.resize(ids.size() * 12 + n);  // (a number and its space: at most 12 chars)
+    char *p = &b.out[0];
     for (unsigned long long i = 0; i < n; i++) {
-      for (unsigned long long k = io[i]; k < io[i + 1]; k++) put_int(b.out, ids[k]);
-      b.out += '\n';
+      for (unsigned long long k = io[i]; k < io[i + 1]; k++) p = put_int(p, ids[k]);
+      *p++ = '\n';
     }
+    b.out.resize((size_t)(p - b.out.data()));
   }
 }
 
@@ -172,7 +191,7 @@ Status BaseEncoder::encode_cli(const std::string &output_type_str, bool stream, 
   std::atomic<bool> stop_reader{false};  // set together with abort: the reader may be inside read() or its line loop, not at the condition variable
   in.stop_when(&stop_reader);
   unsigned long long n_batches = 0;
-  constexpr size_t MAX_AHEAD = 3;  // batches read but not yet written
+  constexpr size_t MAX_AHEAD = 6;  // batches read but not yet written
   size_t in_flight = 0;
 
   std::thread reader([&]() {
@@ -182,12 +201,10 @@ Status BaseEncoder::encode_cli(const std::string &output_type_str, bool stream, 
     for (;;) {
       auto b = std::make_unique<Batch>();
       b->seq = seq++;
-      std::string line;
-      while (b->processed < BATCH_LIMIT) {
-        line.clear();
-        if (stop_reader.load(std::memory_order_relaxed) || !in.next(&line)) break;
-        b->processed += line.size();
-        b->bytes += line;
+      while (b->processed < BATCH_LIMIT) {  // (a line goes straight behind the batch's bytes so far)
+        const size_t before = b->bytes.size();
+        if (stop_reader.load(std::memory_order_relaxed) || !in.next(&b->bytes)) break;
+        b->processed += b->bytes.size() - before;
         b->off.push_back(b->bytes.size());
       }
       const bool last = b->processed < BATCH_LIMIT;
@@ -222,7 +239,8 @@ Status BaseEncoder::encode_cli(const std::string &output_type_str, bool stream, 
       cv.notify_all();
     }
   };
-  std::thread w1(worker), w2(worker);
+  // (four workers on an encoder of two lanes: the encode calls take turns, the formatting of their ids -- most of a worker's time -- runs beside them)
+  std::thread w1(worker), w2(worker), w3(worker), w4(worker);
 
   Status result;
   unsigned long long total_progress = 0, next_seq = 0;
@@ -260,6 +278,8 @@ Status BaseEncoder::encode_cli(const std::string &output_type_str, bool stream, 
   reader.join();
   w1.join();
   w2.join();
+  w3.join();
+  w4.join();
   if (result.ok()) fputc('\n', stderr);
   return result;
 }
