@@ -527,7 +527,7 @@ def _static_traffic(kern, corpus, size_mb, args, world):
                 return name
         return None
     # (the profiled command trains more than once per process -- the file step, the HBM-resident warm-up and step: the histogram is compacted
-    # once per training; K1 itself runs once per part of the text in a file step, gpu_ctx.cpp upload_fd_overlapped)
+    # once per training; K1 itself runs once per part of the text in a file step, gpu_ctx.cpp upload_overlapped)
     n_train = max(1, sum(pm[k]["launches"] for k in pm if k.startswith("k_hist_compact")))
     for name in ("char_hist", "segments", "dedup", "pair_count", "merge_apply", "cand_scan"):
         ks = [k for k in pm if family(k) == name]

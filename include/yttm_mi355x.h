@@ -37,7 +37,8 @@ int yttm_train_bpe_ex(const char *input_path, const char *model_path, int vocab_
  * (profile != 0 times every kernel with HIP events on the launch stream), and counters of the merge loop: "rounds",
  * "rules", "rounds_exhausted", "batch_extensions", "batch_splits" (word-mode batches of 129 .. 256 rules cut to their first
  * 128), "word_switch_round" / "word_rounds" / "word_fused_rounds" (rounds in K4's word mode; of those, one launch each) /
- * "word_all_rounds" (rounds that had to visit every word), "index_builds", "hot_rebuilds", "top_refills", "repacks". */
+ * "word_all_rounds" (rounds that had to visit every word), "index_builds", "hot_rebuilds", "top_refills", "repacks", "front_end_overlapped" (1: the char histogram, the segment
+ * starts and the word dedup ran on the parts of the text while the rest was still being uploaded, and that word table was taken). */
 int yttm_train_bpe_from_memory(const uint8_t *text, uint64_t n, const char *model_path, int vocab_size, double coverage,
                                int pad_id, int unk_id, int bos_id, int eos_id, int device, char *report_json,
                                int report_len, char *err, int errlen);

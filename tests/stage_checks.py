@@ -314,7 +314,7 @@ def train_file_report(text, vocab, tmp_path, coverage=1.0, tag="r"):
 
 
 def check_front_end_under_upload(tmp_path, rounds=10, seed=61):
-    """A text of some size is worked on in parts while it is still being uploaded (gpu_ctx.cpp upload_fd_overlapped): K1, K2a and a
+    """A text of some size is worked on in parts while it is still being uploaded (gpu_ctx.cpp upload_overlapped): K1, K2a and a
     dedup that compares words by code points; the word table is taken when the alphabet keeps every char (coverage 1) and made again the
     usual way when it does not.  Here every text, in parts of 4 KB with upload chunks of 4 KB: models against the oracle's, and the
     report says which way the word table came."""
@@ -342,6 +342,17 @@ def check_front_end_under_upload(tmp_path, rounds=10, seed=61):
             continue
         model, rep = train_file_report(text, vocab, tmp_path, cov, tag=f"fe{it}")
         assert filecmp.cmp(model, m_ora, shallow=False), f"model differs (round {it}, coverage {cov})"
+        if it % 3 == 0:  # the same from host memory (yttm_train_bpe_from_memory): the upload is the same staged one
+            import ctypes as C
+            from youtokentome_amd import _lib
+            L = _lib.load()
+            m_mem = str(tmp_path / f"fe{it}.mem.model")
+            err, rp = C.create_string_buffer(_lib.ERRLEN), C.create_string_buffer(16384)
+            rc = L.yttm_train_bpe_from_memory(text, len(text), m_mem.encode(), vocab, cov, 0, 1, 2, 3, 0, rp, 16384, err, _lib.ERRLEN)
+            assert rc == 0, err.value
+            assert filecmp.cmp(m_mem, m_ora, shallow=False), f"model from memory differs (round {it}, coverage {cov})"
+            import json
+            assert json.loads(rp.value.decode())["front_end_overlapped"] == rep["front_end_overlapped"]
         took += rep["front_end_overlapped"]
         dropped += 1 - rep["front_end_overlapped"]
     assert took > 0 and dropped > 0, (took, dropped)

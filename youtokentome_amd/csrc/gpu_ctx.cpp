@@ -342,7 +342,7 @@ void GpuCtx::resolve_timers() {
 // ------------------------------------------------------------------------------------------------- corpus
 void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
   drop_spec();
-  if (n < (32u << 20) || getenv("YTTM_PLAIN_UPLOAD")) {  // small, or (tuning hook) the one-copy path for comparison
+  if ((n < (32u << 20) && !(getenv("YTTM_FE_OVERLAP_MIN") && overlap_front_end(n))) || getenv("YTTM_PLAIN_UPLOAD")) {  // small, or (tuning hook) the one-copy path for comparison
     HIP_CHECK(hipSetDevice(device_));
     tl_stream = st_;
     tl_device = device_;
@@ -355,10 +355,12 @@ void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
     corpus_bytes = n;
     return;
   }
-  upload_staged(n, [&](void *dst, unsigned long long off, size_t len) {
+  auto from_memory = [&](void *dst, unsigned long long off, size_t len) {
     memcpy(dst, host + off, len);
     return true;
-  });
+  };
+  if (overlap_front_end(n)) upload_overlapped(n, from_memory);
+  else upload_staged(n, from_memory);
 }
 // ---- staged upload: file (or host memory) -> pinned chunks -> HBM -----------------------------------------------------
 // fast_read_file_utf8 (bpe.cpp:67-84) reads the file into one std::string; here the bytes only pass through the host.
@@ -550,8 +552,9 @@ void GpuCtx::drop_spec() {
 // char of the text (coverage 1, the default): the ids are then an injective renaming of the chars.  So the text is worked on in parts as they
 // land -- the workers of staged_transfer report the chunks, a part is ready when every byte up to one scan chunk behind its end is there --
 // and build_word_table() takes the finished word table if the alphabet turns out to keep everything, else runs its own K2a / K2b as before.
+// (`fill` brings bytes [off, off + len) of the source -- a file's byte range, host memory -- into a pinned chunk.)
 // A part's last segment may run on into bytes that have not arrived: it is inserted with the next part that has a segment of its own.
-void GpuCtx::upload_fd_overlapped(int fd, unsigned long long lo, unsigned long long n) {
+void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(void *dst, unsigned long long off, size_t len)> &fill) {
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
@@ -561,16 +564,7 @@ void GpuCtx::upload_fd_overlapped(int fd, unsigned long long lo, unsigned long l
   d_text_ = d_text_owned_;
   n_text_ = n;
   corpus_bytes = n;
-  auto fill = [&](void *dst, unsigned long long off, size_t len) {
-    size_t got = 0;
-    while (got < len) {
-      const ssize_t r = pread(fd, (char *)dst + got, len - got, (off_t)(lo + off + got));
-      if (r <= 0) return false;
-      got += (size_t)r;
-    }
-    return true;
-  };
-  // K1's variant from four samples of the FILE (char_hist samples the text in HBM, which is not there yet)
+  // K1's variant from four samples of the SOURCE (char_hist samples the text in HBM, which is not there yet)
   bool wide_chars = false;
   if (n >= (1u << 16)) {
     unsigned int wide = 0;
@@ -737,10 +731,23 @@ void GpuCtx::upload_fd_overlapped(int fd, unsigned long long lo, unsigned long l
   if (!spec_.words_done && spec_.ht) DFREE(spec_.ht);
 }
 
+// (the front end under the upload: one GPU -- the shards of several are cut and counted together -- and a text worth the trouble)
+bool GpuCtx::overlap_front_end(unsigned long long n) const {
+  return !multi() && n >= (unsigned long long)env_uint("YTTM_FE_OVERLAP_MIN", 32u << 20) && !getenv("YTTM_FE_NO_OVERLAP");
+}
+
 void GpuCtx::upload_corpus_fd(int fd, unsigned long long lo, unsigned long long n) {
-  // (the front end under the upload: one GPU -- the shards of several are cut and counted together -- and a text worth the trouble)
-  if (!multi() && n >= (unsigned long long)env_uint("YTTM_FE_OVERLAP_MIN", 32u << 20) && !getenv("YTTM_FE_NO_OVERLAP")) {
-    upload_fd_overlapped(fd, lo, n);
+  auto from_file = [&](void *dst, unsigned long long off, size_t len) {
+    size_t got = 0;
+    while (got < len) {
+      const ssize_t r = pread(fd, (char *)dst + got, len - got, (off_t)(lo + off + got));
+      if (r <= 0) return false;
+      got += (size_t)r;
+    }
+    return true;
+  };
+  if (overlap_front_end(n)) {
+    upload_overlapped(n, from_file);
     return;
   }
   drop_spec();
@@ -826,7 +833,7 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
-  const bool have_k1 = spec_.hist_done && !multi();  // (upload_fd_overlapped ran K1 on the parts of the text as they arrived)
+  const bool have_k1 = spec_.hist_done && !multi();  // (upload_overlapped ran K1 on the parts of the text as they arrived)
   spec_.hist_done = false;
   if (!have_k1) {
   if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
@@ -916,7 +923,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
 
   const unsigned long long n_segs = n_segments;
   if (n_segs == 0 || n_text_ == 0) { drop_spec(); return; }
-  // The word table upload_fd_overlapped made under the upload is this text's iff words compared by code points are words compared by ids:
+  // The word table upload_overlapped made under the upload is this text's iff words compared by code points are words compared by ids:
   // every char that occurs (and is no space) has an id of its own.  And the table must not have overflowed or filled beyond what the sizing
   // below accepts.
   bool take_spec = spec_.words_done && spec_.n_segs == n_segs && !multi();

@@ -100,7 +100,7 @@ class GpuCtx {
   int last_top_bin() const { return (int)last_top_bin_; }  // no bin above this one is in use
   unsigned long long index_builds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0, word_fused_rounds = 0;  // K4 rounds whose worklist came from the pair index
   unsigned long long word_table_retries = 0;  // K2: the word table had to be redone with the worst-case size
-  bool front_end_overlapped = false;          // K1, K2a, K2b ran under the upload and the word table they made was taken (upload_fd_overlapped)
+  bool front_end_overlapped = false;          // K1, K2a, K2b ran under the upload and the word table they made was taken (upload_overlapped)
   unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0, delta_regrows = 0;
   unsigned long long tail_ticks[3] = {0, 0, 0}, tail_listed = 0;  // round_tail: fold / list scan / publish, in 10 ns ticks; entries it read
   unsigned long long fused_rounds = 0, fused_overflows = 0;  // rounds whose candidate scan ran in the apply kernel's tail; of those, with a hot-list overflow
@@ -193,7 +193,8 @@ class GpuCtx {
   } spec_;
   std::vector<uint32_t> seen_cps_;      // char_hist: the code points that occur
   void drop_spec();
-  void upload_fd_overlapped(int fd, unsigned long long lo, unsigned long long n);
+  bool overlap_front_end(unsigned long long n) const;
+  void upload_overlapped(unsigned long long n, const std::function<bool(void *dst, unsigned long long off, size_t len)> &fill);
   unsigned long long *d_counters_ = nullptr;  // small scratch of u64 counters
   // K2
   uint32_t *d_cpmap_ = nullptr;  // [N_CODEPOINTS]
