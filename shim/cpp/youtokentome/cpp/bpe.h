@@ -1,0 +1,2 @@
+#pragma once
+#include "../../vkcom_adapter.h"  // the reference's bpe.h, as an adapter over the C ABI of libyttm_mi355x.so

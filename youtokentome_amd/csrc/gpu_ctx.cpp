@@ -1164,6 +1164,16 @@ void GpuCtx::maybe_repack(int ci) {
   WordClass &c = cls_[ci];
   if (c.n_tiles < 2) return;
   if (ci == 0 && word_mode_) return;  // (the words live in fixed slots now)
+  if (rp_known_[ci]) {
+    // The look itself costs three launches, a copy and a stream synchronisation.  The class holds at least what the last look counted minus
+    // every merge site since (a site removes one token): the sites the mailbox has reported (a round or two old) plus the summed pair counts
+    // of the last rounds' batches, which bound what it may lack.  While that is more than half the nominal fill there is nothing to look at.
+    // (Round 5: in word mode the trigger's "tokens streamed last round" is small against the nominal size of ALL tiles, so a corpus with
+    // class-B tiles -- CJK-shaped text -- took this look, and its synchronisation, every second round: 75 .. 400 us of host time each.)
+    const unsigned long long gone = (sites_cum_ - rp_sites_at_[ci]) + rp_recent_[0] + rp_recent_[1] + rp_recent_[2];
+    if (rp_total_[ci] > gone && (rp_total_[ci] - gone) * 2 > (unsigned long long)c.n_tiles * c.nom) return;
+  }
+  repack_looks++;
   chain_event_ = nullptr;  // work between two timed intervals: they no longer share an event
   unsigned long long *off = dmalloc<unsigned long long>(c.n_tiles);
   unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(c.n_tiles));
@@ -1172,6 +1182,9 @@ void GpuCtx::maybe_repack(int ci) {
   HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 48, 8, hipMemcpyDeviceToHost, st_));
   sync();
   DFREE(scan_tmp);
+  rp_known_[ci] = true;
+  rp_total_[ci] = total;
+  rp_sites_at_[ci] = sites_cum_;
   if (total == 0 || total * 2 > (unsigned long long)c.n_tiles * c.nom) { DFREE(off); return; }
   const unsigned int n_new = (unsigned int)((total - 1) / c.nom) + 1;
   uint32_t *new_tok = dmalloc<uint32_t>((size_t)n_new * c.slot + 64);
@@ -1727,6 +1740,7 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
           kt.ms[KT_MERGE] += ms;
           if (word_mode_) { merge_ms_words += ms; merge_launches_words++; }
           dev_round_ms_.push_back((float)ms);
+          last_round_dev_ms = ms;
         }
         const unsigned long long *tmk = (const unsigned long long *)(h + 96);  // scan_top's marks (100 MHz wall clock)
         tail_ticks[0] += tmk[1] - tmk[0];
@@ -2196,6 +2210,13 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     split_sites = st[0];
     split_touched_words = st[4];
     split_touched_word_tokens = st[5];
+  }
+  {  // the sites this round may add to what the mailbox has reported so far (maybe_repack)
+    unsigned long long s3 = 0;
+    for (uint32_t j = 0; j < k; j++) s3 += rule_counts ? rule_counts[j] : (~0ull >> 8);
+    rp_recent_[2] = rp_recent_[1];
+    rp_recent_[1] = rp_recent_[0];
+    rp_recent_[0] = std::min<unsigned long long>(s3, ~0ull >> 4);
   }
   pending_zero_ = !sa.on || multi();  // (a fused round zeroes its batch's pairs itself; multi-GPU: exchange_round hands the batch to the fold's scan)
   zero_valid_ = true;

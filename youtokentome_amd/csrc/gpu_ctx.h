@@ -117,7 +117,7 @@ class GpuCtx {
   unsigned long long n_keys_host = 0;
   bool profile = false;
   KernelTimes kt;
-  unsigned long long merge_sites = 0, merge_rounds = 0, repacks = 0;
+  unsigned long long merge_sites = 0, merge_rounds = 0, repacks = 0, repack_looks = 0;  // (looks: scans of a class's tile fills, each with a stream synchronisation)
   // K4 totals over the training: tiles that held a site and their tokens; with `instrument` (a measurement pass, never the
   // timed one) also the WORDS that held a site and their tokens = W_touched / T_touched of SURVEY.md 8d
   unsigned long long touched_tiles = 0, touched_tile_tokens = 0, touched_words = 0, touched_word_tokens = 0;
@@ -125,6 +125,7 @@ class GpuCtx {
   // measurement pass: the totals above as they stood after this many rounds (bench: the round the timed run switched to word mode at, so
   // that the contract's bytes can be stated for the tile rounds and the word-mode rounds apart); 0: no snapshot
   unsigned long long split_round = 0, split_touched_words = 0, split_touched_word_tokens = 0, split_sites = 0;
+  double last_round_dev_ms = 0;            // the last fused round on the device clock (0: that round was not timed so)
   double merge_ms_words = 0;               // device-clock time of the word-mode rounds (part of kt.ms[KT_MERGE])
   unsigned long long merge_launches_words = 0;
   void resolve_timers();
@@ -257,6 +258,9 @@ class GpuCtx {
   void enter_word_mode(uint32_t z_next);
   void free_words();
   unsigned long long rounds_since_check_ = 0;
+  // maybe_repack: live tokens of the class at its last look, the merge sites reported by then, the last three batches' summed pair counts
+  bool rp_known_[2] = {false, false};
+  unsigned long long rp_total_[2] = {0, 0}, rp_sites_at_[2] = {0, 0}, rp_recent_[3] = {0, 0, 0};
   bool pending_zero_ = false, zero_valid_ = false;  // valid: the zero_* members still describe the last batch
   void flush_pending_zero();
   unsigned int zero_cap_ = 0;

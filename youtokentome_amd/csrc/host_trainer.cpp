@@ -153,13 +153,18 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   double w_cand = 0, w_pick = 0, w_apply = 0, w_pick_a = 0, w_pick_b = 0;  // (YTTM_TRACE: pick = threshold + heap build | pops)
   const bool trace_pick = getenv("YTTM_TRACE") != nullptr;
   unsigned long long n_cand_sum = 0;
+  struct RoundLine { float wait_us, pick_us, apply_us, dev_us; uint32_t k; };  // (YTTM_TRACE: where a round's wall time goes, by ranges of rounds)
+  std::vector<RoundLine> round_lines;
   std::vector<uint8_t> in_batch((size_t)vocab_size + 1, 0);  // bit0: token is the x of a batch rule, bit1: the y
   while (used_ids < (uint64_t)vocab_size) {
     // Candidate set = every pair with count > tau, or count == tau and max(x,y) <= tau_mx: a complete prefix of the
     // global order, so the batch built from it is exact.  The threshold only trades list length against early batch ends.
     auto tw0 = clk::now();
+    g.last_round_dev_ms = 0;
     uint32_t n = g.candidates(tau, tau_mx, recs, nullptr);
-    w_cand += since(tw0);
+    const double w_wait_this = since(tw0);
+    w_cand += w_wait_this;
+    const double dev_ms_this = g.last_round_dev_ms;
     if (n && n <= recs.size()) {
       // The fused scan may have raised the threshold (ScanArgs::want): what came back is every pair at or above the smallest count listed --
       // a complete prefix of the order all the same -- and that count is the threshold the rest of this round reasons with.
@@ -286,6 +291,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     auto tw2 = clk::now();
     g.merge_apply(batch_xyz.data(), k, batch_cnt.data(), &tau_hint, MX_ALL, refine_on ? (uint32_t)TARGET : 0u);  // (the next scan's threshold rides along)
     w_apply += since(tw2);
+    if (trace_pick) round_lines.push_back(RoundLine{(float)(w_wait_this * 1e6), (float)(std::chrono::duration<double>(tw2 - tw1).count() * 1e6), (float)(since(tw2) * 1e6), (float)(dev_ms_this * 1e3), k});
     for (uint32_t j = 0; j < k; j++) rules.push_back(BPE_Rule{batch_xyz[3 * j], batch_xyz[3 * j + 1], batch_xyz[3 * j + 2]});
     used_ids += k;
     rounds++;
@@ -303,9 +309,21 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       fprintf(stderr, "[yttm] fused rounds %llu: tail set-up %.2f us, top-list scan %.2f us (%.0f entries), publish %.2f us per round\n", g.fused_rounds,
               g.tail_ticks[0] * 0.01 / g.fused_rounds, g.tail_ticks[1] * 0.01 / g.fused_rounds, (double)g.tail_listed / g.fused_rounds,
               g.tail_ticks[2] * 0.01 / g.fused_rounds);
+    if (trace_pick && !round_lines.empty()) {
+      // line i: the wait for round i-1's mailbox (its device time is beside it), then round i's pick and launch
+      const size_t cuts[] = {0, 11, 28, 46, 100, 200, 300, 450, 700, 1500, 3000, 1u << 30};
+      for (size_t c = 0; c + 1 < sizeof cuts / sizeof cuts[0] && cuts[c] < round_lines.size(); c++) {
+        const size_t a = cuts[c], b = std::min(cuts[c + 1], round_lines.size());
+        double w = 0, p = 0, ap = 0, d = 0, kk = 0, apmax = 0;
+        for (size_t i = a; i < b; i++) { w += round_lines[i].wait_us; p += round_lines[i].pick_us; ap += round_lines[i].apply_us; d += round_lines[i].dev_us; kk += round_lines[i].k; apmax = std::max<double>(apmax, round_lines[i].apply_us); }
+        const double m = (double)(b - a);
+        fprintf(stderr, "[yttm] rounds %zu-%zu: per round %.1f us = wait for the mailbox %.1f (device %.1f) + pick %.1f + merge_apply call %.1f (max %.0f); batch %.1f rules\n", a + 1, b,
+                (w + p + ap) / m, w / m, d / m, p / m, ap / m, apmax, kk / m);
+      }
+    }
     if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] host pick: threshold %.1f ms, heap build %.1f ms of the %.1f; %.0f candidates per round\n", w_pick_a * 1e3, w_pick_b * 1e3, w_pick * 1e3, (double)n_cand_sum / (double)std::max<unsigned long long>(rounds, 1));
-    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu, hot rebuilds %llu, top refills %llu, index builds %llu (%llu rounds in word mode from round %llu on, %llu of them over every word), pair table %llu keys in %llu slots (%llu rehashes)\n",
-                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.hot_rebuilds, g.top_refills, g.index_builds, g.word_rounds, g.word_switch_round, g.word_all_rounds, g.n_keys_host, g.table_capacity(), g.rehashes);
+    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu (%llu looks), hot rebuilds %llu, top refills %llu, index builds %llu (%llu rounds in word mode from round %llu on, %llu of them over every word), pair table %llu keys in %llu slots (%llu rehashes)\n",
+                                       w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.repack_looks, g.hot_rebuilds, g.top_refills, g.index_builds, g.word_rounds, g.word_switch_round, g.word_all_rounds, g.n_keys_host, g.table_capacity(), g.rehashes);
   }
   if (rep) {
     rep->rounds = rounds;
