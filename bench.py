@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size-mb", type=int, default=1000, help="corpus MB (1000 = BASELINE configs[1])")
     ap.add_argument("--vocab", type=int, default=32000)
-    ap.add_argument("--corpus", default="abcd", choices=["abcd", "zipf"])
+    ap.add_argument("--corpus", default="abcd", choices=["abcd", "zipf", "cjk"])  # (zipf / cjk as the main workload: tools/profile_round.sh variants)
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N>1: shard ONE pinned corpus (strong) or one corpus per GPU (weak)")
     ap.add_argument("--encode-sentences", type=int, default=10_000_000)
     ap.add_argument("--no-encode", action="store_true")
@@ -174,6 +174,11 @@ def main():
         out["config"]["parallelism"] = "one process per GPU; the corpus cut into %d byte ranges at white space; every rank keeps the whole pair table; per round ONE collective: an RCCL all-gather of per-pair delta blocks" % world
     model_path = main_res["model_path"]
     host = main_res.pop("host", None)
+    if main_res.get("first_call_s") is not None and not ctx.get("_first_call_done"):
+        # what `value` leaves out: the FIRST call of the process -- code objects loaded, ~6 GB of hipMalloc for the pool, the upload
+        # workers' pinned chunks and streams created; every later call reuses them.  (HIP itself was initialised by torch before.)
+        out.setdefault("e2e", {})["train_first_call"] = {"seconds": round(main_res["first_call_s"], 4), "steady_state_seconds": round(main_res["ms_per_step"] / 1e3, 4),
+                                                          "what": "the first yttm_train_bpe_comm(path -> model) of this process on the same file (an untimed warm-up step): cold device-memory pool, pinned chunks, streams, code objects"}
 
     # ---- encode: configs[3] (and [4]: dropout) with the model just trained --------------------------------------------------
     if not args.no_encode:
@@ -196,6 +201,19 @@ def main():
                                  "kernels": z["kernels"], "phases_s": z["phases_s"]}}
         out["parity"]["zipf_corpus_md5_matches"] = z["corpus_ok"]
         out["parity"]["zipf_model_matches_reference"] = z["model_ok"]
+        if comm_handle is not None:
+            # configs[2] AS WORDED ("8x sharded with RCCL pair-count all-reduce"): the library's own choice for this corpus -- 2.8e6 dedup tokens --
+            # is the replicated merge loop (no collective per round; `extra.zipf` above).  The sharded loop is forced here
+            # (YTTM_REPLICATE_MAX_TOKENS=0, read when the context is made) so that both are measured side by side.
+            os.environ["YTTM_REPLICATE_MAX_TOKENS"] = "0"
+            try:
+                zs = _bench_train(ctx, "zipf", args.size_mb, args.steps, args.warmup, measure_touched=False, keep_host=False)
+            finally:
+                del os.environ["YTTM_REPLICATE_MAX_TOKENS"]
+            out["extra"]["zipf_sharded"] = {"metric": "bpe_train_throughput", "value": zs["value"], "unit": "MB/s", "ms_per_step": zs["ms_per_step"], "config": zs["config"],
+                                            "us_per_round": round(zs["ms_per_step"] * 1e3 / max(1, zs["config"]["merge_rounds"]), 2), "kernels": zs["kernels"],
+                                            "phases_s": zs["phases_s"]}
+            out["parity"]["zipf_sharded_model_matches_reference"] = zs["model_ok"]
         if world == 1 and not args.no_encode and zhost is not None:
             # natural-language-like sentences: the corpus' own lines (16 Zipf words each) through K5 with the model just trained
             out["extra"]["zipf"]["encode"] = _bench_encode_lines(ctx, z["model_path"], zhost)
@@ -318,8 +336,12 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
 
     timed_step = file_step if corpus_path else train_step  # (--scaling weak: every rank has its own corpus, there is no one file)
     with ctx["quiet"]:
-        for _ in range(warmup):
+        first_call_s = None
+        for i in range(warmup):
+            t_first = time.perf_counter()
             timed_step(0)
+            if i == 0:
+                first_call_s = time.perf_counter() - t_first
         ctx["barrier"]()
         t0 = time.perf_counter()
         reports = [timed_step(1) for _ in range(steps)]
@@ -432,7 +454,8 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
            "corpus_bytes_total": total_bytes, "corpus_bytes_this_gpu": n_local, "vocab_size": args.vocab, "unique_words": r["n_unique"],
            "dedup_tokens": r["n_tokens"], "merge_rounds": r["rounds"], "rules": r["rules"],
            "rounds_closed_exhausted": r.get("rounds_exhausted"), "word_mode_from_round": r.get("word_switch_round") or None, "word_mode_rounds": r.get("word_rounds"), "word_mode_one_launch_rounds": r.get("word_fused_rounds"),
-           "index_builds": r.get("index_builds"),
+           "index_builds": r.get("index_builds"), "batch_splits": r.get("batch_splits"), "batch_extensions": r.get("batch_extensions"),
+           "hot_rebuilds": r.get("hot_rebuilds"), "top_refills": r.get("top_refills"), "repacks": r.get("repacks"),
            "input": ("file in the page cache -> yttm_train_bpe_comm(path, model): open + pread into pinned chunks + H2D + train + model file closed (SURVEY.md 8d); "
                      "the HBM-resident figure is `value_hbm_resident`") if corpus_path else "resident in HBM before the timed region (--scaling weak: one corpus per rank, no single file)",
            "front_end_under_the_upload": bool(r.get("front_end_overlapped")),  # (K1, K2a, K2b ran on the parts of the file as they landed: their time is in phases_s.upload)
@@ -440,6 +463,10 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
     if ctx["comm"] is not None:
         cfg["multi_gpu_mode"] = ("replicated merge loop: shards gathered once after the local dedup, every rank runs the merge loop alone, no per-round collective"
                                  if r.get("replicated_merge_loop") else "sharded merge loop: every rank applies the batch to its words, per-pair count deltas all-gathered every round")
+        cfg["rccl_ranks"] = world
+        cfg["exchange_repeats"] = r.get("exchange_retries")
+        xk = kern.get("exchange")
+        cfg["exchange_us_per_round"] = round(xk["ms_total"] * 1e3 / max(1, xk["launches"]), 2) if xk else None  # (all-gather + fold + the round's scan, device clock)
         k4_ms = kern.get("merge_apply", {}).get("ms_total", 0.0)
         if dist is not None:
             t = torch.zeros(world, dtype=torch.float64, device=dev)
@@ -450,7 +477,7 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
             cfg["merge_apply_ms_per_rank"] = [k4_ms]
     res = {"value": round(value, 2), "ms_per_step": round(dt / steps * 1e3, 2), "config": cfg, "roofline": roofline, "roofline_pair_count": roofline_pc,
            "kernels": kern, "phases_s": {"upload": r.get("seconds_upload", 0.0), "frontend": r["seconds_frontend"], "merge_loop": r["seconds_merge"], "dump": r["seconds_io"]},
-           "corpus_ok": corpus_ok, "model_ok": model_ok, "model_path": model_path, "pin": pin, "hbm_resident": hbm}
+           "corpus_ok": corpus_ok, "model_ok": model_ok, "model_path": model_path, "pin": pin, "hbm_resident": hbm, "first_call_s": first_call_s}
     if keep_host:
         res["host"] = host
     del d_corpus
@@ -506,15 +533,20 @@ def _static_traffic(kern, corpus, size_mb, args, world):
     """HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, separate --pmc
     runs of this same command; tools/pmc_summary.py).  STATIC: read from profiles/, not measured by this run."""
     traffic = {}
-    for name in ("r4_1gb_pmc_hbm.json", "r3_1gb_pmc_hbm.json", "r2_1gb_pmc_hbm.json", "r1_1gb_final_pmc_hbm.json"):
-        pmc_file = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(pmc_file):
-            break
-    else:
+    tag = {"abcd": "1gb", "zipf": "zipf", "cjk": "cjk"}.get(corpus)
+    pmc_file = os.path.join(ROOT, "profiles", "r5_%s_pmc_hbm.json" % tag) if tag else None
+    if not pmc_file or not os.path.exists(pmc_file):
         return traffic, None
-    if not (size_mb == 1000 and corpus == "abcd" and args.vocab == 32000 and world == 1):
+    if not (size_mb == 1000 and args.vocab == 32000 and world == 1):
         return traffic, None
     pm = json.load(open(pmc_file))
+    # A profile is quoted only for the build it was taken of (VERDICT r4: the r4 file predated three commits of the head it was quoted at).
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_summary import source_sha16
+    have, want = (pm.get("_meta") or {}).get("source_sha16"), source_sha16(ROOT)
+    if have != want:
+        return traffic, "none: profiles/%s was taken of sources %s, this build is %s -- re-run tools/profile_round.sh" % (os.path.basename(pmc_file), have, want)
+    pm = {k: v for k, v in pm.items() if not k.startswith("_")}
 
     def family(k):  # k_tiles<SLOT, WPB, MERGE, LDSR>: MERGE=false is K3 (pair count), true is K4 (merge apply)
         if k.startswith("k_tiles<"):
@@ -835,11 +867,11 @@ def _cpu_baseline(ctx, host, zhost, model_path, out):
         except Exception as e:  # noqa: BLE001
             res.setdefault("zipf", {})["encode"] = {"error": str(e)}
         os.remove(lines)
-    res["python_boundary"] = _python_boundary(ctx, pre, cores, model_path, enc_host, zhost, out)
+    res["python_boundary"] = _python_boundary(ctx, pre, cores, model_path, enc_host, zhost, out, host)
     return res
 
 
-def _python_boundary(ctx, pre, cores, model_path, enc_host, zhost, out):
+def _python_boundary(ctx, pre, cores, model_path, enc_host, zhost, out, host=None):
     """The reference's OWN Python boundary and command line on this box (its Cython module, compiled from the unmodified sources by
     oracle/Makefile into oracle/_ref/pyref, travels with the tree): youtokentome.BPE.encode(list[str]) (yttm.pyx:87-109) and
     `yttm encode` stdin -> stdout (bpe.cpp:1942-2014, what benchmark.md's "Tokenization" times), beside the drop-in's through shim/."""
@@ -876,6 +908,34 @@ def _python_boundary(ctx, pre, cores, model_path, enc_host, zhost, out):
             res["encode_list_drop_in_over_reference"] = round(a["value"] / b["value"], 2)
             res["encode_list_ids_equal"] = a["ids"] == b["ids"]
         os.remove(lines)
+    if host is not None and ctx["args"].size_mb == 1000 and ctx["args"].corpus == "abcd":
+        # Whole-process training time, what the reference publishes (tests/speed_test/speed_test.py:71-83, benchmark.md): `yttm bpe` from
+        # process start to exit -- interpreter, imports, HIP initialisation, the cold first call and the model file included -- on the 1 GB
+        # corpus of configs[1] (in the page cache), the reference's own CLI beside it (n_threads default: 8 for training, bpe.cpp:1348).
+        cin = os.path.join(tmpdir, "cli_train.txt")
+        with open(cin, "wb") as f:
+            f.write(host)
+        cli = {}
+        for which in ("drop_in", "reference"):
+            cmodel = os.path.join(tmpdir, "cli_train_%s.model" % which)
+            code = "import sys; from youtokentome.yttm_cli import main; sys.argv = ['yttm', 'bpe', '--data', %r, '--model', %r, '--vocab_size', '%d']; main()" % (cin, cmodel, ctx["args"].vocab)
+            try:
+                t0 = time.perf_counter()
+                r = subprocess.run((pre if which == "reference" else []) + [sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env_for(which))
+                dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    raise RuntimeError(r.stderr.decode()[-300:])
+                cli[which] = {"seconds": round(dt, 3), "MBps": round(len(host) / 1e6 / dt, 1),
+                              "what": "`yttm bpe --data <1 GB file> --model m --vocab_size %d`, process start to exit%s" % (ctx["args"].vocab, ", taskset -c 0-7" if (pre and which == "reference") else "")}
+                if which == "drop_in" and ctx["pins"].get("c2_1gb"):
+                    cli[which]["model_matches_reference"] = md5_file(cmodel) == ctx["pins"]["c2_1gb"]["model_md5"]
+                    out["parity"]["cli_train_model_matches_reference"] = cli[which]["model_matches_reference"]
+            except Exception as e:  # noqa: BLE001
+                cli[which] = {"error": str(e)}
+        if cli.get("drop_in", {}).get("seconds") and cli.get("reference", {}).get("seconds"):
+            cli["drop_in_over_reference"] = round(cli["reference"]["seconds"] / cli["drop_in"]["seconds"], 1)
+        out.setdefault("e2e", {})["cli_train"] = cli
+        os.remove(cin)
     if zhost is not None and out.get("extra", {}).get("zipf"):
         # N1: `yttm encode` on the Zipf corpus' lines, stdin -> stdout (a file; /dev/null would hide the writer)
         zin = os.path.join(tmpdir, "cli_in.txt")

@@ -24,6 +24,11 @@ const char *yttm_gpu_last_error(void);
  * counterpart: bpe.cpp allocates with new/std containers.) */
 void yttm_release_device_memory(void);
 
+/* Every YTTM_* environment hook of the library -- test and tuning knobs, none part of the drop-in surface -- as Markdown table rows
+ * "| `NAME` | default | kind | what it does |" (csrc/yttm_config.h holds the one table; INTEGRATION.md prints it).  The hooks are read when a
+ * trainer context or an encoder is created, never per round or per launch.  (No reference counterpart.) */
+const char *yttm_config_table(void);
+
 /* multi-GPU: attach a communicator (yttm_comm* from include/yttm_mi355x.h, passed as void*) before the stages run;
  * the context then holds ITS shard and the pair table holds GLOBAL counts */
 int yttm_gpu_ctx_set_comm(yttm_ctx *ctx, void *comm);

@@ -52,3 +52,37 @@ def test_python_list_boundary_extension_is_built():
         subprocess.run(["make", "-C", os.path.join(ROOT, "youtokentome_amd", "csrc"), "pyapi", "PYTHON=" + sys.executable], check=True, capture_output=True)
     from youtokentome_amd import bpe
     assert bpe._pyapi is not None and hasattr(bpe._pyapi, "encode_ids")
+
+
+def test_environment_hooks_are_one_table():
+    """Every YTTM_* hook of the library lives in csrc/yttm_config.h: no other getenv in the sources, and INTEGRATION.md prints the table."""
+    src = os.path.join(ROOT, "youtokentome_amd", "csrc")
+    offenders = []
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".cpp", ".hip", ".h", ".c")) and f != "yttm_config.cpp":
+            for i, line in enumerate(open(os.path.join(src, f), errors="replace"), 1):
+                if re.search(r"\bgetenv\s*\(", line) and not line.lstrip().startswith("//"):
+                    offenders.append("%s:%d" % (f, i))
+    assert not offenders, offenders
+    if not os.path.exists(LIB):
+        subprocess.run(["make", "-C", src, "-j8"], check=True, capture_output=True)
+    lib = ctypes.CDLL(LIB)
+    lib.yttm_config_table.restype = ctypes.c_char_p
+    table = lib.yttm_config_table().decode()
+    rows = [r for r in table.splitlines() if r.startswith("| `YTTM_")]
+    assert len(rows) >= 70
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [r for r in rows if r not in doc]
+    assert not missing, missing[:3]
+    # every YTTM_ name a test or a tool sets must be a row (or one of the few variables read outside the library)
+    known = set(re.findall(r"`(YTTM_[A-Z0-9_]+)`", table)) | {"YTTM_AMD_LIB", "YTTM_BENCH_FORCE_COMM", "YTTM_FULL_PINS", "YTTM_RUN_REFSUITE_ON_SIM", "YTTM_K4_PROF"}
+    used = set()
+    for d in ("tests", "tools", "."):
+        for base, _, files in os.walk(os.path.join(ROOT, d)):
+            if "_ref" in base or "gpurun_out" in base or ".git" in base or (d == "." and base != ROOT):
+                continue
+            for f in files:
+                if f.endswith((".py", ".sh")):
+                    used |= set(re.findall(r"\b(YTTM_[A-Z0-9_]+)\b", open(os.path.join(base, f), errors="replace").read()))
+    unknown = sorted(n for n in used - known if not n.startswith(("YTTM_TEST_EXPECT", "YTTM_TEST_FREE_BYTES_RANK")))
+    assert not unknown, unknown

@@ -383,6 +383,50 @@ def test_zz_c3_100mb_zipf_model_pin(tmp_path):
     assert hashlib.md5(open(model, "rb").read()).hexdigest() == pin["model_md5"]
 
 
+@pytest.mark.skipif(not os.environ.get("YTTM_FULL_PINS"), reason="the full-size pins (1 GB corpus, 10 M sentences; about a minute of corpus generation): YTTM_FULL_PINS=1 -- bench.py asserts the same pins on every run")
+def test_zz_full_size_pins(tmp_path):
+    """BASELINE.json configs[1] and configs[3] at FULL size, in the test-suite (they lived only in bench.py): the 1 GB `abcd `
+    corpus (md5 63857720...) -> vocab 32000 -> the model the unmodified reference writes (md5 73e74d66..., tests/golden/full_size_pins.json
+    c2_1gb), through the file path (front end under the upload) AND from memory; then all 10 M sentences of C4 encoded with that model:
+    FNV-1a-64 of every (length, ids) against the reference's encode_as_ids (pin c4_10m)."""
+    import ctypes as C
+    import hashlib
+    import numpy as np
+    import youtokentome_amd as yttm
+    from youtokentome_amd import _lib
+    pins = _full_pins()
+    pin = pins["c2_1gb"]
+    text = gen.abcd_corpus(pin["corpus_bytes"] + 1, seed=19, survey_stream=True)
+    assert len(text) == pin["corpus_bytes"] and hashlib.md5(text).hexdigest() == pin["corpus_md5"]
+    corpus, model = str(tmp_path / "c2.txt"), str(tmp_path / "c2.model")
+    open(corpus, "wb").write(text)
+    yttm.BPE.train(corpus, model, pin["vocab_size"])
+    assert hashlib.md5(open(model, "rb").read()).hexdigest() == pin["model_md5"]
+    L = _lib.load()
+    err, model2 = C.create_string_buffer(_lib.ERRLEN), str(tmp_path / "c2m.model")
+    buf = (C.c_uint8 * len(text)).from_buffer_copy(text)
+    assert L.yttm_train_bpe_from_memory(buf, len(text), model2.encode(), pin["vocab_size"], 1.0, 0, 1, 2, 3, 0, None, 0, err, _lib.ERRLEN) == 0, err.value
+    assert hashlib.md5(open(model2, "rb").read()).hexdigest() == pin["model_md5"]
+    del buf, text
+    os.remove(corpus)
+    p4 = pins["c4_10m"]
+    line, n = 128, p4["n_sentences"]
+    sents = gen.abcd_corpus(n * (line + 1), seed=123, line=line, survey_stream=True)
+    assert hashlib.md5(sents).hexdigest() == p4["input_md5"]
+    off_in = (np.arange(n + 1, dtype=np.uint64) * np.uint64(line + 1))
+    h = C.c_void_p()
+    assert L.yttm_encoder_create(model.encode(), 1, 0, C.byref(h), err, _lib.ERRLEN) == 0, err.value
+    ids, off = _lib.i32p(), _lib.u64p()
+    sb = (C.c_uint8 * len(sents)).from_buffer_copy(sents)
+    # (sentence i = bytes [off[i], off[i+1]): the newline rides at the end of each, white space like any other)
+    assert L.yttm_encode_as_ids(h, C.cast(sb, C.c_char_p), off_in.ctypes.data_as(_lib.u64p), n, 0, 0, 0, 0.0, C.byref(ids), C.byref(off), err, _lib.ERRLEN) == 0, err.value
+    assert int(off[n]) == p4["n_ids"]
+    assert "%016x" % L.yttm_ids_fnv1a64(ids, off, n) == p4["fnv1a64"]
+    L.yttm_free(ids)
+    L.yttm_free(off)
+    L.yttm_encoder_destroy(h)
+
+
 def test_zz_rccl_world_of_one(tmp_path):
     """The RCCL transport of the multi-GPU path on the one GPU there is: a communicator of size 1 still runs every collective
     of a round (ncclAllReduce of the char histogram and of the hot-list verdict, the grouped send/recv all-gather after K3,

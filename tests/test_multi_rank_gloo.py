@@ -54,6 +54,28 @@ def test_two_ranks_equal_single_oracle(tmp_path, sim_lib, world):
         assert filecmp.cmp(m_mp, m_ora, shallow=False), f"case {i}"
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_front_end_under_the_upload_on_every_rank(tmp_path, sim_lib, world):
+    """Round 5: K1, K2a and the dedup run under the upload on EVERY rank of a multi-GPU run (each on its own byte range; the char histogram's
+    all-reduce and the pair exchange come behind, as before) -- forced onto toy shards with parts and I/O chunks of a few KB.  With coverage 1
+    every rank takes the word table it made that way (the report says so); with coverage < 1 the common alphabet drops chars and every rank
+    redoes its dedup by ids -- same model either way, sharded and replicated."""
+    rng = random.Random(40 + world)
+    env = {"YTTM_FE_OVERLAP_MIN": "0", "YTTM_FE_PART_KB": "4", "YTTM_IO_CHUNK_KB": "4"}
+    cases = [(gen.readme_corpus(400, 90, "abcdef ", seed=8), 260, 1.0, "front_end_overlapped==1"),
+             (gen.unicode_text(rng, 9000, "mix", p_invalid=0.01), 120, 1.0, "front_end_overlapped==1"),
+             (gen.unicode_text(rng, 9000, "mix", p_invalid=0.01), 100, 0.85, "front_end_overlapped==0")]
+    for i, (text, vocab, cov, expect) in enumerate(cases):
+        corpus = str(tmp_path / f"c{i}.txt")
+        open(corpus, "wb").write(text)
+        m_ora = str(tmp_path / f"ora{i}.model")
+        O.train(text, m_ora, vocab, cov)
+        for sharded in (True, False):
+            m_mp = str(tmp_path / f"mp{i}_{int(sharded)}.model")
+            run_world(corpus, m_mp, vocab, cov, world, sim_lib, dict(env, YTTM_TEST_EXPECT=expect if sharded else ""), sharded=sharded)
+            assert filecmp.cmp(m_mp, m_ora, shallow=False), f"case {i} sharded={sharded}"
+
+
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_replicated_merge_loop_equals_single_oracle(tmp_path, sim_lib, world):
     """Small word tables (the library's own choice below 2^26 dedup tokens): the ranks dedup their shards, gather the shards into the
@@ -117,14 +139,14 @@ def test_word_mode_switch_is_one_decision(tmp_path, sim_lib, world):
     words (many class-A tiles, many merge sites), the last one a handful of words repeated (one tile) or nothing but white space.  With
     thresholds between the two (YTTM_WORD_MIN_TILES) a rank-local rule would switch the big ranks and not the small one; the decision is
     taken from the sums over the ranks' block headers instead, the same on every rank in the same round: every rank with words reports
-    word-mode rounds, the model is the oracle's.  Also with the per-round pack as a kernel of its own (YTTM_XCHG_TAIL_PACK=0)."""
+    word-mode rounds, the model is the oracle's."""
     rng = random.Random(300 + world)
     big = b" ".join("".join(rng.choice("abcdefgh") for _ in range(rng.randint(2, 14))).encode() for _ in range(9000)) + b"\n"
     few = (b"abab cdcd abcd " * (len(big) // (15 * (world - 1)))) + b"\n"
     blank = b" \n" * (len(big) // (2 * (world - 1)))
     hooks = {"YTTM_WORD_MIN_TILES": "6", "YTTM_WORD_MIN_TOKENS": "0", "YTTM_WORD_DIV": "0", "YTTM_HOT_TARGET": "24", "YTTM_HOT_MIN": "6",
              "YTTM_HOT_TARGET_WORDS": "96", "YTTM_WORDS_GRID": "3", "YTTM_WGATHER_GRID": "2"}
-    for i, (tail, extra, expect) in enumerate(((few, {}, "word_rounds>0"), (few, {"YTTM_XCHG_TAIL_PACK": "0"}, "word_rounds>0"), (blank, {}, ""))):
+    for i, (tail, extra, expect) in enumerate(((few, {}, "word_rounds>0"), (blank, {}, ""))):
         text = big * (world - 1) + tail  # rank world-1 gets (nearly) only the tail
         corpus = str(tmp_path / f"c{i}.txt")
         open(corpus, "wb").write(text)

@@ -10,7 +10,7 @@ text = gen.abcd_corpus(mb * 1_000_000, seed=21) if kind == "abcd" else gen.zipf_
 open("/tmp/fc.txt", "wb").write(text)
 code = "import sys; sys.path.insert(0,%r); import youtokentome_amd as y; y.BPE.train('/tmp/fc.txt', sys.argv[1], %d)" % (R, vocab)
 out = {}
-for tag, env in (("nofuse", {"YTTM_NO_FUSE": "1"}), ("fuse1", {}), ("fuse2", {"YTTM_TAIL_NOCOMPACT": "1"})):
+for tag, env in (("nofuse", {"YTTM_NO_FUSE": "1"}), ("fuse1", {}), ("fuse2", {})):
     m = "/tmp/fc_%s.model" % tag
     subprocess.run([sys.executable, "-c", code, m], env=dict(os.environ, YTTM_DBG_CAND="/tmp/fc_%s.cand" % tag, **env), capture_output=True)
     out[tag] = open(m).read().split("\n")

@@ -15,6 +15,23 @@ import sys
 from collections import defaultdict
 
 
+def source_sha16(root=None):
+    """Hash of the product's sources (youtokentome_amd/csrc, include/): what a profile under profiles/ is a profile OF.  The GPU box has
+    no .git, so this -- not a commit id -- is what pmc() records and what bench.py compares before it quotes a file's traffic."""
+    import hashlib
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    files = []
+    for d in ("youtokentome_amd/csrc", "include"):
+        for f in sorted(os.listdir(os.path.join(root, d))):
+            if f.endswith((".hip", ".h", ".cpp", ".c")) or f == "Makefile":
+                files.append(os.path.join(d, f))
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def short(name):
     n = name.split("(")[0]
     return n.replace("void ", "").replace("yttm::", "")
@@ -51,6 +68,7 @@ def pmc(fetch_dir, write_dir, out):
                    "hbm_read_bytes_per_launch_raw": round(rd / n), "hbm_read_bytes_per_launch_x2": round(2 * rd / n),
                    "hbm_write_bytes_per_launch": round(wr / n),
                    "traffic_bytes_per_launch": round((2 * rd + wr) / n)}
+    outd["_meta"] = {"source_sha16": source_sha16(), "what": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; source_sha16 = tools/pmc_summary.py source_sha16() of the build profiled"}
     json.dump(outd, open(out, "w"), indent=1, sort_keys=True)
 
 

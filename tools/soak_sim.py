@@ -70,7 +70,7 @@ while time.time() - t0 < budget:
             text = gen.zipf_corpus(rng.randint(60000, 400000), vocab=rng.randint(500, 20000), seed=rng.randint(0, 10 ** 6))
         vocab = rng.randint(200, 3000)
         for k in ("YTTM_K4_DIRECT", "YTTM_NO_FUSE", "YTTM_HOT_TARGET", "YTTM_HOT_MIN", "YTTM_HOT_CAP", "YTTM_TOP_TARGET", "YTTM_TOP_MIN", "YTTM_TOP_CAP",
-                  "YTTM_INDEX_MIN_TILES", "YTTM_WORD_TABLE_FULL"):
+                  "YTTM_WORD_TABLE_FULL"):
             os.environ.pop(k, None)
         hooks = rng.choice([{}, {"YTTM_K4_DIRECT": "0"}, {"YTTM_NO_FUSE": "1"},
                             {"YTTM_HOT_TARGET": "8", "YTTM_HOT_MIN": "3", "YTTM_HOT_CAP": "32"}, {"YTTM_TOP_TARGET": "4", "YTTM_TOP_MIN": "2", "YTTM_TOP_CAP": "16"},

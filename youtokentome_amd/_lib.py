@@ -25,7 +25,7 @@ EXPORTS = [
     "yttm_device_info", "yttm_comm_rccl_unique_id", "yttm_comm_rccl_create", "yttm_comm_callback_create",
     "yttm_comm_destroy", "yttm_train_bpe_comm", "yttm_train_bpe_from_device_comm", "yttm_train_bpe_from_memory_comm",
     # include/yttm_gpu.h
-    "yttm_gpu_ctx_create", "yttm_gpu_ctx_destroy", "yttm_gpu_ctx_set_comm", "yttm_gpu_last_error", "yttm_release_device_memory",
+    "yttm_gpu_ctx_create", "yttm_gpu_ctx_destroy", "yttm_gpu_ctx_set_comm", "yttm_gpu_last_error", "yttm_release_device_memory", "yttm_config_table",
     "yttm_gpu_upload_corpus",
     "yttm_gpu_attach_corpus", "yttm_gpu_char_hist", "yttm_gpu_build_word_table", "yttm_gpu_download_word_table",
     "yttm_gpu_pair_count", "yttm_gpu_download_pairs", "yttm_gpu_merge_apply", "yttm_gpu_pair_query",

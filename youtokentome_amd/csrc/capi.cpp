@@ -355,5 +355,6 @@ int yttm_gpu_k4_measure(yttm_ctx *c, int on, uint64_t out[6]) {
 }
 
 void yttm_release_device_memory(void) { yttm::release_device_memory(); }
+const char *yttm_config_table(void) { return yttm::config_table_markdown(); }
 
 }  // extern "C"

@@ -51,7 +51,7 @@ thread_local hipStream_t tl_stream = nullptr;
 thread_local int tl_device = 0;
 constexpr size_t POOL_MAX_CACHED = 96ull << 30;  // (a third of the HBM: the segment starts of 4.4e9 one-letter words alone are 35 GB)
 bool pool_enabled() {
-  static const bool on = !(getenv("YTTM_NO_POOL") && *getenv("YTTM_NO_POOL") == '1');
+  static const bool on = !(cfg()->no_pool.set && cfg()->no_pool.raw.c_str()[0] == '1');  // (one verdict per process: blocks cached under one policy are not freed under the other)
   return on;
 }
 void *pool_alloc(size_t bytes) {
@@ -143,17 +143,17 @@ static T *dmalloc(size_t n) {
 
 constexpr unsigned int CAND_CAP = 1u << 20;
 constexpr unsigned int HOT_CAP = 1u << 18;  // hot-list slots (entries appended between rebuilds included)
-constexpr unsigned int TOP_CAP = 1u << 15;  // top-list slots
 // a rebuild picks the threshold that lists about HOT_TARGET pairs; fewer live entries than HOT_MIN: lower the threshold.
 // YTTM_HOT_TARGET / YTTM_HOT_MIN / YTTM_HOT_CAP override them (the test-suite shrinks them to exercise rebuilds on tiny corpora).
-static unsigned int env_uint(const char *name, unsigned int dflt) {
-  const char *v = getenv(name);
-  return v && *v ? (unsigned int)strtoul(v, nullptr, 10) : dflt;
-}
+constexpr unsigned int TOP_CAP = 1u << 15;  // top-list slots
 constexpr unsigned int RULES_CAP = 1u << 14;  // hash slots for the per-round rule table (batch <= RULES_CAP/2)
 constexpr size_t PIN_BYTES = (size_t)CAND_CAP * sizeof(CandRec) + (size_t)RULES_CAP * sizeof(RuleSlot) + (1u << 20);
 
 GpuCtx::GpuCtx(int device) : device_(device) {
+  cfg_refresh();  // the environment hooks are read here, once per context (yttm_config.h); nothing below this constructor calls getenv
+  cfg_ = cfg();
+  const Config &C = *cfg_;
+  xchg_margin_ = C.xchg_margin.d;
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
@@ -175,37 +175,37 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   // one block for everything the host reads back per round, so that it is ONE device-to-host copy:
   // [0] n_cand, [4] n_keys | [64..) count histogram | [8192..) candidates
   d_round_ = dmalloc<unsigned char>(8192 + (size_t)CAND_CAP * sizeof(CandRec));
-  hot_cap_ = std::min(env_uint("YTTM_HOT_CAP", HOT_CAP), HOT_CAP);
-  hot_target_ = env_uint("YTTM_HOT_TARGET", 1u << 13);  // measured at 1 GB: 4096..16384 equal on the abcd corpus, 8192 best on Zipf text (4279 rounds)
-  hot_min_ = env_uint("YTTM_HOT_MIN", 512);
-  fuse_enabled_ = env_uint("YTTM_NO_FUSE", 0) == 0;
-  idx_enabled_ = env_uint("YTTM_NO_INDEX", 0) == 0;  // (no pair index: no word mode either)
-  idx_agg_min_ = env_uint("YTTM_INDEX_AGG_MIN", 16u << 20);  // (fill pass of an index build: postings from which on a workgroup sums them per key in LDS first; tests: 0)
-  hot_target_words_ = env_uint("YTTM_HOT_TARGET_WORDS", 1u << 16);  // (measured at 1 GB, word mode: 8192 -> 6 rebuilds, candidate family 21.0 ms; 32768 -> 3, 16.9 ms; round 4: 32768 -> 3, 14.6 ms; 65536 -> 2, 12.5; 131072 -> 2, 15.0)
+  hot_cap_ = std::min((unsigned int)C.hot_cap.u, HOT_CAP);
+  hot_target_ = (unsigned int)C.hot_target.u;  // measured at 1 GB: 4096..16384 equal on the abcd corpus, 8192 best on Zipf text (4279 rounds)
+  hot_min_ = (unsigned int)C.hot_min.u;
+  fuse_enabled_ = C.no_fuse.u == 0;
+  idx_enabled_ = C.no_index.u == 0;  // (no pair index: no word mode either)
+  idx_agg_min_ = C.index_agg_min.u;  // (fill pass of an index build: postings from which on a workgroup sums them per key in LDS first; tests: 0)
+  hot_target_words_ = (unsigned int)C.hot_target_words.u;  // (measured at 1 GB, word mode: 8192 -> 6 rebuilds, candidate family 21.0 ms; 32768 -> 3, 16.9 ms; round 4: 32768 -> 3, 14.6 ms; 65536 -> 2, 12.5; 131072 -> 2, 15.0)
   // rounds of at most this many words (by the hint) whose batch travels in the kernel arguments are ONE launch, k_words<FUSED>; 0: never.
   // (1 GB random text, wall / K4 ms: never 138.3 / 86.0, 32 k 136.6 / 83.3, 256 k 133.1 / 80.2, 2 M 125.9 / 73.5, every round 125.0 / 72.5)
-  words_fuse_max_ = env_uint("YTTM_WORDS_FUSE_MAX", 1u << 30);
-  word_hint_floor_ = env_uint("YTTM_WORD_HINT_FLOOR", 16384);  // (the words a round is sized for beyond twice the last round's sites; 1 GB random text, K4 ms on the device clock: 1024 -> 73.6, 4096 -> 72.7, 16384 -> 72.1)
-  words_inline_max_ = env_uint("YTTM_WORDS_INLINE_MAX", 1u << 18);  // (measured at 1 GB, K4 ms: 16 k -> 97.2, 64 k -> 95.4, 256 k -> 94.1)
-  profile_events_ = env_uint("YTTM_PROFILE_EVENTS", 0) != 0;
-  words_enabled_ = env_uint("YTTM_WORD_MODE", 1) != 0;   // (0: tiles to the end)
-  direct_enabled_ = env_uint("YTTM_K4_DIRECT", 1) != 0;  // (0: the pair filter + rule hash from the first round on; A/B runs)
-  word_div_ = env_uint("YTTM_WORD_DIV", 200);  // (measured at 1 GB: 96 -> K4 135 ms, 150 -> 107, 200 -> 103.7, 300 -> 103.7, 500 -> 104; round 4, merge loop ms of random 'abcd ': 80 / 100 -> 98.7 (switch at
+  words_fuse_max_ = (unsigned int)C.words_fuse_max.u;
+  word_hint_floor_ = (unsigned int)C.word_hint_floor.u;  // (the words a round is sized for beyond twice the last round's sites; 1 GB random text, K4 ms on the device clock: 1024 -> 73.6, 4096 -> 72.7, 16384 -> 72.1)
+  words_inline_max_ = (unsigned int)C.words_inline_max.u;  // (measured at 1 GB, K4 ms: 16 k -> 97.2, 64 k -> 95.4, 256 k -> 94.1)
+  profile_events_ = C.profile_events.u != 0;
+  words_enabled_ = C.word_mode.u != 0;   // (0: tiles to the end)
+  direct_enabled_ = C.k4_direct.u != 0;  // (0: the pair filter + rule hash from the first round on; A/B runs)
+  word_div_ = (unsigned int)C.word_div.u;  // (measured at 1 GB: 96 -> K4 135 ms, 150 -> 107, 200 -> 103.7, 300 -> 103.7, 500 -> 104; round 4, merge loop ms of random 'abcd ': 80 / 100 -> 98.7 (switch at
                                                // round 13), 120 -> 96.0 (round 20), 150 -> 96.4, 200 -> 99.4 (round 29), 400 -> 101.6 -- but the CJK-shaped corpus: 120 -> 485 ms, 200 -> 472: left at 200)
-  word_min_tiles_ = env_uint("YTTM_WORD_MIN_TILES", 16384);  // (tests: 0 = switch as soon as the hot list is active)
+  word_min_tiles_ = (unsigned int)C.word_min_tiles.u;  // (tests: 0 = switch as soon as the hot list is active)
   // a pass over the tiles must cost more than word mode's three launches: 1 GB enwik-like text (25 M tokens, 48 us per dense round) got 15 % slower
   // in word mode, the 1 GB CJK-shaped corpus (337 M tokens) 21 % faster, random 'abcd ' (94 M tokens at the switch) 10 % faster
-  word_min_tokens_ = (unsigned long long)env_uint("YTTM_WORD_MIN_TOKENS", 48u << 20);
-  no_batch_args_ = getenv("YTTM_NO_BATCH_ARGS") != nullptr;  // (read once per context: a round has no time for getenv)
+  word_min_tokens_ = C.word_min_tokens.u;
+  no_batch_args_ = C.no_batch_args.set;
   launch_env_refresh();
-  trace_rounds_ = getenv("YTTM_TRACE_ROUNDS");
-  dbg_cand_ = getenv("YTTM_DBG_CAND");
+  trace_rounds_ = C.trace_rounds.c_str();  // (points into cfg_, which this context keeps)
+  dbg_cand_ = C.dbg_cand.c_str();
   d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);
   d_hot_n_ = dmalloc<unsigned int>(4);  // [0] list length, [1] k_hot_scan's finished-workgroup ticket, [2..3] overflow verdict (u64)
   HIP_CHECK(hipMemsetAsync(d_hot_n_, 0, 16, st_));
-  top_cap_ = std::max(16u, std::min(env_uint("YTTM_TOP_CAP", 1u << 13), TOP_CAP));
-  top_target_ = env_uint("YTTM_TOP_TARGET", 1024);  // about four times what the host looks at per round
-  top_min_ = env_uint("YTTM_TOP_MIN", 192);
+  top_cap_ = std::max(16u, std::min((unsigned int)C.top_cap.u, TOP_CAP));
+  top_target_ = (unsigned int)C.top_target.u;  // about four times what the host looks at per round
+  top_min_ = (unsigned int)C.top_min.u;
   d_top_slots_ = dmalloc<uint32_t>(TOP_CAP);
   d_top_n_ = dmalloc<unsigned int>(4);
   HIP_CHECK(hipMemsetAsync(d_top_n_, 0, 16, st_));
@@ -261,6 +261,10 @@ GpuCtx::~GpuCtx() {
 }
 
 void GpuCtx::sync() { HIP_CHECK(hipStreamSynchronize(st_)); }
+void GpuCtx::read_stats(int first, int n, unsigned long long *out) {
+  HIP_CHECK(hipMemcpyAsync(out, d_stats_ + first, (size_t)n * 8, hipMemcpyDeviceToHost, st_));
+  sync();
+}
 
 // Kernel-family timers (profile mode): HIP events on the context's stream.  Events come from a process-wide pool, and an
 // interval that starts where the previous one ended shares that event (t_end(..., chain=true) followed by t_begin): a
@@ -320,7 +324,7 @@ void GpuCtx::resolve_timers() {
       touched_word_tokens = st[5];
     }
   }
-  FILE *trace = getenv("YTTM_TRACE") ? fopen(getenv("YTTM_TRACE"), "w") : nullptr;  // per-launch times for tuning
+  FILE *trace = cfg_->trace.set ? fopen(cfg_->trace.raw.c_str(), "w") : nullptr;  // per-launch times for tuning
   for (auto &e : evs_) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) kt.ms[e.which] += ms;
@@ -342,7 +346,7 @@ void GpuCtx::resolve_timers() {
 // ------------------------------------------------------------------------------------------------- corpus
 void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
   drop_spec();
-  if ((n < (32u << 20) && !(getenv("YTTM_FE_OVERLAP_MIN") && overlap_front_end(n))) || getenv("YTTM_PLAIN_UPLOAD")) {  // small, or (tuning hook) the one-copy path for comparison
+  if ((n < (32u << 20) && !(cfg_->fe_overlap_min.set && overlap_front_end(n))) || cfg_->plain_upload.set) {  // small, or (tuning hook) the one-copy path for comparison
     HIP_CHECK(hipSetDevice(device_));
     tl_stream = st_;
     tl_device = device_;
@@ -423,9 +427,10 @@ void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *
 // the bytes -- several workers at once, which also spreads the page faults of a freshly allocated destination).  Returns when every byte
 // has arrived.  Throws GpuError.
 size_t staged_chunk_bytes() {
-  const size_t mb = std::min<size_t>(std::max<size_t>(env_uint("YTTM_IO_CHUNK_MB", 8), 1), IO_CHUNK_MAX >> 20);
+  const std::shared_ptr<const Config> C = cfg();
+  const size_t mb = std::min<size_t>(std::max<size_t>((size_t)C->io_chunk_mb.u, 1), IO_CHUNK_MAX >> 20);
   size_t c = mb << 20;
-  if (const size_t kb = env_uint("YTTM_IO_CHUNK_KB", 0)) c = std::min<size_t>(kb << 10, IO_CHUNK_MAX);  // (tests: many chunks of a small batch)
+  if (const size_t kb = (size_t)C->io_chunk_kb.u) c = std::min<size_t>(kb << 10, IO_CHUNK_MAX);  // (tests: many chunks of a small batch)
   return c;
 }
 void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_device,
@@ -434,9 +439,10 @@ void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_d
   if (!n) return;
   HIP_CHECK(hipSetDevice(device));
   IoStage &g_io = g_io_dir[to_device ? 0 : 1];
-  const size_t IO_CHUNK = chunk_bytes && !getenv("YTTM_IO_CHUNK_MB") && !getenv("YTTM_IO_CHUNK_KB") ? std::min(chunk_bytes, IO_CHUNK_MAX) : staged_chunk_bytes();
+  const std::shared_ptr<const Config> C = cfg();
+  const size_t IO_CHUNK = chunk_bytes && !C->io_chunk_mb.set && !C->io_chunk_kb.set ? std::min(chunk_bytes, IO_CHUNK_MAX) : staged_chunk_bytes();
   const size_t n_chunks = (size_t)((n + IO_CHUNK - 1) / IO_CHUNK);
-  int n_threads = (int)env_uint("YTTM_IO_THREADS", 0);
+  int n_threads = (int)C->io_threads.u;
   // (default 4: one thread preads 40 GB/s out of the page cache on the MI355X box, the link takes 55; eight workers measured SLOWER than three
   // or four -- 34 - 42 ms per GB against 24 -- sixteen much slower: they queue up in the runtime)
   if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 4u));
@@ -577,7 +583,7 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
   } else {
     wide_chars = true;
   }
-  if (const char *e = getenv("YTTM_K1_WIDE")) wide_chars = atoi(e) != 0;
+  if (cfg_->k1_wide.set) wide_chars = cfg_->k1_wide.i != 0;
   if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
   HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
   HIP_CHECK(hipMemsetAsync(d_counters_, 0, 64 * 8, st_));
@@ -636,10 +642,10 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
   };
   // ---- the parts
   const unsigned long long FC = fe_chunk_bytes();
-  unsigned long long part = (unsigned long long)env_uint("YTTM_FE_PART_KB", 32u << 10) << 10;  // (32 MB: the last part is 0.8 ms of work behind the last byte; tests: a few KB)
+  unsigned long long part = cfg_->fe_part_kb.u << 10;  // (32 MB: the last part is 0.8 ms of work behind the last byte; tests: a few KB)
   part = std::max(FC, part / FC * FC);
-  bool spec_on = !getenv("YTTM_FE_NO_SPEC");
-  const unsigned int k2b_blocks = env_uint("YTTM_FE_K2B_BLOCKS", 4096);  // (tuning hook)
+  bool spec_on = !cfg_->fe_no_spec.set;
+  const unsigned int k2b_blocks = (unsigned int)cfg_->fe_k2b_blocks.u;  // (tuning hook)
   unsigned long long *d_seg = nullptr, seg_cap = 0, base = 0;
   unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
   unsigned long long pending = 0;  // the last segment so far: not inserted yet
@@ -668,7 +674,7 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
         d_seg = dmalloc<unsigned long long>(seg_cap);
         spec_.long_segments = n_p == 0 || (b1 - b0) / std::max<unsigned long long>(n_p, 1) >= 16;
         const unsigned long long ns = (unsigned long long)est;
-        spec_.ht_cap = !spec_.long_segments && !getenv("YTTM_WORD_TABLE_FULL") ? pow2_at_least(std::max<unsigned long long>(ns / 4, 1ull << 16))
+        spec_.ht_cap = !spec_.long_segments && !cfg_->word_table_full.set ? pow2_at_least(std::max<unsigned long long>(ns / 4, 1ull << 16))
                                                                                 : pow2_at_least(ns + ns / 2 + 1024);
         spec_.ht = dmalloc<unsigned long long>(3 * spec_.ht_cap);
         launch_word_table_clear(spec_.ht, spec_.ht_cap, st_);
@@ -722,7 +728,7 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
     drop_spec();
     throw GpuError{fail};
   }
-  if (getenv("YTTM_TRACE"))
+  if (cfg_->trace.set)
     fprintf(stderr, "[yttm] front end under the upload: the last byte landed after %.2f ms, the last part was done after %.2f ms (%llu segments, parts of %llu MB, word table %s)\n",
             ms_link, ms_now(), base, part >> 20, spec_on && spec_.ht ? "made" : "left to build_word_table");
   spec_.hist_done = true;
@@ -731,9 +737,12 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
   if (!spec_.words_done && spec_.ht) DFREE(spec_.ht);
 }
 
-// (the front end under the upload: one GPU -- the shards of several are cut and counted together -- and a text worth the trouble)
+// (the front end under the upload: a text worth the trouble.  Round 5: on every rank of a multi-GPU run too -- K1, K2a and K2b of a rank's byte
+// range need nothing from the other ranks; what the ranks exchange -- the char histogram, then the pair counts -- comes after, as before.  The
+// rank's word table is taken if the COMMON alphabet keeps every char of the whole text, a sufficient condition that every rank evaluates
+// alike; a rank that cannot take it redoes its own dedup, no collective depends on it.)
 bool GpuCtx::overlap_front_end(unsigned long long n) const {
-  return !multi() && n >= (unsigned long long)env_uint("YTTM_FE_OVERLAP_MIN", 32u << 20) && !getenv("YTTM_FE_NO_OVERLAP");
+  return n >= cfg_->fe_overlap_min.u && !cfg_->fe_no_overlap.set;
 }
 
 void GpuCtx::upload_corpus_fd(int fd, unsigned long long lo, unsigned long long n) {
@@ -773,7 +782,7 @@ unsigned long long GpuCtx::allreduce_scalar(unsigned long long v) {
   return out;
 }
 unsigned long long GpuCtx::free_device_bytes() const {
-  if (const char *e = getenv("YTTM_TEST_FREE_BYTES")) return strtoull(e, nullptr, 10);
+  if (cfg_->test_free_bytes.set) return cfg_->test_free_bytes.u;
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
   std::lock_guard<std::mutex> g(g_pool.mu);
@@ -833,7 +842,7 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
-  const bool have_k1 = spec_.hist_done && !multi();  // (upload_overlapped ran K1 on the parts of the text as they arrived)
+  const bool have_k1 = spec_.hist_done;  // (upload_overlapped ran K1 on the parts of the text as they arrived; multi-GPU: of this rank's shard -- the sum over the ranks follows below)
   spec_.hist_done = false;
   if (!have_k1) {
   if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
@@ -853,7 +862,7 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
   } else {
     wide_chars = true;  // (small inputs: tests of both variants run on them through YTTM_K1_WIDE)
   }
-  if (const char *e = getenv("YTTM_K1_WIDE")) wide_chars = atoi(e) != 0;
+  if (cfg_->k1_wide.set) wide_chars = cfg_->k1_wide.i != 0;
   t_begin(KT_CHAR_HIST);
   DFREE(d_chunk_segs_);
   d_chunk_segs_ = dmalloc<uint32_t>(fe_chunks(n_text_) + 1);
@@ -926,7 +935,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   // The word table upload_overlapped made under the upload is this text's iff words compared by code points are words compared by ids:
   // every char that occurs (and is no space) has an id of its own.  And the table must not have overflowed or filled beyond what the sizing
   // below accepts.
-  bool take_spec = spec_.words_done && spec_.n_segs == n_segs && !multi();
+  bool take_spec = spec_.words_done && spec_.n_segs == n_segs;  // (multi-GPU: seen_cps_ is the chars of ALL shards -- a superset of this one's)
   if (take_spec) {
     std::vector<uint32_t> kept(cp, cp + n_alpha);
     std::sort(kept.begin(), kept.end());
@@ -972,7 +981,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
     // (long segments -- CJK-shaped text: clauses of dozens of chars between white space -- are nearly all distinct: the estimate is bound to
     // fail there and the whole dedup would run twice; K1 knows the average segment length)
     const bool long_segments = n_text_ / n_segs >= 16;
-    ht_cap = attempt == 0 && !long_segments && !getenv("YTTM_WORD_TABLE_FULL") ? pow2_at_least(std::max<unsigned long long>(n_segs / 4, 1ull << 16))
+    ht_cap = attempt == 0 && !long_segments && !cfg_->word_table_full.set ? pow2_at_least(std::max<unsigned long long>(n_segs / 4, 1ull << 16))
                                                                                  : pow2_at_least(n_segs + n_segs / 2 + 1024);
     ht = dmalloc<unsigned long long>(3 * ht_cap);  // keys, counts, positions of the short words' representatives (k_frontend.hip: WH_SHORT)
     launch_word_table_clear(ht, ht_cap, st_);
@@ -1014,7 +1023,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   unsigned int *d_cursor = (unsigned int *)(d_counters_ + 32);
   HIP_CHECK(hipMemsetAsync(d_cursor, 0, 16, st_));
   unsigned long long *d_heavy = dmalloc<unsigned long long>(3 * HEAVY_CAP);
-  const unsigned long long wmax = getenv("YTTM_TEST_WCNT_MAX") ? strtoull(getenv("YTTM_TEST_WCNT_MAX"), nullptr, 10) : 0xffffffffull;  // (tests: heavy words at toy sizes)
+  const unsigned long long wmax = cfg_->test_wcnt_max.u;  // (tests: heavy words at toy sizes)
   t_begin(KT_BUILD);
   launch_compact_words(d_text_, n_text_, d_cpmap_, ht, ht_cap, posA, cls_[0].d_wcnt, lenA, posB, cls_[1].d_wcnt, lenB, posC, cls_[2].d_wcnt, lenC, d_cursor,
                        d_status, wmax, d_heavy, st_);
@@ -1363,18 +1372,18 @@ void GpuCtx::pair_count() {
       while (cap < n_tokens0 / 2 && cap < (1ull << 27)) cap <<= 1;
       // (... and never less than twice the distinct pairs K3 itself can produce on this rank: a large alphabet on a small corpus)
       while (cap < 2 * initial_table_keys(n_tokens0) && cap < (1ull << 28)) cap <<= 1;
-      if (const unsigned int forced = env_uint("YTTM_XCHG_TABLE_CAP", 0)) {  // (tests: a table that overflows)
+      if (const unsigned int forced = (unsigned int)cfg_->xchg_table_cap.u) {  // (tests: a table that overflows)
         cap = pow2_at_least(std::max(forced, 4u));
         delta_cap_forced_ = true;
       }
       alloc_delta_table(cap);
       d_xstat_ = dmalloc<unsigned long long>(XSTAT_WORDS);
       HIP_CHECK(hipMemsetAsync(d_xstat_, 0, XSTAT_WORDS * 8, st_));
-      maybe_cap_ = std::max(1u, env_uint("YTTM_XCHG_NOTES", 1u << 16));  // (tests shrink it: the fold then walks every record)
+      maybe_cap_ = std::max(1u, (unsigned int)cfg_->xchg_notes.u);  // (tests shrink it: the fold then walks every record)
       d_maybe_ = dmalloc<uint32_t>(maybe_cap_);
       d_maybe_n_ = dmalloc<unsigned int>(4);
       HIP_CHECK(hipMemsetAsync(d_maybe_n_, 0, 16, st_));
-      blk_min_ = std::max(2u * XHDR, env_uint("YTTM_XCHG_BLK_MIN", 4096));  // (tests shrink it to force the repeat path)
+      blk_min_ = std::max(2u * XHDR, (unsigned int)cfg_->xchg_blk_min.u);  // (tests shrink it to force the repeat path)
       blk_ = blk_min_;
       grow_recv(std::max<unsigned long long>(send_cap_, blk_ * (unsigned long long)comm_->world));
     }
@@ -1834,7 +1843,7 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
   d_gm_ = dmalloc<unsigned int>(WGATHER_MAXK + 4);
   HIP_CHECK(hipMemsetAsync(d_gm_, 0, (WGATHER_MAXK + 4) * 4, st_));
   d_xyz_ = dmalloc<uint32_t>(3 * (size_t)RULES_CAP);
-  drec_cap_ = env_uint("YTTM_WORD_DREC", 1u << 15);  // (tests: a region that overflows)
+  drec_cap_ = (unsigned int)cfg_->word_drec.u;  // (tests: a region that overflows)
   d_drec_ = dmalloc<DeltaRec>((size_t)WORDS_MAX_GRID * drec_cap_);
   d_drec_n_ = dmalloc<unsigned int>(WORDS_MAX_GRID);
   d_irec_ = dmalloc<uint4>((size_t)WORDS_MAX_GRID * drec_cap_);
@@ -1849,7 +1858,7 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
   // every record ever matched is a site at most once through each of its two neighbours, and a site removes a token: a few records per
   // live token bound the log between two index builds; should it fill up all the same, the round says so and the index is rebuilt
   const unsigned long long live = std::max<unsigned long long>(live_tokens_last_, 1ull << 16);
-  const unsigned long long log_env = getenv("YTTM_WORD_LOG") ? strtoull(getenv("YTTM_WORD_LOG"), nullptr, 10) : 0;  // (tests: a log that overflows)
+  const unsigned long long log_env = cfg_->word_log.u;  // (tests: a log that overflows)
   tl_.log_cap = log_env ? log_env : 2 * live + (1ull << 20);
   tl_.rec_word = dmalloc<uint32_t>(tl_.log_cap);
   tl_.rec_l = dmalloc<uint32_t>(tl_.log_cap);
@@ -1862,7 +1871,7 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
   word_switch_round = merge_rounds;
   idx_valid_ = false;
   idx_pending_ = true;
-  if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] word mode from round %llu on: %llu words, last round %llu sites, %llu tokens streamed; log %llu records\n", merge_rounds,
+  if (cfg_->trace.set) fprintf(stderr, "[yttm] word mode from round %llu on: %llu words, last round %llu sites, %llu tokens streamed; log %llu records\n", merge_rounds,
                                   c.n_unique, sites_last_, live_tokens_last_, tl_.log_cap);
   build_index(z_next);
 }
@@ -1914,7 +1923,7 @@ void GpuCtx::build_index(uint32_t z_next) {
   HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 56, 8, hipMemcpyDeviceToHost, st_));
   sync();
   index_builds++;
-  if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] index build at round %llu: %u listed pairs, %llu postings, %u tiles, last round touched %llu tiles\n", merge_rounds, listed, total, c.n_tiles, touched_last_);
+  if (cfg_->trace.set) fprintf(stderr, "[yttm] index build at round %llu: %u listed pairs, %llu postings, %u tiles, last round touched %llu tiles\n", merge_rounds, listed, total, c.n_tiles, touched_last_);
   if (total == 0 || total > 0xfffffff0ull) {  // (no postings, or more than the 32-bit run offsets hold: the rounds take every word)
     t_end(KT_CAND, 4ull * c.n_tiles * c.nom);
     return;
@@ -2083,7 +2092,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       bound += std::min<unsigned long long>(rule_counts ? 5 * rule_counts[j] : ~0ull >> 8, 4ull * (vmax + 1) + 4);
     }
     xch_sites_ = sites;
-    static const double margin = getenv("YTTM_XCHG_MARGIN") ? atof(getenv("YTTM_XCHG_MARGIN")) : 3.0;  // (tests: a margin below one forces the repeat path)
+    const double margin = xchg_margin_;  // (YTTM_XCHG_MARGIN; tests: a margin below one forces the repeat path)
     const double pred = rule_counts ? std::max(xrate_[0], xrate_[1]) * (double)sites * margin : (double)bound;
     unsigned long long need = (unsigned long long)std::min((double)std::min<unsigned long long>(bound, send_cap_), pred) + XHDR;
     unsigned long long b2 = blk_min_;
@@ -2185,16 +2194,16 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     launch_fold_stats(d_stats_, pt_.n_keys, st_);
     HIP_CHECK(hipMemcpyAsync(stt, d_stats_, sizeof stt, hipMemcpyDeviceToHost, st_));
     sync();
-    if (getenv("YTTM_TRACE_BLOCKS") && merge_rounds % 50 == 0) {  // PROF build: per-workgroup start / end / dirty tiles of this round
+    if (cfg_->trace_blocks.set && merge_rounds % 50 == 0) {  // PROF build: per-workgroup start / end / dirty tiles of this round
       std::vector<unsigned long long> rows(STATS_WORDS);
       HIP_CHECK(hipMemcpy(rows.data(), d_stats_, STATS_WORDS * 8, hipMemcpyDeviceToHost));
-      std::string name = std::string(getenv("YTTM_TRACE_BLOCKS")) + "." + std::to_string(merge_rounds);
+      std::string name = cfg_->trace_blocks.raw + "." + std::to_string(merge_rounds);
       if (FILE *fb = fopen(name.c_str(), "w")) {
         for (int b = 0; b < 1536; b++) fprintf(fb, "%d %llu %llu %llu\n", b, rows[32 + 8 * b + 5], rows[32 + 8 * b + 6], rows[32 + 8 * b + 7]);
         fclose(fb);
       }
     }
-    FILE *f = fopen(getenv("YTTM_TRACE_ROUNDS"), merge_rounds == 1 ? "w" : "a");
+    FILE *f = fopen(trace_rounds, merge_rounds == 1 ? "w" : "a");
     if (f) {
       fprintf(f, "%llu %u %llu %llu %llu %llu %u", merge_rounds, k, stt[0], stt[1], stt[2], stt[3], cls_[0].n_tiles);
       for (int i = 8; i < 24; i++) fprintf(f, " %llu", stt[i]);
@@ -2227,7 +2236,9 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // round's filters report the tokens they streamed); otherwise look every 8 rounds.
   if (hot_state_ == HOT_ACTIVE && live_tokens_last_) {
     const unsigned long long nominal = (unsigned long long)cls_[0].n_tiles * cls_[0].nom + (unsigned long long)cls_[1].n_tiles * cls_[1].nom;
-    if (live_tokens_last_ * 2 <= nominal && ++rounds_since_check_ >= 2) {
+    // (word mode: class A no longer lives in tiles, and "tokens streamed last round" is small against the nominal size of everything whatever
+    // the fill of class B: its looks are spaced out -- a late repack of the few long words costs less than a look every other round)
+    if (live_tokens_last_ * 2 <= nominal && ++rounds_since_check_ >= (word_mode_ ? 64u : 2u)) {
       rounds_since_check_ = 0;
       for (int ci = 0; ci < 2; ci++) maybe_repack(ci);
     }

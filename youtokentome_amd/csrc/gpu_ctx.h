@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "yttm_config.h"
 #include "yttm_kernels.h"
 
 namespace yttm {
@@ -110,6 +111,7 @@ class GpuCtx {
   void set_comm(Comm *c) { comm_ = c; }
   Comm *comm() const { return comm_; }
   int device() const { return device_; }
+  const Config &config() const { return *cfg_; }  // the YTTM_* hooks as they stood when this context was made (yttm_config.h)
   hipStream_t stream() const { return st_; }
 
   unsigned long long n_unique = 0, n_tokens0 = 0, n_segments = 0, corpus_bytes = 0;
@@ -129,6 +131,7 @@ class GpuCtx {
   double merge_ms_words = 0;               // device-clock time of the word-mode rounds (part of kt.ms[KT_MERGE])
   unsigned long long merge_launches_words = 0;
   void resolve_timers();
+  void read_stats(int first, int n, unsigned long long *out);  // (tuning aid: words of the device statistics block, synchronising)
 
  private:
   void upload_staged(unsigned long long n, const std::function<bool(void *dst, unsigned long long off, size_t len)> &fill);
@@ -171,6 +174,8 @@ class GpuCtx {
   void t_end(int which, unsigned long long bytes, bool chain = false);
 
   int device_;
+  std::shared_ptr<const Config> cfg_;
+  double xchg_margin_ = 3.0;
   hipStream_t st_ = nullptr;
   Comm *comm_ = nullptr;
 

@@ -26,6 +26,7 @@
 #include <thread>
 
 #include "host_core.h"
+#include "yttm_config.h"
 
 namespace yttm {
 
@@ -33,8 +34,7 @@ namespace {
 
 // bpe.cpp:1976 batch_limit.  YTTM_CLI_BATCH_BYTES (tuning / test hook) overrides it: batching never changes the output.
 unsigned long long batch_limit() {
-  const char *v = getenv("YTTM_CLI_BATCH_BYTES");
-  const unsigned long long n = v && *v ? strtoull(v, nullptr, 10) : 0;
+  const unsigned long long n = cfg()->cli_batch_bytes.u;  // (the snapshot the encoder's creation took)
   return n ? n : 10ull * 1024 * 1024;
 }
 

@@ -125,10 +125,12 @@ BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *
       l.d_total = dalloc<unsigned long long>(2);
       l.d_wc_misc = dalloc<unsigned int>(2);
     }
-    if (const char *cv = getenv("YTTM_ENCODE_CACHE")) dev_->cache_mode = atoi(cv) ? 1 : 0;
-    if (const char *cv = getenv("YTTM_ENCODE_CACHE_MIN_MB")) dev_->cache_min_bytes = strtoull(cv, nullptr, 10) << 20;
-    if (const char *sv = getenv("YTTM_DROPOUT_SEED")) {
-      dev_->seed_salt = strtoull(sv, nullptr, 10);
+    cfg_refresh();  // the environment hooks are read here, once per encoder (yttm_config.h)
+    const std::shared_ptr<const Config> C = cfg();
+    if (C->encode_cache.set) dev_->cache_mode = C->encode_cache.i ? 1 : 0;
+    if (C->encode_cache_min_mb.set) dev_->cache_min_bytes = C->encode_cache_min_mb.u << 20;
+    if (C->dropout_seed.set) {
+      dev_->seed_salt = C->dropout_seed.u;
     } else {
       std::random_device rd;
       dev_->seed_salt = ((unsigned long long)rd() << 32) ^ (unsigned long long)rd();
@@ -301,7 +303,11 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
   unsigned long long n_table = 0;
   unsigned int misc[2] = {0, 0};
   unsigned long long short_cap = 1ull << 20;  // slots the words of up to 7 bytes start in (k_wcache.hip wc_insert_word): 8 MB of keys
-  if (const char *e = getenv("YTTM_WC_SHORT_SLOTS")) short_cap = std::max<unsigned long long>(16, strtoull(e, nullptr, 10));  // (measurements, tests; a power of two)
+  if (cfg()->wc_short_slots.set) {  // (measurements, tests) -- rounded up to a power of two: the region's size is used as a mask
+    const unsigned long long want = std::max<unsigned long long>(16, cfg()->wc_short_slots.u);
+    short_cap = 16;
+    while (short_cap < want && short_cap < (1ull << 40)) short_cap <<= 1;
+  }
   for (;;) {
     d.grow(d.d_wc_slot, d.cap_wc_slot, (size_t)cap);
     d.grow(d.d_wc_pos, d.cap_wc_pos, (size_t)cap);
@@ -425,8 +431,8 @@ static Status encode_on_lane(const BaseEncoder &enc, EncoderDevice &D, EncodeLan
 // allocated result array is paid by one thread); small ones as plain copies on the lane's stream.
 constexpr size_t ENC_CHUNK = 2u << 20;  // (the encoder's arrays in chunks of 2 MB: 10^7 sentences host -> host 79 -> 75 ms against 8 MB, 64 against 70 in sub-batches)
 static size_t staged_from() {
-  const char *e = getenv("YTTM_ENC_STAGED_FROM");  // (tests: every copy through the chunks)
-  return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(16u << 20);
+  const std::shared_ptr<const Config> C = cfg();  // (tests: every copy through the chunks)
+  return C->enc_staged_from.set ? (size_t)C->enc_staged_from.u : (size_t)(16u << 20);
 }
 static void copy_up(int device, void *d_dst, const void *src, size_t n, hipStream_t st) {
   if (n >= staged_from() && n) {
@@ -504,7 +510,7 @@ static Status encode_host_to_host(const BaseEncoder &enc, EncoderDevice *dev, in
     return Status();
   }
   if (!dev) return Status(2, "encoder has no device state");
-  const bool trace = getenv("YTTM_TRACE") != nullptr;
+  const bool trace = cfg()->trace.set;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
   unsigned long long total_bytes = offsets[n_sent] - offsets[0], max_len = 0;
@@ -590,9 +596,10 @@ static bool encode_pipelined(const BaseEncoder &enc, EncoderDevice *dev, int dev
                              unsigned long long n_sent, bool bos, bool eos, bool reverse, double dropout_prob, int32_t **ids_out,
                              unsigned long long **off_out, Status *result) {
   const unsigned long long total_bytes = offsets[n_sent] - offsets[0];
-  unsigned long long sub_bytes = (unsigned long long)(getenv("YTTM_ENC_SUB_MB") ? std::max(1, atoi(getenv("YTTM_ENC_SUB_MB"))) : 320) << 20;
-  if (const char *e = getenv("YTTM_ENC_SUB_KB")) sub_bytes = (unsigned long long)std::max(1, atoi(e)) << 10;  // (tests)
-  const unsigned long long min_bytes = getenv("YTTM_ENC_PIPE_FROM") ? strtoull(getenv("YTTM_ENC_PIPE_FROM"), nullptr, 10) : (512ull << 20);
+  const std::shared_ptr<const Config> C = cfg();
+  unsigned long long sub_bytes = (unsigned long long)std::max<long long>(1, C->enc_sub_mb.i) << 20;
+  if (C->enc_sub_kb.set) sub_bytes = (unsigned long long)std::max<long long>(1, C->enc_sub_kb.i) << 10;  // (tests)
+  const unsigned long long min_bytes = C->enc_pipe_from.u;
   if (total_bytes < min_bytes || n_sent < 4) return false;
   // sub-batches of about sub_bytes each, cut at sentence starts
   std::vector<unsigned long long> cut{0};
@@ -713,7 +720,7 @@ static bool encode_pipelined(const BaseEncoder &enc, EncoderDevice *dev, int dev
     *result = st.ok() ? Status(2, error) : st;
     return true;
   }
-  if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] encode host -> host: %llu sentences in %zu sub-batches through both lanes\n", n_sent, K);
+  if (cfg()->trace.set) fprintf(stderr, "[yttm] encode host -> host: %llu sentences in %zu sub-batches through both lanes\n", n_sent, K);
   *ids_out = ids;
   *off_out = off;
   *result = Status();

@@ -59,6 +59,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
                  TrainReport *rep) {
   const auto t_all = clk::now();
   Comm *comm = g.comm();
+  const Config &C = g.config();  // (the YTTM_* hooks, read when the context was made)
   const bool root = !comm || comm->rank == 0;
   bool replicated = false;  // multi-GPU, small word tables: the merge loop runs on every rank alone (see below)
   // ---- K1 + alphabet (bpe.cpp:941-944, :1013-1021)
@@ -98,7 +99,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     // the whole text and runs the merge loop alone, with NO collective per round; rank 0 writes the model.  The choice is made from the
     // summed local token counts (an upper bound of the merged table), the same number on every rank.
     if (comm) {
-      static const unsigned long long rep_max = getenv("YTTM_REPLICATE_MAX_TOKENS") ? strtoull(getenv("YTTM_REPLICATE_MAX_TOKENS"), nullptr, 10) : (1ull << 26);
+      const unsigned long long rep_max = C.replicate_max_tokens.u;
       const unsigned long long t_sum = g.allreduce_scalar(g.n_tokens0);
       // ... and only if the whole corpus fits beside the shard on EVERY rank: the gather holds the shard, the padded blocks of all ranks and
       // the assembled text at once (about twice the whole corpus), the second dedup its segment starts and word table on top.  A large,
@@ -134,9 +135,9 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   rules.reserve((size_t)vocab_size);
   // Candidates asked for per scan: about four times the recent batch size -- what the host does not look at still travels
   // through the mailbox and the heap (natural text: batches of ~8 rules, random text: ~50).  YTTM_CAND_TARGET fixes it (tuning hook).
-  const unsigned long long target_fixed = getenv("YTTM_CAND_TARGET") ? strtoull(getenv("YTTM_CAND_TARGET"), nullptr, 10) : 0;
+  const unsigned long long target_fixed = C.cand_target.u;
   unsigned long long TARGET = target_fixed ? target_fixed : 256;
-  const double target_max = getenv("YTTM_CAND_MAX") ? atof(getenv("YTTM_CAND_MAX")) : 512.0;
+  const double target_max = C.cand_max.d;
   double batch_ema = 64;
   const uint32_t MX_ALL = 0xffffffffu;
   unsigned long long tau = 1;
@@ -146,12 +147,12 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   std::vector<uint32_t> batch_xyz;
   std::vector<unsigned long long> batch_cnt;
   unsigned long long rounds = 0, rescans = 0, rounds_exhausted = 0, batch_extensions = 0, batch_splits = 0;
-  const bool extend_on = !getenv("YTTM_NO_EXTEND");  // (tuning hook / A-B runs)
-  const bool split_on = !getenv("YTTM_NO_BATCH_SPLIT");
-  const bool refine_on = !getenv("YTTM_NO_REFINE");  // (the same: the fused scan keeps the host's threshold)
+  const bool extend_on = !C.no_extend.set;  // (tuning hook / A-B runs)
+  const bool split_on = !C.no_batch_split.set;
+  const bool refine_on = !C.no_refine.set;  // (the same: the fused scan keeps the host's threshold)
   std::vector<unsigned long long> batch_keys;
   double w_cand = 0, w_pick = 0, w_apply = 0, w_pick_a = 0, w_pick_b = 0;  // (YTTM_TRACE: pick = threshold + heap build | pops)
-  const bool trace_pick = getenv("YTTM_TRACE") != nullptr;
+  const bool trace_pick = C.trace.set;
   unsigned long long n_cand_sum = 0;
   struct RoundLine { float wait_us, pick_us, apply_us, dev_us; uint32_t k; };  // (YTTM_TRACE: where a round's wall time goes, by ranges of rounds)
   std::vector<RoundLine> round_lines;
@@ -305,7 +306,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   }
   {
     if (rep) rep->seconds_merge = since(t_merge);
-    if (getenv("YTTM_TRACE") && g.fused_rounds)
+    if (trace_pick && g.fused_rounds)
       fprintf(stderr, "[yttm] fused rounds %llu: tail set-up %.2f us, top-list scan %.2f us (%.0f entries), publish %.2f us per round\n", g.fused_rounds,
               g.tail_ticks[0] * 0.01 / g.fused_rounds, g.tail_ticks[1] * 0.01 / g.fused_rounds, (double)g.tail_listed / g.fused_rounds,
               g.tail_ticks[2] * 0.01 / g.fused_rounds);
@@ -321,8 +322,17 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
                 (w + p + ap) / m, w / m, d / m, p / m, ap / m, apmax, kk / m);
       }
     }
-    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] host pick: threshold %.1f ms, heap build %.1f ms of the %.1f; %.0f candidates per round\n", w_pick_a * 1e3, w_pick_b * 1e3, w_pick * 1e3, (double)n_cand_sum / (double)std::max<unsigned long long>(rounds, 1));
-    if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu (%llu looks), hot rebuilds %llu, top refills %llu, index builds %llu (%llu rounds in word mode from round %llu on, %llu of them over every word), pair table %llu keys in %llu slots (%llu rehashes)\n",
+#ifdef YTTM_K4_PROF
+    if (trace_pick) {
+      unsigned long long tq[8];
+      g.read_stats(24, 8, tq);
+      if (tq[7])
+        fprintf(stderr, "[yttm] scan_top, first pass, us per scan over %llu scans: list lengths %.2f, slot numbers %.2f, keys + counts %.2f, keep / zero / histogram %.2f, refine %.2f, emit %.2f, compaction %.2f\n", tq[7],
+                tq[0] * 0.01 / tq[7], tq[1] * 0.01 / tq[7], tq[2] * 0.01 / tq[7], tq[3] * 0.01 / tq[7], tq[4] * 0.01 / tq[7], tq[5] * 0.01 / tq[7], tq[6] * 0.01 / tq[7]);
+    }
+#endif
+    if (trace_pick) fprintf(stderr, "[yttm] host pick: threshold %.1f ms, heap build %.1f ms of the %.1f; %.0f candidates per round\n", w_pick_a * 1e3, w_pick_b * 1e3, w_pick * 1e3, (double)n_cand_sum / (double)std::max<unsigned long long>(rounds, 1));
+    if (trace_pick) fprintf(stderr, "[yttm] merge loop wall: candidates %.1f ms, host pick %.1f ms, merge_apply %.1f ms, repacks %llu (%llu looks), hot rebuilds %llu, top refills %llu, index builds %llu (%llu rounds in word mode from round %llu on, %llu of them over every word), pair table %llu keys in %llu slots (%llu rehashes)\n",
                                        w_cand * 1e3, w_pick * 1e3, w_apply * 1e3, g.repacks, g.repack_looks, g.hot_rebuilds, g.top_refills, g.index_builds, g.word_rounds, g.word_switch_round, g.word_all_rounds, g.n_keys_host, g.table_capacity(), g.rehashes);
   }
   if (rep) {
@@ -418,9 +428,9 @@ Status train_bpe_from_device(const void *d_text, unsigned long long n, const std
   if (!st.ok()) return st;
   return guarded([&]() {
     GpuCtx g(device);
-    g.profile = profile && !getenv("YTTM_NO_PROFILE");  // (tuning hook: what do the timing events themselves cost?)
+    g.profile = profile && !g.config().no_profile.set;  // (tuning hook: what do the timing events themselves cost?)
     g.instrument = profile == 2;
-    if (g.instrument && getenv("YTTM_MEASURE_SPLIT_ROUND")) g.split_round = strtoull(getenv("YTTM_MEASURE_SPLIT_ROUND"), nullptr, 10);
+    if (g.instrument && g.config().measure_split_round.set) g.split_round = g.config().measure_split_round.u;
     g.set_comm(comm);
     g.attach_corpus(d_text, n);
     return learn_bpe(g, vocab_size, model_path, cfg, nullptr, report);
@@ -476,7 +486,7 @@ Status train_bpe(const std::string &input_path, const std::string &model_path, i
   Status r = guarded([&]() {
     GpuCtx g(device);
     s_ctor = since(t_call);
-    g.profile = profile && !getenv("YTTM_NO_PROFILE");
+    g.profile = profile && !g.config().no_profile.set;
     g.set_comm(comm);
     const auto t_up = clk::now();
     g.upload_corpus_fd(fd, lo, hi - lo);  // file -> pinned chunks -> HBM (replaces fast_read_file_utf8, bpe.cpp:67-84)
@@ -486,7 +496,7 @@ Status train_bpe(const std::string &input_path, const std::string &model_path, i
     s_body = since(t_call);
     return st2;
   });
-  if (getenv("YTTM_TRACE")) fprintf(stderr, "[yttm] train_bpe: context set-up %.2f ms, upload + training %.2f ms, context tear-down %.2f ms\n", s_ctor * 1e3, (s_body - s_ctor) * 1e3, (since(t_call) - s_body) * 1e3);
+  if (yttm::cfg()->trace.set) fprintf(stderr, "[yttm] train_bpe: context set-up %.2f ms, upload + training %.2f ms, context tear-down %.2f ms\n", s_ctor * 1e3, (s_body - s_ctor) * 1e3, (since(t_call) - s_body) * 1e3);
   close(fd);
   return r;
 }

@@ -974,18 +974,18 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   d.always_skip = dropout_prob >= 1.0;
   d.thr = d.always_skip ? ~0ull : (unsigned long long)(dropout_prob * 18446744073709551616.0);
   d.seed = seed;
-  d.heap_from = getenv("YTTM_DROPOUT_HEAP_FROM") ? atoi(getenv("YTTM_DROPOUT_HEAP_FROM")) : 256;  // (tests: 0 = every word)
+  const std::shared_ptr<const Config> C = cfg();  // (the snapshot the encoder's creation took)
+  d.heap_from = (int)C->dropout_heap_from.i;  // (tests: 0 = every word)
   d.wsl = drop_scratch;
   d.ev = nullptr;
   // sentences per wavefront group: large enough that packs are full, small enough that every wavefront of the launch has work
   unsigned long long group = n_sent / ((unsigned long long)n_blocks * ENC_WAVES * 4);
   if (group < 1) group = 1;
   if (group > 24) group = 24;
-  d.lds_queues = m.n_rules < (1u << 23) && !getenv("YTTM_DROPOUT_HBM_QUEUES");  // (tests: every queue in the HBM scratch)
+  d.lds_queues = m.n_rules < (1u << 23) && !C->dropout_hbm_queues.set;  // (tests: every queue in the HBM scratch)
   // one word per lane (merge_lanes) for packs whose words have at most this many tokens; 0 = the wave-wide rounds only.
   // YTTM_K5_LANE_WORDS: the word cache's distinct words, YTTM_K5_LANE_SENT: packed sentences
-  const char *lw = getenv("YTTM_K5_LANE_WORDS"), *ls = getenv("YTTM_K5_LANE_SENT");
-  const int lane_max = ends ? (lw ? atoi(lw) : 48) : (ls ? atoi(ls) : 48);
+  const int lane_max = ends ? (int)C->k5_lane_words.i : (int)C->k5_lane_sent.i;
   if (ends && !d.enabled && pub) {  // the word cache's distinct words
     unsigned int wblocks = (n_blocks + 1) / 2;  // (16 waves each: never more waves than n_blocks + 1 of k5_encode's -- the HBM scratch is sized for those)
     if (wblocks > 256) wblocks = 256;

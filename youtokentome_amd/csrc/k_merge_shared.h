@@ -145,14 +145,14 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
   constexpr int NW = NT / 64;
   unsigned int *lh = lds;                     // [CAND_BINS]
   unsigned int *wcount = lds + CAND_BINS;     // [NW] kept entries per wave of this pass
-  unsigned int *ctl = lds + CAND_BINS + 32;   // [0] kept so far, [1] candidates, [2] live entries
+  unsigned int *ctl = lds + CAND_BINS + 32;   // [1] candidates, [2] live entries, [3] highest bin in use, [4 + (pass & 1)] entries kept up to and including that pass
   unsigned long long *facc = reinterpret_cast<unsigned long long *>(lds + CAND_BINS + 40);  // [5] fold accumulators
   unsigned int *sub = lds + CAND_BINS + 64;   // [64] counts inside the boundary bin, [64..67] the refined threshold (lo, hi), boundary bin, entries above it
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long tm0 = (unsigned long long)wall_clock64();
   for (int b = tid; b < CAND_BINS; b += NT) lh[b] = 0;
   if (tid < 68) sub[tid] = 0;
-  if (tid < 4) ctl[tid] = 0;  // ([3]: highest histogram bin in use)
+  if (tid < 6) ctl[tid] = 0;
   if (tid < 5) facc[tid] = 0;
   __syncthreads();
   const unsigned long long tm1 = (unsigned long long)wall_clock64();
@@ -164,13 +164,22 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
   uint4 *box_out = reinterpret_cast<uint4 *>(sa.mailbox + 8192);
   constexpr int TAIL_E = 8;
   unsigned int my_live = 0;
+  unsigned int pass = 0;  // (ctl[4 + ((pass - 1) & 1)] = entries kept by the passes before this one; 0 for the first)
   // The host wants about `want` candidates (four times its recent batch), and the count histogram it picks its threshold from is too
   // coarse for that (8 bins per power of two): on natural text the top list's counts sit in one or two bins, and every round sent the
   // WHOLE list -- 570 candidates on Zipf text for batches of 8 -- through the mailbox and the host's heap.  When the list fits one pass the
   // scan refines the threshold itself: boundary bin from the histogram, 64 sub-bins inside it, candidates = every entry at or above the
   // refined count (a complete prefix of the order, as the host needs; it reads the threshold back as the smallest count it got).
   const bool refine = sa.want != 0 && tn != 0 && tn <= (unsigned int)(NT * TAIL_E);
-  for (unsigned int base = 0; base < tn; base += NT * TAIL_E) {
+#if defined(YTTM_K4_PROF) && defined(__HIP_DEVICE_COMPILE__)
+  // tuning build: where the scan's time goes (100 MHz ticks, summed over the rounds into stats[24..30]; YTTM_TRACE prints them)
+  unsigned long long tq_[7];
+#define TAIL_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tq_[i] = (unsigned long long)wall_clock64(); } while (0)
+  TAIL_MARK(0);
+#else
+#define TAIL_MARK(i) ((void)0)
+#endif
+  for (unsigned int base = 0; base < tn; base += NT * TAIL_E, pass++) {
     uint32_t sl[TAIL_E];
     unsigned long long k[TAIL_E], c[TAIL_E];
 #pragma unroll
@@ -178,6 +187,7 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
       const unsigned int i = base + (unsigned int)(e * NT + tid);
       sl[e] = i < tn ? __hip_atomic_load(&pt.top_slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
     }
+    if (base == 0) TAIL_MARK(1);
 #pragma unroll
     for (int e = 0; e < TAIL_E; e++) {
       k[e] = PT_EMPTY;
@@ -187,7 +197,9 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
         c[e] = ld_agent(pt.cnt_p(sl[e]));
       }
     }
+    if (base == 0) TAIL_MARK(2);
     uint32_t keepm = 0;  // bit e: entry e stays on the list
+    unsigned int my_maxbin = 0;
 #pragma unroll
     for (int e = 0; e < TAIL_E; e++) {
       if (sl[e] == 0xffffffffu) continue;
@@ -201,10 +213,19 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
         my_live++;
         const int bin = cand_bin(cc);
         atomicAdd(&lh[bin], 1u);
-        if ((unsigned int)bin > ctl[3]) atomicMax(&ctl[3], (unsigned int)bin);
+        my_maxbin = (unsigned int)bin > my_maxbin ? (unsigned int)bin : my_maxbin;
         c[e] = cc;  // (the live count, for the emission below)
       }
     }
+    {  // the highest bin in use: ONE LDS atomic per wave (round 5: one per entry, a thousand on one address, was 1 - 2 us of every scan)
+      unsigned int m = my_maxbin;
+      for (int o = 32; o > 0; o >>= 1) {  // (lane 0 ends up with the maximum)
+        const unsigned int t = (unsigned int)__shfl_down((int)m, o);
+        if (lane + o < 64) m = t > m ? t : m;
+      }
+      if (lane == 0 && m) atomicMax(&ctl[3], m);
+    }
+    if (base == 0) TAIL_MARK(3);
     unsigned long long tau_ref = 0;  // candidates must also reach this count
     if (refine) {  // (uniform; one pass: the histogram is complete after the barrier)
       __syncthreads();
@@ -272,14 +293,22 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
         }
       }
     }
+    if (base == 0) TAIL_MARK(4);
 #pragma unroll
     for (int e = 0; e < TAIL_E; e++) {
-      if (!((keepm >> e) & 1u)) continue;
       const unsigned long long cc = c[e];
       const uint32_t x = (uint32_t)(k[e] >> 32), y = (uint32_t)k[e];
       const uint32_t mx = x > y ? x : y;
-      if (cc >= tau_ref && (cc > sa.tau_cnt || (cc == sa.tau_cnt && mx <= sa.tau_mx))) {
-        const unsigned int o = atomicAdd(&ctl[1], 1u);
+      const bool is_cand = ((keepm >> e) & 1u) && cc >= tau_ref && (cc > sa.tau_cnt || (cc == sa.tau_cnt && mx <= sa.tau_mx));
+      // a wave's candidates of this step take their places with ONE add (a returning add per candidate on one LDS address serialises)
+      const unsigned long long cm = __ballot(is_cand);
+      if (!cm) continue;
+      unsigned int o0 = 0;
+      const int leader = __ffsll((long long)cm) - 1;
+      if (lane == leader) o0 = atomicAdd(&ctl[1], (unsigned int)__popcll(cm));
+      o0 = (unsigned int)__shfl((int)o0, leader);
+      if (is_cand) {
+        const unsigned int o = o0 + (unsigned int)__popcll(cm & ((1ull << lane) - 1ull));
         if (o < sa.cap) {
           sa.out[o].key = k[e];
           sa.out[o].cnt = cc;
@@ -291,29 +320,41 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
         }
       }
     }
+    if (base == 0) TAIL_MARK(5);
     // compaction: the kept entries of this pass move down behind those of the earlier passes (any order)
     const uint32_t mine = (uint32_t)__popc(keepm);
     const uint32_t incl = wave_incl_scan(mine);
     if (lane == 63) wcount[wave] = incl;
     __syncthreads();  // every entry of this pass has been read
-    unsigned int pos = ctl[0] + incl - mine;
+    // (the running total is kept in two alternating words: this pass reads the one the pass before wrote -- ordered by the barrier above --
+    // and thread 0 writes the other; what follows needs no barrier of its own: the next pass, or the publish, has one before it reads)
+    const unsigned int kept_before = pass ? ctl[4 + ((pass - 1) & 1)] : 0u;
+    unsigned int pos = kept_before + incl - mine;
     for (int w = 0; w < wave; w++) pos += wcount[w];
 #pragma unroll
     for (int e = 0; e < TAIL_E; e++)
       if ((keepm >> e) & 1u) pt.top_slots[pos++] = sl[e];
-    __syncthreads();
     if (tid == 0) {
-      unsigned int t = 0;
+      unsigned int t = kept_before;
       for (int w = 0; w < NW; w++) t += wcount[w];
-      ctl[0] += t;
+      ctl[4 + (pass & 1)] = t;
     }
-    __syncthreads();
+    if (base + (unsigned int)(NT * TAIL_E) < tn) __syncthreads();  // (wcount is rewritten by the next pass)
   }
+  const unsigned int kept_total_at = pass ? 4 + ((pass - 1) & 1) : 0;  // (no pass at all: ctl[0] is zero)
   {
     const unsigned long long t = wave_sum_u64((unsigned long long)my_live);
     if (lane == 0 && t) atomicAdd(&ctl[2], (unsigned int)t);
   }
   __syncthreads();
+#if defined(YTTM_K4_PROF) && defined(__HIP_DEVICE_COMPILE__)
+  TAIL_MARK(6);
+  if (tid == 0 && tn != 0) {
+    stats[24] += tq_[0] - tm1;  // list lengths
+    for (int i = 1; i < 7; i++) stats[24 + i] += tq_[i] - tq_[i - 1];  // slots | keys + counts | keep / zero / histogram | refine | emit | compaction + the later passes
+    stats[31] += 1;
+  }
+#endif
   // ---- 3. publish
   const unsigned long long tm2 = (unsigned long long)wall_clock64();
   unsigned int *hdr = reinterpret_cast<unsigned int *>(sa.mailbox);
@@ -329,7 +370,7 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 24) = sa.timed ? (unsigned long long)wall_clock64() - ld_agent(&stats[STAT_T0]) : 0ull;  // the round on the device
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 40) = stats[2];  // tokens streamed so far (repack trigger)
     *reinterpret_cast<unsigned long long *>(sa.mailbox + 48) = stats[1];  // tiles that held a merge site so far
-    if (!overflow) *pt.top_n = ctl[0];
+    if (!overflow) *pt.top_n = ctl[kept_total_at];
     if (sa.done_ctr) *sa.done_ctr = 0;
     unsigned long long *tmark = reinterpret_cast<unsigned long long *>(sa.mailbox + 96);
     tmark[0] = tm0; tmark[1] = tm1; tmark[2] = tm2; tmark[3] = (unsigned long long)wall_clock64();

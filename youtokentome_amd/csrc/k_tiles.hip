@@ -516,9 +516,9 @@ void pm_bloom_host(uint32_t *bloom, const uint32_t *xyz, uint32_t k) {  // (a ba
 
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, uint32_t id_min, uint32_t n_ids, hipStream_t st) {
   if (!ts.n_tiles) return;
-  unsigned int bpc = 4;
-  if (const char *e = getenv("YTTM_K3_BPC")) bpc = (unsigned int)atoi(e);  // (tuning aids; one launch per training)
-  const bool general = getenv("YTTM_K3_GENERAL") != nullptr;
+  const std::shared_ptr<const Config> C = cfg();  // (tuning aids; one launch per training)
+  const unsigned int bpc = (unsigned int)C->k3_bpc.i;
+  const bool general = C->k3_general.set;
   if (cls == 0 && n_ids && n_ids <= K3D_MAX_IDS && !general) {
     if (n_ids <= 32u)
       hipLaunchKernelGGL((k_pair_count_dense<TILE_SLOT_A, 2048u>), dim3(tile_grid(ts.n_tiles, 4, bpc)), dim3(256), 0, st, ts, pt, db, id_min, n_ids);
@@ -550,8 +550,7 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
   // and a serialised ticket at the end (~11 ns each), which a round of ~15 us notices.  YTTM_APPLY_GRID overrides (tuning hook).
   unsigned int grid_a = tile_grid(ts.n_tiles, APPLY_WPB, APPLY_BPC);
   {
-    static const char *g_env = getenv("YTTM_APPLY_GRID");
-    const unsigned int small = g_env ? (unsigned int)atoi(g_env) : 256u;
+    const unsigned int small = (unsigned int)g_apply_grid;  // (YTTM_APPLY_GRID, read by launch_env_refresh when the context was made)
     if (ts.n_tiles <= 16384 && small && grid_a > small) grid_a = small;
   }
   const uint8_t *no_flags = nullptr;

@@ -511,8 +511,9 @@ __global__ __launch_bounds__(BLOCK) void k5w_scatter(EncModel m, const unsigned 
 // ---- launchers -----------------------------------------------------------------------------------------------------------------
 // sentences a wavefront of the flat walks takes at a time: up to WC_SBLK, fewer while that leaves wavefronts without any
 static inline int wc_sblk(unsigned long long n_sent) {
-  if (const char *e = getenv("YTTM_WC_SBLK")) {  // (tests: small batches with many sentences per wavefront)
-    const int v = atoi(e);
+  const std::shared_ptr<const Config> C = cfg();
+  if (C->wc_sblk.set) {  // (tests: small batches with many sentences per wavefront)
+    const int v = (int)C->wc_sblk.i;
     return v < 1 ? 1 : v > WC_SBLK ? WC_SBLK : v;
   }
   const unsigned long long per = n_sent / (256ull * 16 * NWAVES);
@@ -525,8 +526,7 @@ static inline unsigned int wave_grid(unsigned long long n_items, unsigned int ma
 }
 static inline unsigned int wcache_blocks(const WordCache &wc) { return (unsigned int)((wc.mask + WC_CBLK) / WC_CBLK); }
 static int wcache_classes() {
-  const char *e = getenv("YTTM_K5_CLASSES");
-  const int c = e ? atoi(e) : WC_CLASSES;
+  const int c = (int)cfg()->k5_classes.i;
   return c <= 1 ? 1 : WC_CLASSES;
 }
 unsigned long long wcache_count_blocks(const WordCache &wc) { return (unsigned long long)wcache_blocks(wc) * (unsigned long long)wcache_classes(); }

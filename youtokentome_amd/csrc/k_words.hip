@@ -847,14 +847,14 @@ void launch_words_init(const TileSet &ts, unsigned long long *wmeta, hipStream_t
 // The grid hooks of the word-mode launchers (tests, tuning) are read when a context is made, not every round: getenv walks the whole
 // environment, and a round's launch is on its critical path (yttm_kernels.h: launch_env_refresh).
 static int g_wgather_grid = -1, g_words_grid = -1, g_words_wpi = -1;
+int g_apply_grid = 256;  // (k_tiles.hip: launch_merge_apply)
 void launch_env_refresh() {
-  auto rd = [](const char *name) {
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : -1;
-  };
-  g_wgather_grid = rd("YTTM_WGATHER_GRID");
-  g_words_grid = rd("YTTM_WORDS_GRID");
-  g_words_wpi = rd("YTTM_WORDS_WPI");
+  const std::shared_ptr<const Config> C = cfg();
+  auto rd = [](const Hook &h) { return h.set && !h.raw.empty() ? (int)h.i : -1; };
+  g_wgather_grid = rd(C->wgather_grid);
+  g_words_grid = rd(C->words_grid);
+  g_words_wpi = rd(C->words_wpi);
+  g_apply_grid = (int)C->apply_grid.i;
 }
 void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, unsigned int work_hint, hipStream_t st) {
   // every workgroup looks all the rules up and takes a ticket at the end: a small round (work_hint = about how many words it will visit;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "yttm_config.h"
 #include "yttm_device.h"
 
 namespace yttm {
@@ -142,6 +143,7 @@ struct WGatherArgs {
   uint32_t cnt[BATCH_ARGS_MAX];  // k_words<FUSED>: the count the host picked rule j by (saturated): no rule has more sites than that
 };
 constexpr unsigned int WGATHER_MAXK = 4096;
+extern int g_apply_grid;    // YTTM_APPLY_GRID as launch_env_refresh() found it (k_tiles.hip: launch_merge_apply)
 void launch_env_refresh();  // re-reads the launchers' environment hooks (YTTM_WORDS_GRID, YTTM_WORDS_WPI, YTTM_WGATHER_GRID): once per context
 void launch_wgather(const WGatherArgs &a, const BatchArgs *ba, unsigned int work_hint, hipStream_t st);
 bool launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask, const uint32_t *bloom_g,
