@@ -452,6 +452,15 @@ void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_d
     std::lock_guard<std::mutex> g(g_io.mu);
     if (!g_io.busy) { g_io.busy = true; mine = true; }
   }
+  struct BusyGuard {  // (whatever leaves this function -- any exception -- gives the chunks back)
+    IoStage &io;
+    bool held;
+    ~BusyGuard() {
+      if (!held) return;
+      std::lock_guard<std::mutex> g(io.mu);
+      io.busy = false;
+    }
+  } busy_guard{g_io, mine};
   if (mine && g_io.dev != device) {  // (the cached streams and events are another device's)
     for (hipEvent_t &e : g_io.ev) {
       if (e) (void)hipEventDestroy(e);
@@ -534,16 +543,29 @@ void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_d
       failed.store(1);
       std::lock_guard<std::mutex> g(err_mu);
       if (first_error.empty()) first_error = e.msg;
+    } catch (const std::exception &e) {  // (bad_alloc in a callback, ...: reported like a GPU error, never std::terminate in a worker)
+      failed.store(1);
+      std::lock_guard<std::mutex> g(err_mu);
+      if (first_error.empty()) first_error = std::string("staged transfer: ") + e.what();
     }
+    // A worker that gave up may have copies queued on its stream that still read / write its pinned chunks and d_ptr: they must be over
+    // before the caller frees the device buffer or the next transfer reuses the chunks.
+    if (failed.load() && g_io.cs[w]) (void)hipStreamSynchronize(g_io.cs[w]);
   };
-  std::vector<std::thread> th;
-  for (int w = 1; w < n_threads; w++) th.emplace_back(worker, w);
-  worker(0);
-  for (auto &t : th) t.join();
-  {
-    std::lock_guard<std::mutex> g(g_io.mu);
-    g_io.busy = false;
+  struct Joiner {  // (a throwing emplace_back / worker(0) must not destroy joinable threads)
+    std::vector<std::thread> th;
+    ~Joiner() {
+      for (auto &t : th)
+        if (t.joinable()) t.join();
+    }
+  } joiner;
+  try {
+    for (int w = 1; w < n_threads; w++) joiner.th.emplace_back(worker, w);
+  } catch (const std::exception &e) {  // (no more threads to be had: the ones that started, and this one, do the work)
+    (void)e;
   }
+  worker(0);
+  for (auto &t : joiner.th) t.join();
   if (failed.load()) throw GpuError{first_error};
 }
 
@@ -616,9 +638,16 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
   const auto t_start = std::chrono::steady_clock::now();
   auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
   double ms_link = 0;
+  //  a failure on this thread -- a front-end kernel, an allocation -- must not wait for the rest of the corpus to be read and
+  // copied: the wrapper around `fill` gives up once `stop` is set, which ends staged_transfer; and the thread is joined on every way out.
+  // (`fill` is called from several threads at once -- the samples above, then the upload's workers: gpu_ctx.h says so.)
+  std::atomic<bool> stop{false};
+  const std::function<bool(void *, unsigned long long, size_t)> fill_or_stop = [&](void *dst, unsigned long long off, size_t len) {
+    return !stop.load(std::memory_order_relaxed) && fill(dst, off, len);
+  };
   std::thread up([&] {
     try {
-      staged_transfer(device_, d_text_owned_, n, true, fill, [&](unsigned long long off, size_t) {
+      staged_transfer(device_, d_text_owned_, n, true, fill_or_stop, [&](unsigned long long off, size_t) {
         std::lock_guard<std::mutex> g(mu);
         landed[(size_t)(off / io_chunk)] = 1;
         bool moved = false;
@@ -635,6 +664,15 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
     finished = true;
     cv.notify_all();
   });
+  struct UpJoin {
+    std::thread &t;
+    std::atomic<bool> &stop;
+    ~UpJoin() {
+      if (!t.joinable()) return;
+      stop.store(true);
+      t.join();
+    }
+  } up_join{up, stop};
   auto wait_for = [&](unsigned long long bytes) {  // until [0, bytes) has landed (or the upload is over); false: it failed
     std::unique_lock<std::mutex> g(mu);
     cv.wait(g, [&] { return finished || std::min<unsigned long long>(n, (unsigned long long)next_io * io_chunk) >= bytes; });
@@ -703,6 +741,7 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
     }
   } catch (const GpuError &e) {
     fail = e.msg;
+    stop.store(true);  // (the upload ends with its chunk in flight instead of with the file's last byte)
   }
   up.join();
   if (fail.empty() && !up_error.empty()) fail = up_error;

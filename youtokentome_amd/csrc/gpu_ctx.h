@@ -20,6 +20,8 @@ struct GpuError {
 // n bytes between HBM and the host through pinned chunks that several host threads fill (to_device) or drain (gpu_ctx.cpp): what a single
 // hipMemcpy from / to pageable memory does on one thread through one internal buffer.  host_side(chunk, off, len) -> false: give up.
 // arrived(off, len) (to_device only, may be empty): bytes [off, off + len) are in HBM -- called from the workers' threads, chunks in no order.
+// host_side and arrived must be THREAD-SAFE: several workers call them at once, for different chunks (the upload of a corpus: pread / memcpy
+// of disjoint ranges; GpuCtx::upload_overlapped also samples the source through the same callback before the workers start).
 void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_device,
                      const std::function<bool(void *chunk, unsigned long long off, size_t len)> &host_side,
                      const std::function<void(unsigned long long off, size_t len)> &arrived = nullptr, size_t chunk_bytes = 0 /* 0: staged_chunk_bytes() */);

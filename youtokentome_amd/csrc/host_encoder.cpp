@@ -334,8 +334,10 @@ static void encode_cached(EncoderDevice &D, EncodeLane &d, const void *d_bytes, 
     HIP_CHECK(hipMemcpyAsync(misc, d.d_wc_misc, 8, hipMemcpyDeviceToHost, d.st));
     n_table = scan_counts(d, d.d_wc_blk, n_blk, d.d_wc_blk_off);  // (syncs)
     if (!(misc[1] & 1u)) break;
-    // too full for the probe limit: start over -- with the short words spread wider if it may have been them, else with twice the slots
-    if (short_cap < cap) {
+    // too full for the probe limit: start over -- with the short words spread wider if it WAS one of them that found no slot (the kernel
+    // says so: status bit 1), else with twice the slots at once (a batch of mostly distinct LONG words, the usual cause of a full
+    // table, paid up to three insert passes over gigabytes of text for a region that was not the problem)
+    if ((misc[1] & 2u) && short_cap < cap) {
       short_cap = std::min(cap, short_cap << 3);
       continue;
     }
@@ -643,10 +645,15 @@ static bool encode_pipelined(const BaseEncoder &enc, EncoderDevice *dev, int dev
     flags[i] = 1;
     cv.notify_all();
   };
+  auto has_failed = [&] {
+    std::lock_guard<std::mutex> g(mu);
+    return failed;
+  };
   std::thread up([&] {
     try {
       HIP_CHECK(hipSetDevice(device));
       for (size_t i = 0; i < K; i++) {
+        if (has_failed()) return;  // (nobody will encode what this thread would still stage)
         if (i >= 2 && !wait_flag(down_done, i - 2)) return;  // the lane's buffers are free again
         EncodeLane &d = dev->lane[i & 1];
         const unsigned long long s0 = cut[i], ns = cut[i + 1] - s0, b0 = offsets[s0], nb = offsets[s0 + ns] - b0;
@@ -670,6 +677,10 @@ static bool encode_pipelined(const BaseEncoder &enc, EncoderDevice *dev, int dev
       }
     } catch (const GpuError &e) {
       fail("GPU error: " + e.msg);
+    } catch (const std::exception &e) {  // (bad_alloc from a grow, ...: an error of this call, never std::terminate of the host process)
+      fail(std::string("encode (upload thread): ") + e.what());
+    } catch (...) {
+      fail("encode (upload thread): unknown exception");
     }
   });
   std::thread down([&] {
@@ -696,6 +707,10 @@ static bool encode_pipelined(const BaseEncoder &enc, EncoderDevice *dev, int dev
       }
     } catch (const GpuError &e) {
       fail("GPU error: " + e.msg);
+    } catch (const std::exception &e) {
+      fail(std::string("encode (download thread): ") + e.what());
+    } catch (...) {
+      fail("encode (download thread): unknown exception");
     }
   });
   Status st;
@@ -721,6 +736,13 @@ static bool encode_pipelined(const BaseEncoder &enc, EncoderDevice *dev, int dev
     return true;
   }
   if (cfg()->trace.set) fprintf(stderr, "[yttm] encode host -> host: %llu sentences in %zu sub-batches through both lanes\n", n_sent, K);
+  {
+    // The array was asked for at its upper bound (four bytes per input byte and more); what the caller keeps until its free() is the ids
+    // themselves: the tail -- never touched, so never backed by memory, but address space under RLIMIT_AS / strict overcommit -- goes back
+    // now.  A shrinking realloc of an mmap'ed block is an mremap; the alignment of the block's start stays what it was.
+    const unsigned long long used = off[n_sent];
+    if (void *small = realloc(ids, (size_t)std::max<unsigned long long>(used, 1) * sizeof(int32_t))) ids = (int32_t *)small;
+  }
   *ids_out = ids;
   *off_out = off;
   *result = Status();

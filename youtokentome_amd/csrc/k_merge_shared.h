@@ -147,7 +147,7 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
   unsigned int *wcount = lds + CAND_BINS;     // [NW] kept entries per wave of this pass
   unsigned int *ctl = lds + CAND_BINS + 32;   // [1] candidates, [2] live entries, [3] highest bin in use, [4 + (pass & 1)] entries kept up to and including that pass
   unsigned long long *facc = reinterpret_cast<unsigned long long *>(lds + CAND_BINS + 40);  // [5] fold accumulators
-  unsigned int *sub = lds + CAND_BINS + 64;   // [64] counts inside the boundary bin, [64..67] the refined threshold (lo, hi), boundary bin, entries above it
+  unsigned int *sub = lds + CAND_BINS + 64;   // [64] counts inside the boundary bin
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long tm0 = (unsigned long long)wall_clock64();
   for (int b = tid; b < CAND_BINS; b += NT) lh[b] = 0;
@@ -228,37 +228,37 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
     if (base == 0) TAIL_MARK(3);
     unsigned long long tau_ref = 0;  // candidates must also reach this count
     if (refine) {  // (uniform; one pass: the histogram is complete after the barrier)
+      // Round 5: EVERY wave works the threshold out for itself from the histogram in LDS -- the same numbers in every wave -- instead of wave 0
+      // doing it between two barriers while the others wait: two barriers (histogram complete, sub-bins complete) instead of four.
       __syncthreads();
-      if (wave == 0) {  // the bin in which the `want`-th largest count lies: lane l owns bins [11 l, 11 l + 11), summed from the top lane down
-        static_assert(CAND_BINS == 64 * 11, "eleven bins per lane");
-        unsigned int mine_b = 0;
-        for (int b = 0; b < 11; b++) mine_b += lh[lane * 11 + b];
-        unsigned int above = 0;  // entries in the bins of the lanes above me
-        {
-          unsigned int v = mine_b;
-          for (int o = 1; o < 64; o <<= 1) {
-            const unsigned int t = __shfl_down(v, o);
-            if (lane + o < 64) v += t;
-          }
-          above = v - mine_b;
-        }
-        if (above < sa.want && above + mine_b >= sa.want) {  // (exactly one lane, if the list holds `want` entries at all)
+      static_assert(CAND_BINS == 64 * 11, "eleven bins per lane");
+      // the bin in which the `want`-th largest count lies: lane l owns bins [11 l, 11 l + 11), summed from the top lane down
+      unsigned int mine_b = 0;
+      for (int b = 0; b < 11; b++) mine_b += lh[lane * 11 + b];
+      unsigned int incl_b = mine_b;  // entries in my bins and those of the lanes above me
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int t = __shfl_down(incl_b, o);
+        if (lane + o < 64) incl_b += t;
+      }
+      const unsigned int above = incl_b - mine_b;
+      const unsigned long long owner_m = __ballot(above < sa.want && incl_b >= sa.want);  // (exactly one lane, if the list holds `want` entries at all)
+      if (owner_m) {
+        const int owner = __ffsll((long long)owner_m) - 1;
+        unsigned int bnd = 0, acc_above = 0;  // (meaningful in the owner lane)
+        if (lane == owner) {
           unsigned int acc = above;
           for (int b = 10; b >= 0; b--) {
             const unsigned int h = lh[lane * 11 + b];
             if (acc + h >= sa.want) {
-              sub[66] = (unsigned int)(lane * 11 + b) + 1u;  // boundary bin + 1 (0: none)
-              sub[67] = acc;
+              bnd = (unsigned int)(lane * 11 + b);
+              acc_above = acc;
               break;
             }
             acc += h;
           }
         }
-      }
-      __syncthreads();
-      const unsigned int bb = sub[66];
-      if (bb) {
-        const int B = (int)bb - 1;
+        const int B = __shfl((int)bnd, owner);
+        const unsigned int n_above = (unsigned int)__shfl((int)acc_above, owner);
         unsigned long long lo = (unsigned long long)B;
         int shift = 0;
         bool wide = false;
@@ -269,27 +269,20 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
           shift = ex - 3 > 6 ? ex - 3 - 6 : 0;  // (the bin is 2^(ex-3) counts wide: 64 sub-bins)
         }
         tau_ref = lo;
-        if (wide) {
+        if (wide) {  // (uniform over the workgroup: every wave found the same bin)
 #pragma unroll
           for (int e = 0; e < TAIL_E; e++)
             if (((keepm >> e) & 1u) && cand_bin(c[e]) == B) atomicAdd(&sub[(unsigned int)((c[e] - lo) >> shift) & 63u], 1u);
           __syncthreads();
-          if (wave == 0) {  // lane s: entries of the sub-bins s .. 63 plus those above the bin; the highest s that reaches `want` is the threshold
-            unsigned int v = sub[lane];
-            for (int o = 1; o < 64; o <<= 1) {
-              const unsigned int t = __shfl_down(v, o);
-              if (lane + o < 64) v += t;
-            }
-            const unsigned long long ok = __ballot(sub[67] + v >= sa.want);  // (lane 0 always: the bin was chosen so)
-            const int sb = ok ? 63 - __clzll((long long)ok) : 0;
-            if (lane == 0) {
-              const unsigned long long t = lo + ((unsigned long long)sb << shift);
-              sub[64] = (unsigned int)t;
-              sub[65] = (unsigned int)(t >> 32);
-            }
+          // lane s: entries of the sub-bins s .. 63 plus those above the bin; the highest s that reaches `want` is the threshold
+          unsigned int v = sub[lane];
+          for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t = __shfl_down(v, o);
+            if (lane + o < 64) v += t;
           }
-          __syncthreads();
-          tau_ref = ((unsigned long long)sub[65] << 32) | sub[64];
+          const unsigned long long ok = __ballot(n_above + v >= sa.want);  // (lane 0 always: the bin was chosen so)
+          const int sb = ok ? 63 - __clzll((long long)ok) : 0;
+          tau_ref = lo + ((unsigned long long)sb << shift);
         }
       }
     }

@@ -103,7 +103,7 @@ __device__ inline void wc_insert_word(const uint8_t *__restrict__ text, unsigned
     if (len < 8 && probes == WC_SHORT_PROBES - 1 && wc.short_mask != wc.mask) i = (h >> 7) & wc.mask;
     else i = (i + 1) & wc.mask;
   }
-  if (found == WC_NONE) atomicOr(wc.status, 1u);  // table too full: the host doubles it and starts over
+  if (found == WC_NONE) atomicOr(wc.status, len < 8 ? 3u : 1u);  // table too full: the host starts over with a larger one (bit 1: it was a short word that found no slot)
   wc.occ[oidx] = found;
 }
 

@@ -260,7 +260,7 @@ struct WordCache {
   unsigned long long *extra;  // [extra_cap][2] words too long to cache: begin, end; after publish: ids offset, count
   unsigned int *extra_n;
   unsigned int extra_cap;
-  unsigned int *status;       // bit 0: the table was too full
+  unsigned int *status;       // bit 0: the table was too full; bit 1: (also) for a word of up to 7 bytes
 };
 unsigned long long wcache_count_blocks(const WordCache &wc);
 void launch_wcache_insert(const EncModel &m, const uint8_t *text, unsigned long long total, const unsigned long long *offsets, unsigned long long n_sent,
