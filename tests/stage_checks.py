@@ -44,6 +44,32 @@ def texts_by_alphabet_size(sizes=(2, 5, 31, 33, 45, 63, 64, 70), seed=5, n_words
     return out
 
 
+def three_byte_text(rng, n):
+    """Text for the front end's three-byte fast path (k_frontend.hip simple3_window): CJK ideographs with ASCII in between, and -- by kind --
+    everything that must send a lane's window to the exact path instead: U+2581 (E2 96 81, white space), two- and four-byte chars, E0 / ED
+    leads, truncated and stray sequences; at every alignment against the 16-byte lane windows."""
+    cjk = [chr(c) for c in range(0x4E00, 0x4E40)] + ["。", "，", "　", "ሴ", "\uffee", "\ud7ff", "\ue000"]
+    odd = ["▁", "é", "߿", "ࠀ", "\U0001F600", "\u00a0", "\u200b"]
+    bad = [b"\xe4", b"\xe4\xb8", b"\x80", b"\xbf\xbf", b"\xe0\x80\x80", b"\xed\xa0\x80", b"\xf0\x9f", b"\xc0\xaf", b"\xff", b"\xe2\x96", b"\xe4\xb8\xe4"]
+    out = bytearray()
+    kind = rng.choice(["pure", "mixed", "dirty"])
+    while len(out) < n:
+        r = rng.random()
+        if r < 0.55:
+            out += rng.choice(cjk).encode()
+        elif r < 0.70:
+            out += rng.choice("abcxyz").encode()
+        elif r < 0.82:
+            out += rng.choice([" ", " ", "\n", "\t", "  "]).encode()
+        elif kind != "pure" and r < 0.90:
+            out += rng.choice(odd).encode()
+        elif kind == "dirty" and r < 0.96:
+            out += rng.choice(bad)
+        else:
+            out += rng.choice(cjk).encode() * rng.randint(1, 5)
+    return bytes(out[:n])
+
+
 def alphabet_for(text, coverage=1.0, n_special=4):
     cps, cnts, dl = O.char_hist(text)
     acp, aid, rem = O.alphabet(cps, cnts, dl, coverage, n_special)

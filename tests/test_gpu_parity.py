@@ -27,6 +27,21 @@ def test_k1_char_hist():
         S.check_char_hist(t)
 
 
+def test_front_end_three_byte_fast_path(monkeypatch):
+    """The same check as tests/test_sim_stages.py on the MI355X, larger texts (hundreds of workgroups; the wide-char K1 variant picked by
+    the sample of the text as well as forced either way)."""
+    rng = random.Random(6)
+    for n in (4097, 70000, 300000, 1200000):
+        t = S.three_byte_text(rng, n)
+        S.check_char_hist(t)
+        for wide in ("0", "1"):
+            monkeypatch.setenv("YTTM_K1_WIDE", wide)
+            S.check_char_hist(t)
+        monkeypatch.delenv("YTTM_K1_WIDE")
+        if n <= 300000 and t.strip():
+            S.check_word_table_and_pairs(t)
+
+
 def test_k2_k3_word_table_and_pair_count():
     for i, t in enumerate(S.texts_small(1, n=8, size=20000)):
         S.check_word_table_and_pairs(t, coverage=1.0 if i % 2 == 0 else 0.9)

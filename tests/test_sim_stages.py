@@ -17,6 +17,22 @@ def test_char_hist():
         S.check_char_hist(t)
 
 
+def test_front_end_three_byte_fast_path(monkeypatch):
+    """K1 / K2a classify a window of ASCII + three-byte chars four bytes per instruction (round 5); anything else in a lane's 24-byte window
+    takes the exact byte-by-byte path.  Counts, decode steps, segment starts and words must not depend on which path a lane took -- both K1
+    variants (wide chars in an LDS hash, or global atomics), texts below and above one 4 KB chunk."""
+    rng = random.Random(5)
+    for n in (50, 333, 4096, 4097, 9000, 20000):
+        for _ in range(2):
+            t = S.three_byte_text(rng, n)
+            for wide in ("0", "1"):
+                monkeypatch.setenv("YTTM_K1_WIDE", wide)
+                S.check_char_hist(t)
+            monkeypatch.delenv("YTTM_K1_WIDE")
+            if t.strip():
+                S.check_word_table_and_pairs(t)
+
+
 def test_word_table_and_pair_count():
     for i, t in enumerate(S.texts_small(1, n=4, size=2000)):
         S.check_word_table_and_pairs(t, coverage=1.0 if i % 2 == 0 else 0.9)

@@ -1158,7 +1158,7 @@ void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, u
   HIP_CHECK(hipMemsetAsync(c.d_tok, 0, ((size_t)c.n_tiles * c.slot + 64) * 4, st_));
   launch_tiles(uw_off, U, c.nom, tile_start, c.d_tile_word0, st_);
   launch_tile_len(tile_start, c.n_tiles, total, c.d_tile_len, st_);
-  launch_fill_tokens(d_text_, n_text_, d_cpmap_, space_id, uw_pos, uw_off, U, c.nom, c.slot, tile_start, c.d_tok, st_);
+  launch_fill_tokens(d_text_, n_text_, d_cpmap_, space_id, uw_pos, uw_off, U, c.nom, c.slot, tile_start, c.d_tok, st_, total);
   sync();
   DFREE(uw_off);
   DFREE(tile_start);

@@ -20,6 +20,42 @@ constexpr int LH_BINS = 2048;                          // LDS-private histogram 
 // byte k of the 24-byte register window W[6] (k is a compile-time constant after unrolling)
 #define WB(k) ((W[(k) >> 2] >> (8 * ((k)&3))) & 0xffu)
 
+// The 24-byte window W of a lane (4 bytes before its 16, 4 behind) as text of ASCII and "simple" three-byte chars: true iff every byte is
+// ASCII, a continuation byte, or a lead byte E1 / E3 .. EC / EE / EF, and for every position p in 2 .. 23: byte p is a continuation iff a
+// lead stands at p - 1 or p - 2 (so every lead that matters to bytes 4 .. 19 has its two continuations, and every continuation among them
+// belongs to a lead).  *cont: bit p = byte p is a continuation; *sp: bit p = byte p is ASCII white space (0x20, 9 .. 13).
+__device__ inline bool simple3_window(const uint32_t (&W)[6], uint32_t *cont, uint32_t *sp) {
+  uint32_t Cm = 0, Lm = 0, Sm = 0, bad = 0;
+#pragma unroll
+  for (int w = 0; w < 6; w++) {
+    const uint32_t x = W[w];
+    const uint32_t hi = x & 0x80808080u;                  // bytes >= 0x80
+    const uint32_t c = hi & ~(x << 1);                    // 10xxxxxx (the shift moves bit 6 onto bit 7 of its own byte)
+    const uint32_t l = hi & (x << 1);                     // 11xxxxxx
+    const uint32_t e = l & (x << 2) & ~(x << 3);          // 1110xxxx
+    bad |= l & ~e;                                        // a lead byte of a two- or four-byte char, or F8 .. FF
+    // E0 (overlong forms), E2 (U+2581, the white-space marker, lives there), ED (surrogates): exact zero-byte tests of x ^ the byte
+    uint32_t t = x ^ 0xE0E0E0E0u;
+    bad |= ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;
+    t = x ^ 0xE2E2E2E2u;
+    bad |= ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;
+    t = x ^ 0xEDEDEDEDu;
+    bad |= ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;
+    // ASCII white space (k_scan_bytes' ASCII path has the derivation; here bytes >= 0x80 exist and are masked out)
+    t = x ^ 0x20202020u;
+    const uint32_t eq = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;
+    const uint32_t d = (x | 0x80808080u) - 0x09090909u;
+    const uint32_t lt5 = ~((d & 0x7f7f7f7fu) + 0x7b7b7b7bu) & 0x80808080u;
+    const uint32_t f = (eq | (d & lt5)) & ~hi & 0x80808080u;
+    Cm |= ((((c >> 7) & 0x01010101u) * 0x01020408u) >> 24) << (4 * w);
+    Lm |= ((((e >> 7) & 0x01010101u) * 0x01020408u) >> 24) << (4 * w);
+    Sm |= ((((f >> 7) & 0x01010101u) * 0x01020408u) >> 24) << (4 * w);
+  }
+  *cont = Cm;
+  *sp = Sm;
+  return bad == 0u && ((Cm ^ ((Lm << 1) | (Lm << 2))) & 0x00fffffcu) == 0u;
+}
+
 // MODE 0: histogram + number of decode steps + number of segment starts.
 // MODE 1: append the byte offsets of segment starts (a segment = maximal run of non-space chars) to seg_pos.
 // HK (MODE 0): slots of an LDS hash code point -> count for the chars beyond the direct bins.  A text of three-byte chars (CJK: a few
@@ -51,6 +87,28 @@ __global__ __launch_bounds__(BLOCK) void k_scan_bytes(const uint8_t *__restrict_
     for (int b = tid; b < HK; b += BLOCK) { hkey[b] = 0; hval[b] = 0; }
   }
   unsigned long long my_steps = 0, my_segs = 0;
+  // one char beyond the direct bins (cp >= 0x800): the workgroup's LDS hash first, the global histogram for what finds no slot there
+  auto count_wide = [&](uint32_t cp) {
+    bool done = false;
+    if (HK) {  // (cp >= 0x800: never 0, the empty key)
+      unsigned int h = (cp * 0x9E3779B1u) & (unsigned int)(HK - 1);
+      h ^= (cp * 0x9E3779B1u) >> 19;
+      h &= (unsigned int)(HK - 1);
+      for (int probe = 0; probe < 4 && !done; probe++) {
+        unsigned int kcur = __hip_atomic_load(&hkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (kcur == 0u) {
+          kcur = atomicCAS(&hkey[h], 0u, cp);
+          if (kcur == 0u) kcur = cp;
+        }
+        if (kcur == cp) {
+          atomicAdd(&hval[h], 1u);
+          done = true;
+        }
+        h = (h + 1) & (unsigned int)(HK - 1);
+      }
+    }
+    if (!done) atomicAdd(&hist[cp], 1ull);
+  };
   const unsigned long long first_chunk = chunk_lo + blockIdx.x;
   for (unsigned long long chunk = first_chunk; chunk < chunk_hi; chunk += gridDim.x) {
     const unsigned long long c0 = chunk * FE_CHUNK;
@@ -96,6 +154,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_bytes(const uint8_t *__restrict_
     }
     uint32_t seg_mask = 0;  // bit j: byte i0+j starts a segment
     uint32_t n_starts = 0;
+    uint32_t s3_cont = 0, s3_sp = 0;
     const bool all_ascii = ((W[0] | W[1] | W[2] | W[3] | W[4] | W[5]) & 0x80808080u) == 0;
     if (all_ascii && i0 + 20 <= n) {
       // ASCII text, four bytes per instruction: every byte is a char (16 decode steps); a byte is white space iff it is 0x20 or in
@@ -122,6 +181,29 @@ __global__ __launch_bounds__(BLOCK) void k_scan_bytes(const uint8_t *__restrict_
 #pragma unroll
         for (int k = 0; k < 16; k++)
           if (!((sp16 >> k) & 1u)) atomicAdd(&mine[WB(4 + k)], 1u);
+      }
+    } else if (i0 + 20 <= n && simple3_window(W, &s3_cont, &s3_sp)) {
+      // Text of three-byte chars (CJK: E4 .. E9 leads) with ASCII in between, round 5.  The byte-by-byte path below decodes at EVERY position
+      // -- a continuation byte looks back for its lead and decodes that -- ~35 instructions per byte: 22 ms per GB of such text against 0.8
+      // for ASCII.  Here the lane's 24-byte window is classified four bytes per instruction (simple3_window): every byte is ASCII, a
+      // continuation, or a lead E1 / E3 .. EC / EE / EF (with two continuations, such a lead IS a valid char: no overlong forms, no
+      // surrogates, never U+2581), and the leads and continuations fit together.  Then a char starts at every byte that is no continuation,
+      // white space is ASCII white space, and only the leads' code points have to be put together.  Any other byte in the window (two- and
+      // four-byte leads, E0 / E2 / ED, stray continuations) sends the lane to the exact path -- same counts, same starts.
+      const uint32_t own_start = (~s3_cont >> 4) & 0xffffu;  // bit j: byte i0 + j starts a char
+      const uint32_t sp16 = (s3_sp >> 4) & 0xffffu;          // bit j: byte i0 + j is (ASCII) white space
+      const uint32_t prev0 = (i0 == 0 || ((s3_sp >> 3) & 1u)) ? 1u : 0u;
+      seg_mask = own_start & ~sp16 & ((sp16 << 1) | prev0);
+      n_starts = (uint32_t)__popc(own_start);
+      if (MODE == 0) {
+        unsigned int *mine = &lc[(tid & (LC_COPIES - 1)) * LC_STRIDE];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          if (!((own_start >> k) & 1u) || ((sp16 >> k) & 1u)) continue;
+          const uint32_t b = WB(4 + k);
+          if (b < 0x80u) atomicAdd(&mine[b], 1u);
+          else count_wide(((b & 0x0fu) << 12) | ((WB(5 + k) & 0x3fu) << 6) | (WB(6 + k) & 0x3fu));
+        }
       }
     } else if (i0 < n) {
 #pragma unroll
@@ -159,25 +241,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_bytes(const uint8_t *__restrict_
                 } else if (cp < (uint32_t)LH_BINS) {
                   atomicAdd(&lh[cp], 1u);
                 } else {
-                  bool done = false;
-                  if (HK) {  // (cp >= 0x800: never 0, the empty key)
-                    unsigned int h = (cp * 0x9E3779B1u) & (unsigned int)(HK - 1);
-                    h ^= (cp * 0x9E3779B1u) >> 19;
-                    h &= (unsigned int)(HK - 1);
-                    for (int probe = 0; probe < 4 && !done; probe++) {
-                      unsigned int kcur = __hip_atomic_load(&hkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                      if (kcur == 0u) {
-                        kcur = atomicCAS(&hkey[h], 0u, cp);
-                        if (kcur == 0u) kcur = cp;
-                      }
-                      if (kcur == cp) {
-                        atomicAdd(&hval[h], 1u);
-                        done = true;
-                      }
-                      h = (h + 1) & (unsigned int)(HK - 1);
-                    }
-                  }
-                  if (!done) atomicAdd(&hist[cp], 1ull);
+                  count_wide(cp);
                 }
               }
             }
@@ -733,7 +797,11 @@ __global__ __launch_bounds__(BLOCK) void k2g_tile_len(const unsigned long long *
 // coalesced 256-byte writes: a thread storing its word token by token produced 8.4 GB of HBM write traffic for 1 GB of tokens
 // (partial sectors evicted from L2 between the stores).  Words that do not fit the window (classes B and C) are written
 // directly.
-constexpr int FILL_CAP = 2048;  // tokens per wavefront window
+// FILL_CAP: tokens per wavefront window.  2048 for ordinary words (64 words of a few tokens and the odd tile gap); 4096 where words are long
+// -- CJK-shaped text, clauses of ~40 chars: 64 of them and the tile gaps between span ~4600 slots, and while one word behind the window sent
+// the WHOLE wave the direct way (round 4) nearly every wave of such a corpus wrote its tokens one 4-byte store per lane and word position:
+// 16 ms of token fill per GB.  Round 5: the lanes whose word lies inside the window use it, the others write directly.
+template <int FILL_CAP>
 __global__ __launch_bounds__(BLOCK) void k2e_fill_tokens(const uint8_t *__restrict__ text, unsigned long long n,
                                                          const uint32_t *__restrict__ cpmap, uint32_t space_id,
                                                          const unsigned long long *__restrict__ uw_pos,
@@ -801,17 +869,18 @@ __global__ __launch_bounds__(BLOCK) void k2e_fill_tokens(const uint8_t *__restri
     }
   }
   wave_sync();
-  if (__ballot(overflow) == 0ull) {
-    uint32_t end = have ? (uint32_t)rel + cnt : 0u;  // the window ends behind the last word
+  {
+    // the window ends behind the last word that lies in it (a word that ran out of window mid-way left a correct prefix there: harmless,
+    // the direct path below writes the same tokens again)
+    uint32_t end = have && !overflow ? (uint32_t)rel + cnt : 0u;
     for (int d = 32; d > 0; d >>= 1) {
       const uint32_t other = __shfl_down(end, d);
       end = other > end ? other : end;
     }
     end = __shfl(end, 0);
     for (uint32_t k = (uint32_t)lane; k < end; k += 64) tok[o_base + k] = stage[k];  // (zeros in the gaps: tile tails are zero)
-    return;
   }
-  if (!have) return;
+  if (!have || !overflow) return;
   unsigned long long i = i0;
   tok[o++] = space_id | TOK_WS;
   while (i < n) {
@@ -897,10 +966,15 @@ unsigned long long scan_scratch_blocks(unsigned long long n) {
 }
 void launch_fill_tokens(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, uint32_t space_id,
                         const unsigned long long *uw_pos, const unsigned long long *uw_off, unsigned int n_words, unsigned int nom,
-                        unsigned int slot, const unsigned long long *tile_start, uint32_t *tok, hipStream_t st) {
+                        unsigned int slot, const unsigned long long *tile_start, uint32_t *tok, hipStream_t st, unsigned long long total_tokens) {
   if (!n_words) return;
-  hipLaunchKernelGGL(k2e_fill_tokens, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, text, n, cpmap, space_id, uw_pos,
-                     uw_off, n_words, nom, slot, tile_start, tok);
+  // (the window's size by the words' average length: 64 words of 24 tokens and more, with the tile gaps between, outgrow 2048 slots)
+  if (total_tokens / n_words >= 24)
+    hipLaunchKernelGGL(k2e_fill_tokens<4096>, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, text, n, cpmap, space_id, uw_pos,
+                       uw_off, n_words, nom, slot, tile_start, tok);
+  else
+    hipLaunchKernelGGL(k2e_fill_tokens<2048>, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, text, n, cpmap, space_id, uw_pos,
+                       uw_off, n_words, nom, slot, tile_start, tok);
 }
 void launch_tiles(const unsigned long long *uw_off, unsigned int n_words, unsigned int nom, unsigned long long *tile_start,
                   uint32_t *tile_word0, hipStream_t st) {

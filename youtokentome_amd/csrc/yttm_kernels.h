@@ -52,7 +52,8 @@ void launch_exclusive_scan(const uint32_t *in, unsigned long long n, unsigned lo
 unsigned long long scan_scratch_blocks(unsigned long long n);
 void launch_fill_tokens(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, uint32_t space_id,
                         const unsigned long long *uw_pos, const unsigned long long *uw_off, unsigned int n_words, unsigned int nom,
-                        unsigned int slot, const unsigned long long *tile_start, uint32_t *tok, hipStream_t st);
+                        unsigned int slot, const unsigned long long *tile_start, uint32_t *tok, hipStream_t st,
+                        unsigned long long total_tokens /* of these words: picks the size of the wavefronts' LDS windows */);
 void launch_tiles(const unsigned long long *uw_off, unsigned int n_words, unsigned int nom, unsigned long long *tile_start,
                   uint32_t *tile_word0, hipStream_t st);
 void launch_tile_len(const unsigned long long *tile_start, unsigned int n_tiles, unsigned long long total_tokens, uint32_t *tile_len,
