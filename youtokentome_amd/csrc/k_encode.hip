@@ -6,6 +6,8 @@
 // wavefront runs those rounds for ALL words of its sentence at once: lanes = token positions, word-segmented minimum
 // through LDS atomics, x==x runs resolved by parity from the run start, in-place compaction with wave ballots.
 // Working arrays live in LDS (3 x 4 B per token); sentences too long for LDS use an HBM scratch with the same code.
+#include <type_traits>
+
 #include "yttm_device.h"
 #include "yttm_kernels.h"
 
@@ -85,6 +87,14 @@ __device__ inline void enc_pair_prio2(const EncModel &m, const uint32_t *bloom, 
   }
 }
 
+// id of the token that rule r creates.  Trained models number merged tokens consecutively in rule order, skipping the
+// (<= 4) special ids (bpe.cpp:814-837), so z is r + z_base + #{breakpoints <= r}; a hand-made model without that
+// structure reads the table instead.
+__device__ inline uint32_t enc_rule_z(const EncModel &m, uint32_t r) {
+  if (!m.z_affine) return m.rule_z[r];
+  return m.z_base + r + (r >= m.z_bp[0]) + (r >= m.z_bp[1]) + (r >= m.z_bp[2]) + (r >= m.z_bp[3]);
+}
+
 // ---- BPE-dropout (bpe.cpp:1417-1453 DropoutQueue + :1560-1589) --------------------------------------------------------
 // Exact per-word process of the reference: events (rule index, position) in priority order; every pop walks the queue,
 // each event is skipped with probability p, the first one not skipped is taken (stale events included: they consume the
@@ -97,6 +107,8 @@ struct DropoutArgs {
   int enabled, always_skip;
   int heap_from;            // words of at least this many tokens keep their events in a binary heap instead of a sorted array
   int lds_queues;           // packs of up to ENC_DROP_WCAP tokens keep their event queues in LDS (EvLds)
+  int sorted_queue;         // short words keep their events in the sorted array of rounds 3 - 4 instead of the unsorted bag (differential test)
+  int pack_links;           // working arrays in LDS: both links of a position in one word, the third array holds the pairs' rules (dropout_merge)
   uint32_t *wsl;            // [cap] word start positions
   unsigned long long *ev;   // [3*cap] sorted event queues, word w owns [3*ws, 3*we)
 };
@@ -181,6 +193,13 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
   const int lane = lane_id();
   const unsigned long long lt = lanemask_lt();
   constexpr uint32_t DEAD = 0xffffffffu, NIL = 0xffffffffu;
+  // Round 5: a merge cost three dependent global round trips per lane -- rule_xy[rule] to see whether the popped event is stale, rule_z[rule]
+  // for the new token, then the two new pairs' rule-hash slots -- and a wave waits for its longest word.  With the working arrays in LDS
+  // (positions below 512) both links of a position share one word (next | prev << 16) and the third array holds the RULE of the pair that
+  // starts at each position: an event (rule r at p) is live iff that is still r -- the same test as "the tokens are the rule's x and y"
+  // (bpe.cpp:1569-1572: a pair has one rule, a rule one pair) -- and z comes from the rule's number (enc_rule_z).  One trip per merge is left.
+  const bool PACK = std::is_same<A, LdsArr>::value && d.pack_links;  // (YTTM_DROPOUT_NO_PACK: the three-trip scheme, for the differential test)
+  constexpr uint32_t NIL16 = 0xffffu;
   // word starts
   int nw = 0;
   for (int c = 0; c < ((n + 63) >> 6); c++) {
@@ -222,15 +241,27 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
     const int cap = 3 * (we - ws);             // the word's share of the queue space: every event it can ever hold
     const bool heap = we - ws >= d.heap_from;  // (skipped events of a pop wait at the top end of that space)
     int ne = 0;
+    // Short words (the usual case) keep their events in an UNSORTED bag (round 5): adding is an append, removing a swap with the last, and a
+    // pop looks for the smallest event by a scan whose LDS reads are independent of each other -- with p = 0.1 a pop examines 1.1 events on
+    // average.  The sorted array of rounds 3 - 4 paid a chain of dependent LDS round trips per insertion and removal (read, compare, shift:
+    // ~100 cycles a step, two insertions and a removal per merge); the order events are EXAMINED in -- ascending (rule, position), equal events
+    // being interchangeable -- and so every draw and every id is the same (YTTM_DROPOUT_SORTED=1 keeps the array: the differential test).
+    const bool bag = !heap && !d.sorted_queue;
     auto add = [&](unsigned long long key) {
       if (heap) heap_push(ev, ne, key);
+      else if (bag) ev.set(ne++, key);
       else ev_insert(ev, ne, key);
     };
     for (int i = ws; i < we; i++) {
       const uint32_t r = wm.get(i);
       if (i + 1 < we && r != ENC_INF) add(((unsigned long long)r << 32) | (unsigned long long)i);
-      wr.set(i, i + 1 < we ? (uint32_t)(i + 1) : NIL);
-      wm.set(i, i > ws ? (uint32_t)(i - 1) : NIL);
+      if (PACK) {
+        wr.set(i, (i + 1 < we ? (uint32_t)(i + 1) : NIL16) | ((i > ws ? (uint32_t)(i - 1) : NIL16) << 16));
+        wm.set(i, i + 1 < we ? r : ENC_INF);  // the rule of the pair (i, i + 1)
+      } else {
+        wr.set(i, i + 1 < we ? (uint32_t)(i + 1) : NIL);
+        wm.set(i, i > ws ? (uint32_t)(i - 1) : NIL);
+      }
     }
     uint32_t draw = 0;
     for (;;) {
@@ -246,6 +277,32 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
         }
         for (int k = 0; k < ns; k++) heap_push(ev, ne, ev.get(cap - 1 - k));
         if (!found) break;
+      } else if (bag) {
+        // the events in ascending order until one is not skipped: each step = the smallest (event, index) above the one examined before
+        unsigned long long prev_key = 0ull;
+        int prev_idx = -1, acc = -1;
+        for (;;) {
+          unsigned long long best = ~0ull;
+          int best_idx = -1;
+          for (int j = 0; j < ne; j++) {
+            const unsigned long long k = ev.get(j);
+            if ((k > prev_key || (k == prev_key && j > prev_idx)) && k < best) {
+              best = k;
+              best_idx = j;
+            }
+          }
+          if (best_idx < 0) break;  // every event examined and skipped
+          if (!drop_skip(d, sidx, (uint32_t)w, draw++)) {
+            acc = best_idx;
+            e = best;
+            break;
+          }
+          prev_key = best;
+          prev_idx = best_idx;
+        }
+        if (acc < 0) break;  // every event skipped: the word is finished (bpe.cpp:1431-1437)
+        ne--;
+        if (acc != ne) ev.set(acc, ev.get(ne));
       } else {
         int acc = -1;
         for (int j = 0; j < ne; j++) {
@@ -258,14 +315,33 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
       }
       const uint32_t rule = (uint32_t)(e >> 32);
       const int p1 = (int)(uint32_t)e;
+      const uint32_t t1 = wt.get(p1);
+      if (PACK) {
+        if (t1 == DEAD || wm.get(p1) != rule) continue;  // stale (:1569-1572): the position is gone, or its pair is no longer this rule's
+        const uint32_t l1 = wr.get(p1);
+        const uint32_t p2 = l1 & 0xffffu, p0 = l1 >> 16;   // (p2 exists: the last position of a word never has a rule)
+        const uint32_t p3 = wr.get((int)p2) & 0xffffu;
+        const uint32_t zt = enc_rule_z(m, rule);
+        wt.set((int)p2, DEAD);
+        wt.set(p1, zt | (t1 & (TOK_WS | ENC_SENT)));
+        wr.set(p1, p3 | (p0 << 16));
+        if (p3 != NIL16) wr.set((int)p3, (wr.get((int)p3) & 0xffffu) | ((uint32_t)p1 << 16));
+        // the two pairs the merge made (:1580-1585), their rule-hash loads in flight together
+        uint32_t rl, rr;
+        enc_pair_prio2(m, nullptr, p0 != NIL16, p0 != NIL16 ? wt.get((int)p0) & ENC_IDM : 0u, zt, p3 != NIL16, zt, p3 != NIL16 ? wt.get((int)p3) & ENC_IDM : 0u, &rl, &rr);
+        if (p0 != NIL16) wm.set((int)p0, rl);
+        wm.set(p1, rr);
+        if (rl != ENC_INF) add(((unsigned long long)rl << 32) | (unsigned long long)p0);
+        if (rr != ENC_INF) add(((unsigned long long)rr << 32) | (unsigned long long)p1);
+        continue;
+      }
       const uint32_t p2 = wr.get(p1);
       const unsigned long long xy = m.rule_xy[rule];
-      const uint32_t t1 = wt.get(p1);
       if (t1 == DEAD || (t1 & ENC_IDM) != (uint32_t)(xy >> 32) || p2 == NIL || (wt.get((int)p2) & ENC_IDM) != (uint32_t)xy) continue;  // :1569-1572
       const uint32_t p0 = wm.get(p1), p3 = wr.get((int)p2);
       wt.set((int)p2, DEAD);
       wr.set((int)p2, NIL);
-      wt.set(p1, m.rule_z[rule] | (t1 & (TOK_WS | ENC_SENT)));
+      wt.set(p1, enc_rule_z(m, rule) | (t1 & (TOK_WS | ENC_SENT)));
       wr.set(p1, p3);
       if (p3 != NIL) wm.set((int)p3, (uint32_t)p1);
       {  // the two pairs the merge made (:1580-1585), their rule-hash loads in flight together
@@ -348,13 +424,6 @@ __device__ int enc_tokenize(const EncModel &m, const uint8_t *__restrict__ s, un
   return n;
 }
 
-// id of the token that rule r creates.  Trained models number merged tokens consecutively in rule order, skipping the
-// (<= 4) special ids (bpe.cpp:814-837), so z is r + z_base + #{breakpoints <= r}; a hand-made model without that
-// structure reads the table instead.
-__device__ inline uint32_t enc_rule_z(const EncModel &m, uint32_t r) {
-  if (!m.z_affine) return m.rule_z[r];
-  return m.z_base + r + (r >= m.z_bp[0]) + (r >= m.z_bp[1]) + (r >= m.z_bp[2]) + (r >= m.z_bp[3]);
-}
 
 // Merge rounds of the deterministic encoder over the n tokens in wt (words = TOK_WS segments; sentence boundaries are word
 // boundaries, so several sentences can share the arrays).  Returns the new token count.
@@ -982,7 +1051,9 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   unsigned long long group = n_sent / ((unsigned long long)n_blocks * ENC_WAVES * 4);
   if (group < 1) group = 1;
   if (group > 24) group = 24;
-  d.lds_queues = m.n_rules < (1u << 23) && !C->dropout_hbm_queues.set;  // (tests: every queue in the HBM scratch)
+  d.lds_queues = m.n_rules < (1u << 23) && !C->dropout_hbm_queues.set;
+  d.pack_links = !C->dropout_no_pack.set;
+  d.sorted_queue = C->dropout_sorted.set ? 1 : 0;  // (tests: every queue in the HBM scratch)
   // one word per lane (merge_lanes) for packs whose words have at most this many tokens; 0 = the wave-wide rounds only.
   // YTTM_K5_LANE_WORDS: the word cache's distinct words, YTTM_K5_LANE_SENT: packed sentences
   const int lane_max = ends ? (int)C->k5_lane_words.i : (int)C->k5_lane_sent.i;

@@ -797,10 +797,11 @@ __global__ __launch_bounds__(BLOCK) void k2g_tile_len(const unsigned long long *
 // coalesced 256-byte writes: a thread storing its word token by token produced 8.4 GB of HBM write traffic for 1 GB of tokens
 // (partial sectors evicted from L2 between the stores).  Words that do not fit the window (classes B and C) are written
 // directly.
-// FILL_CAP: tokens per wavefront window.  2048 for ordinary words (64 words of a few tokens and the odd tile gap); 4096 where words are long
-// -- CJK-shaped text, clauses of ~40 chars: 64 of them and the tile gaps between span ~4600 slots, and while one word behind the window sent
-// the WHOLE wave the direct way (round 4) nearly every wave of such a corpus wrote its tokens one 4-byte store per lane and word position:
-// 16 ms of token fill per GB.  Round 5: the lanes whose word lies inside the window use it, the others write directly.
+// FILL_CAP: tokens per wavefront window: enough for 64 ordinary words and the odd tile gap.  Where words are long -- CJK-shaped text,
+// clauses of ~40 chars: 64 of them and the tile gaps between span ~4600 slots -- one word behind the window used to send the WHOLE wave the
+// direct way (round 4), one 4-byte store per lane and word position: 16 ms of token fill per GB.  Round 5: the lanes whose word lies inside
+// the window use it, the others write directly, four tokens per store where the slot's alignment allows.  (A window of 4096 was measured:
+// 64 KB of LDS per workgroup halve the waves per CU, and the byte-serial decode is latency-bound: 16.1 -> 21.4 ms.)
 template <int FILL_CAP>
 __global__ __launch_bounds__(BLOCK) void k2e_fill_tokens(const uint8_t *__restrict__ text, unsigned long long n,
                                                          const uint32_t *__restrict__ cpmap, uint32_t space_id,
@@ -882,17 +883,36 @@ __global__ __launch_bounds__(BLOCK) void k2e_fill_tokens(const uint8_t *__restri
   }
   if (!have || !overflow) return;
   unsigned long long i = i0;
-  tok[o++] = space_id | TOK_WS;
+  uint32_t b0 = 0, b1 = 0, b2 = 0;  // tokens on their way out: a 16-byte store once the position is 16-byte aligned and four are there
+  int nb = 0;                       // (three named registers, not an array: a dynamically indexed one would live in scratch)
+  auto put = [&](uint32_t v) {
+    if ((o & 3ull) != 0ull && nb == 0) {  // (up to the first aligned position: one at a time)
+      tok[o++] = v;
+      return;
+    }
+    if (nb == 0) b0 = v;
+    else if (nb == 1) b1 = v;
+    else if (nb == 2) b2 = v;
+    if (++nb == 4) {
+      *reinterpret_cast<uint4 *>(tok + o) = make_uint4(b0, b1, b2, v);
+      o += 4;
+      nb = 0;
+    }
+  };
+  put(space_id | TOK_WS);
   while (i < n) {
     uint32_t len;
     uint32_t cp = u8_decode_at(text, i, n, &len);
     if (cp != INVALID_CP) {
       uint32_t id = cpmap[cp];
       if (id == CP_SPACE) break;
-      if (id != CP_DROP) tok[o++] = id;
+      if (id != CP_DROP) put(id);
     }
     i += len;
   }
+  if (nb > 0) tok[o] = b0;
+  if (nb > 1) tok[o + 1] = b1;
+  if (nb > 2) tok[o + 2] = b2;
 }
 
 // ------------------------------------------------------------------------------------------------- launchers
@@ -968,13 +988,9 @@ void launch_fill_tokens(const uint8_t *text, unsigned long long n, const uint32_
                         const unsigned long long *uw_pos, const unsigned long long *uw_off, unsigned int n_words, unsigned int nom,
                         unsigned int slot, const unsigned long long *tile_start, uint32_t *tok, hipStream_t st, unsigned long long total_tokens) {
   if (!n_words) return;
-  // (the window's size by the words' average length: 64 words of 24 tokens and more, with the tile gaps between, outgrow 2048 slots)
-  if (total_tokens / n_words >= 24)
-    hipLaunchKernelGGL(k2e_fill_tokens<4096>, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, text, n, cpmap, space_id, uw_pos,
-                       uw_off, n_words, nom, slot, tile_start, tok);
-  else
-    hipLaunchKernelGGL(k2e_fill_tokens<2048>, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, text, n, cpmap, space_id, uw_pos,
-                       uw_off, n_words, nom, slot, tile_start, tok);
+  (void)total_tokens;
+  hipLaunchKernelGGL(k2e_fill_tokens<2048>, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, text, n, cpmap, space_id, uw_pos,
+                     uw_off, n_words, nom, slot, tile_start, tok);
 }
 void launch_tiles(const unsigned long long *uw_off, unsigned int n_words, unsigned int nom, unsigned long long *tile_start,
                   uint32_t *tile_word0, hipStream_t st) {

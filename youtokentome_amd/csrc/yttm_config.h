@@ -94,6 +94,8 @@ struct Hook {
   X(dropout_seed, "YTTM_DROPOUT_SEED", "", "test", "fixes the per-encoder salt of the BPE-dropout RNG (default: std::random_device)")      \
   X(dropout_heap_from, "YTTM_DROPOUT_HEAP_FROM", "256", "path", "words of at least this many tokens keep their dropout events in a heap")  \
   X(dropout_hbm_queues, "YTTM_DROPOUT_HBM_QUEUES", "", "path", "set: dropout event queues in the HBM scratch, not LDS")                    \
+  X(dropout_sorted, "YTTM_DROPOUT_SORTED", "", "path", "set: short words' dropout events in a sorted array (rounds 3-4) instead of the unsorted bag") \
+  X(dropout_no_pack, "YTTM_DROPOUT_NO_PACK", "", "path", "set: dropout merges test an event against rule_xy and read rule_z (round 4's three trips per merge)") \
   X(k5_lane_words, "YTTM_K5_LANE_WORDS", "48", "path", "one-word-per-lane for the cache's distinct words up to this many tokens (0: wave-wide rounds)") \
   X(k5_lane_sent, "YTTM_K5_LANE_SENT", "48", "path", "... for packed sentences")                                                            \
   X(k5_classes, "YTTM_K5_CLASSES", "4", "path", "length classes of the distinct-word list (<= 1: one)")                                     \
