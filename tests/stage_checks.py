@@ -472,15 +472,9 @@ def check_dropout_heap_equals_array(model="readme_small", seed=29):
         os.environ["YTTM_DROPOUT_SEED"] = "12345"
         for p in (0.0, 0.1, 0.5, 0.9, 1.0):
             got = []
-            for heap_from, hbm, no_pack, srt in (("1000000000", False, False, False), ("0", False, False, False), ("256", False, False, False), ("256", True, False, False),
-                                                 ("0", True, False, False), ("256", False, True, False), ("0", True, True, False), ("1000000000", False, False, True),
-                                                 ("256", True, True, True)):
+            for heap_from, hbm, no_pack in (("1000000000", False, False), ("0", False, False), ("256", False, False), ("256", True, False), ("0", True, False),
+                                            ("256", False, True), ("0", True, True)):
                 os.environ["YTTM_DROPOUT_HEAP_FROM"] = heap_from
-                # (round 5: short words' events in an unsorted bag, popped by a scan for the smallest -- against the sorted array of rounds 3 - 4)
-                if srt:
-                    os.environ["YTTM_DROPOUT_SORTED"] = "1"
-                else:
-                    os.environ.pop("YTTM_DROPOUT_SORTED", None)
                 # (round 5: an event is live iff its position's pair still has the event's rule, both links of a position in one word -- against
                 # round 4's test on rule_xy with separate link arrays: same pops, same draws, same ids)
                 if no_pack:
@@ -495,7 +489,6 @@ def check_dropout_heap_equals_array(model="readme_small", seed=29):
                 got.append(bpe.encode(sents, yttm.OutputType.ID, dropout_prob=p))
             os.environ.pop("YTTM_DROPOUT_HBM_QUEUES", None)
             os.environ.pop("YTTM_DROPOUT_NO_PACK", None)
-            os.environ.pop("YTTM_DROPOUT_SORTED", None)
             assert all(g == got[0] for g in got), p
         os.environ["YTTM_DROPOUT_HEAP_FROM"] = "256"
         bpe = yttm.BPE(model_path)

@@ -442,6 +442,28 @@ def test_zz_full_size_pins(tmp_path):
     L.yttm_encoder_destroy(h)
 
 
+@pytest.mark.parametrize("name,chunk_mb", [("c2_100mb", "16"), ("c3_100mb", "8")])
+def test_zz_chunked_front_end_100mb_pins(name, chunk_mb, tmp_path, monkeypatch):
+    """The chunked front end (gpu_ctx.cpp front_end_chunked) at a size where chunks are thousands of workgroups: the 100 MB variants of
+    configs[1] / configs[2] in chunks of 16 / 8 MB -- the lexicon and the word table grow on the way -- must give the reference's models."""
+    import ctypes as C
+    import hashlib
+    import json
+    from youtokentome_amd import _lib
+    pin = _full_pins()[name]
+    text = gen.abcd_corpus(pin["corpus_bytes"] + 1, seed=19, survey_stream=True) if name == "c2_100mb" else gen.zipf_corpus_fast(100_000_000, seed=7, vocab=400000)
+    assert hashlib.md5(text).hexdigest() == pin["corpus_md5"]
+    corpus, model = str(tmp_path / "c.txt"), str(tmp_path / "c.model")
+    open(corpus, "wb").write(text)
+    monkeypatch.setenv("YTTM_FE_CHUNK_MB", chunk_mb)
+    L = _lib.load()
+    err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+    assert L.yttm_train_bpe_ex(corpus.encode(), model.encode(), pin["vocab_size"], 1.0, 8, 0, 1, 2, 3, 0, rep, 16384, err, 2048) == 0, err.value
+    r = json.loads(rep.value.decode())
+    assert r["front_end_chunks"] >= 100 // int(chunk_mb) and r["front_end_overlapped"] == 1
+    assert hashlib.md5(open(model, "rb").read()).hexdigest() == pin["model_md5"]
+
+
 def test_zz_rccl_world_of_one(tmp_path):
     """The RCCL transport of the multi-GPU path on the one GPU there is: a communicator of size 1 still runs every collective
     of a round (ncclAllReduce of the char histogram and of the hot-list verdict, the grouped send/recv all-gather after K3,

@@ -76,6 +76,22 @@ def test_front_end_under_the_upload_on_every_rank(tmp_path, sim_lib, world):
             assert filecmp.cmp(m_mp, m_ora, shallow=False), f"case {i} sharded={sharded}"
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_chunked_front_end_on_every_rank(tmp_path, sim_lib, world):
+    """A shard that does not fit a rank's HBM is taken in chunks there (gpu_ctx.cpp front_end_chunked); such a rank no longer holds its text,
+    so the replicated loop -- which gathers the shards -- is declined by the common verdict and every rank stays sharded: same model."""
+    rng = random.Random(70 + world)
+    env = {"YTTM_FE_CHUNK_KB": "2"}
+    for i, (text, vocab, cov) in enumerate([(gen.readme_corpus(300, 90, "abcdef ", seed=8), 260, 1.0), (gen.unicode_text(rng, 9000, "mix", p_invalid=0.01), 100, 0.85)]):
+        corpus, m_ora = str(tmp_path / f"c{i}.txt"), str(tmp_path / f"ora{i}.model")
+        open(corpus, "wb").write(text)
+        O.train(text, m_ora, vocab, cov)
+        for sharded in (True, False):
+            m_mp = str(tmp_path / f"mp{i}_{int(sharded)}.model")
+            run_world(corpus, m_mp, vocab, cov, world, sim_lib, dict(env, YTTM_TEST_EXPECT="front_end_chunks>1,replicated_merge_loop==0"), sharded=sharded)
+            assert filecmp.cmp(m_mp, m_ora, shallow=False), f"case {i} sharded={sharded}"
+
+
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_replicated_merge_loop_equals_single_oracle(tmp_path, sim_lib, world):
     """Small word tables (the library's own choice below 2^26 dedup tokens): the ranks dedup their shards, gather the shards into the

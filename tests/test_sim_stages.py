@@ -33,6 +33,44 @@ def test_front_end_three_byte_fast_path(monkeypatch):
                 S.check_word_table_and_pairs(t)
 
 
+def test_chunked_front_end(tmp_path, monkeypatch):
+    """Round 5: a corpus that does not fit the HBM left for it crosses the device in chunks cut at white space; only the distinct words' bytes
+    stay (a lexicon behind the chunk region), the word table grows by rehashing, and when coverage drops chars the source is read a second
+    time (gpu_ctx.cpp front_end_chunked).  Forced onto toy files with chunks of 4 KB and 8 KB: the model must be the oracle's -- ASCII, mixed
+    scripts with invalid bytes, coverage < 1, three-byte text, a file without a trailing newline, words seen more often than a weight holds;
+    the report says how many chunks there were."""
+    import ctypes as C
+    import filecmp
+    import json
+    import oracle_lib as O
+    from youtokentome_amd import _lib
+    rng = random.Random(3)
+    cases = [(gen.readme_corpus(300, 90, "abcdef ", seed=8), 300, 1.0), (gen.unicode_text(rng, 20000, "mix", p_invalid=0.01), 150, 1.0),
+             (gen.unicode_text(rng, 20000, "mix", p_invalid=0.01), 120, 0.85), (gen.zipf_corpus(60000, vocab=3000), 400, 1.0),
+             (S.three_byte_text(rng, 30000), 200, 1.0), (gen.readme_corpus(200, 90, "abcdef ", seed=9).rstrip(b"\n"), 200, 1.0)]
+    L = _lib.load()
+    for kb in ("4", "8"):
+        monkeypatch.setenv("YTTM_FE_CHUNK_KB", kb)
+        for i, (text, vocab, cov) in enumerate(cases):
+            corpus, m_gpu, m_ora = str(tmp_path / "c.txt"), str(tmp_path / "g.model"), str(tmp_path / "o.model")
+            open(corpus, "wb").write(text)
+            err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+            assert L.yttm_train_bpe_ex(corpus.encode(), m_gpu.encode(), vocab, cov, 1, 0, 1, 2, 3, 0, rep, 16384, err, 2048) == 0, err.value
+            O.train(text, m_ora, vocab, cov)
+            assert filecmp.cmp(m_gpu, m_ora, shallow=False), (kb, i)
+            r = json.loads(rep.value.decode())
+            assert r["front_end_chunks"] >= len(text) // (int(kb) << 10) and r["peak_device_bytes"] > 0, r
+    # from host memory, and a word heavier than a weight holds (the copies are made from the lexicon's bytes)
+    monkeypatch.setenv("YTTM_FE_CHUNK_KB", "4")
+    monkeypatch.setenv("YTTM_TEST_WCNT_MAX", "7")
+    text = gen.readme_corpus(300, 90, "ab ", seed=4)
+    err = C.create_string_buffer(2048)
+    m_gpu, m_ora = str(tmp_path / "g2.model"), str(tmp_path / "o2.model")
+    assert L.yttm_train_bpe_from_memory(text, len(text), m_gpu.encode(), 60, 1.0, 0, 1, 2, 3, 0, None, 0, err, 2048) == 0, err.value
+    O.train(text, m_ora, 60)
+    assert filecmp.cmp(m_gpu, m_ora, shallow=False)
+
+
 def test_word_table_and_pair_count():
     for i, t in enumerate(S.texts_small(1, n=4, size=2000)):
         S.check_word_table_and_pairs(t, coverage=1.0 if i % 2 == 0 else 0.9)

@@ -43,6 +43,7 @@ struct DevPool {
   std::multimap<size_t, PoolBlock> free_blocks;
   std::unordered_map<void *, size_t> live;
   size_t cached = 0;
+  size_t in_use = 0, peak = 0;  // bytes handed out / their high-water mark (GpuCtx::peak_device_bytes; only kept while the pool is on)
 };
 DevPool g_pool;
 void *g_pin_cached = nullptr;  // one pinned staging buffer (PIN_BYTES) kept between contexts
@@ -65,6 +66,8 @@ void *pool_alloc(size_t bytes) {
       void *p = b.p;
       g_pool.live[p] = b.bytes;
       g_pool.cached -= b.bytes;
+      g_pool.in_use += b.bytes;
+      g_pool.peak = std::max(g_pool.peak, g_pool.in_use);
       g_pool.free_blocks.erase(it);
       return p;
     }
@@ -84,6 +87,8 @@ void *pool_alloc(size_t bytes) {
   if (pool_enabled()) {
     std::lock_guard<std::mutex> g(g_pool.mu);
     g_pool.live[p] = bytes;
+    g_pool.in_use += bytes;
+    g_pool.peak = std::max(g_pool.peak, g_pool.in_use);
   }
   return p;
 }
@@ -95,6 +100,7 @@ void pool_free(void *p) {
     if (it != g_pool.live.end()) {
       const size_t bytes = it->second;
       g_pool.live.erase(it);
+      g_pool.in_use -= std::min(g_pool.in_use, bytes);
       if (g_pool.cached + bytes <= POOL_MAX_CACHED) {
         g_pool.free_blocks.emplace(bytes, PoolBlock{p, bytes, tl_stream, tl_device});
         g_pool.cached += bytes;
@@ -154,6 +160,10 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   cfg_ = cfg();
   const Config &C = *cfg_;
   xchg_margin_ = C.xchg_margin.d;
+  {
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    g_pool.peak = g_pool.in_use;
+  }
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
@@ -344,8 +354,23 @@ void GpuCtx::resolve_timers() {
 }
 
 // ------------------------------------------------------------------------------------------------- corpus
+unsigned long long GpuCtx::peak_device_bytes() const {
+  std::lock_guard<std::mutex> g(g_pool.mu);
+  return (unsigned long long)g_pool.peak;
+}
+
 void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
   drop_spec();
+  chunked_ = false;
+  if (chunk_bytes_for(n)) {  // (too large for the HBM that is free: in chunks, gpu_ctx.cpp front_end_chunked)
+    chunk_src_ = [host](void *dst, unsigned long long off, size_t len) {
+      memcpy(dst, host + off, len);
+      return true;
+    };
+    chunk_src_n_ = n;
+    front_end_chunked(true);
+    return;
+  }
   if ((n < (32u << 20) && !(cfg_->fe_overlap_min.set && overlap_front_end(n))) || cfg_->plain_upload.set) {  // small, or (tuning hook) the one-copy path for comparison
     HIP_CHECK(hipSetDevice(device_));
     tl_stream = st_;
@@ -794,6 +819,22 @@ void GpuCtx::upload_corpus_fd(int fd, unsigned long long lo, unsigned long long 
     }
     return true;
   };
+  chunked_ = false;
+  if (chunk_bytes_for(n)) {  // (too large for the HBM that is free: in chunks, front_end_chunked below; the descriptor stays open until the training is over)
+    drop_spec();
+    chunk_src_ = [fd, lo](void *dst, unsigned long long off, size_t len) {
+      size_t got = 0;
+      while (got < len) {
+        const ssize_t r = pread(fd, (char *)dst + got, len - got, (off_t)(lo + off + got));
+        if (r <= 0) return false;
+        got += (size_t)r;
+      }
+      return true;
+    };
+    chunk_src_n_ = n;
+    front_end_chunked(true);
+    return;
+  }
   if (overlap_front_end(n)) {
     upload_overlapped(n, from_file);
     return;
@@ -808,6 +849,217 @@ void GpuCtx::upload_corpus_fd(int fd, unsigned long long lo, unsigned long long 
     }
     return true;
   });
+}
+
+// ---- corpora larger than the HBM left for them (round 5; VERDICT r4 "missing" #2) --------------------------------------------------------
+// The reference's limit is host memory (fast_read_file_utf8, bpe.cpp:67-84); here the whole text, its segment starts (8 bytes per word) and
+// the word table had to sit in HBM together -- about six bytes per byte of text.  Nothing after the dedup needs the text, only the distinct
+// words: so a text that does not fit crosses the device in CHUNKS cut at white space (like the reference's per-thread split, bpe.cpp:864-873).
+// One buffer, [chunk region C bytes | 64 spaces | lexicon]: K1 and K2a see a chunk as they see a whole text; K2b inserts its words into the ONE
+// word table, `sub` segments per launch with the table grown (rehashed) ahead of a launch that could fill it beyond half; then k2b_relocate
+// copies the bytes of every word first seen in this chunk to the lexicon and points its slot there, and the next chunk overwrites the region.
+// At the end the "text" the rest of the trainer reads words from -- compaction, token fill -- is the lexicon: the same offsets into the same
+// buffer.  first_pass: K1 runs and words are compared by code points (upload_overlapped's speculation: right whenever the alphabet keeps every
+// char); else -- coverage dropped chars -- the source is read a second time with the real char map.  Peak HBM is C + the lexicon + the table +
+// 8 bytes per segment of one chunk, whatever the size of the file.
+unsigned long long GpuCtx::chunk_bytes_for(unsigned long long n) const {
+  unsigned long long c = cfg_->fe_chunk_kb.u ? cfg_->fe_chunk_kb.u << 10 : cfg_->fe_chunk_mb.u << 20;
+  if (!c) {
+    const unsigned long long free_b = free_device_bytes();
+    if (6 * n + (1ull << 30) <= free_b / 4 * 3) return 0;  // text + segment starts + word table + tiles fit at once
+    c = std::min<unsigned long long>(std::max<unsigned long long>(free_b / 24, 256ull << 20), 4ull << 30);
+  }
+  c = std::max<unsigned long long>(c / 4096 * 4096, 4096);
+  return n > c ? c : 0;
+}
+
+void GpuCtx::front_end_chunked(bool first_pass) {
+  HIP_CHECK(hipSetDevice(device_));
+  tl_stream = st_;
+  tl_device = device_;
+  const unsigned long long n = chunk_src_n_;
+  const auto &fill = chunk_src_;
+  unsigned long long C = (!first_pass && chunk_cap_) ? chunk_cap_ : chunk_bytes_for(n);  // (a second pass: the first one's size -- less memory is free now)
+  if (!C) C = std::max<unsigned long long>(n / 4096 * 4096 + 4096, 4096);
+  drop_spec();
+  DFREE(d_text_owned_);
+  chunked_ = true;
+  chunk_cap_ = C;
+  corpus_bytes = n;
+  // ---- where the chunks end: behind the last ASCII white space at or before start + C
+  std::vector<unsigned long long> cuts{0};
+  {
+    std::vector<uint8_t> win(1u << 16);
+    while (cuts.back() < n) {
+      const unsigned long long b0 = cuts.back();
+      unsigned long long b1 = std::min(n, b0 + C);
+      if (b1 < n) {
+        unsigned long long hi = b1, found = ~0ull;
+        while (hi > b0 && found == ~0ull) {
+          const unsigned long long lo = hi - std::min<unsigned long long>(hi - b0, win.size());
+          if (!fill(win.data(), lo, (size_t)(hi - lo))) throw GpuError{"corpus read failed"};
+          for (unsigned long long k = hi - lo; k-- > 0;) {
+            const uint8_t b = win[(size_t)k];
+            if (b == 32 || (b >= 9 && b <= 13)) { found = lo + k + 1; break; }
+          }
+          hi = lo;
+        }
+        if (found == ~0ull || found <= b0) throw GpuError{"a word longer than the front end's chunk (" + std::to_string(C) + " bytes): raise YTTM_FE_CHUNK_MB"};
+        b1 = found;
+      }
+      cuts.push_back(b1);
+    }
+  }
+  const size_t n_chunks = cuts.size() - 1;
+  front_end_chunks = n_chunks;
+  // ---- buffers
+  const unsigned long long GAP = 64, LEX0 = C + GAP;
+  lex_cap_ = std::max<unsigned long long>(C / 4, 4096);
+  lex_used_ = 0;
+  uint8_t *B = dmalloc<uint8_t>(LEX0 + lex_cap_ + 2 * GAP);
+  d_text_owned_ = B;
+  d_text_ = B;
+  const unsigned long long sub = std::min<unsigned long long>(std::max<unsigned long long>(C / 16, 256), 4ull << 20);  // segments per K2b launch
+  unsigned long long cap = pow2_at_least(std::max<unsigned long long>(4 * sub, 1024));
+  unsigned long long *ht = dmalloc<unsigned long long>(3 * cap);
+  launch_word_table_clear(ht, cap, st_);
+  unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
+  HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
+  unsigned long long *d_cur = d_counters_ + 56;  // [0] the lexicon's end (an offset into B), [1] bytes a relocation will need
+  {
+    const unsigned long long init[2] = {LEX0, 0};
+    HIP_CHECK(hipMemcpyAsync(d_cur, init, 16, hipMemcpyHostToDevice, st_));
+  }
+  // K1's variant from four samples of the source, as upload_overlapped does
+  bool wide_chars = true;
+  if (n >= (1u << 16)) {
+    unsigned int wide = 0;
+    uint8_t smp[4096];
+    for (int i = 0; i < 4; i++) {
+      if (!fill(smp, (n / 4) * (unsigned long long)i, sizeof smp)) throw GpuError{"corpus read failed"};
+      for (size_t j = 0; j < sizeof smp; j++) wide += smp[j] >= 0xE0u;
+    }
+    wide_chars = wide * 100u > 4u * 4096u;
+  }
+  if (cfg_->k1_wide.set) wide_chars = cfg_->k1_wide.i != 0;
+  unsigned long long *hist = nullptr, *counters = nullptr, *scratch_hist = nullptr;
+  if (first_pass) {
+    if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
+    HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
+    HIP_CHECK(hipMemsetAsync(d_counters_, 0, 24 * 8, st_));
+    hist = d_hist_;
+    counters = d_counters_;
+  } else {  // (the second pass needs K1 only for the chunks' segment counts: its histogram and counters go to a scratch copy)
+    scratch_hist = dmalloc<unsigned long long>(N_CODEPOINTS + 8);
+    HIP_CHECK(hipMemsetAsync(scratch_hist, 0, ((size_t)N_CODEPOINTS + 8) * 8, st_));
+    hist = scratch_hist;
+    counters = scratch_hist + N_CODEPOINTS;
+  }
+  // the char map words are compared by: code points (first pass) or the alphabet's ids
+  uint32_t *d_map_spec = nullptr;
+  const uint32_t *d_map = d_cpmap_;
+  if (first_pass) {
+    std::vector<uint32_t> ident(N_CODEPOINTS);
+    for (uint32_t c = 0; c < N_CODEPOINTS; c++) ident[c] = c;
+    for (uint32_t sp : {9u, 10u, 11u, 12u, 13u, 32u, 9601u}) ident[sp] = CP_SPACE;
+    d_map_spec = dmalloc<uint32_t>(N_CODEPOINTS);
+    HIP_CHECK(hipMemcpyAsync(d_map_spec, ident.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, st_));
+    sync();  // (ident goes out of scope)
+    d_map = d_map_spec;
+  }
+  const unsigned long long nch_max = fe_chunks(C) + 2;
+  DFREE(d_chunk_segs_);
+  d_chunk_segs_ = dmalloc<uint32_t>(nch_max);
+  unsigned long long *d_chunk_off = dmalloc<unsigned long long>(nch_max);
+  unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(nch_max));
+  unsigned long long segs_total = 0, n_unique_host = 0;
+  unsigned int h_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const auto t0 = std::chrono::steady_clock::now();
+  for (size_t ck = 0; ck < n_chunks; ck++) {
+    const unsigned long long b0 = cuts[ck], len = cuts[ck + 1] - b0;
+    if (!len) continue;
+    // ---- the chunk, then spaces behind it (its last segment ends there if the text does not end with white space)
+    staged_transfer(device_, B, len, true, [&](void *dst, unsigned long long off, size_t l) { return fill(dst, b0 + off, l); });
+    HIP_CHECK(hipMemsetAsync(B + len, 32, GAP, st_));
+    const unsigned long long nch = fe_chunks(len);
+    t_begin(KT_CHAR_HIST);
+    launch_char_hist(B, len, hist, counters, wide_chars, d_chunk_segs_, st_);
+    t_end(KT_CHAR_HIST, first_pass ? len : 0);
+    t_begin(KT_SEGS);
+    launch_exclusive_scan(d_chunk_segs_, nch, d_chunk_off, scan_tmp, d_counters_ + 16, st_);
+    unsigned long long n_p = 0;
+    HIP_CHECK(hipMemcpyAsync(&n_p, d_counters_ + 16, 8, hipMemcpyDeviceToHost, st_));
+    sync();
+    unsigned long long *d_seg = dmalloc<unsigned long long>(std::max<unsigned long long>(n_p, 1));
+    launch_seg_write(B, len, d_seg, d_chunk_off, st_);
+    t_end(KT_SEGS, len + 8 * n_p);
+    segs_total += n_p;
+    // ---- its words into the table, `sub` segments per launch; the table is grown ahead of a launch that could fill it beyond half
+    const unsigned long long extent = LEX0 + lex_cap_ + GAP;  // (every offset a kernel may read from: the chunk, the gap, the lexicon)
+    for (unsigned long long s0 = 0; s0 < n_p; s0 += sub) {
+      const unsigned long long cnt = std::min(sub, n_p - s0);
+      if (2 * (n_unique_host + cnt) > cap) {
+        unsigned long long ncap = cap;
+        while (2 * (n_unique_host + cnt) > ncap / 2) ncap <<= 1;  // (a quarter full at most after this launch: growth is rare)
+        unsigned long long *nht = dmalloc<unsigned long long>(3 * ncap);
+        launch_word_table_clear(nht, ncap, st_);
+        launch_word_table_rehash(B, extent, d_map, ht, cap, nht, ncap, st_);
+        sync();
+        DFREE(ht);
+        ht = nht;
+        cap = ncap;
+        word_table_retries++;
+      }
+      t_begin(KT_DEDUP);
+      launch_insert_words(B, extent, d_map, d_seg + s0, cnt, ht, cap - 1, d_status, st_);
+      t_end(KT_DEDUP, (len * cnt) / std::max<unsigned long long>(n_p, 1) + 8 * cnt);
+      HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
+      sync();
+      if (h_status[6]) throw GpuError{"word table overflow (chunked front end)"};
+      n_unique_host = h_status[0];
+    }
+    DFREE(d_seg);
+    // ---- the chunk's new words move to the lexicon: first how many bytes, the lexicon grown if they do not fit, then the move
+    HIP_CHECK(hipMemsetAsync(d_cur + 1, 0, 8, st_));
+    launch_words_relocate(B, C, len + 1, ht, cap, d_cur + 1, /*move=*/false, st_);
+    unsigned long long need = 0;
+    HIP_CHECK(hipMemcpyAsync(&need, d_cur + 1, 8, hipMemcpyDeviceToHost, st_));
+    sync();
+    if (lex_used_ + need > lex_cap_) {
+      unsigned long long ncap = lex_cap_;
+      while (lex_used_ + need > ncap) ncap <<= 1;
+      uint8_t *NB = dmalloc<uint8_t>(LEX0 + ncap + 2 * GAP);
+      HIP_CHECK(hipMemcpyAsync(NB, B, (size_t)(LEX0 + lex_used_), hipMemcpyDeviceToDevice, st_));  // (the chunk too: its new words are still read from it)
+      sync();
+      DFREE(d_text_owned_);
+      B = NB;
+      d_text_owned_ = B;
+      d_text_ = B;
+      lex_cap_ = ncap;
+    }
+    if (need) launch_words_relocate(B, C, len + 1, ht, cap, d_cur, /*move=*/true, st_);
+    lex_used_ += need;
+    sync();  // (the next chunk's upload runs on the workers' streams: the region must not be overwritten under the move)
+  }
+  HIP_CHECK(hipMemsetAsync(B + LEX0 + lex_used_, 32, 2 * GAP, st_));
+  HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
+  sync();
+  DFREE(d_chunk_off);
+  DFREE(scan_tmp);
+  DFREE(d_map_spec);
+  DFREE(scratch_hist);
+  n_text_ = LEX0 + lex_used_ + GAP;  // what build_word_table reads words from: offsets into B, the lexicon behind the (now idle) chunk region
+  if (cfg_->trace.set)
+    fprintf(stderr, "[yttm] chunked front end (%s pass): %zu chunks of <= %llu MB in %.1f ms, %llu segments, %u distinct words in %llu slots, lexicon %llu bytes\n",
+            first_pass ? "first" : "second", n_chunks, C >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), segs_total,
+            h_status[0], cap, lex_used_);
+  spec_.hist_done = first_pass;
+  spec_.words_done = true;
+  spec_.n_segs = segs_total;
+  spec_.ht = ht;
+  spec_.ht_cap = cap;
+  spec_.long_segments = true;  // (the table's fill is what the growth rule above made it: no second guess in build_word_table)
+  memcpy(spec_.h_status, h_status, sizeof h_status);
 }
 
 // multi-GPU, small word tables (host_trainer.cpp learn_bpe): every rank ends up with the WHOLE corpus -- the ranks' byte ranges in rank
@@ -866,6 +1118,7 @@ void GpuCtx::gather_full_corpus() {
 
 void GpuCtx::attach_corpus(const void *dev, unsigned long long n) {
   drop_spec();
+  chunked_ = false;
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
@@ -996,6 +1249,18 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
     front_end_overlapped = true;
   }
   drop_spec();
+  if (!take_spec && chunked_) {
+    // the text was taken in chunks and is gone; the words it left were compared by code points, which is not this alphabet's partition
+    // (coverage dropped chars): the source once more, words compared by the alphabet's ids (d_cpmap_ is in place)
+    front_end_chunked(false);
+    if (spec_.n_segs != n_segs) throw GpuError{"chunked front end: the second pass over the source found another text"};
+    ht = spec_.ht;
+    ht_cap = spec_.ht_cap;
+    memcpy(h_status, spec_.h_status, sizeof h_status);
+    spec_.ht = nullptr;
+    drop_spec();
+    take_spec = true;
+  }
   if (!take_spec) {
   // segment starts
   unsigned long long *d_seg = dmalloc<unsigned long long>(n_segs);

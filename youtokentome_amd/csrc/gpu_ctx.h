@@ -102,6 +102,9 @@ class GpuCtx {
   unsigned long long last_live() const { return last_live_; }
   int last_top_bin() const { return (int)last_top_bin_; }  // no bin above this one is in use
   unsigned long long index_builds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0, word_fused_rounds = 0;  // K4 rounds whose worklist came from the pair index
+  unsigned long long front_end_chunks = 0;    // > 0: the corpus was taken in this many chunks (front_end_chunked)
+  bool corpus_resident() const { return !chunked_; }  // false: only the distinct words' bytes are in HBM
+  unsigned long long peak_device_bytes() const;       // high-water mark of the device memory pool since this context was made
   unsigned long long word_table_retries = 0;  // K2: the word table had to be redone with the worst-case size
   bool front_end_overlapped = false;          // K1, K2a, K2b ran under the upload and the word table they made was taken (upload_overlapped)
   unsigned long long hot_rebuilds = 0, top_refills = 0, rehashes = 0, exchange_retries = 0, delta_regrows = 0;
@@ -201,6 +204,12 @@ class GpuCtx {
   } spec_;
   std::vector<uint32_t> seen_cps_;      // char_hist: the code points that occur
   void drop_spec();
+  // ---- corpora that do not fit (gpu_ctx.cpp front_end_chunked): the text crosses the device in chunks, only the distinct words' bytes stay
+  bool chunked_ = false;
+  unsigned long long chunk_cap_ = 0, lex_cap_ = 0, lex_used_ = 0, chunk_src_n_ = 0;
+  std::function<bool(void *dst, unsigned long long off, size_t len)> chunk_src_;  // the source again (a second pass when coverage drops chars)
+  unsigned long long chunk_bytes_for(unsigned long long n) const;  // 0: the whole text at once
+  void front_end_chunked(bool first_pass);
   bool overlap_front_end(unsigned long long n) const;
   void upload_overlapped(unsigned long long n, const std::function<bool(void *dst, unsigned long long off, size_t len)> &fill);
   unsigned long long *d_counters_ = nullptr;  // small scratch of u64 counters

@@ -109,8 +109,9 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       bool fits_everywhere = true;
       if (t_sum <= rep_max) {
         const unsigned long long total_bytes = g.allreduce_scalar(g.corpus_bytes);
+        // (a rank that took its shard in chunks no longer holds the text: nothing to gather -- the sharded loop then, on every rank)
         const unsigned long long need = 3 * total_bytes + total_bytes / 2 + (64ull << 20);
-        const unsigned long long no_fit = g.allreduce_scalar(need > g.free_device_bytes() / 10 * 9 ? 1ull : 0ull);
+        const unsigned long long no_fit = g.allreduce_scalar((need > g.free_device_bytes() / 10 * 9 || !g.corpus_resident()) ? 1ull : 0ull);
         fits_everywhere = no_fit == 0;
       }
       if (t_sum <= rep_max && fits_everywhere) {
@@ -348,6 +349,8 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     rep->exchange_retries = g.exchange_retries;
     rep->word_table_retries = g.word_table_retries;
     rep->front_end_overlapped = g.front_end_overlapped ? 1 : 0;
+    rep->front_end_chunks = g.front_end_chunks;
+    rep->peak_device_bytes = g.peak_device_bytes();
     rep->top_refills = g.top_refills;
     rep->index_builds = g.index_builds;
     rep->word_rounds = g.word_rounds;

@@ -107,7 +107,6 @@ struct DropoutArgs {
   int enabled, always_skip;
   int heap_from;            // words of at least this many tokens keep their events in a binary heap instead of a sorted array
   int lds_queues;           // packs of up to ENC_DROP_WCAP tokens keep their event queues in LDS (EvLds)
-  int sorted_queue;         // short words keep their events in the sorted array of rounds 3 - 4 instead of the unsorted bag (differential test)
   int pack_links;           // working arrays in LDS: both links of a position in one word, the third array holds the pairs' rules (dropout_merge)
   uint32_t *wsl;            // [cap] word start positions
   unsigned long long *ev;   // [3*cap] sorted event queues, word w owns [3*ws, 3*we)
@@ -241,15 +240,11 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
     const int cap = 3 * (we - ws);             // the word's share of the queue space: every event it can ever hold
     const bool heap = we - ws >= d.heap_from;  // (skipped events of a pop wait at the top end of that space)
     int ne = 0;
-    // Short words (the usual case) keep their events in an UNSORTED bag (round 5): adding is an append, removing a swap with the last, and a
-    // pop looks for the smallest event by a scan whose LDS reads are independent of each other -- with p = 0.1 a pop examines 1.1 events on
-    // average.  The sorted array of rounds 3 - 4 paid a chain of dependent LDS round trips per insertion and removal (read, compare, shift:
-    // ~100 cycles a step, two insertions and a removal per merge); the order events are EXAMINED in -- ascending (rule, position), equal events
-    // being interchangeable -- and so every draw and every id is the same (YTTM_DROPOUT_SORTED=1 keeps the array: the differential test).
-    const bool bag = !heap && !d.sorted_queue;
+    // (Measured and dropped in round 5: the events of short words in an UNSORTED bag -- append, swap-remove, a pop by a scan for the smallest:
+    // the same examined order, draws and ids, but 195 ms per 10^7 sentences against the sorted array's 140: the scan's 64-bit compares per
+    // event cost more than the array's shifts; these loops are bound by instructions, not by LDS latency.)
     auto add = [&](unsigned long long key) {
       if (heap) heap_push(ev, ne, key);
-      else if (bag) ev.set(ne++, key);
       else ev_insert(ev, ne, key);
     };
     for (int i = ws; i < we; i++) {
@@ -277,32 +272,6 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
         }
         for (int k = 0; k < ns; k++) heap_push(ev, ne, ev.get(cap - 1 - k));
         if (!found) break;
-      } else if (bag) {
-        // the events in ascending order until one is not skipped: each step = the smallest (event, index) above the one examined before
-        unsigned long long prev_key = 0ull;
-        int prev_idx = -1, acc = -1;
-        for (;;) {
-          unsigned long long best = ~0ull;
-          int best_idx = -1;
-          for (int j = 0; j < ne; j++) {
-            const unsigned long long k = ev.get(j);
-            if ((k > prev_key || (k == prev_key && j > prev_idx)) && k < best) {
-              best = k;
-              best_idx = j;
-            }
-          }
-          if (best_idx < 0) break;  // every event examined and skipped
-          if (!drop_skip(d, sidx, (uint32_t)w, draw++)) {
-            acc = best_idx;
-            e = best;
-            break;
-          }
-          prev_key = best;
-          prev_idx = best_idx;
-        }
-        if (acc < 0) break;  // every event skipped: the word is finished (bpe.cpp:1431-1437)
-        ne--;
-        if (acc != ne) ev.set(acc, ev.get(ne));
       } else {
         int acc = -1;
         for (int j = 0; j < ne; j++) {
@@ -1053,7 +1022,6 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   if (group > 24) group = 24;
   d.lds_queues = m.n_rules < (1u << 23) && !C->dropout_hbm_queues.set;
   d.pack_links = !C->dropout_no_pack.set;
-  d.sorted_queue = C->dropout_sorted.set ? 1 : 0;  // (tests: every queue in the HBM scratch)
   // one word per lane (merge_lanes) for packs whose words have at most this many tokens; 0 = the wave-wide rounds only.
   // YTTM_K5_LANE_WORDS: the word cache's distinct words, YTTM_K5_LANE_SENT: packed sentences
   const int lane_max = ends ? (int)C->k5_lane_words.i : (int)C->k5_lane_sent.i;

@@ -690,6 +690,75 @@ __global__ __launch_bounds__(BLOCK) void k2c_compact_words(const uint8_t *__rest
   }
 }
 
+// ---- chunked front end (round 5): corpora larger than the HBM left for them ------------------------------------------------------------
+// The text crosses the device one CHUNK at a time: the buffer is [chunk region, `chunk_end` bytes | lexicon]; K1 / K2a / K2b work on the chunk
+// as they do on a whole text, and a word first seen in this chunk has its representative there.  Before the region is overwritten by the next
+// chunk, k2b_relocate copies the bytes of every such word (its segment, then one space) to the lexicon's end and points the word's slot at
+// the copy: the table only ever refers to bytes that stay.  Positions are offsets into the ONE buffer either way, so nothing else changes.
+// move == 0: only add up the bytes that will be needed (the host grows the lexicon first if they do not fit); move == 1: copy and re-point.
+__device__ inline unsigned long long segment_bytes(const uint8_t *__restrict__ text, unsigned long long pos, unsigned long long end) {
+  unsigned long long i = pos;
+  while (i < end) {
+    const uint32_t b = text[i];
+    if (b == 32u || (b >= 9u && b <= 13u)) break;
+    if (b == 0xe2u && i + 2 < end && text[i + 1] == 0x96u && text[i + 2] == 0x81u) break;  // U+2581 is white space too (utils.cpp:99-101)
+    i++;
+  }
+  return i - pos;
+}
+__global__ __launch_bounds__(BLOCK) void k2b_relocate(uint8_t *__restrict__ text, unsigned long long chunk_end, unsigned long long chunk_len,
+                                                      unsigned long long *__restrict__ ht, unsigned long long n_slots,
+                                                      unsigned long long *__restrict__ cursor, int move) {
+  unsigned long long *spos = ht + 2 * n_slots;
+  const unsigned long long per_pass = (unsigned long long)gridDim.x * BLOCK;
+  const unsigned long long passes = (n_slots + per_pass - 1) / per_pass;
+  for (unsigned long long ps = 0; ps < passes; ps++) {  // (every lane takes part in every pass: the wave-wide sums below)
+    const unsigned long long i = ps * per_pass + (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    unsigned long long key = PT_EMPTY, pos = ~0ull;
+    if (i < n_slots) {
+      key = ht[i];
+      if (key != PT_EMPTY) pos = (key & WH_SHORT) ? spos[i] : (key & WH_POS_MASK);
+    }
+    const bool mine = key != PT_EMPTY && pos < chunk_end;
+    const uint32_t need = mine ? (uint32_t)segment_bytes(text, pos, chunk_len) + 1u : 0u;
+    const uint32_t incl = wave_incl_scan(need);
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    if (total == 0u) continue;
+    unsigned long long base = 0;
+    if (lane_id() == 63) base = atomicAdd(cursor, (unsigned long long)total);
+    base = __shfl(base, 63);
+    if (!move || !mine) continue;
+    const unsigned long long dst = base + (unsigned long long)(incl - need);
+    for (uint32_t k = 0; k + 1 < need; k++) text[dst + k] = text[pos + k];
+    text[dst + need - 1] = 32u;
+    if (key & WH_SHORT) spos[i] = dst;
+    else ht[i] = (key & ~WH_POS_MASK) | dst;
+  }
+}
+// the word table into a larger one (the chunked front end cannot size it once from the whole text): every word's hash again from its bytes
+// (they all lie in the lexicon by now), an empty slot by linear probing -- the words are distinct, nothing is compared
+__global__ __launch_bounds__(BLOCK) void k2b_rehash(const uint8_t *__restrict__ text, unsigned long long n, const uint32_t *__restrict__ cpmap,
+                                                    const unsigned long long *__restrict__ old_ht, unsigned long long old_slots,
+                                                    unsigned long long *__restrict__ new_ht, unsigned long long new_mask) {
+  __shared__ uint32_t cp_ascii[128];
+  if (threadIdx.x < 128) cp_ascii[threadIdx.x] = cpmap[threadIdx.x];
+  __syncthreads();
+  unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * BLOCK;
+  for (; i < old_slots; i += stride) {
+    const unsigned long long key = old_ht[i];
+    if (key == PT_EMPTY) continue;
+    const unsigned long long pos = (key & WH_SHORT) ? old_ht[2 * old_slots + i] : (key & WH_POS_MASK);
+    unsigned long long h, skey;
+    bool pure;
+    (void)seg_scan_fast(text, n, cpmap, cp_ascii, pos, &h, &pure, &skey);
+    unsigned long long j = (h >> 8) & new_mask;
+    while (atomicCAS(&new_ht[j], PT_EMPTY, key) != PT_EMPTY) j = (j + 1) & new_mask;
+    new_ht[new_mask + 1 + j] = old_ht[old_slots + i];
+    new_ht[2 * (new_mask + 1) + j] = old_ht[2 * old_slots + i];
+  }
+}
+
 // keys = PT_EMPTY, counts = 0
 __global__ __launch_bounds__(BLOCK) void k_wh_clear(unsigned long long *__restrict__ ht, unsigned long long n_slots) {
   unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -963,6 +1032,16 @@ void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32
                          unsigned int max_blocks) {
   unsigned int g = grid_for(n_segs, BLOCK, max_blocks);  // (256 * 8: dedup 11.6 ms at 1 GB instead of 9.9; 256 * 64: 9.6)
   hipLaunchKernelGGL(k2b_insert_words, dim3(g), dim3(BLOCK), 0, st, text, n, cpmap, seg_pos, n_segs, ht, ht_mask, status);
+}
+void launch_words_relocate(uint8_t *text, unsigned long long chunk_end, unsigned long long chunk_len, unsigned long long *ht, unsigned long long n_slots,
+                           unsigned long long *cursor, bool move, hipStream_t st) {
+  const unsigned long long blocks = std::min<unsigned long long>((n_slots + BLOCK - 1) / BLOCK, 256ull * 16);
+  hipLaunchKernelGGL(k2b_relocate, dim3((unsigned int)std::max<unsigned long long>(blocks, 1)), dim3(BLOCK), 0, st, text, chunk_end, chunk_len, ht, n_slots, cursor, move ? 1 : 0);
+}
+void launch_word_table_rehash(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *old_ht, unsigned long long old_slots,
+                              unsigned long long *new_ht, unsigned long long new_slots, hipStream_t st) {
+  const unsigned long long blocks = std::min<unsigned long long>((old_slots + BLOCK - 1) / BLOCK, 256ull * 16);
+  hipLaunchKernelGGL(k2b_rehash, dim3((unsigned int)std::max<unsigned long long>(blocks, 1)), dim3(BLOCK), 0, st, text, n, cpmap, old_ht, old_slots, new_ht, new_slots - 1);
 }
 void launch_compact_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *ht, unsigned long long n_slots,
                           unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB, uint32_t *cntB, uint32_t *lenB,

@@ -44,6 +44,8 @@ struct Hook {
   X(fe_overlap_min, "YTTM_FE_OVERLAP_MIN", "33554432", "tune", "texts of at least this many bytes run K1/K2a/K2b under the upload")       \
   X(fe_no_overlap, "YTTM_FE_NO_OVERLAP", "", "path", "set: never run the front end under the upload")                                       \
   X(fe_no_spec, "YTTM_FE_NO_SPEC", "", "path", "set: under the upload only K1, not the speculative dedup by code points")                  \
+  X(fe_chunk_mb, "YTTM_FE_CHUNK_MB", "0", "tune", "take the corpus in chunks of this many MB (0: only when the whole text would not fit the free HBM)") \
+  X(fe_chunk_kb, "YTTM_FE_CHUNK_KB", "0", "test", "the same in KB (tests: many chunks of a toy corpus)")                                   \
   X(fe_part_kb, "YTTM_FE_PART_KB", "32768", "tune", "size of a part of the text the overlapped front end works on, KB")                    \
   X(fe_k2b_blocks, "YTTM_FE_K2B_BLOCKS", "4096", "tune", "workgroups of a part's dedup launch")                                             \
   X(word_table_full, "YTTM_WORD_TABLE_FULL", "", "path", "set: size the word table for the worst case at once (no estimate, no retry)")    \
@@ -94,7 +96,6 @@ struct Hook {
   X(dropout_seed, "YTTM_DROPOUT_SEED", "", "test", "fixes the per-encoder salt of the BPE-dropout RNG (default: std::random_device)")      \
   X(dropout_heap_from, "YTTM_DROPOUT_HEAP_FROM", "256", "path", "words of at least this many tokens keep their dropout events in a heap")  \
   X(dropout_hbm_queues, "YTTM_DROPOUT_HBM_QUEUES", "", "path", "set: dropout event queues in the HBM scratch, not LDS")                    \
-  X(dropout_sorted, "YTTM_DROPOUT_SORTED", "", "path", "set: short words' dropout events in a sorted array (rounds 3-4) instead of the unsorted bag") \
   X(dropout_no_pack, "YTTM_DROPOUT_NO_PACK", "", "path", "set: dropout merges test an event against rule_xy and read rule_z (round 4's three trips per merge)") \
   X(k5_lane_words, "YTTM_K5_LANE_WORDS", "48", "path", "one-word-per-lane for the cache's distinct words up to this many tokens (0: wave-wide rounds)") \
   X(k5_lane_sent, "YTTM_K5_LANE_SENT", "48", "path", "... for packed sentences")                                                            \

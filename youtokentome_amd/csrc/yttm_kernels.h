@@ -40,6 +40,12 @@ void launch_word_table_clear(unsigned long long *ht, unsigned long long n_slots,
 void launch_insert_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *seg_pos,
                          unsigned long long n_segs, unsigned long long *ht, unsigned long long ht_mask, unsigned int *status, hipStream_t st,
                          unsigned int max_blocks = 256 * 32 /* (a part of the segments: fewer workgroups, each ends with a flush of its LDS table) */);
+// chunked front end (k_frontend.hip: k2b_relocate, k2b_rehash): words whose representative lies below `chunk_end` move to the lexicon at *cursor
+// (device; advanced by the bytes taken -- move == false only adds them up); the table rebuilt with new_slots (a power of two, cleared) slots
+void launch_words_relocate(uint8_t *text, unsigned long long chunk_end, unsigned long long chunk_len, unsigned long long *ht, unsigned long long n_slots,
+                           unsigned long long *cursor, bool move, hipStream_t st);
+void launch_word_table_rehash(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *old_ht, unsigned long long old_slots,
+                              unsigned long long *new_ht, unsigned long long new_slots, hipStream_t st);
 void launch_compact_words(const uint8_t *text, unsigned long long n, const uint32_t *cpmap, const unsigned long long *ht, unsigned long long n_slots,
                           unsigned long long *posA, uint32_t *cntA, uint32_t *lenA, unsigned long long *posB, uint32_t *cntB, uint32_t *lenB,
                           unsigned long long *posC, uint32_t *cntC, uint32_t *lenC, unsigned int *cursor, unsigned int *status,
