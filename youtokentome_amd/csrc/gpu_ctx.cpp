@@ -1,181 +1,20 @@
-// gpu_ctx.cpp -- HBM buffer management and kernel sequencing for the MI355X BPE trainer (see gpu_ctx.h).
-#include "gpu_ctx.h"
-
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <algorithm>
-#include <unordered_map>
-#include <mutex>
-#include <map>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <functional>
-#include <thread>
-#include <unistd.h>
+// gpu_ctx.cpp -- the trainer's device context (gpu_ctx.h): construction, kernel-family timers, and the merge round (K4) with its one launch and one
+// mailbox poll.  The rest of GpuCtx lives in gpu_pool.cpp, gpu_upload.cpp, gpu_frontend.cpp, gpu_pairs.cpp, gpu_exchange.cpp, gpu_words.cpp
+// (gpu_ctx_internal.h: what went where).
+#include "gpu_ctx_internal.h"
 
 namespace yttm {
-
-static unsigned long long pow2_at_least(unsigned long long v) {
-  unsigned long long c = 1;
-  while (c < v) c <<= 1;
-  return c;
-}
-
-// ---- device memory pool --------------------------------------------------------------------------------------------
-// A training allocates ~10 GB in a dozen large pieces and frees them again; hipMalloc/hipFree of that size cost several
-// milliseconds (hipFree also synchronises the device) and, measured, an occasional 100 ms hiccup.  Freed blocks are kept
-// and handed out again to requests of (nearly) the same size.  A block freed by a context that is still running may
-// only be reused on that context's stream (same-stream order makes that safe); when the context is destroyed -- after
-// a stream synchronisation -- its blocks become free for everyone.  YTTM_NO_POOL=1 turns the pool off,
-// yttm_release_device_memory() (capi.cpp) returns the cached blocks to the driver.
-namespace {
-struct PoolBlock {
-  void *p;
-  size_t bytes;
-  hipStream_t owner;  // nullptr: quiescent
-  int device;
-};
-struct DevPool {
-  std::mutex mu;
-  std::multimap<size_t, PoolBlock> free_blocks;
-  std::unordered_map<void *, size_t> live;
-  size_t cached = 0;
-  size_t in_use = 0, peak = 0;  // bytes handed out / their high-water mark (GpuCtx::peak_device_bytes; only kept while the pool is on)
-};
-DevPool g_pool;
-void *g_pin_cached = nullptr;  // one pinned staging buffer (PIN_BYTES) kept between contexts
-std::vector<std::pair<int, hipStream_t>> g_streams_cached;  // streams of finished contexts, by device (creating and destroying one costs ~2 ms of a training)
-thread_local hipStream_t tl_stream = nullptr;
-thread_local int tl_device = 0;
-constexpr size_t POOL_MAX_CACHED = 96ull << 30;  // (a third of the HBM: the segment starts of 4.4e9 one-letter words alone are 35 GB)
-bool pool_enabled() {
-  static const bool on = !(cfg()->no_pool.set && cfg()->no_pool.raw.c_str()[0] == '1');  // (one verdict per process: blocks cached under one policy are not freed under the other)
-  return on;
-}
-void *pool_alloc(size_t bytes) {
-  if (bytes == 0) bytes = 1;
-  bytes = (bytes + 255) & ~(size_t)255;
-  if (pool_enabled()) {
-    std::lock_guard<std::mutex> g(g_pool.mu);
-    for (auto it = g_pool.free_blocks.lower_bound(bytes); it != g_pool.free_blocks.end() && it->first <= bytes + bytes / 4 + 65536; ++it) {
-      const PoolBlock &b = it->second;
-      if (b.device != tl_device || (b.owner != nullptr && b.owner != tl_stream)) continue;
-      void *p = b.p;
-      g_pool.live[p] = b.bytes;
-      g_pool.cached -= b.bytes;
-      g_pool.in_use += b.bytes;
-      g_pool.peak = std::max(g_pool.peak, g_pool.in_use);
-      g_pool.free_blocks.erase(it);
-      return p;
-    }
-  }
-  void *p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes);
-  if (e != hipSuccess && pool_enabled()) {  // out of memory with blocks cached: give them back and retry
-    {
-      std::lock_guard<std::mutex> g(g_pool.mu);
-      for (auto &kv : g_pool.free_blocks) (void)hipFree(kv.second.p);
-      g_pool.free_blocks.clear();
-      g_pool.cached = 0;
-    }
-    e = hipMalloc(&p, bytes);
-  }
-  HIP_CHECK(e);
-  if (pool_enabled()) {
-    std::lock_guard<std::mutex> g(g_pool.mu);
-    g_pool.live[p] = bytes;
-    g_pool.in_use += bytes;
-    g_pool.peak = std::max(g_pool.peak, g_pool.in_use);
-  }
-  return p;
-}
-void pool_free(void *p) {
-  if (!p) return;
-  if (pool_enabled()) {
-    std::lock_guard<std::mutex> g(g_pool.mu);
-    auto it = g_pool.live.find(p);
-    if (it != g_pool.live.end()) {
-      const size_t bytes = it->second;
-      g_pool.live.erase(it);
-      g_pool.in_use -= std::min(g_pool.in_use, bytes);
-      if (g_pool.cached + bytes <= POOL_MAX_CACHED) {
-        g_pool.free_blocks.emplace(bytes, PoolBlock{p, bytes, tl_stream, tl_device});
-        g_pool.cached += bytes;
-        return;
-      }
-    }
-  }
-  (void)hipFree(p);
-}
-void pool_quiesce(hipStream_t st) {  // the stream was synchronised: its blocks may now go to anybody
-  std::lock_guard<std::mutex> g(g_pool.mu);
-  for (auto &kv : g_pool.free_blocks)
-    if (kv.second.owner == st) kv.second.owner = nullptr;
-}
-}  // namespace
-static void release_io_stage();
-void release_device_memory() {
-  release_io_stage();
-  std::lock_guard<std::mutex> g(g_pool.mu);
-  if (g_pin_cached) {
-    (void)hipHostFree(g_pin_cached);
-    g_pin_cached = nullptr;
-  }
-  for (auto &ds : g_streams_cached) (void)hipStreamDestroy(ds.second);
-  g_streams_cached.clear();
-  for (auto it = g_pool.free_blocks.begin(); it != g_pool.free_blocks.end();) {
-    if (it->second.owner == nullptr) {
-      (void)hipFree(it->second.p);
-      g_pool.cached -= it->second.bytes;
-      it = g_pool.free_blocks.erase(it);
-    } else {
-      ++it;
-    }
-  }
-}
-
-template <class T>
-static T *dmalloc(size_t n) {
-  return (T *)pool_alloc((n ? n : 1) * sizeof(T));
-}
-#define DFREE(p)            \
-  do {                      \
-    if (p) pool_free((void *)(p)); \
-    p = nullptr;            \
-  } while (0)
-
-constexpr unsigned int CAND_CAP = 1u << 20;
-constexpr unsigned int HOT_CAP = 1u << 18;  // hot-list slots (entries appended between rebuilds included)
-// a rebuild picks the threshold that lists about HOT_TARGET pairs; fewer live entries than HOT_MIN: lower the threshold.
-// YTTM_HOT_TARGET / YTTM_HOT_MIN / YTTM_HOT_CAP override them (the test-suite shrinks them to exercise rebuilds on tiny corpora).
-constexpr unsigned int TOP_CAP = 1u << 15;  // top-list slots
-constexpr unsigned int RULES_CAP = 1u << 14;  // hash slots for the per-round rule table (batch <= RULES_CAP/2)
-constexpr size_t PIN_BYTES = (size_t)CAND_CAP * sizeof(CandRec) + (size_t)RULES_CAP * sizeof(RuleSlot) + (1u << 20);
 
 GpuCtx::GpuCtx(int device) : device_(device) {
   cfg_refresh();  // the environment hooks are read here, once per context (yttm_config.h); nothing below this constructor calls getenv
   cfg_ = cfg();
   const Config &C = *cfg_;
   xchg_margin_ = C.xchg_margin.d;
-  {
-    std::lock_guard<std::mutex> g(g_pool.mu);
-    g_pool.peak = g_pool.in_use;
-  }
+  pool_reset_peak();
   HIP_CHECK(hipSetDevice(device_));
   tl_stream = st_;
   tl_device = device_;
-  if (pool_enabled()) {
-    std::lock_guard<std::mutex> g(g_pool.mu);
-    for (size_t i = 0; i < g_streams_cached.size(); i++)
-      if (g_streams_cached[i].first == device_) {
-        st_ = g_streams_cached[i].second;
-        g_streams_cached.erase(g_streams_cached.begin() + (long)i);
-        break;
-      }
-  }
+  st_ = pool_take_stream(device_);  // (a finished context's: creating and destroying one costs ~2 ms of a training)
   if (!st_) HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
   tl_stream = st_;
   tl_device = device_;
@@ -226,11 +65,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   cand_cap_ = CAND_CAP;
   d_rules_ = dmalloc<RuleSlot>(RULES_CAP);
   rules_cap_ = RULES_CAP;
-  {  // pinned staging: one buffer is kept across contexts (hipHostMalloc of 17 MB costs milliseconds)
-    std::lock_guard<std::mutex> g(g_pool.mu);
-    h_pin_ = g_pin_cached;
-    g_pin_cached = nullptr;
-  }
+  h_pin_ = pool_take_pin();  // pinned staging: one buffer is kept across contexts (hipHostMalloc of 17 MB costs milliseconds)
   if (!h_pin_) HIP_CHECK(hipHostMalloc(&h_pin_, PIN_BYTES, hipHostMallocDefault));
   h_pin_bytes_ = PIN_BYTES;
   memset(h_pin_, 0, 8192);  // mailbox header (k_hot_scan publishes its round id at byte 32)
@@ -252,21 +87,9 @@ GpuCtx::~GpuCtx() {
   free_index();
   free_words();
   pool_quiesce(st_);
-  if (h_pin_) {
-    std::lock_guard<std::mutex> g(g_pool.mu);
-    if (!g_pin_cached && pool_enabled()) {
-      g_pin_cached = h_pin_;
-      h_pin_ = nullptr;
-    }
-  }
+  if (h_pin_ && pool_give_pin(h_pin_)) h_pin_ = nullptr;
   if (h_pin_) (void)hipHostFree(h_pin_);
-  if (st_ && pool_enabled()) {  // (synchronised above: nothing is pending on it)
-    std::lock_guard<std::mutex> g(g_pool.mu);
-    if (g_streams_cached.size() < 8) {
-      g_streams_cached.emplace_back(device_, st_);
-      st_ = nullptr;
-    }
-  }
+  if (st_ && pool_give_stream(device_, st_)) st_ = nullptr;  // (synchronised above: nothing is pending on it)
   if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -282,7 +105,7 @@ void GpuCtx::read_stats(int first, int n, unsigned long long *out) {
 static std::vector<hipEvent_t> g_event_pool;
 static hipEvent_t event_get() {
   {
-    std::lock_guard<std::mutex> g(g_pool.mu);
+    std::lock_guard<std::mutex> g(pool_mutex());
     if (!g_event_pool.empty()) {
       hipEvent_t e = g_event_pool.back();
       g_event_pool.pop_back();
@@ -345,7 +168,7 @@ void GpuCtx::resolve_timers() {
     for (float ms : dev_round_ms_) fprintf(trace, "%d %.4f\n", (int)KT_MERGE, ms);
   dev_round_ms_.clear();
   {
-    std::lock_guard<std::mutex> g(g_pool.mu);
+    std::lock_guard<std::mutex> g(pool_mutex());
     g_event_pool.insert(g_event_pool.end(), all_events_.begin(), all_events_.end());
   }
   all_events_.clear();
@@ -353,1908 +176,7 @@ void GpuCtx::resolve_timers() {
   if (trace) fclose(trace);
 }
 
-// ------------------------------------------------------------------------------------------------- corpus
-unsigned long long GpuCtx::peak_device_bytes() const {
-  std::lock_guard<std::mutex> g(g_pool.mu);
-  return (unsigned long long)g_pool.peak;
-}
-
-void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
-  drop_spec();
-  chunked_ = false;
-  if (chunk_bytes_for(n)) {  // (too large for the HBM that is free: in chunks, gpu_ctx.cpp front_end_chunked)
-    chunk_src_ = [host](void *dst, unsigned long long off, size_t len) {
-      memcpy(dst, host + off, len);
-      return true;
-    };
-    chunk_src_n_ = n;
-    front_end_chunked(true);
-    return;
-  }
-  if ((n < (32u << 20) && !(cfg_->fe_overlap_min.set && overlap_front_end(n))) || cfg_->plain_upload.set) {  // small, or (tuning hook) the one-copy path for comparison
-    HIP_CHECK(hipSetDevice(device_));
-    tl_stream = st_;
-    tl_device = device_;
-    DFREE(d_text_owned_);
-    d_text_owned_ = dmalloc<uint8_t>(n + 64);
-    if (n) HIP_CHECK(hipMemcpyAsync(d_text_owned_, host, n, hipMemcpyHostToDevice, st_));
-    sync();
-    d_text_ = d_text_owned_;
-    n_text_ = n;
-    corpus_bytes = n;
-    return;
-  }
-  auto from_memory = [&](void *dst, unsigned long long off, size_t len) {
-    memcpy(dst, host + off, len);
-    return true;
-  };
-  if (overlap_front_end(n)) upload_overlapped(n, from_memory);
-  else upload_staged(n, from_memory);
-}
-// ---- staged upload: file (or host memory) -> pinned chunks -> HBM -----------------------------------------------------
-// fast_read_file_utf8 (bpe.cpp:67-84) reads the file into one std::string; here the bytes only pass through the host.
-// A single hipMemcpy from pageable memory (an mmap of the file, a Python bytes object) is staged by the runtime through
-// one internal buffer on one thread; instead IO_THREADS workers each own two pinned chunks, fill one (pread from the page
-// cache / memcpy) while the other is on its way over PCIe on the worker's own stream.  The pinned chunks are kept for the
-// next call (pinning 128 MB costs tens of milliseconds).
-namespace {
-constexpr size_t IO_CHUNK_MAX = 64u << 20;
-constexpr int IO_MAX_THREADS = 32;
-struct IoStage {
-  std::mutex mu;
-  void *pin[2 * IO_MAX_THREADS] = {nullptr};
-  size_t pin_bytes[2 * IO_MAX_THREADS] = {0};
-  // the workers' copy streams and events are kept as well (creating and destroying a stream and two events per worker and call was
-  // a millisecond of every upload, serialised in the runtime); they belong to device `dev`
-  hipStream_t cs[IO_MAX_THREADS] = {nullptr};
-  hipEvent_t ev[2 * IO_MAX_THREADS] = {nullptr};
-  int dev = -1;
-  bool busy = false;
-} g_io_dir[2];  // [0] towards the device, [1] towards the host: one transfer each way at a time goes through the chunks (the encoder's pipeline)
-}  // namespace
-
-static void release_io_stage() {
-  for (IoStage &g_io : g_io_dir) {
-    std::lock_guard<std::mutex> g(g_io.mu);
-    if (g_io.busy) continue;
-    for (int i = 0; i < 2 * IO_MAX_THREADS; i++) {
-      if (g_io.pin[i]) (void)hipHostFree(g_io.pin[i]);
-      g_io.pin[i] = nullptr;
-      g_io.pin_bytes[i] = 0;
-    }
-    for (hipEvent_t &e : g_io.ev) {
-      if (e) (void)hipEventDestroy(e);
-      e = nullptr;
-    }
-    for (hipStream_t &c : g_io.cs) {
-      if (c) (void)hipStreamDestroy(c);
-      c = nullptr;
-    }
-    g_io.dev = -1;
-  }
-}
-
-void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *dst, unsigned long long off, size_t len)> &fill) {
-  HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
-  tl_device = device_;
-  DFREE(d_text_owned_);
-  d_text_owned_ = dmalloc<uint8_t>(n + 64);
-  d_text_ = d_text_owned_;
-  n_text_ = n;
-  corpus_bytes = n;
-  if (!n) return;
-  staged_transfer(device_, d_text_owned_, n, true, fill);
-}
-
-// n bytes between HBM and the host through the workers' pinned chunks.  to_device: host_side(chunk, off, len) FILLS the pinned chunk with
-// bytes [off, off + len) (pread, memcpy) before it goes up; else it DRAINS the chunk that has come down (memcpy to where the caller wants
-// the bytes -- several workers at once, which also spreads the page faults of a freshly allocated destination).  Returns when every byte
-// has arrived.  Throws GpuError.
-size_t staged_chunk_bytes() {
-  const std::shared_ptr<const Config> C = cfg();
-  const size_t mb = std::min<size_t>(std::max<size_t>((size_t)C->io_chunk_mb.u, 1), IO_CHUNK_MAX >> 20);
-  size_t c = mb << 20;
-  if (const size_t kb = (size_t)C->io_chunk_kb.u) c = std::min<size_t>(kb << 10, IO_CHUNK_MAX);  // (tests: many chunks of a small batch)
-  return c;
-}
-void staged_transfer(int device, uint8_t *d_ptr, unsigned long long n, bool to_device,
-                     const std::function<bool(void *chunk, unsigned long long off, size_t len)> &host_side,
-                     const std::function<void(unsigned long long off, size_t len)> &arrived, size_t chunk_bytes) {
-  if (!n) return;
-  HIP_CHECK(hipSetDevice(device));
-  IoStage &g_io = g_io_dir[to_device ? 0 : 1];
-  const std::shared_ptr<const Config> C = cfg();
-  const size_t IO_CHUNK = chunk_bytes && !C->io_chunk_mb.set && !C->io_chunk_kb.set ? std::min(chunk_bytes, IO_CHUNK_MAX) : staged_chunk_bytes();
-  const size_t n_chunks = (size_t)((n + IO_CHUNK - 1) / IO_CHUNK);
-  int n_threads = (int)C->io_threads.u;
-  // (default 4: one thread preads 40 GB/s out of the page cache on the MI355X box, the link takes 55; eight workers measured SLOWER than three
-  // or four -- 34 - 42 ms per GB against 24 -- sixteen much slower: they queue up in the runtime)
-  if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 4u));
-  n_threads = (int)std::min<size_t>((size_t)std::min(n_threads, IO_MAX_THREADS), n_chunks);
-  bool mine = false;
-  {
-    std::lock_guard<std::mutex> g(g_io.mu);
-    if (!g_io.busy) { g_io.busy = true; mine = true; }
-  }
-  struct BusyGuard {  // (whatever leaves this function -- any exception -- gives the chunks back)
-    IoStage &io;
-    bool held;
-    ~BusyGuard() {
-      if (!held) return;
-      std::lock_guard<std::mutex> g(io.mu);
-      io.busy = false;
-    }
-  } busy_guard{g_io, mine};
-  if (mine && g_io.dev != device) {  // (the cached streams and events are another device's)
-    for (hipEvent_t &e : g_io.ev) {
-      if (e) (void)hipEventDestroy(e);
-      e = nullptr;
-    }
-    for (hipStream_t &c : g_io.cs) {
-      if (c) (void)hipStreamDestroy(c);
-      c = nullptr;
-    }
-    g_io.dev = device;
-  }
-  if (!mine) {  // another thread of this process is moving bytes through the shared chunks: plain copies for this one
-    std::vector<uint8_t> tmp(IO_CHUNK);
-    for (size_t c = 0; c < n_chunks; c++) {
-      const unsigned long long off = (unsigned long long)c * IO_CHUNK;
-      const size_t len = (size_t)std::min<unsigned long long>(IO_CHUNK, n - off);
-      if (to_device) {
-        if (!host_side(tmp.data(), off, len)) throw GpuError{"corpus read failed"};
-        HIP_CHECK(hipMemcpy(d_ptr + off, tmp.data(), len, hipMemcpyHostToDevice));
-        if (arrived) arrived(off, len);
-      } else {
-        HIP_CHECK(hipMemcpy(tmp.data(), d_ptr + off, len, hipMemcpyDeviceToHost));
-        if (!host_side(tmp.data(), off, len)) throw GpuError{"copy to the host failed"};
-      }
-    }
-    return;
-  }
-  std::atomic<size_t> next{0};
-  std::atomic<int> failed{0};
-  std::string first_error;
-  std::mutex err_mu;
-  auto worker = [&](int w) {
-    try {
-      HIP_CHECK(hipSetDevice(device));
-      if (!g_io.cs[w]) HIP_CHECK(hipStreamCreateWithFlags(&g_io.cs[w], hipStreamNonBlocking));
-      hipStream_t cs = g_io.cs[w];
-      hipEvent_t *ev = &g_io.ev[2 * w];
-      bool used[2] = {false, false};
-      unsigned long long held_off[2] = {0, 0};  // (down: the bytes a buffer is receiving)
-      size_t held_len[2] = {0, 0};
-      for (int k = 0; k < 2; k++) {
-        if (!ev[k]) HIP_CHECK(hipEventCreate(&ev[k]));
-        if (g_io.pin_bytes[2 * w + k] < IO_CHUNK) {  // (pinning is slow: the chunks are kept, and only as large as they are used)
-          if (g_io.pin[2 * w + k]) (void)hipHostFree(g_io.pin[2 * w + k]);
-          g_io.pin[2 * w + k] = nullptr;
-          g_io.pin_bytes[2 * w + k] = 0;
-          HIP_CHECK(hipHostMalloc(&g_io.pin[2 * w + k], IO_CHUNK, hipHostMallocDefault));
-          g_io.pin_bytes[2 * w + k] = IO_CHUNK;
-        }
-      }
-      auto drain = [&](int k) {
-        if (!used[k]) return;
-        HIP_CHECK(hipEventSynchronize(ev[k]));
-        used[k] = false;
-        if (!to_device && !host_side(g_io.pin[2 * w + k], held_off[k], held_len[k])) throw GpuError{"copy to the host failed"};
-        if (to_device && arrived) arrived(held_off[k], held_len[k]);
-      };
-      for (int k = 0;; k ^= 1) {
-        const size_t c = next.fetch_add(1);
-        if (c >= n_chunks || failed.load()) break;
-        const unsigned long long off = (unsigned long long)c * IO_CHUNK;
-        const size_t len = (size_t)std::min<unsigned long long>(IO_CHUNK, n - off);
-        drain(k);  // up: the buffer's previous copy has left it; down: its bytes have arrived and are handed over
-        if (to_device) {
-          if (!host_side(g_io.pin[2 * w + k], off, len)) throw GpuError{"corpus read failed"};
-          HIP_CHECK(hipMemcpyAsync(d_ptr + off, g_io.pin[2 * w + k], len, hipMemcpyHostToDevice, cs));
-        } else {
-          HIP_CHECK(hipMemcpyAsync(g_io.pin[2 * w + k], d_ptr + off, len, hipMemcpyDeviceToHost, cs));
-        }
-        held_off[k] = off;
-        held_len[k] = len;
-        HIP_CHECK(hipEventRecord(ev[k], cs));
-        used[k] = true;
-        if (to_device && arrived) drain(k ^ 1);  // (somebody waits for the bytes: say that the previous chunk has landed now, not a fill later)
-      }
-      drain(0);
-      drain(1);
-      HIP_CHECK(hipStreamSynchronize(cs));
-    } catch (const GpuError &e) {
-      failed.store(1);
-      std::lock_guard<std::mutex> g(err_mu);
-      if (first_error.empty()) first_error = e.msg;
-    } catch (const std::exception &e) {  // (bad_alloc in a callback, ...: reported like a GPU error, never std::terminate in a worker)
-      failed.store(1);
-      std::lock_guard<std::mutex> g(err_mu);
-      if (first_error.empty()) first_error = std::string("staged transfer: ") + e.what();
-    }
-    // A worker that gave up may have copies queued on its stream that still read / write its pinned chunks and d_ptr: they must be over
-    // before the caller frees the device buffer or the next transfer reuses the chunks.
-    if (failed.load() && g_io.cs[w]) (void)hipStreamSynchronize(g_io.cs[w]);
-  };
-  struct Joiner {  // (a throwing emplace_back / worker(0) must not destroy joinable threads)
-    std::vector<std::thread> th;
-    ~Joiner() {
-      for (auto &t : th)
-        if (t.joinable()) t.join();
-    }
-  } joiner;
-  try {
-    for (int w = 1; w < n_threads; w++) joiner.th.emplace_back(worker, w);
-  } catch (const std::exception &e) {  // (no more threads to be had: the ones that started, and this one, do the work)
-    (void)e;
-  }
-  worker(0);
-  for (auto &t : joiner.th) t.join();
-  if (failed.load()) throw GpuError{first_error};
-}
-
-void GpuCtx::drop_spec() {
-  if (spec_.ht) DFREE(spec_.ht);
-  spec_ = FrontSpec();
-}
-
-// The front end under the upload (single GPU).  A GB of file needs 18 ms on the link, and the device idles through them; K1, K2a and K2b of
-// the same GB are 10 ms of work that needs nothing but the bytes: K1 and K2a by construction, K2b -- the dedup -- if every word is compared
-// by its CODE POINTS instead of its token ids, which is the same partition of the segments into words whenever the alphabet keeps every
-// char of the text (coverage 1, the default): the ids are then an injective renaming of the chars.  So the text is worked on in parts as they
-// land -- the workers of staged_transfer report the chunks, a part is ready when every byte up to one scan chunk behind its end is there --
-// and build_word_table() takes the finished word table if the alphabet turns out to keep everything, else runs its own K2a / K2b as before.
-// (`fill` brings bytes [off, off + len) of the source -- a file's byte range, host memory -- into a pinned chunk.)
-// A part's last segment may run on into bytes that have not arrived: it is inserted with the next part that has a segment of its own.
-void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(void *dst, unsigned long long off, size_t len)> &fill) {
-  HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
-  tl_device = device_;
-  drop_spec();
-  DFREE(d_text_owned_);
-  d_text_owned_ = dmalloc<uint8_t>(n + 64);
-  d_text_ = d_text_owned_;
-  n_text_ = n;
-  corpus_bytes = n;
-  // K1's variant from four samples of the SOURCE (char_hist samples the text in HBM, which is not there yet)
-  bool wide_chars = false;
-  if (n >= (1u << 16)) {
-    unsigned int wide = 0;
-    uint8_t smp[4096];
-    for (int i = 0; i < 4; i++) {
-      if (!fill(smp, (n / 4) * (unsigned long long)i, sizeof smp)) throw GpuError{"corpus read failed"};
-      for (size_t j = 0; j < sizeof smp; j++) wide += smp[j] >= 0xE0u;
-    }
-    wide_chars = wide * 100u > 4u * 4096u;
-  } else {
-    wide_chars = true;
-  }
-  if (cfg_->k1_wide.set) wide_chars = cfg_->k1_wide.i != 0;
-  if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
-  HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
-  HIP_CHECK(hipMemsetAsync(d_counters_, 0, 64 * 8, st_));
-  const unsigned long long nch = fe_chunks(n);
-  DFREE(d_chunk_segs_);
-  d_chunk_segs_ = dmalloc<uint32_t>(nch + 1);
-  // the speculative map: a char's id is its code point
-  uint32_t *d_cpmap_spec = dmalloc<uint32_t>(N_CODEPOINTS);
-  {
-    static std::vector<uint32_t> ident;
-    static std::once_flag once;
-    std::call_once(once, [] {
-      ident.resize(N_CODEPOINTS);
-      for (uint32_t c = 0; c < N_CODEPOINTS; c++) ident[c] = c;
-      const uint32_t spaces[] = {9, 10, 11, 12, 13, 32, 9601};
-      for (uint32_t sp : spaces) ident[sp] = CP_SPACE;
-    });
-    HIP_CHECK(hipMemcpyAsync(d_cpmap_spec, ident.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, st_));
-  }
-  unsigned long long *d_chunk_off = dmalloc<unsigned long long>(nch + 1);
-  // ---- the upload, on a thread of its own; what has landed, in order
-  const size_t io_chunk = staged_chunk_bytes();
-  const size_t n_io = (size_t)((n + io_chunk - 1) / io_chunk);
-  std::vector<uint8_t> landed(n_io, 0);
-  std::mutex mu;
-  std::condition_variable cv;
-  size_t next_io = 0;  // chunks [0, next_io) have landed
-  bool finished = false, up_failed = false;
-  std::string up_error;  // (read after the join)
-  const auto t_start = std::chrono::steady_clock::now();
-  auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
-  double ms_link = 0;
-  //  a failure on this thread -- a front-end kernel, an allocation -- must not wait for the rest of the corpus to be read and
-  // copied: the wrapper around `fill` gives up once `stop` is set, which ends staged_transfer; and the thread is joined on every way out.
-  // (`fill` is called from several threads at once -- the samples above, then the upload's workers: gpu_ctx.h says so.)
-  std::atomic<bool> stop{false};
-  const std::function<bool(void *, unsigned long long, size_t)> fill_or_stop = [&](void *dst, unsigned long long off, size_t len) {
-    return !stop.load(std::memory_order_relaxed) && fill(dst, off, len);
-  };
-  std::thread up([&] {
-    try {
-      staged_transfer(device_, d_text_owned_, n, true, fill_or_stop, [&](unsigned long long off, size_t) {
-        std::lock_guard<std::mutex> g(mu);
-        landed[(size_t)(off / io_chunk)] = 1;
-        bool moved = false;
-        while (next_io < n_io && landed[next_io]) { next_io++; moved = true; }
-        if (moved) cv.notify_all();
-      });
-    } catch (const GpuError &e) {
-      std::lock_guard<std::mutex> g(mu);
-      up_error = e.msg;
-      up_failed = true;
-    }
-    ms_link = ms_now();
-    std::lock_guard<std::mutex> g(mu);
-    finished = true;
-    cv.notify_all();
-  });
-  struct UpJoin {
-    std::thread &t;
-    std::atomic<bool> &stop;
-    ~UpJoin() {
-      if (!t.joinable()) return;
-      stop.store(true);
-      t.join();
-    }
-  } up_join{up, stop};
-  auto wait_for = [&](unsigned long long bytes) {  // until [0, bytes) has landed (or the upload is over); false: it failed
-    std::unique_lock<std::mutex> g(mu);
-    cv.wait(g, [&] { return finished || std::min<unsigned long long>(n, (unsigned long long)next_io * io_chunk) >= bytes; });
-    return !up_failed;
-  };
-  // ---- the parts
-  const unsigned long long FC = fe_chunk_bytes();
-  unsigned long long part = cfg_->fe_part_kb.u << 10;  // (32 MB: the last part is 0.8 ms of work behind the last byte; tests: a few KB)
-  part = std::max(FC, part / FC * FC);
-  bool spec_on = !cfg_->fe_no_spec.set;
-  const unsigned int k2b_blocks = (unsigned int)cfg_->fe_k2b_blocks.u;  // (tuning hook)
-  unsigned long long *d_seg = nullptr, seg_cap = 0, base = 0;
-  unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
-  unsigned long long pending = 0;  // the last segment so far: not inserted yet
-  bool have_pending = false;
-  std::string fail;
-  try {
-    for (unsigned long long b0 = 0; b0 < n; b0 += part) {
-      const unsigned long long b1 = std::min(n, b0 + part);
-      if (!wait_for(std::min(n, b1 + FC))) break;
-      const unsigned long long c_lo = b0 / FC, c_hi = fe_chunks(b1);
-      t_begin(KT_CHAR_HIST);
-      launch_char_hist(d_text_, n, d_hist_, d_counters_, wide_chars, d_chunk_segs_, st_, c_lo, c_hi);
-      t_end(KT_CHAR_HIST, b1 - b0);
-      if (!spec_on) continue;
-      // the part's segments: where they go (relative to the part's first), how many
-      unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(c_hi - c_lo));
-      t_begin(KT_SEGS);
-      launch_exclusive_scan(d_chunk_segs_ + c_lo, c_hi - c_lo, d_chunk_off + c_lo, scan_tmp, d_counters_ + 16, st_);
-      unsigned long long n_p = 0;
-      HIP_CHECK(hipMemcpyAsync(&n_p, d_counters_ + 16, 8, hipMemcpyDeviceToHost, st_));
-      sync();
-      DFREE(scan_tmp);
-      if (b0 == 0) {  // sizes from the first part's density of segments (build_word_table's rules, on an estimate)
-        const double est = (double)n_p * ((double)n / (double)(b1 - b0)) * 1.1 + 1024.0;
-        seg_cap = (unsigned long long)(est * 1.1);
-        d_seg = dmalloc<unsigned long long>(seg_cap);
-        spec_.long_segments = n_p == 0 || (b1 - b0) / std::max<unsigned long long>(n_p, 1) >= 16;
-        const unsigned long long ns = (unsigned long long)est;
-        spec_.ht_cap = !spec_.long_segments && !cfg_->word_table_full.set ? pow2_at_least(std::max<unsigned long long>(ns / 4, 1ull << 16))
-                                                                                : pow2_at_least(ns + ns / 2 + 1024);
-        spec_.ht = dmalloc<unsigned long long>(3 * spec_.ht_cap);
-        launch_word_table_clear(spec_.ht, spec_.ht_cap, st_);
-        HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
-      }
-      if (base + n_p > seg_cap) {  // denser than the first part promised: no room for the segment starts -- the usual way then
-        t_end(KT_SEGS, 0);
-        spec_on = false;
-        continue;
-      }
-      launch_seg_write(d_text_, n, d_seg + base, d_chunk_off, st_, c_lo, c_hi);
-      t_end(KT_SEGS, (b1 - b0) + 8 * n_p);
-      if (n_p) {
-        // every segment that starts in this part but its last -- that one may run on into bytes that have not landed -- and the last of the
-        // parts before, which ended in front of this part's first segment
-        const unsigned long long from = have_pending ? pending : base, to = base + n_p - 1;
-        if (to > from) {
-          t_begin(KT_DEDUP);
-          launch_insert_words(d_text_, n, d_cpmap_spec, d_seg + from, to - from, spec_.ht, spec_.ht_cap - 1, d_status, st_, k2b_blocks);
-          t_end(KT_DEDUP, (b1 - b0) + 8 * n_p);
-        }
-        pending = to;
-        have_pending = true;
-      }
-      base += n_p;
-    }
-  } catch (const GpuError &e) {
-    fail = e.msg;
-    stop.store(true);  // (the upload ends with its chunk in flight instead of with the file's last byte)
-  }
-  up.join();
-  if (fail.empty() && !up_error.empty()) fail = up_error;
-  if (fail.empty()) {
-    try {
-      if (spec_on && d_seg) {
-        if (have_pending) {
-          t_begin(KT_DEDUP);
-          launch_insert_words(d_text_, n, d_cpmap_spec, d_seg + pending, 1, spec_.ht, spec_.ht_cap - 1, d_status, st_);
-          t_end(KT_DEDUP, 0);
-        }
-        HIP_CHECK(hipMemcpyAsync(spec_.h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
-      }
-      sync();
-    } catch (const GpuError &e) {
-      fail = e.msg;
-    }
-  }
-  DFREE(d_seg);
-  DFREE(d_chunk_off);
-  DFREE(d_cpmap_spec);
-  if (!fail.empty()) {
-    drop_spec();
-    throw GpuError{fail};
-  }
-  if (cfg_->trace.set)
-    fprintf(stderr, "[yttm] front end under the upload: the last byte landed after %.2f ms, the last part was done after %.2f ms (%llu segments, parts of %llu MB, word table %s)\n",
-            ms_link, ms_now(), base, part >> 20, spec_on && spec_.ht ? "made" : "left to build_word_table");
-  spec_.hist_done = true;
-  spec_.n_segs = base;
-  spec_.words_done = spec_on && spec_.ht != nullptr;
-  if (!spec_.words_done && spec_.ht) DFREE(spec_.ht);
-}
-
-// (the front end under the upload: a text worth the trouble.  Round 5: on every rank of a multi-GPU run too -- K1, K2a and K2b of a rank's byte
-// range need nothing from the other ranks; what the ranks exchange -- the char histogram, then the pair counts -- comes after, as before.  The
-// rank's word table is taken if the COMMON alphabet keeps every char of the whole text, a sufficient condition that every rank evaluates
-// alike; a rank that cannot take it redoes its own dedup, no collective depends on it.)
-bool GpuCtx::overlap_front_end(unsigned long long n) const {
-  return n >= cfg_->fe_overlap_min.u && !cfg_->fe_no_overlap.set;
-}
-
-void GpuCtx::upload_corpus_fd(int fd, unsigned long long lo, unsigned long long n) {
-  auto from_file = [&](void *dst, unsigned long long off, size_t len) {
-    size_t got = 0;
-    while (got < len) {
-      const ssize_t r = pread(fd, (char *)dst + got, len - got, (off_t)(lo + off + got));
-      if (r <= 0) return false;
-      got += (size_t)r;
-    }
-    return true;
-  };
-  chunked_ = false;
-  if (chunk_bytes_for(n)) {  // (too large for the HBM that is free: in chunks, front_end_chunked below; the descriptor stays open until the training is over)
-    drop_spec();
-    chunk_src_ = [fd, lo](void *dst, unsigned long long off, size_t len) {
-      size_t got = 0;
-      while (got < len) {
-        const ssize_t r = pread(fd, (char *)dst + got, len - got, (off_t)(lo + off + got));
-        if (r <= 0) return false;
-        got += (size_t)r;
-      }
-      return true;
-    };
-    chunk_src_n_ = n;
-    front_end_chunked(true);
-    return;
-  }
-  if (overlap_front_end(n)) {
-    upload_overlapped(n, from_file);
-    return;
-  }
-  drop_spec();
-  upload_staged(n, [&](void *dst, unsigned long long off, size_t len) {
-    size_t got = 0;
-    while (got < len) {
-      const ssize_t r = pread(fd, (char *)dst + got, len - got, (off_t)(lo + off + got));
-      if (r <= 0) return false;
-      got += (size_t)r;
-    }
-    return true;
-  });
-}
-
-// ---- corpora larger than the HBM left for them (round 5; VERDICT r4 "missing" #2) --------------------------------------------------------
-// The reference's limit is host memory (fast_read_file_utf8, bpe.cpp:67-84); here the whole text, its segment starts (8 bytes per word) and
-// the word table had to sit in HBM together -- about six bytes per byte of text.  Nothing after the dedup needs the text, only the distinct
-// words: so a text that does not fit crosses the device in CHUNKS cut at white space (like the reference's per-thread split, bpe.cpp:864-873).
-// One buffer, [chunk region C bytes | 64 spaces | lexicon]: K1 and K2a see a chunk as they see a whole text; K2b inserts its words into the ONE
-// word table, `sub` segments per launch with the table grown (rehashed) ahead of a launch that could fill it beyond half; then k2b_relocate
-// copies the bytes of every word first seen in this chunk to the lexicon and points its slot there, and the next chunk overwrites the region.
-// At the end the "text" the rest of the trainer reads words from -- compaction, token fill -- is the lexicon: the same offsets into the same
-// buffer.  first_pass: K1 runs and words are compared by code points (upload_overlapped's speculation: right whenever the alphabet keeps every
-// char); else -- coverage dropped chars -- the source is read a second time with the real char map.  Peak HBM is C + the lexicon + the table +
-// 8 bytes per segment of one chunk, whatever the size of the file.
-unsigned long long GpuCtx::chunk_bytes_for(unsigned long long n) const {
-  unsigned long long c = cfg_->fe_chunk_kb.u ? cfg_->fe_chunk_kb.u << 10 : cfg_->fe_chunk_mb.u << 20;
-  if (!c) {
-    const unsigned long long free_b = free_device_bytes();
-    if (6 * n + (1ull << 30) <= free_b / 4 * 3) return 0;  // text + segment starts + word table + tiles fit at once
-    c = std::min<unsigned long long>(std::max<unsigned long long>(free_b / 24, 256ull << 20), 4ull << 30);
-  }
-  c = std::max<unsigned long long>(c / 4096 * 4096, 4096);
-  return n > c ? c : 0;
-}
-
-void GpuCtx::front_end_chunked(bool first_pass) {
-  HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
-  tl_device = device_;
-  const unsigned long long n = chunk_src_n_;
-  const auto &fill = chunk_src_;
-  unsigned long long C = (!first_pass && chunk_cap_) ? chunk_cap_ : chunk_bytes_for(n);  // (a second pass: the first one's size -- less memory is free now)
-  if (!C) C = std::max<unsigned long long>(n / 4096 * 4096 + 4096, 4096);
-  drop_spec();
-  DFREE(d_text_owned_);
-  chunked_ = true;
-  chunk_cap_ = C;
-  corpus_bytes = n;
-  // ---- where the chunks end: behind the last ASCII white space at or before start + C
-  std::vector<unsigned long long> cuts{0};
-  {
-    std::vector<uint8_t> win(1u << 16);
-    while (cuts.back() < n) {
-      const unsigned long long b0 = cuts.back();
-      unsigned long long b1 = std::min(n, b0 + C);
-      if (b1 < n) {
-        unsigned long long hi = b1, found = ~0ull;
-        while (hi > b0 && found == ~0ull) {
-          const unsigned long long lo = hi - std::min<unsigned long long>(hi - b0, win.size());
-          if (!fill(win.data(), lo, (size_t)(hi - lo))) throw GpuError{"corpus read failed"};
-          for (unsigned long long k = hi - lo; k-- > 0;) {
-            const uint8_t b = win[(size_t)k];
-            if (b == 32 || (b >= 9 && b <= 13)) { found = lo + k + 1; break; }
-          }
-          hi = lo;
-        }
-        if (found == ~0ull || found <= b0) throw GpuError{"a word longer than the front end's chunk (" + std::to_string(C) + " bytes): raise YTTM_FE_CHUNK_MB"};
-        b1 = found;
-      }
-      cuts.push_back(b1);
-    }
-  }
-  const size_t n_chunks = cuts.size() - 1;
-  front_end_chunks = n_chunks;
-  // ---- buffers
-  const unsigned long long GAP = 64, LEX0 = C + GAP;
-  lex_cap_ = std::max<unsigned long long>(C / 4, 4096);
-  lex_used_ = 0;
-  uint8_t *B = dmalloc<uint8_t>(LEX0 + lex_cap_ + 2 * GAP);
-  d_text_owned_ = B;
-  d_text_ = B;
-  const unsigned long long sub = std::min<unsigned long long>(std::max<unsigned long long>(C / 16, 256), 4ull << 20);  // segments per K2b launch
-  unsigned long long cap = pow2_at_least(std::max<unsigned long long>(4 * sub, 1024));
-  unsigned long long *ht = dmalloc<unsigned long long>(3 * cap);
-  launch_word_table_clear(ht, cap, st_);
-  unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
-  HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
-  unsigned long long *d_cur = d_counters_ + 56;  // [0] the lexicon's end (an offset into B), [1] bytes a relocation will need
-  {
-    const unsigned long long init[2] = {LEX0, 0};
-    HIP_CHECK(hipMemcpyAsync(d_cur, init, 16, hipMemcpyHostToDevice, st_));
-  }
-  // K1's variant from four samples of the source, as upload_overlapped does
-  bool wide_chars = true;
-  if (n >= (1u << 16)) {
-    unsigned int wide = 0;
-    uint8_t smp[4096];
-    for (int i = 0; i < 4; i++) {
-      if (!fill(smp, (n / 4) * (unsigned long long)i, sizeof smp)) throw GpuError{"corpus read failed"};
-      for (size_t j = 0; j < sizeof smp; j++) wide += smp[j] >= 0xE0u;
-    }
-    wide_chars = wide * 100u > 4u * 4096u;
-  }
-  if (cfg_->k1_wide.set) wide_chars = cfg_->k1_wide.i != 0;
-  unsigned long long *hist = nullptr, *counters = nullptr, *scratch_hist = nullptr;
-  if (first_pass) {
-    if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
-    HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
-    HIP_CHECK(hipMemsetAsync(d_counters_, 0, 24 * 8, st_));
-    hist = d_hist_;
-    counters = d_counters_;
-  } else {  // (the second pass needs K1 only for the chunks' segment counts: its histogram and counters go to a scratch copy)
-    scratch_hist = dmalloc<unsigned long long>(N_CODEPOINTS + 8);
-    HIP_CHECK(hipMemsetAsync(scratch_hist, 0, ((size_t)N_CODEPOINTS + 8) * 8, st_));
-    hist = scratch_hist;
-    counters = scratch_hist + N_CODEPOINTS;
-  }
-  // the char map words are compared by: code points (first pass) or the alphabet's ids
-  uint32_t *d_map_spec = nullptr;
-  const uint32_t *d_map = d_cpmap_;
-  if (first_pass) {
-    std::vector<uint32_t> ident(N_CODEPOINTS);
-    for (uint32_t c = 0; c < N_CODEPOINTS; c++) ident[c] = c;
-    for (uint32_t sp : {9u, 10u, 11u, 12u, 13u, 32u, 9601u}) ident[sp] = CP_SPACE;
-    d_map_spec = dmalloc<uint32_t>(N_CODEPOINTS);
-    HIP_CHECK(hipMemcpyAsync(d_map_spec, ident.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, st_));
-    sync();  // (ident goes out of scope)
-    d_map = d_map_spec;
-  }
-  const unsigned long long nch_max = fe_chunks(C) + 2;
-  DFREE(d_chunk_segs_);
-  d_chunk_segs_ = dmalloc<uint32_t>(nch_max);
-  unsigned long long *d_chunk_off = dmalloc<unsigned long long>(nch_max);
-  unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(nch_max));
-  unsigned long long segs_total = 0, n_unique_host = 0;
-  unsigned int h_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const auto t0 = std::chrono::steady_clock::now();
-  for (size_t ck = 0; ck < n_chunks; ck++) {
-    const unsigned long long b0 = cuts[ck], len = cuts[ck + 1] - b0;
-    if (!len) continue;
-    // ---- the chunk, then spaces behind it (its last segment ends there if the text does not end with white space)
-    staged_transfer(device_, B, len, true, [&](void *dst, unsigned long long off, size_t l) { return fill(dst, b0 + off, l); });
-    HIP_CHECK(hipMemsetAsync(B + len, 32, GAP, st_));
-    const unsigned long long nch = fe_chunks(len);
-    t_begin(KT_CHAR_HIST);
-    launch_char_hist(B, len, hist, counters, wide_chars, d_chunk_segs_, st_);
-    t_end(KT_CHAR_HIST, first_pass ? len : 0);
-    t_begin(KT_SEGS);
-    launch_exclusive_scan(d_chunk_segs_, nch, d_chunk_off, scan_tmp, d_counters_ + 16, st_);
-    unsigned long long n_p = 0;
-    HIP_CHECK(hipMemcpyAsync(&n_p, d_counters_ + 16, 8, hipMemcpyDeviceToHost, st_));
-    sync();
-    unsigned long long *d_seg = dmalloc<unsigned long long>(std::max<unsigned long long>(n_p, 1));
-    launch_seg_write(B, len, d_seg, d_chunk_off, st_);
-    t_end(KT_SEGS, len + 8 * n_p);
-    segs_total += n_p;
-    // ---- its words into the table, `sub` segments per launch; the table is grown ahead of a launch that could fill it beyond half
-    const unsigned long long extent = LEX0 + lex_cap_ + GAP;  // (every offset a kernel may read from: the chunk, the gap, the lexicon)
-    for (unsigned long long s0 = 0; s0 < n_p; s0 += sub) {
-      const unsigned long long cnt = std::min(sub, n_p - s0);
-      if (2 * (n_unique_host + cnt) > cap) {
-        unsigned long long ncap = cap;
-        while (2 * (n_unique_host + cnt) > ncap / 2) ncap <<= 1;  // (a quarter full at most after this launch: growth is rare)
-        unsigned long long *nht = dmalloc<unsigned long long>(3 * ncap);
-        launch_word_table_clear(nht, ncap, st_);
-        launch_word_table_rehash(B, extent, d_map, ht, cap, nht, ncap, st_);
-        sync();
-        DFREE(ht);
-        ht = nht;
-        cap = ncap;
-        word_table_retries++;
-      }
-      t_begin(KT_DEDUP);
-      launch_insert_words(B, extent, d_map, d_seg + s0, cnt, ht, cap - 1, d_status, st_);
-      t_end(KT_DEDUP, (len * cnt) / std::max<unsigned long long>(n_p, 1) + 8 * cnt);
-      HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
-      sync();
-      if (h_status[6]) throw GpuError{"word table overflow (chunked front end)"};
-      n_unique_host = h_status[0];
-    }
-    DFREE(d_seg);
-    // ---- the chunk's new words move to the lexicon: first how many bytes, the lexicon grown if they do not fit, then the move
-    HIP_CHECK(hipMemsetAsync(d_cur + 1, 0, 8, st_));
-    launch_words_relocate(B, C, len + 1, ht, cap, d_cur + 1, /*move=*/false, st_);
-    unsigned long long need = 0;
-    HIP_CHECK(hipMemcpyAsync(&need, d_cur + 1, 8, hipMemcpyDeviceToHost, st_));
-    sync();
-    if (lex_used_ + need > lex_cap_) {
-      unsigned long long ncap = lex_cap_;
-      while (lex_used_ + need > ncap) ncap <<= 1;
-      uint8_t *NB = dmalloc<uint8_t>(LEX0 + ncap + 2 * GAP);
-      HIP_CHECK(hipMemcpyAsync(NB, B, (size_t)(LEX0 + lex_used_), hipMemcpyDeviceToDevice, st_));  // (the chunk too: its new words are still read from it)
-      sync();
-      DFREE(d_text_owned_);
-      B = NB;
-      d_text_owned_ = B;
-      d_text_ = B;
-      lex_cap_ = ncap;
-    }
-    if (need) launch_words_relocate(B, C, len + 1, ht, cap, d_cur, /*move=*/true, st_);
-    lex_used_ += need;
-    sync();  // (the next chunk's upload runs on the workers' streams: the region must not be overwritten under the move)
-  }
-  HIP_CHECK(hipMemsetAsync(B + LEX0 + lex_used_, 32, 2 * GAP, st_));
-  HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
-  sync();
-  DFREE(d_chunk_off);
-  DFREE(scan_tmp);
-  DFREE(d_map_spec);
-  DFREE(scratch_hist);
-  n_text_ = LEX0 + lex_used_ + GAP;  // what build_word_table reads words from: offsets into B, the lexicon behind the (now idle) chunk region
-  if (cfg_->trace.set)
-    fprintf(stderr, "[yttm] chunked front end (%s pass): %zu chunks of <= %llu MB in %.1f ms, %llu segments, %u distinct words in %llu slots, lexicon %llu bytes\n",
-            first_pass ? "first" : "second", n_chunks, C >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), segs_total,
-            h_status[0], cap, lex_used_);
-  spec_.hist_done = first_pass;
-  spec_.words_done = true;
-  spec_.n_segs = segs_total;
-  spec_.ht = ht;
-  spec_.ht_cap = cap;
-  spec_.long_segments = true;  // (the table's fill is what the growth rule above made it: no second guess in build_word_table)
-  memcpy(spec_.h_status, h_status, sizeof h_status);
-}
-
-// multi-GPU, small word tables (host_trainer.cpp learn_bpe): every rank ends up with the WHOLE corpus -- the ranks' byte ranges in rank
-// order are the file -- and goes on alone.  Returns the ranks' summed dedup token count when called with gather = false (the decision).
-unsigned long long GpuCtx::allreduce_scalar(unsigned long long v) {
-  HIP_CHECK(hipMemcpyAsync(d_counters_ + 40, &v, 8, hipMemcpyHostToDevice, st_));
-  comm_->allreduce_sum_u64(d_counters_ + 40, 1, st_);
-  unsigned long long out = 0;
-  HIP_CHECK(hipMemcpyAsync(&out, d_counters_ + 40, 8, hipMemcpyDeviceToHost, st_));
-  sync();
-  return out;
-}
-unsigned long long GpuCtx::free_device_bytes() const {
-  if (cfg_->test_free_bytes.set) return cfg_->test_free_bytes.u;
-  size_t fr = 0, tot = 0;
-  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
-  std::lock_guard<std::mutex> g(g_pool.mu);
-  return (unsigned long long)fr + (unsigned long long)g_pool.cached;
-}
-void GpuCtx::gather_full_corpus() {
-  drop_spec();
-  HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
-  tl_device = device_;
-  chain_event_ = nullptr;
-  const int W = comm_->world, R = comm_->rank;
-  std::vector<unsigned long long> sizes((size_t)W, 0);
-  unsigned long long *d_sz = dmalloc<unsigned long long>((size_t)W);
-  sizes[(size_t)R] = n_text_;
-  HIP_CHECK(hipMemcpyAsync(d_sz, sizes.data(), 8 * (size_t)W, hipMemcpyHostToDevice, st_));
-  comm_->allreduce_sum_u64(d_sz, (size_t)W, st_);
-  HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sz, 8 * (size_t)W, hipMemcpyDeviceToHost, st_));
-  sync();
-  DFREE(d_sz);
-  unsigned long long maxb = 8, total = 0;
-  for (unsigned long long v : sizes) { maxb = std::max(maxb, (v + 7) & ~7ull); total += v; }
-  uint8_t *d_send = dmalloc<uint8_t>(maxb), *d_recv = dmalloc<uint8_t>(maxb * (unsigned long long)W);
-  HIP_CHECK(hipMemsetAsync(d_send, 32, maxb, st_));
-  if (n_text_) HIP_CHECK(hipMemcpyAsync(d_send, d_text_, n_text_, hipMemcpyDeviceToDevice, st_));
-  comm_->allgather_blocks(d_send, d_recv, maxb, st_);
-  uint8_t *d_full = dmalloc<uint8_t>(total + 64);
-  unsigned long long off = 0;
-  for (int r = 0; r < W; r++) {
-    if (sizes[(size_t)r]) HIP_CHECK(hipMemcpyAsync(d_full + off, d_recv + maxb * (unsigned long long)r, sizes[(size_t)r], hipMemcpyDeviceToDevice, st_));
-    off += sizes[(size_t)r];
-  }
-  sync();
-  DFREE(d_send);
-  DFREE(d_recv);
-  DFREE(d_text_owned_);
-  d_text_owned_ = d_full;
-  d_text_ = d_full;
-  n_text_ = total;
-  corpus_bytes = total;
-}
-
-void GpuCtx::attach_corpus(const void *dev, unsigned long long n) {
-  drop_spec();
-  chunked_ = false;
-  HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
-  tl_device = device_;
-  DFREE(d_text_owned_);
-  if (((uintptr_t)dev & 15u) != 0) throw GpuError{"attach_corpus: device pointer must be 16-byte aligned"};
-  d_text_ = (const uint8_t *)dev;
-  n_text_ = n;
-  corpus_bytes = n;
-}
-
-// ------------------------------------------------------------------------------------------------- K1
-void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long long> &cnts, unsigned long long &n_codepoints) {
-  HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
-  tl_device = device_;
-  const bool have_k1 = spec_.hist_done;  // (upload_overlapped ran K1 on the parts of the text as they arrived; multi-GPU: of this rank's shard -- the sum over the ranks follows below)
-  spec_.hist_done = false;
-  if (!have_k1) {
-  if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
-  HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
-  HIP_CHECK(hipMemsetAsync(d_counters_, 0, 64 * 8, st_));
-  // a look at four 4 KB samples of the text: lead bytes of three- and four-byte chars (>= 0xE0) above 1 % pick the kernel variant that
-  // counts such chars in LDS (only speed depends on the verdict)
-  bool wide_chars = false;
-  if (n_text_ >= (1u << 16)) {
-    static thread_local uint8_t smp[4][4096];
-    for (int i = 0; i < 4; i++) HIP_CHECK(hipMemcpyAsync(smp[i], d_text_ + (n_text_ / 4) * (unsigned long long)i, 4096, hipMemcpyDeviceToHost, st_));
-    sync();
-    unsigned int wide = 0;
-    for (int i = 0; i < 4; i++)
-      for (int j = 0; j < 4096; j++) wide += smp[i][j] >= 0xE0u;
-    wide_chars = wide * 100u > 4u * 4096u;
-  } else {
-    wide_chars = true;  // (small inputs: tests of both variants run on them through YTTM_K1_WIDE)
-  }
-  if (cfg_->k1_wide.set) wide_chars = cfg_->k1_wide.i != 0;
-  t_begin(KT_CHAR_HIST);
-  DFREE(d_chunk_segs_);
-  d_chunk_segs_ = dmalloc<uint32_t>(fe_chunks(n_text_) + 1);
-  if (n_text_) launch_char_hist(d_text_, n_text_, d_hist_, d_counters_, wide_chars, d_chunk_segs_, st_);
-  t_end(KT_CHAR_HIST, n_text_);
-  }
-  unsigned long long h_cnt[2] = {0, 0};
-  HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 16, hipMemcpyDeviceToHost, st_));
-  sync();
-  n_segments = h_cnt[1];  // local segments (before any cross-rank reduction)
-  if (multi()) {
-    comm_->allreduce_sum_u64(d_hist_, N_CODEPOINTS, st_);
-    comm_->allreduce_sum_u64(d_counters_, 1, st_);
-    HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 8, hipMemcpyDeviceToHost, st_));
-    sync();
-  }
-  n_codepoints = h_cnt[0];
-  // compact the non-zero bins
-  uint32_t *d_cps = dmalloc<uint32_t>(N_CODEPOINTS);
-  unsigned long long *d_cnts = dmalloc<unsigned long long>(N_CODEPOINTS);
-  unsigned int *d_n = (unsigned int *)(d_counters_ + 8);
-  HIP_CHECK(hipMemsetAsync(d_n, 0, 4, st_));
-  launch_hist_compact(d_hist_, d_cps, d_cnts, d_n, N_CODEPOINTS, st_);
-  unsigned int k = 0;
-  HIP_CHECK(hipMemcpyAsync(&k, d_n, 4, hipMemcpyDeviceToHost, st_));
-  sync();
-  cps.resize(k);
-  cnts.resize(k);
-  if (k) {
-    HIP_CHECK(hipMemcpyAsync(cps.data(), d_cps, (size_t)k * 4, hipMemcpyDeviceToHost, st_));
-    HIP_CHECK(hipMemcpyAsync(cnts.data(), d_cnts, (size_t)k * 8, hipMemcpyDeviceToHost, st_));
-    sync();
-  }
-  seen_cps_ = cps;
-  DFREE(d_cps);
-  DFREE(d_cnts);
-}
-
-// ------------------------------------------------------------------------------------------------- K2
-void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n_alpha, uint32_t space_id, uint32_t n_ids_cap) {
-  max_id_ = space_id;  // largest token id that can occur in a tile (alphabet now, new ids as they are made)
-  for (uint32_t a = 0; a < n_alpha; a++) max_id_ = std::max(max_id_, id[a]);
-  id_min_ = space_id;  // (K3 counts the pairs of a small id range in a dense table)
-  for (uint32_t a = 0; a < n_alpha; a++) id_min_ = std::min(id_min_, id[a]);
-  id_max_ = max_id_;
-  HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
-  tl_device = device_;
-  // code point -> class map
-  {
-    std::vector<uint32_t> cpmap(N_CODEPOINTS, CP_DROP);
-    for (uint32_t i = 0; i < n_alpha; i++)
-      if (cp[i] < N_CODEPOINTS) cpmap[cp[i]] = id[i];
-    const uint32_t spaces[] = {9, 10, 11, 12, 13, 32, 9601};
-    for (uint32_t s : spaces) cpmap[s] = CP_SPACE;
-    if (!d_cpmap_) d_cpmap_ = dmalloc<uint32_t>(N_CODEPOINTS);
-    HIP_CHECK(hipMemcpyAsync(d_cpmap_, cpmap.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, st_));
-    sync();
-  }
-  free_words();
-  free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
-  cls_[0].nom = TILE_NOM_A; cls_[0].slot = TILE_SLOT_A;
-  cls_[1].nom = TILE_NOM_B; cls_[1].slot = TILE_SLOT_B;
-  n_alpha_ = n_alpha;
-  n_unique = 0; n_tokens0 = 0; n_tiles = 0;
-  id_cap_ = n_ids_cap + 64;
-
-  const unsigned long long n_segs = n_segments;
-  if (n_segs == 0 || n_text_ == 0) { drop_spec(); return; }
-  // The word table upload_overlapped made under the upload is this text's iff words compared by code points are words compared by ids:
-  // every char that occurs (and is no space) has an id of its own.  And the table must not have overflowed or filled beyond what the sizing
-  // below accepts.
-  bool take_spec = spec_.words_done && spec_.n_segs == n_segs;  // (multi-GPU: seen_cps_ is the chars of ALL shards -- a superset of this one's)
-  if (take_spec) {
-    std::vector<uint32_t> kept(cp, cp + n_alpha);
-    std::sort(kept.begin(), kept.end());
-    for (uint32_t c : seen_cps_) {
-      const bool space = c == 32 || (c >= 9 && c <= 13) || c == 9601;
-      if (!space && !std::binary_search(kept.begin(), kept.end(), c)) { take_spec = false; break; }
-    }
-    if (spec_.h_status[6] || (!spec_.long_segments && (unsigned long long)spec_.h_status[0] * 2 > spec_.ht_cap)) take_spec = false;
-  }
-  unsigned long long *ht = nullptr;
-  unsigned long long ht_cap = 0;
-  unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
-  unsigned int h_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (take_spec) {
-    ht = spec_.ht;
-    ht_cap = spec_.ht_cap;
-    memcpy(h_status, spec_.h_status, sizeof h_status);
-    spec_.ht = nullptr;
-    front_end_overlapped = true;
-  }
-  drop_spec();
-  if (!take_spec && chunked_) {
-    // the text was taken in chunks and is gone; the words it left were compared by code points, which is not this alphabet's partition
-    // (coverage dropped chars): the source once more, words compared by the alphabet's ids (d_cpmap_ is in place)
-    front_end_chunked(false);
-    if (spec_.n_segs != n_segs) throw GpuError{"chunked front end: the second pass over the source found another text"};
-    ht = spec_.ht;
-    ht_cap = spec_.ht_cap;
-    memcpy(h_status, spec_.h_status, sizeof h_status);
-    spec_.ht = nullptr;
-    drop_spec();
-    take_spec = true;
-  }
-  if (!take_spec) {
-  // segment starts
-  unsigned long long *d_seg = dmalloc<unsigned long long>(n_segs);
-  {
-    // where each 4 KB chunk's segments go: exclusive scan of the counts K1 left (no cursor, and the starts come out in text order)
-    const unsigned long long nch = fe_chunks(n_text_);
-    unsigned long long *d_chunk_off = dmalloc<unsigned long long>(nch + 1);
-    unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(nch));
-    t_begin(KT_SEGS);
-    launch_exclusive_scan(d_chunk_segs_, nch, d_chunk_off, scan_tmp, d_counters_ + 16, st_);
-    launch_seg_write(d_text_, n_text_, d_seg, d_chunk_off, st_);
-    t_end(KT_SEGS, n_text_ + 8 * n_segs);
-    sync();
-    DFREE(d_chunk_off);
-    DFREE(scan_tmp);
-  }
-  // hash dedup.  The table is sized for an eighth as many distinct words as there are occurrences (natural text and the
-  // benchmark corpora have far fewer: Heaps' law) -- the compaction pass streams it, and a small table keeps the frequent words'
-  // slots cache-resident; a corpus of mostly distinct words overflows it (probe chains beyond WH_MAX_PROBES) and is redone
-  // with the worst-case size.
-  for (int attempt = 0;; attempt++) {
-    // (long segments -- CJK-shaped text: clauses of dozens of chars between white space -- are nearly all distinct: the estimate is bound to
-    // fail there and the whole dedup would run twice; K1 knows the average segment length)
-    const bool long_segments = n_text_ / n_segs >= 16;
-    ht_cap = attempt == 0 && !long_segments && !cfg_->word_table_full.set ? pow2_at_least(std::max<unsigned long long>(n_segs / 4, 1ull << 16))
-                                                                                 : pow2_at_least(n_segs + n_segs / 2 + 1024);
-    ht = dmalloc<unsigned long long>(3 * ht_cap);  // keys, counts, positions of the short words' representatives (k_frontend.hip: WH_SHORT)
-    launch_word_table_clear(ht, ht_cap, st_);
-    HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
-    t_begin(KT_DEDUP);
-    launch_insert_words(d_text_, n_text_, d_cpmap_, d_seg, n_segs, ht, ht_cap - 1, d_status, st_);
-    t_end(KT_DEDUP, n_text_ + 8 * n_segs);
-    HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
-    sync();
-    // (more than half full counts as overflow too: the merge loop's tiles do not care, but probe chains do)
-    if (!h_status[6] && (attempt || long_segments || (unsigned long long)h_status[0] * 2 <= ht_cap)) break;
-    if (attempt) { DFREE(ht); DFREE(d_seg); throw GpuError{"word table overflow"}; }
-    DFREE(ht);
-    word_table_retries++;
-  }
-  DFREE(d_seg);
-  }
-  if (h_status[5] >= (1u << 28)) {
-    DFREE(ht);
-    throw GpuError{"a word of 2^28 or more characters is not supported"};
-  }
-  const unsigned int U = h_status[0], UC = h_status[4], UB = h_status[2] - UC, UA = U - UB - UC;
-  if (UC) {  // very long words: same layout, slot sized by the longest of them, one workgroup per tile (k_giant.hip)
-    cls_[2].nom = h_status[5];
-    cls_[2].slot = (2 * h_status[5] + 3u) & ~3u;
-  }
-  // A tile holds whole words in a fixed slot and only ever shrinks, so the slack a slot needs is one word: pack the
-  // slots as full as the longest word allows (HBM pages are then read densely and there are fewer tiles to visit).
-  if (h_status[3] > 0 && h_status[3] < (unsigned int)TILE_NOM_A) cls_[0].nom = (unsigned int)TILE_SLOT_A - h_status[3];
-  n_unique = U;
-  if (U == 0) { DFREE(ht); return; }
-  // (room for the extra copies of words seen more than 2^32 - 1 times: k2c_compact_words)
-  constexpr unsigned int HX = 4 * HEAVY_CAP;
-  unsigned long long *posA = dmalloc<unsigned long long>(UA + HX), *posB = dmalloc<unsigned long long>(UB + HX), *posC = dmalloc<unsigned long long>(UC + HX);
-  uint32_t *lenA = dmalloc<uint32_t>(UA + HX), *lenB = dmalloc<uint32_t>(UB + HX), *lenC = dmalloc<uint32_t>(UC + HX);
-  cls_[2].d_wcnt = dmalloc<uint32_t>(UC + HX + 256);
-  cls_[0].d_wcnt = dmalloc<uint32_t>(UA + HX + 256);  // padding: k_tiles loads SLOT/2 frequencies from a tile's first word unconditionally
-  cls_[1].d_wcnt = dmalloc<uint32_t>(UB + HX + 256);
-  unsigned int *d_cursor = (unsigned int *)(d_counters_ + 32);
-  HIP_CHECK(hipMemsetAsync(d_cursor, 0, 16, st_));
-  unsigned long long *d_heavy = dmalloc<unsigned long long>(3 * HEAVY_CAP);
-  const unsigned long long wmax = cfg_->test_wcnt_max.u;  // (tests: heavy words at toy sizes)
-  t_begin(KT_BUILD);
-  launch_compact_words(d_text_, n_text_, d_cpmap_, ht, ht_cap, posA, cls_[0].d_wcnt, lenA, posB, cls_[1].d_wcnt, lenB, posC, cls_[2].d_wcnt, lenC, d_cursor,
-                       d_status, wmax, d_heavy, st_);
-  unsigned int h_cursor[4] = {0, 0, 0, 0};
-  HIP_CHECK(hipMemcpyAsync(h_status, d_status, 16, hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipMemcpyAsync(h_cursor, d_cursor, 16, hipMemcpyDeviceToHost, st_));
-  sync();
-  DFREE(ht);
-  unsigned int UA2 = UA, UB2 = UB, UC2 = UC;
-  if (h_cursor[3] && !(h_status[1] & 2u)) {
-    // words seen more than wmax times (the reference counts in uint64, bpe.cpp:382-385): more copies of the word until the weights add up
-    // to its count -- every pair count is a sum over words, so the merge loop computes what it would with one word of the whole weight
-    std::vector<unsigned long long> hv(3 * (size_t)h_cursor[3]);
-    HIP_CHECK(hipMemcpy(hv.data(), d_heavy, hv.size() * 8, hipMemcpyDeviceToHost));
-    std::vector<unsigned long long> xp[3];
-    std::vector<uint32_t> xl[3], xc[3];
-    bool too_many = false;
-    for (unsigned int i = 0; i < h_cursor[3]; i++) {
-      const uint32_t len = (uint32_t)hv[3 * i + 1];
-      const int ci = len > (uint32_t)TILE_NOM_B ? 2 : len > (uint32_t)TILE_NOM_A ? 1 : 0;
-      for (unsigned long long left = hv[3 * i + 2]; left;) {
-        const unsigned long long c = std::min(left, wmax);
-        xp[ci].push_back(hv[3 * i]); xl[ci].push_back(len); xc[ci].push_back((uint32_t)c);
-        left -= c;
-        if (xp[ci].size() > HX) { too_many = true; break; }
-      }
-    }
-    if (too_many) h_status[1] |= 2u;
-    else {
-      unsigned long long *pos[3] = {posA, posB, posC};
-      uint32_t *len[3] = {lenA, lenB, lenC};
-      unsigned int *U2[3] = {&UA2, &UB2, &UC2};
-      for (int ci = 0; ci < 3; ci++) {
-        if (xp[ci].empty()) continue;
-        HIP_CHECK(hipMemcpy(pos[ci] + *U2[ci], xp[ci].data(), xp[ci].size() * 8, hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(len[ci] + *U2[ci], xl[ci].data(), xl[ci].size() * 4, hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(cls_[ci].d_wcnt + *U2[ci], xc[ci].data(), xc[ci].size() * 4, hipMemcpyHostToDevice));
-        *U2[ci] += (unsigned int)xp[ci].size();
-      }
-      n_unique = (unsigned long long)UA2 + UB2 + UC2;
-    }
-  }
-  DFREE(d_heavy);
-  if (h_status[1] & 2u) { DFREE(posA); DFREE(posB); DFREE(lenA); DFREE(lenB); DFREE(posC); DFREE(lenC); throw GpuError{"too many words seen 2^32 times or more"}; }
-  build_class(0, posA, lenA, UA2, space_id);
-  build_class(1, posB, lenB, UB2, space_id);
-  build_class(2, posC, lenC, UC2, space_id);
-  if (cls_[2].n_tiles) cls_[2].d_scratch = dmalloc<uint32_t>((size_t)cls_[2].n_tiles * 4 * cls_[2].slot);
-  t_end(KT_BUILD, n_text_ / 8 + 4 * (cls_[0].n_tokens0 + cls_[1].n_tokens0 + cls_[2].n_tokens0) + 16ull * U);
-  sync();
-  DFREE(posA); DFREE(posB); DFREE(lenA); DFREE(lenB); DFREE(posC); DFREE(lenC);
-  n_tokens0 = cls_[0].n_tokens0 + cls_[1].n_tokens0 + cls_[2].n_tokens0;
-  n_tiles = cls_[0].n_tiles + cls_[1].n_tiles + cls_[2].n_tiles;
-}
-
-void GpuCtx::free_class(WordClass &c) {
-  DFREE(c.d_tok); DFREE(c.d_tile_len); DFREE(c.d_tile_word0); DFREE(c.d_wcnt); DFREE(c.d_work_n); DFREE(c.d_scratch);
-  c.ts = TileSet{};
-  c.n_unique = c.n_tokens0 = 0;
-  c.n_tiles = 0;
-}
-
-// offsets -> tiles -> token slots for one class of unique words
-void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, unsigned int U, uint32_t space_id) {
-  WordClass &c = cls_[ci];
-  c.n_unique = U;
-  if (U == 0) return;
-  unsigned long long *uw_off = dmalloc<unsigned long long>(U);
-  unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(U));
-  launch_exclusive_scan(uw_len, U, uw_off, scan_tmp, d_counters_ + 40, st_);
-  unsigned long long total = 0, last_off = 0;
-  HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 40, 8, hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipMemcpyAsync(&last_off, uw_off + (U - 1), 8, hipMemcpyDeviceToHost, st_));
-  sync();
-  DFREE(scan_tmp);
-  c.n_tokens0 = total;
-  c.n_tiles = (unsigned int)(last_off / c.nom) + 1;
-  unsigned long long *tile_start = dmalloc<unsigned long long>(c.n_tiles);
-  c.d_tile_word0 = dmalloc<uint32_t>(c.n_tiles);
-  c.d_tile_len = dmalloc<uint32_t>(c.n_tiles);
-  c.d_work_n = dmalloc<unsigned int>(16);  // word mode: the round's worklist length [0], "take every word" [WL_PARTS + 1]
-  HIP_CHECK(hipMemsetAsync(c.d_work_n, 0, 64, st_));
-  if (ci == 0 && !multi()) {
-    // The pair table is allocated and cleared HERE, ahead of the token fill, not right before K3: K3 then does not start on the
-    // dirty lines of a 1 GB memset (measured: 0.435 -> 0.395 ms at 1 GB).
-    free_table(pt_);
-    pt_cap_ = 0;
-    ensure_table_capacity(initial_table_keys(total));
-    pt_fresh_ = true;
-  }
-  c.d_tok = dmalloc<uint32_t>((size_t)c.n_tiles * c.slot + 64);
-  // slots are read 16 B wide past the live prefix and the staged ids index the flag table: never leave them undefined
-  HIP_CHECK(hipMemsetAsync(c.d_tok, 0, ((size_t)c.n_tiles * c.slot + 64) * 4, st_));
-  launch_tiles(uw_off, U, c.nom, tile_start, c.d_tile_word0, st_);
-  launch_tile_len(tile_start, c.n_tiles, total, c.d_tile_len, st_);
-  launch_fill_tokens(d_text_, n_text_, d_cpmap_, space_id, uw_pos, uw_off, U, c.nom, c.slot, tile_start, c.d_tok, st_, total);
-  sync();
-  DFREE(uw_off);
-  DFREE(tile_start);
-  c.ts.tok = c.d_tok;
-  c.ts.tile_len = c.d_tile_len;
-  c.ts.tile_word0 = c.d_tile_word0;
-  c.ts.wcnt = c.d_wcnt;
-  c.ts.n_tiles = c.n_tiles;
-}
-
-void GpuCtx::download_word_table(std::vector<uint32_t> &tok, std::vector<unsigned long long> &off, std::vector<uint32_t> &cnt) {
-  tok.clear(); off.clear(); cnt.clear();
-  off.push_back(0);
-  for (int ci = 0; ci < 3; ci++) {
-    WordClass &c = cls_[ci];
-    if (!c.n_tiles) continue;
-    std::vector<uint32_t> all((size_t)c.n_tiles * c.slot), tl(c.n_tiles), wc(c.n_unique);
-    HIP_CHECK(hipMemcpyAsync(all.data(), c.d_tok, all.size() * 4, hipMemcpyDeviceToHost, st_));
-    HIP_CHECK(hipMemcpyAsync(tl.data(), c.d_tile_len, (size_t)c.n_tiles * 4, hipMemcpyDeviceToHost, st_));
-    HIP_CHECK(hipMemcpyAsync(wc.data(), c.d_wcnt, (size_t)c.n_unique * 4, hipMemcpyDeviceToHost, st_));
-    sync();
-    if (ci == 0 && word_mode_) {  // class A in word mode: the words are where wmeta says
-      std::vector<unsigned long long> wm(c.n_unique);
-      HIP_CHECK(hipMemcpy(wm.data(), d_wmeta_, (size_t)c.n_unique * 8, hipMemcpyDeviceToHost));
-      for (unsigned long long w = 0; w < c.n_unique; w++) {
-        const unsigned long long o = wm[w] >> 16, len = wm[w] & 0xffffull;
-        for (unsigned long long p = 0; p < len; p++) {
-          const uint32_t v = all[o + p];
-          if (p == 0 && !tok.empty()) off.push_back(tok.size());
-          tok.push_back(v & TOK_MASK);
-        }
-      }
-      cnt.insert(cnt.end(), wc.begin(), wc.end());
-      continue;
-    }
-    for (unsigned int t = 0; t < c.n_tiles; t++) {
-      for (uint32_t p = 0; p < tl[t]; p++) {
-        uint32_t v = all[(size_t)t * c.slot + p];
-        if ((v & TOK_WS) && !tok.empty()) off.push_back(tok.size());
-        tok.push_back(v & TOK_MASK);
-      }
-    }
-    cnt.insert(cnt.end(), wc.begin(), wc.end());
-  }
-  off.push_back(tok.size());
-  if (tok.empty()) { off.assign(1, 0); }
-}
-
-// Re-deal the live words of a tile class into fresh, full tiles when the average fill has dropped below half.
-void GpuCtx::maybe_repack(int ci) {
-  WordClass &c = cls_[ci];
-  if (c.n_tiles < 2) return;
-  if (ci == 0 && word_mode_) return;  // (the words live in fixed slots now)
-  if (rp_known_[ci]) {
-    // The look itself costs three launches, a copy and a stream synchronisation.  The class holds at least what the last look counted minus
-    // every merge site since (a site removes one token): the sites the mailbox has reported (a round or two old) plus the summed pair counts
-    // of the last rounds' batches, which bound what it may lack.  While that is more than half the nominal fill there is nothing to look at.
-    // (Round 5: in word mode the trigger's "tokens streamed last round" is small against the nominal size of ALL tiles, so a corpus with
-    // class-B tiles -- CJK-shaped text -- took this look, and its synchronisation, every second round: 75 .. 400 us of host time each.)
-    const unsigned long long gone = (sites_cum_ - rp_sites_at_[ci]) + rp_recent_[0] + rp_recent_[1] + rp_recent_[2];
-    if (rp_total_[ci] > gone && (rp_total_[ci] - gone) * 2 > (unsigned long long)c.n_tiles * c.nom) return;
-  }
-  repack_looks++;
-  chain_event_ = nullptr;  // work between two timed intervals: they no longer share an event
-  unsigned long long *off = dmalloc<unsigned long long>(c.n_tiles);
-  unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(c.n_tiles));
-  launch_exclusive_scan(c.d_tile_len, c.n_tiles, off, scan_tmp, d_counters_ + 48, st_);
-  unsigned long long total = 0;
-  HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 48, 8, hipMemcpyDeviceToHost, st_));
-  sync();
-  DFREE(scan_tmp);
-  rp_known_[ci] = true;
-  rp_total_[ci] = total;
-  rp_sites_at_[ci] = sites_cum_;
-  if (total == 0 || total * 2 > (unsigned long long)c.n_tiles * c.nom) { DFREE(off); return; }
-  const unsigned int n_new = (unsigned int)((total - 1) / c.nom) + 1;
-  uint32_t *new_tok = dmalloc<uint32_t>((size_t)n_new * c.slot + 64);
-  uint32_t *new_len = dmalloc<uint32_t>(n_new), *new_word0 = dmalloc<uint32_t>(n_new);
-  unsigned long long *gstart = dmalloc<unsigned long long>(n_new);
-  HIP_CHECK(hipMemsetAsync(new_tok, 0, ((size_t)n_new * c.slot + 64) * 4, st_));
-  HIP_CHECK(hipMemsetAsync(gstart, 0xff, (size_t)n_new * 8, st_));
-  HIP_CHECK(hipMemsetAsync(new_word0, 0xff, (size_t)n_new * 4, st_));
-  launch_repack(ci, c.ts, off, c.nom, total, gstart, n_new, new_tok, new_len, new_word0, st_);
-  sync();
-  DFREE(off); DFREE(gstart);
-  DFREE(c.d_tok); DFREE(c.d_tile_len); DFREE(c.d_tile_word0);
-  c.d_tok = new_tok; c.d_tile_len = new_len; c.d_tile_word0 = new_word0;
-  c.n_tiles = n_new;
-  c.ts.tok = new_tok; c.ts.tile_len = new_len; c.ts.tile_word0 = new_word0; c.ts.n_tiles = n_new;
-  n_tiles = cls_[0].n_tiles + cls_[1].n_tiles + cls_[2].n_tiles;
-  repacks++;
-  if (ci == 0) {  // tile numbers changed: the pair index is void until it is built again
-    idx_valid_ = false;
-    idx_pending_ = true;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------- pair table
-void GpuCtx::alloc_table(PairTable &pt, unsigned long long cap) {
-  pt.slots = dmalloc<unsigned long long>(2 * cap);
-  pt.n_keys = dmalloc<unsigned int>(4);
-  pt.mask = cap - 1;
-  pt.hot_tau = ~0ull;  // no hot list until rebuild_hot()
-  pt.hot_slots = d_hot_slots_;
-  pt.hot_n = d_hot_n_;
-  pt.hot_cap = hot_cap_;
-  pt.top_tau = ~0ull;
-  pt.top_slots = d_top_slots_;
-  pt.top_n = d_top_n_;
-  pt.top_cap = top_cap_;
-  hot_state_ = HOT_INVALID;
-  top_state_ = TOP_INVALID;
-  launch_pt_clear(pt, st_);
-  HIP_CHECK(hipMemsetAsync(pt.n_keys, 0, 16, st_));
-}
-void GpuCtx::free_table(PairTable &pt) {
-  DFREE(pt.slots);
-  DFREE(pt.n_keys);
-  pt.mask = 0;
-}
-
-void GpuCtx::ensure_table_capacity(unsigned long long need_keys) {
-  if (pt_cap_ && need_keys * 2 <= pt_cap_) return;
-  chain_event_ = nullptr;
-  // load stays below 1/2; growth is by 4x (a rehash also costs a rebuild of the hot list)
-  unsigned long long new_cap = pow2_at_least(std::max<unsigned long long>(1ull << 16, need_keys * 4));
-  if (!pt_cap_) {
-    alloc_table(pt_, new_cap);
-    pt_cap_ = new_cap;
-    return;
-  }
-  PairTable nt{};
-  alloc_table(nt, new_cap);
-  launch_pt_rehash(pt_, nt, st_);
-  rehashes++;
-  unsigned int nk = 0;
-  HIP_CHECK(hipMemcpyAsync(&nk, nt.n_keys, 4, hipMemcpyDeviceToHost, st_));
-  sync();
-  free_table(pt_);
-  pt_ = nt;
-  pt_cap_ = new_cap;
-  n_keys_host = nk;
-}
-
-void GpuCtx::grow_recv(unsigned long long need) {
-  if (need <= recv_cap_) return;
-  DFREE(d_recv_);
-  recv_cap_ = need + need / 4 + 1024;
-  d_recv_ = dmalloc<DeltaRec>(recv_cap_);
-}
-
-// Set-up exchange (after K3, once per training): every rank's records, however many.  The counts travel first, so buffers
-// grow before anything is received and the verdicts (fits / overflow) are the same on every rank: nobody is left waiting in a
-// collective the others never posted.
-void GpuCtx::exchange_deltas() {
-  if (!multi()) return;
-  chain_event_ = nullptr;
-  launch_fold_stats(d_stats_, pt_.n_keys, st_);  // the apply kernels leave their slot counts in per-workgroup rows
-  DeltaRec *cur = d_send2_[xch_parity_];  // (K3's updates went straight into the block's records: dt_add)
-  unsigned long long n_local = 0;
-  unsigned int nk_local = 0;  // keys in the table after this rank's own updates (one round trip for both numbers)
-  HIP_CHECK(hipMemcpyAsync(&n_local, cur, 8, hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipMemcpyAsync(&nk_local, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
-  sync();
-  n_keys_host = nk_local;
-  const unsigned long long mine = n_local > send_cap_ ? ~0ull : n_local;
-  size_t n_remote = 0;
-  for (int attempt = 0;; attempt++) {
-    unsigned long long need_all = 0;
-    if (comm_->allgather_recs(cur + XHDR, mine, d_recv_, (size_t)recv_cap_, st_, &need_all, &n_remote)) break;
-    if (need_all == ~0ull) throw GpuError{"delta exchange buffer overflow (on some rank)"};
-    if (attempt) throw GpuError{"delta receive buffer could not be sized"};
-    grow_recv(need_all);
-  }
-  finish_block((unsigned int)std::min<unsigned long long>(n_local, 1u << 20));
-  ensure_table_capacity(n_keys_host + n_remote);
-  launch_pt_apply(pt_, d_recv_, n_remote, st_);  // (no candidate list exists yet: nothing is listed)
-  unsigned int nk = 0;
-  HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
-  sync();
-  n_keys_host = nk;
-}
-
-// Per-round exchange, all stream-ordered, no host round trip:
-//   ncclAllGather of the first blk_ units (header + records) of every rank's send block -- the apply kernels left it complete: dt_add -- ->
-//   k_pt_apply_blocks (phase 1: the other ranks' deltas into the replica, thresholds off) -> k_fold_list (phase 2: the lists, by the final
-//   counts; then -- `scan` -- the round's candidate scan straight into the host's mailbox) -> k_dt_clean (during the host's turn).
-// ONE collective per round.  What does not fit a block is reported through the mailbox (xstat), and candidates() repeats the exchange
-// for exactly those ranks with larger blocks.
-// behind an exchange: the table's slots of the block just sent are freed, the other block is made ready, and the next round's updates go
-// there (k_dt_clean: off the critical path -- it runs while the host picks the next batch)
-void GpuCtx::finish_block(unsigned int n_hint) {
-  db_.send = d_send2_[xch_parity_];
-  launch_dt_clean(db_, d_send2_[xch_parity_ ^ 1u], n_hint, d_stats_, cls_[0].n_tiles, d_maybe_n_ + 1, st_);
-  xch_last_ = d_send2_[xch_parity_];
-  xch_parity_ ^= 1u;
-  db_.send = d_send2_[xch_parity_];
-}
-PairTable GpuCtx::pt_nolist() const {
-  PairTable p = pt_;
-  p.maybe = d_maybe_;  // (the adds note the slots that may have crossed a threshold: k_fold_list looks at those, by their final counts)
-  p.maybe_n = d_maybe_n_;
-  p.maybe_cap = maybe_cap_;
-  p.maybe_hot = pt_.hot_tau;
-  p.maybe_top = pt_.top_tau;
-  p.hot_tau = ~0ull;
-  p.top_tau = ~0ull;
-  return p;
-}
-
-void GpuCtx::exchange_round(unsigned long long only_mask, const ScanArgs *scan) {
-  chain_event_ = nullptr;
-  const DeltaRec *block = only_mask ? xch_last_ : d_send2_[xch_parity_];  // (a repeat gathers the same block again, wider)
-  grow_recv(blk_ * (unsigned long long)comm_->world);
-  comm_->allgather_blocks(block, d_recv_, (size_t)blk_ * sizeof(DeltaRec), st_);
-  const bool alone = comm_->world == 1;  // (no other rank's block: phase 1 has nothing to add, the fold kernel reads the header itself)
-  if (!alone) launch_pt_apply_blocks(pt_nolist(), d_recv_, blk_, comm_->world, comm_->rank, only_mask, d_xstat_, d_stats_, st_);
-  PairTable fpt = pt_;  // (the real thresholds, and the notes to go through)
-  fpt.maybe = d_maybe_;
-  fpt.maybe_n = d_maybe_n_;
-  fpt.maybe_cap = maybe_cap_;
-  launch_fold_list(fpt, d_recv_, blk_, comm_->world, only_mask, scan, d_stats_, pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_,
-                   pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, d_xstat_, alone, st_);
-  if (scan) pending_zero_ = false;  // (the scan zeroes the finished batch's pairs)
-  if (!only_mask) finish_block((unsigned int)std::min<unsigned long long>(blk_ / 2, 1u << 18));  // (about as many records as the block was sized for)
-}
-
-// keys the pair table is sized for before the first merge: distinct initial pairs <= adjacencies <= tokens, and -- the candidate filter
-// does not stream the table, so its size costs nothing per round, while every growth step is a rehash plus a hot-list rebuild -- the
-// size a corpus of this many tokens typically ends with
-unsigned long long GpuCtx::initial_table_keys(unsigned long long n_tok) const {
-  unsigned long long bound = std::min<unsigned long long>(n_tok + 16, ((unsigned long long)n_alpha_ + 1) * (n_alpha_ + 1));
-  bound = std::min<unsigned long long>(bound, 1ull << 26);
-  return std::max(bound, std::min<unsigned long long>(n_tok / 16, 1ull << 25));
-}
-
-void GpuCtx::pair_count() {
-  HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
-  tl_device = device_;
-  n_keys_host = 0;
-  unsigned long long bound = initial_table_keys(n_tokens0);
-  if (multi()) {
-    bound = std::min<unsigned long long>(bound * comm_->world, 1ull << 27);
-    if (!d_send2_[0]) {
-      // distinct pairs a round of this rank can touch: bounded by its updates (a handful per live token); sized for a
-      // quarter of that -- dense rounds touch few distinct pairs, sparse rounds few tokens -- and checked: a rank whose table or
-      // send block overflowed says so in its block's header and every rank stops
-      unsigned long long cap = 1ull << 20;
-      while (cap < n_tokens0 / 2 && cap < (1ull << 27)) cap <<= 1;
-      // (... and never less than twice the distinct pairs K3 itself can produce on this rank: a large alphabet on a small corpus)
-      while (cap < 2 * initial_table_keys(n_tokens0) && cap < (1ull << 28)) cap <<= 1;
-      if (const unsigned int forced = (unsigned int)cfg_->xchg_table_cap.u) {  // (tests: a table that overflows)
-        cap = pow2_at_least(std::max(forced, 4u));
-        delta_cap_forced_ = true;
-      }
-      alloc_delta_table(cap);
-      d_xstat_ = dmalloc<unsigned long long>(XSTAT_WORDS);
-      HIP_CHECK(hipMemsetAsync(d_xstat_, 0, XSTAT_WORDS * 8, st_));
-      maybe_cap_ = std::max(1u, (unsigned int)cfg_->xchg_notes.u);  // (tests shrink it: the fold then walks every record)
-      d_maybe_ = dmalloc<uint32_t>(maybe_cap_);
-      d_maybe_n_ = dmalloc<unsigned int>(4);
-      HIP_CHECK(hipMemsetAsync(d_maybe_n_, 0, 16, st_));
-      blk_min_ = std::max(2u * XHDR, (unsigned int)cfg_->xchg_blk_min.u);  // (tests shrink it to force the repeat path)
-      blk_ = blk_min_;
-      grow_recv(std::max<unsigned long long>(send_cap_, blk_ * (unsigned long long)comm_->world));
-    }
-  }
-  if (multi()) bound = std::max(bound, std::min<unsigned long long>(n_tokens0 / 16 * (unsigned long long)comm_->world, 1ull << 25));
-  if (!pt_fresh_ || bound * 2 > pt_cap_) {  // (normally build_class(0) has put a cleared table of this size in place)
-    free_table(pt_);
-    pt_cap_ = 0;
-  }
-  pt_fresh_ = false;
-  ensure_table_capacity(bound);
-  t_begin(KT_PAIR_COUNT);
-  for (int ci = 0; ci < 2; ci++) launch_pair_count(ci, cls_[ci].ts, pt_, db_, id_min_, id_max_ >= id_min_ ? id_max_ - id_min_ + 1 : 0, st_);
-  launch_giant(false, cls_[2].ts, cls_[2].slot, pt_, db_, nullptr, 0, 0xffffffffu, 0, cls_[2].d_scratch, d_stats_, st_);
-  t_end(KT_PAIR_COUNT, 4 * n_tokens0 + 8 * n_unique);
-  unsigned int nk = 0;
-  HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
-  sync();
-  n_keys_host = nk;
-  exchange_deltas();
-}
-
-// multi-GPU: the round's delta table (pair -> this rank's summed count change) and the send block made from it, for `cap` slots; a
-// table more than half full counts as overflow.  Called at set-up and, from merge_apply, when a round's bound on the distinct pairs it
-// can touch does not fit -- between rounds the table is empty (k_dt_pack frees what a round claimed).
-void GpuCtx::alloc_delta_table(unsigned long long cap) {
-  DFREE(db_.keys); DFREE(db_.touched); DFREE(d_send2_[0]); DFREE(d_send2_[1]);
-  db_.keys = dmalloc<DtSlot>(cap);
-  db_.mask = cap - 1;
-  launch_dt_init(db_.keys, cap, st_);
-  send_cap_ = cap / 2;
-  db_.send_cap = send_cap_;
-  db_.touched = dmalloc<uint32_t>(send_cap_);
-  // the two send blocks { header, records }: all zeros but the capacity in the header -- the peers check a block's count against it
-  for (int b = 0; b < 2; b++) {
-    d_send2_[b] = dmalloc<DeltaRec>(send_cap_ + XHDR);
-    HIP_CHECK(hipMemsetAsync(d_send2_[b], 0, (send_cap_ + XHDR) * sizeof(DeltaRec), st_));
-    const long long capv = (long long)send_cap_;
-    HIP_CHECK(hipMemcpyAsync(&d_send2_[b][0].delta, &capv, 8, hipMemcpyHostToDevice, st_));
-  }
-  xch_parity_ = 0;
-  xch_last_ = d_send2_[0];
-  db_.send = d_send2_[0];
-  sync();
-}
-
-void GpuCtx::download_pairs(std::vector<unsigned long long> &keys, std::vector<unsigned long long> &cnts) {
-  std::vector<CandRec> out;
-  uint32_t n = scan_full(0, 0xffffffffu, out, nullptr);
-  if (n > out.size()) throw GpuError{"download_pairs: more than 2^20 live pairs"};
-  keys.resize(n);
-  cnts.resize(n);
-  for (uint32_t i = 0; i < n; i++) { keys[i] = out[i].key; cnts[i] = out[i].cnt; }
-}
-
-uint32_t GpuCtx::scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist) {
-  HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
-  tl_device = device_;
-  out.clear();
-  if (!pt_cap_) {
-    if (hist) memset(hist, 0, CAND_BINS * 8);
-    memset(hist_buf_, 0, sizeof hist_buf_);
-    last_hist_ = hist_buf_;
-    last_live_ = 0;
-    return 0;
-  }
-  flush_pending_zero();
-  launch_fold_stats(d_stats_, pt_.n_keys, st_);
-  HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, st_));
-  HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, st_));
-  t_begin(KT_CAND);
-  launch_cand_scan(pt_, tau_cnt, tau_mx, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, st_);  // (always with the histogram: last_hist())
-  t_end(KT_CAND, 16 * pt_cap_);
-  // ONE device-to-host copy per round: header + histogram + the first CAND_FAST candidates; a second copy only when
-  // more candidates passed (the host rarely looks past a few thousand)
-  constexpr unsigned int CAND_FAST = 4096;
-  unsigned char *h = (unsigned char *)h_pin_;
-  HIP_CHECK(hipMemcpyAsync(h, d_round_, 8192 + (size_t)CAND_FAST * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
-  sync();
-  const unsigned int n = *(unsigned int *)h;
-  n_keys_host = *(unsigned int *)(h + 4);
-  if (hist) memcpy(hist, h + 64, CAND_BINS * 8);
-  memcpy(hist_buf_, h + 64, CAND_BINS * 8);
-  last_hist_ = hist_buf_;
-  last_live_ = 0;
-  last_top_bin_ = CAND_BINS - 1;
-  for (int b = 1; b < CAND_BINS; b++) last_live_ += hist_buf_[b];
-  const unsigned int take = std::min(n, cand_cap_);
-  CandRec *h_c = (CandRec *)(h + 8192);
-  if (take > CAND_FAST) {
-    HIP_CHECK(hipMemcpyAsync(h_c + CAND_FAST, d_cand_ + CAND_FAST, (size_t)(take - CAND_FAST) * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
-    sync();
-  }
-  out.assign(h_c, h_c + take);
-  HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, st_));  // the hot-list filter expects its counters cleared
-  HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, st_));
-  return n;
-}
-
-// Choose hot_tau from the histogram of the whole table (about HOT_TARGET pairs at or above it, never more than half the
-// list) and list those slots.  Huge ties that do not fit switch the filter back to whole-table scans for a while.
-void GpuCtx::rebuild_hot() {
-  std::vector<CandRec> none;
-  unsigned long long hist[CAND_BINS];
-  pt_.hot_tau = ~0ull;
-  pt_.top_tau = ~0ull;  // (the top list is refilled from the new hot list; k_hot_rebuild clears every PT_TOP)
-  top_state_ = TOP_INVALID;
-  idx_valid_ = false;  // (the pair index holds the OLD list's pairs)
-  idx_pending_ = true;
-  scan_full(~0ull >> 1, 0, none, hist);
-  unsigned long long acc = 0;
-  int chosen = -1;
-  for (int b = CAND_BINS - 1; b >= 1; b--) {
-    if (acc + hist[b] > hot_cap_ / 2) break;
-    acc += hist[b];
-    chosen = b;
-    // (word mode: a rebuilt list means a rebuilt pair index -- two passes over the words.  word_global_, not word_mode_: the threshold this
-    // picks shapes the candidate lists, which must come out alike on every rank of a sharded training)
-    if (acc >= (word_global_ ? std::max(hot_target_, hot_target_words_) : hot_target_)) break;
-  }
-  hot_rebuilds++;
-  if (chosen < 0 || (acc < hot_min_ && chosen > 1)) {  // ties too large for the list right below the few top pairs
-    hot_state_ = HOT_FULLSCAN;
-    fullscan_rounds_ = 0;
-    return;
-  }
-  pt_.hot_tau = std::max<unsigned long long>(1, cand_bin_lower(chosen));
-  HIP_CHECK(hipMemsetAsync(d_hot_n_, 0, 4, st_));
-  t_begin(KT_CAND);
-  launch_hot_rebuild(pt_, st_);
-  t_end(KT_CAND, 8 * pt_cap_);
-  hot_state_ = HOT_ACTIVE;
-  hot_just_rebuilt_ = true;
-}
-
-// multi-GPU: what the fold kernel of this round's exchange reported (ranks whose block was too small, the largest record count,
-// "a rank lost records").  Repeats the exchange for the skipped ranks with blocks that fit, and sizes the next round's blocks --
-// from numbers that are the same on every rank.  True if the table changed (a scan made before that is stale).
-bool GpuCtx::settle_exchange(unsigned long long xmask, unsigned long long xmax, unsigned long long fatal) {
-  if (fatal) throw GpuError{"delta exchange buffer overflow (on some rank)"};
-  unsigned long long want = blk_min_;  // (after a repeat: twice what the busiest rank sent this round)
-  while (want < 2 * xmax + 2 * XHDR) want <<= 1;
-  if (xmax || xmask) {
-    // records per merge site of the round that was just exchanged (its batch's summed pair counts = its sites, over all ranks): what the
-    // next rounds' blocks are sized from (merge_apply) -- rounds differ by a factor of four in their batches, much less in this rate
-    xrate_[1] = xrate_[0];
-    xrate_[0] = xch_sites_ ? (double)xmax / (double)xch_sites_ : 5.0;
-  }
-  if (!xmask) return false;
-  blk_ = blk_min_;
-  while (blk_ < xmax + XHDR) blk_ <<= 1;
-  exchange_round(xmask, nullptr);
-  {  // that fold's own report (same blocks, so nothing new): consumed here
-    HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, st_));
-  }
-  blk_ = std::max(blk_, want);
-  exchange_retries++;
-  // the scan that came too early also zeroed the finished batch's pairs; deltas that arrived after that (k_giant.hip retracts
-  // every old adjacency of a re-counted tile, the merged pairs included) must be zeroed again
-  pending_zero_ = zero_valid_;
-  return true;
-}
-
-// Waits for `round_id` in the pinned mailbox: the kernel that publishes it writes header + histogram + first candidates there
-// first (a copy + stream synchronisation would cost tens of microseconds per round).
-void GpuCtx::poll_mailbox(uint32_t round_id) {
-  unsigned char *h = (unsigned char *)h_pin_;
-  volatile uint32_t *flag = (volatile uint32_t *)(h + 32);
-  for (unsigned long long spins = 0; *flag != round_id; spins++) {
-    if ((spins & 0x3fff) == 0x3fff) {
-      const hipError_t q = hipStreamQuery(st_);
-      if (q == hipSuccess) {
-        if (*flag != round_id) throw GpuError{"candidate mailbox was not published"};
-      } else if (q != hipErrorNotReady) {
-        throw GpuError{std::string("candidate filter: ") + hipGetErrorString(q)};
-      }
-    }
-  }
-  std::atomic_thread_fence(std::memory_order_acquire);
-  const unsigned long long cum = *(const unsigned long long *)(h + 40);
-  if (cum != scanned_cum_) {  // a merge round ran since the last call: that is how many tokens its filters streamed
-    live_tokens_last_ = cum - scanned_cum_;
-    scanned_cum_ = cum;
-    const unsigned long long touched = *(const unsigned long long *)(h + 48);
-    touched_last_ = touched - touched_cum_;
-    touched_cum_ = touched;
-  }
-  const unsigned long long sites = *(const unsigned long long *)(h + 88);  // (published by scan_top only; one round old, like the token counts)
-  if (sites > sites_cum_) {
-    sites_last_ = sites - sites_cum_;
-    sites_cum_ = sites;
-  }
-  if (multi()) {  // the same numbers summed over the ranks' block headers: what the switch to word mode is decided from
-    const unsigned long long *xs = (const unsigned long long *)(h + MB_XSUM);
-    if (xs[3] == (unsigned long long)comm_->world) {  // (a scan that ran before any exchange leaves zeros)
-      if (xs[0] > g_sites_cum_) { g_sites_last_ = xs[0] - g_sites_cum_; g_sites_cum_ = xs[0]; }
-      if (xs[1] > g_tokens_cum_) { g_tokens_last_ = xs[1] - g_tokens_cum_; g_tokens_cum_ = xs[1]; }
-      g_tiles_a_ = xs[2];
-    }
-  }
-}
-
-// One scan of the hot list (L1) by k_hot_scan -- every listed slot, many workgroups: candidates above (t, tm), histogram of the
-// live counts, the pending zeroing of the finished batch's pairs.  Leaves the result in the mailbox.  False: the exchange of
-// this round had to be completed first (multi-GPU), scan again.
-bool GpuCtx::scan_hot(unsigned long long t, uint32_t tm) {
-  constexpr unsigned int CAND_FAST = 4096;
-  unsigned char *h = (unsigned char *)h_pin_;
-  const uint32_t round_id = ++mail_round_;
-  t_begin(KT_CAND);
-  launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_,
-                  pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, listed_last_ ? listed_last_ + 4096 : hot_cap_,
-                  pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, multi() ? d_xstat_ : nullptr, st_);
-  pending_zero_ = false;
-  t_end(KT_CAND, 20ull * listed_last_);  // (not chained: the host round trip that follows belongs to no kernel family)
-  poll_mailbox(round_id);
-  const unsigned int *hdr = (const unsigned int *)h;
-  n_keys_host = hdr[1];
-  listed_last_ = std::min(hdr[2], hot_cap_);
-  if (multi() && settle_exchange(*(const unsigned long long *)(h + 56), *(const unsigned long long *)(h + 64), *(const unsigned long long *)(h + 80))) return false;
-  return true;
-}
-
-// Refill of the top list (L2) from the hot list (L1): one scan of L1 for the histogram of its live counts, the threshold that
-// puts about top_target_ of them on the top list, one pass that lists them.  False: L1 itself has to be rebuilt first (it
-// overflowed or ran dry; hot_state_ says so) or the scan has to be repeated.
-bool GpuCtx::refill_top() {
-  unsigned char *h = (unsigned char *)h_pin_;
-  if (!scan_hot(~0ull >> 2, 0)) return false;
-  const unsigned int *hdr = (const unsigned int *)h;
-  const unsigned int listed = hdr[2], live = hdr[3];
-  const bool over = listed > hot_cap_;  // (multi-GPU: the lists hold the same pairs on every rank -- k_fold_list -- so this verdict is every rank's)
-  if (over || (live < hot_min_ && pt_.hot_tau > 1 && !hot_just_rebuilt_)) {
-    hot_state_ = HOT_INVALID;  // overflowed, or running dry: relist with a new threshold (a list that is short right after its
-    return false;              // rebuild stays: ties kept the threshold up)
-  }
-  hot_just_rebuilt_ = false;
-  const unsigned long long *hist = (const unsigned long long *)(h + MB_HIST);
-  unsigned long long acc = 0;
-  int chosen = -1;
-  for (int b = CAND_BINS - 1; b >= 1; b--) {
-    if (acc + hist[b] > top_cap_ / 2) break;
-    acc += hist[b];
-    chosen = b;
-    if (acc >= top_target_) break;
-  }
-  top_refills++;
-  if (chosen < 0 || (acc < top_min_ && acc < live)) {  // ties too large for the top list right below its first few entries: scan the hot list itself for a while
-    pt_.top_tau = ~0ull;
-    top_state_ = TOP_BYPASS;
-    bypass_rounds_ = 0;
-    return true;
-  }
-  pt_.top_tau = std::max<unsigned long long>(pt_.hot_tau, cand_bin_lower(chosen));
-  HIP_CHECK(hipMemsetAsync(d_top_n_, 0, 4, st_));
-  t_begin(KT_CAND);
-  launch_top_rebuild(pt_, listed_last_, st_);
-  t_end(KT_CAND, 20ull * listed_last_);
-  top_state_ = TOP_ACTIVE;
-  return true;
-}
-
-// Candidates for the host's pick (see gpu_ctx.h).  Three tiers: the top list (about a thousand slots, read by one workgroup --
-// in the tail of the round's apply kernel when the round is one launch), refilled from the hot list (tens of thousands, read by a
-// kernel of its own) when it runs dry or overflows, which is rebuilt from the whole table when IT runs dry or overflows.
-uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist) {
-  HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
-  tl_device = device_;
-  out.clear();
-  if (!pt_cap_) {
-    if (hist) memset(hist, 0, CAND_BINS * 8);
-    memset(hist_buf_, 0, sizeof hist_buf_);
-    last_hist_ = hist_buf_;
-    last_live_ = 0;
-    return 0;
-  }
-  constexpr unsigned int CAND_FAST = 4096;
-  unsigned char *h = (unsigned char *)h_pin_;
-  const bool fused_ok = fused_pending_ && fused_tau_ == tau_cnt && fused_mx_ == tau_mx;
-  fused_pending_ = false;  // (a scan that was fused but is not wanted any more is simply ignored)
-  int dry_refills = 0, dry_rebuilds = 0;
-  for (int attempt = 0;; attempt++) {
-    if (attempt > 24) throw GpuError{"candidate lists do not settle"};
-    const bool use_fused = fused_ok && attempt == 0 && top_state_ == TOP_ACTIVE && hot_state_ == HOT_ACTIVE;
-    if (multi() && hot_state_ != HOT_ACTIVE) {
-      // whole-table scans ahead (list rebuild, or no list at all): they synchronise anyway, so the verdict of this round's
-      // exchange is fetched directly instead of travelling with the mailbox
-      unsigned long long x[4] = {0, 0, 0, 0};
-      HIP_CHECK(hipMemcpyAsync(x, d_xstat_, 32, hipMemcpyDeviceToHost, st_));
-      HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, st_));
-      sync();
-      settle_exchange(x[0], x[1], x[3]);
-    }
-    if (hot_state_ == HOT_FULLSCAN && ++fullscan_rounds_ >= 64) hot_state_ = HOT_INVALID;  // ties may have dissolved
-    if (hot_state_ == HOT_INVALID) {
-      rebuild_hot();
-      top_state_ = TOP_INVALID;
-      pt_.top_tau = ~0ull;
-    }
-    if (hot_state_ == HOT_FULLSCAN) return scan_full(tau_cnt, tau_mx, out, hist);
-    if (top_state_ == TOP_BYPASS && ++bypass_rounds_ >= 64) top_state_ = TOP_INVALID;
-    if (top_state_ == TOP_INVALID && !refill_top()) continue;
-    unsigned long long t = tau_cnt;
-    uint32_t tm = tau_mx;
-    const unsigned long long floor_tau = top_state_ == TOP_ACTIVE ? pt_.top_tau : pt_.hot_tau;
-    if (t < floor_tau) {  // a list is complete only from its threshold up
-      t = floor_tau;
-      tm = 0xffffffffu;
-    }
-    unsigned int n = 0, live = 0;
-    bool hot_over = false, top_over = false;
-    if (top_state_ == TOP_BYPASS) {
-      if (!scan_hot(t, tm)) continue;
-      const unsigned int *hdr = (const unsigned int *)h;
-      n = hdr[0];
-      live = hdr[3];
-      hot_over = hdr[2] > hot_cap_;
-      if (hot_over || (live < hot_min_ && pt_.hot_tau > 1 && dry_rebuilds < 1)) {
-        if (!hot_over) dry_rebuilds++;
-        hot_state_ = HOT_INVALID;
-        continue;
-      }
-    } else {
-      const uint32_t round_id = use_fused ? fused_round_ : ++mail_round_;
-      if (!use_fused) {
-        ScanArgs sa{};
-        sa.on = 1;
-        sa.tau_cnt = t;
-        sa.tau_mx = tm;
-        sa.out = d_cand_;
-        sa.cap = cand_cap_;
-        sa.fast = CAND_FAST;
-        sa.done_ctr = nullptr;
-        sa.mailbox = h;
-        sa.round_id = round_id;
-        t_begin(KT_CAND);
-        launch_top_scan(pt_, sa, d_stats_, pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_,
-                        pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, multi() ? d_xstat_ : nullptr, st_);
-        pending_zero_ = false;
-        t_end(KT_CAND, 20ull * top_listed_last_);
-      }
-      poll_mailbox(round_id);
-      const unsigned int *hdr = (const unsigned int *)h;
-      n = hdr[0];
-      n_keys_host = hdr[1];
-      const unsigned int top_listed = hdr[2], hot_listed = hdr[4];
-      live = hdr[3];
-      top_listed_last_ = std::min(live, top_cap_);
-      hot_over = hot_listed > hot_cap_;
-      top_over = top_listed > top_cap_;
-      if (use_fused) {
-        fused_rounds++;
-        if (dev_timing_pending_) {  // the round's duration by the device's 100 MHz clock (merge_apply: dev_timing)
-          double ms = (double)*(const unsigned long long *)(h + 24) * 1e-5;
-          if (multi()) {  // the apply kernels, and what follows them (pack, all-gather, fold, scan), apart
-            const double k4 = std::min(ms, (double)*(const unsigned long long *)(h + MB_XSUM + 32) * 1e-5);
-            kt.ms[KT_XCHG] += ms - k4;
-            kt.launches[KT_XCHG]++;
-            ms = k4;
-          }
-          kt.ms[KT_MERGE] += ms;
-          if (word_mode_) { merge_ms_words += ms; merge_launches_words++; }
-          dev_round_ms_.push_back((float)ms);
-          last_round_dev_ms = ms;
-        }
-        const unsigned long long *tmk = (const unsigned long long *)(h + 96);  // scan_top's marks (100 MHz wall clock)
-        tail_ticks[0] += tmk[1] - tmk[0];
-        tail_ticks[1] += tmk[2] - tmk[1];
-        tail_ticks[2] += tmk[3] - tmk[2];
-        tail_listed += top_listed;
-        if (top_over) fused_overflows++;
-      }
-      // a scan that found its list overflowed read nothing -- and so did not zero the finished batch's pairs: k_pt_zero /
-      // the next scan does it (the batch is still described by the zero_* members)
-      if (top_over) pending_zero_ = zero_valid_;
-      if (multi() && settle_exchange(*(const unsigned long long *)(h + 56), *(const unsigned long long *)(h + 64), *(const unsigned long long *)(h + 80))) continue;
-      if (hot_over) {
-        hot_state_ = HOT_INVALID;
-        continue;
-      }
-      if (top_over) {
-        top_state_ = TOP_INVALID;
-        continue;
-      }
-      if (live < top_min_) {  // running dry: a lower threshold for the top list; at the hot list's own threshold, for that one
-        if (pt_.top_tau > pt_.hot_tau && dry_refills < 1) {  // (once per call: large ties can leave a refilled list short)
-          dry_refills++;
-          top_state_ = TOP_INVALID;
-          continue;
-        }
-        if (pt_.top_tau <= pt_.hot_tau && live < hot_min_ && pt_.hot_tau > 1 && dry_rebuilds < 1) {
-          dry_rebuilds++;
-          hot_state_ = HOT_INVALID;
-          continue;
-        }
-      }
-    }
-    if (hist) memcpy(hist, h + MB_HIST, CAND_BINS * 8);
-    last_hist_ = (const unsigned long long *)(h + MB_HIST);
-    last_live_ = live;
-    last_top_bin_ = top_state_ == TOP_ACTIVE ? std::min<unsigned int>(((const unsigned int *)h)[5], CAND_BINS - 1) : CAND_BINS - 1;
-    const unsigned int take = std::min(n, cand_cap_);
-    CandRec *h_c = (CandRec *)(h + 8192);
-    if (take > CAND_FAST) {
-      HIP_CHECK(hipMemcpyAsync(h_c + CAND_FAST, d_cand_ + CAND_FAST, (size_t)(take - CAND_FAST) * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
-      sync();
-    }
-    out.assign(h_c, h_c + take);
-    if (const char *dbg = dbg_cand_) {  // debugging aid: one line per scan, comparable across scan implementations
-      static FILE *f = nullptr;
-      if (!f) f = fopen(dbg, "w");
-      unsigned long long hx = 0;
-      for (unsigned int i = 0; i < take; i++) hx ^= mix64(out[i].key * 31 + out[i].cnt);
-      if (f) fprintf(f, "r=%llu fused=%d tau=%llu mx=%u hot_tau=%llu top_tau=%llu n=%u live=%u nkeys=%llu cand=%016llx\n", merge_rounds, (int)use_fused, t, tm,
-                     pt_.hot_tau, pt_.top_tau, n, live, n_keys_host, hx);
-      if (f) fflush(f);
-    }
-    return n;
-  }
-}
-
-void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned long long *outv) {
-  if (!n) return;
-  flush_pending_zero();
-  unsigned long long *d_k = dmalloc<unsigned long long>(n), *d_o = dmalloc<unsigned long long>(n);
-  HIP_CHECK(hipMemcpyAsync(d_k, keys, (size_t)n * 8, hipMemcpyHostToDevice, st_));
-  launch_pt_query(pt_, d_k, n, d_o, st_);
-  HIP_CHECK(hipMemcpyAsync(outv, d_o, (size_t)n * 8, hipMemcpyDeviceToHost, st_));
-  sync();
-  DFREE(d_k);
-  DFREE(d_o);
-}
-
 // ------------------------------------------------------------------------------------------------- K4
-void GpuCtx::free_words() {
-  DFREE(d_wmeta_); DFREE(d_gm_); DFREE(d_xyz_); DFREE(d_wworklist_); DFREE(d_drec_); DFREE(d_drec_n_); DFREE(d_irec_);
-  DFREE(tl_.base); DFREE(tl_.cap); DFREE(tl_.fill); DFREE(tl_.rec_word); DFREE(tl_.rec_l); DFREE(tl_.rec_r); DFREE(tl_.cursor);
-  tl_ = TokLists{};
-  word_mode_ = false;
-  word_global_ = false;
-  sites_last_ = ~0ull;
-  g_sites_last_ = ~0ull;
-  g_sites_cum_ = g_tokens_cum_ = g_tokens_last_ = g_tiles_a_ = 0;
-}
-
-// The switch to word mode (k_words.hip): from here on class-A words live in the slots they have now and a round visits the words
-// that hold a merge site.  Called between rounds.
-void GpuCtx::enter_word_mode(uint32_t z_next) {
-  WordClass &c = cls_[0];
-  chain_event_ = nullptr;
-  d_wmeta_ = dmalloc<unsigned long long>(c.n_unique + 1);
-  launch_words_init(c.ts, d_wmeta_, st_);
-  d_wworklist_ = dmalloc<uint32_t>(c.n_unique + 64);
-  HIP_CHECK(hipMemsetAsync(c.d_work_n, 0, 64, st_));
-  d_gm_ = dmalloc<unsigned int>(WGATHER_MAXK + 4);
-  HIP_CHECK(hipMemsetAsync(d_gm_, 0, (WGATHER_MAXK + 4) * 4, st_));
-  d_xyz_ = dmalloc<uint32_t>(3 * (size_t)RULES_CAP);
-  drec_cap_ = (unsigned int)cfg_->word_drec.u;  // (tests: a region that overflows)
-  d_drec_ = dmalloc<DeltaRec>((size_t)WORDS_MAX_GRID * drec_cap_);
-  d_drec_n_ = dmalloc<unsigned int>(WORDS_MAX_GRID);
-  d_irec_ = dmalloc<uint4>((size_t)WORDS_MAX_GRID * drec_cap_);
-  tl_.base = dmalloc<unsigned long long>(id_cap_);
-  tl_.cap = dmalloc<uint32_t>(id_cap_);
-  tl_.fill = dmalloc<uint32_t>(id_cap_);
-  HIP_CHECK(hipMemsetAsync(tl_.base, 0, (size_t)id_cap_ * 8, st_));
-  HIP_CHECK(hipMemsetAsync(tl_.cap, 0, (size_t)id_cap_ * 4, st_));
-  HIP_CHECK(hipMemsetAsync(tl_.fill, 0, (size_t)id_cap_ * 4, st_));
-  tl_.cursor = dmalloc<unsigned long long>(2);
-  HIP_CHECK(hipMemsetAsync(tl_.cursor, 0, 16, st_));
-  // every record ever matched is a site at most once through each of its two neighbours, and a site removes a token: a few records per
-  // live token bound the log between two index builds; should it fill up all the same, the round says so and the index is rebuilt
-  const unsigned long long live = std::max<unsigned long long>(live_tokens_last_, 1ull << 16);
-  const unsigned long long log_env = cfg_->word_log.u;  // (tests: a log that overflows)
-  tl_.log_cap = log_env ? log_env : 2 * live + (1ull << 20);
-  tl_.rec_word = dmalloc<uint32_t>(tl_.log_cap);
-  tl_.rec_l = dmalloc<uint32_t>(tl_.log_cap);
-  tl_.rec_r = dmalloc<uint32_t>(tl_.log_cap);
-  tl_.broken = (unsigned int *)((unsigned char *)h_pin_ + PIN_BYTES - 64);  // (the last line of the pinned block -- behind the mailbox, the candidates' read-back
-                                                                            // area and the batch staging; the kernels write it with system-scope stores)
-  *(volatile unsigned int *)tl_.broken = 0;
-  word_mode_ = true;
-  word_global_ = true;
-  word_switch_round = merge_rounds;
-  idx_valid_ = false;
-  idx_pending_ = true;
-  if (cfg_->trace.set) fprintf(stderr, "[yttm] word mode from round %llu on: %llu words, last round %llu sites, %llu tokens streamed; log %llu records\n", merge_rounds,
-                                  c.n_unique, sites_last_, live_tokens_last_, tl_.log_cap);
-  build_index(z_next);
-}
-
-void GpuCtx::free_index() {
-  DFREE(idx_.key); DFREE(idx_.cnt); DFREE(idx_.off); DFREE(idx_.bloom); DFREE(idx_.post); DFREE(d_stamp_); DFREE(idx_scan_tmp_); DFREE(idx_save_);
-  idx_cap_ = post_cap_ = 0;
-  stamp_cap_ = 0;
-  idx_valid_ = false;
-}
-
-// (Re)builds the pair index of word mode from the hot list as it is now and the class-A words as they are now (see k_index_core.h PairIndex).
-// Called between rounds.
-void GpuCtx::build_index(uint32_t z_next) {
-  idx_pending_ = false;
-  idx_valid_ = false;
-  WordClass &c = cls_[0];
-  if (!c.n_tiles || hot_state_ != HOT_ACTIVE || !word_mode_) return;
-  chain_event_ = nullptr;
-  unsigned int listed = 0;  // (the list has grown since the scan that last reported its length)
-  HIP_CHECK(hipMemcpyAsync(&listed, d_hot_n_, 4, hipMemcpyDeviceToHost, st_));
-  sync();
-  if (listed > hot_cap_) return;  // overflowed: the next scan rebuilds the list, and the index after it
-  unsigned long long want = 1024;
-  while (want < 2ull * ((unsigned long long)listed + 256)) want <<= 1;
-  if (want > idx_cap_) {
-    DFREE(idx_.key); DFREE(idx_.cnt); DFREE(idx_.off);
-    idx_.key = dmalloc<unsigned long long>(want);
-    idx_.cnt = dmalloc<uint32_t>(want * IDX_SHARDS + 1);
-    idx_.off = dmalloc<unsigned long long>(want * IDX_SHARDS + 2);
-    DFREE(idx_scan_tmp_);
-    idx_scan_tmp_ = dmalloc<unsigned long long>(scan_scratch_blocks(want * IDX_SHARDS + 1));
-    idx_cap_ = want;
-  }
-  if (!idx_.bloom) idx_.bloom = dmalloc<uint32_t>(ENC_BLOOM_WORDS);
-  idx_.mask = (unsigned int)(want - 1);
-  launch_fill_u64(idx_.key, PT_EMPTY, want, st_);
-  HIP_CHECK(hipMemsetAsync(idx_.cnt, 0, want * IDX_SHARDS * 4, st_));
-  HIP_CHECK(hipMemsetAsync(idx_.bloom, 0, ENC_BLOOM_WORDS * 4, st_));
-  t_begin(KT_CAND);
-  launch_idx_seed(pt_, idx_, listed, st_);
-  if (!idx_save_) idx_save_ = dmalloc<unsigned char>(idx_save_bytes());
-  launch_idx_stream(false, c.ts, idx_, st_, true, idx_save_);
-  // offsets = exclusive scan of the counts (one extra zero count behind the last slot: off[mask + 1] = the total)
-  HIP_CHECK(hipMemsetAsync(idx_.cnt + want * IDX_SHARDS, 0, 4, st_));
-  launch_exclusive_scan(idx_.cnt, want * IDX_SHARDS + 1, idx_.off, idx_scan_tmp_, d_counters_ + 56, st_);
-  HIP_CHECK(hipMemsetAsync(idx_.cnt, 0, want * IDX_SHARDS * 4, st_));  // the fill pass's cursors
-  unsigned long long total = 0;
-  HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 56, 8, hipMemcpyDeviceToHost, st_));
-  sync();
-  index_builds++;
-  if (cfg_->trace.set) fprintf(stderr, "[yttm] index build at round %llu: %u listed pairs, %llu postings, %u tiles, last round touched %llu tiles\n", merge_rounds, listed, total, c.n_tiles, touched_last_);
-  if (total == 0 || total > 0xfffffff0ull) {  // (no postings, or more than the 32-bit run offsets hold: the rounds take every word)
-    t_end(KT_CAND, 4ull * c.n_tiles * c.nom);
-    return;
-  }
-  if (total > post_cap_) {
-    DFREE(idx_.post);
-    post_cap_ = total + total / 4 + 1024;
-    idx_.post = dmalloc<uint32_t>(post_cap_);
-  }
-  launch_idx_stream(true, c.ts, idx_, st_, /*agg=*/total > idx_agg_min_, idx_save_);
-  t_end(KT_CAND, 8ull * c.n_tiles * c.nom);
-  const unsigned long long stamps = c.n_unique;  // (a posting is a word, and a round claims words)
-  if (stamps > stamp_cap_) {
-    DFREE(d_stamp_);
-    stamp_cap_ = (unsigned int)(stamps + stamps / 8 + 64);
-    d_stamp_ = dmalloc<uint32_t>(stamp_cap_);
-  }
-  HIP_CHECK(hipMemsetAsync(d_stamp_, 0, (size_t)stamp_cap_ * 4, st_));
-  {  // every token that exists now is covered by the postings: the instance lists start over
-    HIP_CHECK(hipMemsetAsync(tl_.cursor, 0, 16, st_));
-    sync();
-    *(volatile unsigned int *)tl_.broken = 0;
-  }
-  idx_valid_ = true;
-  idx_zbuild_ = z_next;
-}
-
 void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts, const unsigned long long *next_tau_cnt,
                          uint32_t next_tau_mx, uint32_t next_want) {
   HIP_CHECK(hipSetDevice(device_));
@@ -2557,27 +479,6 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // (its sync also makes the pinned rule staging reusable for the next round)
   // every occurrence of the batch's pairs has been merged (on every rank): their counts are exactly zero.  The candidate
   // filter that follows zeroes them while it reads the hot list; any other reader goes through flush_pending_zero().
-}
-
-void GpuCtx::flush_pending_zero() {
-  if (!pending_zero_) return;
-  chain_event_ = nullptr;
-  if (zero_ba_.k) {  // the batch never went to HBM: upload its rule hash for k_pt_zero (rare: only readers other than the hot scan)
-    std::vector<RuleSlot> tab(zero_cap_);
-    for (auto &r : tab) { r.key = PT_EMPTY; r.z = 0; r.pad = 0; }
-    for (uint32_t j = 0; j < zero_ba_.k; j++) {
-      const uint32_t x = zero_ba_.xy[2 * j], y = zero_ba_.xy[2 * j + 1];
-      if (x == y) continue;
-      const unsigned long long key = pair_key(x, y);
-      unsigned int h = pair_hash32(key) & (zero_cap_ - 1);
-      while (tab[h].key != PT_EMPTY) h = (h + 1) & (zero_cap_ - 1);
-      tab[h].key = key;
-    }
-    HIP_CHECK(hipMemcpyAsync(d_rules_, tab.data(), tab.size() * sizeof(RuleSlot), hipMemcpyHostToDevice, st_));
-    sync();
-  }
-  launch_pt_zero(pt_, d_rules_, zero_cap_, zero_self_key_, st_);
-  pending_zero_ = false;
 }
 
 }  // namespace yttm
