@@ -40,7 +40,9 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   words_enabled_ = C.word_mode.u != 0;   // (0: tiles to the end)
   direct_enabled_ = C.k4_direct.u != 0;  // (0: the pair filter + rule hash from the first round on; A/B runs)
   word_div_ = (unsigned int)C.word_div.u;  // (measured at 1 GB: 96 -> K4 135 ms, 150 -> 107, 200 -> 103.7, 300 -> 103.7, 500 -> 104; round 4, merge loop ms of random 'abcd ': 80 / 100 -> 98.7 (switch at
-                                               // round 13), 120 -> 96.0 (round 20), 150 -> 96.4, 200 -> 99.4 (round 29), 400 -> 101.6 -- but the CJK-shaped corpus: 120 -> 485 ms, 200 -> 472: left at 200)
+                                               // round 13), 120 -> 96.0 (round 20), 150 -> 96.4, 200 -> 99.4 (round 29), 400 -> 101.6 -- but the CJK-shaped corpus: 120 -> 485 ms, 200 -> 472: left at 200;
+                                               // round 5, with class B's repack looks no longer a sync every second word-mode round: CJK 120 / 200 / 300 -> 493 / 493 / 492 ms, 'abcd ' 100 / 120 / 150 / 200 ->
+                                               // 113.4 / 110.8 / 110.8 / 112.7 ms: 150)
   word_min_tiles_ = (unsigned int)C.word_min_tiles.u;  // (tests: 0 = switch as soon as the hot list is active)
   // a pass over the tiles must cost more than word mode's three launches: 1 GB enwik-like text (25 M tokens, 48 us per dense round) got 15 % slower
   // in word mode, the 1 GB CJK-shaped corpus (337 M tokens) 21 % faster, random 'abcd ' (94 M tokens at the switch) 10 % faster

@@ -72,7 +72,7 @@ struct Hook {
   X(k4_direct, "YTTM_K4_DIRECT", "1", "path", "0: no direct pair->rule table in the first rounds")                                          \
   X(word_mode, "YTTM_WORD_MODE", "1", "path", "0: tiles to the end (differential test of word mode)")                                      \
   X(no_index, "YTTM_NO_INDEX", "0", "path", "1: no pair index (and so no word mode)")                                                       \
-  X(word_div, "YTTM_WORD_DIV", "200", "tune", "switch to word mode when sites * this < tokens streamed")                                    \
+  X(word_div, "YTTM_WORD_DIV", "150", "tune", "switch to word mode when sites * this < tokens streamed")                                    \
   X(word_min_tiles, "YTTM_WORD_MIN_TILES", "16384", "tune", "... and class A has at least this many tiles (tests: 0)")                      \
   X(word_min_tokens, "YTTM_WORD_MIN_TOKENS", "50331648", "tune", "... and a pass streams at least this many tokens")                        \
   X(word_hint_floor, "YTTM_WORD_HINT_FLOOR", "16384", "tune", "words a round is sized for beyond twice the last round's sites")            \
