@@ -419,10 +419,9 @@ def test_zz_full_size_pins(tmp_path):
     assert hashlib.md5(open(model, "rb").read()).hexdigest() == pin["model_md5"]
     L = _lib.load()
     err, model2 = C.create_string_buffer(_lib.ERRLEN), str(tmp_path / "c2m.model")
-    buf = (C.c_uint8 * len(text)).from_buffer_copy(text)
-    assert L.yttm_train_bpe_from_memory(buf, len(text), model2.encode(), pin["vocab_size"], 1.0, 0, 1, 2, 3, 0, None, 0, err, _lib.ERRLEN) == 0, err.value
+    assert L.yttm_train_bpe_from_memory(text, len(text), model2.encode(), pin["vocab_size"], 1.0, 0, 1, 2, 3, 0, None, 0, err, _lib.ERRLEN) == 0, err.value
     assert hashlib.md5(open(model2, "rb").read()).hexdigest() == pin["model_md5"]
-    del buf, text
+    del text
     os.remove(corpus)
     p4 = pins["c4_10m"]
     line, n = 128, p4["n_sentences"]
@@ -432,9 +431,8 @@ def test_zz_full_size_pins(tmp_path):
     h = C.c_void_p()
     assert L.yttm_encoder_create(model.encode(), 1, 0, C.byref(h), err, _lib.ERRLEN) == 0, err.value
     ids, off = _lib.i32p(), _lib.u64p()
-    sb = (C.c_uint8 * len(sents)).from_buffer_copy(sents)
     # (sentence i = bytes [off[i], off[i+1]): the newline rides at the end of each, white space like any other)
-    assert L.yttm_encode_as_ids(h, C.cast(sb, C.c_char_p), off_in.ctypes.data_as(_lib.u64p), n, 0, 0, 0, 0.0, C.byref(ids), C.byref(off), err, _lib.ERRLEN) == 0, err.value
+    assert L.yttm_encode_as_ids(h, sents, off_in.ctypes.data_as(_lib.u64p), n, 0, 0, 0, 0.0, C.byref(ids), C.byref(off), err, _lib.ERRLEN) == 0, err.value
     assert int(off[n]) == p4["n_ids"]
     assert "%016x" % L.yttm_ids_fnv1a64(ids, off, n) == p4["fnv1a64"]
     L.yttm_free(ids)

@@ -89,6 +89,15 @@ while time.time() - t0 < budget:
     if words_mode and rng.random() < 0.1:  # batches of hundreds of disjoint rules (the trainer's batch split)
         nw = rng.randint(130, 400)
         text, cov, vocab = gen.disjoint_words_corpus(nw, shuffle_seed=rng.randint(0, 10 ** 6)), 1.0, 8 + 4 * nw + rng.randint(nw, 3 * nw)
+    # round 5: a third of the corpora cross the device in chunks of 4 / 8 / 16 KB (the chunked front end: lexicon, table growth, the second pass
+    # when coverage drops chars), some of the three-byte kind (K1 / K2a's window classification against the exact path)
+    os.environ.pop("YTTM_FE_CHUNK_KB", None)
+    if rng.random() < 0.33:
+        os.environ["YTTM_FE_CHUNK_KB"] = rng.choice(["4", "8", "16"])
+    if not big and rng.random() < 0.15:
+        text, cov = S.three_byte_text(rng, rng.choice([300, 5000, 30000])), rng.choice([1.0, 1.0, 0.9])
+        if not text.strip():
+            text = b"ab " + text
     ids = rng.choice([(0, 1, 2, 3), (3, 2, 1, 0), (-1, 0, -1, -1), (5, 7, -1, 2)])
     try:
         model = S.check_train_vs_oracle(text, vocab, tmp, cov, ids, tag=f"s{n}")
