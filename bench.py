@@ -522,19 +522,30 @@ def _bench_big(ctx, name):
         chunked = None
         os.environ["YTTM_FE_CHUNK_MB"] = "512"
         try:
+            tcs = {}
             with ctx["quiet"]:
-                t0 = time.perf_counter()
-                rc = L.yttm_train_bpe_comm(path.encode(), (model + ".chunked").encode(), args.vocab, 1.0, 8, 0, 1, 2, 3, ctx["local_rank"], 1, None, rep, 16384, err, _lib.ERRLEN)
-                dtc = time.perf_counter() - t0
+                for variant in ("serial", "overlapped", "overlapped"):  # (serial: upload a chunk, then work on it -- round 5's first version)
+                    if variant == "serial":
+                        os.environ["YTTM_FE_CHUNK_SERIAL"] = "1"
+                    else:
+                        os.environ.pop("YTTM_FE_CHUNK_SERIAL", None)
+                    t0 = time.perf_counter()
+                    rc = L.yttm_train_bpe_comm(path.encode(), (model + ".chunked").encode(), args.vocab, 1.0, 8, 0, 1, 2, 3, ctx["local_rank"], 1, None, rep, 16384, err, _lib.ERRLEN)
+                    tcs[variant] = min(tcs.get(variant, 1e9), time.perf_counter() - t0)
+                    if rc != 0:
+                        break
+            dtc = tcs.get("overlapped", 0.0)
             if rc == 0:
                 rc_ = json.loads(rep.value.decode())
                 chunked = {"chunk_MB": 512, "chunks": rc_["front_end_chunks"], "seconds": round(dtc, 4), "MBps": round(nbytes / 1e6 / dtc, 1),
+                           "seconds_upload_then_work": round(tcs["serial"], 4),
                            "peak_device_GB": round(rc_["peak_device_bytes"] / 1e9, 3), "peak_device_GB_whole_text": round(r["peak_device_bytes"] / 1e9, 3),
                            "model_matches_reference": md5_file(model + ".chunked") == pin["model_md5"]}
             else:
                 chunked = {"error": err.value.decode()}
         finally:
             del os.environ["YTTM_FE_CHUNK_MB"]
+            os.environ.pop("YTTM_FE_CHUNK_SERIAL", None)
             if os.path.exists(model + ".chunked"):
                 os.remove(model + ".chunked")
         return {"metric": "bpe_train_throughput", "value": round(nbytes / 1e6 / best, 2), "unit": "MB/s", "seconds": round(best, 4), "all_seconds": [round(t, 4) for t in times],

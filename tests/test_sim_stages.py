@@ -49,8 +49,10 @@ def test_chunked_front_end(tmp_path, monkeypatch):
              (gen.unicode_text(rng, 20000, "mix", p_invalid=0.01), 120, 0.85), (gen.zipf_corpus(60000, vocab=3000), 400, 1.0),
              (S.three_byte_text(rng, 30000), 200, 1.0), (gen.readme_corpus(200, 90, "abcdef ", seed=9).rstrip(b"\n"), 200, 1.0)]
     L = _lib.load()
-    for kb in ("4", "8"):
+    for kb, serial in (("4", False), ("8", False), ("4", True)):  # (serial: no landing buffer, a chunk is uploaded, then worked on)
         monkeypatch.setenv("YTTM_FE_CHUNK_KB", kb)
+        if serial:
+            monkeypatch.setenv("YTTM_FE_CHUNK_SERIAL", "1")
         for i, (text, vocab, cov) in enumerate(cases):
             corpus, m_gpu, m_ora = str(tmp_path / "c.txt"), str(tmp_path / "g.model"), str(tmp_path / "o.model")
             open(corpus, "wb").write(text)
@@ -60,6 +62,7 @@ def test_chunked_front_end(tmp_path, monkeypatch):
             assert filecmp.cmp(m_gpu, m_ora, shallow=False), (kb, i)
             r = json.loads(rep.value.decode())
             assert r["front_end_chunks"] >= len(text) // (int(kb) << 10) and r["peak_device_bytes"] > 0, r
+    monkeypatch.delenv("YTTM_FE_CHUNK_SERIAL")
     # from host memory, and a word heavier than a weight holds (the copies are made from the lexicon's bytes)
     monkeypatch.setenv("YTTM_FE_CHUNK_KB", "4")
     monkeypatch.setenv("YTTM_TEST_WCNT_MAX", "7")

@@ -133,6 +133,12 @@ class GpuCtx {
   // that the contract's bytes can be stated for the tile rounds and the word-mode rounds apart); 0: no snapshot
   unsigned long long split_round = 0, split_touched_words = 0, split_touched_word_tokens = 0, split_sites = 0;
   double last_round_dev_ms = 0;            // the last fused round on the device clock (0: that round was not timed so)
+  // the last merge round by the mailbox's counters (YTTM_TRACE): merge sites | tiles (word mode: words) that held one | tokens its kernels streamed
+  void last_round_counts(unsigned long long out[3]) const {
+    out[0] = sites_last_ == ~0ull ? 0 : sites_last_;
+    out[1] = touched_last_ == ~0ull >> 2 ? 0 : touched_last_;
+    out[2] = live_tokens_last_;
+  }
   double merge_ms_words = 0;               // device-clock time of the word-mode rounds (part of kt.ms[KT_MERGE])
   unsigned long long merge_launches_words = 0;
   void resolve_timers();

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <future>
 #include <map>
 #include <mutex>
 #include <thread>

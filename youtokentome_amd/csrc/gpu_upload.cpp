@@ -508,8 +508,8 @@ void GpuCtx::upload_corpus_fd(int fd, unsigned long long lo, unsigned long long 
 // copies the bytes of every word first seen in this chunk to the lexicon and points its slot there, and the next chunk overwrites the region.
 // At the end the "text" the rest of the trainer reads words from -- compaction, token fill -- is the lexicon: the same offsets into the same
 // buffer.  first_pass: K1 runs and words are compared by code points (upload_overlapped's speculation: right whenever the alphabet keeps every
-// char); else -- coverage dropped chars -- the source is read a second time with the real char map.  Peak HBM is C + the lexicon + the table +
-// 8 bytes per segment of one chunk, whatever the size of the file.
+// char); else -- coverage dropped chars -- the source is read a second time with the real char map.  Peak HBM is 2 C (the region and the next
+// chunk's landing buffer) + the lexicon + the table + 8 bytes per segment of one chunk, whatever the size of the file.
 unsigned long long GpuCtx::chunk_bytes_for(unsigned long long n) const {
   unsigned long long c = cfg_->fe_chunk_kb.u ? cfg_->fe_chunk_kb.u << 10 : cfg_->fe_chunk_mb.u << 20;
   if (!c) {
@@ -623,11 +623,34 @@ void GpuCtx::front_end_chunked(bool first_pass) {
   unsigned long long segs_total = 0, n_unique_host = 0;
   unsigned int h_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const auto t0 = std::chrono::steady_clock::now();
-  for (size_t ck = 0; ck < n_chunks; ck++) {
+  // The link and the kernels at once: chunk k + 1 crosses the link into a landing buffer of its own while the kernels work on chunk k in
+  // the region; a device-to-device copy (C bytes at HBM's rate: 0.3 ms per 512 MB) then moves it over.  Two regions the kernels alternate
+  // between would save that copy and cost every offset in the word table a region base; the copy is 1 % of a chunk's upload.
+  uint8_t *landing = n_chunks > 1 && !cfg_->fe_chunk_serial.set ? dmalloc<uint8_t>(C) : nullptr;
+  auto upload = [&](size_t ck, uint8_t *dst) {
     const unsigned long long b0 = cuts[ck], len = cuts[ck + 1] - b0;
-    if (!len) continue;
+    if (len) staged_transfer(device_, dst, len, true, [&fill, b0](void *d, unsigned long long off, size_t l) { return fill(d, b0 + off, l); });
+  };
+  std::future<void> in_flight;
+  struct Landed {  // (whatever leaves this loop: no upload still writing into a buffer that is being freed)
+    std::future<void> &f;
+    ~Landed() {
+      if (f.valid()) f.wait();
+    }
+  } landed{in_flight};
+  if (landing) in_flight = std::async(std::launch::async, upload, (size_t)0, landing);
+  for (size_t ck = 0; ck < n_chunks; ck++) {
+    const unsigned long long len = cuts[ck + 1] - cuts[ck];
     // ---- the chunk, then spaces behind it (its last segment ends there if the text does not end with white space)
-    staged_transfer(device_, B, len, true, [&](void *dst, unsigned long long off, size_t l) { return fill(dst, b0 + off, l); });
+    if (landing) {
+      in_flight.get();  // (rethrows the uploader's error)
+      if (len) HIP_CHECK(hipMemcpyAsync(B, landing, (size_t)len, hipMemcpyDeviceToDevice, st_));
+      sync();
+      if (ck + 1 < n_chunks) in_flight = std::async(std::launch::async, upload, ck + 1, landing);
+    } else {
+      upload(ck, B);
+    }
+    if (!len) continue;
     HIP_CHECK(hipMemsetAsync(B + len, 32, GAP, st_));
     const unsigned long long nch = fe_chunks(len);
     t_begin(KT_CHAR_HIST);
@@ -692,6 +715,7 @@ void GpuCtx::front_end_chunked(bool first_pass) {
   HIP_CHECK(hipMemsetAsync(B + LEX0 + lex_used_, 32, 2 * GAP, st_));
   HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
   sync();
+  DFREE(landing);
   DFREE(d_chunk_off);
   DFREE(scan_tmp);
   DFREE(d_map_spec);

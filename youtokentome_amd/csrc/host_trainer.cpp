@@ -155,7 +155,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
   double w_cand = 0, w_pick = 0, w_apply = 0, w_pick_a = 0, w_pick_b = 0;  // (YTTM_TRACE: pick = threshold + heap build | pops)
   const bool trace_pick = C.trace.set;
   unsigned long long n_cand_sum = 0;
-  struct RoundLine { float wait_us, pick_us, apply_us, dev_us; uint32_t k; };  // (YTTM_TRACE: where a round's wall time goes, by ranges of rounds)
+  struct RoundLine { float wait_us, pick_us, apply_us, dev_us; uint32_t k; unsigned long long sites, touched, tokens; };  // (YTTM_TRACE: where a round's wall time goes, by ranges of rounds)
   std::vector<RoundLine> round_lines;
   std::vector<uint8_t> in_batch((size_t)vocab_size + 1, 0);  // bit0: token is the x of a batch rule, bit1: the y
   while (used_ids < (uint64_t)vocab_size) {
@@ -293,7 +293,11 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     auto tw2 = clk::now();
     g.merge_apply(batch_xyz.data(), k, batch_cnt.data(), &tau_hint, MX_ALL, refine_on ? (uint32_t)TARGET : 0u);  // (the next scan's threshold rides along)
     w_apply += since(tw2);
-    if (trace_pick) round_lines.push_back(RoundLine{(float)(w_wait_this * 1e6), (float)(std::chrono::duration<double>(tw2 - tw1).count() * 1e6), (float)(since(tw2) * 1e6), (float)(dev_ms_this * 1e3), k});
+    if (trace_pick) {
+      unsigned long long lc[3];
+      g.last_round_counts(lc);  // (of the round whose mailbox this round waited for, like the device time)
+      round_lines.push_back(RoundLine{(float)(w_wait_this * 1e6), (float)(std::chrono::duration<double>(tw2 - tw1).count() * 1e6), (float)(since(tw2) * 1e6), (float)(dev_ms_this * 1e3), k, lc[0], lc[1], lc[2]});
+    }
     for (uint32_t j = 0; j < k; j++) rules.push_back(BPE_Rule{batch_xyz[3 * j], batch_xyz[3 * j + 1], batch_xyz[3 * j + 2]});
     used_ids += k;
     rounds++;
@@ -316,11 +320,14 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
       const size_t cuts[] = {0, 11, 28, 46, 100, 200, 300, 450, 700, 1500, 3000, 1u << 30};
       for (size_t c = 0; c + 1 < sizeof cuts / sizeof cuts[0] && cuts[c] < round_lines.size(); c++) {
         const size_t a = cuts[c], b = std::min(cuts[c + 1], round_lines.size());
-        double w = 0, p = 0, ap = 0, d = 0, kk = 0, apmax = 0;
-        for (size_t i = a; i < b; i++) { w += round_lines[i].wait_us; p += round_lines[i].pick_us; ap += round_lines[i].apply_us; d += round_lines[i].dev_us; kk += round_lines[i].k; apmax = std::max<double>(apmax, round_lines[i].apply_us); }
+        double w = 0, p = 0, ap = 0, d = 0, kk = 0, apmax = 0, si = 0, to = 0, tk = 0;
+        for (size_t i = a; i < b; i++) {
+          w += round_lines[i].wait_us; p += round_lines[i].pick_us; ap += round_lines[i].apply_us; d += round_lines[i].dev_us; kk += round_lines[i].k; apmax = std::max<double>(apmax, round_lines[i].apply_us);
+          if (i + 1 < round_lines.size()) { si += (double)round_lines[i + 1].sites; to += (double)round_lines[i + 1].touched; tk += (double)round_lines[i + 1].tokens; }  // (line i + 1 holds round i's counts)
+        }
         const double m = (double)(b - a);
-        fprintf(stderr, "[yttm] rounds %zu-%zu: per round %.1f us = wait for the mailbox %.1f (device %.1f) + pick %.1f + merge_apply call %.1f (max %.0f); batch %.1f rules\n", a + 1, b,
-                (w + p + ap) / m, w / m, d / m, p / m, ap / m, apmax, kk / m);
+        fprintf(stderr, "[yttm] rounds %zu-%zu: per round %.1f us = wait for the mailbox %.1f (device %.1f) + pick %.1f + merge_apply call %.1f (max %.0f); batch %.1f rules, %.0f merge sites in %.0f tiles / words, %.0f tokens streamed\n", a + 1, b,
+                (w + p + ap) / m, w / m, d / m, p / m, ap / m, apmax, kk / m, si / m, to / m, tk / m);
       }
     }
 #ifdef YTTM_K4_PROF

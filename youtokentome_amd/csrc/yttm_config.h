@@ -46,6 +46,7 @@ struct Hook {
   X(fe_no_spec, "YTTM_FE_NO_SPEC", "", "path", "set: under the upload only K1, not the speculative dedup by code points")                  \
   X(fe_chunk_mb, "YTTM_FE_CHUNK_MB", "0", "tune", "take the corpus in chunks of this many MB (0: only when the whole text would not fit the free HBM)") \
   X(fe_chunk_kb, "YTTM_FE_CHUNK_KB", "0", "test", "the same in KB (tests: many chunks of a toy corpus)")                                   \
+  X(fe_chunk_serial, "YTTM_FE_CHUNK_SERIAL", "", "path", "chunked front end: upload a chunk, then work on it (no landing buffer: one chunk less of HBM)") \
   X(fe_part_kb, "YTTM_FE_PART_KB", "32768", "tune", "size of a part of the text the overlapped front end works on, KB")                    \
   X(fe_k2b_blocks, "YTTM_FE_K2B_BLOCKS", "4096", "tune", "workgroups of a part's dedup launch")                                             \
   X(word_table_full, "YTTM_WORD_TABLE_FULL", "", "path", "set: size the word table for the worst case at once (no estimate, no retry)")    \
