@@ -13,7 +13,7 @@ python - $O <<'P' | tee $O/calibration.txt
 import csv, glob, sys
 o = sys.argv[1]
 known = {"calib_stream16": (4 << 30, "B streamed"), "calib_stream4": (4 << 30, "B streamed"), "calib_stream1": (1 << 30, "B streamed"), "calib_gather<8>": (1 << 24, "accesses"),
-         "calib_gather<16>": (1 << 24, "accesses"), "calib_gather<64>": (1 << 24, "accesses"), "calib_atomic8": (1 << 24, "accesses"), "calib_scatter8": (1 << 24, "accesses"),
+         "calib_gather<16>": (1 << 24, "accesses"), "calib_gather<64>": (1 << 24, "accesses"), "calib_gather<128>": (1 << 24, "accesses"), "calib_atomic8": (1 << 24, "accesses"), "calib_scatter8": (1 << 24, "accesses"),
          "calib_store16": (4 << 30, "B stored"), "calib_fill": (4 << 30, "B stored")}
 res = {}
 for d, c in (("cal_fetch", "FETCH_SIZE"), ("cal_write", "WRITE_SIZE")):

@@ -31,7 +31,7 @@ __global__ void calib_stream1(const unsigned char *p, unsigned long long n, unsi
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) acc += p[i];
   if (acc == 0x12345678u) *sink = acc;
 }
-// one random aligned 8-byte load per lane (a hash probe, an index entry); BYTES: 8, 16 (uint4, a table slot), 64 (four uint4 in a row: a word's tokens)
+// one random aligned 8-byte load per lane (a hash probe, an index entry); BYTES: 8, 16 (uint4, a table slot), 64 (four uint4 in a row: a word's tokens), 128 (a whole L2 line)
 template <int BYTES>
 __global__ void calib_gather(const uint4 *p, unsigned long long mask16, int per_thread, unsigned long long *sink) {
   unsigned acc = 0;
@@ -41,6 +41,7 @@ __global__ void calib_gather(const uint4 *p, unsigned long long mask16, int per_
     if (BYTES == 8) acc += (unsigned)reinterpret_cast<const unsigned long long *>(p)[2 * i];
     if (BYTES == 16) { uint4 v = p[i]; acc += v.x ^ v.w; }
     if (BYTES == 64) for (int q = 0; q < 4; q++) { uint4 v = p[i + q]; acc += v.x ^ v.w; }
+    if (BYTES == 128) for (int q = 0; q < 8; q++) { uint4 v = p[(i & ~7ull) + q]; acc += v.x ^ v.w; }  // (both halves of a 128-byte line)
   }
   if (acc == 0x12345678u) *sink = acc;
 }
@@ -75,6 +76,7 @@ int main() {
   hipLaunchKernelGGL(calib_gather<8>, dim3(G), dim3(T), 0, 0, buf, n16 - 1, PER, sink);
   hipLaunchKernelGGL(calib_gather<16>, dim3(G), dim3(T), 0, 0, buf, n16 - 1, PER, sink);
   hipLaunchKernelGGL(calib_gather<64>, dim3(G), dim3(T), 0, 0, buf, n16 - 1, PER, sink);
+  hipLaunchKernelGGL(calib_gather<128>, dim3(G), dim3(T), 0, 0, buf, n16 - 1, PER, sink);
   hipLaunchKernelGGL(calib_atomic8, dim3(G), dim3(T), 0, 0, (unsigned long long *)buf, BYTES / 8 - 1, PER);
   hipLaunchKernelGGL(calib_scatter8, dim3(G), dim3(T), 0, 0, (unsigned long long *)buf, BYTES / 8 - 1, PER);
   hipLaunchKernelGGL(calib_store16, dim3(G), dim3(T), 0, 0, buf, n16);
