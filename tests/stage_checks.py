@@ -467,14 +467,24 @@ def check_dropout_heap_equals_array(model="readme_small", seed=29):
     model_path = os.path.join(G, f"train_{model}.model")
     sents = [" ".join("".join(rng.choice("abcd") for _ in range(rng.choice((1, 2, 3, 5, 8, 13, 40, 200, 255, 256, 257, 700)))) for _ in range(rng.randint(1, 6)))
              for _ in range(60)] + ["", "a", "ab" * 300, "abcd" * 250]  # (the array costs O(events) per step and lane: no 6 000-token word here)
-    old = {k: os.environ.get(k) for k in ("YTTM_DROPOUT_SEED", "YTTM_DROPOUT_HEAP_FROM")}
+    # short sentences, empty ones among them: several share a pack (more words than lanes in some: the lanes take words from a counter)
+    sents += [" ".join("".join(rng.choice("abcd") for _ in range(rng.choice((1, 2, 3, 4, 5, 8)))) for _ in range(rng.randint(0, 30))) for _ in range(70)]
+    old = {k: os.environ.get(k) for k in ("YTTM_DROPOUT_SEED", "YTTM_DROPOUT_HEAP_FROM", "YTTM_K5_GROUP")}
     try:
         os.environ["YTTM_DROPOUT_SEED"] = "12345"
         for p in (0.0, 0.1, 0.5, 0.9, 1.0):
             got = []
-            for heap_from, hbm, no_pack in (("1000000000", False, False), ("0", False, False), ("256", False, False), ("256", True, False), ("0", True, False),
-                                            ("256", False, True), ("0", True, True)):
+            # group: consecutive sentences a wavefront packs from (1: every sentence alone).  A word's draws are keyed by its sentence and its
+            # number there, so the ids do not depend on how the batch was cut into packs, nor on which lane took the word.
+            for heap_from, hbm, no_pack, group in (("1000000000", False, False, "1"), ("0", False, False, "1"), ("256", False, False, "1"), ("256", True, False, "1"),
+                                                   ("0", True, False, "7"), ("256", False, True, "1"), ("0", True, True, "1"), ("256", False, False, "7"),
+                                                   ("0", False, False, "24"), ("256", False, True, "24"), ("256", False, False, "0"),
+                                                   ("256", False, False, "24s2"), ("0", False, False, "24s2")):
                 os.environ["YTTM_DROPOUT_HEAP_FROM"] = heap_from
+                os.environ["YTTM_K5_GROUP"] = group[:-2] if group.endswith("s2") else group
+                os.environ.pop("YTTM_DROPOUT_PACK_SENT", None)
+                if group.endswith("s2"):  # at most two sentences per pack
+                    os.environ["YTTM_DROPOUT_PACK_SENT"] = "2"
                 # (round 5: an event is live iff its position's pair still has the event's rule, both links of a position in one word -- against
                 # round 4's test on rule_xy with separate link arrays: same pops, same draws, same ids)
                 if no_pack:
@@ -487,8 +497,8 @@ def check_dropout_heap_equals_array(model="readme_small", seed=29):
                     os.environ.pop("YTTM_DROPOUT_HBM_QUEUES", None)
                 bpe = yttm.BPE(model_path)  # (a fresh encoder: the draws are numbered per encoder and call)
                 got.append(bpe.encode(sents, yttm.OutputType.ID, dropout_prob=p))
-            os.environ.pop("YTTM_DROPOUT_HBM_QUEUES", None)
-            os.environ.pop("YTTM_DROPOUT_NO_PACK", None)
+            for k in ("YTTM_DROPOUT_HBM_QUEUES", "YTTM_DROPOUT_NO_PACK", "YTTM_DROPOUT_PACK_SENT"):
+                os.environ.pop(k, None)
             assert all(g == got[0] for g in got), p
         os.environ["YTTM_DROPOUT_HEAP_FROM"] = "256"
         bpe = yttm.BPE(model_path)

@@ -1,5 +1,6 @@
 """GPU tuning aid: BPE-dropout encode (BASELINE configs[4]: 1e7 sentences of 128 chars, p = 0.1) under environment hooks, one process.
-usage: python tools/dbg/dropout_ab.py [n_sentences] -- NAME:K=V,K=V NAME2: ...     (hooks are read when an encoder is created)"""
+usage: python tools/dbg/dropout_ab.py [n_sentences] -- NAME:K=V,K=V NAME2: ...     (hooks are read when an encoder is created; the pseudo-hook
+P=<prob> sets the dropout probability of a variant: 1.0 = every word ends at its first pop, the fixed part of the kernel)"""
 import ctypes as C, os, sys, time
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,6 +23,7 @@ n = len(host) // (line + 1)
 db = torch.frombuffer(bytearray(host), dtype=torch.uint8).cuda()
 do = torch.arange(n + 1, dtype=torch.int64, device="cuda") * (line + 1)
 for name, env in variants:
+    prob = float(env.pop("P", "0.1"))
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     os.environ["YTTM_DROPOUT_SEED"] = "777"
@@ -30,7 +32,7 @@ for name, env in variants:
     n_ids, kms = C.c_uint64(), C.c_double()
     ks = []
     for i in range(4):
-        assert L.yttm_encode_device(h, C.c_void_p(db.data_ptr()), C.c_void_p(do.data_ptr()), n, db.numel(), line + 1, 0, 0, 0, 0.1, C.byref(n_ids), C.byref(kms), err, 2048) == 0, err.value
+        assert L.yttm_encode_device(h, C.c_void_p(db.data_ptr()), C.c_void_p(do.data_ptr()), n, db.numel(), line + 1, 0, 0, 0, prob, C.byref(n_ids), C.byref(kms), err, 2048) == 0, err.value
         if i:
             ks.append(kms.value)
     ids = np.zeros(n_ids.value, dtype=np.int32); off = np.zeros(n + 1, dtype=np.uint64)

@@ -1,7 +1,7 @@
 """CPU soak of the batch encoder: random sentences (every script, invalid bytes, cuts inside UTF-8 sequences, words of 1..60 chars, runs of one
 letter) through the product sources under the HIP emulator against the oracle, with and without the word cache, under random settings of
 the hooks that steer K5's paths (sentences per wavefront of the word cache's walks, one word per lane or the whole wave, a crowded short
-region of the word table).  usage: python tools/soak_encode.py [seconds] [seed]"""
+region of the word table); a fifth of the rounds: BPE-dropout's differential check on random sentences.  usage: python tools/soak_encode.py [seconds] [seed]"""
 import os, pathlib, random, sys, tempfile, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("YTTM_AMD_LIB", os.path.join(R, "tests", "hipsim", "_build", "libyttm_sim.so"))
@@ -27,7 +27,9 @@ while time.time() - t0 < budget:
     s = rng.randint(0, 10 ** 9)
     try:
         kind = rng.random()
-        if kind < 0.4:
+        if kind < 0.2:  # BPE-dropout: the same ids however the batch is cut into packs, wherever the queues live, array or heap (round 5)
+            S.check_dropout_heap_equals_array(seed=s)
+        elif kind < 0.4:
             S.check_encode_word_cache_fuzz(tmp, trials=rng.randint(1, 3), seed=s)
         elif kind < 0.7:
             S.check_encode_word_cache(n_sent=rng.randint(5, 150), seed=s)

@@ -108,14 +108,14 @@ struct DropoutArgs {
   int heap_from;            // words of at least this many tokens keep their events in a binary heap instead of a sorted array
   int lds_queues;           // packs of up to ENC_DROP_WCAP tokens keep their event queues in LDS (EvLds)
   int pack_links;           // working arrays in LDS: both links of a position in one word, the third array holds the pairs' rules (dropout_merge)
+  int pack_sent;            // at most this many sentences share a pack (0: as many as fit; tests)
   uint32_t *wsl;            // [cap] word start positions
   unsigned long long *ev;   // [3*cap] sorted event queues, word w owns [3*ws, 3*we)
 };
 
-__device__ inline bool drop_skip(const DropoutArgs &d, unsigned long long sidx, uint32_t word, uint32_t draw) {
-  if (d.always_skip) return true;
-  const unsigned long long r = mix64(d.seed + sidx * 0x9e3779b97f4a7c15ull + ((unsigned long long)word << 34) + draw);
-  return r < d.thr;
+// A word's stream of draws is keyed by the encoder's salt, the word's sentence and its number there (dropout_merge: skip()).
+__device__ inline unsigned long long drop_key(const DropoutArgs &d, unsigned long long sidx, uint32_t word) {
+  return d.seed + sidx * 0x9e3779b97f4a7c15ull + ((unsigned long long)word << 34);
 }
 
 // Where a word's event queue lives.  Sentences that fit the wavefront's LDS arrays (the common case) keep it in LDS, an event packed into
@@ -123,27 +123,37 @@ __device__ inline bool drop_skip(const DropoutArgs &d, unsigned long long sidx, 
 // insertion, shift and pop a chain of dependent global round trips (10^7 sentences of 128 chars: 381 ms against 62 ms without dropout).
 // Long sentences (HBM working arrays) keep 64-bit events in the per-wave HBM scratch.  Same order of pops either way.
 struct EvGlb {
+  typedef unsigned long long raw_t;  // rule index << 32 | position
   unsigned long long *p;
-  __device__ unsigned long long get(int i) const { return p[i]; }
-  __device__ void set(int i, unsigned long long v) const { p[i] = v; }
+  static __device__ raw_t pack(uint32_t rule, uint32_t pos) { return ((unsigned long long)rule << 32) | (unsigned long long)pos; }
+  static __device__ uint32_t rule(raw_t v) { return (uint32_t)(v >> 32); }
+  static __device__ uint32_t pos(raw_t v) { return (uint32_t)v; }
+  __device__ raw_t get(int i) const { return p[i]; }
+  __device__ void set(int i, raw_t v) const { p[i] = v; }
   __device__ EvGlb at(size_t off) const { return EvGlb{p + off}; }
 };
 struct EvLds {
+  typedef uint32_t raw_t;  // rule index << 9 | position: the same order as the pair (rule, position), compared without unpacking
   uint32_t *p;
-  __device__ unsigned long long get(int i) const {
-    const uint32_t v = p[i];
-    return ((unsigned long long)(v >> 9) << 32) | (unsigned long long)(v & 511u);
-  }
-  __device__ void set(int i, unsigned long long v) const { p[i] = ((uint32_t)(v >> 32) << 9) | ((uint32_t)v & 511u); }
+  static __device__ raw_t pack(uint32_t rule, uint32_t pos) { return (rule << 9) | pos; }
+  static __device__ uint32_t rule(raw_t v) { return v >> 9; }
+  static __device__ uint32_t pos(raw_t v) { return v & 511u; }
+  __device__ raw_t get(int i) const { return p[i]; }
+  __device__ void set(int i, raw_t v) const { p[i] = v; }
   __device__ EvLds at(size_t off) const { return EvLds{p + off}; }
 };
-constexpr int ENC_DROP_WCAP = 256;  // dropout: tokens of a pack whose event queues fit the wave's LDS share (3 events per token)
+// dropout: tokens of a pack.  A wave's share of the workgroup's 80 KB is 2 560 words: three working arrays, the event queues (3 events per
+// token) and the word starts (a word has at least two tokens) + the next-word counter = 6.5 tokens' worth -> 392 tokens: THREE sentences of
+// 128 chars (at most 130 tokens each) where round 4's 256 held two of the shorter ones at best.
+constexpr int ENC_DROP_WCAP = 392;
+constexpr int ENC_DROP_WORDS = ENC_DROP_WCAP / 2;              // word-start entries; entry [ENC_DROP_WORDS] is the counter
+constexpr int ENC_DROP_WAVE_WORDS = 6 * ENC_DROP_WCAP + ENC_DROP_WORDS + 4;  // LDS words per wave
 
 template <class Q>
-__device__ inline void ev_insert(const Q &ev, int &ne, unsigned long long key) {
+__device__ inline void ev_insert(const Q &ev, int &ne, typename Q::raw_t key) {
   int j = ne++;
   while (j > 0) {
-    const unsigned long long prev = ev.get(j - 1);
+    const typename Q::raw_t prev = ev.get(j - 1);
     if (prev <= key) break;
     ev.set(j, prev);
     j--;
@@ -151,15 +161,15 @@ __device__ inline void ev_insert(const Q &ev, int &ne, unsigned long long key) {
   ev.set(j, key);
 }
 
-// The same queue as a binary min-heap, for long words: the sorted array costs O(queue) per insertion and removal -- a single word of
+// The same queue as a binary min-heap, for long words: the sorted array costs O(queue) per insertion -- a single word of
 // 80 000 chars (a base64 blob in the input) kept one lane busy for minutes.  Pops come in the same ascending order, so the draws
 // and the result are those of the array (DropoutQueue itself is a std::priority_queue plus the skipped events, bpe.cpp:1417-1453).
 template <class Q>
-__device__ inline void heap_push(const Q &ev, int &nh, unsigned long long key) {
+__device__ inline void heap_push(const Q &ev, int &nh, typename Q::raw_t key) {
   int i = nh++;
   while (i > 0) {
     const int p = (i - 1) >> 1;
-    const unsigned long long pv = ev.get(p);
+    const typename Q::raw_t pv = ev.get(p);
     if (pv <= key) break;
     ev.set(i, pv);
     i = p;
@@ -167,15 +177,15 @@ __device__ inline void heap_push(const Q &ev, int &nh, unsigned long long key) {
   ev.set(i, key);
 }
 template <class Q>
-__device__ inline unsigned long long heap_pop(const Q &ev, int &nh) {
-  const unsigned long long top = ev.get(0), last = ev.get(--nh);
+__device__ inline typename Q::raw_t heap_pop(const Q &ev, int &nh) {
+  const typename Q::raw_t top = ev.get(0), last = ev.get(--nh);
   int i = 0;
   for (;;) {
     int c = 2 * i + 1;
     if (c >= nh) break;
-    unsigned long long cv = ev.get(c);
+    typename Q::raw_t cv = ev.get(c);
     if (c + 1 < nh) {
-      const unsigned long long c1 = ev.get(c + 1);
+      const typename Q::raw_t c1 = ev.get(c + 1);
       if (c1 < cv) { c++; cv = c1; }
     }
     if (cv >= last) break;
@@ -188,7 +198,8 @@ __device__ inline unsigned long long heap_pop(const Q &ev, int &nh) {
 
 template <class A, class WS, class Q>
 __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev*/, int n, const DropoutArgs &d, unsigned long long sidx,
-                             WS wsl /* [words] word start positions */, Q evq /* [3 * tokens] the words' event queues, word w owns [3 ws, 3 we) */) {
+                             WS wsl /* [words] word start positions */, Q evq /* [3 * tokens] the words' event queues, word w owns [3 ws, 3 we) */,
+                             unsigned long long my_sid = 0 /* a pack: lane j holds the index of its j-th non-empty sentence */) {
   const int lane = lane_id();
   const unsigned long long lt = lanemask_lt();
   constexpr uint32_t DEAD = 0xffffffffu, NIL = 0xffffffffu;
@@ -198,16 +209,39 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
   // starts at each position: an event (rule r at p) is live iff that is still r -- the same test as "the tokens are the rule's x and y"
   // (bpe.cpp:1569-1572: a pair has one rule, a rule one pair) -- and z comes from the rule's number (enc_rule_z).  One trip per merge is left.
   const bool PACK = std::is_same<A, LdsArr>::value && d.pack_links;  // (YTTM_DROPOUT_NO_PACK: the three-trip scheme, for the differential test)
+  // A pack of several sentences (LDS word starts): a word's draws are keyed by ITS sentence and its number within that sentence, never by the
+  // pack -- the ids do not depend on how a batch was cut into packs (and equal those of the one-sentence-at-a-time HBM path).  A word-start
+  // entry is position | number in the sentence << 9 | (sentence - the pack's first) << 18: all three below 512 (ENC_DROP_WCAP), and the words
+  // are handed to the lanes by a counter behind the entries -- a lane that is done takes the next word, the wave waits for its longest LANE.
+  constexpr bool WPACK = std::is_same<WS, LdsArr>::value;
   constexpr uint32_t NIL16 = 0xffffu;
   // word starts
   int nw = 0;
-  for (int c = 0; c < ((n + 63) >> 6); c++) {
-    const int p = c * 64 + lane;
-    const bool ws = p < n && (wt.get(p) & TOK_WS);
-    const unsigned long long W = __ballot(ws);
-    if (ws) wsl.set(nw + __popcll(W & lt), (uint32_t)p);
-    nw += __popcll(W);
+  {
+    int sent_carry = -1, first_carry = 0;  // ordinal of the sentence the previous chunk ended in; the number of that sentence's first word
+    for (int c = 0; c < ((n + 63) >> 6); c++) {
+      const int p = c * 64 + lane;
+      const uint32_t t0 = p < n ? wt.get(p) : 0u;
+      const bool ws = p < n && (t0 & TOK_WS);
+      const unsigned long long W = __ballot(ws);
+      if (WPACK) {
+        const unsigned long long S = __ballot(ws && (t0 & ENC_SENT));
+        const unsigned long long sle = S & (lt | (1ull << lane));
+        const int so = sent_carry + __popcll(sle);
+        int first = first_carry;
+        if (sle) first = nw + __popcll(W & ((1ull << (63 - __clzll((long long)sle))) - 1ull));
+        const unsigned long long sid = __shfl(my_sid, so < 0 ? 0 : so);
+        const int wi = nw + __popcll(W & lt);
+        if (ws) wsl.set(wi, (uint32_t)p | ((uint32_t)(wi - first) << 9) | ((uint32_t)(sid - sidx) << 18));
+        if (S) first_carry = nw + __popcll(W & ((1ull << (63 - __clzll((long long)S))) - 1ull));
+        sent_carry += __popcll(S);
+      } else {
+        if (ws) wsl.set(nw + __popcll(W & lt), (uint32_t)p);
+      }
+      nw += __popcll(W);
+    }
   }
+  if (WPACK && lane == 0) wsl.set(ENC_DROP_WORDS, 64u);  // the next word nobody has yet (lanes start with words 0 .. 63)
   // every pair's rule, lanes = positions: the words' first events (bpe.cpp:1556-1558) come from here -- one rule-hash round trip per 64
   // pairs, where a lane looking its word's pairs up one after the other made the wave wait for as many trips as its longest word has pairs.
   // (wm is free until a lane lays its word's links into it.)
@@ -233,23 +267,51 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
     if (p1 < n) wm.set(p1, r1);
   }
   wave_sync();
-  for (int w = lane; w < nw; w += 64) {
-    const int ws = (int)wsl.get(w);
-    const int we = w + 1 < nw ? (int)wsl.get(w + 1) : n;
-    const Q ev = evq.at(3 * (size_t)ws);
-    const int cap = 3 * (we - ws);             // the word's share of the queue space: every event it can ever hold
-    const bool heap = we - ws >= d.heap_from;  // (skipped events of a pop wait at the top end of that space)
-    int ne = 0;
-    // (Measured and dropped in round 5: the events of short words in an UNSORTED bag -- append, swap-remove, a pop by a scan for the smallest:
-    // the same examined order, draws and ids, but 195 ms per 10^7 sentences against the sorted array's 140: the scan's 64-bit compares per
-    // event cost more than the array's shifts; these loops are bound by instructions, not by LDS latency.)
-    auto add = [&](unsigned long long key) {
-      if (heap) heap_push(ev, ne, key);
-      else ev_insert(ev, ne, key);
-    };
+  // The lane's word: set-up (its first events into the queue, its links), then pops until one finds every event skipped.
+  int ws = 0, we = 0, cap = 0, ne = 0, head = 0;  // the queue is ev[head, head + ne) (sorted array) or ev[0, ne) (heap)
+  bool heap = false;
+  uint32_t draw = 0;            // the Weyl counter of the word's draws
+  unsigned long long wkey = 0;  // the word's RNG stream: seed, sentence and number in the sentence, mixed once per word
+  Q ev = evq;
+  // (Measured and dropped in round 5: the events of short words in an UNSORTED bag -- append, swap-remove, a pop by a scan for the smallest:
+  // the same examined order, draws and ids, but 195 ms per 10^7 sentences against the sorted array's 140: the scan's 64-bit compares per
+  // event cost more than the array's shifts; these loops are bound by instructions, not by LDS latency.)
+  // The sorted array never moves its front back: a pop of the smallest event is head++, not a shift of the whole array (round 5; it was the
+  // largest loop of a pop), and an insertion shifts only the events behind the new one -- few: a merge's new pairs are younger rules than most
+  // of what waits.  head + ne = the events ever inserted <= 3 (tokens - 1) < cap: the word's share of the space is never left.
+  auto add = [&](uint32_t rule, uint32_t pos) {
+    const typename Q::raw_t key = Q::pack(rule, pos);
+    if (heap) heap_push(ev, ne, key);
+    else ev_insert(ev.at((size_t)head), ne, key);
+  };
+  // A draw: the murmur3 finalizer over a Weyl sequence that starts at the word's well-mixed key -- two 32-bit multiplies, where mix64 of
+  // (key + draw) cost eight of them (v_mul_lo_u32 runs at a quarter of the VALU's rate, and a draw is the innermost step of a pop).  The
+  // threshold is the top 32 bits of p * 2^64: p is resolved to 2.3e-10.
+  auto skip = [&]() {
+    if (d.always_skip) return true;
+    draw += 0x9e3779b9u;
+    uint32_t h = draw ^ (uint32_t)(wkey >> 32);
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h < (uint32_t)(d.thr >> 32);
+  };
+  auto setup = [&](int w) {
+    const uint32_t e0 = wsl.get(w);
+    ws = WPACK ? (int)(e0 & 511u) : (int)e0;
+    we = w + 1 < nw ? (WPACK ? (int)(wsl.get(w + 1) & 511u) : (int)wsl.get(w + 1)) : n;
+    wkey = mix64(drop_key(d, WPACK ? sidx + (unsigned long long)(e0 >> 18) : sidx, WPACK ? (e0 >> 9) & 511u : (uint32_t)w));
+    ev = evq.at(3 * (size_t)ws);
+    cap = 3 * (we - ws);             // the word's share of the queue space: every event it can ever hold
+    heap = we - ws >= d.heap_from;   // (skipped events of a pop wait at the top end of that space)
+    ne = 0;
+    head = 0;
+    draw = (uint32_t)wkey;
     for (int i = ws; i < we; i++) {
       const uint32_t r = wm.get(i);
-      if (i + 1 < we && r != ENC_INF) add(((unsigned long long)r << 32) | (unsigned long long)i);
+      if (i + 1 < we && r != ENC_INF) add(r, (uint32_t)i);
       if (PACK) {
         wr.set(i, (i + 1 < we ? (uint32_t)(i + 1) : NIL16) | ((i > ws ? (uint32_t)(i - 1) : NIL16) << 16));
         wm.set(i, i + 1 < we ? r : ENC_INF);  // the rule of the pair (i, i + 1)
@@ -258,67 +320,91 @@ __device__ int dropout_merge(const EncModel &m, A wt, A wr /*next*/, A wm /*prev
         wm.set(i, i > ws ? (uint32_t)(i - 1) : NIL);
       }
     }
-    uint32_t draw = 0;
-    for (;;) {
-      unsigned long long e = 0;
-      if (heap) {
-        int ns = 0;
-        bool found = false;
-        while (ne > 0) {
-          e = heap_pop(ev, ne);
-          if (!drop_skip(d, sidx, (uint32_t)w, draw++)) { found = true; break; }
-          ev.set(cap - 1 - ns, e);
-          ns++;
-        }
-        for (int k = 0; k < ns; k++) heap_push(ev, ne, ev.get(cap - 1 - k));
-        if (!found) break;
-      } else {
-        int acc = -1;
-        for (int j = 0; j < ne; j++) {
-          if (!drop_skip(d, sidx, (uint32_t)w, draw++)) { acc = j; break; }
-        }
-        if (acc < 0) break;  // every event skipped: the word is finished (bpe.cpp:1431-1437)
-        e = ev.get(acc);
-        for (int j = acc; j + 1 < ne; j++) ev.set(j, ev.get(j + 1));
+  };
+  auto pop = [&]() -> bool {  // false: every event was skipped, the word is finished (bpe.cpp:1431-1437)
+    typename Q::raw_t e = 0;
+    bool found = false;
+    if (heap) {
+      int ns = 0;
+      while (ne > 0) {
+        e = heap_pop(ev, ne);
+        if (!skip()) { found = true; break; }
+        ev.set(cap - 1 - ns, e);
+        ns++;
+      }
+      for (int k = 0; k < ns; k++) heap_push(ev, ne, ev.get(cap - 1 - k));
+    } else {
+      int acc = -1;
+      for (int j = 0; j < ne; j++) {
+        if (!skip()) { acc = j; break; }
+      }
+      if (acc >= 0) {
+        found = true;
+        e = ev.get(head + acc);
+        for (int j = acc; j > 0; j--) ev.set(head + j, ev.get(head + j - 1));  // (the skipped ones before it move up one; acc is 0 nine times of ten)
+        head++;
         ne--;
       }
-      const uint32_t rule = (uint32_t)(e >> 32);
-      const int p1 = (int)(uint32_t)e;
-      const uint32_t t1 = wt.get(p1);
-      if (PACK) {
-        if (t1 == DEAD || wm.get(p1) != rule) continue;  // stale (:1569-1572): the position is gone, or its pair is no longer this rule's
-        const uint32_t l1 = wr.get(p1);
-        const uint32_t p2 = l1 & 0xffffu, p0 = l1 >> 16;   // (p2 exists: the last position of a word never has a rule)
-        const uint32_t p3 = wr.get((int)p2) & 0xffffu;
-        const uint32_t zt = enc_rule_z(m, rule);
-        wt.set((int)p2, DEAD);
-        wt.set(p1, zt | (t1 & (TOK_WS | ENC_SENT)));
-        wr.set(p1, p3 | (p0 << 16));
-        if (p3 != NIL16) wr.set((int)p3, (wr.get((int)p3) & 0xffffu) | ((uint32_t)p1 << 16));
-        // the two pairs the merge made (:1580-1585), their rule-hash loads in flight together
-        uint32_t rl, rr;
-        enc_pair_prio2(m, nullptr, p0 != NIL16, p0 != NIL16 ? wt.get((int)p0) & ENC_IDM : 0u, zt, p3 != NIL16, zt, p3 != NIL16 ? wt.get((int)p3) & ENC_IDM : 0u, &rl, &rr);
-        if (p0 != NIL16) wm.set((int)p0, rl);
-        wm.set(p1, rr);
-        if (rl != ENC_INF) add(((unsigned long long)rl << 32) | (unsigned long long)p0);
-        if (rr != ENC_INF) add(((unsigned long long)rr << 32) | (unsigned long long)p1);
-        continue;
-      }
-      const uint32_t p2 = wr.get(p1);
-      const unsigned long long xy = m.rule_xy[rule];
-      if (t1 == DEAD || (t1 & ENC_IDM) != (uint32_t)(xy >> 32) || p2 == NIL || (wt.get((int)p2) & ENC_IDM) != (uint32_t)xy) continue;  // :1569-1572
-      const uint32_t p0 = wm.get(p1), p3 = wr.get((int)p2);
+    }
+    if (!found) return false;
+    const uint32_t rule = Q::rule(e);
+    const int p1 = (int)Q::pos(e);
+    const uint32_t t1 = wt.get(p1);
+    if (PACK) {
+      if (t1 == DEAD || wm.get(p1) != rule) return true;  // stale (:1569-1572): the position is gone, or its pair is no longer this rule's
+      const uint32_t l1 = wr.get(p1);
+      const uint32_t p2 = l1 & 0xffffu, p0 = l1 >> 16;   // (p2 exists: the last position of a word never has a rule)
+      const uint32_t p3 = wr.get((int)p2) & 0xffffu;
+      const uint32_t zt = enc_rule_z(m, rule);
       wt.set((int)p2, DEAD);
-      wr.set((int)p2, NIL);
-      wt.set(p1, enc_rule_z(m, rule) | (t1 & (TOK_WS | ENC_SENT)));
-      wr.set(p1, p3);
-      if (p3 != NIL) wm.set((int)p3, (uint32_t)p1);
-      {  // the two pairs the merge made (:1580-1585), their rule-hash loads in flight together
-        const uint32_t zt = wt.get(p1) & ENC_IDM;
-        uint32_t rl, rr;
-        enc_pair_prio2(m, nullptr, p0 != NIL, p0 != NIL ? wt.get((int)p0) & ENC_IDM : 0u, zt, p3 != NIL, zt, p3 != NIL ? wt.get((int)p3) & ENC_IDM : 0u, &rl, &rr);
-        if (rl != ENC_INF) add(((unsigned long long)rl << 32) | (unsigned long long)p0);
-        if (rr != ENC_INF) add(((unsigned long long)rr << 32) | (unsigned long long)p1);
+      wt.set(p1, zt | (t1 & (TOK_WS | ENC_SENT)));
+      wr.set(p1, p3 | (p0 << 16));
+      if (p3 != NIL16) wr.set((int)p3, (wr.get((int)p3) & 0xffffu) | ((uint32_t)p1 << 16));
+      // the two pairs the merge made (:1580-1585), their rule-hash loads in flight together
+      uint32_t rl, rr;
+      enc_pair_prio2(m, nullptr, p0 != NIL16, p0 != NIL16 ? wt.get((int)p0) & ENC_IDM : 0u, zt, p3 != NIL16, zt, p3 != NIL16 ? wt.get((int)p3) & ENC_IDM : 0u, &rl, &rr);
+      if (p0 != NIL16) wm.set((int)p0, rl);
+      wm.set(p1, rr);
+      if (rl != ENC_INF) add(rl, (uint32_t)p0);
+      if (rr != ENC_INF) add(rr, (uint32_t)p1);
+      return true;
+    }
+    const uint32_t p2 = wr.get(p1);
+    const unsigned long long xy = m.rule_xy[rule];
+    if (t1 == DEAD || (t1 & ENC_IDM) != (uint32_t)(xy >> 32) || p2 == NIL || (wt.get((int)p2) & ENC_IDM) != (uint32_t)xy) return true;  // :1569-1572
+    const uint32_t p0 = wm.get(p1), p3 = wr.get((int)p2);
+    wt.set((int)p2, DEAD);
+    wr.set((int)p2, NIL);
+    wt.set(p1, enc_rule_z(m, rule) | (t1 & (TOK_WS | ENC_SENT)));
+    wr.set(p1, p3);
+    if (p3 != NIL) wm.set((int)p3, (uint32_t)p1);
+    {  // the two pairs the merge made (:1580-1585), their rule-hash loads in flight together
+      const uint32_t zt = wt.get(p1) & ENC_IDM;
+      uint32_t rl, rr;
+      enc_pair_prio2(m, nullptr, p0 != NIL, p0 != NIL ? wt.get((int)p0) & ENC_IDM : 0u, zt, p3 != NIL, zt, p3 != NIL ? wt.get((int)p3) & ENC_IDM : 0u, &rl, &rr);
+      if (rl != ENC_INF) add(rl, (uint32_t)p0);
+      if (rr != ENC_INF) add(rr, (uint32_t)p1);
+    }
+    return true;
+  };
+  if constexpr (!WPACK) {  // (a long sentence on the HBM scratch: a lane finishes its word, the wave its longest word, then every lane takes its next one)
+    for (int w = lane; w < nw; w += 64) {
+      setup(w);
+      while (pop()) {}
+    }
+  } else {
+    // One flat loop: an iteration is one pop of the lane's word (or, for a lane that has just taken a word, the word's set-up first): a lane
+    // that is done takes the next word from the counter while the others go on -- the wave waits for its longest LANE, not once per word.
+    int w = lane;
+    bool fresh = true;
+    while (w < nw) {
+      if (fresh) {
+        setup(w);
+        fresh = false;
+      }
+      if (!pop()) {
+        w = (int)atomicAdd(&wsl.p[ENC_DROP_WORDS], 1u);
+        fresh = true;
       }
     }
   }
@@ -698,7 +784,8 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
   const unsigned long long lt = lanemask_lt();
   int n = 0, consumed = 0, k = 0;
   unsigned long long my_sid = 0;  // lane j: index of the j-th non-empty sentence of the pack
-  for (unsigned long long j = s; j < e && k < 64; j++) {
+  const int kmax = drop.enabled && drop.pack_sent > 0 && drop.pack_sent < 64 ? drop.pack_sent : 64;
+  for (unsigned long long j = s; j < e && k < kmax; j++) {
     const unsigned long long b0 = sv.lo(j), nbytes = sv.hi(j) - b0;
     if (nbytes + 1 > (unsigned long long)(wcap - n)) break;
     const int n0 = n;
@@ -721,8 +808,8 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
   }
   wave_sync();
   if (k == 0) return consumed;
-  if (drop.enabled) {  // BPE-dropout: one word per lane (the RNG stream is keyed by the pack's first sentence)
-    n = dropout_merge<LdsArr, LdsArr, EvLds>(m, wt, wr, wm, n, drop, s, dws, dq);
+  if (drop.enabled) {  // BPE-dropout: a word per lane at a time (the RNG stream of a word is keyed by its sentence and its number there)
+    n = dropout_merge<LdsArr, LdsArr, EvLds>(m, wt, wr, wm, n, drop, s, dws, dq, my_sid);
   } else {
     const int nl = lane_max > 0 ? merge_lanes(m, bloom, wt, wr, wm, n, lane_max) : -1;
     n = nl >= 0 ? nl : merge_rounds<LdsArr>(m, bloom, wt, wr, wm, n);
@@ -779,19 +866,19 @@ __device__ int encode_pack(const EncModel &m, const uint32_t *bloom, const uint8
 }
 
 // DROP: the BPE-dropout instantiation -- no Bloom filter of the rules (its look-ups go to the rule hash), the wave's LDS share holds the
-// word starts and event queues of a pack of up to ENC_DROP_WCAP tokens instead (72 KB per workgroup: two per CU, as without dropout).
+// working arrays, word starts and event queues of a pack of up to ENC_DROP_WCAP tokens instead (80 KB per workgroup: two per CU, as without dropout).
 template <bool DROP>
 __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8_t *__restrict__ text,
                                                    SentView sv, unsigned long long n_sent, int bos,
                                                    int eos, int reverse, int32_t *__restrict__ scratch_ids,
                                                    uint32_t *__restrict__ counts, uint32_t *__restrict__ work,
                                                    unsigned long long work_stride, DropoutArgs drop, unsigned long long drop_stride, unsigned int group, int lane_max) {
-  __shared__ uint32_t lds[ENC_WAVES][3][ENC_WCAP];
-  // 32 KB beside the working arrays -- 80 KB in all, two workgroups per CU (one byte more and it is one): the rules' Bloom filter, or with
-  // dropout the waves' event queues (3 x 256 packed events each) and word starts (256 each)
-  __shared__ uint32_t aux[ENC_BLOOM_WORDS];
-  static_assert(ENC_WAVES * (3 * ENC_DROP_WCAP + ENC_DROP_WCAP) <= ENC_BLOOM_WORDS, "the dropout queues take the Bloom filter's place");
-  uint32_t *bloom = aux;
+  // 80 KB, two workgroups per CU (one byte more and it is one).  Without dropout: 48 KB of working arrays (3 x 512 tokens per wave) + the
+  // rules' Bloom filter (32 KB).  With dropout: per wave three arrays of ENC_DROP_WCAP tokens, the event queues and the word starts.
+  __shared__ uint32_t smem[ENC_WAVES * 3 * ENC_WCAP + ENC_BLOOM_WORDS];
+  static_assert(ENC_WAVES * ENC_DROP_WAVE_WORDS <= ENC_WAVES * 3 * ENC_WCAP + ENC_BLOOM_WORDS, "the dropout layout fits the same 80 KB");
+  static_assert(ENC_DROP_WCAP <= 512, "positions of a pack are packed into 9 bits");
+  uint32_t *bloom = smem + ENC_WAVES * 3 * ENC_WCAP;
   if (!DROP) {
     for (int i = (int)threadIdx.x; i < ENC_BLOOM_WORDS; i += ENC_THREADS) bloom[i] = m.bloom[i];
     __syncthreads();
@@ -810,7 +897,9 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
     while (sidx < grp_end) {
       const unsigned long long b0 = sv.lo(sidx), b1 = sv.hi(sidx);
       const unsigned long long nbytes = b1 - b0;
-      LdsArr a{lds[wave][0]}, b{lds[wave][1]}, c{lds[wave][2]};
+      uint32_t *const wbase = DROP ? smem + wave * ENC_DROP_WAVE_WORDS : smem + wave * 3 * ENC_WCAP;
+      constexpr int WSTR = DROP ? ENC_DROP_WCAP : ENC_WCAP;
+      LdsArr a{wbase}, b{wbase + WSTR}, c{wbase + 2 * WSTR};
       DropoutArgs d = drop;
       if (d.enabled) {  // per-wave slice of the dropout scratch (long sentences): word starts, then the event queues
         d.wsl = drop.wsl + gw * 7 * drop_stride;
@@ -818,7 +907,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k5_encode(EncModel m, const uint8
       }
       if (nbytes + 1 <= (unsigned long long)wcap) {
         sidx += (unsigned long long)encode_pack(m, bloom, text, sv, sidx, grp_end, a, b, c, bos, eos, reverse, scratch_ids, counts, d, wcap,
-                                                LdsArr{aux + ENC_WAVES * 3 * ENC_DROP_WCAP + wave * ENC_DROP_WCAP}, EvLds{aux + wave * 3 * ENC_DROP_WCAP}, lane_max);
+                                                LdsArr{wbase + 6 * ENC_DROP_WCAP}, EvLds{wbase + 3 * ENC_DROP_WCAP}, lane_max);
         continue;
       }
       // too long for the LDS arrays: one sentence at a time on the wavefront's HBM scratch
@@ -1020,8 +1109,10 @@ void launch_encode(const EncModel &m, const uint8_t *text, const unsigned long l
   unsigned long long group = n_sent / ((unsigned long long)n_blocks * ENC_WAVES * 4);
   if (group < 1) group = 1;
   if (group > 24) group = 24;
+  if (C->k5_group.u) group = C->k5_group.u;  // (tests: packs of several sentences in a small batch)
   d.lds_queues = m.n_rules < (1u << 23) && !C->dropout_hbm_queues.set;
   d.pack_links = !C->dropout_no_pack.set;
+  d.pack_sent = (int)C->dropout_pack_sent.u;
   // one word per lane (merge_lanes) for packs whose words have at most this many tokens; 0 = the wave-wide rounds only.
   // YTTM_K5_LANE_WORDS: the word cache's distinct words, YTTM_K5_LANE_SENT: packed sentences
   const int lane_max = ends ? (int)C->k5_lane_words.i : (int)C->k5_lane_sent.i;

@@ -101,6 +101,8 @@ struct Hook {
   X(k5_lane_words, "YTTM_K5_LANE_WORDS", "48", "path", "one-word-per-lane for the cache's distinct words up to this many tokens (0: wave-wide rounds)") \
   X(k5_lane_sent, "YTTM_K5_LANE_SENT", "48", "path", "... for packed sentences")                                                            \
   X(k5_classes, "YTTM_K5_CLASSES", "4", "path", "length classes of the distinct-word list (<= 1: one)")                                     \
+  X(dropout_pack_sent, "YTTM_DROPOUT_PACK_SENT", "0", "test", "dropout: at most this many sentences share a pack (0: as many as fit)") \
+  X(k5_group, "YTTM_K5_GROUP", "0", "test", "K5: consecutive sentences a wavefront owns at a time (packs are cut from them; 0: by the batch's size)") \
   X(wc_sblk, "YTTM_WC_SBLK", "", "test", "sentences a wavefront of the word cache's walks takes at a time")                                 \
   X(wc_short_slots, "YTTM_WC_SHORT_SLOTS", "", "test", "slots of the short-word region of the word cache (rounded up to a power of two)")  \
   X(enc_staged_from, "YTTM_ENC_STAGED_FROM", "", "test", "host <-> device copies of at least this many bytes go through the pinned chunks")\
