@@ -29,7 +29,9 @@ cd $R
 python tools/pmc_summary.py kernel-stats $OUT/stats profiles/${TAG}_kernel_stats.csv
 python tools/pmc_summary.py pmc $OUT/fetch $OUT/write profiles/${TAG}_pmc_hbm.json
 if [ "$WHAT" = abcd ]; then
+  T0=$(date +%s)
   python bench.py ${BENCH_ARGS:-} > profiles/${TAG}_bench.json 2> $OUT/bench.err   # (BENCH_ARGS: e.g. "--cpu-runs 1" when GPU minutes are short)
+  echo "default bench.py run: $(( $(date +%s) - T0 )) s of wall clock"
   tail -c 600 profiles/${TAG}_bench.json
 fi
 cp profiles/${TAG}_*.* $R/gpurun_out/ 2>/dev/null
