@@ -112,6 +112,7 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (multi-process GPU work on this pool: the host driver only supports dmabuf IPC)
     import numpy as np
     import torch
 
