@@ -493,8 +493,8 @@ def test_zz_rccl_world_of_one(tmp_path):
         L.yttm_comm_destroy(comm)
 
 
-@pytest.mark.parametrize("use_comm", [0, 1])
-def test_zz_fused_tail_ordering(tmp_path, use_comm):
+@pytest.mark.parametrize("use_comm,pin_name", [(0, "c2_100mb"), (1, "c2_100mb"), (0, "c6_cjk_100mb")])
+def test_zz_fused_tail_ordering(tmp_path, use_comm, pin_name):
     """The round's candidate scan rides in the tail of the round's last kernel: the LAST workgroup to take its ticket reads what every
     other workgroup -- on other XCDs -- published before taking its own (device-scope atomics, write-through stores, a workgroup-scope
     release + s_waitcnt vmcnt(0); k_tiles.hip / k_words.hip / k_pairtable.hip k_fold_list).  The emulator cannot show that ordering; this does: the
@@ -502,13 +502,14 @@ def test_zz_fused_tail_ordering(tmp_path, use_comm):
     with the scan as a kernel of its own (YTTM_NO_FUSE=1: ordered by a kernel boundary), ten times (four through the communicator): the candidate traces
     (YTTM_DBG_CAND: one line per scan -- thresholds, list lengths, key count, a hash of the candidates) must agree line by line and the
     models must be the reference's pin.  use_comm=1: through an RCCL communicator of one rank -- the multi-GPU round, whose scan sits in
-    the fold kernel's tail behind the all-gather."""
+    the fold kernel's tail behind the all-gather.  c6_cjk_100mb (round 5): long clauses -- class-B tiles, whose launch precedes k_words in every
+    word-mode round (two kernels before the tail), and a large alphabet."""
     import hashlib
     import re
     import subprocess
     import sys
-    pin = _full_pins()["c2_100mb"]
-    text = gen.abcd_corpus(pin["corpus_bytes"] + 1, seed=19, survey_stream=True)
+    pin = _full_pins()[pin_name]
+    text = gen.abcd_corpus(pin["corpus_bytes"] + 1, seed=19, survey_stream=True) if pin_name == "c2_100mb" else gen.cjk_corpus_fast(100_000_000, seed=11)[:pin["corpus_bytes"]]
     assert hashlib.md5(text).hexdigest() == pin["corpus_md5"]
     corpus = str(tmp_path / "c2.txt")
     open(corpus, "wb").write(text)
@@ -531,7 +532,7 @@ def test_zz_fused_tail_ordering(tmp_path, use_comm):
     hooks = {"YTTM_NO_REFINE": "1", "YTTM_WORD_MIN_TOKENS": "0", "YTTM_NO_BATCH_SPLIT": "1"}
     ref, rep0 = run("nofuse", dict(hooks, YTTM_NO_FUSE="1"))
     assert rep0["fused_rounds"] == 0
-    for i in range(10 if not use_comm else 4):  # (the ordering rests on an empirical check -- more runs of it, ten on the headline path)
+    for i in range(10 if not use_comm and pin_name == "c2_100mb" else 4):  # (the ordering rests on an empirical check -- more runs of it, ten on the headline path)
         got, rep = run("fuse%d" % i, hooks)
         assert rep["fused_rounds"] > 100 and rep["word_fused_rounds"] > 100, (rep["fused_rounds"], rep["word_fused_rounds"])
         assert len(got) == len(ref), (len(got), len(ref))

@@ -442,6 +442,36 @@ def test_word_table_overflow_is_redone(tmp_path):
     assert filecmp.cmp(m_gpu, m_ora, shallow=False)
 
 
+def test_word_mode_with_class_b_tiles(tmp_path, monkeypatch):
+    """Word mode with class-B tiles beside it (words of 257 .. 2 048 tokens -- the long clauses of unsegmented scripts -- stay in tiles of their own,
+    whose launch precedes k_words in every round): same model as the oracle."""
+    import ctypes as C
+    import filecmp
+    import json
+    from youtokentome_amd import _lib
+    import oracle_lib as O
+    L = _lib.load()
+    for k in ("YTTM_WORD_MIN_TILES", "YTTM_WORD_MIN_TOKENS", "YTTM_WORD_DIV"):
+        monkeypatch.setenv(k, "0")
+    monkeypatch.setenv("YTTM_WORDS_GRID", "3")
+    rng = random.Random(5)
+    ws = []
+    for _ in range(60):  # long clauses, some of them periodic (runs of one pair), among many short words
+        n_ch = rng.choice([rng.randint(260, 420), rng.randint(500, 900), rng.randint(1500, 2040)])
+        w = (rng.choice("ab") * rng.randint(1, 4) + rng.choice("abc") * rng.randint(1, 4)) * (n_ch // 2) if rng.random() < 0.3 else "".join(rng.choice("abc") for _ in range(n_ch))
+        ws.append(w[:n_ch])
+    ws += ["".join(rng.choice("abcd") for _ in range(rng.randint(1, 9))) for _ in range(3000)]
+    rng.shuffle(ws)
+    text = (" ".join(ws) + "\n").encode()
+    O.train(text, str(tmp_path / "o.model"), 260)
+    cp, mg = str(tmp_path / "c.txt"), str(tmp_path / "g.model")
+    open(cp, "wb").write(text)
+    err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+    assert L.yttm_train_bpe_ex(cp.encode(), mg.encode(), 260, 1.0, 1, 0, 1, 2, 3, 0, rep, 16384, err, 2048) == 0, err.value
+    assert filecmp.cmp(mg, str(tmp_path / "o.model"), shallow=False)
+    assert json.loads(rep.value.decode())["word_rounds"] > 20
+
+
 def test_word_mode(tmp_path, monkeypatch):
     """Word mode (class-A words in fixed slots, a round visits the words that hold a merge site, found through the pair index at word
     granularity or the instance list of the pair's younger token) forced on from the second round, on corpora of several tiles: the round

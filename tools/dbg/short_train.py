@@ -9,7 +9,8 @@ cache = "/tmp/corpus_%s_%d.bin" % (kind, mb)
 if os.path.exists(cache):
     text = open(cache, "rb").read()
 else:
-    text = gen.abcd_corpus(mb * 1_000_000, seed=19, survey_stream=True) if kind == "abcd" else gen.zipf_corpus_fast(mb * 1_000_000, seed=7, vocab=400000)
+    text = (gen.abcd_corpus(mb * 1_000_000, seed=19, survey_stream=True) if kind == "abcd" else gen.cjk_corpus_fast(mb * 1_000_000, seed=11) if kind == "cjk"
+            else gen.zipf_corpus_fast(mb * 1_000_000, seed=7, vocab=400000))
     open(cache, "wb").write(text)
 from youtokentome_amd import _lib
 L = _lib.load()

@@ -4,7 +4,8 @@ R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import gen
 kind, mb, vocab = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-text = gen.abcd_corpus(mb * 1_000_000, seed=19, survey_stream=True) if kind == "abcd" else gen.zipf_corpus_fast(mb * 1_000_000, seed=7, vocab=400000)
+text = (gen.abcd_corpus(mb * 1_000_000, seed=19, survey_stream=True) if kind == "abcd" else gen.cjk_corpus_fast(mb * 1_000_000, seed=11) if kind == "cjk"
+            else gen.zipf_corpus_fast(mb * 1_000_000, seed=7, vocab=400000))
 open("/tmp/tt.txt", "wb").write(text)
 os.environ["YTTM_TRACE"] = "1"
 from youtokentome_amd import _lib
