@@ -63,6 +63,13 @@ def test_chunked_front_end(tmp_path, monkeypatch):
             r = json.loads(rep.value.decode())
             assert r["front_end_chunks"] >= len(text) // (int(kb) << 10) and r["peak_device_bytes"] > 0, r
     monkeypatch.delenv("YTTM_FE_CHUNK_SERIAL")
+    # a word longer than a chunk is refused, and says so (the documented limit: INTEGRATION.md)
+    monkeypatch.setenv("YTTM_FE_CHUNK_KB", "4")
+    corpus = str(tmp_path / "long.txt")
+    open(corpus, "wb").write(b"ab " * 3000 + b"abcd" * 1300 + b" ab\n")
+    err = C.create_string_buffer(2048)
+    assert L.yttm_train_bpe_ex(corpus.encode(), str(tmp_path / "l.model").encode(), 50, 1.0, 1, 0, 1, 2, 3, 0, None, 0, err, 2048) != 0
+    assert b"a word longer than the front end's chunk" in err.value, err.value
     # from host memory, and a word heavier than a weight holds (the copies are made from the lexicon's bytes)
     monkeypatch.setenv("YTTM_FE_CHUNK_KB", "4")
     monkeypatch.setenv("YTTM_TEST_WCNT_MAX", "7")

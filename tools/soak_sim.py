@@ -92,8 +92,8 @@ while time.time() - t0 < budget:
     # round 5: a third of the corpora cross the device in chunks of 4 / 8 / 16 KB (the chunked front end: lexicon, table growth, the second pass
     # when coverage drops chars), some of the three-byte kind (K1 / K2a's window classification against the exact path)
     os.environ.pop("YTTM_FE_CHUNK_KB", None)
-    if rng.random() < 0.33:
-        os.environ["YTTM_FE_CHUNK_KB"] = rng.choice(["4", "8", "16"])
+    if rng.random() < 0.33:  # (a word longer than a chunk is refused, loudly: the `long` mode's words have up to 5 000 chars)
+        os.environ["YTTM_FE_CHUNK_KB"] = rng.choice(["8", "16"] if long_words else ["4", "8", "16"])
     if not big and rng.random() < 0.15:
         text, cov = S.three_byte_text(rng, rng.choice([300, 5000, 30000])), rng.choice([1.0, 1.0, 0.9])
         if not text.strip():
