@@ -535,6 +535,8 @@ def test_zz_fused_tail_ordering(tmp_path, use_comm, pin_name):
     for i in range(10 if not use_comm and pin_name == "c2_100mb" else 4):  # (the ordering rests on an empirical check -- more runs of it, ten on the headline path)
         got, rep = run("fuse%d" % i, hooks)
         assert rep["fused_rounds"] > 100 and rep["word_fused_rounds"] > 100, (rep["fused_rounds"], rep["word_fused_rounds"])
+        if pin_name == "c6_cjk_100mb":  # (class-B tiles: their launch of a word-mode round runs beside k_words on a second stream, the tail waits for its flag)
+            assert rep["classb_overlapped"] > 100, rep["classb_overlapped"]
         assert len(got) == len(ref), (len(got), len(ref))
         for n, (a, b) in enumerate(zip(ref, got)):
             assert a == b, "scan %d differs (run %d):\n  separate scan: %s\n  fused tail:    %s" % (n, i, a, b)

@@ -449,9 +449,11 @@ def test_word_table_overflow_is_redone(tmp_path):
     assert filecmp.cmp(m_gpu, m_ora, shallow=False)
 
 
-def test_word_mode_with_class_b_tiles(tmp_path, monkeypatch):
-    """Word mode with class-B tiles beside it (words of 257 .. 2 048 tokens -- the long clauses of unsegmented scripts -- stay in tiles of their own,
-    whose launch precedes k_words in every round): same model as the oracle."""
+def test_word_mode_with_class_b_tiles_beside(tmp_path, monkeypatch):
+    """Word mode with class-B tiles (words of 257 .. 2 048 tokens -- the long clauses of unsegmented scripts -- stay in tiles of their own): the
+    round's class-B launch goes to a second stream beside k_words, its last workgroup raises a flag the round's tail waits for (gpu_ctx.cpp
+    merge_apply, ScanArgs::peer_flag).  Same model as the oracle with the launches side by side and -- YTTM_NO_CLASSB_OVERLAP -- one after the
+    other; the report counts the rounds that ran side by side."""
     import ctypes as C
     import filecmp
     import json
@@ -471,12 +473,19 @@ def test_word_mode_with_class_b_tiles(tmp_path, monkeypatch):
     rng.shuffle(ws)
     text = (" ".join(ws) + "\n").encode()
     O.train(text, str(tmp_path / "o.model"), 260)
-    cp, mg = str(tmp_path / "c.txt"), str(tmp_path / "g.model")
-    open(cp, "wb").write(text)
-    err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
-    assert L.yttm_train_bpe_ex(cp.encode(), mg.encode(), 260, 1.0, 1, 0, 1, 2, 3, 0, rep, 16384, err, 2048) == 0, err.value
-    assert filecmp.cmp(mg, str(tmp_path / "o.model"), shallow=False)
-    assert json.loads(rep.value.decode())["word_rounds"] > 20
+    seen = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("YTTM_NO_CLASSB_OVERLAP", "1")
+        cp, mg = str(tmp_path / "c.txt"), str(tmp_path / "g.model")
+        open(cp, "wb").write(text)
+        err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+        assert L.yttm_train_bpe_ex(cp.encode(), mg.encode(), 260, 1.0, 1, 0, 1, 2, 3, 0, rep, 16384, err, 2048) == 0, err.value
+        assert filecmp.cmp(mg, str(tmp_path / "o.model"), shallow=False), off
+        r = json.loads(rep.value.decode())
+        assert r["word_rounds"] > 20, r
+        seen[off] = r["classb_overlapped"]
+    assert seen[False] > 20 and seen[True] == 0, seen
 
 
 def test_word_mode(tmp_path, monkeypatch):

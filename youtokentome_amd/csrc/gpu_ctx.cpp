@@ -12,15 +12,15 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   xchg_margin_ = C.xchg_margin.d;
   pool_reset_peak();
   HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
+  tl_stream = strm();
   tl_device = device_;
-  st_ = pool_take_stream(device_);  // (a finished context's: creating and destroying one costs ~2 ms of a training)
-  if (!st_) HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
-  tl_stream = st_;
+  st_raw_ = pool_take_stream(device_);  // (a finished context's: creating and destroying one costs ~2 ms of a training)
+  if (!st_raw_) HIP_CHECK(hipStreamCreateWithFlags(&st_raw_, hipStreamNonBlocking));
+  tl_stream = strm();
   tl_device = device_;
   d_counters_ = dmalloc<unsigned long long>(64);
   d_stats_ = dmalloc<unsigned long long>(STATS_WORDS);  // [0..3] K4 counters, [8..23] per-phase cycles of a YTTM_K4_PROF build, [32..) per-workgroup rows
-  HIP_CHECK(hipMemsetAsync(d_stats_, 0, STATS_WORDS * sizeof(unsigned long long), st_));  // (stream-ordered like everything that uses them)
+  HIP_CHECK(hipMemsetAsync(d_stats_, 0, STATS_WORDS * sizeof(unsigned long long), strm()));  // (stream-ordered like everything that uses them)
   // one block for everything the host reads back per round, so that it is ONE device-to-host copy:
   // [0] n_cand, [4] n_keys | [64..) count histogram | [8192..) candidates
   d_round_ = dmalloc<unsigned char>(8192 + (size_t)CAND_CAP * sizeof(CandRec));
@@ -28,6 +28,7 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   hot_target_ = (unsigned int)C.hot_target.u;  // measured at 1 GB: 4096..16384 equal on the abcd corpus, 8192 best on Zipf text (4279 rounds)
   hot_min_ = (unsigned int)C.hot_min.u;
   fuse_enabled_ = C.no_fuse.u == 0;
+  classb_overlap_ = !C.no_classb_overlap.set;
   idx_enabled_ = C.no_index.u == 0;  // (no pair index: no word mode either)
   idx_agg_min_ = C.index_agg_min.u;  // (fill pass of an index build: postings from which on a workgroup sums them per key in LDS first; tests: 0)
   hot_target_words_ = (unsigned int)C.hot_target_words.u;  // (measured at 1 GB, word mode: 8192 -> 6 rebuilds, candidate family 21.0 ms; 32768 -> 3, 16.9 ms; round 4: 32768 -> 3, 14.6 ms; 65536 -> 2, 12.5; 131072 -> 2, 15.0)
@@ -53,14 +54,14 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   dbg_cand_ = C.dbg_cand.c_str();
   d_hot_slots_ = dmalloc<uint32_t>(HOT_CAP);
   d_hot_n_ = dmalloc<unsigned int>(4);  // [0] list length, [1] k_hot_scan's finished-workgroup ticket, [2..3] overflow verdict (u64)
-  HIP_CHECK(hipMemsetAsync(d_hot_n_, 0, 16, st_));
+  HIP_CHECK(hipMemsetAsync(d_hot_n_, 0, 16, strm()));
   top_cap_ = std::max(16u, std::min((unsigned int)C.top_cap.u, TOP_CAP));
   top_target_ = (unsigned int)C.top_target.u;  // about four times what the host looks at per round
   top_min_ = (unsigned int)C.top_min.u;
   d_top_slots_ = dmalloc<uint32_t>(TOP_CAP);
   d_top_n_ = dmalloc<unsigned int>(4);
-  HIP_CHECK(hipMemsetAsync(d_top_n_, 0, 16, st_));
-  HIP_CHECK(hipMemsetAsync(d_round_, 0, 8192, st_));  // k_hot_scan leaves its counters zeroed for the next call
+  HIP_CHECK(hipMemsetAsync(d_top_n_, 0, 16, strm()));
+  HIP_CHECK(hipMemsetAsync(d_round_, 0, 8192, strm()));  // k_hot_scan leaves its counters zeroed for the next call
   d_cand_n_ = (unsigned int *)d_round_;
   d_cand_hist_ = (unsigned long long *)(d_round_ + 64);
   d_cand_ = (CandRec *)(d_round_ + 8192);
@@ -75,29 +76,32 @@ GpuCtx::GpuCtx(int device) : device_(device) {
 
 GpuCtx::~GpuCtx() {
   (void)hipSetDevice(device_);
-  tl_stream = st_;
+  tl_stream = strm();
   tl_device = device_;
-  (void)hipStreamSynchronize(st_);
+  (void)hipStreamSynchronize(strm());
+  if (st_b_) (void)hipStreamSynchronize(st_b_);
   drop_spec();
   for (hipEvent_t e : all_events_) (void)hipEventDestroy(e);
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_chunk_segs_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_);
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_); DFREE(d_top_slots_); DFREE(d_top_n_);
-  DFREE(d_xstat_); DFREE(d_bloom_); DFREE(d_maybe_); DFREE(d_maybe_n_);
+  DFREE(d_xstat_); DFREE(d_bloom_); DFREE(d_maybe_); DFREE(d_maybe_n_); DFREE(d_bsync_);
   DFREE(db_.keys); DFREE(db_.touched); DFREE(d_send2_[0]); DFREE(d_send2_[1]);
   free_table(pt_);
   free_index();
   free_words();
-  pool_quiesce(st_);
+  pool_quiesce(strm());
   if (h_pin_ && pool_give_pin(h_pin_)) h_pin_ = nullptr;
   if (h_pin_) (void)hipHostFree(h_pin_);
-  if (st_ && pool_give_stream(device_, st_)) st_ = nullptr;  // (synchronised above: nothing is pending on it)
-  if (st_) (void)hipStreamDestroy(st_);
+  if (st_raw_ && pool_give_stream(device_, st_raw_)) st_raw_ = nullptr;  // (synchronised above: nothing is pending on it)
+  if (st_raw_) (void)hipStreamDestroy(st_raw_);
+  if (st_b_ && pool_give_stream(device_, st_b_)) st_b_ = nullptr;
+  if (st_b_) (void)hipStreamDestroy(st_b_);
 }
 
-void GpuCtx::sync() { HIP_CHECK(hipStreamSynchronize(st_)); }
+void GpuCtx::sync() { HIP_CHECK(hipStreamSynchronize(strm())); }
 void GpuCtx::read_stats(int first, int n, unsigned long long *out) {
-  HIP_CHECK(hipMemcpyAsync(out, d_stats_ + first, (size_t)n * 8, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(out, d_stats_ + first, (size_t)n * 8, hipMemcpyDeviceToHost, strm()));
   sync();
 }
 
@@ -128,7 +132,7 @@ void GpuCtx::t_begin(int which) {
   }
   cur_a_ = event_get();
   all_events_.push_back(cur_a_);
-  HIP_CHECK(hipEventRecord(cur_a_, st_));
+  HIP_CHECK(hipEventRecord(cur_a_, strm()));
 }
 void GpuCtx::t_end(int which, unsigned long long bytes, bool chain) {
   kt.launches[which]++;
@@ -136,7 +140,7 @@ void GpuCtx::t_end(int which, unsigned long long bytes, bool chain) {
   if (!profile) return;
   hipEvent_t b = event_get();
   all_events_.push_back(b);
-  HIP_CHECK(hipEventRecord(b, st_));
+  HIP_CHECK(hipEventRecord(b, strm()));
   evs_.push_back(Ev{cur_a_, b, which});
   cur_a_ = nullptr;
   chain_event_ = chain ? b : nullptr;
@@ -148,7 +152,7 @@ void GpuCtx::resolve_timers() {
     // counted once more as re-read and rewritten (8 B per token of those -- an upper bound since single-site tiles are
     // rewritten from the registers they were loaded into)
     unsigned long long st[8] = {0};
-    if (pt_cap_) launch_fold_stats(d_stats_, pt_.n_keys, st_);
+    if (pt_cap_) launch_fold_stats(d_stats_, pt_.n_keys, strm());
     sync();
     if (hipMemcpy(st, d_stats_, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
       merge_sites = st[0];
@@ -182,7 +186,7 @@ void GpuCtx::resolve_timers() {
 void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long long *rule_counts, const unsigned long long *next_tau_cnt,
                          uint32_t next_tau_mx, uint32_t next_want) {
   HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
+  tl_stream = st_raw_;  // (not strm(): naming the stream queues nothing -- see st_touched_)
   tl_device = device_;
   if (!k) return;
   if (!n_tiles && !multi()) return;  // a rank without words still takes part in the exchange
@@ -352,7 +356,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     uint32_t *h_bloom = (uint32_t *)(pin + (size_t)RULES_CAP * sizeof(RuleSlot) + 8 * (size_t)RULES_CAP * sizeof(uint32_t));
     pm_bloom_host(h_bloom, xyz, k);  // the batch's pair filter for the apply kernels (built here: a few hundred hashes)
     if (!d_bloom_) d_bloom_ = dmalloc<uint32_t>(PM_BLOOM_WORDS_H);
-    launch_round_begin(h_rules, cap, d_rules_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr, cls_[1].n_tiles ? cls_[1].d_work_n : nullptr, h_bloom, d_bloom_, st_);
+    launch_round_begin(h_rules, cap, d_rules_, cls_[0].n_tiles ? cls_[0].d_work_n : nullptr, cls_[1].n_tiles ? cls_[1].d_work_n : nullptr, h_bloom, d_bloom_, strm());
   }
   const PairTable kpt = multi() ? pt_nolist() : pt_;  // (multi-GPU: the lists are filled behind the exchange, by the final counts -- k_fold_list)
   // the tail of class ci's launch: the scan (single GPU) or the exchange tail (multi-GPU) in the round's last tile-class launch, nothing elsewhere
@@ -361,8 +365,42 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     if (multi()) return ci == 0 && word_mode_ ? &xa : nullptr;  // (the tile kernels have nothing to do in a tail)
     return sa.on ? &sa : nullptr;
   };
+  // Word mode on one GPU with class-B tiles (words of 257 .. 2 048 tokens: long clauses of unsegmented scripts): the round was two launches
+  // in a row, the class-B tiles (~37 us on the CJK-shaped corpus) and then k_words (~138 us).  They share nothing until the tail, so class B
+  // goes to a second stream and its last workgroup raises a flag the tail waits for (ScanArgs::peer_flag; tools/micro/two_streams.hip: the
+  // whole of the shorter kernel comes off the round).  No join: the main stream's next kernel starts after k_words has ended, k_words' tail
+  // has waited for the flag, and the flag is stored behind everything class B wrote -- stream order on the main stream IS the join.  The
+  // fork: when nothing was queued on the main stream since the host read the last round's mailbox (st_clean: the common round), all that
+  // can still run there is that round's tail folding the statistics rows -- by exchanges, so that this launch may add to them meanwhile --
+  // and class B starts at once; otherwise (a list refill, a repack, a rule table on its way) it waits for an event, which costs the
+  // round ~35 us of cross-queue latency and is why it is not the rule.
+  const bool beside = classb_overlap_ && !multi() && sa.on == 1u && word_mode_ && cls_[0].n_tiles && cls_[1].n_tiles && !cls_[2].n_tiles;
   for (int ci = 1; ci >= 0; ci--) {
     if (!cls_[ci].n_tiles) continue;
+    if (ci == 1 && beside) {
+      bool st_clean = !st_touched_;
+      if (!st_b_) {
+        st_b_ = pool_take_stream(device_);
+        HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        d_bsync_ = dmalloc<unsigned int>(4);
+        HIP_CHECK(hipMemsetAsync(d_bsync_, 0, 16, strm()));
+        st_clean = false;
+      }
+      if (!st_clean) {
+        HIP_CHECK(hipEventRecord(ev_fork_, strm()));
+        HIP_CHECK(hipStreamWaitEvent(st_b_, ev_fork_, 0));
+      }
+      ScanArgs sb{};
+      sb.on = 4u;
+      sb.done_ctr = d_bsync_;
+      sb.peer_flag = d_bsync_ + 1;
+      sb.round_id = sa.round_id;
+      const BatchArgs tba = first_ba();
+      launch_merge_apply(1, cls_[1].ts, kpt, db_, d_rules_, cap - 1, self_x, self_z, z_base, d_stats_, &tba, &sb, d_bloom_, st_b_);
+      sa.peer_flag = d_bsync_ + 1;
+      classb_overlapped++;
+      continue;
+    }
     if (ci == 0 && word_mode_) {
       // the batch's rules -> worklist of words (k_wgather; it also allots the new tokens' instance lists), then the words (k_words)
       WordClass &c = cls_[0];
@@ -370,7 +408,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       if (!by_args) {
         uint32_t *h_xyz = (uint32_t *)(pin + (size_t)RULES_CAP * sizeof(RuleSlot) + 8 * (size_t)RULES_CAP * sizeof(uint32_t) + 16384);
         memcpy(h_xyz, xyz, (size_t)k * 12);
-        HIP_CHECK(hipMemcpyAsync(d_xyz_, h_xyz, (size_t)k * 12, hipMemcpyHostToDevice, st_));
+        HIP_CHECK(hipMemcpyAsync(d_xyz_, h_xyz, (size_t)k * 12, hipMemcpyHostToDevice, strm()));
         d_xyz = d_xyz_;
       }
       if (k > WGATHER_MAXK) throw GpuError{"merge_apply: batch too large for the word-mode gather"};
@@ -394,7 +432,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       if (!d_stamp_) {  // (the index could not be built yet: no stamps either -- the gather must not claim words)
         stamp_cap_ = (unsigned int)(c.n_unique + c.n_unique / 8 + 64);
         d_stamp_ = dmalloc<uint32_t>(stamp_cap_);
-        HIP_CHECK(hipMemsetAsync(d_stamp_, 0, (size_t)stamp_cap_ * 4, st_));
+        HIP_CHECK(hipMemsetAsync(d_stamp_, 0, (size_t)stamp_cap_ * 4, strm()));
         ga.stamp = d_stamp_;
       }
       const unsigned int work_hint = sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + word_hint_floor_, 1ull << 30) : 0u;
@@ -402,16 +440,16 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       const BatchArgs gba = first_ba();
       const WordSet wset{c.d_tok, d_wmeta_, c.d_wcnt, (uint32_t)c.n_unique};
       if (launch_words_apply(wset, kpt, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, d_irec_, &gba,
-                             tail_of(0), work_hint, words_inline_max_, &ga, words_fuse_max_, st_))
+                             tail_of(0), work_hint, words_inline_max_, &ga, words_fuse_max_, strm()))
         word_fused_rounds++;
       word_rounds++;
       if (!idx_valid_) word_all_rounds++;
       continue;
     }
     const BatchArgs tba = first_ba();
-    launch_merge_apply(ci, cls_[ci].ts, kpt, db_, d_rules_, cap - 1, self_x, self_z, z_base, d_stats_, &tba, tail_of(ci), d_bloom_, st_);
+    launch_merge_apply(ci, cls_[ci].ts, kpt, db_, d_rules_, cap - 1, self_x, self_z, z_base, d_stats_, &tba, tail_of(ci), d_bloom_, strm());
   }
-  launch_giant(true, cls_[2].ts, cls_[2].slot, kpt, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, st_);
+  launch_giant(true, cls_[2].ts, cls_[2].slot, kpt, db_, d_rules_, cap - 1, self_x, self_z, cls_[2].d_scratch, d_stats_, strm());
   if (dev_timing) kt.launches[KT_MERGE]++;
   else t_end(KT_MERGE, 0, /*chain=*/!sa.on);  // (a fused round is followed by the host's turn, not by another kernel: its end event must not start the next interval)
   merge_rounds++;
@@ -419,8 +457,8 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   if (trace_rounds) {
     chain_event_ = nullptr;  // tuning aid: cumulative device stats after every round (adds a sync)
     unsigned long long stt[24];
-    launch_fold_stats(d_stats_, pt_.n_keys, st_);
-    HIP_CHECK(hipMemcpyAsync(stt, d_stats_, sizeof stt, hipMemcpyDeviceToHost, st_));
+    launch_fold_stats(d_stats_, pt_.n_keys, strm());
+    HIP_CHECK(hipMemcpyAsync(stt, d_stats_, sizeof stt, hipMemcpyDeviceToHost, strm()));
     sync();
     if (cfg_->trace_blocks.set && merge_rounds % 50 == 0) {  // PROF build: per-workgroup start / end / dirty tiles of this round
       std::vector<unsigned long long> rows(STATS_WORDS);
@@ -441,8 +479,8 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   }
   if (instrument && split_round && merge_rounds == split_round) {  // (measurement pass only: a sync does not matter)
     unsigned long long st[8] = {0};
-    launch_fold_stats(d_stats_, pt_.n_keys, st_);
-    HIP_CHECK(hipMemcpyAsync(st, d_stats_, sizeof st, hipMemcpyDeviceToHost, st_));
+    launch_fold_stats(d_stats_, pt_.n_keys, strm());
+    HIP_CHECK(hipMemcpyAsync(st, d_stats_, sizeof st, hipMemcpyDeviceToHost, strm()));
     sync();
     split_sites = st[0];
     split_touched_words = st[4];

@@ -102,6 +102,7 @@ class GpuCtx {
   unsigned long long last_live() const { return last_live_; }
   int last_top_bin() const { return (int)last_top_bin_; }  // no bin above this one is in use
   unsigned long long index_builds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0, word_fused_rounds = 0;  // K4 rounds whose worklist came from the pair index
+  unsigned long long classb_overlapped = 0;   // word-mode rounds whose class-B tiles ran beside k_words on a second stream
   unsigned long long front_end_chunks = 0;    // > 0: the corpus was taken in this many chunks (front_end_chunked)
   bool corpus_resident() const { return !chunked_; }  // false: only the distinct words' bytes are in HBM
   unsigned long long peak_device_bytes() const;       // high-water mark of the device memory pool since this context was made
@@ -117,7 +118,7 @@ class GpuCtx {
   Comm *comm() const { return comm_; }
   int device() const { return device_; }
   const Config &config() const { return *cfg_; }  // the YTTM_* hooks as they stood when this context was made (yttm_config.h)
-  hipStream_t stream() const { return st_; }
+  hipStream_t stream() const { return st_raw_; }
 
   unsigned long long n_unique = 0, n_tokens0 = 0, n_segments = 0, corpus_bytes = 0;
   unsigned int n_tiles = 0;
@@ -174,6 +175,11 @@ class GpuCtx {
   uint32_t *d_bloom_ = nullptr;   // pair filter of a batch that does not travel in the kernel arguments
   const char *trace_rounds_ = nullptr, *dbg_cand_ = nullptr;
   bool fuse_enabled_ = true;  // YTTM_NO_FUSE=1: always the separate scan kernel (tuning hook / tests)
+  // word mode, single GPU: the class-B tiles' launch of a round runs on a second stream beside k_words (merge_apply; ScanArgs::peer_flag)
+  bool classb_overlap_ = true;       // YTTM_NO_CLASSB_OVERLAP
+  hipStream_t st_b_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr;
+  unsigned int *d_bsync_ = nullptr;  // [0] the class-B launch's ticket, [1] the round it has finished
   uint32_t id_min_ = 0, id_max_ = 0;  // id range of the alphabet (K3)
   uint32_t max_id_ = 0xffffffffu;  // largest token id in the tiles (unknown until the word table is built)
   unsigned long long scanned_cum_ = 0, live_tokens_last_ = 0, touched_cum_ = 0, touched_last_ = ~0ull >> 2;  // (first round: dense)
@@ -187,7 +193,15 @@ class GpuCtx {
   int device_;
   std::shared_ptr<const Config> cfg_;
   double xchg_margin_ = 3.0;
-  hipStream_t st_ = nullptr;
+  // The context's stream.  Every use goes through strm(), which notes that something may have been queued since the host last read a
+  // round's mailbox (poll_mailbox clears the note: whatever was queued before the kernel that published is over, and that kernel is past
+  // everything but its statistics fold) -- merge_apply asks before it puts a launch on the second stream (class-B tiles beside k_words).
+  hipStream_t st_raw_ = nullptr;
+  mutable bool st_touched_ = true;
+  hipStream_t strm() const {
+    st_touched_ = true;
+    return st_raw_;
+  }
   Comm *comm_ = nullptr;
 
   // corpus

@@ -17,28 +17,28 @@ void GpuCtx::grow_recv(unsigned long long need) {
 void GpuCtx::exchange_deltas() {
   if (!multi()) return;
   chain_event_ = nullptr;
-  launch_fold_stats(d_stats_, pt_.n_keys, st_);  // the apply kernels leave their slot counts in per-workgroup rows
+  launch_fold_stats(d_stats_, pt_.n_keys, strm());  // the apply kernels leave their slot counts in per-workgroup rows
   DeltaRec *cur = d_send2_[xch_parity_];  // (K3's updates went straight into the block's records: dt_add)
   unsigned long long n_local = 0;
   unsigned int nk_local = 0;  // keys in the table after this rank's own updates (one round trip for both numbers)
-  HIP_CHECK(hipMemcpyAsync(&n_local, cur, 8, hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipMemcpyAsync(&nk_local, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&n_local, cur, 8, hipMemcpyDeviceToHost, strm()));
+  HIP_CHECK(hipMemcpyAsync(&nk_local, pt_.n_keys, 4, hipMemcpyDeviceToHost, strm()));
   sync();
   n_keys_host = nk_local;
   const unsigned long long mine = n_local > send_cap_ ? ~0ull : n_local;
   size_t n_remote = 0;
   for (int attempt = 0;; attempt++) {
     unsigned long long need_all = 0;
-    if (comm_->allgather_recs(cur + XHDR, mine, d_recv_, (size_t)recv_cap_, st_, &need_all, &n_remote)) break;
+    if (comm_->allgather_recs(cur + XHDR, mine, d_recv_, (size_t)recv_cap_, strm(), &need_all, &n_remote)) break;
     if (need_all == ~0ull) throw GpuError{"delta exchange buffer overflow (on some rank)"};
     if (attempt) throw GpuError{"delta receive buffer could not be sized"};
     grow_recv(need_all);
   }
   finish_block((unsigned int)std::min<unsigned long long>(n_local, 1u << 20));
   ensure_table_capacity(n_keys_host + n_remote);
-  launch_pt_apply(pt_, d_recv_, n_remote, st_);  // (no candidate list exists yet: nothing is listed)
+  launch_pt_apply(pt_, d_recv_, n_remote, strm());  // (no candidate list exists yet: nothing is listed)
   unsigned int nk = 0;
-  HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, strm()));
   sync();
   n_keys_host = nk;
 }
@@ -53,7 +53,7 @@ void GpuCtx::exchange_deltas() {
 // there (k_dt_clean: off the critical path -- it runs while the host picks the next batch)
 void GpuCtx::finish_block(unsigned int n_hint) {
   db_.send = d_send2_[xch_parity_];
-  launch_dt_clean(db_, d_send2_[xch_parity_ ^ 1u], n_hint, d_stats_, cls_[0].n_tiles, d_maybe_n_ + 1, st_);
+  launch_dt_clean(db_, d_send2_[xch_parity_ ^ 1u], n_hint, d_stats_, cls_[0].n_tiles, d_maybe_n_ + 1, strm());
   xch_last_ = d_send2_[xch_parity_];
   xch_parity_ ^= 1u;
   db_.send = d_send2_[xch_parity_];
@@ -74,15 +74,15 @@ void GpuCtx::exchange_round(unsigned long long only_mask, const ScanArgs *scan) 
   chain_event_ = nullptr;
   const DeltaRec *block = only_mask ? xch_last_ : d_send2_[xch_parity_];  // (a repeat gathers the same block again, wider)
   grow_recv(blk_ * (unsigned long long)comm_->world);
-  comm_->allgather_blocks(block, d_recv_, (size_t)blk_ * sizeof(DeltaRec), st_);
+  comm_->allgather_blocks(block, d_recv_, (size_t)blk_ * sizeof(DeltaRec), strm());
   const bool alone = comm_->world == 1;  // (no other rank's block: phase 1 has nothing to add, the fold kernel reads the header itself)
-  if (!alone) launch_pt_apply_blocks(pt_nolist(), d_recv_, blk_, comm_->world, comm_->rank, only_mask, d_xstat_, d_stats_, st_);
+  if (!alone) launch_pt_apply_blocks(pt_nolist(), d_recv_, blk_, comm_->world, comm_->rank, only_mask, d_xstat_, d_stats_, strm());
   PairTable fpt = pt_;  // (the real thresholds, and the notes to go through)
   fpt.maybe = d_maybe_;
   fpt.maybe_n = d_maybe_n_;
   fpt.maybe_cap = maybe_cap_;
   launch_fold_list(fpt, d_recv_, blk_, comm_->world, only_mask, scan, d_stats_, pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_,
-                   pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, d_xstat_, alone, st_);
+                   pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, d_xstat_, alone, strm());
   if (scan) pending_zero_ = false;  // (the scan zeroes the finished batch's pairs)
   if (!only_mask) finish_block((unsigned int)std::min<unsigned long long>(blk_ / 2, 1u << 18));  // (about as many records as the block was sized for)
 }
@@ -94,16 +94,16 @@ void GpuCtx::alloc_delta_table(unsigned long long cap) {
   DFREE(db_.keys); DFREE(db_.touched); DFREE(d_send2_[0]); DFREE(d_send2_[1]);
   db_.keys = dmalloc<DtSlot>(cap);
   db_.mask = cap - 1;
-  launch_dt_init(db_.keys, cap, st_);
+  launch_dt_init(db_.keys, cap, strm());
   send_cap_ = cap / 2;
   db_.send_cap = send_cap_;
   db_.touched = dmalloc<uint32_t>(send_cap_);
   // the two send blocks { header, records }: all zeros but the capacity in the header -- the peers check a block's count against it
   for (int b = 0; b < 2; b++) {
     d_send2_[b] = dmalloc<DeltaRec>(send_cap_ + XHDR);
-    HIP_CHECK(hipMemsetAsync(d_send2_[b], 0, (send_cap_ + XHDR) * sizeof(DeltaRec), st_));
+    HIP_CHECK(hipMemsetAsync(d_send2_[b], 0, (send_cap_ + XHDR) * sizeof(DeltaRec), strm()));
     const long long capv = (long long)send_cap_;
-    HIP_CHECK(hipMemcpyAsync(&d_send2_[b][0].delta, &capv, 8, hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipMemcpyAsync(&d_send2_[b][0].delta, &capv, 8, hipMemcpyHostToDevice, strm()));
   }
   xch_parity_ = 0;
   xch_last_ = d_send2_[0];
@@ -129,7 +129,7 @@ bool GpuCtx::settle_exchange(unsigned long long xmask, unsigned long long xmax, 
   while (blk_ < xmax + XHDR) blk_ <<= 1;
   exchange_round(xmask, nullptr);
   {  // that fold's own report (same blocks, so nothing new): consumed here
-    HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, st_));
+    HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, strm()));
   }
   blk_ = std::max(blk_, want);
   exchange_retries++;

@@ -7,20 +7,20 @@ namespace yttm {
 // ------------------------------------------------------------------------------------------------- K1
 void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long long> &cnts, unsigned long long &n_codepoints) {
   HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
+  tl_stream = strm();
   tl_device = device_;
   const bool have_k1 = spec_.hist_done;  // (upload_overlapped ran K1 on the parts of the text as they arrived; multi-GPU: of this rank's shard -- the sum over the ranks follows below)
   spec_.hist_done = false;
   if (!have_k1) {
   if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
-  HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
-  HIP_CHECK(hipMemsetAsync(d_counters_, 0, 64 * 8, st_));
+  HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, strm()));
+  HIP_CHECK(hipMemsetAsync(d_counters_, 0, 64 * 8, strm()));
   // a look at four 4 KB samples of the text: lead bytes of three- and four-byte chars (>= 0xE0) above 1 % pick the kernel variant that
   // counts such chars in LDS (only speed depends on the verdict)
   bool wide_chars = false;
   if (n_text_ >= (1u << 16)) {
     static thread_local uint8_t smp[4][4096];
-    for (int i = 0; i < 4; i++) HIP_CHECK(hipMemcpyAsync(smp[i], d_text_ + (n_text_ / 4) * (unsigned long long)i, 4096, hipMemcpyDeviceToHost, st_));
+    for (int i = 0; i < 4; i++) HIP_CHECK(hipMemcpyAsync(smp[i], d_text_ + (n_text_ / 4) * (unsigned long long)i, 4096, hipMemcpyDeviceToHost, strm()));
     sync();
     unsigned int wide = 0;
     for (int i = 0; i < 4; i++)
@@ -33,17 +33,17 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
   t_begin(KT_CHAR_HIST);
   DFREE(d_chunk_segs_);
   d_chunk_segs_ = dmalloc<uint32_t>(fe_chunks(n_text_) + 1);
-  if (n_text_) launch_char_hist(d_text_, n_text_, d_hist_, d_counters_, wide_chars, d_chunk_segs_, st_);
+  if (n_text_) launch_char_hist(d_text_, n_text_, d_hist_, d_counters_, wide_chars, d_chunk_segs_, strm());
   t_end(KT_CHAR_HIST, n_text_);
   }
   unsigned long long h_cnt[2] = {0, 0};
-  HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 16, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 16, hipMemcpyDeviceToHost, strm()));
   sync();
   n_segments = h_cnt[1];  // local segments (before any cross-rank reduction)
   if (multi()) {
-    comm_->allreduce_sum_u64(d_hist_, N_CODEPOINTS, st_);
-    comm_->allreduce_sum_u64(d_counters_, 1, st_);
-    HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 8, hipMemcpyDeviceToHost, st_));
+    comm_->allreduce_sum_u64(d_hist_, N_CODEPOINTS, strm());
+    comm_->allreduce_sum_u64(d_counters_, 1, strm());
+    HIP_CHECK(hipMemcpyAsync(h_cnt, d_counters_, 8, hipMemcpyDeviceToHost, strm()));
     sync();
   }
   n_codepoints = h_cnt[0];
@@ -51,16 +51,16 @@ void GpuCtx::char_hist(std::vector<uint32_t> &cps, std::vector<unsigned long lon
   uint32_t *d_cps = dmalloc<uint32_t>(N_CODEPOINTS);
   unsigned long long *d_cnts = dmalloc<unsigned long long>(N_CODEPOINTS);
   unsigned int *d_n = (unsigned int *)(d_counters_ + 8);
-  HIP_CHECK(hipMemsetAsync(d_n, 0, 4, st_));
-  launch_hist_compact(d_hist_, d_cps, d_cnts, d_n, N_CODEPOINTS, st_);
+  HIP_CHECK(hipMemsetAsync(d_n, 0, 4, strm()));
+  launch_hist_compact(d_hist_, d_cps, d_cnts, d_n, N_CODEPOINTS, strm());
   unsigned int k = 0;
-  HIP_CHECK(hipMemcpyAsync(&k, d_n, 4, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&k, d_n, 4, hipMemcpyDeviceToHost, strm()));
   sync();
   cps.resize(k);
   cnts.resize(k);
   if (k) {
-    HIP_CHECK(hipMemcpyAsync(cps.data(), d_cps, (size_t)k * 4, hipMemcpyDeviceToHost, st_));
-    HIP_CHECK(hipMemcpyAsync(cnts.data(), d_cnts, (size_t)k * 8, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipMemcpyAsync(cps.data(), d_cps, (size_t)k * 4, hipMemcpyDeviceToHost, strm()));
+    HIP_CHECK(hipMemcpyAsync(cnts.data(), d_cnts, (size_t)k * 8, hipMemcpyDeviceToHost, strm()));
     sync();
   }
   seen_cps_ = cps;
@@ -76,7 +76,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   for (uint32_t a = 0; a < n_alpha; a++) id_min_ = std::min(id_min_, id[a]);
   id_max_ = max_id_;
   HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
+  tl_stream = strm();
   tl_device = device_;
   // code point -> class map
   {
@@ -86,7 +86,7 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
     const uint32_t spaces[] = {9, 10, 11, 12, 13, 32, 9601};
     for (uint32_t s : spaces) cpmap[s] = CP_SPACE;
     if (!d_cpmap_) d_cpmap_ = dmalloc<uint32_t>(N_CODEPOINTS);
-    HIP_CHECK(hipMemcpyAsync(d_cpmap_, cpmap.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipMemcpyAsync(d_cpmap_, cpmap.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, strm()));
     sync();
   }
   free_words();
@@ -145,8 +145,8 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
     unsigned long long *d_chunk_off = dmalloc<unsigned long long>(nch + 1);
     unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(nch));
     t_begin(KT_SEGS);
-    launch_exclusive_scan(d_chunk_segs_, nch, d_chunk_off, scan_tmp, d_counters_ + 16, st_);
-    launch_seg_write(d_text_, n_text_, d_seg, d_chunk_off, st_);
+    launch_exclusive_scan(d_chunk_segs_, nch, d_chunk_off, scan_tmp, d_counters_ + 16, strm());
+    launch_seg_write(d_text_, n_text_, d_seg, d_chunk_off, strm());
     t_end(KT_SEGS, n_text_ + 8 * n_segs);
     sync();
     DFREE(d_chunk_off);
@@ -163,12 +163,12 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
     ht_cap = attempt == 0 && !long_segments && !cfg_->word_table_full.set ? pow2_at_least(std::max<unsigned long long>(n_segs / 4, 1ull << 16))
                                                                                  : pow2_at_least(n_segs + n_segs / 2 + 1024);
     ht = dmalloc<unsigned long long>(3 * ht_cap);  // keys, counts, positions of the short words' representatives (k_frontend.hip: WH_SHORT)
-    launch_word_table_clear(ht, ht_cap, st_);
-    HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
+    launch_word_table_clear(ht, ht_cap, strm());
+    HIP_CHECK(hipMemsetAsync(d_status, 0, 32, strm()));
     t_begin(KT_DEDUP);
-    launch_insert_words(d_text_, n_text_, d_cpmap_, d_seg, n_segs, ht, ht_cap - 1, d_status, st_);
+    launch_insert_words(d_text_, n_text_, d_cpmap_, d_seg, n_segs, ht, ht_cap - 1, d_status, strm());
     t_end(KT_DEDUP, n_text_ + 8 * n_segs);
-    HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, strm()));
     sync();
     // (more than half full counts as overflow too: the merge loop's tiles do not care, but probe chains do)
     if (!h_status[6] && (attempt || long_segments || (unsigned long long)h_status[0] * 2 <= ht_cap)) break;
@@ -200,15 +200,15 @@ void GpuCtx::build_word_table(const uint32_t *cp, const uint32_t *id, uint32_t n
   cls_[0].d_wcnt = dmalloc<uint32_t>(UA + HX + 256);  // padding: k_tiles loads SLOT/2 frequencies from a tile's first word unconditionally
   cls_[1].d_wcnt = dmalloc<uint32_t>(UB + HX + 256);
   unsigned int *d_cursor = (unsigned int *)(d_counters_ + 32);
-  HIP_CHECK(hipMemsetAsync(d_cursor, 0, 16, st_));
+  HIP_CHECK(hipMemsetAsync(d_cursor, 0, 16, strm()));
   unsigned long long *d_heavy = dmalloc<unsigned long long>(3 * HEAVY_CAP);
   const unsigned long long wmax = cfg_->test_wcnt_max.u;  // (tests: heavy words at toy sizes)
   t_begin(KT_BUILD);
   launch_compact_words(d_text_, n_text_, d_cpmap_, ht, ht_cap, posA, cls_[0].d_wcnt, lenA, posB, cls_[1].d_wcnt, lenB, posC, cls_[2].d_wcnt, lenC, d_cursor,
-                       d_status, wmax, d_heavy, st_);
+                       d_status, wmax, d_heavy, strm());
   unsigned int h_cursor[4] = {0, 0, 0, 0};
-  HIP_CHECK(hipMemcpyAsync(h_status, d_status, 16, hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipMemcpyAsync(h_cursor, d_cursor, 16, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(h_status, d_status, 16, hipMemcpyDeviceToHost, strm()));
+  HIP_CHECK(hipMemcpyAsync(h_cursor, d_cursor, 16, hipMemcpyDeviceToHost, strm()));
   sync();
   DFREE(ht);
   unsigned int UA2 = UA, UB2 = UB, UC2 = UC;
@@ -272,10 +272,10 @@ void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, u
   if (U == 0) return;
   unsigned long long *uw_off = dmalloc<unsigned long long>(U);
   unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(U));
-  launch_exclusive_scan(uw_len, U, uw_off, scan_tmp, d_counters_ + 40, st_);
+  launch_exclusive_scan(uw_len, U, uw_off, scan_tmp, d_counters_ + 40, strm());
   unsigned long long total = 0, last_off = 0;
-  HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 40, 8, hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipMemcpyAsync(&last_off, uw_off + (U - 1), 8, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 40, 8, hipMemcpyDeviceToHost, strm()));
+  HIP_CHECK(hipMemcpyAsync(&last_off, uw_off + (U - 1), 8, hipMemcpyDeviceToHost, strm()));
   sync();
   DFREE(scan_tmp);
   c.n_tokens0 = total;
@@ -284,7 +284,7 @@ void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, u
   c.d_tile_word0 = dmalloc<uint32_t>(c.n_tiles);
   c.d_tile_len = dmalloc<uint32_t>(c.n_tiles);
   c.d_work_n = dmalloc<unsigned int>(16);  // word mode: the round's worklist length [0], "take every word" [WL_PARTS + 1]
-  HIP_CHECK(hipMemsetAsync(c.d_work_n, 0, 64, st_));
+  HIP_CHECK(hipMemsetAsync(c.d_work_n, 0, 64, strm()));
   if (ci == 0 && !multi()) {
     // The pair table is allocated and cleared HERE, ahead of the token fill, not right before K3: K3 then does not start on the
     // dirty lines of a 1 GB memset (measured: 0.435 -> 0.395 ms at 1 GB).
@@ -295,10 +295,10 @@ void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, u
   }
   c.d_tok = dmalloc<uint32_t>((size_t)c.n_tiles * c.slot + 64);
   // slots are read 16 B wide past the live prefix and the staged ids index the flag table: never leave them undefined
-  HIP_CHECK(hipMemsetAsync(c.d_tok, 0, ((size_t)c.n_tiles * c.slot + 64) * 4, st_));
-  launch_tiles(uw_off, U, c.nom, tile_start, c.d_tile_word0, st_);
-  launch_tile_len(tile_start, c.n_tiles, total, c.d_tile_len, st_);
-  launch_fill_tokens(d_text_, n_text_, d_cpmap_, space_id, uw_pos, uw_off, U, c.nom, c.slot, tile_start, c.d_tok, st_, total);
+  HIP_CHECK(hipMemsetAsync(c.d_tok, 0, ((size_t)c.n_tiles * c.slot + 64) * 4, strm()));
+  launch_tiles(uw_off, U, c.nom, tile_start, c.d_tile_word0, strm());
+  launch_tile_len(tile_start, c.n_tiles, total, c.d_tile_len, strm());
+  launch_fill_tokens(d_text_, n_text_, d_cpmap_, space_id, uw_pos, uw_off, U, c.nom, c.slot, tile_start, c.d_tok, strm(), total);
   sync();
   DFREE(uw_off);
   DFREE(tile_start);
@@ -316,9 +316,9 @@ void GpuCtx::download_word_table(std::vector<uint32_t> &tok, std::vector<unsigne
     WordClass &c = cls_[ci];
     if (!c.n_tiles) continue;
     std::vector<uint32_t> all((size_t)c.n_tiles * c.slot), tl(c.n_tiles), wc(c.n_unique);
-    HIP_CHECK(hipMemcpyAsync(all.data(), c.d_tok, all.size() * 4, hipMemcpyDeviceToHost, st_));
-    HIP_CHECK(hipMemcpyAsync(tl.data(), c.d_tile_len, (size_t)c.n_tiles * 4, hipMemcpyDeviceToHost, st_));
-    HIP_CHECK(hipMemcpyAsync(wc.data(), c.d_wcnt, (size_t)c.n_unique * 4, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipMemcpyAsync(all.data(), c.d_tok, all.size() * 4, hipMemcpyDeviceToHost, strm()));
+    HIP_CHECK(hipMemcpyAsync(tl.data(), c.d_tile_len, (size_t)c.n_tiles * 4, hipMemcpyDeviceToHost, strm()));
+    HIP_CHECK(hipMemcpyAsync(wc.data(), c.d_wcnt, (size_t)c.n_unique * 4, hipMemcpyDeviceToHost, strm()));
     sync();
     if (ci == 0 && word_mode_) {  // class A in word mode: the words are where wmeta says
       std::vector<unsigned long long> wm(c.n_unique);
@@ -365,9 +365,9 @@ void GpuCtx::maybe_repack(int ci) {
   chain_event_ = nullptr;  // work between two timed intervals: they no longer share an event
   unsigned long long *off = dmalloc<unsigned long long>(c.n_tiles);
   unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(c.n_tiles));
-  launch_exclusive_scan(c.d_tile_len, c.n_tiles, off, scan_tmp, d_counters_ + 48, st_);
+  launch_exclusive_scan(c.d_tile_len, c.n_tiles, off, scan_tmp, d_counters_ + 48, strm());
   unsigned long long total = 0;
-  HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 48, 8, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 48, 8, hipMemcpyDeviceToHost, strm()));
   sync();
   DFREE(scan_tmp);
   rp_known_[ci] = true;
@@ -378,10 +378,10 @@ void GpuCtx::maybe_repack(int ci) {
   uint32_t *new_tok = dmalloc<uint32_t>((size_t)n_new * c.slot + 64);
   uint32_t *new_len = dmalloc<uint32_t>(n_new), *new_word0 = dmalloc<uint32_t>(n_new);
   unsigned long long *gstart = dmalloc<unsigned long long>(n_new);
-  HIP_CHECK(hipMemsetAsync(new_tok, 0, ((size_t)n_new * c.slot + 64) * 4, st_));
-  HIP_CHECK(hipMemsetAsync(gstart, 0xff, (size_t)n_new * 8, st_));
-  HIP_CHECK(hipMemsetAsync(new_word0, 0xff, (size_t)n_new * 4, st_));
-  launch_repack(ci, c.ts, off, c.nom, total, gstart, n_new, new_tok, new_len, new_word0, st_);
+  HIP_CHECK(hipMemsetAsync(new_tok, 0, ((size_t)n_new * c.slot + 64) * 4, strm()));
+  HIP_CHECK(hipMemsetAsync(gstart, 0xff, (size_t)n_new * 8, strm()));
+  HIP_CHECK(hipMemsetAsync(new_word0, 0xff, (size_t)n_new * 4, strm()));
+  launch_repack(ci, c.ts, off, c.nom, total, gstart, n_new, new_tok, new_len, new_word0, strm());
   sync();
   DFREE(off); DFREE(gstart);
   DFREE(c.d_tok); DFREE(c.d_tile_len); DFREE(c.d_tile_word0);

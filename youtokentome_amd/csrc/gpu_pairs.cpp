@@ -19,8 +19,8 @@ void GpuCtx::alloc_table(PairTable &pt, unsigned long long cap) {
   pt.top_cap = top_cap_;
   hot_state_ = HOT_INVALID;
   top_state_ = TOP_INVALID;
-  launch_pt_clear(pt, st_);
-  HIP_CHECK(hipMemsetAsync(pt.n_keys, 0, 16, st_));
+  launch_pt_clear(pt, strm());
+  HIP_CHECK(hipMemsetAsync(pt.n_keys, 0, 16, strm()));
 }
 void GpuCtx::free_table(PairTable &pt) {
   DFREE(pt.slots);
@@ -40,10 +40,10 @@ void GpuCtx::ensure_table_capacity(unsigned long long need_keys) {
   }
   PairTable nt{};
   alloc_table(nt, new_cap);
-  launch_pt_rehash(pt_, nt, st_);
+  launch_pt_rehash(pt_, nt, strm());
   rehashes++;
   unsigned int nk = 0;
-  HIP_CHECK(hipMemcpyAsync(&nk, nt.n_keys, 4, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&nk, nt.n_keys, 4, hipMemcpyDeviceToHost, strm()));
   sync();
   free_table(pt_);
   pt_ = nt;
@@ -62,7 +62,7 @@ unsigned long long GpuCtx::initial_table_keys(unsigned long long n_tok) const {
 
 void GpuCtx::pair_count() {
   HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
+  tl_stream = strm();
   tl_device = device_;
   n_keys_host = 0;
   unsigned long long bound = initial_table_keys(n_tokens0);
@@ -82,11 +82,11 @@ void GpuCtx::pair_count() {
       }
       alloc_delta_table(cap);
       d_xstat_ = dmalloc<unsigned long long>(XSTAT_WORDS);
-      HIP_CHECK(hipMemsetAsync(d_xstat_, 0, XSTAT_WORDS * 8, st_));
+      HIP_CHECK(hipMemsetAsync(d_xstat_, 0, XSTAT_WORDS * 8, strm()));
       maybe_cap_ = std::max(1u, (unsigned int)cfg_->xchg_notes.u);  // (tests shrink it: the fold then walks every record)
       d_maybe_ = dmalloc<uint32_t>(maybe_cap_);
       d_maybe_n_ = dmalloc<unsigned int>(4);
-      HIP_CHECK(hipMemsetAsync(d_maybe_n_, 0, 16, st_));
+      HIP_CHECK(hipMemsetAsync(d_maybe_n_, 0, 16, strm()));
       blk_min_ = std::max(2u * XHDR, (unsigned int)cfg_->xchg_blk_min.u);  // (tests shrink it to force the repeat path)
       blk_ = blk_min_;
       grow_recv(std::max<unsigned long long>(send_cap_, blk_ * (unsigned long long)comm_->world));
@@ -100,11 +100,11 @@ void GpuCtx::pair_count() {
   pt_fresh_ = false;
   ensure_table_capacity(bound);
   t_begin(KT_PAIR_COUNT);
-  for (int ci = 0; ci < 2; ci++) launch_pair_count(ci, cls_[ci].ts, pt_, db_, id_min_, id_max_ >= id_min_ ? id_max_ - id_min_ + 1 : 0, st_);
-  launch_giant(false, cls_[2].ts, cls_[2].slot, pt_, db_, nullptr, 0, 0xffffffffu, 0, cls_[2].d_scratch, d_stats_, st_);
+  for (int ci = 0; ci < 2; ci++) launch_pair_count(ci, cls_[ci].ts, pt_, db_, id_min_, id_max_ >= id_min_ ? id_max_ - id_min_ + 1 : 0, strm());
+  launch_giant(false, cls_[2].ts, cls_[2].slot, pt_, db_, nullptr, 0, 0xffffffffu, 0, cls_[2].d_scratch, d_stats_, strm());
   t_end(KT_PAIR_COUNT, 4 * n_tokens0 + 8 * n_unique);
   unsigned int nk = 0;
-  HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, strm()));
   sync();
   n_keys_host = nk;
   exchange_deltas();
@@ -121,7 +121,7 @@ void GpuCtx::download_pairs(std::vector<unsigned long long> &keys, std::vector<u
 
 uint32_t GpuCtx::scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist) {
   HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
+  tl_stream = strm();
   tl_device = device_;
   out.clear();
   if (!pt_cap_) {
@@ -132,17 +132,17 @@ uint32_t GpuCtx::scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vec
     return 0;
   }
   flush_pending_zero();
-  launch_fold_stats(d_stats_, pt_.n_keys, st_);
-  HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, st_));
-  HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, st_));
+  launch_fold_stats(d_stats_, pt_.n_keys, strm());
+  HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, strm()));
+  HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, strm()));
   t_begin(KT_CAND);
-  launch_cand_scan(pt_, tau_cnt, tau_mx, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, st_);  // (always with the histogram: last_hist())
+  launch_cand_scan(pt_, tau_cnt, tau_mx, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, strm());  // (always with the histogram: last_hist())
   t_end(KT_CAND, 16 * pt_cap_);
   // ONE device-to-host copy per round: header + histogram + the first CAND_FAST candidates; a second copy only when
   // more candidates passed (the host rarely looks past a few thousand)
   constexpr unsigned int CAND_FAST = 4096;
   unsigned char *h = (unsigned char *)h_pin_;
-  HIP_CHECK(hipMemcpyAsync(h, d_round_, 8192 + (size_t)CAND_FAST * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(h, d_round_, 8192 + (size_t)CAND_FAST * sizeof(CandRec), hipMemcpyDeviceToHost, strm()));
   sync();
   const unsigned int n = *(unsigned int *)h;
   n_keys_host = *(unsigned int *)(h + 4);
@@ -155,12 +155,12 @@ uint32_t GpuCtx::scan_full(unsigned long long tau_cnt, uint32_t tau_mx, std::vec
   const unsigned int take = std::min(n, cand_cap_);
   CandRec *h_c = (CandRec *)(h + 8192);
   if (take > CAND_FAST) {
-    HIP_CHECK(hipMemcpyAsync(h_c + CAND_FAST, d_cand_ + CAND_FAST, (size_t)(take - CAND_FAST) * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipMemcpyAsync(h_c + CAND_FAST, d_cand_ + CAND_FAST, (size_t)(take - CAND_FAST) * sizeof(CandRec), hipMemcpyDeviceToHost, strm()));
     sync();
   }
   out.assign(h_c, h_c + take);
-  HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, st_));  // the hot-list filter expects its counters cleared
-  HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, st_));
+  HIP_CHECK(hipMemsetAsync(d_cand_n_, 0, 16, strm()));  // the hot-list filter expects its counters cleared
+  HIP_CHECK(hipMemsetAsync(d_cand_hist_, 0, CAND_BINS * 8, strm()));
   return n;
 }
 
@@ -192,9 +192,9 @@ void GpuCtx::rebuild_hot() {
     return;
   }
   pt_.hot_tau = std::max<unsigned long long>(1, cand_bin_lower(chosen));
-  HIP_CHECK(hipMemsetAsync(d_hot_n_, 0, 4, st_));
+  HIP_CHECK(hipMemsetAsync(d_hot_n_, 0, 4, strm()));
   t_begin(KT_CAND);
-  launch_hot_rebuild(pt_, st_);
+  launch_hot_rebuild(pt_, strm());
   t_end(KT_CAND, 8 * pt_cap_);
   hot_state_ = HOT_ACTIVE;
   hot_just_rebuilt_ = true;
@@ -207,7 +207,7 @@ void GpuCtx::poll_mailbox(uint32_t round_id) {
   volatile uint32_t *flag = (volatile uint32_t *)(h + 32);
   for (unsigned long long spins = 0; *flag != round_id; spins++) {
     if ((spins & 0x3fff) == 0x3fff) {
-      const hipError_t q = hipStreamQuery(st_);
+      const hipError_t q = hipStreamQuery(st_raw_);
       if (q == hipSuccess) {
         if (*flag != round_id) throw GpuError{"candidate mailbox was not published"};
       } else if (q != hipErrorNotReady) {
@@ -224,6 +224,7 @@ void GpuCtx::poll_mailbox(uint32_t round_id) {
     touched_last_ = touched - touched_cum_;
     touched_cum_ = touched;
   }
+  st_touched_ = false;  // (whatever was queued before the kernel that published is over; that kernel is past everything but its statistics fold)
   const unsigned long long sites = *(const unsigned long long *)(h + 88);  // (published by scan_top only; one round old, like the token counts)
   if (sites > sites_cum_) {
     sites_last_ = sites - sites_cum_;
@@ -249,7 +250,7 @@ bool GpuCtx::scan_hot(unsigned long long t, uint32_t tm) {
   t_begin(KT_CAND);
   launch_hot_scan(pt_, t, tm, d_cand_, cand_cap_, d_cand_n_, d_cand_hist_, d_hot_n_ + 1, h, CAND_FAST, round_id, d_stats_,
                   pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_, listed_last_ ? listed_last_ + 4096 : hot_cap_,
-                  pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, multi() ? d_xstat_ : nullptr, st_);
+                  pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, multi() ? d_xstat_ : nullptr, strm());
   pending_zero_ = false;
   t_end(KT_CAND, 20ull * listed_last_);  // (not chained: the host round trip that follows belongs to no kernel family)
   poll_mailbox(round_id);
@@ -291,9 +292,9 @@ bool GpuCtx::refill_top() {
     return true;
   }
   pt_.top_tau = std::max<unsigned long long>(pt_.hot_tau, cand_bin_lower(chosen));
-  HIP_CHECK(hipMemsetAsync(d_top_n_, 0, 4, st_));
+  HIP_CHECK(hipMemsetAsync(d_top_n_, 0, 4, strm()));
   t_begin(KT_CAND);
-  launch_top_rebuild(pt_, listed_last_, st_);
+  launch_top_rebuild(pt_, listed_last_, strm());
   t_end(KT_CAND, 20ull * listed_last_);
   top_state_ = TOP_ACTIVE;
   return true;
@@ -304,7 +305,7 @@ bool GpuCtx::refill_top() {
 // kernel of its own) when it runs dry or overflows, which is rebuilt from the whole table when IT runs dry or overflows.
 uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::vector<CandRec> &out, unsigned long long *hist) {
   HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
+  tl_stream = strm();
   tl_device = device_;
   out.clear();
   if (!pt_cap_) {
@@ -326,8 +327,8 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
       // whole-table scans ahead (list rebuild, or no list at all): they synchronise anyway, so the verdict of this round's
       // exchange is fetched directly instead of travelling with the mailbox
       unsigned long long x[4] = {0, 0, 0, 0};
-      HIP_CHECK(hipMemcpyAsync(x, d_xstat_, 32, hipMemcpyDeviceToHost, st_));
-      HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, st_));
+      HIP_CHECK(hipMemcpyAsync(x, d_xstat_, 32, hipMemcpyDeviceToHost, strm()));
+      HIP_CHECK(hipMemsetAsync(d_xstat_, 0, 32, strm()));
       sync();
       settle_exchange(x[0], x[1], x[3]);
     }
@@ -375,7 +376,7 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
         sa.round_id = round_id;
         t_begin(KT_CAND);
         launch_top_scan(pt_, sa, d_stats_, pending_zero_ && !zero_ba_.k ? d_rules_ : nullptr, zero_cap_ - 1, zero_self_key_,
-                        pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, multi() ? d_xstat_ : nullptr, st_);
+                        pending_zero_ && zero_ba_.k ? &zero_ba_ : nullptr, multi() ? d_xstat_ : nullptr, strm());
         pending_zero_ = false;
         t_end(KT_CAND, 20ull * top_listed_last_);
       }
@@ -442,7 +443,7 @@ uint32_t GpuCtx::candidates(unsigned long long tau_cnt, uint32_t tau_mx, std::ve
     const unsigned int take = std::min(n, cand_cap_);
     CandRec *h_c = (CandRec *)(h + 8192);
     if (take > CAND_FAST) {
-      HIP_CHECK(hipMemcpyAsync(h_c + CAND_FAST, d_cand_ + CAND_FAST, (size_t)(take - CAND_FAST) * sizeof(CandRec), hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipMemcpyAsync(h_c + CAND_FAST, d_cand_ + CAND_FAST, (size_t)(take - CAND_FAST) * sizeof(CandRec), hipMemcpyDeviceToHost, strm()));
       sync();
     }
     out.assign(h_c, h_c + take);
@@ -463,9 +464,9 @@ void GpuCtx::pair_query(const unsigned long long *keys, uint32_t n, unsigned lon
   if (!n) return;
   flush_pending_zero();
   unsigned long long *d_k = dmalloc<unsigned long long>(n), *d_o = dmalloc<unsigned long long>(n);
-  HIP_CHECK(hipMemcpyAsync(d_k, keys, (size_t)n * 8, hipMemcpyHostToDevice, st_));
-  launch_pt_query(pt_, d_k, n, d_o, st_);
-  HIP_CHECK(hipMemcpyAsync(outv, d_o, (size_t)n * 8, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(d_k, keys, (size_t)n * 8, hipMemcpyHostToDevice, strm()));
+  launch_pt_query(pt_, d_k, n, d_o, strm());
+  HIP_CHECK(hipMemcpyAsync(outv, d_o, (size_t)n * 8, hipMemcpyDeviceToHost, strm()));
   sync();
   DFREE(d_k);
   DFREE(d_o);
@@ -485,10 +486,10 @@ void GpuCtx::flush_pending_zero() {
       while (tab[h].key != PT_EMPTY) h = (h + 1) & (zero_cap_ - 1);
       tab[h].key = key;
     }
-    HIP_CHECK(hipMemcpyAsync(d_rules_, tab.data(), tab.size() * sizeof(RuleSlot), hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipMemcpyAsync(d_rules_, tab.data(), tab.size() * sizeof(RuleSlot), hipMemcpyHostToDevice, strm()));
     sync();
   }
-  launch_pt_zero(pt_, d_rules_, zero_cap_, zero_self_key_, st_);
+  launch_pt_zero(pt_, d_rules_, zero_cap_, zero_self_key_, strm());
   pending_zero_ = false;
 }
 

@@ -21,11 +21,11 @@ void GpuCtx::upload_corpus(const uint8_t *host, unsigned long long n) {
   }
   if ((n < (32u << 20) && !(cfg_->fe_overlap_min.set && overlap_front_end(n))) || cfg_->plain_upload.set) {  // small, or (tuning hook) the one-copy path for comparison
     HIP_CHECK(hipSetDevice(device_));
-    tl_stream = st_;
+    tl_stream = strm();
     tl_device = device_;
     DFREE(d_text_owned_);
     d_text_owned_ = dmalloc<uint8_t>(n + 64);
-    if (n) HIP_CHECK(hipMemcpyAsync(d_text_owned_, host, n, hipMemcpyHostToDevice, st_));
+    if (n) HIP_CHECK(hipMemcpyAsync(d_text_owned_, host, n, hipMemcpyHostToDevice, strm()));
     sync();
     d_text_ = d_text_owned_;
     n_text_ = n;
@@ -84,7 +84,7 @@ void release_io_stage() {
 
 void GpuCtx::upload_staged(unsigned long long n, const std::function<bool(void *dst, unsigned long long off, size_t len)> &fill) {
   HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
+  tl_stream = strm();
   tl_device = device_;
   DFREE(d_text_owned_);
   d_text_owned_ = dmalloc<uint8_t>(n + 64);
@@ -257,7 +257,7 @@ void GpuCtx::drop_spec() {
 // A part's last segment may run on into bytes that have not arrived: it is inserted with the next part that has a segment of its own.
 void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(void *dst, unsigned long long off, size_t len)> &fill) {
   HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
+  tl_stream = strm();
   tl_device = device_;
   drop_spec();
   DFREE(d_text_owned_);
@@ -280,8 +280,8 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
   }
   if (cfg_->k1_wide.set) wide_chars = cfg_->k1_wide.i != 0;
   if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
-  HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
-  HIP_CHECK(hipMemsetAsync(d_counters_, 0, 64 * 8, st_));
+  HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, strm()));
+  HIP_CHECK(hipMemsetAsync(d_counters_, 0, 64 * 8, strm()));
   const unsigned long long nch = fe_chunks(n);
   DFREE(d_chunk_segs_);
   d_chunk_segs_ = dmalloc<uint32_t>(nch + 1);
@@ -296,7 +296,7 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
       const uint32_t spaces[] = {9, 10, 11, 12, 13, 32, 9601};
       for (uint32_t sp : spaces) ident[sp] = CP_SPACE;
     });
-    HIP_CHECK(hipMemcpyAsync(d_cpmap_spec, ident.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipMemcpyAsync(d_cpmap_spec, ident.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, strm()));
   }
   unsigned long long *d_chunk_off = dmalloc<unsigned long long>(nch + 1);
   // ---- the upload, on a thread of its own; what has landed, in order
@@ -368,15 +368,15 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
       if (!wait_for(std::min(n, b1 + FC))) break;
       const unsigned long long c_lo = b0 / FC, c_hi = fe_chunks(b1);
       t_begin(KT_CHAR_HIST);
-      launch_char_hist(d_text_, n, d_hist_, d_counters_, wide_chars, d_chunk_segs_, st_, c_lo, c_hi);
+      launch_char_hist(d_text_, n, d_hist_, d_counters_, wide_chars, d_chunk_segs_, strm(), c_lo, c_hi);
       t_end(KT_CHAR_HIST, b1 - b0);
       if (!spec_on) continue;
       // the part's segments: where they go (relative to the part's first), how many
       unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(c_hi - c_lo));
       t_begin(KT_SEGS);
-      launch_exclusive_scan(d_chunk_segs_ + c_lo, c_hi - c_lo, d_chunk_off + c_lo, scan_tmp, d_counters_ + 16, st_);
+      launch_exclusive_scan(d_chunk_segs_ + c_lo, c_hi - c_lo, d_chunk_off + c_lo, scan_tmp, d_counters_ + 16, strm());
       unsigned long long n_p = 0;
-      HIP_CHECK(hipMemcpyAsync(&n_p, d_counters_ + 16, 8, hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipMemcpyAsync(&n_p, d_counters_ + 16, 8, hipMemcpyDeviceToHost, strm()));
       sync();
       DFREE(scan_tmp);
       if (b0 == 0) {  // sizes from the first part's density of segments (build_word_table's rules, on an estimate)
@@ -388,15 +388,15 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
         spec_.ht_cap = !spec_.long_segments && !cfg_->word_table_full.set ? pow2_at_least(std::max<unsigned long long>(ns / 4, 1ull << 16))
                                                                                 : pow2_at_least(ns + ns / 2 + 1024);
         spec_.ht = dmalloc<unsigned long long>(3 * spec_.ht_cap);
-        launch_word_table_clear(spec_.ht, spec_.ht_cap, st_);
-        HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
+        launch_word_table_clear(spec_.ht, spec_.ht_cap, strm());
+        HIP_CHECK(hipMemsetAsync(d_status, 0, 32, strm()));
       }
       if (base + n_p > seg_cap) {  // denser than the first part promised: no room for the segment starts -- the usual way then
         t_end(KT_SEGS, 0);
         spec_on = false;
         continue;
       }
-      launch_seg_write(d_text_, n, d_seg + base, d_chunk_off, st_, c_lo, c_hi);
+      launch_seg_write(d_text_, n, d_seg + base, d_chunk_off, strm(), c_lo, c_hi);
       t_end(KT_SEGS, (b1 - b0) + 8 * n_p);
       if (n_p) {
         // every segment that starts in this part but its last -- that one may run on into bytes that have not landed -- and the last of the
@@ -404,7 +404,7 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
         const unsigned long long from = have_pending ? pending : base, to = base + n_p - 1;
         if (to > from) {
           t_begin(KT_DEDUP);
-          launch_insert_words(d_text_, n, d_cpmap_spec, d_seg + from, to - from, spec_.ht, spec_.ht_cap - 1, d_status, st_, k2b_blocks);
+          launch_insert_words(d_text_, n, d_cpmap_spec, d_seg + from, to - from, spec_.ht, spec_.ht_cap - 1, d_status, strm(), k2b_blocks);
           t_end(KT_DEDUP, (b1 - b0) + 8 * n_p);
         }
         pending = to;
@@ -423,10 +423,10 @@ void GpuCtx::upload_overlapped(unsigned long long n, const std::function<bool(vo
       if (spec_on && d_seg) {
         if (have_pending) {
           t_begin(KT_DEDUP);
-          launch_insert_words(d_text_, n, d_cpmap_spec, d_seg + pending, 1, spec_.ht, spec_.ht_cap - 1, d_status, st_);
+          launch_insert_words(d_text_, n, d_cpmap_spec, d_seg + pending, 1, spec_.ht, spec_.ht_cap - 1, d_status, strm());
           t_end(KT_DEDUP, 0);
         }
-        HIP_CHECK(hipMemcpyAsync(spec_.h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipMemcpyAsync(spec_.h_status, d_status, 32, hipMemcpyDeviceToHost, strm()));
       }
       sync();
     } catch (const GpuError &e) {
@@ -523,7 +523,7 @@ unsigned long long GpuCtx::chunk_bytes_for(unsigned long long n) const {
 
 void GpuCtx::front_end_chunked(bool first_pass) {
   HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
+  tl_stream = strm();
   tl_device = device_;
   const unsigned long long n = chunk_src_n_;
   const auto &fill = chunk_src_;
@@ -570,13 +570,13 @@ void GpuCtx::front_end_chunked(bool first_pass) {
   const unsigned long long sub = std::min<unsigned long long>(std::max<unsigned long long>(C / 16, 256), 4ull << 20);  // segments per K2b launch
   unsigned long long cap = pow2_at_least(std::max<unsigned long long>(4 * sub, 1024));
   unsigned long long *ht = dmalloc<unsigned long long>(3 * cap);
-  launch_word_table_clear(ht, cap, st_);
+  launch_word_table_clear(ht, cap, strm());
   unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
-  HIP_CHECK(hipMemsetAsync(d_status, 0, 32, st_));
+  HIP_CHECK(hipMemsetAsync(d_status, 0, 32, strm()));
   unsigned long long *d_cur = d_counters_ + 56;  // [0] the lexicon's end (an offset into B), [1] bytes a relocation will need
   {
     const unsigned long long init[2] = {LEX0, 0};
-    HIP_CHECK(hipMemcpyAsync(d_cur, init, 16, hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipMemcpyAsync(d_cur, init, 16, hipMemcpyHostToDevice, strm()));
   }
   // K1's variant from four samples of the source, as upload_overlapped does
   bool wide_chars = true;
@@ -593,13 +593,13 @@ void GpuCtx::front_end_chunked(bool first_pass) {
   unsigned long long *hist = nullptr, *counters = nullptr, *scratch_hist = nullptr;
   if (first_pass) {
     if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
-    HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, st_));
-    HIP_CHECK(hipMemsetAsync(d_counters_, 0, 24 * 8, st_));
+    HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, strm()));
+    HIP_CHECK(hipMemsetAsync(d_counters_, 0, 24 * 8, strm()));
     hist = d_hist_;
     counters = d_counters_;
   } else {  // (the second pass needs K1 only for the chunks' segment counts: its histogram and counters go to a scratch copy)
     scratch_hist = dmalloc<unsigned long long>(N_CODEPOINTS + 8);
-    HIP_CHECK(hipMemsetAsync(scratch_hist, 0, ((size_t)N_CODEPOINTS + 8) * 8, st_));
+    HIP_CHECK(hipMemsetAsync(scratch_hist, 0, ((size_t)N_CODEPOINTS + 8) * 8, strm()));
     hist = scratch_hist;
     counters = scratch_hist + N_CODEPOINTS;
   }
@@ -611,7 +611,7 @@ void GpuCtx::front_end_chunked(bool first_pass) {
     for (uint32_t c = 0; c < N_CODEPOINTS; c++) ident[c] = c;
     for (uint32_t sp : {9u, 10u, 11u, 12u, 13u, 32u, 9601u}) ident[sp] = CP_SPACE;
     d_map_spec = dmalloc<uint32_t>(N_CODEPOINTS);
-    HIP_CHECK(hipMemcpyAsync(d_map_spec, ident.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipMemcpyAsync(d_map_spec, ident.data(), (size_t)N_CODEPOINTS * 4, hipMemcpyHostToDevice, strm()));
     sync();  // (ident goes out of scope)
     d_map = d_map_spec;
   }
@@ -644,25 +644,25 @@ void GpuCtx::front_end_chunked(bool first_pass) {
     // ---- the chunk, then spaces behind it (its last segment ends there if the text does not end with white space)
     if (landing) {
       in_flight.get();  // (rethrows the uploader's error)
-      if (len) HIP_CHECK(hipMemcpyAsync(B, landing, (size_t)len, hipMemcpyDeviceToDevice, st_));
+      if (len) HIP_CHECK(hipMemcpyAsync(B, landing, (size_t)len, hipMemcpyDeviceToDevice, strm()));
       sync();
       if (ck + 1 < n_chunks) in_flight = std::async(std::launch::async, upload, ck + 1, landing);
     } else {
       upload(ck, B);
     }
     if (!len) continue;
-    HIP_CHECK(hipMemsetAsync(B + len, 32, GAP, st_));
+    HIP_CHECK(hipMemsetAsync(B + len, 32, GAP, strm()));
     const unsigned long long nch = fe_chunks(len);
     t_begin(KT_CHAR_HIST);
-    launch_char_hist(B, len, hist, counters, wide_chars, d_chunk_segs_, st_);
+    launch_char_hist(B, len, hist, counters, wide_chars, d_chunk_segs_, strm());
     t_end(KT_CHAR_HIST, first_pass ? len : 0);
     t_begin(KT_SEGS);
-    launch_exclusive_scan(d_chunk_segs_, nch, d_chunk_off, scan_tmp, d_counters_ + 16, st_);
+    launch_exclusive_scan(d_chunk_segs_, nch, d_chunk_off, scan_tmp, d_counters_ + 16, strm());
     unsigned long long n_p = 0;
-    HIP_CHECK(hipMemcpyAsync(&n_p, d_counters_ + 16, 8, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipMemcpyAsync(&n_p, d_counters_ + 16, 8, hipMemcpyDeviceToHost, strm()));
     sync();
     unsigned long long *d_seg = dmalloc<unsigned long long>(std::max<unsigned long long>(n_p, 1));
-    launch_seg_write(B, len, d_seg, d_chunk_off, st_);
+    launch_seg_write(B, len, d_seg, d_chunk_off, strm());
     t_end(KT_SEGS, len + 8 * n_p);
     segs_total += n_p;
     // ---- its words into the table, `sub` segments per launch; the table is grown ahead of a launch that could fill it beyond half
@@ -673,8 +673,8 @@ void GpuCtx::front_end_chunked(bool first_pass) {
         unsigned long long ncap = cap;
         while (2 * (n_unique_host + cnt) > ncap / 2) ncap <<= 1;  // (a quarter full at most after this launch: growth is rare)
         unsigned long long *nht = dmalloc<unsigned long long>(3 * ncap);
-        launch_word_table_clear(nht, ncap, st_);
-        launch_word_table_rehash(B, extent, d_map, ht, cap, nht, ncap, st_);
+        launch_word_table_clear(nht, ncap, strm());
+        launch_word_table_rehash(B, extent, d_map, ht, cap, nht, ncap, strm());
         sync();
         DFREE(ht);
         ht = nht;
@@ -682,25 +682,25 @@ void GpuCtx::front_end_chunked(bool first_pass) {
         word_table_retries++;
       }
       t_begin(KT_DEDUP);
-      launch_insert_words(B, extent, d_map, d_seg + s0, cnt, ht, cap - 1, d_status, st_);
+      launch_insert_words(B, extent, d_map, d_seg + s0, cnt, ht, cap - 1, d_status, strm());
       t_end(KT_DEDUP, (len * cnt) / std::max<unsigned long long>(n_p, 1) + 8 * cnt);
-      HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, strm()));
       sync();
       if (h_status[6]) throw GpuError{"word table overflow (chunked front end)"};
       n_unique_host = h_status[0];
     }
     DFREE(d_seg);
     // ---- the chunk's new words move to the lexicon: first how many bytes, the lexicon grown if they do not fit, then the move
-    HIP_CHECK(hipMemsetAsync(d_cur + 1, 0, 8, st_));
-    launch_words_relocate(B, C, len + 1, ht, cap, d_cur + 1, /*move=*/false, st_);
+    HIP_CHECK(hipMemsetAsync(d_cur + 1, 0, 8, strm()));
+    launch_words_relocate(B, C, len + 1, ht, cap, d_cur + 1, /*move=*/false, strm());
     unsigned long long need = 0;
-    HIP_CHECK(hipMemcpyAsync(&need, d_cur + 1, 8, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipMemcpyAsync(&need, d_cur + 1, 8, hipMemcpyDeviceToHost, strm()));
     sync();
     if (lex_used_ + need > lex_cap_) {
       unsigned long long ncap = lex_cap_;
       while (lex_used_ + need > ncap) ncap <<= 1;
       uint8_t *NB = dmalloc<uint8_t>(LEX0 + ncap + 2 * GAP);
-      HIP_CHECK(hipMemcpyAsync(NB, B, (size_t)(LEX0 + lex_used_), hipMemcpyDeviceToDevice, st_));  // (the chunk too: its new words are still read from it)
+      HIP_CHECK(hipMemcpyAsync(NB, B, (size_t)(LEX0 + lex_used_), hipMemcpyDeviceToDevice, strm()));  // (the chunk too: its new words are still read from it)
       sync();
       DFREE(d_text_owned_);
       B = NB;
@@ -708,12 +708,12 @@ void GpuCtx::front_end_chunked(bool first_pass) {
       d_text_ = B;
       lex_cap_ = ncap;
     }
-    if (need) launch_words_relocate(B, C, len + 1, ht, cap, d_cur, /*move=*/true, st_);
+    if (need) launch_words_relocate(B, C, len + 1, ht, cap, d_cur, /*move=*/true, strm());
     lex_used_ += need;
     sync();  // (the next chunk's upload runs on the workers' streams: the region must not be overwritten under the move)
   }
-  HIP_CHECK(hipMemsetAsync(B + LEX0 + lex_used_, 32, 2 * GAP, st_));
-  HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemsetAsync(B + LEX0 + lex_used_, 32, 2 * GAP, strm()));
+  HIP_CHECK(hipMemcpyAsync(h_status, d_status, 32, hipMemcpyDeviceToHost, strm()));
   sync();
   DFREE(landing);
   DFREE(d_chunk_off);
@@ -737,10 +737,10 @@ void GpuCtx::front_end_chunked(bool first_pass) {
 // multi-GPU, small word tables (host_trainer.cpp learn_bpe): every rank ends up with the WHOLE corpus -- the ranks' byte ranges in rank
 // order are the file -- and goes on alone.  Returns the ranks' summed dedup token count when called with gather = false (the decision).
 unsigned long long GpuCtx::allreduce_scalar(unsigned long long v) {
-  HIP_CHECK(hipMemcpyAsync(d_counters_ + 40, &v, 8, hipMemcpyHostToDevice, st_));
-  comm_->allreduce_sum_u64(d_counters_ + 40, 1, st_);
+  HIP_CHECK(hipMemcpyAsync(d_counters_ + 40, &v, 8, hipMemcpyHostToDevice, strm()));
+  comm_->allreduce_sum_u64(d_counters_ + 40, 1, strm());
   unsigned long long out = 0;
-  HIP_CHECK(hipMemcpyAsync(&out, d_counters_ + 40, 8, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&out, d_counters_ + 40, 8, hipMemcpyDeviceToHost, strm()));
   sync();
   return out;
 }
@@ -753,28 +753,28 @@ unsigned long long GpuCtx::free_device_bytes() const {
 void GpuCtx::gather_full_corpus() {
   drop_spec();
   HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
+  tl_stream = strm();
   tl_device = device_;
   chain_event_ = nullptr;
   const int W = comm_->world, R = comm_->rank;
   std::vector<unsigned long long> sizes((size_t)W, 0);
   unsigned long long *d_sz = dmalloc<unsigned long long>((size_t)W);
   sizes[(size_t)R] = n_text_;
-  HIP_CHECK(hipMemcpyAsync(d_sz, sizes.data(), 8 * (size_t)W, hipMemcpyHostToDevice, st_));
-  comm_->allreduce_sum_u64(d_sz, (size_t)W, st_);
-  HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sz, 8 * (size_t)W, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(d_sz, sizes.data(), 8 * (size_t)W, hipMemcpyHostToDevice, strm()));
+  comm_->allreduce_sum_u64(d_sz, (size_t)W, strm());
+  HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sz, 8 * (size_t)W, hipMemcpyDeviceToHost, strm()));
   sync();
   DFREE(d_sz);
   unsigned long long maxb = 8, total = 0;
   for (unsigned long long v : sizes) { maxb = std::max(maxb, (v + 7) & ~7ull); total += v; }
   uint8_t *d_send = dmalloc<uint8_t>(maxb), *d_recv = dmalloc<uint8_t>(maxb * (unsigned long long)W);
-  HIP_CHECK(hipMemsetAsync(d_send, 32, maxb, st_));
-  if (n_text_) HIP_CHECK(hipMemcpyAsync(d_send, d_text_, n_text_, hipMemcpyDeviceToDevice, st_));
-  comm_->allgather_blocks(d_send, d_recv, maxb, st_);
+  HIP_CHECK(hipMemsetAsync(d_send, 32, maxb, strm()));
+  if (n_text_) HIP_CHECK(hipMemcpyAsync(d_send, d_text_, n_text_, hipMemcpyDeviceToDevice, strm()));
+  comm_->allgather_blocks(d_send, d_recv, maxb, strm());
   uint8_t *d_full = dmalloc<uint8_t>(total + 64);
   unsigned long long off = 0;
   for (int r = 0; r < W; r++) {
-    if (sizes[(size_t)r]) HIP_CHECK(hipMemcpyAsync(d_full + off, d_recv + maxb * (unsigned long long)r, sizes[(size_t)r], hipMemcpyDeviceToDevice, st_));
+    if (sizes[(size_t)r]) HIP_CHECK(hipMemcpyAsync(d_full + off, d_recv + maxb * (unsigned long long)r, sizes[(size_t)r], hipMemcpyDeviceToDevice, strm()));
     off += sizes[(size_t)r];
   }
   sync();
@@ -791,7 +791,7 @@ void GpuCtx::attach_corpus(const void *dev, unsigned long long n) {
   drop_spec();
   chunked_ = false;
   HIP_CHECK(hipSetDevice(device_));
-  tl_stream = st_;
+  tl_stream = strm();
   tl_device = device_;
   DFREE(d_text_owned_);
   if (((uintptr_t)dev & 15u) != 0) throw GpuError{"attach_corpus: device pointer must be 16-byte aligned"};

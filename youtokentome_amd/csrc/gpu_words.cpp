@@ -21,11 +21,11 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
   WordClass &c = cls_[0];
   chain_event_ = nullptr;
   d_wmeta_ = dmalloc<unsigned long long>(c.n_unique + 1);
-  launch_words_init(c.ts, d_wmeta_, st_);
+  launch_words_init(c.ts, d_wmeta_, strm());
   d_wworklist_ = dmalloc<uint32_t>(c.n_unique + 64);
-  HIP_CHECK(hipMemsetAsync(c.d_work_n, 0, 64, st_));
+  HIP_CHECK(hipMemsetAsync(c.d_work_n, 0, 64, strm()));
   d_gm_ = dmalloc<unsigned int>(WGATHER_MAXK + 4);
-  HIP_CHECK(hipMemsetAsync(d_gm_, 0, (WGATHER_MAXK + 4) * 4, st_));
+  HIP_CHECK(hipMemsetAsync(d_gm_, 0, (WGATHER_MAXK + 4) * 4, strm()));
   d_xyz_ = dmalloc<uint32_t>(3 * (size_t)RULES_CAP);
   drec_cap_ = (unsigned int)cfg_->word_drec.u;  // (tests: a region that overflows)
   d_drec_ = dmalloc<DeltaRec>((size_t)WORDS_MAX_GRID * drec_cap_);
@@ -34,11 +34,11 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
   tl_.base = dmalloc<unsigned long long>(id_cap_);
   tl_.cap = dmalloc<uint32_t>(id_cap_);
   tl_.fill = dmalloc<uint32_t>(id_cap_);
-  HIP_CHECK(hipMemsetAsync(tl_.base, 0, (size_t)id_cap_ * 8, st_));
-  HIP_CHECK(hipMemsetAsync(tl_.cap, 0, (size_t)id_cap_ * 4, st_));
-  HIP_CHECK(hipMemsetAsync(tl_.fill, 0, (size_t)id_cap_ * 4, st_));
+  HIP_CHECK(hipMemsetAsync(tl_.base, 0, (size_t)id_cap_ * 8, strm()));
+  HIP_CHECK(hipMemsetAsync(tl_.cap, 0, (size_t)id_cap_ * 4, strm()));
+  HIP_CHECK(hipMemsetAsync(tl_.fill, 0, (size_t)id_cap_ * 4, strm()));
   tl_.cursor = dmalloc<unsigned long long>(2);
-  HIP_CHECK(hipMemsetAsync(tl_.cursor, 0, 16, st_));
+  HIP_CHECK(hipMemsetAsync(tl_.cursor, 0, 16, strm()));
   // every record ever matched is a site at most once through each of its two neighbours, and a site removes a token: a few records per
   // live token bound the log between two index builds; should it fill up all the same, the round says so and the index is rebuilt
   const unsigned long long live = std::max<unsigned long long>(live_tokens_last_, 1ull << 16);
@@ -76,7 +76,7 @@ void GpuCtx::build_index(uint32_t z_next) {
   if (!c.n_tiles || hot_state_ != HOT_ACTIVE || !word_mode_) return;
   chain_event_ = nullptr;
   unsigned int listed = 0;  // (the list has grown since the scan that last reported its length)
-  HIP_CHECK(hipMemcpyAsync(&listed, d_hot_n_, 4, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&listed, d_hot_n_, 4, hipMemcpyDeviceToHost, strm()));
   sync();
   if (listed > hot_cap_) return;  // overflowed: the next scan rebuilds the list, and the index after it
   unsigned long long want = 1024;
@@ -92,19 +92,19 @@ void GpuCtx::build_index(uint32_t z_next) {
   }
   if (!idx_.bloom) idx_.bloom = dmalloc<uint32_t>(ENC_BLOOM_WORDS);
   idx_.mask = (unsigned int)(want - 1);
-  launch_fill_u64(idx_.key, PT_EMPTY, want, st_);
-  HIP_CHECK(hipMemsetAsync(idx_.cnt, 0, want * IDX_SHARDS * 4, st_));
-  HIP_CHECK(hipMemsetAsync(idx_.bloom, 0, ENC_BLOOM_WORDS * 4, st_));
+  launch_fill_u64(idx_.key, PT_EMPTY, want, strm());
+  HIP_CHECK(hipMemsetAsync(idx_.cnt, 0, want * IDX_SHARDS * 4, strm()));
+  HIP_CHECK(hipMemsetAsync(idx_.bloom, 0, ENC_BLOOM_WORDS * 4, strm()));
   t_begin(KT_CAND);
-  launch_idx_seed(pt_, idx_, listed, st_);
+  launch_idx_seed(pt_, idx_, listed, strm());
   if (!idx_save_) idx_save_ = dmalloc<unsigned char>(idx_save_bytes());
-  launch_idx_stream(false, c.ts, idx_, st_, true, idx_save_);
+  launch_idx_stream(false, c.ts, idx_, strm(), true, idx_save_);
   // offsets = exclusive scan of the counts (one extra zero count behind the last slot: off[mask + 1] = the total)
-  HIP_CHECK(hipMemsetAsync(idx_.cnt + want * IDX_SHARDS, 0, 4, st_));
-  launch_exclusive_scan(idx_.cnt, want * IDX_SHARDS + 1, idx_.off, idx_scan_tmp_, d_counters_ + 56, st_);
-  HIP_CHECK(hipMemsetAsync(idx_.cnt, 0, want * IDX_SHARDS * 4, st_));  // the fill pass's cursors
+  HIP_CHECK(hipMemsetAsync(idx_.cnt + want * IDX_SHARDS, 0, 4, strm()));
+  launch_exclusive_scan(idx_.cnt, want * IDX_SHARDS + 1, idx_.off, idx_scan_tmp_, d_counters_ + 56, strm());
+  HIP_CHECK(hipMemsetAsync(idx_.cnt, 0, want * IDX_SHARDS * 4, strm()));  // the fill pass's cursors
   unsigned long long total = 0;
-  HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 56, 8, hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipMemcpyAsync(&total, d_counters_ + 56, 8, hipMemcpyDeviceToHost, strm()));
   sync();
   index_builds++;
   if (cfg_->trace.set) fprintf(stderr, "[yttm] index build at round %llu: %u listed pairs, %llu postings, %u tiles, last round touched %llu tiles\n", merge_rounds, listed, total, c.n_tiles, touched_last_);
@@ -117,7 +117,7 @@ void GpuCtx::build_index(uint32_t z_next) {
     post_cap_ = total + total / 4 + 1024;
     idx_.post = dmalloc<uint32_t>(post_cap_);
   }
-  launch_idx_stream(true, c.ts, idx_, st_, /*agg=*/total > idx_agg_min_, idx_save_);
+  launch_idx_stream(true, c.ts, idx_, strm(), /*agg=*/total > idx_agg_min_, idx_save_);
   t_end(KT_CAND, 8ull * c.n_tiles * c.nom);
   const unsigned long long stamps = c.n_unique;  // (a posting is a word, and a round claims words)
   if (stamps > stamp_cap_) {
@@ -125,9 +125,9 @@ void GpuCtx::build_index(uint32_t z_next) {
     stamp_cap_ = (unsigned int)(stamps + stamps / 8 + 64);
     d_stamp_ = dmalloc<uint32_t>(stamp_cap_);
   }
-  HIP_CHECK(hipMemsetAsync(d_stamp_, 0, (size_t)stamp_cap_ * 4, st_));
+  HIP_CHECK(hipMemsetAsync(d_stamp_, 0, (size_t)stamp_cap_ * 4, strm()));
   {  // every token that exists now is covered by the postings: the instance lists start over
-    HIP_CHECK(hipMemsetAsync(tl_.cursor, 0, 16, st_));
+    HIP_CHECK(hipMemsetAsync(tl_.cursor, 0, 16, strm()));
     sync();
     *(volatile unsigned int *)tl_.broken = 0;
   }

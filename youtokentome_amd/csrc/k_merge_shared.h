@@ -44,8 +44,10 @@ constexpr int BLK_BASE = 32, BLK_ROWS = 1536;  // >= the largest grid of k_filte
 __device__ inline void blk_add(unsigned long long *stats, int j, unsigned long long v) {
   // (the row is this workgroup's alone; the store is write-through because the round's tail may read it from another XCD before
   // any cache write-back -- see round_tail)
+  // (round 5: an atomic add, not load + store: two launches of a round may run side by side -- ScanArgs::peer_flag -- and share a row, and
+  // the tail of the round before may still be folding the rows; an atomic on a line nobody else touches costs what the write-through store did)
   unsigned long long *p = &stats[BLK_BASE + 8 * (blockIdx.x % BLK_ROWS) + j];
-  if (v) __hip_atomic_store(p, *p + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (v) atomicAdd(p, v);
 }
 // called by ONE workgroup of 256 threads, all threads; ends with the totals in stats[0..3] and *n_keys
 __device__ inline void fold_blk_stats(unsigned long long *stats, unsigned int *n_keys) {
@@ -149,6 +151,26 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
   unsigned long long *facc = reinterpret_cast<unsigned long long *>(lds + CAND_BINS + 40);  // [5] fold accumulators
   unsigned int *sub = lds + CAND_BINS + 64;   // [64] counts inside the boundary bin
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (sa.peer_flag) {
+    // The round's other launch (the class-B tiles, on a second stream) must be over: its last workgroup stores the round's number behind an
+    // agent-scope release.  It was submitted BEFORE this launch, so it runs whatever this workgroup does; the spin is bounded all the same
+    // -- a peer that never signals leaves the round unpublished, which the host reports (poll_mailbox), instead of a hung device.
+    if (tid == 0) {
+      unsigned int ok = 0;
+      for (unsigned int spins = 0; spins < (1u << 24); spins++) {
+        if (__hip_atomic_load(sa.peer_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == sa.round_id) { ok = 1; break; }
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_s_sleep(8);
+#endif
+      }
+      lh[0] = ok;
+    }
+    __syncthreads();
+    const unsigned int ok = lh[0];
+    __syncthreads();
+    if (!ok) return;
+    __threadfence();  // (acquire for every thread: nothing of the peer's is stale in this CU's caches)
+  }
   const unsigned long long tm0 = (unsigned long long)wall_clock64();
   for (int b = tid; b < CAND_BINS; b += NT) lh[b] = 0;
   if (tid < 68) sub[tid] = 0;
@@ -395,8 +417,9 @@ __device__ inline void scan_top(const PairTable &pt, const ScanArgs &sa, unsigne
         const int b = b0 + tid + r * NT;
 #pragma unroll
         for (int jj = 0; jj < 5; jj++) {
-          a[jj] += v[r][jj];
-          if (v[r][jj]) stats[BLK_BASE + 8 * b + jj] = 0;
+          // (taken by an exchange: the NEXT round's class-B launch may already be adding to the row -- gpu_ctx.cpp merge_apply puts it on a
+          // second stream without waiting for this kernel's end -- and what it adds after the exchange belongs to the next fold)
+          if (v[r][jj]) a[jj] += atomicExch(&stats[BLK_BASE + 8 * b + jj], 0ull);
         }
       }
     }

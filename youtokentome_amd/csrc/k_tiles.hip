@@ -283,7 +283,12 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     __syncthreads();
     if (threadIdx.x == 0) is_last = atomicAdd(sa.done_ctr, 1u) == gridDim.x - 1;
     __syncthreads();
-    if (is_last) {
+    if (is_last && sa.on == 4u) {  // beside another launch of the round, which has the tail: say that this one is over (ScanArgs::peer_flag)
+      if (threadIdx.x == 0) {
+        *sa.done_ctr = 0;
+        __hip_atomic_store(sa.peer_flag, sa.round_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else if (is_last) {
       __threadfence();  // (acquire: nothing stale in this CU's caches)
       static_assert(sizeof(WL) >= (CAND_BINS + 160) * sizeof(unsigned int), "tile buffers double as the tail's scratch");
       const RuleProbe zprobe{LDSR ? rkeys : nullptr, LDSR ? nullptr : rules, rule_mask};

@@ -88,7 +88,7 @@ struct BatchArgs {
 // statistics rows, zeroes the batch's pairs, scans (and compacts) the hot list and publishes header + histogram + candidates
 // in the host's pinned mailbox -- one launch per round instead of two, and no second trip through the launch path.
 struct ScanArgs {
-  uint32_t on;  // 0: no tail in this launch; 1: the candidate scan; 2 (multi-GPU, word mode): the last workgroup only leaves the worklist
+  uint32_t on;  // 0: no tail in this launch; 1: the candidate scan; 4: see peer_flag; 2 (multi-GPU, word mode): the last workgroup only leaves the worklist
                 // counters at zero -- the scan rides in the fold kernel behind the all-gather (k_fold_list); 3 (multi-GPU, set by
                 // launch_words_apply): a one-launch word round, which leaves no worklist behind -- no ticket, no tail
   uint32_t tau_mx;
@@ -100,6 +100,10 @@ struct ScanArgs {
   uint32_t round_id;           // published in the mailbox when everything else is there; 0: nothing is published
   uint32_t want;               // != 0: about this many candidates are wanted -- the scan may raise the threshold by itself (scan_top: refine)
   uint32_t timed;              // the round's first launch left its start time in stats[STAT_T0]: the mailbox gets the duration (100 MHz ticks)
+  // Two launches of one round side by side (single GPU, word mode: the class-B tiles on a second stream beside k_words; gpu_ctx.cpp merge_apply).
+  // on == 4: this launch is the one WITHOUT the tail -- its last workgroup (ticket: done_ctr, its own) stores round_id to *peer_flag;
+  // on == 1 with peer_flag != nullptr: the tail starts once *peer_flag == round_id (scan_top).
+  unsigned int *peer_flag;
 };
 constexpr int STAT_T0 = 6;  // stats[6]: wall_clock64() at the start of the round's first launch
 constexpr int STAT_T1 = 7;  // stats[7] (multi-GPU): ... when the round's apply kernels and the all-gather behind them were done (noted by the fold's first kernel)
