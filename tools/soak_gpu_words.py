@@ -1,7 +1,7 @@
 """GPU soak of K4's word mode: random corpora of tens of megabytes (thousands of workgroups: what the CPU emulator cannot show -- the ordering of the
 kernels' tickets and tails across XCDs) trained twice on the MI355X, with word mode under random switch rules / rare-path hooks and with the tiles to
 the end (YTTM_WORD_MODE=0: the path pinned against the reference); the two model files must be the same bytes.
-usage: python tools/soak_gpu_words.py [seconds] [seed]"""
+usage: python tools/soak_gpu_words.py [seconds] [seed] [kinds, e.g. cjk: long clauses -- class-B tiles beside k_words on a second stream]"""
 import ctypes as C, filecmp, json, os, random, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -28,7 +28,7 @@ def train(d, vocab, out, env):
 t0, n, wr, ar, fr = time.time(), 0, 0, 0, 0
 while time.time() - t0 < budget:
     mb = rng.choice([3, 8, 20, 40, 60])
-    kind = rng.choice(["abcd", "abcd", "ab", "zipf", "zipfbig", "cjk", "disjoint"])
+    kind = rng.choice(sys.argv[3].split(",") if len(sys.argv) > 3 else ["abcd", "abcd", "ab", "zipf", "zipfbig", "cjk", "disjoint"])
     seed = rng.randint(0, 10 ** 6)
     if kind == "abcd":
         text = gen.abcd_corpus(mb * 1_000_000, seed=seed, survey_stream=True)
