@@ -36,12 +36,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md) -- what `frac` is of
+HBM_COPY_GBS = 6290.0  # the measured float4-copy ceiling of the same guide ("report fraction of both") -- `frac_of_measured_copy`
 PINS = os.path.join(ROOT, "tests", "golden", "full_size_pins.json")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def both_fracs(r):
+    """A roofline object's `frac` (of the 8 TB/s spec) gets `frac_of_measured_copy` (of the 6.29 TB/s a copy kernel reaches) beside it."""
+    if isinstance(r, dict) and isinstance(r.get("achieved"), (int, float)):
+        r["frac_of_measured_copy"] = round(r["achieved"] / HBM_COPY_GBS, 4)
+        r["peak_measured_copy"] = HBM_COPY_GBS
+    return r
+
+
+def profile_for(tag, suffix):
+    """The newest profiles/rN_<tag>_<suffix> (N = round number) -- a file is only QUOTED when its `_meta.source_sha16` (or its sibling
+    PMC summary's) names this build's sources, see _static_traffic."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_%s_%s" % (tag, suffix))):
+        m = re.match(r"r(\d+)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
+def sources_sha():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_summary import source_sha16
+    return source_sha16(ROOT)
 
 
 def md5_file(path):
@@ -252,6 +280,8 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
         if bad:
             log("PARITY FAILURE:", bad)
+        # the LAST line of stderr (a driver that keeps only the tail of the log still shows which pins were checked and how they came out)
+        log("parity: " + json.dumps(out["parity"], sort_keys=True))
     if dist is not None:
         dist.destroy_process_group()
     if bad:
@@ -444,12 +474,21 @@ def _bench_train(ctx, corpus, size_mb, steps, warmup, measure_touched, keep_host
                         "word_mode_rounds": {"launches": wl, "ms_device_clock": round(wms, 3), "algorithmic_bytes_per_launch": round(bw / wl),
                                              "achieved_GBps": round(bw / 1e9 / (wms / 1e3), 1), "frac": round(bw / 1e9 / (wms / 1e3) / HBM_PEAK_GBS, 4)},
                         "note": "contract bytes 8*T_touched + 8*W_touched of the rounds before / from the word-mode switch (round %d), device-clock time of the timed steps" % sr}
+    if roofline is not None:
+        both_fracs(roofline)
+        for hv in (roofline.get("halves") or {}).values():
+            if isinstance(hv, dict) and "achieved_GBps" in hv:
+                hv["frac_of_measured_copy"] = round(hv["achieved_GBps"] / HBM_COPY_GBS, 4)
+        dk = _dominant_rocprof_kernel(corpus, size_mb, args, world, roofline)
+        if dk:
+            roofline["dominant_rocprof_kernel"] = dk
     roofline_pc = None
     if "pair_count" in kern:
         roofline_pc = {"kernel": "pair_count (K3)", "bound": "hbm", "achieved": kern["pair_count"]["GBps"], "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": round(kern["pair_count"]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic.get("pair_count"),
                        "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(kern["pair_count"]["algorithmic_GB"] * 1e9),
                        "avg_launch_ms": kern["pair_count"]["avg_ms"]}
+        both_fracs(roofline_pc)
     names = {"abcd": "random 'abcd ' corpus (BASELINE.json configs[1])", "zipf": "Zipf ASCII corpus, 400k-word lexicon (BASELINE.json configs[2])",
              "cjk": "CJK-shaped corpus (4096 ideographs, clauses without spaces)", "zipf4m": "Zipf ASCII corpus, 4e6-word lexicon, exponent 1.0 (enwik-like)"}
     cfg = {"workload": f"{size_mb} MB {names[corpus]}, vocab_size={args.vocab}"
@@ -569,7 +608,7 @@ def _static_traffic(kern, corpus, size_mb, args, world):
     runs of this same command; tools/pmc_summary.py).  STATIC: read from profiles/, not measured by this run."""
     traffic = {}
     tag = {"abcd": "1gb", "zipf": "zipf", "cjk": "cjk"}.get(corpus)
-    pmc_file = os.path.join(ROOT, "profiles", "r5_%s_pmc_hbm.json" % tag) if tag else None
+    pmc_file = profile_for(tag, "pmc_hbm.json") if tag else None
     if not pmc_file or not os.path.exists(pmc_file):
         return traffic, None
     if not (size_mb == 1000 and args.vocab == 32000 and world == 1):
@@ -602,6 +641,58 @@ def _static_traffic(kern, corpus, size_mb, args, world):
             total = sum(pm[k]["traffic_bytes_per_launch"] * pm[k]["launches"] for k in ks) / n_train
             traffic[name] = round(total / max(1, kern[name]["launches"]))
     return traffic, "static: bytes per launch from profiles/%s (rocprofv3 --pmc passes of this command, tools/profile_round.sh; a PMC pass cannot share a run with the timed region, so it is not re-measured here)" % os.path.basename(pmc_file)
+
+
+def _dominant_rocprof_kernel(corpus, size_mb, args, world, roofline):
+    """The kernel rocprofv3 ranks first among the training's kernels, BY NAME (`roofline.kernel = merge_apply` is a family of four
+    rocprof kernels), with its own bytes, time and fraction so that the figure can be checked against profiles/*_kernel_stats.csv without
+    arithmetic.  STATIC like `traffic`: calls and average duration come from the committed --kernel-trace --stats summary of this command
+    (quoted only when the PMC summary taken in the same profile_round.sh run names this build's sources); the bytes are this run's -- the
+    contract's 8*T_touched + 8*W_touched of the rounds that kernel serves (word-mode rounds for k_words, tile rounds for k_tiles)."""
+    import csv
+    tag = {"abcd": "1gb", "zipf": "zipf", "cjk": "cjk"}.get(corpus)
+    if not tag or not (size_mb == 1000 and args.vocab == 32000 and world == 1):
+        return None
+    stats, pmc = profile_for(tag, "kernel_stats.csv"), profile_for(tag, "pmc_hbm.json")
+    if not stats or not pmc or os.path.basename(stats).split("_")[0] != os.path.basename(pmc).split("_")[0]:
+        return None
+    try:
+        meta = (json.load(open(pmc)).get("_meta") or {})
+        if meta.get("source_sha16") != sources_sha():
+            return {"note": "none: profiles/%s is of sources %s, this build is %s -- re-run tools/profile_round.sh" % (os.path.basename(stats), meta.get("source_sha16"), sources_sha())}
+        rows = [r for r in csv.DictReader(open(stats)) if r.get("kernel")]
+    except Exception as e:  # noqa: BLE001
+        return {"note": "unreadable profile: %s" % e}
+    train = [r for r in rows if r["kernel"].startswith(("k_words<", "k_tiles<", "k_giant<", "k_delta_apply", "k_wgather", "k_idx_", "k_hot_", "k_top_", "k_cand_", "k_pair_count"))]
+    if not train:
+        return None
+    top = max(train, key=lambda r: float(r["total_ms"]))
+    n_train = max(1, sum(int(r["calls"]) for r in rows if r["kernel"].startswith("k_hist_compact")))
+    halves = roofline.get("halves") or {}
+    half = halves.get("word_mode_rounds") if top["kernel"].startswith("k_words<") else halves.get("tile_rounds") if top["kernel"].startswith("k_tiles<") else None
+    out = {"name": top["kernel"], "calls_per_training": round(int(top["calls"]) / n_train, 1), "avg_us": float(top["avg_us"]), "pct_of_gpu_time": float(top["pct"]),
+           "source": "profiles/%s (rocprofv3 --kernel-trace --stats of this command, %d trainings in the process)" % (os.path.basename(stats), n_train)}
+    if half:
+        b = half["algorithmic_bytes_per_launch"]
+        ach = b / 1e9 / (float(top["avg_us"]) / 1e6)
+        out.update({"algorithmic_bytes_per_launch": b, "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "frac_of_measured_copy": round(ach / HBM_COPY_GBS, 4),
+                    "bytes_definition": "8*T_touched + 8*W_touched of the rounds this kernel serves (this run's measurement pass) / their launches"})
+    return out
+
+
+def _encode_traffic(args, world, cached):
+    """HBM traffic of configs[3]'s encode kernels per batch from the committed PMC passes (profiles/rN_encode10m_pmc_hbm.json), quoted only
+    for this build's sources.  Sum over the kernels of the path that ran (word cache: insert, list, words, count, scatter; else k5_encode)."""
+    f = profile_for("encode10m", "pmc_hbm.json")
+    if not f or world != 1 or args.encode_sentences != 10_000_000:
+        return None, None
+    pm = json.load(open(f))
+    if (pm.get("_meta") or {}).get("source_sha16") != sources_sha():
+        return None, "none: profiles/%s is of other sources than this build" % os.path.basename(f)
+    names = ("k5w_", "k5_words", "k5_gather") if cached else ("k5_encode<false>", "k5_gather")
+    per = {k: v["traffic_bytes_per_launch"] for k, v in pm.items() if not k.startswith("_") and k.startswith(names)}
+    return (sum(per.values()) if per else None), "static: profiles/%s, per batch of 10^7 sentences: %s" % (os.path.basename(f), per)
 
 
 def _bench_encode(ctx, model_path, main_res):
@@ -672,6 +763,14 @@ def _bench_encode(ctx, model_path, main_res):
     res["encode"]["word_cache"] = {"distinct_words": words, "without_cache_sentences_per_s": direct["value"], "without_cache_kernel_ms": direct["kernel_ms"],
                                    "gain": round(res["encode"]["value"] / direct["value"], 3)}
     res["encode"]["roofline"]["kernel"] = "k5w_insert + k5_words (the distinct words) + k5w_count + k5w_scatter" if words else "k5_encode"
+    tr, src = _encode_traffic(args, world, bool(words))
+    res["encode"]["roofline"]["traffic"] = tr
+    res["encode"]["roofline"]["traffic_source"] = src
+    if tr:
+        res["encode"]["roofline"]["traffic_over_algorithmic"] = round(tr / res["encode"]["roofline"]["algorithmic_bytes_per_launch"], 2)
+    both_fracs(res["encode"]["roofline"])
+    both_fracs(res["dropout"]["roofline"])
+    res["dropout"]["compared"] = "distribution match on the first 1 000 000 of the 10 M sentences (the reference at n_threads=1 needs ~40 s per million); every sentence is encoded and timed"
     # ---- parity: FNV-1a-64 of (len, ids...) per sentence over ALL sentences vs the reference's (pinned) ---------------------
     ids = np.zeros(n_ids.value, dtype=np.int32)
     off = np.zeros(n_sent + 1, dtype=np.uint64)
@@ -861,6 +960,18 @@ def _cpu_baseline(ctx, host, zhost, model_path, out):
             res["gpu_hbm_resident_over_cpu"] = round(out["value_hbm_resident"] / res["value"], 1)
     except Exception as e:  # noqa: BLE001
         res["error"] = str(e)
+    det = os.path.join(ROOT, "oracle", "_ref", "yttm_ref_det")
+    if os.path.exists(det) and res.get("value"):  # "prod-oracle and det-oracle, same files, same box" -- the parity target's own time, one run
+        try:
+            prod_ref, ref, runs_saved = ref, det, runs
+            runs = 1
+            n, secs, _ = train(host, "cpu_c2_det")
+            res["det_oracle"] = {"value": round(n / 1e6 / secs, 2), "unit": "MB/s", "train_seconds": round(secs, 2), "cores": cores, "runs": 1,
+                                 "sample": "the same reference sources with -DDETERMINISTIC_QUEUE (oracle/_ref/yttm_ref_det: the build whose model is the parity target), same file, same flags"}
+        except Exception as e:  # noqa: BLE001
+            res["det_oracle"] = {"error": str(e)}
+        finally:
+            ref, runs = prod_ref, runs_saved
     if zhost is not None:
         try:
             n, secs, all_secs = train(zhost, "cpu_c3")

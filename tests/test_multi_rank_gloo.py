@@ -54,6 +54,30 @@ def test_two_ranks_equal_single_oracle(tmp_path, sim_lib, world):
         assert filecmp.cmp(m_mp, m_ora, shallow=False), f"case {i}"
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_node_sized_worlds_equal_single_oracle(tmp_path, sim_lib, world):
+    """The target machine is EIGHT GPUs (BASELINE.json north_star: 1/2/4/8); rounds 1 - 5 only ever ran worlds of 1 .. 3.  Four and
+    eight ranks here, one emulator process each: the sharded loop (per-round all-gather of delta blocks; the records after K3 through
+    comm_plan.h's offsets, seven peers' runs back to back), the replicated loop, word mode forced on, and a corpus so small that some ranks'
+    byte ranges hold no word at all (a rank without words still takes part in every collective): the oracle's model on the whole corpus."""
+    rng = random.Random(800 + world)
+    small = {"YTTM_WORDS_GRID": "2", "YTTM_WGATHER_GRID": "2", "YTTM_WORD_HINT_FLOOR": "256"}  # (the emulator's time goes with the workgroups; 8 processes share 8 cores)
+    force = dict(small, YTTM_WORD_MIN_TILES="0", YTTM_WORD_MIN_TOKENS="0", YTTM_WORD_DIV="0")
+    cases = [(gen.readme_corpus(160, 80, seed=12), 260, 1.0, {}, True, ""),
+             (gen.unicode_text(rng, 5000, "mix", p_invalid=0.01), 90, 0.9, {}, True, ""),
+             (gen.readme_corpus(160, 80, "abcde ", seed=13), 220, 1.0, force, True, "word_rounds>0"),
+             (gen.zipf_corpus(30000, vocab=500, seed=9), 260, 1.0, small, False, "replicated_merge_loop==1"),
+             (b"ab abab  \n\n   ba ab\n", 12, 1.0, {}, True, "")]  # (23 bytes over 4 / 8 ranks: most ranges are white space or empty)
+    for i, (text, vocab, cov, env, sharded, expect) in enumerate(cases):
+        corpus = str(tmp_path / f"c{i}.txt")
+        open(corpus, "wb").write(text)
+        m_mp, m_ora = str(tmp_path / f"mp{i}.model"), str(tmp_path / f"ora{i}.model")
+        # (a rank without class-A words follows the word-mode decision without switching: the report check is rank 0's, which always has words here)
+        run_world(corpus, m_mp, vocab, cov, world, sim_lib, dict(env, YTTM_TEST_EXPECT_RANK0=expect), sharded=sharded)
+        O.train(text, m_ora, vocab, cov)
+        assert filecmp.cmp(m_mp, m_ora, shallow=False), f"world {world} case {i}"
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_front_end_under_the_upload_on_every_rank(tmp_path, sim_lib, world):
     """Round 5: K1, K2a and the dedup run under the upload on EVERY rank of a multi-GPU run (each on its own byte range; the char histogram's

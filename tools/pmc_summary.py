@@ -41,9 +41,9 @@ def kernel_stats(d, out):
     f = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     with open(out, "w") as o:
-        o.write("kernel,calls,total_ms,avg_us,pct,min_us,max_us\n")
+        o.write("kernel,calls,total_ms,avg_us,pct,min_us,max_us\n")  # (names are quoted: template arguments hold commas)
         for r in rows:
-            o.write("%s,%s,%.3f,%.3f,%s,%.3f,%.3f\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+            o.write("\"%s\",%s,%.3f,%.3f,%s,%.3f,%.3f\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                       float(r["AverageNs"]) / 1e3, r["Percentage"], float(r["MinNs"]) / 1e3,
                                                       float(r["MaxNs"]) / 1e3))
 

@@ -270,6 +270,9 @@ struct yttm_ctx {
     return 2;                                        \
   }
 
+// the same with the context's own snapshot of the YTTM_* hooks bound to the calling thread (yttm_config.h CfgBind)
+#define GUARD_CTX(...) GUARD({ const CfgBind _bind(c && c->g ? c->g->config_ptr() : nullptr); __VA_ARGS__; })
+
 int yttm_gpu_ctx_create(int device, yttm_ctx **out) {
   *out = nullptr;
   GUARD({ *out = new yttm_ctx{new GpuCtx(device)}; })
@@ -279,12 +282,12 @@ void yttm_gpu_ctx_destroy(yttm_ctx *c) {
   delete c->g;
   delete c;
 }
-int yttm_gpu_ctx_set_comm(yttm_ctx *c, void *comm) { GUARD(c->g->set_comm((Comm *)comm)) }
-int yttm_gpu_upload_corpus(yttm_ctx *c, const uint8_t *utf8, uint64_t n) { GUARD(c->g->upload_corpus(utf8, n)) }
-int yttm_gpu_attach_corpus(yttm_ctx *c, const void *p, uint64_t n) { GUARD(c->g->attach_corpus(p, n)) }
+int yttm_gpu_ctx_set_comm(yttm_ctx *c, void *comm) { GUARD_CTX(c->g->set_comm((Comm *)comm)) }
+int yttm_gpu_upload_corpus(yttm_ctx *c, const uint8_t *utf8, uint64_t n) { GUARD_CTX(c->g->upload_corpus(utf8, n)) }
+int yttm_gpu_attach_corpus(yttm_ctx *c, const void *p, uint64_t n) { GUARD_CTX(c->g->attach_corpus(p, n)) }
 
 int yttm_gpu_char_hist(yttm_ctx *c, uint32_t *cps, uint64_t *cnts, uint32_t *n_inout, uint64_t *n_codepoints) {
-  GUARD({
+  GUARD_CTX({
     std::vector<uint32_t> a;
     std::vector<unsigned long long> b;
     unsigned long long steps = 0;
@@ -297,14 +300,14 @@ int yttm_gpu_char_hist(yttm_ctx *c, uint32_t *cps, uint64_t *cnts, uint32_t *n_i
 }
 int yttm_gpu_build_word_table(yttm_ctx *c, const uint32_t *cp, const uint32_t *id, uint32_t n_alpha, uint32_t space_id, uint32_t n_ids_cap,
                               uint64_t *n_unique, uint64_t *n_tokens) {
-  GUARD({
+  GUARD_CTX({
     c->g->build_word_table(cp, id, n_alpha, space_id, n_ids_cap);
     *n_unique = c->g->n_unique;
     *n_tokens = c->g->n_tokens0;
   })
 }
 int yttm_gpu_download_word_table(yttm_ctx *c, uint32_t *tok, uint64_t *off, uint32_t *cnt, uint64_t *n_tokens_now) {
-  GUARD({
+  GUARD_CTX({
     std::vector<uint32_t> t, w;
     std::vector<unsigned long long> o;
     c->g->download_word_table(t, o, w);
@@ -315,13 +318,13 @@ int yttm_gpu_download_word_table(yttm_ctx *c, uint32_t *tok, uint64_t *off, uint
   })
 }
 int yttm_gpu_pair_count(yttm_ctx *c, uint64_t *n_pairs) {
-  GUARD({
+  GUARD_CTX({
     c->g->pair_count();
     *n_pairs = c->g->n_keys_host;
   })
 }
 int yttm_gpu_download_pairs(yttm_ctx *c, uint64_t *pairs, uint64_t *counts, uint64_t *n_inout) {
-  GUARD({
+  GUARD_CTX({
     std::vector<unsigned long long> k, v;
     c->g->download_pairs(k, v);
     if (k.size() > *n_inout) throw GpuError{"download_pairs: output capacity too small"};
@@ -329,12 +332,12 @@ int yttm_gpu_download_pairs(yttm_ctx *c, uint64_t *pairs, uint64_t *counts, uint
     *n_inout = k.size();
   })
 }
-int yttm_gpu_merge_apply(yttm_ctx *c, const uint32_t *xyz, uint32_t k) { GUARD(c->g->merge_apply(xyz, k, nullptr)) }
+int yttm_gpu_merge_apply(yttm_ctx *c, const uint32_t *xyz, uint32_t k) { GUARD_CTX(c->g->merge_apply(xyz, k, nullptr)) }
 int yttm_gpu_pair_query(yttm_ctx *c, const uint64_t *pairs, uint32_t n, uint64_t *counts) {
-  GUARD(c->g->pair_query((const unsigned long long *)pairs, n, (unsigned long long *)counts))
+  GUARD_CTX(c->g->pair_query((const unsigned long long *)pairs, n, (unsigned long long *)counts))
 }
 int yttm_gpu_candidates(yttm_ctx *c, uint64_t tau_cnt, uint32_t tau_mx, uint64_t *pairs, uint64_t *counts, uint32_t *n_inout) {
-  GUARD({
+  GUARD_CTX({
     std::vector<CandRec> out;
     uint32_t n = c->g->candidates(tau_cnt, tau_mx, out, nullptr);
     uint32_t take = std::min<uint32_t>((uint32_t)out.size(), *n_inout);
@@ -344,7 +347,7 @@ int yttm_gpu_candidates(yttm_ctx *c, uint64_t tau_cnt, uint32_t tau_mx, uint64_t
 }
 
 int yttm_gpu_k4_measure(yttm_ctx *c, int on, uint64_t out[6]) {
-  GUARD({
+  GUARD_CTX({
     c->g->instrument = on != 0;
     if (out) {
       c->g->resolve_timers();

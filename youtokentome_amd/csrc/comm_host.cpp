@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/yttm_mi355x.h"
+#include "comm_plan.h"
 #include "gpu_ctx.h"
 #include "host_core.h"
 
@@ -33,26 +34,34 @@ struct CallbackComm : Comm {
   }
   bool allgather_recs(const DeltaRec *send, unsigned long long n_local, DeltaRec *recv, size_t cap, hipStream_t st, unsigned long long *need_all,
                       size_t *n_remote) override {
-    // counts first (8 bytes per rank), so that every rank takes the same branch
+    // counts first (8 bytes per rank), so that every rank takes the same branch; the callback hands back the OTHERS' strings in rank order:
+    // with this rank's own count put in its place they are the all-gathered count vector the RCCL transport has (comm_rccl.cpp)
     unsigned long long got = 0;
     gather_others(&n_local, 8, 8 * (size_t)world, &got);
-    unsigned long long all = n_local;
-    bool lost = n_local == ~0ull;
-    for (size_t k = 0; k < got / 8; k++) {
-      unsigned long long c;
-      memcpy(&c, h_recv.data() + 8 * k, 8);
-      if (c == ~0ull) lost = true;
-      all += c;
+    if (got != 8 * (size_t)(world - 1)) throw GpuError{"allgather callback returned the wrong number of counts"};
+    std::vector<unsigned long long> counts((size_t)world, 0);
+    for (int r = 0, k = 0; r < world; r++) {
+      if (r == rank) counts[(size_t)r] = n_local;
+      else memcpy(&counts[(size_t)r], h_recv.data() + 8 * (size_t)k++, 8);
     }
-    if (lost) { *need_all = ~0ull; return false; }
-    *need_all = all;
-    *n_remote = (size_t)(all - n_local);
-    if (all > cap) return false;
+    const RecsPlan plan = plan_allgather_recs(counts.data(), world, rank, cap);  // (comm_plan.h: the verdicts and offsets of the RCCL path)
+    *need_all = plan.all;
+    if (plan.lost) return false;
+    *n_remote = plan.n_remote;
+    if (!plan.fits) return false;
     h_send.resize((size_t)n_local * sizeof(DeltaRec) + 1);
     if (n_local) HIP_CHECK(hipMemcpyAsync(h_send.data(), send, (size_t)n_local * sizeof(DeltaRec), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (!gather_others(h_send.data(), (size_t)n_local * sizeof(DeltaRec), cap * sizeof(DeltaRec), &got)) throw GpuError{"allgather callback overflow"};
-    if (got) HIP_CHECK(hipMemcpyAsync(recv, h_recv.data(), (size_t)got, hipMemcpyHostToDevice, st));
+    if (got != plan.n_remote * sizeof(DeltaRec)) throw GpuError{"allgather callback returned the wrong number of records"};
+    // every peer's run to where the plan puts it (one copy per peer, like the RCCL path's one ncclRecv per peer)
+    size_t src = 0;
+    for (int r = 0; r < world; r++) {
+      const size_t c = plan.recv_cnt[(size_t)r];
+      if (r == rank || !c) continue;
+      HIP_CHECK(hipMemcpyAsync(recv + plan.recv_off[(size_t)r], h_recv.data() + src, c * sizeof(DeltaRec), hipMemcpyHostToDevice, st));
+      src += c * sizeof(DeltaRec);
+    }
     HIP_CHECK(hipStreamSynchronize(st));
     return true;
   }

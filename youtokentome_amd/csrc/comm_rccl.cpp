@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/yttm_mi355x.h"
+#include "comm_plan.h"
 #include "gpu_ctx.h"
 #include "host_core.h"
 
@@ -45,23 +46,16 @@ struct RcclComm : Comm {
     NCCL_CHECK(ncclAllGather(d_counts + rank, d_counts, 1, ncclUint64, comm, st));
     HIP_CHECK(hipMemcpyAsync(h_counts.data(), d_counts, 8 * (size_t)world, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    unsigned long long all = 0;
-    size_t others = 0;
-    for (int r = 0; r < world; r++) {
-      if (h_counts[r] == ~0ull) { *need_all = ~0ull; return false; }
-      all += h_counts[r];
-      if (r != rank) others += (size_t)h_counts[r];
-    }
-    *need_all = all;
-    *n_remote = others;
-    if (all > cap) return false;  // (the same verdict on every rank: `all` and the agreed capacity are)
+    const RecsPlan plan = plan_allgather_recs(h_counts.data(), world, rank, cap);  // (comm_plan.h: shared with the host transport the gloo tests drive)
+    *need_all = plan.all;
+    if (plan.lost) return false;
+    *n_remote = plan.n_remote;
+    if (!plan.fits) return false;  // (the same verdict on every rank: `all` and the agreed capacity are)
     NCCL_CHECK(ncclGroupStart());
-    size_t off = 0;
     for (int r = 0; r < world; r++) {
       if (r == rank) continue;
       if (n_local) NCCL_CHECK(ncclSend(send, n_local * 2, ncclUint64, r, comm, st));
-      if (h_counts[r]) NCCL_CHECK(ncclRecv(recv + off, (size_t)h_counts[r] * 2, ncclUint64, r, comm, st));
-      off += (size_t)h_counts[r];
+      if (plan.recv_cnt[(size_t)r]) NCCL_CHECK(ncclRecv(recv + plan.recv_off[(size_t)r], plan.recv_cnt[(size_t)r] * 2, ncclUint64, r, comm, st));
     }
     NCCL_CHECK(ncclGroupEnd());
     return true;

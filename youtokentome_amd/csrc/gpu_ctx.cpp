@@ -82,6 +82,8 @@ GpuCtx::~GpuCtx() {
   if (st_b_) (void)hipStreamSynchronize(st_b_);
   drop_spec();
   for (hipEvent_t e : all_events_) (void)hipEventDestroy(e);
+  if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  if (ev_join_) (void)hipEventDestroy(ev_join_);
   DFREE(d_text_owned_); DFREE(d_hist_); DFREE(d_chunk_segs_); DFREE(d_counters_); DFREE(d_cpmap_); DFREE(d_rules_);
   free_class(cls_[0]); free_class(cls_[1]); free_class(cls_[2]);
   DFREE(d_stats_); DFREE(d_round_); DFREE(d_recv_); DFREE(d_hot_slots_); DFREE(d_hot_n_); DFREE(d_top_slots_); DFREE(d_top_n_);
@@ -100,6 +102,13 @@ GpuCtx::~GpuCtx() {
 }
 
 void GpuCtx::sync() { HIP_CHECK(hipStreamSynchronize(strm())); }
+void GpuCtx::join_class_b() {
+  if (!classb_unjoined_ || !st_b_) return;
+  if (!ev_join_) HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(ev_join_, st_b_));
+  HIP_CHECK(hipStreamWaitEvent(strm(), ev_join_, 0));
+  classb_unjoined_ = false;
+}
 void GpuCtx::read_stats(int first, int n, unsigned long long *out) {
   HIP_CHECK(hipMemcpyAsync(out, d_stats_ + first, (size_t)n * 8, hipMemcpyDeviceToHost, strm()));
   sync();
@@ -379,11 +388,17 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     if (!cls_[ci].n_tiles) continue;
     if (ci == 1 && beside) {
       bool st_clean = !st_touched_;
-      if (!st_b_) {
+      if (!st_b_) {  // first class-B launch beside k_words of this context: the second stream, the fork event, the flag block -- each once
         st_b_ = pool_take_stream(device_);
-        HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        d_bsync_ = dmalloc<unsigned int>(4);
-        HIP_CHECK(hipMemsetAsync(d_bsync_, 0, 16, strm()));
+        // (the pool holds a stream only if a finished context gave one back: never the legacy NULL stream -- it would serialise with the
+        // embedding application's default-stream work and the tail's bounded spin on peer_flag could run out)
+        if (!st_b_) HIP_CHECK(hipStreamCreateWithFlags(&st_b_, hipStreamNonBlocking));
+        if (!ev_fork_)
+          HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));  // (destroyed by ~GpuCtx: not one of the pooled timing events)
+        if (!d_bsync_) {
+          d_bsync_ = dmalloc<unsigned int>(4);
+          HIP_CHECK(hipMemsetAsync(d_bsync_, 0, 16, strm()));
+        }
         st_clean = false;
       }
       if (!st_clean) {
@@ -399,8 +414,10 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       launch_merge_apply(1, cls_[1].ts, kpt, db_, d_rules_, cap - 1, self_x, self_z, z_base, d_stats_, &tba, &sb, d_bloom_, st_b_);
       sa.peer_flag = d_bsync_ + 1;
       classb_overlapped++;
+      classb_unjoined_ = true;
       continue;
     }
+    if (ci == 1) join_class_b();  // (class B on the main stream again behind rounds that ran it beside)
     if (ci == 0 && word_mode_) {
       // the batch's rules -> worklist of words (k_wgather; it also allots the new tokens' instance lists), then the words (k_words)
       WordClass &c = cls_[0];

@@ -118,6 +118,7 @@ class GpuCtx {
   Comm *comm() const { return comm_; }
   int device() const { return device_; }
   const Config &config() const { return *cfg_; }  // the YTTM_* hooks as they stood when this context was made (yttm_config.h)
+  std::shared_ptr<const Config> config_ptr() const { return cfg_; }  // (for CfgBind: the launchers' tuning hooks read cfg() on the calling thread)
   hipStream_t stream() const { return st_raw_; }
 
   unsigned long long n_unique = 0, n_tokens0 = 0, n_segments = 0, corpus_bytes = 0;
@@ -178,7 +179,13 @@ class GpuCtx {
   // word mode, single GPU: the class-B tiles' launch of a round runs on a second stream beside k_words (merge_apply; ScanArgs::peer_flag)
   bool classb_overlap_ = true;       // YTTM_NO_CLASSB_OVERLAP
   hipStream_t st_b_ = nullptr;
-  hipEvent_t ev_fork_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  // A class-B launch on st_b_ is joined with the main stream by the tail's wait for peer_flag: that orders what the TAIL reads (atomics,
+  // write-through stores).  The tiles' plain in-place token rewrites are only guaranteed visible at that kernel's END, and nothing on the main
+  // stream depends on its end -- so before the main stream next touches class-B tiles itself (a repack, a class-B launch that is not beside,
+  // a download) it waits for an event recorded behind the last beside-launch.  Off the common path: a beside-round never calls it.
+  bool classb_unjoined_ = false;
+  void join_class_b();
   unsigned int *d_bsync_ = nullptr;  // [0] the class-B launch's ticket, [1] the round it has finished
   uint32_t id_min_ = 0, id_max_ = 0;  // id range of the alphabet (K3)
   uint32_t max_id_ = 0xffffffffu;  // largest token id in the tiles (unknown until the word table is built)

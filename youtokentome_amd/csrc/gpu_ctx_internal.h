@@ -56,6 +56,18 @@ static T *dmalloc(size_t n) {
     p = nullptr;            \
   } while (0)
 
+// Pool blocks a function holds in local raw pointers: whatever is still non-null when the scope is left -- by return or by a throw -- goes back
+// to the pool (DFREE nulls what it frees; a block handed on to a member is nulled by hand).  Declare it BEFORE anything whose destructor must
+// run while the blocks are still alive (destruction is in reverse order).
+struct DevScope {
+  std::vector<void **> held;
+  template <class T> void hold(T *&p) { held.push_back((void **)&p); }
+  ~DevScope() {
+    for (void **pp : held)
+      if (*pp) { pool_free(*pp); *pp = nullptr; }
+  }
+};
+
 
 constexpr unsigned int CAND_CAP = 1u << 20;
 constexpr unsigned int HOT_CAP = 1u << 18;  // hot-list slots (entries appended between rebuilds included)

@@ -312,6 +312,7 @@ void GpuCtx::build_class(int ci, unsigned long long *uw_pos, uint32_t *uw_len, u
 void GpuCtx::download_word_table(std::vector<uint32_t> &tok, std::vector<unsigned long long> &off, std::vector<uint32_t> &cnt) {
   tok.clear(); off.clear(); cnt.clear();
   off.push_back(0);
+  join_class_b();
   for (int ci = 0; ci < 3; ci++) {
     WordClass &c = cls_[ci];
     if (!c.n_tiles) continue;
@@ -363,6 +364,7 @@ void GpuCtx::maybe_repack(int ci) {
   }
   repack_looks++;
   chain_event_ = nullptr;  // work between two timed intervals: they no longer share an event
+  if (ci == 1) join_class_b();  // (the look reads the tiles' lengths, the repack their tokens: behind the END of the last class-B launch on the second stream)
   unsigned long long *off = dmalloc<unsigned long long>(c.n_tiles);
   unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(c.n_tiles));
   launch_exclusive_scan(c.d_tile_len, c.n_tiles, off, scan_tmp, d_counters_ + 48, strm());

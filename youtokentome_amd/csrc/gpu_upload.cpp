@@ -569,7 +569,14 @@ void GpuCtx::front_end_chunked(bool first_pass) {
   d_text_ = B;
   const unsigned long long sub = std::min<unsigned long long>(std::max<unsigned long long>(C / 16, 256), 4ull << 20);  // segments per K2b launch
   unsigned long long cap = pow2_at_least(std::max<unsigned long long>(4 * sub, 1024));
-  unsigned long long *ht = dmalloc<unsigned long long>(3 * cap);
+  // every block this function holds in a local: freed when it is left by a throw as well (a caller that catches the error and retries -- the C
+  // ABI's guarded() -- must not lose up to a chunk of HBM per attempt); `landing` outlives the uploader's future (Landed, declared below)
+  unsigned long long *ht = nullptr, *nht = nullptr, *d_seg = nullptr, *d_chunk_off = nullptr, *scan_tmp = nullptr, *scratch_hist = nullptr;
+  uint32_t *d_map_spec = nullptr;
+  uint8_t *landing = nullptr;
+  DevScope scope;
+  scope.hold(ht); scope.hold(nht); scope.hold(d_seg); scope.hold(d_chunk_off); scope.hold(scan_tmp); scope.hold(scratch_hist); scope.hold(d_map_spec); scope.hold(landing);
+  ht = dmalloc<unsigned long long>(3 * cap);
   launch_word_table_clear(ht, cap, strm());
   unsigned int *d_status = (unsigned int *)(d_counters_ + 24);
   HIP_CHECK(hipMemsetAsync(d_status, 0, 32, strm()));
@@ -590,7 +597,7 @@ void GpuCtx::front_end_chunked(bool first_pass) {
     wide_chars = wide * 100u > 4u * 4096u;
   }
   if (cfg_->k1_wide.set) wide_chars = cfg_->k1_wide.i != 0;
-  unsigned long long *hist = nullptr, *counters = nullptr, *scratch_hist = nullptr;
+  unsigned long long *hist = nullptr, *counters = nullptr;
   if (first_pass) {
     if (!d_hist_) d_hist_ = dmalloc<unsigned long long>(N_CODEPOINTS);
     HIP_CHECK(hipMemsetAsync(d_hist_, 0, (size_t)N_CODEPOINTS * 8, strm()));
@@ -604,7 +611,6 @@ void GpuCtx::front_end_chunked(bool first_pass) {
     counters = scratch_hist + N_CODEPOINTS;
   }
   // the char map words are compared by: code points (first pass) or the alphabet's ids
-  uint32_t *d_map_spec = nullptr;
   const uint32_t *d_map = d_cpmap_;
   if (first_pass) {
     std::vector<uint32_t> ident(N_CODEPOINTS);
@@ -618,15 +624,15 @@ void GpuCtx::front_end_chunked(bool first_pass) {
   const unsigned long long nch_max = fe_chunks(C) + 2;
   DFREE(d_chunk_segs_);
   d_chunk_segs_ = dmalloc<uint32_t>(nch_max);
-  unsigned long long *d_chunk_off = dmalloc<unsigned long long>(nch_max);
-  unsigned long long *scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(nch_max));
+  d_chunk_off = dmalloc<unsigned long long>(nch_max);
+  scan_tmp = dmalloc<unsigned long long>(scan_scratch_blocks(nch_max));
   unsigned long long segs_total = 0, n_unique_host = 0;
   unsigned int h_status[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const auto t0 = std::chrono::steady_clock::now();
   // The link and the kernels at once: chunk k + 1 crosses the link into a landing buffer of its own while the kernels work on chunk k in
   // the region; a device-to-device copy (C bytes at HBM's rate: 0.3 ms per 512 MB) then moves it over.  Two regions the kernels alternate
   // between would save that copy and cost every offset in the word table a region base; the copy is 1 % of a chunk's upload.
-  uint8_t *landing = n_chunks > 1 && !cfg_->fe_chunk_serial.set ? dmalloc<uint8_t>(C) : nullptr;
+  landing = n_chunks > 1 && !cfg_->fe_chunk_serial.set ? dmalloc<uint8_t>(C) : nullptr;
   auto upload = [&](size_t ck, uint8_t *dst) {
     const unsigned long long b0 = cuts[ck], len = cuts[ck + 1] - b0;
     if (len) staged_transfer(device_, dst, len, true, [&fill, b0](void *d, unsigned long long off, size_t l) { return fill(d, b0 + off, l); });
@@ -661,7 +667,7 @@ void GpuCtx::front_end_chunked(bool first_pass) {
     unsigned long long n_p = 0;
     HIP_CHECK(hipMemcpyAsync(&n_p, d_counters_ + 16, 8, hipMemcpyDeviceToHost, strm()));
     sync();
-    unsigned long long *d_seg = dmalloc<unsigned long long>(std::max<unsigned long long>(n_p, 1));
+    d_seg = dmalloc<unsigned long long>(std::max<unsigned long long>(n_p, 1));
     launch_seg_write(B, len, d_seg, d_chunk_off, strm());
     t_end(KT_SEGS, len + 8 * n_p);
     segs_total += n_p;
@@ -672,12 +678,13 @@ void GpuCtx::front_end_chunked(bool first_pass) {
       if (2 * (n_unique_host + cnt) > cap) {
         unsigned long long ncap = cap;
         while (2 * (n_unique_host + cnt) > ncap / 2) ncap <<= 1;  // (a quarter full at most after this launch: growth is rare)
-        unsigned long long *nht = dmalloc<unsigned long long>(3 * ncap);
+        nht = dmalloc<unsigned long long>(3 * ncap);
         launch_word_table_clear(nht, ncap, strm());
         launch_word_table_rehash(B, extent, d_map, ht, cap, nht, ncap, strm());
         sync();
         DFREE(ht);
         ht = nht;
+        nht = nullptr;
         cap = ncap;
         word_table_retries++;
       }
@@ -729,6 +736,7 @@ void GpuCtx::front_end_chunked(bool first_pass) {
   spec_.words_done = true;
   spec_.n_segs = segs_total;
   spec_.ht = ht;
+  ht = nullptr;  // (handed on: no longer this scope's to free)
   spec_.ht_cap = cap;
   spec_.long_segments = true;  // (the table's fill is what the growth rule above made it: no second guess in build_word_table)
   memcpy(spec_.h_status, h_status, sizeof h_status);

@@ -167,6 +167,7 @@ void encode_and_format(const BaseEncoder &enc, Batch &b, bool subword, bool bos,
 Status BaseEncoder::encode_cli(const std::string &output_type_str, bool stream, bool bos, bool eos, bool reverse, double dropout_prob, int in_fd,
                                int out_fd) const {
   const bool subword = output_type_str != "id";  // the reference asserts "subword" otherwise (bpe.cpp:1949)
+  const CfgBind bind(config());  // (the workers below call encode_as_ids / encode_as_subwords, which bind it on their own threads)
   LineReader in(in_fd);
   if (stream) {  // bpe.cpp:1952-1974
     Batch b;

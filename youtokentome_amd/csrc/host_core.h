@@ -4,6 +4,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -87,6 +88,7 @@ Status train_bpe_from_device(const void *d_text, unsigned long long n, const std
 Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const BpeConfig &cfg, BPEState *state, TrainReport *report);
 
 struct EncoderDevice;  // HBM-resident model tables for K5
+struct Config;         // yttm_config.h
 
 class BaseEncoder {  // bpe.h:22-82
  public:
@@ -112,6 +114,9 @@ class BaseEncoder {  // bpe.h:22-82
                        unsigned long long max_sentence_bytes, bool bos, bool eos, bool reverse, double dropout_prob,
                        unsigned long long *n_ids_out, double *kernel_ms) const;
   Status fetch_device_result(int32_t *ids, unsigned long long *out_off, unsigned long long n_sent) const;
+  // the YTTM_* hooks as they stood when THIS encoder was made: every entry point binds them to its thread (yttm_config.h CfgBind), so that a
+  // later encoder or training never changes the paths of this one
+  std::shared_ptr<const Config> config() const;
   void set_cache(int mode, unsigned long long min_bytes) const;  // word cache of the batch encoder: 0 off, 1 always, 2 from min_bytes up
   unsigned long long cache_words() const;                          // distinct words of the last encode_device batch (0: not cached)
 

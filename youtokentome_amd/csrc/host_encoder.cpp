@@ -83,6 +83,7 @@ struct EncoderDevice {
   unsigned long long *d_rule_xy = nullptr;
   uint32_t *d_bloom = nullptr;
   EncModel m{};
+  std::shared_ptr<const Config> cfg;  // the hooks as they stood at creation (BaseEncoder::config)
   // BPE-dropout draws: counter-based, seeded per call from a per-encoder random salt (the reference draws from a
   // std::random_device-independent global mt19937, bpe.cpp:1415; YTTM_DROPOUT_SEED pins the salt for reproducible runs)
   std::atomic<unsigned long long> dropout_calls{0};
@@ -125,8 +126,9 @@ BaseEncoder::BaseEncoder(const std::string &model_path, int _n_threads, Status *
       l.d_total = dalloc<unsigned long long>(2);
       l.d_wc_misc = dalloc<unsigned int>(2);
     }
-    cfg_refresh();  // the environment hooks are read here, once per encoder (yttm_config.h)
+    cfg_refresh();  // the environment hooks are read here, once per encoder (yttm_config.h) ...
     const std::shared_ptr<const Config> C = cfg();
+    dev_->cfg = C;  // ... and kept: the entry points below bind this snapshot, not whatever a later refresh made the process-wide one
     if (C->encode_cache.set) dev_->cache_mode = C->encode_cache.i ? 1 : 0;
     if (C->encode_cache_min_mb.set) dev_->cache_min_bytes = C->encode_cache_min_mb.u << 20;
     if (C->dropout_seed.set) {
@@ -477,11 +479,13 @@ Status BaseEncoder::encode_device(const void *d_bytes, const void *d_offsets, un
                                   unsigned long long max_sentence_bytes, bool bos, bool eos, bool reverse, double dropout_prob,
                                   unsigned long long *n_ids_out, double *kernel_ms) const {
   if (!dev_) return Status(2, "encoder has no device state");
+  const CfgBind bind(dev_->cfg);
   std::lock_guard<std::mutex> lk(dev_->lane[0].mu);
   return encode_on_lane(*this, *dev_, dev_->lane[0], device_, d_bytes, d_offsets, n_sent, total_bytes, max_sentence_bytes, bos, eos, reverse,
                         dropout_prob, n_ids_out, kernel_ms);
 }
 
+std::shared_ptr<const Config> BaseEncoder::config() const { return dev_ ? dev_->cfg : nullptr; }
 void BaseEncoder::set_cache(int mode, unsigned long long min_bytes) const {
   if (!dev_) return;
   dev_->cache_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
@@ -494,6 +498,7 @@ unsigned long long BaseEncoder::cache_words() const {
 
 Status BaseEncoder::fetch_device_result(int32_t *ids, unsigned long long *out_off, unsigned long long n_sent) const {
   if (!dev_) return Status(2, "fetch_device_result: no matching result");
+  const CfgBind bind(dev_->cfg);
   std::lock_guard<std::mutex> lk(dev_->lane[0].mu);
   if (n_sent != dev_->lane[0].last_n_sent) return Status(2, "fetch_device_result: no matching result");
   return fetch_lane(dev_->lane[0], device_, ids, out_off, n_sent);
@@ -569,6 +574,7 @@ Status BaseEncoder::encode_as_ids(const uint8_t *bytes, const unsigned long long
                                   bool reverse, double dropout_prob, std::vector<int32_t> *ids, std::vector<unsigned long long> *out_off) const {
   ids->clear();
   out_off->clear();
+  const CfgBind bind(config());
   return encode_host_to_host(
       *this, dev_, device_, bytes, offsets, n_sent, bos, eos, reverse, dropout_prob,
       [&](size_t n) { ids->resize(n); return ids->data(); }, [&](size_t n) { out_off->assign(n, 0); return out_off->data(); });
@@ -650,6 +656,7 @@ static bool encode_pipelined(const BaseEncoder &enc, EncoderDevice *dev, int dev
     return failed;
   };
   std::thread up([&] {
+    const CfgBind bind(C);  // (the caller's snapshot: this thread's copies read the hooks too)
     try {
       HIP_CHECK(hipSetDevice(device));
       for (size_t i = 0; i < K; i++) {
@@ -684,6 +691,7 @@ static bool encode_pipelined(const BaseEncoder &enc, EncoderDevice *dev, int dev
     }
   });
   std::thread down([&] {
+    const CfgBind bind(C);
     try {
       HIP_CHECK(hipSetDevice(device));
       unsigned long long ids_base = 0;
@@ -754,6 +762,7 @@ Status BaseEncoder::encode_as_ids_malloc(const uint8_t *bytes, const unsigned lo
                                          bool reverse, double dropout_prob, int32_t **ids, unsigned long long **out_off) const {
   *ids = nullptr;
   *out_off = nullptr;
+  const CfgBind bind(config());
   if (dev_ && n_sent && !(bos && bpe_state.special_tokens.bos_id == -1) && !(eos && bpe_state.special_tokens.eos_id == -1)) {
     Status piped;
     if (encode_pipelined(*this, dev_, device_, bytes, offsets, n_sent, bos, eos, reverse, dropout_prob, ids, out_off, &piped)) return piped;
@@ -776,6 +785,7 @@ Status BaseEncoder::encode_as_subwords(const uint8_t *bytes, const unsigned long
                                        std::vector<unsigned long long> *piece_off) const {
   // ids come from the GPU (forward order, no bos/eos); pieces are a host lookup (bpe.cpp:1597-1613).  The k-th unk id
   // of a sentence is the k-th run of unknown chars, whose text is recovered from the sentence itself.
+  const CfgBind bind(config());
   if (bos && bpe_state.special_tokens.bos_id == -1) return Status(1, "Can't add <BOS> token. Model was trained without it.");
   if (eos && bpe_state.special_tokens.eos_id == -1) return Status(1, "Can't add <EOS> token. Model was trained without it.");
   std::vector<int32_t> ids;

@@ -439,6 +439,7 @@ Status train_bpe_from_device(const void *d_text, unsigned long long n, const std
   if (!st.ok()) return st;
   return guarded([&]() {
     GpuCtx g(device);
+    const CfgBind bind(g.config_ptr());  // (the launchers' own hook reads see this training's snapshot whatever another thread refreshes)
     g.profile = profile && !g.config().no_profile.set;  // (tuning hook: what do the timing events themselves cost?)
     g.instrument = profile == 2;
     if (g.instrument && g.config().measure_split_round.set) g.split_round = g.config().measure_split_round.u;
@@ -454,6 +455,7 @@ Status train_bpe_from_memory(const uint8_t *text, unsigned long long n, const st
   if (!st.ok()) return st;
   return guarded([&]() {
     GpuCtx g(device);
+    const CfgBind bind(g.config_ptr());  // (the launchers' own hook reads see this training's snapshot whatever another thread refreshes)
     g.set_comm(comm);
     g.upload_corpus(text, n);
     return learn_bpe(g, vocab_size, model_path, cfg, nullptr, report);
@@ -496,6 +498,7 @@ Status train_bpe(const std::string &input_path, const std::string &model_path, i
   double s_ctor = 0, s_body = 0;
   Status r = guarded([&]() {
     GpuCtx g(device);
+    const CfgBind bind(g.config_ptr());  // (the launchers' own hook reads see this training's snapshot whatever another thread refreshes)
     s_ctor = since(t_call);
     g.profile = profile && !g.config().no_profile.set;
     g.set_comm(comm);

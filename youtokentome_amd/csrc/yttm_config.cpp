@@ -30,9 +30,21 @@ std::shared_ptr<const Config> make() {
   return c;
 }
 
+thread_local std::shared_ptr<const Config> tl_bound;
+
 }  // namespace
 
+CfgBind::CfgBind(std::shared_ptr<const Config> c) : bound_(c != nullptr) {
+  if (!bound_) return;
+  prev_ = std::move(tl_bound);
+  tl_bound = std::move(c);
+}
+CfgBind::~CfgBind() {
+  if (bound_) tl_bound = std::move(prev_);
+}
+
 std::shared_ptr<const Config> cfg() {
+  if (tl_bound) return tl_bound;
   std::lock_guard<std::mutex> g(g_mu);
   if (!g_cfg) g_cfg = make();
   return g_cfg;

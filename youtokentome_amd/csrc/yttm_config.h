@@ -118,10 +118,25 @@ struct Config {
 #undef X
 };
 
-// the snapshot taken by the last cfg_refresh() (the first call takes one itself)
+// The snapshot the calling thread is BOUND to (CfgBind: an encoder's or a context's own, for the length of a call into it), else the one
+// taken by the last cfg_refresh() (the first call takes one itself).
 std::shared_ptr<const Config> cfg();
-// re-reads the environment: GpuCtx's constructor, encoder creation, the CLI loops
+// re-reads the environment into a new process-wide snapshot: GpuCtx's constructor, encoder creation.  Objects keep the shared_ptr they took
+// then; a later refresh -- another encoder, a training on another thread -- never changes the hooks of an object that already exists.
 void cfg_refresh();
+// Binds a snapshot to the calling thread for a scope (nests; a null pointer binds nothing).  Every entry point of BaseEncoder and of the
+// trainer binds its object's snapshot, so that the launchers deep below (k_encode.hip, k_wcache.hip, ...) read THAT one through cfg().
+// Threads started inside such a call bind the same snapshot themselves.
+struct CfgBind {
+  explicit CfgBind(std::shared_ptr<const Config> c);
+  ~CfgBind();
+  CfgBind(const CfgBind &) = delete;
+  CfgBind &operator=(const CfgBind &) = delete;
+
+ private:
+  std::shared_ptr<const Config> prev_;
+  bool bound_;
+};
 // the table above as Markdown rows "| `NAME` | default | kind | what |" 
 const char *config_table_markdown();
 
