@@ -137,8 +137,9 @@ __global__ __launch_bounds__(WG_NT) void k_wgather(WGatherArgs g, BatchArgs ba) 
       if (mode == 0) {
         w = ix.post[at];
       } else {
-        match = (mode == 1 ? g.tl.rec_l[at] : g.tl.rec_r[at]) == s_filt[a];
-        if (match) w = g.tl.rec_word[at];
+        const uint32_t nb = mode == 1 ? g.tl.rec_l[at] : g.tl.rec_r[at], ww = g.tl.rec_word[at];  // (both loads in flight together)
+        match = nb == s_filt[a];
+        w = ww;
       }
       if (match) {
         atomicAdd(&s_cnt[a], 1u);
@@ -425,9 +426,10 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
         if (mode == 0) {
           cw[it] = g.ix.post[at];
           cok[it] = true;
-        } else {
-          cok[it] = (mode == 1 ? g.tl.rec_l[at] : g.tl.rec_r[at]) == f_filt[a];
-          if (cok[it]) cw[it] = g.tl.rec_word[at];
+        } else {  // (the record's word is loaded WITH its neighbour, not behind the comparison: one dependent trip less per pass)
+          const uint32_t nb = mode == 1 ? g.tl.rec_l[at] : g.tl.rec_r[at], ww = g.tl.rec_word[at];
+          cok[it] = nb == f_filt[a];
+          cw[it] = ww;
         }
       }
     }
