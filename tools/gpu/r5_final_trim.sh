@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, after a change of the kernels late in the round: the evidence that names the build (GPU suite with the full-size pins, configs[1] with its
-# PMC passes and the default bench line, the CJK-shaped corpus' kernel stats and PMC passes) -- tools/gpu/r5_final.sh without the blocks that do not
+# PMC passes and the default bench line, the CJK-shaped corpus' kernel stats and PMC passes) -- (round 5's full script, r5_final.sh, is gone) without the blocks that do not
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out profiles
 export TMPDIR=/tmp

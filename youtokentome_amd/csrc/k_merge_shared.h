@@ -124,6 +124,38 @@ __device__ inline int cand_bin(unsigned long long c) {
 }
 
 
+// ---- ORDERING OF A FUSED TAIL (the memory-model argument; gfx950).  Sites: k_tiles.hip (tile rounds), k_words.hip (k_words<FUSED>, k_delta_apply,
+// k_wgather's allotment), k_pairtable.hip (k_fold_list, k_hot_scan).  tests/test_gpu_parity.py::test_zz_fused_tail_ordering backs it, it does not replace it.
+// The hand-off.  Workgroups P (any CU, any XCD) update the pair table, the hot / top lists' slots and lengths, their statistics row and (multi-GPU)
+// the send block; the LAST workgroup C of the same launch then reads all of that (scan_top).  Nothing orders P and C but what is written here.
+// Hardware facts relied on (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): (F1) per-XCD L2s are not
+// coherent for plain accesses and a CU's vector L1 is never refreshed by another CU's stores; (F2) an agent-scope atomic RMW and an `sc1`
+// (write-through, __hip_atomic_store relaxed/agent) store leave the issuing XCD's L2 -- they are performed where every XCD sees them -- and count
+// in the wave's vmcnt until acknowledged; (F3) an agent-scope atomic load (`sc1`) bypasses the reader's L1; "`sc1` payload -> s_waitcnt vmcnt(0)
+// -> flag" with `sc1` loads (or an agent acquire) on the consumer is one of the guide's valid cross-CU hand-offs; (F4) a workgroup-scope fence
+// is nothing another CU can observe, an agent-scope RELEASE writes the whole XCD L2 back (1.7 - 6.5 us each: +150 us per round at 768 workgroups).
+// Producer side, every workgroup of the launch:
+//   P1  every store C may read is an atomic RMW (pt_add, list appends, blk_add, dt_add) or an `sc1` store -- never a plain store.  (Plain stores
+//       exist, into data C does NOT read in this launch: token tiles, wmeta, record regions read back by the writer itself; the kernel boundary
+//       orders those for the next launch.)
+//   P2  each wave executes `s_waitcnt vmcnt(0)` (asm volatile: the compiler may drop the wait of a fence it believes has nothing to wait for), so by
+//       F2 all of P1 is performed; __builtin_amdgcn_fence(release, "workgroup") keeps the compiler from sinking stores below; __syncthreads()
+//       joins the waves; THEN one lane takes the ticket, atomicAdd(done_ctr) -- agent scope, performed after everything before it in program order
+//       because the wave waited for vmcnt(0) first.  No agent-scope release: there is nothing dirty in L2 that C reads (P1), see F4.
+// Consumer side, the workgroup whose ticket is gridDim.x - 1:
+//   C1  the ticket values form one modification order on one address, so every other workgroup's P1 + P2 happened before C's RMW returned;
+//   C2  __threadfence() (agent acq_rel: buffer_inv sc1) drops this CU's L1 lines, which may predate the producers' updates (F1); then
+//       __syncthreads() before any thread reads;
+//   C3  everything C reads of P1 is read with agent-scope atomic loads (ld_agent, __hip_atomic_load relaxed/agent): F3.  Plain loads in the tail
+//       touch only kernel arguments, LDS and data no workgroup of this launch wrote.
+// Two launches of one round side by side (class-B tiles on a second stream, ScanArgs::peer_flag): the peer's last workgroup -- after the same P1/P2
+// and its own ticket -- stores the round's number with an agent-scope RELEASE store; C polls it with agent-scope ACQUIRE loads (bounded) before C2.
+// The peer's plain tile stores are NOT covered by that; they are ordered for later launches by an event the host records on the second stream and
+// waits for before the main stream touches class-B tiles again (gpu_ctx.cpp).
+// Towards the host: candidates, histogram and header are plain stores into pinned host memory, then __threadfence_system() + __syncthreads(),
+// then ONE system-scope release store of the round id; the host spins on that word and issues an acquire fence before reading the rest.
+// After the publish C folds the statistics rows with atomic exchanges (the NEXT round's class-B launch may already be adding to them).
+//
 // The candidate scan of a merge round: ONE workgroup reads the top list (PairTable::top_slots, about a thousand entries).
 // Run by the LAST workgroup of the apply kernel to finish (ScanArgs, yttm_kernels.h; every other workgroup has published its
 // updates as device-scope atomics or write-through stores and then taken its ticket, nothing else touches the pair table), or as

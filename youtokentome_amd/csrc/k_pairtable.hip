@@ -443,6 +443,10 @@ __global__ __launch_bounds__(BLOCK) void k_pt_apply_blocks(PairTable pt, const D
 // (PairTable::maybe, a superset of the slots that can have crossed; a few dozen per round); should they have overflowed, every record
 // with a positive delta of every block, this rank's included.  Several notes of one slot meet at the flag (atomicOr: whoever sets it
 // appends).  Then the round's candidate scan (scan_top, straight into the host's mailbox), with the fold's report on the exchange (xstat).
+// Ordering (k_merge_shared.h, "ORDERING OF A FUSED TAIL"): k_fold_list is ONE workgroup launched behind the apply kernels, the collective and phase
+// 1 on the same stream -- what those wrote is ordered by kernel boundaries, not by tickets.  Inside the workgroup, the list appends below are atomics and
+// `sc1` stores by some threads that scan_top's threads read back: __syncthreads() (which waits for each wave's outstanding memory operations) + the
+// agent-scope loads of scan_top order them; no cross-workgroup hand-off happens in this kernel.
 constexpr int FOLD_NT = 512;
 __device__ inline void fold_list_slot(const PairTable &pt, unsigned long long j) {
   const unsigned long long raw = ld_agent(pt.cnt_p(j)), c = raw & PT_CNT;

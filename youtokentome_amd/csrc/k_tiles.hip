@@ -268,6 +268,7 @@ __global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WP
     }
   }
   if (MERGE && sa.on) {  // the round's candidate scan, by the last workgroup to get here (scan_top)
+    // (The full argument -- which store is ordered before which load, by what -- is in k_merge_shared.h, "ORDERING OF A FUSED TAIL"; this is its P2.)
     // Everything this workgroup leaves for the tail went out as device-scope atomics or write-through stores (pair table, hot
     // list, statistics row), so the ticket only has to wait until those have completed -- a workgroup-scope release: an
     // agent-scope one would also write the XCD's L2 back, once per workgroup (measured: +150 us per round at 768 workgroups).

@@ -762,6 +762,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
       for (int i = 0; i < 4; i++) blk_add(stats, i, A.st[i]);
     }
   }
+  // (ordering: k_merge_shared.h "ORDERING OF A FUSED TAIL" -- P1: the inline apply above is atomics only, blk_add atomics; P2 here; C1 - C3 in the branch)
   if (sa.on != 3u) {  // the candidate scan, by the last workgroup to get here (as in k_tiles); it also leaves the worklist's length at zero
     __shared__ unsigned int is_last;
 #if defined(__HIP_DEVICE_COMPILE__)
