@@ -51,6 +51,32 @@ def test_k2_k3_word_table_and_pair_count():
         S.check_word_table_and_pairs(t)
 
 
+def test_k3_radix_partition(tmp_path, monkeypatch):
+    """K3 of large alphabets by two-level radix partition (k_pairradix.hip, round 6) against the oracle's count: forced on at small sizes
+    (YTTM_K3_RADIX_MIN=0) on alphabets of 66 .. 5000 symbols with runs of one symbol, then 4 MB of the CJK-shaped corpus -- thousands of
+    workgroups, every level-1 group, chunks that span several first tokens -- and the same text counted by the general kernel."""
+    import ctypes as C
+    import json
+    from youtokentome_amd import _lib
+    monkeypatch.setenv("YTTM_K3_RADIX_MIN", "0")
+    for t in S.texts_by_alphabet_size(sizes=(66, 130, 300, 1500, 5000), n_words=3000):
+        S.check_word_table_and_pairs(t)
+    big = gen.cjk_corpus_fast(4_000_000, seed=3)
+    S.check_word_table_and_pairs(big)
+    S.check_word_table_and_pairs(gen.cjk_corpus_fast(1_000_000, seed=4), coverage=0.95)
+    L = _lib.load()
+    corpus = str(tmp_path / "c.txt")
+    open(corpus, "wb").write(big)
+    models = []
+    for radix_min, want in (("0", 1), ("1000000000000", 0)):
+        monkeypatch.setenv("YTTM_K3_RADIX_MIN", radix_min)
+        err, rep, model = C.create_string_buffer(2048), C.create_string_buffer(16384), str(tmp_path / ("m%d.model" % want))
+        assert L.yttm_train_bpe_ex(corpus.encode(), model.encode(), 6000, 1.0, 8, 0, 1, 2, 3, 0, rep, 16384, err, 2048) == 0, err.value
+        assert json.loads(rep.value.decode())["k3_radix"] == want
+        models.append(open(model, "rb").read())
+    assert models[0] == models[1]
+
+
 def test_k5_dropout_heap_equals_array():
     S.check_dropout_heap_equals_array()
 

@@ -538,3 +538,32 @@ def test_word_mode(tmp_path, monkeypatch):
         for k in (cfg or {}):
             monkeypatch.delenv(k)
     assert word_rounds > 1000 and all_rounds > 10 and builds > 20 and 500 < fused < word_rounds - 500, (word_rounds, all_rounds, builds, fused)
+
+
+def test_k3_radix_partition(tmp_path, monkeypatch):
+    """K3 of large alphabets (k_pairradix.hip, round 6): (pair, weight) records partitioned by their first token in two levels, summed in a dense
+    LDS array per first token -- forced on at toy sizes (YTTM_K3_RADIX_MIN=0).  The whole pair table must equal the oracle's count (alphabets of 66 ..
+    1500 symbols: one, two and more level-1 groups per chunk; runs of one symbol, odd and even: the floor(L/2) rule), and a training that
+    counted this way must write the oracle's model."""
+    import ctypes as C
+    import filecmp
+    import json
+    from youtokentome_amd import _lib
+    import oracle_lib as O
+    monkeypatch.setenv("YTTM_K3_RADIX_MIN", "0")
+    for t in S.texts_by_alphabet_size(sizes=(66, 130, 300, 1500), n_words=300):
+        S.check_word_table_and_pairs(t)
+    S.check_word_table_and_pairs(gen.cjk_corpus_fast(40000, seed=3))  # (up to 4096 ideographs, clauses without spaces)
+    S.check_word_table_and_pairs(gen.cjk_corpus_fast(40000, seed=4), coverage=0.95)
+    L = _lib.load()
+    for i, (text, vocab) in enumerate(((S.texts_by_alphabet_size(sizes=(200,), n_words=300)[0], 500), (gen.cjk_corpus_fast(40000, seed=5), 4600))):
+        corpus, m_gpu, m_ora = str(tmp_path / f"c{i}.txt"), str(tmp_path / f"g{i}.model"), str(tmp_path / f"o{i}.model")
+        open(corpus, "wb").write(text)
+        err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+        assert L.yttm_train_bpe_ex(corpus.encode(), m_gpu.encode(), vocab, 1.0, 1, 0, 1, 2, 3, 0, rep, 16384, err, 2048) == 0, err.value
+        r = json.loads(rep.value.decode())
+        assert r["k3_radix"] == 1, r
+        O.train(text, m_ora, vocab)
+        assert filecmp.cmp(m_gpu, m_ora, shallow=False), i
+    monkeypatch.setenv("YTTM_K3_RADIX_MIN", "1000000000000")
+    S.check_word_table_and_pairs(S.texts_by_alphabet_size(sizes=(130,), n_words=300)[0])

@@ -42,8 +42,8 @@ void yttm_report_to_json(const TrainReport &r, char *buf, int len) {
   snprintf(tmp, sizeof tmp, "\"corpus_bytes\": %llu, \"n_unique\": %llu, \"n_tokens\": %llu, \"rounds\": %llu, \"rules\": %llu, \"cand_rescans\": %llu, \"hot_rebuilds\": %llu, \"repacks\": %llu, \"merge_sites\": %llu, ",
            r.corpus_bytes, r.n_unique, r.n_tokens, r.rounds, r.rules, r.cand_rescans, r.hot_rebuilds, r.repacks, r.merge_sites);
   s += tmp;
-  snprintf(tmp, sizeof tmp, "\"fused_rounds\": %llu, \"fused_overflows\": %llu, \"exchange_retries\": %llu, \"word_table_retries\": %llu, \"front_end_overlapped\": %llu, \"top_refills\": %llu, \"index_builds\": %llu, \"word_rounds\": %llu, \"word_switch_round\": %llu, \"word_all_rounds\": %llu, \"word_fused_rounds\": %llu, \"rounds_exhausted\": %llu, \"batch_extensions\": %llu, \"batch_splits\": %llu, \"replicated_merge_loop\": %llu, \"front_end_chunks\": %llu, \"peak_device_bytes\": %llu, \"classb_overlapped\": %llu, ",
-           r.fused_rounds, r.fused_overflows, r.exchange_retries, r.word_table_retries, r.front_end_overlapped, r.top_refills, r.index_builds, r.word_rounds, r.word_switch_round, r.word_all_rounds, r.word_fused_rounds, r.rounds_exhausted, r.batch_extensions, r.batch_splits, r.replicated_merge_loop, r.front_end_chunks, r.peak_device_bytes, r.classb_overlapped);
+  snprintf(tmp, sizeof tmp, "\"fused_rounds\": %llu, \"fused_overflows\": %llu, \"exchange_retries\": %llu, \"word_table_retries\": %llu, \"front_end_overlapped\": %llu, \"top_refills\": %llu, \"index_builds\": %llu, \"word_rounds\": %llu, \"word_switch_round\": %llu, \"word_all_rounds\": %llu, \"word_fused_rounds\": %llu, \"rounds_exhausted\": %llu, \"batch_extensions\": %llu, \"batch_splits\": %llu, \"replicated_merge_loop\": %llu, \"front_end_chunks\": %llu, \"peak_device_bytes\": %llu, \"classb_overlapped\": %llu, \"k3_radix\": %llu, ",
+           r.fused_rounds, r.fused_overflows, r.exchange_retries, r.word_table_retries, r.front_end_overlapped, r.top_refills, r.index_builds, r.word_rounds, r.word_switch_round, r.word_all_rounds, r.word_fused_rounds, r.rounds_exhausted, r.batch_extensions, r.batch_splits, r.replicated_merge_loop, r.front_end_chunks, r.peak_device_bytes, r.classb_overlapped, r.k3_radix);
   s += tmp;
   snprintf(tmp, sizeof tmp, "\"touched_tiles\": %llu, \"touched_tile_tokens\": %llu, \"touched_words\": %llu, \"touched_word_tokens\": %llu, ",
            r.touched_tiles, r.touched_tile_tokens, r.touched_words, r.touched_word_tokens);

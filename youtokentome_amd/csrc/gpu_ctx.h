@@ -103,6 +103,7 @@ class GpuCtx {
   int last_top_bin() const { return (int)last_top_bin_; }  // no bin above this one is in use
   unsigned long long index_builds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0, word_fused_rounds = 0;  // K4 rounds whose worklist came from the pair index
   unsigned long long classb_overlapped = 0;   // word-mode rounds whose class-B tiles ran beside k_words on a second stream
+  unsigned long long k3_radix = 0;            // 1: K3 of class A ran by radix partition (k_pairradix.hip)
   unsigned long long front_end_chunks = 0;    // > 0: the corpus was taken in this many chunks (front_end_chunked)
   bool corpus_resident() const { return !chunked_; }  // false: only the distinct words' bytes are in HBM
   unsigned long long peak_device_bytes() const;       // high-water mark of the device memory pool since this context was made

@@ -100,12 +100,27 @@ void GpuCtx::pair_count() {
   pt_fresh_ = false;
   ensure_table_capacity(bound);
   t_begin(KT_PAIR_COUNT);
-  for (int ci = 0; ci < 2; ci++) launch_pair_count(ci, cls_[ci].ts, pt_, db_, id_min_, id_max_ >= id_min_ ? id_max_ - id_min_ + 1 : 0, strm());
+  const uint32_t n_ids = id_max_ >= id_min_ ? id_max_ - id_min_ + 1 : 0;
+  // class A of a large alphabet (CJK: thousands of symbols, millions of pairs): records partitioned by their first token instead of one random
+  // atomic per adjacency (k_pairradix.hip; 16 B of scratch per class-A token for the length of the count)
+  uint32_t *rx_scratch = nullptr;
+  unsigned long long *rx_buf1 = nullptr, *rx_buf2 = nullptr;
+  const bool radix = cls_[0].n_tiles && pair_count_radix_takes(n_ids, cls_[0].n_tokens0) && cls_[0].n_tokens0 >= cfg_->k3_radix_min.u && !cfg_->k3_general.set;
+  if (radix) {
+    rx_scratch = dmalloc<uint32_t>(pair_count_radix_scratch_u32(n_ids));
+    rx_buf1 = dmalloc<unsigned long long>(cls_[0].n_tokens0 + 1);
+    rx_buf2 = dmalloc<unsigned long long>(cls_[0].n_tokens0 + 1);
+    HIP_CHECK(hipMemsetAsync(rx_scratch, 0, (size_t)n_ids * 4, strm()));
+    launch_pair_count_radix(cls_[0].ts, pt_, db_, id_min_, n_ids, rx_scratch, rx_buf1, rx_buf2, cls_[0].n_tokens0, strm());
+    k3_radix = 1;
+  }
+  for (int ci = radix ? 1 : 0; ci < 2; ci++) launch_pair_count(ci, cls_[ci].ts, pt_, db_, id_min_, n_ids, strm());
   launch_giant(false, cls_[2].ts, cls_[2].slot, pt_, db_, nullptr, 0, 0xffffffffu, 0, cls_[2].d_scratch, d_stats_, strm());
   t_end(KT_PAIR_COUNT, 4 * n_tokens0 + 8 * n_unique);
   unsigned int nk = 0;
   HIP_CHECK(hipMemcpyAsync(&nk, pt_.n_keys, 4, hipMemcpyDeviceToHost, strm()));
   sync();
+  DFREE(rx_scratch); DFREE(rx_buf1); DFREE(rx_buf2);
   n_keys_host = nk;
   exchange_deltas();
 }

@@ -61,7 +61,7 @@ struct TrainReport {
   double seconds_total = 0, seconds_frontend = 0, seconds_merge = 0, seconds_io = 0, seconds_upload = 0;  // upload: file/host -> HBM (train_bpe only)
   unsigned long long corpus_bytes = 0, n_unique = 0, n_tokens = 0, rounds = 0, rules = 0, cand_rescans = 0, repacks = 0, merge_sites = 0, hot_rebuilds = 0, fused_rounds = 0, fused_overflows = 0, exchange_retries = 0, word_table_retries = 0, front_end_overlapped = 0, top_refills = 0, index_builds = 0, word_rounds = 0, word_switch_round = 0, word_all_rounds = 0, word_fused_rounds = 0,
                      rounds_exhausted = 0 /* batches closed for lack of candidates, not at an intersection */, batch_extensions = 0 /* extra scans that refilled the pick */, batch_splits = 0 /* batches cut to the first BATCH_ARGS_MAX rules: word mode, two one-launch rounds instead of a four-launch one */,
-                     classb_overlapped = 0 /* word-mode rounds whose class-B tiles ran beside k_words on a second stream */, front_end_chunks = 0 /* > 0: the corpus crossed the device in this many chunks (it did not fit the HBM at once) */, peak_device_bytes = 0 /* high-water mark of the device memory pool during the call */,
+                     classb_overlapped = 0 /* word-mode rounds whose class-B tiles ran beside k_words on a second stream */, k3_radix = 0 /* 1: the pair count of a large alphabet ran by radix partition */, front_end_chunks = 0 /* > 0: the corpus crossed the device in this many chunks (it did not fit the HBM at once) */, peak_device_bytes = 0 /* high-water mark of the device memory pool during the call */,
                      replicated_merge_loop = 0 /* multi-GPU: the shards were gathered, every rank ran the merge loop alone (no per-round collective) */;
   // K4 totals: tiles with a merge site and their tokens; words with a merge site and their tokens (measurement pass only, else 0)
   unsigned long long touched_tiles = 0, touched_tile_tokens = 0, touched_words = 0, touched_word_tokens = 0;

@@ -358,6 +358,7 @@ Status learn_bpe(GpuCtx &g, int vocab_size, const std::string &model_path, const
     rep->front_end_overlapped = g.front_end_overlapped ? 1 : 0;
     rep->front_end_chunks = g.front_end_chunks;
     rep->classb_overlapped = g.classb_overlapped;
+    rep->k3_radix = g.k3_radix;
     rep->peak_device_bytes = g.peak_device_bytes();
     rep->top_refills = g.top_refills;
     rep->index_builds = g.index_builds;

@@ -523,7 +523,7 @@ void pm_bloom_host(uint32_t *bloom, const uint32_t *xyz, uint32_t k) {  // (a ba
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, uint32_t id_min, uint32_t n_ids, hipStream_t st) {
   if (!ts.n_tiles) return;
   const std::shared_ptr<const Config> C = cfg();  // (tuning aids; one launch per training)
-  const unsigned int bpc = (unsigned int)C->k3_bpc.i;
+  const unsigned int bpc = 4;  // (workgroups per CU; measured best, round 2)
   const bool general = C->k3_general.set;
   if (cls == 0 && n_ids && n_ids <= K3D_MAX_IDS && !general) {
     if (n_ids <= 32u)

@@ -250,12 +250,44 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   __shared__ unsigned int dn;  // records of this workgroup
   __shared__ AggLds A;
   __shared__ unsigned int rn;  // new-instance records of this workgroup (its region of irec; put into the tokens' lists at the end)
+  __shared__ uint32_t rcnt_a[FUSED ? BATCH_ARGS_MAX : 1];  // FUSED: the workgroup's records per new token, counted as they are appended (a record's rank rides in it)
   __shared__ unsigned long long rkeys[LDSR ? APPLY_LDS_RULES : 1];
   __shared__ uint16_t rridx[LDSR ? APPLY_LDS_RULES : 1];
   const bool from_args = LDSR && ba.k != 0;
+  // FUSED, round 6: the rules' runs are looked up FIRST -- thread j: rule j; two or three dependent trips to the index / the lists' headers in L2 --
+  // and the lists' cursor loaded with them, so that those trips run under the LDS set-up below (no barrier waits for a load in flight: a
+  // workgroup-scope fence drains LDS operations only) instead of behind it: 5 -> 2.5 us of every round's prologue.
+  unsigned long long fq_base = 0, fq_len = 0, fq_cur = 0;
+  uint32_t fq_filt = 0, fq_mode = 0;
+  bool fq_found = true;
+  if (FUSED) {
+    fq_cur = g.tl.cursor[g.round_id & 1u];
+    const PairIndex ix{g.ix.key, g.ix.cnt, g.ix.off, g.ix.bloom, g.ix.post, g.ix.mask};
+    const uint32_t j = threadIdx.x;
+    if (j < ba.k) {
+      const uint32_t x = ba.xy[2 * j], y = ba.xy[2 * j + 1];
+      const uint32_t m = x > y ? x : y;
+      if (m < g.z_static) {
+        uint32_t sl = 0xffffffffu;
+        if (g.ix_valid) sl = idx_find(ix, pair_key(x, y), enc_hash(x, y));
+        if (sl == 0xffffffffu) {
+          fq_found = false;  // not in the index: this round takes every word (f_every, set behind the LDS set-up)
+        } else {
+          fq_base = ix.off[(size_t)sl * IDX_SHARDS];
+          fq_len = ix.off[((size_t)sl + 1) * IDX_SHARDS] - fq_base;
+        }
+      } else {
+        fq_base = g.tl.base[m];
+        const uint32_t f = g.tl.fill[m], c = g.tl.cap[m];
+        fq_len = f < c ? f : c;
+        if (x > y) { fq_mode = 2; fq_filt = y; } else { fq_mode = 1; fq_filt = x; }
+      }
+    }
+  }
   agg_init<WPB * 64>(A, from_args ? nullptr : bloom_g);  // (A.flagbits holds the batch's pair filter)
   if (threadIdx.x == 0) rn = 0;
   if (threadIdx.x == 0) dn = 0;
+  if (FUSED && threadIdx.x < BATCH_ARGS_MAX) rcnt_a[threadIdx.x] = 0;
   if (from_args) {
     for (int s = (int)threadIdx.x; s < (int)(FLAG_LDS_IDS / 16); s += WPB * 64) A.flagbits[s] = 0;
     for (unsigned int i = threadIdx.x; i <= rule_mask; i += WPB * 64) rkeys[i] = PT_EMPTY;
@@ -290,39 +322,19 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   }
   __syncthreads();
   const int wave = uni((int)(threadIdx.x >> 6)), lane = lane_id();
-  if (FUSED) {  // where each rule's candidates are (as k_wgather: a posting run of the index, or the younger token's instance list)
-    const PairIndex ix{g.ix.key, g.ix.cnt, g.ix.off, g.ix.bloom, g.ix.post, g.ix.mask};
+  if (FUSED) {  // where each rule's candidates are (as k_wgather: a posting run of the index, or the younger token's instance list): looked up above
     const uint32_t j = threadIdx.x;
     unsigned long long len = 0, lcap = 0;
     bool f_mode_of_mine = false;
     if (j < ba.k) {
-      const uint32_t x = ba.xy[2 * j], y = ba.xy[2 * j + 1];
-      const uint32_t m = x > y ? x : y;
-      unsigned long long base = 0;
-      uint32_t filt = 0, mode = 0;
-      bool found = true;
-      if (m < g.z_static) {
-        uint32_t s = 0xffffffffu;
-        if (g.ix_valid) s = idx_find(ix, pair_key(x, y), enc_hash(x, y));
-        if (s == 0xffffffffu) {
-          f_every = 1u;  // not in the index: this round takes every word
-          found = false;
-        } else {
-          base = ix.off[(size_t)s * IDX_SHARDS];
-          len = ix.off[((size_t)s + 1) * IDX_SHARDS] - base;
-        }
-      } else {
-        base = g.tl.base[m];
-        const uint32_t f = g.tl.fill[m], c = g.tl.cap[m];
-        len = f < c ? f : c;
-        if (x > y) { mode = 2; filt = y; } else { mode = 1; filt = x; }
-      }
-      f_base[j] = base;
-      f_filt[j] = filt;
-      f_mode[j] = (uint8_t)mode;
-      f_mode_of_mine = mode != 0;
+      len = fq_len;
+      if (!fq_found) f_every = 1u;  // not in the index: this round takes every word
+      f_base[j] = fq_base;
+      f_filt[j] = fq_filt;
+      f_mode[j] = (uint8_t)fq_mode;
+      f_mode_of_mine = fq_mode != 0;
       const unsigned long long cj = g.cnt[j];
-      lcap = found && len < cj ? len : cj;
+      lcap = fq_found && len < cj ? len : cj;
     }
     static_assert(BATCH_ARGS_MAX <= 128, "two waves scan the runs");
     // what a run costs: a record to read each, and FUSE_WORD_COST of those per word to work on -- every posting's word, but only the
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
     const unsigned long long w0 = f_tmp[0], wc0 = f_tmp[1], ww0 = f_tmp[2];
     const unsigned long long call = wc0 + f_tmp[3];
     if (wave == 1) { inc += w0; cinc += wc0; winc += ww0; }
-    const unsigned long long cur = g.tl.cursor[g.round_id & 1u];
+    const unsigned long long cur = fq_cur;
     const bool fits = cur + call <= g.tl.log_cap;
     if (j < ba.k) {
       f_pref[j] = inc - len;
@@ -621,7 +633,9 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
                   if (!(tr & TOK_WS)) rnb = tr & L_ID;
                   const unsigned int pos = b0 + (unsigned int)__popcll(nm & lanemask_lt());
                   if (pos < drec_cap) {
-                    my_irec[pos] = make_uint4(z - z_base, word_id, lnb, rnb);
+                    // (FUSED: the record's rank among the workgroup's records of its token is taken here, not by a pass over the region at the end)
+                    const uint32_t rank = FUSED ? atomicAdd(&rcnt_a[z - z_base], 1u) : 0u;
+                    my_irec[pos] = make_uint4((z - z_base) | (rank << 12), word_id, lnb, rnb);
                   } else {
                     direct = true;
                   }
@@ -697,25 +711,35 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   K4_MARK(12);
 #endif
   // ---- the workgroup's records: one bump of a token's fill count per workgroup (the tile buffers are free: counts per rule live there)
+  DeltaRec drec_first{};  // (FUSED: this thread's first count record, loaded with its first instance record -- below)
   {
     static_assert(sizeof(WL) >= WGATHER_MAXK * sizeof(uint32_t), "per-rule counters of the record flush");
-    uint32_t *rcnt = reinterpret_cast<uint32_t *>(&WL[0]);
+    uint32_t *rcnt = FUSED ? rcnt_a : reinterpret_cast<uint32_t *>(&WL[0]);
     __syncthreads();
     const unsigned int nrec = rn < drec_cap ? rn : drec_cap;
+    // Round 6, the late rounds' latency: a thread's first instance record and its first count record are loaded HERE, ahead of the returning
+    // adds on the lists' fill counts below -- three trips to L2 side by side instead of one behind the other (the records were stored by this
+    // workgroup: a barrier orders them; a FUSED round already knows every record's rank, so nothing has to be read before the adds).
+    uint4 rec_first = make_uint4(0u, 0u, 0u, 0u);
+    if (FUSED && threadIdx.x < nrec) rec_first = my_irec[threadIdx.x];
+    const unsigned int nd_pre = dn < drec_cap ? dn : drec_cap;
+    if (FUSED && inline_apply && threadIdx.x < nd_pre) drec_first = dout.recs[threadIdx.x];
     if (nrec) {  // (uniform)
       const uint32_t kk = k_rules < WGATHER_MAXK ? k_rules : WGATHER_MAXK;
-      for (uint32_t j = threadIdx.x; j < kk; j += WPB * 64) rcnt[j] = 0;
-      __syncthreads();
-      for (unsigned int i = threadIdx.x; i < nrec; i += WPB * 64) {  // rank of the record among the workgroup's records of its token
-        const uint32_t zr = my_irec[i].x & 0xfffu;
-        my_irec[i].x = zr | (atomicAdd(&rcnt[zr], 1u) << 12);
+      if (!FUSED) {
+        for (uint32_t j = threadIdx.x; j < kk; j += WPB * 64) rcnt[j] = 0;
+        __syncthreads();
+        for (unsigned int i = threadIdx.x; i < nrec; i += WPB * 64) {  // rank of the record among the workgroup's records of its token
+          const uint32_t zr = my_irec[i].x & 0xfffu;
+          my_irec[i].x = zr | (atomicAdd(&rcnt[zr], 1u) << 12);
+        }
+        __syncthreads();
       }
-      __syncthreads();
       for (uint32_t j = threadIdx.x; j < kk; j += WPB * 64)
         if (rcnt[j]) rcnt[j] = atomicAdd(&tl.fill[z_base + j], rcnt[j]);
       __syncthreads();
       for (unsigned int i = threadIdx.x; i < nrec; i += WPB * 64) {
-        const uint4 rec = my_irec[i];
+        const uint4 rec = FUSED && i == threadIdx.x ? rec_first : my_irec[i];
         const uint32_t zr = rec.x & 0xfffu, z = z_base + zr;
         const uint32_t at = rcnt[zr] + (rec.x >> 12);
         if (at < (FUSED ? f_lcap[zr] : tl.cap[z])) {
@@ -753,7 +777,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   {
     const unsigned int nd = dn < drec_cap ? dn : drec_cap;
     for (unsigned int i = threadIdx.x; i < nd; i += WPB * 64) {
-      const DeltaRec rec = dout.recs[i];
+      const DeltaRec rec = FUSED && i == threadIdx.x ? drec_first : dout.recs[i];  // (FUSED: the first one came with the instance records, above)
       global_emit(pt, db, rec.key, rec.delta, &A.new_keys);
     }
     __syncthreads();

@@ -51,7 +51,7 @@ struct Hook {
   X(fe_k2b_blocks, "YTTM_FE_K2B_BLOCKS", "4096", "tune", "workgroups of a part's dedup launch")                                             \
   X(word_table_full, "YTTM_WORD_TABLE_FULL", "", "path", "set: size the word table for the worst case at once (no estimate, no retry)")    \
   X(test_wcnt_max, "YTTM_TEST_WCNT_MAX", "4294967295", "test", "largest weight a word may carry (tests: words 'seen 2^32 times' at toy sizes)") \
-  X(k3_bpc, "YTTM_K3_BPC", "4", "tune", "K3: workgroups per CU")                                                                            \
+  X(k3_radix_min, "YTTM_K3_RADIX_MIN", "4194304", "path", "K3 of alphabets of 65 .. 8192 symbols: class-A tokens from which it runs by radix partition (tests: 0; huge: never)") \
   X(k3_general, "YTTM_K3_GENERAL", "", "path", "set: K3 through the general tile kernel even on a small alphabet")                          \
   /* ---- candidate lists, pick */                                                                                                           \
   X(hot_cap, "YTTM_HOT_CAP", "262144", "test", "capacity of the hot list (tests: overflows)")                                               \

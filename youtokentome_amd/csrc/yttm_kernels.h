@@ -113,6 +113,13 @@ void launch_top_rebuild(const PairTable &pt, unsigned int listed_hint, hipStream
 // id_min / n_ids: the token ids in the tiles are id_min .. id_min + n_ids - 1 (K3 runs before any merge: the alphabet); n_ids <= 32
 // counts pairs in a dense LDS table, 0 (unknown / larger) in the LDS hash
 void launch_pair_count(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, uint32_t id_min, uint32_t n_ids, hipStream_t st);
+// K3 of class A for alphabets of 65 .. K3R_MAX_IDS symbols by two-level radix partition of (pair, weight) records (k_pairradix.hip): no atomic per
+// adjacency.  scratch: pair_count_radix_scratch_u32(n_ids) words; buf1, buf2: one 8-byte record per class-A token each.
+constexpr uint32_t K3R_MAX_IDS = 8192;
+size_t pair_count_radix_scratch_u32(uint32_t n_ids);
+bool pair_count_radix_takes(uint32_t n_ids, unsigned long long n_tokens);
+void launch_pair_count_radix(const TileSet &ts, const PairTable &pt, const DeltaBuf &db, uint32_t id_min, uint32_t n_ids, uint32_t *scratch,
+                             unsigned long long *buf1, unsigned long long *buf2, unsigned long long n_tokens, hipStream_t st);
 void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const DeltaBuf &db, const RuleSlot *rules, unsigned int rule_mask,
                         uint32_t self_x, uint32_t self_z, uint32_t z_base, unsigned long long *stats, const BatchArgs *ba,
                         const ScanArgs *scan /* the round's last launch only */,
