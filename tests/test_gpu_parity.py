@@ -559,10 +559,13 @@ def test_zz_fused_tail_ordering(tmp_path, use_comm, pin_name):
     ref, rep0 = run("nofuse", dict(hooks, YTTM_NO_FUSE="1"))
     assert rep0["fused_rounds"] == 0
     for i in range(10 if not use_comm and pin_name == "c2_100mb" else 4):  # (the ordering rests on an empirical check -- more runs of it, ten on the headline path)
-        got, rep = run("fuse%d" % i, hooks)
+        # (class-B tiles, the CJK-shaped pin: runs 0 and 2 with their launch of a word-mode round BESIDE k_words on a second stream -- the tail waits
+        # for its flag, ScanArgs::peer_flag --, runs 1 and 3 the default: before it on the main stream)
+        beside = pin_name == "c6_cjk_100mb" and i % 2 == 0
+        got, rep = run("fuse%d" % i, dict(hooks, YTTM_CLASSB_BESIDE="1") if beside else hooks)
         assert rep["fused_rounds"] > 100 and rep["word_fused_rounds"] > 100, (rep["fused_rounds"], rep["word_fused_rounds"])
-        if pin_name == "c6_cjk_100mb":  # (class-B tiles: their launch of a word-mode round runs beside k_words on a second stream, the tail waits for its flag)
-            assert rep["classb_overlapped"] > 100, rep["classb_overlapped"]
+        if pin_name == "c6_cjk_100mb":
+            assert (rep["classb_overlapped"] > 100) == beside, rep["classb_overlapped"]
         assert len(got) == len(ref), (len(got), len(ref))
         for n, (a, b) in enumerate(zip(ref, got)):
             assert a == b, "scan %d differs (run %d):\n  separate scan: %s\n  fused tail:    %s" % (n, i, a, b)

@@ -452,8 +452,8 @@ def test_word_table_overflow_is_redone(tmp_path):
 def test_word_mode_with_class_b_tiles_beside(tmp_path, monkeypatch):
     """Word mode with class-B tiles (words of 257 .. 2 048 tokens -- the long clauses of unsegmented scripts -- stay in tiles of their own): the
     round's class-B launch goes to a second stream beside k_words, its last workgroup raises a flag the round's tail waits for (gpu_ctx.cpp
-    merge_apply, ScanArgs::peer_flag).  Same model as the oracle with the launches side by side and -- YTTM_NO_CLASSB_OVERLAP -- one after the
-    other; the report counts the rounds that ran side by side."""
+    merge_apply, ScanArgs::peer_flag) -- with YTTM_CLASSB_BESIDE=1; since round 6 the default is one stream (measured faster: profiles/r6_classb_order.txt).
+    Same model as the oracle either way; the report counts the rounds that ran side by side."""
     import ctypes as C
     import filecmp
     import json
@@ -476,7 +476,9 @@ def test_word_mode_with_class_b_tiles_beside(tmp_path, monkeypatch):
     seen = {}
     for off in (False, True):
         if off:
-            monkeypatch.setenv("YTTM_NO_CLASSB_OVERLAP", "1")
+            monkeypatch.delenv("YTTM_CLASSB_BESIDE")
+        else:
+            monkeypatch.setenv("YTTM_CLASSB_BESIDE", "1")
         cp, mg = str(tmp_path / "c.txt"), str(tmp_path / "g.model")
         open(cp, "wb").write(text)
         err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)

@@ -7,7 +7,8 @@ os.environ["YTTM_NO_FUSE"] = "1"
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import gen, torch
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-text = gen.abcd_corpus(mb * 1_000_000, seed=19, survey_stream=True)
+kind = sys.argv[2] if len(sys.argv) > 2 else "abcd"
+text = gen.cjk_corpus_fast(mb * 1_000_000, seed=11) if kind == "cjk" else gen.abcd_corpus(mb * 1_000_000, seed=19, survey_stream=True)
 from youtokentome_amd import _lib
 L = _lib.load()
 d = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
@@ -17,7 +18,7 @@ assert rc == 0, err.value
 rows = [[int(x) for x in l.split()] for l in open("/tmp/k4ph.txt")]
 names = {0: "find sites (regs)", 1: "single-site / stage", 2: "prefetch issue", 3: "phase 1a", 4: "4", 5: "phase 2 emits", 13: "phase 2 context", 6: "phase 3 (compact; word mode: + write-back, records)", 7: "loop end", 9: "word mode: fetch", 10: "word mode: record flush", 11: "wait for block", 12: "flush"}
 prev = [0] * 16
-for a, b in ((1, 11), (12, 28), (29, 46), (47, 100), (101, 200), (201, 400), (401, len(rows))):
+for a, b in ((1, 11), (12, 28), (29, 46), (47, 100), (101, 200), (201, 400), (401, 700), (701, len(rows))):
     cur = rows[min(b, len(rows)) - 1][7:23]
     base = rows[a - 2][7:23] if a > 1 else [0] * 16
     dlt = [c - p for c, p in zip(cur, base)]

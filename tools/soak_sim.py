@@ -65,13 +65,13 @@ while time.time() - t0 < budget:
         text = (" ".join(ws) + "\n").encode() * rng.randint(1, 3)
         cov = 1.0
         vocab = rng.randint(100, 2500)
-        # half of them in word mode from the second round: class-B tiles beside k_words (round 5: on a second stream, the tail waits for their flag)
-        for k in ("YTTM_WORD_MIN_TILES", "YTTM_WORD_MIN_TOKENS", "YTTM_WORD_DIV", "YTTM_NO_CLASSB_OVERLAP"):
+        # half of them in word mode from the second round: class-B tiles before k_words or (YTTM_CLASSB_BESIDE) beside it on a second stream, the tail waiting for their flag
+        for k in ("YTTM_WORD_MIN_TILES", "YTTM_WORD_MIN_TOKENS", "YTTM_WORD_DIV", "YTTM_CLASSB_BESIDE"):
             os.environ.pop(k, None)
         if rng.random() < 0.5:
             os.environ.update({"YTTM_WORD_MIN_TILES": "0", "YTTM_WORD_MIN_TOKENS": "0", "YTTM_WORD_DIV": "0"})
-            if rng.random() < 0.25:
-                os.environ["YTTM_NO_CLASSB_OVERLAP"] = "1"
+            if rng.random() < 0.5:
+                os.environ["YTTM_CLASSB_BESIDE"] = "1"
     if big:  # larger tables (several tiles, repacks, the pair index) and the tuning hooks that force the rare paths
         if r >= 0.7:
             text = gen.zipf_corpus(rng.randint(60000, 400000), vocab=rng.randint(500, 20000), seed=rng.randint(0, 10 ** 6))

@@ -28,7 +28,8 @@ GpuCtx::GpuCtx(int device) : device_(device) {
   hot_target_ = (unsigned int)C.hot_target.u;  // measured at 1 GB: 4096..16384 equal on the abcd corpus, 8192 best on Zipf text (4279 rounds)
   hot_min_ = (unsigned int)C.hot_min.u;
   fuse_enabled_ = C.no_fuse.u == 0;
-  classb_overlap_ = !C.no_classb_overlap.set;
+  // class-B tiles of a word-mode round: one stream (default, round 6) or beside k_words on a second one (YTTM_CLASSB_BESIDE=1: round 5's protocol)
+  classb_overlap_ = C.classb_beside.set && C.classb_beside.u == 1;
   idx_enabled_ = C.no_index.u == 0;  // (no pair index: no word mode either)
   idx_agg_min_ = C.index_agg_min.u;  // (fill pass of an index build: postings from which on a workgroup sums them per key in LDS first; tests: 0)
   hot_target_words_ = (unsigned int)C.hot_target_words.u;  // (measured at 1 GB, word mode: 8192 -> 6 rebuilds, candidate family 21.0 ms; 32768 -> 3, 16.9 ms; round 4: 32768 -> 3, 14.6 ms; 65536 -> 2, 12.5; 131072 -> 2, 15.0)
@@ -384,9 +385,7 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
   // and class B starts at once; otherwise (a list refill, a repack, a rule table on its way) it waits for an event, which costs the
   // round ~35 us of cross-queue latency and is why it is not the rule.
   const bool beside = classb_overlap_ && !multi() && sa.on == 1u && word_mode_ && cls_[0].n_tiles && cls_[1].n_tiles && !cls_[2].n_tiles;
-  for (int ci = 1; ci >= 0; ci--) {
-    if (!cls_[ci].n_tiles) continue;
-    if (ci == 1 && beside) {
+  auto prep_b_beside = [&]() {  // the second stream, and the fork event when the main stream holds more than the last round's tail
       bool st_clean = !st_touched_;
       if (!st_b_) {  // first class-B launch beside k_words of this context: the second stream, the fork event, the flag block -- each once
         st_b_ = pool_take_stream(device_);
@@ -405,6 +404,8 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
         HIP_CHECK(hipEventRecord(ev_fork_, strm()));
         HIP_CHECK(hipStreamWaitEvent(st_b_, ev_fork_, 0));
       }
+  };
+  auto launch_b_beside = [&]() {
       ScanArgs sb{};
       sb.on = 4u;
       sb.done_ctr = d_bsync_;
@@ -412,9 +413,22 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
       sb.round_id = sa.round_id;
       const BatchArgs tba = first_ba();
       launch_merge_apply(1, cls_[1].ts, kpt, db_, d_rules_, cap - 1, self_x, self_z, z_base, d_stats_, &tba, &sb, d_bloom_, st_b_);
-      sa.peer_flag = d_bsync_ + 1;
       classb_overlapped++;
       classb_unjoined_ = true;
+  };
+  for (int ci = 1; ci >= 0; ci--) {
+    if (!cls_[ci].n_tiles) continue;
+    if (ci == 1 && beside) {
+      if (!d_bsync_) {
+        d_bsync_ = dmalloc<unsigned int>(4);
+        HIP_CHECK(hipMemsetAsync(d_bsync_, 0, 16, strm()));
+      }
+      sa.peer_flag = d_bsync_ + 1;
+      // Submitted BEFORE k_words, whose tail waits for the flag: two HIP streams may share one hardware queue, where kernels run in submission
+      // order (measured, round 6: submitted behind k_words the class-B launch never started -- the tail's bounded spin ran out and the round
+      // was reported unpublished; profiles/r6_classb_order.txt).
+      prep_b_beside();
+      launch_b_beside();
       continue;
     }
     if (ci == 1) join_class_b();  // (class B on the main stream again behind rounds that ran it beside)

@@ -178,7 +178,7 @@ class GpuCtx {
   const char *trace_rounds_ = nullptr, *dbg_cand_ = nullptr;
   bool fuse_enabled_ = true;  // YTTM_NO_FUSE=1: always the separate scan kernel (tuning hook / tests)
   // word mode, single GPU: the class-B tiles' launch of a round runs on a second stream beside k_words (merge_apply; ScanArgs::peer_flag)
-  bool classb_overlap_ = true;       // YTTM_NO_CLASSB_OVERLAP
+  bool classb_overlap_ = false;      // YTTM_CLASSB_BESIDE
   hipStream_t st_b_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   // A class-B launch on st_b_ is joined with the main stream by the tail's wait for peer_flag: that orders what the TAIL reads (atomics,

@@ -67,7 +67,7 @@ struct Hook {
   X(no_batch_split, "YTTM_NO_BATCH_SPLIT", "", "path", "set: word-mode batches of 129..256 rules are not cut in two")                       \
   X(no_refine, "YTTM_NO_REFINE", "", "path", "set: the fused scan keeps the host's threshold")                                              \
   X(no_fuse, "YTTM_NO_FUSE", "0", "path", "1: the candidate scan is always a kernel of its own (differential test of the fused tail)")     \
-  X(no_classb_overlap, "YTTM_NO_CLASSB_OVERLAP", "", "path", "word mode: the class-B tiles' launch before k_words on one stream, not beside it on a second") \
+  X(classb_beside, "YTTM_CLASSB_BESIDE", "", "path", "1: word mode, the class-B tiles' launch of a round beside k_words on a second stream (round 5; default since round 6: before it on one stream)") \
   X(no_batch_args, "YTTM_NO_BATCH_ARGS", "", "path", "set: every batch travels through k_round_begin, none in the kernel arguments")       \
   /* ---- K4 */                                                                                                                              \
   X(apply_grid, "YTTM_APPLY_GRID", "256", "tune", "class-A grid cap for small tile sets (0: none)")                                          \
