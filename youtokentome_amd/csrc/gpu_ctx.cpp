@@ -466,12 +466,18 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
         HIP_CHECK(hipMemsetAsync(d_stamp_, 0, (size_t)stamp_cap_ * 4, strm()));
         ga.stamp = d_stamp_;
       }
+      // live tokens per class-A word, about: what the class held when it left the tiles, less a token per merge site since (a round or two behind)
+      if (sites_last_ != ~0ull && word_sites_seen_ != sites_cum_) {
+        word_live_tokens_ -= std::min(word_live_tokens_, sites_cum_ - std::min(sites_cum_, word_sites_seen_));
+        word_sites_seen_ = sites_cum_;
+      }
+      const unsigned int avg_word_tokens = (unsigned int)std::min<unsigned long long>(std::max<unsigned long long>(1, word_live_tokens_ / std::max<unsigned long long>(1, c.n_unique)), 1u << 16);
       const unsigned int work_hint = sites_last_ != ~0ull && idx_valid_ ? (unsigned int)std::min<unsigned long long>(2 * sites_last_ + word_hint_floor_, 1ull << 30) : 0u;
       ga.stats = d_stats_;
       const BatchArgs gba = first_ba();
       const WordSet wset{c.d_tok, d_wmeta_, c.d_wcnt, (uint32_t)c.n_unique};
       if (launch_words_apply(wset, kpt, db_, d_rules_, cap - 1, d_bloom_, self_x, self_z, z_base, k, d_wworklist_, c.n_unique + 64, c.d_work_n, d_stats_, tl_, d_drec_, drec_cap_, d_drec_n_, d_irec_, &gba,
-                             tail_of(0), work_hint, words_inline_max_, &ga, words_fuse_max_, strm()))
+                             tail_of(0), work_hint, words_inline_max_, &ga, words_fuse_max_, strm(), avg_word_tokens))
         word_fused_rounds++;
       word_rounds++;
       if (!idx_valid_) word_all_rounds++;

@@ -298,6 +298,7 @@ class GpuCtx {
   unsigned int *d_drec_n_ = nullptr, drec_cap_ = 0;
   uint4 *d_irec_ = nullptr;          // [WORDS_MAX_GRID * drec_cap_] the round's new-instance records before they go to the tokens' lists
   TokLists tl_{};
+  unsigned long long word_live_tokens_ = 0, word_sites_seen_ = 0;  // class A in word mode: its live tokens (about), the merge sites already taken off them
   unsigned long long sites_cum_ = 0, sites_last_ = ~0ull;
   void enter_word_mode(uint32_t z_next);
   void free_words();

@@ -52,6 +52,8 @@ void GpuCtx::enter_word_mode(uint32_t z_next) {
   *(volatile unsigned int *)tl_.broken = 0;
   word_mode_ = true;
   word_global_ = true;
+  word_live_tokens_ = std::min<unsigned long long>(c.n_tokens0, live_tokens_last_ ? live_tokens_last_ : c.n_tokens0);
+  word_sites_seen_ = sites_cum_;
   word_switch_round = merge_rounds;
   idx_valid_ = false;
   idx_pending_ = true;

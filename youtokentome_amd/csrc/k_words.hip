@@ -895,7 +895,7 @@ bool launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &
                         uint32_t self_x, uint32_t self_z, uint32_t z_base, uint32_t k_rules, const uint32_t *worklist, unsigned long long wl_seg,
                         const unsigned int *work_n, unsigned long long *stats, const TokLists &tl, DeltaRec *drec, unsigned int drec_cap, unsigned int *drec_n,
                         uint4 *irec, const BatchArgs *ba, const ScanArgs *scan, unsigned int work_hint, unsigned int inline_max, const WGatherArgs *ga,
-                        unsigned int fuse_max, hipStream_t st) {
+                        unsigned int fuse_max, hipStream_t st, unsigned int avg_word_tokens) {
   if (!ws.n_words) return false;
   BatchArgs bargs = ba ? *ba : BatchArgs{};
   ScanArgs sargs = scan ? *scan : ScanArgs{};
@@ -910,6 +910,10 @@ bool launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &
   unsigned int wpi = 64;
   if (worklist && work_hint) {
     while (wpi > 8 && (unsigned long long)work_hint < (unsigned long long)wpi * APPLY_WPB * gmax / 2) wpi >>= 1;
+    // Long words (round 6): a wave's LDS tile holds 512 tokens, and a work item whose words do not fit it takes a second (third ...) gather-and-merge
+    // pass, one behind the other -- CJK-shaped text, clauses of ~41 tokens: 16 words per item were 656 tokens, two passes; 8 words per item, one
+    // pass and twice the waves at work: merge loop 0.432 -> 0.385 s (profiles/r6_words_per_item.txt).
+    while (wpi > 4 && avg_word_tokens && (unsigned long long)wpi * avg_word_tokens > 600ull) wpi >>= 1;
     if (g_words_wpi >= 0) wpi = (unsigned int)g_words_wpi;
   }
   unsigned long long items = worklist && work_hint ? ((unsigned long long)work_hint + wpi - 1) / wpi + 1 : ((unsigned long long)ws.n_words + 63) / 64;

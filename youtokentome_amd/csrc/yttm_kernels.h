@@ -170,7 +170,8 @@ bool launch_words_apply(const WordSet &ws, const PairTable &pt, const DeltaBuf &
                         unsigned int drec_cap, unsigned int *drec_n /* [WORDS_MAX_GRID] */, uint4 *irec /* [WORDS_MAX_GRID * drec_cap] */, const BatchArgs *ba, const ScanArgs *scan, unsigned int work_hint,
                         unsigned int inline_max /* rounds of at most this many words (by the hint) apply their records themselves */,
                         const WGatherArgs *ga /* the round's gather: launched here (k_wgather) ... */,
-                        unsigned int fuse_max /* ... unless the hint is at most this and the batch is in the arguments: k_words gathers itself */, hipStream_t st);
+                        unsigned int fuse_max /* ... unless the hint is at most this and the batch is in the arguments: k_words gathers itself */, hipStream_t st,
+                        unsigned int avg_word_tokens = 0 /* live tokens per word, about (0: unknown): a wave takes no more words at a time than fit its 512-token tile */);
 constexpr unsigned int WORDS_MAX_GRID = 512;  // workgroups of k_words: each owns a region of the round's count-update records
 void launch_repack(int cls, const TileSet &ts, const unsigned long long *off, unsigned int nom, unsigned long long total,
                    unsigned long long *gstart, unsigned int n_new, uint32_t *new_tok, uint32_t *new_len, uint32_t *new_word0, hipStream_t st);
