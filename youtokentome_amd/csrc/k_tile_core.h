@@ -872,6 +872,7 @@ __device__ inline void process_tile(WaveLds<SLOT> &W, AggLds &A, const TileSet &
 
 // class-A apply kernels (k_tiles<MERGE>, k_words): waves per workgroup x workgroups per CU (8 x 3 = 6 waves per SIMD: <= 80 VGPRs, <= 48.5 KB LDS per workgroup)
 constexpr int APPLY_WPB = 8, APPLY_BPC = 3;
+constexpr int APPLY_WPB_B = 4;  // class-B tiles (4096-token slots): waves per workgroup of the merge-apply launch
 // workgroups of a tile launch: blocks_per_cu per CU, never more than there are tiles to hand out
 static inline unsigned int tile_grid(unsigned int n_tiles, unsigned int wpb, unsigned int blocks_per_cu) {
   unsigned int need = (n_tiles + wpb - 1) / wpb;

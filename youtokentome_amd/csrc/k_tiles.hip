@@ -25,7 +25,7 @@
 namespace yttm {
 
 template <int SLOT, int WPB, bool MERGE, bool LDSR, bool DIRECT = false>
-__global__ __launch_bounds__(WPB * 64, MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WPB) : WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
+__global__ __launch_bounds__(WPB * 64, SLOT == TILE_SLOT_B ? 1 : MERGE ? (WPB == 4 ? 5 : WPB == 8 ? 6 : WPB) : WPB) void k_tiles(TileSet ts, PairTable pt, DeltaBuf db, const RuleSlot *__restrict__ rules,
                                                     unsigned int rule_mask, const uint8_t *__restrict__ tokflag,
                                                     const uint32_t *__restrict__ flagbits, uint32_t self_x, uint32_t self_z, uint32_t z_base,
                                                     const uint32_t *__restrict__ worklist, const unsigned int *__restrict__ work_n,
@@ -573,11 +573,13 @@ void launch_merge_apply(int cls, const TileSet &ts, const PairTable &pt, const D
       hipLaunchKernelGGL((k_tiles<TILE_SLOT_A, APPLY_WPB, true, false>), dim3(grid_a), dim3(64 * APPLY_WPB), 0, st, ts, pt, db, rules, rule_mask,
                          no_flags, bloom_g, self_x, self_z, z_base, no_list, no_n, stats, bargs, sargs);
   } else {
+    // class B (round 6): APPLY_WPB_B waves -- tiles -- per workgroup share one set-up of the batch's tables in LDS (one wave per workgroup spent
+    // most of a 20 us launch on it: 315 workgroups each clearing and filling 22 KB with 64 threads; profiles/r6_classb_waves.txt)
     if (rule_mask < APPLY_LDS_RULES)
-      hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, true>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, APPLY_WPB_B, true, true>), dim3(tile_grid(ts.n_tiles, APPLY_WPB_B, 4)), dim3(64 * APPLY_WPB_B), 0, st, ts, pt, db, rules, rule_mask,
                          no_flags, bloom_g, self_x, self_z, z_base, no_list, no_n, stats, bargs, sargs);
     else
-      hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, 1, true, false>), dim3(tile_grid(ts.n_tiles, 1, 4)), dim3(64), 0, st, ts, pt, db, rules, rule_mask,
+      hipLaunchKernelGGL((k_tiles<TILE_SLOT_B, APPLY_WPB_B, true, false>), dim3(tile_grid(ts.n_tiles, APPLY_WPB_B, 4)), dim3(64 * APPLY_WPB_B), 0, st, ts, pt, db, rules, rule_mask,
                          no_flags, bloom_g, self_x, self_z, z_base, no_list, no_n, stats, bargs, sargs);
   }
 }
