@@ -253,6 +253,10 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   __shared__ uint32_t rcnt_a[FUSED ? BATCH_ARGS_MAX : 1];  // FUSED: the workgroup's records per new token, counted as they are appended (a record's rank rides in it)
   __shared__ unsigned long long rkeys[LDSR ? APPLY_LDS_RULES : 1];
   __shared__ uint16_t rridx[LDSR ? APPLY_LDS_RULES : 1];
+#ifdef YTTM_K4_PROF
+  const unsigned long long wall0_ = wall_clock64();  // (tuning build: this workgroup's timeline, 100 MHz: start | set-up done, words done | end, words)
+  unsigned long long wall_setup_ = 0, wall_words_ = 0;
+#endif
   const bool from_args = LDSR && ba.k != 0;
   // FUSED, round 6: the rules' runs are looked up FIRST -- thread j: rule j; two or three dependent trips to the index / the lists' headers in L2 --
   // and the lists' cursor loaded with them, so that those trips run under the LDS set-up below (no barrier waits for a load in flight: a
@@ -413,6 +417,7 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   TileStats S;
 #ifdef YTTM_K4_PROF
   S.t_last = (unsigned long long)clock64();
+  wall_setup_ = wall_clock64();
 #endif
   for (;;) {  // (once; fused: once per list of claimed words)
   unsigned long long n_all = n_glob, item0 = (unsigned long long)blockIdx.x * WPB + (unsigned long long)wave, istride = (unsigned long long)gridDim.x * WPB;
@@ -684,6 +689,9 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   if (threadIdx.x == 0) f_n = 0;
   __syncthreads();
   }
+#ifdef YTTM_K4_PROF
+  wall_words_ = wall_clock64();
+#endif
   {
     S.sites = wave_sum_u64(S.sites);
     if (lane == 0) {
@@ -786,6 +794,14 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
       for (int i = 0; i < 4; i++) blk_add(stats, i, A.st[i]);
     }
   }
+#ifdef YTTM_K4_PROF
+  if (threadIdx.x == 0) {
+    unsigned long long *row = stats + BLK_BASE + 8 * (blockIdx.x % BLK_ROWS);
+    row[5] = wall0_;
+    row[6] = ((wall_setup_ - wall0_) & 0xffffffffull) | ((wall_words_ - wall0_) << 32);
+    row[7] = ((wall_clock64() - wall0_) & 0xffffffffull) | ((unsigned long long)A.st[1] << 32);
+  }
+#endif
   // (ordering: k_merge_shared.h "ORDERING OF A FUSED TAIL" -- P1: the inline apply above is atomics only, blk_add atomics; P2 here; C1 - C3 in the branch)
   if (sa.on != 3u) {  // the candidate scan, by the last workgroup to get here (as in k_tiles); it also leaves the worklist's length at zero
     __shared__ unsigned int is_last;
