@@ -22,6 +22,7 @@ assert rc == 0, err.value
 for f in sorted(glob.glob("/tmp/wb_blocks.*"), key=lambda p: int(p.rsplit(".", 1)[1])):
     rnd = int(f.rsplit(".", 1)[1])
     rows = [[int(x) for x in l.split()] for l in open(f)]
+    marks = {r[0] - 512: r[1] for r in rows if 512 <= r[0] < 1024}
     # (rows k_words wrote this round: packed offsets of a few hundred microseconds at most -- rows beyond its grid still hold what a tile round left)
     rows = [r for r in rows if r[1] and 0 < (r[3] & 0xffffffff) < 1000000 and (r[2] >> 32) < 1000000 and (r[2] & 0xffffffff) < 1000000]
     t_med = sorted(r[1] for r in rows)[len(rows) // 2] if rows else 0
@@ -36,6 +37,8 @@ for f in sorted(glob.glob("/tmp/wb_blocks.*"), key=lambda p: int(p.rsplit(".", 1
     epi = [t - ((r[2] >> 32) / 100.0) for t, r in zip(tot, rows)]
     nw = [r[3] >> 32 for r in rows]
     end = [s + t for s, t in zip(start, tot)]
+    mk = [marks.get(r[0], 0) for r in rows]
+    m1, m2, m3 = [(m & 0xffff) / 100.0 for m in mk], [((m >> 16) & 0xffff) / 100.0 for m in mk], [((m >> 32) & 0xffff) / 100.0 for m in mk]
     q = lambda v: "%.1f / %.1f / %.1f" % (st.median(v), sorted(v)[int(0.9 * (len(v) - 1))], max(v))
-    print("round %5d: %3d workgroups, %5d words (max %3d per workgroup); us median / p90 / max: start %s | set-up %s | words %s | epilogue %s | whole %s | last end %.1f"
-          % (rnd, len(rows), sum(nw), max(nw), q(start), q(setup), q(words), q(epi), q(tot), max(end)), flush=True)
+    print("round %5d: %3d workgroups, %5d words (max %3d per workgroup); us median / p90 / max: start %s | set-up %s (look-ups issued at %s, tables + barrier %s, runs scanned %s) | words %s | epilogue %s | whole %s | last end %.1f"
+          % (rnd, len(rows), sum(nw), max(nw), q(start), q(setup), q(m1), q(m2), q(m3), q(words), q(epi), q(tot), max(end)), flush=True)

@@ -255,39 +255,44 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   __shared__ uint16_t rridx[LDSR ? APPLY_LDS_RULES : 1];
 #ifdef YTTM_K4_PROF
   const unsigned long long wall0_ = wall_clock64();  // (tuning build: this workgroup's timeline, 100 MHz: start | set-up done, words done | end, words)
-  unsigned long long wall_setup_ = 0, wall_words_ = 0;
+  unsigned long long wall_setup_ = 0, wall_words_ = 0, wall_m1_ = 0, wall_m2_ = 0, wall_m3_ = 0;  // (m1: look-ups issued, m2: tables set up + first barrier, m3: runs scanned)
 #endif
   const bool from_args = LDSR && ba.k != 0;
-  // FUSED, round 6: the rules' runs are looked up FIRST -- thread j: rule j; two or three dependent trips to the index / the lists' headers in L2 --
-  // and the lists' cursor loaded with them, so that those trips run under the LDS set-up below (no barrier waits for a load in flight: a
-  // workgroup-scope fence drains LDS operations only) instead of behind it: 5 -> 2.5 us of every round's prologue.
+  // FUSED, round 6: the rules' runs are looked up FIRST -- thread j: rule j -- and every load of a look-up is issued HERE at once, none behind
+  // another: the rule's first probe slot of the index WITH that slot's run (the offsets of its first and of the next key's first shard), the
+  // list header of the pair's younger token, the lists' cursor.  Nothing waits for them before the LDS set-up below is done (no barrier waits for
+  // a load in flight: a workgroup-scope fence drains LDS operations only); a probe that misses its first slot -- rare at the index's load of
+  // at most a half -- goes on from there, behind the set-up.  (The first cut called idx_find here: its probe loop waits for every key it loads,
+  // and a workgroup sat 3.2 us in front of its set-up -- tools/dbg/words_blocks.py, profiles/r6_words_blocks.txt.)
   unsigned long long fq_base = 0, fq_len = 0, fq_cur = 0;
   uint32_t fq_filt = 0, fq_mode = 0;
   bool fq_found = true;
+  unsigned long long sp_key = PT_EMPTY, sp_o0 = 0, sp_o1 = 0, sp_lb = 0, q_key = 0;
+  uint32_t sp_f = 0, sp_c = 0, sp_slot = 0, q_x = 0, q_y = 0, q_cnt = 0;
+  bool q_old = false;
   if (FUSED) {
     fq_cur = g.tl.cursor[g.round_id & 1u];
-    const PairIndex ix{g.ix.key, g.ix.cnt, g.ix.off, g.ix.bloom, g.ix.post, g.ix.mask};
-    const uint32_t j = threadIdx.x;
-    if (j < ba.k) {
-      const uint32_t x = ba.xy[2 * j], y = ba.xy[2 * j + 1];
-      const uint32_t m = x > y ? x : y;
-      if (m < g.z_static) {
-        uint32_t sl = 0xffffffffu;
-        if (g.ix_valid) sl = idx_find(ix, pair_key(x, y), enc_hash(x, y));
-        if (sl == 0xffffffffu) {
-          fq_found = false;  // not in the index: this round takes every word (f_every, set behind the LDS set-up)
-        } else {
-          fq_base = ix.off[(size_t)sl * IDX_SHARDS];
-          fq_len = ix.off[((size_t)sl + 1) * IDX_SHARDS] - fq_base;
-        }
-      } else {
-        fq_base = g.tl.base[m];
-        const uint32_t f = g.tl.fill[m], c = g.tl.cap[m];
-        fq_len = f < c ? f : c;
-        if (x > y) { fq_mode = 2; fq_filt = y; } else { fq_mode = 1; fq_filt = x; }
+    if (threadIdx.x < ba.k) {
+      q_x = ba.xy[2 * threadIdx.x];
+      q_y = ba.xy[2 * threadIdx.x + 1];
+      q_cnt = g.cnt[threadIdx.x];  // (a dynamically indexed kernel argument is a load from the argument buffer in HBM: with the others, not behind the barrier)
+      const uint32_t m = q_x > q_y ? q_x : q_y;
+      q_old = m < g.z_static;
+      q_key = pair_key(q_x, q_y);
+      if (g.ix_valid) {  // (uniform)
+        sp_slot = enc_hash(q_x, q_y) & g.ix.mask;
+        sp_key = g.ix.key[sp_slot];
+        sp_o0 = g.ix.off[(size_t)sp_slot * IDX_SHARDS];
+        sp_o1 = g.ix.off[((size_t)sp_slot + 1) * IDX_SHARDS];
       }
+      sp_lb = g.tl.base[m];
+      sp_f = g.tl.fill[m];
+      sp_c = g.tl.cap[m];
     }
   }
+#ifdef YTTM_K4_PROF
+  wall_m1_ = wall_clock64();
+#endif
   agg_init<WPB * 64>(A, from_args ? nullptr : bloom_g);  // (A.flagbits holds the batch's pair filter)
   if (threadIdx.x == 0) rn = 0;
   if (threadIdx.x == 0) dn = 0;
@@ -297,7 +302,8 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
     for (unsigned int i = threadIdx.x; i <= rule_mask; i += WPB * 64) rkeys[i] = PT_EMPTY;
     __syncthreads();
     for (unsigned int j = threadIdx.x; j < ba.k; j += WPB * 64) {
-      const uint32_t x = ba.xy[2 * j], y = ba.xy[2 * j + 1];
+      // (FUSED: the thread's rule was fetched at the top -- a dynamically indexed kernel argument is a load from the argument buffer)
+      const uint32_t x = FUSED && j == threadIdx.x ? q_x : ba.xy[2 * j], y = FUSED && j == threadIdx.x ? q_y : ba.xy[2 * j + 1];
       if (x != y) {
         const uint32_t bh = pm_hash(x, y);
         atomicOr(&A.flagbits[pm_word(bh)], pm_bits(bh));
@@ -325,19 +331,43 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
     if (ba.mark && blockIdx.x == 0) __hip_atomic_store(&stats[STAT_T0], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
+#ifdef YTTM_K4_PROF
+  wall_m2_ = wall_clock64();
+#endif
   const int wave = uni((int)(threadIdx.x >> 6)), lane = lane_id();
   if (FUSED) {  // where each rule's candidates are (as k_wgather: a posting run of the index, or the younger token's instance list): looked up above
     const uint32_t j = threadIdx.x;
     unsigned long long len = 0, lcap = 0;
     bool f_mode_of_mine = false;
     if (j < ba.k) {
+      if (q_old) {  // a pair of two tokens the index covers: its postings, if it is a key
+        const PairIndex ix{g.ix.key, g.ix.cnt, g.ix.off, g.ix.bloom, g.ix.post, g.ix.mask};
+        uint32_t sl = 0xffffffffu;
+        if (g.ix_valid) {
+          if (sp_key == q_key) sl = sp_slot;
+          else if (sp_key != PT_EMPTY) sl = idx_find(ix, q_key, sp_slot + 1u);  // (the first slot held another key: on from the next one)
+        }
+        if (sl == 0xffffffffu) {
+          fq_found = false;
+        } else if (sl == sp_slot) {
+          fq_base = sp_o0;
+          fq_len = sp_o1 - sp_o0;
+        } else {
+          fq_base = ix.off[(size_t)sl * IDX_SHARDS];
+          fq_len = ix.off[((size_t)sl + 1) * IDX_SHARDS] - fq_base;
+        }
+      } else {  // the instance list of the pair's younger token, filtered by the other one
+        fq_base = sp_lb;
+        fq_len = sp_f < sp_c ? sp_f : sp_c;
+        if (q_x > q_y) { fq_mode = 2; fq_filt = q_y; } else { fq_mode = 1; fq_filt = q_x; }
+      }
       len = fq_len;
       if (!fq_found) f_every = 1u;  // not in the index: this round takes every word
       f_base[j] = fq_base;
       f_filt[j] = fq_filt;
       f_mode[j] = (uint8_t)fq_mode;
       f_mode_of_mine = fq_mode != 0;
-      const unsigned long long cj = g.cnt[j];
+      const unsigned long long cj = q_cnt;
       lcap = fq_found && len < cj ? len : cj;
     }
     static_assert(BATCH_ARGS_MAX <= 128, "two waves scan the runs");
@@ -375,6 +405,9 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
     }
     __syncthreads();
   }
+#ifdef YTTM_K4_PROF
+  wall_m3_ = wall_clock64();
+#endif
   WaveLds<SLOT> &W = WL[wave];
   WordsLds &X = XL[wave];
   const TileSet ts{ws.tok, nullptr, nullptr, ws.wcnt, 0u};
@@ -411,8 +444,10 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
       return f_pref[a] + off;
     };
     const unsigned long long lo_w = (unsigned long long)blockIdx.x * wchunk < wtotal ? (unsigned long long)blockIdx.x * wchunk : wtotal;
-    f_pos = rec_of(lo_w);
-    f_hi = rec_of(lo_w + wchunk);
+    // (both ends of the stretch at once: odd lanes search the upper one -- two binary searches over LDS one behind the other were a microsecond)
+    const unsigned long long r_q = rec_of(lo_w + ((lane & 1) ? wchunk : 0ull));
+    f_pos = __shfl(r_q, 0);
+    f_hi = __shfl(r_q, 1);
   }
   TileStats S;
 #ifdef YTTM_K4_PROF
@@ -798,6 +833,8 @@ __global__ __launch_bounds__(WPB * 64) void k_words(WordSet ws, PairTable pt, De
   if (threadIdx.x == 0) {
     unsigned long long *row = stats + BLK_BASE + 8 * (blockIdx.x % BLK_ROWS);
     row[5] = wall0_;
+    // (set-up marks: word 5 of row 512 + b -- k_words runs at most 512 workgroups, the rows behind are nobody's in a word-mode round)
+    stats[BLK_BASE + 8 * (512 + blockIdx.x % 512) + 5] = ((wall_m1_ - wall0_) & 0xffffull) | (((wall_m2_ - wall0_) & 0xffffull) << 16) | (((wall_m3_ - wall0_) & 0xffffull) << 32);
     row[6] = ((wall_setup_ - wall0_) & 0xffffffffull) | ((wall_words_ - wall0_) << 32);
     row[7] = ((wall_clock64() - wall0_) & 0xffffffffull) | ((unsigned long long)A.st[1] << 32);
   }
