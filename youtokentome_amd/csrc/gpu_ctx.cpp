@@ -375,10 +375,12 @@ void GpuCtx::merge_apply(const uint32_t *xyz, uint32_t k, const unsigned long lo
     if (multi()) return ci == 0 && word_mode_ ? &xa : nullptr;  // (the tile kernels have nothing to do in a tail)
     return sa.on ? &sa : nullptr;
   };
-  // Word mode on one GPU with class-B tiles (words of 257 .. 2 048 tokens: long clauses of unsegmented scripts): the round was two launches
-  // in a row, the class-B tiles (~37 us on the CJK-shaped corpus) and then k_words (~138 us).  They share nothing until the tail, so class B
+  // Word mode on one GPU with class-B tiles (words of 257 .. 2 048 tokens: long clauses of unsegmented scripts): the round is two launches
+  // in a row, the class-B tiles (~31 us on the CJK-shaped corpus) and then k_words (~120 us).  DEFAULT since round 6: just that, on the main
+  // stream.  YTTM_CLASSB_BESIDE=1 (`beside` below) is round 5's protocol, kept and tested: they share nothing until the tail, so class B
   // goes to a second stream and its last workgroup raises a flag the tail waits for (ScanArgs::peer_flag; tools/micro/two_streams.hip: the
-  // whole of the shorter kernel comes off the round).  No join: the main stream's next kernel starts after k_words has ended, k_words' tail
+  // whole of the shorter kernel comes off the round IN A MICRO-BENCHMARK; in the trainer it measured 14 ms slower per CJK training than one
+  // stream once the second stream was a real one and not, by accident, the NULL stream: profiles/r6_classb_order.txt).  No join: the main stream's next kernel starts after k_words has ended, k_words' tail
   // has waited for the flag, and the flag is stored behind everything class B wrote -- stream order on the main stream IS the join.  The
   // fork: when nothing was queued on the main stream since the host read the last round's mailbox (st_clean: the common round), all that
   // can still run there is that round's tail folding the statistics rows -- by exchanges, so that this launch may add to them meanwhile --

@@ -177,7 +177,7 @@ class GpuCtx {
   uint32_t *d_bloom_ = nullptr;   // pair filter of a batch that does not travel in the kernel arguments
   const char *trace_rounds_ = nullptr, *dbg_cand_ = nullptr;
   bool fuse_enabled_ = true;  // YTTM_NO_FUSE=1: always the separate scan kernel (tuning hook / tests)
-  // word mode, single GPU: the class-B tiles' launch of a round runs on a second stream beside k_words (merge_apply; ScanArgs::peer_flag)
+  // word mode, single GPU, YTTM_CLASSB_BESIDE=1: the class-B tiles' launch of a round runs on a second stream beside k_words (merge_apply; ScanArgs::peer_flag)
   bool classb_overlap_ = false;      // YTTM_CLASSB_BESIDE
   hipStream_t st_b_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
