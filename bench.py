@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the Zipf (configs[2]) block")
     ap.add_argument("--no-extra2", action="store_true", help="skip the large-alphabet (CJK-shaped) and enwik-like (4e6-word lexicon) training blocks")
+    ap.add_argument("--watchdog-seconds", type=int, default=-1,
+                    help="N > 1: every rank prints an error line and exits non-zero if the run has not finished by then (default: 1500 for N > 1, off for one GPU). "
+                         "The RCCL exchange has never run with more than one rank on hardware; a hang must end as a verdict, not as the driver's time-out")
     ap.add_argument("--no-big", action="store_true", help="skip the beyond-2^32 block: the 8.8 GB corpus with a word seen 4.4e9 times (file -> model, pinned)")
     ap.add_argument("--big-zipf", action="store_true", help="also the 8 GB Zipf corpus (its generation alone takes two minutes: profiles/ holds a run)")
     ap.add_argument("--no-touched-pass", action="store_true", help="skip the untimed K4 measurement pass (profiling runs: one training per process)")
@@ -153,6 +156,17 @@ def main():
     if args.gpus != world and world > 1:
         log(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     n_gpus = world
+    wd = args.watchdog_seconds if args.watchdog_seconds >= 0 else (1500 if world > 1 else 0)
+    if wd:
+        import signal
+
+        def _watchdog(signum, frame):
+            if rank == 0:
+                print(json.dumps({"metric": "bpe_train_throughput", "value": None, "unit": "MB/s", "n_gpus": world, "error": "watchdog: not finished after %d s (rank 0)" % wd}), flush=True)
+            log("rank %d: watchdog after %d s -- exiting" % (rank, wd))
+            os._exit(3)
+        signal.signal(signal.SIGALRM, _watchdog)
+        signal.alarm(wd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
