@@ -567,5 +567,16 @@ def test_k3_radix_partition(tmp_path, monkeypatch):
         assert r["k3_radix"] == 1, r
         O.train(text, m_ora, vocab)
         assert filecmp.cmp(m_gpu, m_ora, shallow=False), i
+    # the path's scratch (16 bytes per class-A token) must fit the free device memory with room to spare: short of it, the general kernel counts
+    monkeypatch.setenv("YTTM_TEST_FREE_BYTES", "100000")
+    text = S.texts_by_alphabet_size(sizes=(200,), n_words=300)[0]
+    corpus, m_gpu, m_ora = str(tmp_path / "cm.txt"), str(tmp_path / "gm.model"), str(tmp_path / "om.model")
+    open(corpus, "wb").write(text)
+    err, rep = C.create_string_buffer(2048), C.create_string_buffer(16384)
+    assert L.yttm_train_bpe_ex(corpus.encode(), m_gpu.encode(), 500, 1.0, 1, 0, 1, 2, 3, 0, rep, 16384, err, 2048) == 0, err.value
+    assert json.loads(rep.value.decode())["k3_radix"] == 0
+    O.train(text, m_ora, 500)
+    assert filecmp.cmp(m_gpu, m_ora, shallow=False)
+    monkeypatch.delenv("YTTM_TEST_FREE_BYTES")
     monkeypatch.setenv("YTTM_K3_RADIX_MIN", "1000000000000")
     S.check_word_table_and_pairs(S.texts_by_alphabet_size(sizes=(130,), n_words=300)[0])

@@ -105,7 +105,9 @@ void GpuCtx::pair_count() {
   // atomic per adjacency (k_pairradix.hip; 16 B of scratch per class-A token for the length of the count)
   uint32_t *rx_scratch = nullptr;
   unsigned long long *rx_buf1 = nullptr, *rx_buf2 = nullptr;
-  const bool radix = cls_[0].n_tiles && pair_count_radix_takes(n_ids, cls_[0].n_tokens0) && cls_[0].n_tokens0 >= cfg_->k3_radix_min.u && !cfg_->k3_general.set;
+  // (its scratch -- two 8-byte records per class-A token -- must fit what is free with room to spare: else the general kernel, never an out-of-memory)
+  const bool radix = cls_[0].n_tiles && pair_count_radix_takes(n_ids, cls_[0].n_tokens0) && cls_[0].n_tokens0 >= cfg_->k3_radix_min.u && !cfg_->k3_general.set &&
+                     16ull * (cls_[0].n_tokens0 + 1) + (64ull << 20) <= free_device_bytes() / 4 * 3;
   if (radix) {
     rx_scratch = dmalloc<uint32_t>(pair_count_radix_scratch_u32(n_ids));
     rx_buf1 = dmalloc<unsigned long long>(cls_[0].n_tokens0 + 1);

@@ -156,12 +156,11 @@ __global__ __launch_bounds__(K3R_NT) void k3r_scatter1(TileSet ts, uint32_t id_m
 }
 
 // buf1 (grouped by a >> s1) -> buf2 (grouped by a).  A chunk of buf1 lies in a few consecutive groups: its first tokens span [a_lo, a_hi).
-__global__ __launch_bounds__(K3R_NT) void k3r_scatter2(const unsigned long long *__restrict__ buf1, uint32_t total_p_unused, const uint32_t *__restrict__ offA,
+__global__ __launch_bounds__(K3R_NT) void k3r_scatter2(const unsigned long long *__restrict__ buf1, const uint32_t *__restrict__ offA,
                                                        uint32_t n_ids, uint32_t s1, uint32_t *__restrict__ cur2, unsigned long long *__restrict__ buf2) {
   constexpr int PER = K3R_CHUNK / K3R_NT;
   __shared__ uint32_t cntA[K3R_MAX_IDS], cntC[K3R_MAX_IDS];
   __shared__ uint32_t span[2];
-  (void)total_p_unused;
   const uint32_t total = offA[n_ids];
   const uint32_t n_chunks = (total + K3R_CHUNK - 1) / K3R_CHUNK;
   for (uint32_t i = threadIdx.x; i < n_ids; i += K3R_NT) { cntA[i] = 0; cntC[i] = 0; }
@@ -259,7 +258,7 @@ void launch_pair_count_radix(const TileSet &ts, const PairTable &pt, const Delta
   hipLaunchKernelGGL((k3r_scatter1<TILE_SLOT_A>), dim3(g), dim3(K3R_NT), 0, st, ts, id_min, s1, nb1, (const uint32_t *)wgoff, buf1);
   // (records < tokens: grids no larger than the chunks there can be)
   const unsigned int g2 = (unsigned int)std::min<unsigned long long>(2048, n_tokens / K3R_CHUNK + 1), g3 = (unsigned int)std::min<unsigned long long>(2048, n_tokens / K3R_FCHUNK + 1);
-  hipLaunchKernelGGL(k3r_scatter2, dim3(g2), dim3(K3R_NT), 0, st, (const unsigned long long *)buf1, 0u, (const uint32_t *)offA, n_ids, s1, cur2, buf2);
+  hipLaunchKernelGGL(k3r_scatter2, dim3(g2), dim3(K3R_NT), 0, st, (const unsigned long long *)buf1, (const uint32_t *)offA, n_ids, s1, cur2, buf2);
   hipLaunchKernelGGL(k3r_final, dim3(g3), dim3(K3R_NT), 0, st, (const unsigned long long *)buf2, (const uint32_t *)offA, id_min, n_ids, pt, db);
 }
 }  // namespace yttm
